@@ -1,0 +1,155 @@
+/* ssm_hip.h -- C ABI of libssm_hip.so, the MI355X (gfx950) implementation of the per-frame semantic-mapping
+ * front end of MuMuJun97/semantic_slam_mapping.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference has no FFI: its hot path sits behind plain C++ classes linked into librgbd_tutor_lib.so
+ * (/root/reference/src/CMakeLists.txt:1-5).  Each entry point below names the reference interface it replaces;
+ * the C++ classes of the same names (include/ssm/ *.h in this repo) are thin callers of these functions, and
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: every function returns SSM_OK (0) or a negative ssm_status; nothing throws across the ABI; the caller
+ * owns every host buffer and passes capacities; the context owns device memory and one HIP stream; calls on one
+ * context are serialised by an internal mutex (the reference calls detectFeatures on the main thread and
+ * generatePointCloud on the viewer thread, SURVEY.md s.8b "threading": give each thread its own context or share one).
+ * Host-pointer functions are synchronous.  *_dev functions take DEVICE pointers, enqueue on the context stream and
+ * return without waiting (ssm_sync waits).
+ */
+#ifndef SSM_HIP_H
+#define SSM_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SSM_OK = 0,
+    SSM_E_INVAL = -1,        /* bad argument / unsupported configuration */
+    SSM_E_NOMEM = -2,        /* device or host allocation failed */
+    SSM_E_HIP = -3,          /* HIP runtime error (ssm_last_error has the text) */
+    SSM_E_CAPACITY = -4,     /* caller buffer or internal table too small */
+    SSM_E_TOO_FEW_TRAIN = -5,/* matcher needs >= 2 train descriptors (src/orb.cpp:25 indexes [1] unguarded) */
+    SSM_E_VOXEL_RANGE = -6,  /* PCL VoxelGrid index-overflow guard would trip: output == input in the reference */
+    SSM_E_NODEVICE = -7
+} ssm_status;
+
+/* layout-identical to cv::KeyPoint (OpenCV 2.4), 28 bytes */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } ssm_keypoint;
+/* layout-identical to cv::DMatch, 16 bytes */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } ssm_dmatch;
+/* layout-identical to pcl::PointXYZRGBL (a superset of Mapper::PointT = pcl::PointXYZRGBA, include/mapper.h:18), 32 bytes */
+typedef struct { float x, y, z, w; uint8_t b, g, r, a; uint32_t label; uint32_t pad[2]; } ssm_point;
+/* rgbd_tutor::CAMERA_INTRINSIC_PARAMETERS (include/utils.h:8-16) */
+typedef struct { double cx, cy, fx, fy, scale; } ssm_camera;
+/* one voxel of the map table: exact integer sums (DESIGN.md "voxel contract"), 112 bytes */
+typedef struct {
+    int64_t  key;            /* ((k+2^20)<<42)|((j+2^20)<<21)|(i+2^20), ijk = floor(p * (1.0f/leaf)) */
+    int64_t  sx, sy, sz;     /* sums of llrint(coord * 2^24) */
+    uint64_t sr, sg, sb, n;  /* colour sums, point count */
+    uint32_t hist[12];       /* label votes */
+} ssm_voxel;
+
+/* keys of /root/reference/parameters.txt that the path reads (include/orb.h:21-28, include/mapper.h:24-29,
+ * include/track.h:69-70, src/parameter_reader.cpp:6-18) plus sizing knobs of this implementation */
+typedef struct {
+    int    width, height;            /* frame geometry the context is sized for */
+    int    orb_features;             /* parameters.txt:66 */
+    float  orb_scale;                /* :68 */
+    int    orb_levels;               /* :69 */
+    int    orb_iniThFAST;            /* :70 */
+    int    orb_minThFAST;            /* :71 */
+    double knn_match_ratio;          /* :72 */
+    int    tracker_ref_frames;       /* :81 */
+    double mapper_resolution;        /* :97 */
+    double mapper_max_distance;      /* :98 */
+    ssm_camera camera;               /* :37-40,63 */
+    int    max_batch;                /* frames per batched launch (device workspace is sized for this) */
+    int    voxel_capacity_log2;      /* slots of the device voxel hash table = 2^this */
+    const int8_t* brief_pattern;     /* NULL = built-in 256x4 table; else 1024 int8 (x0,y0,x1,y1)*256 */
+} ssm_config;
+
+typedef struct ssm_ctx ssm_ctx;
+
+void        ssm_config_default(ssm_config* cfg);        /* parameters.txt values, 640x480 TUM fr1 camera at scale 1000 */
+int         ssm_create(int device, const ssm_config* cfg, ssm_ctx** out);
+void        ssm_destroy(ssm_ctx* ctx);
+const char* ssm_last_error(const ssm_ctx* ctx);          /* valid until the next call on ctx; ctx==NULL: last create error */
+const char* ssm_version(void);
+int         ssm_orb_capacity(const ssm_ctx* ctx);        /* max keypoints per frame: orb_features + 3*orb_levels */
+int         ssm_sync(ssm_ctx* ctx);
+void*       ssm_stream(ssm_ctx* ctx);                    /* hipStream_t of the context */
+
+/* ---- OrbFeature::detectFeatures (include/orb.h:32-53): gray conversion, ORB, 3-D position per keypoint.
+ * img: 8-bit, channels 1 (gray) or 3 (BGR interleaved), row stride in bytes.  depth: u16 row-major w x h or NULL.
+ * kps/desc/pos3d hold cap entries (desc 32 B each, pos3d 3 floats each, may be NULL). */
+int ssm_orb_extract(ssm_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+                    ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out);
+
+/* ---- cv::BFMatcher(NORM_HAMMING)::knnMatch(q,t,knn,2) as called at src/orb.cpp:21.  idx/dist: nq x 2 */
+int ssm_hamming_knn2(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist);
+/* ---- OrbFeature::match (src/orb.cpp:16-29): knn + ratio test, ascending queryIdx */
+int ssm_match(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+              ssm_dmatch* out, int cap, int* n_out);
+
+/* ---- Mapper::semantic_motion_fuse (src/mapper.cpp:189-216): sem = BGR class-colour image, mask = w*h bytes */
+int ssm_moving_mask(ssm_ctx* ctx, const uint8_t* sem_bgr, int w, int h, int stride, uint8_t* mask);
+/* ---- Mapper::generatePointCloud (src/mapper.cpp:12-94) incl. RGBDFrame::project2dTo3d (include/rgbdframe.h:63-75)
+ * and pcl::transformPointCloud by T (16 doubles, column-major = Eigen::Isometry3d::matrix(); NULL = camera frame).
+ * packed images (stride = w*channels).  out holds cap points (w*h always suffices). */
+int ssm_backproject(ssm_ctx* ctx, const uint16_t* depth, const uint8_t* rgb_bgr, const uint8_t* sem_bgr, int w, int h,
+                    const ssm_camera* cam, const double* T, double max_distance, ssm_point* out, int cap, int* n_out);
+
+/* ---- pcl::VoxelGrid::filter as used in Mapper::viewer (src/mapper.cpp:106-107,154-155) */
+int ssm_voxel_filter(ssm_ctx* ctx, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out);
+/* the persistent map of the context: table of exact sums keyed by voxel */
+int ssm_map_clear(ssm_ctx* ctx);
+int ssm_map_insert(ssm_ctx* ctx, const ssm_point* pts, int n);                 /* globalMap += cloud */
+int ssm_map_size(ssm_ctx* ctx, int* n_voxels);
+int ssm_map_export(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);         /* centroids sorted by voxel index */
+int ssm_map_export_table(ssm_ctx* ctx, ssm_voxel* out, int cap, int* n_out);   /* key-sorted table, for merging */
+int ssm_map_merge_table(ssm_ctx* ctx, const ssm_voxel* tab, int n);            /* add another rank's table */
+
+/* ---- device-resident batched path (the benchmarked one): n frames of a sequence, packed, all DEVICE pointers.
+ * Runs detectFeatures for every frame, match(ref, cur) against the <= tracker_ref_frames preceding frames (the
+ * refFrames deque of Tracker::trackRefFrame, src/track.cpp:150-152, when every frame tracks), the moving mask,
+ * generatePointCloud with pose[f], and fuses every cloud into the context map. */
+typedef struct {
+    const uint8_t*  bgr;      /* n x h x w x 3 */
+    const uint16_t* depth;    /* n x h x w     */
+    const uint8_t*  sem_bgr;  /* n x h x w x 3 */
+    const double*   pose;     /* n x 16, column-major T_f_w */
+    int n;
+    int continue_sequence;    /* 1: the last tracker_ref_frames frames of the previous call are the first refs */
+    int stages;               /* bit mask of SSM_STAGE_*, 0 = all */
+} ssm_frames_dev;
+enum { SSM_STAGE_ORB = 1, SSM_STAGE_MATCH = 2, SSM_STAGE_MAP = 4 };
+typedef struct {              /* DEVICE pointers owned by the context, valid until the next ssm_seq_process/destroy */
+    const ssm_keypoint* kps;  /* n x cap */
+    const uint8_t*  desc;     /* n x cap x 32 */
+    const float*    pos3d;    /* n x cap x 3 */
+    const int32_t*  nkp;      /* n */
+    const ssm_dmatch* matches;/* n x R x cap ; slot r of frame f = match(frame f-R+r ... ), see nmatch */
+    const int32_t*  nmatch;   /* n x R ; -1 where the ref frame does not exist */
+    const int32_t*  npoints;  /* n : points emitted by generatePointCloud */
+    int cap, R;
+} ssm_seq_out_dev;
+int ssm_seq_process(ssm_ctx* ctx, const ssm_frames_dev* in, ssm_seq_out_dev* out);
+
+/* per-stage device time of the most recent ssm_seq_process, measured with hipEvents on the context stream.
+ * enable with ssm_set_profiling(ctx,1).  names/ms/launches hold cap entries; returns count in *n_out. */
+int ssm_set_profiling(ssm_ctx* ctx, int on);
+int ssm_get_stage_times(ssm_ctx* ctx, const char** names, float* ms, int* launches, int cap, int* n_out);
+
+/* ---- utilities (device memory without torch; synthetic stream generator for bench/tests) */
+int ssm_dev_alloc(ssm_ctx* ctx, size_t bytes, void** out);
+int ssm_dev_free(ssm_ctx* ctx, void* p);
+int ssm_memcpy_h2d(ssm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int ssm_memcpy_d2h(ssm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* synthetic 640x480 RGB-D + 12-class stream of BASELINE.json configs[1]; device pointers;
+ * label_ids may be NULL */
+int ssm_synth_frames_dev(ssm_ctx* ctx, uint64_t seed, int first_frame, int n, int w, int h,
+                         uint8_t* bgr, uint16_t* depth, uint8_t* sem_bgr, uint8_t* label_ids, double* pose);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+"""Python mirror of the reference's operator interface over the C ABI.
+
+Names follow the reference: ``detect_features`` = OrbFeature::detectFeatures (include/orb.h:32-53), ``match`` =
+OrbFeature::match (src/orb.cpp:16-29), ``moving_mask`` = Mapper::semantic_motion_fuse (src/mapper.cpp:189-216),
+``generate_point_cloud`` = Mapper::generatePointCloud (src/mapper.cpp:12-94), ``voxel_filter`` = pcl::VoxelGrid as
+used in Mapper::viewer (src/mapper.cpp:154-155).
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import Camera, Config, FramesDev, SeqOutDev
+
+KEYPOINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                           ("octave", "i4"), ("class_id", "i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "i4"), ("trainIdx", "i4"), ("imgIdx", "i4"), ("distance", "f4")])
+POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("w", "f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"),
+                        ("a", "u1"), ("label", "u4"), ("pad", "u4", (2,))])
+VOXEL_DTYPE = np.dtype([("key", "i8"), ("sx", "i8"), ("sy", "i8"), ("sz", "i8"), ("sr", "u8"), ("sg", "u8"),
+                        ("sb", "u8"), ("n", "u8"), ("hist", "u4", (12,))])
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
+
+STAGE_ORB, STAGE_MATCH, STAGE_MAP = 1, 2, 4
+
+
+class SsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ssm error {code}: {msg}")
+        self.code = code
+
+
+def default_config(**kw):
+    lib = _lib.load()
+    cfg = Config()
+    lib.ssm_config_default(C.byref(cfg))
+    cam = kw.pop("camera", None)
+    if cam is not None:
+        cfg.camera = Camera(*cam)
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Context:
+    """One ssm_ctx: device workspace + stream on one GPU."""
+
+    def __init__(self, device=0, cfg=None, **kw):
+        self.lib = _lib.load()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        self._pattern_keep = None
+        h = C.c_void_p()
+        rc = self.lib.ssm_create(device, C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise SsmError(rc, (self.lib.ssm_last_error(None) or b"").decode())
+        self.h = h
+        self.cap = self.lib.ssm_orb_capacity(self.h)
+        self.W, self.H = self.cfg.width, self.cfg.height
+        self.R = max(1, self.cfg.tracker_ref_frames)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ssm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SsmError(rc, (self.lib.ssm_last_error(self.h) or b"").decode())
+
+    # ---- OrbFeature
+    def detect_features(self, img, depth=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        h, w = img.shape[:2]
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+        kps = np.zeros(self.cap, KEYPOINT_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        pos = np.zeros((self.cap, 3), np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_orb_extract(self.h, _ptr(img), w, h, img.strides[0], ch, _ptr(depth), _ptr(kps), _ptr(desc),
+                                           _ptr(pos), self.cap, C.byref(n)))
+        return kps[:n.value], desc[:n.value], pos[:n.value]
+
+    def knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32)
+        dist = np.zeros((len(q), 2), np.int32)
+        self._chk(self.lib.ssm_hamming_knn2(self.h, _ptr(q), len(q), _ptr(t), len(t), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def match(self, q, t, ratio=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(q), 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        r = self.cfg.knn_match_ratio if ratio is None else ratio
+        self._chk(self.lib.ssm_match(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    # ---- Mapper
+    def moving_mask(self, sem):
+        sem = np.ascontiguousarray(sem, np.uint8)
+        h, w = sem.shape[:2]
+        mask = np.zeros((h, w), np.uint8)
+        self._chk(self.lib.ssm_moving_mask(self.h, _ptr(sem), w, h, sem.strides[0], _ptr(mask)))
+        return mask
+
+    def generate_point_cloud(self, depth, rgb, sem, T=None, camera=None, max_distance=None):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        sem = np.ascontiguousarray(sem, np.uint8)
+        h, w = depth.shape
+        cam = Camera(*camera) if camera is not None else self.cfg.camera
+        md = self.cfg.mapper_max_distance if max_distance is None else max_distance
+        Tc = None if T is None else np.ascontiguousarray(np.asarray(T, np.float64).reshape(4, 4).T)  # column-major
+        out = np.zeros(w * h, POINT_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_backproject(self.h, _ptr(depth), _ptr(rgb), _ptr(sem), w, h, C.byref(cam), _ptr(Tc), md,
+                                           _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def voxel_filter(self, pts, leaf=None, cap=None):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        leaf = self.cfg.mapper_resolution if leaf is None else leaf
+        out = np.zeros(cap if cap is not None else max(len(pts), 1), POINT_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_voxel_filter(self.h, _ptr(pts), len(pts), leaf, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def map_clear(self):
+        self._chk(self.lib.ssm_map_clear(self.h))
+
+    def map_insert(self, pts):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        self._chk(self.lib.ssm_map_insert(self.h, _ptr(pts), len(pts)))
+
+    def map_size(self):
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_map_size(self.h, C.byref(n)))
+        return n.value
+
+    def map_export(self):
+        out = np.zeros(max(self.map_size(), 1), POINT_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_map_export(self.h, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def map_export_table(self):
+        out = np.zeros(max(self.map_size(), 1), VOXEL_DTYPE)
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_map_export_table(self.h, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def map_merge_table(self, tab):
+        tab = np.ascontiguousarray(tab, VOXEL_DTYPE)
+        self._chk(self.lib.ssm_map_merge_table(self.h, _ptr(tab), len(tab)))
+
+    # ---- device-resident sequence path
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.ssm_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, p):
+        self._chk(self.lib.ssm_dev_free(self.h, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.ssm_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes))
+
+    def d2h(self, dptr, shape, dtype):
+        out = np.zeros(shape, dtype)
+        if out.nbytes:
+            self._chk(self.lib.ssm_memcpy_d2h(self.h, _ptr(out), dptr, out.nbytes))
+        return out
+
+    def synth_frames_dev(self, seed, first, n, bgr, depth, sem, pose, labels=None):
+        self._chk(self.lib.ssm_synth_frames_dev(self.h, seed, first, n, self.W, self.H, bgr, depth, sem, labels, pose))
+
+    def seq_process(self, bgr, depth, sem, pose, n, continue_sequence=False, stages=0):
+        fr = FramesDev(bgr, depth, sem, pose, n, int(continue_sequence), stages)
+        out = SeqOutDev()
+        self._chk(self.lib.ssm_seq_process(self.h, C.byref(fr), C.byref(out)))
+        return out
+
+    def sync(self):
+        self._chk(self.lib.ssm_sync(self.h))
+
+    def set_profiling(self, on):
+        self._chk(self.lib.ssm_set_profiling(self.h, int(on)))
+
+    def stage_times(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        ln = (C.c_int * 32)()
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_get_stage_times(self.h, names, ms, ln, 32, C.byref(n)))
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(min(n.value, 32))}
+
+    def seq_fetch(self, out, n):
+        """Copy the outputs of seq_process back to the host (test helper)."""
+        cap, R = out.cap, out.R
+        res = {
+            "nkp": self.d2h(out.nkp, n, np.int32),
+            "kps": self.d2h(out.kps, (n, cap), KEYPOINT_DTYPE),
+            "desc": self.d2h(out.desc, (n, cap, 32), np.uint8),
+            "pos3d": self.d2h(out.pos3d, (n, cap, 3), np.float32),
+            "nmatch": self.d2h(out.nmatch, (n, R), np.int32),
+            "matches": self.d2h(out.matches, (n, R, cap), DMATCH_DTYPE),
+            "npoints": self.d2h(out.npoints, n, np.int32),
+        }
+        return res

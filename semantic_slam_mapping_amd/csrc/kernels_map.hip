@@ -1,0 +1,424 @@
+// kernels_map.hip -- K10, K11, K12 of the hot path for gfx950 (HBM-bound byte/integer kernels; no MFMA by design):
+//   K10 Mapper::semantic_motion_fuse    /root/reference/src/mapper.cpp:189-216
+//   K11 Mapper::generatePointCloud      /root/reference/src/mapper.cpp:12-94  (+ rgbdframe.h:63-75, transformPointCloud :90-91)
+//   K12 pcl::VoxelGrid in Mapper::viewer /root/reference/src/mapper.cpp:106-107,154-155
+// Contracts = oracle/mapper.c.  Batched over frames.
+#include "ssm_internal.h"
+
+// ------------------------------------------------------------------ K10: moving-class mask + 5x5 box dilate
+#define MK_W 64
+#define MK_H 16
+__global__ void __launch_bounds__(256)
+mask_kernel(const uint8_t* __restrict__ sem, int w, int h, int tiles_x, uint8_t* __restrict__ mask)
+{
+    __shared__ uint8_t m0[MK_H + 4][MK_W + 4];
+    __shared__ uint8_t m1[MK_H + 4][MK_W];
+    const int tx0 = (blockIdx.x % tiles_x) * MK_W, ty0 = (blockIdx.x / tiles_x) * MK_H;
+    const uint8_t* s = sem + (size_t)blockIdx.y * w * h * 3;
+    for (int i = threadIdx.x; i < (MK_H + 4) * (MK_W + 4); i += 256) {
+        const int ly = i / (MK_W + 4), lx = i - ly * (MK_W + 4);
+        const int gx = tx0 + lx - 2, gy = ty0 + ly - 2;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+            const uint8_t* p = s + ((size_t)gy * w + gx) * 3;
+            const int b = p[0], g = p[1], r = p[2];
+            v = ((b == 0 && g == 64 && r == 64) || (b == 192 && g == 128 && r == 0)) ? 255 : 0;   // pedestrian | cyclist
+        }
+        m0[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (MK_H + 4) * MK_W; i += 256) {
+        const int ly = i / MK_W, lx = i - ly * MK_W;
+        const uint8_t* p = &m0[ly][lx];
+        m1[ly][lx] = p[0] | p[1] | p[2] | p[3] | p[4];
+    }
+    __syncthreads();
+    uint8_t* dst = mask + (size_t)blockIdx.y * w * h;
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < MK_H; ly += 4) {
+        const int gx = tx0 + lx, gy = ty0 + ly;
+        if (gx < w && gy < h) dst[(size_t)gy * w + gx] = m1[ly][lx] | m1[ly+1][lx] | m1[ly+2][lx] | m1[ly+3][lx] | m1[ly+4][lx];
+    }
+}
+hipError_t k_moving_mask(const uint8_t* sem, int n, int w, int h, uint8_t* mask, hipStream_t s)
+{
+    const int tx = (w + MK_W - 1) / MK_W, ty = (h + MK_H - 1) / MK_H;
+    mask_kernel<<<dim3(tx * ty, n), 256, 0, s>>>(sem, w, h, tx, mask);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K11: gated back-projection, ordered compaction
+// chunk = 1024 consecutive row-major pixels (256 threads x 4).  count -> global exclusive scan -> emit, so the point
+// list is in the reference's row-major order (the serial loop of mapper.cpp:21-86).
+#define BP_PIX 1024
+int backproject_chunks(int w, int h) { return (w * h + BP_PIX - 1) / BP_PIX; }
+
+__device__ __forceinline__ bool bp_keep(int d, int mk, int b, int g, int r, double maxd)
+{
+    if (d == 0) return false;
+    if ((double)d > maxd) return false;                    // mapper.cpp:30  d > max_distance * camera.scale
+    if (mk == 255) return false;                           // mapper.cpp:32
+    if ((b == 128 && g == 128 && r == 128) || (b == 128 && g == 192 && r == 192) || (b == 192 && g == 128 && r == 0)) return false;  // :41-55
+    return true;
+}
+__global__ void __launch_bounds__(256)
+bp_count_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ sem, const uint8_t* __restrict__ mask,
+                int npix, double maxd, int chunks, int32_t* __restrict__ chunk_cnt)
+{
+    __shared__ int wsum[4];
+    const size_t fo = (size_t)blockIdx.y * npix;
+    const int p0 = blockIdx.x * BP_PIX + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = p0 + i;
+        if (p < npix) {
+            const uint8_t* s = sem + (fo + p) * 3;
+            c += bp_keep(depth[fo + p], mask[fo + p], s[0], s[1], s[2], maxd);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.y * chunks + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// one block: exclusive scan of all n*chunks counts (int64 offsets), per-frame totals
+__global__ void __launch_bounds__(1024)
+bp_scan_kernel(const int32_t* __restrict__ chunk_cnt, int n, int chunks, int64_t* __restrict__ chunk_off,
+               int32_t* __restrict__ npoints, int64_t* __restrict__ total)
+{
+    __shared__ long long part[1024];
+    const int tot = n * chunks, tid = threadIdx.x;
+    const int per = (tot + 1023) / 1024;
+    const int b = tid * per, e = min(b + per, tot);
+    long long s = 0;
+    for (int i = b; i < e; i++) s += chunk_cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        long long v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long run = part[tid] - s;
+    for (int i = b; i < e; i++) { chunk_off[i] = run; run += chunk_cnt[i]; }
+    if (tid == 1023) *total = part[1023];
+    __syncthreads();
+    // per-frame totals
+    for (int f = tid; f < n; f += 1024) {
+        int t = 0;
+        for (int c = 0; c < chunks; c++) t += chunk_cnt[f * chunks + c];
+        npoints[f] = t;
+    }
+}
+__global__ void __launch_bounds__(256)
+bp_emit_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
+               const uint8_t* __restrict__ mask, const double* __restrict__ pose, int w, int npix, ssm_camera cam, double maxd,
+               int chunks, const int64_t* __restrict__ chunk_off, ssm_point* __restrict__ out)
+{
+    __shared__ int wsum[4];
+    const size_t fo = (size_t)blockIdx.y * npix;
+    const int p0 = blockIdx.x * BP_PIX + threadIdx.x * 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool k[4]; int c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int p = p0 + i; k[i] = false;
+        if (p < npix) {
+            const uint8_t* s = sem + (fo + p) * 3;
+            k[i] = bp_keep(depth[fo + p], mask[fo + p], s[0], s[1], s[2], maxd);
+        }
+        c += k[i];
+    }
+    int inc = c;                                             // inclusive wave scan
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int off = inc - c;
+    for (int i = 0; i < wv; i++) off += wsum[i];
+    if (c == 0) return;
+    ssm_point* dst = out + chunk_off[blockIdx.y * chunks + blockIdx.x] + off;
+    double T[12];
+    const bool hasT = pose != nullptr;
+    if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!k[i]) continue;
+        const int p = p0 + i;
+        const int v = p / w, u = p - v * w;
+        const int d = depth[fo + p];
+        const float z = (float)((double)d / cam.scale);                            // rgbdframe.h:71-73
+        const float x = (float)(((double)u - cam.cx) * (double)z / cam.fx);
+        const float y = (float)(((double)v - cam.cy) * (double)z / cam.fy);
+        float ox = x, oy = y, oz = z;
+        if (hasT) {                                                                // pcl::transformPointCloud, double, left to right
+            const double X = x, Y = y, Z = z;
+            ox = (float)(T[0] * X + T[3] * Y + T[6] * Z + T[9]);
+            oy = (float)(T[1] * X + T[4] * Y + T[7] * Z + T[10]);
+            oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
+        }
+        const uint8_t* c3 = rgb + (fo + p) * 3;
+        const uint8_t* s3 = sem + (fo + p) * 3;
+        const int sb = s3[0], sg = s3[1], sr = s3[2];
+        uint32_t label = 255;
+        // 12-class palette (BGR), SegNet driving_webdemo id order
+        switch ((sb << 16) | (sg << 8) | sr) {
+            case (128 << 16) | (128 << 8) | 128: label = 0; break;   case (0 << 16) | (0 << 8) | 128: label = 1; break;
+            case (128 << 16) | (192 << 8) | 192: label = 2; break;   case (0 << 16) | (69 << 8) | 255: label = 3; break;
+            case (128 << 16) | (64 << 8) | 128: label = 4; break;    case (222 << 16) | (40 << 8) | 60: label = 5; break;
+            case (0 << 16) | (128 << 8) | 128: label = 6; break;     case (128 << 16) | (128 << 8) | 192: label = 7; break;
+            case (128 << 16) | (64 << 8) | 64: label = 8; break;     case (128 << 16) | (0 << 8) | 64: label = 9; break;
+            case (0 << 16) | (64 << 8) | 64: label = 10; break;      case (192 << 16) | (128 << 8) | 0: label = 11; break;
+        }
+        uint4 lo, hi;
+        lo.x = __float_as_uint(ox); lo.y = __float_as_uint(oy); lo.z = __float_as_uint(oz); lo.w = __float_as_uint(1.0f);
+        hi.x = (uint32_t)c3[0] | ((uint32_t)c3[1] << 8) | ((uint32_t)c3[2] << 16); hi.y = label; hi.z = 0; hi.w = 0;
+        uint4* o = reinterpret_cast<uint4*>(dst);
+        o[0] = lo; o[1] = hi;
+        dst++;
+    }
+}
+hipError_t k_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const uint8_t* mask,
+                         const double* pose, int n, int w, int h, ssm_camera cam, double max_distance,
+                         int32_t* chunk_cnt, int64_t* chunk_off, int32_t* npoints, int64_t* total,
+                         ssm_point* out, hipStream_t s)
+{
+    const int npix = w * h, chunks = backproject_chunks(w, h);
+    const double maxd = max_distance * cam.scale;
+    bp_count_kernel<<<dim3(chunks, n), 256, 0, s>>>(depth, sem, mask, npix, maxd, chunks, chunk_cnt);
+    bp_scan_kernel<<<1, 1024, 0, s>>>(chunk_cnt, n, chunks, chunk_off, npoints, total);
+    bp_emit_kernel<<<dim3(chunks, n), 256, 0, s>>>(depth, rgb, sem, mask, pose, w, npix, cam, maxd, chunks, chunk_off, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K12: voxel table of exact integer sums
+// open-addressing hash (linear probing) keyed by the 63-bit voxel key; slot layout == ssm_voxel (112 B).  Exact int64
+// sums make the result independent of arrival order, so plain device-scope atomics are bit-reproducible.  Points arrive
+// in row-major pixel order, so a wave's 64 points fall into a few runs of equal key: a segmented wave scan reduces each
+// run in registers and only the run's last lane touches memory.
+// counters: [0] occupied slots, [1] error flags (1 = table full), occupied-slot list follows the table.
+__device__ __forceinline__ uint32_t vox_hash(int64_t key)
+{
+    uint64_t z = (uint64_t)key * 0x9E3779B97F4A7C15ULL;
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
+    return (uint32_t)z;
+}
+__device__ __forceinline__ ssm_voxel* vox_find_or_insert(ssm_voxel* tab, int cap_log2, int64_t key, int32_t* counters, uint32_t* occ)
+{
+    const uint32_t mask = (1u << cap_log2) - 1u;
+    uint32_t slot = vox_hash(key) & mask;
+    for (uint32_t probe = 0; probe <= mask; probe++, slot = (slot + 1) & mask) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&tab[slot].key);
+        unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == (unsigned long long)key) return &tab[slot];
+        if (cur == (unsigned long long)SSM_VOX_EMPTY) {
+            const unsigned long long prev = atomicCAS(kp, (unsigned long long)SSM_VOX_EMPTY, (unsigned long long)key);
+            if (prev == (unsigned long long)SSM_VOX_EMPTY) { const int i = atomicAdd(&counters[0], 1); occ[i] = slot; return &tab[slot]; }
+            if (prev == (unsigned long long)key) return &tab[slot];
+        }
+    }
+    atomicOr(&counters[1], 1);
+    return nullptr;
+}
+__device__ __forceinline__ void vox_add(ssm_voxel* v, long long sx, long long sy, long long sz, unsigned long long sr, unsigned long long sg,
+                                        unsigned long long sb, unsigned long long n)
+{
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sx), (unsigned long long)sx);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sy), (unsigned long long)sy);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sz), (unsigned long long)sz);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sr), sr);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sg), sg);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->sb), sb);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v->n), n);
+}
+__global__ void vox_clear_kernel(ssm_voxel* __restrict__ tab, uint32_t* __restrict__ occ, int32_t* __restrict__ counters, int full, unsigned slots)
+{
+    // clears only the occupied slots (or everything when `full`)
+    const unsigned n = full ? slots : (unsigned)counters[0];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        ssm_voxel* v = &tab[full ? i : occ[i]];
+        uint4* p = reinterpret_cast<uint4*>(v);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < 7; k++) p[k] = z;
+        p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+    }
+}
+__global__ void vox_reset_counters(int32_t* counters) { counters[0] = 0; counters[1] = 0; }
+hipError_t k_voxel_clear(ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
+{
+    // cap_log2 < 0  =>  full clear of 2^-cap_log2 slots (first use)
+    const int full = cap_log2 < 0; const unsigned slots = 1u << (full ? -cap_log2 : cap_log2);
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + slots);
+    vox_clear_kernel<<<2048, 256, 0, s>>>(tab, occ, counters, full, slots);
+    vox_reset_counters<<<1, 1, 0, s>>>(counters);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__ n_dev, int64_t n_max, float inv_leaf,
+                  ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters)
+{
+    const int64_t n = n_dev ? min(*n_dev, n_max) : n_max;
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        long long key = -2, sx = 0, sy = 0, sz = 0; uint32_t rg = 0, bn = 0, label = 255;
+        if (valid) {
+            const uint4* p = reinterpret_cast<const uint4*>(pts + i);
+            const uint4 lo = p[0], hi = p[1];
+            const float x = __uint_as_float(lo.x), y = __uint_as_float(lo.y), z = __uint_as_float(lo.z);
+            const long long vi = (long long)floorf(x * inv_leaf) + (1 << 20);
+            const long long vj = (long long)floorf(y * inv_leaf) + (1 << 20);
+            const long long vk = (long long)floorf(z * inv_leaf) + (1 << 20);
+            key = (vk << 42) | (vj << 21) | vi;
+            sx = __double2ll_rn((double)x * 16777216.0); sy = __double2ll_rn((double)y * 16777216.0); sz = __double2ll_rn((double)z * 16777216.0);
+            rg = ((hi.x >> 16) & 255) | (((hi.x >> 8) & 255) << 16);       // r | g<<16
+            bn = (hi.x & 255) | (1u << 16);                               // b | n<<16
+            label = hi.y;
+        }
+        // runs of equal key inside the wave
+        const long long kprev = __shfl_up(key, 1, 64);
+        const bool head = lane == 0 || kprev != key;
+        const unsigned long long heads = __ballot(head);
+        const int start = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long ax = __shfl_up(sx, o, 64), ay = __shfl_up(sy, o, 64), az = __shfl_up(sz, o, 64);
+            const uint32_t arg = __shfl_up(rg, o, 64), abn = __shfl_up(bn, o, 64);
+            if (lane - o >= start) { sx += ax; sy += ay; sz += az; rg += arg; bn += abn; }
+        }
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        // label votes of the run: 12 ballots masked by the run
+        unsigned long long lb[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) lb[c] = __ballot(label == (uint32_t)c);
+        if (valid && tail) {
+            ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
+            if (v) {
+                vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
+                const unsigned long long run = (~0ull >> (63 - lane)) & (~0ull << start);
+#pragma unroll
+                for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&v->hist[c], (uint32_t)k); }
+            }
+        }
+    }
+}
+hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_max, float leaf, ssm_voxel* tab,
+                          int cap_log2, int32_t* counters, hipStream_t s)
+{
+    if (n_max <= 0) return hipSuccess;
+    int64_t blocks = (n_max + 255) / 256; if (blocks > 8192) blocks = 8192;
+    vox_insert_kernel<<<(int)blocks, 256, 0, s>>>(pts, n_dev, n_max, 1.0f / leaf, tab, cap_log2, counters);
+    return hipGetLastError();
+}
+__global__ void vox_merge_kernel(const ssm_voxel* __restrict__ src, int n, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters)
+{
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ssm_voxel sv = src[i];
+    ssm_voxel* v = vox_find_or_insert(tab, cap_log2, sv.key, counters, occ);
+    if (!v) return;
+    vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
+    for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
+}
+hipError_t k_voxel_merge(const ssm_voxel* src, int n, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    vox_merge_kernel<<<(n + 255) / 256, 256, 0, s>>>(src, n, tab, cap_log2, counters);
+    return hipGetLastError();
+}
+// gather the occupied slots (unordered) into a dense array
+__global__ void vox_compact_kernel(const ssm_voxel* __restrict__ tab, const uint32_t* __restrict__ occ, const int32_t* __restrict__ counters,
+                                   ssm_voxel* __restrict__ out, int32_t* __restrict__ n_out)
+{
+    const int n = counters[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4* s = reinterpret_cast<const uint4*>(&tab[occ[i]]);
+        uint4* d = reinterpret_cast<uint4*>(&out[i]);
+#pragma unroll
+        for (int k = 0; k < 7; k++) d[k] = s[k];
+    }
+}
+hipError_t k_voxel_compact(const ssm_voxel* tab, int cap_log2, ssm_voxel* out, int32_t* n_out, hipStream_t s)
+{
+    const uint32_t* occ = reinterpret_cast<const uint32_t*>(tab + (1u << cap_log2));
+    const int32_t* counters = reinterpret_cast<const int32_t*>(occ + (1u << cap_log2));
+    vox_compact_kernel<<<1024, 256, 0, s>>>(tab, occ, counters, out, n_out);
+    return hipGetLastError();
+}
+__global__ void vox_gather_points_kernel(const ssm_voxel* __restrict__ c, const uint32_t* __restrict__ order, int n, ssm_point* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ssm_voxel v = c[order[i]];
+    const double nn = (double)v.n;
+    const float x = (float)(((double)v.sx / nn) * (1.0 / 16777216.0));
+    const float y = (float)(((double)v.sy / nn) * (1.0 / 16777216.0));
+    const float z = (float)(((double)v.sz / nn) * (1.0 / 16777216.0));
+    const uint32_t r = (uint32_t)(v.sr / v.n), g = (uint32_t)(v.sg / v.n), b = (uint32_t)(v.sb / v.n);
+    uint32_t best = 0, lab = 255;
+#pragma unroll
+    for (int k = 0; k < 12; k++) if (v.hist[k] > best) { best = v.hist[k]; lab = k; }
+    uint4 lo, hi;
+    lo.x = __float_as_uint(x); lo.y = __float_as_uint(y); lo.z = __float_as_uint(z); lo.w = __float_as_uint(1.0f);
+    hi.x = b | (g << 8) | (r << 16); hi.y = lab; hi.z = 0; hi.w = 0;
+    uint4* o = reinterpret_cast<uint4*>(out + i);
+    o[0] = lo; o[1] = hi;
+}
+hipError_t k_voxel_gather_points(const ssm_voxel* compact, const uint32_t* order, int n, ssm_point* out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    vox_gather_points_kernel<<<(n + 255) / 256, 256, 0, s>>>(compact, order, n, out);
+    return hipGetLastError();
+}
+__global__ void vox_gather_table_kernel(const ssm_voxel* __restrict__ c, const uint32_t* __restrict__ order, int n, ssm_voxel* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* s = reinterpret_cast<const uint4*>(&c[order[i]]);
+    uint4* d = reinterpret_cast<uint4*>(&out[i]);
+#pragma unroll
+    for (int k = 0; k < 7; k++) d[k] = s[k];
+}
+hipError_t k_voxel_gather_table(const ssm_voxel* compact, const uint32_t* order, int n, ssm_voxel* out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    vox_gather_table_kernel<<<(n + 255) / 256, 256, 0, s>>>(compact, order, n, out);
+    return hipGetLastError();
+}
+// bounding box of a cloud (for pcl::VoxelGrid's index-overflow guard); minmax6 pre-set to +inf x3, -inf x3 as ordered ints
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__global__ void vox_bounds_kernel(const ssm_point* __restrict__ pts, int n, int* __restrict__ mm)
+{
+    int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = *reinterpret_cast<const float4*>(pts + i);
+        const int a[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = min(mn[k], a[k]); mx[k] = max(mx[k], a[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], o, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], o, 64)); }
+    }
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; k++) { atomicMin(&mm[k], mn[k]); atomicMax(&mm[3 + k], mx[k]); }
+}
+__global__ void vox_bounds_init(int* mm) { mm[0] = mm[1] = mm[2] = 0x7FFFFFFF; mm[3] = mm[4] = mm[5] = (int)0x80000000; }
+hipError_t k_voxel_bounds(const ssm_point* pts, int n, float* minmax6, hipStream_t s)
+{
+    vox_bounds_init<<<1, 1, 0, s>>>(reinterpret_cast<int*>(minmax6));
+    if (n > 0) vox_bounds_kernel<<<min((n + 255) / 256, 1024), 256, 0, s>>>(pts, n, reinterpret_cast<int*>(minmax6));
+    return hipGetLastError();
+}

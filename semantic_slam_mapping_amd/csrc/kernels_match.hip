@@ -1,0 +1,95 @@
+// kernels_match.hip -- K6: OrbFeature::match (/root/reference/src/orb.cpp:16-29) = cv::BFMatcher(NORM_HAMMING)
+// knnMatch(k=2) + Lowe ratio test, for gfx950.  One 1024-thread block per (query frame, train frame) pair: the train
+// descriptors are staged in LDS (32 B each, read back as wave-wide broadcasts), every lane owns one query descriptor
+// in 8 VGPRs, distance = 8 x (v_xor + v_bcnt accumulate); the kept matches are compacted in ascending queryIdx with
+// wave ballots.  Integer work, VALU-bound: no MFMA by design.  Tie rule = oracle/match.c (strict '<' scan in train
+// order, so equal distances resolve to the lower trainIdx).
+#include "ssm_internal.h"
+
+#define MT 1024          // threads per block = queries per pass
+#define TCH 1024         // train descriptors staged per chunk (32 KiB)
+
+__device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                           double ratio, int cap, ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout,
+                                           int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
+{
+    __shared__ uint4 tr[TCH * 2];
+    __shared__ int wcnt[MT / 64];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    for (int q0 = 0; q0 < nq; q0 += MT) {
+        const int qi = q0 + tid;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (qi < nq) { const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); a = p[0]; b = p[1]; }
+        int d0 = 1 << 30, d1 = 1 << 30, i0 = -1, i1 = -1;
+        for (int t0 = 0; t0 < nt; t0 += TCH) {
+            const int m = min(TCH, nt - t0);
+            __syncthreads();
+            for (int i = tid; i < m * 2; i += MT) tr[i] = reinterpret_cast<const uint4*>(t + (size_t)t0 * 32)[i];
+            __syncthreads();
+#pragma unroll 4
+            for (int j = 0; j < m; j++) {
+                const uint4 x = tr[2 * j], y = tr[2 * j + 1];
+                int d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w)
+                      + __popc(b.x ^ y.x) + __popc(b.y ^ y.y) + __popc(b.z ^ y.z) + __popc(b.w ^ y.w);
+                const int jj = t0 + j;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = jj; }
+                else if (d < d1) { d1 = d; i1 = jj; }
+            }
+        }
+        if (knn_idx && qi < nq) { knn_idx[2*qi] = i0; knn_idx[2*qi+1] = i1; knn_dist[2*qi] = d0; knn_dist[2*qi+1] = d1; }
+        // ratio test exactly as orb.cpp:25: float distance < double ratio * float distance, compared in double
+        const bool keep = (qi < nq) && ((double)(float)d0 < ratio * (double)(float)d1);
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; w++) off += wcnt[w];
+        if (keep) {
+            const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (out && k < cap) { ssm_dmatch m; m.queryIdx = qi; m.trainIdx = i0; m.imgIdx = 0; m.distance = (float)d0; out[k] = m; }
+        }
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int w = 0; w < MT / 64; w++) s += wcnt[w]; base += s; }
+    }
+    __syncthreads();
+    if (tid == 0 && nout) *nout = base;
+}
+
+__global__ void __launch_bounds__(MT)
+match_pairs_kernel(const uint8_t* __restrict__ desc, const MatchPair* __restrict__ pairs, double ratio, int cap,
+                   ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout, int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
+{
+    const MatchPair p = pairs[blockIdx.x];
+    match_pair(desc + (size_t)p.qoff * 32, p.nq, desc + (size_t)p.toff * 32, p.nt, ratio, cap,
+               out ? out + (size_t)p.out_slot * cap : nullptr, nout ? nout + p.out_slot : nullptr, knn_idx, knn_dist);
+}
+hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs, double ratio, int cap,
+                         ssm_dmatch* out, int32_t* nout, int32_t* knn_idx, int32_t* knn_dist, hipStream_t s)
+{
+    match_pairs_kernel<<<npairs, MT, 0, s>>>(desc, pairs, ratio, cap, out, nout, knn_idx, knn_dist);
+    return hipGetLastError();
+}
+
+// sequence mode: desc/nkp hold `hist` history frames followed by the frames of the call; frame f (0-based in the call)
+// sits at row hist+f.  Block (r, f): query = ref frame row f+r+hist-R ... i.e. the r-th of the R frames preceding f,
+// oldest first (std::deque order of Tracker::refFrames, src/track.cpp:150); train = frame f (orb->match(pFrame, cur)).
+__global__ void __launch_bounds__(MT)
+match_seq_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int f0, int R, int hist, double ratio, int cap,
+                 ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout)
+{
+    const int f = f0 + blockIdx.y, r = blockIdx.x;
+    const int cur = hist + f, ref = cur - R + r;
+    const int slot = f * R + r;
+    const int nq = ref >= 0 ? nkp[ref] : -1, nt = nkp[cur];
+    if (nq < 0 || nt < 2) { if (threadIdx.x == 0) nout[slot] = -1; return; }
+    match_pair(desc + (size_t)ref * cap * 32, nq, desc + (size_t)cur * cap * 32, nt, ratio, cap,
+               out + (size_t)slot * cap, nout + slot, nullptr, nullptr);
+}
+hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
+                       ssm_dmatch* out, int32_t* nout, hipStream_t s)
+{
+    match_seq_kernel<<<dim3(R, n), MT, 0, s>>>(desc, nkp, f0, R, hist, ratio, cap, out, nout);
+    return hipGetLastError();
+}

@@ -1,0 +1,569 @@
+// kernels_orb.hip -- K1..K5 of the hot path for gfx950: what OrbFeature::detectFeatures
+// (/root/reference/include/orb.h:32-53) does through cv::cvtColor (orb.h:39) and ORB_SLAM2::ORBextractor (orb.h:44),
+// batched over frames (grid.y = frame).  Integer / byte work, HBM- and LDS-bound: no MFMA here by design.
+// Contracts (rounding rules, tie-breaks) are those of oracle/orb.c; compile with -ffp-contract=off.
+#include "ssm_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ K1: BGR -> gray (level 0 of the pyramid)
+// 4 pixels per thread: 3 dword loads (12 B) -> 1 dword store when rows are 4-aligned.
+template <bool VEC>
+__global__ void gray_kernel(const uint8_t* __restrict__ img, int W, int H, int stride0, uint8_t* __restrict__ pyr, int pyr_bytes)
+{
+    const int quads = stride0 >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads * H) return;
+    const int y = q / quads, x = (q - y * quads) << 2;
+    const uint8_t* src = img + (size_t)blockIdx.y * W * H * 3 + ((size_t)y * W + x) * 3;
+    uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_bytes + (size_t)y * stride0 + x;
+    uint32_t out = 0;
+    if (VEC) {
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+        uint32_t a = s[0], b = s[1], c = s[2];
+        uint32_t p0 = ((a & 255) * 1868 + ((a >> 8) & 255) * 9617 + ((a >> 16) & 255) * 4899 + 8192) >> 14;
+        uint32_t p1 = ((a >> 24) * 1868 + (b & 255) * 9617 + ((b >> 8) & 255) * 4899 + 8192) >> 14;
+        uint32_t p2 = (((b >> 16) & 255) * 1868 + (b >> 24) * 9617 + (c & 255) * 4899 + 8192) >> 14;
+        uint32_t p3 = (((c >> 8) & 255) * 1868 + ((c >> 16) & 255) * 9617 + (c >> 24) * 4899 + 8192) >> 14;
+        out = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    } else {
+        for (int i = 0; i < 4; i++)
+            if (x + i < W) out |= ((src[3*i] * 1868u + src[3*i+1] * 9617u + src[3*i+2] * 4899u + 8192u) >> 14) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst) = out;
+}
+__global__ void graycopy_kernel(const uint8_t* __restrict__ img, int in_stride, size_t frame_bytes, int W, int H, int stride0,
+                                uint8_t* __restrict__ pyr, int pyr_bytes)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= stride0 * H) return;
+    const int y = q / stride0, x = q - y * stride0;
+    pyr[(size_t)blockIdx.y * pyr_bytes + q] = x < W ? img[(size_t)blockIdx.y * frame_bytes + (size_t)y * in_stride + x] : 0;
+}
+hipError_t k_gray(const uint8_t* img, int channels, int n, const OrbGeom& g, uint8_t* pyr, hipStream_t s)
+{
+    const int stride0 = g.L[0].stride;
+    if (channels == 3) {
+        dim3 grid(((stride0 >> 2) * g.H + 255) / 256, n);
+        if ((g.W & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0)
+            gray_kernel<true><<<grid, 256, 0, s>>>(img, g.W, g.H, stride0, pyr, g.pyr_bytes);
+        else
+            gray_kernel<false><<<grid, 256, 0, s>>>(img, g.W, g.H, stride0, pyr, g.pyr_bytes);
+    } else {
+        dim3 grid((stride0 * g.H + 255) / 256, n);
+        graycopy_kernel<<<grid, 256, 0, s>>>(img, g.W, (size_t)g.W * g.H, g.W, g.H, stride0, pyr, g.pyr_bytes);
+    }
+    return hipGetLastError();
+}
+hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g, uint8_t* pyr, hipStream_t s)
+{
+    dim3 grid((g.L[0].stride * g.H + 255) / 256, 1);
+    graycopy_kernel<<<grid, 256, 0, s>>>(img, stride, 0, g.W, g.H, g.L[0].stride, pyr, g.pyr_bytes);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K2: pyramid level from the previous level
+// cv::resize INTER_LINEAR 8u fixed point (coefficient tables built on the host, oracle/orb.c sso_resize_tables)
+__global__ void resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int sh, int sstride,
+                              int dst_off, int dw, int dh, int dstride,
+                              const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
+                              const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+{
+    const int quads = dstride >> 2;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads * dh) return;
+    const int y = q / quads, x0 = (q - y * quads) << 2;
+    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + src_off;
+    const int sy0 = yofs[y], sy1 = min(sy0 + 1, sh - 1);
+    const int b0 = ya[2*y], b1 = ya[2*y+1];
+    const uint8_t* r0 = src + (size_t)sy0 * sstride;
+    const uint8_t* r1 = src + (size_t)sy1 * sstride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + i;
+        if (x < dw) {
+            const int sx0 = xofs[x], sx1 = min(sx0 + 1, sw - 1);
+            const int a0 = xa[2*x], a1 = xa[2*x+1];
+            const int h0 = r0[sx0] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx0] * a0 + r1[sx1] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 255) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(pyr + (size_t)blockIdx.y * pyr_bytes + dst_off + (size_t)y * dstride + x0) = out;
+}
+hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
+                     const int32_t* const* yofs, const int16_t* const* ya, hipStream_t s)
+{
+    for (int l = 1; l < g.nlevels; l++) {
+        const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
+        dim3 grid(((b.stride >> 2) * b.h + 255) / 256, n);
+        resize_kernel<<<grid, 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.w, a.h, a.stride, b.img_off, b.w, b.h, b.stride,
+                                           xofs[l], xa[l], yofs[l], ya[l]);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K5a: 7x7 sigma-2 Gaussian, fixed point
+// taps {18,34,49,55,49,34,18}; row pass fits u16 (<= 257*255); (v + 2^15) >> 16, saturate.  64x16 tile per block,
+// input tile + 3-px apron staged in LDS, row-pass intermediate kept in LDS.
+#define BT_W 64
+#define BT_H 16
+__global__ void __launch_bounds__(256)
+blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int pyr_bytes, int off, int w, int h, int stride, int tiles_x)
+{
+    __shared__ uint8_t  in[BT_H + 6][BT_W + 8];
+    __shared__ uint16_t hp[BT_H + 6][BT_W];
+    const int tx0 = (blockIdx.x % tiles_x) * BT_W, ty0 = (blockIdx.x / tiles_x) * BT_H;
+    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + off;
+    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        const int ly = i / (BT_W + 6), lx = i - ly * (BT_W + 6);
+        int gx = tx0 + lx - 3, gy = ty0 + ly - 3;
+        gx = gx < 0 ? -gx : gx; gx = gx >= w ? 2 * w - 2 - gx : gx; gx = max(gx, 0);     // BORDER_REFLECT_101 (tiles past the edge clamp)
+        gy = gy < 0 ? -gy : gy; gy = gy >= h ? 2 * h - 2 - gy : gy; gy = max(gy, 0);
+        in[ly][lx] = src[(size_t)gy * stride + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
+        const int ly = i / BT_W, lx = i - ly * BT_W;
+        const uint8_t* p = &in[ly][lx];
+        hp[ly][lx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    uint8_t* dst = blur + (size_t)blockIdx.y * pyr_bytes + off;
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < BT_H; ly += 4) {
+        const int gx = tx0 + lx, gy = ty0 + ly;
+        if (gx < w && gy < h) {
+            int sacc = 18 * (hp[ly][lx] + hp[ly+6][lx]) + 34 * (hp[ly+1][lx] + hp[ly+5][lx]) + 49 * (hp[ly+2][lx] + hp[ly+4][lx]) + 55 * hp[ly+3][lx];
+            sacc = (sacc + 32768) >> 16;
+            dst[(size_t)gy * stride + gx] = (uint8_t)min(sacc, 255);
+        }
+    }
+}
+hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s)
+{
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.L[l];
+        const int tx = (L.w + BT_W - 1) / BT_W, ty = (L.h + BT_H - 1) / BT_H;
+        blur_kernel<<<dim3(tx * ty, n), 256, 0, s>>>(pyr, blur, g.pyr_bytes, L.img_off, L.w, L.h, L.stride, tx);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K3: per-cell FAST-9/16 + NMS
+// One block per (cell, frame).  Sub-image (wCell+6)x(hCell+6) staged in LDS; S = max over the 16 arcs of 9 of the
+// arc-min of (ring - v) / (v - ring); corner at t iff S > t; cv response = S - 1; NMS = strictly greater than the 8
+// neighbours inside the cell's inner region; iniThFAST first, minThFAST if the cell found nothing.
+#define FC_MAX 72
+__device__ __forceinline__ int fast_S(const uint8_t* p, int st)
+{
+    const int v = p[0];
+    int d[16];
+    d[0] = p[3*st] - v;      d[1] = p[3*st+1] - v;   d[2] = p[2*st+2] - v;   d[3] = p[st+3] - v;
+    d[4] = p[3] - v;         d[5] = p[-st+3] - v;    d[6] = p[-2*st+2] - v;  d[7] = p[-3*st+1] - v;
+    d[8] = p[-3*st] - v;     d[9] = p[-3*st-1] - v;  d[10] = p[-2*st-2] - v; d[11] = p[-st-3] - v;
+    d[12] = p[-3] - v;       d[13] = p[st-3] - v;    d[14] = p[2*st-2] - v;  d[15] = p[3*st-1] - v;
+    // quick reject at threshold 0: a 9-arc contains >= 2 of the 4 compass points
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min(d[k], min(d[(k+1)&15], d[(k+2)&15]));
+        mx3[k] = max(d[k], max(d[(k+1)&15], d[(k+2)&15]));
+    }
+    int bright = -256, dark = -256;      // bright ring: min(ring - v); dark ring: min(v - ring) = -max(ring - v)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(mn3[k], min(mn3[(k+3)&15], mn3[(k+6)&15]));
+        const int mx9 = max(mx3[k], max(mx3[(k+3)&15], mx3[(k+6)&15]));
+        bright = max(bright, mn9); dark = max(dark, -mx9);
+    }
+    return max(bright, dark);
+}
+__global__ void __launch_bounds__(128)
+fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand)
+{
+    __shared__ uint8_t px[FC_MAX * FC_MAX];
+    __shared__ uint8_t sc[FC_MAX * FC_MAX];
+    __shared__ cand_t  list[(FC_MAX / 2) * (FC_MAX / 2)];
+    __shared__ int n_ini, n_min, n_out, g_base;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].cell_off) l++;
+    const LevelGeom& L = g.L[l];
+    const int cell = blockIdx.x - L.cell_off;
+    const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+    const int iniY = L.minBY + ci * L.hCell, iniX = L.minBX + cj * L.wCell;
+    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) return;
+    const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
+    const int cw = maxX - iniX, ch = maxY - iniY;
+    const uint8_t* im = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    if (threadIdx.x == 0) { n_ini = 0; n_min = 0; n_out = 0; }
+    for (int i = threadIdx.x; i < cw * ch; i += 128) {
+        const int y = i / cw, x = i - y * cw;
+        px[y * FC_MAX + x] = im[(size_t)(iniY + y) * L.stride + iniX + x];
+        sc[y * FC_MAX + x] = 0;
+    }
+    __syncthreads();
+    const int iw = cw - 6, ih = ch - 6;
+    for (int i = threadIdx.x; i < iw * ih; i += 128) {
+        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+        const int S = fast_S(&px[y * FC_MAX + x], FC_MAX);
+        sc[y * FC_MAX + x] = (uint8_t)max(S, 0);
+    }
+    __syncthreads();
+    // local maxima; which threshold class they reach
+    int kept_ini = 0, kept_min = 0;
+    for (int i = threadIdx.x; i < iw * ih; i += 128) {
+        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+        const uint8_t* q = &sc[y * FC_MAX + x];
+        const int S = q[0];
+        if (S <= g.min_th) continue;
+        const int nb = max(max(max(q[-FC_MAX-1], q[-FC_MAX]), max(q[-FC_MAX+1], q[-1])), max(max(q[1], q[FC_MAX-1]), max(q[FC_MAX], q[FC_MAX+1])));
+        // keep at th iff S-1 > (n > th ? n-1 : 0) for every neighbour n.  With S > th this is S > max over neighbours that exceed th.
+        if (S > g.ini_th && !(nb > g.ini_th && nb >= S)) kept_ini++;
+        if (!(nb > g.min_th && nb >= S)) kept_min++;
+    }
+    if (kept_ini) atomicAdd(&n_ini, kept_ini);
+    if (kept_min) atomicAdd(&n_min, kept_min);
+    __syncthreads();
+    const int th = n_ini > 0 ? g.ini_th : g.min_th;
+    if ((n_ini > 0 ? n_ini : n_min) == 0) return;
+    for (int i = threadIdx.x; i < iw * ih; i += 128) {
+        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
+        const uint8_t* q = &sc[y * FC_MAX + x];
+        const int S = q[0];
+        if (S <= th) continue;
+        const int nb = max(max(max(q[-FC_MAX-1], q[-FC_MAX]), max(q[-FC_MAX+1], q[-1])), max(max(q[1], q[FC_MAX-1]), max(q[FC_MAX], q[FC_MAX+1])));
+        if (nb > th && nb >= S) continue;
+        const int k = atomicAdd(&n_out, 1);
+        cand_t c;
+        c.x = (uint32_t)(x + cj * L.wCell) | ((uint32_t)(y + ci * L.hCell) << 12) | ((uint32_t)(S - 1) << 24);
+        c.y = ((uint32_t)cell << 14) | ((uint32_t)y << 7) | (uint32_t)x;
+        list[k] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) g_base = atomicAdd(&ncand[blockIdx.y * g.nlevels + l], n_out);
+    __syncthreads();
+    cand_t* out = cand + (size_t)blockIdx.y * g.cand_total + L.cand_off;
+    for (int i = threadIdx.x; i < n_out; i += 128)
+        if (g_base + i < L.cand_cap) out[g_base + i] = list[i];
+}
+hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s);
+    if (e != hipSuccess) return e;
+    fast_kernel<<<dim3(g.cells_total, n), 128, 0, s>>>(pyr, g, cand, ncand);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K4: ORBextractor::DistributeOctTree
+// One block per (level, frame).  Keys stay in global scratch (node id per key in node_of); the node LIST lives in LDS as
+// an array in std::list order and is rebuilt once per pass by lane 0, while the per-key work (child counting,
+// re-labelling, best-response selection) is spread over the block.  Equivalence with the literal std::list code of
+// oracle/orb.c: a pass splits parents p_1..p_m in processing order (list order in the first phase, (size desc, newest
+// first) in the second, stopping when the list reaches N); push_front of n1..n4 then erase(parent) leaves
+//   [n4..n1 of p_m] ... [n4..n1 of p_1] ++ (old list without the split parents).
+struct QNode { short x0, y0, x1, y1; };
+__global__ void __launch_bounds__(256)
+octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, uint16_t* __restrict__ node_of,
+              uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
+{
+    __shared__ QNode    nd[2][SSM_MAX_NODES];
+    __shared__ uint32_t cnt[2][SSM_MAX_NODES];
+    __shared__ uint32_t sq[2][SSM_MAX_NODES];
+    __shared__ uint32_t cc[SSM_MAX_NODES][4];
+    __shared__ short    newpos[SSM_MAX_NODES];
+    __shared__ short    childpos[SSM_MAX_NODES][4];
+    __shared__ short    order[SSM_MAX_NODES];
+    __shared__ unsigned long long best[SSM_MAX_NODES];
+    __shared__ int sL, sFinish, sMode, sE, sErr;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g.L[l];
+    const int N = L.nfeat;
+    int nc = ncand[f * g.nlevels + l];
+    if (nc > L.cand_cap) { nc = L.cand_cap; if (tid == 0) atomicOr(status, 1); }
+    const cand_t* keys = cand + (size_t)f * g.cand_total + L.cand_off;
+    uint16_t* nof = node_of + (size_t)f * g.cand_total + L.cand_off;
+    uint32_t* out = sel + (size_t)f * g.sel_total + L.sel_off;
+    if (nc == 0) { if (tid == 0) nsel[f * g.nlevels + l] = 0; return; }
+    // ---- root nodes
+    const int nIni = L.nIni; const float hX = L.hX;
+    for (int i = tid; i < nIni; i += 256) {
+        QNode q; q.x0 = (short)(int)(hX * (float)i); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(i + 1)); q.y1 = (short)(L.maxBY - L.minBY);
+        nd[0][i] = q; cnt[0][i] = 0; sq[0][i] = i;
+    }
+    if (tid == 0) { sErr = 0; }
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) {
+        const int x = keys[i].x & 4095;
+        int b = (int)((float)x / hX); b = min(b, nIni - 1);
+        nof[i] = (uint16_t)b; atomicAdd(&cnt[0][b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int i = 0; i < nIni; i++) {
+            if (cnt[0][i] == 0) { newpos[i] = -1; continue; }
+            nd[1][pos] = nd[0][i]; cnt[1][pos] = cnt[0][i]; sq[1][pos] = sq[0][i]; newpos[i] = (short)pos; pos++;
+        }
+        sL = pos; sFinish = 0; sMode = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) nof[i] = (uint16_t)newpos[nof[i]];
+    int cur = 1;      // buffer holding the current list
+    __syncthreads();
+    // ---- split passes
+    while (!sFinish) {
+        const int Lsz = sL;
+        QNode* cn = nd[cur]; uint32_t* ccnt = cnt[cur]; uint32_t* csq = sq[cur];
+        QNode* nn = nd[cur ^ 1]; uint32_t* ncnt = cnt[cur ^ 1]; uint32_t* nsq = sq[cur ^ 1];
+        for (int i = tid; i < Lsz; i += 256) { cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0; }
+        __syncthreads();
+        for (int i = tid; i < nc; i += 256) {
+            const int ni = nof[i];
+            if (ccnt[ni] > 1) {
+                const QNode q = cn[ni];
+                const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
+                const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+                const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                atomicAdd(&cc[ni][qd], 1u);
+            }
+        }
+        // processing order for the second phase: rank among expandable nodes by (size desc, creation seq desc)
+        for (int i = tid; i < Lsz; i += 256) {
+            if (ccnt[i] > 1) {
+                const uint32_t ci = ccnt[i], si = csq[i];
+                int r = 0;
+                for (int j = 0; j < Lsz; j++) {
+                    const uint32_t cj = ccnt[j];
+                    if (cj > 1 && (cj > ci || (cj == ci && csq[j] > si))) r++;
+                }
+                order[r] = (short)i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int E = 0;
+            for (int i = 0; i < Lsz; i++) if (ccnt[i] > 1) E++;
+            int pos = 0, nToExpand = 0, err = 0;
+            // emit the children of one parent (n4..n1), processing index e
+            #define EMIT_CHILDREN(i, e)                                                                         \
+                {   const QNode q = cn[i];                                                                      \
+                    const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);       \
+                    for (int qd = 3; qd >= 0; qd--) {                                                           \
+                        const uint32_t c = cc[i][qd];                                                           \
+                        if (c == 0) { childpos[i][qd] = -1; continue; }                                         \
+                        if (pos >= SSM_MAX_NODES) { err = 1; childpos[i][qd] = 0; continue; }                   \
+                        QNode ch;                                                                               \
+                        ch.x0 = (qd & 1) ? (short)mx : q.x0; ch.x1 = (qd & 1) ? q.x1 : (short)mx;               \
+                        ch.y0 = (qd & 2) ? (short)my : q.y0; ch.y1 = (qd & 2) ? q.y1 : (short)my;               \
+                        nn[pos] = ch; ncnt[pos] = c; nsq[pos] = 4u * (uint32_t)(e) + (uint32_t)qd;              \
+                        childpos[i][qd] = (short)pos; pos++;                                                    \
+                        if (c > 1) nToExpand++;                                                                 \
+                    }                                                                                           \
+                }
+            if (sMode == 0) {
+                int e = E;
+                for (int i = Lsz - 1; i >= 0; i--) if (ccnt[i] > 1) { e--; EMIT_CHILDREN(i, e); newpos[i] = -2; }
+                for (int i = 0; i < Lsz; i++) if (ccnt[i] <= 1) {
+                    if (pos >= SSM_MAX_NODES) { err = 1; newpos[i] = 0; continue; }
+                    nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
+                }
+                if (pos >= N || pos == Lsz) sFinish = 1;
+                else if (pos + 3 * nToExpand > N) sMode = 1;
+            } else {
+                int size = Lsz, nsplit = 0;
+                for (int r = 0; r < E; r++) {
+                    const int i = order[r];
+                    int nonempty = 0;
+                    for (int qd = 0; qd < 4; qd++) nonempty += cc[i][qd] > 0;
+                    size += nonempty - 1; nsplit++;
+                    if (size >= N) break;
+                }
+                for (int i = 0; i < Lsz; i++) newpos[i] = 0;
+                for (int r = nsplit - 1; r >= 0; r--) { const int i = order[r]; EMIT_CHILDREN(i, r); newpos[i] = -2; }
+                for (int i = 0; i < Lsz; i++) if (newpos[i] != -2) {
+                    if (pos >= SSM_MAX_NODES) { err = 1; newpos[i] = 0; continue; }
+                    nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
+                }
+                if (pos >= N || pos == Lsz) sFinish = 1;
+            }
+            #undef EMIT_CHILDREN
+            if (err) { sErr = 1; sFinish = 1; }
+            sL = pos;
+        }
+        __syncthreads();
+        for (int i = tid; i < nc; i += 256) {
+            const int ni = nof[i];
+            if (newpos[ni] == -2) {
+                const QNode q = cn[ni];
+                const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
+                const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+                const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                nof[i] = (uint16_t)childpos[ni][qd];
+            } else nof[i] = (uint16_t)newpos[ni];
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    // ---- best response per node (ties: first in detection order == lowest rank)
+    const int Lf = sL;
+    if (sErr && tid == 0) atomicOr(status, 2);
+    for (int i = tid; i < Lf; i += 256) best[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) {
+        const cand_t k = keys[i];
+        const unsigned long long v = ((unsigned long long)(k.x >> 24) << 56) | ((unsigned long long)(0xFFFFFFFFu - k.y) << 24) | (k.x & 0xFFFFFFu);
+        atomicMax(&best[nof[i]], v);
+    }
+    __syncthreads();
+    for (int i = tid; i < Lf && i < L.sel_cap; i += 256) {
+        const unsigned long long v = best[i];
+        const uint32_t x = (uint32_t)(v & 4095) + L.minBX, y = (uint32_t)((v >> 12) & 4095) + L.minBY, s = (uint32_t)(v >> 56);
+        out[i] = x | (y << 12) | (s << 24);
+    }
+    if (tid == 0) { nsel[f * g.nlevels + l] = min(Lf, L.sel_cap); if (Lf > L.sel_cap) atomicOr(status, 4); }
+}
+hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, uint16_t* node_of,
+                    uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s)
+{
+    octree_kernel<<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, node_of, sel, nsel, status);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K5b: IC_Angle + steered BRIEF + 3-D position
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)2.2204460492503131e-16); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else          { c = ax / (ay + (float)2.2204460492503131e-16); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+__device__ __forceinline__ void contract_sincos(float angle_rad, float* s, float* c)
+{
+    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11;
+    const double x = (double)angle_rad;
+    const double kd = rint(x * 0.63661977236758134308);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = ps * r2 + 1.0 / 6227020800.0;
+    ps = ps * r2 - 1.0 / 39916800.0;
+    ps = ps * r2 + 1.0 / 362880.0;
+    ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0;
+    ps = ps * r2 - 1.0 / 6.0;
+    const double sn = r + r * (r2 * ps);
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    pc = pc * r2 - 0.5;
+    const double cs = 1.0 + r2 * pc;
+    double S, C;
+    switch (k & 3) { case 0: S = sn; C = cs; break; case 1: S = cs; C = -sn; break; case 2: S = -sn; C = -cs; break; default: S = -cs; C = sn; break; }
+    *s = (float)S; *c = (float)C;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ void __launch_bounds__(256)
+describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, const uint32_t* __restrict__ sel,
+                const int32_t* __restrict__ nsel, const int8_t* __restrict__ pattern, const uint16_t* __restrict__ depth, ssm_camera cam,
+                ssm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, float* __restrict__ pos3d, int32_t* __restrict__ nkp)
+{
+    const int lane = threadIdx.x & 63, f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int32_t* ns = nsel + f * g.nlevels;
+    if (slot == 0 && lane == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
+    if (slot >= g.sel_total) return;
+    int l = 0;
+    while (l + 1 < g.nlevels && slot >= g.L[l+1].sel_off) l++;
+    const LevelGeom& L = g.L[l];
+    const int i = slot - L.sel_off;
+    if (i >= ns[l]) return;
+    int oidx = i;
+    for (int k = 0; k < l; k++) oidx += ns[k];
+    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
+    const int x = pk & 4095, y = (pk >> 12) & 4095, score = pk >> 24;
+    const uint8_t* im = pyr + (size_t)f * g.pyr_bytes + L.img_off + (size_t)y * L.stride + x;
+    const uint8_t* bl = blur + (size_t)f * g.pyr_bytes + L.img_off + (size_t)y * L.stride + x;
+    // intensity centroid over the radius-15 disc: lane -> (row, half-row)
+    int m10 = 0, m01 = 0;
+    {
+        const int r = lane >> 1, v = r - SSM_HALF_PATCH;
+        if (r <= 2 * SSM_HALF_PATCH) {
+            const int d = g.umax[v < 0 ? -v : v];
+            const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+            const uint8_t* row = im + v * L.stride;
+            int si = 0, sui = 0;
+            for (int u = u0; u <= u1; u++) { const int p = row[u]; si += p; sui += u * p; }
+            m10 = sui; m01 = v * si;
+        }
+    }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // steered BRIEF: lane -> 4 of the 256 comparisons
+    float sb, ca;
+    contract_sincos(angle * (float)(3.14159265358979323846 / 180.f), &sb, &ca);
+    uint32_t nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int8_t* q = pattern + (lane * 4 + k) * 4;
+        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const int yy0 = __float2int_rn(x0 * sb + y0 * ca), xx0 = __float2int_rn(x0 * ca - y0 * sb);
+        const int yy1 = __float2int_rn(x1 * sb + y1 * ca), xx1 = __float2int_rn(x1 * ca - y1 * sb);
+        const int t0 = bl[yy0 * L.stride + xx0], t1 = bl[yy1 * L.stride + xx1];
+        nib |= (uint32_t)(t0 < t1) << k;
+    }
+    // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word
+    uint32_t b = nib | (__shfl_down(nib, 1, 64) << 4);           // even lanes: one byte
+    b |= __shfl_down(b, 2, 64) << 8;                             // lanes %4==0: 2 bytes
+    b |= __shfl_down(b, 4, 64) << 16;                            // lanes %8==0: 4 bytes
+    const uint32_t hi = __shfl_down(b, 8, 64);
+    if ((lane & 15) == 0)
+        reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + oidx) * 32)[lane >> 4] = make_uint2(b, hi);
+    if (lane == 0) {
+        ssm_keypoint kp;
+        kp.x = (float)x; kp.y = (float)y;
+        if (l != 0) { kp.x *= L.sf; kp.y *= L.sf; }
+        kp.size = (float)SSM_PATCH * L.sf; kp.angle = angle; kp.response = (float)score; kp.octave = l; kp.class_id = -1;
+        kps[(size_t)f * g.cap + oidx] = kp;
+        if (pos3d) {
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (depth) {
+                const int u = (int)kp.x, v = (int)kp.y;            // include/orb.h:50 float -> int truncation
+                const uint16_t d = depth[(size_t)f * g.W * g.H + (size_t)v * g.W + u];
+                if (d != 0) {
+                    pz = (float)((double)d / cam.scale);
+                    px = (float)(((double)u - cam.cx) * (double)pz / cam.fx);
+                    py = (float)(((double)v - cam.cy) * (double)pz / cam.fy);
+                }
+            }
+            float* o = pos3d + ((size_t)f * g.cap + oidx) * 3;
+            o[0] = px; o[1] = py; o[2] = pz;
+        }
+    }
+}
+hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
+                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam,
+                      ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp, hipStream_t s)
+{
+    describe_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, pyr, blur, sel, nsel, pattern, depth, cam, kps, desc, pos3d, nkp);
+    return hipGetLastError();
+}

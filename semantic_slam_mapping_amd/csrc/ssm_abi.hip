@@ -1,0 +1,681 @@
+// ssm_abi.hip -- host side of libssm_hip.so: context, geometry, device workspace and the extern "C" entry points
+// declared in include/ssm_hip.h.  No computation of the path happens on the host: this file only sizes buffers,
+// moves caller data and enqueues the kernels of kernels_*.hip on the context stream.  There is NO CPU fallback: if
+// HIP is unusable ssm_create fails with SSM_E_NODEVICE / SSM_E_HIP.
+#include "ssm_internal.h"
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+static const int8_t k_default_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+static thread_local std::string g_create_err;
+
+namespace {
+
+struct VoxTable {           // tab[slots] | occ[slots] | counters[4]
+    ssm_voxel* tab = nullptr; uint32_t* occ = nullptr; int32_t* counters = nullptr; int cap_log2 = 0;
+    size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 16; }
+};
+struct StageRec { const char* name; hipEvent_t a, b; };
+
+} // namespace
+
+struct ssm_ctx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ssm_config cfg{};
+    OrbGeom g{};
+    std::string err;
+    int B = 1, R = 5;
+    // constant tables
+    int8_t* d_pattern = nullptr;
+    int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
+    int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
+    // batch workspace (B frames)
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
+    int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr;
+    uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
+    ssm_point* d_points = nullptr;
+    // staging for the host-pointer entry points (one frame) + generic scratch
+    uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
+    void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    void* d_scratch2 = nullptr; size_t scratch2_bytes = 0;
+    // sequence outputs
+    int seq_cap = 0, prev_n = -1;
+    ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
+    ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
+    // voxel tables
+    VoxTable map, tmp;
+    // profiling
+    bool profiling = false;
+    std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
+    std::vector<std::string> stage_names; std::vector<float> stage_ms; std::vector<int> stage_launches;
+};
+
+#define FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+#define HIPCHK(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return SSM_E_HIP; } } while (0)
+
+static inline int cv_round_f(float v) { return (int)lrint((double)v); }
+
+// ---------------------------------------------------------------- geometry (mirrors ORBextractor ctor / ComputePyramid)
+static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
+{
+    memset(&g, 0, sizeof(g));
+    if (c.orb_levels < 1 || c.orb_levels > SSM_MAX_LEVELS) { err = "orb_levels must be 1..12"; return SSM_E_INVAL; }
+    if (c.orb_features < 1) { err = "orb_features must be >= 1"; return SSM_E_INVAL; }
+    if (c.orb_iniThFAST < 1 || c.orb_minThFAST < 1 || c.orb_minThFAST > 254 || c.orb_iniThFAST > 254) { err = "FAST thresholds must be 1..254"; return SSM_E_INVAL; }
+    if (c.width < 64 || c.height < 64 || c.width > 4000 || c.height > 4000) { err = "frame size must be 64..4000"; return SSM_E_INVAL; }
+    if (!(c.orb_scale > 1.0f)) { err = "orb_scale must be > 1"; return SSM_E_INVAL; }
+    g.nlevels = c.orb_levels; g.W = c.width; g.H = c.height; g.ini_th = c.orb_iniThFAST; g.min_th = c.orb_minThFAST;
+    const double scaleFactor = (double)c.orb_scale;
+    float sf[SSM_MAX_LEVELS], inv[SSM_MAX_LEVELS];
+    sf[0] = 1.0f;
+    for (int i = 1; i < g.nlevels; i++) sf[i] = (float)(sf[i-1] * scaleFactor);
+    for (int i = 0; i < g.nlevels; i++) inv[i] = 1.0f / sf[i];
+    int feat[SSM_MAX_LEVELS];
+    {
+        const float factor = (float)(1.0f / scaleFactor);
+        float nd = c.orb_features * (1 - factor) / (1 - (float)pow((double)factor, (double)g.nlevels));
+        int sum = 0;
+        for (int l = 0; l < g.nlevels - 1; l++) { feat[l] = cv_round_f(nd); sum += feat[l]; nd *= factor; }
+        feat[g.nlevels-1] = c.orb_features - sum > 0 ? c.orb_features - sum : 0;
+    }
+    {
+        const int vmax = (int)floor(SSM_HALF_PATCH * sqrt(2.0) / 2 + 1), vmin = (int)ceil(SSM_HALF_PATCH * sqrt(2.0) / 2);
+        const double hp2 = SSM_HALF_PATCH * SSM_HALF_PATCH;
+        int um[SSM_HALF_PATCH + 2] = {0};
+        for (int v = 0; v <= vmax; ++v) um[v] = (int)lrint(sqrt(hp2 - v * v));
+        for (int v = SSM_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
+        for (int v = 0; v <= SSM_HALF_PATCH; v++) g.umax[v] = um[v];
+    }
+    int off = 0, cells = 0, cands = 0, sels = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelGeom& L = g.L[l];
+        L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
+        if (L.w < 2 * SSM_EDGE + 8 + 30 || L.h < 2 * SSM_EDGE + 8 + 30) { err = "pyramid level too small for the ORB border; lower orb_levels"; return SSM_E_INVAL; }
+        L.stride = (L.w + 3) & ~3; L.img_off = off; off += (L.stride * L.h + 15) & ~15;
+        L.minBX = SSM_EDGE - 3; L.minBY = SSM_EDGE - 3; L.maxBX = L.w - SSM_EDGE + 3; L.maxBY = L.h - SSM_EDGE + 3;
+        const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
+        L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+        L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
+        if (L.wCell + 6 > 72 || L.hCell + 6 > 72) { err = "FAST cell larger than the LDS tile"; return SSM_E_INVAL; }
+        L.cell_off = cells; cells += L.nCols * L.nRows;
+        L.nfeat = feat[l];
+        if (L.nfeat + 3 > SSM_MAX_NODES - 8) { err = "too many features per level for the LDS quad-tree (max 1013 per level)"; return SSM_E_INVAL; }
+        L.cand_off = cands; L.cand_cap = ((L.w + 1) / 2) * ((L.h + 1) / 2); cands += L.cand_cap;
+        if (L.cand_cap > 65535 * 16) { err = "level too large"; return SSM_E_INVAL; }
+        L.sel_off = sels; L.sel_cap = L.nfeat + 3; sels += L.sel_cap;
+        int nIni = (int)roundf((float)(L.maxBX - L.minBX) / (float)(L.maxBY - L.minBY)); if (nIni < 1) nIni = 1;
+        L.nIni = nIni; L.hX = (float)(L.maxBX - L.minBX) / nIni;
+        if (4 * nIni + 8 > SSM_MAX_NODES) { err = "aspect ratio too extreme"; return SSM_E_INVAL; }
+        L.sf = sf[l];
+    }
+    g.pyr_bytes = off; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
+    g.cap = c.orb_features + 3 * g.nlevels;
+    return SSM_OK;
+}
+static void resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<int16_t>& coef)
+{
+    ofs.resize(dsize); coef.resize(2 * dsize);
+    const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+        ofs[d] = s;
+        coef[2*d] = (int16_t)cv_round_f((1.f - f) * 2048.f); coef[2*d+1] = (int16_t)cv_round_f(f * 2048.f);
+    }
+}
+
+// ---------------------------------------------------------------- helpers
+template <class T> static int dalloc(ssm_ctx* c, T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) { c->err = std::string("hipMalloc(") + std::to_string(count * sizeof(T)) + "): " + hipGetErrorString(e); return SSM_E_NOMEM; }
+    return SSM_OK;
+}
+#define DALLOC(ctx, p, n) do { int r__ = dalloc(ctx, &(p), (size_t)(n)); if (r__) return r__; } while (0)
+static int ensure_scratch(ssm_ctx* c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return SSM_OK;
+    if (c->d_scratch) { hipStreamSynchronize(c->stream); hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
+    uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
+    c->d_scratch = p; c->scratch_bytes = bytes; return SSM_OK;
+}
+static int ensure_scratch2(ssm_ctx* c, size_t bytes)
+{
+    if (bytes <= c->scratch2_bytes) return SSM_OK;
+    if (c->d_scratch2) { hipStreamSynchronize(c->stream); hipFree(c->d_scratch2); c->d_scratch2 = nullptr; c->scratch2_bytes = 0; }
+    uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
+    c->d_scratch2 = p; c->scratch2_bytes = bytes; return SSM_OK;
+}
+static int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
+{
+    t.cap_log2 = cap_log2;
+    uint8_t* p; int r = dalloc(c, &p, t.bytes()); if (r) return r;
+    const size_t slots = (size_t)1 << cap_log2;
+    t.tab = reinterpret_cast<ssm_voxel*>(p); t.occ = reinterpret_cast<uint32_t*>(t.tab + slots); t.counters = reinterpret_cast<int32_t*>(t.occ + slots);
+    HIPCHK(c, k_voxel_clear(t.tab, -cap_log2, t.counters, c->stream));
+    return SSM_OK;
+}
+static void prof_begin(ssm_ctx* c, const char* name)
+{
+    if (!c->profiling) return;
+    auto get = [&]() { if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); } return c->pool[c->pool_used++]; };
+    StageRec r; r.name = name; r.a = get(); r.b = get();
+    hipEventRecord(r.a, c->stream);
+    c->recs.push_back(r);
+}
+static void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back().b, c->stream); }
+
+static int check_device_flags(ssm_ctx* c)
+{
+    int32_t st = 0, cnt[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
+    if (st) { hipMemset(c->d_status, 0, 4); FAIL(c, SSM_E_CAPACITY, "ORB scratch capacity exceeded (status " + std::to_string(st) + ")"); }
+    if (cnt[1]) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    return SSM_OK;
+}
+
+// ---------------------------------------------------------------- lifecycle
+extern "C" void ssm_config_default(ssm_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->width = 640; c->height = 480;
+    c->orb_features = 2000; c->orb_scale = 1.2f; c->orb_levels = 8; c->orb_iniThFAST = 20; c->orb_minThFAST = 7;   // parameters.txt:66-71
+    c->knn_match_ratio = 0.8; c->tracker_ref_frames = 5;                                                            // :72,:81
+    c->mapper_resolution = 0.1; c->mapper_max_distance = 40;                                                        // :97-98
+    c->camera.cx = 318.6; c->camera.cy = 255.3; c->camera.fx = 517.3; c->camera.fy = 516.5; c->camera.scale = 1000.0;
+    c->max_batch = 16; c->voxel_capacity_log2 = 20; c->brief_pattern = nullptr;
+}
+extern "C" const char* ssm_version(void) { return "ssm_hip 0.1 (gfx950)"; }
+extern "C" const char* ssm_last_error(const ssm_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+static int ctx_init(ssm_ctx* c)
+{
+    const ssm_config& cfg = c->cfg; const OrbGeom& g = c->g; const int B = c->B, W = g.W, H = g.H;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    DALLOC(c, c->d_pattern, 1024);
+    HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
+    for (int l = 1; l < g.nlevels; l++) {
+        std::vector<int32_t> xo, yo; std::vector<int16_t> xa, ya;
+        resize_tables(g.L[l-1].w, g.L[l].w, xo, xa); resize_tables(g.L[l-1].h, g.L[l].h, yo, ya);
+        DALLOC(c, c->d_xofs[l], xo.size()); DALLOC(c, c->d_xa[l], xa.size()); DALLOC(c, c->d_yofs[l], yo.size()); DALLOC(c, c->d_ya[l], ya.size());
+        HIPCHK(c, hipMemcpy(c->d_xofs[l], xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_xa[l], xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_ya[l], ya.data(), ya.size() * 2, hipMemcpyHostToDevice));
+    }
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes);
+    DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
+    DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
+    DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
+    const int chunks = backproject_chunks(W, H);
+    DALLOC(c, c->d_mask, (size_t)B * W * H); DALLOC(c, c->d_chunk_cnt, (size_t)B * chunks); DALLOC(c, c->d_chunk_off, (size_t)B * chunks);
+    DALLOC(c, c->d_total, 2); DALLOC(c, c->d_points, (size_t)B * W * H);
+    DALLOC(c, c->d_in_img, (size_t)W * H * 3); DALLOC(c, c->d_in_sem, (size_t)W * H * 3); DALLOC(c, c->d_in_depth, (size_t)W * H); DALLOC(c, c->d_in_pose, 16);
+    int r = table_alloc(c, c->map, cfg.voxel_capacity_log2); if (r) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return SSM_E_INVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_err = std::string("no HIP device: ") + hipGetErrorString(e); return SSM_E_NODEVICE; }
+    if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return SSM_E_INVAL; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SSM_E_HIP; }
+    ssm_ctx* c = new ssm_ctx();
+    c->device = device; c->cfg = *cfg;
+    c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
+    int r = build_geometry(*cfg, c->g, c->err);
+    if (!r && (cfg->voxel_capacity_log2 < 8 || cfg->voxel_capacity_log2 > 28)) { c->err = "voxel_capacity_log2 must be 8..28"; r = SSM_E_INVAL; }
+    if (!r && !(cfg->mapper_resolution > 0)) { c->err = "mapper_resolution must be > 0"; r = SSM_E_INVAL; }
+    if (!r) r = ctx_init(c);
+    if (r) { g_create_err = c->err; ssm_destroy(c); return r; }
+    c->cfg.brief_pattern = nullptr;
+    *out = c;
+    return SSM_OK;
+}
+extern "C" void ssm_destroy(ssm_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
+                     c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
+                     c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints,
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab };
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); }
+    for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
+extern "C" void* ssm_stream(ssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int ssm_sync(ssm_ctx* c)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_device_flags(c);
+}
+extern "C" int ssm_set_profiling(ssm_ctx* c, int on) { if (!c) return SSM_E_INVAL; std::lock_guard<std::mutex> lk(c->mu); c->profiling = on != 0; return SSM_OK; }
+extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, int* launches, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stage_names.clear(); c->stage_ms.clear(); c->stage_launches.clear();
+    for (const StageRec& r : c->recs) {
+        float t = 0.f; hipEventElapsedTime(&t, r.a, r.b);
+        size_t i = 0;
+        for (; i < c->stage_names.size(); i++) if (c->stage_names[i] == r.name) break;
+        if (i == c->stage_names.size()) { c->stage_names.push_back(r.name); c->stage_ms.push_back(0.f); c->stage_launches.push_back(0); }
+        c->stage_ms[i] += t; c->stage_launches[i] += 1;
+    }
+    const int n = (int)c->stage_names.size();
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; i++) { if (names) names[i] = c->stage_names[i].c_str(); if (ms) ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_launches[i]; }
+    return SSM_OK;
+}
+
+// ---------------------------------------------------------------- the ORB front end for nb frames already on the device
+static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_t* d_depth, int nb,
+                   ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp)
+{
+    const OrbGeom& g = c->g; hipStream_t s = c->stream;
+    prof_begin(c, "gray");      HIPCHK(c, k_gray(d_img, channels, nb, g, c->d_pyr, s)); prof_end(c);
+    prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(nb, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, s)); prof_end(c);
+    prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, s)); prof_end(c);
+    prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
+    prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
+    prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern, d_depth, c->cfg.camera, kps, desc, pos3d, nkp, s)); prof_end(c);
+    return SSM_OK;
+}
+
+extern "C" int ssm_orb_extract(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+                               ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipSetDevice(c->device);
+    if (!img || !kps || !desc || !n_out) FAIL(c, SSM_E_INVAL, "null argument");
+    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
+    if (channels != 1 && channels != 3) FAIL(c, SSM_E_INVAL, "channels must be 1 or 3");
+    if (stride < w * channels) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
+    const int ocap = c->g.cap;
+    size_t need = (size_t)ocap * (sizeof(ssm_keypoint) + 32 + 12) + 64;
+    int r = ensure_scratch(c, need); if (r) return r;
+    ssm_keypoint* dk = reinterpret_cast<ssm_keypoint*>(c->d_scratch);
+    uint8_t* dd = reinterpret_cast<uint8_t*>(dk + ocap);
+    float* dp = reinterpret_cast<float*>(dd + (size_t)ocap * 32);
+    int32_t* dn = reinterpret_cast<int32_t*>(dp + (size_t)ocap * 3);
+    HIPCHK(c, hipMemcpy2DAsync(c->d_in_img, (size_t)w * channels, img, stride, (size_t)w * channels, h, hipMemcpyHostToDevice, c->stream));
+    if (depth) HIPCHK(c, hipMemcpyAsync(c->d_in_depth, depth, (size_t)w * h * 2, hipMemcpyHostToDevice, c->stream));
+    r = run_orb(c, c->d_in_img, channels, depth ? c->d_in_depth : nullptr, 1, dk, dd, dp, dn); if (r) return r;
+    int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    r = check_device_flags(c); if (r) return r;
+    *n_out = n;
+    if (n > cap) FAIL(c, SSM_E_CAPACITY, "keypoint buffer too small (need " + std::to_string(n) + ")");
+    HIPCHK(c, hipMemcpy(kps, dk, sizeof(ssm_keypoint) * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(desc, dd, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (pos3d) HIPCHK(c, hipMemcpy(pos3d, dp, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return SSM_OK;
+}
+
+// ---------------------------------------------------------------- matcher, host pointers
+static int match_host(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, bool want_knn,
+                      int32_t* idx, int32_t* dist, ssm_dmatch* out, int cap, int* n_out)
+{
+    if (nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) FAIL(c, SSM_E_INVAL, "bad descriptor arguments");
+    if (nt < 2) FAIL(c, SSM_E_TOO_FEW_TRAIN, "knnMatch(k=2) needs at least 2 train descriptors");
+    if (nq == 0) { if (n_out) *n_out = 0; return SSM_OK; }
+    const size_t need = (size_t)(nq + nt) * 32 + sizeof(MatchPair) + (size_t)nq * (16 + 16) + 64;
+    int r = ensure_scratch(c, need); if (r) return r;
+    uint8_t* dd = reinterpret_cast<uint8_t*>(c->d_scratch);
+    ssm_dmatch* dm = reinterpret_cast<ssm_dmatch*>(dd + (size_t)(nq + nt) * 32);
+    int32_t* di = reinterpret_cast<int32_t*>(dm + nq); int32_t* ds = di + 2 * (size_t)nq;
+    MatchPair* dp = reinterpret_cast<MatchPair*>(ds + 2 * (size_t)nq); int32_t* dn = reinterpret_cast<int32_t*>(dp + 1);
+    MatchPair p; p.qoff = 0; p.nq = nq; p.toff = nq; p.nt = nt; p.out_slot = 0;
+    HIPCHK(c, hipMemcpyAsync(dd, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dd + (size_t)nq * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dp, &p, sizeof(p), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_match_pairs(dd, dp, 1, ratio, nq, dm, dn, want_knn ? di : nullptr, want_knn ? ds : nullptr, c->stream));
+    int n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (want_knn) {
+        HIPCHK(c, hipMemcpy(idx, di, (size_t)nq * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dist, ds, (size_t)nq * 8, hipMemcpyDeviceToHost));
+    } else {
+        *n_out = n;
+        if (n > cap) FAIL(c, SSM_E_CAPACITY, "match buffer too small (need " + std::to_string(n) + ")");
+        HIPCHK(c, hipMemcpy(out, dm, sizeof(ssm_dmatch) * n, hipMemcpyDeviceToHost));
+    }
+    return SSM_OK;
+}
+extern "C" int ssm_hamming_knn2(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (nq > 0 && (!idx || !dist)) FAIL(c, SSM_E_INVAL, "null output");
+    return match_host(c, q, nq, t, nt, c->cfg.knn_match_ratio, true, idx, dist, nullptr, 0, nullptr);
+}
+extern "C" int ssm_match(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, ssm_dmatch* out, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!n_out || (cap > 0 && !out)) FAIL(c, SSM_E_INVAL, "null output");
+    return match_host(c, q, nq, t, nt, ratio, false, nullptr, nullptr, out, cap, n_out);
+}
+
+// ---------------------------------------------------------------- mapper front half, host pointers
+extern "C" int ssm_moving_mask(ssm_ctx* c, const uint8_t* sem, int w, int h, int stride, uint8_t* mask)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!sem || !mask) FAIL(c, SSM_E_INVAL, "null argument");
+    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
+    if (stride < w * 3) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
+    HIPCHK(c, hipMemcpy2DAsync(c->d_in_sem, (size_t)w * 3, sem, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_moving_mask(c->d_in_sem, 1, w, h, c->d_mask, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mask, c->d_mask, (size_t)w * h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_backproject(ssm_ctx* c, const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, int w, int h,
+                               const ssm_camera* cam, const double* T, double max_distance, ssm_point* out, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!depth || !rgb || !sem || !cam || !n_out || (cap > 0 && !out)) FAIL(c, SSM_E_INVAL, "null argument");
+    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
+    const size_t np = (size_t)w * h;
+    HIPCHK(c, hipMemcpyAsync(c->d_in_depth, depth, np * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in_img, rgb, np * 3, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in_sem, sem, np * 3, hipMemcpyHostToDevice, c->stream));
+    if (T) HIPCHK(c, hipMemcpyAsync(c->d_in_pose, T, 128, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_moving_mask(c->d_in_sem, 1, w, h, c->d_mask, c->stream));
+    HIPCHK(c, k_backproject(c->d_in_depth, c->d_in_img, c->d_in_sem, c->d_mask, T ? c->d_in_pose : nullptr, 1, w, h, *cam, max_distance,
+                            c->d_chunk_cnt, c->d_chunk_off, reinterpret_cast<int32_t*>(c->d_total + 1), c->d_total, c->d_points, c->stream));
+    int64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_out = (int)total;
+    if (total > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(total) + ")");
+    HIPCHK(c, hipMemcpy(out, c->d_points, sizeof(ssm_point) * (size_t)total, hipMemcpyDeviceToHost));
+    return SSM_OK;
+}
+
+// ---------------------------------------------------------------- voxel map
+static int table_count(ssm_ctx* c, VoxTable& t, int* n)
+{
+    int32_t cnt[2];
+    HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (cnt[1]) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    *n = cnt[0];
+    return SSM_OK;
+}
+// sorts the table's voxels by key; leaves compact array + order in scratch2.  returns pointers
+static int table_sorted(ssm_ctx* c, VoxTable& t, int* n_out, ssm_voxel** compact, uint32_t** order)
+{
+    int n = 0; int r = table_count(c, t, &n); if (r) return r;
+    *n_out = n; *compact = nullptr; *order = nullptr;
+    if (n == 0) return SSM_OK;
+    size_t tmp_bytes = 0;
+    HIPCHK(c, voxel_sort_pairs(nullptr, &tmp_bytes, nullptr, n, nullptr, nullptr, nullptr, nullptr, c->stream));
+    const size_t a = ((size_t)n * sizeof(ssm_voxel) + 255) & ~(size_t)255, kb = ((size_t)n * 8 + 255) & ~(size_t)255, ib = ((size_t)n * 4 + 255) & ~(size_t)255;
+    r = ensure_scratch2(c, a + 2 * kb + 2 * ib + tmp_bytes + 512); if (r) return r;
+    uint8_t* p = reinterpret_cast<uint8_t*>(c->d_scratch2);
+    ssm_voxel* comp = reinterpret_cast<ssm_voxel*>(p); p += a;
+    uint64_t* ka = reinterpret_cast<uint64_t*>(p); p += kb; uint64_t* kbuf = reinterpret_cast<uint64_t*>(p); p += kb;
+    uint32_t* ia = reinterpret_cast<uint32_t*>(p); p += ib; uint32_t* ibuf = reinterpret_cast<uint32_t*>(p); p += ib;
+    int32_t* dn = reinterpret_cast<int32_t*>(p); p += 256;
+    HIPCHK(c, k_voxel_compact(t.tab, t.cap_log2, comp, dn, c->stream));
+    HIPCHK(c, voxel_sort_pairs(p, &tmp_bytes, comp, n, ka, kbuf, ia, ibuf, c->stream));
+    *compact = comp; *order = ibuf;
+    return SSM_OK;
+}
+static int table_export_points(ssm_ctx* c, VoxTable& t, ssm_point* out, int cap, int* n_out)
+{
+    int n; ssm_voxel* comp; uint32_t* order;
+    int r = table_sorted(c, t, &n, &comp, &order); if (r) return r;
+    *n_out = n;
+    if (n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(n) + ")");
+    if (n == 0) return SSM_OK;
+    r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
+    HIPCHK(c, k_voxel_gather_points(comp, order, n, reinterpret_cast<ssm_point*>(c->d_scratch), c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_map_clear(ssm_ctx* c)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || (n && !pts)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (n == 0) return SSM_OK;
+    int r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_scratch, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_voxel_insert(reinterpret_cast<ssm_point*>(c->d_scratch), nullptr, n, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_map_size(ssm_ctx* c, int* n)
+{
+    if (!c || !n) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    return table_count(c, c->map, n);
+}
+extern "C" int ssm_map_export(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    return table_export_points(c, c->map, out, cap, n_out);
+}
+extern "C" int ssm_map_export_table(ssm_ctx* c, ssm_voxel* out, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    int n; ssm_voxel* comp; uint32_t* order;
+    int r = table_sorted(c, c->map, &n, &comp, &order); if (r) return r;
+    *n_out = n;
+    if (n > cap) FAIL(c, SSM_E_CAPACITY, "table buffer too small (need " + std::to_string(n) + ")");
+    if (n == 0) return SSM_OK;
+    r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
+    HIPCHK(c, k_voxel_gather_table(comp, order, n, reinterpret_cast<ssm_voxel*>(c->d_scratch), c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)n * sizeof(ssm_voxel), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_map_merge_table(ssm_ctx* c, const ssm_voxel* tab, int n)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (n == 0) return SSM_OK;
+    int r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(c->d_scratch, tab, (size_t)n * sizeof(ssm_voxel), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_voxel_merge(reinterpret_cast<ssm_voxel*>(c->d_scratch), n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+static inline float ord2f(int i) { i = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; memcpy(&f, &i, 4); return f; }
+extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || (n && !pts) || !(leaf > 0)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    *n_out = 0;
+    if (n == 0) return SSM_OK;
+    int r;
+    if (!c->tmp.tab) { r = table_alloc(c, c->tmp, c->cfg.voxel_capacity_log2); if (r) return r; }
+    else HIPCHK(c, k_voxel_clear(c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+    r = ensure_scratch(c, (size_t)n * sizeof(ssm_point) + 64); if (r) return r;
+    ssm_point* dp = reinterpret_cast<ssm_point*>(c->d_scratch);
+    float* mm = reinterpret_cast<float*>(dp + n);
+    HIPCHK(c, hipMemcpyAsync(dp, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_voxel_bounds(dp, n, mm, c->stream));
+    int ord[6];
+    HIPCHK(c, hipMemcpyAsync(ord, mm, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // pcl::VoxelGrid::applyFilter overflow guard: (dx*dy*dz) > INT_MAX -> warning, output = input
+        const float inv = 1.0f / leaf;
+        const int64_t dx = (int64_t)((ord2f(ord[3]) - ord2f(ord[0])) * inv) + 1, dy = (int64_t)((ord2f(ord[4]) - ord2f(ord[1])) * inv) + 1,
+                      dz = (int64_t)((ord2f(ord[5]) - ord2f(ord[2])) * inv) + 1;
+        if (dx * dy * dz > (int64_t)2147483647) FAIL(c, SSM_E_VOXEL_RANGE, "leaf size too small for the cloud extent (PCL would return the input unfiltered)");
+    }
+    HIPCHK(c, k_voxel_insert(dp, nullptr, n, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+    return table_export_points(c, c->tmp, out, cap, n_out);
+}
+
+// ---------------------------------------------------------------- device-resident sequence path
+static int ensure_seq(ssm_ctx* c, int n)
+{
+    if (n <= c->seq_cap) return SSM_OK;
+    const OrbGeom& g = c->g; const int R = c->R;
+    // keep the history rows across the re-allocation
+    uint8_t* old_desc = c->d_desc_all; int32_t* old_nkp = c->d_nkp_all; const int old_prev = c->prev_n;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    void* olds[] = { c->d_kps, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints };
+    for (void* p : olds) if (p) hipFree(p);
+    c->d_kps = nullptr; c->d_pos3d = nullptr; c->d_matches = nullptr; c->d_nmatch = nullptr; c->d_npoints = nullptr;
+    DALLOC(c, c->d_kps, (size_t)n * g.cap); DALLOC(c, c->d_pos3d, (size_t)n * g.cap * 3);
+    DALLOC(c, c->d_matches, (size_t)n * R * g.cap); DALLOC(c, c->d_nmatch, (size_t)n * R); DALLOC(c, c->d_npoints, (size_t)n);
+    uint8_t* nd; int32_t* nn;
+    DALLOC(c, nd, (size_t)(n + R) * g.cap * 32); DALLOC(c, nn, (size_t)(n + R));
+    if (!c->d_hist_tmp) DALLOC(c, c->d_hist_tmp, (size_t)R * g.cap * 32 + (size_t)R * 4);
+    if (old_desc && old_prev >= 0) {
+        HIPCHK(c, hipMemcpy(nd, old_desc, (size_t)(old_prev + R) * g.cap * 32, hipMemcpyDeviceToDevice));
+        HIPCHK(c, hipMemcpy(nn, old_nkp, (size_t)(old_prev + R) * 4, hipMemcpyDeviceToDevice));
+    }
+    if (old_desc) hipFree(old_desc);
+    if (old_nkp) hipFree(old_nkp);
+    c->d_desc_all = nd; c->d_nkp_all = nn; c->seq_cap = n;
+    return SSM_OK;
+}
+extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out_dev* out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!in || in->n < 0) FAIL(c, SSM_E_INVAL, "bad arguments");
+    const int stages = in->stages ? in->stages : (SSM_STAGE_ORB | SSM_STAGE_MATCH | SSM_STAGE_MAP);
+    if ((stages & (SSM_STAGE_ORB | SSM_STAGE_MATCH)) && !in->bgr) FAIL(c, SSM_E_INVAL, "bgr is required");
+    if ((stages & SSM_STAGE_MAP) && (!in->depth || !in->sem_bgr || !in->bgr)) FAIL(c, SSM_E_INVAL, "bgr, depth and sem_bgr are required for the map stage");
+    const OrbGeom& g = c->g; const int R = c->R, n = in->n, W = g.W, H = g.H; hipStream_t s = c->stream;
+    const size_t npix = (size_t)W * H;
+    int r = ensure_seq(c, n > 0 ? n : 1); if (r) return r;
+    c->recs.clear(); c->pool_used = 0;
+    // history rows
+    const size_t row = (size_t)g.cap * 32;
+    if (in->continue_sequence && c->prev_n >= 0) {
+        int32_t* tn = reinterpret_cast<int32_t*>(c->d_hist_tmp + (size_t)R * row);
+        HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, c->d_desc_all + (size_t)c->prev_n * row, (size_t)R * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(tn, c->d_nkp_all + c->prev_n, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_desc_all, c->d_hist_tmp, (size_t)R * row, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_nkp_all, tn, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_nkp_all, 0xFF, (size_t)R * 4, s));     // -1: no such reference frame
+    }
+    uint8_t* desc = c->d_desc_all + (size_t)R * row; int32_t* nkp = c->d_nkp_all + R;
+    for (int f0 = 0; f0 < n; f0 += c->B) {
+        const int nb = (n - f0 < c->B) ? n - f0 : c->B;
+        if (stages & SSM_STAGE_ORB) {
+            r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
+                        c->d_kps + (size_t)f0 * g.cap, desc + (size_t)f0 * row, c->d_pos3d + (size_t)f0 * g.cap * 3, nkp + f0);
+            if (r) return r;
+        }
+        if (stages & SSM_STAGE_MATCH) {
+            prof_begin(c, "match");
+            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, s));
+            prof_end(c);
+        }
+        if (stages & SSM_STAGE_MAP) {
+            prof_begin(c, "mask");
+            HIPCHK(c, k_moving_mask(in->sem_bgr + (size_t)f0 * npix * 3, nb, W, H, c->d_mask, s)); prof_end(c);
+            prof_begin(c, "backproject");
+            HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3, c->d_mask,
+                                    in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                    c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
+            prof_begin(c, "voxel_insert");
+            HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nb * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
+            prof_end(c);
+        }
+    }
+    c->prev_n = n;
+    if (out) {
+        out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;
+        out->npoints = c->d_npoints; out->cap = g.cap; out->R = R;
+    }
+    return SSM_OK;
+}
+
+// ---------------------------------------------------------------- utilities
+extern "C" int ssm_dev_alloc(ssm_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
+    *out = p; return SSM_OK;
+}
+extern "C" int ssm_dev_free(ssm_ctx* c, void* p)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (p) HIPCHK(c, hipFree(p));
+    return SSM_OK;
+}
+extern "C" int ssm_memcpy_h2d(ssm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_memcpy_d2h(ssm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_synth_frames_dev(ssm_ctx* c, uint64_t seed, int first, int n, int w, int h,
+                                    uint8_t* bgr, uint16_t* depth, uint8_t* sem, uint8_t* lab, double* pose)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n <= 0 || !bgr || !depth || !sem) FAIL(c, SSM_E_INVAL, "bad arguments");
+    HIPCHK(c, k_synth(seed, first, n, w, h, bgr, depth, sem, lab, pose, c->stream));
+    return SSM_OK;
+}

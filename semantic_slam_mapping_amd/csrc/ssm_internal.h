@@ -1,0 +1,83 @@
+// ssm_internal.h -- shared between the translation units of libssm_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ssm_hip.h"
+
+#define SSM_MAX_LEVELS 12
+#define SSM_EDGE 19            // ORBextractor EDGE_THRESHOLD
+#define SSM_HALF_PATCH 15
+#define SSM_PATCH 31
+#define SSM_MAX_NODES 1024     // quad-tree nodes held in LDS per (frame, level)
+#define SSM_VOX_EMPTY ((int64_t)-1)
+
+struct LevelGeom {
+    int w, h, stride;          // level image; rows padded to a multiple of 4 bytes
+    int img_off;               // byte offset inside one frame's pyramid buffer (16-B aligned)
+    int nCols, nRows, wCell, hCell;   // FAST cell grid (ComputeKeyPointsOctTree, W = 30)
+    int cell_off;              // first flattened cell id of this level
+    int nfeat;                 // mnFeaturesPerLevel
+    int cand_off, cand_cap;    // entries inside one frame's candidate buffer
+    int sel_off, sel_cap;      // slots inside one frame's selected-keypoint staging (nfeat + 3)
+    int minBX, minBY, maxBX, maxBY;
+    int nIni;                  // quad-tree root nodes
+    float hX;                  // root node width
+    float sf;                  // mvScaleFactor[level]
+};
+struct OrbGeom {
+    int nlevels, W, H;
+    int pyr_bytes;             // one frame's pyramid (all levels)
+    int cells_total, cand_total, sel_total;
+    int cap;                   // output keypoints per frame (orb_features + 3*levels)
+    int ini_th, min_th;
+    int umax[SSM_HALF_PATCH + 1];
+    LevelGeom L[SSM_MAX_LEVELS];
+};
+// candidate: lo = x | y<<12 | score<<24 (x,y relative to minBorder), hi = rank (cell-major raster order)
+typedef uint2 cand_t;
+
+// ---- launchers (each enqueues on `s`; returns hipGetLastError()) ----
+hipError_t k_gray(const uint8_t* img, int channels, int n, const OrbGeom& g, uint8_t* pyr, hipStream_t s);
+hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g, uint8_t* pyr, hipStream_t s);
+hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
+                     const int32_t* const* yofs, const int16_t* const* ya, hipStream_t s);
+hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s);
+hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, hipStream_t s);
+hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, uint16_t* node_of,
+                    uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s);
+hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
+                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam,
+                      ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp, hipStream_t s);
+
+// matcher.  pair p: query = desc + qoff[p]*32 (nq[p] rows), train = desc + toff[p]*32 (nt[p] rows)
+struct MatchPair { int32_t qoff, nq, toff, nt, out_slot; };
+hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs, double ratio, int cap,
+                         ssm_dmatch* out, int32_t* nout, int32_t* knn_idx, int32_t* knn_dist, hipStream_t s);
+// as k_match_pairs but pair descriptors derived on the device from nkp[] (sequence mode)
+hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
+                       ssm_dmatch* out, int32_t* nout, hipStream_t s);
+
+// mapper front half
+hipError_t k_moving_mask(const uint8_t* sem, int n, int w, int h, uint8_t* mask, hipStream_t s);
+hipError_t k_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const uint8_t* mask,
+                         const double* pose, int n, int w, int h, ssm_camera cam, double max_distance,
+                         int32_t* chunk_cnt, int64_t* chunk_off, int32_t* npoints, int64_t* total,
+                         ssm_point* out, hipStream_t s);
+int backproject_chunks(int w, int h);
+
+// voxel table
+hipError_t k_voxel_clear(ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
+hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_max, float leaf, ssm_voxel* tab,
+                          int cap_log2, int32_t* counters, hipStream_t s);
+hipError_t k_voxel_merge(const ssm_voxel* src, int n, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
+hipError_t k_voxel_compact(const ssm_voxel* tab, int cap_log2, ssm_voxel* out, int32_t* n_out, hipStream_t s);
+hipError_t k_voxel_gather_points(const ssm_voxel* compact, const uint32_t* order, int n, ssm_point* out, hipStream_t s);
+hipError_t k_voxel_gather_table(const ssm_voxel* compact, const uint32_t* order, int n, ssm_voxel* out, hipStream_t s);
+hipError_t k_voxel_bounds(const ssm_point* pts, int n, float* minmax6, hipStream_t s);
+// sort n (key,index) pairs by key; tmp storage managed by caller via size query (tmp==nullptr)
+hipError_t voxel_sort_pairs(void* tmp, size_t* tmp_bytes, const ssm_voxel* compact, int n, uint64_t* keys_a, uint64_t* keys_b,
+                            uint32_t* idx_a, uint32_t* idx_b, hipStream_t s);
+
+// synthetic stream
+hipError_t k_synth(uint64_t seed, int first, int n, int w, int h, uint8_t* bgr, uint16_t* depth, uint8_t* sem,
+                   uint8_t* lab, double* pose, hipStream_t s);

@@ -1,0 +1,208 @@
+"""ctypes binding of the CPU oracle (oracle/libssm_oracle.so).  TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product path (api.py / _lib.py)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from .api import KEYPOINT_DTYPE, DMATCH_DTYPE, POINT_DTYPE, VOXEL_DTYPE
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+
+
+class Cam(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("cx", "cy", "fx", "fy", "scale")]
+
+
+class PipeCfg(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("nfeatures", C.c_int), ("nlevels", C.c_int), ("ini_th", C.c_int),
+                ("min_th", C.c_int), ("ref_frames", C.c_int), ("scale_factor", C.c_float), ("leaf", C.c_float),
+                ("ratio", C.c_double), ("max_distance", C.c_double), ("cam", Cam), ("seed", C.c_uint64)]
+
+
+class PipeStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("t_synth", "t_orb", "t_match", "t_mask", "t_backproject", "t_voxel")] + \
+               [(n, C.c_int64) for n in ("keypoints", "matches", "points", "voxels")] + [("checksum", C.c_uint64)]
+
+
+def build(native=False):
+    out = os.path.join(ORACLE_DIR, "libssm_oracle_native.so" if native else "libssm_oracle.so")
+    cmd = ["make", "-C", ORACLE_DIR] + (["NATIVE=1"] if native else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return out
+
+
+class Oracle:
+    def __init__(self, native=False):
+        path = os.path.join(ORACLE_DIR, "libssm_oracle_native.so" if native else "libssm_oracle.so")
+        if not os.path.exists(path):
+            build(native)
+        L = self.L = C.CDLL(path)
+        P, I = C.c_void_p, C.c_int
+        L.sso_orb_create.restype = P
+        L.sso_orb_create.argtypes = [I, C.c_float, I, I, I]
+        L.sso_orb_destroy.argtypes = [P]
+        L.sso_orb_set_pattern.argtypes = [P, P]
+        L.sso_orb_capacity.argtypes = [P]
+        L.sso_orb_extract.argtypes = [P, P, I, I, I, P, P]
+        L.sso_orb_level_size.argtypes = [P, I, I, I, C.POINTER(I), C.POINTER(I)]
+        L.sso_orb_level_image.restype = P
+        L.sso_orb_level_image.argtypes = [P, I, I]
+        L.sso_orb_level_candidates.argtypes = [P, I, P, I]
+        L.sso_orb_features_per_level.argtypes = [P, I]
+        L.sso_bgr2gray.argtypes = [P, I, I, I, P]
+        L.sso_resize_linear_u8.argtypes = [P, I, I, P, I, I]
+        L.sso_gaussian7.argtypes = [P, I, I, P]
+        L.sso_fast_score.argtypes = [P, I]
+        L.sso_fast_atan2.restype = C.c_float
+        L.sso_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.sso_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.sso_hamming_knn2.argtypes = [P, I, P, I, P, P]
+        L.sso_match.argtypes = [P, I, P, I, C.c_double, P]
+        L.sso_project2dTo3d.argtypes = [P, I, I, C.POINTER(Cam), I, I, P]
+        L.sso_moving_mask.argtypes = [P, I, I, P]
+        L.sso_label_of_bgr.argtypes = [C.c_uint8] * 3
+        L.sso_backproject.argtypes = [P, P, P, P, I, I, C.POINTER(Cam), P, C.c_double, P]
+        L.sso_voxel_key.restype = C.c_int64
+        L.sso_voxel_key.argtypes = [C.c_float] * 4
+        L.sso_voxel_accumulate.argtypes = [P, I, C.c_float, P, I, I]
+        L.sso_voxel_merge.argtypes = [P, I, I, P, I]
+        L.sso_voxel_export.argtypes = [P, I, P]
+        L.sso_voxel_filter.argtypes = [P, I, C.c_float, P, I]
+        L.sso_synth_frame.argtypes = [C.c_uint64, I, I, I, P, P, P, P]
+        L.sso_synth_pose.argtypes = [I, P]
+        L.sso_pipeline_run.argtypes = [C.POINTER(PipeCfg), I, I, C.POINTER(PipeStats)]
+
+    # ---- synthetic stream
+    def synth_frame(self, seed, fid, w=640, h=480):
+        bgr = np.zeros((h, w, 3), np.uint8); dep = np.zeros((h, w), np.uint16)
+        sem = np.zeros((h, w, 3), np.uint8); lab = np.zeros((h, w), np.uint8)
+        self.L.sso_synth_frame(seed, fid, w, h, bgr.ctypes.data, dep.ctypes.data, sem.ctypes.data, lab.ctypes.data)
+        T = np.zeros(16, np.float64)
+        self.L.sso_synth_pose(fid, T.ctypes.data)
+        return bgr, dep, sem, lab, T.reshape(4, 4).T.copy()   # row-major 4x4
+
+    # ---- ORB
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8); h, w = bgr.shape[:2]
+        g = np.zeros((h, w), np.uint8)
+        self.L.sso_bgr2gray(bgr.ctypes.data, w, h, bgr.strides[0], g.ctypes.data)
+        return g
+
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8); sh, sw = src.shape
+        d = np.zeros((dh, dw), np.uint8)
+        self.L.sso_resize_linear_u8(src.ctypes.data, sw, sh, d.ctypes.data, dw, dh)
+        return d
+
+    def gaussian7(self, src):
+        src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+        d = np.zeros((h, w), np.uint8)
+        self.L.sso_gaussian7(src.ctypes.data, w, h, d.ctypes.data)
+        return d
+
+    def orb_extract(self, gray, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7, pattern=None, want_stages=False):
+        gray = np.ascontiguousarray(gray, np.uint8); h, w = gray.shape
+        o = self.L.sso_orb_create(nfeatures, scale, nlevels, ini, mn)
+        if not o:
+            raise ValueError("sso_orb_create failed")
+        try:
+            if pattern is not None:
+                p = np.ascontiguousarray(pattern, np.int8); self.L.sso_orb_set_pattern(o, p.ctypes.data)
+            cap = self.L.sso_orb_capacity(o)
+            kps = np.zeros(cap, KEYPOINT_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+            n = self.L.sso_orb_extract(o, gray.ctypes.data, w, h, gray.strides[0], kps.ctypes.data, desc.ctypes.data)
+            if n < 0:
+                raise ValueError("image too small for the pyramid")
+            if not want_stages:
+                return kps[:n].copy(), desc[:n].copy()
+            stages = []
+            for l in range(nlevels):
+                lw, lh = C.c_int(), C.c_int()
+                self.L.sso_orb_level_size(o, w, h, l, C.byref(lw), C.byref(lh))
+                sz = lw.value * lh.value
+                img = np.ctypeslib.as_array(C.cast(self.L.sso_orb_level_image(o, l, 0), C.POINTER(C.c_uint8)), (sz,)).reshape(lh.value, lw.value).copy()
+                blur = np.ctypeslib.as_array(C.cast(self.L.sso_orb_level_image(o, l, 1), C.POINTER(C.c_uint8)), (sz,)).reshape(lh.value, lw.value).copy()
+                nc = self.L.sso_orb_level_candidates(o, l, None, 0)
+                c = np.zeros((max(nc, 1), 3), np.int32)
+                self.L.sso_orb_level_candidates(o, l, c.ctypes.data, nc)
+                stages.append({"img": img, "blur": blur, "cand": c[:nc], "nfeat": self.L.sso_orb_features_per_level(o, l)})
+            return kps[:n].copy(), desc[:n].copy(), stages
+        finally:
+            self.L.sso_orb_destroy(o)
+
+    def project2dTo3d(self, depth, cam, u, v):
+        depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+        out = np.zeros(3, np.float32); c = Cam(*cam)
+        self.L.sso_project2dTo3d(depth.ctypes.data, w, h, C.byref(c), int(u), int(v), out.ctypes.data)
+        return out
+
+    # ---- matcher
+    def knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+        rc = self.L.sso_hamming_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, dist.ctypes.data)
+        if rc < 0:
+            raise ValueError("needs >= 2 train descriptors")
+        return idx, dist
+
+    def match(self, q, t, ratio=0.8):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(q), 1), DMATCH_DTYPE)
+        n = self.L.sso_match(q.ctypes.data, len(q), t.ctypes.data, len(t), ratio, out.ctypes.data)
+        if n < 0:
+            raise ValueError("needs >= 2 train descriptors")
+        return out[:n].copy()
+
+    # ---- mapper
+    def moving_mask(self, sem):
+        sem = np.ascontiguousarray(sem, np.uint8); h, w = sem.shape[:2]
+        m = np.zeros((h, w), np.uint8)
+        self.L.sso_moving_mask(sem.ctypes.data, w, h, m.ctypes.data)
+        return m
+
+    def backproject(self, depth, rgb, sem, mask, cam, T=None, max_distance=40.0):
+        depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+        rgb = np.ascontiguousarray(rgb, np.uint8); sem = np.ascontiguousarray(sem, np.uint8); mask = np.ascontiguousarray(mask, np.uint8)
+        out = np.zeros(w * h, POINT_DTYPE); c = Cam(*cam)
+        Tc = None if T is None else np.ascontiguousarray(np.asarray(T, np.float64).reshape(4, 4).T)
+        n = self.L.sso_backproject(depth.ctypes.data, rgb.ctypes.data, sem.ctypes.data, mask.ctypes.data, w, h, C.byref(c),
+                                   Tc.ctypes.data if Tc is not None else None, max_distance, out.ctypes.data)
+        return out[:n].copy()
+
+    def voxel_filter(self, pts, leaf):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        out = np.zeros(max(len(pts), 1), POINT_DTYPE)
+        n = self.L.sso_voxel_filter(pts.ctypes.data, len(pts), leaf, out.ctypes.data, len(out))
+        if n < 0:
+            raise ValueError(f"sso_voxel_filter: {n}")
+        return out[:n].copy()
+
+    def voxel_table(self, pts, leaf, cap=None):
+        pts = np.ascontiguousarray(pts, POINT_DTYPE)
+        tab = np.zeros(cap or max(len(pts), 1), VOXEL_DTYPE)
+        m = self.L.sso_voxel_accumulate(pts.ctypes.data, len(pts), leaf, tab.ctypes.data, 0, len(tab))
+        if m < 0:
+            raise ValueError("capacity")
+        return tab[:m].copy()
+
+    def voxel_merge(self, a, b):
+        out = np.zeros(len(a) + len(b) + 1, VOXEL_DTYPE); out[:len(a)] = a
+        b = np.ascontiguousarray(b, VOXEL_DTYPE)
+        m = self.L.sso_voxel_merge(out.ctypes.data, len(a), len(out), b.ctypes.data, len(b))
+        return out[:m].copy()
+
+    def voxel_export(self, tab):
+        tab = np.ascontiguousarray(tab, VOXEL_DTYPE)
+        out = np.zeros(max(len(tab), 1), POINT_DTYPE)
+        self.L.sso_voxel_export(tab.ctypes.data, len(tab), out.ctypes.data)
+        return out[:len(tab)].copy()
+
+    def pipeline(self, first, count, w=640, h=480, nfeatures=1000, nlevels=8, ini=20, mn=7, ref_frames=5, scale=1.2,
+                 leaf=0.1, ratio=0.8, max_distance=40.0, cam=(318.6, 255.3, 517.3, 516.5, 1000.0), seed=0x5EED0000):
+        cfg = PipeCfg(w, h, nfeatures, nlevels, ini, mn, ref_frames, scale, leaf, ratio, max_distance, Cam(*cam), seed)
+        st = PipeStats()
+        rc = self.L.sso_pipeline_run(C.byref(cfg), first, count, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"sso_pipeline_run: {rc}")
+        return {n: getattr(st, n) for n, _ in PipeStats._fields_}
