@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the per-frame semantic-mapping front end on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch = the configs[1] stream: 1000 synthetic 640x480 RGB-D frames with
+precomputed 12-class masks, ORB 1000 kp/frame, match against the 5 preceding frames, moving mask, gated
+back-projection with the frame pose, voxel fusion (leaf 0.1 m) and the export of the fused map.  Inputs are generated
+on the device before the timed region (resident in HBM).  N>1: every rank processes its own 1000-frame block (weak
+scaling) and the per-GPU voxel tables are merged with one all-gather (RCCL) inside the step.
+
+Prints ONE JSON line on rank 0.  cpu_baseline = the CPU oracle (oracle/, kind "port") timed on a bounded sample of
+the same stream on the host cores of this box (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
+SEED = 0x5EED0000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+VALU_LANEOPS_PEAK = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def algorithmic_bytes(stage, P, nkp):
+    """ALGORITHMIC HBM bytes per FRAME of each stage, P = emitted points of the frame"""
+    px, pyr = W * H, 950532
+    return {
+        "gray": 3 * px + px,                       # R bgr + W gray                               1.229 MB
+        "pyramid": 926546 + 643332,                # each level from the previous                 1.570 MB
+        "fast": pyr + nkp * 8,                     # R pyramid (+ candidate list)                 0.951 MB
+        "octree": nkp * 8 * 2,                     # candidate list re-read (tiny)
+        "blur": 2 * pyr,                           # R + W                                        1.901 MB
+        "describe": nkp * (32 + 28 + 12),          # descriptors + keypoints + 3-D positions      0.072 MB
+        "mask": 3 * px + px,                       # R semantic + W mask (1.843 MB with the dilate passes in LDS)
+        "backproject": (2 + 3 + 3 + 1) * px + 32 * P,   # R depth,rgb,sem,mask + W points         2.765 MB + 32 P
+        "voxel_insert": 32 * P + 32 * P,           # R points + table update                      64 P
+    }.get(stage, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (configs[1]: 1000)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSM_BATCH", "125")), help="frames per batched launch")
+    ap.add_argument("--leaf", type=float, default=0.1)
+    ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import semantic_slam_mapping_amd as ssm
+    from semantic_slam_mapping_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    F = args.frames
+    ctx = ssm.Context(local_rank, orb_features=1000, max_batch=args.batch, voxel_capacity_log2=20,
+                      mapper_resolution=args.leaf, camera=CAM)
+    # ---- inputs resident in HBM: this rank's block of the stream (weak scaling: F frames per rank)
+    first = rank * F
+    bgr = torch.empty(F * H * W * 3, dtype=torch.uint8, device=dev)
+    dep = torch.empty(F * H * W, dtype=torch.int16, device=dev)
+    sem = torch.empty(F * H * W * 3, dtype=torch.uint8, device=dev)
+    pose = torch.empty(F * 16, dtype=torch.float64, device=dev)
+    ctx.synth_frames_dev(SEED, first, F, bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr())
+    ctx.sync()
+    tab_cap = 1 << 20
+    tab_buf = torch.empty(tab_cap * sharding.VOXEL_BYTES, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.map_clear()
+        out = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr(), F)
+        if world > 1:       # merge the per-GPU voxel maps: one all-gather of the key-sorted tables
+            n_local = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
+            for r, (t, n) in enumerate(sharding.allgather_tables(tab_buf, n_local, dist, dev)):
+                if r != rank:
+                    ctx.map_merge_table_dev(t.data_ptr(), n)
+            torch.cuda.synchronize()
+        n_vox = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)      # sorted fused map (sync)
+        return out, n_vox
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    stage_acc = {}
+    for _ in range(args.steps):
+        out, n_vox = step()
+        for k, (ms, ln) in ctx.stage_times().items():       # hipEvents on the context stream, this step
+            a = stage_acc.setdefault(k, [0.0, 0])
+            a[0] += ms; a[1] += ln
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    res = ctx.seq_fetch(out, F)
+    P_total = int(res["npoints"].sum()); kp_total = int(res["nkp"].sum())
+    m = res["nmatch"]; match_total = int(m[m > 0].sum())
+    if rank == 0:
+        frames_total = world * F * args.steps
+        value = frames_total / dt
+        P = P_total / F; nkp = kp_total / F
+        # dominant kernel and its roofline
+        per_stage = {k: (v[0] / max(v[1], 1), v[0] / args.steps / F * 1e3) for k, v in stage_acc.items()}   # ms/launch-group, us/frame
+        nb = -(-F // args.batch)
+        dom = max(stage_acc, key=lambda k: stage_acc[k][0])
+        launches_per_step = stage_acc[dom][1] / args.steps
+        ms_per_launch = stage_acc[dom][0] / max(stage_acc[dom][1], 1)
+        frames_per_launch = F / launches_per_step
+        if dom == "match":
+            pairs = sum(max(int(res["nkp"][f - 5 + r]), 0) * int(res["nkp"][f]) for f in range(F) for r in range(5) if f - 5 + r >= 0) / F
+            ach = pairs * 24 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12      # 8 x (xor + bcnt + add) lane-ops per pair
+            roof = {"bound": "valu_int", "kernel": "match_seq_kernel", "achieved": round(ach, 3), "peak": VALU_LANEOPS_PEAK / 1e12,
+                    "unit": "Tlaneop/s", "frac": round(ach / (VALU_LANEOPS_PEAK / 1e12), 4), "traffic": None}
+        else:
+            gb = algorithmic_bytes(dom, P, nkp) * frames_per_launch / 1e9
+            ach = gb / (ms_per_launch * 1e-3)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
+        cpu = None
+        if world == 1 and not args.no_cpu and args.cpu_frames > 0:
+            from semantic_slam_mapping_amd.oracle_binding import Oracle, build
+            try:
+                build(native=True); orc = Oracle(native=True)
+            except Exception:
+                orc = Oracle()
+            st = orc.pipeline(0, args.cpu_frames, nfeatures=1000, leaf=np.float32(args.leaf))
+            tcpu = st["t_orb"] + st["t_match"] + st["t_mask"] + st["t_backproject"] + st["t_voxel"]
+            cpu = {"value": round(args.cpu_frames / tcpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": f"first {args.cpu_frames} frames of the same stream, oracle/ (C, -O3 -march=native, 1 thread), synth excluded",
+                   "ms_per_frame": {k[2:]: round(st[k] / args.cpu_frames * 1e3, 3) for k in ("t_orb", "t_match", "t_mask", "t_backproject", "t_voxel")}}
+        line = {
+            "metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 640x480 RGB-D + precomputed 12-class masks, 1k frames per GPU, ORB 1000 kp/frame, "
+                                   "5 ref frames, leaf %.2f m" % args.leaf,
+                       "frames_per_gpu": F, "batch_frames": args.batch, "parallelism": "frame-block x%d + voxel-table all-gather" % world if world > 1 else "single GPU"},
+            "mpoints_per_s": round(world * P_total * args.steps / dt / 1e6, 2),
+            "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,10 @@ int ssm_map_size(ssm_ctx* ctx, int* n_voxels);
 int ssm_map_export(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);         /* centroids sorted by voxel index */
 int ssm_map_export_table(ssm_ctx* ctx, ssm_voxel* out, int cap, int* n_out);   /* key-sorted table, for merging */
 int ssm_map_merge_table(ssm_ctx* ctx, const ssm_voxel* tab, int n);            /* add another rank's table */
+/* same two with DEVICE buffers (the RCCL all-gather of per-GPU tables works on device memory); export is synchronous
+ * (it needs the voxel count on the host), merge is enqueued on the context stream */
+int ssm_map_export_table_dev(ssm_ctx* ctx, ssm_voxel* out_dev, int cap, int* n_out);
+int ssm_map_merge_table_dev(ssm_ctx* ctx, const ssm_voxel* tab_dev, int n);
 
 /* ---- device-resident batched path (the benchmarked one): n frames of a sequence, packed, all DEVICE pointers.
  * Runs detectFeatures for every frame, match(ref, cur) against the <= tracker_ref_frames preceding frames (the

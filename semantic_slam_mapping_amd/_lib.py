@@ -56,6 +56,8 @@ SYMBOLS = {
     "ssm_map_export": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_export_table": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_merge_table": (_I, [_P, _P, _I]),
+    "ssm_map_export_table_dev": (_I, [_P, _P, _I, C.POINTER(_I)]),
+    "ssm_map_merge_table_dev": (_I, [_P, _P, _I]),
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
     "ssm_set_profiling": (_I, [_P, _I]),
     "ssm_get_stage_times": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I)]),

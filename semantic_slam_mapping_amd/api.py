@@ -167,6 +167,14 @@ class Context:
         tab = np.ascontiguousarray(tab, VOXEL_DTYPE)
         self._chk(self.lib.ssm_map_merge_table(self.h, _ptr(tab), len(tab)))
 
+    def map_export_table_dev(self, dptr, cap):
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_map_export_table_dev(self.h, dptr, cap, C.byref(n)))
+        return n.value
+
+    def map_merge_table_dev(self, dptr, n):
+        self._chk(self.lib.ssm_map_merge_table_dev(self.h, dptr, n))
+
     # ---- device-resident sequence path
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

@@ -528,6 +528,28 @@ extern "C" int ssm_map_merge_table(ssm_ctx* c, const ssm_voxel* tab, int n)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SSM_OK;
 }
+extern "C" int ssm_map_export_table_dev(ssm_ctx* c, ssm_voxel* out, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    int n; ssm_voxel* comp; uint32_t* order;
+    int r = table_sorted(c, c->map, &n, &comp, &order); if (r) return r;
+    *n_out = n;
+    if (n > cap) FAIL(c, SSM_E_CAPACITY, "table buffer too small (need " + std::to_string(n) + ")");
+    if (n == 0) return SSM_OK;
+    if (!out) FAIL(c, SSM_E_INVAL, "null output");
+    HIPCHK(c, k_voxel_gather_table(comp, order, n, out, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_map_merge_table_dev(ssm_ctx* c, const ssm_voxel* tab, int n)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    HIPCHK(c, k_voxel_merge(tab, n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    return SSM_OK;
+}
 static inline float ord2f(int i) { i = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; memcpy(&f, &i, 4); return f; }
 extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out)
 {

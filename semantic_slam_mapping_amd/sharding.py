@@ -1,0 +1,56 @@
+"""Frame sharding across GPUs and the voxel-map merge (BASELINE.json configs[4]).
+
+The reference is single-process; this is the one place a collective exists.  Frames of a sequence are split into
+contiguous blocks, one per rank (each rank's matcher then only needs a tracker_ref_frames halo at its block start);
+every rank fuses its own frames into its own voxel table; ONE all-gather of the key-sorted tables (counts first, then
+tables padded to the longest) merges them.  Tables hold exact integer sums, so the merged map is bit-identical to the
+single-GPU map whatever the rank order.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" runs the same code on CPU
+tensors for the world_size-2 tests.
+"""
+import numpy as np
+
+VOXEL_BYTES = 112
+
+
+def frame_block(n_frames, rank, world):
+    """contiguous block [lo, hi) of rank; earlier ranks take the remainder"""
+    base, rem = divmod(n_frames, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_tables(local_table_u8, n_local, dist, device):
+    """local_table_u8: torch.uint8 tensor [cap*112] on `device` holding n_local voxels.
+    Returns (list of (tensor, n) for every rank) after one count all-gather and one padded table all-gather."""
+    import torch
+    world = dist.get_world_size()
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    mx = max(max(counts), 1)
+    send = torch.zeros(mx * VOXEL_BYTES, dtype=torch.uint8, device=device)
+    send[: n_local * VOXEL_BYTES] = local_table_u8[: n_local * VOXEL_BYTES]
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)      # the merge runs on the context's own HIP stream
+    return [(recv[r], counts[r]) for r in range(world)]
+
+
+def merge_tables_numpy(tables):
+    """CPU merge of key-sorted voxel tables (numpy structured arrays, VOXEL_DTYPE): used by the gloo tests as the
+    checker of the device merge; exact integer sums, so order does not matter."""
+    from .api import VOXEL_DTYPE
+    allv = np.concatenate([np.asarray(t, VOXEL_DTYPE) for t in tables]) if tables else np.zeros(0, VOXEL_DTYPE)
+    if len(allv) == 0:
+        return allv
+    order = np.argsort(allv["key"], kind="stable")
+    allv = allv[order]
+    keys, start = np.unique(allv["key"], return_index=True)
+    out = np.zeros(len(keys), VOXEL_DTYPE)
+    out["key"] = keys
+    for f in ("sx", "sy", "sz", "sr", "sg", "sb", "n"):
+        out[f] = np.add.reduceat(allv[f], start)
+    out["hist"] = np.add.reduceat(allv["hist"], start, axis=0)
+    return out

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Mints the committed golden fixtures under tests/golden/ from the independent numpy/Python restatement in pyref.py
+(NOT from the C oracle and NOT from the HIP path).  The reference ships no test vectors, so these are
+the pins of the CPU oracle; the palette fixture is cross-checked against /root/reference/000000.png when present.
+Run:  python tests/golden/make_golden.py        (about a minute; pure-Python ORB on a small image)"""
+import json
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import pyref  # noqa: E402
+
+CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
+
+
+def pattern_from_inc():
+    import re
+    t = open(os.path.join(HERE, "..", "..", "oracle", "orb_pattern.inc")).read()
+    t = t[t.index("*/") + 2:]
+    return [int(x) for x in re.findall(r"-?\d+", t)]
+
+
+def g_matcher():
+    out = {}
+    rng = np.random.default_rng(1234)
+    for name, nq, nt in (("n2", 2, 2), ("n3", 3, 3), ("n64", 64, 64), ("n1000", 1000, 1000)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nq >= 64:      # engineered structure: duplicates, exact copies (d0 = 0), near copies, all-equal rows
+            t[5] = t[4]; t[40] = t[4]; q[0] = t[4]; q[1] = t[40]
+            q[2] = t[7]; q[2, 0] ^= 1
+            q[3] = 0; t[10] = 0; t[11] = 0; t[12] = 255
+        idx, dist = pyref.knn2(q, t)
+        m = pyref.match(q, t, 0.8)
+        out[name + "_q"] = q; out[name + "_t"] = t; out[name + "_idx"] = idx; out[name + "_dist"] = dist
+        out[name + "_match"] = np.array([(a, b, c, d) for a, b, c, d in m], np.float64).reshape(-1, 4)
+    lut = np.array([[pyref.ratio_keep(d0, d1, 0.8) for d1 in range(257)] for d0 in range(257)], np.uint8)
+    out["ratio_lut_0p8"] = np.packbits(lut)
+    np.savez_compressed(os.path.join(HERE, "matcher.npz"), **out)
+
+
+def synth_small(rng, h, w):
+    img = rng.integers(90, 140, (h, w, 3)).astype(np.uint8)
+    img = (img // 8 * 8).astype(np.uint8)
+    for _ in range(60):
+        x0, y0 = rng.integers(0, w - 8), rng.integers(0, h - 8)
+        ww, hh = rng.integers(4, 25), rng.integers(4, 25)
+        img[y0:y0 + hh, x0:x0 + ww] = rng.integers(0, 256, 3)
+    return img
+
+
+def g_mapper():
+    rng = np.random.default_rng(77)
+    h, w = 24, 32
+    depth = rng.integers(300, 3000, (h, w)).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.1] = 0
+    depth[3, 3] = 50000
+    cls = rng.integers(0, 12, (h // 4, w // 4))
+    sem = np.array(pyref.PALETTE_BGR, np.uint8)[np.kron(cls, np.ones((4, 4), int))]
+    sem[0, 0] = (1, 2, 3)
+    rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    a = 0.4
+    T = [[np.cos(a), 0, np.sin(a), 0.5], [0, 1, 0, -0.25], [-np.sin(a), 0, np.cos(a), 2.0], [0, 0, 0, 1]]
+    mask = pyref.moving_mask(sem)
+    cam = (15.5, 11.5, 30.0, 31.0, 1000.0)
+    pts = pyref.backproject(depth, rgb, sem, mask, cam, T, 2.5)
+    pts0 = pyref.backproject(depth, rgb, sem, mask, cam, None, 40.0)
+    vox = pyref.voxel_filter(pts0, 0.1)
+    vox2 = pyref.voxel_filter(pts, 0.05)
+    arr = lambda p: np.array([(float(x), float(y), float(z), b, g, r, l) for x, y, z, b, g, r, l in p], np.float64).reshape(-1, 7)
+    np.savez_compressed(os.path.join(HERE, "mapper.npz"), depth=depth, sem=sem, rgb=rgb, T=np.array(T, np.float64), cam=np.array(cam),
+                        mask=mask, pts_T_2p5=arr(pts), pts_cam_40=arr(pts0), vox_cam_0p1=arr(vox), vox_T_0p05=arr(vox2))
+
+
+def g_orb():
+    rng = np.random.default_rng(2024)
+    bgr = synth_small(rng, 150, 180)
+    gray = pyref.bgr2gray(bgr)
+    pat = pattern_from_inc()
+    kps, desc = pyref.orb_extract(gray, 120, 1.2, 3, 20, 7, pat)
+    small = pyref.resize_linear(gray, 150, 125)
+    blur = pyref.gaussian7(gray)
+    S = np.array([[pyref.fast_S(gray, x, y) for x in range(3, 60)] for y in range(3, 40)], np.int32)
+    ang_in = rng.integers(-40000, 40000, (200, 2)).astype(np.float32)
+    ang_in[:4] = [[0, 0], [0, 5], [-3, 0], [7, 7]]
+    ang = np.array([pyref.fast_atan2(y, x) for y, x in ang_in], np.float32)
+    sc_in = rng.uniform(0, 6.3, 300).astype(np.float32)
+    sc = np.array([pyref.contract_sincos(a) for a in sc_in], np.float32)
+    np.savez_compressed(os.path.join(HERE, "orb.npz"), bgr=bgr, gray=gray, resized_150x125=small, blur=blur, fast_S_3_3=S,
+                        kps=np.array([[float(v) for v in k] for k in kps], np.float64).reshape(-1, 7), desc=desc,
+                        atan2_in=ang_in, atan2_out=ang, sincos_in=sc_in, sincos_out=sc,
+                        taps=np.array(pyref.gaussian_taps()), umax=np.array(pyref.umax_table()),
+                        feat_1000_8=np.array(pyref.level_params(1000, 1.2, 8)[2]), feat_2000_8=np.array(pyref.level_params(2000, 1.2, 8)[2]))
+
+
+def g_palette():
+    info = {"palette_bgr": pyref.PALETTE_BGR, "source": "src/mapper.cpp:42-54 comments; SegNet driving_webdemo id order"}
+    ref_png = "/root/reference/000000.png"
+    if os.path.exists(ref_png):
+        from PIL import Image
+        im = np.array(Image.open(ref_png).convert("RGB"))
+        cols = sorted({(int(c[2]), int(c[1]), int(c[0])) for c in np.unique(im.reshape(-1, 3), axis=0)})
+        info["colours_in_reference_000000_png_bgr"] = cols
+        info["all_png_colours_in_palette"] = all(tuple(c) in [tuple(p) for p in pyref.PALETTE_BGR] for c in cols)
+    json.dump(info, open(os.path.join(HERE, "palette.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    g_palette(); g_matcher(); g_mapper(); g_orb()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,64 @@
+"""N>1 path on CPU: world_size 2 over gloo.  Each rank fuses its contiguous block of frames into a voxel table (the CPU
+oracle stands in for the device kernels here -- this test is about the sharding + all-gather + merge logic, the
+device merge kernel is covered by tests/test_gpu_parity.py), the tables are exchanged with the same
+sharding.allgather_tables() bench.py uses, and every rank must end with the bit-identical single-process map."""
+import os
+import socket
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
+N_FRAMES = 5
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from semantic_slam_mapping_amd import sharding, VOXEL_DTYPE
+    from semantic_slam_mapping_amd.oracle_binding import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = Oracle()
+        lo, hi = sharding.frame_block(N_FRAMES, rank, world)
+        clouds = []
+        for f in range(lo, hi):
+            bgr, dep, sem, _, T = orc.synth_frame(0x5EED0000, f, 160, 120)
+            clouds.append(orc.backproject(dep, bgr, sem, orc.moving_mask(sem), CAM, T, 40.0))
+        tab = orc.voxel_table(np.concatenate(clouds), np.float32(0.05))
+        dev = torch.device("cpu")
+        buf = torch.from_numpy(tab.view(np.uint8).copy())
+        got = sharding.allgather_tables(buf, len(tab), dist, dev)
+        tabs = [np.frombuffer(t.numpy().tobytes(), VOXEL_DTYPE)[:n] for t, n in got]
+        merged = sharding.merge_tables_numpy(tabs)
+        q.put((rank, lo, hi, [len(t) for t in tabs], merged.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_merge_equals_single_process(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    clouds = []
+    for f in range(N_FRAMES):
+        bgr, dep, sem, _, T = oracle.synth_frame(0x5EED0000, f, 160, 120)
+        clouds.append(oracle.backproject(dep, bgr, sem, oracle.moving_mask(sem), CAM, T, 40.0))
+    single = oracle.voxel_table(np.concatenate(clouds), np.float32(0.05))
+    assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 3, 3, 5)
+    assert res[0][3] == res[1][3] and len(single) > 100
+    assert res[0][4] == single.tobytes() and res[1][4] == single.tobytes()
