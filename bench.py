@@ -39,6 +39,7 @@ def algorithmic_bytes(stage, P, nkp):
         "mask": 3 * px + px,                       # R semantic + W mask (1.843 MB with the dilate passes in LDS)
         "backproject": (2 + 3 + 3 + 1) * px + 32 * P,   # R depth,rgb,sem,mask + W points         2.765 MB + 32 P
         "voxel_insert": 32 * P + 32 * P,           # R points + table update                      64 P
+        "map_fuse": (2 + 3 + 3) * px,              # fused K10+K11+K12: R depth, rgb, semantic once; points stay on chip
     }.get(stage, 0)
 
 

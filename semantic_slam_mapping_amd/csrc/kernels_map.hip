@@ -320,6 +320,173 @@ hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_
     vox_insert_kernel<<<(int)blocks, 256, 0, s>>>(pts, n_dev, n_max, 1.0f / leaf, tab, cap_log2, counters);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------ K10+K11+K12 fused (sequence path)
+// One block per 64x32-pixel tile of one frame: class flags + 2-px apron in LDS -> 5x5 dilate -> per pixel gates,
+// unprojection, pose transform, voxel key, 2^-24 quantisation -> wave run-reduction along the row -> tile-local LDS hash
+// (<= 256 voxels) -> one flush of global atomics per (tile, voxel).  The point list of generatePointCloud is never
+// written: exact integer sums make the map independent of order, so the result is bit-identical to
+// mask -> backproject -> insert (tests/test_gpu_parity.py::test_seq_process_matches_oracle_per_frame).
+#define MF_W 64
+#define MF_H 32
+#define MF_SLOTS 256
+struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
+
+__device__ __forceinline__ uint32_t label_of_bgr(int sb, int sg, int sr)
+{
+    switch ((sb << 16) | (sg << 8) | sr) {
+        case (128 << 16) | (128 << 8) | 128: return 0;   case (0 << 16) | (0 << 8) | 128: return 1;
+        case (128 << 16) | (192 << 8) | 192: return 2;   case (0 << 16) | (69 << 8) | 255: return 3;
+        case (128 << 16) | (64 << 8) | 128: return 4;    case (222 << 16) | (40 << 8) | 60: return 5;
+        case (0 << 16) | (128 << 8) | 128: return 6;     case (128 << 16) | (128 << 8) | 192: return 7;
+        case (128 << 16) | (64 << 8) | 64: return 8;     case (128 << 16) | (0 << 8) | 64: return 9;
+        case (0 << 16) | (64 << 8) | 64: return 10;      case (192 << 16) | (128 << 8) | 0: return 11;
+    }
+    return 255;
+}
+__global__ void __launch_bounds__(256)
+map_fuse_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
+                const double* __restrict__ pose, int w, int h, int tiles_x, ssm_camera cam, double maxd, float inv_leaf,
+                ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints)
+{
+    __shared__ uint8_t m0[MF_H + 4][MF_W + 4];
+    __shared__ uint8_t mh[MF_H + 4][MF_W];
+    __shared__ LdsVox lt[MF_SLOTS];
+    __shared__ int s_npts;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tx0 = (blockIdx.x % tiles_x) * MF_W, ty0 = (blockIdx.x / tiles_x) * MF_H;
+    const size_t fo = (size_t)blockIdx.y * w * h;
+    const uint8_t* S = sem + fo * 3;
+    for (int i = tid; i < MF_SLOTS; i += 256) {
+        lt[i].key = SSM_VOX_EMPTY; lt[i].sx = 0; lt[i].sy = 0; lt[i].sz = 0; lt[i].r = lt[i].g = lt[i].b = lt[i].n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) lt[i].hist[k] = 0;
+    }
+    if (tid == 0) s_npts = 0;
+    for (int i = tid; i < (MF_H + 4) * (MF_W + 4); i += 256) {
+        const int ly = i / (MF_W + 4), lx = i - ly * (MF_W + 4);
+        const int gx = tx0 + lx - 2, gy = ty0 + ly - 2;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
+            const uint8_t* p = S + ((size_t)gy * w + gx) * 3;
+            const int b = p[0], g = p[1], r = p[2];
+            v = ((b == 0 && g == 64 && r == 64) || (b == 192 && g == 128 && r == 0)) ? 1 : 0;
+        }
+        m0[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < (MF_H + 4) * MF_W; i += 256) {
+        const int ly = i >> 6, lx = i & 63;
+        const uint8_t* p = &m0[ly][lx];
+        mh[ly][lx] = p[0] | p[1] | p[2] | p[3] | p[4];
+    }
+    __syncthreads();
+    double T[12];
+    const bool hasT = pose != nullptr;
+    if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    int kept = 0;
+    for (int it = 0; it < MF_H / 4; it++) {
+        const int ly = wv + 4 * it, gy = ty0 + ly, gx = tx0 + lane;
+        long long key = -2, sx = 0, sy = 0, sz = 0; uint32_t rg = 0, bn = 0, label = 255;
+        bool keep = false;
+        if (gx < w && gy < h) {
+            const size_t p = fo + (size_t)gy * w + gx;
+            const int d = depth[p];
+            const int moving = mh[ly][lane] | mh[ly+1][lane] | mh[ly+2][lane] | mh[ly+3][lane] | mh[ly+4][lane];
+            const uint8_t* s3 = sem + p * 3;
+            const int sb = s3[0], sg = s3[1], sr = s3[2];
+            keep = bp_keep(d, moving ? 255 : 0, sb, sg, sr, maxd);
+            if (keep) {
+                const float z = (float)((double)d / cam.scale);
+                const float x = (float)(((double)gx - cam.cx) * (double)z / cam.fx);
+                const float y = (float)(((double)gy - cam.cy) * (double)z / cam.fy);
+                float ox = x, oy = y, oz = z;
+                if (hasT) {
+                    const double X = x, Y = y, Z = z;
+                    ox = (float)(T[0] * X + T[3] * Y + T[6] * Z + T[9]);
+                    oy = (float)(T[1] * X + T[4] * Y + T[7] * Z + T[10]);
+                    oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
+                }
+                const long long vi = (long long)floorf(ox * inv_leaf) + (1 << 20);
+                const long long vj = (long long)floorf(oy * inv_leaf) + (1 << 20);
+                const long long vk = (long long)floorf(oz * inv_leaf) + (1 << 20);
+                key = (vk << 42) | (vj << 21) | vi;
+                sx = __double2ll_rn((double)ox * 16777216.0); sy = __double2ll_rn((double)oy * 16777216.0); sz = __double2ll_rn((double)oz * 16777216.0);
+                const uint8_t* c3 = rgb + p * 3;
+                rg = (uint32_t)c3[2] | ((uint32_t)c3[1] << 16);
+                bn = (uint32_t)c3[0] | (1u << 16);
+                label = label_of_bgr(sb, sg, sr);
+            }
+        }
+        const unsigned long long kb = __ballot(keep);
+        if (kb == 0ull) continue;                               // wave-uniform
+        kept += __popcll(kb);
+        const long long kprev = __shfl_up(key, 1, 64);
+        const bool head = lane == 0 || kprev != key;
+        const unsigned long long heads = __ballot(head);
+        const int start = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long ax = __shfl_up(sx, o, 64), ay = __shfl_up(sy, o, 64), az = __shfl_up(sz, o, 64);
+            const uint32_t arg = __shfl_up(rg, o, 64), abn = __shfl_up(bn, o, 64);
+            if (lane - o >= start) { sx += ax; sy += ay; sz += az; rg += arg; bn += abn; }
+        }
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        unsigned long long lb[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) lb[c] = __ballot(label == (uint32_t)c);
+        if (keep && tail) {
+            const unsigned long long run = (~0ull >> (63 - lane)) & (~0ull << start);
+            // tile-local table
+            uint32_t slot = vox_hash(key) & (MF_SLOTS - 1);
+            LdsVox* e = nullptr;
+            for (int probe = 0; probe < MF_SLOTS; probe++, slot = (slot + 1) & (MF_SLOTS - 1)) {
+                const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&lt[slot].key), (unsigned long long)SSM_VOX_EMPTY, (unsigned long long)key);
+                if (prev == (unsigned long long)SSM_VOX_EMPTY || prev == (unsigned long long)key) { e = &lt[slot]; break; }
+            }
+            if (e) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sx), (unsigned long long)sx);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sy), (unsigned long long)sy);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sz), (unsigned long long)sz);
+                atomicAdd(&e->r, rg & 0xFFFF); atomicAdd(&e->g, rg >> 16); atomicAdd(&e->b, bn & 0xFFFF); atomicAdd(&e->n, bn >> 16);
+#pragma unroll
+                for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&e->hist[c >> 1], (uint32_t)k << (16 * (c & 1))); }
+            } else {                                            // tile touches > 256 voxels: straight to the global table
+                ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
+                if (v) {
+                    vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
+#pragma unroll
+                    for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&v->hist[c], (uint32_t)k); }
+                }
+            }
+        }
+    }
+    if (lane == 0 && kept) atomicAdd(&s_npts, kept);
+    __syncthreads();
+    for (int i = tid; i < MF_SLOTS; i += 256) {
+        if (lt[i].key == SSM_VOX_EMPTY) continue;
+        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
+        if (!v) continue;
+        vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
+#pragma unroll
+        for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
+    }
+    if (tid == 0 && s_npts) atomicAdd(&npoints[blockIdx.y], s_npts);
+}
+hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
+                      ssm_camera cam, double max_distance, float leaf, ssm_voxel* tab, int cap_log2, int32_t* counters,
+                      int32_t* npoints, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s);
+    if (e != hipSuccess) return e;
+    const int tx = (w + MF_W - 1) / MF_W, ty = (h + MF_H - 1) / MF_H;
+    map_fuse_kernel<<<dim3(tx * ty, n), 256, 0, s>>>(depth, rgb, sem, pose, w, h, tx, cam, max_distance * cam.scale, 1.0f / leaf,
+                                                     tab, cap_log2, counters, npoints);
+    return hipGetLastError();
+}
+
 __global__ void vox_merge_kernel(const ssm_voxel* __restrict__ src, int n, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters)
 {
     uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
