@@ -153,10 +153,18 @@ hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hi
 }
 
 // ------------------------------------------------------------------ K3: per-cell FAST-9/16 + NMS
-// One block per (cell, frame).  Sub-image (wCell+6)x(hCell+6) staged in LDS; S = max over the 16 arcs of 9 of the
-// arc-min of (ring - v) / (v - ring); corner at t iff S > t; cv response = S - 1; NMS = strictly greater than the 8
-// neighbours inside the cell's inner region; iniThFAST first, minThFAST if the cell found nothing.
-#define FC_MAX 72
+// ORBextractor runs cv::FAST on every cell of a 30-px grid (sub-image = cell + 3-px margin): S = max over the 16 arcs of
+// 9 of the arc-min of (ring - v) / (v - ring); corner at t iff S > t; response = S - 1; NMS keeps a corner whose
+// response beats its 8 neighbours INSIDE the cell's detection region; iniThFAST first, minThFAST if the cell is empty.
+// Restated for the GPU without per-cell blocks:
+//   * keep(p, t)  <=>  S(p) > t  and no same-cell neighbour n with S(n) >= S(p)      (for t in {ini, min}: a neighbour
+//     with S(n) >= S(p) > t is itself a corner at t), so ONE local-maximum flag serves both thresholds;
+//   * a 9-arc always contains two adjacent compass points, so pixels failing that test at minThFAST are dropped before
+//     scoring (about 3/4 of a textured image); survivors are compacted in LDS and scored densely;
+//   * the kernel emits every local maximum with S > minThFAST plus max S per cell; the consumer (quad-tree kernel)
+//     keeps a maximum iff S > (cellmax > iniThFAST ? iniThFAST : minThFAST)  ==  "retry the cell at minThFAST".
+// One block per 128x32 tile of one level of one frame (all levels in one launch), tile + 4-px apron staged in LDS by
+// dword loads.
 __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
 {
     const int v = p[0];
@@ -165,7 +173,6 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
     d[4] = p[3] - v;         d[5] = p[-st+3] - v;    d[6] = p[-2*st+2] - v;  d[7] = p[-3*st+1] - v;
     d[8] = p[-3*st] - v;     d[9] = p[-3*st-1] - v;  d[10] = p[-2*st-2] - v; d[11] = p[-st-3] - v;
     d[12] = p[-3] - v;       d[13] = p[st-3] - v;    d[14] = p[2*st-2] - v;  d[15] = p[3*st-1] - v;
-    // quick reject at threshold 0: a 9-arc contains >= 2 of the 4 compass points
     int mn3[16], mx3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -181,79 +188,138 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
     }
     return max(bright, dark);
 }
-__global__ void __launch_bounds__(128)
-fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand)
+#define FT_W 128
+#define FT_H 32
+#define FT_PW (FT_W + 8)      // staged pixel row: 4-px apron each side (3 for the ring + 1 for the NMS neighbours)
+#define FT_PH (FT_H + 8)
+#define FT_SW (FT_W + 2)      // scored positions: tile + 1
+#define FT_SH (FT_H + 2)
+#define FT_SST 132
+#define FT_STAGE 1024
+__global__ void __launch_bounds__(256)
+fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax)
 {
-    __shared__ uint8_t px[FC_MAX * FC_MAX];
-    __shared__ uint8_t sc[FC_MAX * FC_MAX];
-    __shared__ cand_t  list[(FC_MAX / 2) * (FC_MAX / 2)];
-    __shared__ int n_ini, n_min, n_out, g_base;
+    __shared__ __attribute__((aligned(16))) uint8_t px[FT_PH * FT_PW];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_SH * FT_SST];
+    __shared__ uint16_t list[FT_SW * FT_SH];
+    __shared__ int16_t cellx[FT_SW], celly[FT_SH];
+    __shared__ int lmax[64];
+    __shared__ cand_t stage[FT_STAGE];
+    __shared__ int nlist, nstage, gbase;
+    const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].cell_off) l++;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
     const LevelGeom& L = g.L[l];
-    const int cell = blockIdx.x - L.cell_off;
-    const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
-    const int iniY = L.minBY + ci * L.hCell, iniX = L.minBX + cj * L.wCell;
-    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) return;
-    const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
-    const int cw = maxX - iniX, ch = maxY - iniY;
+    const int t = blockIdx.x - L.tile_off;
+    const int tx0 = (t % L.tiles_x) * FT_W, ty0 = (t / L.tiles_x) * FT_H;
+    const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* im = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
-    if (threadIdx.x == 0) { n_ini = 0; n_min = 0; n_out = 0; }
-    for (int i = threadIdx.x; i < cw * ch; i += 128) {
-        const int y = i / cw, x = i - y * cw;
-        px[y * FC_MAX + x] = im[(size_t)(iniY + y) * L.stride + iniX + x];
-        sc[y * FC_MAX + x] = 0;
+    // ---- stage the tile (dword loads; out-of-image dwords read as 0: no valid position ever looks at them)
+    for (int i = tid; i < FT_PH * (FT_PW / 4); i += 256) {
+        const int ly = i / (FT_PW / 4), lq = i - ly * (FT_PW / 4);
+        const int gx = tx0 - 4 + 4 * lq, gy = ty0 - 4 + ly;
+        uint32_t v = 0;
+        if (gx >= 0 && gx < stride && gy >= 0 && gy < h) v = *reinterpret_cast<const uint32_t*>(im + (size_t)gy * stride + gx);
+        reinterpret_cast<uint32_t*>(px)[i] = v;
+    }
+    for (int i = tid; i < FT_SH * FT_SST / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    if (tid < FT_SW) { const int gx = tx0 + tid - 1 - L.minBX - 3; cellx[tid] = (int16_t)(gx >= 0 ? gx / L.wCell : -1); }
+    if (tid < FT_SH) { const int gy = ty0 + tid - 1 - L.minBY - 3; celly[tid] = (int16_t)(gy >= 0 ? gy / L.hCell : -1); }
+    if (tid < 64) lmax[tid] = 0;
+    if (tid == 0) { nlist = 0; nstage = 0; gbase = 0; }
+    __syncthreads();
+    // ---- quick reject + compaction of the positions worth scoring
+    const int min_th = g.min_th;
+    for (int i0 = 0; i0 < FT_SW * FT_SH; i0 += 256) {
+        const int i = i0 + tid;
+        bool pass = false;
+        if (i < FT_SW * FT_SH) {
+            const int sy = i / FT_SW, sx = i - sy * FT_SW;
+            const int gx = tx0 + sx - 1, gy = ty0 + sy - 1;
+            if (gx >= SSM_EDGE && gx < w - SSM_EDGE && gy >= SSM_EDGE && gy < h - SSM_EDGE) {
+                const uint8_t* p = &px[(sy + 3) * FT_PW + sx + 3];
+                const int v = p[0];
+                const int a = p[3 * FT_PW] - v, b = p[3] - v, c = p[-3 * FT_PW] - v, d = p[-3] - v;
+                const bool ba = a > min_th, bb = b > min_th, bc = c > min_th, bd = d > min_th;
+                const bool da = -a > min_th, db = -b > min_th, dc = -c > min_th, dd = -d > min_th;
+                pass = (ba && bb) || (bb && bc) || (bc && bd) || (bd && ba) || (da && db) || (db && dc) || (dc && dd) || (dd && da);
+            }
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&nlist, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (pass) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
     }
     __syncthreads();
-    const int iw = cw - 6, ih = ch - 6;
-    for (int i = threadIdx.x; i < iw * ih; i += 128) {
-        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
-        const int S = fast_S(&px[y * FC_MAX + x], FC_MAX);
-        sc[y * FC_MAX + x] = (uint8_t)max(S, 0);
+    const int n = nlist;
+    for (int e = tid; e < n; e += 256) {
+        const int i = list[e], sy = i / FT_SW, sx = i - sy * FT_SW;
+        const int S = fast_S(&px[(sy + 3) * FT_PW + sx + 3], FT_PW);
+        sc[sy * FT_SST + sx] = (uint8_t)max(S, 0);
     }
     __syncthreads();
-    // local maxima; which threshold class they reach
-    int kept_ini = 0, kept_min = 0;
-    for (int i = threadIdx.x; i < iw * ih; i += 128) {
-        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
-        const uint8_t* q = &sc[y * FC_MAX + x];
-        const int S = q[0];
-        if (S <= g.min_th) continue;
-        const int nb = max(max(max(q[-FC_MAX-1], q[-FC_MAX]), max(q[-FC_MAX+1], q[-1])), max(max(q[1], q[FC_MAX-1]), max(q[FC_MAX], q[FC_MAX+1])));
-        // keep at th iff S-1 > (n > th ? n-1 : 0) for every neighbour n.  With S > th this is S > max over neighbours that exceed th.
-        if (S > g.ini_th && !(nb > g.ini_th && nb >= S)) kept_ini++;
-        if (!(nb > g.min_th && nb >= S)) kept_min++;
-    }
-    if (kept_ini) atomicAdd(&n_ini, kept_ini);
-    if (kept_min) atomicAdd(&n_min, kept_min);
-    __syncthreads();
-    const int th = n_ini > 0 ? g.ini_th : g.min_th;
-    if ((n_ini > 0 ? n_ini : n_min) == 0) return;
-    for (int i = threadIdx.x; i < iw * ih; i += 128) {
-        const int y = i / iw + 3, x = i - (y - 3) * iw + 3;
-        const uint8_t* q = &sc[y * FC_MAX + x];
-        const int S = q[0];
-        if (S <= th) continue;
-        const int nb = max(max(max(q[-FC_MAX-1], q[-FC_MAX]), max(q[-FC_MAX+1], q[-1])), max(max(q[1], q[FC_MAX-1]), max(q[FC_MAX], q[FC_MAX+1])));
-        if (nb > th && nb >= S) continue;
-        const int k = atomicAdd(&n_out, 1);
-        cand_t c;
-        c.x = (uint32_t)(x + cj * L.wCell) | ((uint32_t)(y + ci * L.hCell) << 12) | ((uint32_t)(S - 1) << 24);
-        c.y = ((uint32_t)cell << 14) | ((uint32_t)y << 7) | (uint32_t)x;
-        list[k] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) g_base = atomicAdd(&ncand[blockIdx.y * g.nlevels + l], n_out);
-    __syncthreads();
+    // ---- local maxima among same-cell neighbours; staged in LDS, ONE global reservation per tile
+    const int cx0 = max((int)cellx[1], 0), cy0 = max((int)celly[1], 0);
     cand_t* out = cand + (size_t)blockIdx.y * g.cand_total + L.cand_off;
-    for (int i = threadIdx.x; i < n_out; i += 128)
-        if (g_base + i < L.cand_cap) out[g_base + i] = list[i];
+    int32_t* nc = ncand + blockIdx.y * g.nlevels + l;
+    for (int e0 = 0; e0 < n; e0 += 256) {
+        const int e = e0 + tid;
+        bool keep = false; int S = 0, sx = 0, sy = 0;
+        if (e < n) {
+            const int i = list[e]; sy = i / FT_SW; sx = i - sy * FT_SW;
+            if (sx >= 1 && sx <= FT_W && sy >= 1 && sy <= FT_H && tx0 + sx - 1 < w && ty0 + sy - 1 < h) {
+                const uint8_t* q = &sc[sy * FT_SST + sx];
+                S = q[0];
+                if (S > min_th) {
+                    const int cx = cellx[sx], cy = celly[sy];
+                    const bool xl = cellx[sx-1] == cx, xr = cellx[sx+1] == cx, yu = celly[sy-1] == cy, yd = celly[sy+1] == cy;
+                    int nb = 0;
+                    if (yu) { nb = max(nb, (int)q[-FT_SST]); if (xl) nb = max(nb, (int)q[-FT_SST-1]); if (xr) nb = max(nb, (int)q[-FT_SST+1]); }
+                    if (yd) { nb = max(nb, (int)q[FT_SST]);  if (xl) nb = max(nb, (int)q[FT_SST-1]);  if (xr) nb = max(nb, (int)q[FT_SST+1]); }
+                    if (xl) nb = max(nb, (int)q[-1]);
+                    if (xr) nb = max(nb, (int)q[1]);
+                    keep = nb < S;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&nstage, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) {
+                const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+                const int gx = tx0 + sx - 1, gy = ty0 + sy - 1;
+                const int cj = cellx[sx], ci = celly[sy];
+                atomicMax(&lmax[((ci - cy0) & 7) * 8 + ((cj - cx0) & 7)], S);
+                cand_t c;
+                c.x = (uint32_t)(gx - L.minBX) | ((uint32_t)(gy - L.minBY) << 12) | ((uint32_t)(S - 1) << 24);
+                c.y = ((uint32_t)(ci * L.nCols + cj) << 14) | ((uint32_t)(gy - L.minBY - ci * L.hCell) << 7) | (uint32_t)(gx - L.minBX - cj * L.wCell);
+                if (k < FT_STAGE) stage[k] = c;
+                else { const int kg = atomicAdd(nc, 1); if (kg < L.cand_cap) out[kg] = c; }     // tile with > FT_STAGE maxima: rare
+            }
+        }
+    }
+    __syncthreads();
+    const int ns = min(nstage, FT_STAGE);
+    if (tid == 0 && ns) gbase = atomicAdd(nc, ns);
+    __syncthreads();
+    for (int k = tid; k < ns; k += 256) if (gbase + k < L.cand_cap) out[gbase + k] = stage[k];
+    if (tid < 64 && lmax[tid] > 0) {
+        const int ci = cy0 + (tid >> 3), cj = cx0 + (tid & 7);
+        atomicMax(&cellmax[(size_t)blockIdx.y * g.cells_total + L.cell_off + ci * L.nCols + cj], lmax[tid]);
+    }
 }
-hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, hipStream_t s)
+hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s);
     if (e != hipSuccess) return e;
-    fast_kernel<<<dim3(g.cells_total, n), 128, 0, s>>>(pyr, g, cand, ncand);
+    e = hipMemsetAsync(cellmax, 0, sizeof(int32_t) * (size_t)n * g.cells_total, s);
+    if (e != hipSuccess) return e;
+    fast_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, g, cand, ncand, cellmax);
     return hipGetLastError();
 }
 
@@ -265,9 +331,10 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
 // first) in the second, stopping when the list reaches N); push_front of n1..n4 then erase(parent) leaves
 //   [n4..n1 of p_m] ... [n4..n1 of p_1] ++ (old list without the split parents).
 struct QNode { short x0, y0, x1, y1; };
+#define DROPPED 0xFFFF
 __global__ void __launch_bounds__(256)
-octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, uint16_t* __restrict__ node_of,
-              uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
+octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, const int32_t* __restrict__ cellmax,
+              uint16_t* __restrict__ node_of, uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
 {
     __shared__ QNode    nd[2][SSM_MAX_NODES];
     __shared__ uint32_t cnt[2][SSM_MAX_NODES];
@@ -277,7 +344,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     __shared__ short    childpos[SSM_MAX_NODES][4];
     __shared__ short    order[SSM_MAX_NODES];
     __shared__ unsigned long long best[SSM_MAX_NODES];
-    __shared__ int sL, sFinish, sMode, sE, sErr;
+    __shared__ int sL, sFinish, sMode, sErr, sValid;
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g.L[l];
     const int N = L.nfeat;
@@ -293,14 +360,23 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         QNode q; q.x0 = (short)(int)(hX * (float)i); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(i + 1)); q.y1 = (short)(L.maxBY - L.minBY);
         nd[0][i] = q; cnt[0][i] = 0; sq[0][i] = i;
     }
-    if (tid == 0) { sErr = 0; }
+    if (tid == 0) { sErr = 0; sValid = 0; }
     __syncthreads();
+    // keys are the local maxima at minThFAST; a cell that has one above iniThFAST keeps only those (DROPPED otherwise)
+    const int32_t* cm = cellmax + (size_t)f * g.cells_total + L.cell_off;
+    int nvalid = 0;
     for (int i = tid; i < nc; i += 256) {
-        const int x = keys[i].x & 4095;
+        const cand_t k = keys[i];
+        const int S = (int)(k.x >> 24) + 1;
+        const int th = cm[k.y >> 14] > g.ini_th ? g.ini_th : g.min_th;
+        if (S <= th) { nof[i] = DROPPED; continue; }
+        const int x = k.x & 4095;
         int b = (int)((float)x / hX); b = min(b, nIni - 1);
-        nof[i] = (uint16_t)b; atomicAdd(&cnt[0][b], 1u);
+        nof[i] = (uint16_t)b; atomicAdd(&cnt[0][b], 1u); nvalid++;
     }
+    if (nvalid) atomicAdd(&sValid, nvalid);
     __syncthreads();
+    if (sValid == 0) { if (tid == 0) nsel[f * g.nlevels + l] = 0; return; }
     if (tid == 0) {
         int pos = 0;
         for (int i = 0; i < nIni; i++) {
@@ -310,7 +386,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         sL = pos; sFinish = 0; sMode = 0;
     }
     __syncthreads();
-    for (int i = tid; i < nc; i += 256) nof[i] = (uint16_t)newpos[nof[i]];
+    for (int i = tid; i < nc; i += 256) if (nof[i] != DROPPED) nof[i] = (uint16_t)newpos[nof[i]];
     int cur = 1;      // buffer holding the current list
     __syncthreads();
     // ---- split passes
@@ -322,7 +398,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         __syncthreads();
         for (int i = tid; i < nc; i += 256) {
             const int ni = nof[i];
-            if (ccnt[ni] > 1) {
+            if (ni != DROPPED && ccnt[ni] > 1) {
                 const QNode q = cn[ni];
                 const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
                 const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
@@ -396,6 +472,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         __syncthreads();
         for (int i = tid; i < nc; i += 256) {
             const int ni = nof[i];
+            if (ni == DROPPED) continue;
             if (newpos[ni] == -2) {
                 const QNode q = cn[ni];
                 const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
@@ -413,6 +490,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     for (int i = tid; i < Lf; i += 256) best[i] = 0ull;
     __syncthreads();
     for (int i = tid; i < nc; i += 256) {
+        if (nof[i] == DROPPED) continue;
         const cand_t k = keys[i];
         const unsigned long long v = ((unsigned long long)(k.x >> 24) << 56) | ((unsigned long long)(0xFFFFFFFFu - k.y) << 24) | (k.x & 0xFFFFFFu);
         atomicMax(&best[nof[i]], v);
@@ -425,10 +503,10 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     }
     if (tid == 0) { nsel[f * g.nlevels + l] = min(Lf, L.sel_cap); if (Lf > L.sel_cap) atomicOr(status, 4); }
 }
-hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, uint16_t* node_of,
+hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s)
 {
-    octree_kernel<<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, node_of, sel, nsel, status);
+    octree_kernel<<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
     return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ struct ssm_ctx {
     int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
     int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
     // batch workspace (B frames)
-    uint8_t *d_pyr = nullptr, *d_blur = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr; int32_t* d_cellmax = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
     int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr;
     uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
     ssm_point* d_points = nullptr;
@@ -95,7 +95,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         for (int v = SSM_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
         for (int v = 0; v <= SSM_HALF_PATCH; v++) g.umax[v] = um[v];
     }
-    int off = 0, cells = 0, cands = 0, sels = 0;
+    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.L[l];
         L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
@@ -105,11 +105,13 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
         L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
-        if (L.wCell + 6 > 72 || L.hCell + 6 > 72) { err = "FAST cell larger than the LDS tile"; return SSM_E_INVAL; }
+        if (L.wCell < 17 || L.hCell < 5) { err = "FAST cell too small"; return SSM_E_INVAL; }   /* <= 8x8 cells per 128x32 tile */
         L.cell_off = cells; cells += L.nCols * L.nRows;
+        L.tiles_x = (L.w + 127) / 128; L.tile_off = tiles; tiles += L.tiles_x * ((L.h + 31) / 32);
+        if (L.nCols * L.nRows >= (1 << 17)) { err = "too many FAST cells"; return SSM_E_INVAL; }
         L.nfeat = feat[l];
         if (L.nfeat + 3 > SSM_MAX_NODES - 8) { err = "too many features per level for the LDS quad-tree (max 1013 per level)"; return SSM_E_INVAL; }
-        L.cand_off = cands; L.cand_cap = ((L.w + 1) / 2) * ((L.h + 1) / 2); cands += L.cand_cap;
+        L.cand_off = cands; L.cand_cap = ((L.w + 1) / 2 + L.nCols + 1) * ((L.h + 1) / 2 + L.nRows + 1); cands += L.cand_cap;
         if (L.cand_cap > 65535 * 16) { err = "level too large"; return SSM_E_INVAL; }
         L.sel_off = sels; L.sel_cap = L.nfeat + 3; sels += L.sel_cap;
         int nIni = (int)roundf((float)(L.maxBX - L.minBX) / (float)(L.maxBY - L.minBY)); if (nIni < 1) nIni = 1;
@@ -117,7 +119,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         if (4 * nIni + 8 > SSM_MAX_NODES) { err = "aspect ratio too extreme"; return SSM_E_INVAL; }
         L.sf = sf[l];
     }
-    g.pyr_bytes = off; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
+    g.pyr_bytes = off; g.tiles_total = tiles; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
     g.cap = c.orb_features + 3 * g.nlevels;
     return SSM_OK;
 }
@@ -218,7 +220,7 @@ static int ctx_init(ssm_ctx* c)
         HIPCHK(c, hipMemcpy(c->d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_ya[l], ya.data(), ya.size() * 2, hipMemcpyHostToDevice));
     }
-    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes);
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
@@ -256,7 +258,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
+    void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab };
@@ -304,8 +306,8 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
     const OrbGeom& g = c->g; hipStream_t s = c->stream;
     prof_begin(c, "gray");      HIPCHK(c, k_gray(d_img, channels, nb, g, c->d_pyr, s)); prof_end(c);
     prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(nb, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, s)); prof_end(c);
-    prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, s)); prof_end(c);
-    prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
+    prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
+    prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
     prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
     prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern, d_depth, c->cfg.camera, kps, desc, pos3d, nkp, s)); prof_end(c);
     return SSM_OK;

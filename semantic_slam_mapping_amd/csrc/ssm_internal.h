@@ -16,6 +16,7 @@ struct LevelGeom {
     int img_off;               // byte offset inside one frame's pyramid buffer (16-B aligned)
     int nCols, nRows, wCell, hCell;   // FAST cell grid (ComputeKeyPointsOctTree, W = 30)
     int cell_off;              // first flattened cell id of this level
+    int tile_off, tiles_x;     // FAST tiles (128x32) of this level in the flattened grid
     int nfeat;                 // mnFeaturesPerLevel
     int cand_off, cand_cap;    // entries inside one frame's candidate buffer
     int sel_off, sel_cap;      // slots inside one frame's selected-keypoint staging (nfeat + 3)
@@ -27,7 +28,7 @@ struct LevelGeom {
 struct OrbGeom {
     int nlevels, W, H;
     int pyr_bytes;             // one frame's pyramid (all levels)
-    int cells_total, cand_total, sel_total;
+    int cells_total, cand_total, sel_total, tiles_total;
     int cap;                   // output keypoints per frame (orb_features + 3*levels)
     int ini_th, min_th;
     int umax[SSM_HALF_PATCH + 1];
@@ -42,8 +43,8 @@ hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g,
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
                      const int32_t* const* yofs, const int16_t* const* ya, hipStream_t s);
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s);
-hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, hipStream_t s);
-hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, uint16_t* node_of,
+hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s);
+hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s);
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
                       const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam,
