@@ -320,88 +320,174 @@ hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_
     vox_insert_kernel<<<(int)blocks, 256, 0, s>>>(pts, n_dev, n_max, 1.0f / leaf, tab, cap_log2, counters);
     return hipGetLastError();
 }
-// ------------------------------------------------------------------ K10+K11+K12 fused (sequence path)
-// One block per 64x32-pixel tile of one frame: class flags + 2-px apron in LDS -> 5x5 dilate -> per pixel gates,
-// unprojection, pose transform, voxel key, 2^-24 quantisation -> wave run-reduction along the row -> tile-local LDS hash
-// (<= 256 voxels) -> one flush of global atomics per (tile, voxel).  The point list of generatePointCloud is never
-// written: exact integer sums make the map independent of order, so the result is bit-identical to
-// mask -> backproject -> insert (tests/test_gpu_parity.py::test_seq_process_matches_oracle_per_frame).
-#define MF_W 64
-#define MF_H 32
-#define MF_SLOTS 256
-struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
-
-__device__ __forceinline__ uint32_t label_of_bgr(int sb, int sg, int sr)
+// ------------------------------------------------------------------ K10+K11+K12, streaming form (w % 16 == 0)
+// (1) class_bits_kernel: 1 bit per pixel = pedestrian|cyclist colour, 16 px per thread from three 16-B loads.
+// (2) vdilate_bits_kernel: OR of rows y-2..y+2 of those bits (the vertical half of the 5x5 box dilate).
+// (3) map_stream_kernel: one thread = 16 consecutive pixels of a row: depth/rgb/semantic arrive in eight 16-B loads
+//     issued up front, the horizontal half of the dilate is done on a 48-bit window in registers, every kept pixel is
+//     unprojected / transformed / quantised exactly like K11+K12, consecutive pixels with the same (voxel, label) are
+//     summed in registers (two runs per thread, further runs go straight to LDS), then ONE wave-wide segmented DPP scan
+//     per run slot merges neighbouring threads, the run tails update a block-local LDS hash (<= 128 voxels per 4096
+//     pixels) and the block flushes it with one global atomic group per voxel.  No block barrier before the flush.
+//     The point list of generatePointCloud is never written: exact integer sums make the map independent of order, so
+//     the result is bit-identical to mask -> backproject -> insert (tests/test_gpu_parity.py).
+__global__ void __launch_bounds__(256)
+class_bits_kernel(const uint8_t* __restrict__ sem, int words_per_frame, uint16_t* __restrict__ raw)
 {
-    switch ((sb << 16) | (sg << 8) | sr) {
-        case (128 << 16) | (128 << 8) | 128: return 0;   case (0 << 16) | (0 << 8) | 128: return 1;
-        case (128 << 16) | (192 << 8) | 192: return 2;   case (0 << 16) | (69 << 8) | 255: return 3;
-        case (128 << 16) | (64 << 8) | 128: return 4;    case (222 << 16) | (40 << 8) | 60: return 5;
-        case (0 << 16) | (128 << 8) | 128: return 6;     case (128 << 16) | (128 << 8) | 192: return 7;
-        case (128 << 16) | (64 << 8) | 64: return 8;     case (128 << 16) | (0 << 8) | 64: return 9;
-        case (0 << 16) | (64 << 8) | 64: return 10;      case (192 << 16) | (128 << 8) | 0: return 11;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words_per_frame) return;
+    const size_t wi = (size_t)blockIdx.y * words_per_frame + i;
+    const uint4* p = reinterpret_cast<const uint4*>(sem + wi * 48);
+    const uint4 a = p[0], b = p[1], c = p[2];
+    const uint32_t d[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int o = 3 * k;                                   // byte offset of pixel k inside the 48 bytes
+        const uint32_t px = (o & 3) ? __builtin_amdgcn_alignbyte(d[(o >> 2) + 1], d[o >> 2], o & 3) : d[o >> 2];   // b | g<<8 | r<<16 | ..
+        const uint32_t bgr = px & 0xFFFFFFu;
+        bits |= (uint32_t)(bgr == (0u | (64u << 8) | (64u << 16)) || bgr == (192u | (128u << 8) | (0u << 16))) << k;   // (0,64,64) | (192,128,0) BGR
+    }
+    raw[wi] = (uint16_t)bits;
+}
+__global__ void __launch_bounds__(256)
+vdilate_bits_kernel(const uint16_t* __restrict__ raw, int wpr, int h, uint16_t* __restrict__ vb)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wpr * h) return;
+    const int y = i / wpr, x = i - y * wpr;
+    const uint16_t* r = raw + (size_t)blockIdx.y * wpr * h;
+    uint32_t v = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) { const int yy = y + dy; if (yy >= 0 && yy < h) v |= r[yy * wpr + x]; }
+    vb[(size_t)blockIdx.y * wpr * h + i] = (uint16_t)v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_mov0_ll(long long v)
+{
+    const int lo = dpp_mov0<CTRL, ROW_MASK>((int)(unsigned)(unsigned long long)v), hi = dpp_mov0<CTRL, ROW_MASK>((int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+struct RunAcc { long long sx, sy, sz; uint32_t r, g, b, n; };
+// inclusive segmented scan over runs that start at lane `start` (start <= lane): the run's LAST lane ends with the run total.
+// DPP only (VALU): row_shr:1/2/4/8 inside rows of 16, then row_bcast:15 and row_bcast:31 across rows.
+__device__ __forceinline__ void run_scan(RunAcc& a, int lane, int start)
+{
+#define RS_STEP(CTRL, MASK, COND)                                                                                   \
+    {   const long long tx = dpp_mov0_ll<CTRL, MASK>(a.sx), ty = dpp_mov0_ll<CTRL, MASK>(a.sy), tz = dpp_mov0_ll<CTRL, MASK>(a.sz); \
+        const uint32_t t1 = (uint32_t)dpp_mov0<CTRL, MASK>((int)a.r), t2 = (uint32_t)dpp_mov0<CTRL, MASK>((int)a.g);             \
+        const uint32_t t3 = (uint32_t)dpp_mov0<CTRL, MASK>((int)a.b), t4 = (uint32_t)dpp_mov0<CTRL, MASK>((int)a.n);             \
+        if (COND) { a.sx += tx; a.sy += ty; a.sz += tz; a.r += t1; a.g += t2; a.b += t3; a.n += t4; } }
+    const int li = lane & 15, row = lane >> 4;
+    RS_STEP(0x111, 0xF, (li >= 1 && lane - 1 >= start))
+    RS_STEP(0x112, 0xF, (li >= 2 && lane - 2 >= start))
+    RS_STEP(0x114, 0xF, (li >= 4 && lane - 4 >= start))
+    RS_STEP(0x118, 0xF, (li >= 8 && lane - 8 >= start))
+    RS_STEP(0x142, 0xA, ((row & 1) && start < 16 * row))
+    RS_STEP(0x143, 0xC, (row >= 2 && start < 32))
+#undef RS_STEP
+}
+#define MS_SLOTS 128
+struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
+__device__ __forceinline__ uint32_t label_of_bgr24(uint32_t bgr)     // b | g<<8 | r<<16
+{
+    switch (bgr) {
+        case 128u | (128u << 8) | (128u << 16): return 0;   case 0u | (0u << 8) | (128u << 16): return 1;
+        case 128u | (192u << 8) | (192u << 16): return 2;   case 0u | (69u << 8) | (255u << 16): return 3;
+        case 128u | (64u << 8) | (128u << 16): return 4;    case 222u | (40u << 8) | (60u << 16): return 5;
+        case 0u | (128u << 8) | (128u << 16): return 6;     case 128u | (128u << 8) | (192u << 16): return 7;
+        case 128u | (64u << 8) | (64u << 16): return 8;     case 128u | (0u << 8) | (64u << 16): return 9;
+        case 0u | (64u << 8) | (64u << 16): return 10;      case 192u | (128u << 8) | (0u << 16): return 11;
     }
     return 255;
 }
-__global__ void __launch_bounds__(256)
-map_fuse_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
-                const double* __restrict__ pose, int w, int h, int tiles_x, ssm_camera cam, double maxd, float inv_leaf,
-                ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints)
+__device__ __forceinline__ void lds_vox_update(LdsVox* lt, long long key, uint32_t lab, const RunAcc& f,
+                                               ssm_voxel* tab, int cap_log2, int32_t* counters, uint32_t* occ)
 {
-    __shared__ uint8_t m0[MF_H + 4][MF_W + 4];
-    __shared__ uint8_t mh[MF_H + 4][MF_W];
-    __shared__ LdsVox lt[MF_SLOTS];
+    uint32_t slot = vox_hash(key) & (MS_SLOTS - 1);
+    LdsVox* e = nullptr;
+    for (int probe = 0; probe < MS_SLOTS; probe++, slot = (slot + 1) & (MS_SLOTS - 1)) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&lt[slot].key), (unsigned long long)SSM_VOX_EMPTY, (unsigned long long)key);
+        if (prev == (unsigned long long)SSM_VOX_EMPTY || prev == (unsigned long long)key) { e = &lt[slot]; break; }
+    }
+    if (e) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&e->sx), (unsigned long long)f.sx);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&e->sy), (unsigned long long)f.sy);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&e->sz), (unsigned long long)f.sz);
+        atomicAdd(&e->r, f.r); atomicAdd(&e->g, f.g); atomicAdd(&e->b, f.b); atomicAdd(&e->n, f.n);
+        if (lab < 12) atomicAdd(&e->hist[lab >> 1], f.n << (16 * (lab & 1)));
+    } else {                                                    // block touches > 128 voxels: straight to the global table
+        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
+        if (v) { vox_add(v, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n); if (lab < 12) atomicAdd(&v->hist[lab], f.n); }
+    }
+}
+// merge equal neighbouring runs across the wave and push the tails into the block table
+__device__ __forceinline__ void wave_flush(LdsVox* lt, long long key, uint32_t lab, RunAcc f, int lane,
+                                           ssm_voxel* tab, int cap_log2, int32_t* counters, uint32_t* occ)
+{
+    const long long kprev = dpp_mov0_ll<0x138, 0xF>(key);      // wave_shr:1
+    const uint32_t lprev = (uint32_t)dpp_mov0<0x138, 0xF>((int)lab);
+    const bool head = lane == 0 || kprev != key || lprev != lab;
+    const unsigned long long heads = __ballot(head);
+    const int start = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+    run_scan(f, lane, start);
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (key >= 0 && tail) lds_vox_update(lt, key, lab, f, tab, cap_log2, counters, occ);
+}
+__global__ void __launch_bounds__(256)
+map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
+                  const uint16_t* __restrict__ vbits, const double* __restrict__ pose, int w, int h, ssm_camera cam, double maxd,
+                  float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints)
+{
+    __shared__ LdsVox lt[MS_SLOTS];
     __shared__ int s_npts;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tx0 = (blockIdx.x % tiles_x) * MF_W, ty0 = (blockIdx.x / tiles_x) * MF_H;
-    const size_t fo = (size_t)blockIdx.y * w * h;
-    const uint8_t* S = sem + fo * 3;
-    for (int i = tid; i < MF_SLOTS; i += 256) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wpr = w >> 4, words = wpr * h;
+    for (int i = tid; i < MS_SLOTS; i += 256) {
         lt[i].key = SSM_VOX_EMPTY; lt[i].sx = 0; lt[i].sy = 0; lt[i].sz = 0; lt[i].r = lt[i].g = lt[i].b = lt[i].n = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) lt[i].hist[k] = 0;
     }
     if (tid == 0) s_npts = 0;
-    for (int i = tid; i < (MF_H + 4) * (MF_W + 4); i += 256) {
-        const int ly = i / (MF_W + 4), lx = i - ly * (MF_W + 4);
-        const int gx = tx0 + lx - 2, gy = ty0 + ly - 2;
-        uint8_t v = 0;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) {
-            const uint8_t* p = S + ((size_t)gy * w + gx) * 3;
-            const int b = p[0], g = p[1], r = p[2];
-            v = ((b == 0 && g == 64 && r == 64) || (b == 192 && g == 128 && r == 0)) ? 1 : 0;
-        }
-        m0[ly][lx] = v;
-    }
     __syncthreads();
-    for (int i = tid; i < (MF_H + 4) * MF_W; i += 256) {
-        const int ly = i >> 6, lx = i & 63;
-        const uint8_t* p = &m0[ly][lx];
-        mh[ly][lx] = p[0] | p[1] | p[2] | p[3] | p[4];
-    }
-    __syncthreads();
-    double T[12];
-    const bool hasT = pose != nullptr;
-    if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
     uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    const int wi = blockIdx.x * 256 + tid;                      // 16-pixel word of this frame
+    long long k0 = -2, k1 = -2; uint32_t l0 = 255, l1 = 255; RunAcc a0, a1;
+    a0.sx = a0.sy = a0.sz = 0; a0.r = a0.g = a0.b = a0.n = 0; a1 = a0;
     int kept = 0;
-    for (int it = 0; it < MF_H / 4; it++) {
-        const int ly = wv + 4 * it, gy = ty0 + ly, gx = tx0 + lane;
-        long long key = -2, sx = 0, sy = 0, sz = 0; uint32_t rg = 0, bn = 0, label = 255;
-        bool keep = false;
-        if (gx < w && gy < h) {
-            const size_t p = fo + (size_t)gy * w + gx;
-            const int d = depth[p];
-            const int moving = mh[ly][lane] | mh[ly+1][lane] | mh[ly+2][lane] | mh[ly+3][lane] | mh[ly+4][lane];
-            const uint8_t* s3 = sem + p * 3;
-            const int sb = s3[0], sg = s3[1], sr = s3[2];
-            keep = bp_keep(d, moving ? 255 : 0, sb, sg, sr, maxd);
+    if (wi < words) {
+        const size_t gw = (size_t)blockIdx.y * words + wi;
+        const int gy = wi / wpr, xw = wi - gy * wpr, gx0 = xw << 4;
+        const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
+        const uint4* pc = reinterpret_cast<const uint4*>(rgb + gw * 48);
+        const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
+        const uint4 D0 = pd[0], D1 = pd[1], C0 = pc[0], C1 = pc[1], C2 = pc[2], S0 = ps[0], S1 = ps[1], S2 = ps[2];
+        const uint16_t* vb = vbits + (size_t)blockIdx.y * words + (size_t)gy * wpr;
+        const unsigned long long win = ((unsigned long long)(xw > 0 ? vb[xw - 1] : 0)) | ((unsigned long long)vb[xw] << 16) |
+                                       ((unsigned long long)(xw + 1 < wpr ? vb[xw + 1] : 0) << 32);
+        const uint32_t moving = (uint32_t)((win >> 14) | (win >> 15) | (win >> 16) | (win >> 17) | (win >> 18)) & 0xFFFFu;   // 5-wide OR
+        const uint32_t dd[8] = {D0.x, D0.y, D0.z, D0.w, D1.x, D1.y, D1.z, D1.w};
+        const uint32_t cc[13] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w, C2.x, C2.y, C2.z, C2.w, 0u};
+        const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
+        double T[12];
+        const bool hasT = pose != nullptr;
+        if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
+        const double yf = (double)gy - cam.cy;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+            const int o = 3 * k;
+            const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
+            const bool keep = bp_keep(d, ((moving >> k) & 1) ? 255 : 0, sbgr & 255, (sbgr >> 8) & 255, sbgr >> 16, maxd);
             if (keep) {
+                const uint32_t cbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(cc[(o >> 2) + 1], cc[o >> 2], o & 3) : cc[o >> 2]) & 0xFFFFFFu;
                 const float z = (float)((double)d / cam.scale);
-                const float x = (float)(((double)gx - cam.cx) * (double)z / cam.fx);
-                const float y = (float)(((double)gy - cam.cy) * (double)z / cam.fy);
+                const float x = (float)(((double)(gx0 + k) - cam.cx) * (double)z / cam.fx);
+                const float y = (float)(yf * (double)z / cam.fy);
                 float ox = x, oy = y, oz = z;
                 if (hasT) {
                     const double X = x, Y = y, Z = z;
@@ -412,60 +498,31 @@ map_fuse_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ 
                 const long long vi = (long long)floorf(ox * inv_leaf) + (1 << 20);
                 const long long vj = (long long)floorf(oy * inv_leaf) + (1 << 20);
                 const long long vk = (long long)floorf(oz * inv_leaf) + (1 << 20);
-                key = (vk << 42) | (vj << 21) | vi;
-                sx = __double2ll_rn((double)ox * 16777216.0); sy = __double2ll_rn((double)oy * 16777216.0); sz = __double2ll_rn((double)oz * 16777216.0);
-                const uint8_t* c3 = rgb + p * 3;
-                rg = (uint32_t)c3[2] | ((uint32_t)c3[1] << 16);
-                bn = (uint32_t)c3[0] | (1u << 16);
-                label = label_of_bgr(sb, sg, sr);
-            }
-        }
-        const unsigned long long kb = __ballot(keep);
-        if (kb == 0ull) continue;                               // wave-uniform
-        kept += __popcll(kb);
-        const long long kprev = __shfl_up(key, 1, 64);
-        const bool head = lane == 0 || kprev != key;
-        const unsigned long long heads = __ballot(head);
-        const int start = 63 - __clzll(heads & (~0ull >> (63 - lane)));
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long ax = __shfl_up(sx, o, 64), ay = __shfl_up(sy, o, 64), az = __shfl_up(sz, o, 64);
-            const uint32_t arg = __shfl_up(rg, o, 64), abn = __shfl_up(bn, o, 64);
-            if (lane - o >= start) { sx += ax; sy += ay; sz += az; rg += arg; bn += abn; }
-        }
-        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-        unsigned long long lb[12];
-#pragma unroll
-        for (int c = 0; c < 12; c++) lb[c] = __ballot(label == (uint32_t)c);
-        if (keep && tail) {
-            const unsigned long long run = (~0ull >> (63 - lane)) & (~0ull << start);
-            // tile-local table
-            uint32_t slot = vox_hash(key) & (MF_SLOTS - 1);
-            LdsVox* e = nullptr;
-            for (int probe = 0; probe < MF_SLOTS; probe++, slot = (slot + 1) & (MF_SLOTS - 1)) {
-                const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&lt[slot].key), (unsigned long long)SSM_VOX_EMPTY, (unsigned long long)key);
-                if (prev == (unsigned long long)SSM_VOX_EMPTY || prev == (unsigned long long)key) { e = &lt[slot]; break; }
-            }
-            if (e) {
-                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sx), (unsigned long long)sx);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sy), (unsigned long long)sy);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&e->sz), (unsigned long long)sz);
-                atomicAdd(&e->r, rg & 0xFFFF); atomicAdd(&e->g, rg >> 16); atomicAdd(&e->b, bn & 0xFFFF); atomicAdd(&e->n, bn >> 16);
-#pragma unroll
-                for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&e->hist[c >> 1], (uint32_t)k << (16 * (c & 1))); }
-            } else {                                            // tile touches > 256 voxels: straight to the global table
-                ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
-                if (v) {
-                    vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
-#pragma unroll
-                    for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&v->hist[c], (uint32_t)k); }
+                const long long key = (vk << 42) | (vj << 21) | vi;
+                const uint32_t lab = label_of_bgr24(sbgr);
+                RunAcc p;
+                p.sx = __double2ll_rn((double)ox * 16777216.0); p.sy = __double2ll_rn((double)oy * 16777216.0); p.sz = __double2ll_rn((double)oz * 16777216.0);
+                p.b = cbgr & 255; p.g = (cbgr >> 8) & 255; p.r = cbgr >> 16; p.n = 1;
+                kept++;
+                if (k1 == -2 && (k0 == -2 || (k0 == key && l0 == lab))) {                 // still in the first run
+                    k0 = key; l0 = lab; a0.sx += p.sx; a0.sy += p.sy; a0.sz += p.sz; a0.r += p.r; a0.g += p.g; a0.b += p.b; a0.n += 1;
+                } else if (k1 == -2 || (k1 == key && l1 == lab)) {                       // second run
+                    k1 = key; l1 = lab; a1.sx += p.sx; a1.sy += p.sy; a1.sz += p.sz; a1.r += p.r; a1.g += p.g; a1.b += p.b; a1.n += 1;
+                } else {                                                                 // a third run inside 16 pixels: rare
+                    lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
+                    k1 = key; l1 = lab; a1 = p;
                 }
             }
         }
     }
+    // two wave-wide merges (first runs, second runs); waves of a block are independent until the final flush
+    if (__ballot(k0 != -2)) wave_flush(lt, k0, l0, a0, lane, tab, cap_log2, counters, occ);
+    if (__ballot(k1 != -2)) wave_flush(lt, k1, l1, a1, lane, tab, cap_log2, counters, occ);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
     if (lane == 0 && kept) atomicAdd(&s_npts, kept);
     __syncthreads();
-    for (int i = tid; i < MF_SLOTS; i += 256) {
+    for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
         if (!v) continue;
@@ -476,14 +533,16 @@ map_fuse_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ 
     if (tid == 0 && s_npts) atomicAdd(&npoints[blockIdx.y], s_npts);
 }
 hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
-                      ssm_camera cam, double max_distance, float leaf, ssm_voxel* tab, int cap_log2, int32_t* counters,
-                      int32_t* npoints, hipStream_t s)
+                      ssm_camera cam, double max_distance, float leaf, uint16_t* bits_raw, uint16_t* bits_v,
+                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return e;
-    const int tx = (w + MF_W - 1) / MF_W, ty = (h + MF_H - 1) / MF_H;
-    map_fuse_kernel<<<dim3(tx * ty, n), 256, 0, s>>>(depth, rgb, sem, pose, w, h, tx, cam, max_distance * cam.scale, 1.0f / leaf,
-                                                     tab, cap_log2, counters, npoints);
+    const int wpr = w >> 4, words = wpr * h;
+    class_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(sem, words, bits_raw);
+    vdilate_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(bits_raw, wpr, h, bits_v);
+    map_stream_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, max_distance * cam.scale,
+                                                                   1.0f / leaf, tab, cap_log2, counters, npoints);
     return hipGetLastError();
 }
 

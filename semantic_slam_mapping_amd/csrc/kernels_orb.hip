@@ -106,49 +106,73 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
 }
 
 // ------------------------------------------------------------------ K5a: 7x7 sigma-2 Gaussian, fixed point
-// taps {18,34,49,55,49,34,18}; row pass fits u16 (<= 257*255); (v + 2^15) >> 16, saturate.  64x16 tile per block,
-// input tile + 3-px apron staged in LDS, row-pass intermediate kept in LDS.
-#define BT_W 64
-#define BT_H 16
+// taps {18,34,49,55,49,34,18}; row pass fits u16 (<= 257*255); (v + 2^15) >> 16, saturate; BORDER_REFLECT_101.
+// One block per 128x32 tile of one level of one frame (all levels in one launch, same tiling as the FAST kernel):
+// tile + apron staged in LDS by dword loads (all issued before first use), 4 pixels per thread in both passes, row-pass
+// intermediate kept in LDS as u16, output written as dwords.
+#define BT_W 128
+#define BT_H 32
+#define BT_PW (BT_W + 8)      // staged row: [tx0-4, tx0+132)
+#define BT_PH (BT_H + 6)
+__device__ __forceinline__ int reflect101(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
 __global__ void __launch_bounds__(256)
-blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int pyr_bytes, int off, int w, int h, int stride, int tiles_x)
+blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom g)
 {
-    __shared__ uint8_t  in[BT_H + 6][BT_W + 8];
-    __shared__ uint16_t hp[BT_H + 6][BT_W];
-    const int tx0 = (blockIdx.x % tiles_x) * BT_W, ty0 = (blockIdx.x / tiles_x) * BT_H;
-    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + off;
-    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        const int ly = i / (BT_W + 6), lx = i - ly * (BT_W + 6);
-        int gx = tx0 + lx - 3, gy = ty0 + ly - 3;
-        gx = gx < 0 ? -gx : gx; gx = gx >= w ? 2 * w - 2 - gx : gx; gx = max(gx, 0);     // BORDER_REFLECT_101 (tiles past the edge clamp)
-        gy = gy < 0 ? -gy : gy; gy = gy >= h ? 2 * h - 2 - gy : gy; gy = max(gy, 0);
-        in[ly][lx] = src[(size_t)gy * stride + gx];
+    __shared__ __attribute__((aligned(16))) uint8_t  in[BT_PH * BT_PW];
+    __shared__ __attribute__((aligned(16))) uint16_t hp[BT_PH * BT_W];
+    const int tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
+    const LevelGeom& L = g.L[l];
+    const int t = blockIdx.x - L.tile_off;
+    const int tx0 = (t % L.tiles_x) * BT_W, ty0 = (t / L.tiles_x) * BT_H;
+    const int w = L.w, h = L.h, stride = L.stride;
+    const uint8_t* src = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    for (int i = tid; i < BT_PH * (BT_PW / 4); i += 256) {
+        const int ly = i / (BT_PW / 4), lq = i - ly * (BT_PW / 4);
+        const int gx = tx0 - 4 + 4 * lq, gy = reflect101(ty0 - 3 + ly, h);
+        const uint8_t* row = src + (size_t)gy * stride;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < w) v = *reinterpret_cast<const uint32_t*>(row + gx);
+        else v = (uint32_t)row[reflect101(gx, w)] | ((uint32_t)row[reflect101(gx + 1, w)] << 8) | ((uint32_t)row[reflect101(gx + 2, w)] << 16) | ((uint32_t)row[reflect101(gx + 3, w)] << 24);
+        reinterpret_cast<uint32_t*>(in)[i] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
-        const int ly = i / BT_W, lx = i - ly * BT_W;
-        const uint8_t* p = &in[ly][lx];
-        hp[ly][lx] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    for (int i = tid; i < BT_PH * (BT_W / 4); i += 256) {
+        const int ly = i >> 5, lq = i & 31;
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(in + ly * BT_PW) + lq;     // dwords at x-4, x, x+4
+        const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
+        int b[10];
+        b[0] = (d0 >> 8) & 255; b[1] = (d0 >> 16) & 255; b[2] = d0 >> 24;
+        b[3] = d1 & 255; b[4] = (d1 >> 8) & 255; b[5] = (d1 >> 16) & 255; b[6] = d1 >> 24;
+        b[7] = d2 & 255; b[8] = (d2 >> 8) & 255; b[9] = (d2 >> 16) & 255;
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = 18 * (b[k] + b[k+6]) + 34 * (b[k+1] + b[k+5]) + 49 * (b[k+2] + b[k+4]) + 55 * b[k+3];
+        reinterpret_cast<uint2*>(hp + ly * BT_W)[lq] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
-    uint8_t* dst = blur + (size_t)blockIdx.y * pyr_bytes + off;
-    const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < BT_H; ly += 4) {
-        const int gx = tx0 + lx, gy = ty0 + ly;
-        if (gx < w && gy < h) {
-            int sacc = 18 * (hp[ly][lx] + hp[ly+6][lx]) + 34 * (hp[ly+1][lx] + hp[ly+5][lx]) + 49 * (hp[ly+2][lx] + hp[ly+4][lx]) + 55 * hp[ly+3][lx];
-            sacc = (sacc + 32768) >> 16;
-            dst[(size_t)gy * stride + gx] = (uint8_t)min(sacc, 255);
+    uint8_t* dst = blur + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
+        const int ly = i >> 5, lq = i & 31;
+        const int gx = tx0 + 4 * lq, gy = ty0 + ly;
+        if (gx >= stride || gy >= h) continue;
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const uint2 v = reinterpret_cast<const uint2*>(hp + (ly + k) * BT_W)[lq];
+            acc[0] += taps[k] * (v.x & 0xFFFF); acc[1] += taps[k] * (v.x >> 16); acc[2] += taps[k] * (v.y & 0xFFFF); acc[3] += taps[k] * (v.y >> 16);
         }
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t q = min((acc[k] + 32768u) >> 16, 255u); out |= (gx + k < w ? q : 0u) << (8 * k); }
+        *reinterpret_cast<uint32_t*>(dst + (size_t)gy * stride + gx) = out;
     }
 }
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s)
 {
-    for (int l = 0; l < g.nlevels; l++) {
-        const LevelGeom& L = g.L[l];
-        const int tx = (L.w + BT_W - 1) / BT_W, ty = (L.h + BT_H - 1) / BT_H;
-        blur_kernel<<<dim3(tx * ty, n), 256, 0, s>>>(pyr, blur, g.pyr_bytes, L.img_off, L.w, L.h, L.stride, tx);
-    }
+    blur_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, blur, g);
     return hipGetLastError();
 }
 

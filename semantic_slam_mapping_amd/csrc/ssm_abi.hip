@@ -643,11 +643,24 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             prof_end(c);
         }
         if (stages & SSM_STAGE_MAP) {
-            prof_begin(c, "map_fuse");
-            HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3,
-                                 in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                 (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
-            prof_end(c);
+            if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
+                prof_begin(c, "map_fuse");
+                HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3,
+                                     in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                     (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(c->d_mask), reinterpret_cast<uint16_t*>(c->d_mask) + (size_t)nb * (W >> 4) * H,
+                                     c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
+                prof_end(c);
+            } else {                     // odd widths: mask -> ordered back-projection -> insert
+                prof_begin(c, "mask");
+                HIPCHK(c, k_moving_mask(in->sem_bgr + (size_t)f0 * npix * 3, nb, W, H, c->d_mask, s)); prof_end(c);
+                prof_begin(c, "backproject");
+                HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3, c->d_mask,
+                                        in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                        c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
+                prof_begin(c, "voxel_insert");
+                HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nb * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
+                prof_end(c);
+            }
         }
     }
     c->prev_n = n;
