@@ -6,9 +6,13 @@
 // order, so equal distances resolve to the lower trainIdx).
 #include "ssm_internal.h"
 
-#define MT 1024          // threads per block = queries per pass
+#define MT 512           // threads per block; each lane owns 2 queries -> 1024 queries per pass
 #define TCH 1024         // train descriptors staged per chunk (32 KiB)
 
+// Two queries per lane (QPL): halves the LDS broadcast traffic per pair and gives the VALU two independent chains.
+// Best two kept as packed keys (distance << 16 | trainIdx): min/max/min on the packed key == "strict < in scan order"
+// (equal distances order by index), 3 VALU ops instead of a compare-select ladder.  trainIdx < 65536.
+#define QPL 2
 __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
                                            double ratio, int cap, ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout,
                                            int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
@@ -18,11 +22,14 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) base = 0;
-    for (int q0 = 0; q0 < nq; q0 += MT) {
-        const int qi = q0 + tid;
-        uint4 a = make_uint4(0, 0, 0, 0), b = a;
-        if (qi < nq) { const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); a = p[0]; b = p[1]; }
-        int d0 = 1 << 30, d1 = 1 << 30, i0 = -1, i1 = -1;
+    for (int q0 = 0; q0 < nq; q0 += MT * QPL) {
+        uint4 a[QPL], b[QPL]; uint32_t k0[QPL], k1[QPL];
+#pragma unroll
+        for (int u = 0; u < QPL; u++) {
+            const int qi = q0 + u * MT + tid;
+            a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u]; k0[u] = 0xFFFFFFFFu; k1[u] = 0xFFFFFFFFu;
+            if (qi < nq) { const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); a[u] = p[0]; b[u] = p[1]; }
+        }
         for (int t0 = 0; t0 < nt; t0 += TCH) {
             const int m = min(TCH, nt - t0);
             __syncthreads();
@@ -31,27 +38,36 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
 #pragma unroll 4
             for (int j = 0; j < m; j++) {
                 const uint4 x = tr[2 * j], y = tr[2 * j + 1];
-                int d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w)
-                      + __popc(b.x ^ y.x) + __popc(b.y ^ y.y) + __popc(b.z ^ y.z) + __popc(b.w ^ y.w);
-                const int jj = t0 + j;
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = jj; }
-                else if (d < d1) { d1 = d; i1 = jj; }
+#pragma unroll
+                for (int u = 0; u < QPL; u++) {
+                    const int d = __popc(a[u].x ^ x.x) + __popc(a[u].y ^ x.y) + __popc(a[u].z ^ x.z) + __popc(a[u].w ^ x.w)
+                                + __popc(b[u].x ^ y.x) + __popc(b[u].y ^ y.y) + __popc(b[u].z ^ y.z) + __popc(b[u].w ^ y.w);
+                    const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + j);
+                    const uint32_t hi = max(key, k0[u]);
+                    k0[u] = min(key, k0[u]); k1[u] = min(hi, k1[u]);
+                }
             }
         }
-        if (knn_idx && qi < nq) { knn_idx[2*qi] = i0; knn_idx[2*qi+1] = i1; knn_dist[2*qi] = d0; knn_dist[2*qi+1] = d1; }
-        // ratio test exactly as orb.cpp:25: float distance < double ratio * float distance, compared in double
-        const bool keep = (qi < nq) && ((double)(float)d0 < ratio * (double)(float)d1);
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wv; w++) off += wcnt[w];
-        if (keep) {
-            const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (out && k < cap) { ssm_dmatch m; m.queryIdx = qi; m.trainIdx = i0; m.imgIdx = 0; m.distance = (float)d0; out[k] = m; }
+#pragma unroll
+        for (int u = 0; u < QPL; u++) {
+            const int qi = q0 + u * MT + tid;
+            const int d0 = k0[u] >> 16, i0 = k0[u] & 0xFFFF, d1 = k1[u] >> 16, i1 = k1[u] & 0xFFFF;
+            if (knn_idx && qi < nq) { knn_idx[2*qi] = i0; knn_idx[2*qi+1] = i1; knn_dist[2*qi] = d0; knn_dist[2*qi+1] = d1; }
+            // ratio test exactly as orb.cpp:25: float distance < double ratio * float distance, compared in double
+            const bool keep = (qi < nq) && ((double)(float)d0 < ratio * (double)(float)d1);
+            const unsigned long long bal = __ballot(keep);
+            __syncthreads();
+            if (lane == 0) wcnt[wv] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wv; w++) off += wcnt[w];
+            if (keep) {
+                const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (out && k < cap) { ssm_dmatch mm; mm.queryIdx = qi; mm.trainIdx = i0; mm.imgIdx = 0; mm.distance = (float)d0; out[k] = mm; }
+            }
+            __syncthreads();
+            if (tid == 0) { int s = 0; for (int w = 0; w < MT / 64; w++) s += wcnt[w]; base += s; }
         }
-        __syncthreads();
-        if (tid == 0) { int s = 0; for (int w = 0; w < MT / 64; w++) s += wcnt[w]; base += s; }
     }
     __syncthreads();
     if (tid == 0 && nout) *nout = base;

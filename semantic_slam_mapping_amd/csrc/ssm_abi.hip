@@ -351,6 +351,7 @@ static int match_host(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, in
 {
     if (nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) FAIL(c, SSM_E_INVAL, "bad descriptor arguments");
     if (nt < 2) FAIL(c, SSM_E_TOO_FEW_TRAIN, "knnMatch(k=2) needs at least 2 train descriptors");
+    if (nt > 65535) FAIL(c, SSM_E_INVAL, "at most 65535 train descriptors per call");
     if (nq == 0) { if (n_out) *n_out = 0; return SSM_OK; }
     const size_t need = (size_t)(nq + nt) * 32 + sizeof(MatchPair) + (size_t)nq * (16 + 16) + 64;
     int r = ensure_scratch(c, need); if (r) return r;
