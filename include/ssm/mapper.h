@@ -1,0 +1,115 @@
+// ssm/mapper.h -- rgbd_tutor::Mapper (reference include/mapper.h:15-70, src/mapper.cpp): the viewer thread that turns
+// key-frames into the global voxel map.  generatePointCloud (+ semantic_motion_fuse) and the pcl::VoxelGrid filter run
+// on the GPU through ssm_backproject / ssm_voxel_filter; the schedule of Mapper::viewer (src/mapper.cpp:109-162) is
+// kept: every 15th update rebuilds from every 2nd key-frame, otherwise the last <= 5 key-frames are added, then one
+// VoxelGrid pass over the whole map.  Differences, all deliberate: no PCL visualiser window; key-frames are read under
+// keyframes_mutex (the reference polls them unlocked, mapper.cpp:114-136); the PCD path comes from `map_output`
+// instead of a hard-coded absolute path (mapper.cpp:167).  The unsigned wrap of `i > keyframes.size()-6`
+// (mapper.cpp:134: with fewer than 6 key-frames the incremental branch adds nothing) IS reproduced unless
+// mapper_fix_incremental=1.
+#pragma once
+#include "common_headers.h"
+#include "device.h"
+#include "pose_graph.h"
+#include "rgbdframe.h"
+namespace rgbd_tutor {
+class Mapper {
+public:
+    typedef pcl::PointXYZRGBA PointT;
+    typedef pcl::PointCloud<PointT> PointCloud;
+    Mapper(const ParameterReader& para, PoseGraph& graph) : parameterReader(para), poseGraph(graph) {
+        resolution = para.getData<double>("mapper_resolution", 0.1);
+        max_distance = para.getData<double>("mapper_max_distance", 40.0);
+        area_thres = para.getData<int>("motion_area_thres", 1000);
+        overlay_portion_thres = para.getData<double>("motion_overlay_portion_thres", 0.143);
+        fix_incremental = para.getData<int>("mapper_fix_incremental", 0) != 0;
+        invert_pose = para.getData<int>("mapper_invert_pose", 0) != 0;          // the commented alternative at mapper.cpp:89
+        map_output = para.getData<string>("map_output", string(""));
+        viewerThread = make_shared<thread>(bind(&Mapper::viewer, this));
+    }
+    void shutdown() { shutdownFlag = true; if (viewerThread != nullptr && viewerThread->joinable()) viewerThread->join(); }
+    void SaveMap() {}                                                          // empty in the reference too (mapper.cpp:179-187)
+    PointCloud::Ptr getGlobalMap() { unique_lock<mutex> lck(mapMutex); return globalMap; }
+    int updates() const { return cntGlobalUpdate; }
+
+    // viewer thread (src/mapper.cpp:96-171)
+    void viewer() {
+        PointCloud::Ptr map(new PointCloud);
+        while (!shutdownFlag) {
+            size_t nkf; { unique_lock<mutex> lck(poseGraph.keyframes_mutex); nkf = poseGraph.keyframes.size(); }
+            if (nkf <= (size_t)keyframe_size) { this_thread::sleep_for(chrono::milliseconds(1)); continue; }
+            vector<RGBDFrame::Ptr> kfs; { unique_lock<mutex> lck(poseGraph.keyframes_mutex); kfs = poseGraph.keyframes; }
+            auto t0 = chrono::steady_clock::now();
+            if (cntGlobalUpdate % 15 == 0) {
+                map->clear();
+                for (size_t i = 0; i < kfs.size(); i += 2) *map += *generatePointCloud(kfs[i]);
+            } else if (fix_incremental) {
+                for (int i = (int)kfs.size() - 1; i >= 0 && i > (int)kfs.size() - 6; i--) *map += *generatePointCloud(kfs[i]);
+            } else {
+                for (int i = (int)kfs.size() - 1; i >= 0 && (size_t)i > kfs.size() - 6; i--) *map += *generatePointCloud(kfs[i]);   // size_t wrap as in mapper.cpp:134
+            }
+            cntGlobalUpdate++;
+            PointCloud::Ptr tmp = voxelFilter(map);
+            keyframe_size = (int)kfs.size();
+            map->swap(*tmp);
+            { unique_lock<mutex> lck(mapMutex); globalMap.reset(new PointCloud(*map)); }
+            const double ms = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
+            cout << "points in global map: " << map->points.size() << endl;
+            cout << "Mapping cost time: " << ms << "ms" << endl;
+        }
+        if (poseGraph.shutDownFlag && !map_output.empty()) { writePCD(map_output, *map); cout << "Map saved!" << endl; }
+    }
+    // binary PCD, FIELDS x y z rgba (what pcl::PCDWriter::write emits for PointXYZRGBA)
+    static bool writePCD(const string& path, const PointCloud& c) {
+        ofstream out(path, ios::binary);
+        if (!out) return false;
+        out << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+            << "WIDTH " << c.points.size() << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << c.points.size() << "\nDATA binary\n";
+        for (const PointT& p : c.points) { out.write((const char*)&p.x, 12); out.write((const char*)&p.b, 4); }
+        return (bool)out;
+    }
+    // src/mapper.cpp:12-94: moving-class mask, gated unprojection, camera colour, pose; cached on the frame like the reference
+    PointCloud::Ptr generatePointCloud(const RGBDFrame::Ptr& frame) {
+        ssm::Device& d = device(frame->depth.cols, frame->depth.rows);
+        const int w = frame->depth.cols, h = frame->depth.rows;
+        ssm_camera cam; cam.cx = frame->camera.cx; cam.cy = frame->camera.cy; cam.fx = frame->camera.fx; cam.fy = frame->camera.fy; cam.scale = frame->camera.scale;
+        PointCloud::Ptr tmp(new PointCloud());
+        Eigen::Isometry3d T = invert_pose ? frame->getTransform().inverse() : frame->getTransform();
+        tmp->points.resize((size_t)w * h);
+        int n = 0;
+        d.check(ssm_backproject(d.ctx(), frame->depth.ptr<uint16_t>(), frame->rgb.data, frame->semantic.data, w, h, &cam, T.data(), max_distance,
+                                reinterpret_cast<ssm_point*>(tmp->points.data()), w * h, &n), "ssm_backproject");
+        tmp->points.resize(n); tmp->width = n; tmp->is_dense = false;
+        return tmp;
+    }
+    PointCloud::Ptr voxelFilter(const PointCloud::Ptr& in) {                  // pcl::VoxelGrid::filter, mapper.cpp:154-155
+        PointCloud::Ptr out(new PointCloud());
+        if (in->points.empty()) return out;
+        ssm::Device& d = device(0, 0);
+        out->points.resize(in->points.size());
+        int n = 0;
+        int rc = ssm_voxel_filter(d.ctx(), reinterpret_cast<const ssm_point*>(in->points.data()), (int)in->points.size(), (float)resolution,
+                                  reinterpret_cast<ssm_point*>(out->points.data()), (int)out->points.size(), &n);
+        if (rc == SSM_E_VOXEL_RANGE) { *out = *in; return out; }              // PCL: "Leaf size is too small ..." -> output = input
+        d.check(rc, "ssm_voxel_filter");
+        out->points.resize(n); out->width = n;
+        return out;
+    }
+protected:
+    ssm::Device& device(int w, int h) {
+        if (!dev) { if (w == 0) { w = 640; h = 480; } dev.reset(new ssm::Device(parameterReader.deviceConfig(w, h))); }
+        return *dev;
+    }
+    shared_ptr<thread> viewerThread = nullptr;
+    const ParameterReader& parameterReader;
+    PoseGraph& poseGraph;
+    unique_ptr<ssm::Device> dev;
+    PointCloud::Ptr globalMap; mutex mapMutex;
+    int keyframe_size = 0, cntGlobalUpdate = 0;
+    double resolution = 0.8, max_distance = 8.0;
+    volatile bool shutdownFlag = false;
+    bool fix_incremental = false, invert_pose = false;
+    int area_thres = 1000; double overlay_portion_thres = 0.143;
+    string map_output;
+};
+}  // namespace rgbd_tutor

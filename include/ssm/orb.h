@@ -1,0 +1,53 @@
+// ssm/orb.h -- rgbd_tutor::OrbFeature (reference include/orb.h:16-64, src/orb.cpp:16-29): same constructor, same two
+// methods.  The ORB_SLAM2 extractor + cv::BFMatcher pair is replaced by libssm_hip.so (ssm_orb_extract / ssm_match).
+#pragma once
+#include "common_headers.h"
+#include "device.h"
+#include "rgbdframe.h"
+namespace rgbd_tutor {
+class OrbFeature {
+public:
+    OrbFeature(const ParameterReader& para) : parameterReader(para) { knn_match_ratio = para.getData<double>("knn_match_ratio", 0.8); }
+    // extract features into frame->features (gray conversion, ORB, 3-D position of every keypoint): orb.h:32-53
+    void detectFeatures(RGBDFrame::Ptr& frame) const {
+        ssm::Device& d = device(frame->rgb.cols, frame->rgb.rows);
+        const int cap = ssm_orb_capacity(d.ctx());
+        vector<ssm_keypoint> kps(cap); vector<uint8_t> desc((size_t)cap * 32); vector<float> pos((size_t)cap * 3);
+        int n = 0;
+        const bool has_depth = !frame->depth.empty() && frame->depth.isContinuous();
+        d.check(ssm_orb_extract(d.ctx(), frame->rgb.data, frame->rgb.cols, frame->rgb.rows, (int)frame->rgb.step, frame->rgb.channels(),
+                                has_depth ? frame->depth.ptr<uint16_t>() : nullptr, kps.data(), desc.data(), pos.data(), cap, &n), "ssm_orb_extract");
+        for (int i = 0; i < n; i++) {
+            Feature f;
+            static_assert(sizeof(cv::KeyPoint) == sizeof(ssm_keypoint), "cv::KeyPoint layout");
+            memcpy((void*)&f.keypoint, &kps[i], sizeof(ssm_keypoint));
+            f.descriptor.create(1, 32, CV_8UC1); memcpy(f.descriptor.data, &desc[(size_t)i * 32], 32);
+            f.position = cv::Point3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);     // == frame->project2dTo3d(int(pt.x), int(pt.y)), orb.h:50
+            frame->features.push_back(f);
+        }
+    }
+    // descriptors of frame1 = query, frame2 = train; knn(2) + ratio test (src/orb.cpp:16-29)
+    vector<cv::DMatch> match(const RGBDFrame::Ptr& frame1, const RGBDFrame::Ptr& frame2) const {
+        vector<cv::DMatch> matches;
+        cv::Mat d1 = frame1->getAllDescriptors(), d2 = frame2->getAllDescriptors();
+        if (d1.rows == 0) return matches;
+        ssm::Device& d = device(frame2->rgb.cols, frame2->rgb.rows);
+        matches.resize(d1.rows);
+        int n = 0;
+        static_assert(sizeof(cv::DMatch) == sizeof(ssm_dmatch), "cv::DMatch layout");
+        d.check(ssm_match(d.ctx(), d1.data, d1.rows, d2.data, d2.rows, knn_match_ratio, reinterpret_cast<ssm_dmatch*>(matches.data()), d1.rows, &n), "ssm_match");
+        matches.resize(n);
+        return matches;
+    }
+    ssm::Device& device(int w, int h) const {     // one context per calling thread and frame geometry
+        thread_local map<pair<const void*, pair<int, int>>, unique_ptr<ssm::Device>> devs;
+        auto key = make_pair((const void*)this, make_pair(w, h));
+        auto it = devs.find(key);
+        if (it == devs.end()) it = devs.emplace(key, unique_ptr<ssm::Device>(new ssm::Device(parameterReader.deviceConfig(w, h)))).first;
+        return *it->second;
+    }
+protected:
+    const ParameterReader& parameterReader;
+    double knn_match_ratio = 0.8;
+};
+}  // namespace rgbd_tutor

@@ -1,0 +1,95 @@
+// test_host -- GPU-side checks of the C++ host classes (run by tests/test_host_cpp.py under -m gpu).
+// Prints one "PASS name" / "FAIL name" line per check; exit code = number of failures.
+#include "ssm/rgbdframe.h"
+#include "ssm/track.h"
+#include "ssm/pose_graph.h"
+#include "ssm/mapper.h"
+using namespace std;
+using namespace rgbd_tutor;
+static int fails = 0;
+#define CHECK(name, cond) do { if (cond) cout << "PASS " << name << endl; else { cout << "FAIL " << name << endl; fails++; } } while (0)
+
+int main(int argc, char** argv)
+{
+    ParameterReader para(argc > 1 ? argv[1] : "./parameters.txt");
+    CHECK("parameter_reader", para.getData<int>("orb_features") == 1000 && para.getData<double>("knn_match_ratio") == 0.8 && !para.has("#comment"));
+    bool threw = false; try { para.getData<int>("no_such_key"); } catch (const out_of_range&) { threw = true; }
+    CHECK("parameter_missing_key_throws", threw);
+
+    FrameReader reader(para, FrameReader::SYNTHETIC);
+    RGBDFrame::Ptr f0 = reader.next(), f1 = reader.next();
+    CHECK("frame_reader", f0 && f1 && f0->id == 0 && f1->id == 1 && f0->rgb.cols == 640 && f0->depth.rows == 480 && f1->T_f_w(0, 3) == 0.01);
+
+    OrbFeature orb(para);
+    orb.detectFeatures(f0); orb.detectFeatures(f1);
+    CHECK("detectFeatures", f0->features.size() > 900 && f0->features.size() <= 1024 && f0->features[0].descriptor.cols == 32);
+    bool pos_ok = true;
+    for (auto& ft : f0->features) { cv::Point3f p = f0->project2dTo3d((int)ft.keypoint.pt.x, (int)ft.keypoint.pt.y); if (!(p == ft.position)) pos_ok = false; }
+    CHECK("feature_position_is_project2dTo3d", pos_ok);
+    vector<cv::DMatch> m = orb.match(f0, f1);
+    bool asc = true; for (size_t i = 1; i < m.size(); i++) if (m[i].queryIdx <= m[i-1].queryIdx) asc = false;
+    CHECK("match", m.size() > 200 && asc && m[0].imgIdx == 0);
+    vector<cv::DMatch> self = orb.match(f0, f0);
+    bool selfok = self.size() > 0; for (auto& d : self) if (d.queryIdx != d.trainIdx || d.distance != 0) selfok = false;
+    CHECK("match_self_is_identity", selfok);
+
+    // PnP on exact synthetic correspondences: recover a known world->camera transform
+    {
+        PnPSolver pnp(para, orb);
+        Eigen::Isometry3d Tgt; const double a = 0.05;
+        Tgt(0, 0) = cos(a); Tgt(0, 2) = sin(a); Tgt(2, 0) = -sin(a); Tgt(2, 2) = cos(a); Tgt(0, 3) = 0.03; Tgt(1, 3) = -0.02; Tgt(2, 3) = 0.05;
+        vector<cv::Point3f> obj; vector<cv::Point2f> img; CAMERA_INTRINSIC_PARAMETERS k = para.getCamera();
+        unsigned s = 12345;
+        for (int i = 0; i < 200; i++) {
+            auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / 16777216.0; };
+            cv::Point3f X((float)(rnd() * 2 - 1), (float)(rnd() * 1.5 - 0.75), (float)(1.0 + rnd() * 2));
+            Eigen::Vector4d p = Tgt * Eigen::Vector4d(X.x, X.y, X.z, 1);
+            cv::Point2f u((float)(k.fx * p(0) / p(2) + k.cx), (float)(k.fy * p(1) / p(2) + k.cy));
+            if (i % 10 == 0) { u.x += 40; u.y -= 25; }                       // 10 % gross outliers
+            obj.push_back(X); img.push_back(u);
+        }
+        vector<int> inl; Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+        bool ok = pnp.solvePnP(img, obj, k, inl, T);
+        double err = 0; for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) err = max(err, fabs(T(r, c) - Tgt(r, c)));
+        CHECK("pnp_recovers_pose_and_rejects_outliers", ok && err < 1e-3 && inl.size() == 180);
+    }
+
+    // Tracker state machine on a static scene (the same frame fed three times): state OK, pose ~ identity (not exact: 3-D positions come from truncated pixel coordinates, include/orb.h:50, while the 2-D side is the scaled sub-pixel keypoint)
+    {
+        VisualOdometryStereo::parameters vo;
+        Tracker tracker(para, vo);
+        RGBDFrame::Ptr a = reader.get(5), b = reader.get(5), c = reader.get(5);
+        a->T_f_w = Eigen::Isometry3d::Identity(); b->T_f_w = a->T_f_w; c->T_f_w = a->T_f_w;
+        tracker.updateFrame(a);
+        CHECK("tracker_first_frame", tracker.getState() == Tracker::OK && tracker.referenceFrames().size() == 1);
+        Eigen::Isometry3d T1 = tracker.updateFrame(b); tracker.updateFrame(c);
+        double dev = 0; for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) dev = max(dev, fabs(T1(r, cc) - (r == cc ? 1.0 : 0.0)));
+        cout << "  static scene: state " << tracker.getState() << " dev " << dev << " matches " << tracker.lastMatches << " inliers " << tracker.lastInliers << " refs " << tracker.referenceFrames().size() << endl;
+        CHECK("tracker_static_scene", tracker.getState() == Tracker::OK && dev < 5e-3 && tracker.lastInliers > 100 && tracker.referenceFrames().size() == 3);
+    }
+
+    // PoseGraph key-frame gate + Mapper viewer thread
+    {
+        VisualOdometryStereo::parameters vo;
+        Tracker::Ptr tracker(new Tracker(para, vo));
+        PoseGraph pg(para, tracker);
+        Mapper mapper(para, pg);
+        reader.reset();
+        int inserted = 0;
+        for (int i = 0; i < 8; i++) { RGBDFrame::Ptr f = reader.next(); inserted += pg.tryInsertKeyFrame(f); }
+        CHECK("keyframe_gate", inserted == 8 && pg.keyframes.size() == 8);     // test parameters: keyframe_min_translation below the 0.01 m step
+        for (int k = 0; k < 300 && mapper.updates() < 1; k++) this_thread::sleep_for(chrono::milliseconds(10));
+        this_thread::sleep_for(chrono::milliseconds(200));
+        pg.shutdown(); mapper.shutdown();
+        Mapper::PointCloud::Ptr gm = mapper.getGlobalMap();
+        bool sorted_ok = gm && gm->points.size() > 500;
+        CHECK("mapper_viewer_builds_map", sorted_ok && mapper.updates() >= 1);
+        // the map of one update == VoxelGrid over the clouds it added (first update: every 2nd key-frame)
+        Mapper::PointCloud::Ptr c0 = mapper.generatePointCloud(pg.keyframes[0]);
+        CHECK("generatePointCloud", c0->points.size() > 100000 && c0->points[0].data3 == 1.0f);
+        ifstream pcd(para.getData<string>("map_output"), ios::binary); string line; getline(pcd, line);
+        CHECK("pcd_written", (bool)pcd && line.find(".PCD") != string::npos);
+    }
+    cout << (fails ? "FAILED " : "ALL PASSED ") << fails << endl;
+    return fails;
+}
