@@ -23,7 +23,7 @@ W, H = 640, 480
 CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
 SEED = 0x5EED0000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-VALU_LANEOPS_PEAK = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_LANEOPS_PEAK = 36.0e12    # measured on this part: scripts/ubench/valu_rate.hip (integer VALU: one wave64 op / 4 clk / SIMD)
 
 
 def algorithmic_bytes(stage, P, nkp):
@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--leaf", type=float, default=0.1)
     ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,9 +87,16 @@ def main():
     tab_cap = 1 << 20
     tab_buf = torch.empty(tab_cap * sharding.VOXEL_BYTES, dtype=torch.uint8, device=dev)
 
+    stages = 0
+    if args.segnet:
+        from semantic_slam_mapping_amd import segnet_model
+        for l, (wt, sc, sh) in enumerate(segnet_model.make_weights(1234)):
+            ctx.segnet_set_layer(l, wt, sc, sh)
+        stages = 1 | 2 | 4 | 8
+
     def step():
         ctx.map_clear()
-        out = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr(), F)
+        out = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None if args.segnet else sem.data_ptr(), pose.data_ptr(), F, stages=stages)
         if world > 1:       # merge the per-GPU voxel maps: one all-gather of the key-sorted tables
             n_local = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
             for r, (t, n) in enumerate(sharding.allgather_tables(tab_buf, n_local, dist, dev)):
@@ -137,9 +145,14 @@ def main():
         launches_per_step = stage_acc[dom][1] / args.steps
         ms_per_launch = stage_acc[dom][0] / max(stage_acc[dom][1], 1)
         frames_per_launch = F / launches_per_step
-        if dom == "match":
+        if dom == "segnet":
+            from semantic_slam_mapping_amd import segnet_model
+            tf = segnet_model.flops() * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (26 layers + pool/unpool, whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
+                    "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
+        elif dom == "match":
             pairs = sum(max(int(res["nkp"][f - 5 + r]), 0) * int(res["nkp"][f]) for f in range(F) for r in range(5) if f - 5 + r >= 0) / F
-            ach = pairs * 24 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12      # 8 x (xor + bcnt + add) lane-ops per pair
+            ach = pairs * 23 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12      # 23 VALU ops per descriptor pair (8 xor, 8 bcnt, 3 add3, key, max, min, min3/2)
             roof = {"bound": "valu_int", "kernel": "match_seq_kernel", "achieved": round(ach, 3), "peak": VALU_LANEOPS_PEAK / 1e12,
                     "unit": "Tlaneop/s", "frac": round(ach / (VALU_LANEOPS_PEAK / 1e12), 4), "traffic": None}
         else:
@@ -163,9 +176,11 @@ def main():
         line = {
             "metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 640x480 RGB-D + precomputed 12-class masks, 1k frames per GPU, ORB 1000 kp/frame, "
-                                   "5 ref frames, leaf %.2f m" % args.leaf,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.segnet else "u8", "data": "synthetic",
+            "config": {"workload": ("configs[2]: SegNet driving_webdemo fp16 on-GPU (seeded weights), synthetic 640x480 RGB-D, full pipeline, %d frames per GPU, "
+                                    "ORB 1000 kp/frame, 5 ref frames, leaf %.2f m" % (F, args.leaf)) if args.segnet else
+                                   ("configs[1]: synthetic 640x480 RGB-D + precomputed 12-class masks, 1k frames per GPU, ORB 1000 kp/frame, "
+                                    "5 ref frames, leaf %.2f m" % args.leaf),
                        "frames_per_gpu": F, "batch_frames": args.batch, "parallelism": "frame-block x%d + voxel-table all-gather" % world if world > 1 else "single GPU"},
             "mpoints_per_s": round(world * P_total * args.steps / dt / 1e6, 2),
             "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},

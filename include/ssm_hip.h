@@ -125,7 +125,8 @@ typedef struct {
     int continue_sequence;    /* 1: the last tracker_ref_frames frames of the previous call are the first refs */
     int stages;               /* bit mask of SSM_STAGE_*, 0 = all */
 } ssm_frames_dev;
-enum { SSM_STAGE_ORB = 1, SSM_STAGE_MATCH = 2, SSM_STAGE_MAP = 4 };
+enum { SSM_STAGE_ORB = 1, SSM_STAGE_MATCH = 2, SSM_STAGE_MAP = 4,
+       SSM_STAGE_SEGNET = 8 /* BASELINE configs[2]: labels come from the on-GPU SegNet instead of sem_bgr (sem_bgr may be NULL) */ };
 typedef struct {              /* DEVICE pointers owned by the context, valid until the next ssm_seq_process/destroy */
     const ssm_keypoint* kps;  /* n x cap */
     const uint8_t*  desc;     /* n x cap x 32 */
@@ -137,6 +138,29 @@ typedef struct {              /* DEVICE pointers owned by the context, valid unt
     int cap, R;
 } ssm_seq_out_dev;
 int ssm_seq_process(ssm_ctx* ctx, const ssm_frames_dev* in, ssm_seq_out_dev* out);
+
+/* ---- Classifier (include/segnet.h:22-46, src/segnet.cpp): SegNet driving_webdemo forward, fp16 MFMA, on the device.
+ * Topology is fixed (VGG-16 encoder / mirrored decoder, 26 conv3x3 layers, 12 classes, 480x360 net input); weights
+ * are DATA: the .caffemodel is not in the reference tree (README.md:25-32), so the caller supplies every layer.
+ * layer l: weight[Cout][Cin][3][3] fp32 (Caffe blob order), scale[Cout], shift[Cout] = conv bias + BatchNorm folded:
+ * y = scale * conv(x) + shift, then ReLU for every layer but the last. */
+int ssm_segnet_num_layers(void);
+int ssm_segnet_layer_shape(int layer, int* cin, int* cout, int* h, int* w);
+int ssm_segnet_set_layer(ssm_ctx* ctx, int layer, const float* weight, const float* scale, const float* shift);
+/* Classifier::Classify on one host frame (any size equal to the context geometry): Preprocess (cv::resize to 480x360,
+ * float, mean 0; segnet.cpp:130-167) -> forward -> ArgMax.  labels_net: 360*480 class ids (may be NULL).
+ * sem_bgr (may be NULL): the colour-label image at FRAME size produced like experiment/segnet.cpp:80-83,131-146
+ * (Pavement->Road remap, resize of the ids, LUT through the 12-colour palette). */
+int ssm_segnet_forward(ssm_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* labels_net, uint8_t* sem_bgr);
+/* n device frames (packed BGR); outputs are device buffers or NULL.  flags: bit0 = nearest-neighbour resize of the ids
+ * instead of the reference's bilinear-on-ids, bit1 = skip the Pavement->Road remap */
+int ssm_segnet_forward_dev(ssm_ctx* ctx, const uint8_t* bgr_dev, int n, uint8_t* labels_net_dev, uint8_t* sem_bgr_dev, int flags);
+/* single layer ops on host NHWC fp16 tensors, for exact per-op tests (integer-valued data makes fp16/fp32 exact):
+ * op 0 = conv layer `arg` on in[H][W][CinPad16] -> out[H][W][CoutPad16]; op 1 = max-pool 2x2 s2 ceil with C = arg:
+ * in[H][W][C] -> out[PH][PW][C] + code[PH][PW][C]; op 2 = unpool: in[PH][PW][C] + code -> out[H][W][C] */
+int ssm_segnet_debug_op(ssm_ctx* ctx, int op, int arg, const uint16_t* in, int H, int W, uint16_t* out, uint8_t* code);
+/* class logits (12 floats per net pixel, 360*480 pixels) of frame 0 of the most recent forward: for tolerance tests */
+int ssm_segnet_logits(ssm_ctx* ctx, float* out);
 
 /* per-stage device time of the most recent ssm_seq_process, measured with hipEvents on the context stream.
  * enable with ssm_set_profiling(ctx,1).  names/ms/launches hold cap entries; returns count in *n_out. */

@@ -59,6 +59,13 @@ SYMBOLS = {
     "ssm_map_export_table_dev": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_merge_table_dev": (_I, [_P, _P, _I]),
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
+    "ssm_segnet_num_layers": (_I, []),
+    "ssm_segnet_layer_shape": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ssm_segnet_set_layer": (_I, [_P, _I, _P, _P, _P]),
+    "ssm_segnet_forward": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "ssm_segnet_forward_dev": (_I, [_P, _P, _I, _P, _P, _I]),
+    "ssm_segnet_logits": (_I, [_P, _P]),
+    "ssm_segnet_debug_op": (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     "ssm_set_profiling": (_I, [_P, _I]),
     "ssm_get_stage_times": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I)]),
     "ssm_dev_alloc": (_I, [_P, _SZ, C.POINTER(_P)]),

@@ -19,7 +19,8 @@ VOXEL_DTYPE = np.dtype([("key", "i8"), ("sx", "i8"), ("sy", "i8"), ("sz", "i8"),
                         ("sb", "u8"), ("n", "u8"), ("hist", "u4", (12,))])
 assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
 
-STAGE_ORB, STAGE_MATCH, STAGE_MAP = 1, 2, 4
+STAGE_ORB, STAGE_MATCH, STAGE_MAP, STAGE_SEGNET = 1, 2, 4, 8
+SEG_NET_W, SEG_NET_H, SEG_CLASSES = 480, 360, 12
 
 
 class SsmError(RuntimeError):
@@ -108,6 +109,56 @@ class Context:
         r = self.cfg.knn_match_ratio if ratio is None else ratio
         self._chk(self.lib.ssm_match(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    # ---- Classifier (SegNet)
+    def segnet_layers(self):
+        out = []
+        for l in range(self.lib.ssm_segnet_num_layers()):
+            a, b, h, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            self.lib.ssm_segnet_layer_shape(l, C.byref(a), C.byref(b), C.byref(h), C.byref(w))
+            out.append((a.value, b.value, h.value, w.value))
+        return out
+
+    def segnet_set_layer(self, layer, weight, scale, shift):
+        w = np.ascontiguousarray(weight, np.float32); sc = np.ascontiguousarray(scale, np.float32); sh = np.ascontiguousarray(shift, np.float32)
+        self._chk(self.lib.ssm_segnet_set_layer(self.h, layer, _ptr(w), _ptr(sc), _ptr(sh)))
+
+    def classify(self, bgr, want_sem=True):
+        """Classifier::Classify: returns (labels 360x480 u8, colour-label image at frame size or None)"""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        labels = np.zeros((SEG_NET_H, SEG_NET_W), np.uint8)
+        sem = np.zeros((h, w, 3), np.uint8) if want_sem else None
+        self._chk(self.lib.ssm_segnet_forward(self.h, _ptr(bgr), w, h, bgr.strides[0], _ptr(labels), _ptr(sem)))
+        return labels, sem
+
+    def segnet_logits(self):
+        out = np.zeros((SEG_NET_H, SEG_NET_W, SEG_CLASSES), np.float32)
+        self._chk(self.lib.ssm_segnet_logits(self.h, _ptr(out)))
+        return out
+
+    def segnet_debug_conv(self, layer, x_hwc_f16):
+        cin, cout, _, _ = self.segnet_layers()[layer]
+        x = np.ascontiguousarray(x_hwc_f16, np.float16); h, w, c = x.shape
+        assert c == (cin + 15) // 16 * 16
+        out = np.zeros((h, w, (cout + 15) // 16 * 16), np.float16)
+        self._chk(self.lib.ssm_segnet_debug_op(self.h, 0, layer, _ptr(x), h, w, _ptr(out), None))
+        return out[:, :, :cout]
+
+    def segnet_debug_pool(self, x_hwc_f16):
+        x = np.ascontiguousarray(x_hwc_f16, np.float16); h, w, c = x.shape
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2, c), np.float16); code = np.zeros(out.shape, np.uint8)
+        self._chk(self.lib.ssm_segnet_debug_op(self.h, 1, c, _ptr(x), h, w, _ptr(out), _ptr(code)))
+        return out, code
+
+    def segnet_debug_unpool(self, x_hwc_f16, code, h, w):
+        x = np.ascontiguousarray(x_hwc_f16, np.float16); code = np.ascontiguousarray(code, np.uint8); c = x.shape[2]
+        out = np.zeros((h, w, c), np.float16)
+        self._chk(self.lib.ssm_segnet_debug_op(self.h, 2, c, _ptr(x), h, w, _ptr(out), _ptr(code)))
+        return out
+
+    def segnet_forward_dev(self, bgr_dev, n, labels_dev=None, sem_dev=None, flags=0):
+        self._chk(self.lib.ssm_segnet_forward_dev(self.h, bgr_dev, n, labels_dev, sem_dev, flags))
 
     # ---- Mapper
     def moving_mask(self, sem):

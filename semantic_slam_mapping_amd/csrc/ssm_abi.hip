@@ -23,8 +23,33 @@ struct VoxTable {           // tab[slots] | occ[slots] | counters[4]
     size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 16; }
 };
 struct StageRec { const char* name; hipEvent_t a, b; };
+// SegNet driving_webdemo: 26 conv layers; op list interleaves pools / unpools
+struct SegLayerDef { int cin, cout, h, w; };
+static const int SEG_NW = 480, SEG_NH = 360, SEG_NCLS = 12, SEG_LAYERS = 26;
+static const SegLayerDef k_seg_layers[SEG_LAYERS] = {
+    {3, 64, 360, 480}, {64, 64, 360, 480},                                   // conv1_1 conv1_2 | pool1
+    {64, 128, 180, 240}, {128, 128, 180, 240},                               // conv2_x         | pool2
+    {128, 256, 90, 120}, {256, 256, 90, 120}, {256, 256, 90, 120},           // conv3_x         | pool3
+    {256, 512, 45, 60}, {512, 512, 45, 60}, {512, 512, 45, 60},              // conv4_x         | pool4 (ceil: 23x30)
+    {512, 512, 23, 30}, {512, 512, 23, 30}, {512, 512, 23, 30},              // conv5_x         | pool5 (ceil: 12x15)
+    {512, 512, 23, 30}, {512, 512, 23, 30}, {512, 512, 23, 30},              // upsample5 | conv5_3_D conv5_2_D conv5_1_D
+    {512, 512, 45, 60}, {512, 512, 45, 60}, {512, 256, 45, 60},              // upsample4 | conv4_x_D
+    {256, 256, 90, 120}, {256, 256, 90, 120}, {256, 128, 90, 120},           // upsample3 | conv3_x_D
+    {128, 128, 180, 240}, {128, 64, 180, 240},                               // upsample2 | conv2_x_D
+    {64, 64, 360, 480}, {64, 12, 360, 480}                                   // upsample1 | conv1_2_D conv1_1_D (no BN/ReLU)
+};
 
 } // namespace
+struct SegNetState {
+    bool set[SEG_LAYERS] = {};
+    void* w[SEG_LAYERS] = {}; float* scale[SEG_LAYERS] = {}; float* shift[SEG_LAYERS] = {};
+    int cinp[SEG_LAYERS], coutp[SEG_LAYERS], coutstore[SEG_LAYERS];
+    int batch = 0;
+    void *actA = nullptr, *actB = nullptr; uint8_t* code[5] = {}; uint8_t* labels = nullptr;
+    int32_t *pre_xofs = nullptr, *pre_yofs = nullptr, *post_xofs = nullptr, *post_yofs = nullptr;
+    int16_t *pre_xa = nullptr, *pre_ya = nullptr, *post_xa = nullptr, *post_ya = nullptr;
+    uint8_t* d_sem_gen = nullptr;       // generated colour labels for the sequence path (max_batch frames)
+};
 
 struct ssm_ctx {
     std::mutex mu;
@@ -53,6 +78,8 @@ struct ssm_ctx {
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
     // voxel tables
     VoxTable map, tmp;
+    // SegNet
+    struct SegNetState* seg = nullptr;
     // profiling
     bool profiling = false;
     std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -264,6 +291,14 @@ extern "C" void ssm_destroy(ssm_ctx* c)
                      c->d_hist_tmp, c->map.tab, c->tmp.tab };
     for (void* p : ptrs) if (p) hipFree(p);
     for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); }
+    if (c->seg) {
+        SegNetState* g = c->seg;
+        void* sp[] = { g->actA, g->actB, g->labels, g->d_sem_gen, g->pre_xofs, g->pre_yofs, g->post_xofs, g->post_yofs, g->pre_xa, g->pre_ya, g->post_xa, g->post_ya,
+                       g->code[0], g->code[1], g->code[2], g->code[3], g->code[4] };
+        for (void* p : sp) if (p) hipFree(p);
+        for (int l = 0; l < SEG_LAYERS; l++) { if (g->w[l]) hipFree(g->w[l]); if (g->scale[l]) hipFree(g->scale[l]); if (g->shift[l]) hipFree(g->shift[l]); }
+        delete g;
+    }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -583,6 +618,8 @@ extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float l
 }
 
 // ---------------------------------------------------------------- device-resident sequence path
+static int seg_init(ssm_ctx* c);
+static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags);
 static int ensure_seq(ssm_ctx* c, int n)
 {
     if (n <= c->seq_cap) return SSM_OK;
@@ -614,7 +651,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     if (!in || in->n < 0) FAIL(c, SSM_E_INVAL, "bad arguments");
     const int stages = in->stages ? in->stages : (SSM_STAGE_ORB | SSM_STAGE_MATCH | SSM_STAGE_MAP);
     if ((stages & (SSM_STAGE_ORB | SSM_STAGE_MATCH)) && !in->bgr) FAIL(c, SSM_E_INVAL, "bgr is required");
-    if ((stages & SSM_STAGE_MAP) && (!in->depth || !in->sem_bgr || !in->bgr)) FAIL(c, SSM_E_INVAL, "bgr, depth and sem_bgr are required for the map stage");
+    if ((stages & SSM_STAGE_MAP) && (!in->depth || !in->bgr || (!in->sem_bgr && !(stages & SSM_STAGE_SEGNET)))) FAIL(c, SSM_E_INVAL, "bgr, depth and sem_bgr (or SSM_STAGE_SEGNET) are required for the map stage");
     const OrbGeom& g = c->g; const int R = c->R, n = in->n, W = g.W, H = g.H; hipStream_t s = c->stream;
     const size_t npix = (size_t)W * H;
     int r = ensure_seq(c, n > 0 ? n : 1); if (r) return r;
@@ -643,19 +680,27 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, s));
             prof_end(c);
         }
+        const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
+        if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
+            r = seg_init(c); if (r) return r;
+            prof_begin(c, "segnet");
+            r = seg_forward_dev(c, in->bgr + (size_t)f0 * npix * 3, nb, nullptr, c->seg->d_sem_gen, 0); if (r) return r;
+            prof_end(c);
+            sem_src = c->seg->d_sem_gen;
+        }
         if (stages & SSM_STAGE_MAP) {
             if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
                 prof_begin(c, "map_fuse");
-                HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3,
+                HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src,
                                      in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
                                      (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(c->d_mask), reinterpret_cast<uint16_t*>(c->d_mask) + (size_t)nb * (W >> 4) * H,
                                      c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
                 prof_end(c);
             } else {                     // odd widths: mask -> ordered back-projection -> insert
                 prof_begin(c, "mask");
-                HIPCHK(c, k_moving_mask(in->sem_bgr + (size_t)f0 * npix * 3, nb, W, H, c->d_mask, s)); prof_end(c);
+                HIPCHK(c, k_moving_mask(sem_src, nb, W, H, c->d_mask, s)); prof_end(c);
                 prof_begin(c, "backproject");
-                HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, in->sem_bgr + (size_t)f0 * npix * 3, c->d_mask,
+                HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src, c->d_mask,
                                         in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
                                         c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
                 prof_begin(c, "voxel_insert");
@@ -669,6 +714,181 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;
         out->npoints = c->d_npoints; out->cap = g.cap; out->R = R;
     }
+    return SSM_OK;
+}
+
+
+// ---------------------------------------------------------------- SegNet (Classifier)
+static inline uint16_t f32_to_f16(float f)
+{
+    _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u;
+}
+extern "C" int ssm_segnet_num_layers(void) { return SEG_LAYERS; }
+extern "C" int ssm_segnet_layer_shape(int l, int* cin, int* cout, int* h, int* w)
+{
+    if (l < 0 || l >= SEG_LAYERS) return SSM_E_INVAL;
+    if (cin) *cin = k_seg_layers[l].cin; if (cout) *cout = k_seg_layers[l].cout; if (h) *h = k_seg_layers[l].h; if (w) *w = k_seg_layers[l].w;
+    return SSM_OK;
+}
+static int seg_init(ssm_ctx* c)
+{
+    if (c->seg) return SSM_OK;
+    SegNetState* g = new SegNetState();
+    c->seg = g;
+    for (int l = 0; l < SEG_LAYERS; l++) {
+        g->cinp[l] = (k_seg_layers[l].cin + 15) & ~15; g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
+        g->coutstore[l] = (k_seg_layers[l].cout + 15) & ~15;            // the next layer reads multiples of 16 channels
+    }
+    g->batch = c->B < 4 ? c->B : 4;
+    const size_t act = (size_t)g->batch * SEG_NW * SEG_NH * 64 * 2;
+    uint8_t* p;
+    int r = dalloc(c, &p, act); if (r) return r; g->actA = p;
+    r = dalloc(c, &p, act); if (r) return r; g->actB = p;
+    const int ph[5] = {180, 90, 45, 23, 12}, pw[5] = {240, 120, 60, 30, 15}, pc[5] = {64, 128, 256, 512, 512};
+    for (int i = 0; i < 5; i++) DALLOC(c, g->code[i], (size_t)g->batch * ph[i] * pw[i] * pc[i]);
+    DALLOC(c, g->labels, (size_t)g->batch * SEG_NW * SEG_NH);
+    DALLOC(c, g->d_sem_gen, (size_t)c->B * c->g.W * c->g.H * 3);
+    auto up = [&](int ssize, int dsize, int32_t** o, int16_t** a) -> int {
+        std::vector<int32_t> ofs; std::vector<int16_t> co; resize_tables(ssize, dsize, ofs, co);
+        int rr = dalloc(c, o, ofs.size()); if (rr) return rr; rr = dalloc(c, a, co.size()); if (rr) return rr;
+        if (hipMemcpy(*o, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(*a, co.data(), co.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { c->err = "segnet table upload"; return SSM_E_HIP; }
+        return SSM_OK;
+    };
+    if ((r = up(c->g.W, SEG_NW, &g->pre_xofs, &g->pre_xa)) || (r = up(c->g.H, SEG_NH, &g->pre_yofs, &g->pre_ya)) ||
+        (r = up(SEG_NW, c->g.W, &g->post_xofs, &g->post_xa)) || (r = up(SEG_NH, c->g.H, &g->post_yofs, &g->post_ya))) return r;
+    return SSM_OK;
+}
+extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, const float* scale, const float* shift)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (l < 0 || l >= SEG_LAYERS || !weight || !scale || !shift) FAIL(c, SSM_E_INVAL, "bad arguments");
+    int r = seg_init(c); if (r) return r;
+    SegNetState* g = c->seg;
+    const int cin = k_seg_layers[l].cin, cout = k_seg_layers[l].cout, cinp = g->cinp[l], coutp = g->coutp[l];
+    std::vector<uint16_t> w((size_t)coutp * 9 * cinp, 0);            // [CoutPad][tap][CinPad], tap = ky*3 + kx
+    for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++)
+        w[((size_t)o * 9 + t) * cinp + i] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+    if (!g->w[l]) { uint16_t* p; r = dalloc(c, &p, w.size()); if (r) return r; g->w[l] = p; DALLOC(c, g->scale[l], coutp); DALLOC(c, g->shift[l], coutp); }
+    std::vector<float> sc(coutp, 0.f), sh(coutp, 0.f);
+    for (int o = 0; o < cout; o++) { sc[o] = scale[o]; sh[o] = shift[o]; }
+    HIPCHK(c, hipMemcpy(g->w[l], w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g->scale[l], sc.data(), coutp * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g->shift[l], sh.data(), coutp * 4, hipMemcpyHostToDevice));
+    g->set[l] = true;
+    return SSM_OK;
+}
+// forward for nb <= seg->batch device frames already pre-processed into actA; leaves logits in the returned buffer
+static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
+{
+    SegNetState* g = c->seg; hipStream_t s = c->stream;
+    void* cur = g->actA; void* nxt = g->actB;
+    auto conv = [&](int l) -> int {
+        const SegLayerDef& d = k_seg_layers[l];
+        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, g->coutp[l], g->coutstore[l], l != SEG_LAYERS - 1, s));
+        std::swap(cur, nxt); return SSM_OK;
+    };
+    auto pool = [&](int i, int H, int W, int C) -> int { HIPCHK(c, k_segnet_pool(cur, nb, H, W, C, nxt, g->code[i], s)); std::swap(cur, nxt); return SSM_OK; };
+    auto unpool = [&](int i, int PH, int PW, int C, int H, int W) -> int { HIPCHK(c, k_segnet_unpool(cur, g->code[i], nb, PH, PW, C, nxt, H, W, s)); std::swap(cur, nxt); return SSM_OK; };
+    int r;
+    if ((r = conv(0)) || (r = conv(1)) || (r = pool(0, 360, 480, 64))) return r;
+    if ((r = conv(2)) || (r = conv(3)) || (r = pool(1, 180, 240, 128))) return r;
+    if ((r = conv(4)) || (r = conv(5)) || (r = conv(6)) || (r = pool(2, 90, 120, 256))) return r;
+    if ((r = conv(7)) || (r = conv(8)) || (r = conv(9)) || (r = pool(3, 45, 60, 512))) return r;
+    if ((r = conv(10)) || (r = conv(11)) || (r = conv(12)) || (r = pool(4, 23, 30, 512))) return r;
+    if ((r = unpool(4, 12, 15, 512, 23, 30)) || (r = conv(13)) || (r = conv(14)) || (r = conv(15))) return r;
+    if ((r = unpool(3, 23, 30, 512, 45, 60)) || (r = conv(16)) || (r = conv(17)) || (r = conv(18))) return r;
+    if ((r = unpool(2, 45, 60, 256, 90, 120)) || (r = conv(19)) || (r = conv(20)) || (r = conv(21))) return r;
+    if ((r = unpool(1, 90, 120, 128, 180, 240)) || (r = conv(22)) || (r = conv(23))) return r;
+    if ((r = unpool(0, 180, 240, 64, 360, 480)) || (r = conv(24)) || (r = conv(25))) return r;
+    *logits_out = cur;
+    return SSM_OK;
+}
+static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags)
+{
+    int r = seg_init(c); if (r) return r;
+    SegNetState* g = c->seg;
+    for (int l = 0; l < SEG_LAYERS; l++) if (!g->set[l]) FAIL(c, SSM_E_INVAL, "SegNet layer " + std::to_string(l) + " has no weights (ssm_segnet_set_layer)");
+    const int W = c->g.W, H = c->g.H; hipStream_t s = c->stream;
+    for (int f0 = 0; f0 < n; f0 += g->batch) {
+        const int nb = n - f0 < g->batch ? n - f0 : g->batch;
+        HIPCHK(c, k_segnet_prep(bgr + (size_t)f0 * W * H * 3, nb, W, H, SEG_NW, SEG_NH, g->pre_xofs, g->pre_xa, g->pre_yofs, g->pre_ya, g->actA, s));
+        void* logits = nullptr;
+        r = seg_forward_core(c, nb, &logits); if (r) return r;
+        HIPCHK(c, k_segnet_argmax(logits, nb, SEG_NW * SEG_NH, g->coutstore[SEG_LAYERS - 1], SEG_NCLS, g->labels, s));
+        if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net + (size_t)f0 * SEG_NW * SEG_NH, g->labels, (size_t)nb * SEG_NW * SEG_NH, hipMemcpyDeviceToDevice, s));
+        if (sem_bgr) HIPCHK(c, k_segnet_color(g->labels, nb, SEG_NW, SEG_NH, W, H, g->post_xofs, g->post_xa, g->post_yofs, g->post_ya,
+                                              !(flags & 2), flags & 1, sem_bgr + (size_t)f0 * W * H * 3, nullptr, s));
+    }
+    return SSM_OK;
+}
+extern "C" int ssm_segnet_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!bgr || n < 0) FAIL(c, SSM_E_INVAL, "bad arguments");
+    return seg_forward_dev(c, bgr, n, labels_net, sem_bgr, flags);
+}
+extern "C" int ssm_segnet_forward(ssm_ctx* c, const uint8_t* bgr, int w, int h, int stride, uint8_t* labels_net, uint8_t* sem_bgr)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!bgr) FAIL(c, SSM_E_INVAL, "null argument");
+    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
+    if (stride < w * 3) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
+    HIPCHK(c, hipMemcpy2DAsync(c->d_in_img, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
+    int r = ensure_scratch(c, (size_t)SEG_NW * SEG_NH); if (r) return r;
+    r = seg_forward_dev(c, c->d_in_img, 1, labels_net ? (uint8_t*)c->d_scratch : nullptr, sem_bgr ? c->d_in_sem : nullptr, 0); if (r) return r;
+    if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net, c->d_scratch, (size_t)SEG_NW * SEG_NH, hipMemcpyDeviceToHost, c->stream));
+    if (sem_bgr) HIPCHK(c, hipMemcpyAsync(sem_bgr, c->d_in_sem, (size_t)w * h * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* in, int H, int W, uint16_t* out, uint8_t* code)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!in || !out || H < 1 || W < 1 || (size_t)H * W > (size_t)SEG_NW * SEG_NH) FAIL(c, SSM_E_INVAL, "bad arguments");
+    int r = seg_init(c); if (r) return r;
+    SegNetState* g = c->seg; hipStream_t s = c->stream;
+    const int PH = (H + 1) / 2, PW = (W + 1) / 2;
+    if (op == 0) {
+        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg]) FAIL(c, SSM_E_INVAL, "layer not set");
+        HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)H * W * g->cinp[arg] * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, g->coutp[arg], g->coutstore[arg], arg != SEG_LAYERS - 1, s));
+        HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)H * W * g->coutstore[arg] * 2, hipMemcpyDeviceToHost, s));
+    } else if (op == 1 || op == 2) {
+        const int C = arg;
+        if (C < 8 || C > 512 || (C & 7) || !code) FAIL(c, SSM_E_INVAL, "bad channel count");
+        r = ensure_scratch(c, (size_t)PH * PW * C); if (r) return r;
+        uint8_t* dcode = (uint8_t*)c->d_scratch;
+        if (op == 1) {
+            HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)H * W * C * 2, hipMemcpyHostToDevice, s));
+            HIPCHK(c, k_segnet_pool(g->actA, 1, H, W, C, g->actB, dcode, s));
+            HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)PH * PW * C * 2, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(code, dcode, (size_t)PH * PW * C, hipMemcpyDeviceToHost, s));
+        } else {
+            HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)PH * PW * C * 2, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(dcode, code, (size_t)PH * PW * C, hipMemcpyHostToDevice, s));
+            HIPCHK(c, k_segnet_unpool(g->actA, dcode, 1, PH, PW, C, g->actB, H, W, s));
+            HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)H * W * C * 2, hipMemcpyDeviceToHost, s));
+        }
+    } else FAIL(c, SSM_E_INVAL, "unknown op");
+    HIPCHK(c, hipStreamSynchronize(s));
+    return SSM_OK;
+}
+extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
+{
+    if (!c || !out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!c->seg) FAIL(c, SSM_E_INVAL, "no forward has run");
+    // the last conv wrote into whichever ping-pong buffer 26 convs + 10 pool/unpool swaps end in: actA (even number of swaps)
+    const int cs = c->seg->coutstore[SEG_LAYERS - 1];
+    std::vector<uint16_t> h((size_t)SEG_NW * SEG_NH * cs);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h.data(), c->seg->actA, h.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < (size_t)SEG_NW * SEG_NH; p++)
+        for (int k = 0; k < SEG_NCLS; k++) { _Float16 v; memcpy(&v, &h[p * cs + k], 2); out[p * SEG_NCLS + k] = (float)v; }
     return SSM_OK;
 }
 

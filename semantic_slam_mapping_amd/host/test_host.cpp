@@ -4,6 +4,7 @@
 #include "ssm/track.h"
 #include "ssm/pose_graph.h"
 #include "ssm/mapper.h"
+#include "ssm/segnet.h"
 using namespace std;
 using namespace rgbd_tutor;
 static int fails = 0;
@@ -89,6 +90,16 @@ int main(int argc, char** argv)
         CHECK("generatePointCloud", c0->points.size() > 100000 && c0->points[0].data3 == 1.0f);
         ifstream pcd(para.getData<string>("map_output"), ios::binary); string line; getline(pcd, line);
         CHECK("pcd_written", (bool)pcd && line.find(".PCD") != string::npos);
+    }
+    // Classifier (SegNet) from a weight file, when the test harness provides one
+    if (argc > 2) {
+        Classifier classifier(argv[2], "/nonexistent/semantic12.txt");
+        std::vector<Prediction> pr = classifier.Classify(f0->rgb);
+        bool ok = pr.size() == 360u * 480u; int mx = 0; for (auto& q : pr) { if (q.second < 0 || q.second > 11) ok = false; mx = max(mx, q.second); }
+        cv::Mat sem = classifier.ColorLabels(f0->rgb);
+        CHECK("classifier_classify", ok && mx > 0 && sem.rows == 480 && sem.cols == 640 && sem.channels() == 3);
+        bool threw2 = false; try { Classifier bad("/nonexistent.ssmw", "x"); } catch (const runtime_error&) { threw2 = true; }
+        CHECK("classifier_missing_model_throws", threw2);
     }
     cout << (fails ? "FAILED " : "ALL PASSED ") << fails << endl;
     return fails;

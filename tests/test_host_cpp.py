@@ -1,6 +1,7 @@
 """The C++ host layer (include/ssm/*.h: the reference's class names over the C ABI) and the exp_mapping driver."""
 import os
 import subprocess
+import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,7 @@ def test_host_layer_builds_and_keeps_reference_names():
                         "void setTransform(const Eigen::Isometry3d& T)", "Eigen::Isometry3d getTransform()", "class FrameReader", "RGBDFrame::Ptr next()"],
         "pose_graph.h": ["bool tryInsertKeyFrame(RGBDFrame::Ptr& frame)", "vector<RGBDFrame::Ptr> keyframes"],
         "parameter_reader.h": ["class ParameterReader", "T getData(const string& key) const", "CAMERA_INTRINSIC_PARAMETERS getCamera() const"],
+        "segnet.h": ["class Classifier", "Classifier()", "std::vector<Prediction> Classify(const cv::Mat& img, int N = 1)"],
         "pnp.h": ["bool solvePnP(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj", "bool solvePnPLazy("],
     }
     for f, needles in want.items():
@@ -34,10 +36,12 @@ def test_host_layer_builds_and_keeps_reference_names():
 @pytest.mark.gpu
 def test_host_classes_on_gpu():
     subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt")], capture_output=True, text=True, timeout=300)
+    wfile = "/tmp/ssm_test_segnet.ssmw"
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "export_ssmw.py"), wfile], check=True)
+    r = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), wfile], capture_output=True, text=True, timeout=300)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert "ALL PASSED" in r.stdout and r.returncode == 0
-    assert r.stdout.count("PASS ") >= 14
+    assert r.stdout.count("PASS ") >= 16
 
 
 @pytest.mark.gpu
