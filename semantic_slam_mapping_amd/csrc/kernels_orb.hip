@@ -18,6 +18,7 @@ __global__ void gray_kernel(const uint8_t* __restrict__ img, int W, int H, int s
     const uint8_t* src = img + (size_t)blockIdx.y * W * H * 3 + ((size_t)y * W + x) * 3;
     uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_bytes + (size_t)y * stride0 + x;
     uint32_t out = 0;
+    if (x >= W) { *reinterpret_cast<uint32_t*>(dst) = 0; return; }      // row padding
     if (VEC) {
         const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
         uint32_t a = s[0], b = s[1], c = s[2];
@@ -63,44 +64,63 @@ hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g,
 }
 
 // ------------------------------------------------------------------ K2: pyramid level from the previous level
-// cv::resize INTER_LINEAR 8u fixed point (coefficient tables built on the host, oracle/orb.c sso_resize_tables)
-__global__ void resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int sh, int sstride,
-                              int dst_off, int dw, int dh, int dstride,
-                              const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
-                              const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+// cv::resize INTER_LINEAR 8u fixed point (coefficient tables built on the host, oracle/orb.c sso_resize_tables).
+// The per-CU texture-address unit spends >= 16 cycles on every vector-memory instruction whatever its width, so the
+// source rows a block needs are staged in LDS with 16-byte loads and the results leave as 16-byte stores:
+// one block = PY_ROWS output rows x the full output width; 16 output pixels per thread-iteration.
+#define PY_ROWS 8
+__global__ void __launch_bounds__(256)
+resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int sh, int sstride,
+              int dst_off, int dw, int dh, int dstride,
+              const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
+              const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
 {
-    const int quads = dstride >> 2;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= quads * dh) return;
-    const int y = q / quads, x0 = (q - y * quads) << 2;
-    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + src_off;
-    const int sy0 = yofs[y], sy1 = min(sy0 + 1, sh - 1);
-    const int b0 = ya[2*y], b1 = ya[2*y+1];
-    const uint8_t* r0 = src + (size_t)sy0 * sstride;
-    const uint8_t* r1 = src + (size_t)sy1 * sstride;
-    uint32_t out = 0;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];      // [xtab: dw x u32 (ofs | a0 << 16)] [xa1: dw x u16] [rows: nrows x sstride]
+    uint32_t* xt = reinterpret_cast<uint32_t*>(smem);
+    uint16_t* x1 = reinterpret_cast<uint16_t*>(smem + (size_t)dstride * 4);
+    uint8_t* rows = smem + (size_t)dstride * 6;                         // dstride % 16 == 0 keeps this 16-B aligned
+    const int y0 = blockIdx.x * PY_ROWS, y1 = min(y0 + PY_ROWS, dh);
+    const int sy_first = yofs[y0], sy_last = min(yofs[y1 - 1] + 1, sh - 1);
+    const int nrows = sy_last - sy_first + 1;
+    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + src_off + (size_t)sy_first * sstride;
+    const int nvec = (nrows * sstride) >> 4;                            // strides are multiples of 16
+    for (int i = threadIdx.x; i < nvec; i += 256) reinterpret_cast<uint4*>(rows)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (int x = threadIdx.x; x < dw; x += 256) { xt[x] = (uint32_t)xofs[x] | ((uint32_t)(uint16_t)xa[2*x] << 16); x1[x] = (uint16_t)xa[2*x+1]; }
+    __syncthreads();
+    uint8_t* dst = pyr + (size_t)blockIdx.y * pyr_bytes + dst_off;
+    const int groups = dstride >> 4;                                    // 16-pixel groups per output row
+    for (int i = threadIdx.x; i < groups * (y1 - y0); i += 256) {
+        const int ry = i / groups, g = i - ry * groups, y = y0 + ry, x0 = g << 4;
+        const int syA = yofs[y], syB = min(syA + 1, sh - 1);
+        const int b0 = ya[2*y], b1 = ya[2*y+1];
+        const uint8_t* r0 = rows + (syA - sy_first) * sstride;
+        const uint8_t* r1 = rows + (syB - sy_first) * sstride;
+        uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int x = x0 + i;
-        if (x < dw) {
-            const int sx0 = xofs[x], sx1 = min(sx0 + 1, sw - 1);
-            const int a0 = xa[2*x], a1 = xa[2*x+1];
-            const int h0 = r0[sx0] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx0] * a0 + r1[sx1] * a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 255) << (8 * i);
+        for (int k = 0; k < 16; k++) {
+            const int x = x0 + k;
+            if (x < dw) {
+                const uint32_t t = xt[x];
+                const int sx0 = t & 0xFFFF, sx1 = min(sx0 + 1, sw - 1);
+                const int a0 = t >> 16, a1 = x1[x];
+                const int h0 = r0[sx0] * a0 + r0[sx1] * a1;
+                const int h1 = r1[sx0] * a0 + r1[sx1] * a1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                o[k >> 2] |= (uint32_t)(v & 255) << (8 * (k & 3));
+            }
         }
+        *reinterpret_cast<uint4*>(dst + (size_t)y * dstride + x0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    *reinterpret_cast<uint32_t*>(pyr + (size_t)blockIdx.y * pyr_bytes + dst_off + (size_t)y * dstride + x0) = out;
 }
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
                      const int32_t* const* yofs, const int16_t* const* ya, hipStream_t s)
 {
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
-        dim3 grid(((b.stride >> 2) * b.h + 255) / 256, n);
-        resize_kernel<<<grid, 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.w, a.h, a.stride, b.img_off, b.w, b.h, b.stride,
-                                           xofs[l], xa[l], yofs[l], ya[l]);
+        const int max_rows = (int)((PY_ROWS - 1) * ((double)a.h / b.h)) + 4;     // source rows one block can touch
+        dim3 grid((b.h + PY_ROWS - 1) / PY_ROWS, n);
+        resize_kernel<<<grid, 256, (size_t)max_rows * a.stride + (size_t)b.stride * 6, s>>>(pyr, g.pyr_bytes, a.img_off, a.w, a.h, a.stride, b.img_off, b.w, b.h, b.stride,
+                                                                     xofs[l], xa[l], yofs[l], ya[l]);
     }
     return hipGetLastError();
 }

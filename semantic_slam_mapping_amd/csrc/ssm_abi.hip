@@ -127,7 +127,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         LevelGeom& L = g.L[l];
         L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
         if (L.w < 2 * SSM_EDGE + 8 + 30 || L.h < 2 * SSM_EDGE + 8 + 30) { err = "pyramid level too small for the ORB border; lower orb_levels"; return SSM_E_INVAL; }
-        L.stride = (L.w + 3) & ~3; L.img_off = off; off += (L.stride * L.h + 15) & ~15;
+        L.stride = (L.w + 15) & ~15; L.img_off = off; off += L.stride * L.h;      /* rows 16-B aligned: wide loads/stores everywhere */
         L.minBX = SSM_EDGE - 3; L.minBY = SSM_EDGE - 3; L.maxBX = L.w - SSM_EDGE + 3; L.maxBY = L.h - SSM_EDGE + 3;
         const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);

@@ -12,7 +12,7 @@
 #define SSM_VOX_EMPTY ((int64_t)-1)
 
 struct LevelGeom {
-    int w, h, stride;          // level image; rows padded to a multiple of 4 bytes
+    int w, h, stride;          // level image; rows padded to a multiple of 16 bytes
     int img_off;               // byte offset inside one frame's pyramid buffer (16-B aligned)
     int nCols, nRows, wCell, hCell;   // FAST cell grid (ComputeKeyPointsOctTree, W = 30)
     int cell_off;              // first flattened cell id of this level
