@@ -604,13 +604,23 @@ __device__ __forceinline__ int wave_sum(int v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// One wave per selected keypoint.  The per-CU texture-address unit charges >= 16 cycles per vector-memory instruction
+// whatever its width, and byte-granular patch reads made this kernel exactly TA-bound; so each wave first stages its two
+// patches in LDS with ALIGNED DWORD loads (31 rows of the level image for the moments, 37 rows of the blurred image for
+// the steered BRIEF reach of +-18), then works on LDS bytes.  ~12 vector-memory instructions per keypoint instead of ~60.
+#define DP_ROWS_O 31
+#define DP_DW_O 10          // dwords per staged row of the orientation patch (covers x-15 .. x+15 from an aligned base)
+#define DP_ROWS_B 37
+#define DP_DW_B 11          // dwords per staged row of the blurred patch (x-18 .. x+18)
 __global__ void __launch_bounds__(256)
 describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, const uint32_t* __restrict__ sel,
                 const int32_t* __restrict__ nsel, const int8_t* __restrict__ pattern, const uint16_t* __restrict__ depth, ssm_camera cam,
                 ssm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, float* __restrict__ pos3d, int32_t* __restrict__ nkp)
 {
-    const int lane = threadIdx.x & 63, f = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t po[4][DP_ROWS_O * DP_DW_O];
+    __shared__ uint32_t pb[4][DP_ROWS_B * DP_DW_B];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wv;
     const int32_t* ns = nsel + f * g.nlevels;
     if (slot == 0 && lane == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
     if (slot >= g.sel_total) return;
@@ -623,8 +633,24 @@ describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __res
     for (int k = 0; k < l; k++) oidx += ns[k];
     const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
     const int x = pk & 4095, y = (pk >> 12) & 4095, score = pk >> 24;
-    const uint8_t* im = pyr + (size_t)f * g.pyr_bytes + L.img_off + (size_t)y * L.stride + x;
-    const uint8_t* bl = blur + (size_t)f * g.pyr_bytes + L.img_off + (size_t)y * L.stride + x;
+    // ---- stage both patches (keypoints sit >= 19 px from every border, so all rows/columns exist; rows are 16-B aligned)
+    const uint8_t* imrow = pyr + (size_t)f * g.pyr_bytes + L.img_off;
+    const uint8_t* blrow = blur + (size_t)f * g.pyr_bytes + L.img_off;
+    const int xo0 = (x - 15) & ~3, xb0 = (x - 18) & ~3;             // aligned first column of each staged patch
+    for (int e = lane; e < DP_ROWS_O * DP_DW_O; e += 64) {
+        const int r = e / DP_DW_O, c = e - r * DP_DW_O;
+        const int gx = xo0 + 4 * c;
+        po[wv][e] = gx < L.stride ? *reinterpret_cast<const uint32_t*>(imrow + (size_t)(y - 15 + r) * L.stride + gx) : 0u;
+    }
+    for (int e = lane; e < DP_ROWS_B * DP_DW_B; e += 64) {
+        const int r = e / DP_DW_B, c = e - r * DP_DW_B;
+        const int gx = xb0 + 4 * c;
+        pb[wv][e] = gx < L.stride ? *reinterpret_cast<const uint32_t*>(blrow + (size_t)(y - 18 + r) * L.stride + gx) : 0u;
+    }
+    const uint8_t* ob = reinterpret_cast<const uint8_t*>(po[wv]) + 15 * (DP_DW_O * 4) + (x - xo0);      // centre pixel of the orientation patch
+    const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv]) + 18 * (DP_DW_B * 4) + (x - xb0);      // centre pixel of the blurred patch
+    __builtin_amdgcn_s_waitcnt(0);                                   // this wave's own LDS writes are complete before it reads them back
+    __builtin_amdgcn_wave_barrier();
     // intensity centroid over the radius-15 disc: lane -> (row, half-row)
     int m10 = 0, m01 = 0;
     {
@@ -632,7 +658,7 @@ describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __res
         if (r <= 2 * SSM_HALF_PATCH) {
             const int d = g.umax[v < 0 ? -v : v];
             const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-            const uint8_t* row = im + v * L.stride;
+            const uint8_t* row = ob + v * (DP_DW_O * 4);
             int si = 0, sui = 0;
             for (int u = u0; u <= u1; u++) { const int p = row[u]; si += p; sui += u * p; }
             m10 = sui; m01 = v * si;
@@ -640,17 +666,19 @@ describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __res
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-    // steered BRIEF: lane -> 4 of the 256 comparisons
+    // steered BRIEF: lane -> 4 of the 256 comparisons (its 16 pattern bytes arrive in one 16-byte load)
     float sb, ca;
     contract_sincos(angle * (float)(3.14159265358979323846 / 180.f), &sb, &ca);
+    const uint4 pw = *reinterpret_cast<const uint4*>(pattern + lane * 16);
+    const uint32_t pwv[4] = {pw.x, pw.y, pw.z, pw.w};
     uint32_t nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int8_t* q = pattern + (lane * 4 + k) * 4;
-        const float x0 = (float)q[0], y0 = (float)q[1], x1 = (float)q[2], y1 = (float)q[3];
+        const uint32_t q = pwv[k];
+        const float x0 = (float)(int8_t)(q & 255), y0 = (float)(int8_t)((q >> 8) & 255), x1 = (float)(int8_t)((q >> 16) & 255), y1 = (float)(int8_t)(q >> 24);
         const int yy0 = __float2int_rn(x0 * sb + y0 * ca), xx0 = __float2int_rn(x0 * ca - y0 * sb);
         const int yy1 = __float2int_rn(x1 * sb + y1 * ca), xx1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = bl[yy0 * L.stride + xx0], t1 = bl[yy1 * L.stride + xx1];
+        const int t0 = bb[yy0 * (DP_DW_B * 4) + xx0], t1 = bb[yy1 * (DP_DW_B * 4) + xx1];
         nib |= (uint32_t)(t0 < t1) << k;
     }
     // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word
