@@ -43,6 +43,21 @@ def algorithmic_bytes(stage, P, nkp):
     }.get(stage, 0)
 
 
+STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
+                 "blur": ["blur_kernel"], "describe": ["describe_kernel"], "match": ["match_seq_kernel"],
+                 "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel"]}
+
+
+def measured_traffic(stage, frames_per_launch):
+    """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None"""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+        return round(sum(k[n]["total_bytes_per_frame_fetch_x2"] for n in STAGE_KERNELS[stage]) * frames_per_launch)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +174,9 @@ def main():
             gb = algorithmic_bytes(dom, P, nkp) * frames_per_launch / 1e9
             ach = gb / (ms_per_launch * 1e-3)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, frames_per_launch),
+                    "algorithmic_bytes_per_launch": round(gb * 1e9),
+                    "note": "integer/byte kernel limited by VALU issue (measured 36 T lane-op/s) and LDS, not HBM: see DESIGN.md s.4"}
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
         cpu = None
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:

@@ -72,6 +72,8 @@ private:
 };
 template <class T> using Ptr = std::shared_ptr<T>;
 }  // namespace cv
+typedef unsigned char uchar;      // OpenCV exports these at global scope too (the reference uses them unqualified)
+typedef unsigned short ushort;
 #endif
 
 #ifdef SSM_WITH_EIGEN

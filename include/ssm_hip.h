@@ -139,6 +139,27 @@ typedef struct {              /* DEVICE pointers owned by the context, valid unt
 } ssm_seq_out_dev;
 int ssm_seq_process(ssm_ctx* ctx, const ssm_frames_dev* in, ssm_seq_out_dev* out);
 
+/* ---- QuadFeatureMatch (include/quadmatcher.hpp:51-136, src/quadmatcher.cpp): the stereo quad matcher of the KITTI path
+ * (Tracker::estimateVO, src/track.cpp:45-55).  Images are 8-bit gray, any size (buffers are re-sized on demand). */
+/* layout-identical to struct pmatch (include/quadmatcher.hpp:33-49), 52 bytes */
+typedef struct { float u1p, v1p; int32_t i1p; float u2p, v2p; int32_t i2p; float u1c, v1c; int32_t i1c; float u2c, v2c; int32_t i2c; int16_t dis_c, dis_p; } ssm_pmatch;
+/* init(DET_GFTT, ..) + detectFeature() + circularMatching() in tracking mode (mode_track = true): GFTT (quality 0.04,
+ * minDistance 8, max_corners: cv default 1000) on the current-left image, four pyramidal LK passes lc->rc, rc->rp,
+ * rp->lp, lc->lp (11x11 window, 3 pyramid levels, <= 200 iterations, eps 0.01, min-eigen threshold 1e-6),
+ * filteringTracks.  out: quadmatches in feature order. */
+int ssm_quad_track(ssm_ctx* ctx, const uint8_t* lc, const uint8_t* rc, const uint8_t* lp, const uint8_t* rp, int w, int h, int stride,
+                   int max_corners, ssm_pmatch* out, int cap, int* n_out);
+/* the two OpenCV calls on their own: cv::goodFeaturesToTrack (blockSize 3, no Harris) and cv::calcOpticalFlowPyrLK
+ * (win 11x11, maxLevel 3, OPTFLOW_LK_GET_MIN_EIGENVALS).  pts arrays hold (x, y) float pairs. */
+int ssm_gftt(ssm_ctx* ctx, const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance,
+             float* pts, int cap, int* n_out);
+int ssm_lk_track(ssm_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
+                 float* next_pts, uint8_t* status, float* err, int max_count, double epsilon, double min_eig_threshold);
+/* QuadFeatureMatch::matching on binary descriptors (:41-83, caldistance :525-544): windowed brute-force nearest
+ * neighbour, one DMatch per query (trainIdx -1 when unmatched), kp = (x, y) float pairs, descriptors 32 B */
+int ssm_window_match(ssm_ctx* ctx, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
+                     int search_width, int search_height, float distance_threshold, ssm_dmatch* out);
+
 /* ---- Classifier (include/segnet.h:22-46, src/segnet.cpp): SegNet driving_webdemo forward, fp16 MFMA, on the device.
  * Topology is fixed (VGG-16 encoder / mirrored decoder, 26 conv3x3 layers, 12 classes, 480x360 net input); weights
  * are DATA: the .caffemodel is not in the reference tree (README.md:25-32), so the caller supplies every layer.

@@ -104,6 +104,22 @@ void sso_voxel_export(const sso_voxel* tab, int m, sso_point* out);
  * -2 if the PCL index-overflow guard would trip (dx*dy*dz > INT_MAX: PCL returns the input unfiltered) */
 int  sso_voxel_filter(const sso_point* pts, int n, float leaf, sso_point* out, int cap);
 
+/* ---------------- a5/a6 stereo quad-matcher (src/quadmatcher.cpp) ---------------- */
+/* layout-identical to struct pmatch (include/quadmatcher.hpp:33-49): 52 bytes */
+typedef struct { float u1p, v1p; int32_t i1p; float u2p, v2p; int32_t i2p; float u1c, v1c; int32_t i1c; float u2c, v2c; int32_t i2c; int16_t dis_c, dis_p; } sso_pmatch;
+void sso_min_eigen_map(const uint8_t* img, int w, int h, float* eig);
+int  sso_gftt(const uint8_t* img, int w, int h, int max_corners, double quality, double min_distance, float* pts);
+void sso_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst);
+void sso_scharr(const uint8_t* src, int w, int h, int16_t* dxdy);
+void sso_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err,
+                  int max_count, double epsilon, double min_eig_threshold);
+int  sso_filter_tracks(const float* lc, const float* rc, const float* lp, const float* rp, const float* lp_direct, int n, sso_pmatch* out);
+int  sso_quad_track(const uint8_t* lc, const uint8_t* rc, const uint8_t* lp, const uint8_t* rp, int w, int h, int max_corners, sso_pmatch* out);
+int  sso_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
+                      int search_w, int search_h, float distance_threshold, sso_dmatch* out);
+int  sso_quad_chain(const float* k_lc, const float* k_rc, const float* k_rp, const float* k_lp, int n_lc,
+                    const sso_dmatch* m_lrc, const sso_dmatch* m_rcp, const sso_dmatch* m_rlp, sso_pmatch* out);
+
 /* ---------------- synthetic stream, integer-only ---------------- */
 void sso_synth_frame(uint64_t seed, int frame_id, int w, int h,
                      uint8_t* bgr, uint16_t* depth, uint8_t* sem_bgr, uint8_t* label_ids);

@@ -59,6 +59,10 @@ SYMBOLS = {
     "ssm_map_export_table_dev": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_merge_table_dev": (_I, [_P, _P, _I]),
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
+    "ssm_quad_track": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I)]),
+    "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),
+    "ssm_lk_track": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _D, _D]),
+    "ssm_window_match": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P]),
     "ssm_segnet_num_layers": (_I, []),
     "ssm_segnet_layer_shape": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ssm_segnet_set_layer": (_I, [_P, _I, _P, _P, _P]),

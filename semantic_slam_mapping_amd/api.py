@@ -17,6 +17,9 @@ POINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("w", "f4"), ("b"
                         ("a", "u1"), ("label", "u4"), ("pad", "u4", (2,))])
 VOXEL_DTYPE = np.dtype([("key", "i8"), ("sx", "i8"), ("sy", "i8"), ("sz", "i8"), ("sr", "u8"), ("sg", "u8"),
                         ("sb", "u8"), ("n", "u8"), ("hist", "u4", (12,))])
+PMATCH_DTYPE = np.dtype([("u1p", "f4"), ("v1p", "f4"), ("i1p", "i4"), ("u2p", "f4"), ("v2p", "f4"), ("i2p", "i4"), ("u1c", "f4"), ("v1c", "f4"),
+                         ("i1c", "i4"), ("u2c", "f4"), ("v2c", "f4"), ("i2c", "i4"), ("dis_c", "i2"), ("dis_p", "i2")])
+assert PMATCH_DTYPE.itemsize == 52
 assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
 
 STAGE_ORB, STAGE_MATCH, STAGE_MAP, STAGE_SEGNET = 1, 2, 4, 8
@@ -109,6 +112,34 @@ class Context:
         r = self.cfg.knn_match_ratio if ratio is None else ratio
         self._chk(self.lib.ssm_match(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    # ---- QuadFeatureMatch (stereo)
+    def quad_track(self, lc, rc, lp, rp, max_corners=1000):
+        ims = [np.ascontiguousarray(a, np.uint8) for a in (lc, rc, lp, rp)]
+        h, w = ims[0].shape
+        out = np.zeros(max_corners, PMATCH_DTYPE); n = C.c_int(0)
+        self._chk(self.lib.ssm_quad_track(self.h, _ptr(ims[0]), _ptr(ims[1]), _ptr(ims[2]), _ptr(ims[3]), w, h, w, max_corners, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def gftt(self, img, max_corners=1000, quality=0.04, min_distance=8.0):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        pts = np.zeros((max_corners, 2), np.float32); n = C.c_int(0)
+        self._chk(self.lib.ssm_gftt(self.h, _ptr(img), w, h, img.strides[0], max_corners, quality, min_distance, _ptr(pts), max_corners, C.byref(n)))
+        return pts[:n.value]
+
+    def lk_track(self, prev, nxt, pts, max_count=200, epsilon=0.01, min_eig=1e-6):
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8); h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(pts); st = np.zeros(len(pts), np.uint8); err = np.zeros(len(pts), np.float32)
+        self._chk(self.lib.ssm_lk_track(self.h, _ptr(prev), _ptr(nxt), w, h, w, _ptr(pts), len(pts), _ptr(out), _ptr(st), _ptr(err), max_count, epsilon, min_eig))
+        return out, st, err
+
+    def window_match(self, kp1, d1, kp2, d2, sw, sh, thr):
+        kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2); kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(kp1), 1), DMATCH_DTYPE)
+        self._chk(self.lib.ssm_window_match(self.h, _ptr(kp1), _ptr(d1), len(kp1), _ptr(kp2), _ptr(d2), len(kp2), sw, sh, thr, _ptr(out)))
+        return out[:len(kp1)]
 
     # ---- Classifier (SegNet)
     def segnet_layers(self):

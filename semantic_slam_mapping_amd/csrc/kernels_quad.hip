@@ -1,0 +1,380 @@
+// kernels_quad.hip -- K7/K8: the stereo quad-matcher of /root/reference/src/quadmatcher.cpp on gfx950:
+//   cv::goodFeaturesToTrack (detectFeature :388-417, GFTT q=0.04 minDistance 8)    -> mineig / collect / select kernels
+//   cv::calcOpticalFlowPyrLK x4 (circularMatching :548-588, win 11, 3 levels)      -> pyrdown / scharr / lk kernels
+//   filteringTracks (:420-503)                                                      -> filter kernel
+//   matching()/caldistance (:41-83, 525-544), the windowed brute-force Hamming NN   -> window_match kernel
+// Contracts = oracle/quad.c (exact integer window sums, (value desc, raster asc) corner order).  Integer / float VALU
+// work with LDS staging: no MFMA by design.
+#include "ssm_internal.h"
+#include <cfloat>
+#include <cmath>
+
+__device__ __forceinline__ int refl101d(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
+__device__ __forceinline__ int f2ordq(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+
+// ------------------------------------------------------------------ cornerMinEigenVal(block 3, ksize 3) on exact integers
+#define ME_W 64
+#define ME_H 16
+__global__ void __launch_bounds__(256)
+mineig_kernel(const uint8_t* __restrict__ img, int w, int h, int stride, float* __restrict__ eig, int* __restrict__ maxord)
+{
+    __shared__ uint8_t px[ME_H + 4][ME_W + 4];
+    __shared__ int16_t dx[ME_H + 2][ME_W + 2], dy[ME_H + 2][ME_W + 2];
+    __shared__ int smax;
+    const int tiles_x = (w + ME_W - 1) / ME_W;
+    const int tx0 = (blockIdx.x % tiles_x) * ME_W, ty0 = (blockIdx.x / tiles_x) * ME_H;
+    if (threadIdx.x == 0) smax = (int)0x80000000;
+    for (int i = threadIdx.x; i < (ME_H + 4) * (ME_W + 4); i += 256) {
+        const int ly = i / (ME_W + 4), lx = i - ly * (ME_W + 4);
+        px[ly][lx] = img[(size_t)refl101d(ty0 + ly - 2, h) * stride + refl101d(tx0 + lx - 2, w)];
+    }
+    __syncthreads();
+    // derivative maps on tile + 1; positions outside the image hold the REFLECT_101 neighbour's derivative (boxFilter border)
+    for (int i = threadIdx.x; i < (ME_H + 2) * (ME_W + 2); i += 256) {
+        const int ly = i / (ME_W + 2), lx = i - ly * (ME_W + 2);
+        const int gx = refl101d(tx0 + lx - 1, w), gy = refl101d(ty0 + ly - 1, h);
+        // where does (gx, gy) sit in the staged pixels?  its 3x3 neighbourhood must be staged: true for positions within tile+-1 after reflection
+        const int sx = gx - tx0 + 2, sy = gy - ty0 + 2;
+        int vx = 0, vy = 0;
+        if (sx >= 1 && sx <= ME_W + 2 && sy >= 1 && sy <= ME_H + 2) {
+            // the staged pixels are themselves REFLECT_101 of the image, so plain neighbours give the reflected Sobel
+            const int xm = refl101d(gx - 1, w) - tx0 + 2, xp = refl101d(gx + 1, w) - tx0 + 2, ym = refl101d(gy - 1, h) - ty0 + 2, yp = refl101d(gy + 1, h) - ty0 + 2;
+            vx = (px[ym][xp] - px[ym][xm]) + 2 * (px[sy][xp] - px[sy][xm]) + (px[yp][xp] - px[yp][xm]);
+            vy = (px[yp][xm] - px[ym][xm]) + 2 * (px[yp][sx] - px[ym][sx]) + (px[yp][xp] - px[ym][xp]);
+        }
+        dx[ly][lx] = (int16_t)vx; dy[ly][lx] = (int16_t)vy;
+    }
+    __syncthreads();
+    const float s = (float)(1.0 / (255.0 * 4.0 * 3.0)), s2 = s * s;
+    int lmax = (int)0x80000000;
+    for (int i = threadIdx.x; i < ME_H * ME_W; i += 256) {
+        const int ly = i >> 6, lx = i & 63, gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= w || gy >= h) continue;
+        long long sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int a = dx[ly + j][lx + k], b = dy[ly + j][lx + k]; sxx += a * a; sxy += a * b; syy += b * b; }
+        const float a = (float)sxx * s2 * 0.5f, b = (float)sxy * s2, c = (float)syy * s2 * 0.5f;
+        const float d = a - c;
+        const float e = (a + c) - sqrtf(d * d + b * b);
+        eig[(size_t)gy * w + gx] = e;
+        lmax = max(lmax, f2ordq(e));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&smax, lmax);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(maxord, smax);
+}
+// candidates: v > thr and v equals the 3x3 max of the thresholded map, interior pixels only.  key = value bits << 32 | ~index (sorted descending)
+__global__ void __launch_bounds__(256)
+gftt_collect_kernel(const float* __restrict__ eig, int w, int h, const int* __restrict__ maxord, double quality, unsigned long long* __restrict__ keys,
+                    int* __restrict__ count, int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int mo = *maxord; const float mx = __int_as_float(mo >= 0 ? mo : mo ^ 0x7FFFFFFF);
+    const float thr = (float)((double)fmaxf(mx, 0.f) * quality);
+    bool keep = false; float v = 0.f;
+    const int y = i / w, x = i - y * w;
+    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+        v = eig[i];
+        if (v > thr) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = -1; j <= 1; j++)
+#pragma unroll
+                for (int k = -1; k <= 1; k++) { float q = eig[i + j * w + k]; q = q > thr ? q : 0.f; m = fmaxf(m, q); }
+            keep = v == m;
+        }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (keep) { const int k = base + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); }
+    }
+}
+// greedy minDistance selection over the sorted candidates (goodFeaturesToTrack's grid of cell = round(minDistance)); serial by nature:
+// one lane walks the list, the grid heads live in LDS.  Writes (x, y) float pairs.
+__global__ void __launch_bounds__(64)
+gftt_select_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int h, int max_corners, float min_distance,
+                   float* __restrict__ pts, int* __restrict__ nout, int* __restrict__ next)
+{
+    extern __shared__ int16_t head[];                // one list head per grid cell (corner index < 32768), up to 65536 cells = 128 KiB
+    const int cell = max(__float2int_rn(min_distance), 1);
+    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+    for (int i = threadIdx.x; i < gw * gh; i += 64) head[i] = -1;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float md2 = min_distance * min_distance;
+    int n = 0;
+    for (int i = 0; i < nc; i++) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
+        const int y = idx / w, x = idx - y * w;
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
+        bool good = true;
+        for (int yy = y1; yy <= y2 && good; yy++)
+            for (int xx = x1; xx <= x2 && good; xx++)
+                for (int k = head[yy * gw + xx]; k >= 0; k = next[k]) {
+                    const float ddx = (float)(x - (int)pts[2*k]), ddy = (float)(y - (int)pts[2*k+1]);
+                    if (ddx * ddx + ddy * ddy < md2) { good = false; break; }
+                }
+        if (good) {
+            next[n] = head[yc * gw + xc]; head[yc * gw + xc] = (int16_t)n;
+            pts[2*n] = (float)x; pts[2*n+1] = (float)y; n++;
+            if (max_corners > 0 && n == max_corners) break;
+        }
+    }
+    *nout = n;
+}
+
+// ------------------------------------------------------------------ pyramid + Scharr for LK
+__global__ void __launch_bounds__(256)
+pyrdown_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int dw, int dh)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dw * dh) return;
+    const int y = i / dw, x = i - y * dw;
+    const int k[5] = {1, 4, 6, 4, 1};
+    int s = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+        const uint8_t* r = src + (size_t)refl101d(2 * y + j, h) * w;
+        int rs = 0;
+#pragma unroll
+        for (int q = -2; q <= 2; q++) rs += k[q + 2] * r[refl101d(2 * x + q, w)];
+        s += k[j + 2] * rs;
+    }
+    dst[i] = (uint8_t)((s + 128) >> 8);
+}
+__global__ void __launch_bounds__(256)
+scharr_kernel(const uint8_t* __restrict__ src, int w, int h, short2* __restrict__ d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const uint8_t *r0 = src + (size_t)refl101d(y - 1, h) * w, *r1 = src + (size_t)y * w, *r2 = src + (size_t)refl101d(y + 1, h) * w;
+    const int xm = refl101d(x - 1, w), xp = refl101d(x + 1, w);
+    d[i] = make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
+                       (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[x] - r0[x]) + 3 * (r2[xp] - r0[xp])));
+}
+
+// ------------------------------------------------------------------ pyramidal LK, one wave per point, all levels in one launch
+#define LKW 11
+#define LKL 4
+struct LkPyr { const uint8_t* P[LKL]; const uint8_t* N[LKL]; const short2* D[LKL]; int w[LKL], h[LKL]; };
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#define DESCALE(v, n) (((v) + (1 << ((n) - 1))) >> (n))
+__global__ void __launch_bounds__(256)
+lk_kernel(LkPyr py, const float* __restrict__ prev_pts, int n, float* __restrict__ next_pts, uint8_t* __restrict__ status, float* __restrict__ err,
+          int max_count, float eps2, float min_eig_thr)
+{
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= n) return;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float half = (LKW - 1) * 0.5f;
+    const float p0x = prev_pts[2*pi], p0y = prev_pts[2*pi+1];
+    float nx = 0.f, ny = 0.f; int st = 1; float er = 0.f;
+    // this lane's two window pixels: e0 = lane, e1 = lane + 64 (valid when < 121)
+    const int e0 = lane, e1 = lane + 64;
+    const int wy0 = e0 / LKW, wx0 = e0 - wy0 * LKW, wy1 = e1 / LKW, wx1 = e1 - wy1 * LKW;
+    const bool v1 = e1 < LKW * LKW;
+    for (int level = LKL - 1; level >= 0; level--) {
+        const int W = py.w[level], H = py.h[level];
+        const uint8_t* P = py.P[level]; const uint8_t* N = py.N[level]; const short2* D = py.D[level];
+        float ppx = p0x * (float)(1. / (1 << level)), ppy = p0y * (float)(1. / (1 << level));
+        if (level == LKL - 1) { nx = ppx; ny = ppy; } else { nx *= 2.f; ny *= 2.f; }
+        ppx -= half; ppy -= half;
+        const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+        if (ipx < -LKW || ipx >= W || ipy < -LKW || ipy >= H) { if (level == 0) { st = 0; er = 0.f; } continue; }
+        float a = ppx - ipx, b = ppy - ipy;
+        int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)), iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)), iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
+        int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+        int I[2], Ix[2], Iy[2];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            I[t] = Ix[t] = Iy[t] = 0;
+            if (t == 1 && !v1) continue;
+            const int gx = ipx + (t ? wx1 : wx0), gy = ipy + (t ? wy1 : wy0);
+            const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
+            const int iv = DESCALE(P[(size_t)y0 * W + x0] * iw00 + P[(size_t)y0 * W + x1] * iw01 + P[(size_t)y1 * W + x0] * iw10 + P[(size_t)y1 * W + x1] * iw11, 14 - 5);
+            const bool i00 = gx >= 0 && gx < W && gy >= 0 && gy < H, i01 = gx + 1 >= 0 && gx + 1 < W && gy >= 0 && gy < H;
+            const bool i10 = gx >= 0 && gx < W && gy + 1 >= 0 && gy + 1 < H, i11 = gx + 1 >= 0 && gx + 1 < W && gy + 1 >= 0 && gy + 1 < H;
+            const short2 z = make_short2(0, 0);
+            const short2 d00 = i00 ? D[(size_t)gy * W + gx] : z, d01 = i01 ? D[(size_t)gy * W + gx + 1] : z;
+            const short2 d10 = i10 ? D[(size_t)(gy + 1) * W + gx] : z, d11 = i11 ? D[(size_t)(gy + 1) * W + gx + 1] : z;
+            const int ix = DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+            const int iy = DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+            I[t] = (short)iv; Ix[t] = (short)ix; Iy[t] = (short)iy;
+            sA11 += (long long)Ix[t] * Ix[t]; sA12 += (long long)Ix[t] * Iy[t]; sA22 += (long long)Iy[t] * Iy[t];
+        }
+        sA11 = wave_sum_ll(sA11); sA12 = wave_sum_ll(sA12); sA22 = wave_sum_ll(sA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float Dt = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LKW * LKW);
+        er = minEig;
+        if (minEig < min_eig_thr || Dt < FLT_EPSILON) { if (level == 0) st = 0; continue; }
+        Dt = 1.f / Dt;
+        float npx = nx - half, npy = ny - half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; j++) {
+            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
+            if (inx < -LKW || inx >= W || iny < -LKW || iny >= H) { if (level == 0) st = 0; break; }
+            a = npx - inx; b = npy - iny;
+            iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)); iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)); iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
+            iw11 = (1 << 14) - iw00 - iw01 - iw10;
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (t == 1 && !v1) continue;
+                const int gx = inx + (t ? wx1 : wx0), gy = iny + (t ? wy1 : wy0);
+                const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
+                const int diff = DESCALE(N[(size_t)y0 * W + x0] * iw00 + N[(size_t)y0 * W + x1] * iw01 + N[(size_t)y1 * W + x0] * iw10 + N[(size_t)y1 * W + x1] * iw11, 14 - 5) - I[t];
+                sb1 += (long long)diff * Ix[t]; sb2 += (long long)diff * Iy[t];
+            }
+            sb1 = wave_sum_ll(sb1); sb2 = wave_sum_ll(sb2);
+            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float ddx = (A12 * b2 - A22 * b1) * Dt, ddy = (A12 * b1 - A11 * b2) * Dt;
+            npx += ddx; npy += ddy;
+            nx = npx + half; ny = npy + half;
+            if (ddx * ddx + ddy * ddy <= eps2) break;
+            if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) { nx -= ddx * 0.5f; ny -= ddy * 0.5f; break; }
+            pdx = ddx; pdy = ddy;
+        }
+    }
+    if (lane == 0) { next_pts[2*pi] = nx; next_pts[2*pi+1] = ny; status[pi] = (uint8_t)st; if (err) err[pi] = er; }
+}
+
+// ------------------------------------------------------------------ filteringTracks (quadmatcher.cpp:420-503), ordered compaction, one block
+struct QPmatch { float u1p, v1p; int i1p; float u2p, v2p; int i2p; float u1c, v1c; int i1c; float u2c, v2c; int i2c; short dis_c, dis_p; };
+__device__ __forceinline__ bool within_region(float x, float y) { return x < 1280 && x > 0.0f && y < 960 && y > 0.0f; }
+__global__ void __launch_bounds__(1024)
+filter_tracks_kernel(const float* __restrict__ lc, const float* __restrict__ rc, const float* __restrict__ lp, const float* __restrict__ rp,
+                     const float* __restrict__ ld, int n, QPmatch* __restrict__ out, int* __restrict__ nout)
+{
+    __shared__ int wcnt[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false; QPmatch r;
+        if (i < n) {
+            const float lcx = lc[2*i], lcy = lc[2*i+1], rcx = rc[2*i], rcy = rc[2*i+1], lpx = lp[2*i], lpy = lp[2*i+1], rpx = rp[2*i], rpy = rp[2*i+1];
+            const float ldx = ld[2*i], ldy = ld[2*i+1];
+            const int dh1 = __float2int_rn(fabsf(lcy - rcy)), dh2 = __float2int_rn(fabsf(lpy - rpy));
+            const int dh11 = __float2int_rn(fabsf(lcy - lpy)), dh22 = __float2int_rn(fabsf(rcy - rpy));
+            const int dw1 = __float2int_rn(fabsf(lcx - lpx)), dw2 = __float2int_rn(fabsf(rcx - rpx));
+            const int disp1 = __float2int_rn(fabsf(lcx - rcx)), disp2 = __float2int_rn(fabsf(lpx - rpx));
+            const int dfx = __float2int_rn(fabsf(lpx - ldx)), dfy = __float2int_rn(fabsf(lpy - ldy));
+            keep = within_region(lcx, lcy) && within_region(lpx, lpy) && within_region(rcx, rcy) && within_region(rpx, rpy) &&
+                   dh1 < 20 && dh2 < 20 && dh11 < 30 && dh22 < 30 && dw1 < 200 && dw2 < 200 && disp1 > 3 && disp2 > 3 && dfx < 1 && dfy < 1;
+            r.u1c = lcx; r.v1c = lcy; r.u1p = lpx; r.v1p = lpy; r.u2c = rcx; r.v2c = rcy; r.u2p = rpx; r.v2p = rpy;
+            r.i1c = r.i1p = r.i2c = r.i2p = i; r.dis_c = 0; r.dis_p = 0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        __syncthreads();
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; k++) off += wcnt[k];
+        if (keep) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int k = 0; k < 16; k++) s += wcnt[k]; base += s; }
+    }
+    __syncthreads();
+    if (tid == 0) *nout = base;
+}
+
+// ------------------------------------------------------------------ QuadFeatureMatch::matching on binary descriptors (:41-83)
+__global__ void __launch_bounds__(256)
+window_match_kernel(const float* __restrict__ kp1, const uint8_t* __restrict__ d1, int n1, const float* __restrict__ kp2, const uint8_t* __restrict__ d2, int n2,
+                    float sw, float sh, float thr, ssm_dmatch* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const uint4* q = reinterpret_cast<const uint4*>(d1 + (size_t)i * 32);
+    const uint4 a = q[0], b = q[1];
+    const float x1 = kp1[2*i], y1 = kp1[2*i+1];
+    int id = 0; float mind = 999999999.9f;
+    for (int j = 0; j < n2; j++) {
+        if (fabsf(kp2[2*j] - x1) < sw && fabsf(kp2[2*j+1] - y1) < sh) {
+            const uint4* t = reinterpret_cast<const uint4*>(d2 + (size_t)j * 32);
+            const uint4 x = t[0], y = t[1];
+            const int d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) + __popc(b.y ^ y.y) + __popc(b.z ^ y.z) + __popc(b.w ^ y.w);
+            if ((float)d < mind) { mind = (float)d; id = j; }
+        }
+    }
+    if (mind > thr) id = -1;
+    ssm_dmatch m; m.queryIdx = i; m.trainIdx = id; m.imgIdx = -1; m.distance = mind;
+    out[i] = m;
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t k_quad_mineig(const uint8_t* img, int w, int h, int stride, float* eig, int* maxord, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(maxord, 0x80, 4, s);          // 0x80808080: below any real value in the ordered-int encoding
+    if (e != hipSuccess) return e;
+    const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
+    mineig_kernel<<<tx * ty, 256, 0, s>>>(img, w, h, stride, eig, maxord);
+    return hipGetLastError();
+}
+hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, double quality, unsigned long long* keys, int* count, int cap, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(count, 0, 4, s);
+    if (e != hipSuccess) return e;
+    gftt_collect_kernel<<<(w * h + 255) / 256, 256, 0, s>>>(eig, w, h, maxord, quality, keys, count, cap);
+    return hipGetLastError();
+}
+hipError_t k_quad_select(const unsigned long long* keys, int nc, int w, int h, int max_corners, float min_distance, float* pts, int* nout, int* next, hipStream_t s)
+{
+    const int cell = max((int)lrintf(min_distance), 1);
+    const size_t lds = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell) * sizeof(int16_t);
+    if (lds > 65536 * 2) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)gftt_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    gftt_select_kernel<<<1, 64, lds, s>>>(keys, nc, w, h, max_corners, min_distance, pts, nout, next);
+    return hipGetLastError();
+}
+hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s)
+{
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    pyrdown_kernel<<<(dw * dh + 255) / 256, 256, 0, s>>>(src, w, h, dst, dw, dh);
+    return hipGetLastError();
+}
+hipError_t k_quad_scharr(const uint8_t* src, int w, int h, int16_t* d, hipStream_t s)
+{
+    scharr_kernel<<<(w * h + 255) / 256, 256, 0, s>>>(src, w, h, reinterpret_cast<short2*>(d));
+    return hipGetLastError();
+}
+hipError_t k_quad_lk(const uint8_t* const* P, const uint8_t* const* N, const int16_t* const* D, const int* lw, const int* lh, const float* prev_pts, int n,
+                     float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    LkPyr py;
+    for (int l = 0; l < LKL; l++) { py.P[l] = P[l]; py.N[l] = N[l]; py.D[l] = reinterpret_cast<const short2*>(D[l]); py.w[l] = lw[l]; py.h[l] = lh[l]; }
+    lk_kernel<<<(n + 3) / 4, 256, 0, s>>>(py, prev_pts, n, next_pts, status, err, max_count, eps2, min_eig_thr);
+    return hipGetLastError();
+}
+hipError_t k_quad_filter(const float* lc, const float* rc, const float* lp, const float* rp, const float* ld, int n, void* out, int* nout, hipStream_t s)
+{
+    filter_tracks_kernel<<<1, 1024, 0, s>>>(lc, rc, lp, rp, ld, n, reinterpret_cast<QPmatch*>(out), nout);
+    return hipGetLastError();
+}
+hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,
+                               ssm_dmatch* out, hipStream_t s)
+{
+    if (n1 <= 0) return hipSuccess;
+    window_match_kernel<<<(n1 + 255) / 256, 256, 0, s>>>(kp1, d1, n1, kp2, d2, n2, (float)sw, (float)sh, thr, out);
+    return hipGetLastError();
+}

@@ -40,6 +40,15 @@ static const SegLayerDef k_seg_layers[SEG_LAYERS] = {
 };
 
 } // namespace
+struct QuadState {          // buffers of the stereo quad matcher for one image geometry
+    int w = 0, h = 0, maxc = 0;
+    int lw[4], lh[4];
+    uint8_t* pyr[4][4] = {};                // [image lc,rc,lp,rp][level]
+    int16_t* der[4][4] = {};                // Scharr derivatives (used for lc, rc, rp)
+    float* eig = nullptr; int* maxord = nullptr; int* count = nullptr; unsigned long long *keys = nullptr, *keys2 = nullptr; void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0; int keycap = 0;
+    float* pts[5] = {};                     // lc, rc, rp, lp, lp_direct
+    uint8_t* status = nullptr; float* err = nullptr; int* next = nullptr; int* nout = nullptr; void* pm = nullptr;
+};
 struct SegNetState {
     bool set[SEG_LAYERS] = {};
     void* w[SEG_LAYERS] = {}; float* scale[SEG_LAYERS] = {}; float* shift[SEG_LAYERS] = {};
@@ -50,6 +59,8 @@ struct SegNetState {
     int16_t *pre_xa = nullptr, *pre_ya = nullptr, *post_xa = nullptr, *post_ya = nullptr;
     uint8_t* d_sem_gen = nullptr;       // generated colour labels for the sequence path (max_batch frames)
 };
+
+static void quad_free(QuadState* q);
 
 struct ssm_ctx {
     std::mutex mu;
@@ -80,6 +91,8 @@ struct ssm_ctx {
     VoxTable map, tmp;
     // SegNet
     struct SegNetState* seg = nullptr;
+    // quad matcher
+    struct QuadState* quad = nullptr;
     // profiling
     bool profiling = false;
     std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -299,6 +312,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
         for (int l = 0; l < SEG_LAYERS; l++) { if (g->w[l]) hipFree(g->w[l]); if (g->scale[l]) hipFree(g->scale[l]); if (g->shift[l]) hipFree(g->shift[l]); }
         delete g;
     }
+    if (c->quad) { quad_free(c->quad); delete c->quad; }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -889,6 +903,145 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
     HIPCHK(c, hipMemcpy(h.data(), c->seg->actA, h.size() * 2, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < (size_t)SEG_NW * SEG_NH; p++)
         for (int k = 0; k < SEG_NCLS; k++) { _Float16 v; memcpy(&v, &h[p * cs + k], 2); out[p * SEG_NCLS + k] = (float)v; }
+    return SSM_OK;
+}
+
+
+// ---------------------------------------------------------------- QuadFeatureMatch
+static void quad_free(QuadState* q)
+{
+    for (int i = 0; i < 4; i++) for (int l = 0; l < 4; l++) { if (q->pyr[i][l]) hipFree(q->pyr[i][l]); if (q->der[i][l]) hipFree(q->der[i][l]); q->pyr[i][l] = nullptr; q->der[i][l] = nullptr; }
+    void* p[] = { q->eig, q->maxord, q->count, q->keys, q->keys2, q->sort_tmp, q->pts[0], q->pts[1], q->pts[2], q->pts[3], q->pts[4], q->status, q->err, q->next, q->nout, q->pm };
+    for (void* x : p) if (x) hipFree(x);
+}
+static int quad_init(ssm_ctx* c, int w, int h, int maxc)
+{
+    if (c->quad && c->quad->w == w && c->quad->h == h && c->quad->maxc >= maxc) return SSM_OK;
+    if (w < 32 || h < 32 || w > 4096 || h > 4096) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
+    if (((w + 7) / 8) * ((h + 7) / 8) > 65536) FAIL(c, SSM_E_INVAL, "quad matcher: image too large for the minDistance grid");
+    if (c->quad) { hipStreamSynchronize(c->stream); quad_free(c->quad); delete c->quad; c->quad = nullptr; }
+    QuadState* q = new QuadState(); c->quad = q;
+    q->w = w; q->h = h; q->maxc = maxc;
+    for (int l = 0; l < 4; l++) { q->lw[l] = l ? (q->lw[l-1] + 1) / 2 : w; q->lh[l] = l ? (q->lh[l-1] + 1) / 2 : h; }
+    for (int i = 0; i < 4; i++) for (int l = 0; l < 4; l++) { DALLOC(c, q->pyr[i][l], (size_t)q->lw[l] * q->lh[l]); if (i != 2) DALLOC(c, q->der[i][l], (size_t)q->lw[l] * q->lh[l] * 2); }
+    q->keycap = w * h / 4 + 1024;
+    DALLOC(c, q->eig, (size_t)w * h); DALLOC(c, q->maxord, 1); DALLOC(c, q->count, 1); DALLOC(c, q->keys, q->keycap); DALLOC(c, q->keys2, q->keycap);
+    HIPCHK(c, sort_keys_desc_u64(nullptr, &q->sort_tmp_bytes, q->keys, q->keys2, q->keycap, c->stream));
+    uint8_t* t; int r = dalloc(c, &t, q->sort_tmp_bytes + 256); if (r) return r; q->sort_tmp = t;
+    for (int i = 0; i < 5; i++) DALLOC(c, q->pts[i], (size_t)2 * maxc);
+    DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc); DALLOC(c, q->next, maxc); DALLOC(c, q->nout, 1);
+    uint8_t* pm; r = dalloc(c, &pm, (size_t)maxc * sizeof(ssm_pmatch)); if (r) return r; q->pm = pm;
+    return SSM_OK;
+}
+// image i (0 lc, 1 rc, 2 lp, 3 rp) from the host: level 0 packed + 3 pyrDown levels (+ Scharr when asked)
+static int quad_upload(ssm_ctx* c, int i, const uint8_t* img, int stride, bool deriv)
+{
+    QuadState* q = c->quad; hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpy2DAsync(q->pyr[i][0], q->w, img, stride, q->w, q->h, hipMemcpyHostToDevice, s));
+    for (int l = 1; l < 4; l++) HIPCHK(c, k_quad_pyrdown(q->pyr[i][l-1], q->lw[l-1], q->lh[l-1], q->pyr[i][l], s));
+    if (deriv) for (int l = 0; l < 4; l++) HIPCHK(c, k_quad_scharr(q->pyr[i][l], q->lw[l], q->lh[l], q->der[i][l], s));
+    return SSM_OK;
+}
+static int quad_gftt(ssm_ctx* c, int img, int max_corners, double quality, double min_distance, float* d_pts, int* n_out)
+{
+    QuadState* q = c->quad; hipStream_t s = c->stream;
+    HIPCHK(c, k_quad_mineig(q->pyr[img][0], q->w, q->h, q->w, q->eig, q->maxord, s));
+    HIPCHK(c, k_quad_collect(q->eig, q->w, q->h, q->maxord, quality, q->keys, q->count, q->keycap, s));
+    int nc = 0;
+    HIPCHK(c, hipMemcpyAsync(&nc, q->count, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (nc > q->keycap) FAIL(c, SSM_E_CAPACITY, "corner candidate buffer too small");
+    *n_out = 0;
+    if (nc == 0) return SSM_OK;
+    HIPCHK(c, sort_keys_desc_u64(q->sort_tmp, &q->sort_tmp_bytes, q->keys, q->keys2, nc, s));
+    HIPCHK(c, k_quad_select(q->keys2, nc, q->w, q->h, max_corners, (float)min_distance, d_pts, q->nout, q->next, s));
+    HIPCHK(c, hipMemcpyAsync(n_out, q->nout, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return SSM_OK;
+}
+static int quad_lk(ssm_ctx* c, int prev, int next, const float* p_prev, int n, float* p_next, int max_count, double eps, double min_eig)
+{
+    QuadState* q = c->quad;
+    HIPCHK(c, k_quad_lk(q->pyr[prev], q->pyr[next], q->der[prev], q->lw, q->lh, p_prev, n, p_next, q->status, q->err, max_count, (float)(eps * eps), (float)min_eig, c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_quad_track(ssm_ctx* c, const uint8_t* lc, const uint8_t* rc, const uint8_t* lp, const uint8_t* rp, int w, int h, int stride,
+                              int max_corners, ssm_pmatch* out, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!lc || !rc || !lp || !rp || !n_out || stride < w || max_corners < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
+    int r = quad_init(c, w, h, max_corners); if (r) return r;
+    QuadState* q = c->quad;
+    if ((r = quad_upload(c, 0, lc, stride, true)) || (r = quad_upload(c, 1, rc, stride, true)) || (r = quad_upload(c, 2, lp, stride, false)) || (r = quad_upload(c, 3, rp, stride, true))) return r;
+    int n = 0;
+    r = quad_gftt(c, 0, max_corners, 0.04, 8.0, q->pts[0], &n); if (r) return r;           // quadmatcher.cpp:301-308
+    *n_out = 0;
+    if (n == 0) return SSM_OK;
+    // quadmatcher.cpp:566-576: lc->rc, rc->rp, rp->lp, lc->lp(direct); pts: 0 lc, 1 rc, 2 rp, 3 lp, 4 lp_direct; images: 0 lc, 1 rc, 2 lp, 3 rp
+    if ((r = quad_lk(c, 0, 1, q->pts[0], n, q->pts[1], 200, 0.01, 1e-6)) || (r = quad_lk(c, 1, 3, q->pts[1], n, q->pts[2], 200, 0.01, 1e-6)) ||
+        (r = quad_lk(c, 3, 2, q->pts[2], n, q->pts[3], 200, 0.01, 1e-6)) || (r = quad_lk(c, 0, 2, q->pts[0], n, q->pts[4], 200, 0.01, 1e-6))) return r;
+    HIPCHK(c, k_quad_filter(q->pts[0], q->pts[1], q->pts[3], q->pts[2], q->pts[4], n, q->pm, q->nout, c->stream));
+    int m = 0;
+    HIPCHK(c, hipMemcpyAsync(&m, q->nout, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_out = m;
+    if (m > cap) FAIL(c, SSM_E_CAPACITY, "pmatch buffer too small (need " + std::to_string(m) + ")");
+    if (m) HIPCHK(c, hipMemcpy(out, q->pm, (size_t)m * sizeof(ssm_pmatch), hipMemcpyDeviceToHost));
+    return SSM_OK;
+}
+extern "C" int ssm_gftt(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance,
+                        float* pts, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!img || !pts || !n_out || stride < w || max_corners < 1 || !(min_distance >= 1.0)) FAIL(c, SSM_E_INVAL, "bad arguments (max_corners >= 1, min_distance >= 1)");
+    { const int cell = (int)lrint(min_distance) > 0 ? (int)lrint(min_distance) : 1;
+      if ((long long)((w + cell - 1) / cell) * ((h + cell - 1) / cell) > 65536) FAIL(c, SSM_E_INVAL, "min_distance too small for this image size (grid > 65536 cells)"); }
+    if (max_corners > 32767) FAIL(c, SSM_E_INVAL, "max_corners must be <= 32767");
+    int r = quad_init(c, w, h, max_corners); if (r) return r;
+    HIPCHK(c, hipMemcpy2DAsync(c->quad->pyr[0][0], w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    int n = 0;
+    r = quad_gftt(c, 0, max_corners, quality, min_distance, c->quad->pts[0], &n); if (r) return r;
+    *n_out = n;
+    if (n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small");
+    if (n) HIPCHK(c, hipMemcpy(pts, c->quad->pts[0], (size_t)n * 8, hipMemcpyDeviceToHost));
+    return SSM_OK;
+}
+extern "C" int ssm_lk_track(ssm_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
+                            float* next_pts, uint8_t* status, float* err, int max_count, double epsilon, double min_eig_threshold)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!prev || !next || n < 0 || (n && (!prev_pts || !next_pts)) || stride < w || max_count < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (n == 0) return SSM_OK;
+    int r = quad_init(c, w, h, n > 1000 ? n : 1000); if (r) return r;
+    QuadState* q = c->quad;
+    if ((r = quad_upload(c, 0, prev, stride, true)) || (r = quad_upload(c, 1, next, stride, false))) return r;
+    HIPCHK(c, hipMemcpyAsync(q->pts[0], prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    r = quad_lk(c, 0, 1, q->pts[0], n, q->pts[1], max_count, epsilon, min_eig_threshold); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(next_pts, q->pts[1], (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, q->status, n, hipMemcpyDeviceToHost, c->stream));
+    if (err) HIPCHK(c, hipMemcpyAsync(err, q->err, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_window_match(ssm_ctx* c, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
+                                int search_width, int search_height, float distance_threshold, ssm_dmatch* out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n1 < 0 || n2 < 0 || (n1 && (!kp1 || !d1 || !out)) || (n2 && (!kp2 || !d2))) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (n1 == 0) return SSM_OK;
+    const size_t a1 = ((size_t)n1 * 8 + 255) & ~(size_t)255, a2 = ((size_t)n2 * 8 + 255) & ~(size_t)255, b1 = ((size_t)n1 * 32 + 255) & ~(size_t)255, b2 = ((size_t)n2 * 32 + 255) & ~(size_t)255;
+    int r = ensure_scratch(c, a1 + a2 + b1 + b2 + (size_t)n1 * 16 + 256); if (r) return r;
+    uint8_t* p = (uint8_t*)c->d_scratch;
+    float* dk1 = (float*)p; p += a1; float* dk2 = (float*)p; p += a2; uint8_t* dd1 = p; p += b1; uint8_t* dd2 = p; p += b2; ssm_dmatch* dm = (ssm_dmatch*)p;
+    HIPCHK(c, hipMemcpyAsync(dk1, kp1, (size_t)n1 * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
+    if (n2) { HIPCHK(c, hipMemcpyAsync(dk2, kp2, (size_t)n2 * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream)); }
+    HIPCHK(c, k_quad_window_match(dk1, dd1, n1, dk2, dd2, n2, search_width, search_height, distance_threshold, dm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, dm, (size_t)n1 * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return SSM_OK;
 }
 

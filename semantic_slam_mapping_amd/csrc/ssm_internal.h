@@ -96,3 +96,16 @@ hipError_t k_segnet_unpool(const void* in, const uint8_t* code, int n, int PH, i
 hipError_t k_segnet_argmax(const void* logits, int n, int npix, int Cstore, int ncls, uint8_t* labels, hipStream_t s);
 hipError_t k_segnet_color(const uint8_t* ids, int n, int sw, int sh, int dw, int dh, const int32_t* xofs, const int16_t* xa,
                           const int32_t* yofs, const int16_t* ya, int pavement_to_road, int nearest, uint8_t* sem_bgr, uint8_t* ids_out, hipStream_t s);
+
+// quad matcher (kernels_quad.hip)
+hipError_t k_quad_mineig(const uint8_t* img, int w, int h, int stride, float* eig, int* maxord, hipStream_t s);
+hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, double quality, unsigned long long* keys, int* count, int cap, hipStream_t s);
+hipError_t k_quad_select(const unsigned long long* keys, int nc, int w, int h, int max_corners, float min_distance, float* pts, int* nout, int* next, hipStream_t s);
+hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
+hipError_t k_quad_scharr(const uint8_t* src, int w, int h, int16_t* d, hipStream_t s);
+hipError_t k_quad_lk(const uint8_t* const* P, const uint8_t* const* N, const int16_t* const* D, const int* lw, const int* lh, const float* prev_pts, int n,
+                     float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s);
+hipError_t k_quad_filter(const float* lc, const float* rc, const float* lp, const float* rp, const float* ld, int n, void* out, int* nout, hipStream_t s);
+hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,
+                               ssm_dmatch* out, hipStream_t s);
+hipError_t sort_keys_desc_u64(void* tmp, size_t* tmp_bytes, unsigned long long* in, unsigned long long* out, int n, hipStream_t s);

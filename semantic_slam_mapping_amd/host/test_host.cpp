@@ -5,6 +5,7 @@
 #include "ssm/pose_graph.h"
 #include "ssm/mapper.h"
 #include "ssm/segnet.h"
+#include "ssm/quadmatcher.hpp"
 using namespace std;
 using namespace rgbd_tutor;
 static int fails = 0;
@@ -90,6 +91,25 @@ int main(int argc, char** argv)
         CHECK("generatePointCloud", c0->points.size() > 100000 && c0->points[0].data3 == 1.0f);
         ifstream pcd(para.getData<string>("map_output"), ios::binary); string line; getline(pcd, line);
         CHECK("pcd_written", (bool)pcd && line.find(".PCD") != string::npos);
+    }
+    // QuadFeatureMatch on a synthetic rectified stereo pair: right = left shifted by the disparity, previous = current shifted by the flow
+    {
+        const int W = 640, H = 480;
+        auto gray_of = [&](const cv::Mat& bgr) { cv::Mat g(H, W, CV_8UC1); for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const uchar* p = bgr.ptr<uchar>(y) + 3 * x; g.ptr<uchar>(y)[x] = (uchar)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14); } return g; };
+        auto shift = [&](const cv::Mat& a, int dx, int dy) { cv::Mat o(H, W, CV_8UC1); for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) o.ptr<uchar>(y)[x] = a.ptr<uchar>(((y - dy) % H + H) % H)[((x - dx) % W + W) % W]; return o; };
+        cv::Mat lc = gray_of(f0->rgb), rc = shift(lc, -9, 0), lp = shift(lc, 2, 1), rp = shift(lp, -9, 0), s1, s2;
+        QuadFeatureMatch* qm = new QuadFeatureMatch(lc, rc, lp, rp, s1, s2, true);
+        qm->init(DET_GFTT, DES_SIFT);                      // exactly the call of Tracker::estimateVO (track.cpp:52)
+        qm->detectFeature();
+        qm->circularMatching();
+        bool ok = qm->quadmatches.size() > 300;
+        double md = 0; for (auto& m : qm->quadmatches) md += (m.u1c - m.u2c); md /= max<size_t>(qm->quadmatches.size(), 1);
+        CHECK("quadmatcher_tracking_branch", ok && fabs(md - 9.0) < 0.2);
+        delete qm;
+        QuadFeatureMatch qb(lc, rc, lp, rp, s1, s2, false);
+        qb.init(DET_ORB, DES_ORB); qb.detectFeature(); qb.circularMatching();
+        bool ok2 = qb.quadmatches.size() > 50; for (auto& m : qb.quadmatches) if (!(fabs(m.u1c - m.u2c) > 3)) ok2 = false;
+        CHECK("quadmatcher_matching_branch", ok2);
     }
     // Classifier (SegNet) from a weight file, when the test harness provides one
     if (argc > 2) {

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 import subprocess
 import numpy as np
-from .api import KEYPOINT_DTYPE, DMATCH_DTYPE, POINT_DTYPE, VOXEL_DTYPE
+from .api import KEYPOINT_DTYPE, DMATCH_DTYPE, POINT_DTYPE, VOXEL_DTYPE, PMATCH_DTYPE
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(_ROOT, "oracle")
@@ -72,6 +72,15 @@ class Oracle:
         L.sso_synth_frame.argtypes = [C.c_uint64, I, I, I, P, P, P, P]
         L.sso_synth_pose.argtypes = [I, P]
         L.sso_pipeline_run.argtypes = [C.POINTER(PipeCfg), I, I, C.POINTER(PipeStats)]
+        L.sso_min_eigen_map.argtypes = [P, I, I, P]
+        L.sso_gftt.argtypes = [P, I, I, I, C.c_double, C.c_double, P]
+        L.sso_pyrdown.argtypes = [P, I, I, P]
+        L.sso_scharr.argtypes = [P, I, I, P]
+        L.sso_lk_track.argtypes = [P, P, I, I, P, I, P, P, P, I, C.c_double, C.c_double]
+        L.sso_filter_tracks.argtypes = [P, P, P, P, P, I, P]
+        L.sso_quad_track.argtypes = [P, P, P, P, I, I, I, P]
+        L.sso_window_match.argtypes = [P, P, I, P, P, I, I, I, C.c_float, P]
+        L.sso_quad_chain.argtypes = [P, P, P, P, I, P, P, P, P]
 
     # ---- synthetic stream
     def synth_frame(self, seed, fid, w=640, h=480):
@@ -197,6 +206,65 @@ class Oracle:
         out = np.zeros(max(len(tab), 1), POINT_DTYPE)
         self.L.sso_voxel_export(tab.ctypes.data, len(tab), out.ctypes.data)
         return out[:len(tab)].copy()
+
+    # ---- stereo quad matcher
+    def gftt(self, img, max_corners=1000, quality=0.04, min_distance=8.0):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        pts = np.zeros((max_corners if max_corners > 0 else w * h, 2), np.float32)
+        n = self.L.sso_gftt(img.ctypes.data, w, h, max_corners, quality, min_distance, pts.ctypes.data)
+        return pts[:n].copy()
+
+    def min_eigen_map(self, img):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        e = np.zeros((h, w), np.float32)
+        self.L.sso_min_eigen_map(img.ctypes.data, w, h, e.ctypes.data)
+        return e
+
+    def pyrdown(self, img):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        d = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.L.sso_pyrdown(img.ctypes.data, w, h, d.ctypes.data)
+        return d
+
+    def scharr(self, img):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        d = np.zeros((h, w, 2), np.int16)
+        self.L.sso_scharr(img.ctypes.data, w, h, d.ctypes.data)
+        return d
+
+    def lk_track(self, prev, nxt, pts, max_count=200, epsilon=0.01, min_eig=1e-6):
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8); h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(pts); st = np.zeros(len(pts), np.uint8); err = np.zeros(len(pts), np.float32)
+        self.L.sso_lk_track(prev.ctypes.data, nxt.ctypes.data, w, h, pts.ctypes.data, len(pts), out.ctypes.data, st.ctypes.data, err.ctypes.data, max_count, epsilon, min_eig)
+        return out, st, err
+
+    def filter_tracks(self, lc, rc, lp, rp, ld):
+        a = [np.ascontiguousarray(x, np.float32).reshape(-1, 2) for x in (lc, rc, lp, rp, ld)]
+        out = np.zeros(max(len(a[0]), 1), PMATCH_DTYPE)
+        n = self.L.sso_filter_tracks(*[x.ctypes.data for x in a], len(a[0]), out.ctypes.data)
+        return out[:n].copy()
+
+    def quad_track(self, lc, rc, lp, rp, max_corners=1000):
+        ims = [np.ascontiguousarray(x, np.uint8) for x in (lc, rc, lp, rp)]
+        h, w = ims[0].shape
+        out = np.zeros(max_corners, PMATCH_DTYPE)
+        n = self.L.sso_quad_track(*[x.ctypes.data for x in ims], w, h, max_corners, out.ctypes.data)
+        return out[:n].copy()
+
+    def window_match(self, kp1, d1, kp2, d2, sw, sh, thr):
+        kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2); kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(kp1), 1), DMATCH_DTYPE)
+        self.L.sso_window_match(kp1.ctypes.data, d1.ctypes.data, len(kp1), kp2.ctypes.data, d2.ctypes.data, len(kp2), sw, sh, thr, out.ctypes.data)
+        return out[:len(kp1)].copy()
+
+    def quad_chain(self, k_lc, k_rc, k_rp, k_lp, m_lrc, m_rcp, m_rlp):
+        ks = [np.ascontiguousarray(x, np.float32).reshape(-1, 2) for x in (k_lc, k_rc, k_rp, k_lp)]
+        ms = [np.ascontiguousarray(x, DMATCH_DTYPE) for x in (m_lrc, m_rcp, m_rlp)]
+        out = np.zeros(max(len(ks[0]), 1), PMATCH_DTYPE)
+        n = self.L.sso_quad_chain(*[x.ctypes.data for x in ks], len(ks[0]), *[x.ctypes.data for x in ms], out.ctypes.data)
+        return out[:n].copy()
 
     def pipeline(self, first, count, w=640, h=480, nfeatures=1000, nlevels=8, ini=20, mn=7, ref_frames=5, scale=1.2,
                  leaf=0.1, ratio=0.8, max_distance=40.0, cam=(318.6, 255.3, 517.3, 516.5, 1000.0), seed=0x5EED0000):

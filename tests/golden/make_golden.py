@@ -106,6 +106,20 @@ def g_palette():
     json.dump(info, open(os.path.join(HERE, "palette.json"), "w"), indent=1)
 
 
+def g_quad():
+    rng = np.random.default_rng(31)
+    a = synth_small(rng, 72, 96)
+    lc = pyref.bgr2gray(a)
+    rc = np.roll(lc, -5, axis=1).copy(); rc[:, -5:] = 100
+    pts = pyref.gftt(lc, 40, 0.04, 8.0)
+    nxt, st, err = pyref.lk_track(lc, rc, pts[:12])
+    edge = np.array([[1.0, 1.0], [94.5, 70.5], [-20.0, 5.0], [50.0, 90.0]], np.float32)
+    e_out, e_st, e_err = pyref.lk_track(lc, rc, edge)
+    np.savez_compressed(os.path.join(HERE, "quad.npz"), lc=lc, rc=rc, eig=pyref.min_eigen_map(lc), gftt_40_0p04_8=pts, gftt_15_0p1_12=pyref.gftt(lc, 15, 0.1, 12.0),
+                        pyrdown=pyref.pyrdown(lc), scharr=pyref.scharr(lc), lk_next=nxt, lk_status=st, lk_err=err,
+                        edge_pts=edge, edge_next=e_out, edge_status=e_st, edge_err=e_err)
+
+
 if __name__ == "__main__":
-    g_palette(); g_matcher(); g_mapper(); g_orb()
+    g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad()
     print("golden fixtures written to", HERE)

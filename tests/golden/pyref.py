@@ -424,3 +424,140 @@ def orb_extract(gray, nfeatures, scale, nlevels, ini_th, min_th, pattern):
                 fx, fy = f32(fx * sf[l]), f32(fy * sf[l])
             kps.append((fx, fy, f32(f32(31) * sf[l]), ang, f32(s), l, -1))
     return kps, np.array(descs, np.uint8).reshape(-1, 32)
+
+
+# ---------------------------------------------------------------- stereo quad matcher (cv::goodFeaturesToTrack, cv::calcOpticalFlowPyrLK restated)
+def _refl(i, n):
+    i = np.abs(i); i = np.where(i >= n, 2 * n - 2 - i, i)
+    return np.clip(i, 0, n - 1)
+
+
+def min_eigen_map(img):
+    h, w = img.shape
+    p = img.astype(np.int64)
+    ys, xs = np.arange(h), np.arange(w)
+    R = lambda dy, dx: p[_refl(ys + dy, h)][:, _refl(xs + dx, w)]
+    dx = (R(-1, 1) - R(-1, -1)) + 2 * (R(0, 1) - R(0, -1)) + (R(1, 1) - R(1, -1))
+    dy = (R(1, -1) - R(-1, -1)) + 2 * (R(1, 0) - R(-1, 0)) + (R(1, 1) - R(-1, 1))
+    box = lambda a: sum(a[_refl(ys + j, h)][:, _refl(xs + i, w)] for j in (-1, 0, 1) for i in (-1, 0, 1))
+    sxx, sxy, syy = box(dx * dx), box(dx * dy), box(dy * dy)
+    s = f32(1.0 / (255.0 * 4.0 * 3.0)); s2 = f32(s * s)
+    a = (sxx.astype(np.float32) * s2) * f32(0.5); b = sxy.astype(np.float32) * s2; c = (syy.astype(np.float32) * s2) * f32(0.5)
+    d = a - c
+    return ((a + c) - np.sqrt(d * d + b * b)).astype(np.float32)
+
+
+def gftt(img, max_corners, quality, min_distance):
+    e = min_eigen_map(img); h, w = e.shape
+    thr = f32(float(max(e.max(), f32(0))) * quality)
+    t = np.where(e > thr, e, f32(0))
+    cands = []
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            v = e[y, x]
+            if v > thr and v == t[y - 1:y + 2, x - 1:x + 2].max():
+                cands.append((-float(v), y * w + x))
+    cands.sort()
+    out = []
+    md2 = f32(min_distance * min_distance)
+    for _, idx in cands:
+        y, x = divmod(idx, w)
+        if all(f32(f32(x - px) * f32(x - px) + f32(y - py) * f32(y - py)) >= md2 for px, py in out):
+            out.append((x, y))
+            if len(out) == max_corners:
+                break
+    return np.array(out, np.float32).reshape(-1, 2)
+
+
+def pyrdown(img):
+    h, w = img.shape; dh, dw = (h + 1) // 2, (w + 1) // 2
+    k = np.array([1, 4, 6, 4, 1], np.int64); p = img.astype(np.int64)
+    ys, xs = 2 * np.arange(dh), 2 * np.arange(dw)
+    rows = sum(k[i + 2] * p[:, _refl(xs + i, w)] for i in range(-2, 3))
+    out = sum(k[j + 2] * rows[_refl(ys + j, h)] for j in range(-2, 3))
+    return ((out + 128) >> 8).astype(np.uint8)
+
+
+def scharr(img):
+    h, w = img.shape; p = img.astype(np.int64); ys, xs = np.arange(h), np.arange(w)
+    R = lambda dy, dx: p[_refl(ys + dy, h)][:, _refl(xs + dx, w)]
+    dx = 3 * (R(-1, 1) - R(-1, -1)) + 10 * (R(0, 1) - R(0, -1)) + 3 * (R(1, 1) - R(1, -1))
+    dy = 3 * (R(1, -1) - R(-1, -1)) + 10 * (R(1, 0) - R(-1, 0)) + 3 * (R(1, 1) - R(-1, 1))
+    return np.stack([dx, dy], 2).astype(np.int16)
+
+
+def lk_track(prev, nxt, pts, max_count=200, epsilon=0.01, min_eig_thr=1e-6, win=11, levels=4):
+    P, N = [prev], [nxt]
+    for _ in range(1, levels):
+        P.append(pyrdown(P[-1])); N.append(pyrdown(N[-1]))
+    D = [scharr(p) for p in P]
+    n = len(pts); out = np.zeros((n, 2), np.float32); status = np.ones(n, np.uint8); err = np.zeros(n, np.float32)
+    half = f32((win - 1) * 0.5); SC = f32(1.0 / (1 << 20)); eps2 = f32(epsilon * epsilon)
+    desc = lambda v, b: (v + (1 << (b - 1))) >> b
+
+    def wts(fx, fy):
+        ix, iy = int(math.floor(float(fx))), int(math.floor(float(fy)))
+        a, b = f32(fx - f32(ix)), f32(fy - f32(iy))
+        w00 = cv_round(float(f32(f32(f32(1) - a) * f32(f32(1) - b)) * f32(1 << 14))); w01 = cv_round(float(f32(a * f32(f32(1) - b)) * f32(1 << 14)))
+        w10 = cv_round(float(f32(f32(f32(1) - a) * b) * f32(1 << 14)))
+        return ix, iy, w00, w01, w10, (1 << 14) - w00 - w01 - w10
+
+    for lv in range(levels - 1, -1, -1):
+        H, W = P[lv].shape
+        pix = lambda im, x, y: int(im[int(_refl(np.array(y), H)), int(_refl(np.array(x), W))])
+        der = lambda x, y, c: 0 if (x < 0 or y < 0 or x >= W or y >= H) else int(D[lv][y, x, c])
+        for i in range(n):
+            ppx = f32(f32(pts[i][0]) * f32(1.0 / (1 << lv))); ppy = f32(f32(pts[i][1]) * f32(1.0 / (1 << lv)))
+            if lv == levels - 1:
+                nx, ny = ppx, ppy
+            else:
+                nx, ny = f32(out[i][0] * f32(2)), f32(out[i][1] * f32(2))
+            out[i] = (nx, ny)
+            ppx = f32(ppx - half); ppy = f32(ppy - half)
+            ipx, ipy, w00, w01, w10, w11 = wts(ppx, ppy)
+            if ipx < -win or ipx >= W or ipy < -win or ipy >= H:
+                if lv == 0:
+                    status[i] = 0; err[i] = 0
+                continue
+            I, Ix, Iy = [], [], []
+            for y in range(win):
+                for x in range(win):
+                    gx, gy = ipx + x, ipy + y
+                    I.append(desc(pix(P[lv], gx, gy) * w00 + pix(P[lv], gx + 1, gy) * w01 + pix(P[lv], gx, gy + 1) * w10 + pix(P[lv], gx + 1, gy + 1) * w11, 9))
+                    Ix.append(desc(der(gx, gy, 0) * w00 + der(gx + 1, gy, 0) * w01 + der(gx, gy + 1, 0) * w10 + der(gx + 1, gy + 1, 0) * w11, 14))
+                    Iy.append(desc(der(gx, gy, 1) * w00 + der(gx + 1, gy, 1) * w01 + der(gx, gy + 1, 1) * w10 + der(gx + 1, gy + 1, 1) * w11, 14))
+            A11 = f32(f32(sum(a * a for a in Ix)) * SC); A12 = f32(f32(sum(a * b for a, b in zip(Ix, Iy))) * SC); A22 = f32(f32(sum(b * b for b in Iy)) * SC)
+            Dt = f32(f32(A11 * A22) - f32(A12 * A12))
+            dd = f32(A11 - A22)
+            minEig = f32(f32(f32(A22 + A11) - np.sqrt(f32(f32(dd * dd) + f32(f32(f32(4) * A12) * A12)))) / f32(2 * win * win))
+            err[i] = minEig
+            if minEig < f32(min_eig_thr) or Dt < f32(np.finfo(np.float32).eps):
+                if lv == 0:
+                    status[i] = 0
+                continue
+            Dt = f32(f32(1) / Dt)
+            npx, npy = f32(nx - half), f32(ny - half)
+            pdx = pdy = f32(0)
+            for j in range(max_count):
+                inx, iny, w00, w01, w10, w11 = wts(npx, npy)
+                if inx < -win or inx >= W or iny < -win or iny >= H:
+                    if lv == 0:
+                        status[i] = 0
+                    break
+                sb1 = sb2 = 0; k = 0
+                for y in range(win):
+                    for x in range(win):
+                        gx, gy = inx + x, iny + y
+                        diff = desc(pix(N[lv], gx, gy) * w00 + pix(N[lv], gx + 1, gy) * w01 + pix(N[lv], gx, gy + 1) * w10 + pix(N[lv], gx + 1, gy + 1) * w11, 9) - I[k]
+                        sb1 += diff * Ix[k]; sb2 += diff * Iy[k]; k += 1
+                b1, b2 = f32(f32(sb1) * SC), f32(f32(sb2) * SC)
+                ddx = f32(f32(f32(A12 * b2) - f32(A22 * b1)) * Dt); ddy = f32(f32(f32(A12 * b1) - f32(A11 * b2)) * Dt)
+                npx, npy = f32(npx + ddx), f32(npy + ddy)
+                out[i] = (f32(npx + half), f32(npy + half))
+                if f32(f32(ddx * ddx) + f32(ddy * ddy)) <= eps2:
+                    break
+                if j > 0 and abs(f32(ddx + pdx)) < f32(0.01) and abs(f32(ddy + pdy)) < f32(0.01):
+                    out[i] = (f32(out[i][0] - f32(ddx * f32(0.5))), f32(out[i][1] - f32(ddy * f32(0.5))))
+                    break
+                pdx, pdy = ddx, ddy
+    return out, status, err

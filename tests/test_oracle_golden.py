@@ -194,3 +194,19 @@ def test_synthetic_stream_properties(oracle):
     st = oracle.pipeline(0, 3, nfeatures=300)
     assert st["keypoints"] > 800 and st["matches"] > 200 and st["points"] > 400000 and st["voxels"] > 500
     assert oracle.pipeline(0, 3, nfeatures=300)["checksum"] == st["checksum"]                 # deterministic
+
+
+# ---------------------------------------------------------------- stereo quad matcher pieces
+def test_quad_golden(oracle):
+    g = load("quad.npz")
+    lc, rc = g["lc"], g["rc"]
+    assert oracle.min_eigen_map(lc).tobytes() == g["eig"].tobytes()
+    assert np.array_equal(oracle.gftt(lc, 40, 0.04, 8.0), g["gftt_40_0p04_8"]) and len(g["gftt_40_0p04_8"]) > 10
+    assert np.array_equal(oracle.gftt(lc, 15, 0.1, 12.0), g["gftt_15_0p1_12"])
+    assert np.array_equal(oracle.pyrdown(lc), g["pyrdown"]) and np.array_equal(oracle.scharr(lc), g["scharr"])
+    nxt, st, err = oracle.lk_track(lc, rc, g["gftt_40_0p04_8"][:12])
+    assert np.array_equal(st, g["lk_status"]) and nxt.tobytes() == g["lk_next"].tobytes() and err.tobytes() == g["lk_err"].tobytes()
+    good = st == 1
+    assert good.sum() >= 8 and np.abs((g["gftt_40_0p04_8"][:12] - nxt)[good][:, 0] - 5.0).max() < 0.3      # the 5-px disparity is recovered
+    nxt, st, err = oracle.lk_track(lc, rc, g["edge_pts"])
+    assert np.array_equal(st, g["edge_status"]) and nxt.tobytes() == g["edge_next"].tobytes() and err.tobytes() == g["edge_err"].tobytes()
