@@ -84,8 +84,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_merge = os.environ.get("SSM_FORCE_MERGE") == "1"      # exercise the all-gather + merge path even at world size 1 (tests)
+    if world > 1 or force_merge:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     F = args.frames
@@ -112,7 +114,7 @@ def main():
     def step():
         ctx.map_clear()
         out = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None if args.segnet else sem.data_ptr(), pose.data_ptr(), F, stages=stages)
-        if world > 1:       # merge the per-GPU voxel maps: one all-gather of the key-sorted tables
+        if world > 1 or force_merge:       # merge the per-GPU voxel maps: one all-gather of the key-sorted tables
             n_local = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
             for r, (t, n) in enumerate(sharding.allgather_tables(tab_buf, n_local, dist, dev)):
                 if r != rank:
@@ -204,7 +206,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_merge:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

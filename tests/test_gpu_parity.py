@@ -241,3 +241,20 @@ def test_seq_process_matches_oracle_per_frame(ctx, oracle):
     finally:
         for p in (d_bgr, d_dep, d_sem, d_pose):
             ctx.dev_free(p)
+
+
+# ---------------------------------------------------------------- bench.py contract (and its all-gather path on one GPU)
+def test_bench_line_and_allgather_path():
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSM_FORCE_MERGE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "40", "--batch", "20", "--steps", "2", "--warmup", "1", "--cpu-frames", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "frames/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert line["value"] > 1000 and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 1
+    assert line["per_frame"]["voxels_in_map"] > 500
