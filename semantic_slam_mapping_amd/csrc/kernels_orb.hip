@@ -376,26 +376,37 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
 //   [n4..n1 of p_m] ... [n4..n1 of p_1] ++ (old list without the split parents).
 struct QNode { short x0, y0, x1, y1; };
 #define DROPPED 0xFFFF
+// NODES = LDS node capacity (512 covers 2000 features / 8 levels); keys (8 B) and their node ids (2 B) are copied into LDS
+// when the level has <= OT_KCAP candidates (always, in practice): the split passes then never touch global memory.
+#define OT_KCAP 4096
+template <int NODES>
 __global__ void __launch_bounds__(256)
 octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, const int32_t* __restrict__ cellmax,
               uint16_t* __restrict__ node_of, uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
 {
-    __shared__ QNode    nd[2][SSM_MAX_NODES];
-    __shared__ uint32_t cnt[2][SSM_MAX_NODES];
-    __shared__ uint32_t sq[2][SSM_MAX_NODES];
-    __shared__ uint32_t cc[SSM_MAX_NODES][4];
-    __shared__ short    newpos[SSM_MAX_NODES];
-    __shared__ short    childpos[SSM_MAX_NODES][4];
-    __shared__ short    order[SSM_MAX_NODES];
-    __shared__ unsigned long long best[SSM_MAX_NODES];
+    __shared__ QNode    nd[2][NODES];
+    __shared__ uint32_t cnt[2][NODES];
+    __shared__ uint32_t sq[2][NODES];
+    __shared__ uint32_t cc[NODES][4];
+    __shared__ short    newpos[NODES];
+    __shared__ short    childpos[NODES][4];
+    __shared__ short    order[NODES];
+    __shared__ unsigned long long best[NODES];
+    __shared__ cand_t   lkeys[OT_KCAP];
+    __shared__ uint16_t lnof[OT_KCAP];
     __shared__ int sL, sFinish, sMode, sErr, sValid;
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g.L[l];
     const int N = L.nfeat;
     int nc = ncand[f * g.nlevels + l];
     if (nc > L.cand_cap) { nc = L.cand_cap; if (tid == 0) atomicOr(status, 1); }
-    const cand_t* keys = cand + (size_t)f * g.cand_total + L.cand_off;
-    uint16_t* nof = node_of + (size_t)f * g.cand_total + L.cand_off;
+    const cand_t* gkeys = cand + (size_t)f * g.cand_total + L.cand_off;
+    uint16_t* gnof = node_of + (size_t)f * g.cand_total + L.cand_off;
+    const bool in_lds = nc <= OT_KCAP;                      // block-uniform
+    if (in_lds) for (int i = tid; i < nc; i += 256) lkeys[i] = gkeys[i];
+#define KEY(i) (in_lds ? lkeys[i] : gkeys[i])
+#define NOF(i) (in_lds ? lnof[i] : gnof[i])
+#define SETNOF(i, v) do { if (in_lds) lnof[i] = (uint16_t)(v); else gnof[i] = (uint16_t)(v); } while (0)
     uint32_t* out = sel + (size_t)f * g.sel_total + L.sel_off;
     if (nc == 0) { if (tid == 0) nsel[f * g.nlevels + l] = 0; return; }
     // ---- root nodes
@@ -410,13 +421,13 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     const int32_t* cm = cellmax + (size_t)f * g.cells_total + L.cell_off;
     int nvalid = 0;
     for (int i = tid; i < nc; i += 256) {
-        const cand_t k = keys[i];
+        const cand_t k = KEY(i);
         const int S = (int)(k.x >> 24) + 1;
         const int th = cm[k.y >> 14] > g.ini_th ? g.ini_th : g.min_th;
-        if (S <= th) { nof[i] = DROPPED; continue; }
+        if (S <= th) { SETNOF(i, DROPPED); continue; }
         const int x = k.x & 4095;
         int b = (int)((float)x / hX); b = min(b, nIni - 1);
-        nof[i] = (uint16_t)b; atomicAdd(&cnt[0][b], 1u); nvalid++;
+        SETNOF(i, b); atomicAdd(&cnt[0][b], 1u); nvalid++;
     }
     if (nvalid) atomicAdd(&sValid, nvalid);
     __syncthreads();
@@ -430,7 +441,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         sL = pos; sFinish = 0; sMode = 0;
     }
     __syncthreads();
-    for (int i = tid; i < nc; i += 256) if (nof[i] != DROPPED) nof[i] = (uint16_t)newpos[nof[i]];
+    for (int i = tid; i < nc; i += 256) { const int o = NOF(i); if (o != DROPPED) SETNOF(i, newpos[o]); }
     int cur = 1;      // buffer holding the current list
     __syncthreads();
     // ---- split passes
@@ -441,17 +452,18 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         for (int i = tid; i < Lsz; i += 256) { cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0; }
         __syncthreads();
         for (int i = tid; i < nc; i += 256) {
-            const int ni = nof[i];
+            const int ni = NOF(i);
             if (ni != DROPPED && ccnt[ni] > 1) {
                 const QNode q = cn[ni];
-                const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
+                const uint32_t kx = KEY(i).x;
+                const int x = kx & 4095, y = (kx >> 12) & 4095;
                 const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
                 atomicAdd(&cc[ni][qd], 1u);
             }
         }
-        // processing order for the second phase: rank among expandable nodes by (size desc, creation seq desc)
-        for (int i = tid; i < Lsz; i += 256) {
+        // processing order for the second phase only: rank among expandable nodes by (size desc, creation seq desc)
+        if (sMode == 1) for (int i = tid; i < Lsz; i += 256) {
             if (ccnt[i] > 1) {
                 const uint32_t ci = ccnt[i], si = csq[i];
                 int r = 0;
@@ -474,7 +486,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
                     for (int qd = 3; qd >= 0; qd--) {                                                           \
                         const uint32_t c = cc[i][qd];                                                           \
                         if (c == 0) { childpos[i][qd] = -1; continue; }                                         \
-                        if (pos >= SSM_MAX_NODES) { err = 1; childpos[i][qd] = 0; continue; }                   \
+                        if (pos >= NODES) { err = 1; childpos[i][qd] = 0; continue; }                   \
                         QNode ch;                                                                               \
                         ch.x0 = (qd & 1) ? (short)mx : q.x0; ch.x1 = (qd & 1) ? q.x1 : (short)mx;               \
                         ch.y0 = (qd & 2) ? (short)my : q.y0; ch.y1 = (qd & 2) ? q.y1 : (short)my;               \
@@ -487,7 +499,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
                 int e = E;
                 for (int i = Lsz - 1; i >= 0; i--) if (ccnt[i] > 1) { e--; EMIT_CHILDREN(i, e); newpos[i] = -2; }
                 for (int i = 0; i < Lsz; i++) if (ccnt[i] <= 1) {
-                    if (pos >= SSM_MAX_NODES) { err = 1; newpos[i] = 0; continue; }
+                    if (pos >= NODES) { err = 1; newpos[i] = 0; continue; }
                     nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
                 }
                 if (pos >= N || pos == Lsz) sFinish = 1;
@@ -504,7 +516,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
                 for (int i = 0; i < Lsz; i++) newpos[i] = 0;
                 for (int r = nsplit - 1; r >= 0; r--) { const int i = order[r]; EMIT_CHILDREN(i, r); newpos[i] = -2; }
                 for (int i = 0; i < Lsz; i++) if (newpos[i] != -2) {
-                    if (pos >= SSM_MAX_NODES) { err = 1; newpos[i] = 0; continue; }
+                    if (pos >= NODES) { err = 1; newpos[i] = 0; continue; }
                     nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
                 }
                 if (pos >= N || pos == Lsz) sFinish = 1;
@@ -515,15 +527,16 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         }
         __syncthreads();
         for (int i = tid; i < nc; i += 256) {
-            const int ni = nof[i];
+            const int ni = NOF(i);
             if (ni == DROPPED) continue;
             if (newpos[ni] == -2) {
                 const QNode q = cn[ni];
-                const int x = keys[i].x & 4095, y = (keys[i].x >> 12) & 4095;
+                const uint32_t kx = KEY(i).x;
+                const int x = kx & 4095, y = (kx >> 12) & 4095;
                 const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                nof[i] = (uint16_t)childpos[ni][qd];
-            } else nof[i] = (uint16_t)newpos[ni];
+                SETNOF(i, childpos[ni][qd]);
+            } else SETNOF(i, newpos[ni]);
         }
         cur ^= 1;
         __syncthreads();
@@ -534,10 +547,11 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     for (int i = tid; i < Lf; i += 256) best[i] = 0ull;
     __syncthreads();
     for (int i = tid; i < nc; i += 256) {
-        if (nof[i] == DROPPED) continue;
-        const cand_t k = keys[i];
+        const int ni = NOF(i);
+        if (ni == DROPPED) continue;
+        const cand_t k = KEY(i);
         const unsigned long long v = ((unsigned long long)(k.x >> 24) << 56) | ((unsigned long long)(0xFFFFFFFFu - k.y) << 24) | (k.x & 0xFFFFFFu);
-        atomicMax(&best[nof[i]], v);
+        atomicMax(&best[ni], v);
     }
     __syncthreads();
     for (int i = tid; i < Lf && i < L.sel_cap; i += 256) {
@@ -550,7 +564,11 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s)
 {
-    octree_kernel<<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    int need = 0;
+    for (int l = 0; l < g.nlevels; l++) need = need > g.L[l].nfeat + 3 ? need : g.L[l].nfeat + 3;
+    for (int l = 0; l < g.nlevels; l++) need = need > 4 * g.L[l].nIni + 8 ? need : 4 * g.L[l].nIni + 8;
+    if (need <= 512 - 8) octree_kernel<512><<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    else                 octree_kernel<1024><<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
     return hipGetLastError();
 }
 

@@ -750,8 +750,8 @@ static int seg_init(ssm_ctx* c)
     SegNetState* g = new SegNetState();
     c->seg = g;
     for (int l = 0; l < SEG_LAYERS; l++) {
-        g->cinp[l] = (k_seg_layers[l].cin + 15) & ~15; g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
-        g->coutstore[l] = (k_seg_layers[l].cout + 15) & ~15;            // the next layer reads multiples of 16 channels
+        g->cinp[l] = (k_seg_layers[l].cin + 31) & ~31; g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
+        g->coutstore[l] = (k_seg_layers[l].cout + 31) & ~31;            // activations live in 32-channel chunks: [C/32][H][W][32]
     }
     g->batch = c->B < 4 ? c->B : 4;
     const size_t act = (size_t)g->batch * SEG_NW * SEG_NH * 64 * 2;
@@ -780,9 +780,13 @@ extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, cons
     int r = seg_init(c); if (r) return r;
     SegNetState* g = c->seg;
     const int cin = k_seg_layers[l].cin, cout = k_seg_layers[l].cout, cinp = g->cinp[l], coutp = g->coutp[l];
-    std::vector<uint16_t> w((size_t)coutp * 9 * cinp, 0);            // [CoutPad][tap][CinPad], tap = ky*3 + kx
-    for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++)
-        w[((size_t)o * 9 + t) * cinp + i] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+    // packed for the LDS-tiled kernel: [Cout tile of 64][Cin chunk of 32][tap][c8 (4)][cout in tile (64)][8 channels]
+    std::vector<uint16_t> w((size_t)coutp * 9 * cinp, 0);
+    const int nck = cinp / 32;
+    for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++) {
+        const size_t idx = ((((((size_t)(o / 64) * nck + i / 32) * 9 + t) * 4 + (i % 32) / 8) * 64 + o % 64) * 8) + i % 8;
+        w[idx] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+    }
     if (!g->w[l]) { uint16_t* p; r = dalloc(c, &p, w.size()); if (r) return r; g->w[l] = p; DALLOC(c, g->scale[l], coutp); DALLOC(c, g->shift[l], coutp); }
     std::vector<float> sc(coutp, 0.f), sh(coutp, 0.f);
     for (int o = 0; o < cout; o++) { sc[o] = scale[o]; sh[o] = shift[o]; }
@@ -799,7 +803,7 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
     void* cur = g->actA; void* nxt = g->actB;
     auto conv = [&](int l) -> int {
         const SegLayerDef& d = k_seg_layers[l];
-        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, g->coutp[l], g->coutstore[l], l != SEG_LAYERS - 1, s));
+        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s));
         std::swap(cur, nxt); return SSM_OK;
     };
     auto pool = [&](int i, int H, int W, int C) -> int { HIPCHK(c, k_segnet_pool(cur, nb, H, W, C, nxt, g->code[i], s)); std::swap(cur, nxt); return SSM_OK; };
@@ -868,24 +872,42 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
     const int PH = (H + 1) / 2, PW = (W + 1) / 2;
     if (op == 0) {
         if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg]) FAIL(c, SSM_E_INVAL, "layer not set");
-        HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)H * W * g->cinp[arg] * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, g->coutp[arg], g->coutstore[arg], arg != SEG_LAYERS - 1, s));
-        HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)H * W * g->coutstore[arg] * 2, hipMemcpyDeviceToHost, s));
+        // host tensors are NHWC with channels padded to 16; the device layout is [C/32][H][W][32]
+        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15;
+        std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)H * W * g->coutstore[arg]);
+        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
+        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, arg != SEG_LAYERS - 1, s));
+        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < co16; ch++) out[p * co16 + ch] = hout[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32];
     } else if (op == 1 || op == 2) {
         const int C = arg;
-        if (C < 8 || C > 512 || (C & 7) || !code) FAIL(c, SSM_E_INVAL, "bad channel count");
+        if (C < 32 || C > 512 || (C & 31) || !code) FAIL(c, SSM_E_INVAL, "channel count must be a multiple of 32 (the activation chunk)");
         r = ensure_scratch(c, (size_t)PH * PW * C); if (r) return r;
         uint8_t* dcode = (uint8_t*)c->d_scratch;
+        // host NHWC <-> device [C/32][h][w][32]; the arg-max codes use the same element order as the pooled tensor
+        auto to_dev = [&](const uint16_t* src, int hh, int ww, std::vector<uint16_t>& d) { d.assign((size_t)hh * ww * C, 0); for (size_t p = 0; p < (size_t)hh * ww; p++) for (int ch = 0; ch < C; ch++) d[((size_t)(ch / 32) * hh * ww + p) * 32 + ch % 32] = src[p * C + ch]; };
+        auto to_host = [&](const std::vector<uint16_t>& d, int hh, int ww, uint16_t* dst) { for (size_t p = 0; p < (size_t)hh * ww; p++) for (int ch = 0; ch < C; ch++) dst[p * C + ch] = d[((size_t)(ch / 32) * hh * ww + p) * 32 + ch % 32]; };
+        std::vector<uint16_t> hin, hout; std::vector<uint8_t> hcode((size_t)PH * PW * C);
         if (op == 1) {
-            HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)H * W * C * 2, hipMemcpyHostToDevice, s));
+            to_dev(in, H, W, hin); hout.resize((size_t)PH * PW * C);
+            HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
             HIPCHK(c, k_segnet_pool(g->actA, 1, H, W, C, g->actB, dcode, s));
-            HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)PH * PW * C * 2, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(code, dcode, (size_t)PH * PW * C, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(hcode.data(), dcode, hcode.size(), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            to_host(hout, PH, PW, out);
+            for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < C; ch++) code[p * C + ch] = hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
         } else {
-            HIPCHK(c, hipMemcpyAsync(g->actA, in, (size_t)PH * PW * C * 2, hipMemcpyHostToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(dcode, code, (size_t)PH * PW * C, hipMemcpyHostToDevice, s));
+            to_dev(in, PH, PW, hin); hout.resize((size_t)H * W * C);
+            for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < C; ch++) hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = code[p * C + ch];
+            HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(dcode, hcode.data(), hcode.size(), hipMemcpyHostToDevice, s));
             HIPCHK(c, k_segnet_unpool(g->actA, dcode, 1, PH, PW, C, g->actB, H, W, s));
-            HIPCHK(c, hipMemcpyAsync(out, g->actB, (size_t)H * W * C * 2, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            to_host(hout, H, W, out);
         }
     } else FAIL(c, SSM_E_INVAL, "unknown op");
     HIPCHK(c, hipStreamSynchronize(s));

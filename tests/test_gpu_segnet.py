@@ -74,7 +74,7 @@ def test_conv_layer_exact(ctx, layer, h, w):
     assert np.array_equal(got, y.transpose(1, 2, 0).astype(np.float16))
 
 
-@pytest.mark.parametrize("h,w,c", [(45, 60, 16), (23, 30, 64), (8, 8, 8), (5, 7, 24)])
+@pytest.mark.parametrize("h,w,c", [(45, 60, 32), (23, 30, 64), (8, 8, 32), (5, 7, 96)])
 def test_pool_unpool_exact(ctx, seg, h, w, c):
     """2x2 s2 CEIL max-pool with first-maximum arg-max code, and the mask-driven Upsample with explicit (odd) output size"""
     import torch
