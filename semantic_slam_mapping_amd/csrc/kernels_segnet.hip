@@ -106,28 +106,43 @@ conv3x3_lds_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
     CT_FETCH(0)
     for (int ck = 0; ck < nchunks; ck++) {
         __syncthreads();                                             // previous stage fully consumed
+#ifdef CT_ABL_NOLDSW
+        if (ck == 0) {
+#endif
 #pragma unroll
         for (int k = 0; k < NA; k++) if (a_dst[k] >= 0) sa[a_dst[k]] = ra[k];
 #pragma unroll
         for (int k = 0; k < NB; k++) sb[tid + 256 * k] = rb[k];
+#ifdef CT_ABL_NOLDSW
+        }
+#endif
         __syncthreads();
+#ifndef CT_ABL_NOFETCH
         if (ck + 1 < nchunks) CT_FETCH(ck + 1)
+#endif
+        // 18 steps (tap, K-half) of 4 MFMAs; the 4 operand fragments of step s+1 are read from LDS while step s runs
+        half8 fa[2][2], fb[2][2];
+#define CT_LOADF(buf, st)                                                                               \
+        {   const int tap_ = (st) >> 1, c8_ = ((st) & 1) * 2 + hh, dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;      \
+            const half8* pa_ = sa + c8_ * (CT_PH * CT_PW) + (2 * wv + dy_) * CT_PW + r + dx_;                 \
+            const half8* pb_ = sb + (tap_ * 4 + c8_) * CT_N + r;                                              \
+            fa[buf][0] = pa_[0]; fa[buf][1] = pa_[CT_PW]; fb[buf][0] = pb_[0]; fb[buf][1] = pb_[32]; }
+        CT_LOADF(0, 0)
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3, dx = tap - dy * 3;                 // already offset by the halo (+1)
+        for (int st = 0; st < 18; st++) {
+            const int cur = st & 1;
+            if (st + 1 < 18) CT_LOADF(cur ^ 1, st + 1)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int c8 = ks * 2 + hh;
-                const half8* pa = sa + c8 * (CT_PH * CT_PW) + (2 * wv + dy) * CT_PW + r + dx;
-                const half8 A0 = pa[0], A1 = pa[CT_PW];
-                const half8* pbv = sb + (tap * 4 + c8) * CT_N + r;
-                const half8 B0 = pbv[0], B1 = pbv[32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, acc[1][1], 0, 0, 0);
+            for (int q = 0; q < 4; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one ds_read of the next step ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // ... then one MFMA of this step
             }
         }
+#undef CT_LOADF
     }
 #undef CT_FETCH
     // output in the same chunked layout: chunk = channel / 32; a wave-half writes 64 contiguous bytes per pixel
@@ -153,6 +168,202 @@ conv3x3_lds_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ conv3x3, LDS-DMA staged (the kernel the network runs on)
+// Same implicit GEMM and the same LDS images as above, but
+//   * one 512-thread block (8 waves) per CU owns a 32 x 16 pixel tile x 64 output channels, so a staged weight slab is
+//     shared by twice the pixels (L2 -> LDS bytes per flop -35 %);
+//   * operands go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass): the LDS image
+//     of a stage is lane-linear (wave-instruction j fills chunks 64j..64j+63), halo pixels outside the image are
+//     out-of-range buffer offsets, which the DMA writes as zeros;
+//   * two LDS buffers: the DMA of stage k+1 is issued, one instruction per MFMA step, under the MFMAs of stage k; one
+//     barrier per stage;
+//   * the frames of a batch are stacked into one virtual image of n x VH rows (VH = H rounded up to even, + >= 1 zero row,
+//     so vertical halos never leak between frames); 16-row tiles run over the stack: the 23-row layers waste 4 %, not 28 %;
+//   * MFMA operands are swapped (D rows = output channels, columns = pixels) so a lane ends up with 4 consecutive output
+//     channels of one pixel per accumulator quad: 8-byte stores, 4 per 32 channels;
+//   * blockIdx.x = pixel_tile * n_cout_tiles + cout_tile: the cout tiles of one pixel tile are neighbours in launch order,
+//     i.e. spread round-robin over the 8 XCDs, so every XCD's L2 keeps re-serving the same 64-channel weight slab.
+#define DT_W 32
+#define DT_H 16
+#define DT_PW (DT_W + 2)
+#define DT_PH (DT_H + 2)
+#define DT_PLANE (DT_PH * DT_PW)              // 612 pixels per 8-channel plane
+#define DT_ACH (4 * DT_PLANE)                 // 2448 16-byte chunks of input per stage
+#define DT_AINS 40                            // A wave-instructions per stage (5 per wave; 2560 slots, the tail is padding)
+#define DT_BCH (9 * 4 * CT_N)                 // 2304 chunks of weights per stage = 36 wave-instructions
+#define DT_STAGE (DT_AINS * 64 + DT_BCH)      // chunks per LDS buffer (77,824 B)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <bool RELU>
+__global__ void __launch_bounds__(512, 1)
+conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
+                   _Float16* __restrict__ out, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                   unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
+{
+    // two stage buffers, as two objects: the compiler then knows that the DMA into one never aliases the fragment reads of
+    // the other (with one array and a run-time index it drains vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) half8 lds0[DT_STAGE];
+    __shared__ __attribute__((aligned(16))) half8 lds1[DT_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int VH = (H + 2) & ~1, VR = n * VH;                                      // the launcher keeps VR < 65536
+    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;                   // floor(v / VH) = umulhi(v, magic) for v < 2^16
+    const int nchunks = Cin / CT_KC;
+    const unsigned plane_bytes = (unsigned)H * W * 64u;                            // one 32-channel chunk of one frame
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    // folded BN scale / shift of the block's 64 output channels (a persistent block keeps its cout tile), zero for padding
+    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    if (tid < 2 * CT_N) {
+        const int ch = (blockIdx.x % ncout_tiles) * CT_N + (tid & (CT_N - 1));
+        s_ss[tid >> 6][tid & (CT_N - 1)] = ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+    }
+    // per-thread DMA slots: wave-instruction j = wv + 8k fills LDS chunks 64j..64j+63 of a stage.  Within a tile only the
+    // scalar offset moves from stage to stage; the per-lane input offsets are recomputed when the pipeline crosses into the
+    // block's next tile.
+    unsigned a_off[5], b_off[5]; int b_j[5];
+    int a_py[5], a_px[5]; unsigned a_c8[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int i = (wv + 8 * k) * 64 + lane;
+        const int c8 = i / DT_PLANE, p = i - c8 * DT_PLANE;
+        a_py[k] = i < DT_ACH ? p / DT_PW : -0x10000;                                // padding slots never become valid
+        a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
+        b_j[k] = min(wv + 8 * k, DT_BCH / 64 - 1);                                 // waves 4..7 repeat instruction 35 (same bytes, same place)
+        b_off[k] = (unsigned)(b_j[k] * 64 + lane) * 16u;
+    }
+#define DT_TILE_OFFSETS(tile)                                                                           \
+    {   const int pt_ = (tile) / ncout_tiles;                                                           \
+        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
+            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;   /* exact for 0 <= v < 65536 */ \
+            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
+            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u;   /* out of range -> zeros */ \
+        } }
+#define DT_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 8 * (k)) * 64], 16, a_off[k], so, 0, 0);
+#define DT_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[DT_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
+    int tile = blockIdx.x;
+    DT_TILE_OFFSETS(tile)
+    {
+        const unsigned bso = (unsigned)(tile % ncout_tiles) * nchunks * (DT_BCH * 16u);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { DT_DMA_A(k, lds0, 0u) DT_DMA_B(k, lds0, bso) }
+        // eight out-of-range (dropped) stores, so that "a tile's first DMA batch is followed by exactly 8 stores" also holds for
+        // the first tile: the wait at the top of every tile is then the same vmcnt(8) on every path
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        const uint4v z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);
+    }
+    // nchunks is even (the launcher sends the 32-channel first layer elsewhere), so every tile starts in lds0 and the two
+    // stage bodies below use compile-time buffers
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
+        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;      // ty0 is a row of the stacked virtual image
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+        // one stage: 18 steps of 4 MFMAs on buffer `rd`, with the next stage's 10 DMA instructions (into `wr`) and the next
+        // step's fragment reads issued ahead of each step's MFMAs.  Past the block's last stage every DMA lane is out of
+        // range: a zero fill of the idle buffer, which keeps the stage body one basic block.
+#define DT_LOADF(rd, fbuf, st)                                                                          \
+        {   const int tap_ = (st) >> 1, c8_ = ((st) & 1) * 2 + hh, dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;      \
+            const half8* pa_ = rd + c8_ * DT_PLANE + (2 * wv + dy_) * DT_PW + r + dx_;                        \
+            const half8* pb_ = rd + DT_AINS * 64 + (tap_ * 4 + c8_) * CT_N + r;                               \
+            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fb[fbuf][0] = pb_[0]; fb[fbuf][1] = pb_[32]; }
+#define DT_STAGE_BODY(rd, wr)                                                                           \
+        {   half8 fa[2][2], fb[2][2];                                                                   \
+            DT_LOADF(rd, 0, 0)                                                                          \
+            _Pragma("unroll") for (int st = 0; st < 18; st++) {                                         \
+                const int cur = st & 1;                                                                 \
+                if (st < 5) DT_DMA_A(st, wr, a_so)                                                      \
+                else if (st < 10) DT_DMA_B(st - 5, wr, b_so)                                            \
+                if (st + 1 < 18) DT_LOADF(rd, cur ^ 1, st + 1)                                          \
+                __builtin_amdgcn_sched_barrier(0);   /* reads of step st+1 stay ahead of the MFMAs of step st */ \
+                /* D[cout][pixel] += W[cout][k] X[k][pixel]: weights are the row operand */             \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][0], fa[cur][0], acc[0][0], 0, 0, 0); \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][1], fa[cur][0], acc[0][1], 0, 0, 0); \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][0], fa[cur][1], acc[1][0], 0, 0, 0); \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][1], fa[cur][1], acc[1][1], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+            } }
+        for (int ck = 0; ck < nchunks; ck += 2) {
+            // this wave's share of the stage has landed (the DMA is older than the previous tile's epilogue stores, which may
+            // stay in flight: vmcnt retires in order); after the barrier everybody's has, and the previous stage is consumed
+            if (ck == 0) __builtin_amdgcn_s_waitcnt(0x0F78);                     // vmcnt(8): exactly 8 stores per epilogue, all younger than the DMA
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            unsigned a_so = (unsigned)(ck + 1) * plane_bytes, b_so = ((unsigned)ct * nchunks + ck + 1) * (DT_BCH * 16u);
+            DT_STAGE_BODY(lds0, lds1)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            // the stage after this one: the next 32 input channels of this tile, or the first 32 of the block's next tile
+            if (ck + 2 < nchunks) {
+                a_so = (unsigned)(ck + 2) * plane_bytes;
+                b_so = ((unsigned)ct * nchunks + ck + 2) * (DT_BCH * 16u);
+            } else {
+                const int nt = tile + gridDim.x;
+                DT_TILE_OFFSETS(nt)
+                a_so = 0u;
+                b_so = nt < total_tiles ? (unsigned)(nt % ncout_tiles) * nchunks * (DT_BCH * 16u) : 0x80000000u;
+            }
+            DT_STAGE_BODY(lds1, lds0)
+        }
+#undef DT_STAGE_BODY
+#undef DT_LOADF
+        // epilogue: lane = (pixel x = tx0 + r, channel quad): acc[tm][tn][4g+q] is channel n0 + 32 tn + 8 g + 4 hh + q.
+        // The two halves of the wave trade quads (v_permlane32_swap) so that a lane owns 8 consecutive channels: 16-byte stores.
+        const int cout_chunks = (Cout + 31) >> 5, n0 = ct * CT_N;
+        const int gx = tx0 + r;
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const int v = ty0 + 2 * wv + tm;
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;
+            const bool live = v < VR && y < H && gx < W;
+#pragma unroll
+            for (int tn = 0; tn < 2; tn++) {
+                const int chunk = (n0 >> 5) + tn;
+                // dead lanes (and a padding 32-channel chunk) get an out-of-range offset: the buffer store drops them, and every
+                // wave issues exactly 8 store instructions per tile (the vmcnt(8) above relies on it)
+                const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y) * W + gx) * 64 + 16 * hh) : 0x80000000u;
+#pragma unroll
+                for (int gp = 0; gp < 2; gp++) {
+                    unsigned pk[2][2];                                            // [quad of the pair][half2]
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int g = 2 * gp + e, cl = 32 * tn + 8 * g + 4 * hh;
+                        const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
+                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                        _Float16 hv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float val = acc[tm][tn][4 * g + q] * scv[q] + sfv[q];
+                            if (RELU) val = fmaxf(val, 0.f);
+                            hv[q] = (_Float16)val;
+                        }
+                        memcpy(&pk[e][0], &hv[0], 4); memcpy(&pk[e][1], &hv[2], 4);
+                    }
+                    // lanes 0-31 keep quad 2gp (channels +0..3) and receive the upper half's quad 2gp (+4..7);
+                    // lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own (+12..15)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+                    uint4v st; st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
+                    __builtin_amdgcn_raw_buffer_store_b128(st, rsO, ob + 32u * gp, 0, 0);
+                }
+            }
+        }
+    }
+#undef DT_DMA_A
+#undef DT_DMA_B
+#undef DT_TILE_OFFSETS
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 stride 2, CEIL mode, with arg-max code
@@ -259,8 +470,33 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
     segnet_prep_kernel<<<dim3((dw * dh + 255) / 256, n), 256, 0, s>>>(bgr, sw, sh, dw, dh, xofs, xa, yofs, ya, (_Float16*)out_f16);
     return hipGetLastError();
 }
+hipError_t k_segnet_conv_regstage(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
+                                  int CinPad, int Cout, int relu, hipStream_t s);
+static int conv_grid_limit()
+{
+    static int cus = 0;
+    if (!cus) { int dev = 0; hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    return cus;
+}
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s)
+{
+    if ((CinPad / CT_KC) & 1) return k_segnet_conv_regstage(in, wt, scale, shift, out, n, H, W, CinPad, Cout, relu, s);
+    const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1;
+    const unsigned long long in_bytes = (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct * CT_N * CinPad * 9 * 2;
+    const unsigned long long out_bytes = (unsigned long long)n * H * W * ((Cout + 31) & ~31) * 2;
+    // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
+    if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
+    const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
+    // persistent blocks, one per CU (the LDS holds one); a multiple of the cout-tile count so a block keeps its weight slab
+    int grid = conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
+    if (relu) conv3x3_dma_kernel<true><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
+    else      conv3x3_dma_kernel<false><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
+    return hipGetLastError();
+}
+// the register-staged kernel (two 256-thread blocks per CU); kept for scripts/ubench/conv_bench.hip comparisons
+hipError_t k_segnet_conv_regstage(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
+                                  int CinPad, int Cout, int relu, hipStream_t s)
 {
     const int tx = (W + CT_W - 1) / CT_W, ty = (H + CT_H - 1) / CT_H;
     dim3 grid(tx * ty, (Cout + CT_N - 1) / CT_N, n);

@@ -753,7 +753,7 @@ static int seg_init(ssm_ctx* c)
         g->cinp[l] = (k_seg_layers[l].cin + 31) & ~31; g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
         g->coutstore[l] = (k_seg_layers[l].cout + 31) & ~31;            // activations live in 32-channel chunks: [C/32][H][W][32]
     }
-    g->batch = c->B < 4 ? c->B : 4;
+    g->batch = c->B < 32 ? c->B : 32;          // 32 frames per launch: the 23x30 layers then have 768 workgroups (3 at one frame)
     const size_t act = (size_t)g->batch * SEG_NW * SEG_NH * 64 * 2;
     uint8_t* p;
     int r = dalloc(c, &p, act); if (r) return r; g->actA = p;
