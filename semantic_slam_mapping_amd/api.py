@@ -176,6 +176,16 @@ class Context:
         self._chk(self.lib.ssm_segnet_debug_op(self.h, 0, layer, _ptr(x), h, w, _ptr(out), None))
         return out[:, :, :cout]
 
+    def segnet_debug_conv_pool(self, layer, x_hwc_f16):
+        """conv + BN + ReLU + 2x2 max-pool of `layer` through the fused kernel the network uses: (pooled, codes)."""
+        cin, cout, _, _ = self.segnet_layers()[layer]
+        x = np.ascontiguousarray(x_hwc_f16, np.float16); h, w, c = x.shape
+        ci16, co16 = (cin + 15) & ~15, (cout + 15) & ~15
+        xin = np.zeros((h, w, ci16), np.float16); xin[:, :, :c] = x
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2, co16), np.float16); code = np.zeros(out.shape, np.uint8)
+        self._chk(self.lib.ssm_segnet_debug_op(self.h, 3, layer, _ptr(xin), h, w, _ptr(out), _ptr(code)))
+        return out[:, :, :cout], code[:, :, :cout]
+
     def segnet_debug_pool(self, x_hwc_f16):
         x = np.ascontiguousarray(x_hwc_f16, np.float16); h, w, c = x.shape
         out = np.zeros(((h + 1) // 2, (w + 1) // 2, c), np.float16); code = np.zeros(out.shape, np.uint8)

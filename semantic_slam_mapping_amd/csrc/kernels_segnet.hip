@@ -195,10 +195,12 @@ conv3x3_lds_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
 #define DT_BCH (9 * 4 * CT_N)                 // 2304 chunks of weights per stage = 36 wave-instructions
 #define DT_STAGE (DT_AINS * 64 + DT_BCH)      // chunks per LDS buffer (77,824 B)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <bool RELU>
+// EPI 0: out = conv (+BN, ReLU).  EPI 1: out = the 2x2 max-pooled conv, code = the arg-max codes; the full-resolution
+// activation is never written.
+template <bool RELU, int EPI>
 __global__ void __launch_bounds__(512, 1)
 conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
-                   _Float16* __restrict__ out, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                   _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
 {
     // two stage buffers, as two objects: the compiler then knows that the DMA into one never aliases the fragment reads of
@@ -214,6 +216,7 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
     // folded BN scale / shift of the block's 64 output channels (a persistent block keeps its cout tile), zero for padding
     __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
     if (tid < 2 * CT_N) {
@@ -320,21 +323,22 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
 #undef DT_LOADF
         // epilogue: lane = (pixel x = tx0 + r, channel quad): acc[tm][tn][4g+q] is channel n0 + 32 tn + 8 g + 4 hh + q.
         // The two halves of the wave trade quads (v_permlane32_swap) so that a lane owns 8 consecutive channels: 16-byte stores.
+        // Dead lanes (and a padding 32-channel chunk) get an out-of-range offset: the buffer store drops them, and every wave
+        // issues exactly 8 store instructions per tile (the vmcnt(8) above relies on it).
         const int cout_chunks = (Cout + 31) >> 5, n0 = ct * CT_N;
         const int gx = tx0 + r;
+        const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
+        const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
+        const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const int v = ty0 + 2 * wv + tm;
-            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;
-            const bool live = v < VR && y < H && gx < W;
+        for (int tn = 0; tn < 2; tn++) {
+            const int chunk = (n0 >> 5) + tn;
 #pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int chunk = (n0 >> 5) + tn;
-                // dead lanes (and a padding 32-channel chunk) get an out-of-range offset: the buffer store drops them, and every
-                // wave issues exactly 8 store instructions per tile (the vmcnt(8) above relies on it)
-                const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y) * W + gx) * 64 + 16 * hh) : 0x80000000u;
+            for (int gp = 0; gp < 2; gp++) {
+                uint4v vec[2];                                                    // [row] 8 consecutive channels, fp16
 #pragma unroll
-                for (int gp = 0; gp < 2; gp++) {
+                for (int tm = 0; tm < 2; tm++) {
                     unsigned pk[2][2];                                            // [quad of the pair][half2]
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
@@ -354,9 +358,44 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
                     // lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own (+12..15)
                     const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-                    uint4v st; st.x = s0[0]; st.y = s1[0]; st.z = s0[1]; st.w = s1[1];
-                    __builtin_amdgcn_raw_buffer_store_b128(st, rsO, ob + 32u * gp, 0, 0);
+                    vec[tm].x = s0[0]; vec[tm].y = s1[0]; vec[tm].z = s0[1]; vec[tm].w = s1[1];
+                }
+                if (EPI == 0) {
+#pragma unroll
+                    for (int tm = 0; tm < 2; tm++) {
+                        const bool live = tm ? live1 : live0;
+                        const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y0 + tm) * W + gx) * 64 + 16 * hh + 32 * gp) : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(vec[tm], rsO, ob, 0, 0);
+                    }
+                } else {
+                    // fused 2x2 / stride 2 max-pool with arg-max code (pool2x2_kernel's contract: window scanned row-major,
+                    // strict '>' so the first maximum wins; windows are clipped at the right / bottom edge).  The window of an
+                    // even lane is its own two rows and those of lane + 1 (quad_perm [1,0,3,2]).
+                    uint4v nb[2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; tm++) {
+                        nb[tm].x = __builtin_amdgcn_mov_dpp(vec[tm].x, 0xB1, 0xF, 0xF, true); nb[tm].y = __builtin_amdgcn_mov_dpp(vec[tm].y, 0xB1, 0xF, 0xF, true);
+                        nb[tm].z = __builtin_amdgcn_mov_dpp(vec[tm].z, 0xB1, 0xF, 0xF, true); nb[tm].w = __builtin_amdgcn_mov_dpp(vec[tm].w, 0xB1, 0xF, 0xF, true);
+                    }
+                    const bool right = gx + 1 < W;
+                    _Float16 best[8]; unsigned char bc[8];
+                    _Float16 c01[8], c10[8], c11[8];
+                    memcpy(best, &vec[0], 16); memcpy(c01, &nb[0], 16); memcpy(c10, &vec[1], 16); memcpy(c11, &nb[1], 16);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        bc[k] = 0;
+                        if (right && c01[k] > best[k]) { best[k] = c01[k]; bc[k] = 1; }
+                        if (live1 && c10[k] > best[k]) { best[k] = c10[k]; bc[k] = 2; }
+                        if (live1 && right && c11[k] > best[k]) { best[k] = c11[k]; bc[k] = 3; }
+                    }
+                    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+                    const bool plive = live0 && !(r & 1) && chunk < cout_chunks;
+                    const unsigned pidx = (unsigned)(((f * cout_chunks + chunk) * PH + (y0 >> 1)) * PW + (gx >> 1)) * 32u + 8u * hh + 16u * gp;   // elements
+                    uint4v pv; memcpy(&pv, best, 16);
+                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                    uint2v cv; memcpy(&cv, bc, 8);
+                    __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, plive ? pidx * 2u : 0x80000000u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(cv, rsC, plive ? pidx : 0x80000000u, 0, 0);
                 }
             }
         }
@@ -478,21 +517,35 @@ static int conv_grid_limit()
     if (!cus) { int dev = 0; hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
     return cus;
 }
-hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
-                         int CinPad, int Cout, int relu, hipStream_t s)
+static hipError_t conv_dma_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
+                                  int CinPad, int Cout, int relu, int pool, hipStream_t s)
 {
-    if ((CinPad / CT_KC) & 1) return k_segnet_conv_regstage(in, wt, scale, shift, out, n, H, W, CinPad, Cout, relu, s);
-    const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1;
+    const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1, cs = (Cout + 31) & ~31;
     const unsigned long long in_bytes = (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct * CT_N * CinPad * 9 * 2;
-    const unsigned long long out_bytes = (unsigned long long)n * H * W * ((Cout + 31) & ~31) * 2;
+    const unsigned long long out_bytes = pool ? (unsigned long long)n * ((H + 1) / 2) * ((W + 1) / 2) * cs * 2 : (unsigned long long)n * H * W * cs * 2;
     // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
     if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
     // persistent blocks, one per CU (the LDS holds one); a multiple of the cout-tile count so a block keeps its weight slab
     int grid = conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
-    if (relu) conv3x3_dma_kernel<true><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
-    else      conv3x3_dma_kernel<false><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
+#define DT_LAUNCH(R, E) conv3x3_dma_kernel<R, E><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+    if (pool) { if (relu) DT_LAUNCH(true, 1); else DT_LAUNCH(false, 1); }
+    else      { if (relu) DT_LAUNCH(true, 0); else DT_LAUNCH(false, 0); }
+#undef DT_LAUNCH
     return hipGetLastError();
+}
+hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
+                         int CinPad, int Cout, int relu, hipStream_t s)
+{
+    if ((CinPad / CT_KC) & 1) return k_segnet_conv_regstage(in, wt, scale, shift, out, n, H, W, CinPad, Cout, relu, s);
+    return conv_dma_launch(in, wt, scale, shift, out, nullptr, n, H, W, CinPad, Cout, relu, 0, s);
+}
+// conv + BN + ReLU + max-pool 2x2 (CEIL) in one pass: out is [n][Cout/32][PH][PW][32], code the arg-max codes in the same index space
+hipError_t k_segnet_conv_pool(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
+                              int CinPad, int Cout, hipStream_t s)
+{
+    if ((CinPad / CT_KC) & 1) return hipErrorInvalidValue;
+    return conv_dma_launch(in, wt, scale, shift, out, code, n, H, W, CinPad, Cout, 1, 1, s);
 }
 // the register-staged kernel (two 256-thread blocks per CU); kept for scripts/ubench/conv_bench.hip comparisons
 hipError_t k_segnet_conv_regstage(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,

@@ -54,7 +54,7 @@ struct SegNetState {
     void* w[SEG_LAYERS] = {}; float* scale[SEG_LAYERS] = {}; float* shift[SEG_LAYERS] = {};
     int cinp[SEG_LAYERS], coutp[SEG_LAYERS], coutstore[SEG_LAYERS];
     int batch = 0;
-    void *actA = nullptr, *actB = nullptr; uint8_t* code[5] = {}; uint8_t* labels = nullptr;
+    void *actA = nullptr, *actB = nullptr, *last_logits = nullptr; uint8_t* code[5] = {}; uint8_t* labels = nullptr;
     int32_t *pre_xofs = nullptr, *pre_yofs = nullptr, *post_xofs = nullptr, *post_yofs = nullptr;
     int16_t *pre_xa = nullptr, *pre_ya = nullptr, *post_xa = nullptr, *post_ya = nullptr;
     uint8_t* d_sem_gen = nullptr;       // generated colour labels for the sequence path (max_batch frames)
@@ -806,14 +806,19 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
         HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s));
         std::swap(cur, nxt); return SSM_OK;
     };
-    auto pool = [&](int i, int H, int W, int C) -> int { HIPCHK(c, k_segnet_pool(cur, nb, H, W, C, nxt, g->code[i], s)); std::swap(cur, nxt); return SSM_OK; };
     auto unpool = [&](int i, int PH, int PW, int C, int H, int W) -> int { HIPCHK(c, k_segnet_unpool(cur, g->code[i], nb, PH, PW, C, nxt, H, W, s)); std::swap(cur, nxt); return SSM_OK; };
+    // conv + pool pairs run as one kernel (the full-resolution activation of the pooled layer is never written)
+    auto conv_pool = [&](int l, int i) -> int {
+        const SegLayerDef& d = k_seg_layers[l];
+        HIPCHK(c, k_segnet_conv_pool(cur, g->w[l], g->scale[l], g->shift[l], nxt, g->code[i], nb, d.h, d.w, g->cinp[l], d.cout, s));
+        std::swap(cur, nxt); return SSM_OK;
+    };
     int r;
-    if ((r = conv(0)) || (r = conv(1)) || (r = pool(0, 360, 480, 64))) return r;
-    if ((r = conv(2)) || (r = conv(3)) || (r = pool(1, 180, 240, 128))) return r;
-    if ((r = conv(4)) || (r = conv(5)) || (r = conv(6)) || (r = pool(2, 90, 120, 256))) return r;
-    if ((r = conv(7)) || (r = conv(8)) || (r = conv(9)) || (r = pool(3, 45, 60, 512))) return r;
-    if ((r = conv(10)) || (r = conv(11)) || (r = conv(12)) || (r = pool(4, 23, 30, 512))) return r;
+    if ((r = conv(0)) || (r = conv_pool(1, 0))) return r;
+    if ((r = conv(2)) || (r = conv_pool(3, 1))) return r;
+    if ((r = conv(4)) || (r = conv(5)) || (r = conv_pool(6, 2))) return r;
+    if ((r = conv(7)) || (r = conv(8)) || (r = conv_pool(9, 3))) return r;
+    if ((r = conv(10)) || (r = conv(11)) || (r = conv_pool(12, 4))) return r;
     if ((r = unpool(4, 12, 15, 512, 23, 30)) || (r = conv(13)) || (r = conv(14)) || (r = conv(15))) return r;
     if ((r = unpool(3, 23, 30, 512, 45, 60)) || (r = conv(16)) || (r = conv(17)) || (r = conv(18))) return r;
     if ((r = unpool(2, 45, 60, 256, 90, 120)) || (r = conv(19)) || (r = conv(20)) || (r = conv(21))) return r;
@@ -833,6 +838,7 @@ static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* label
         HIPCHK(c, k_segnet_prep(bgr + (size_t)f0 * W * H * 3, nb, W, H, SEG_NW, SEG_NH, g->pre_xofs, g->pre_xa, g->pre_yofs, g->pre_ya, g->actA, s));
         void* logits = nullptr;
         r = seg_forward_core(c, nb, &logits); if (r) return r;
+        g->last_logits = logits;                   // frame f0 of the last sub-batch starts the buffer (ssm_segnet_logits reads it)
         HIPCHK(c, k_segnet_argmax(logits, nb, SEG_NW * SEG_NH, g->coutstore[SEG_LAYERS - 1], SEG_NCLS, g->labels, s));
         if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net + (size_t)f0 * SEG_NW * SEG_NH, g->labels, (size_t)nb * SEG_NW * SEG_NH, hipMemcpyDeviceToDevice, s));
         if (sem_bgr) HIPCHK(c, k_segnet_color(g->labels, nb, SEG_NW, SEG_NH, W, H, g->post_xofs, g->post_xa, g->post_yofs, g->post_ya,
@@ -909,6 +915,23 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
             HIPCHK(c, hipStreamSynchronize(s));
             to_host(hout, H, W, out);
         }
+    } else if (op == 3) {                 // conv + BN + ReLU + max-pool of layer `arg` as the network runs it (one kernel)
+        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || (g->cinp[arg] / 32) % 2) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused conv+pool kernel takes");
+        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15, cs = g->coutstore[arg];
+        std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)PH * PW * cs);
+        std::vector<uint8_t> hcode((size_t)PH * PW * cs);
+        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
+        r = ensure_scratch(c, hcode.size()); if (r) return r;
+        uint8_t* dcode = (uint8_t*)c->d_scratch;
+        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(c, k_segnet_conv_pool(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, dcode, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, s));
+        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(hcode.data(), dcode, hcode.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < co16; ch++) {
+            out[p * co16 + ch] = hout[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
+            code[p * co16 + ch] = hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
+        }
     } else FAIL(c, SSM_E_INVAL, "unknown op");
     HIPCHK(c, hipStreamSynchronize(s));
     return SSM_OK;
@@ -918,11 +941,11 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
     if (!c || !out) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!c->seg) FAIL(c, SSM_E_INVAL, "no forward has run");
-    // the last conv wrote into whichever ping-pong buffer 26 convs + 10 pool/unpool swaps end in: actA (even number of swaps)
+    if (!c->seg->last_logits) FAIL(c, SSM_E_INVAL, "no forward has run");
     const int cs = c->seg->coutstore[SEG_LAYERS - 1];
     std::vector<uint16_t> h((size_t)SEG_NW * SEG_NH * cs);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h.data(), c->seg->actA, h.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h.data(), c->seg->last_logits, h.size() * 2, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < (size_t)SEG_NW * SEG_NH; p++)
         for (int k = 0; k < SEG_NCLS; k++) { _Float16 v; memcpy(&v, &h[p * cs + k], 2); out[p * SEG_NCLS + k] = (float)v; }
     return SSM_OK;

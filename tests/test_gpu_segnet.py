@@ -74,6 +74,23 @@ def test_conv_layer_exact(ctx, layer, h, w):
     assert np.array_equal(got, y.transpose(1, 2, 0).astype(np.float16))
 
 
+@pytest.mark.parametrize("layer,h,w", [(1, 23, 31), (3, 45, 60), (6, 16, 32), (12, 17, 33)])
+def test_conv_pool_fused_exact(ctx, layer, h, w):
+    """the encoder's conv+pool pairs run as ONE kernel (pool in the conv epilogue): values and arg-max codes must equal
+    conv -> pool through the separate kernels, bit for bit (integer data with many ties; odd sizes clip the last windows)"""
+    cin, cout, _, _ = ctx.segnet_layers()[layer]
+    rng = np.random.default_rng(layer * 977 + h)
+    wt = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
+    sc = (2.0 ** rng.integers(-7, -4, cout)).astype(np.float32); sh = rng.integers(-3, 4, cout).astype(np.float32)
+    ctx.segnet_set_layer(layer, wt, sc, sh)
+    x = rng.integers(-2, 3, (h, w, cin)).astype(np.float16)
+    full = ctx.segnet_debug_conv(layer, x)
+    p_ref, c_ref = ctx.segnet_debug_pool(full)
+    p, c = ctx.segnet_debug_conv_pool(layer, x)
+    assert np.array_equal(p, p_ref)
+    assert np.array_equal(c, c_ref)
+
+
 @pytest.mark.parametrize("h,w,c", [(45, 60, 32), (23, 30, 64), (8, 8, 32), (5, 7, 96)])
 def test_pool_unpool_exact(ctx, seg, h, w, c):
     """2x2 s2 CEIL max-pool with first-maximum arg-max code, and the mask-driven Upsample with explicit (odd) output size"""
