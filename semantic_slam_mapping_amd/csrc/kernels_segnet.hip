@@ -14,7 +14,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-// ------------------------------------------------------------------ pre-processing: BGR u8 frame -> 480x360 NHWC fp16 (C padded to 16)
+// ------------------------------------------------------------------ pre-processing: BGR u8 frame -> 480x360 [H][W][8] fp16 (B, G, R, zeros)
 // cv::resize INTER_LINEAR 8u per channel (same fixed-point contract as the ORB pyramid), then float (exact in fp16), mean 0
 __global__ void __launch_bounds__(256)
 segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int dh,
@@ -27,9 +27,9 @@ segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int 
     const uint8_t* src = bgr + (size_t)blockIdx.y * sw * sh * 3;
     const int sy0 = yofs[y], sy1 = min(sy0 + 1, sh - 1), b0 = ya[2*y], b1 = ya[2*y+1];
     const int sx0 = xofs[x], sx1 = min(sx0 + 1, sw - 1), a0 = xa[2*x], a1 = xa[2*x+1];
-    half8 lo, z;
+    half8 lo;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { lo[k] = (_Float16)0.f; z[k] = (_Float16)0.f; }
+    for (int k = 0; k < 8; k++) lo[k] = (_Float16)0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const int h0 = src[((size_t)sy0 * sw + sx0) * 3 + c] * a0 + src[((size_t)sy0 * sw + sx1) * 3 + c] * a1;
@@ -37,134 +37,98 @@ segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int 
         const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
         lo[c] = (_Float16)(float)(v & 255);
     }
-    half8* o = reinterpret_cast<half8*>(out + ((size_t)blockIdx.y * dw * dh + p) * 32);     // one 32-channel chunk: B, G, R, 29 zeros
-    o[0] = lo; o[1] = z; o[2] = z; o[3] = z;
+    *reinterpret_cast<half8*>(out + ((size_t)blockIdx.y * dw * dh + p) * 8) = lo;           // [n][H][W][8]: B, G, R, 5 zeros (conv3x3_first_kernel's input)
 }
 
-// ------------------------------------------------------------------ conv3x3 pad 1 (+ scale/shift + ReLU): implicit GEMM on MFMA, LDS-staged operands
+// ------------------------------------------------------------------ conv3x3 pad 1 (+ scale/shift + ReLU): implicit GEMM on MFMA
 // A/B operand maps (cdna guide s.3): lane l holds A[row l&31][k 8(l>>5)..+7] and B[k 8(l>>5)..+7][col l&31];
 // C/D: col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5).
-// block = 256 threads = 4 waves; output tile = 32 px wide x 8 rows (256 pixels) x 64 output channels.  Per stage of
-// KC = 32 input channels the block stages, with 16-byte loads issued together:
-//   * the input halo tile (34 x 10 pixels) as 4 planes of 8 channels: plane[c8][pixel][8 x f16]  (21.8 KB)
-//   * the weights [tap][c8][cout 64][8 x f16]                                                     (36.9 KB)
-// and then runs 9 taps x 2 K-steps x 4 MFMAs per wave with every operand fragment coming from ONE ds_read_b128:
-// a wave owns two output rows (2 M-tiles of 32 contiguous pixels -> conflict-free 512-byte reads) x 2 N-tiles.
-// 58.7 KB LDS per block -> two blocks per CU overlap each other's staging and MFMA phases.
-#define CT_W 32
-#define CT_H 8
+// Per stage of KC = 32 input channels a block stages in LDS
+//   * the input halo tile as 4 planes of 8 channels: plane[c8][pixel][8 x f16]
+//   * the weights [tap][c8][cout 64][8 x f16]
+// and runs 9 taps x 2 K-steps x 4 MFMAs per wave with every operand fragment coming from ONE ds_read_b128: a wave owns two
+// output rows (2 tiles of 32 contiguous pixels -> conflict-free 512-byte reads) x 2 tiles of 32 output channels.
 #define CT_N 64
 #define CT_KC 32
-#define CT_PW (CT_W + 2)
-#define CT_PH (CT_H + 2)
-template <bool RELU>
-__global__ void __launch_bounds__(256, 2)
-conv3x3_lds_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
-                   _Float16* __restrict__ out, int H, int W, int Cin, int Cout, int tiles_x)
+// ------------------------------------------------------------------ conv epilogue shared by the MFMA kernels below
+// The MFMAs run with the weights as the row operand, so lane (r = pixel x, hh) holds acc[tm][tn][4g+q] = channel
+// 32 tn + 8 g + 4 hh + q of rows y0 + tm.  BN scale/shift (s_ss, in LDS, zero for padding channels) and ReLU are applied,
+// the two halves of the wave trade quads (v_permlane32_swap) so that a lane owns 8 consecutive channels, and
+//   EPI 0: the rows are stored (16-byte buffer stores),
+//   EPI 1: the 2x2 max-pool of the tile and its arg-max codes are stored instead.
+// Dead lanes (and a padding 32-channel chunk) get an out-of-range offset, which the buffer store drops, so every wave issues
+// exactly 8 store instructions per tile (the callers' vmcnt(8) relies on it).
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+template <bool RELU, int EPI, typename RS>
+__device__ __forceinline__ void conv_epilogue(const floatx16 (&acc)[2][2], const float (*s_ss)[CT_N], const RS& rsO, const RS& rsC,
+                                              int f, int y0, int gx, bool live0, bool live1, int chunk0, int cout_chunks, int H, int W, int r, int hh)
 {
-    __shared__ __attribute__((aligned(16))) half8 sa[4 * CT_PH * CT_PW];     // [c8][py][px]
-    __shared__ __attribute__((aligned(16))) half8 sb[9 * 4 * CT_N];          // [tap][c8][cout]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int tx0 = (blockIdx.x % tiles_x) * CT_W, ty0 = (blockIdx.x / tiles_x) * CT_H;
-    const int n0 = blockIdx.y * CT_N;
-    const _Float16* inf = in + (size_t)blockIdx.z * H * W * Cin;          // [Cin/32][H][W][32]
-    const int nchunks = Cin / CT_KC;
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
-    half8 zero;
-#pragma unroll
-    for (int k = 0; k < 8; k++) zero[k] = (_Float16)0.f;
-    // software pipeline: the next stage's global data is fetched into registers (15 x 16 B per thread, all loads issued
-    // back to back) while the current stage's MFMAs run; it is written to LDS after the barrier that retires the stage.
-    constexpr int NA = (CT_PH * CT_PW * 4 + 255) / 256;             // 6 input chunks per thread (last one partial)
-    constexpr int NB = 9 * 4 * CT_N / 256;                          // 9 weight chunks per thread
-    half8 ra[NA], rb[NB];
-    int a_dst[NA]; const _Float16* a_src[NA];                       // per-thread staging slots are the same for every stage
-#pragma unroll
-    for (int k = 0; k < NA; k++) {
-        const int i = tid + 256 * k;
-        a_dst[k] = -1; a_src[k] = nullptr;
-        if (i < CT_PH * CT_PW * 4) {
-            const int c8 = i & 3, p = i >> 2;
-            const int py = p / CT_PW, px = p - py * CT_PW;
-            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-            a_dst[k] = c8 * (CT_PH * CT_PW) + p;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_src[k] = inf + ((size_t)gy * W + gx) * CT_KC + 8 * c8;
-        }
-    }
-    const half8* wbase = reinterpret_cast<const half8*>(wt) + (size_t)blockIdx.y * nchunks * (9 * 4 * CT_N) + tid;
-    const size_t chunk_stride = (size_t)H * W * CT_KC;
-#define CT_FETCH(ck)                                                                                   \
-    {   _Pragma("unroll") for (int k = 0; k < NA; k++) ra[k] = a_src[k] ? *reinterpret_cast<const half8*>(a_src[k] + (size_t)(ck) * chunk_stride) : zero; \
-        _Pragma("unroll") for (int k = 0; k < NB; k++) rb[k] = wbase[(size_t)(ck) * (9 * 4 * CT_N) + 256 * k]; }
-    CT_FETCH(0)
-    for (int ck = 0; ck < nchunks; ck++) {
-        __syncthreads();                                             // previous stage fully consumed
-#ifdef CT_ABL_NOLDSW
-        if (ck == 0) {
-#endif
-#pragma unroll
-        for (int k = 0; k < NA; k++) if (a_dst[k] >= 0) sa[a_dst[k]] = ra[k];
-#pragma unroll
-        for (int k = 0; k < NB; k++) sb[tid + 256 * k] = rb[k];
-#ifdef CT_ABL_NOLDSW
-        }
-#endif
-        __syncthreads();
-#ifndef CT_ABL_NOFETCH
-        if (ck + 1 < nchunks) CT_FETCH(ck + 1)
-#endif
-        // 18 steps (tap, K-half) of 4 MFMAs; the 4 operand fragments of step s+1 are read from LDS while step s runs
-        half8 fa[2][2], fb[2][2];
-#define CT_LOADF(buf, st)                                                                               \
-        {   const int tap_ = (st) >> 1, c8_ = ((st) & 1) * 2 + hh, dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;      \
-            const half8* pa_ = sa + c8_ * (CT_PH * CT_PW) + (2 * wv + dy_) * CT_PW + r + dx_;                 \
-            const half8* pb_ = sb + (tap_ * 4 + c8_) * CT_N + r;                                              \
-            fa[buf][0] = pa_[0]; fa[buf][1] = pa_[CT_PW]; fb[buf][0] = pb_[0]; fb[buf][1] = pb_[32]; }
-        CT_LOADF(0, 0)
-#pragma unroll
-        for (int st = 0; st < 18; st++) {
-            const int cur = st & 1;
-            if (st + 1 < 18) CT_LOADF(cur ^ 1, st + 1)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one ds_read of the next step ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // ... then one MFMA of this step
-            }
-        }
-#undef CT_LOADF
-    }
-#undef CT_FETCH
-    // output in the same chunked layout: chunk = channel / 32; a wave-half writes 64 contiguous bytes per pixel
-    const int cout_chunks = (Cout + 31) >> 5;
-    _Float16* of = out + (size_t)blockIdx.z * H * W * cout_chunks * 32;
 #pragma unroll
     for (int tn = 0; tn < 2; tn++) {
-        const int ch = n0 + 32 * tn + r, chunk = (n0 >> 5) + tn;
-        if (chunk >= cout_chunks) continue;
-        const float sc = ch < Cout ? scale[ch] : 0.f, sh = ch < Cout ? shift[ch] : 0.f;      // padded channels store 0
+        const int chunk = chunk0 + tn;
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const int gy = ty0 + 2 * wv + tm;
-            if (gy >= H) continue;
+        for (int gp = 0; gp < 2; gp++) {
+            uint4v vec[2];                                                    // [row] 8 consecutive channels, fp16
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int gx = tx0 + (k & 3) + 8 * (k >> 2) + 4 * hh;
-                if (gx < W) {
-                    float v = acc[tm][tn][k] * sc + sh;
-                    if (RELU) v = fmaxf(v, 0.f);
-                    of[(((size_t)chunk * H + gy) * W + gx) * 32 + r] = (_Float16)v;
+            for (int tm = 0; tm < 2; tm++) {
+                unsigned pk[2][2];                                            // [quad of the pair][half2]
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int g = 2 * gp + e, cl = 32 * tn + 8 * g + 4 * hh;
+                    const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                    _Float16 hv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float val = acc[tm][tn][4 * g + q] * scv[q] + sfv[q];
+                        if (RELU) val = fmaxf(val, 0.f);
+                        hv[q] = (_Float16)val;
+                    }
+                    memcpy(&pk[e][0], &hv[0], 4); memcpy(&pk[e][1], &hv[2], 4);
                 }
+                // lanes 0-31 keep quad 2gp (channels +0..3) and receive the upper half's quad 2gp (+4..7);
+                // lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own (+12..15)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                vec[tm].x = s0[0]; vec[tm].y = s1[0]; vec[tm].z = s0[1]; vec[tm].w = s1[1];
+            }
+            if (EPI == 0) {
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    const bool live = tm ? live1 : live0;
+                    const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y0 + tm) * W + gx) * 64 + 16 * hh + 32 * gp) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(vec[tm], rsO, ob, 0, 0);
+                }
+            } else {
+                // fused 2x2 / stride 2 max-pool with arg-max code (pool2x2_kernel's contract: window scanned row-major,
+                // strict '>' so the first maximum wins; windows are clipped at the right / bottom edge).  The window of an
+                // even lane is its own two rows and those of lane + 1 (quad_perm [1,0,3,2]).
+                uint4v nb[2];
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    nb[tm].x = __builtin_amdgcn_mov_dpp(vec[tm].x, 0xB1, 0xF, 0xF, true); nb[tm].y = __builtin_amdgcn_mov_dpp(vec[tm].y, 0xB1, 0xF, 0xF, true);
+                    nb[tm].z = __builtin_amdgcn_mov_dpp(vec[tm].z, 0xB1, 0xF, 0xF, true); nb[tm].w = __builtin_amdgcn_mov_dpp(vec[tm].w, 0xB1, 0xF, 0xF, true);
+                }
+                const bool right = gx + 1 < W;
+                _Float16 best[8]; unsigned char bc[8];
+                _Float16 c01[8], c10[8], c11[8];
+                memcpy(best, &vec[0], 16); memcpy(c01, &nb[0], 16); memcpy(c10, &vec[1], 16); memcpy(c11, &nb[1], 16);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    bc[k] = 0;
+                    if (right && c01[k] > best[k]) { best[k] = c01[k]; bc[k] = 1; }
+                    if (live1 && c10[k] > best[k]) { best[k] = c10[k]; bc[k] = 2; }
+                    if (live1 && right && c11[k] > best[k]) { best[k] = c11[k]; bc[k] = 3; }
+                }
+                const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+                const bool plive = live0 && !(r & 1) && chunk < cout_chunks;
+                const unsigned pidx = (unsigned)(((f * cout_chunks + chunk) * PH + (y0 >> 1)) * PW + (gx >> 1)) * 32u + 8u * hh + 16u * gp;   // elements
+                uint4v pv; memcpy(&pv, best, 16);
+                typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                uint2v cv; memcpy(&cv, bc, 8);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, plive ? pidx * 2u : 0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(cv, rsC, plive ? pidx : 0x80000000u, 0, 0);
             }
         }
     }
@@ -321,88 +285,118 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
         }
 #undef DT_STAGE_BODY
 #undef DT_LOADF
-        // epilogue: lane = (pixel x = tx0 + r, channel quad): acc[tm][tn][4g+q] is channel n0 + 32 tn + 8 g + 4 hh + q.
-        // The two halves of the wave trade quads (v_permlane32_swap) so that a lane owns 8 consecutive channels: 16-byte stores.
-        // Dead lanes (and a padding 32-channel chunk) get an out-of-range offset: the buffer store drops them, and every wave
-        // issues exactly 8 store instructions per tile (the vmcnt(8) above relies on it).
-        const int cout_chunks = (Cout + 31) >> 5, n0 = ct * CT_N;
+        // epilogue (conv_epilogue): this wave's two rows, 64 channels
+        const int cout_chunks = (Cout + 31) >> 5;
         const int gx = tx0 + r;
         const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
         const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
         const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int tn = 0; tn < 2; tn++) {
-            const int chunk = (n0 >> 5) + tn;
-#pragma unroll
-            for (int gp = 0; gp < 2; gp++) {
-                uint4v vec[2];                                                    // [row] 8 consecutive channels, fp16
-#pragma unroll
-                for (int tm = 0; tm < 2; tm++) {
-                    unsigned pk[2][2];                                            // [quad of the pair][half2]
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int g = 2 * gp + e, cl = 32 * tn + 8 * g + 4 * hh;
-                        const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
-                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
-                        _Float16 hv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            float val = acc[tm][tn][4 * g + q] * scv[q] + sfv[q];
-                            if (RELU) val = fmaxf(val, 0.f);
-                            hv[q] = (_Float16)val;
-                        }
-                        memcpy(&pk[e][0], &hv[0], 4); memcpy(&pk[e][1], &hv[2], 4);
-                    }
-                    // lanes 0-31 keep quad 2gp (channels +0..3) and receive the upper half's quad 2gp (+4..7);
-                    // lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own (+12..15)
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-                    vec[tm].x = s0[0]; vec[tm].y = s1[0]; vec[tm].z = s0[1]; vec[tm].w = s1[1];
-                }
-                if (EPI == 0) {
-#pragma unroll
-                    for (int tm = 0; tm < 2; tm++) {
-                        const bool live = tm ? live1 : live0;
-                        const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y0 + tm) * W + gx) * 64 + 16 * hh + 32 * gp) : 0x80000000u;
-                        __builtin_amdgcn_raw_buffer_store_b128(vec[tm], rsO, ob, 0, 0);
-                    }
-                } else {
-                    // fused 2x2 / stride 2 max-pool with arg-max code (pool2x2_kernel's contract: window scanned row-major,
-                    // strict '>' so the first maximum wins; windows are clipped at the right / bottom edge).  The window of an
-                    // even lane is its own two rows and those of lane + 1 (quad_perm [1,0,3,2]).
-                    uint4v nb[2];
-#pragma unroll
-                    for (int tm = 0; tm < 2; tm++) {
-                        nb[tm].x = __builtin_amdgcn_mov_dpp(vec[tm].x, 0xB1, 0xF, 0xF, true); nb[tm].y = __builtin_amdgcn_mov_dpp(vec[tm].y, 0xB1, 0xF, 0xF, true);
-                        nb[tm].z = __builtin_amdgcn_mov_dpp(vec[tm].z, 0xB1, 0xF, 0xF, true); nb[tm].w = __builtin_amdgcn_mov_dpp(vec[tm].w, 0xB1, 0xF, 0xF, true);
-                    }
-                    const bool right = gx + 1 < W;
-                    _Float16 best[8]; unsigned char bc[8];
-                    _Float16 c01[8], c10[8], c11[8];
-                    memcpy(best, &vec[0], 16); memcpy(c01, &nb[0], 16); memcpy(c10, &vec[1], 16); memcpy(c11, &nb[1], 16);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        bc[k] = 0;
-                        if (right && c01[k] > best[k]) { best[k] = c01[k]; bc[k] = 1; }
-                        if (live1 && c10[k] > best[k]) { best[k] = c10[k]; bc[k] = 2; }
-                        if (live1 && right && c11[k] > best[k]) { best[k] = c11[k]; bc[k] = 3; }
-                    }
-                    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
-                    const bool plive = live0 && !(r & 1) && chunk < cout_chunks;
-                    const unsigned pidx = (unsigned)(((f * cout_chunks + chunk) * PH + (y0 >> 1)) * PW + (gx >> 1)) * 32u + 8u * hh + 16u * gp;   // elements
-                    uint4v pv; memcpy(&pv, best, 16);
-                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-                    uint2v cv; memcpy(&cv, bc, 8);
-                    __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, plive ? pidx * 2u : 0x80000000u, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(cv, rsC, plive ? pidx : 0x80000000u, 0, 0);
-                }
-            }
-        }
+        conv_epilogue<RELU, EPI>(acc, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
     }
 #undef DT_DMA_A
 #undef DT_DMA_B
 #undef DT_TILE_OFFSETS
+}
+
+// ------------------------------------------------------------------ conv3x3 of an input with <= 8 channels (the network's first layer)
+// The input is one 8-channel (16-byte) vector per pixel, [n][H][W][8].  A 16-deep MFMA K step then covers TWO taps: the
+// lower half-wave (k 0..7) reads tap 2s and the upper (k 8..15) tap 2s+1 of the same LDS plane, i.e. the two halves just use
+// different pixel offsets for their fragment read.  9 taps = 5 steps (the 10th half has zero weights) instead of the 18 the
+// 32-channel chunk kernel would spend on a chunk that is 29/32 padding.  Weights: [cout tile][step 5][half 2][cout 64][8],
+// staged once per block; the input tile (18 x 34 pixels, 9.6 KB) is double-buffered by LDS-DMA across the block's tiles as
+// in conv3x3_dma_kernel, and the epilogue is shared.  The layer is bound by its 64-channel output write.
+#define FT_ACH (DT_PH * DT_PW)                // 612 chunks = one plane
+#define FT_ASLOTS 640                         // 10 wave-instructions
+#define FT_BCH (5 * 2 * CT_N)                 // 640 chunks of weights
+template <bool RELU>
+__global__ void __launch_bounds__(512, 1)
+conv3x3_first_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
+                     _Float16* __restrict__ out, int n, int H, int W, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                     unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
+{
+    __shared__ __attribute__((aligned(16))) half8 lda0[FT_ASLOTS];
+    __shared__ __attribute__((aligned(16))) half8 lda1[FT_ASLOTS];
+    __shared__ __attribute__((aligned(16))) half8 ldb[FT_BCH];
+    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int VH = (H + 2) & ~1, VR = n * VH;
+    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    const int ct = blockIdx.x % ncout_tiles;                                       // constant for the block (grid is a multiple of ncout_tiles)
+    if (tid < 2 * CT_N) {
+        const int ch = ct * CT_N + (tid & (CT_N - 1));
+        s_ss[tid >> 6][tid & (CT_N - 1)] = ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+    }
+    // the block's weights, once: 10 wave-instructions, waves 0 and 1 take two
+    for (int j = wv; j < FT_BCH / 64; j += 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&ldb[j * 64], 16, (unsigned)(ct * FT_BCH + j * 64 + lane) * 16u, 0, 0, 0);
+    // input DMA slots of this thread: chunk i = (wv + 8k) * 64 + lane of the 18 x 34 halo tile, k = 0, 1 (k = 1: waves 0, 1 only)
+    int a_py[2], a_px[2]; unsigned a_off[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = (wv + 8 * k) * 64 + lane;
+        a_py[k] = i < FT_ACH ? i / DT_PW : -0x10000;
+        a_px[k] = i - (i / DT_PW) * DT_PW;
+    }
+#define FT_TILE_OFFSETS(tile)                                                                           \
+    {   const int pt_ = (tile) / ncout_tiles;                                                           \
+        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
+        _Pragma("unroll") for (int k = 0; k < 2; k++) {                                                 \
+            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
+            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
+            a_off[k] = ok ? (((unsigned)f * H + y) * W + gx) * 16u : 0x80000000u;                       \
+        } }
+#define FT_DMA_A(dst)                                                                                   \
+    {   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[wv * 64], 16, a_off[0], 0, 0, 0); \
+        if (wv < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 8) * 64], 16, a_off[1], 0, 0, 0); }
+    int tile = blockIdx.x;
+    FT_TILE_OFFSETS(tile)
+    FT_DMA_A(lda0)
+    {
+        const uint4v z4 = {0u, 0u, 0u, 0u};                                       // see conv3x3_dma_kernel: 8 dropped stores make vmcnt(8) path-invariant
+#pragma unroll
+        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);
+    }
+    // per-lane fragment offsets of the 5 steps: tap = min(2 s + hh, 8) (the 10th half multiplies zero weights)
+    int fo[5];
+#pragma unroll
+    for (int st = 0; st < 5; st++) { const int tap = min(2 * st + hh, 8), dy = tap / 3, dx = tap - dy * 3; fo[st] = (2 * wv + dy) * DT_PW + r + dx; }
+    const int cout_chunks = (Cout + 31) >> 5;
+#define FT_TILE_BODY(rd, wr)                                                                            \
+    {   const int pt = tile / ncout_tiles;                                                              \
+        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;                             \
+        __builtin_amdgcn_s_waitcnt(0x0F78);      /* vmcnt(8): this tile's input has landed; the last epilogue's stores may fly on */ \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        { const int nt = tile + gridDim.x; FT_TILE_OFFSETS(nt) }                                        \
+        FT_DMA_A(wr)                                                                                    \
+        floatx16 acc[2][2];                                                                             \
+        _Pragma("unroll") for (int a = 0; a < 2; a++) _Pragma("unroll") for (int b = 0; b < 2; b++) _Pragma("unroll") for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f; \
+        _Pragma("unroll") for (int st = 0; st < 5; st++) {                                              \
+            const half8 fa0 = rd[fo[st]], fa1 = rd[fo[st] + DT_PW];                                     \
+            const half8 fb0 = ldb[(st * 2 + hh) * CT_N + r], fb1 = ldb[(st * 2 + hh) * CT_N + r + 32];  \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb0, fa0, acc[0][0], 0, 0, 0);           \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb1, fa0, acc[0][1], 0, 0, 0);           \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb0, fa1, acc[1][0], 0, 0, 0);           \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb1, fa1, acc[1][1], 0, 0, 0);           \
+        }                                                                                               \
+        const int gx = tx0 + r, v0 = ty0 + 2 * wv;                                                      \
+        const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;                          \
+        const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;                    \
+        conv_epilogue<RELU, 0>(acc, s_ss, rsO, rsO, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh); \
+    }
+    for (; tile < total_tiles; tile += gridDim.x) {
+        FT_TILE_BODY(lda0, lda1)
+        tile += gridDim.x;
+        if (tile >= total_tiles) break;
+        FT_TILE_BODY(lda1, lda0)
+    }
+#undef FT_TILE_BODY
+#undef FT_DMA_A
+#undef FT_TILE_OFFSETS
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 stride 2, CEIL mode, with arg-max code
@@ -509,8 +503,6 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
     segnet_prep_kernel<<<dim3((dw * dh + 255) / 256, n), 256, 0, s>>>(bgr, sw, sh, dw, dh, xofs, xa, yofs, ya, (_Float16*)out_f16);
     return hipGetLastError();
 }
-hipError_t k_segnet_conv_regstage(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
-                                  int CinPad, int Cout, int relu, hipStream_t s);
 static int conv_grid_limit()
 {
     static int cus = 0;
@@ -534,10 +526,23 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
 #undef DT_LAUNCH
     return hipGetLastError();
 }
+static hipError_t conv_first_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W, int Cout, int relu, hipStream_t s)
+{
+    const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1, cs = (Cout + 31) & ~31;
+    const unsigned long long in_bytes = (unsigned long long)n * H * W * 16, wt_bytes = (unsigned long long)nct * FT_BCH * 16, out_bytes = (unsigned long long)n * H * W * cs * 2;
+    if (in_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
+    const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
+    int grid = 2 * conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;        // 31 KB of LDS: two blocks per CU
+    if (relu) conv3x3_first_kernel<true><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
+    else      conv3x3_first_kernel<false><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes);
+    return hipGetLastError();
+}
+// CinPad == 8: the <= 8-channel first layer ([n][H][W][8] input, its own weight packing); otherwise CinPad is a multiple of 64
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s)
 {
-    if ((CinPad / CT_KC) & 1) return k_segnet_conv_regstage(in, wt, scale, shift, out, n, H, W, CinPad, Cout, relu, s);
+    if (CinPad == 8) return conv_first_launch(in, wt, scale, shift, out, n, H, W, Cout, relu, s);
+    if (CinPad % (2 * CT_KC)) return hipErrorInvalidValue;
     return conv_dma_launch(in, wt, scale, shift, out, nullptr, n, H, W, CinPad, Cout, relu, 0, s);
 }
 // conv + BN + ReLU + max-pool 2x2 (CEIL) in one pass: out is [n][Cout/32][PH][PW][32], code the arg-max codes in the same index space
@@ -546,16 +551,6 @@ hipError_t k_segnet_conv_pool(const void* in, const void* wt, const float* scale
 {
     if ((CinPad / CT_KC) & 1) return hipErrorInvalidValue;
     return conv_dma_launch(in, wt, scale, shift, out, code, n, H, W, CinPad, Cout, 1, 1, s);
-}
-// the register-staged kernel (two 256-thread blocks per CU); kept for scripts/ubench/conv_bench.hip comparisons
-hipError_t k_segnet_conv_regstage(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
-                                  int CinPad, int Cout, int relu, hipStream_t s)
-{
-    const int tx = (W + CT_W - 1) / CT_W, ty = (H + CT_H - 1) / CT_H;
-    dim3 grid(tx * ty, (Cout + CT_N - 1) / CT_N, n);
-    if (relu) conv3x3_lds_kernel<true><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, H, W, CinPad, Cout, tx);
-    else      conv3x3_lds_kernel<false><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, H, W, CinPad, Cout, tx);
-    return hipGetLastError();
 }
 hipError_t k_segnet_pool(const void* in, int n, int H, int W, int C, void* out, uint8_t* code, hipStream_t s)
 {

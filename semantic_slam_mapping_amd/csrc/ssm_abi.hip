@@ -750,7 +750,8 @@ static int seg_init(ssm_ctx* c)
     SegNetState* g = new SegNetState();
     c->seg = g;
     for (int l = 0; l < SEG_LAYERS; l++) {
-        g->cinp[l] = (k_seg_layers[l].cin + 31) & ~31; g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
+        g->cinp[l] = k_seg_layers[l].cin <= 8 ? 8 : (k_seg_layers[l].cin + 63) & ~63;   // <= 8 channels: the first-layer kernel ([H][W][8] input)
+        g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
         g->coutstore[l] = (k_seg_layers[l].cout + 31) & ~31;            // activations live in 32-channel chunks: [C/32][H][W][32]
     }
     g->batch = c->B < 32 ? c->B : 32;          // 32 frames per launch: the 23x30 layers then have 768 workgroups (3 at one frame)
@@ -780,12 +781,20 @@ extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, cons
     int r = seg_init(c); if (r) return r;
     SegNetState* g = c->seg;
     const int cin = k_seg_layers[l].cin, cout = k_seg_layers[l].cout, cinp = g->cinp[l], coutp = g->coutp[l];
-    // packed for the LDS-tiled kernel: [Cout tile of 64][Cin chunk of 32][tap][c8 (4)][cout in tile (64)][8 channels]
-    std::vector<uint16_t> w((size_t)coutp * 9 * cinp, 0);
-    const int nck = cinp / 32;
-    for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++) {
-        const size_t idx = ((((((size_t)(o / 64) * nck + i / 32) * 9 + t) * 4 + (i % 32) / 8) * 64 + o % 64) * 8) + i % 8;
-        w[idx] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+    std::vector<uint16_t> w;
+    if (cinp == 8) {
+        // first-layer kernel: [Cout tile of 64][K step 5][half 2][cout in tile 64][8 channels], tap = 2 step + half (tap 9: zeros)
+        w.assign((size_t)coutp * 10 * 8, 0);
+        for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++)
+            w[((((size_t)(o / 64) * 5 + t / 2) * 2 + t % 2) * 64 + o % 64) * 8 + i] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+    } else {
+        // LDS-DMA kernel: [Cout tile of 64][Cin chunk of 32][tap][c8 (4)][cout in tile (64)][8 channels]
+        w.assign((size_t)coutp * 9 * cinp, 0);
+        const int nck = cinp / 32;
+        for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++) {
+            const size_t idx = ((((((size_t)(o / 64) * nck + i / 32) * 9 + t) * 4 + (i % 32) / 8) * 64 + o % 64) * 8) + i % 8;
+            w[idx] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
+        }
     }
     if (!g->w[l]) { uint16_t* p; r = dalloc(c, &p, w.size()); if (r) return r; g->w[l] = p; DALLOC(c, g->scale[l], coutp); DALLOC(c, g->shift[l], coutp); }
     std::vector<float> sc(coutp, 0.f), sh(coutp, 0.f);
@@ -881,7 +890,8 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
         // host tensors are NHWC with channels padded to 16; the device layout is [C/32][H][W][32]
         const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15;
         std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)H * W * g->coutstore[arg]);
-        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
+        if (g->cinp[arg] == 8) { for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < k_seg_layers[arg].cin; ch++) hin[p * 8 + ch] = in[p * ci16 + ch]; }
+        else for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
         HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
         HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, arg != SEG_LAYERS - 1, s));
         HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
@@ -916,7 +926,7 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
             to_host(hout, H, W, out);
         }
     } else if (op == 3) {                 // conv + BN + ReLU + max-pool of layer `arg` as the network runs it (one kernel)
-        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || (g->cinp[arg] / 32) % 2) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused conv+pool kernel takes");
+        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || g->cinp[arg] == 8) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused conv+pool kernel takes");
         const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15, cs = g->coutstore[arg];
         std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)PH * PW * cs);
         std::vector<uint8_t> hcode((size_t)PH * PW * cs);
