@@ -174,11 +174,14 @@ int ssm_segnet_set_layer(ssm_ctx* ctx, int layer, const float* weight, const flo
  * (Pavement->Road remap, resize of the ids, LUT through the 12-colour palette). */
 int ssm_segnet_forward(ssm_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* labels_net, uint8_t* sem_bgr);
 /* n device frames (packed BGR); outputs are device buffers or NULL.  flags: bit0 = nearest-neighbour resize of the ids
- * instead of the reference's bilinear-on-ids, bit1 = skip the Pavement->Road remap */
+ * instead of the reference's bilinear-on-ids, bit1 = skip the Pavement->Road remap, bit2 = materialise the class logits
+ * (ssm_segnet_logits can then read frame 0 of the last sub-batch; without it the ArgMax runs in the last layer's epilogue
+ * and the logits never reach memory -- the labels are identical either way) */
 int ssm_segnet_forward_dev(ssm_ctx* ctx, const uint8_t* bgr_dev, int n, uint8_t* labels_net_dev, uint8_t* sem_bgr_dev, int flags);
 /* single layer ops on host NHWC fp16 tensors, for exact per-op tests (integer-valued data makes fp16/fp32 exact):
  * op 0 = conv layer `arg` on in[H][W][CinPad16] -> out[H][W][CoutPad16]; op 1 = max-pool 2x2 s2 ceil with C = arg:
- * in[H][W][C] -> out[PH][PW][C] + code[PH][PW][C]; op 2 = unpool: in[PH][PW][C] + code -> out[H][W][C] */
+ * in[H][W][C] -> out[PH][PW][C] + code[PH][PW][C]; op 2 = unpool: in[PH][PW][C] + code -> out[H][W][C];
+ * op 3 = conv layer `arg` + max-pool through the fused kernel: out[PH][PW][CoutPad16] + code (same shape) */
 int ssm_segnet_debug_op(ssm_ctx* ctx, int op, int arg, const uint16_t* in, int H, int W, uint16_t* out, uint8_t* code);
 /* class logits (12 floats per net pixel, 360*480 pixels) of frame 0 of the most recent forward: for tolerance tests */
 int ssm_segnet_logits(ssm_ctx* ctx, float* out);

@@ -161,7 +161,9 @@ __device__ __forceinline__ void conv_epilogue(const floatx16 (&acc)[2][2], const
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // EPI 0: out = conv (+BN, ReLU).  EPI 1: out = the 2x2 max-pooled conv, code = the arg-max codes; the full-resolution
 // activation is never written.
-template <bool RELU, int EPI>
+// EPI 2 (with NT = 1: one 32-channel output tile, half the weight staging and MFMAs): the class ArgMax of the last layer --
+// out is the uint8 label image [n][H][W]; the logits are never written.
+template <bool RELU, int EPI, int NT>
 __global__ void __launch_bounds__(512, 1)
 conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
                    _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
@@ -181,6 +183,10 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
     const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
+    constexpr int BROW = 32 * NT;                                                  // output channels per staged weight row
+    constexpr int BINS = 9 * 4 * BROW / 64;                                        // weight wave-instructions per stage: 36 or 18
+    constexpr int BK = (BINS + 7) / 8;                                             // per wave: 5 or 3
+    constexpr int NSTORE = EPI == 2 ? 2 : 8;                                       // store instructions per tile epilogue
     // folded BN scale / shift of the block's 64 output channels (a persistent block keeps its cout tile), zero for padding
     __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
     if (tid < 2 * CT_N) {
@@ -198,8 +204,9 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
         const int c8 = i / DT_PLANE, p = i - c8 * DT_PLANE;
         a_py[k] = i < DT_ACH ? p / DT_PW : -0x10000;                                // padding slots never become valid
         a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
-        b_j[k] = min(wv + 8 * k, DT_BCH / 64 - 1);                                 // waves 4..7 repeat instruction 35 (same bytes, same place)
-        b_off[k] = (unsigned)(b_j[k] * 64 + lane) * 16u;
+        b_j[k] = min(wv + 8 * k, BINS - 1);                                        // surplus slots repeat the last instruction (same bytes, same place)
+        // the packed weights have 64-channel rows; with NT = 1 a wave-instruction takes the first 32 channels of two rows
+        b_off[k] = NT == 2 ? (unsigned)(b_j[k] * 64 + lane) * 16u : (unsigned)((2 * b_j[k] + (lane >> 5)) * 64 + (lane & 31)) * 16u;
     }
 #define DT_TILE_OFFSETS(tile)                                                                           \
     {   const int pt_ = (tile) / ncout_tiles;                                                           \
@@ -217,24 +224,24 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
     {
         const unsigned bso = (unsigned)(tile % ncout_tiles) * nchunks * (DT_BCH * 16u);
 #pragma unroll
-        for (int k = 0; k < 5; k++) { DT_DMA_A(k, lds0, 0u) DT_DMA_B(k, lds0, bso) }
-        // eight out-of-range (dropped) stores, so that "a tile's first DMA batch is followed by exactly 8 stores" also holds for
-        // the first tile: the wait at the top of every tile is then the same vmcnt(8) on every path
+        for (int k = 0; k < 5; k++) { DT_DMA_A(k, lds0, 0u) if (k < BK) DT_DMA_B(k, lds0, bso) }
+        // NSTORE out-of-range (dropped) stores, so that "a tile's first DMA batch is followed by exactly NSTORE stores" also holds
+        // for the first tile: the wait at the top of every tile is then the same vmcnt(NSTORE) on every path
         typedef unsigned uint4v __attribute__((ext_vector_type(4)));
         const uint4v z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 8; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);
+        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);
     }
     // nchunks is even (the launcher sends the 32-channel first layer elsewhere), so every tile starts in lds0 and the two
     // stage bodies below use compile-time buffers
     for (; tile < total_tiles; tile += gridDim.x) {
         const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
         const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;      // ty0 is a row of the stacked virtual image
-        floatx16 acc[2][2];
+        floatx16 acc[2][NT];
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
+            for (int b = 0; b < NT; b++)
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
         // one stage: 18 steps of 4 MFMAs on buffer `rd`, with the next stage's 10 DMA instructions (into `wr`) and the next
@@ -243,28 +250,26 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
 #define DT_LOADF(rd, fbuf, st)                                                                          \
         {   const int tap_ = (st) >> 1, c8_ = ((st) & 1) * 2 + hh, dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;      \
             const half8* pa_ = rd + c8_ * DT_PLANE + (2 * wv + dy_) * DT_PW + r + dx_;                        \
-            const half8* pb_ = rd + DT_AINS * 64 + (tap_ * 4 + c8_) * CT_N + r;                               \
-            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fb[fbuf][0] = pb_[0]; fb[fbuf][1] = pb_[32]; }
+            const half8* pb_ = rd + DT_AINS * 64 + (tap_ * 4 + c8_) * BROW + r;                               \
+            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; }
 #define DT_STAGE_BODY(rd, wr)                                                                           \
-        {   half8 fa[2][2], fb[2][2];                                                                   \
+        {   half8 fa[2][2], fb[2][NT];                                                                  \
             DT_LOADF(rd, 0, 0)                                                                          \
             _Pragma("unroll") for (int st = 0; st < 18; st++) {                                         \
                 const int cur = st & 1;                                                                 \
                 if (st < 5) DT_DMA_A(st, wr, a_so)                                                      \
-                else if (st < 10) DT_DMA_B(st - 5, wr, b_so)                                            \
+                else if (st < 5 + BK) DT_DMA_B(st - 5, wr, b_so)                                        \
                 if (st + 1 < 18) DT_LOADF(rd, cur ^ 1, st + 1)                                          \
                 __builtin_amdgcn_sched_barrier(0);   /* reads of step st+1 stay ahead of the MFMAs of step st */ \
                 /* D[cout][pixel] += W[cout][k] X[k][pixel]: weights are the row operand */             \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][0], fa[cur][0], acc[0][0], 0, 0, 0); \
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][1], fa[cur][0], acc[0][1], 0, 0, 0); \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][0], fa[cur][1], acc[1][0], 0, 0, 0); \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][1], fa[cur][1], acc[1][1], 0, 0, 0); \
+                _Pragma("unroll") for (int tm_ = 0; tm_ < 2; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
+                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
             } }
         for (int ck = 0; ck < nchunks; ck += 2) {
             // this wave's share of the stage has landed (the DMA is older than the previous tile's epilogue stores, which may
             // stay in flight: vmcnt retires in order); after the barrier everybody's has, and the previous stage is consumed
-            if (ck == 0) __builtin_amdgcn_s_waitcnt(0x0F78);                     // vmcnt(8): exactly 8 stores per epilogue, all younger than the DMA
+            if (ck == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NSTORE);            // vmcnt(NSTORE): exactly that many stores per epilogue, all younger than the DMA
             else __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
             __builtin_amdgcn_s_barrier();
             unsigned a_so = (unsigned)(ck + 1) * plane_bytes, b_so = ((unsigned)ct * nchunks + ck + 1) * (DT_BCH * 16u);
@@ -291,7 +296,40 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
         const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
         const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
         const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
-        conv_epilogue<RELU, EPI>(acc, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
+        if constexpr (EPI == 2) {
+            // ArgMax over the classes (channels < Cout <= 12) of the fp16-rounded logits, first maximum wins (argmax_kernel's
+            // contract).  acc[tm][0][4g+q] is class 8g + 4hh + q: the lower half-wave owns classes 0-3 and 8-11, the upper 4-7.
+#pragma unroll
+            for (int tm = 0; tm < 2; tm++) {
+                _Float16 bv[2]; int bi[2];                                        // [g]: best of the lane's quad g
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const int c0 = 8 * g + 4 * hh;
+                    const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][c0]), sf = *reinterpret_cast<const float4*>(&s_ss[1][c0]);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                    bv[g] = (_Float16)-65504.f; bi[g] = 255;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float val = acc[tm][0][4 * g + q] * scv[q] + sfv[q];
+                        if (RELU) val = fmaxf(val, 0.f);
+                        const _Float16 hvq = (_Float16)val;
+                        if (c0 + q < Cout && (bi[g] == 255 || hvq > bv[g])) { bv[g] = hvq; bi[g] = c0 + q; }
+                    }
+                }
+                // the upper half's classes 4-7 travel to the lower half as (value bits << 8 | index)
+                unsigned short vb; memcpy(&vb, &bv[0], 2);
+                const unsigned mine = ((unsigned)vb << 8) | (unsigned)bi[0];
+                const unsigned theirs = __builtin_amdgcn_permlane32_swap(mine, mine, false, false)[1];     // lower lanes: the upper half's word
+                unsigned short tb = (unsigned short)(theirs >> 8); _Float16 tv; memcpy(&tv, &tb, 2);
+                const int ti = (int)(theirs & 255u);
+                _Float16 best = bv[0]; int lab = bi[0];                           // classes 0-3
+                if (ti != 255 && tv > best) { best = tv; lab = ti; }              // then 4-7
+                if (bi[1] != 255 && bv[1] > best) { best = bv[1]; lab = bi[1]; }  // then 8-11
+                const bool live = (tm ? live1 : live0) && hh == 0;
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lab, rsO, live ? (unsigned)((f * H + y0 + tm) * W + gx) : 0x80000000u, 0, 0);
+            }
+        } else
+            conv_epilogue<RELU, EPI>(acc, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
     }
 #undef DT_DMA_A
 #undef DT_DMA_B
@@ -509,20 +547,23 @@ static int conv_grid_limit()
     if (!cus) { int dev = 0; hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
     return cus;
 }
+// epi 0: conv; 1: conv + max-pool (out pooled, code); 2: conv + class ArgMax (out = uint8 labels [n][H][W]; Cout <= 12)
 static hipError_t conv_dma_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
-                                  int CinPad, int Cout, int relu, int pool, hipStream_t s)
+                                  int CinPad, int Cout, int relu, int epi, hipStream_t s)
 {
     const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1, cs = (Cout + 31) & ~31;
     const unsigned long long in_bytes = (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct * CT_N * CinPad * 9 * 2;
-    const unsigned long long out_bytes = pool ? (unsigned long long)n * ((H + 1) / 2) * ((W + 1) / 2) * cs * 2 : (unsigned long long)n * H * W * cs * 2;
+    const unsigned long long out_bytes = epi == 1 ? (unsigned long long)n * ((H + 1) / 2) * ((W + 1) / 2) * cs * 2 : epi == 2 ? (unsigned long long)n * H * W : (unsigned long long)n * H * W * cs * 2;
+    if (epi == 2 && Cout > 12) return hipErrorInvalidValue;
     // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
     if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
     // persistent blocks, one per CU (the LDS holds one); a multiple of the cout-tile count so a block keeps its weight slab
     int grid = conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
-#define DT_LAUNCH(R, E) conv3x3_dma_kernel<R, E><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
-    if (pool) { if (relu) DT_LAUNCH(true, 1); else DT_LAUNCH(false, 1); }
-    else      { if (relu) DT_LAUNCH(true, 0); else DT_LAUNCH(false, 0); }
+#define DT_LAUNCH(R, E, N) conv3x3_dma_kernel<R, E, N><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+    if (epi == 2) { if (relu) DT_LAUNCH(true, 2, 1); else DT_LAUNCH(false, 2, 1); }
+    else if (epi == 1) { if (relu) DT_LAUNCH(true, 1, 2); else DT_LAUNCH(false, 1, 2); }
+    else { if (relu) DT_LAUNCH(true, 0, 2); else DT_LAUNCH(false, 0, 2); }
 #undef DT_LAUNCH
     return hipGetLastError();
 }
@@ -551,6 +592,13 @@ hipError_t k_segnet_conv_pool(const void* in, const void* wt, const float* scale
 {
     if ((CinPad / CT_KC) & 1) return hipErrorInvalidValue;
     return conv_dma_launch(in, wt, scale, shift, out, code, n, H, W, CinPad, Cout, 1, 1, s);
+}
+// last layer + ArgMax in one pass: labels [n][H][W] uint8 (the class logits are not materialised)
+hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* scale, const float* shift, uint8_t* labels, int n, int H, int W,
+                                int CinPad, int Cout, hipStream_t s)
+{
+    if (CinPad % (2 * CT_KC)) return hipErrorInvalidValue;
+    return conv_dma_launch(in, wt, scale, shift, labels, nullptr, n, H, W, CinPad, Cout, 0, 2, s);
 }
 hipError_t k_segnet_pool(const void* in, int n, int H, int W, int C, void* out, uint8_t* code, hipStream_t s)
 {

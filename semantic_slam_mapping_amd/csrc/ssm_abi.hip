@@ -806,6 +806,8 @@ extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, cons
     return SSM_OK;
 }
 // forward for nb <= seg->batch device frames already pre-processed into actA; leaves logits in the returned buffer
+// logits_out != nullptr: the class logits are materialised (returned buffer) and the caller runs the ArgMax kernel;
+// logits_out == nullptr: the last layer writes the labels (g->labels) straight from its epilogue.
 static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
 {
     SegNetState* g = c->seg; hipStream_t s = c->stream;
@@ -832,8 +834,12 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
     if ((r = unpool(3, 23, 30, 512, 45, 60)) || (r = conv(16)) || (r = conv(17)) || (r = conv(18))) return r;
     if ((r = unpool(2, 45, 60, 256, 90, 120)) || (r = conv(19)) || (r = conv(20)) || (r = conv(21))) return r;
     if ((r = unpool(1, 90, 120, 128, 180, 240)) || (r = conv(22)) || (r = conv(23))) return r;
-    if ((r = unpool(0, 180, 240, 64, 360, 480)) || (r = conv(24)) || (r = conv(25))) return r;
-    *logits_out = cur;
+    if ((r = unpool(0, 180, 240, 64, 360, 480)) || (r = conv(24))) return r;
+    if (logits_out) { if ((r = conv(25))) return r; *logits_out = cur; }
+    else {
+        const SegLayerDef& d = k_seg_layers[25];
+        HIPCHK(c, k_segnet_conv_argmax(cur, g->w[25], g->scale[25], g->shift[25], g->labels, nb, d.h, d.w, g->cinp[25], d.cout, s));
+    }
     return SSM_OK;
 }
 static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags)
@@ -845,10 +851,15 @@ static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* label
     for (int f0 = 0; f0 < n; f0 += g->batch) {
         const int nb = n - f0 < g->batch ? n - f0 : g->batch;
         HIPCHK(c, k_segnet_prep(bgr + (size_t)f0 * W * H * 3, nb, W, H, SEG_NW, SEG_NH, g->pre_xofs, g->pre_xa, g->pre_yofs, g->pre_ya, g->actA, s));
-        void* logits = nullptr;
-        r = seg_forward_core(c, nb, &logits); if (r) return r;
-        g->last_logits = logits;                   // frame f0 of the last sub-batch starts the buffer (ssm_segnet_logits reads it)
-        HIPCHK(c, k_segnet_argmax(logits, nb, SEG_NW * SEG_NH, g->coutstore[SEG_LAYERS - 1], SEG_NCLS, g->labels, s));
+        if (flags & 4) {                           // keep the class logits (ssm_segnet_forward / ssm_segnet_logits): separate ArgMax kernel
+            void* logits = nullptr;
+            r = seg_forward_core(c, nb, &logits); if (r) return r;
+            g->last_logits = logits;               // frame f0 of the last sub-batch starts the buffer
+            HIPCHK(c, k_segnet_argmax(logits, nb, SEG_NW * SEG_NH, g->coutstore[SEG_LAYERS - 1], SEG_NCLS, g->labels, s));
+        } else {
+            r = seg_forward_core(c, nb, nullptr); if (r) return r;
+            g->last_logits = nullptr;
+        }
         if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net + (size_t)f0 * SEG_NW * SEG_NH, g->labels, (size_t)nb * SEG_NW * SEG_NH, hipMemcpyDeviceToDevice, s));
         if (sem_bgr) HIPCHK(c, k_segnet_color(g->labels, nb, SEG_NW, SEG_NH, W, H, g->post_xofs, g->post_xa, g->post_yofs, g->post_ya,
                                               !(flags & 2), flags & 1, sem_bgr + (size_t)f0 * W * H * 3, nullptr, s));
@@ -871,7 +882,7 @@ extern "C" int ssm_segnet_forward(ssm_ctx* c, const uint8_t* bgr, int w, int h, 
     if (stride < w * 3) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
     HIPCHK(c, hipMemcpy2DAsync(c->d_in_img, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
     int r = ensure_scratch(c, (size_t)SEG_NW * SEG_NH); if (r) return r;
-    r = seg_forward_dev(c, c->d_in_img, 1, labels_net ? (uint8_t*)c->d_scratch : nullptr, sem_bgr ? c->d_in_sem : nullptr, 0); if (r) return r;
+    r = seg_forward_dev(c, c->d_in_img, 1, labels_net ? (uint8_t*)c->d_scratch : nullptr, sem_bgr ? c->d_in_sem : nullptr, 4); if (r) return r;
     if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net, c->d_scratch, (size_t)SEG_NW * SEG_NH, hipMemcpyDeviceToHost, c->stream));
     if (sem_bgr) HIPCHK(c, hipMemcpyAsync(sem_bgr, c->d_in_sem, (size_t)w * h * 3, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

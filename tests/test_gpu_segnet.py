@@ -121,6 +121,28 @@ def test_pool_unpool_exact(ctx, seg, h, w, c):
         pass
 
 
+def test_forward_dev_fused_argmax_equals_logits_path(ctx, oracle, seg):
+    """ssm_segnet_forward_dev runs the ArgMax inside the last layer's epilogue (no logits in memory); the labels must equal
+    those of the logits + ArgMax-kernel path (flag bit 2, which ssm_segnet_forward uses) bit for bit"""
+    for l, (wt, sc, sh) in enumerate(seg):
+        ctx.segnet_set_layer(l, wt, sc, sh)
+    n, W, H = 3, 640, 480
+    frames = np.stack([oracle.synth_frame(SEED, 7 + 11 * i)[0] for i in range(n)])
+    d_bgr = ctx.dev_alloc(frames.nbytes); d_a = ctx.dev_alloc(n * 360 * 480); d_b = ctx.dev_alloc(n * 360 * 480)
+    try:
+        ctx.h2d(d_bgr, frames)
+        ctx.segnet_forward_dev(d_bgr, n, d_a, None, 0)
+        ctx.segnet_forward_dev(d_bgr, n, d_b, None, 4)
+        ctx.sync()
+        a = ctx.d2h(d_a, (n, 360, 480), np.uint8); b = ctx.d2h(d_b, (n, 360, 480), np.uint8)
+        assert np.array_equal(a, b)
+        assert len(np.unique(a)) > 3
+        assert np.array_equal(a[0], ctx.classify(frames[0], want_sem=False)[0])
+    finally:
+        for p in (d_bgr, d_a, d_b):
+            ctx.dev_free(p)
+
+
 def test_seq_process_with_segnet_stage(ctx, oracle, seg):
     """BASELINE configs[2]: labels from the on-GPU SegNet drive the mapper (sem_bgr not supplied)"""
     for l, (wt, sc, sh) in enumerate(seg):
