@@ -165,7 +165,7 @@ def main():
         if dom == "segnet":
             from semantic_slam_mapping_amd import segnet_model
             tf = segnet_model.flops() * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (26 layers + pool/unpool, whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
+            roof = {"bound": "mfma", "kernel": "conv3x3_dma_kernel + conv3x3_first_kernel (26 conv layers with fused pool / ArgMax epilogues, unpool, prep, colouring: whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
         elif dom == "match":
             pairs = sum(max(int(res["nkp"][f - 5 + r]), 0) * int(res["nkp"][f]) for f in range(F) for r in range(5) if f - 5 + r >= 0) / F
