@@ -379,6 +379,30 @@ struct QNode { short x0, y0, x1, y1; };
 // NODES = LDS node capacity (512 covers 2000 features / 8 levels); keys (8 B) and their node ids (2 B) are copied into LDS
 // when the level has <= OT_KCAP candidates (always, in practice): the split passes then never touch global memory.
 #define OT_KCAP 4096
+// inclusive scan of a u32 across a wave64 (DPP Hillis-Steele inside the 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// exclusive scan over the 256 threads of a block (thread order), `total` = the block sum; sw = 4 words of LDS.
+// Contains two barriers; every thread of the block must call it.
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sw, uint32_t& total)
+{
+    const uint32_t inc = wave_incl_scan_u32(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) sw[w] = inc;
+    __syncthreads();
+    const uint32_t s0 = sw[0], s1 = sw[1], s2 = sw[2], s3 = sw[3];
+    __syncthreads();
+    total = s0 + s1 + s2 + s3;
+    return inc - v + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+}
 template <int NODES>
 __global__ void __launch_bounds__(256)
 octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, const int32_t* __restrict__ cellmax,
@@ -394,7 +418,9 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     __shared__ unsigned long long best[NODES];
     __shared__ cand_t   lkeys[OT_KCAP];
     __shared__ uint16_t lnof[OT_KCAP];
-    __shared__ int sL, sFinish, sMode, sErr, sValid;
+    __shared__ uint16_t cumn[NODES];
+    __shared__ uint32_t sscan[4];
+    __shared__ int sL, sFinish, sMode, sErr, sValid, sFirst;
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g.L[l];
     const int N = L.nfeat;
@@ -475,55 +501,122 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            int E = 0;
-            for (int i = 0; i < Lsz; i++) if (ccnt[i] > 1) E++;
-            int pos = 0, nToExpand = 0, err = 0;
-            // emit the children of one parent (n4..n1), processing index e
-            #define EMIT_CHILDREN(i, e)                                                                         \
-                {   const QNode q = cn[i];                                                                      \
-                    const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);       \
-                    for (int qd = 3; qd >= 0; qd--) {                                                           \
-                        const uint32_t c = cc[i][qd];                                                           \
-                        if (c == 0) { childpos[i][qd] = -1; continue; }                                         \
-                        if (pos >= NODES) { err = 1; childpos[i][qd] = 0; continue; }                   \
-                        QNode ch;                                                                               \
-                        ch.x0 = (qd & 1) ? (short)mx : q.x0; ch.x1 = (qd & 1) ? q.x1 : (short)mx;               \
-                        ch.y0 = (qd & 2) ? (short)my : q.y0; ch.y1 = (qd & 2) ? q.y1 : (short)my;               \
-                        nn[pos] = ch; ncnt[pos] = c; nsq[pos] = 4u * (uint32_t)(e) + (uint32_t)qd;              \
-                        childpos[i][qd] = (short)pos; pos++;                                                    \
-                        if (c > 1) nToExpand++;                                                                 \
-                    }                                                                                           \
-                }
-            if (sMode == 0) {
-                int e = E;
-                for (int i = Lsz - 1; i >= 0; i--) if (ccnt[i] > 1) { e--; EMIT_CHILDREN(i, e); newpos[i] = -2; }
-                for (int i = 0; i < Lsz; i++) if (ccnt[i] <= 1) {
-                    if (pos >= NODES) { err = 1; newpos[i] = 0; continue; }
-                    nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
-                }
-                if (pos >= N || pos == Lsz) sFinish = 1;
-                else if (pos + 3 * nToExpand > N) sMode = 1;
-            } else {
-                int size = Lsz, nsplit = 0;
-                for (int r = 0; r < E; r++) {
-                    const int i = order[r];
-                    int nonempty = 0;
-                    for (int qd = 0; qd < 4; qd++) nonempty += cc[i][qd] > 0;
-                    size += nonempty - 1; nsplit++;
-                    if (size >= N) break;
-                }
-                for (int i = 0; i < Lsz; i++) newpos[i] = 0;
-                for (int r = nsplit - 1; r >= 0; r--) { const int i = order[r]; EMIT_CHILDREN(i, r); newpos[i] = -2; }
-                for (int i = 0; i < Lsz; i++) if (newpos[i] != -2) {
-                    if (pos >= NODES) { err = 1; newpos[i] = 0; continue; }
-                    nn[pos] = cn[i]; ncnt[pos] = ccnt[i]; nsq[pos] = csq[i]; newpos[i] = (short)pos; pos++;
-                }
-                if (pos >= N || pos == Lsz) sFinish = 1;
+        // ---- rebuild of the node list, all 256 threads (thread t owns nodes / ranks t*IPT .. t*IPT+IPT-1, so block scans
+        // run in list order).  The list semantics are ORB-SLAM2's std::list with push_front: the children of the split nodes
+        // come first -- parents in reverse processing order, each as n4, n3, n2, n1 -- then the nodes that were not split,
+        // in their previous order.  A child's creation sequence number is 4 * (its parent's processing index) + quadrant.
+        // emit the children of parent i (processing index e) at positions cb, cb+1, ...
+        #define EMIT_CHILDREN(i, e, cb)                                                                     \
+            {   const QNode q = cn[i];                                                                      \
+                const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);       \
+                int p_ = (cb);                                                                              \
+                for (int qd = 3; qd >= 0; qd--) {                                                           \
+                    const uint32_t c = cc[i][qd];                                                           \
+                    if (c == 0) { childpos[i][qd] = -1; continue; }                                         \
+                    if (p_ < NODES) {                                                                       \
+                        QNode ch;                                                                           \
+                        ch.x0 = (qd & 1) ? (short)mx : q.x0; ch.x1 = (qd & 1) ? q.x1 : (short)mx;           \
+                        ch.y0 = (qd & 2) ? (short)my : q.y0; ch.y1 = (qd & 2) ? q.y1 : (short)my;           \
+                        nn[p_] = ch; ncnt[p_] = c; nsq[p_] = 4u * (uint32_t)(e) + (uint32_t)qd;             \
+                        childpos[i][qd] = (short)p_;                                                        \
+                    } else childpos[i][qd] = 0;                                                             \
+                    p_++;                                                                                   \
+                }                                                                                           \
             }
-            #undef EMIT_CHILDREN
-            if (err) { sErr = 1; sFinish = 1; }
-            sL = pos;
+        constexpr int IPT = NODES / 256;
+        const int mode = sMode;
+        // scan A over nodes: expandable count (low half) | kept-as-is count (high half); scan B: children | children with > 1 key
+        uint32_t aloc[IPT], bloc[IPT], asum = 0, bsum = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; k++) {
+            const int i = tid * IPT + k;
+            aloc[k] = 0; bloc[k] = 0;
+            if (i < Lsz) {
+                if (ccnt[i] > 1) {
+                    aloc[k] = 1u;
+                    for (int qd = 0; qd < 4; qd++) { const uint32_t c = cc[i][qd]; bloc[k] += (c > 0 ? 1u : 0u) + (c > 1 ? 0x10000u : 0u); }
+                } else aloc[k] = 0x10000u;
+            }
+            asum += aloc[k]; bsum += bloc[k];
+        }
+        uint32_t aT, bT;
+        uint32_t aP = block_excl_scan_u32(asum, sscan, aT);
+        uint32_t bP = block_excl_scan_u32(bsum, sscan, bT);
+        const int E = (int)(aT & 0xFFFFu);
+        int pos_total;
+        if (mode == 0) {
+            const int totalCh = (int)(bT & 0xFFFFu);
+            pos_total = totalCh + (int)(aT >> 16);
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int i = tid * IPT + k;
+                if (i < Lsz) {
+                    if (aloc[k] & 1u) {                 // split: children go in front, in reverse parent order
+                        const int e = (int)(aP & 0xFFFFu), cb = totalCh - (int)((bP & 0xFFFFu) + (bloc[k] & 0xFFFFu));
+                        EMIT_CHILDREN(i, e, cb); newpos[i] = -2;
+                    } else {
+                        const int p_ = totalCh + (int)(aP >> 16);
+                        if (p_ < NODES) { nn[p_] = cn[i]; ncnt[p_] = ccnt[i]; nsq[p_] = csq[i]; newpos[i] = (short)p_; } else newpos[i] = 0;
+                    }
+                }
+                aP += aloc[k]; bP += bloc[k];
+            }
+            if (tid == 0) {
+                if (pos_total >= N || pos_total == Lsz) sFinish = 1;
+                else if (pos_total + 3 * (int)(bT >> 16) > N) sMode = 1;
+            }
+        } else {
+            // second phase: nodes are taken in `order` (size desc, creation desc) until the list would reach N
+            if (tid == 0) sFirst = E - 1;
+            uint32_t nloc[IPT], nsum = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                nloc[k] = 0;
+                if (r < E) { const int i = order[r]; for (int qd = 0; qd < 4; qd++) nloc[k] += cc[i][qd] > 0 ? 1u : 0u; }
+                nsum += nloc[k];
+            }
+            uint32_t nT;
+            uint32_t nP = block_excl_scan_u32(nsum, sscan, nT);           // (the barriers inside also publish sFirst)
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                nP += nloc[k];                                             // inclusive: children of ranks 0..r
+                if (r < E) {
+                    cumn[r] = (uint16_t)nP;
+                    if (Lsz + (int)nP - (r + 1) >= N) atomicMin(&sFirst, r);
+                }
+            }
+            for (int i = tid; i < Lsz; i += 256) newpos[i] = 0;
+            __syncthreads();
+            const int nsplit = E > 0 ? sFirst + 1 : 0, totalCh = nsplit > 0 ? (int)cumn[nsplit - 1] : 0;
+            pos_total = totalCh + Lsz - nsplit;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int r = tid * IPT + k;
+                if (r < nsplit) { const int i = order[r]; EMIT_CHILDREN(i, r, totalCh - (int)cumn[r]); newpos[i] = -2; }
+            }
+            __syncthreads();
+            uint32_t kloc[IPT], ksum = 0;
+#pragma unroll
+            for (int k = 0; k < IPT; k++) { const int i = tid * IPT + k; kloc[k] = (i < Lsz && newpos[i] != -2) ? 1u : 0u; ksum += kloc[k]; }
+            uint32_t kT;
+            uint32_t kP = block_excl_scan_u32(ksum, sscan, kT);
+#pragma unroll
+            for (int k = 0; k < IPT; k++) {
+                const int i = tid * IPT + k;
+                if (kloc[k]) {
+                    const int p_ = totalCh + (int)kP;
+                    if (p_ < NODES) { nn[p_] = cn[i]; ncnt[p_] = ccnt[i]; nsq[p_] = csq[i]; newpos[i] = (short)p_; } else newpos[i] = 0;
+                }
+                kP += kloc[k];
+            }
+            if (tid == 0 && (pos_total >= N || pos_total == Lsz)) sFinish = 1;
+        }
+        #undef EMIT_CHILDREN
+        if (tid == 0) {
+            if (pos_total > NODES) { sErr = 1; sFinish = 1; pos_total = NODES; }
+            sL = pos_total;
         }
         __syncthreads();
         for (int i = tid; i < nc; i += 256) {
