@@ -390,21 +390,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return v;
 }
-// exclusive scan over the 256 threads of a block (thread order), `total` = the block sum; sw = 4 words of LDS.
+// exclusive scan over the OT_T threads of a block (thread order), `total` = the block sum; sw = OT_T/64 words of LDS.
 // Contains two barriers; every thread of the block must call it.
+#define OT_T 256                              // threads per octree block (1024 measured 6 % slower: the passes are barrier chains)
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sw, uint32_t& total)
 {
     const uint32_t inc = wave_incl_scan_u32(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) sw[w] = inc;
     __syncthreads();
-    const uint32_t s0 = sw[0], s1 = sw[1], s2 = sw[2], s3 = sw[3];
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < OT_T / 64; k++) { const uint32_t x = sw[k]; tot += x; if (k < w) base += x; }
     __syncthreads();
-    total = s0 + s1 + s2 + s3;
-    return inc - v + (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+    total = tot;
+    return inc - v + base;
 }
 template <int NODES>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(OT_T)
 octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, const int32_t* __restrict__ cellmax,
               uint16_t* __restrict__ node_of, uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
 {
@@ -419,9 +422,9 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     __shared__ cand_t   lkeys[OT_KCAP];
     __shared__ uint16_t lnof[OT_KCAP];
     __shared__ uint16_t cumn[NODES];
-    __shared__ uint32_t sscan[4];
+    __shared__ uint32_t sscan[OT_T / 64];
     __shared__ int sL, sFinish, sMode, sErr, sValid, sFirst;
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;        // level-major launch order: the long level-0 blocks start first
     const LevelGeom& L = g.L[l];
     const int N = L.nfeat;
     int nc = ncand[f * g.nlevels + l];
@@ -429,7 +432,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     const cand_t* gkeys = cand + (size_t)f * g.cand_total + L.cand_off;
     uint16_t* gnof = node_of + (size_t)f * g.cand_total + L.cand_off;
     const bool in_lds = nc <= OT_KCAP;                      // block-uniform
-    if (in_lds) for (int i = tid; i < nc; i += 256) lkeys[i] = gkeys[i];
+    if (in_lds) for (int i = tid; i < nc; i += OT_T) lkeys[i] = gkeys[i];
 #define KEY(i) (in_lds ? lkeys[i] : gkeys[i])
 #define NOF(i) (in_lds ? lnof[i] : gnof[i])
 #define SETNOF(i, v) do { if (in_lds) lnof[i] = (uint16_t)(v); else gnof[i] = (uint16_t)(v); } while (0)
@@ -437,7 +440,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     if (nc == 0) { if (tid == 0) nsel[f * g.nlevels + l] = 0; return; }
     // ---- root nodes
     const int nIni = L.nIni; const float hX = L.hX;
-    for (int i = tid; i < nIni; i += 256) {
+    for (int i = tid; i < nIni; i += OT_T) {
         QNode q; q.x0 = (short)(int)(hX * (float)i); q.y0 = 0; q.x1 = (short)(int)(hX * (float)(i + 1)); q.y1 = (short)(L.maxBY - L.minBY);
         nd[0][i] = q; cnt[0][i] = 0; sq[0][i] = i;
     }
@@ -446,7 +449,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     // keys are the local maxima at minThFAST; a cell that has one above iniThFAST keeps only those (DROPPED otherwise)
     const int32_t* cm = cellmax + (size_t)f * g.cells_total + L.cell_off;
     int nvalid = 0;
-    for (int i = tid; i < nc; i += 256) {
+    for (int i = tid; i < nc; i += OT_T) {
         const cand_t k = KEY(i);
         const int S = (int)(k.x >> 24) + 1;
         const int th = cm[k.y >> 14] > g.ini_th ? g.ini_th : g.min_th;
@@ -467,7 +470,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         sL = pos; sFinish = 0; sMode = 0;
     }
     __syncthreads();
-    for (int i = tid; i < nc; i += 256) { const int o = NOF(i); if (o != DROPPED) SETNOF(i, newpos[o]); }
+    for (int i = tid; i < nc; i += OT_T) { const int o = NOF(i); if (o != DROPPED) SETNOF(i, newpos[o]); }
     int cur = 1;      // buffer holding the current list
     __syncthreads();
     // ---- split passes
@@ -475,9 +478,9 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         const int Lsz = sL;
         QNode* cn = nd[cur]; uint32_t* ccnt = cnt[cur]; uint32_t* csq = sq[cur];
         QNode* nn = nd[cur ^ 1]; uint32_t* ncnt = cnt[cur ^ 1]; uint32_t* nsq = sq[cur ^ 1];
-        for (int i = tid; i < Lsz; i += 256) { cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0; }
+        for (int i = tid; i < Lsz; i += OT_T) { cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0; }
         __syncthreads();
-        for (int i = tid; i < nc; i += 256) {
+        for (int i = tid; i < nc; i += OT_T) {
             const int ni = NOF(i);
             if (ni != DROPPED && ccnt[ni] > 1) {
                 const QNode q = cn[ni];
@@ -489,7 +492,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             }
         }
         // processing order for the second phase only: rank among expandable nodes by (size desc, creation seq desc)
-        if (sMode == 1) for (int i = tid; i < Lsz; i += 256) {
+        if (sMode == 1) for (int i = tid; i < Lsz; i += OT_T) {
             if (ccnt[i] > 1) {
                 const uint32_t ci = ccnt[i], si = csq[i];
                 int r = 0;
@@ -501,7 +504,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             }
         }
         __syncthreads();
-        // ---- rebuild of the node list, all 256 threads (thread t owns nodes / ranks t*IPT .. t*IPT+IPT-1, so block scans
+        // ---- rebuild of the node list, all threads (thread t owns nodes / ranks t*IPT .. t*IPT+IPT-1, so block scans
         // run in list order).  The list semantics are ORB-SLAM2's std::list with push_front: the children of the split nodes
         // come first -- parents in reverse processing order, each as n4, n3, n2, n1 -- then the nodes that were not split,
         // in their previous order.  A child's creation sequence number is 4 * (its parent's processing index) + quadrant.
@@ -523,7 +526,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
                     p_++;                                                                                   \
                 }                                                                                           \
             }
-        constexpr int IPT = NODES / 256;
+        constexpr int IPT = NODES > OT_T ? NODES / OT_T : 1;
         const int mode = sMode;
         // scan A over nodes: expandable count (low half) | kept-as-is count (high half); scan B: children | children with > 1 key
         uint32_t aloc[IPT], bloc[IPT], asum = 0, bsum = 0;
@@ -587,7 +590,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
                     if (Lsz + (int)nP - (r + 1) >= N) atomicMin(&sFirst, r);
                 }
             }
-            for (int i = tid; i < Lsz; i += 256) newpos[i] = 0;
+            for (int i = tid; i < Lsz; i += OT_T) newpos[i] = 0;
             __syncthreads();
             const int nsplit = E > 0 ? sFirst + 1 : 0, totalCh = nsplit > 0 ? (int)cumn[nsplit - 1] : 0;
             pos_total = totalCh + Lsz - nsplit;
@@ -619,7 +622,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             sL = pos_total;
         }
         __syncthreads();
-        for (int i = tid; i < nc; i += 256) {
+        for (int i = tid; i < nc; i += OT_T) {
             const int ni = NOF(i);
             if (ni == DROPPED) continue;
             if (newpos[ni] == -2) {
@@ -637,9 +640,9 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     // ---- best response per node (ties: first in detection order == lowest rank)
     const int Lf = sL;
     if (sErr && tid == 0) atomicOr(status, 2);
-    for (int i = tid; i < Lf; i += 256) best[i] = 0ull;
+    for (int i = tid; i < Lf; i += OT_T) best[i] = 0ull;
     __syncthreads();
-    for (int i = tid; i < nc; i += 256) {
+    for (int i = tid; i < nc; i += OT_T) {
         const int ni = NOF(i);
         if (ni == DROPPED) continue;
         const cand_t k = KEY(i);
@@ -647,7 +650,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         atomicMax(&best[ni], v);
     }
     __syncthreads();
-    for (int i = tid; i < Lf && i < L.sel_cap; i += 256) {
+    for (int i = tid; i < Lf && i < L.sel_cap; i += OT_T) {
         const unsigned long long v = best[i];
         const uint32_t x = (uint32_t)(v & 4095) + L.minBX, y = (uint32_t)((v >> 12) & 4095) + L.minBY, s = (uint32_t)(v >> 56);
         out[i] = x | (y << 12) | (s << 24);
@@ -660,8 +663,8 @@ hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* 
     int need = 0;
     for (int l = 0; l < g.nlevels; l++) need = need > g.L[l].nfeat + 3 ? need : g.L[l].nfeat + 3;
     for (int l = 0; l < g.nlevels; l++) need = need > 4 * g.L[l].nIni + 8 ? need : 4 * g.L[l].nIni + 8;
-    if (need <= 512 - 8) octree_kernel<512><<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
-    else                 octree_kernel<1024><<<dim3(g.nlevels, n), 256, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    if (need <= 512 - 8) octree_kernel<512><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    else                 octree_kernel<1024><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
     return hipGetLastError();
 }
 
