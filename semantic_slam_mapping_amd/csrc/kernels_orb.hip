@@ -209,6 +209,17 @@ hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hi
 //     keeps a maximum iff S > (cellmax > iniThFAST ? iniThFAST : minThFAST)  ==  "retry the cell at minThFAST".
 // One block per 128x32 tile of one level of one frame (all levels in one launch), tile + 4-px apron staged in LDS by
 // dword loads.
+// inclusive scan of a u32 across a wave64 (DPP Hillis-Steele inside the 16-lane rows, then row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
 {
     const int v = p[0];
@@ -272,35 +283,81 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     if (tid < 64) lmax[tid] = 0;
     if (tid == 0) { nlist = 0; nstage = 0; gbase = 0; }
     __syncthreads();
-    // ---- quick reject + compaction of the positions worth scoring
+    // ---- quick reject + compaction of the positions worth scoring.  A position passes when two ADJACENT compass points of
+    // the ring (N, E, S, W at distance 3) are both brighter than v + t or both darker than v - t (necessary for a 9-arc).
+    // Four horizontally adjacent positions per thread: five dword LDS reads (the centre dword, its left/right neighbours and
+    // the dwords 3 rows up/down), bytes widened to packed u16 pairs, then packed 16-bit min/max:
+    //   bright = max over adjacent pairs of min(x - v, y - v),  dark = max over pairs of min(v - x, v - y) = -min over pairs of max
+    // thread = (group of 4 columns g = tid & 31, row tid >> 5 + 8k): no division, conflict-free rows.
     const int min_th = g.min_th;
-    for (int i0 = 0; i0 < FT_SW * FT_SH; i0 += 256) {
-        const int i = i0 + tid;
-        bool pass = false;
-        if (i < FT_SW * FT_SH) {
-            const int sy = i / FT_SW, sx = i - sy * FT_SW;
+    {
+        const uint32_t* pxw = reinterpret_cast<const uint32_t*>(px);
+        const int gq = tid & 31, r0 = tid >> 5;
+        const uint32_t t1 = (uint32_t)(min_th + 1) * 0x00010001u;
+        const int gx0 = tx0 + 4 * gq;                                   // first of the 4 positions; sx = 4 gq + 1 + j
+#pragma unroll 1
+        for (int sy = r0; sy < FT_SH; sy += 8) {
+            const int gy = ty0 + sy - 1;
+            const int rowc = (sy + 3) * (FT_PW / 4) + gq + 1;
+            const uint32_t C = pxw[rowc], P = pxw[rowc - 1], Nx = pxw[rowc + 1];
+            const uint32_t U = pxw[rowc - 3 * (FT_PW / 4)], D = pxw[rowc + 3 * (FT_PW / 4)];
+            const uint32_t Lw = __builtin_amdgcn_alignbyte(C, P, 1);     // pixels x-3 of the four positions
+            const uint32_t Rw = __builtin_amdgcn_alignbyte(Nx, C, 3);    // pixels x+3
+            unsigned passbits = 0;
+#pragma unroll
+            for (int hpair = 0; hpair < 2; hpair++) {
+                const uint32_t sel = hpair ? 0x0C030C02u : 0x0C010C00u;  // bytes (2h, 2h+1) zero-extended to u16 pairs
+                typedef short short2v __attribute__((ext_vector_type(2)));
+                auto widen = [&](uint32_t w) { uint32_t r = __builtin_amdgcn_perm(0u, w, sel); short2v o; __builtin_memcpy(&o, &r, 4); return o; };
+                const short2v c = widen(C);
+                const short2v a = widen(D) - c, bq = widen(Rw) - c, cq = widen(U) - c, d = widen(Lw) - c;
+                const short2v br = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(a, bq), __builtin_elementwise_min(bq, cq)),
+                                                             __builtin_elementwise_max(__builtin_elementwise_min(cq, d), __builtin_elementwise_min(d, a)));
+                const short2v dk = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(a, bq), __builtin_elementwise_max(bq, cq)),
+                                                             __builtin_elementwise_min(__builtin_elementwise_max(cq, d), __builtin_elementwise_max(d, a)));
+                short2v t1v; __builtin_memcpy(&t1v, &t1, 4);
+                const short2v e = __builtin_elementwise_max(br, (short2v)(0 - dk)) - t1v;      // >= 0  <=>  pass
+                uint32_t eb; __builtin_memcpy(&eb, &e, 4);
+                passbits |= ((~eb >> 15) & 1u) << (2 * hpair);
+                passbits |= ((~eb >> 31) & 1u) << (2 * hpair + 1);
+            }
+            // positions outside the FAST window of the level never pass
+            unsigned valid = 0;
+            if (gy >= SSM_EDGE && gy < h - SSM_EDGE) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (gx0 + j >= SSM_EDGE && gx0 + j < w - SSM_EDGE) valid |= 1u << j;
+            }
+            passbits &= valid;
+            // compaction: wave scan of the per-thread counts, one LDS reservation per wave
+            const uint32_t cntp = __popc(passbits);
+            const uint32_t incl = wave_incl_scan_u32(cntp);
+            const uint32_t tot = __shfl(incl, 63, 64);
+            if (tot) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&nlist, (int)tot);
+                base = __shfl(base, 0, 64) + (int)(incl - cntp);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (passbits & (1u << j)) list[base++] = (uint16_t)((sy << 8) | (4 * gq + 1 + j));
+            }
+        }
+        // the two apron columns sx = 0 and sx = FT_W + 1 (scored only as NMS neighbours)
+        if (tid < 2 * FT_SH) {
+            const int sy = tid >> 1, sx = (tid & 1) ? FT_W + 1 : 0;
             const int gx = tx0 + sx - 1, gy = ty0 + sy - 1;
             if (gx >= SSM_EDGE && gx < w - SSM_EDGE && gy >= SSM_EDGE && gy < h - SSM_EDGE) {
                 const uint8_t* p = &px[(sy + 3) * FT_PW + sx + 3];
                 const int v = p[0];
                 const int a = p[3 * FT_PW] - v, b = p[3] - v, c = p[-3 * FT_PW] - v, d = p[-3] - v;
-                const bool ba = a > min_th, bb = b > min_th, bc = c > min_th, bd = d > min_th;
-                const bool da = -a > min_th, db = -b > min_th, dc = -c > min_th, dd = -d > min_th;
-                pass = (ba && bb) || (bb && bc) || (bc && bd) || (bd && ba) || (da && db) || (db && dc) || (dc && dd) || (dd && da);
+                const int br = max(max(min(a, b), min(b, c)), max(min(c, d), min(d, a)));
+                const int dk = min(min(max(a, b), max(b, c)), min(max(c, d), max(d, a)));
+                if (max(br, -dk) > min_th) list[atomicAdd(&nlist, 1)] = (uint16_t)((sy << 8) | sx);
             }
-        }
-        const unsigned long long bal = __ballot(pass);
-        if (bal) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&nlist, __popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (pass) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
         }
     }
     __syncthreads();
     const int n = nlist;
     for (int e = tid; e < n; e += 256) {
-        const int i = list[e], sy = i / FT_SW, sx = i - sy * FT_SW;
+        const int i = list[e], sy = i >> 8, sx = i & 255;
         const int S = fast_S(&px[(sy + 3) * FT_PW + sx + 3], FT_PW);
         sc[sy * FT_SST + sx] = (uint8_t)max(S, 0);
     }
@@ -313,7 +370,7 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
         const int e = e0 + tid;
         bool keep = false; int S = 0, sx = 0, sy = 0;
         if (e < n) {
-            const int i = list[e]; sy = i / FT_SW; sx = i - sy * FT_SW;
+            const int i = list[e]; sy = i >> 8; sx = i & 255;
             if (sx >= 1 && sx <= FT_W && sy >= 1 && sy <= FT_H && tx0 + sx - 1 < w && ty0 + sy - 1 < h) {
                 const uint8_t* q = &sc[sy * FT_SST + sx];
                 S = q[0];
@@ -379,17 +436,6 @@ struct QNode { short x0, y0, x1, y1; };
 // NODES = LDS node capacity (512 covers 2000 features / 8 levels); keys (8 B) and their node ids (2 B) are copied into LDS
 // when the level has <= OT_KCAP candidates (always, in practice): the split passes then never touch global memory.
 #define OT_KCAP 4096
-// inclusive scan of a u32 across a wave64 (DPP Hillis-Steele inside the 16-lane rows, then row broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
-    return v;
-}
 // exclusive scan over the OT_T threads of a block (thread order), `total` = the block sum; sw = OT_T/64 words of LDS.
 // Contains two barriers; every thread of the block must call it.
 #define OT_T 256                              // threads per octree block (1024 measured 6 % slower: the passes are barrier chains)
