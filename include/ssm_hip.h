@@ -186,8 +186,11 @@ int ssm_segnet_debug_op(ssm_ctx* ctx, int op, int arg, const uint16_t* in, int H
 /* class logits (12 floats per net pixel, 360*480 pixels) of frame 0 of the most recent forward: for tolerance tests */
 int ssm_segnet_logits(ssm_ctx* ctx, float* out);
 
-/* per-stage device time of the most recent ssm_seq_process, measured with hipEvents on the context stream.
- * enable with ssm_set_profiling(ctx,1).  names/ms/launches hold cap entries; returns count in *n_out. */
+/* per-stage device time of the most recent ssm_seq_process, measured with hipEvents on the stream each stage runs on.
+ * ssm_seq_process runs the (SegNet ->) map stage of a sub-batch on a second stream beside the ORB -> match chain, so with
+ * on = 1 the stage times overlap (their sum exceeds the wall time); on = 2 additionally keeps everything on the context
+ * stream, which gives each stage's undisturbed duration (and a lower throughput).  0 = off.
+ * names/ms/launches hold cap entries; returns count in *n_out. */
 int ssm_set_profiling(ssm_ctx* ctx, int on);
 int ssm_get_stage_times(ssm_ctx* ctx, const char** names, float* ms, int* launches, int cap, int* n_out);
 

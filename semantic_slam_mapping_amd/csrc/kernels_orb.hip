@@ -68,10 +68,11 @@ hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g,
 // The per-CU texture-address unit spends >= 16 cycles on every vector-memory instruction whatever its width, so the
 // source rows a block needs are staged in LDS with 16-byte loads and the results leave as 16-byte stores:
 // one block = PY_ROWS output rows x the full output width; 16 output pixels per thread-iteration.
-#define PY_ROWS 8
+// a block makes `prows` output rows; the launcher picks prows = floor(256 / (16-pixel groups per row)) so that the block's
+// work items fill its 256 threads in ONE pass (a fixed 8 rows left a second pass with 16 active threads at level 1)
 __global__ void __launch_bounds__(256)
 resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int sh, int sstride,
-              int dst_off, int dw, int dh, int dstride,
+              int dst_off, int dw, int dh, int dstride, int prows,
               const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
               const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
 {
@@ -79,7 +80,7 @@ resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int
     uint32_t* xt = reinterpret_cast<uint32_t*>(smem);
     uint16_t* x1 = reinterpret_cast<uint16_t*>(smem + (size_t)dstride * 4);
     uint8_t* rows = smem + (size_t)dstride * 6;                         // dstride % 16 == 0 keeps this 16-B aligned
-    const int y0 = blockIdx.x * PY_ROWS, y1 = min(y0 + PY_ROWS, dh);
+    const int y0 = blockIdx.x * prows, y1 = min(y0 + prows, dh);
     const int sy_first = yofs[y0], sy_last = min(yofs[y1 - 1] + 1, sh - 1);
     const int nrows = sy_last - sy_first + 1;
     const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + src_off + (size_t)sy_first * sstride;
@@ -117,9 +118,10 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
 {
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
-        const int max_rows = (int)((PY_ROWS - 1) * ((double)a.h / b.h)) + 4;     // source rows one block can touch
-        dim3 grid((b.h + PY_ROWS - 1) / PY_ROWS, n);
-        resize_kernel<<<grid, 256, (size_t)max_rows * a.stride + (size_t)b.stride * 6, s>>>(pyr, g.pyr_bytes, a.img_off, a.w, a.h, a.stride, b.img_off, b.w, b.h, b.stride,
+        int prows = 256 / (b.stride >> 4); if (prows < 1) prows = 1; if (prows > 24) prows = 24;
+        const int max_rows = (int)((prows - 1) * ((double)a.h / b.h)) + 4;       // source rows one block can touch
+        dim3 grid((b.h + prows - 1) / prows, n);
+        resize_kernel<<<grid, 256, (size_t)max_rows * a.stride + (size_t)b.stride * 6, s>>>(pyr, g.pyr_bytes, a.img_off, a.w, a.h, a.stride, b.img_off, b.w, b.h, b.stride, prows,
                                                                      xofs[l], xa[l], yofs[l], ya[l]);
     }
     return hipGetLastError();

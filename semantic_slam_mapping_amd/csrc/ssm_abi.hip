@@ -66,6 +66,8 @@ struct ssm_ctx {
     std::mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // ssm_seq_process: the SegNet + map stage of a sub-batch runs here, beside the ORB + match chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ssm_config cfg{};
     OrbGeom g{};
     std::string err;
@@ -95,6 +97,7 @@ struct ssm_ctx {
     struct QuadState* quad = nullptr;
     // profiling
     bool profiling = false;
+    bool serialize = false;             // profiling mode 2: keep the side work of ssm_seq_process on the context stream (clean per-stage times)
     std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::vector<std::string> stage_names; std::vector<float> stage_ms; std::vector<int> stage_launches;
 };
@@ -249,6 +252,8 @@ static int ctx_init(ssm_ctx* c)
 {
     const ssm_config& cfg = c->cfg; const OrbGeom& g = c->g; const int B = c->B, W = g.W, H = g.H;
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
     for (int l = 1; l < g.nlevels; l++) {
@@ -315,6 +320,9 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->quad) { quad_free(c->quad); delete c->quad; }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     delete c;
 }
 extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
@@ -327,7 +335,7 @@ extern "C" int ssm_sync(ssm_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_device_flags(c);
 }
-extern "C" int ssm_set_profiling(ssm_ctx* c, int on) { if (!c) return SSM_E_INVAL; std::lock_guard<std::mutex> lk(c->mu); c->profiling = on != 0; return SSM_OK; }
+extern "C" int ssm_set_profiling(ssm_ctx* c, int on) { if (!c) return SSM_E_INVAL; std::lock_guard<std::mutex> lk(c->mu); c->profiling = on != 0; c->serialize = on == 2; return SSM_OK; }
 extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, int* launches, int cap, int* n_out)
 {
     if (!c || !n_out) return SSM_E_INVAL;
@@ -682,6 +690,16 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         HIPCHK(c, hipMemsetAsync(c->d_nkp_all, 0xFF, (size_t)R * 4, s));     // -1: no such reference frame
     }
     uint8_t* desc = c->d_desc_all + (size_t)R * row; int32_t* nkp = c->d_nkp_all + R;
+    // Two streams: the ORB -> match chain of a sub-batch and its (SegNet ->) map stage share no data, only the inputs, so the
+    // map side runs on stream2.  The chain's latency-bound kernels (pyramid, octree, describe) then overlap VALU/MFMA-bound
+    // map / SegNet work.  stream2 starts behind everything already queued on the context stream and is joined at the end.
+    const bool side_work = (stages & (SSM_STAGE_MAP | SSM_STAGE_SEGNET)) != 0, side = side_work && !c->serialize;
+    if (side) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    struct StreamSwap {               // the helpers below launch on c->stream; point it at stream2 for the side work
+        ssm_ctx* c; bool on;
+        StreamSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) std::swap(c->stream, c->stream2); }
+        ~StreamSwap() { if (on) std::swap(c->stream, c->stream2); }
+    };
     for (int f0 = 0; f0 < n; f0 += c->B) {
         const int nb = (n - f0 < c->B) ? n - f0 : c->B;
         if (stages & SSM_STAGE_ORB) {
@@ -691,9 +709,12 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         }
         if (stages & SSM_STAGE_MATCH) {
             prof_begin(c, "match");
-            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, s));
+            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->stream));
             prof_end(c);
         }
+        if (!side_work) continue;
+        StreamSwap sw(c, side);
+        hipStream_t s = c->stream;                                    // = stream2 inside this scope (unless serialised)
         const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
         if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
             r = seg_init(c); if (r) return r;
@@ -723,6 +744,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             }
         }
     }
+    if (side) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     c->prev_n = n;
     if (out) {
         out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;
