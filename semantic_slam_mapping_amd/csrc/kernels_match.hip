@@ -11,8 +11,20 @@
 
 // Two queries per lane (QPL): halves the LDS broadcast traffic per pair and gives the VALU two independent chains.
 // Best two kept as packed keys (distance << 16 | trainIdx): min/max/min on the packed key == "strict < in scan order"
-// (equal distances order by index), 3 VALU ops instead of a compare-select ladder.  trainIdx < 65536.
+// (equal distances order by index), 2 VALU ops (v_min, v_med3) instead of a compare-select ladder.  trainIdx < 65536.
 #define QPL 2
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)      // popcount(x) + acc in one instruction
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)   // median of three (no clang builtin for the unsigned form)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
                                            double ratio, int cap, ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout,
                                            int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
@@ -35,18 +47,28 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
             __syncthreads();
             for (int i = tid; i < m * 2; i += MT) tr[i] = reinterpret_cast<const uint4*>(t + (size_t)t0 * 32)[i];
             __syncthreads();
-#pragma unroll 4
-            for (int j = 0; j < m; j++) {
+            // one train descriptor (two ds_read_b128 broadcasts) against the lane's QPL queries
+            auto one_train = [&](int j) {
                 const uint4 x = tr[2 * j], y = tr[2 * j + 1];
 #pragma unroll
                 for (int u = 0; u < QPL; u++) {
-                    const int d = __popc(a[u].x ^ x.x) + __popc(a[u].y ^ x.y) + __popc(a[u].z ^ x.z) + __popc(a[u].w ^ x.w)
-                                + __popc(b[u].x ^ y.x) + __popc(b[u].y ^ y.y) + __popc(b[u].z ^ y.z) + __popc(b[u].w ^ y.w);
-                    const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + j);
-                    const uint32_t hi = max(key, k0[u]);
-                    k0[u] = min(key, k0[u]); k1[u] = min(hi, k1[u]);
+                    // 8 x (v_xor + accumulating v_bcnt): one dependent chain per (query, train) pair -- the unrolled loop keeps 8
+                    // such chains in flight.  (Left to itself the compiler breaks the chain with three extra v_add3.)
+                    uint32_t d = bcnt_acc(a[u].x ^ x.x, 0u);
+                    d = bcnt_acc(a[u].y ^ x.y, d); d = bcnt_acc(a[u].z ^ x.z, d); d = bcnt_acc(a[u].w ^ x.w, d);
+                    d = bcnt_acc(b[u].x ^ y.x, d); d = bcnt_acc(b[u].y ^ y.y, d); d = bcnt_acc(b[u].z ^ y.z, d); d = bcnt_acc(b[u].w ^ y.w, d);
+                    const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
+                    // k0 <= k1 are the two smallest keys so far: the new pair is (min, median) of {key, k0, k1}
+                    k1[u] = umed3(key, k0[u], k1[u]);
+                    k0[u] = min(key, k0[u]);
                 }
+            };
+            const int m4 = m & ~3;
+            for (int j = 0; j < m4; j += 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) one_train(j + jj);
             }
+            for (int j = m4; j < m; j++) one_train(j);
         }
 #pragma unroll
         for (int u = 0; u < QPL; u++) {
