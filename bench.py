@@ -181,7 +181,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
         elif dom == "match":
             pairs = sum(max(int(res["nkp"][f - 5 + r]), 0) * int(res["nkp"][f]) for f in range(F) for r in range(5) if f - 5 + r >= 0) / F
-            ach = pairs * 23 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12      # 23 VALU ops per descriptor pair (8 xor, 8 bcnt, 3 add3, key, max, min, min3/2)
+            ach = pairs * 19 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12      # 19 VALU ops per descriptor pair (8 xor, 8 accumulating bcnt, key, med3, min)
             roof = {"bound": "valu_int", "kernel": "match_seq_kernel", "achieved": round(ach, 3), "peak": VALU_LANEOPS_PEAK / 1e12,
                     "unit": "Tlaneop/s", "frac": round(ach / (VALU_LANEOPS_PEAK / 1e12), 4), "traffic": None}
         else:

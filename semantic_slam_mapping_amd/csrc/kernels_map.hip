@@ -389,6 +389,26 @@ __device__ __forceinline__ void run_scan(RunAcc& a, int lane, int start)
     RS_STEP(0x143, 0xC, (row >= 2 && start < 32))
 #undef RS_STEP
 }
+// llrint for |v| < 2^51: adding 1.5 * 2^52 rounds to the nearest-even integer in the FP adder and leaves it in the low
+// mantissa bits (3 instructions instead of the generic f64 -> i64 conversion sequence)
+__device__ __forceinline__ long long f64_to_ll_rn(double v)
+{
+    const double M = 6755399441055744.0;
+    return __double_as_longlong(v + M) - __double_as_longlong(M);
+}
+// slot k of the palette's perfect hash ((bgr * 0x7589a82b) >> 28): label << 24 | b | g << 8 | r << 16; empty slots hold label 255
+__device__ __forceinline__ uint32_t label_hash_entry(int k)
+{
+    switch (k) {
+        case 10: return (0u << 24) | 128u | (128u << 8) | (128u << 16);   case 1:  return (1u << 24) | 0u | (0u << 8) | (128u << 16);
+        case 2:  return (2u << 24) | 128u | (192u << 8) | (192u << 16);   case 9:  return (3u << 24) | 0u | (69u << 8) | (255u << 16);
+        case 4:  return (4u << 24) | 128u | (64u << 8) | (128u << 16);    case 13: return (5u << 24) | 222u | (40u << 8) | (60u << 16);
+        case 14: return (6u << 24) | 0u | (128u << 8) | (128u << 16);     case 11: return (7u << 24) | 128u | (128u << 8) | (192u << 16);
+        case 3:  return (8u << 24) | 128u | (64u << 8) | (64u << 16);     case 12: return (9u << 24) | 128u | (0u << 8) | (64u << 16);
+        case 7:  return (10u << 24) | 0u | (64u << 8) | (64u << 16);      case 15: return (11u << 24) | 192u | (128u << 8) | (0u << 16);
+    }
+    return 0xFF000001u;
+}
 #define MS_SLOTS 128
 struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
 __device__ __forceinline__ uint32_t label_of_bgr24(uint32_t bgr)     // b | g<<8 | r<<16
@@ -477,13 +497,29 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
         const double yf = (double)gy - cam.cy;
+        // class id of every pixel, branch-free and outside the divergent part: a 16-slot perfect hash of the 12 palette
+        // colours ((bgr * K) >> 28), the table lives in lanes 0..15 of a register and is read with a wave shuffle; an entry
+        // is (label << 24 | bgr), so a colour outside the palette compares unequal and gets 255.  The same ids drive
+        // generatePointCloud's class gate (sky 0, pole 2, cyclist 11 are dropped, mapper.cpp:41-55).
+        const uint32_t tab_entry = label_hash_entry(lane & 15);
+        uint32_t labs[16]; uint32_t keepbits = 0;
+        const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
             const int o = 3 * k;
             const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
-            const bool keep = bp_keep(d, ((moving >> k) & 1) ? 255 : 0, sbgr & 255, (sbgr >> 8) & 255, sbgr >> 16, maxd);
-            if (keep) {
+            const uint32_t ent = (uint32_t)__shfl((int)tab_entry, (int)((sbgr * 0x7589a82bu) >> 28), 64);
+            labs[k] = (ent & 0xFFFFFFu) == sbgr ? ent >> 24 : 255u;
+            const bool gated = labs[k] < 12 && ((0x805u >> labs[k]) & 1u);
+            keepbits |= (uint32_t)(d != 0 && d <= dmax && !gated) << k;
+        }
+        keepbits &= ~moving;                                          // mapper.cpp:32
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((keepbits >> k) & 1u) {
+                const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+                const int o = 3 * k;
                 const uint32_t cbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(cc[(o >> 2) + 1], cc[o >> 2], o & 3) : cc[o >> 2]) & 0xFFFFFFu;
                 const float z = (float)((double)d / cam.scale);
                 const float x = (float)(((double)(gx0 + k) - cam.cx) * (double)z / cam.fx);
@@ -499,9 +535,9 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
                 const long long vj = (long long)floorf(oy * inv_leaf) + (1 << 20);
                 const long long vk = (long long)floorf(oz * inv_leaf) + (1 << 20);
                 const long long key = (vk << 42) | (vj << 21) | vi;
-                const uint32_t lab = label_of_bgr24(sbgr);
+                const uint32_t lab = labs[k];
                 RunAcc p;
-                p.sx = __double2ll_rn((double)ox * 16777216.0); p.sy = __double2ll_rn((double)oy * 16777216.0); p.sz = __double2ll_rn((double)oz * 16777216.0);
+                p.sx = f64_to_ll_rn((double)ox * 16777216.0); p.sy = f64_to_ll_rn((double)oy * 16777216.0); p.sz = f64_to_ll_rn((double)oz * 16777216.0);
                 p.b = cbgr & 255; p.g = (cbgr >> 8) & 255; p.r = cbgr >> 16; p.n = 1;
                 kept++;
                 if (k1 == -2 && (k0 == -2 || (k0 == key && l0 == lab))) {                 // still in the first run
