@@ -73,6 +73,7 @@ public:
         }
     }
     vector<pmatch> quadmatches;
+    ssm_ctx* deviceContext() const { return dev ? dev->ctx() : nullptr; }       // shared with VisualOdometryStereo::Process
 private:
     void matching(vector<KeyPoint>& k1, cv::Mat& d1, vector<KeyPoint>& k2, cv::Mat& d2, int sw, int sh, vector<DMatch>& matches) {   // :41-83
         vector<float> p1(2 * k1.size()), p2(2 * k2.size());

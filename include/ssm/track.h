@@ -1,7 +1,9 @@
 // ssm/track.h -- rgbd_tutor::Tracker (reference include/track.h:50-191, src/track.cpp): the per-frame state machine.
 // RGB-D mode = Tracker::trackRefFrame (src/track.cpp:140-200), restated line for line on the device-backed
-// OrbFeature; the checked-in reference instead calls the stereo estimateVO() (track.cpp:19) whose quad-matcher / VO
-// are "next" rows, so tracker_mode=stereo is rejected here.  PoseGraph is out of scope: setPoseGraph is kept as a no-op hook.
+// OrbFeature; the checked-in reference instead calls the stereo estimateVO() (track.cpp:19).  Its two device stages exist
+// (QuadFeatureMatch, VisualOdometryStereo: quadmatcher.hpp, vo_stereo.hpp) but the SGBM depth / UVDisparity steps between
+// them (track.cpp:68-80) are "next" rows, so tracker_mode=stereo is still rejected here.  PoseGraph is out of scope:
+// setPoseGraph is kept as a no-op hook.
 #pragma once
 #include "common_headers.h"
 #include "orb.h"

@@ -160,6 +160,17 @@ int ssm_lk_track(ssm_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, 
 int ssm_window_match(ssm_ctx* ctx, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
                      int search_width, int search_height, float distance_threshold, ssm_dmatch* out);
 
+/* ---- stereo visual odometry on the quad matches: VisualOdometryStereo::estimateMotion (src/vo_stereo.cpp:47-152) --------
+ * params mirror VisualOdometryStereo::parameters (include/vo_stereo.hpp: calib.f/cu/cv, base, inlier_threshold,
+ * reweighting).  samples: iters x 3 match indices, what VisualOdometry::getRandomSample (src/vo.cpp:74-93) draws per RANSAC
+ * iteration -- the host class owns the rand() stream (include/ssm/vo_stereo.hpp).  tr = (rx, ry, rz, tx, ty, tz) of
+ * the best hypothesis after refinement; inliers (cap entries) / n_inliers = its consensus set in index order; *success = 0
+ * where the reference returns an empty vector (fewer than 6 matches or inliers, refinement not converged).
+ * Contracts (sin/cos, LU, summation order): oracle/vo.c. */
+typedef struct { double f, cu, cv, base, inlier_threshold; int32_t reweighting, pad; } ssm_vo_params;
+int ssm_vo_estimate(ssm_ctx* ctx, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
+                    double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success);
+
 /* ---- Classifier (include/segnet.h:22-46, src/segnet.cpp): SegNet driving_webdemo forward, fp16 MFMA, on the device.
  * Topology is fixed (VGG-16 encoder / mirrored decoder, 26 conv3x3 layers, 12 classes, 480x360 net input); weights
  * are DATA: the .caffemodel is not in the reference tree (README.md:25-32), so the caller supplies every layer.

@@ -120,6 +120,20 @@ int  sso_window_match(const float* kp1, const uint8_t* d1, int n1, const float* 
 int  sso_quad_chain(const float* k_lc, const float* k_rc, const float* k_rp, const float* k_lp, int n_lc,
                     const sso_dmatch* m_lrc, const sso_dmatch* m_rcp, const sso_dmatch* m_rlp, sso_pmatch* out);
 
+/* ---------------- stereo visual odometry on the quad matches (src/vo_stereo.cpp, src/vo.cpp): see vo.c ---------------- */
+typedef struct { int32_t r[34]; int f, b; } sso_rand_state;             /* glibc rand(): TYPE_3 additive feedback */
+void    sso_rand_seed(sso_rand_state* st, unsigned seed);               /* srand(seed) */
+int32_t sso_rand_next(sso_rand_state* st);                              /* rand() */
+void    sso_vo_random_sample(sso_rand_state* st, int N, int num, int32_t* out);   /* VisualOdometry::getRandomSample */
+void    sso_sincos64(double x, double* s, double* c);                   /* the sin/cos contract shared with the HIP kernel */
+int     sso_solve6_lu(double A[36], double b[6]);                       /* cv::solve(.., DECOMP_LU), 6x6; b <- x; 0 = singular */
+typedef struct { double f, cu, cv, base, inlier_threshold; int32_t reweighting, pad; } sso_vo_params;
+/* estimateMotion: samples = iters x 3 match indices (from sso_vo_random_sample).  tr = (rx, ry, rz, tx, ty, tz);
+ * inliers (cap n) / n_inliers = the best RANSAC consensus set.  returns 1 on success (refinement converged, >= 6 inliers) */
+int     sso_vo_estimate(const sso_pmatch* m, int n, const sso_vo_params* P, const int32_t* samples, int iters,
+                        double tr[6], int32_t* inliers, int* n_inliers);
+void    sso_vo_tr_to_matrix(const double tr[6], double T[16]);          /* transformationVectorToMatrix, row-major */
+
 /* ---------------- synthetic stream, integer-only ---------------- */
 void sso_synth_frame(uint64_t seed, int frame_id, int w, int h,
                      uint8_t* bgr, uint16_t* depth, uint8_t* sem_bgr, uint8_t* label_ids);

@@ -19,6 +19,7 @@ VOXEL_DTYPE = np.dtype([("key", "i8"), ("sx", "i8"), ("sy", "i8"), ("sz", "i8"),
                         ("sb", "u8"), ("n", "u8"), ("hist", "u4", (12,))])
 PMATCH_DTYPE = np.dtype([("u1p", "f4"), ("v1p", "f4"), ("i1p", "i4"), ("u2p", "f4"), ("v2p", "f4"), ("i2p", "i4"), ("u1c", "f4"), ("v1c", "f4"),
                          ("i1c", "i4"), ("u2c", "f4"), ("v2c", "f4"), ("i2c", "i4"), ("dis_c", "i2"), ("dis_p", "i2")])
+VO_PARAMS_DTYPE = np.dtype([("f", "f8"), ("cu", "f8"), ("cv", "f8"), ("base", "f8"), ("inlier_threshold", "f8"), ("reweighting", "i4"), ("pad", "i4")])
 assert PMATCH_DTYPE.itemsize == 52
 assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
 
@@ -120,6 +121,14 @@ class Context:
         out = np.zeros(max_corners, PMATCH_DTYPE); n = C.c_int(0)
         self._chk(self.lib.ssm_quad_track(self.h, _ptr(ims[0]), _ptr(ims[1]), _ptr(ims[2]), _ptr(ims[3]), w, h, w, max_corners, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    def vo_estimate(self, matches, f, cu, cv, base, samples, inlier_threshold=2.0, reweighting=True):
+        """VisualOdometryStereo::estimateMotion on quad matches: (success, tr[6], inlier indices)"""
+        m = np.ascontiguousarray(matches, PMATCH_DTYPE); samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 3)
+        prm = np.array([(f, cu, cv, base, inlier_threshold, int(reweighting), 0)], VO_PARAMS_DTYPE)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(m), 1), np.int32); n = C.c_int(0); ok = C.c_int(0)
+        self._chk(self.lib.ssm_vo_estimate(self.h, _ptr(m), len(m), _ptr(prm), _ptr(samples), len(samples), _ptr(tr), _ptr(inl), len(inl), C.byref(n), C.byref(ok)))
+        return bool(ok.value), tr, inl[:n.value].copy()
 
     def gftt(self, img, max_corners=1000, quality=0.04, min_distance=8.0):
         img = np.ascontiguousarray(img, np.uint8); h, w = img.shape

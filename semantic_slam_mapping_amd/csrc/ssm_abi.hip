@@ -1133,6 +1133,38 @@ extern "C" int ssm_window_match(ssm_ctx* c, const float* kp1, const uint8_t* d1,
     return SSM_OK;
 }
 
+// ---------------------------------------------------------------- VisualOdometryStereo::estimateMotion
+extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
+                               double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || iters < 0 || !params || !tr || !n_inliers || !success || (n && !matches) || (iters && !samples)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    for (int k = 0; k < 6; k++) tr[k] = 0.0;
+    *n_inliers = 0; *success = 0;
+    if (n < 6) return SSM_OK;                                 // estimateMotion returns an empty vector (vo_stereo.cpp:61-63)
+    for (int k = 0; k < 3 * iters; k++) if (samples[k] < 0 || samples[k] >= n) FAIL(c, SSM_E_INVAL, "sample index out of range");
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_m = 0, o_s = o_m + al((size_t)n * sizeof(ssm_pmatch)), o_tr = o_s + al((size_t)iters * 12 + 16), o_cnt = o_tr + al((size_t)iters * 48 + 48),
+                 o_out = o_cnt + al((size_t)iters * 4 + 16), o_inl = o_out + 256, o_res = o_inl + al((size_t)n * 4), total = o_res + 256;
+    int r = ensure_scratch(c, total); if (r) return r;
+    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(p + o_m, matches, (size_t)n * sizeof(ssm_pmatch), hipMemcpyHostToDevice, s));
+    if (iters) HIPCHK(c, hipMemcpyAsync(p + o_s, samples, (size_t)iters * 12, hipMemcpyHostToDevice, s));
+    HIPCHK(c, k_vo_estimate((const ssm_pmatch*)(p + o_m), n, *params, (const int32_t*)(p + o_s), iters, (double*)(p + o_tr), (int32_t*)(p + o_cnt),
+                            (double*)(p + o_out), (int32_t*)(p + o_inl), (int32_t*)(p + o_res), s));
+    int32_t res[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(tr, p + o_out, 48, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(res, p + o_res, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_inliers = res[0]; *success = res[1];
+    if (inliers && res[0] > 0) {
+        if (res[0] > cap) FAIL(c, SSM_E_CAPACITY, "inlier buffer too small (need " + std::to_string(res[0]) + ")");
+        HIPCHK(c, hipMemcpy(inliers, p + o_inl, (size_t)res[0] * 4, hipMemcpyDeviceToHost));
+    }
+    return SSM_OK;
+}
+
 // ---------------------------------------------------------------- utilities
 extern "C" int ssm_dev_alloc(ssm_ctx* c, size_t bytes, void** out)
 {

@@ -6,6 +6,7 @@
 #include "ssm/mapper.h"
 #include "ssm/segnet.h"
 #include "ssm/quadmatcher.hpp"
+#include "ssm/vo_stereo.hpp"
 using namespace std;
 using namespace rgbd_tutor;
 static int fails = 0;
@@ -54,6 +55,35 @@ int main(int argc, char** argv)
         bool ok = pnp.solvePnP(img, obj, k, inl, T);
         double err = 0; for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) err = max(err, fabs(T(r, c) - Tgt(r, c)));
         CHECK("pnp_recovers_pose_and_rejects_outliers", ok && err < 1e-3 && inl.size() == 180);
+    }
+
+    // VisualOdometryStereo on synthetic quad matches (the consumer of QuadFeatureMatch::quadmatches, src/track.cpp:57-66)
+    {
+        VisualOdometryStereo::parameters vp; vp.calib.f = 718.856; vp.calib.cu = 607.1928; vp.calib.cv = 185.2157; vp.base = 0.5323; vp.inlier_threshold = 2.0;
+        VisualOdometryStereo viso(vp);
+        QuadFeatureMatch qm;
+        const double tr[6] = {0.01, -0.02, 0.005, 0.05, -0.02, -0.8};
+        const double sx = sin(tr[0]), cx = cos(tr[0]), sy = sin(tr[1]), cy = cos(tr[1]), sz = sin(tr[2]), cz = cos(tr[2]);
+        const double R[9] = {cy*cz, -cy*sz, sy, sx*sy*cz+cx*sz, -sx*sy*sz+cx*cz, -sx*cy, -cx*sy*cz+sx*sz, cx*sy*sz+sx*cz, cx*cy};
+        unsigned s = 777;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / 16777216.0; };
+        for (int i = 0; i < 300; i++) {
+            const double X = rnd() * 20 - 10, Y = rnd() * 4 - 2, Z = 5 + rnd() * 35;
+            const double Xc = R[0]*X + R[1]*Y + R[2]*Z + tr[3], Yc = R[3]*X + R[4]*Y + R[5]*Z + tr[4], Zc = R[6]*X + R[7]*Y + R[8]*Z + tr[5];
+            pmatch q; memset(static_cast<void*>(&q), 0, sizeof(q));
+            q.u1p = (float)(vp.calib.f * X / Z + vp.calib.cu); q.v1p = (float)(vp.calib.f * Y / Z + vp.calib.cv); q.u2p = (float)(vp.calib.f * (X - vp.base) / Z + vp.calib.cu); q.v2p = q.v1p;
+            q.u1c = (float)(vp.calib.f * Xc / Zc + vp.calib.cu); q.v1c = (float)(vp.calib.f * Yc / Zc + vp.calib.cv); q.u2c = (float)(vp.calib.f * (Xc - vp.base) / Zc + vp.calib.cu); q.v2c = q.v1c;
+            if (i % 6 == 0) { q.u1c += 35; q.v2c -= 18; }                    // gross outliers
+            qm.quadmatches.push_back(q);
+        }
+        const bool ok = viso.Process(qm);
+        cv::Mat M = viso.getMotion();
+        double err = 0;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) err = max(err, fabs(M.at<double>(r, c) - R[r * 3 + c])); err = max(err, fabs(M.at<double>(r, 3) - tr[3 + r])); }
+        CHECK("vo_stereo_recovers_motion", ok && err < 1e-3 && viso.getNumberOfMatches() == 300 && viso.getNumberOfInliers() == 250 &&
+              viso.quadmatches_inlier.size() == 250 && viso.quadmatches_outlier.size() == 50);
+        QuadFeatureMatch few; few.quadmatches.assign(qm.quadmatches.begin(), qm.quadmatches.begin() + 5);
+        CHECK("vo_stereo_needs_six_matches", !viso.Process(few));
     }
 
     // Tracker state machine on a static scene (the same frame fed three times): state OK, pose ~ identity (not exact: 3-D positions come from truncated pixel coordinates, include/orb.h:50, while the 2-D side is the scaled sub-pixel keypoint)

@@ -57,6 +57,12 @@ class Oracle:
         L.sso_fast_atan2.restype = C.c_float
         L.sso_fast_atan2.argtypes = [C.c_float, C.c_float]
         L.sso_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.sso_rand_seed.argtypes = [P, C.c_uint]; L.sso_rand_next.argtypes = [P]
+        L.sso_vo_random_sample.argtypes = [P, I, I, P]
+        L.sso_sincos64.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.sso_solve6_lu.argtypes = [P, P]
+        L.sso_vo_estimate.argtypes = [P, I, P, P, I, P, P, C.POINTER(I)]
+        L.sso_vo_tr_to_matrix.argtypes = [P, P]
         L.sso_hamming_knn2.argtypes = [P, I, P, I, P, P]
         L.sso_match.argtypes = [P, I, P, I, C.c_double, P]
         L.sso_project2dTo3d.argtypes = [P, I, I, C.POINTER(Cam), I, I, P]
@@ -265,6 +271,42 @@ class Oracle:
         out = np.zeros(max(len(ks[0]), 1), PMATCH_DTYPE)
         n = self.L.sso_quad_chain(*[x.ctypes.data for x in ks], len(ks[0]), *[x.ctypes.data for x in ms], out.ctypes.data)
         return out[:n].copy()
+
+    # ---- stereo visual odometry (oracle/vo.c)
+    def rand_state(self, seed):
+        st = np.zeros(36, np.int32); self.L.sso_rand_seed(st.ctypes.data, seed); return st
+
+    def rand_next(self, st):
+        return int(self.L.sso_rand_next(st.ctypes.data))
+
+    def vo_samples(self, st, n, iters, num=3):
+        out = np.zeros((iters, num), np.int32)
+        for k in range(iters):
+            self.L.sso_vo_random_sample(st.ctypes.data, n, num, out[k].ctypes.data)
+        return out
+
+    def sincos64(self, x):
+        s = C.c_double(); c = C.c_double(); self.L.sso_sincos64(x, C.byref(s), C.byref(c)); return s.value, c.value
+
+    def solve6_lu(self, A, b):
+        A = np.ascontiguousarray(A, np.float64).copy(); b = np.ascontiguousarray(b, np.float64).copy()
+        ok = self.L.sso_solve6_lu(A.ctypes.data, b.ctypes.data)
+        return bool(ok), b
+
+    @staticmethod
+    def vo_params(f, cu, cv, base, inlier_threshold=2.0, reweighting=True):
+        return np.array([(f, cu, cv, base, inlier_threshold, int(reweighting), 0)],
+                        np.dtype([("f", "f8"), ("cu", "f8"), ("cv", "f8"), ("base", "f8"), ("thr", "f8"), ("rw", "i4"), ("pad", "i4")]))
+
+    def vo_estimate(self, matches, params, samples):
+        m = np.ascontiguousarray(matches, PMATCH_DTYPE); samples = np.ascontiguousarray(samples, np.int32)
+        tr = np.zeros(6, np.float64); inl = np.zeros(max(len(m), 1), np.int32); n = C.c_int(0)
+        ok = self.L.sso_vo_estimate(m.ctypes.data, len(m), params.ctypes.data, samples.ctypes.data, len(samples), tr.ctypes.data, inl.ctypes.data, C.byref(n))
+        return bool(ok), tr, inl[:n.value].copy()
+
+    def vo_tr_to_matrix(self, tr):
+        tr = np.ascontiguousarray(tr, np.float64); T = np.zeros((4, 4), np.float64)
+        self.L.sso_vo_tr_to_matrix(tr.ctypes.data, T.ctypes.data); return T
 
     def pipeline(self, first, count, w=640, h=480, nfeatures=1000, nlevels=8, ini=20, mn=7, ref_frames=5, scale=1.2,
                  leaf=0.1, ratio=0.8, max_distance=40.0, cam=(318.6, 255.3, 517.3, 516.5, 1000.0), seed=0x5EED0000):

@@ -561,3 +561,171 @@ def lk_track(prev, nxt, pts, max_count=200, epsilon=0.01, min_eig_thr=1e-6, win=
                     break
                 pdx, pdy = ddx, ddy
     return out, status, err
+
+
+# ---------------------------------------------------------------- stereo visual odometry (src/vo_stereo.cpp, src/vo.cpp)
+# An independent restatement of oracle/vo.c in Python floats (IEEE double, never fused): same contracts (glibc rand,
+# the sin/cos polynomial, OpenCV 2.4 LU, the 64-way summation order of the refinement).
+class GlibcRand:
+    def __init__(self, seed):
+        seed = seed or 1
+        r = [seed]
+        for _ in range(30):
+            hi, lo = divmod(r[-1], 127773)
+            w = 16807 * lo - 2836 * hi
+            if w < 0:
+                w += 2147483647
+            r.append(w)
+        self.r = [x & 0xFFFFFFFF for x in r]; self.f = 3; self.b = 0
+        for _ in range(310):
+            self.next()
+
+    def next(self):
+        self.r[self.f] = (self.r[self.f] + self.r[self.b]) & 0xFFFFFFFF
+        out = self.r[self.f] >> 1
+        self.f = (self.f + 1) % 31; self.b = (self.b + 1) % 31
+        return out
+
+    def sample(self, n, num):
+        pool = list(range(n)); out = []
+        for _ in range(num):
+            out.append(pool.pop(self.next() % len(pool)))
+        return out
+
+
+def vo_sincos(x):
+    fn = float(np.rint(x * 6.36619772367581382433e-01))
+    r = x - fn * 1.57079632673412561417e+00
+    r = r - fn * 6.07710050650619224932e-11
+    r = r - fn * 2.02226624879595063154e-21
+    z = r * r
+    S = (-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10)
+    Cc = (4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11)
+    ps = S[1] + z * (S[2] + z * (S[3] + z * (S[4] + z * S[5])))
+    sr = r + (r * z) * (S[0] + z * ps)
+    pc = Cc[0] + z * (Cc[1] + z * (Cc[2] + z * (Cc[3] + z * (Cc[4] + z * Cc[5]))))
+    cr = (1.0 - 0.5 * z) + (z * z) * pc
+    return ((sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr))[int(fn) & 3]
+
+
+def vo_solve6(A, b):
+    A = [list(map(float, row)) for row in A]; b = list(map(float, b)); eps = 2.220446049250313e-16 * 100
+    for i in range(6):
+        k = i
+        for j in range(i + 1, 6):
+            if abs(A[j][i]) > abs(A[k][i]):
+                k = j
+        if abs(A[k][i]) < eps:
+            return None
+        if k != i:
+            for j in range(i, 6):
+                A[i][j], A[k][j] = A[k][j], A[i][j]
+            b[i], b[k] = b[k], b[i]
+        d = -1 / A[i][i]
+        for j in range(i + 1, 6):
+            alpha = A[j][i] * d
+            for kk in range(i + 1, 6):
+                A[j][kk] += alpha * A[i][kk]
+            b[j] += alpha * b[i]
+        A[i][i] = -d
+    for i in range(5, -1, -1):
+        s = b[i]
+        for k in range(i + 1, 6):
+            s -= A[i][k] * b[k]
+        b[i] = s * A[i][i]
+    return b
+
+
+def _vo_rot(tr):
+    (sx, cx), (sy, cy), (sz, cz) = vo_sincos(tr[0]), vo_sincos(tr[1]), vo_sincos(tr[2])
+    R = dict(r00=+cy*cz, r01=-cy*sz, r02=+sy, r10=+sx*sy*cz+cx*sz, r11=-sx*sy*sz+cx*cz, r12=-sx*cy, r20=-cx*sy*cz+sx*sz, r21=+cx*sy*sz+sx*cz, r22=+cx*cy,
+             x10=+cx*sy*cz-sx*sz, x11=-cx*sy*sz-sx*sz, x12=-cx*cy, x20=+sx*sy*cz+cx*sz, x21=-sx*sy*sz+cx*cz, x22=-sx*cy,
+             y00=-sy*cz, y01=+sy*sz, y02=+cy, y10=+sx*cy*cz, y11=-sx*cy*sz, y12=+sx*sy, y20=-cx*cy*cz, y21=+cx*cy*sz, y22=-cx*sy,
+             z00=-cy*sz, z01=-cy*cz, z10=-sx*sy*sz+cx*cz, z11=-sx*sy*cz-cx*sz, z20=+cx*sy*sz+sx*cz, z21=+cx*sy*cz-sx*sz, tx=tr[3], ty=tr[4], tz=tr[5])
+    return R
+
+
+def _vo_point(m, P, R, want_j):
+    f, cu, cv, base, thr, rw = P
+    dd = max(float(np.float32(m["u1p"]) - np.float32(m["u2p"])), 1.0)
+    X = (float(m["u1p"]) - cu) * base / dd; Y = (float(m["v1p"]) - cv) * base / dd; Z = f * base / dd
+    X1c = R["r00"]*X + R["r01"]*Y + R["r02"]*Z + R["tx"]; Y1c = R["r10"]*X + R["r11"]*Y + R["r12"]*Z + R["ty"]; Z1c = R["r20"]*X + R["r21"]*Y + R["r22"]*Z + R["tz"]
+    obs = [float(m["u1c"]), float(m["v1c"]), float(m["u2c"]), float(m["v2c"])]
+    w = 1.0 / (abs(obs[0] - cu) / abs(cu) + 0.05) if rw else 1.0
+    X2c = X1c - base
+    pred = [f * X1c / Z1c + cu, f * Y1c / Z1c + cv, f * X2c / Z1c + cu, f * Y1c / Z1c + cv]
+    if not want_j:
+        return pred, None, None
+    J = [[0.0] * 6 for _ in range(4)]
+    for j in range(6):
+        if j == 0: d = (0.0, R["x10"]*X + R["x11"]*Y + R["x12"]*Z, R["x20"]*X + R["x21"]*Y + R["x22"]*Z)
+        elif j == 1: d = (R["y00"]*X + R["y01"]*Y + R["y02"]*Z, R["y10"]*X + R["y11"]*Y + R["y12"]*Z, R["y20"]*X + R["y21"]*Y + R["y22"]*Z)
+        elif j == 2: d = (R["z00"]*X + R["z01"]*Y, R["z10"]*X + R["z11"]*Y, R["z20"]*X + R["z21"]*Y)
+        else: d = (1.0 if j == 3 else 0.0, 1.0 if j == 4 else 0.0, 1.0 if j == 5 else 0.0)
+        J[0][j] = w * f * (d[0]*Z1c - X1c*d[2]) / (Z1c*Z1c); J[1][j] = w * f * (d[1]*Z1c - Y1c*d[2]) / (Z1c*Z1c)
+        J[2][j] = w * f * (d[0]*Z1c - X2c*d[2]) / (Z1c*Z1c); J[3][j] = w * f * (d[1]*Z1c - Y1c*d[2]) / (Z1c*Z1c)
+    return pred, J, [w * (obs[k] - pred[k]) for k in range(4)]
+
+
+def _vo_update(ms, active, P, tr, eps, lanes):
+    if len(active) < 3:
+        return 1
+    R = _vo_rot(tr)
+    acc = [[0.0] * 42 for _ in range(lanes)]
+    for q, idx in enumerate(active):
+        _, J, res = _vo_point(ms[idx], P, R, True)
+        a = acc[q % lanes]
+        for r in range(4):
+            for mm in range(6):
+                for nn in range(6):
+                    a[mm * 6 + nn] += J[r][mm] * J[r][nn]
+                a[36 + mm] += J[r][mm] * res[r]
+    s = 1
+    while s < lanes:
+        acc = [[acc[l][k] + acc[l ^ s][k] for k in range(42)] for l in range(lanes)]
+        s <<= 1
+    x = vo_solve6([acc[0][6 * i:6 * i + 6] for i in range(6)], acc[0][36:])
+    if x is None:
+        return 1
+    conv = True
+    for k in range(6):
+        tr[k] += 1.0 * x[k]
+        if abs(x[k]) > eps:
+            conv = False
+    return 2 if conv else 0
+
+
+def vo_estimate(ms, P, samples):
+    """P = (f, cu, cv, base, inlier_threshold, reweighting).  returns (success, tr, inliers)"""
+    n = len(ms)
+    if n < 6:
+        return False, [0.0] * 6, []
+    best, tr_best = [], [0.0] * 6
+    for smp in samples:
+        tr = [0.0] * 6; res = 0; it = 0
+        while res == 0:
+            res = _vo_update(ms, list(smp), P, tr, 1e-6, 1)
+            it += 1
+            if it - 1 > 20 or res == 2:
+                break
+        if res != 1:
+            R = _vo_rot(tr); cur = []
+            for i in range(n):
+                pred, _, _ = _vo_point(ms[i], P, R, False)
+                o = [float(ms[i]["u1c"]), float(ms[i]["v1c"]), float(ms[i]["u2c"]), float(ms[i]["v2c"])]
+                if sum((o[k] - pred[k]) * (o[k] - pred[k]) for k in range(4)) < P[4] * P[4]:
+                    cur.append(i)
+            if len(cur) > len(best):
+                best, tr_best = cur, list(tr)
+    ok = True
+    if len(best) >= 6:
+        res = 0; it = 0
+        while res == 0:
+            res = _vo_update(ms, best, P, tr_best, 1e-8, 64)
+            it += 1
+            if it - 1 > 100 or res == 2:
+                break
+        ok = res == 2
+    else:
+        ok = False
+    return ok, tr_best, best

@@ -27,6 +27,8 @@ def test_host_layer_builds_and_keeps_reference_names():
         "quadmatcher.hpp": ["class QuadFeatureMatch", "void init(int detector_type, int descriptor_type)", "void detectFeature()", "void extractDescriptor()",
                             "void circularMatching()", "vector<pmatch> quadmatches", "struct pmatch"],
         "segnet.h": ["class Classifier", "Classifier()", "std::vector<Prediction> Classify(const cv::Mat& img, int N = 1)"],
+        "vo_stereo.hpp": ["class VisualOdometry", "class VisualOdometryStereo : public VisualOdometry", "bool Process(QuadFeatureMatch& quadmatcher)", "cv::Mat getMotion()",
+                          "int getNumberOfInliers()", "std::vector<int> getInlierIndices()", "quadmatches_inlier", "std::vector<int> getRandomSample(int N, int num)"],
         "pnp.h": ["bool solvePnP(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj", "bool solvePnPLazy("],
     }
     for f, needles in want.items():
