@@ -160,6 +160,24 @@ int ssm_lk_track(ssm_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, 
 int ssm_window_match(ssm_ctx* ctx, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
                      int search_width, int search_height, float distance_threshold, ssm_dmatch* out);
 
+/* ---- depth from stereo: calDisparity_SGBM (src/stereo.cpp:11-30, cv::StereoSGBM) and FrameReader's disparity -> depth
+ * conversion with the 3-D ROI gate (src/rgbdframe.cpp:81-116) -------------------------------------------------------------
+ * params mirror the public fields of cv::StereoSGBM (fullDP = false).  ssm_sgbm_params_default fills what stereo.cpp sets:
+ * 80 disparities, SAD window 11, P1 = 4*11*11, P2 = 32*11*11, uniqueness 10, speckle window 100 / range 32, disp12MaxDiff 1,
+ * preFilterCap 63.  left / right: rectified 8-bit images.  disp: int16 per pixel, fixed point with 4 fractional bits,
+ * (minDisparity - 1) * 16 where no disparity was accepted (what cv::StereoSGBM::operator() writes).  stage 1 stops after
+ * computeDisparitySGBM (no medianBlur / filterSpeckles), for tests.  numberOfDisparities: a multiple of 16, <= 128. */
+typedef struct { int32_t minDisparity, numberOfDisparities, SADWindowSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+                 speckleWindowSize, speckleRange; } ssm_sgbm_params;
+void ssm_sgbm_params_default(ssm_sgbm_params* p);
+int ssm_sgbm(ssm_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp);
+/* the whole depth step of FrameReader::next() in KITTI mode: SGBM, then depth = ushort(f * baseline / d * 16 * scale) inside
+ * the ROI (|x| < roix, |y| < roiy, 0 < z < roiz), 0 elsewhere and where d is 0 or the image's minimum disparity value.
+ * disp (may be NULL) receives the disparity image too. */
+int ssm_stereo_depth(ssm_ctx* ctx, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
+                     double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+                     uint16_t* depth, int16_t* disp);
+
 /* ---- stereo visual odometry on the quad matches: VisualOdometryStereo::estimateMotion (src/vo_stereo.cpp:47-152) --------
  * params mirror VisualOdometryStereo::parameters (include/vo_stereo.hpp: calib.f/cu/cv, base, inlier_threshold,
  * reweighting).  samples: iters x 3 match indices, what VisualOdometry::getRandomSample (src/vo.cpp:74-93) draws per RANSAC

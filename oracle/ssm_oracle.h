@@ -134,6 +134,16 @@ int     sso_vo_estimate(const sso_pmatch* m, int n, const sso_vo_params* P, cons
                         double tr[6], int32_t* inliers, int* n_inliers);
 void    sso_vo_tr_to_matrix(const double tr[6], double T[16]);          /* transformationVectorToMatrix, row-major */
 
+/* ---------------- depth from stereo (src/stereo.cpp:11-30 cv::StereoSGBM; src/rgbdframe.cpp:81-116): see sgbm.c ---------------- */
+typedef struct { int32_t minDisparity, numberOfDisparities, SADWindowSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+                 speckleWindowSize, speckleRange; } sso_sgbm_params;
+int  sso_sgbm_raw(const uint8_t* left, const uint8_t* right, int w, int h, const sso_sgbm_params* p, int16_t* disp);   /* computeDisparitySGBM */
+void sso_median3_s16(const int16_t* src, int w, int h, int16_t* dst);                                                  /* cv::medianBlur 3 */
+void sso_filter_speckles(int16_t* img, int w, int h, int newVal, int maxSpeckleSize, int maxDiff);                    /* cv::filterSpeckles */
+int  sso_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const sso_sgbm_params* p, int16_t* disp);       /* StereoSGBM::operator() */
+void sso_disparity_to_depth(const int16_t* disp, int w, int h, double baseline, double cu, double cv, double f,
+                            double roix, double roiy, double roiz, double scale, uint16_t* depth);
+
 /* ---------------- synthetic stream, integer-only ---------------- */
 void sso_synth_frame(uint64_t seed, int frame_id, int w, int h,
                      uint8_t* bgr, uint16_t* depth, uint8_t* sem_bgr, uint8_t* label_ids);

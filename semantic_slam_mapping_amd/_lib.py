@@ -63,6 +63,9 @@ SYMBOLS = {
     "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),
     "ssm_lk_track": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _D, _D]),
     "ssm_window_match": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P]),
+    "ssm_sgbm_params_default": (None, [_P]),
+    "ssm_sgbm": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "ssm_stereo_depth": (_I, [_P, _P, _P, _I, _I, _I, _P] + [_D] * 8 + [_P, _P]),
     "ssm_vo_estimate": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
     "ssm_segnet_num_layers": (_I, []),
     "ssm_segnet_layer_shape": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

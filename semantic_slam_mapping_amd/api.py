@@ -122,6 +122,34 @@ class Context:
         self._chk(self.lib.ssm_quad_track(self.h, _ptr(ims[0]), _ptr(ims[1]), _ptr(ims[2]), _ptr(ims[3]), w, h, w, max_corners, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
 
+    @staticmethod
+    def sgbm_params(**kw):
+        """cv::StereoSGBM fields as src/stereo.cpp:11-30 sets them; override by keyword"""
+        d = dict(minDisparity=0, numberOfDisparities=80, SADWindowSize=11, P1=None, P2=None, disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10,
+                 speckleWindowSize=100, speckleRange=32)
+        d.update(kw)
+        if d["P1"] is None: d["P1"] = 4 * d["SADWindowSize"] ** 2
+        if d["P2"] is None: d["P2"] = 32 * d["SADWindowSize"] ** 2
+        return np.array([d[k] for k in ("minDisparity", "numberOfDisparities", "SADWindowSize", "P1", "P2", "disp12MaxDiff", "preFilterCap", "uniquenessRatio",
+                                        "speckleWindowSize", "speckleRange")], np.int32)
+
+    def sgbm(self, left, right, params=None, raw=False):
+        """cv::StereoSGBM::operator(): int16 disparity x16 ((minDisparity-1)*16 = invalid); raw=True stops before medianBlur / filterSpeckles"""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8); h, w = left.shape
+        params = self.sgbm_params() if params is None else np.ascontiguousarray(params, np.int32)
+        disp = np.zeros((h, w), np.int16)
+        self._chk(self.lib.ssm_sgbm(self.h, _ptr(left), _ptr(right), w, h, left.strides[0], _ptr(params), int(raw), _ptr(disp)))
+        return disp
+
+    def stereo_depth(self, left, right, baseline, cu, cv, f, roix, roiy, roiz, scale, params=None):
+        """FrameReader's KITTI depth step (src/rgbdframe.cpp:81-116): (depth u16, disparity int16)"""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8); h, w = left.shape
+        params = self.sgbm_params() if params is None else np.ascontiguousarray(params, np.int32)
+        depth = np.zeros((h, w), np.uint16); disp = np.zeros((h, w), np.int16)
+        self._chk(self.lib.ssm_stereo_depth(self.h, _ptr(left), _ptr(right), w, h, left.strides[0], _ptr(params), baseline, cu, cv, f, roix, roiy, roiz, scale,
+                                            _ptr(depth), _ptr(disp)))
+        return depth, disp
+
     def vo_estimate(self, matches, f, cu, cv, base, samples, inlier_threshold=2.0, reweighting=True):
         """VisualOdometryStereo::estimateMotion on quad matches: (success, tr[6], inlier indices)"""
         m = np.ascontiguousarray(matches, PMATCH_DTYPE); samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 3)

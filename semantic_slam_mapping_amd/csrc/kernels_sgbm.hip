@@ -1,0 +1,414 @@
+// kernels_sgbm.hip -- depth from stereo for the KITTI path: cv::StereoSGBM as calDisparity_SGBM configures it
+// (/root/reference/src/stereo.cpp:11-30) and the disparity -> depth conversion of FrameReader
+// (/root/reference/src/rgbdframe.cpp:81-116).  SURVEY.md s.8(f) rank 2.  The contract is oracle/sgbm.c (OpenCV 2.4's
+// computeDisparitySGBM in single-pass mode, medianBlur 3, filterSpeckles), all int16 arithmetic, bit-exact.
+//
+// OpenCV walks the image row by row with ring buffers; here every stage is a volume kernel over (y, x, d):
+//   sgbm_prefilter   per pixel of both images: the clipped x-Sobel and the raw intensity, each with the Birchfield-Tomasi
+//                    half-sample interval [v0, v1] (6 byte planes per image)
+//   sgbm_pixcost     BT cost of (y, x, d), gradient plane + raw plane / 4                              -> u8 volume
+//   sgbm_hbox/vbox   the SAD window as a separable box sum with OpenCV's replicate borders (+ P2, + the two 2.4 quirks:
+//                    column 0 keeps row 0's cost, rows past height-1-SH2 keep the last full window)     -> C, u16 volume
+//   sgbm_path<...>   one scan direction r: L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d+-1) + P1, min_k L_r(p-r,k) + P2)
+//                    - min_k L_r(p-r,k).  A PATH (a row for r = (-1,0); a column or diagonal for the three directions that
+//                    come from the previous row) is owned by 16 lanes = one DPP row, each lane K = D/16 consecutive
+//                    disparities: the d+-1 neighbours cross lanes by row_shr/row_shl, min_k by four row_ror steps -- no LDS,
+//                    no barrier in the recurrence.  Paths are independent, so a direction is one launch of (#paths x 16)
+//                    threads that runs its own sequential loop; S += L_r with a saturating add (all terms are >= 0, so
+//                    the progressive saturation equals OpenCV's saturate_cast of the four-term sum).
+//   sgbm_wta         per row, right to left like OpenCV: the fifth direction r = (+1,0) on the fly, S += L, winner, uniqueness
+//                    ratio, the right-image disparity table (disp2), sub-pixel parabola; then the left-right check
+//   sgbm_median3, sgbm_speckle_* (connected components by union-find), sgbm_depth
+// HBM-bound by design (about a GB of volume traffic per 1241x376x80 frame); no MFMA.
+#include "ssm_internal.h"
+#include <climits>
+
+#define SG_MAXC 32767
+#define SG_DISP_SHIFT 4
+#define SG_DISP_SCALE 16
+
+// ------------------------------------------------------------------ pre-filter + BT intervals
+// planes (u8, [h][w]): 0 = value, 1 = min(value, half-sample neighbours), 2 = max(...); gradient planes first, then raw
+__global__ void __launch_bounds__(256)
+sgbm_prefilter(const uint8_t* __restrict__ img, int w, int h, int ftzero, uint8_t* __restrict__ planes)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t np = (size_t)w * h;
+    const uint8_t* row = img + (size_t)y * w;
+    const int n1 = y > 0 ? -w : 0, s1 = y < h - 1 ? w : 0;
+    auto grad = [&](int xx) -> int {            // prow[x]: tab[...] for 1 <= x <= w-2, tab[0] = ftzero at the two border columns
+        if (xx < 1 || xx > w - 2) return ftzero;
+        const int g = (row[xx + 1] - row[xx - 1]) * 2 + row[xx + n1 + 1] - row[xx + n1 - 1] + row[xx + s1 + 1] - row[xx + s1 - 1];
+        return min(max(g, -ftzero), ftzero) + ftzero;
+    };
+    auto raw = [&](int xx) -> int { return (xx < 1 || xx > w - 2) ? ftzero : (int)row[xx]; };     // the border columns of the raw plane hold tab[0] too
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int v = c ? raw(x) : grad(x);
+        const int vl = x > 0 ? (v + (c ? raw(x - 1) : grad(x - 1))) / 2 : v, vr = x < w - 1 ? (v + (c ? raw(x + 1) : grad(x + 1))) / 2 : v;
+        uint8_t* p = planes + (size_t)(3 * c) * np + (size_t)y * w + x;
+        p[0] = (uint8_t)v; p[np] = (uint8_t)min(min(vl, vr), v); p[2 * np] = (uint8_t)max(max(vl, vr), v);
+    }
+}
+// BT cost of left pixel x (image column) against right pixel x - d; thread = (d, x); volume index ((y * w1 + x - minX1) * D + d - minD)
+__global__ void __launch_bounds__(256)
+sgbm_pixcost(const uint8_t* __restrict__ pl1, const uint8_t* __restrict__ pl2, int w, int h, int minD, int D, int minX1, int w1, uint8_t* __restrict__ pix)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= w1 * D) return;
+    const int xi = i / D, d = i - xi * D + minD, x = xi + minX1;
+    const size_t np = (size_t)w * h, o1 = (size_t)y * w + x, o2 = (size_t)y * w + (x - d);
+    int cost = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint8_t *a = pl1 + (size_t)(3 * c) * np + o1, *b = pl2 + (size_t)(3 * c) * np + o2;
+        const int u = a[0], u0 = a[np], u1 = a[2 * np], v = b[0], v0 = b[np], v1 = b[2 * np];
+        const int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
+        cost += min(c0, c1) >> (c ? 2 : 0);
+    }
+    pix[((size_t)y * w1 + xi) * D + (d - minD)] = (uint8_t)cost;
+}
+__global__ void __launch_bounds__(256)
+sgbm_hbox(const uint8_t* __restrict__ pix, int w1, int D, int SW2, uint16_t* __restrict__ hs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= w1 * D) return;
+    const int x = i / D, d = i - x * D;
+    const uint8_t* r = pix + (size_t)y * w1 * D + d;
+    int s = 0;
+    for (int j = -SW2; j <= SW2; j++) s += r[(size_t)min(max(x + j, 0), w1 - 1) * D];
+    hs[(size_t)y * w1 * D + i] = (uint16_t)s;
+}
+__global__ void __launch_bounds__(256)
+sgbm_vbox(const uint16_t* __restrict__ hs, int w1, int h, int D, int SH2, int P2, uint16_t* __restrict__ C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= w1 * D) return;
+    const int x = i / D;
+    const int yy = x == 0 ? 0 : min(y, h - 1 - SH2);          // OpenCV 2.4: column 0 and the bottom rows stop being updated
+    int s = P2;
+    for (int k = -SH2; k <= SH2; k++) s += hs[(size_t)min(max(yy + k, 0), h - 1) * w1 * D + i];
+    C[(size_t)y * w1 * D + i] = (uint16_t)s;
+}
+
+// ------------------------------------------------------------------ one aggregation step on a 16-lane row (K disparities per lane)
+template <int CTRL>
+__device__ __forceinline__ int sg_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int sg_rowmin(int v)
+{
+    v = min(v, sg_dpp<0x128>(v, v));      // row_ror:8
+    v = min(v, sg_dpp<0x124>(v, v));      // row_ror:4
+    v = min(v, sg_dpp<0x122>(v, v));      // row_ror:2
+    v = min(v, sg_dpp<0x121>(v, v));      // row_ror:1
+    return v;
+}
+template <int K>
+__device__ __forceinline__ void sg_step(int (&L)[K], int& minPrev, const int (&Cp)[K], int P1, int P2)
+{
+    const int left = sg_dpp<0x111>(SG_MAXC, L[K - 1]);        // row_shr:1 -- L(d-1) of the lane's first disparity; d = -1 is MAX_COST
+    const int right = sg_dpp<0x101>(SG_MAXC, L[0]);           // row_shl:1 -- L(d+1) of the lane's last disparity;  d = D  is MAX_COST
+    const int delta = minPrev + P2;
+    int Ln[K], m = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int lm = k > 0 ? L[k - 1] : left, lp = k < K - 1 ? L[k + 1] : right;
+        Ln[k] = Cp[k] + min(L[k], min(lm + P1, min(lp + P1, delta))) - delta;
+        m = min(m, Ln[k]);
+    }
+    minPrev = sg_rowmin(m);
+#pragma unroll
+    for (int k = 0; k < K; k++) L[k] = Ln[k];
+}
+// MODE 0: r = (-1, 0): path = row y, steps x = 0..w1-1, S = L (first direction written)
+// MODE 1..3: r = (-1,-1), (0,-1), (+1,-1): path = diagonal / column, steps y = 0..h-1, S = sat(S + L)
+template <int K, int MODE>
+__global__ void __launch_bounds__(256)
+sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w1, int h, int P1, int P2)
+{
+    constexpr int D = 16 * K;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
+    const int npaths = MODE == 0 ? h : (MODE == 2 ? w1 : w1 + h - 1);
+    const bool live = g < npaths;                             // dead groups run the loop too (DPP wants the whole wave), clamped to path 0
+    const int gp = live ? g : 0;
+    const int rx = MODE == 1 ? 1 : MODE == 3 ? -1 : 0;        // x(y) = o + rx * y
+    const int o = MODE == 1 ? gp - (h - 1) : gp;
+    int L[K], minPrev = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) L[k] = 0;
+    const int steps = MODE == 0 ? w1 : h;
+    for (int t = 0; t < steps; t++) {
+        const int y = MODE == 0 ? gp : t, x = MODE == 0 ? t : o + rx * t;
+        const bool in = x >= 0 && x < w1;
+        if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
+#pragma unroll
+            for (int k = 0; k < K; k++) L[k] = 0;
+            minPrev = 0;
+        }
+        const size_t base = ((size_t)y * w1 + (in ? x : 0)) * D + li * K;
+        int Cp[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) Cp[k] = C[base + k];
+        int Lc[K], mp = minPrev;
+#pragma unroll
+        for (int k = 0; k < K; k++) Lc[k] = L[k];
+        sg_step<K>(Lc, mp, Cp, P1, P2);
+        if (in) {
+#pragma unroll
+            for (int k = 0; k < K; k++) L[k] = Lc[k];
+            minPrev = mp;
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (MODE == 0) S[base + k] = (uint16_t)Lc[k];
+                    else S[base + k] = (uint16_t)min((int)S[base + k] + Lc[k], SG_MAXC);
+                }
+            }
+        }
+    }
+}
+// ------------------------------------------------------------------ winner-takes-all per row (16 lanes per row), then the left-right check
+// block = one wave = 4 rows; the three per-row tables (disp1, disp2, disp2cost) live in LDS while the row is being decided
+template <int K>
+__global__ void __launch_bounds__(64)
+sgbm_wta(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w, int w1, int h, int minD, int minX1, int P1, int P2,
+         int uniquenessRatio, int disp12MaxDiff, int16_t* __restrict__ disp1)
+{
+    constexpr int D = 16 * K;
+    extern __shared__ int16_t sg_rows[];                      // [4 rows][3 tables][w]
+    __shared__ uint16_t srow[4][D];                           // S of the current pixel, for the three sub-pixel taps
+    const int gl = threadIdx.x >> 4, li = threadIdx.x & 15, g = blockIdx.x * 4 + gl;
+    const bool live = g < h;
+    const int y = live ? g : 0;
+    const int INVALID = (minD - 1) * SG_DISP_SCALE;
+    int16_t *d1 = sg_rows + (size_t)gl * 3 * w, *d2 = d1 + w, *d2c = d2 + w;
+    for (int x = li; x < w; x += 16) { d1[x] = (int16_t)INVALID; d2[x] = (int16_t)INVALID; d2c[x] = (int16_t)SG_MAXC; }
+    int L[K], minPrev = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) L[k] = 0;
+    for (int x = w1 - 1; x >= 0; x--) {
+        const size_t base = ((size_t)y * w1 + x) * D + li * K;
+        int Cp[K], Sv[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { Cp[k] = C[base + k]; Sv[k] = S[base + k]; }
+        sg_step<K>(L, minPrev, Cp, P1, P2);                    // r = (+1, 0): the predecessor is the pixel to the right
+        int best = INT_MAX;                                    // (S << 8 | d): smallest S, then smallest d ("Sval < minS" scanning d upwards)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            Sv[k] = min(Sv[k] + L[k], SG_MAXC);
+            best = min(best, (Sv[k] << 8) | (li * K + k));
+            srow[gl][li * K + k] = (uint16_t)Sv[k];
+        }
+        best = sg_rowmin(best);
+        const int minS = best >> 8, bestDisp = best & 255;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
+        const unsigned long long bal = __ballot(bad);
+        const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;       // any lane of my 16-lane row
+        if (!rejected && li == 0) {
+            int d = bestDisp;
+            const int x2 = x + minX1 - d - minD;
+            if (d2c[x2] > minS) { d2c[x2] = (int16_t)minS; d2[x2] = (int16_t)(d + minD); }
+            if (0 < d && d < D - 1) {
+                const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
+                const int denom2 = max(sm + sp - 2 * s0, 1);
+                d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+            } else d *= SG_DISP_SCALE;
+            d1[x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+        }
+    }
+    __syncthreads();
+    // left-right check: the disparity rounded down and up must both disagree with the right-image table to be dropped
+    const int maxX1 = minX1 + w1;
+    for (int x = li; x < w; x += 16) {
+        int v = d1[x];
+        if (x >= minX1 && x < maxX1 && v != INVALID) {
+            const int _d = v >> SG_DISP_SHIFT, d_ = (v + SG_DISP_SCALE - 1) >> SG_DISP_SHIFT;
+            const int _x = x - _d, x_ = x - d_;
+            if (0 <= _x && _x < w && d2[_x] >= minD && abs(d2[_x] - _d) > disp12MaxDiff &&
+                0 <= x_ && x_ < w && d2[x_] >= minD && abs(d2[x_] - d_) > disp12MaxDiff)
+                v = INVALID;
+        }
+        if (live) disp1[(size_t)y * w + x] = (int16_t)v;
+    }
+}
+// ------------------------------------------------------------------ cv::medianBlur 3x3 (int16, replicate border)
+__global__ void __launch_bounds__(256)
+sgbm_median3(const int16_t* __restrict__ src, int w, int h, int16_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    int v[9];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) v[(dy + 1) * 3 + dx + 1] = src[(size_t)min(max(y + dy, 0), h - 1) * w + min(max(x + dx, 0), w - 1)];
+#define SG_CE(a, b) { const int lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+    SG_CE(1, 2) SG_CE(4, 5) SG_CE(7, 8) SG_CE(0, 1) SG_CE(3, 4) SG_CE(6, 7) SG_CE(1, 2) SG_CE(4, 5) SG_CE(7, 8)
+    SG_CE(0, 3) SG_CE(5, 8) SG_CE(4, 7) SG_CE(3, 6) SG_CE(1, 4) SG_CE(2, 5) SG_CE(4, 7) SG_CE(4, 2) SG_CE(6, 4) SG_CE(4, 2)
+#undef SG_CE
+    dst[(size_t)y * w + x] = (int16_t)v[4];
+}
+// ------------------------------------------------------------------ cv::filterSpeckles by union-find
+// components: 4-neighbours, both != newVal, |difference| <= maxDiff.  label = smallest pixel index of the component.
+__device__ __forceinline__ int uf_find(int* parent, int i)
+{
+    int p = __atomic_load_n(&parent[i], __ATOMIC_RELAXED);
+    while (p != i) { i = p; p = __atomic_load_n(&parent[i], __ATOMIC_RELAXED); }
+    return i;
+}
+__device__ __forceinline__ void uf_union(int* parent, int a, int b)
+{
+    while (true) {
+        a = uf_find(parent, a); b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }         // hook the larger root under the smaller, only while it still is a root
+        if (atomicCAS(&parent[a], a, b) == a) return;          // (otherwise somebody hooked a first: find again and retry)
+    }
+}
+__global__ void __launch_bounds__(256)
+sgbm_speckle_init(int n, int* __restrict__ parent, int* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { parent[i] = i; count[i] = 0; }
+}
+__global__ void __launch_bounds__(256)
+sgbm_speckle_link(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* __restrict__ parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const int v = img[i];
+    if (v == newVal) return;
+    const int x = i % w, y = i / w;
+    if (x < w - 1) { const int r = img[i + 1]; if (r != newVal && abs(v - r) <= maxDiff) uf_union(parent, i, i + 1); }
+    if (y < h - 1) { const int b = img[i + w]; if (b != newVal && abs(v - b) <= maxDiff) uf_union(parent, i, i + w); }
+}
+__global__ void __launch_bounds__(256)
+sgbm_speckle_count(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ parent, int* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || img[i] == newVal) return;
+    const int r = uf_find(parent, i);
+    parent[i] = r;
+    atomicAdd(&count[r], 1);
+}
+__global__ void __launch_bounds__(256)
+sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleSize, const int* __restrict__ parent, const int* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || img[i] == newVal) return;
+    if (count[parent[i]] <= maxSpeckleSize) img[i] = (int16_t)newVal;
+}
+// ------------------------------------------------------------------ disparity -> depth (rgbdframe.cpp:81-116)
+__global__ void __launch_bounds__(256)
+sgbm_min_kernel(const int16_t* __restrict__ disp, int n, int* __restrict__ out)
+{
+    int m = INT_MAX;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = min(m, (int)disp[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+}
+__global__ void __launch_bounds__(256)
+sgbm_depth(const int16_t* __restrict__ disp, int w, int h, const int* __restrict__ min_disp, double baseline, double cu, double cv, double f,
+           double roix, double roiy, double roiz, double scale, uint16_t* __restrict__ depth)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+    if (u >= w) return;
+    const int d = disp[(size_t)v * w + u];
+    uint16_t out = 0;
+    if (d != 0 && d != *min_disp) {                           // |d| > FLT_EPSILON and |d - min| > FLT_EPSILON on integers
+        const double pw = baseline / (1.0 * (double)d);
+        const double px = (((double)u - cu) * pw) * 16.0, py = (((double)v - cv) * pw) * 16.0, pz = (f * pw) * 16.0;
+        if (fabs(px) < roix && fabs(py) < roiy && fabs(pz) < roiz && pz > 0) out = (uint16_t)(pz * scale);
+    }
+    depth[(size_t)v * w + u] = out;
+}
+
+__global__ void __launch_bounds__(256)
+sgbm_fill(int16_t* __restrict__ p, int n, int16_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+// ------------------------------------------------------------------ launcher
+template <int K>
+static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* S, int w, int w1, int h, const ssm_sgbm_params& p, int minX1, int P1, int P2,
+                                 int16_t* disp1, hipStream_t s)
+{
+    auto blocks = [](int paths) { return (paths * 16 + 255) / 256; };
+    sgbm_path<K, 0><<<blocks(h), 256, 0, s>>>(C, S, w1, h, P1, P2);
+    sgbm_path<K, 1><<<blocks(w1 + h - 1), 256, 0, s>>>(C, S, w1, h, P1, P2);
+    sgbm_path<K, 2><<<blocks(w1), 256, 0, s>>>(C, S, w1, h, P1, P2);
+    sgbm_path<K, 3><<<blocks(w1 + h - 1), 256, 0, s>>>(C, S, w1, h, P1, P2);
+    sgbm_wta<K><<<(h + 3) / 4, 64, (size_t)4 * 3 * w * sizeof(int16_t), s>>>(C, S, w, w1, h, p.minDisparity, minX1, P1, P2, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10,
+                                                                              p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
+    return hipGetLastError();
+}
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p)
+{
+    const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
+    const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities, np = (size_t)w * h;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(12 * np) + al(vol) + 3 * al(vol * 2) + al(np * 2) + 2 * al(np * 4) + 256;
+}
+// left / right: device u8 images [h][w]; disp_out: device int16 [h][w] (x16 fixed point, (minD-1)*16 = invalid)
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
+{
+    const int minD = p.minDisparity, D = p.numberOfDisparities, maxD = minD + D;
+    const int SW = p.SADWindowSize > 0 ? p.SADWindowSize : 5, SW2 = SW / 2;
+    const int ftzero = (p.preFilterCap > 15 ? p.preFilterCap : 15) | 1;
+    const int P1 = p.P1 > 0 ? p.P1 : 2, P2 = (p.P2 > 0 ? p.P2 : 5) > P1 + 1 ? (p.P2 > 0 ? p.P2 : 5) : P1 + 1;
+    const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0), w1 = maxX1 - minX1;
+    const int INVALID = (minD - 1) * SG_DISP_SCALE;
+    const size_t np = (size_t)w * h;
+    if (w1 <= 0) {                                            // no valid column: everything invalid (OpenCV's early return)
+        sgbm_fill<<<(int)((np + 255) / 256), 256, 0, s>>>(disp_out, (int)np, (int16_t)INVALID);
+        return hipGetLastError();
+    }
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    uint8_t* q = (uint8_t*)workspace;
+    uint8_t* pl1 = q; uint8_t* pl2 = q + 6 * np; q += al(12 * np);
+    const size_t vol = (size_t)w1 * h * D;
+    uint8_t* pix = q; q += al(vol);
+    uint16_t* hs = (uint16_t*)q; q += al(vol * 2);
+    uint16_t* C = (uint16_t*)q; q += al(vol * 2);
+    uint16_t* S = (uint16_t*)q; q += al(vol * 2);
+    int16_t* d_raw = (int16_t*)q; q += al(np * 2);
+    int* parent = (int*)q; q += al(np * 4);
+    int* count = (int*)q; q += al(np * 4);
+    const dim3 gimg((w + 255) / 256, h), gvol((w1 * D + 255) / 256, h);
+    sgbm_prefilter<<<gimg, 256, 0, s>>>(left, w, h, ftzero, pl1);
+    sgbm_prefilter<<<gimg, 256, 0, s>>>(right, w, h, ftzero, pl2);
+    sgbm_pixcost<<<gvol, 256, 0, s>>>(pl1, pl2, w, h, minD, D, minX1, w1, pix);
+    sgbm_hbox<<<gvol, 256, 0, s>>>(pix, w1, D, SW2, hs);
+    sgbm_vbox<<<gvol, 256, 0, s>>>(hs, w1, h, D, SW2, P2, C);
+    int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
+    hipError_t e;
+    switch (D / 16) {
+        case 1: e = sgbm_aggregate<1>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 2: e = sgbm_aggregate<2>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 3: e = sgbm_aggregate<3>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 4: e = sgbm_aggregate<4>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 5: e = sgbm_aggregate<5>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 6: e = sgbm_aggregate<6>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 8: e = sgbm_aggregate<8>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess || raw_only == 1) return e;
+    sgbm_median3<<<gimg, 256, 0, s>>>(d_raw, w, h, disp_out);
+    if (p.speckleWindowSize > 0 && raw_only != 2) {
+        const int n = (int)np, nb = (n + 255) / 256;
+        sgbm_speckle_init<<<nb, 256, 0, s>>>(n, parent, count);
+        sgbm_speckle_link<<<nb, 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
+        sgbm_speckle_count<<<nb, 256, 0, s>>>(disp_out, n, INVALID, parent, count);
+        sgbm_speckle_apply<<<nb, 256, 0, s>>>(disp_out, n, INVALID, p.speckleWindowSize, parent, count);
+    }
+    return hipGetLastError();
+}
+hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+                        int* min_scratch, uint16_t* depth, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(min_scratch, 0x7F, 4, s);         // 0x7F7F7F7F: above any int16
+    if (e != hipSuccess) return e;
+    sgbm_min_kernel<<<64, 256, 0, s>>>(disp, w * h, min_scratch);
+    sgbm_depth<<<dim3((w + 255) / 256, h), 256, 0, s>>>(disp, w, h, min_scratch, baseline, cu, cv, f, roix, roiy, roiz, scale, depth);
+    return hipGetLastError();
+}

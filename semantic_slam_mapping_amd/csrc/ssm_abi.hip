@@ -1133,6 +1133,63 @@ extern "C" int ssm_window_match(ssm_ctx* c, const float* kp1, const uint8_t* d1,
     return SSM_OK;
 }
 
+// ---------------------------------------------------------------- depth from stereo (cv::StereoSGBM + FrameReader's conversion)
+extern "C" void ssm_sgbm_params_default(ssm_sgbm_params* p)
+{
+    if (!p) return;
+    p->minDisparity = 0; p->numberOfDisparities = 80; p->SADWindowSize = 11; p->P1 = 4 * 11 * 11; p->P2 = 32 * 11 * 11;       // src/stereo.cpp:16-27
+    p->disp12MaxDiff = 1; p->preFilterCap = 63; p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32;
+}
+static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage,
+                    int16_t** d_disp_out, uint8_t** d_tail_out)
+{
+    if (!left || !right || !params || w < 3 || h < 1 || stride < w) FAIL(c, SSM_E_INVAL, "bad arguments");
+    const int D = params->numberOfDisparities, SW = params->SADWindowSize > 0 ? params->SADWindowSize : 5;
+    if (D <= 0 || D % 16 || D > 128 || D / 16 == 7) FAIL(c, SSM_E_INVAL, "numberOfDisparities must be 16, 32, 48, 64, 80, 96 or 128");
+    if (!(SW & 1) || h <= SW || w <= SW) FAIL(c, SSM_E_INVAL, "SADWindowSize must be odd and smaller than the image");
+    if ((long long)w * h >= (1ll << 30)) FAIL(c, SSM_E_INVAL, "image too large");
+    const size_t np = (size_t)w * h, ws = k_sgbm_workspace_bytes(w, h, *params);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    int r = ensure_scratch(c, al(np) * 2 + al(np * 2) * 2 + 256 + ws); if (r) return r;
+    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
+    uint8_t* dl = p; p += al(np); uint8_t* dr = p; p += al(np);
+    int16_t* dd = (int16_t*)p; p += al(np * 2);
+    uint8_t* tail = p; p += al(np * 2) + 256;                  // depth image + the min-disparity word, for ssm_stereo_depth
+    HIPCHK(c, hipMemcpy2DAsync(dl, w, left, stride, w, h, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpy2DAsync(dr, w, right, stride, w, h, hipMemcpyHostToDevice, s));
+    HIPCHK(c, k_sgbm(dl, dr, w, h, *params, p, dd, stage, s));
+    *d_disp_out = dd; *d_tail_out = tail;
+    return SSM_OK;
+}
+extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
+    int16_t* dd; uint8_t* tail;
+    int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &tail); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(disp, dd, (size_t)w * h * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
+                                double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+                                uint16_t* depth, int16_t* disp)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!depth) FAIL(c, SSM_E_INVAL, "null argument");
+    int16_t* dd; uint8_t* tail;
+    int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &tail); if (r) return r;
+    const size_t np = (size_t)w * h;
+    uint16_t* ddepth = (uint16_t*)tail; int* dmin = (int*)(tail + ((np * 2 + 255) & ~(size_t)255));
+    HIPCHK(c, k_sgbm_depth(dd, w, h, baseline, cu, cv, f, roix, roiy, roiz, scale, dmin, ddepth, c->stream));
+    HIPCHK(c, hipMemcpyAsync(depth, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
+    if (disp) HIPCHK(c, hipMemcpyAsync(disp, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+
 // ---------------------------------------------------------------- VisualOdometryStereo::estimateMotion
 extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
                                double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success)

@@ -91,6 +91,10 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
                          const int32_t* yofs, const int16_t* ya, void* out_f16, hipStream_t s);
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s);
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p);
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s);
+hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+                        int* min_scratch, uint16_t* depth, hipStream_t s);
 hipError_t k_vo_estimate(const ssm_pmatch* m, int n, const ssm_vo_params& P, const int32_t* samples, int iters,
                          double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s);
 hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* scale, const float* shift, uint8_t* labels, int n, int H, int W,

@@ -63,6 +63,9 @@ class Oracle:
         L.sso_solve6_lu.argtypes = [P, P]
         L.sso_vo_estimate.argtypes = [P, I, P, P, I, P, P, C.POINTER(I)]
         L.sso_vo_tr_to_matrix.argtypes = [P, P]
+        L.sso_sgbm_raw.argtypes = [P, P, I, I, P, P]; L.sso_sgbm.argtypes = [P, P, I, I, P, P]
+        L.sso_median3_s16.argtypes = [P, I, I, P]; L.sso_filter_speckles.argtypes = [P, I, I, I, I, I]
+        L.sso_disparity_to_depth.argtypes = [P, I, I] + [C.c_double] * 8 + [P]
         L.sso_hamming_knn2.argtypes = [P, I, P, I, P, P]
         L.sso_match.argtypes = [P, I, P, I, C.c_double, P]
         L.sso_project2dTo3d.argtypes = [P, I, I, C.POINTER(Cam), I, I, P]
@@ -271,6 +274,32 @@ class Oracle:
         out = np.zeros(max(len(ks[0]), 1), PMATCH_DTYPE)
         n = self.L.sso_quad_chain(*[x.ctypes.data for x in ks], len(ks[0]), *[x.ctypes.data for x in ms], out.ctypes.data)
         return out[:n].copy()
+
+    # ---- depth from stereo (oracle/sgbm.c)
+    @staticmethod
+    def sgbm_params(num_disp=80, sad=11, min_disp=0, uniqueness=10, speckle_window=100, speckle_range=32, disp12=1, prefilter_cap=63, p1=None, p2=None):
+        p1 = 4 * sad * sad if p1 is None else p1; p2 = 32 * sad * sad if p2 is None else p2        # src/stereo.cpp:22-23
+        return np.array([min_disp, num_disp, sad, p1, p2, disp12, prefilter_cap, uniqueness, speckle_window, speckle_range], np.int32)
+
+    def sgbm(self, left, right, params, raw=False):
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8); h, w = left.shape
+        disp = np.zeros((h, w), np.int16)
+        rc = (self.L.sso_sgbm_raw if raw else self.L.sso_sgbm)(left.ctypes.data, right.ctypes.data, w, h, params.ctypes.data, disp.ctypes.data)
+        if rc:
+            raise ValueError(f"sso_sgbm: {rc}")
+        return disp
+
+    def median3_s16(self, img):
+        img = np.ascontiguousarray(img, np.int16); out = np.zeros_like(img)
+        self.L.sso_median3_s16(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data); return out
+
+    def filter_speckles(self, img, new_val, max_size, max_diff):
+        img = np.ascontiguousarray(img, np.int16).copy()
+        self.L.sso_filter_speckles(img.ctypes.data, img.shape[1], img.shape[0], new_val, max_size, max_diff); return img
+
+    def disparity_to_depth(self, disp, baseline, cu, cv, f, roix, roiy, roiz, scale):
+        disp = np.ascontiguousarray(disp, np.int16); h, w = disp.shape; out = np.zeros((h, w), np.uint16)
+        self.L.sso_disparity_to_depth(disp.ctypes.data, w, h, baseline, cu, cv, f, roix, roiy, roiz, scale, out.ctypes.data); return out
 
     # ---- stereo visual odometry (oracle/vo.c)
     def rand_state(self, seed):

@@ -1,0 +1,108 @@
+"""Depth from stereo (oracle/sgbm.c, kernels_sgbm.hip): cv::StereoSGBM as /root/reference/src/stereo.cpp:11-30 configures it +
+FrameReader's disparity -> depth conversion (/root/reference/src/rgbdframe.cpp:81-116).  CPU: properties of the oracle on
+synthetic rectified pairs with known disparity.  GPU: every stage against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+KITTI = dict(baseline=0.532331858, cu=607.1928, cv=185.2157, f=718.856, roix=20.0, roiy=5.0, roiz=40.0, scale=1000.0)   # parameters.txt:37-63
+
+
+def stereo_pair(h, w, seed, planes=((20, None), (45, (0.3, 0.75, 0.3, 0.7))), noise=0):
+    """textured right image; the left image shows the same texture shifted by the disparity of fronto-parallel planes"""
+    rng = np.random.default_rng(seed)
+    tex = rng.integers(0, 256, (h, w + 160)).astype(np.float32)
+    k = np.array([1, 4, 6, 4, 1], np.float32); k /= k.sum()
+    for ax in (0, 1):
+        tex = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), ax, tex)
+    tex = ((tex - tex.min()) / (tex.max() - tex.min()) * 255).astype(np.uint8)
+    dmap = np.zeros((h, w), np.int32)
+    for d, box in planes:
+        if box is None:
+            dmap[:] = d
+        else:
+            y0, y1, x0, x1 = int(box[0] * h), int(box[1] * h), int(box[2] * w), int(box[3] * w)
+            dmap[y0:y1, x0:x1] = d
+    right = tex[:, 80:80 + w].copy()
+    xs = np.arange(w)[None, :] - dmap + 80
+    left = np.take_along_axis(tex, xs, axis=1)
+    if noise:
+        left = np.clip(left.astype(np.int32) + rng.integers(-noise, noise + 1, left.shape), 0, 255).astype(np.uint8)
+    return left, right, dmap
+
+
+def test_oracle_recovers_plane_disparities(oracle):
+    left, right, dmap = stereo_pair(96, 320, 0)
+    d = oracle.sgbm(left, right, oracle.sgbm_params())
+    assert d.dtype == np.int16 and (d[:, :80] == -16).all()                     # columns < numberOfDisparities are never matched
+    bg = d[5:25, 120:300]; fg = d[35:65, 130:210]
+    assert np.median(bg) == 20 * 16 and np.median(fg) == 45 * 16
+    assert (np.abs(bg[bg != -16] - 320) <= 8).mean() > 0.99
+    raw = oracle.sgbm(left, right, oracle.sgbm_params(), raw=True)
+    assert np.array_equal(oracle.filter_speckles(oracle.median3_s16(raw), -16, 100, 512), d)
+    # too few columns for any disparity: everything invalid
+    assert (oracle.sgbm(left[:, :60], right[:, :60], oracle.sgbm_params()) == -16).all()
+    with pytest.raises(ValueError):
+        oracle.sgbm(left, right, oracle.sgbm_params(num_disp=40))                # not a multiple of 16
+
+
+def test_oracle_speckle_and_median(oracle):
+    img = np.full((40, 50), -16, np.int16)
+    img[5:8, 5:8] = 300                      # 9-pixel blob: removed at maxSpeckleSize 10
+    img[20:30, 10:40] = 500                  # 300-pixel region: kept
+    img[22, 12] = 500 + 600                  # differs by more than maxDiff from its neighbours: a 1-pixel component
+    out = oracle.filter_speckles(img, -16, 10, 512)
+    assert (out[5:8, 5:8] == -16).all() and out[22, 12] == -16 and (out[20:30, 10:40] == 500).sum() == 299
+    r = np.random.default_rng(1).integers(-16, 1000, (17, 23)).astype(np.int16)
+    m = oracle.median3_s16(r)
+    p = np.pad(r, 1, mode="edge")
+    ref = np.median(np.stack([p[i:i + 17, j:j + 23] for i in range(3) for j in range(3)]), axis=0).astype(np.int16)
+    assert np.array_equal(m, ref)
+
+
+def test_oracle_depth_conversion(oracle):
+    disp = np.full((20, 40), -16, np.int16)
+    disp[5, 10] = 320; disp[6, 11] = 0; disp[7, 12] = 16 * 2                     # 20 px -> 19.1 m; zero; 2 px -> 191 m (outside roiz)
+    depth = oracle.disparity_to_depth(disp, **KITTI)
+    z = KITTI["f"] * KITTI["baseline"] / 320.0 * 16.0
+    assert depth[5, 10] == int(z * 1000.0) and depth[6, 11] == 0 and depth[7, 12] == 0
+    assert (depth[disp == -16] == 0).all()                                        # the minimum value of the image is "no measurement"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,num_disp,sad,seed,noise", [(96, 320, 80, 11, 0, 0), (64, 200, 64, 5, 1, 6), (50, 150, 32, 3, 2, 0),
+                                                          (120, 400, 80, 11, 3, 10), (37, 181, 48, 7, 4, 3), (30, 140, 128, 9, 5, 2)])
+def test_gpu_sgbm_bit_exact(ctx, oracle, h, w, num_disp, sad, seed, noise):
+    left, right, _ = stereo_pair(h, w, seed, planes=((num_disp // 4, None), (num_disp // 2 + 3, (0.3, 0.75, 0.3, 0.7))), noise=noise)
+    po = oracle.sgbm_params(num_disp=num_disp, sad=sad)
+    pg = ctx.sgbm_params(numberOfDisparities=num_disp, SADWindowSize=sad)
+    assert np.array_equal(po, pg)
+    raw_o = oracle.sgbm(left, right, po, raw=True); raw_g = ctx.sgbm(left, right, pg, raw=True)
+    assert np.array_equal(raw_g, raw_o), f"{(raw_g != raw_o).sum()} of {raw_o.size} raw disparities differ"
+    assert np.array_equal(ctx.sgbm(left, right, pg), oracle.sgbm(left, right, po))
+    assert (raw_o != (-16)).any()
+
+
+@pytest.mark.gpu
+def test_gpu_sgbm_options_and_depth(ctx, oracle):
+    left, right, _ = stereo_pair(80, 300, 7, noise=4)
+    for kw_o, kw_g in ((dict(uniqueness=0, disp12=2), dict(uniquenessRatio=0, disp12MaxDiff=2)),
+                       (dict(speckle_window=0), dict(speckleWindowSize=0)),
+                       (dict(prefilter_cap=10, p1=50, p2=800, speckle_window=30, speckle_range=2), dict(preFilterCap=10, P1=50, P2=800, speckleWindowSize=30, speckleRange=2))):
+        assert np.array_equal(ctx.sgbm(left, right, ctx.sgbm_params(**kw_g)), oracle.sgbm(left, right, oracle.sgbm_params(**kw_o)))
+    depth, disp = ctx.stereo_depth(left, right, **KITTI)
+    ref_disp = oracle.sgbm(left, right, oracle.sgbm_params())
+    assert np.array_equal(disp, ref_disp)
+    assert np.array_equal(depth, oracle.disparity_to_depth(ref_disp, **KITTI))
+    assert (depth > 0).sum() > 1000
+    from semantic_slam_mapping_amd.api import SsmError
+    with pytest.raises(SsmError):
+        ctx.sgbm(left, right, ctx.sgbm_params(numberOfDisparities=40))
+    assert (ctx.sgbm(left[:, :70], right[:, :70]) == -16).all()                  # fewer columns than disparities
+
+
+@pytest.mark.gpu
+def test_gpu_sgbm_kitti_size(ctx, oracle):
+    """configs[3] geometry: 1241 x 376, 80 disparities"""
+    left, right, _ = stereo_pair(376, 1241, 11, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), noise=5)
+    g = ctx.sgbm(left, right)
+    assert np.array_equal(g, oracle.sgbm(left, right, oracle.sgbm_params()))
