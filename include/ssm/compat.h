@@ -18,11 +18,12 @@
 namespace cv {
 typedef unsigned char uchar;
 typedef unsigned short ushort;
-enum { CV_8U = 0, CV_16U = 2, CV_32F = 5, CV_64F = 6 };
+enum { CV_8U = 0, CV_16U = 2, CV_16S = 3, CV_32F = 5, CV_64F = 6 };
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
 #define CV_8UC1 CV_MAKETYPE(cv::CV_8U, 1)
 #define CV_8UC3 CV_MAKETYPE(cv::CV_8U, 3)
 #define CV_16UC1 CV_MAKETYPE(cv::CV_16U, 1)
+#define CV_16SC1 CV_MAKETYPE(cv::CV_16S, 1)
 #define CV_32FC1 CV_MAKETYPE(cv::CV_32F, 1)
 #define CV_64F cv::CV_64F
 struct Size { int width = 0, height = 0; Size() {} Size(int w, int h) : width(w), height(h) {} };

@@ -254,9 +254,16 @@ sgbm_median3(const int16_t* __restrict__ src, int w, int h, int16_t* __restrict_
 // components: 4-neighbours, both != newVal, |difference| <= maxDiff.  label = smallest pixel index of the component.
 __device__ __forceinline__ int uf_find(int* parent, int i)
 {
-    int p = __atomic_load_n(&parent[i], __ATOMIC_RELAXED);
-    while (p != i) { i = p; p = __atomic_load_n(&parent[i], __ATOMIC_RELAXED); }
-    return i;
+    // parents always point to a smaller index (roots are hooked under smaller roots) and only ever decrease, so pointing a
+    // traversed node at the root found -- with atomicMin, never a plain store -- keeps every entry an ancestor of its node
+    int root = i;
+    while (true) { const int p = __atomic_load_n(&parent[root], __ATOMIC_RELAXED); if (p == root) break; root = p; }
+    while (i > root) {                                        // (a concurrent compression may already point past `root`: indices only fall)
+        const int p = __atomic_load_n(&parent[i], __ATOMIC_RELAXED);
+        if (p > root) atomicMin(&parent[i], root);
+        i = p;
+    }
+    return root;
 }
 __device__ __forceinline__ void uf_union(int* parent, int a, int b)
 {
@@ -288,10 +295,18 @@ __global__ void __launch_bounds__(256)
 sgbm_speckle_count(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ parent, int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || img[i] == newVal) return;
-    const int r = uf_find(parent, i);
-    parent[i] = r;
-    atomicAdd(&count[r], 1);
+    const bool on = i < n && img[i] != newVal;
+    int r = -1;
+    if (on) { r = uf_find(parent, i); parent[i] = r; }
+    // neighbouring pixels mostly share a root: one atomic per distinct root of the wave, not per pixel
+    unsigned long long todo = __ballot(on);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lr = __shfl(r, leader, 64);
+        const unsigned long long same = __ballot(on && r == lr) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&count[lr], __popcll(same));
+        todo &= ~same;
+    }
 }
 __global__ void __launch_bounds__(256)
 sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleSize, const int* __restrict__ parent, const int* __restrict__ count)

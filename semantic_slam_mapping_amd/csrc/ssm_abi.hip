@@ -97,6 +97,7 @@ struct ssm_ctx {
     struct QuadState* quad = nullptr;
     // profiling
     bool profiling = false;
+    uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
     bool serialize = false;             // profiling mode 2: keep the side work of ssm_seq_process on the context stream (clean per-stage times)
     std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::vector<std::string> stage_names; std::vector<float> stage_ms; std::vector<int> stage_launches;
@@ -197,6 +198,14 @@ static int ensure_scratch(ssm_ctx* c, size_t bytes)
     if (c->d_scratch) { hipStreamSynchronize(c->stream); hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
     uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
     c->d_scratch = p; c->scratch_bytes = bytes; return SSM_OK;
+}
+static int ensure_pinned(ssm_ctx* c, size_t bytes)
+{
+    if (bytes <= c->pinned_bytes) return SSM_OK;
+    if (c->h_pinned) { hipStreamSynchronize(c->stream); hipHostFree(c->h_pinned); c->h_pinned = nullptr; c->pinned_bytes = 0; }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return SSM_E_HIP; }
+    c->h_pinned = (uint8_t*)p; c->pinned_bytes = bytes; return SSM_OK;
 }
 static int ensure_scratch2(ssm_ctx* c, size_t bytes)
 {
@@ -320,6 +329,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->quad) { quad_free(c->quad); delete c->quad; }
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -1155,8 +1165,11 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     uint8_t* dl = p; p += al(np); uint8_t* dr = p; p += al(np);
     int16_t* dd = (int16_t*)p; p += al(np * 2);
     uint8_t* tail = p; p += al(np * 2) + 256;                  // depth image + the min-disparity word, for ssm_stereo_depth
-    HIPCHK(c, hipMemcpy2DAsync(dl, w, left, stride, w, h, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpy2DAsync(dr, w, right, stride, w, h, hipMemcpyHostToDevice, s));
+    r = ensure_pinned(c, np * 6); if (r) return r;               // 2 images in; disparity + depth out
+    HIPCHK(c, hipStreamSynchronize(s));                           // the staging buffer may still be in flight from the previous call
+    for (int y = 0; y < h; y++) { memcpy(c->h_pinned + (size_t)y * w, left + (size_t)y * stride, w); memcpy(c->h_pinned + np + (size_t)y * w, right + (size_t)y * stride, w); }
+    HIPCHK(c, hipMemcpyAsync(dl, c->h_pinned, np, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dr, c->h_pinned + np, np, hipMemcpyHostToDevice, s));
     HIPCHK(c, k_sgbm(dl, dr, w, h, *params, p, dd, stage, s));
     *d_disp_out = dd; *d_tail_out = tail;
     return SSM_OK;
@@ -1168,8 +1181,10 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
     int16_t* dd; uint8_t* tail;
     int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &tail); if (r) return r;
-    HIPCHK(c, hipMemcpyAsync(disp, dd, (size_t)w * h * 2, hipMemcpyDeviceToHost, c->stream));
+    const size_t np = (size_t)w * h;
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(disp, c->h_pinned + 2 * np, np * 2);
     return SSM_OK;
 }
 extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
@@ -1184,9 +1199,11 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     const size_t np = (size_t)w * h;
     uint16_t* ddepth = (uint16_t*)tail; int* dmin = (int*)(tail + ((np * 2 + 255) & ~(size_t)255));
     HIPCHK(c, k_sgbm_depth(dd, w, h, baseline, cu, cv, f, roix, roiy, roiz, scale, dmin, ddepth, c->stream));
-    HIPCHK(c, hipMemcpyAsync(depth, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
-    if (disp) HIPCHK(c, hipMemcpyAsync(disp, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
+    if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(depth, c->h_pinned + 4 * np, np * 2);
+    if (disp) memcpy(disp, c->h_pinned + 2 * np, np * 2);
     return SSM_OK;
 }
 

@@ -7,6 +7,7 @@
 #include "ssm/segnet.h"
 #include "ssm/quadmatcher.hpp"
 #include "ssm/vo_stereo.hpp"
+#include "ssm/stereo.h"
 using namespace std;
 using namespace rgbd_tutor;
 static int fails = 0;
@@ -84,6 +85,27 @@ int main(int argc, char** argv)
               viso.quadmatches_inlier.size() == 250 && viso.quadmatches_outlier.size() == 50);
         QuadFeatureMatch few; few.quadmatches.assign(qm.quadmatches.begin(), qm.quadmatches.begin() + 5);
         CHECK("vo_stereo_needs_six_matches", !viso.Process(few));
+    }
+
+    // calDisparity_SGBM + the depth conversion on a synthetic rectified pair (a textured plane at disparity 24)
+    {
+        const int W = 320, H = 96, D0 = 24;
+        cv::Mat L(H, W, CV_8UC1), R(H, W, CV_8UC1);
+        unsigned s = 4242;
+        std::vector<uint8_t> tex((size_t)H * (W + 64));
+        for (auto& v : tex) { s = s * 1664525u + 1013904223u; v = (uint8_t)(s >> 24); }
+        auto T = [&](int y, int x) { int a = 0; for (int k = -1; k <= 1; k++) a += tex[(size_t)y * (W + 64) + x + 1 + k]; return (uint8_t)(a / 3); };
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { R.at<uchar>(y, x) = T(y, x + 30); L.at<uchar>(y, x) = T(y, x + 30 - D0); }
+        cv::Mat disp, depth, disp2;
+        calDisparity_SGBM(L, R, disp);
+        int good = 0, valid = 0;
+        for (int y = 8; y < H - 8; y++) for (int x = 100; x < W - 8; x++) { const int d = disp.at<int16_t>(y, x); if (d != -16) { valid++; if (abs(d - D0 * 16) <= 8) good++; } }
+        CHECK("calDisparity_SGBM_recovers_a_plane", disp.rows == H && disp.cols == W && valid > 10000 && good > valid * 0.98 && disp.at<int16_t>(10, 5) == -16);
+        stereoDepth(L, R, 0.532331858, 607.1928 - 450, 185.2157 - 140, 718.856, 20, 5, 40, 1000.0, depth, disp2);
+        const int zexp = (int)(718.856 * (0.532331858 / (double)(D0 * 16)) * 16.0 * 1000.0);
+        bool same = true; for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if (disp.at<int16_t>(y, x) != disp2.at<int16_t>(y, x)) same = false;
+        int zok = 0; for (int y = 20; y < H - 20; y++) for (int x = 120; x < 200; x++) if (depth.at<ushort>(y, x) == zexp) zok++;
+        CHECK("stereoDepth_matches_the_reference_formula", same && zok > 2000);
     }
 
     // Tracker state machine on a static scene (the same frame fed three times): state OK, pose ~ identity (not exact: 3-D positions come from truncated pixel coordinates, include/orb.h:50, while the 2-D side is the scaled sub-pixel keypoint)

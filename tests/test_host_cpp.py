@@ -29,6 +29,7 @@ def test_host_layer_builds_and_keeps_reference_names():
         "segnet.h": ["class Classifier", "Classifier()", "std::vector<Prediction> Classify(const cv::Mat& img, int N = 1)"],
         "vo_stereo.hpp": ["class VisualOdometry", "class VisualOdometryStereo : public VisualOdometry", "bool Process(QuadFeatureMatch& quadmatcher)", "cv::Mat getMotion()",
                           "int getNumberOfInliers()", "std::vector<int> getInlierIndices()", "quadmatches_inlier", "std::vector<int> getRandomSample(int N, int num)"],
+        "stereo.h": ["void calDisparity_SGBM(const cv::Mat& img_L, const cv::Mat& img_R, cv::Mat& disp)"],
         "pnp.h": ["bool solvePnP(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj", "bool solvePnPLazy("],
     }
     for f, needles in want.items():
