@@ -31,6 +31,7 @@ public:
     }
     template <class T> T getData(const string& key, const T& dflt) const { return data.count(key) ? getData<T>(key) : dflt; }
     bool has(const string& key) const { return data.count(key) != 0; }
+    void set(const string& key, const string& value) { data[key] = value; }       // override a key after loading (tests, drivers); not in the reference
     CAMERA_INTRINSIC_PARAMETERS getCamera() const {           // reference src/parameter_reader.cpp:4-19
         CAMERA_INTRINSIC_PARAMETERS c;
         c.fx = getData<double>("camera.fx"); c.fy = getData<double>("camera.fy"); c.cx = getData<double>("camera.cx"); c.cy = getData<double>("camera.cy");

@@ -7,6 +7,8 @@
 #include "feature.h"
 #include "parameter_reader.h"
 #include "utils.h"
+#include "png_io.h"
+#include "stereo.h"
 namespace rgbd_tutor {
 class RGBDFrame {
 public:
@@ -55,8 +57,9 @@ public:
         seed = (uint64_t)para.getData<unsigned long long>("synthetic_seed", 0x5EED0000ull);
         dataset_dir = para.getData<string>("data_source", string("./"));
         camera = para.getCamera(); currentIndex = start_index;
-        if (dataset_type == TUM || dataset_type == KITTI || dataset_type == NYUD)
-            cerr << RED << "FrameReader: TUM/KITTI/NYUD layouts need PNG decoding (not built, SURVEY.md s.8f); use SYNTHETIC or RAW" << RESET << endl;
+        if (dataset_type == TUM) init_tum();
+        else if (dataset_type == KITTI) init_kitti();
+        else if (dataset_type == NYUD) cerr << RED << "FrameReader: the NYUD branch is empty in the reference too (rgbdframe.cpp:9-13)" << RESET << endl;
     }
     RGBDFrame::Ptr next() {
         if (currentIndex < start_index || currentIndex >= end_index) return nullptr;
@@ -87,10 +90,49 @@ protected:
             char name[64]; snprintf(name, sizeof(name), "%06d", index);
             if (!readAll(dataset_dir + name + ".bgr", f->rgb.data, np * 3) || !readAll(dataset_dir + name + ".depth", f->depth.data, np * 2) ||
                 !readAll(dataset_dir + name + ".sem", f->semantic.data, np * 3)) return nullptr;                      // missing file -> nullptr, like the reference
+        } else if (dataset_type == TUM) {                    // rgbdframe.cpp:14-33: colour + unchanged (16-bit) depth PNGs named by associate.txt
+            if (index < 0 || index >= (int)rgbFiles.size()) return nullptr;
+            f->rgb = ssm::imreadPNG(dataset_dir + rgbFiles[index], 1);
+            f->depth = ssm::imreadPNG(dataset_dir + depthFiles[index], -1);
+            if (f->rgb.empty() || f->depth.empty() || f->depth.type() != CV_16UC1) return nullptr;
+            f->semantic.create(f->rgb.rows, f->rgb.cols, CV_8UC3);             // TUM has no labels: an all-black image is outside the palette (label 255)
+        } else if (dataset_type == KITTI) {                  // rgbdframe.cpp:34-195: frame i pairs image i+1 (current) with image i (previous)
+            if (index < 0 || index + 1 >= (int)rgbFiles.size()) return nullptr;
+            const string rgb_dir = parameterReader.getData<string>("rgb_dir", string("image_2/"));
+            f->rgb = ssm::imreadPNG(dataset_dir + rgb_dir + rgbFiles[index + 1], 1);
+            f->img_lc = ssm::imreadPNG(dataset_dir + "image_2/" + rgbFiles[index + 1], 0); f->img_lp = ssm::imreadPNG(dataset_dir + "image_2/" + rgbFiles[index], 0);
+            f->img_rc = ssm::imreadPNG(dataset_dir + "image_3/" + rgbFiles[index + 1], 0); f->img_rp = ssm::imreadPNG(dataset_dir + "image_3/" + rgbFiles[index], 0);
+            if (f->rgb.empty() || f->img_lc.empty() || f->img_rc.empty() || f->img_lp.empty() || f->img_rp.empty()) return nullptr;
+            // depth from the current stereo pair: calDisparity_SGBM + the ROI-gated conversion (rgbdframe.cpp:81-116), on the GPU
+            stereoDepth(f->img_lc, f->img_rc, parameterReader.getData<double>("camera.baseline"), camera.cx, camera.cy, camera.fx,
+                        parameterReader.getData<double>("camera.roix", 20.0), parameterReader.getData<double>("camera.roiy", 5.0),
+                        parameterReader.getData<double>("camera.roiz", 40.0), camera.scale, f->depth, f->disparity);
+            f->semantic = ssm::imreadPNG(dataset_dir + "segnet_0/" + rgbFiles[index + 1], 1);                         // precomputed label images, when present
+            if (f->semantic.empty()) f->semantic.create(f->rgb.rows, f->rgb.cols, CV_8UC3);
         } else return nullptr;
         f->raw_semantic = f->semantic; f->result = f->rgb;
         return f;
     }
+    void init_tum() {                                        // rgbdframe.cpp:198-226: lines of "rgb_time rgb_file depth_time depth_file"
+        ifstream fin((dataset_dir + "/associate.txt").c_str());
+        if (!fin) { cerr << RED << "FrameReader: " << dataset_dir << "/associate.txt not found (python associate.py rgb.txt depth.txt > associate.txt)" << RESET << endl; return; }
+        string rgbTime, rgbFile, depthTime, depthFile;
+        while (fin >> rgbTime >> rgbFile >> depthTime >> depthFile) { rgbFiles.push_back(rgbFile); depthFiles.push_back(depthFile); }
+        if (!dataset_dir.empty() && dataset_dir.back() != '/') dataset_dir += "/";
+        end_index = min(end_index, (int)rgbFiles.size());
+    }
+    void init_kitti() {                                      // rgbdframe.cpp:228-265: %06d.png for every entry of data_source/rgb_dir
+        if (!dataset_dir.empty() && dataset_dir.back() != '/') dataset_dir += "/";
+        const string rgb_dir = parameterReader.getData<string>("rgb_dir", string("image_2/"));
+        for (int i = 0;; i++) {
+            char name[32]; snprintf(name, sizeof(name), "%06d.png", i);
+            ifstream probe((dataset_dir + rgb_dir + name).c_str(), ios::binary);
+            if (!probe) break;
+            rgbFiles.push_back(name); depthFiles.push_back(name);
+        }
+        end_index = min(end_index, (int)rgbFiles.size() - 1);
+    }
+    vector<string> rgbFiles, depthFiles;
     static bool readAll(const string& path, void* dst, size_t n) { ifstream in(path, ios::binary); if (!in) return false; in.read((char*)dst, (streamsize)n); return (size_t)in.gcount() == n; }
     const ParameterReader& parameterReader;
     DATASET dataset_type; int currentIndex = 0, start_index = 0, end_index = 0; uint64_t seed = 0; string dataset_dir;

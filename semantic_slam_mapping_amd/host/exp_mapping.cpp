@@ -1,7 +1,8 @@
 // exp_mapping -- the reference's product driver (experiment/exp_mapping.cpp:18-59) on the MI355X front end: build the
 // ParameterReader, Tracker, FrameReader, PoseGraph and Mapper, then loop next() -> updateFrame() -> tryInsertKeyFrame(),
 // finally shut the graph and the mapper down.  Differences: no cv::imshow; the frame source is selected by `dataset`
-// (synthetic | raw) because the TUM/KITTI PNG readers are a next row; prints frames/s at the end.
+// (synthetic | raw | tum | kitti; the reference hard-codes its FrameReader type); with tum / kitti the poses come from the
+// tracker (use_stream_pose defaults to 0 there); prints frames/s at the end.
 #include "ssm/rgbdframe.h"
 #include "ssm/track.h"
 #include "ssm/pose_graph.h"
@@ -26,10 +27,11 @@ int main(int argc, char** argv)
     try {
         Tracker::Ptr tracker(new Tracker(parameterReader, voparam));
         const string ds = parameterReader.getData<string>("dataset", string("synthetic"));
-        FrameReader frameReader(parameterReader, ds == "raw" ? FrameReader::RAW : FrameReader::SYNTHETIC);
+        const FrameReader::DATASET type = ds == "raw" ? FrameReader::RAW : ds == "tum" ? FrameReader::TUM : ds == "kitti" ? FrameReader::KITTI : FrameReader::SYNTHETIC;
+        FrameReader frameReader(parameterReader, type);
         PoseGraph poseGraph(parameterReader, tracker);
         Mapper mapper(parameterReader, poseGraph);
-        const bool use_gt_pose = parameterReader.getData<int>("use_stream_pose", 1) != 0;
+        const bool use_gt_pose = parameterReader.getData<int>("use_stream_pose", (type == FrameReader::TUM || type == FrameReader::KITTI) ? 0 : 1) != 0;
         int nframes = 0;
         auto t0 = chrono::steady_clock::now();
         while (RGBDFrame::Ptr frame = frameReader.next()) {

@@ -16,6 +16,20 @@ static int fails = 0;
 int main(int argc, char** argv)
 {
     ParameterReader para(argc > 1 ? argv[1] : "./parameters.txt");
+    if (argc > 3) {                      // dataset-layout checks only (tests/test_host_cpp.py::test_frame_reader_tum_and_kitti_layouts)
+        para.set("data_source", argv[2]); para.set("start_index", "0"); para.set("end_index", "100");
+        FrameReader tum(para, FrameReader::TUM);
+        RGBDFrame::Ptr a = tum.next(), b = tum.next(), c3 = tum.next(), d = tum.next();
+        CHECK("frame_reader_tum", a && b && c3 && !d && a->rgb.cols == 640 && a->rgb.type() == CV_8UC3 && a->depth.type() == CV_16UC1 &&
+              a->depth.at<ushort>(100, 100) == 1000 && c3->depth.at<ushort>(5, 5) == 1002 && c3->id == 2);
+        para.set("data_source", argv[3]); para.set("camera.baseline", "0.532331858"); para.set("camera.roix", "2000"); para.set("camera.roiy", "2000"); para.set("camera.roiz", "4000");
+        FrameReader kitti(para, FrameReader::KITTI);
+        RGBDFrame::Ptr k0 = kitti.next(), k1 = kitti.next(), k2 = kitti.next();
+        int good = 0; if (k0) for (int y = 10; y < 110; y++) for (int x = 120; x < 390; x++) if (abs(k0->disparity.at<int16_t>(y, x) - 24 * 16) <= 8) good++;
+        CHECK("frame_reader_kitti", k0 && k1 && !k2 && k0->img_lc.cols == 400 && k0->img_rp.rows == 120 && k0->depth.type() == CV_16UC1 && good > 26000 && k0->depth.at<ushort>(60, 200) > 0);
+        cout << (fails ? "FAILED" : "ALL PASSED") << endl;
+        return fails;
+    }
     CHECK("parameter_reader", para.getData<int>("orb_features") == 1000 && para.getData<double>("knn_match_ratio") == 0.8 && !para.has("#comment"));
     bool threw = false; try { para.getData<int>("no_such_key"); } catch (const out_of_range&) { threw = true; }
     CHECK("parameter_missing_key_throws", threw);

@@ -38,6 +38,57 @@ def test_host_layer_builds_and_keeps_reference_names():
             assert n in src, (f, n)
 
 
+def _write_png_set(d):
+    """the files semantic_slam_mapping_amd/host/test_png.cpp expects, written by PIL (an independent encoder)"""
+    import numpy as np
+    from PIL import Image
+    W, H = 37, 23
+    y, x = np.mgrid[0:H, 0:W]
+    px = lambda c: ((7 * x + 13 * y + 29 * c) & 255).astype(np.uint8)
+    Image.fromarray(np.stack([px(0), px(1), px(2)], -1), "RGB").save(os.path.join(d, "rgb.png"))
+    Image.fromarray(px(0), "L").save(os.path.join(d, "gray.png"))
+    Image.fromarray(((257 * x + 31 * y) & 65535).astype(np.uint16)).save(os.path.join(d, "depth.png"))          # mode I;16 -> 16-bit gray PNG
+    Image.fromarray(np.stack([px(0), px(1), px(2), px(3)], -1), "RGBA").save(os.path.join(d, "rgba.png"))
+    pal = Image.fromarray(((x + y) % 12).astype(np.uint8), "P")
+    pal.putpalette(sum(([i * 20, i * 20 + 1, (i * 20 + 2) & 255] for i in range(12)), []) + [0] * (768 - 36))
+    pal.save(os.path.join(d, "pal.png"))
+    open(os.path.join(d, "garbage.png"), "wb").write(b"\x89PNG\r\n\x1a\n" + bytes(range(64)))
+
+
+def test_png_reader(tmp_path):
+    """the PNG decoder behind FrameReader's TUM / KITTI modes (the slice of cv::imread the reference uses): host only"""
+    subprocess.run(["make", "-C", HOST, "test_png"], check=True, stdout=subprocess.DEVNULL)
+    _write_png_set(str(tmp_path))
+    out = subprocess.run([os.path.join(HOST, "test_png"), str(tmp_path)], capture_output=True, text=True)
+    assert "ALL PASSED" in out.stdout and out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("PASS ") == 9
+
+
+@pytest.mark.gpu
+def test_frame_reader_tum_and_kitti_layouts(tmp_path):
+    """FrameReader::TUM (associate.txt + colour / 16-bit depth PNGs) and FrameReader::KITTI (image_2 / image_3 pairs, depth by
+    SGBM on the GPU) on small synthetic datasets written here"""
+    import numpy as np
+    from PIL import Image
+    subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(5)
+    tum = tmp_path / "tum"; (tum / "rgb").mkdir(parents=True); (tum / "depth").mkdir()
+    lines = []
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8), "RGB").save(tum / "rgb" / f"{i}.png")
+        Image.fromarray(np.full((480, 640), 1000 + i, np.uint16)).save(tum / "depth" / f"{i}.png")
+        lines.append(f"{i}.0 rgb/{i}.png {i}.0 depth/{i}.png")
+    (tum / "associate.txt").write_text("\n".join(lines) + "\n")
+    kitti = tmp_path / "kitti"; (kitti / "image_2").mkdir(parents=True); (kitti / "image_3").mkdir()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sgbm import stereo_pair
+    for i in range(3):
+        left, right, _ = stereo_pair(120, 400, 20 + i, planes=((24, None),))
+        Image.fromarray(left, "L").save(kitti / "image_2" / f"{i:06d}.png"); Image.fromarray(right, "L").save(kitti / "image_3" / f"{i:06d}.png")
+    out = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), str(tum), str(kitti)], capture_output=True, text=True)
+    assert "PASS frame_reader_tum" in out.stdout and "PASS frame_reader_kitti" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_host_classes_on_gpu():
     subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
