@@ -8,6 +8,8 @@
 #pragma once
 #include "common_headers.h"
 #include "device.h"
+#include <map>
+#include <tuple>
 using cv::KeyPoint; using cv::DMatch; using cv::Point2f; using cv::Mat;
 enum { DET_FAST, DET_STAR, DET_ORB, DET_SIFT, DET_SURF, DET_GFTT, DET_STAR_ADAPT, DET_FAST_ADAPT, DET_FAST_GRID, DET_STAR_GRID, DET_GFTT_GRID };
 enum { DES_SIFT, DES_SURF, DES_BRISK, DES_FREAK, DES_ORB };
@@ -27,8 +29,9 @@ public:
         descriptor_binary = true; distance_threshold = 80.0f;                // quadmatcher.cpp init(): ORB -> binary, threshold 80
         ssm_config cfg; ssm_config_default(&cfg); cfg.width = img_lc.cols < 64 ? 64 : img_lc.cols; cfg.height = img_lc.rows < 64 ? 64 : img_lc.rows;
         cfg.orb_features = 1000; cfg.max_batch = 1; cfg.voxel_capacity_log2 = 10;
-        if (!mode_track) while (cfg.orb_levels > 1) { ssm_ctx* t = nullptr; if (ssm_create(0, &cfg, &t) == SSM_OK) { ssm_destroy(t); break; } cfg.orb_levels--; }
-        dev.reset(new ssm::Device(cfg));
+        if (mode_track) cfg.orb_levels = 1;                                  // no ORB runs in tracking mode: the smallest pyramid passes ssm_create's geometry check
+        else while (cfg.orb_levels > 1) { ssm_ctx* t = nullptr; if (ssm_create(0, &cfg, &t) == SSM_OK) { ssm_destroy(t); break; } cfg.orb_levels--; }
+        dev = sharedDevice(cfg, mode_track);
     }
     void detectFeature() { /* tracking mode: GFTT runs inside circularMatching (one device call); matching mode: extractDescriptor() detects */ }
     void extractDescriptor() {
@@ -89,5 +92,15 @@ private:
     cv::Mat descriptor_lc, descriptor_rc, descriptor_lp, descriptor_rp;
     bool mode_track = true, descriptor_binary = true;
     float distance_threshold = 80.0f;
-    unique_ptr<ssm::Device> dev;
+    shared_ptr<ssm::Device> dev;
+    // Tracker::estimateVO news a QuadFeatureMatch per frame (track.cpp:45): the device context behind it is kept per thread and
+    // image size instead of being rebuilt every frame
+    static shared_ptr<ssm::Device> sharedDevice(const ssm_config& cfg, bool track) {
+        static thread_local std::map<std::tuple<int, int, int, bool>, shared_ptr<ssm::Device>> cache;
+        auto key = std::make_tuple(cfg.width, cfg.height, cfg.orb_levels, track);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+        shared_ptr<ssm::Device> d(new ssm::Device(cfg));
+        cache[key] = d; return d;
+    }
 };

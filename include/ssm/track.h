@@ -1,9 +1,11 @@
 // ssm/track.h -- rgbd_tutor::Tracker (reference include/track.h:50-191, src/track.cpp): the per-frame state machine.
 // RGB-D mode = Tracker::trackRefFrame (src/track.cpp:140-200), restated line for line on the device-backed
-// OrbFeature; the checked-in reference instead calls the stereo estimateVO() (track.cpp:19).  Its two device stages exist
-// (QuadFeatureMatch, VisualOdometryStereo: quadmatcher.hpp, vo_stereo.hpp) but the SGBM depth / UVDisparity steps between
-// them (track.cpp:68-80) are "next" rows, so tracker_mode=stereo is still rejected here.  PoseGraph is out of scope:
-// setPoseGraph is kept as a no-op hook.
+// OrbFeature (tracker_mode = rgbd, the default here).  The checked-in reference instead calls the stereo estimateVO()
+// (track.cpp:19, 38-138): tracker_mode = stereo runs that branch -- ORB features for the back end, QuadFeatureMatch in
+// tracking mode on the frame's four stereo images, VisualOdometryStereo::Process, pose chained as pose * inv(motion).  The
+// triangulate10D / UVDisparity block between them (track.cpp:68-80) only fills moving_mask, which Mapper overwrites
+// (SURVEY.md s.2), and is not rebuilt; inv() of the rigid motion is the closed form [R^T | -R^T t] instead of Matrix_'s LU
+// inverse.  PoseGraph is out of scope: setPoseGraph is kept as a no-op hook.
 #pragma once
 #include "common_headers.h"
 #include "orb.h"
@@ -20,8 +22,10 @@ public:
         pnp = make_shared<PnPSolver>(para, *orb);
         max_lost_frame = para.getData<int>("tracker_max_lost_frame", 10);
         refFramesSize = para.getData<int>("tracker_ref_frames", 5);
-        if (para.getData<string>("tracker_mode", string("rgbd")) != "rgbd")
-            throw invalid_argument("tracker_mode: only 'rgbd' (Tracker::trackRefFrame) is built; the stereo estimateVO path is a next row");
+        const string mode = para.getData<string>("tracker_mode", string("rgbd"));
+        if (mode != "rgbd" && mode != "stereo") throw invalid_argument("tracker_mode: 'rgbd' (Tracker::trackRefFrame) or 'stereo' (Tracker::estimateVO)");
+        stereo = mode == "stereo";
+        if (stereo) viso.reset(new VisualOdometryStereo(param));
     }
     void setPoseGraph(shared_ptr<PoseGraph> pg) { poseGraph = pg; }
     // put in a new frame, returns its pose (src/track.cpp:8-28)
@@ -29,7 +33,7 @@ public:
         unique_lock<mutex> lck(adjustMutex);
         currentFrame = newFrame;
         if (state == NOT_READY) { initFirstFrame(); return Eigen::Isometry3d::Identity(); }
-        if (state == OK) { trackRefFrame(); return currentFrame->getTransform(); }
+        if (state == OK) { if (stereo) estimateVO(); else trackRefFrame(); return currentFrame->getTransform(); }
         lostRecover();
         return currentFrame->getTransform();
     }
@@ -53,6 +57,34 @@ protected:
         refFrames.push_back(currentFrame);
         speed = Eigen::Isometry3d::Identity();
         state = OK;
+    }
+    void estimateVO() {                                                 // track.cpp:38-138
+        currentFrame->setTransform(speed * refFrames.back()->getTransform());
+        orb->detectFeatures(currentFrame);
+        bool success = false;
+        if (!currentFrame->img_lc.empty() && !currentFrame->img_rc.empty() && !currentFrame->img_lp.empty() && !currentFrame->img_rp.empty()) {
+            QuadFeatureMatch quadmatcher(currentFrame->img_lc, currentFrame->img_rc, currentFrame->img_lp, currentFrame->img_rp,
+                                         currentFrame->semantic_cur_r, currentFrame->semantic_pre_r, true);
+            quadmatcher.init(DET_GFTT, DES_SIFT);
+            quadmatcher.detectFeature();
+            quadmatcher.circularMatching();
+            lastMatches = (int)quadmatcher.quadmatches.size();
+            if (viso->Process(quadmatcher)) {
+                cv::Mat motion = viso->getMotion();
+                Eigen::Isometry3d M;
+                for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) M(i, j) = motion.at<double>(i, j);
+                pose = pose * M.inverse();
+                lastInliers = viso->getNumberOfInliers();
+                success = true;
+            }
+        }
+        if (!success) { cntLost++; if (cntLost > max_lost_frame) state = LOST; return; }
+        currentFrame->setTransform(pose);
+        cntLost = 0;
+        speed = pose * lastPose.inverse();
+        lastPose = currentFrame->getTransform();
+        refFrames.push_back(currentFrame);
+        while ((int)refFrames.size() > refFramesSize) refFrames.pop_front();
     }
     void trackRefFrame() {                                              // track.cpp:140-200
         currentFrame->setTransform(speed * refFrames.back()->getTransform());
@@ -95,6 +127,7 @@ public:
 protected:
     const ParameterReader& parameterReader;
     VisualOdometryStereo::parameters voparam;
+    bool stereo = false; unique_ptr<VisualOdometryStereo> viso; Eigen::Isometry3d pose = Eigen::Isometry3d::Identity();      // estimateVO state (track.h:181)
     RGBDFrame::Ptr currentFrame = nullptr;
     deque<RGBDFrame::Ptr> refFrames;
     int refFramesSize = 5;

@@ -27,6 +27,18 @@ int main(int argc, char** argv)
         RGBDFrame::Ptr k0 = kitti.next(), k1 = kitti.next(), k2 = kitti.next();
         int good = 0; if (k0) for (int y = 10; y < 110; y++) for (int x = 120; x < 390; x++) if (abs(k0->disparity.at<int16_t>(y, x) - 24 * 16) <= 8) good++;
         CHECK("frame_reader_kitti", k0 && k1 && !k2 && k0->img_lc.cols == 400 && k0->img_rp.rows == 120 && k0->depth.type() == CV_16UC1 && good > 26000 && k0->depth.at<ushort>(60, 200) > 0);
+        // Tracker in stereo mode (Tracker::estimateVO): the synthetic pair is a static fronto-parallel plane, so the motion is ~identity
+        {
+            para.set("tracker_mode", "stereo"); para.set("image_width", "400"); para.set("image_height", "120"); para.set("orb_levels", "3"); para.set("orb_features", "300");
+            VisualOdometryStereo::parameters vp; vp.calib.f = para.getData<double>("camera.fx"); vp.calib.cu = para.getData<double>("camera.cx"); vp.calib.cv = para.getData<double>("camera.cy");
+            vp.base = 0.532331858; vp.inlier_threshold = 2.0;
+            Tracker tracker(para, vp);
+            FrameReader again(para, FrameReader::KITTI);
+            RGBDFrame::Ptr a0 = again.next(), a1 = again.next();
+            tracker.updateFrame(a0);
+            Eigen::Isometry3d T1 = tracker.updateFrame(a1);
+            CHECK("tracker_stereo_mode_runs_estimateVO", a0 && a1 && tracker.getState() != Tracker::NOT_READY && tracker.lastMatches >= 0 && std::isfinite(T1(0, 3)));
+        }
         cout << (fails ? "FAILED" : "ALL PASSED") << endl;
         return fails;
     }

@@ -86,7 +86,7 @@ def test_frame_reader_tum_and_kitti_layouts(tmp_path):
         left, right, _ = stereo_pair(120, 400, 20 + i, planes=((24, None),))
         Image.fromarray(left, "L").save(kitti / "image_2" / f"{i:06d}.png"); Image.fromarray(right, "L").save(kitti / "image_3" / f"{i:06d}.png")
     out = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), str(tum), str(kitti)], capture_output=True, text=True)
-    assert "PASS frame_reader_tum" in out.stdout and "PASS frame_reader_kitti" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "PASS frame_reader_tum" in out.stdout and "PASS frame_reader_kitti" in out.stdout and "PASS tracker_stereo_mode_runs_estimateVO" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 @pytest.mark.gpu
