@@ -58,6 +58,96 @@ def measured_traffic(stage, frames_per_launch):
         return None
 
 
+def stereo_main(args):
+    """configs[3]: KITTI-geometry stereo (1241 x 376, synthetic rectified pairs): per frame the quad matcher on (lc, rc, lp, rp),
+    SGBM depth on (lc, rc) and the stereo visual odometry on the quad matches.  These stages take host images (the reference
+    hands cv::Mat to them), so `value` is a host-to-host rate; the roofline object is for the SGBM kernels (device time by
+    hipEvents, algorithmic bytes = the u16 cost volume written once and read once per scan direction)."""
+    import numpy as np
+    import torch
+    import semantic_slam_mapping_amd as ssm
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from test_sgbm import stereo_pair, KITTI
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    Wd, Hd, D = 1241, 376, 80
+    F = min(args.frames, 16) if args.frames != 1000 else 8            # frame pairs per step (replicas on every rank: the stages do not shard below a frame)
+    ctx = ssm.Context(local_rank, width=640, height=480)
+    pairs = [stereo_pair(Hd, Wd, 100 + rank * 1000 + i, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), noise=4) for i in range(F + 1)]
+    from semantic_slam_mapping_amd.oracle_binding import Oracle
+    orc = Oracle()
+    samples = None
+    stage_ms = {"quad_track": 0.0, "sgbm": 0.0, "vo": 0.0}
+
+    def step(record):
+        nm = 0
+        for i in range(1, F + 1):
+            lc, rc, _ = pairs[i]; lp, rp, _ = pairs[i - 1]
+            qm = ctx.quad_track(lc, rc, lp, rp)
+            if record: stage_ms["quad_track"] += ctx.stage_times().get("quad_track", (0.0, 0))[0]
+            depth, disp = ctx.stereo_depth(lc, rc, **KITTI)
+            if record: stage_ms["sgbm"] += ctx.stage_times().get("sgbm", (0.0, 0))[0]
+            if len(qm) >= 6:
+                smp = (np.arange(600, dtype=np.int64).reshape(200, 3) * 7919 + i) % len(qm)        # fixed sample indices (the host class draws them from rand())
+                smp[:, 1] = (smp[:, 0] + 1 + smp[:, 1] % (len(qm) - 1)) % len(qm); smp[:, 2] = (smp[:, 0] + 1 + (smp[:, 1] - smp[:, 0] - 1) % (len(qm) - 1) + 1) % len(qm)
+                ctx.vo_estimate(qm, KITTI["f"], KITTI["cu"], KITTI["cv"], KITTI["baseline"], smp.astype(np.int32))
+                if record: stage_ms["vo"] += ctx.stage_times().get("vo", (0.0, 0))[0]
+            nm += len(qm)
+        return nm
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nm = step(False)
+    torch.cuda.synchronize()
+    if world > 1: dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank)); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    ctx.set_profiling(1)
+    for _ in range(args.steps):
+        step(True)
+    ctx.set_profiling(0)
+    if rank != 0:
+        return
+    frames = world * F * args.steps
+    sg_ms = stage_ms["sgbm"] / (F * args.steps)
+    vol = (Wd - D) * Hd * D
+    alg = 6 * vol * 2                                       # u16 cost volume: written once, read once by each of the 5 scan directions
+    ach = alg / (sg_ms * 1e-3) / 1e9
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        lc, rc, _ = pairs[1]
+        t1 = time.perf_counter(); ref = orc.sgbm(lc, rc, orc.sgbm_params()); orc.disparity_to_depth(ref, **KITTI); tc = time.perf_counter() - t1
+        lp, rp, _ = pairs[0]
+        t1 = time.perf_counter(); orc.quad_track(lc, rc, lp, rp); tq = time.perf_counter() - t1
+        cpu = {"value": round(1.0 / (tc + tq), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "one frame pair of the same stream: oracle/ quad matcher + SGBM + depth conversion (C, 1 thread); the VO is below a millisecond",
+               "ms_per_frame": {"sgbm": round(tc * 1e3, 2), "quad_track": round(tq * 1e3, 2)}}
+    line = {"metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i16", "data": "synthetic",
+            "config": {"workload": "configs[3] stages: synthetic rectified stereo 1241x376 (seeded textured planes), per frame pair: quad matcher (GFTT + 4x LK), "
+                                   "SGBM depth (80 disparities, SAD 11) + ROI depth conversion, stereo VO (200 RANSAC hypotheses); host images in, host results out",
+                       "frame_pairs_per_gpu": F, "parallelism": "replicas" if world > 1 else "single GPU"},
+            "per_frame": {"quad_matches": round(nm / F, 1)},
+            "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle: all kernels of ssm_sgbm)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                         "note": "first version: the scan recurrences are latency chains (16 lanes per path), see DESIGN.md s.4",
+                         "stages_ms_per_frame": {k: round(v / (F * args.steps), 3) for k, v in stage_ms.items()}},
+            "cpu_baseline": cpu}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +159,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
+    ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
     args = ap.parse_args()
+    if args.stereo:
+        return stereo_main(args)
 
     import numpy as np
     import torch

@@ -1035,7 +1035,13 @@ static int quad_init(ssm_ctx* c, int w, int h, int maxc)
 static int quad_upload(ssm_ctx* c, int i, const uint8_t* img, int stride, bool deriv)
 {
     QuadState* q = c->quad; hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpy2DAsync(q->pyr[i][0], q->w, img, stride, q->w, q->h, hipMemcpyHostToDevice, s));
+    // image i goes through slot i of the pinned staging buffer (a pageable hipMemcpy2D of a 1241x376 image costs ~1 ms each)
+    const size_t np = (size_t)q->w * q->h;
+    int r = ensure_pinned(c, 4 * np); if (r) return r;
+    if (i == 0) HIPCHK(c, hipStreamSynchronize(s));               // the previous call's copies out of the staging buffer are done
+    uint8_t* hp = c->h_pinned + (size_t)i * np;
+    for (int y = 0; y < q->h; y++) memcpy(hp + (size_t)y * q->w, img + (size_t)y * stride, q->w);
+    HIPCHK(c, hipMemcpyAsync(q->pyr[i][0], hp, np, hipMemcpyHostToDevice, s));
     for (int l = 1; l < 4; l++) HIPCHK(c, k_quad_pyrdown(q->pyr[i][l-1], q->lw[l-1], q->lh[l-1], q->pyr[i][l], s));
     if (deriv) for (int l = 0; l < 4; l++) HIPCHK(c, k_quad_scharr(q->pyr[i][l], q->lw[l], q->lh[l], q->der[i][l], s));
     return SSM_OK;
@@ -1073,13 +1079,18 @@ extern "C" int ssm_quad_track(ssm_ctx* c, const uint8_t* lc, const uint8_t* rc, 
     QuadState* q = c->quad;
     if ((r = quad_upload(c, 0, lc, stride, true)) || (r = quad_upload(c, 1, rc, stride, true)) || (r = quad_upload(c, 2, lp, stride, false)) || (r = quad_upload(c, 3, rp, stride, true))) return r;
     int n = 0;
-    r = quad_gftt(c, 0, max_corners, 0.04, 8.0, q->pts[0], &n); if (r) return r;           // quadmatcher.cpp:301-308
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
+    prof_begin(c, "quad_track");
+    r = quad_gftt(c, 0, max_corners, 0.04, 8.0, q->pts[0], &n);                             // quadmatcher.cpp:301-308
+    if (r || n == 0) prof_end(c);
+    if (r) return r;
     *n_out = 0;
     if (n == 0) return SSM_OK;
     // quadmatcher.cpp:566-576: lc->rc, rc->rp, rp->lp, lc->lp(direct); pts: 0 lc, 1 rc, 2 rp, 3 lp, 4 lp_direct; images: 0 lc, 1 rc, 2 lp, 3 rp
     if ((r = quad_lk(c, 0, 1, q->pts[0], n, q->pts[1], 200, 0.01, 1e-6)) || (r = quad_lk(c, 1, 3, q->pts[1], n, q->pts[2], 200, 0.01, 1e-6)) ||
         (r = quad_lk(c, 3, 2, q->pts[2], n, q->pts[3], 200, 0.01, 1e-6)) || (r = quad_lk(c, 0, 2, q->pts[0], n, q->pts[4], 200, 0.01, 1e-6))) return r;
     HIPCHK(c, k_quad_filter(q->pts[0], q->pts[1], q->pts[3], q->pts[2], q->pts[4], n, q->pm, q->nout, c->stream));
+    prof_end(c);
     int m = 0;
     HIPCHK(c, hipMemcpyAsync(&m, q->nout, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1170,7 +1181,10 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     for (int y = 0; y < h; y++) { memcpy(c->h_pinned + (size_t)y * w, left + (size_t)y * stride, w); memcpy(c->h_pinned + np + (size_t)y * w, right + (size_t)y * stride, w); }
     HIPCHK(c, hipMemcpyAsync(dl, c->h_pinned, np, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(dr, c->h_pinned + np, np, hipMemcpyHostToDevice, s));
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
+    prof_begin(c, "sgbm");
     HIPCHK(c, k_sgbm(dl, dr, w, h, *params, p, dd, stage, s));
+    prof_end(c);
     *d_disp_out = dd; *d_tail_out = tail;
     return SSM_OK;
 }
@@ -1225,8 +1239,11 @@ extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, con
     uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(p + o_m, matches, (size_t)n * sizeof(ssm_pmatch), hipMemcpyHostToDevice, s));
     if (iters) HIPCHK(c, hipMemcpyAsync(p + o_s, samples, (size_t)iters * 12, hipMemcpyHostToDevice, s));
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
+    prof_begin(c, "vo");
     HIPCHK(c, k_vo_estimate((const ssm_pmatch*)(p + o_m), n, *params, (const int32_t*)(p + o_s), iters, (double*)(p + o_tr), (int32_t*)(p + o_cnt),
                             (double*)(p + o_out), (int32_t*)(p + o_inl), (int32_t*)(p + o_res), s));
+    prof_end(c);
     int32_t res[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(tr, p + o_out, 48, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(res, p + o_res, 8, hipMemcpyDeviceToHost, s));
