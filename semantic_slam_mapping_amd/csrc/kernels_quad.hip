@@ -97,39 +97,82 @@ gftt_collect_kernel(const float* __restrict__ eig, int w, int h, const int* __re
         if (keep) { const int k = base + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); }
     }
 }
-// greedy minDistance selection over the sorted candidates (goodFeaturesToTrack's grid of cell = round(minDistance)); serial by nature:
-// one lane walks the list, the grid heads live in LDS.  Writes (x, y) float pairs.
-__global__ void __launch_bounds__(64)
-gftt_select_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int h, int max_corners, float min_distance,
-                   float* __restrict__ pts, int* __restrict__ nout, int* __restrict__ next)
+// minDistance selection over the sorted candidates (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one
+// unless an already kept corner lies closer than minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds
+// of local decisions, because a corner's fate depends only on STRONGER corners within minDistance:
+//   rejected  as soon as a kept corner is that close,
+//   kept      once no stronger corner that close is still undecided (and none is kept),
+// so every round decides at least the strongest undecided corner and most corners settle in the first few rounds.  States only
+// move undecided -> kept / rejected and a decision never reads a weaker corner, so updating in place during a round is safe.
+// The first maxCorners kept corners in strength order are the reference's result (a kept corner never depends on weaker ones).
+// rank_at: per-pixel rank of the candidate sitting there (-1 none); state: 0 undecided, 1 kept, 2 rejected.
+__global__ void __launch_bounds__(256)
+gftt_rank_kernel(const unsigned long long* __restrict__ keys, int nc, int* __restrict__ rank_at, uint8_t* __restrict__ state)
 {
-    extern __shared__ int16_t head[];                // one list head per grid cell (corner index < 32768), up to 65536 cells = 128 KiB
-    const int cell = max(__float2int_rn(min_distance), 1);
-    const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
-    for (int i = threadIdx.x; i < gw * gh; i += 64) head[i] = -1;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    rank_at[0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu)] = i;
+    state[i] = 0;
+}
+__global__ void __launch_bounds__(256)
+gftt_round_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int h, float min_distance, const int* __restrict__ rank_at,
+                  uint8_t* __restrict__ state, int* __restrict__ pending, int round)
+{
+    if (round > 0 && pending[round] == 0) return;             // everything was decided in an earlier round
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc || state[i] != 0) return;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
+    const int y = idx / w, x = idx - y * w;
     const float md2 = min_distance * min_distance;
-    int n = 0;
-    for (int i = 0; i < nc; i++) {
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
-        const int y = idx / w, x = idx - y * w;
-        const int xc = x / cell, yc = y / cell;
-        const int x1 = max(xc - 1, 0), y1 = max(yc - 1, 0), x2 = min(xc + 1, gw - 1), y2 = min(yc + 1, gh - 1);
-        bool good = true;
-        for (int yy = y1; yy <= y2 && good; yy++)
-            for (int xx = x1; xx <= x2 && good; xx++)
-                for (int k = head[yy * gw + xx]; k >= 0; k = next[k]) {
-                    const float ddx = (float)(x - (int)pts[2*k]), ddy = (float)(y - (int)pts[2*k+1]);
-                    if (ddx * ddx + ddy * ddy < md2) { good = false; break; }
-                }
-        if (good) {
-            next[n] = head[yc * gw + xc]; head[yc * gw + xc] = (int16_t)n;
-            pts[2*n] = (float)x; pts[2*n+1] = (float)y; n++;
-            if (max_corners > 0 && n == max_corners) break;
+    const int rad = (int)ceilf(min_distance);                 // |dx|, |dy| < minDistance
+    bool blocked = false, rejected = false;
+    for (int dy = -rad; dy <= rad && !rejected; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -rad; dx <= rad; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+            if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+            const int j = rank_at[yy * w + xx];
+            if (j < 0 || j > i) continue;                     // no candidate there, or a weaker one
+            const int sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
+            if (sj == 1) { rejected = true; break; }
+            if (sj == 0) blocked = true;
         }
     }
-    *nout = n;
+    if (rejected) state[i] = 2;
+    else if (!blocked) state[i] = 1;
+    else atomicOr(&pending[round + 1], 1);
+}
+// kept corners in strength order, the first max_corners of them: (x, y) float pairs + count
+__global__ void __launch_bounds__(1024)
+gftt_emit_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int max_corners, const uint8_t* __restrict__ state,
+                 float* __restrict__ pts, int* __restrict__ nout)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nc; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool keep = i < nc && state[i] == 1;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wv; k++) off += wsum[k];
+        const int n = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && (max_corners <= 0 || n < max_corners)) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
+            pts[2 * n] = (float)(idx % (unsigned)w); pts[2 * n + 1] = (float)(idx / (unsigned)w);
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wsum[k]; base += t; }
+        __syncthreads();
+        if (max_corners > 0 && base >= max_corners) break;
+    }
+    if (tid == 0) *nout = (max_corners > 0 && base > max_corners) ? max_corners : base;
 }
 
 // ------------------------------------------------------------------ pyramid + Scharr for LK
@@ -337,13 +380,25 @@ hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, dou
     gftt_collect_kernel<<<(w * h + 255) / 256, 256, 0, s>>>(eig, w, h, maxord, quality, keys, count, cap);
     return hipGetLastError();
 }
-hipError_t k_quad_select(const unsigned long long* keys, int nc, int w, int h, int max_corners, float min_distance, float* pts, int* nout, int* next, hipStream_t s)
+// rank_at: w*h ints; state: nc bytes; pending: GFTT_ROUNDS + 1 ints.  *more = 1 when corners are still undecided after
+// GFTT_ROUNDS rounds (the caller runs another batch); the emit kernel runs when everything is decided.
+hipError_t k_quad_select_begin(const unsigned long long* keys, int nc, int w, int h, int* rank_at, uint8_t* state, hipStream_t s)
 {
-    const int cell = max((int)lrintf(min_distance), 1);
-    const size_t lds = (size_t)((w + cell - 1) / cell) * ((h + cell - 1) / cell) * sizeof(int16_t);
-    if (lds > 65536 * 2) return hipErrorInvalidValue;
-    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)gftt_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-    gftt_select_kernel<<<1, 64, lds, s>>>(keys, nc, w, h, max_corners, min_distance, pts, nout, next);
+    hipError_t e = hipMemsetAsync(rank_at, 0xFF, sizeof(int) * (size_t)w * h, s);
+    if (e != hipSuccess) return e;
+    gftt_rank_kernel<<<(nc + 255) / 256, 256, 0, s>>>(keys, nc, rank_at, state);
+    return hipGetLastError();
+}
+hipError_t k_quad_select_rounds(const unsigned long long* keys, int nc, int w, int h, float min_distance, const int* rank_at, uint8_t* state, int* pending, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(pending, 0, sizeof(int) * (GFTT_ROUNDS + 1), s);
+    if (e != hipSuccess) return e;
+    for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<(nc + 255) / 256, 256, 0, s>>>(keys, nc, w, h, min_distance, rank_at, state, pending, r);
+    return hipGetLastError();
+}
+hipError_t k_quad_select_emit(const unsigned long long* keys, int nc, int w, int max_corners, const uint8_t* state, float* pts, int* nout, hipStream_t s)
+{
+    gftt_emit_kernel<<<1, 1024, 0, s>>>(keys, nc, w, max_corners, state, pts, nout);
     return hipGetLastError();
 }
 hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s)

@@ -46,6 +46,7 @@ struct QuadState {          // buffers of the stereo quad matcher for one image 
     uint8_t* pyr[4][4] = {};                // [image lc,rc,lp,rp][level]
     int16_t* der[4][4] = {};                // Scharr derivatives (used for lc, rc, rp)
     float* eig = nullptr; int* maxord = nullptr; int* count = nullptr; unsigned long long *keys = nullptr, *keys2 = nullptr; void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0; int keycap = 0;
+    int* rank_at = nullptr; uint8_t* sel_state = nullptr; int* pending = nullptr;      // minDistance selection (k_quad_select_*)
     float* pts[5] = {};                     // lc, rc, rp, lp, lp_direct
     uint8_t* status = nullptr; float* err = nullptr; int* next = nullptr; int* nout = nullptr; void* pm = nullptr;
 };
@@ -1009,7 +1010,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 static void quad_free(QuadState* q)
 {
     for (int i = 0; i < 4; i++) for (int l = 0; l < 4; l++) { if (q->pyr[i][l]) hipFree(q->pyr[i][l]); if (q->der[i][l]) hipFree(q->der[i][l]); q->pyr[i][l] = nullptr; q->der[i][l] = nullptr; }
-    void* p[] = { q->eig, q->maxord, q->count, q->keys, q->keys2, q->sort_tmp, q->pts[0], q->pts[1], q->pts[2], q->pts[3], q->pts[4], q->status, q->err, q->next, q->nout, q->pm };
+    void* p[] = { q->eig, q->maxord, q->count, q->keys, q->keys2, q->sort_tmp, q->pts[0], q->pts[1], q->pts[2], q->pts[3], q->pts[4], q->status, q->err, q->next, q->nout, q->pm, q->rank_at, q->sel_state, q->pending };
     for (void* x : p) if (x) hipFree(x);
 }
 static int quad_init(ssm_ctx* c, int w, int h, int maxc)
@@ -1027,6 +1028,7 @@ static int quad_init(ssm_ctx* c, int w, int h, int maxc)
     HIPCHK(c, sort_keys_desc_u64(nullptr, &q->sort_tmp_bytes, q->keys, q->keys2, q->keycap, c->stream));
     uint8_t* t; int r = dalloc(c, &t, q->sort_tmp_bytes + 256); if (r) return r; q->sort_tmp = t;
     for (int i = 0; i < 5; i++) DALLOC(c, q->pts[i], (size_t)2 * maxc);
+    DALLOC(c, q->rank_at, (size_t)w * h); DALLOC(c, q->sel_state, q->keycap); DALLOC(c, q->pending, GFTT_ROUNDS + 1);
     DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc); DALLOC(c, q->next, maxc); DALLOC(c, q->nout, 1);
     uint8_t* pm; r = dalloc(c, &pm, (size_t)maxc * sizeof(ssm_pmatch)); if (r) return r; q->pm = pm;
     return SSM_OK;
@@ -1058,7 +1060,14 @@ static int quad_gftt(ssm_ctx* c, int img, int max_corners, double quality, doubl
     *n_out = 0;
     if (nc == 0) return SSM_OK;
     HIPCHK(c, sort_keys_desc_u64(q->sort_tmp, &q->sort_tmp_bytes, q->keys, q->keys2, nc, s));
-    HIPCHK(c, k_quad_select(q->keys2, nc, q->w, q->h, max_corners, (float)min_distance, d_pts, q->nout, q->next, s));
+    HIPCHK(c, k_quad_select_begin(q->keys2, nc, q->w, q->h, q->rank_at, q->sel_state, s));
+    for (int more = 1, batch = 0; more; batch++) {               // GFTT_ROUNDS decision rounds per batch; one batch is the normal case
+        if (batch > nc) FAIL(c, SSM_E_HIP, "corner selection did not converge");
+        HIPCHK(c, k_quad_select_rounds(q->keys2, nc, q->w, q->h, (float)min_distance, q->rank_at, q->sel_state, q->pending, s));
+        HIPCHK(c, hipMemcpyAsync(&more, q->pending + GFTT_ROUNDS, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    HIPCHK(c, k_quad_select_emit(q->keys2, nc, q->w, max_corners, q->sel_state, d_pts, q->nout, s));
     HIPCHK(c, hipMemcpyAsync(n_out, q->nout, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return SSM_OK;

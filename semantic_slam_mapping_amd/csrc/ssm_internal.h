@@ -110,7 +110,10 @@ hipError_t k_segnet_color(const uint8_t* ids, int n, int sw, int sh, int dw, int
 // quad matcher (kernels_quad.hip)
 hipError_t k_quad_mineig(const uint8_t* img, int w, int h, int stride, float* eig, int* maxord, hipStream_t s);
 hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, double quality, unsigned long long* keys, int* count, int cap, hipStream_t s);
-hipError_t k_quad_select(const unsigned long long* keys, int nc, int w, int h, int max_corners, float min_distance, float* pts, int* nout, int* next, hipStream_t s);
+#define GFTT_ROUNDS 24
+hipError_t k_quad_select_begin(const unsigned long long* keys, int nc, int w, int h, int* rank_at, uint8_t* state, hipStream_t s);
+hipError_t k_quad_select_rounds(const unsigned long long* keys, int nc, int w, int h, float min_distance, const int* rank_at, uint8_t* state, int* pending, hipStream_t s);
+hipError_t k_quad_select_emit(const unsigned long long* keys, int nc, int w, int max_corners, const uint8_t* state, float* pts, int* nout, hipStream_t s);
 hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
 hipError_t k_quad_scharr(const uint8_t* src, int w, int h, int16_t* d, hipStream_t s);
 hipError_t k_quad_lk(const uint8_t* const* P, const uint8_t* const* N, const int16_t* const* D, const int* lw, const int* lh, const float* prev_pts, int n,
