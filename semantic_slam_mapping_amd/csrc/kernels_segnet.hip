@@ -2,10 +2,12 @@
 // /root/reference/src/segnet.cpp:87-108: net_->ForwardPrefilled()) for the driving_webdemo network: VGG-16 encoder
 // (13 conv3x3 pad 1 + BN + ReLU, 5 max-pool 2x2 s2 CEIL with arg-max mask), mirrored decoder (5 mask-driven Upsample,
 // 13 conv), last conv -> 12 classes, ArgMax.  This is the ONLY place on the path where MFMA is used:
-//   conv = implicit GEMM  M = pixels, N = Cout, K = 9 * Cin  on v_mfma_f32_32x32x16_f16 (fp16 storage, fp32 accumulate),
-//   activations fp16 in channel-chunked layout [C/32][H][W][32] and weights pre-packed per (Cout tile, Cin chunk) so that
-//   every staging load of the LDS-tiled kernel is a contiguous 16-byte read; a lane's 8-element K fragment is one
-//   ds_read_b128; BN (folded scale/shift) + ReLU fused into the epilogue.
+//   conv = implicit GEMM  D[cout][pixel] += W[cout][k] X[k][pixel], k = (tap, Cin), on v_mfma_f32_32x32x16_f16 (fp16 storage,
+//   fp32 accumulate); activations fp16 in channel-chunked layout [n][C/32][H][W][32] and weights pre-packed per (Cout tile,
+//   Cin chunk) so that every staging transfer is a contiguous 16-byte piece and a lane's 8-element K fragment is one
+//   ds_read_b128; operands reach LDS by buffer_load .. lds (LDS-DMA) in a persistent, double-buffered kernel; BN (folded
+//   scale/shift) + ReLU, the 2x2 max-pool with its arg-max codes and the final class ArgMax are epilogue variants
+//   (DESIGN.md s.4.1).
 // Also here: Classifier::Preprocess (segnet.cpp:130-167; cv::resize to 480x360, planar float, mean 0) and the label
 // colouring of experiment/segnet.cpp:80-83,131-146 (Pavement->Road remap, cv::resize back to the frame size, cv::LUT).
 #include "ssm_internal.h"
