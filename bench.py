@@ -58,6 +58,19 @@ def measured_traffic(stage, frames_per_launch):
         return None
 
 
+def measured_valu(stage, us_per_frame):
+    """VALU issue rate of a stage: wave-instructions per frame from the committed rocprofv3 SQ pass (profiles/r01_sq_counters.json)
+    x 64 lanes / the stage time measured now, against the measured integer issue ceiling (VALU_LANEOPS_PEAK), or None"""
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_counters.json")))["kernels"]
+        insts = sum(v["valu_wave_insts_per_frame"] for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage]))
+        ach = insts * 64 / (us_per_frame * 1e-6) / 1e12
+        return {"achieved": round(ach, 2), "peak": VALU_LANEOPS_PEAK / 1e12, "unit": "Tlaneop/s", "frac": round(ach / (VALU_LANEOPS_PEAK / 1e12), 3),
+                "wave_insts_per_frame": round(insts)}
+    except Exception:
+        return None
+
+
 def stereo_main(args):
     """configs[3]: KITTI-geometry stereo (1241 x 376, synthetic rectified pairs): per frame the quad matcher on (lc, rc, lp, rp),
     SGBM depth on (lc, rc) and the stereo visual odometry on the quad matches.  These stages take host images (the reference
@@ -284,6 +297,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, frames_per_launch),
                     "algorithmic_bytes_per_launch": round(gb * 1e9),
                     "note": "integer/byte kernel limited by VALU issue (measured 36 T lane-op/s) and LDS, not HBM: see DESIGN.md s.4"}
+        if roof.get("bound") == "hbm":
+            roof["valu"] = measured_valu(dom, per_stage[dom][1])      # what actually bounds the integer stages
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
         roof["stages_us_per_frame_overlapped"] = {k: round(v[0] / args.steps / F * 1e3, 3) for k, v in sorted(stage_ovl.items(), key=lambda kv: -kv[1][0])}
         roof["timing"] = ("achieved / stages_us_per_frame: hipEvents around each stage in a second pass of the same K steps with all stages "

@@ -22,6 +22,12 @@ def main():
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"]); ns[k] += dur.get(r["Dispatch_Id"], 0)
+    import json
+    frames = int(sys.argv[4]) if len(sys.argv) > 4 else 2000            # frames processed in the profiled run
+    js = {"note": "rocprofv3 --pmc SQ_INSTS_VALU per kernel: wave-instructions; x64 = lane-ops", "frames_in_run": frames, "kernels": {}}
+    for k, c in agg.items():
+        js["kernels"][k] = {"valu_wave_insts_per_frame": c["SQ_INSTS_VALU"] / frames, "waves_per_frame": c["SQ_WAVES"] / frames}
+    json.dump(js, open(dst.rsplit(".", 1)[0] + ".json", "w"), indent=1)
     with open(dst, "w") as o:
         o.write(f"# {title}\n\nper-wave averages; clock = SQ_BUSY_CYCLES / 32 / duration; `VALU IPC/SIMD` = SQ_INSTS_VALU / (duration x clock x 1024 SIMDs); "
                 "the issue ceiling measured by scripts/ubench/valu_rate.hip is ~0.25 (one wave64 integer op per 4 clk per SIMD)\n\n")
