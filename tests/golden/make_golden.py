@@ -120,6 +120,42 @@ def g_quad():
                         edge_pts=edge, edge_next=e_out, edge_status=e_st, edge_err=e_err)
 
 
+def g_segnet():
+    """G6: SegNet building blocks from PyTorch-CPU fp32 on small seeded integer-valued tensors, on which
+    fp16 storage / fp32 accumulation is exact: conv3x3 pad 1 + folded BN + ReLU for five layer shapes (incl. the 3-channel
+    first and the 12-channel last layer, odd sizes), max_pool2d(2, 2, ceil_mode, return_indices), max_unpool2d(output_size),
+    channel arg-max with first-maximum ties."""
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from semantic_slam_mapping_amd.segnet_model import LAYERS
+    out = {}
+    for layer, h, w in ((0, 21, 34), (1, 23, 30), (3, 12, 15), (12, 17, 33), (25, 31, 17)):
+        cin, cout = LAYERS[layer][:2]
+        rng = np.random.default_rng(9000 + layer)
+        wt = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
+        sc = (2.0 ** rng.integers(-7, -4, cout)).astype(np.float32); sh = rng.integers(-3, 4, cout).astype(np.float32)
+        x = rng.integers(-4, 5, (h, w, cin)).astype(np.float32)
+        y = F.conv2d(torch.from_numpy(x.transpose(2, 0, 1))[None], torch.from_numpy(wt), padding=1)[0].numpy() * sc[:, None, None] + sh[:, None, None]
+        if layer != len(LAYERS) - 1:
+            y = np.maximum(y, 0)
+        y16 = y.transpose(1, 2, 0).astype(np.float16)
+        assert np.array_equal(y16.astype(np.float32), y.transpose(1, 2, 0)), "fixture must be exact in fp16"
+        k = f"conv{layer}_"
+        out[k + "w"] = wt.astype(np.int8); out[k + "scale_log2"] = np.log2(sc).astype(np.int8); out[k + "shift"] = sh.astype(np.int8)
+        out[k + "x"] = x.astype(np.int8); out[k + "y"] = y16
+    for name, h, w, c in (("a", 23, 30, 64), ("b", 5, 7, 96)):
+        rng = np.random.default_rng(9100 + h)
+        x = rng.integers(-3, 4, (h, w, c)).astype(np.float32)
+        xt = torch.from_numpy(x.transpose(2, 0, 1))[None]
+        p, idx = F.max_pool2d(xt, 2, 2, ceil_mode=True, return_indices=True)
+        u = F.max_unpool2d(p, idx, 2, 2, output_size=(h, w))
+        out[f"pool_{name}_x"] = x.astype(np.int8); out[f"pool_{name}_y"] = p[0].numpy().transpose(1, 2, 0).astype(np.int8)
+        out[f"pool_{name}_idx"] = idx[0].numpy().transpose(1, 2, 0).astype(np.int32)      # flat index h*W + w of the (first) maximum
+        out[f"pool_{name}_unpool"] = u[0].numpy().transpose(1, 2, 0).astype(np.int8)
+    np.savez_compressed(os.path.join(HERE, "segnet.npz"), **out)
+
+
 if __name__ == "__main__":
-    g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad()
+    g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad(); g_segnet()
     print("golden fixtures written to", HERE)

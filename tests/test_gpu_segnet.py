@@ -91,6 +91,30 @@ def test_conv_pool_fused_exact(ctx, layer, h, w):
     assert np.array_equal(c, c_ref)
 
 
+def test_segnet_blocks_against_committed_fixture(ctx, seg):
+    """G6 fixtures (tests/golden/segnet.npz, minted from PyTorch-CPU by make_golden.py): conv + BN + ReLU layers incl. the
+    3-channel first and the 12-channel last one, max-pool with first-maximum indices, mask-driven unpool -- bit for bit"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "segnet.npz"))
+    for layer in (0, 1, 3, 12, 25):
+        k = f"conv{layer}_"
+        cin, cout, _, _ = ctx.segnet_layers()[layer]
+        ctx.segnet_set_layer(layer, g[k + "w"].astype(np.float32), (2.0 ** g[k + "scale_log2"].astype(np.float32)), g[k + "shift"].astype(np.float32))
+        x = g[k + "x"].astype(np.float16); h, w, _ = x.shape
+        xp = np.zeros((h, w, (cin + 15) // 16 * 16), np.float16); xp[:, :, :cin] = x
+        assert np.array_equal(ctx.segnet_debug_conv(layer, xp), g[k + "y"]), f"layer {layer}"
+    for name in ("a", "b"):
+        x = g[f"pool_{name}_x"].astype(np.float16); h, w, c = x.shape
+        p, code = ctx.segnet_debug_pool(x)
+        assert np.array_equal(p, g[f"pool_{name}_y"].astype(np.float16))
+        ph, pw = p.shape[:2]
+        yy, xx = np.meshgrid(np.arange(ph), np.arange(pw), indexing="ij")
+        assert np.array_equal((2 * yy[:, :, None] + code // 2) * w + 2 * xx[:, :, None] + code % 2, g[f"pool_{name}_idx"])
+        assert np.array_equal(ctx.segnet_debug_unpool(p, code, h, w), g[f"pool_{name}_unpool"].astype(np.float16))
+    for l, (wt, sc, sh) in enumerate(seg):                      # restore the seeded weights for the tests that follow
+        ctx.segnet_set_layer(l, wt, sc, sh)
+
+
 @pytest.mark.parametrize("h,w,c", [(45, 60, 32), (23, 30, 64), (8, 8, 32), (5, 7, 96)])
 def test_pool_unpool_exact(ctx, seg, h, w, c):
     """2x2 s2 CEIL max-pool with first-maximum arg-max code, and the mask-driven Upsample with explicit (odd) output size"""

@@ -210,3 +210,28 @@ def test_quad_golden(oracle):
     assert good.sum() >= 8 and np.abs((g["gftt_40_0p04_8"][:12] - nxt)[good][:, 0] - 5.0).max() < 0.3      # the 5-px disparity is recovered
     nxt, st, err = oracle.lk_track(lc, rc, g["edge_pts"])
     assert np.array_equal(st, g["edge_status"]) and nxt.tobytes() == g["edge_next"].tobytes() and err.tobytes() == g["edge_err"].tobytes()
+
+
+def test_segnet_block_fixture_is_self_consistent():
+    """G6: tests/golden/segnet.npz (PyTorch-CPU fp32 on integer data).  Checked here without a GPU: the recorded pooling
+    indices are the FIRST maximum of each clipped 2x2 window in row-major order (Caffe's rule; tests/test_gpu_segnet.py
+    compares the kernels with these tensors), the unpooled tensor scatters exactly those, conv outputs are fp16-exact."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "segnet.npz"))
+    for name in ("a", "b"):
+        x = g[f"pool_{name}_x"].astype(np.int32); p = g[f"pool_{name}_y"].astype(np.int32); idx = g[f"pool_{name}_idx"]
+        h, w, c = x.shape; ph, pw = (h + 1) // 2, (w + 1) // 2
+        assert p.shape == (ph, pw, c)
+        first = np.full((ph, pw, c), -1); best = np.full((ph, pw, c), -10 ** 6)
+        yy, xx = np.meshgrid(np.arange(ph), np.arange(pw), indexing="ij")
+        for dy, dx in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            ys, xs = 2 * yy + dy, 2 * xx + dx
+            ok = (ys < h) & (xs < w)
+            v = np.where(ok[:, :, None], x[np.minimum(ys, h - 1), np.minimum(xs, w - 1)], -10 ** 6)
+            better = v > best
+            first = np.where(better, (ys * w + xs)[:, :, None], first); best = np.where(better, v, best)
+        assert np.array_equal(best, p) and np.array_equal(first, idx)
+        u = np.zeros((h * w, c), np.int32); np.put_along_axis(u, idx.reshape(-1, c), p.reshape(-1, c), axis=0)
+        assert np.array_equal(u.reshape(h, w, c), g[f"pool_{name}_unpool"].astype(np.int32))
+    for layer in (0, 1, 3, 12, 25):
+        y = g[f"conv{layer}_y"]
+        assert y.dtype == np.float16 and np.isfinite(y).all() and (layer == 25 or (y >= 0).all())
