@@ -9,19 +9,21 @@
 //   sgbm_pixcost     BT cost of (y, x, d), gradient plane + raw plane / 4                              -> u8 volume
 //   sgbm_hbox/vbox   the SAD window as a separable box sum with OpenCV's replicate borders (+ P2, + the two 2.4 quirks:
 //                    column 0 keeps row 0's cost, rows past height-1-SH2 keep the last full window)     -> C, u16 volume
-//   sgbm_path<...>   one scan direction r: L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d+-1) + P1, min_k L_r(p-r,k) + P2)
-//                    - min_k L_r(p-r,k).  A PATH (a row for r = (-1,0); a column or diagonal for the three directions that
-//                    come from the previous row) is owned by 16 lanes = one DPP row, each lane K = D/16 consecutive
+//   sgbm_path<K,M>   one scan direction r: L_r(p,d) = C(p,d) + min(L_r(p-r,d), L_r(p-r,d+-1) + P1, min_k L_r(p-r,k) + P2)
+//                    - min_k L_r(p-r,k).  A PATH (a row for r = (-1,0) and (+1,0); a column or diagonal for the three directions
+//                    that come from the previous row) is owned by 16 lanes = one DPP row, each lane K = D/16 consecutive
 //                    disparities: the d+-1 neighbours cross lanes by row_shr/row_shl, min_k by four row_ror steps -- no LDS,
-//                    no barrier in the recurrence.  Paths are independent, so a direction is one launch of (#paths x 16)
-//                    threads that runs its own sequential loop; S += L_r with a saturating add (all terms are >= 0, so
-//                    the progressive saturation equals OpenCV's saturate_cast of the four-term sum).
-//   sgbm_wta         per row, right to left like OpenCV: the fifth direction r = (+1,0) on the fly, S += L, winner, uniqueness
-//                    ratio, the right-image disparity table (disp2), sub-pixel parabola; then the left-right check
+//                    no barrier in the recurrence.  Paths are independent and every direction writes its own L volume, so the
+//                    five directions are five launches on five streams, each (#paths x 16) threads running its own loop.
+//   sgbm_wta         one pixel per 16 lanes, all pixels in parallel: S = min(32767, sum of the five L) (terms >= 0: equal to
+//                    OpenCV's two saturate_casts), first minimum, uniqueness ratio, sub-pixel parabola; the right-image table
+//                    OpenCV fills while walking right to left becomes an atomicMin on (cost, x) keys
+//   sgbm_lrcheck     the left-right consistency check on both roundings of the disparity
 //   sgbm_median3, sgbm_speckle_* (connected components by union-find), sgbm_depth
 // HBM-bound by design (about a GB of volume traffic per 1241x376x80 frame); no MFMA.
 #include "ssm_internal.h"
 #include <climits>
+#include <mutex>
 
 #define SG_MAXC 32767
 #define SG_DISP_SHIFT 4
@@ -120,15 +122,17 @@ __device__ __forceinline__ void sg_step(int (&L)[K], int& minPrev, const int (&C
 #pragma unroll
     for (int k = 0; k < K; k++) L[k] = Ln[k];
 }
-// MODE 0: r = (-1, 0): path = row y, steps x = 0..w1-1, S = L (first direction written)
-// MODE 1..3: r = (-1,-1), (0,-1), (+1,-1): path = diagonal / column, steps y = 0..h-1, S = sat(S + L)
+// MODE 0: r = (-1, 0): path = row y, steps x = 0 .. w1-1        MODE 4: r = (+1, 0): path = row y, steps x = w1-1 .. 0
+// MODE 1..3: r = (-1,-1), (0,-1), (+1,-1): path = diagonal / column, steps y = 0 .. h-1
+// Every direction writes its own L volume: the five launches share nothing but C and run concurrently on five streams.
 template <int K, int MODE>
 __global__ void __launch_bounds__(256)
-sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w1, int h, int P1, int P2)
+sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, int h, int P1, int P2)
 {
     constexpr int D = 16 * K;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
-    const int npaths = MODE == 0 ? h : (MODE == 2 ? w1 : w1 + h - 1);
+    constexpr bool ROW = MODE == 0 || MODE == 4;
+    const int npaths = ROW ? h : (MODE == 2 ? w1 : w1 + h - 1);
     const bool live = g < npaths;                             // dead groups run the loop too (DPP wants the whole wave), clamped to path 0
     const int gp = live ? g : 0;
     const int rx = MODE == 1 ? 1 : MODE == 3 ? -1 : 0;        // x(y) = o + rx * y
@@ -136,9 +140,36 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w1, int 
     int L[K], minPrev = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) L[k] = 0;
-    const int steps = MODE == 0 ? w1 : h;
+    const int steps = ROW ? w1 : h;
+    if (ROW) {
+        // a row path walks contiguous memory: the costs of SG_UNR steps are loaded together, then the SG_UNR dependent steps
+        // run from registers (one memory latency per group instead of one per step)
+        constexpr int SG_UNR = 8;
+        for (int t0 = 0; t0 < steps; t0 += SG_UNR) {
+            int Cq[SG_UNR][K];
+#pragma unroll
+            for (int u = 0; u < SG_UNR; u++) {
+                const int t = min(t0 + u, steps - 1), x = MODE == 0 ? t : w1 - 1 - t;
+                const size_t base = ((size_t)gp * w1 + x) * D + li * K;
+#pragma unroll
+                for (int k = 0; k < K; k++) Cq[u][k] = C[base + k];
+            }
+#pragma unroll
+            for (int u = 0; u < SG_UNR; u++) {
+                const int t = t0 + u;
+                sg_step<K>(L, minPrev, Cq[u], P1, P2);           // (steps past the end recompute the last pixel; nothing is stored)
+                if (live && t < steps) {
+                    const int x = MODE == 0 ? t : w1 - 1 - t;
+                    const size_t base = ((size_t)gp * w1 + x) * D + li * K;
+#pragma unroll
+                    for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)L[k];
+                }
+            }
+        }
+        return;
+    }
     for (int t = 0; t < steps; t++) {
-        const int y = MODE == 0 ? gp : t, x = MODE == 0 ? t : o + rx * t;
+        const int y = ROW ? gp : t, x = MODE == 0 ? t : MODE == 4 ? w1 - 1 - t : o + rx * t;
         const bool in = x >= 0 && x < w1;
         if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
 #pragma unroll
@@ -159,79 +190,77 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w1, int 
             minPrev = mp;
             if (live) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    if (MODE == 0) S[base + k] = (uint16_t)Lc[k];
-                    else S[base + k] = (uint16_t)min((int)S[base + k] + Lc[k], SG_MAXC);
-                }
+                for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)Lc[k];
             }
         }
     }
 }
-// ------------------------------------------------------------------ winner-takes-all per row (16 lanes per row), then the left-right check
-// block = one wave = 4 rows; the three per-row tables (disp1, disp2, disp2cost) live in LDS while the row is being decided
+// ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
+// S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
+// disparity table OpenCV fills while walking x from right to left, replacing an entry only by a strictly smaller cost) becomes
+// an atomicMin on the key (cost << 16 | 65535 - x): smallest cost, then the larger x, i.e. the entry the walk would have kept.
 template <int K>
-__global__ void __launch_bounds__(64)
-sgbm_wta(const uint16_t* __restrict__ C, uint16_t* __restrict__ S, int w, int w1, int h, int minD, int minX1, int P1, int P2,
-         int uniquenessRatio, int disp12MaxDiff, int16_t* __restrict__ disp1)
+__global__ void __launch_bounds__(256)
+sgbm_wta(const uint16_t* __restrict__ L0, const uint16_t* __restrict__ L1, const uint16_t* __restrict__ L2, const uint16_t* __restrict__ L3,
+         const uint16_t* __restrict__ L4, int w, int w1, int h, int minD, int minX1, int uniquenessRatio, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key)
 {
     constexpr int D = 16 * K;
-    extern __shared__ int16_t sg_rows[];                      // [4 rows][3 tables][w]
-    __shared__ uint16_t srow[4][D];                           // S of the current pixel, for the three sub-pixel taps
-    const int gl = threadIdx.x >> 4, li = threadIdx.x & 15, g = blockIdx.x * 4 + gl;
-    const bool live = g < h;
-    const int y = live ? g : 0;
+    __shared__ uint16_t srow[16][D];                          // S of the group's pixel, for the three sub-pixel taps
+    const int gl = threadIdx.x >> 4, li = threadIdx.x & 15;
+    const long long gid = (long long)blockIdx.x * 16 + gl, npix = (long long)w1 * h;
+    const bool live = gid < npix;
+    const long long pid = live ? gid : 0;
+    const int y = (int)(pid / w1), x = (int)(pid - (long long)y * w1);
+    const size_t base = (size_t)pid * D + li * K;
+    int Sv[K], best = INT_MAX;                                 // (S << 8 | d): smallest S, then smallest d ("Sval < minS" scanning d upwards)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        Sv[k] = min((int)L0[base + k] + L1[base + k] + L2[base + k] + L3[base + k] + L4[base + k], SG_MAXC);
+        best = min(best, (Sv[k] << 8) | (li * K + k));
+        srow[gl][li * K + k] = (uint16_t)Sv[k];
+    }
+    best = sg_rowmin(best);
+    const int minS = best >> 8, bestDisp = best & 255;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
+    const unsigned long long bal = __ballot(bad);
+    const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;           // any lane of my 16-lane group
+    if (live && !rejected && li == 0) {
+        int d = bestDisp;
+        const int x2 = x + minX1 - d - minD;
+        if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));     // "disp2cost > minS" from MAX_COST
+        if (0 < d && d < D - 1) {
+            const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
+            const int denom2 = max(sm + sp - 2 * s0, 1);
+            d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+        } else d *= SG_DISP_SCALE;
+        disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+    }
+}
+// left-right check: the disparity rounded down and up must both disagree with the right-image table to be dropped
+__global__ void __launch_bounds__(256)
+sgbm_lrcheck(const int16_t* __restrict__ disp1, const unsigned* __restrict__ disp2key, int w, int w1, int minD, int minX1, int disp12MaxDiff, int16_t* __restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
     const int INVALID = (minD - 1) * SG_DISP_SCALE;
-    int16_t *d1 = sg_rows + (size_t)gl * 3 * w, *d2 = d1 + w, *d2c = d2 + w;
-    for (int x = li; x < w; x += 16) { d1[x] = (int16_t)INVALID; d2[x] = (int16_t)INVALID; d2c[x] = (int16_t)SG_MAXC; }
-    int L[K], minPrev = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) L[k] = 0;
-    for (int x = w1 - 1; x >= 0; x--) {
-        const size_t base = ((size_t)y * w1 + x) * D + li * K;
-        int Cp[K], Sv[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) { Cp[k] = C[base + k]; Sv[k] = S[base + k]; }
-        sg_step<K>(L, minPrev, Cp, P1, P2);                    // r = (+1, 0): the predecessor is the pixel to the right
-        int best = INT_MAX;                                    // (S << 8 | d): smallest S, then smallest d ("Sval < minS" scanning d upwards)
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            Sv[k] = min(Sv[k] + L[k], SG_MAXC);
-            best = min(best, (Sv[k] << 8) | (li * K + k));
-            srow[gl][li * K + k] = (uint16_t)Sv[k];
-        }
-        best = sg_rowmin(best);
-        const int minS = best >> 8, bestDisp = best & 255;
-        bool bad = false;
-#pragma unroll
-        for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
-        const unsigned long long bal = __ballot(bad);
-        const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;       // any lane of my 16-lane row
-        if (!rejected && li == 0) {
-            int d = bestDisp;
-            const int x2 = x + minX1 - d - minD;
-            if (d2c[x2] > minS) { d2c[x2] = (int16_t)minS; d2[x2] = (int16_t)(d + minD); }
-            if (0 < d && d < D - 1) {
-                const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
-                const int denom2 = max(sm + sp - 2 * s0, 1);
-                d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
-            } else d *= SG_DISP_SCALE;
-            d1[x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
-        }
+    const unsigned* k2 = disp2key + (size_t)y * w;
+    auto disp2 = [&](int xx) -> int {                          // the disparity the winning pixel assigned to right-image column xx
+        const unsigned key = k2[xx];
+        if (key == 0xFFFFFFFFu) return INVALID;
+        const int xw = 65535 - (int)(key & 0xFFFFu);
+        return xw + minX1 - xx;                               // x2 = x + minX1 - d - minD  =>  d + minD = x + minX1 - x2
+    };
+    int v = disp1[(size_t)y * w + x];
+    if (x >= minX1 && x < minX1 + w1 && v != INVALID) {
+        const int _d = v >> SG_DISP_SHIFT, d_ = (v + SG_DISP_SCALE - 1) >> SG_DISP_SHIFT;
+        const int _x = x - _d, x_ = x - d_;
+        if (0 <= _x && _x < w && disp2(_x) >= minD && abs(disp2(_x) - _d) > disp12MaxDiff &&
+            0 <= x_ && x_ < w && disp2(x_) >= minD && abs(disp2(x_) - d_) > disp12MaxDiff)
+            v = INVALID;
     }
-    __syncthreads();
-    // left-right check: the disparity rounded down and up must both disagree with the right-image table to be dropped
-    const int maxX1 = minX1 + w1;
-    for (int x = li; x < w; x += 16) {
-        int v = d1[x];
-        if (x >= minX1 && x < maxX1 && v != INVALID) {
-            const int _d = v >> SG_DISP_SHIFT, d_ = (v + SG_DISP_SCALE - 1) >> SG_DISP_SHIFT;
-            const int _x = x - _d, x_ = x - d_;
-            if (0 <= _x && _x < w && d2[_x] >= minD && abs(d2[_x] - _d) > disp12MaxDiff &&
-                0 <= x_ && x_ < w && d2[x_] >= minD && abs(d2[x_] - d_) > disp12MaxDiff)
-                v = INVALID;
-        }
-        if (live) disp1[(size_t)y * w + x] = (int16_t)v;
-    }
+    out[(size_t)y * w + x] = (int16_t)v;
 }
 // ------------------------------------------------------------------ cv::medianBlur 3x3 (int16, replicate border)
 __global__ void __launch_bounds__(256)
@@ -344,17 +373,45 @@ sgbm_depth(const int16_t* __restrict__ disp, int w, int h, const int* __restrict
 __global__ void __launch_bounds__(256)
 sgbm_fill(int16_t* __restrict__ p, int n, int16_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 // ------------------------------------------------------------------ launcher
+// side streams for the five concurrent scan directions (created once per process; every call forks them from and joins them
+// into the caller's stream by events, so calls on one context stay ordered)
+struct SgStreams { hipStream_t s[4]; hipEvent_t fork, done[4]; bool ok = false; };
+static SgStreams& sg_streams()
+{
+    static SgStreams st;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        bool ok = hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++)
+            ok = hipStreamCreateWithFlags(&st.s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) == hipSuccess;
+        st.ok = ok;
+    });
+    return st;
+}
 template <int K>
-static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* S, int w, int w1, int h, const ssm_sgbm_params& p, int minX1, int P1, int P2,
-                                 int16_t* disp1, hipStream_t s)
+static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, const ssm_sgbm_params& p, int minX1, int P1, int P2,
+                                 int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, hipStream_t s)
 {
     auto blocks = [](int paths) { return (paths * 16 + 255) / 256; };
-    sgbm_path<K, 0><<<blocks(h), 256, 0, s>>>(C, S, w1, h, P1, P2);
-    sgbm_path<K, 1><<<blocks(w1 + h - 1), 256, 0, s>>>(C, S, w1, h, P1, P2);
-    sgbm_path<K, 2><<<blocks(w1), 256, 0, s>>>(C, S, w1, h, P1, P2);
-    sgbm_path<K, 3><<<blocks(w1 + h - 1), 256, 0, s>>>(C, S, w1, h, P1, P2);
-    sgbm_wta<K><<<(h + 3) / 4, 64, (size_t)4 * 3 * w * sizeof(int16_t), s>>>(C, S, w, w1, h, p.minDisparity, minX1, P1, P2, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10,
-                                                                              p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
+    SgStreams& st = sg_streams();
+    if (!st.ok) return hipErrorUnknown;
+    hipError_t e = hipEventRecord(st.fork, s);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st.s[i], st.fork, 0);
+    if (e != hipSuccess) return e;
+    sgbm_path<K, 0><<<blocks(h), 256, 0, s>>>(C, Lv[0], w1, h, P1, P2);
+    sgbm_path<K, 4><<<blocks(h), 256, 0, st.s[0]>>>(C, Lv[4], w1, h, P1, P2);
+    sgbm_path<K, 1><<<blocks(w1 + h - 1), 256, 0, st.s[1]>>>(C, Lv[1], w1, h, P1, P2);
+    sgbm_path<K, 2><<<blocks(w1), 256, 0, st.s[2]>>>(C, Lv[2], w1, h, P1, P2);
+    sgbm_path<K, 3><<<blocks(w1 + h - 1), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipEventRecord(st.done[i], st.s[i]); if (e == hipSuccess) e = hipStreamWaitEvent(s, st.done[i], 0); }
+    if (e != hipSuccess) return e;
+    const size_t np = (size_t)w * h;
+    sgbm_fill<<<(int)((np + 255) / 256), 256, 0, s>>>(disp_tmp, (int)np, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
+    e = hipMemsetAsync(disp2key, 0xFF, np * 4, s);
+    if (e != hipSuccess) return e;
+    const long long npix = (long long)w1 * h;
+    sgbm_wta<K><<<(unsigned)((npix + 15) / 16), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
+    sgbm_lrcheck<<<dim3((w + 255) / 256, h), 256, 0, s>>>(disp_tmp, disp2key, w, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
 size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p)
@@ -362,7 +419,7 @@ size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p)
     const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
     const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities, np = (size_t)w * h;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(12 * np) + al(vol) + 3 * al(vol * 2) + al(np * 2) + 2 * al(np * 4) + 256;
+    return al(12 * np) + al(vol) + 7 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256;
 }
 // left / right: device u8 images [h][w]; disp_out: device int16 [h][w] (x16 fixed point, (minD-1)*16 = invalid)
 hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
@@ -385,8 +442,11 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const
     uint8_t* pix = q; q += al(vol);
     uint16_t* hs = (uint16_t*)q; q += al(vol * 2);
     uint16_t* C = (uint16_t*)q; q += al(vol * 2);
-    uint16_t* S = (uint16_t*)q; q += al(vol * 2);
+    uint16_t* Lv[5];
+    for (int i = 0; i < 5; i++) { Lv[i] = (uint16_t*)q; q += al(vol * 2); }
     int16_t* d_raw = (int16_t*)q; q += al(np * 2);
+    int16_t* d_tmp = (int16_t*)q; q += al(np * 2);
+    unsigned* d2key = (unsigned*)q; q += al(np * 4);
     int* parent = (int*)q; q += al(np * 4);
     int* count = (int*)q; q += al(np * 4);
     const dim3 gimg((w + 255) / 256, h), gvol((w1 * D + 255) / 256, h);
@@ -398,13 +458,13 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
     switch (D / 16) {
-        case 1: e = sgbm_aggregate<1>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 2: e = sgbm_aggregate<2>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 3: e = sgbm_aggregate<3>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 4: e = sgbm_aggregate<4>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 5: e = sgbm_aggregate<5>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 6: e = sgbm_aggregate<6>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
-        case 8: e = sgbm_aggregate<8>(C, S, w, w1, h, p, minX1, P1, P2, wta_out, s); break;
+        case 1: e = sgbm_aggregate<1>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 2: e = sgbm_aggregate<2>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 3: e = sgbm_aggregate<3>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 4: e = sgbm_aggregate<4>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 5: e = sgbm_aggregate<5>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 6: e = sgbm_aggregate<6>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 8: e = sgbm_aggregate<8>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess || raw_only == 1) return e;
