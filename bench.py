@@ -261,6 +261,24 @@ def main():
             a[0] += ms; a[1] += ln
     fence()
     ctx.set_profiling(0)
+    # ---- PCIe-inclusive rate (reported beside `value`, never as `value`): the same steps with the frames copied from pinned
+    # host memory to the device inside the timed region (bgr + depth + labels + pose = 2.46 MB per frame)
+    h2d_fps = None
+    if world == 1 and not args.segnet and os.environ.get("SSM_BENCH_H2D", "1") == "1":
+        try:
+            hb = [t.cpu().pin_memory() for t in (bgr, dep, sem, pose)]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(1, min(args.steps, 3))):
+                for src, dst in zip(hb, (bgr, dep, sem, pose)):
+                    dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize()                   # the context stream is not torch's: order the copies before the kernels
+                step()
+            torch.cuda.synchronize()
+            h2d_fps = F * max(1, min(args.steps, 3)) / (time.perf_counter() - t1)
+            del hb
+        except Exception:
+            h2d_fps = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,6 +344,7 @@ def main():
                                     "5 ref frames, leaf %.2f m" % args.leaf),
                        "frames_per_gpu": F, "batch_frames": args.batch, "parallelism": "frame-block x%d + voxel-table all-gather" % world if world > 1 else "single GPU"},
             "mpoints_per_s": round(world * P_total * args.steps / dt / 1e6, 2),
+            "frames_per_s_including_h2d": None if h2d_fps is None else round(h2d_fps, 1),
             "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},
             "roofline": roof, "cpu_baseline": cpu,
         }
