@@ -222,6 +222,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return v;
 }
+// three-input min / max in one instruction (the compiler shares pairwise minima between neighbouring arcs instead, which costs
+// twice the instructions on this pattern)
+__device__ __forceinline__ int imin3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
 {
     const int v = p[0];
@@ -230,20 +234,19 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
     d[4] = p[3] - v;         d[5] = p[-st+3] - v;    d[6] = p[-2*st+2] - v;  d[7] = p[-3*st+1] - v;
     d[8] = p[-3*st] - v;     d[9] = p[-3*st-1] - v;  d[10] = p[-2*st-2] - v; d[11] = p[-st-3] - v;
     d[12] = p[-3] - v;       d[13] = p[st-3] - v;    d[14] = p[2*st-2] - v;  d[15] = p[3*st-1] - v;
+    // min / max over every 9-arc as (3 of 3): 4 x 16 three-input ops, then the max over the 16 arcs
     int mn3[16], mx3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn3[k] = min(d[k], min(d[(k+1)&15], d[(k+2)&15]));
-        mx3[k] = max(d[k], max(d[(k+1)&15], d[(k+2)&15]));
-    }
-    int bright = -256, dark = -256;      // bright ring: min(ring - v); dark ring: min(v - ring) = -max(ring - v)
+    for (int k = 0; k < 16; k++) { mn3[k] = imin3(d[k], d[(k+1)&15], d[(k+2)&15]); mx3[k] = imax3(d[k], d[(k+1)&15], d[(k+2)&15]); }
+    int mn9[16], mx9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int mn9 = min(mn3[k], min(mn3[(k+3)&15], mn3[(k+6)&15]));
-        const int mx9 = max(mx3[k], max(mx3[(k+3)&15], mx3[(k+6)&15]));
-        bright = max(bright, mn9); dark = max(dark, -mx9);
-    }
-    return max(bright, dark);
+    for (int k = 0; k < 16; k++) { mn9[k] = imin3(mn3[k], mn3[(k+3)&15], mn3[(k+6)&15]); mx9[k] = imax3(mx3[k], mx3[(k+3)&15], mx3[(k+6)&15]); }
+    // bright ring: max over arcs of min(ring - v); dark ring: max over arcs of min(v - ring) = -(min over arcs of max(ring - v))
+    int bright = imax3(mn9[0], mn9[1], mn9[2]), dark = imin3(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) { bright = imax3(bright, mn9[k], mn9[k+1]); dark = imin3(dark, mx9[k], mx9[k+1]); }
+    bright = max(bright, mn9[15]); dark = min(dark, mx9[15]);
+    return max(bright, -dark);
 }
 #define FT_W 128
 #define FT_H 32
