@@ -164,13 +164,14 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         const int ly = i >> 5, lq = i & 31;
         const uint32_t* r = reinterpret_cast<const uint32_t*>(in + ly * BT_PW) + lq;     // dwords at x-4, x, x+4
         const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
-        int b[10];
-        b[0] = (d0 >> 8) & 255; b[1] = (d0 >> 16) & 255; b[2] = d0 >> 24;
-        b[3] = d1 & 255; b[4] = (d1 >> 8) & 255; b[5] = (d1 >> 16) & 255; b[6] = d1 >> 24;
-        b[7] = d2 & 255; b[8] = (d2 >> 8) & 255; b[9] = (d2 >> 16) & 255;
+        // output k (pixel x + k) is the 7-tap dot product of the bytes x+k-3 .. x+k+3 = bytes k+1 .. k+7 of (d0, d1, d2):
+        // two v_dot4_u32_u8 on the byte-aligned dwords (taps 18 34 49 55 | 49 34 18 0)
+        const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
         uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = 18 * (b[k] + b[k+6]) + 34 * (b[k+1] + b[k+5]) + 49 * (b[k+2] + b[k+4]) + 55 * b[k+3];
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), TB, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), TB, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), TB, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(d1, TA, __builtin_amdgcn_udot4(d2, TB, 0u, false), false);
         reinterpret_cast<uint2*>(hp + ly * BT_W)[lq] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
     __syncthreads();
@@ -179,13 +180,23 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         const int ly = i >> 5, lq = i & 31;
         const int gx = tx0 + 4 * lq, gy = ty0 + ly;
         if (gx >= stride || gy >= h) continue;
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const int taps[7] = {18, 34, 49, 55, 49, 34, 18};
+        // column pass: rows are paired (k, k+1) per pixel with v_perm and reduced by v_dot2_u32_u16 (two taps per instruction)
+        typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+        auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false); };
+        uint2 v[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const uint2 v = reinterpret_cast<const uint2*>(hp + (ly + k) * BT_W)[lq];
-            acc[0] += taps[k] * (v.x & 0xFFFF); acc[1] += taps[k] * (v.x >> 16); acc[2] += taps[k] * (v.y & 0xFFFF); acc[3] += taps[k] * (v.y >> 16);
+        for (int k = 0; k < 7; k++) v[k] = reinterpret_cast<const uint2*>(hp + (ly + k) * BT_W)[lq];
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const uint32_t T2[3] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16)};       // taps of rows (0,1), (2,3), (4,5); row 6: 18
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint2 a = v[2 * k], b = v[2 * k + 1];
+            acc[0] = dot2(__builtin_amdgcn_perm(b.x, a.x, 0x05040100u), T2[k], acc[0]);         // (a.lo, b.lo)
+            acc[1] = dot2(__builtin_amdgcn_perm(b.x, a.x, 0x07060302u), T2[k], acc[1]);         // (a.hi, b.hi)
+            acc[2] = dot2(__builtin_amdgcn_perm(b.y, a.y, 0x05040100u), T2[k], acc[2]);
+            acc[3] = dot2(__builtin_amdgcn_perm(b.y, a.y, 0x07060302u), T2[k], acc[3]);
         }
+        acc[0] += 18u * (v[6].x & 0xFFFF); acc[1] += 18u * (v[6].x >> 16); acc[2] += 18u * (v[6].y & 0xFFFF); acc[3] += 18u * (v[6].y >> 16);
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { const uint32_t q = min((acc[k] + 32768u) >> 16, 255u); out |= (gx + k < w ? q : 0u) << (8 * k); }
