@@ -296,3 +296,71 @@ def test_bench_line_and_allgather_path():
     assert line["value"] > 1000 and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 1
     assert line["per_frame"]["voxels_in_map"] > 500
+
+
+def test_full_size_properties_of_configs1(oracle):
+    """BASELINE.json configs[1] at its full size (1000 frames of 640x480 resident in HBM, 1000 keypoints, 5 reference
+    frames): size-independent properties instead of the oracle, which needs ~0.1 s per frame.
+      * batching is invisible: 8 launches of 125 frames and 13 ragged launches of 77(+76) give the same per-frame
+        keypoints / descriptors / match tables / point counts (a CRC per frame, then a CRC over the CRCs) and the same map;
+      * the map does not depend on frame order (exact integer voxel sums): batches fed last-to-first give the same voxels;
+      * sharding is exact: two half-sequence tables merged (the all-gather step of the multi-GPU path) == the whole;
+      * spot checks against the oracle inside the long run: ORB of frames 499 and 999, the match table 998 -> 999."""
+    import zlib
+    import semantic_slam_mapping_amd as ssm
+    N, W, H = 1000, 640, 480
+    c = ssm.Context(0, orb_features=1000, max_batch=125, voxel_capacity_log2=20, camera=CAM)
+    R = c.R
+    KEEP = (499, 998, 999); kept = {}
+    bufs = [c.dev_alloc(N * W * H * 3), c.dev_alloc(N * W * H * 2), c.dev_alloc(N * W * H * 3), c.dev_alloc(N * 128)]
+    off = (W * H * 3, W * H * 2, W * H * 3, 128)
+    try:
+        for s in range(0, N, 125):
+            c.synth_frames_dev(SEED, s, 125, *[b + s * o for b, o in zip(bufs, off)])
+
+        def run(batch, order=None, stages=0, fetch=True):
+            crcs = {}
+            starts = list(range(0, N, batch)) if order is None else order
+            for bi, s in enumerate(starts):
+                n = min(batch, N - s)
+                out = c.seq_process(*[b + s * o for b, o in zip(bufs, off)], n, continue_sequence=(order is None and bi > 0), stages=stages)
+                c.sync()
+                if not fetch:
+                    continue
+                res = c.seq_fetch(out, n)
+                for i in range(n):
+                    k = int(res["nkp"][i]); h = zlib.crc32(res["kps"][i, :k].tobytes()); h = zlib.crc32(res["desc"][i, :k].tobytes(), h)
+                    h = zlib.crc32(res["pos3d"][i, :k].tobytes(), h); h = zlib.crc32(res["nmatch"][i].tobytes(), h)
+                    for r in range(R):
+                        m = int(res["nmatch"][i, r])
+                        if m > 0:
+                            h = zlib.crc32(res["matches"][i, r, :m].tobytes(), h)
+                    crcs[s + i] = (h, k, int(res["npoints"][i]), tuple(int(v) for v in res["nmatch"][i]))
+                    if s + i in KEEP:
+                        kept[s + i] = (res["kps"][i, :k].copy(), res["desc"][i, :k].copy(), res["matches"][i, R - 1, :max(int(res["nmatch"][i, R - 1]), 0)].copy())
+            return crcs
+
+        c.map_clear(); a = run(125); map_a = c.map_export()
+        od = {}
+        for f in KEEP:
+            ok, od[f] = oracle.orb_extract(oracle.bgr2gray(oracle.synth_frame(SEED, f)[0]), nfeatures=c.cfg.orb_features)
+            assert same_struct(kept[f][0], ok) and np.array_equal(kept[f][1], od[f])
+        assert same_struct(kept[999][2], oracle.match(od[998], od[999], c.cfg.knn_match_ratio))
+        c.map_clear(); b = run(77); map_b = c.map_export()
+        assert sorted(a) == list(range(N)) and a == b
+        assert zlib.crc32(np.array([a[i][0] for i in range(N)], np.uint32).tobytes()) == zlib.crc32(np.array([b[i][0] for i in range(N)], np.uint32).tobytes())
+        assert same_struct(map_a, map_b) and len(map_a) > 10000
+        assert all(500 <= a[i][1] <= c.cfg.orb_features + 64 for i in range(N)) and all(a[i][2] > 50000 for i in range(N))
+        assert all(a[i][3][:R - min(i, R)] == (-1,) * (R - min(i, R)) and min(a[i][3][R - min(i, R):], default=1) > 0 for i in range(N))
+        # order independence of the map (map stage only, batches last to first)
+        c.map_clear(); run(125, order=list(range(N - 125, -1, -125)), stages=4, fetch=False)
+        assert same_struct(c.map_export(), map_a)
+        # two shards merged == whole (ssm_map_export_table / ssm_map_merge_table: the multi-GPU all-gather step)
+        c.map_clear(); run(125, order=[0, 125, 250, 375], stages=4, fetch=False); t0 = c.map_export_table()
+        c.map_clear(); run(125, order=[500, 625, 750, 875], stages=4, fetch=False); c.map_merge_table(t0)
+        assert same_struct(c.map_export(), map_a)
+        c.map_clear()
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
