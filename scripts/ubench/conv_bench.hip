@@ -36,7 +36,18 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps, fl = 2.0 * n * sh.H * sh.W * (double)sh.Cin * sh.Cout * 9;
-        printf("%3dx%3d %3d->%3d n=%d : %8.1f us  %7.1f TFLOP/s\n", sh.H, sh.W, sh.Cin, sh.Cout, n, us, fl / us * 1e-6);
+        double util = 0, ghz = 0;
+#ifdef SSM_CONV_ABLATE
+        {   // one more launch with the block-lifetime counter: MFMA utilisation in shader clocks, independent of the clock the chip holds
+            unsigned long long zero = 0, cyc = 0;
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_cycles), &zero, 8));
+            CK(k_segnet_conv(da, dw, dsc, dsf, dout, n, sh.H, sh.W, sh.Cin, sh.Cout, 1, 0));
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpyFromSymbol(&cyc, HIP_SYMBOL(g_conv_cycles), 8));
+            if (cyc) { util = fl / (double)cyc / 1048576.0; ghz = (double)cyc / us * 1e-3; }
+        }
+#endif
+        printf("%3dx%3d %3d->%3d n=%d : %8.1f us  %7.1f TFLOP/s  mfma-util %.3f  clock %.2f GHz\n", sh.H, sh.W, sh.Cin, sh.Cout, n, us, fl / us * 1e-6, util, ghz);
         // weights: the five shapes appear in the network with these multiplicities (Cin==Cout layers only; an approximation)
         tot_us += us; tot_fl += fl;
         hipFree(da); hipFree(dw); hipFree(dout); hipFree(dsc); hipFree(dsf);

@@ -338,6 +338,224 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
 #undef DT_TILE_OFFSETS
 }
 
+// ------------------------------------------------------------------ conv3x3, LDS-DMA staged, TWO independent 4-wave blocks per CU
+// Same tile (32 x 16 pixels x 64 output channels), same LDS images, same DMA scheme and the same epilogue as
+// conv3x3_dma_kernel, but
+//   * a block is 4 waves and a wave owns FOUR rows x 64 channels (8 accumulators): 6 fragment reads feed 8 MFMAs (was 4 : 4);
+//   * a stage is 16 input channels (one MFMA K step per tap, 9 steps of 8 MFMAs), 38 KB, so two stage buffers are 76 KB and
+//     TWO blocks share a CU.  Their barriers are independent: while one block is in its epilogue (BN, pack, stores) or waits
+//     at a barrier, the other block's waves keep the matrix cores busy.  With one 8-wave block all waves reach the epilogue
+//     together and the MFMA pipe idles for its whole length, which costs most on the 64- and 128-channel layers (2 and 4
+//     stages per tile).
+//   * the second half of the grid starts half a tile late so that the two blocks of a CU run out of phase.
+#ifdef SSM_CONV_ABLATE
+__device__ unsigned long long g_conv_cycles;     // scripts/ubench/conv_bench.hip: longest block lifetime in shader clocks
+#endif
+#define D2_AINS 20                            // input wave-instructions per stage (5 per wave; 1280 slots for 2 planes = 1224 chunks)
+#define D2_ACH (2 * DT_PLANE)
+#define D2_BCH (9 * 2 * CT_N)                 // 1152 chunks of weights per stage = 18 wave-instructions
+#define D2_STAGE (D2_AINS * 64 + D2_BCH)      // 2432 chunks = 38,912 B per LDS buffer
+template <bool RELU, int EPI, int NT>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
+                    _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
+{
+    __shared__ __attribute__((aligned(16))) half8 lds0[D2_STAGE];
+    __shared__ __attribute__((aligned(16))) half8 lds1[D2_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int VH = (H + 2) & ~1, VR = n * VH;
+    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
+    const int nchunks = Cin / CT_KC;
+    const unsigned plane_bytes = (unsigned)H * W * 64u;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
+    constexpr int BROW = 32 * NT;
+    constexpr int BINS = 9 * 2 * BROW / 64;                                        // weight wave-instructions per stage: 18 or 9
+    constexpr int BK = (BINS + 3) / 4;                                             // per wave: 5 or 3
+    constexpr int NSTORE = EPI == 2 ? 4 : 16;                                      // store instructions per tile epilogue
+    constexpr int WAIT_TILE = NSTORE == 16 ? 0x4F70 : 0x0F74;                      // s_waitcnt vmcnt(NSTORE) (vmcnt is split: bits 3:0 and 15:14)
+    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    if (tid < 2 * CT_N) {
+        const int ch = (blockIdx.x % ncout_tiles) * CT_N + (tid & (CT_N - 1));
+        s_ss[tid >> 6][tid & (CT_N - 1)] = ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+    }
+    unsigned a_off[5], b_off[5]; int b_j[5];
+    int a_py[5], a_px[5]; unsigned a_c8[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int i = (wv + 4 * k) * 64 + lane;
+        const int c8 = i / DT_PLANE, p = i - c8 * DT_PLANE;
+        a_py[k] = i < D2_ACH ? p / DT_PW : -0x10000;
+        a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
+        b_j[k] = min(wv + 4 * k, BINS - 1);
+        // packed weights: [tap][c8 of 4][cout 64][8]; a stage takes c8 = 2 half + {0, 1} (the half is in the scalar offset).
+        // LDS rows are (tap, c) x BROW couts; with NT = 1 a wave-instruction fills two rows with the first 32 couts of each
+        const int row = NT == 2 ? b_j[k] : 2 * b_j[k] + (lane >> 5);
+        b_off[k] = (unsigned)((((row >> 1) * 4 + (row & 1)) * 64) + (NT == 2 ? lane : (lane & 31))) * 16u;
+    }
+#define D2_TILE_OFFSETS(tile)                                                                           \
+    {   const int pt_ = (tile) / ncout_tiles;                                                           \
+        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
+            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
+            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
+            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u; \
+        } }
+#ifdef CT_ABL_NODMA
+#define D2_DMA_A(k, dst, so) asm volatile("" :: "v"(a_off[k]), "s"(so));
+#define D2_DMA_B(k, dst, so) asm volatile("" :: "v"(b_off[k]), "s"(so));
+#else
+#define D2_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 4 * (k)) * 64], 16, a_off[k], so, 0, 0);
+#define D2_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[D2_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
+#endif
+#ifdef CT_ABL_NOBAR
+#define D2_BARRIER()
+#else
+#define D2_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef SSM_CONV_ABLATE
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    int tile = blockIdx.x;
+    // phase shift between the two blocks of a CU (blocks i and i + gridDim/2 are dispatched to the same CU when the grid is
+    // 2 x CUs): about half of a tile's MFMA time
+    if (blockIdx.x >= (gridDim.x >> 1)) {
+        for (int i = 0; i < nchunks; i++) __builtin_amdgcn_s_sleep(36);       // 36 x 64 clk = one stage (72 MFMAs x 32 clk) per chunk
+    }
+    D2_TILE_OFFSETS(tile)
+    {
+        const unsigned bso = (unsigned)(tile % ncout_tiles) * nchunks * (DT_BCH * 16u);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { D2_DMA_A(k, lds0, 0u) if (k < BK) D2_DMA_B(k, lds0, bso) }
+        const uint4v z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 256 * k), 0, 0);
+    }
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
+        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
+        floatx16 acc[4][NT];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < NT; b++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+        // one stage: 9 steps (taps) of 4 NT MFMAs on buffer `rd`; the next stage's 10 DMA instructions (into `wr`) and the next
+        // step's fragment reads are issued ahead of each step's MFMAs
+#ifdef CT_ABL_NOREAD
+#define D2_READ_ALL 0
+#else
+#define D2_READ_ALL 1
+#endif
+#define D2_LOADF(rd, fbuf, st)                                                                          \
+        {   const int dy_ = (st) / 3, dx_ = (st) - dy_ * 3;                                                   \
+            const half8* pa_ = rd + hh * DT_PLANE + (4 * wv + dy_) * DT_PW + r + dx_;                         \
+            const half8* pb_ = rd + D2_AINS * 64 + ((st) * 2 + hh) * BROW + r;                                \
+            if (D2_READ_ALL || (st) < 2) {                                                                    \
+            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fa[fbuf][2] = pa_[2 * DT_PW]; fa[fbuf][3] = pa_[3 * DT_PW]; \
+            fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; } }
+#define D2_STAGE_BODY(rd, wr)                                                                           \
+        {   half8 fa[2][4], fb[2][NT];                                                                  \
+            D2_LOADF(rd, 0, 0)                                                                          \
+            _Pragma("unroll") for (int st = 0; st < 9; st++) {                                          \
+                const int cur = st & 1;                                                                 \
+                if (st < 5) D2_DMA_A(st, wr, a_so)                                                      \
+                if (st >= 5 && st - 5 < BK) D2_DMA_B(st - 5, wr, b_so)                                  \
+                if (st == 0 && BK == 5) D2_DMA_B(4, wr, b_so)                                           \
+                if (st + 1 < 9) D2_LOADF(rd, cur ^ 1, st + 1)                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                _Pragma("unroll") for (int tm_ = 0; tm_ < 4; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
+                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+            } }
+        // the two stages of one 32-channel chunk; the first chunk of a tile is written out separately because its wait differs
+        // (one merged path makes the compiler's own vmcnt bookkeeping pessimistic: it then drains the epilogue stores)
+#define D2_CHUNK(ck, WAITC)                                                                             \
+        {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
+            D2_BARRIER();                                                               \
+            const unsigned slab = ((unsigned)ct * nchunks + (ck)) * (DT_BCH * 16u);                     \
+            unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
+            D2_STAGE_BODY(lds0, lds1)                                                                   \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
+            D2_BARRIER();                                                               \
+            if ((ck) + 1 < nchunks) {                                                                   \
+                a_so = (unsigned)((ck) + 1) * plane_bytes;                                              \
+                b_so = slab + DT_BCH * 16u;                                                             \
+            } else {                                                                                    \
+                const int nt = tile + gridDim.x;                                                        \
+                D2_TILE_OFFSETS(nt)                                                                     \
+                a_so = 0u;                                                                              \
+                b_so = nt < total_tiles ? (unsigned)(nt % ncout_tiles) * nchunks * (DT_BCH * 16u) : 0x80000000u; \
+            }                                                                                           \
+            D2_STAGE_BODY(lds1, lds0) }
+        // the tile's first DMA batch is older than the NSTORE stores of the previous epilogue, which may stay in flight
+        D2_CHUNK(0, WAIT_TILE)
+        for (int ck = 1; ck < nchunks; ck++) D2_CHUNK(ck, 0x0F70)
+#undef D2_CHUNK
+#undef D2_STAGE_BODY
+#undef D2_LOADF
+        const int cout_chunks = (Cout + 31) >> 5;
+        const int gx = tx0 + r;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int v0 = ty0 + 4 * wv + 2 * half;                               // even row of the stacked image; VH is even, so y0 is even too
+            const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
+            const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
+            if constexpr (EPI == 2) {
+                // class ArgMax, see conv3x3_dma_kernel
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    _Float16 bv[2]; int bi[2];
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        const int c0 = 8 * g + 4 * hh;
+                        const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][c0]), sf = *reinterpret_cast<const float4*>(&s_ss[1][c0]);
+                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                        bv[g] = (_Float16)-65504.f; bi[g] = 255;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float val = acc[2 * half + tm][0][4 * g + q] * scv[q] + sfv[q];
+                            if (RELU) val = fmaxf(val, 0.f);
+                            const _Float16 hvq = (_Float16)val;
+                            if (c0 + q < Cout && (bi[g] == 255 || hvq > bv[g])) { bv[g] = hvq; bi[g] = c0 + q; }
+                        }
+                    }
+                    unsigned short vb; memcpy(&vb, &bv[0], 2);
+                    const unsigned mine = ((unsigned)vb << 8) | (unsigned)bi[0];
+                    const unsigned theirs = __builtin_amdgcn_permlane32_swap(mine, mine, false, false)[1];
+                    unsigned short tb = (unsigned short)(theirs >> 8); _Float16 tv; memcpy(&tv, &tb, 2);
+                    const int ti = (int)(theirs & 255u);
+                    _Float16 best = bv[0]; int lab = bi[0];
+                    if (ti != 255 && tv > best) { best = tv; lab = ti; }
+                    if (bi[1] != 255 && bv[1] > best) { best = bv[1]; lab = bi[1]; }
+                    const bool live = (tm ? live1 : live0) && hh == 0;
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lab, rsO, live ? (unsigned)((f * H + y0 + tm) * W + gx) : 0x80000000u, 0, 0);
+                }
+            } else {
+                floatx16 a2[2][2];
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+                    for (int tn = 0; tn < 2; tn++) a2[tm][tn] = acc[2 * half + tm][tn < NT ? tn : 0];
+                conv_epilogue<RELU, EPI>(a2, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
+            }
+        }
+    }
+#ifdef SSM_CONV_ABLATE
+    if (tid == 0) atomicMax(&g_conv_cycles, __builtin_amdgcn_s_memtime() - t_start);
+#endif
+#undef D2_DMA_A
+#undef D2_DMA_B
+#undef D2_BARRIER
+#undef D2_TILE_OFFSETS
+}
+
 // ------------------------------------------------------------------ conv3x3 of an input with <= 8 channels (the network's first layer)
 // The input is one 8-channel (16-byte) vector per pixel, [n][H][W][8].  A 16-deep MFMA K step then covers TWO taps: the
 // lower half-wave (k 0..7) reads tap 2s and the upper (k 8..15) tap 2s+1 of the same LDS plane, i.e. the two halves just use
@@ -560,13 +778,36 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
     // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
     if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
-    // persistent blocks, one per CU (the LDS holds one); a multiple of the cout-tile count so a block keeps its weight slab
+    static const int variant = [] { const char* e = getenv("SSM_CONV_VARIANT"); return e ? atoi(e) : 2; }();
+#ifdef SSM_CONV_ABLATE   /* scripts/ubench/conv_bench.hip only: zero-sized buffer descriptors drop the stores (1) / turn the DMA into zero fills (2) */
+    static const int abl = [] { const char* e = getenv("SSM_CONV_ABL"); return e ? atoi(e) : 0; }();
+    const unsigned long long in_bytes_k = (abl & 2) ? 0 : in_bytes, wt_bytes_k = (abl & 2) ? 0 : wt_bytes, out_bytes_k = (abl & 1) ? 0 : out_bytes;
+#define in_bytes in_bytes_k
+#define wt_bytes wt_bytes_k
+#define out_bytes out_bytes_k
+#endif
+    if (variant == 2) {
+        // two persistent 4-wave blocks per CU (conv3x3_dma2_kernel); a multiple of the cout-tile count so a block keeps its weight slab
+        int grid = 2 * conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
+#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+        if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
+        else if (epi == 1) { if (relu) D2_LAUNCH(true, 1, 2); else D2_LAUNCH(false, 1, 2); }
+        else { if (relu) D2_LAUNCH(true, 0, 2); else D2_LAUNCH(false, 0, 2); }
+#undef D2_LAUNCH
+        return hipGetLastError();
+    }
+    // variant 1: one persistent 8-wave block per CU (the LDS holds one)
     int grid = conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
 #define DT_LAUNCH(R, E, N) conv3x3_dma_kernel<R, E, N><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
     if (epi == 2) { if (relu) DT_LAUNCH(true, 2, 1); else DT_LAUNCH(false, 2, 1); }
     else if (epi == 1) { if (relu) DT_LAUNCH(true, 1, 2); else DT_LAUNCH(false, 1, 2); }
     else { if (relu) DT_LAUNCH(true, 0, 2); else DT_LAUNCH(false, 0, 2); }
 #undef DT_LAUNCH
+#ifdef SSM_CONV_ABLATE
+#undef in_bytes
+#undef wt_bytes
+#undef out_bytes
+#endif
     return hipGetLastError();
 }
 static hipError_t conv_first_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W, int Cout, int relu, hipStream_t s)
