@@ -62,12 +62,12 @@ segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int 
 // exactly 8 store instructions per tile (the callers' vmcnt(8) relies on it).
 typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
-template <bool RELU, int EPI, typename RS>
+template <bool RELU, int EPI, int NTN = 2, typename RS>
 __device__ __forceinline__ void conv_epilogue(const floatx16 (&acc)[2][2], const float (*s_ss)[CT_N], const RS& rsO, const RS& rsC,
                                               int f, int y0, int gx, bool live0, bool live1, int chunk0, int cout_chunks, int H, int W, int r, int hh)
 {
 #pragma unroll
-    for (int tn = 0; tn < 2; tn++) {
+    for (int tn = 0; tn < NTN; tn++) {                                        // NTN = 1: a 32-channel output tile
         const int chunk = chunk0 + tn;
 #pragma unroll
         for (int gp = 0; gp < 2; gp++) {
@@ -376,12 +376,13 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     constexpr int BROW = 32 * NT;
     constexpr int BINS = 9 * 2 * BROW / 64;                                        // weight wave-instructions per stage: 18 or 9
     constexpr int BK = (BINS + 3) / 4;                                             // per wave: 5 or 3
-    constexpr int NSTORE = EPI == 2 ? 4 : 16;                                      // store instructions per tile epilogue
-    constexpr int WAIT_TILE = NSTORE == 16 ? 0x4F70 : 0x0F74;                      // s_waitcnt vmcnt(NSTORE) (vmcnt is split: bits 3:0 and 15:14)
+    constexpr int NSTORE = EPI == 2 ? 4 : 8 * NT;                                  // store instructions per tile epilogue
+    constexpr int WAIT_TILE = 0x0F70 | (NSTORE & 15) | ((NSTORE >> 4) << 14);      // s_waitcnt vmcnt(NSTORE) (vmcnt is split: bits 3:0 and 15:14)
+    constexpr int CTW = 32 * NT;                                                   // output channels per tile: ncout_tiles counts tiles of this width
     __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
     if (tid < 2 * CT_N) {
-        const int ch = (blockIdx.x % ncout_tiles) * CT_N + (tid & (CT_N - 1));
-        s_ss[tid >> 6][tid & (CT_N - 1)] = ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+        const int cl = tid & (CT_N - 1), ch = (blockIdx.x % ncout_tiles) * CTW + cl;
+        s_ss[tid >> 6][cl] = cl < CTW && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
     }
     unsigned a_off[5], b_off[5]; int b_j[5];
     int a_py[5], a_px[5]; unsigned a_c8[5];
@@ -421,6 +422,9 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #ifdef SSM_CONV_ABLATE
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
+    // byte offset of cout tile ct's weights for chunk 0: packed per 64-cout tile [chunk][tap][c8][cout 64][8]; a 32-cout tile is
+    // the first or second half of each 64-cout row
+#define D2_SLAB0(ct_) (NT == 2 ? (unsigned)(ct_) * nchunks * (DT_BCH * 16u) : (unsigned)((ct_) >> 1) * nchunks * (DT_BCH * 16u) + (unsigned)((ct_) & 1) * 512u)
     int tile = blockIdx.x;
     // phase shift between the two blocks of a CU (blocks i and i + gridDim/2 are dispatched to the same CU when the grid is
     // 2 x CUs): about half of a tile's MFMA time
@@ -429,7 +433,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     }
     D2_TILE_OFFSETS(tile)
     {
-        const unsigned bso = (unsigned)(tile % ncout_tiles) * nchunks * (DT_BCH * 16u);
+        const unsigned bso = D2_SLAB0(tile % ncout_tiles);
 #pragma unroll
         for (int k = 0; k < 5; k++) { D2_DMA_A(k, lds0, 0u) if (k < BK) D2_DMA_B(k, lds0, bso) }
         const uint4v z4 = {0u, 0u, 0u, 0u};
@@ -479,7 +483,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #define D2_CHUNK(ck, WAITC)                                                                             \
         {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
             D2_BARRIER();                                                               \
-            const unsigned slab = ((unsigned)ct * nchunks + (ck)) * (DT_BCH * 16u);                     \
+            const unsigned slab = D2_SLAB0(ct) + (unsigned)(ck) * (DT_BCH * 16u);                       \
             unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
             D2_STAGE_BODY(lds0, lds1)                                                                   \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
@@ -491,7 +495,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                 const int nt = tile + gridDim.x;                                                        \
                 D2_TILE_OFFSETS(nt)                                                                     \
                 a_so = 0u;                                                                              \
-                b_so = nt < total_tiles ? (unsigned)(nt % ncout_tiles) * nchunks * (DT_BCH * 16u) : 0x80000000u; \
+                b_so = nt < total_tiles ? D2_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
             }                                                                                           \
             D2_STAGE_BODY(lds1, lds0) }
         // the tile's first DMA batch is older than the NSTORE stores of the previous epilogue, which may stay in flight
@@ -543,7 +547,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                 for (int tm = 0; tm < 2; tm++)
 #pragma unroll
                     for (int tn = 0; tn < 2; tn++) a2[tm][tn] = acc[2 * half + tm][tn < NT ? tn : 0];
-                conv_epilogue<RELU, EPI>(a2, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
+                conv_epilogue<RELU, EPI, NT>(a2, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * NT, cout_chunks, H, W, r, hh);
             }
         }
     }
@@ -554,6 +558,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #undef D2_DMA_B
 #undef D2_BARRIER
 #undef D2_TILE_OFFSETS
+#undef D2_SLAB0
 }
 
 // ------------------------------------------------------------------ conv3x3 of an input with <= 8 channels (the network's first layer)
@@ -787,11 +792,32 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
 #define out_bytes out_bytes_k
 #endif
     if (variant == 2) {
-        // two persistent 4-wave blocks per CU (conv3x3_dma2_kernel); a multiple of the cout-tile count so a block keeps its weight slab
-        int grid = 2 * conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
-#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+        // two persistent 4-wave blocks per CU (conv3x3_dma2_kernel); the grid is a multiple of the cout-tile count so a block keeps
+        // its weight slab.  Tiles are 64 output channels wide, or 32 when that balances the CUs better: blocks b and b + grid/2
+        // share a CU and its matrix cores, so a CU's time is the work of both; a 32-wide tile costs a bit more than half
+        // (the input tile is staged once per 32 channels instead of once per 64).
+        const int cus = conv_grid_limit();
+        auto makespan = [&](int units, int tiles_n, double cost) {
+            int grid = 2 * cus; grid -= grid % tiles_n; if (grid > units) grid = units;
+            const int half = cus;                                                  // blocks b and b + cus share a CU
+            long worst = 0;
+            for (int b = 0; b < half && b < grid; b++) {
+                long c = (units - b + grid - 1) / grid;
+                if (b + half < grid) c += (units - (b + half) + grid - 1) / grid;
+                worst = c > worst ? c : worst;
+            }
+            return worst * cost;
+        };
+        int nt_w = 2, nct_k = nct;
+        if (epi == 2) nt_w = 1;
+        else if (Cout % 64 == 0 && makespan(2 * total, 2 * nct, 0.56) < makespan(total, nct, 1.0)) { nt_w = 1; nct_k = 2 * nct; }
+        const int total_k = tx * ty * nct_k;
+        int grid = 2 * cus; grid -= grid % nct_k; if (grid > total_k) grid = total_k;
+#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
         if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
+        else if (epi == 1 && nt_w == 1) { if (relu) D2_LAUNCH(true, 1, 1); else D2_LAUNCH(false, 1, 1); }
         else if (epi == 1) { if (relu) D2_LAUNCH(true, 1, 2); else D2_LAUNCH(false, 1, 2); }
+        else if (nt_w == 1) { if (relu) D2_LAUNCH(true, 0, 1); else D2_LAUNCH(false, 0, 1); }
         else { if (relu) D2_LAUNCH(true, 0, 2); else D2_LAUNCH(false, 0, 2); }
 #undef D2_LAUNCH
         return hipGetLastError();
