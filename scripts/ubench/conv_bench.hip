@@ -45,6 +45,10 @@ int main(int argc, char** argv)
             CK(hipDeviceSynchronize());
             CK(hipMemcpyFromSymbol(&cyc, HIP_SYMBOL(g_conv_cycles), 8));
             if (cyc) { util = fl / (double)cyc / 1048576.0; ghz = (double)cyc / us * 1e-3; }
+            unsigned long long ph[8][4];
+            CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_conv_phase), sizeof(ph)));
+            if (getenv("SSM_CONV_PHASES")) for (int b = 0; b < 8; b++) if (ph[b][2])
+                printf("    probe %d: tiles %llu  mfma-phase %.0f clk/tile  other %.0f clk/tile  lifetime %llu\n", b, ph[b][2], (double)ph[b][0] / ph[b][2], (double)ph[b][1] / ph[b][2], ph[b][3]);
         }
 #endif
         printf("%3dx%3d %3d->%3d n=%d : %8.1f us  %7.1f TFLOP/s  mfma-util %.3f  clock %.2f GHz\n", sh.H, sh.W, sh.Cin, sh.Cout, n, us, fl / us * 1e-6, util, ghz);

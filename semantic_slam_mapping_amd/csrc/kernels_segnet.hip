@@ -11,6 +11,9 @@
 // Also here: Classifier::Preprocess (segnet.cpp:130-167; cv::resize to 480x360, planar float, mean 0) and the label
 // colouring of experiment/segnet.cpp:80-83,131-146 (Pavement->Road remap, cv::resize back to the frame size, cv::LUT).
 #include "ssm_internal.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -350,6 +353,7 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
 //   * the second half of the grid starts half a tile late so that the two blocks of a CU run out of phase.
 #ifdef SSM_CONV_ABLATE
 __device__ unsigned long long g_conv_cycles;     // scripts/ubench/conv_bench.hip: longest block lifetime in shader clocks
+__device__ unsigned long long g_conv_phase[8][4]; // [probe block][mfma phase, epilogue, tiles, lifetime] of wave 0
 #endif
 #define D2_AINS 20                            // input wave-instructions per stage (5 per wave; 1280 slots for 2 planes = 1224 chunks)
 #define D2_ACH (2 * DT_PLANE)
@@ -359,7 +363,7 @@ template <bool RELU, int EPI, int NT>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
                     _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
-                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
+                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue)
 {
     __shared__ __attribute__((aligned(16))) half8 lds0[D2_STAGE];
     __shared__ __attribute__((aligned(16))) half8 lds1[D2_STAGE];
@@ -380,6 +384,13 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     constexpr int WAIT_TILE = 0x0F70 | (NSTORE & 15) | ((NSTORE >> 4) << 14);      // s_waitcnt vmcnt(NSTORE) (vmcnt is split: bits 3:0 and 15:14)
     constexpr int CTW = 32 * NT;                                                   // output channels per tile: ncout_tiles counts tiles of this width
     __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    // dynamic tile order: a block starts with tile blockIdx.x and keeps its cout tile; the following pixel tiles come from a
+    // per-cout-tile counter (queue[2 ct]), fetched one tile ahead because the pipeline prefetches across tile boundaries.
+    // The two blocks of a CU do not run at the same speed (the SIMD issues the older wave first), so a static split leaves the
+    // faster block idle at the end.  queue[2 ct + 1] counts the blocks that have drained the counter; the last one zeroes
+    // both, so the buffer is ready for the next launch on the stream.
+    __shared__ int s_next;
+    const int my_ct = blockIdx.x % ncout_tiles, blocks_per_ct = gridDim.x / ncout_tiles;
     if (tid < 2 * CT_N) {
         const int cl = tid & (CT_N - 1), ch = (blockIdx.x % ncout_tiles) * CTW + cl;
         s_ss[tid >> 6][cl] = cl < CTW && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
@@ -421,6 +432,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #endif
 #ifdef SSM_CONV_ABLATE
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long ph_mfma = 0, ph_tiles = 0;
 #endif
     // byte offset of cout tile ct's weights for chunk 0: packed per 64-cout tile [chunk][tap][c8][cout 64][8]; a 32-cout tile is
     // the first or second half of each 64-cout row
@@ -440,7 +452,8 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #pragma unroll
         for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 256 * k), 0, 0);
     }
-    for (; tile < total_tiles; tile += gridDim.x) {
+    int next_tile = total_tiles;
+    for (; tile < total_tiles; tile = next_tile) {
         const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
         const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
         floatx16 acc[4][NT];
@@ -480,28 +493,42 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             } }
         // the two stages of one 32-channel chunk; the first chunk of a tile is written out separately because its wait differs
         // (one merged path makes the compiler's own vmcnt bookkeeping pessimistic: it then drains the epilogue stores)
-#define D2_CHUNK(ck, WAITC)                                                                             \
+#define D2_CHUNK(ck, WAITC, FIRST)                                                                      \
         {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
             D2_BARRIER();                                                               \
+            /* the counter fetch is older than this stage's DMA and is covered by the stage's closing vmcnt(0); as inline    \
+               assembly, because the compiler would wait for a returning atomic at the end of the branch (draining the   \
+               previous tile's stores) */                                                                  \
+            int fetched_;                                                                               \
+            if (FIRST && tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched_) : "v"(0), "v"(1), "s"(queue + 2 * my_ct) : "memory"); \
             const unsigned slab = D2_SLAB0(ct) + (unsigned)(ck) * (DT_BCH * 16u);                       \
             unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
             D2_STAGE_BODY(lds0, lds1)                                                                   \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
+            if (FIRST && tid == 0) s_next = (blocks_per_ct + fetched_) * ncout_tiles + my_ct;           \
             D2_BARRIER();                                                               \
             if ((ck) + 1 < nchunks) {                                                                   \
                 a_so = (unsigned)((ck) + 1) * plane_bytes;                                              \
                 b_so = slab + DT_BCH * 16u;                                                             \
             } else {                                                                                    \
-                const int nt = tile + gridDim.x;                                                        \
+                const int nt = __builtin_amdgcn_readfirstlane(s_next);                                  \
+                next_tile = nt;                                                                         \
                 D2_TILE_OFFSETS(nt)                                                                     \
                 a_so = 0u;                                                                              \
                 b_so = nt < total_tiles ? D2_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
             }                                                                                           \
             D2_STAGE_BODY(lds1, lds0) }
+#ifdef SSM_CONV_ABLATE
+        const unsigned long long t_a = __builtin_amdgcn_s_memtime();
+#endif
         // the tile's first DMA batch is older than the NSTORE stores of the previous epilogue, which may stay in flight
-        D2_CHUNK(0, WAIT_TILE)
-        for (int ck = 1; ck < nchunks; ck++) D2_CHUNK(ck, 0x0F70)
+        D2_CHUNK(0, WAIT_TILE, true)
+        for (int ck = 1; ck < nchunks; ck++) D2_CHUNK(ck, 0x0F70, false)
 #undef D2_CHUNK
+#ifdef SSM_CONV_ABLATE
+        const unsigned long long t_b = __builtin_amdgcn_s_memtime();
+        ph_mfma += t_b - t_a; ph_tiles++;
+#endif
 #undef D2_STAGE_BODY
 #undef D2_LOADF
         const int cout_chunks = (Cout + 31) >> 5;
@@ -551,8 +578,15 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             }
         }
     }
+    // exactly one fetch per block came back past the end: the last block of this cout tile to get there resets the counters
+    if (tid == 0 && atomicAdd(&queue[2 * my_ct + 1], 1) == blocks_per_ct - 1) { queue[2 * my_ct] = 0; queue[2 * my_ct + 1] = 0; }
 #ifdef SSM_CONV_ABLATE
-    if (tid == 0) atomicMax(&g_conv_cycles, __builtin_amdgcn_s_memtime() - t_start);
+    if (tid == 0) {
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - t_start;
+        atomicMax(&g_conv_cycles, life);
+        const int probe = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == 100 ? 2 : blockIdx.x == 255 ? 3 : blockIdx.x == 256 ? 4 : blockIdx.x == 257 ? 5 : blockIdx.x == 400 ? 6 : blockIdx.x == 511 ? 7 : -1;
+        if (probe >= 0) { g_conv_phase[probe][0] = ph_mfma; g_conv_phase[probe][1] = life - ph_mfma; g_conv_phase[probe][2] = ph_tiles; g_conv_phase[probe][3] = life; }
+    }
 #endif
 #undef D2_DMA_A
 #undef D2_DMA_B
@@ -766,6 +800,20 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
     segnet_prep_kernel<<<dim3((dw * dh + 255) / 256, n), 256, 0, s>>>(bgr, sw, sh, dw, dh, xofs, xa, yofs, ya, (_Float16*)out_f16);
     return hipGetLastError();
 }
+// tile counters of conv3x3_dma2_kernel (self-resetting, see there): one small zeroed buffer per (device, stream); launches on a
+// stream are ordered, so they can share it
+static int* conv_tile_queue(hipStream_t s)
+{
+    static std::mutex mu; static std::map<std::pair<int, hipStream_t>, int*> bufs;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = bufs.find({dev, s});
+    if (it != bufs.end()) return it->second;
+    int* p = nullptr;
+    if (hipMalloc(&p, 64 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 64 * sizeof(int)) != hipSuccess) return nullptr;
+    bufs[{dev, s}] = p;
+    return p;
+}
 static int conv_grid_limit()
 {
     static int cus = 0;
@@ -813,7 +861,9 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
         else if (Cout % 64 == 0 && makespan(2 * total, 2 * nct, 0.56) < makespan(total, nct, 1.0)) { nt_w = 1; nct_k = 2 * nct; }
         const int total_k = tx * ty * nct_k;
         int grid = 2 * cus; grid -= grid % nct_k; if (grid > total_k) grid = total_k;
-#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue)
+        int* queue = conv_tile_queue(s);
+        if (!queue || nct_k > 32) return hipErrorOutOfMemory;
         if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
         else if (epi == 1 && nt_w == 1) { if (relu) D2_LAUNCH(true, 1, 1); else D2_LAUNCH(false, 1, 1); }
         else if (epi == 1) { if (relu) D2_LAUNCH(true, 1, 2); else D2_LAUNCH(false, 1, 2); }
