@@ -83,14 +83,17 @@ __device__ __forceinline__ void conv_epilogue(const floatx16 (&acc)[2][2], const
                     const int g = 2 * gp + e, cl = 32 * tn + 8 * g + 4 * hh;
                     const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
                     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
-                    _Float16 hv[4];
+                    // one FMA per value, conversion two at a time (v_cvt_pk_f16_f32, round to nearest even), ReLU on the packed
+                    // halves (v_pk_max_f16): max(cvt(x), 0) == cvt(max(x, 0)) because the conversion is monotonic and keeps 0
+                    typedef float float2v __attribute__((ext_vector_type(2)));
+                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float val = acc[tm][tn][4 * g + q] * scv[q] + sfv[q];
-                        if (RELU) val = fmaxf(val, 0.f);
-                        hv[q] = (_Float16)val;
+                    for (int q = 0; q < 4; q += 2) {
+                        const float2v val = {__builtin_fmaf(acc[tm][tn][4 * g + q], scv[q], sfv[q]), __builtin_fmaf(acc[tm][tn][4 * g + q + 1], scv[q + 1], sfv[q + 1])};
+                        half2v h2 = __builtin_convertvector(val, half2v);
+                        if (RELU) h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
+                        memcpy(&pk[e][q >> 1], &h2, 4);
                     }
-                    memcpy(&pk[e][0], &hv[0], 4); memcpy(&pk[e][1], &hv[2], 4);
                 }
                 // lanes 0-31 keep quad 2gp (channels +0..3) and receive the upper half's quad 2gp (+4..7);
                 // lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own (+12..15)
@@ -315,7 +318,7 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
                     bv[g] = (_Float16)-65504.f; bi[g] = 255;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        float val = acc[tm][0][4 * g + q] * scv[q] + sfv[q];
+                        float val = __builtin_fmaf(acc[tm][0][4 * g + q], scv[q], sfv[q]);
                         if (RELU) val = fmaxf(val, 0.f);
                         const _Float16 hvq = (_Float16)val;
                         if (c0 + q < Cout && (bi[g] == 255 || hvq > bv[g])) { bv[g] = hvq; bi[g] = c0 + q; }
@@ -453,16 +456,11 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 256 * k), 0, 0);
     }
     int next_tile = total_tiles;
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (; tile < total_tiles; tile = next_tile) {
         const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
         const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
-        floatx16 acc[4][NT];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < NT; b++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
+        floatx16 acc[4][NT];                                                       // first written by the tile's first MFMAs (C = 0)
         // one stage: 9 steps (taps) of 4 NT MFMAs on buffer `rd`; the next stage's 10 DMA instructions (into `wr`) and the next
         // step's fragment reads are issued ahead of each step's MFMAs
 #ifdef CT_ABL_NOREAD
@@ -477,7 +475,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             if (D2_READ_ALL || (st) < 2) {                                                                    \
             fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fa[fbuf][2] = pa_[2 * DT_PW]; fa[fbuf][3] = pa_[3 * DT_PW]; \
             fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; } }
-#define D2_STAGE_BODY(rd, wr)                                                                           \
+#define D2_STAGE_BODY(rd, wr, Z)                                                                        \
         {   half8 fa[2][4], fb[2][NT];                                                                  \
             D2_LOADF(rd, 0, 0)                                                                          \
             _Pragma("unroll") for (int st = 0; st < 9; st++) {                                          \
@@ -488,7 +486,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                 if (st + 1 < 9) D2_LOADF(rd, cur ^ 1, st + 1)                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
                 _Pragma("unroll") for (int tm_ = 0; tm_ < 4; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
-                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_], 0, 0, 0); \
+                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], (Z) && st == 0 ? zero16 : acc[tm_][tn_], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
             } }
         // the two stages of one 32-channel chunk; the first chunk of a tile is written out separately because its wait differs
@@ -503,7 +501,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             if (FIRST && tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched_) : "v"(0), "v"(1), "s"(queue + 2 * my_ct) : "memory"); \
             const unsigned slab = D2_SLAB0(ct) + (unsigned)(ck) * (DT_BCH * 16u);                       \
             unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
-            D2_STAGE_BODY(lds0, lds1)                                                                   \
+            D2_STAGE_BODY(lds0, lds1, FIRST)                                                                \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
             if (FIRST && tid == 0) s_next = (blocks_per_ct + fetched_) * ncout_tiles + my_ct;           \
             D2_BARRIER();                                                               \
@@ -517,7 +515,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                 a_so = 0u;                                                                              \
                 b_so = nt < total_tiles ? D2_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
             }                                                                                           \
-            D2_STAGE_BODY(lds1, lds0) }
+            D2_STAGE_BODY(lds1, lds0, false) }
 #ifdef SSM_CONV_ABLATE
         const unsigned long long t_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -551,7 +549,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                         bv[g] = (_Float16)-65504.f; bi[g] = 255;
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            float val = acc[2 * half + tm][0][4 * g + q] * scv[q] + sfv[q];
+                            float val = __builtin_fmaf(acc[2 * half + tm][0][4 * g + q], scv[q], sfv[q]);
                             if (RELU) val = fmaxf(val, 0.f);
                             const _Float16 hvq = (_Float16)val;
                             if (c0 + q < Cout && (bi[g] == 255 || hvq > bv[g])) { bv[g] = hvq; bi[g] = c0 + q; }
