@@ -812,6 +812,13 @@ static int* conv_tile_queue(hipStream_t s)
     bufs[{dev, s}] = p;
     return p;
 }
+// start of a forward pass: zero the stream's tile counters (they reset themselves at the end of every launch; this only
+// keeps an aborted launch from poisoning the passes after it)
+hipError_t k_segnet_begin(hipStream_t s)
+{
+    int* q = conv_tile_queue(s);
+    return q ? hipMemsetAsync(q, 0, 64 * sizeof(int), s) : hipErrorOutOfMemory;
+}
 static int conv_grid_limit()
 {
     static int cus = 0;

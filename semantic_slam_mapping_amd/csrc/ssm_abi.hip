@@ -845,6 +845,7 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
 {
     SegNetState* g = c->seg; hipStream_t s = c->stream;
     void* cur = g->actA; void* nxt = g->actB;
+    HIPCHK(c, k_segnet_begin(s));
     auto conv = [&](int l) -> int {
         const SegLayerDef& d = k_seg_layers[l];
         HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s));
