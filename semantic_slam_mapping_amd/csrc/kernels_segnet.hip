@@ -461,32 +461,35 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
         const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
         floatx16 acc[4][NT];                                                       // first written by the tile's first MFMAs (C = 0)
-        // one stage: 9 steps (taps) of 4 NT MFMAs on buffer `rd`; the next stage's 10 DMA instructions (into `wr`) and the next
-        // step's fragment reads are issued ahead of each step's MFMAs
+        // one stage: 9 steps (taps) of 4 NT MFMAs on buffer `rd`, column offset (dx) major: the six halo rows a wave needs at one
+        // dx are read ONCE and serve the three taps (dy) of that column -- 6 pixel + 3 x NT weight fragment reads per 12 NT MFMAs
+        // (a tap-by-tap walk reads 12 + 3 NT).  The next stage's 10 DMA instructions (into `wr`), the next step's weight
+        // fragments and a third of the next column's pixel fragments are issued ahead of each step's MFMAs.
 #ifdef CT_ABL_NOREAD
 #define D2_READ_ALL 0
 #else
 #define D2_READ_ALL 1
 #endif
-#define D2_LOADF(rd, fbuf, st)                                                                          \
-        {   const int dy_ = (st) / 3, dx_ = (st) - dy_ * 3;                                                   \
-            const half8* pa_ = rd + hh * DT_PLANE + (4 * wv + dy_) * DT_PW + r + dx_;                         \
-            const half8* pb_ = rd + D2_AINS * 64 + ((st) * 2 + hh) * BROW + r;                                \
-            if (D2_READ_ALL || (st) < 2) {                                                                    \
-            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fa[fbuf][2] = pa_[2 * DT_PW]; fa[fbuf][3] = pa_[3 * DT_PW]; \
-            fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; } }
+#define D2_LOADW(rd, fbuf, st)      /* weight fragments of step st: tap = 3 dy + dx with dx = st / 3, dy = st % 3 */ \
+        {   const int tap_ = 3 * ((st) % 3) + (st) / 3;                                                       \
+            const half8* pb_ = rd + D2_AINS * 64 + (tap_ * 2 + hh) * BROW + r;                                \
+            if (D2_READ_ALL || (st) < 2) { fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; } }
+#define D2_LOADX(rd, gbuf, dx_, hr_) /* pixel fragment: halo row hr_ of this wave's six, column offset dx_ */          \
+        {   if (D2_READ_ALL || (dx_) == 0) fa[gbuf][hr_] = (rd + hh * DT_PLANE + (4 * wv + (hr_)) * DT_PW + r + (dx_))[0]; }
 #define D2_STAGE_BODY(rd, wr, Z)                                                                        \
-        {   half8 fa[2][4], fb[2][NT];                                                                  \
-            D2_LOADF(rd, 0, 0)                                                                          \
+        {   half8 fa[2][6], fb[2][NT];                                                                  \
+            _Pragma("unroll") for (int hr = 0; hr < 6; hr++) D2_LOADX(rd, 0, 0, hr)                     \
+            D2_LOADW(rd, 0, 0)                                                                          \
             _Pragma("unroll") for (int st = 0; st < 9; st++) {                                          \
-                const int cur = st & 1;                                                                 \
+                const int cur = st & 1, dxs = st / 3, dys = st - 3 * dxs, grp = dxs & 1;                \
                 if (st < 5) D2_DMA_A(st, wr, a_so)                                                      \
                 if (st >= 5 && st - 5 < BK) D2_DMA_B(st - 5, wr, b_so)                                  \
                 if (st == 0 && BK == 5) D2_DMA_B(4, wr, b_so)                                           \
-                if (st + 1 < 9) D2_LOADF(rd, cur ^ 1, st + 1)                                           \
+                if (st + 1 < 9) D2_LOADW(rd, cur ^ 1, st + 1)                                           \
+                if (dxs < 2) { D2_LOADX(rd, grp ^ 1, dxs + 1, 2 * dys) D2_LOADX(rd, grp ^ 1, dxs + 1, 2 * dys + 1) } \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
                 _Pragma("unroll") for (int tm_ = 0; tm_ < 4; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
-                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], (Z) && st == 0 ? zero16 : acc[tm_][tn_], 0, 0, 0); \
+                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[grp][tm_ + dys], (Z) && st == 0 ? zero16 : acc[tm_][tn_], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
             } }
         // the two stages of one 32-channel chunk; the first chunk of a tile is written out separately because its wait differs
@@ -528,7 +531,8 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         ph_mfma += t_b - t_a; ph_tiles++;
 #endif
 #undef D2_STAGE_BODY
-#undef D2_LOADF
+#undef D2_LOADW
+#undef D2_LOADX
         const int cout_chunks = (Cout + 31) >> 5;
         const int gx = tx0 + r;
 #pragma unroll
