@@ -24,6 +24,8 @@
 #include "ssm_internal.h"
 #include <climits>
 #include <mutex>
+#include <map>
+#include <utility>
 
 #define SG_MAXC 32767
 #define SG_DISP_SHIFT 4
@@ -373,27 +375,32 @@ sgbm_depth(const int16_t* __restrict__ disp, int w, int h, const int* __restrict
 __global__ void __launch_bounds__(256)
 sgbm_fill(int16_t* __restrict__ p, int n, int16_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 // ------------------------------------------------------------------ launcher
-// side streams for the five concurrent scan directions (created once per process; every call forks them from and joins them
-// into the caller's stream by events, so calls on one context stay ordered)
+// side streams for the five concurrent scan directions: one set per caller stream (a context), created at its first call;
+// every call forks them from and joins them into the caller's stream by events, so calls on one context stay ordered and
+// contexts used from different host threads never share an event
 struct SgStreams { hipStream_t s[4]; hipEvent_t fork, done[4]; bool ok = false; };
-static SgStreams& sg_streams()
+static SgStreams& sg_streams(hipStream_t caller)
 {
-    static SgStreams st;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        bool ok = hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) == hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SgStreams*> sets;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    SgStreams*& st = sets[{dev, caller}];
+    if (!st) {
+        st = new SgStreams;
+        bool ok = hipEventCreateWithFlags(&st->fork, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 4 && ok; i++)
-            ok = hipStreamCreateWithFlags(&st.s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) == hipSuccess;
-        st.ok = ok;
-    });
-    return st;
+            ok = hipStreamCreateWithFlags(&st->s[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&st->done[i], hipEventDisableTiming) == hipSuccess;
+        st->ok = ok;
+    }
+    return *st;
 }
 template <int K>
 static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, const ssm_sgbm_params& p, int minX1, int P1, int P2,
                                  int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, hipStream_t s)
 {
     auto blocks = [](int paths) { return (paths * 16 + 255) / 256; };
-    SgStreams& st = sg_streams();
+    SgStreams& st = sg_streams(s);
     if (!st.ok) return hipErrorUnknown;
     hipError_t e = hipEventRecord(st.fork, s);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st.s[i], st.fork, 0);
