@@ -76,6 +76,7 @@ struct ssm_ctx {
     // constant tables
     int8_t* d_pattern = nullptr;
     int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
+    void* d_xgrp[SSM_MAX_LEVELS] = {};       // resize4_kernel's per-group constants (null: the level uses the general resize kernel)
     int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
     // batch workspace (B frames)
     uint8_t *d_pyr = nullptr, *d_blur = nullptr; int32_t* d_cellmax = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
@@ -274,8 +275,31 @@ static int ctx_init(ssm_ctx* c)
         HIPCHK(c, hipMemcpy(c->d_xa[l], xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_ya[l], ya.data(), ya.size() * 2, hipMemcpyHostToDevice));
+        // per 4-pixel group: the (a0, a1) pairs, the 4-byte-aligned start of the source window and each pixel's byte offset in
+        // it; the streaming kernel needs every offset + 1 inside the first 8 bytes
+        const int groups = g.L[l].stride / 4, dw = g.L[l].w;
+        std::vector<uint32_t> xg((size_t)groups * 8, 0u); bool fits = true;
+        for (int q = 0; q < groups; q++) {
+            uint32_t* e = &xg[(size_t)q * 8];
+            const int x0 = 4 * q;
+            if (x0 >= dw) continue;                                               // padding group: coefficients 0 -> zeros, window at 0
+            const int base = (xo[x0] >> 2) << 2;
+            e[4] = (uint32_t)base;
+            for (int k = 0; k < 4 && x0 + k < dw; k++) {
+                const int off = xo[x0 + k] - base;
+                if (off < 0 || off > 7) fits = false;
+                e[k] = (uint32_t)(uint16_t)xa[2 * (x0 + k)] | ((uint32_t)(uint16_t)xa[2 * (x0 + k) + 1] << 16);
+                e[5] |= (uint32_t)(off & 15) << (4 * k);
+            }
+        }
+        if (fits) {
+            uint32_t* d = nullptr; DALLOC(c, d, xg.size());
+            HIPCHK(c, hipMemcpy(d, xg.data(), xg.size() * 4, hipMemcpyHostToDevice));
+            c->d_xgrp[l] = d;
+        }
     }
-    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
+    // d_pyr + 16: resize4_kernel's 12-byte windows may end past the last row
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
@@ -318,7 +342,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab };
     for (void* p : ptrs) if (p) hipFree(p);
-    for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); }
+    for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); if (c->d_xgrp[l]) hipFree(c->d_xgrp[l]); }
     if (c->seg) {
         SegNetState* g = c->seg;
         void* sp[] = { g->actA, g->actB, g->labels, g->d_sem_gen, g->pre_xofs, g->pre_yofs, g->post_xofs, g->post_yofs, g->pre_xa, g->pre_ya, g->post_xa, g->post_ya,
@@ -373,7 +397,7 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
 {
     const OrbGeom& g = c->g; hipStream_t s = c->stream;
     prof_begin(c, "gray");      HIPCHK(c, k_gray(d_img, channels, nb, g, c->d_pyr, s)); prof_end(c);
-    prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(nb, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, s)); prof_end(c);
+    prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(nb, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, c->d_xgrp, s)); prof_end(c);
     prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
     prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
     prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);

@@ -41,7 +41,7 @@ typedef uint2 cand_t;
 hipError_t k_gray(const uint8_t* img, int channels, int n, const OrbGeom& g, uint8_t* pyr, hipStream_t s);
 hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g, uint8_t* pyr, hipStream_t s);
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
-                     const int32_t* const* yofs, const int16_t* const* ya, hipStream_t s);
+                     const int32_t* const* yofs, const int16_t* const* ya, const void* const* xgroups, hipStream_t s);
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s);
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s);
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,

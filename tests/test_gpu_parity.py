@@ -364,3 +364,21 @@ def test_full_size_properties_of_configs1(oracle):
         for p in bufs:
             c.dev_free(p)
         c.close()
+
+
+@pytest.mark.parametrize("scale,levels", [(1.5, 5), (2.0, 3), (1.1, 8)])
+def test_orb_other_scale_factors(oracle, frames, scale, levels):
+    """pyramid scale factors other than 1.2: at 1.5 and 2.0 the source window of four output pixels no longer fits the
+    streaming resize kernel (the general LDS-staged one runs); 1.1 stays on the streaming kernel with other offsets"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=600, orb_levels=levels, orb_scale=scale, max_batch=1, voxel_capacity_log2=12, camera=CAM)
+    try:
+        bgr = frames[2][0]
+        gk, gd, _ = c.detect_features(bgr)
+        ok, od = oracle.orb_extract(oracle.bgr2gray(bgr), nfeatures=600, scale=scale, nlevels=levels)
+        assert len(gk) == len(ok) and len(ok) > 300
+        for f in ("x", "y", "size", "response", "octave", "class_id", "angle"):
+            assert np.array_equal(gk[f], ok[f]), f
+        assert np.array_equal(gd, od)
+    finally:
+        c.close()
