@@ -55,6 +55,22 @@ segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int 
 // output rows (2 tiles of 32 contiguous pixels -> conflict-free 512-byte reads) x 2 tiles of 32 output channels.
 #define CT_N 64
 #define CT_KC 32
+// scripts/ubench only (-DCT_ABL_MFMA16): the same FLOPs, operand registers and LDS traffic issued as two v_mfma_f32_16x16x32_f16
+// per 32x32x16 (results are garbage) -- measures what clock the other MFMA shape would hold inside this kernel
+#ifdef CT_ABL_MFMA16
+typedef float floatx4_abl __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx16 mfma_abl(half8 a, half8 b, floatx16 c)
+{
+    floatx4_abl c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+}
+#define CT_MFMA(a, b, c) mfma_abl(a, b, c)
+#else
+#define CT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 // ------------------------------------------------------------------ conv epilogue shared by the MFMA kernels below
 // The MFMAs run with the weights as the row operand, so lane (r = pixel x, hh) holds acc[tm][tn][4g+q] = channel
 // 32 tn + 8 g + 4 hh + q of rows y0 + tm.  BN scale/shift (s_ss, in LDS, zero for padding channels) and ReLU are applied,
@@ -271,7 +287,7 @@ conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__
                 __builtin_amdgcn_sched_barrier(0);   /* reads of step st+1 stay ahead of the MFMAs of step st */ \
                 /* D[cout][pixel] += W[cout][k] X[k][pixel]: weights are the row operand */             \
                 _Pragma("unroll") for (int tm_ = 0; tm_ < 2; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
-                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_], 0, 0, 0); \
+                    acc[tm_][tn_] = CT_MFMA(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_]); \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
             } }
         for (int ck = 0; ck < nchunks; ck += 2) {
@@ -489,7 +505,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                 if (dxs < 2) { D2_LOADX(rd, grp ^ 1, dxs + 1, 2 * dys) D2_LOADX(rd, grp ^ 1, dxs + 1, 2 * dys + 1) } \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
                 _Pragma("unroll") for (int tm_ = 0; tm_ < 4; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
-                    acc[tm_][tn_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[cur][tn_], fa[grp][tm_ + dys], (Z) && st == 0 ? zero16 : acc[tm_][tn_], 0, 0, 0); \
+                    acc[tm_][tn_] = CT_MFMA(fb[cur][tn_], fa[grp][tm_ + dys], (Z) && st == 0 ? zero16 : acc[tm_][tn_]); \
                 __builtin_amdgcn_sched_barrier(0);                                                      \
             } }
         // the two stages of one 32-channel chunk; the first chunk of a tile is written out separately because its wait differs
