@@ -613,6 +613,263 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #undef D2_SLAB0
 }
 
+// ------------------------------------------------------------------ conv3x3 on v_mfma_f32_16x16x32_f16 (SSM_CONV_VARIANT=3; not the default)
+// On dense random operands the chip is power-limited and holds a markedly higher clock on the 16x16x32 MFMA shape than on
+// 32x32x16 at the same FLOPs per clock (the CT_ABL_MFMA16 build of scripts/ubench/conv_bench.hip: +18..21 % TFLOP/s), and this
+// kernel is 5 % faster than conv3x3_dma2_kernel there.  Inside the network (post-ReLU activations, half of them zero) the
+// chip is less power-limited, the shape buys nothing and the one-block-per-CU structure K = 32 forces costs 2 %: DESIGN.md 4.1.  K = 32 per MFMA = the four 8-channel planes of a 32-channel stage
+// (lane group g = lane / 16 supplies plane g), one MFMA step per tap.  Structure as conv3x3_dma_kernel: one persistent
+// 512-thread block per CU (a 32-channel stage is 76 KB, two buffers fill the LDS), 32 x 16 pixel tile x 16 MB output
+// channels, LDS-DMA staging with halo zeros from out-of-range offsets, one barrier per stage, pipeline across tiles.
+//   * a wave owns 2 rows: N blocks (row tm, half h) of 16 pixels, M blocks of 16 output channels: 4 MB MFMAs per tap;
+//   * taps are walked column (dx) major: the 4 halo rows x 2 halves a wave needs at one dx are read once for three taps;
+//   * plane pitch 624 chunks (a multiple of 16: the four lane groups of a ds_read_b128 then hit disjoint banks);
+//   * C/D: lane (g, p) holds channels 4g..4g+3 of pixel p of an M block; v_permlane16_swap between the M blocks of a pair
+//     gives every lane 8 consecutive channels, and one store instruction then writes 16 pixels x 64 contiguous bytes;
+//   * MB = 4: 64-channel tiles; MB = 2: 32-channel tiles where they balance the CUs better; MB = 1: the 12-class layer.
+#define K3_PP 624
+#define K3_AINS 40                            // input wave-instructions per stage (4 x 624 = 2496 of 2560 slots)
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+// store (EPI 0) or 2x2 max-pool + codes (EPI 1) of two rows x 8 consecutive channels per lane; byte = offset of those channels
+// inside the pixel's 64-byte chunk; even = the lane's pixel has an even x (its right neighbour is lane + 1, quad_perm)
+template <int EPI, typename RS>
+__device__ __forceinline__ void conv_emit(const uint4v (&vec)[2], const RS& rsO, const RS& rsC, int f, int y0, int gx, bool live0, bool live1,
+                                          int chunk, int cout_chunks, int H, int W, unsigned byte, bool even)
+{
+    if (EPI == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            const bool live = tm ? live1 : live0;
+            const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y0 + tm) * W + gx) * 64) + byte : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(vec[tm], rsO, ob, 0, 0);
+        }
+    } else {
+        uint4v nb[2];
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+            nb[tm].x = __builtin_amdgcn_mov_dpp(vec[tm].x, 0xB1, 0xF, 0xF, true); nb[tm].y = __builtin_amdgcn_mov_dpp(vec[tm].y, 0xB1, 0xF, 0xF, true);
+            nb[tm].z = __builtin_amdgcn_mov_dpp(vec[tm].z, 0xB1, 0xF, 0xF, true); nb[tm].w = __builtin_amdgcn_mov_dpp(vec[tm].w, 0xB1, 0xF, 0xF, true);
+        }
+        const bool right = gx + 1 < W;
+        _Float16 best[8]; unsigned char bc[8];
+        _Float16 c01[8], c10[8], c11[8];
+        memcpy(best, &vec[0], 16); memcpy(c01, &nb[0], 16); memcpy(c10, &vec[1], 16); memcpy(c11, &nb[1], 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                                             // pool2x2_kernel's contract: row-major scan, strict '>'
+            bc[k] = 0;
+            if (right && c01[k] > best[k]) { best[k] = c01[k]; bc[k] = 1; }
+            if (live1 && c10[k] > best[k]) { best[k] = c10[k]; bc[k] = 2; }
+            if (live1 && right && c11[k] > best[k]) { best[k] = c11[k]; bc[k] = 3; }
+        }
+        const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+        const bool plive = live0 && even && chunk < cout_chunks;
+        const unsigned pidx = (unsigned)(((f * cout_chunks + chunk) * PH + (y0 >> 1)) * PW + (gx >> 1)) * 32u + (byte >> 1);   // elements
+        uint4v pv; memcpy(&pv, best, 16);
+        uint2v cv; memcpy(&cv, bc, 8);
+        __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, plive ? pidx * 2u : 0x80000000u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(cv, rsC, plive ? pidx : 0x80000000u, 0, 0);
+    }
+}
+template <bool RELU, int EPI, int MB>
+__global__ void __launch_bounds__(512, 1)
+conv3x3_k32_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
+                   _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                   unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
+{
+    constexpr int BROW = 16 * MB;                                                  // output channels per tile = per staged weight row
+    constexpr int BINS = 9 * 4 * BROW / 64;                                        // weight wave-instructions per stage: 36, 18 or 9
+    constexpr int BK = (BINS + 7) / 8;                                             // per wave: 5, 3 or 2
+    constexpr int STAGE = K3_AINS * 64 + 36 * BROW;                                // chunks per LDS buffer (MB = 4: 77,824 B)
+    constexpr int NSTORE = EPI == 2 ? 4 : 2 * MB;                                  // store instructions per tile epilogue
+    constexpr int WAIT_TILE = 0x0F70 | NSTORE;                                     // s_waitcnt vmcnt(NSTORE)
+    constexpr int TPS = 4 / MB;                                                    // tiles per packed 64-channel weight slab
+    __shared__ __attribute__((aligned(16))) half8 lds0[STAGE];
+    __shared__ __attribute__((aligned(16))) half8 lds1[STAGE];
+    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, g = lane >> 4;
+    const int VH = (H + 2) & ~1, VR = n * VH;
+    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
+    const int nchunks = Cin / CT_KC;
+    const unsigned plane_bytes = (unsigned)H * W * 64u;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
+    const int my_ct = blockIdx.x % ncout_tiles;
+    if (tid < 2 * CT_N) {
+        const int cl = tid & (CT_N - 1), ch = my_ct * BROW + cl;
+        s_ss[tid >> 6][cl] = cl < BROW && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+    }
+    unsigned a_off[5], b_off[5]; int b_j[5];
+    int a_py[5], a_px[5]; unsigned a_c8[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int i = (wv + 8 * k) * 64 + lane;
+        const int c8 = i / K3_PP, p = i - c8 * K3_PP;
+        a_py[k] = (c8 < 4 && p < DT_PLANE) ? p / DT_PW : -0x10000;                  // padding slots never become valid
+        a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
+        b_j[k] = min(wv + 8 * k, BINS - 1);
+        const int idx = b_j[k] * 64 + lane, row = idx / BROW, col = idx - row * BROW;   // LDS rows are (tap, c8) x BROW channels
+        b_off[k] = (unsigned)(row * 64 + col) * 16u;                              // packed weights: [tap][c8][cout 64][8]
+    }
+#define K3_SLAB0(ct_) ((unsigned)((ct_) / TPS) * nchunks * (DT_BCH * 16u) + (unsigned)((ct_) % TPS) * (BROW * 16u))
+#define K3_TILE_OFFSETS(tile)                                                                           \
+    {   const int pt_ = (tile) / ncout_tiles;                                                           \
+        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
+            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
+            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
+            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u; \
+        } }
+#define K3_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 8 * (k)) * 64], 16, a_off[k], so, 0, 0);
+#define K3_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[K3_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
+    int tile = blockIdx.x;
+    K3_TILE_OFFSETS(tile)
+    {
+        const unsigned bso = K3_SLAB0(tile % ncout_tiles);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { K3_DMA_A(k, lds0, 0u) if (k < BK) K3_DMA_B(k, lds0, bso) }
+        const uint4v z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);   // see conv3x3_dma_kernel
+    }
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int x_idx = g * K3_PP + 2 * wv * DT_PW + p16;                           // this lane's pixel fragment base (plane g, the wave's first halo row)
+    const int w_idx = K3_AINS * 64 + g * BROW + p16;                              // this lane's weight fragment base (k group g)
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
+        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
+        floatx4 acc[2][2][MB];                                                    // [row][half][M block], first written with C = 0
+        // weight fragments of step st (tap = 3 dy + dx with dx = st / 3, dy = st % 3) and pixel fragments (halo row hr of the
+        // wave's four, half h) at column offset dx
+        // (one integer index per read: the pass that tags LDS accesses with the alias scopes of lds0 / lds1 follows pointer
+        // arithmetic only a few steps deep; an untagged ds_read makes the compiler wait for the DMA in flight)
+#define K3_LOADW(rd, fbuf, st)                                                                          \
+        {   _Pragma("unroll") for (int mb_ = 0; mb_ < MB; mb_++) fb[fbuf][mb_] = rd[w_idx + (3 * ((st) % 3) + (st) / 3) * 4 * BROW + 16 * mb_]; }
+#define K3_LOADX(rd, gbuf, dx_, q_) fa[gbuf][q_] = rd[x_idx + ((q_) >> 1) * DT_PW + 16 * ((q_) & 1) + (dx_)];   /* q = 2 hr + h */
+#define K3_STAGE_BODY(rd, wr, Z)                                                                        \
+        {   half8 fa[2][8], fb[2][MB];                                                                  \
+            _Pragma("unroll") for (int q = 0; q < 8; q++) K3_LOADX(rd, 0, 0, q)                         \
+            K3_LOADW(rd, 0, 0)                                                                          \
+            _Pragma("unroll") for (int st = 0; st < 9; st++) {                                          \
+                const int cur = st & 1, dxs = st / 3, dys = st - 3 * dxs, grp = dxs & 1;                \
+                if (st < 5) K3_DMA_A(st, wr, a_so)                                                      \
+                if (st >= 5 && st - 5 < BK) K3_DMA_B(st - 5, wr, b_so)                                  \
+                if (st == 0 && BK == 5) K3_DMA_B(4, wr, b_so)                                           \
+                if (st + 1 < 9) K3_LOADW(rd, cur ^ 1, st + 1)                                           \
+                if (dxs < 2) {   /* a third of the next column's 8 pixel fragments */                  \
+                    _Pragma("unroll") for (int q = 3 * dys; q < 3 * dys + 3 && q < 8; q++) K3_LOADX(rd, grp ^ 1, dxs + 1, q) \
+                }                                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                /* D[cout][pixel] += W[cout][k] X[k][pixel] */                                          \
+                _Pragma("unroll") for (int tm_ = 0; tm_ < 2; tm_++) _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) _Pragma("unroll") for (int mb_ = 0; mb_ < MB; mb_++) \
+                    acc[tm_][h_][mb_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][mb_], fa[grp][2 * (tm_ + dys) + h_], (Z) && st == 0 ? zero4 : acc[tm_][h_][mb_], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+            } }
+        // two stages (64 input channels) per step of the chunk loop, so that the buffers are compile-time; the tile's first pair
+        // is a separate instantiation (its wait differs, see conv3x3_dma2_kernel)
+#define K3_PAIR(ck, WAITC, FIRST)                                                                       \
+        {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
+            __builtin_amdgcn_s_barrier();                                                               \
+            unsigned a_so = (unsigned)((ck) + 1) * plane_bytes, b_so = K3_SLAB0(ct) + (unsigned)((ck) + 1) * (DT_BCH * 16u); \
+            K3_STAGE_BODY(lds0, lds1, FIRST)                                                            \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
+            __builtin_amdgcn_s_barrier();                                                               \
+            if ((ck) + 2 < nchunks) {                                                                   \
+                a_so = (unsigned)((ck) + 2) * plane_bytes;                                              \
+                b_so = K3_SLAB0(ct) + (unsigned)((ck) + 2) * (DT_BCH * 16u);                            \
+            } else {                                                                                    \
+                const int nt = tile + gridDim.x;                                                        \
+                K3_TILE_OFFSETS(nt)                                                                     \
+                a_so = 0u;                                                                              \
+                b_so = nt < total_tiles ? K3_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
+            }                                                                                           \
+            K3_STAGE_BODY(lds1, lds0, false) }
+        K3_PAIR(0, WAIT_TILE, true)
+        for (int ck = 2; ck < nchunks; ck += 2) K3_PAIR(ck, 0x0F70, false)
+#undef K3_PAIR
+#undef K3_STAGE_BODY
+#undef K3_LOADW
+#undef K3_LOADX
+        // epilogue: this wave's two rows
+        const int cout_chunks = (Cout + 31) >> 5;
+        const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
+        const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int gx = tx0 + 16 * h + p16;
+            const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
+            if constexpr (EPI == 2) {
+                // class ArgMax (channels < Cout <= 12) of the fp16-rounded logits, first maximum wins: lane group g holds classes
+                // 4g..4g+3 of pixel p16; groups 1 and 2 send (value bits << 8 | index) to group 0
+#pragma unroll
+                for (int tm = 0; tm < 2; tm++) {
+                    const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][4 * g]), sf = *reinterpret_cast<const float4*>(&s_ss[1][4 * g]);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                    _Float16 bv = (_Float16)-65504.f; int bi = 255;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float val = __builtin_fmaf(acc[tm][h][0][q], scv[q], sfv[q]);
+                        if (RELU) val = fmaxf(val, 0.f);
+                        const _Float16 hvq = (_Float16)val;
+                        if (4 * g + q < Cout && (bi == 255 || hvq > bv)) { bv = hvq; bi = 4 * g + q; }
+                    }
+                    unsigned short vb; memcpy(&vb, &bv, 2);
+                    const int mine = (int)(((unsigned)vb << 8) | (unsigned)bi);
+                    const int t1 = __shfl(mine, p16 + 16, 64), t2 = __shfl(mine, p16 + 32, 64);
+                    _Float16 best = bv; int lab = bi;                                   // classes 0-3 (group 0)
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int t = k ? t2 : t1;
+                        unsigned short tb = (unsigned short)((unsigned)t >> 8); _Float16 tv; memcpy(&tv, &tb, 2);
+                        const int ti = t & 255;
+                        if (ti != 255 && (lab == 255 || tv > best)) { best = tv; lab = ti; }
+                    }
+                    const bool live = (tm ? live1 : live0) && g == 0;
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lab, rsO, live ? (unsigned)((f * H + y0 + tm) * W + gx) : 0x80000000u, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < MB / 2; j++) {                                // pairs of M blocks = 32-channel chunks
+                    uint4v vec[2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; tm++) {
+                        unsigned pk[2][2];                                            // [M block of the pair][half2]
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const int cl = 16 * (2 * j + e) + 4 * g;
+                            const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
+                            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2) {
+                                const float2v val = {__builtin_fmaf(acc[tm][h][2 * j + e][q], scv[q], sfv[q]), __builtin_fmaf(acc[tm][h][2 * j + e][q + 1], scv[q + 1], sfv[q + 1])};
+                                half2v h2 = __builtin_convertvector(val, half2v);
+                                if (RELU) h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
+                                memcpy(&pk[e][q >> 1], &h2, 4);
+                            }
+                        }
+                        // even lane groups keep block 2j (channels 4g..4g+3) and receive the odd group's block 2j (4g+4..4g+7);
+                        // odd groups receive the even group's block 2j+1 (4g-4..4g-1) and keep their own (4g..4g+3)
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                        vec[tm].x = s0[0]; vec[tm].y = s1[0]; vec[tm].z = s0[1]; vec[tm].w = s1[1];
+                    }
+                    const unsigned byte = (unsigned)((g & 1) * 32 + (g >> 1) * 16);   // even groups: block 2j, channels 4g..; odd: block 2j+1, channels 4(g-1)..
+                    conv_emit<EPI>(vec, rsO, rsC, f, y0, gx, live0, live1, ct * (MB / 2) + j, cout_chunks, H, W, byte, !(p16 & 1));
+                }
+            }
+        }
+    }
+#undef K3_DMA_A
+#undef K3_DMA_B
+#undef K3_TILE_OFFSETS
+#undef K3_SLAB0
+}
+
 // ------------------------------------------------------------------ conv3x3 of an input with <= 8 channels (the network's first layer)
 // The input is one 8-channel (16-byte) vector per pixel, [n][H][W][8].  A 16-deep MFMA K step then covers TWO taps: the
 // lower half-wave (k 0..7) reads tap 2s and the upper (k 8..15) tap 2s+1 of the same LDS plane, i.e. the two halves just use
@@ -864,6 +1121,25 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
 #define wt_bytes wt_bytes_k
 #define out_bytes out_bytes_k
 #endif
+    if (variant == 3) {
+        // conv3x3_k32_kernel: one persistent 8-wave block per CU; 64-channel tiles, or 32-channel ones when the last round of
+        // 64-wide tiles would leave more of the chip idle than the extra input staging of 32-wide tiles costs
+        const int cus = conv_grid_limit();
+        auto rounds = [&](int units, int tiles_n) { int gr = cus - cus % tiles_n; if (gr > units) gr = units; return (units + gr - 1) / gr; };
+        int mb = 4, nct_k = nct;
+        if (epi == 2) { mb = 1; nct_k = (Cout + 15) / 16; }
+        else if (Cout % 64 == 0 && rounds(2 * total, 2 * nct) * 0.56 < rounds(total, nct) * 1.0) { mb = 2; nct_k = 2 * nct; }
+        const int total_k = tx * ty * nct_k;
+        int grid = cus - cus % nct_k; if (grid > total_k) grid = total_k;
+#define K3_LAUNCH(R, E, M) conv3x3_k32_kernel<R, E, M><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
+        if (epi == 2) { if (relu) K3_LAUNCH(true, 2, 1); else K3_LAUNCH(false, 2, 1); }
+        else if (epi == 1 && mb == 2) { if (relu) K3_LAUNCH(true, 1, 2); else K3_LAUNCH(false, 1, 2); }
+        else if (epi == 1) { if (relu) K3_LAUNCH(true, 1, 4); else K3_LAUNCH(false, 1, 4); }
+        else if (mb == 2) { if (relu) K3_LAUNCH(true, 0, 2); else K3_LAUNCH(false, 0, 2); }
+        else { if (relu) K3_LAUNCH(true, 0, 4); else K3_LAUNCH(false, 0, 4); }
+#undef K3_LAUNCH
+        return hipGetLastError();
+    }
     if (variant == 2) {
         // two persistent 4-wave blocks per CU (conv3x3_dma2_kernel); the grid is a multiple of the cout-tile count so a block keeps
         // its weight slab.  Tiles are 64 output channels wide, or 32 when that balances the CUs better: blocks b and b + grid/2
