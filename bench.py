@@ -43,7 +43,7 @@ def algorithmic_bytes(stage, P, nkp):
     }.get(stage, 0)
 
 
-STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
+STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
                  "blur": ["blur_kernel"], "describe": ["describe_kernel"], "match": ["match_seq_kernel"],
                  "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel"]}
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the three bench lines and the rocprofv3 runs the summaries under profiles/ are made from.
+# Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc'
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+if [ "$1" = "stats" ]; then
+  timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err
+  timeout 300 python3 bench.py --segnet --frames 256 --batch 32 --steps 3 --warmup 1 > $O/line_segnet.json 2> $O/line_segnet.err
+  timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 > $O/line_stereo.json 2> $O/line_stereo.err
+  rm -rf $O/p_stats $O/p_seg $O/p_st
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 2 --warmup 1 --no-cpu > $O/p_stats.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 128 --batch 32 --steps 2 --warmup 1 --no-cpu > $O/p_seg.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --stereo-workers 1 > $O/p_st.log 2>&1
+  tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
+else
+  export SSM_BENCH_H2D=0
+  rm -rf $O/p_sq $O/p_fetch $O/p_write
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_sq.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_write.log 2>&1
+  tail -3 $O/p_sq.log | cut -c1-300
+fi
