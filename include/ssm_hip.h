@@ -210,7 +210,8 @@ int ssm_segnet_forward_dev(ssm_ctx* ctx, const uint8_t* bgr_dev, int n, uint8_t*
 /* single layer ops on host NHWC fp16 tensors, for exact per-op tests (integer-valued data makes fp16/fp32 exact):
  * op 0 = conv layer `arg` on in[H][W][CinPad16] -> out[H][W][CoutPad16]; op 1 = max-pool 2x2 s2 ceil with C = arg:
  * in[H][W][C] -> out[PH][PW][C] + code[PH][PW][C]; op 2 = unpool: in[PH][PW][C] + code -> out[H][W][C];
- * op 3 = conv layer `arg` + max-pool through the fused kernel: out[PH][PW][CoutPad16] + code (same shape) */
+ * op 3 = conv layer `arg` + max-pool through the fused kernel: out[PH][PW][CoutPad16] + code (same shape);
+ * op 4 = un-pool + conv layer `arg` through the fused kernel: in[PH][PW][CinPad16] + code (same shape) -> out[H][W][CoutPad16] */
 int ssm_segnet_debug_op(ssm_ctx* ctx, int op, int arg, const uint16_t* in, int H, int W, uint16_t* out, uint8_t* code);
 /* class logits (12 floats per net pixel, 360*480 pixels) of frame 0 of the most recent forward: for tolerance tests */
 int ssm_segnet_logits(ssm_ctx* ctx, float* out);

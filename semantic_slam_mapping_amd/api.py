@@ -223,6 +223,17 @@ class Context:
         self._chk(self.lib.ssm_segnet_debug_op(self.h, 3, layer, _ptr(xin), h, w, _ptr(out), _ptr(code)))
         return out[:, :, :cout], code[:, :, :cout]
 
+    def segnet_debug_unpool_conv(self, layer, pooled_hwc_f16, code, h, w):
+        """un-pool (to h x w) + conv + BN + ReLU of `layer` through the fused kernel the network uses."""
+        cin, cout, _, _ = self.segnet_layers()[layer]
+        x = np.ascontiguousarray(pooled_hwc_f16, np.float16); ph, pw, c = x.shape
+        ci16, co16 = (cin + 15) & ~15, (cout + 15) & ~15
+        xin = np.zeros((ph, pw, ci16), np.float16); xin[:, :, :c] = x
+        cin_code = np.zeros((ph, pw, ci16), np.uint8); cin_code[:, :, :c] = code
+        out = np.zeros((h, w, co16), np.float16)
+        self._chk(self.lib.ssm_segnet_debug_op(self.h, 4, layer, _ptr(xin), h, w, _ptr(out), _ptr(cin_code)))
+        return out[:, :, :cout]
+
     def segnet_debug_pool(self, x_hwc_f16):
         x = np.ascontiguousarray(x_hwc_f16, np.float16); h, w, c = x.shape
         out = np.zeros(((h + 1) // 2, (w + 1) // 2, c), np.float16); code = np.zeros(out.shape, np.uint8)

@@ -378,11 +378,15 @@ __device__ unsigned long long g_conv_phase[8][4]; // [probe block][mfma phase, e
 #define D2_ACH (2 * DT_PLANE)
 #define D2_BCH (9 * 2 * CT_N)                 // 1152 chunks of weights per stage = 18 wave-instructions
 #define D2_STAGE (D2_AINS * 64 + D2_BCH)      // 2432 chunks = 38,912 B per LDS buffer
-template <bool RELU, int EPI, int NT>
+// UP: the input is a max-pooled tensor + its arg-max codes and the convolution runs on the un-pooled (2x) image without that
+// image ever being written: the DMA of a halo pixel fetches the pooled pixel (y/2, x/2), the thread that issued it also loads
+// the 8 code bytes of that chunk, and once the stage has landed it zeroes, in LDS, the channels whose code is not this
+// pixel's position in its 2x2 window (each thread masks exactly the chunks it fetched, before the stage's barrier).
+template <bool RELU, int EPI, int NT, bool UP = false>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
                     _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
-                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue)
+                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue, const uint8_t* __restrict__ ucode)
 {
     __shared__ __attribute__((aligned(16))) half8 lds0[D2_STAGE];
     __shared__ __attribute__((aligned(16))) half8 lds1[D2_STAGE];
@@ -391,11 +395,13 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     const int VH = (H + 2) & ~1, VR = n * VH;
     const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
     const int nchunks = Cin / CT_KC;
-    const unsigned plane_bytes = (unsigned)H * W * 64u;
+    const int UPH = (H + 1) >> 1, UPW = (W + 1) >> 1;                             // UP: the pooled input's size
+    const unsigned plane_bytes = UP ? (unsigned)UPH * UPW * 64u : (unsigned)H * W * 64u;   // one 32-channel chunk of one input frame
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
     const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
     const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
+    const auto rsU = __builtin_amdgcn_make_buffer_rsrc((void*)ucode, 0, UP ? in_bytes / 2 : 0, 0x00020000);   // codes: one byte per pooled element
     constexpr int BROW = 32 * NT;
     constexpr int BINS = 9 * 2 * BROW / 64;                                        // weight wave-instructions per stage: 18 or 9
     constexpr int BK = (BINS + 3) / 4;                                             // per wave: 5 or 3
@@ -416,12 +422,15 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     }
     unsigned a_off[5], b_off[5]; int b_j[5];
     int a_py[5], a_px[5]; unsigned a_c8[5];
+    unsigned u_pos[5]; uint2v u_code[5];                                           // UP: 2x2 position of the slot's pixel (x 0x01010101), its chunk's codes
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const int i = (wv + 4 * k) * 64 + lane;
         const int c8 = i / DT_PLANE, p = i - c8 * DT_PLANE;
         a_py[k] = i < D2_ACH ? p / DT_PW : -0x10000;
         a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
+        // tile origins are even in x and y (and so is a frame's first row in the stacked image): the parity of a halo pixel is the slot's
+        u_pos[k] = (unsigned)((((p / DT_PW) - 1) & 1) * 2 + ((a_px[k] - 1) & 1)) * 0x01010101u; u_code[k] = uint2v{0u, 0u};
         b_j[k] = min(wv + 4 * k, BINS - 1);
         // packed weights: [tap][c8 of 4][cout 64][8]; a stage takes c8 = 2 half + {0, 1} (the half is in the scalar offset).
         // LDS rows are (tap, c) x BROW couts; with NT = 1 a wave-instruction fills two rows with the first 32 couts of each
@@ -435,15 +444,36 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
             const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
             const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
-            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u; \
+            a_off[k] = !ok ? 0x80000000u : UP ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)(y >> 1) * UPW + (gx >> 1)) * 64u + a_c8[k] \
+                                              : ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k]; \
         } }
 #ifdef CT_ABL_NODMA
 #define D2_DMA_A(k, dst, so) asm volatile("" :: "v"(a_off[k]), "s"(so));
 #define D2_DMA_B(k, dst, so) asm volatile("" :: "v"(b_off[k]), "s"(so));
 #else
-#define D2_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 4 * (k)) * 64], 16, a_off[k], so, 0, 0);
+#define D2_DMA_A(k, dst, so) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 4 * (k)) * 64], 16, a_off[k], so, 0, 0); \
+                               if (UP) u_code[k] = __builtin_amdgcn_raw_buffer_load_b64(rsU, a_off[k] >> 1, (so) >> 1, 0); }   /* out of range -> 0 */
 #define D2_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[D2_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
 #endif
+    // UP: zero the channels of this thread's five chunks of `buf` whose code differs from the pixel's position; codes are 0..3, so
+    // byte equality is ~(t | t >> 1) & 1 on t = code ^ position; v_perm spreads the flags to 16-bit lanes, v_pk_mul_lo_u16 applies them
+#define D2_UNPOOL_MASK(buf)                                                                             \
+    if (UP) {                                                                                           \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
+            const int idx_ = (wv + 4 * k) * 64 + lane;                                                  \
+            uint4v d_ = *reinterpret_cast<const uint4v*>(&buf[idx_]);                                   \
+            const unsigned t0_ = u_code[k].x ^ u_pos[k], t1_ = u_code[k].y ^ u_pos[k];                  \
+            const unsigned e0_ = ~(t0_ | (t0_ >> 1)) & 0x01010101u, e1_ = ~(t1_ | (t1_ >> 1)) & 0x01010101u; \
+            typedef unsigned short us2_ __attribute__((ext_vector_type(2)));                            \
+            const unsigned m_[4] = {__builtin_amdgcn_perm(0u, e0_, 0x0C010C00u), __builtin_amdgcn_perm(0u, e0_, 0x0C030C02u), \
+                                    __builtin_amdgcn_perm(0u, e1_, 0x0C010C00u), __builtin_amdgcn_perm(0u, e1_, 0x0C030C02u)}; \
+            unsigned o_[4] = {d_.x, d_.y, d_.z, d_.w};                                                  \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) { us2_ a_, b_; memcpy(&a_, &o_[q], 4); memcpy(&b_, &m_[q], 4); a_ = a_ * b_; memcpy(&o_[q], &a_, 4); } \
+            d_.x = o_[0]; d_.y = o_[1]; d_.z = o_[2]; d_.w = o_[3];                                     \
+            *reinterpret_cast<uint4v*>(&buf[idx_]) = d_;                                                \
+        }                                                                                               \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): the masked chunks are in LDS before the barrier */ \
+    }
 #ifdef CT_ABL_NOBAR
 #define D2_BARRIER()
 #else
@@ -467,6 +497,10 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         const unsigned bso = D2_SLAB0(tile % ncout_tiles);
 #pragma unroll
         for (int k = 0; k < 5; k++) { D2_DMA_A(k, lds0, 0u) if (k < BK) D2_DMA_B(k, lds0, bso) }
+        // UP: the first tile's codes are waited for here, once: left alone the compiler sinks these loads below the stores that
+        // follow, and the wait it then needs at the top of the tile loop (one code path for the first and all later tiles)
+        // would drain the epilogue stores of every tile
+        if (UP) { _Pragma("unroll") for (int k = 0; k < 5; k++) asm volatile("" : "+v"(u_code[k].x), "+v"(u_code[k].y) :: "memory"); }
         const uint4v z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 256 * k), 0, 0);
@@ -512,6 +546,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         // (one merged path makes the compiler's own vmcnt bookkeeping pessimistic: it then drains the epilogue stores)
 #define D2_CHUNK(ck, WAITC, FIRST)                                                                      \
         {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
+            D2_UNPOOL_MASK(lds0)                                                                        \
             D2_BARRIER();                                                               \
             /* the counter fetch is older than this stage's DMA and is covered by the stage's closing vmcnt(0); as inline    \
                assembly, because the compiler would wait for a returning atomic at the end of the branch (draining the   \
@@ -523,6 +558,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             D2_STAGE_BODY(lds0, lds1, FIRST)                                                                \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
             if (FIRST && tid == 0) s_next = (blocks_per_ct + fetched_) * ncout_tiles + my_ct;           \
+            D2_UNPOOL_MASK(lds1)                                                                        \
             D2_BARRIER();                                                               \
             if ((ck) + 1 < nchunks) {                                                                   \
                 a_so = (unsigned)((ck) + 1) * plane_bytes;                                              \
@@ -609,6 +645,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #undef D2_DMA_A
 #undef D2_DMA_B
 #undef D2_BARRIER
+#undef D2_UNPOOL_MASK
 #undef D2_TILE_OFFSETS
 #undef D2_SLAB0
 }
@@ -1103,17 +1140,24 @@ static int conv_grid_limit()
     return cus;
 }
 // epi 0: conv; 1: conv + max-pool (out pooled, code); 2: conv + class ArgMax (out = uint8 labels [n][H][W]; Cout <= 12)
+static int conv_variant()
+{
+    static const int variant = [] { const char* e = getenv("SSM_CONV_VARIANT"); return e ? atoi(e) : 2; }();
+    return variant;
+}
+// ucode != nullptr: `in` is the max-pooled tensor of an H x W image and ucode its arg-max codes (un-pool on load, variant 2 only)
 static hipError_t conv_dma_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
-                                  int CinPad, int Cout, int relu, int epi, hipStream_t s)
+                                  int CinPad, int Cout, int relu, int epi, hipStream_t s, const uint8_t* ucode = nullptr)
 {
     const int nct = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1, cs = (Cout + 31) & ~31;
-    const unsigned long long in_bytes = (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct * CT_N * CinPad * 9 * 2;
+    const unsigned long long in_bytes = ucode ? (unsigned long long)n * ((H + 1) / 2) * ((W + 1) / 2) * CinPad * 2 : (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct * CT_N * CinPad * 9 * 2;
     const unsigned long long out_bytes = epi == 1 ? (unsigned long long)n * ((H + 1) / 2) * ((W + 1) / 2) * cs * 2 : epi == 2 ? (unsigned long long)n * H * W : (unsigned long long)n * H * W * cs * 2;
     if (epi == 2 && Cout > 12) return hipErrorInvalidValue;
     // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
     if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
-    static const int variant = [] { const char* e = getenv("SSM_CONV_VARIANT"); return e ? atoi(e) : 2; }();
+    const int variant = conv_variant();
+    if (ucode && (variant != 2 || epi != 0 || !relu)) return hipErrorInvalidValue;
 #ifdef SSM_CONV_ABLATE   /* scripts/ubench/conv_bench.hip only: zero-sized buffer descriptors drop the stores (1) / turn the DMA into zero fills (2) */
     static const int abl = [] { const char* e = getenv("SSM_CONV_ABL"); return e ? atoi(e) : 0; }();
     const unsigned long long in_bytes_k = (abl & 2) ? 0 : in_bytes, wt_bytes_k = (abl & 2) ? 0 : wt_bytes, out_bytes_k = (abl & 1) ? 0 : out_bytes;
@@ -1162,15 +1206,18 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
         else if (Cout % 64 == 0 && makespan(2 * total, 2 * nct, 0.56) < makespan(total, nct, 1.0)) { nt_w = 1; nct_k = 2 * nct; }
         const int total_k = tx * ty * nct_k;
         int grid = 2 * cus; grid -= grid % nct_k; if (grid > total_k) grid = total_k;
-#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue)
+#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode)
+#define D2_LAUNCH_UP(N) conv3x3_dma2_kernel<true, 0, N, true><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode)
         int* queue = conv_tile_queue(s);
         if (!queue || nct_k > 32) return hipErrorOutOfMemory;
-        if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
+        if (ucode) { if (nt_w == 1) D2_LAUNCH_UP(1); else D2_LAUNCH_UP(2); }
+        else if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
         else if (epi == 1 && nt_w == 1) { if (relu) D2_LAUNCH(true, 1, 1); else D2_LAUNCH(false, 1, 1); }
         else if (epi == 1) { if (relu) D2_LAUNCH(true, 1, 2); else D2_LAUNCH(false, 1, 2); }
         else if (nt_w == 1) { if (relu) D2_LAUNCH(true, 0, 1); else D2_LAUNCH(false, 0, 1); }
         else { if (relu) D2_LAUNCH(true, 0, 2); else D2_LAUNCH(false, 0, 2); }
 #undef D2_LAUNCH
+#undef D2_LAUNCH_UP
         return hipGetLastError();
     }
     // variant 1: one persistent 8-wave block per CU (the LDS holds one)
@@ -1219,6 +1266,15 @@ hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* sca
 {
     if (CinPad % (2 * CT_KC)) return hipErrorInvalidValue;
     return conv_dma_launch(in, wt, scale, shift, labels, nullptr, n, H, W, CinPad, Cout, 0, 2, s);
+}
+// un-pool + conv + BN + ReLU in one pass: `pooled` is [n][CinPad/32][(H+1)/2][(W+1)/2][32] with its codes, out the H x W convolution
+// of the un-pooled image (which is never written).  Only the default kernel has this form: k_segnet_conv_unpool_available().
+int k_segnet_conv_unpool_available() { return conv_variant() == 2; }
+hipError_t k_segnet_conv_unpool(const void* pooled, const uint8_t* ucode, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
+                                int CinPad, int Cout, hipStream_t s)
+{
+    if (CinPad % (2 * CT_KC) || !ucode) return hipErrorInvalidValue;
+    return conv_dma_launch(pooled, wt, scale, shift, out, nullptr, n, H, W, CinPad, Cout, 1, 0, s, ucode);
 }
 hipError_t k_segnet_pool(const void* in, int n, int H, int W, int C, void* out, uint8_t* code, hipStream_t s)
 {

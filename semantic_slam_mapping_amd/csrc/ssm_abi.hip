@@ -876,6 +876,15 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
         std::swap(cur, nxt); return SSM_OK;
     };
     auto unpool = [&](int i, int PH, int PW, int C, int H, int W) -> int { HIPCHK(c, k_segnet_unpool(cur, g->code[i], nb, PH, PW, C, nxt, H, W, s)); std::swap(cur, nxt); return SSM_OK; };
+    // un-pool + the convolution that consumes it as one kernel (the 4x sparse tensor is never written); the other conv kernels
+    // (SSM_CONV_VARIANT) run the two steps
+    const bool fused_up = k_segnet_conv_unpool_available() != 0;
+    auto unpool_conv = [&](int i, int PH, int PW, int C, int H, int W, int l) -> int {
+        if (!fused_up) { int r_ = unpool(i, PH, PW, C, H, W); return r_ ? r_ : conv(l); }
+        const SegLayerDef& d = k_seg_layers[l];
+        HIPCHK(c, k_segnet_conv_unpool(cur, g->code[i], g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, s));
+        std::swap(cur, nxt); return SSM_OK;
+    };
     // conv + pool pairs run as one kernel (the full-resolution activation of the pooled layer is never written)
     auto conv_pool = [&](int l, int i) -> int {
         const SegLayerDef& d = k_seg_layers[l];
@@ -888,11 +897,11 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
     if ((r = conv(4)) || (r = conv(5)) || (r = conv_pool(6, 2))) return r;
     if ((r = conv(7)) || (r = conv(8)) || (r = conv_pool(9, 3))) return r;
     if ((r = conv(10)) || (r = conv(11)) || (r = conv_pool(12, 4))) return r;
-    if ((r = unpool(4, 12, 15, 512, 23, 30)) || (r = conv(13)) || (r = conv(14)) || (r = conv(15))) return r;
-    if ((r = unpool(3, 23, 30, 512, 45, 60)) || (r = conv(16)) || (r = conv(17)) || (r = conv(18))) return r;
-    if ((r = unpool(2, 45, 60, 256, 90, 120)) || (r = conv(19)) || (r = conv(20)) || (r = conv(21))) return r;
-    if ((r = unpool(1, 90, 120, 128, 180, 240)) || (r = conv(22)) || (r = conv(23))) return r;
-    if ((r = unpool(0, 180, 240, 64, 360, 480)) || (r = conv(24))) return r;
+    if ((r = unpool_conv(4, 12, 15, 512, 23, 30, 13)) || (r = conv(14)) || (r = conv(15))) return r;
+    if ((r = unpool_conv(3, 23, 30, 512, 45, 60, 16)) || (r = conv(17)) || (r = conv(18))) return r;
+    if ((r = unpool_conv(2, 45, 60, 256, 90, 120, 19)) || (r = conv(20)) || (r = conv(21))) return r;
+    if ((r = unpool_conv(1, 90, 120, 128, 180, 240, 22)) || (r = conv(23))) return r;
+    if ((r = unpool_conv(0, 180, 240, 64, 360, 480, 24))) return r;
     if (logits_out) { if ((r = conv(25))) return r; *logits_out = cur; }
     else {
         const SegLayerDef& d = k_seg_layers[25];
@@ -1011,6 +1020,25 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
             out[p * co16 + ch] = hout[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
             code[p * co16 + ch] = hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
         }
+    } else if (op == 4) {                 // un-pool (in = pooled PH x PW image of the layer's input channels, code = its arg-max codes) + conv + BN + ReLU of layer `arg`, one kernel
+        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || g->cinp[arg] == 8) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused un-pool + conv kernel takes");
+        if (!k_segnet_conv_unpool_available()) FAIL(c, SSM_E_INVAL, "the selected conv kernel (SSM_CONV_VARIANT) has no un-pool-on-load form");
+        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15, cs = g->coutstore[arg], cip = g->cinp[arg];
+        std::vector<uint16_t> hin((size_t)PH * PW * cip, 0), hout((size_t)H * W * cs);
+        std::vector<uint8_t> hcode((size_t)PH * PW * cip, 0);
+        for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < ci16; ch++) {
+            hin[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = in[p * ci16 + ch];
+            hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = code[p * ci16 + ch];
+        }
+        r = ensure_scratch(c, hcode.size()); if (r) return r;
+        uint8_t* dcode = (uint8_t*)c->d_scratch;
+        HIPCHK(c, k_segnet_begin(s));
+        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(dcode, hcode.data(), hcode.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(c, k_segnet_conv_unpool(g->actA, dcode, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, cip, k_seg_layers[arg].cout, s));
+        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < co16; ch++) out[p * co16 + ch] = hout[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32];
     } else FAIL(c, SSM_E_INVAL, "unknown op");
     HIPCHK(c, hipStreamSynchronize(s));
     return SSM_OK;

@@ -102,6 +102,9 @@ hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* sca
                                 int CinPad, int Cout, hipStream_t s);
 hipError_t k_segnet_conv_pool(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
                               int CinPad, int Cout, hipStream_t s);
+int k_segnet_conv_unpool_available();
+hipError_t k_segnet_conv_unpool(const void* pooled, const uint8_t* ucode, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
+                                int CinPad, int Cout, hipStream_t s);
 hipError_t k_segnet_pool(const void* in, int n, int H, int W, int C, void* out, uint8_t* code, hipStream_t s);
 hipError_t k_segnet_unpool(const void* in, const uint8_t* code, int n, int PH, int PW, int C, void* out, int H, int W, hipStream_t s);
 hipError_t k_segnet_argmax(const void* logits, int n, int npix, int Cstore, int ncls, uint8_t* labels, hipStream_t s);

@@ -91,6 +91,25 @@ def test_conv_pool_fused_exact(ctx, layer, h, w):
     assert np.array_equal(c, c_ref)
 
 
+@pytest.mark.parametrize("layer,h,w", [(24, 23, 31), (22, 45, 60), (19, 16, 32), (13, 17, 33), (16, 90, 64)])
+def test_unpool_conv_fused_exact(ctx, layer, h, w):
+    """the decoder's un-pool -> conv pairs run as ONE kernel (the pooled tensor is expanded and masked while it is staged in
+    LDS; the 4x sparse image is never written): output must equal un-pool -> conv through the separate kernels bit for bit
+    (integer data, random codes incl. clipped windows at odd sizes)"""
+    cin, cout, _, _ = ctx.segnet_layers()[layer]
+    rng = np.random.default_rng(layer * 131 + h)
+    wt = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
+    sc = (2.0 ** rng.integers(-7, -4, cout)).astype(np.float32); sh = rng.integers(-3, 4, cout).astype(np.float32)
+    ctx.segnet_set_layer(layer, wt, sc, sh)
+    full = rng.integers(-2, 6, (h, w, cin)).astype(np.float16)                # codes of a real pooling (never point outside the image)
+    pooled, code = ctx.segnet_debug_pool(full)
+    up = ctx.segnet_debug_unpool(pooled, code, h, w)
+    ref = ctx.segnet_debug_conv(layer, up)
+    out = ctx.segnet_debug_unpool_conv(layer, pooled, code, h, w)
+    assert np.array_equal(out, ref)
+    assert np.abs(ref.astype(np.float32)).sum() > 0
+
+
 def test_segnet_blocks_against_committed_fixture(ctx, seg):
     """G6 fixtures (tests/golden/segnet.npz, minted from PyTorch-CPU by make_golden.py): conv + BN + ReLU layers incl. the
     3-channel first and the 12-channel last one, max-pool with first-maximum indices, mask-driven unpool -- bit for bit"""
