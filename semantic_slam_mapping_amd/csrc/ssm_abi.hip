@@ -880,7 +880,10 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
     // (SSM_CONV_VARIANT) run the two steps
     const bool fused_up = k_segnet_conv_unpool_available() != 0;
     auto unpool_conv = [&](int i, int PH, int PW, int C, int H, int W, int l) -> int {
-        if (!fused_up) { int r_ = unpool(i, PH, PW, C, H, W); return r_ ? r_ : conv(l); }
+        // measured per layer (32 frames): the fused form wins where the un-pooled tensor is large (64 ch @360x480: 357 vs 586 us,
+        // 128 ch @180x240: 330 vs 433, 256 ch @90x120: 338 vs 354) and loses on the small 512-channel images, where the masking
+        // pass on the stage's critical path costs more than the separate un-pool (362 vs 327, 121 vs 103 us)
+        if (!fused_up || C > 256) { int r_ = unpool(i, PH, PW, C, H, W); return r_ ? r_ : conv(l); }
         const SegLayerDef& d = k_seg_layers[l];
         HIPCHK(c, k_segnet_conv_unpool(cur, g->code[i], g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, s));
         std::swap(cur, nxt); return SSM_OK;
