@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
+    ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
+                    "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
     ap.add_argument("--stereo-workers", type=int, default=int(os.environ.get("SSM_STEREO_WORKERS", "4")), help="configs[3]: frame pairs in flight (host threads, one context each)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
     args = ap.parse_args()
@@ -249,7 +251,7 @@ def main():
         step()
     # ---- timed region: K steps as a user runs them (map / SegNet stage on a second stream beside the ORB -> match chain);
     # hipEvents per stage are recorded here too, but these stage times overlap
-    ctx.set_profiling(1)
+    ctx.set_profiling(2 if args.serial_only else 1)
     fence()
     t0 = time.perf_counter()
     stage_ovl = {}
@@ -264,7 +266,9 @@ def main():
     # so that a stage's hipEvent bracket is that kernel alone (this is also what profiles/*_kernel_stats.md lists)
     ctx.set_profiling(2)
     stage_acc = {}
-    for _ in range(args.steps):
+    if args.serial_only:                               # the timed region already ran serialised: every launch of the process is of that kind
+        stage_acc = {k: list(v) for k, v in stage_ovl.items()}
+    for _ in range(0 if args.serial_only else args.steps):
         step()
         for k, (ms, ln) in ctx.stage_times().items():
             a = stage_acc.setdefault(k, [0.0, 0])
@@ -274,7 +278,7 @@ def main():
     # ---- PCIe-inclusive rate (reported beside `value`, never as `value`): the same steps with the frames copied from pinned
     # host memory to the device inside the timed region (bgr + depth + labels + pose = 2.46 MB per frame), copy and compute overlapped
     h2d_fps = None
-    if world == 1 and not args.segnet and os.environ.get("SSM_BENCH_H2D", "1") == "1":
+    if world == 1 and not args.segnet and not args.serial_only and os.environ.get("SSM_BENCH_H2D", "1") == "1":
         try:
             hb = [t.cpu().pin_memory() for t in (bgr, dep, sem, pose)]
             torch.cuda.synchronize()
