@@ -330,7 +330,7 @@ hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_
 //     issued up front, the horizontal half of the dilate is done on a 48-bit window in registers, every kept pixel is
 //     unprojected / transformed / quantised exactly like K11+K12, consecutive pixels with the same (voxel, label) are
 //     summed in registers (two runs per thread, further runs go straight to LDS), then ONE wave-wide segmented DPP scan
-//     per run slot merges neighbouring threads, the run tails update a block-local LDS hash (<= 128 voxels per 4096
+//     per run slot merges neighbouring threads, the run tails update a block-local LDS hash (256 slots for the 3 x 4096
 //     pixels) and the block flushes it with one global atomic group per voxel.  No block barrier before the flush.
 //     The point list of generatePointCloud is never written: exact integer sums make the map independent of order, so
 //     the result is bit-identical to mask -> backproject -> insert (tests/test_gpu_parity.py).
@@ -412,7 +412,8 @@ __device__ __forceinline__ uint32_t label_hash_entry(int k)
     }
     return 0xFF000001u;
 }
-#define MS_SLOTS 128
+#define MS_SLOTS 256
+#define MS_CH 3                // 4096-pixel chunks (consecutive rows of one frame) a block accumulates in its LDS table before the flush
 struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
 __device__ __forceinline__ uint32_t label_of_bgr24(uint32_t bgr)     // b | g<<8 | r<<16
 {
@@ -441,7 +442,7 @@ __device__ __forceinline__ void lds_vox_update(LdsVox* lt, long long key, uint32
         atomicAdd(reinterpret_cast<unsigned long long*>(&e->sz), (unsigned long long)f.sz);
         atomicAdd(&e->r, f.r); atomicAdd(&e->g, f.g); atomicAdd(&e->b, f.b); atomicAdd(&e->n, f.n);
         if (lab < 12) atomicAdd(&e->hist[lab >> 1], f.n << (16 * (lab & 1)));
-    } else {                                                    // block touches > 128 voxels: straight to the global table
+    } else {                                                    // the block table is full: straight to the global table
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
         if (v) { vox_add(v, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n); if (lab < 12) atomicAdd(&v->hist[lab], f.n); }
     }
@@ -491,10 +492,14 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     if (tid == 0) s_npts = 0;
     __syncthreads();
     uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
-    const int wi = blockIdx.x * 256 + tid;                      // 16-pixel word of this frame
+    int kept = 0;
+    // MS_CH chunks per block: neighbouring rows share most of their voxels, so the block table (and the global atomics of the
+    // flush, whose latency nothing overlaps) is paid once per 16 K pixels instead of once per 4 K
+#pragma unroll 1
+    for (int ch = 0; ch < MS_CH; ch++) {
+    const int wi = (blockIdx.x * MS_CH + ch) * 256 + tid;       // 16-pixel word of this frame
     long long k0 = -2, k1 = -2; uint32_t l0 = 255, l1 = 255; RunAcc a0, a1;
     a0.sx = a0.sy = a0.sz = 0; a0.r = a0.g = a0.b = a0.n = 0; a1 = a0;
-    int kept = 0;
     if (wi < words) {
         const size_t gw = (size_t)blockIdx.y * words + wi;
         const int gy = wi / wpr, xw = wi - gy * wpr, gx0 = xw << 4;
@@ -579,6 +584,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     // two wave-wide merges (first runs, second runs); waves of a block are independent until the final flush
     if (__ballot(k0 != -2)) wave_flush(lt, k0, l0, a0, lane, tab, cap_log2, counters, occ);
     if (__ballot(k1 != -2)) wave_flush(lt, k1, l1, a1, lane, tab, cap_log2, counters, occ);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
     if (lane == 0 && kept) atomicAdd(&s_npts, kept);
@@ -623,9 +629,9 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
         }
         fast = seen_ok;
     }
-    if (fast) map_stream_kernel<true><<<dim3((words + 255) / 256, n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
+    if (fast) map_stream_kernel<true><<<dim3((words + 256 * MS_CH - 1) / (256 * MS_CH), n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
                                                                                   1.0f / leaf, tab, cap_log2, counters, npoints);
-    else map_stream_kernel<false><<<dim3((words + 255) / 256, n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
+    else map_stream_kernel<false><<<dim3((words + 256 * MS_CH - 1) / (256 * MS_CH), n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
                                                                                1.0f / leaf, tab, cap_log2, counters, npoints);
     return hipGetLastError();
 }
