@@ -1,5 +1,5 @@
 // kernels_match.hip -- K6: OrbFeature::match (/root/reference/src/orb.cpp:16-29) = cv::BFMatcher(NORM_HAMMING)
-// knnMatch(k=2) + Lowe ratio test, for gfx950.  One 1024-thread block per (query frame, train frame) pair: the train
+// knnMatch(k=2) + Lowe ratio test, for gfx950.  One block per (query frame, train frame) pair (two in the sequence kernel): the train
 // descriptors are staged in LDS (32 B each, read back as wave-wide broadcasts), every lane owns one query descriptor
 // in 8 VGPRs, distance = 8 x (v_xor + v_bcnt accumulate); the kept matches are compacted in ascending queryIdx with
 // wave ballots.  Integer work, VALU-bound: no MFMA by design.  Tie rule = oracle/match.c (strict '<' scan in train
@@ -25,27 +25,35 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)   
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// T threads work on the queries [qb, qe).  pend == nullptr: the block owns the whole pair.  Otherwise the pair is split over two
+// blocks (the sequence kernel: 5 pairs per frame are too few, and too coarse, to balance 256 CUs): role 1 (queries from 0) publishes
+// its match count in *pend when its matches are written; role 2 (the rest) computes, then waits for that count, appends its matches
+// behind it and writes the total.  Role 1 has the lower block index, so it is dispatched no later than role 2: the wait cannot starve it.
+template <int T>
 __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
                                            double ratio, int cap, ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout,
-                                           int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
+                                           int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist,
+                                           int qb = 0, int qe = -1, int32_t* __restrict__ pend = nullptr, int role = 0)
 {
     __shared__ uint4 tr[TCH * 2];
-    __shared__ int wcnt[MT / 64];
+    __shared__ int wcnt[T / 64];
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (qe < 0) qe = nq;
     if (tid == 0) base = 0;
-    for (int q0 = 0; q0 < nq; q0 += MT * QPL) {
+    bool waited = role != 2;
+    for (int q0 = qb; q0 < qe; q0 += T * QPL) {
         uint4 a[QPL], b[QPL]; uint32_t k0[QPL], k1[QPL];
 #pragma unroll
         for (int u = 0; u < QPL; u++) {
-            const int qi = q0 + u * MT + tid;
+            const int qi = q0 + u * T + tid;
             a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u]; k0[u] = 0xFFFFFFFFu; k1[u] = 0xFFFFFFFFu;
-            if (qi < nq) { const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); a[u] = p[0]; b[u] = p[1]; }
+            if (qi < qe) { const uint4* p = reinterpret_cast<const uint4*>(q + (size_t)qi * 32); a[u] = p[0]; b[u] = p[1]; }
         }
         for (int t0 = 0; t0 < nt; t0 += TCH) {
             const int m = min(TCH, nt - t0);
             __syncthreads();
-            for (int i = tid; i < m * 2; i += MT) tr[i] = reinterpret_cast<const uint4*>(t + (size_t)t0 * 32)[i];
+            for (int i = tid; i < m * 2; i += T) tr[i] = reinterpret_cast<const uint4*>(t + (size_t)t0 * 32)[i];
             __syncthreads();
             // one train descriptor (two ds_read_b128 broadcasts) against the lane's QPL queries
             auto one_train = [&](int j) {
@@ -72,12 +80,16 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
         }
 #pragma unroll
         for (int u = 0; u < QPL; u++) {
-            const int qi = q0 + u * MT + tid;
+            const int qi = q0 + u * T + tid;
             const int d0 = k0[u] >> 16, i0 = k0[u] & 0xFFFF, d1 = k1[u] >> 16, i1 = k1[u] & 0xFFFF;
-            if (knn_idx && qi < nq) { knn_idx[2*qi] = i0; knn_idx[2*qi+1] = i1; knn_dist[2*qi] = d0; knn_dist[2*qi+1] = d1; }
+            if (knn_idx && qi < qe) { knn_idx[2*qi] = i0; knn_idx[2*qi+1] = i1; knn_dist[2*qi] = d0; knn_dist[2*qi+1] = d1; }
             // ratio test exactly as orb.cpp:25: float distance < double ratio * float distance, compared in double
-            const bool keep = (qi < nq) && ((double)(float)d0 < ratio * (double)(float)d1);
+            const bool keep = (qi < qe) && ((double)(float)d0 < ratio * (double)(float)d1);
             const unsigned long long bal = __ballot(keep);
+            if (!waited) {                                      // role 2, first compaction: the matches of the first half come first
+                if (tid == 0) { int v; while ((v = atomicAdd(pend, 0)) < 0) __builtin_amdgcn_s_sleep(8); base = v; }
+                waited = true;
+            }
             __syncthreads();
             if (lane == 0) wcnt[wv] = __popcll(bal);
             __syncthreads();
@@ -88,10 +100,12 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
                 if (out && k < cap) { ssm_dmatch mm; mm.queryIdx = qi; mm.trainIdx = i0; mm.imgIdx = 0; mm.distance = (float)d0; out[k] = mm; }
             }
             __syncthreads();
-            if (tid == 0) { int s = 0; for (int w = 0; w < MT / 64; w++) s += wcnt[w]; base += s; }
+            if (tid == 0) { int s = 0; for (int w = 0; w < T / 64; w++) s += wcnt[w]; base += s; }
         }
     }
     __syncthreads();
+    if (role == 1) { __threadfence(); if (tid == 0) atomicExch(pend, base); return; }     // matches visible, then the count
+    if (!waited && tid == 0) { int v; while ((v = atomicAdd(pend, 0)) < 0) __builtin_amdgcn_s_sleep(8); base = v; }   // role 2 without queries
     if (tid == 0 && nout) *nout = base;
 }
 
@@ -100,7 +114,7 @@ match_pairs_kernel(const uint8_t* __restrict__ desc, const MatchPair* __restrict
                    ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout, int32_t* __restrict__ knn_idx, int32_t* __restrict__ knn_dist)
 {
     const MatchPair p = pairs[blockIdx.x];
-    match_pair(desc + (size_t)p.qoff * 32, p.nq, desc + (size_t)p.toff * 32, p.nt, ratio, cap,
+    match_pair<MT>(desc + (size_t)p.qoff * 32, p.nq, desc + (size_t)p.toff * 32, p.nt, ratio, cap,
                out ? out + (size_t)p.out_slot * cap : nullptr, nout ? nout + p.out_slot : nullptr, knn_idx, knn_dist);
 }
 hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs, double ratio, int cap,
@@ -113,21 +127,26 @@ hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs
 // sequence mode: desc/nkp hold `hist` history frames followed by the frames of the call; frame f (0-based in the call)
 // sits at row hist+f.  Block (r, f): query = ref frame row f+r+hist-R ... i.e. the r-th of the R frames preceding f,
 // oldest first (std::deque order of Tracker::refFrames, src/track.cpp:150); train = frame f (orb->match(pFrame, cur)).
-__global__ void __launch_bounds__(MT)
+// Two blocks of MT / 2 threads per pair (blockIdx.x = 2 r + half): R n pairs of ~150 us each on 256 CUs leave a third of the chip
+// idle in the last round; halves give twice the blocks at half the length.  pend[pair] starts at -1 (the launcher's memset).
+__global__ void __launch_bounds__(MT / 2)
 match_seq_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int f0, int R, int hist, double ratio, int cap,
-                 ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout)
+                 ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout, int32_t* __restrict__ pend)
 {
-    const int f = f0 + blockIdx.y, r = blockIdx.x;
+    const int f = f0 + blockIdx.y, r = blockIdx.x >> 1, half = blockIdx.x & 1;
     const int cur = hist + f, ref = cur - R + r;
     const int slot = f * R + r;
     const int nq = ref >= 0 ? nkp[ref] : -1, nt = nkp[cur];
-    if (nq < 0 || nt < 2) { if (threadIdx.x == 0) nout[slot] = -1; return; }
-    match_pair(desc + (size_t)ref * cap * 32, nq, desc + (size_t)cur * cap * 32, nt, ratio, cap,
-               out + (size_t)slot * cap, nout + slot, nullptr, nullptr);
+    if (nq < 0 || nt < 2) { if (threadIdx.x == 0 && half == 0) nout[slot] = -1; return; }
+    const int split = min(nq, (((nq + 1) >> 1) + 63) & ~63);
+    match_pair<MT / 2>(desc + (size_t)ref * cap * 32, nq, desc + (size_t)cur * cap * 32, nt, ratio, cap,
+                       out + (size_t)slot * cap, nout + slot, nullptr, nullptr, half ? split : 0, half ? nq : split, pend + blockIdx.y * R + r, half + 1);
 }
 hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
-                       ssm_dmatch* out, int32_t* nout, hipStream_t s)
+                       ssm_dmatch* out, int32_t* nout, int32_t* pend, hipStream_t s)
 {
-    match_seq_kernel<<<dim3(R, n), MT, 0, s>>>(desc, nkp, f0, R, hist, ratio, cap, out, nout);
+    hipError_t e = hipMemsetAsync(pend, 0xFF, sizeof(int32_t) * (size_t)n * R, s);
+    if (e != hipSuccess) return e;
+    match_seq_kernel<<<dim3(2 * R, n), MT / 2, 0, s>>>(desc, nkp, f0, R, hist, ratio, cap, out, nout, pend);
     return hipGetLastError();
 }

@@ -90,7 +90,7 @@ struct ssm_ctx {
     // sequence outputs
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
-    ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
+    ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
     // voxel tables
     VoxTable map, tmp;
     // SegNet
@@ -339,7 +339,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
-                     c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints,
+                     c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab };
     for (void* p : ptrs) if (p) hipFree(p);
     for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); if (c->d_xgrp[l]) hipFree(c->d_xgrp[l]); }
@@ -684,11 +684,11 @@ static int ensure_seq(ssm_ctx* c, int n)
     // keep the history rows across the re-allocation
     uint8_t* old_desc = c->d_desc_all; int32_t* old_nkp = c->d_nkp_all; const int old_prev = c->prev_n;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    void* olds[] = { c->d_kps, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints };
+    void* olds[] = { c->d_kps, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints, c->d_match_pend };
     for (void* p : olds) if (p) hipFree(p);
-    c->d_kps = nullptr; c->d_pos3d = nullptr; c->d_matches = nullptr; c->d_nmatch = nullptr; c->d_npoints = nullptr;
+    c->d_kps = nullptr; c->d_pos3d = nullptr; c->d_matches = nullptr; c->d_nmatch = nullptr; c->d_npoints = nullptr; c->d_match_pend = nullptr;
     DALLOC(c, c->d_kps, (size_t)n * g.cap); DALLOC(c, c->d_pos3d, (size_t)n * g.cap * 3);
-    DALLOC(c, c->d_matches, (size_t)n * R * g.cap); DALLOC(c, c->d_nmatch, (size_t)n * R); DALLOC(c, c->d_npoints, (size_t)n);
+    DALLOC(c, c->d_matches, (size_t)n * R * g.cap); DALLOC(c, c->d_nmatch, (size_t)n * R); DALLOC(c, c->d_match_pend, (size_t)n * R); DALLOC(c, c->d_npoints, (size_t)n);
     uint8_t* nd; int32_t* nn;
     DALLOC(c, nd, (size_t)(n + R) * g.cap * 32); DALLOC(c, nn, (size_t)(n + R));
     if (!c->d_hist_tmp) DALLOC(c, c->d_hist_tmp, (size_t)R * g.cap * 32 + (size_t)R * 4);
@@ -744,7 +744,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         }
         if (stages & SSM_STAGE_MATCH) {
             prof_begin(c, "match");
-            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->stream));
+            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend, c->stream));
             prof_end(c);
         }
         if (!side_work) continue;

@@ -56,7 +56,7 @@ hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs
                          ssm_dmatch* out, int32_t* nout, int32_t* knn_idx, int32_t* knn_dist, hipStream_t s);
 // as k_match_pairs but pair descriptors derived on the device from nkp[] (sequence mode)
 hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
-                       ssm_dmatch* out, int32_t* nout, hipStream_t s);
+                       ssm_dmatch* out, int32_t* nout, int32_t* pend /* n * R ints of scratch */, hipStream_t s);
 
 // mapper front half
 hipError_t k_moving_mask(const uint8_t* sem, int n, int w, int h, uint8_t* mask, hipStream_t s);
