@@ -53,7 +53,7 @@ def measured_traffic(stage, frames_per_launch):
     FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None"""
     try:
         k = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
-        return round(sum(k[n]["total_bytes_per_frame_fetch_x2"] for n in STAGE_KERNELS[stage]) * frames_per_launch)
+        return round(sum(v["total_bytes_per_frame_fetch_x2"] for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage])) * frames_per_launch)
     except Exception:
         return None
 

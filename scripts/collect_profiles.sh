@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 if [ "$1" = "stats" ]; then
   timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err
-  timeout 300 python3 bench.py --segnet --frames 256 --batch 32 --steps 3 --warmup 1 > $O/line_segnet.json 2> $O/line_segnet.err
+  timeout 300 python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 > $O/line_segnet.json 2> $O/line_segnet.err
   timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 > $O/line_stereo.json 2> $O/line_stereo.err
   rm -rf $O/p_stats $O/p_seg $O/p_st
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_stats.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 128 --batch 32 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --stereo-workers 1 > $O/p_st.log 2>&1
   tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
 else
