@@ -81,6 +81,10 @@ struct ssm_ctx {
     // batch workspace (B frames)
     uint8_t *d_pyr = nullptr, *d_blur = nullptr; int32_t* d_cellmax = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
     int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr;
+    // second ORB / map workspace: ssm_seq_process runs alternate sub-batches as two chains on two streams (allocated at first use)
+    struct AltWork { uint8_t *pyr = nullptr, *blur = nullptr; int32_t* cellmax = nullptr; cand_t* cand = nullptr; uint16_t* nodeof = nullptr;
+                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; bool ready = false; } alt;
+    hipEvent_t ev_orb[2] = {nullptr, nullptr};
     uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
     ssm_point* d_points = nullptr;
     // staging for the host-pointer entry points (one frame) + generic scratch
@@ -265,6 +269,7 @@ static int ctx_init(ssm_ctx* c)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[1], hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
     for (int l = 1; l < g.nlevels; l++) {
@@ -342,6 +347,9 @@ extern "C" void ssm_destroy(ssm_ctx* c)
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab };
     for (void* p : ptrs) if (p) hipFree(p);
+    { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask };
+      for (void* p : ap) if (p) hipFree(p); }
+    for (int i = 0; i < 2; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
     for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); if (c->d_xgrp[l]) hipFree(c->d_xgrp[l]); }
     if (c->seg) {
         SegNetState* g = c->seg;
@@ -391,6 +399,26 @@ extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, in
     return SSM_OK;
 }
 
+// second workspace for the two-chain mode of ssm_seq_process (same sizes as ctx_init's)
+static int ensure_alt(ssm_ctx* c)
+{
+    if (c->alt.ready) return SSM_OK;
+    const OrbGeom& g = c->g; const int B = c->B;
+    DALLOC(c, c->alt.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->alt.blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->alt.cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, c->alt.cand, (size_t)B * g.cand_total); DALLOC(c, c->alt.nodeof, (size_t)B * g.cand_total);
+    DALLOC(c, c->alt.ncand, (size_t)B * g.nlevels); DALLOC(c, c->alt.sel, (size_t)B * g.sel_total); DALLOC(c, c->alt.nsel, (size_t)B * g.nlevels);
+    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H);
+    c->alt.ready = true;
+    return SSM_OK;
+}
+struct ChainSwap {                    // chain 1 of ssm_seq_process: the helpers use c->stream and the c->d_* workspace; point both at the second set
+    ssm_ctx* c; bool on;
+    void swap_all() { std::swap(c->stream, c->stream2); std::swap(c->d_pyr, c->alt.pyr); std::swap(c->d_blur, c->alt.blur); std::swap(c->d_cellmax, c->alt.cellmax);
+                      std::swap(c->d_cand, c->alt.cand); std::swap(c->d_nodeof, c->alt.nodeof); std::swap(c->d_ncand, c->alt.ncand); std::swap(c->d_sel, c->alt.sel);
+                      std::swap(c->d_nsel, c->alt.nsel); std::swap(c->d_mask, c->alt.mask); }
+    ChainSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) swap_all(); }
+    ~ChainSwap() { if (on) swap_all(); }
+};
 // ---------------------------------------------------------------- the ORB front end for nb frames already on the device
 static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_t* d_depth, int nb,
                    ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp)
@@ -728,23 +756,37 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     // Two streams: the ORB -> match chain of a sub-batch and its (SegNet ->) map stage share no data, only the inputs, so the
     // map side runs on stream2.  The chain's latency-bound kernels (pyramid, octree, describe) then overlap VALU/MFMA-bound
     // map / SegNet work.  stream2 starts behind everything already queued on the context stream and is joined at the end.
-    const bool side_work = (stages & (SSM_STAGE_MAP | SSM_STAGE_SEGNET)) != 0, side = side_work && !c->serialize;
-    if (side) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    const bool side_work = (stages & (SSM_STAGE_MAP | SSM_STAGE_SEGNET)) != 0;
+    // Two chains: without the SegNet stage (one activation workspace) and with two or more sub-batches, alternate sub-batches run
+    // their whole ORB -> match -> map chain on the context stream and on stream2 with a workspace each, so that one chain's
+    // latency-bound kernels (quad-tree, pyramid launches, block tails) overlap the other chain's VALU-bound ones.  The only
+    // dependence between neighbours is the matcher's: the reference descriptors of sub-batch b - 1 (an event per chain).
+    const bool two_chains = !c->serialize && !(stages & SSM_STAGE_SEGNET) && n > c->B && (stages & SSM_STAGE_ORB) && (W & 15) == 0;
+    const bool side = side_work && !c->serialize && !two_chains;
+    if (two_chains) { r = ensure_alt(c); if (r) return r; }
+    if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     struct StreamSwap {               // the helpers below launch on c->stream; point it at stream2 for the side work
         ssm_ctx* c; bool on;
         StreamSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) std::swap(c->stream, c->stream2); }
         ~StreamSwap() { if (on) std::swap(c->stream, c->stream2); }
     };
-    for (int f0 = 0; f0 < n; f0 += c->B) {
+    int bi = 0;
+    for (int f0 = 0; f0 < n; f0 += c->B, bi++) {
         const int nb = (n - f0 < c->B) ? n - f0 : c->B;
+        const int chain = two_chains ? (bi & 1) : 0;
+        ChainSwap cs(c, chain == 1);                                      // from here c->stream / c->d_* are this chain's
         if (stages & SSM_STAGE_ORB) {
             r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
                         c->d_kps + (size_t)f0 * g.cap, desc + (size_t)f0 * row, c->d_pos3d + (size_t)f0 * g.cap * 3, nkp + f0);
             if (r) return r;
+            if (two_chains) {
+                HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
+                if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[chain ^ 1], 0));     // the previous sub-batch's descriptors
+            }
         }
         if (stages & SSM_STAGE_MATCH) {
             prof_begin(c, "match");
-            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend, c->stream));
+            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend + (size_t)f0 * R, c->stream));
             prof_end(c);
         }
         if (!side_work) continue;
@@ -779,7 +821,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             }
         }
     }
-    if (side) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     c->prev_n = n;
     if (out) {
         out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;
