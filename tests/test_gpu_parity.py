@@ -382,3 +382,40 @@ def test_orb_other_scale_factors(oracle, frames, scale, levels):
         assert np.array_equal(gd, od)
     finally:
         c.close()
+
+
+def test_two_chain_mode_equals_single_stream():
+    """ssm_seq_process runs alternate sub-batches as two chains on two streams (own workspace each, one event per chain for the
+    matcher's reference descriptors); profiling mode 2 keeps every kernel on one stream with one workspace.  Same outputs, bit for
+    bit, incl. ragged last sub-batch and a continued sequence."""
+    import semantic_slam_mapping_amd as ssm
+    W, H, n = 640, 480, 23
+    c = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=18, camera=CAM)
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    off = (W * H * 3, W * H * 2, W * H * 3, 128)
+    try:
+        c.synth_frames_dev(SEED, 200, n, *bufs)
+        def run(mode):
+            c.set_profiling(mode); c.map_clear()
+            out = c.seq_process(*bufs, 15); c.sync(); a = c.seq_fetch(out, 15)
+            out = c.seq_process(*[b + 15 * o for b, o in zip(bufs, off)], n - 15, continue_sequence=True); c.sync(); b = c.seq_fetch(out, n - 15)
+            c.set_profiling(0)
+            return a, b, c.map_export()
+        a1, b1, m1 = run(0)
+        a2, b2, m2 = run(2)
+        for x, y in ((a1, a2), (b1, b2)):
+            for k in ("nkp", "nmatch", "npoints"):
+                assert np.array_equal(x[k], y[k]), k
+            for f in range(len(x["nkp"])):
+                kk = int(x["nkp"][f])
+                assert same_struct(x["kps"][f, :kk], y["kps"][f, :kk]) and np.array_equal(x["desc"][f, :kk], y["desc"][f, :kk])
+                for r in range(x["nmatch"].shape[1]):
+                    m = int(x["nmatch"][f, r])
+                    if m > 0:
+                        assert same_struct(x["matches"][f, r, :m], y["matches"][f, r, :m])
+        assert same_struct(m1, m2) and len(m1) > 1000
+        assert (b1["nmatch"][0] > 0).all()                       # the continued call saw the previous call's frames as references
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
