@@ -99,7 +99,7 @@ def stereo_main(args):
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=K) if K > 1 else None
     pairs = [stereo_pair(Hd, Wd, 100 + rank * 1000 + i, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), noise=4) for i in range(F + 1)]
-    from semantic_slam_mapping_amd.oracle_binding import Oracle
+    from oracle.binding import Oracle
     orc = Oracle()
     samples = None
     stage_ms = {"quad_track": 0.0, "sgbm": 0.0, "vo": 0.0}
@@ -354,7 +354,7 @@ def main():
                           "stream beside ORB + match (stages_us_per_frame_overlapped)")
         cpu = None
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:
-            from semantic_slam_mapping_amd.oracle_binding import Oracle, build
+            from oracle.binding import Oracle, build
             try:
                 build(native=True); orc = Oracle(native=True)
             except Exception:

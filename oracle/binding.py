@@ -1,13 +1,13 @@
-"""ctypes binding of the CPU oracle (oracle/libssm_oracle.so).  TEST INFRASTRUCTURE: imported only by tests/,
+"""ctypes binding of the CPU oracle (oracle/libssm_oracle.so), kept beside it.  TEST INFRASTRUCTURE: imported only by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product path (api.py / _lib.py)."""
 import ctypes as C
 import os
 import subprocess
 import numpy as np
-from .api import KEYPOINT_DTYPE, DMATCH_DTYPE, POINT_DTYPE, VOXEL_DTYPE, PMATCH_DTYPE
+from semantic_slam_mapping_amd.api import KEYPOINT_DTYPE, DMATCH_DTYPE, POINT_DTYPE, VOXEL_DTYPE, PMATCH_DTYPE
 
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_DIR = os.path.join(_ROOT, "oracle")
+ORACLE_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(ORACLE_DIR)
 
 
 class Cam(C.Structure):

@@ -5,7 +5,7 @@ import sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import semantic_slam_mapping_amd as ssm
-from semantic_slam_mapping_amd.oracle_binding import Oracle
+from oracle.binding import Oracle
 from test_sgbm import stereo_pair, KITTI
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
-    from semantic_slam_mapping_amd.oracle_binding import Oracle, build
+    from oracle.binding import Oracle, build
     build()
     return Oracle()
 

@@ -104,7 +104,7 @@ def test_voxel_tables_merge_exactly(oracle):
 
 def test_palette_matches_reference_png():
     info = json.load(open(os.path.join(G, "palette.json")))
-    from semantic_slam_mapping_amd.oracle_binding import Oracle
+    from oracle.binding import Oracle
     o = Oracle()
     for i, (b, g, r) in enumerate(info["palette_bgr"]):
         assert o.L.sso_label_of_bgr(b, g, r) == i

@@ -22,7 +22,7 @@ def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
     from semantic_slam_mapping_amd import sharding, VOXEL_DTYPE
-    from semantic_slam_mapping_amd.oracle_binding import Oracle
+    from oracle.binding import Oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
