@@ -347,6 +347,15 @@ def main():
                     "note": "integer/byte kernel limited by VALU issue (measured 36 T lane-op/s) and LDS, not HBM: see DESIGN.md s.4"}
         if roof.get("bound") == "hbm":
             roof["valu"] = measured_valu(dom, per_stage[dom][1])      # what actually bounds the integer stages
+        try:    # the whole pipeline against the VALU issue ceiling: every kernel's wave-instructions per frame (committed SQ pass) x 64 x frames/s
+            kk = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_counters.json")))["kernels"]
+            wi = sum(v["valu_wave_insts_per_frame"] for name, v in kk.items() if "synth" not in name)
+            if not args.segnet:
+                roof["pipeline_valu"] = {"achieved": round(wi * 64 * value / 1e12, 2), "peak": VALU_LANEOPS_PEAK / 1e12, "unit": "Tlaneop/s",
+                                         "frac": round(wi * 64 * value / VALU_LANEOPS_PEAK, 3), "wave_insts_per_frame": round(wi),
+                                         "note": "all kernels of a frame (ORB, match, map) at the timed rate `value`, two chains overlapped"}
+        except Exception:
+            pass
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
         roof["stages_us_per_frame_overlapped"] = {k: round(v[0] / args.steps / F * 1e3, 3) for k, v in sorted(stage_ovl.items(), key=lambda kv: -kv[1][0])}
         roof["timing"] = ("achieved / stages_us_per_frame: hipEvents around each stage in a second pass of the same K steps with all stages "
