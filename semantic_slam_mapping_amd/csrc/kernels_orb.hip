@@ -356,6 +356,9 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
         const int gq = tid & 31, r0 = tid >> 5;
         const uint32_t t1 = (uint32_t)(min_th + 1) * 0x00010001u;
         const int gx0 = tx0 + 4 * gq;                                   // first of the 4 positions; sx = 4 gq + 1 + j
+        unsigned xvalid = 0;                                            // positions inside the FAST window of the level, in x (the same for every row)
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (gx0 + j >= SSM_EDGE && gx0 + j < w - SSM_EDGE) xvalid |= 1u << j;
 #pragma unroll 1
         for (int sy = r0; sy < FT_SH; sy += 8) {
             const int gy = ty0 + sy - 1;
@@ -372,10 +375,10 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
                 auto widen = [&](uint32_t w) { uint32_t r = __builtin_amdgcn_perm(0u, w, sel); short2v o; __builtin_memcpy(&o, &r, 4); return o; };
                 const short2v c = widen(C);
                 const short2v a = widen(D) - c, bq = widen(Rw) - c, cq = widen(U) - c, d = widen(Lw) - c;
-                const short2v br = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(a, bq), __builtin_elementwise_min(bq, cq)),
-                                                             __builtin_elementwise_max(__builtin_elementwise_min(cq, d), __builtin_elementwise_min(d, a)));
-                const short2v dk = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_max(a, bq), __builtin_elementwise_max(bq, cq)),
-                                                             __builtin_elementwise_min(__builtin_elementwise_max(cq, d), __builtin_elementwise_max(d, a)));
+                // max over the four adjacent pairs of the cycle a-b-c-d of min(x, y) = min(max(a, c), max(b, d)): "some adjacent pair is
+                // above the threshold" is (A or C) and (B or D); likewise the min over pairs of max = max(min(a, c), min(b, d))
+                const short2v br = __builtin_elementwise_min(__builtin_elementwise_max(a, cq), __builtin_elementwise_max(bq, d));
+                const short2v dk = __builtin_elementwise_max(__builtin_elementwise_min(a, cq), __builtin_elementwise_min(bq, d));
                 short2v t1v; __builtin_memcpy(&t1v, &t1, 4);
                 const short2v e = __builtin_elementwise_max(br, (short2v)(0 - dk)) - t1v;      // >= 0  <=>  pass
                 uint32_t eb; __builtin_memcpy(&eb, &e, 4);
@@ -383,12 +386,7 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
                 passbits |= ((~eb >> 31) & 1u) << (2 * hpair + 1);
             }
             // positions outside the FAST window of the level never pass
-            unsigned valid = 0;
-            if (gy >= SSM_EDGE && gy < h - SSM_EDGE) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (gx0 + j >= SSM_EDGE && gx0 + j < w - SSM_EDGE) valid |= 1u << j;
-            }
-            passbits &= valid;
+            passbits &= (gy >= SSM_EDGE && gy < h - SSM_EDGE) ? xvalid : 0u;
             // compaction: wave scan of the per-thread counts, one LDS reservation per wave
             const uint32_t cntp = __popc(passbits);
             const uint32_t incl = wave_incl_scan_u32(cntp);
@@ -409,8 +407,8 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
                 const uint8_t* p = &px[(sy + 3) * FT_PW + sx + 3];
                 const int v = p[0];
                 const int a = p[3 * FT_PW] - v, b = p[3] - v, c = p[-3 * FT_PW] - v, d = p[-3] - v;
-                const int br = max(max(min(a, b), min(b, c)), max(min(c, d), min(d, a)));
-                const int dk = min(min(max(a, b), max(b, c)), min(max(c, d), max(d, a)));
+                const int br = min(max(a, c), max(b, d));
+                const int dk = max(min(a, c), min(b, d));
                 if (max(br, -dk) > min_th) list[atomicAdd(&nlist, 1)] = (uint16_t)((sy << 8) | sx);
             }
         }
