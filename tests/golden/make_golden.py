@@ -103,6 +103,16 @@ def g_palette():
         cols = sorted({(int(c[2]), int(c[1]), int(c[0])) for c in np.unique(im.reshape(-1, 3), axis=0)})
         info["colours_in_reference_000000_png_bgr"] = cols
         info["all_png_colours_in_palette"] = all(tuple(c) in [tuple(p) for p in pyref.PALETTE_BGR] for c in cols)
+    ref2 = "/root/reference/0002.png"                    # the README's SegNet output sample, at the net's 480 x 360
+    if os.path.exists(ref2):
+        from PIL import Image
+        im = np.array(Image.open(ref2).convert("RGB"))
+        cols, cnt = np.unique(im.reshape(-1, 3), axis=0, return_counts=True)
+        pal = [tuple(p) for p in pyref.PALETTE_BGR]
+        info["reference_0002_png"] = {"size_wh": [int(im.shape[1]), int(im.shape[0])],
+                                      "label_histogram": {str(pal.index((int(c[2]), int(c[1]), int(c[0])))): int(n) for c, n in zip(cols, cnt)
+                                                          if (int(c[2]), int(c[1]), int(c[0])) in pal},
+                                      "all_colours_in_palette": all((int(c[2]), int(c[1]), int(c[0])) in pal for c in cols)}
     json.dump(info, open(os.path.join(HERE, "palette.json"), "w"), indent=1)
 
 

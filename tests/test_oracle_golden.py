@@ -111,6 +111,9 @@ def test_palette_matches_reference_png():
     assert o.L.sso_label_of_bgr(1, 2, 3) == 255
     if "colours_in_reference_000000_png_bgr" in info:     # recorded when the fixture was minted next to /root/reference
         assert info["all_png_colours_in_palette"] and len(info["colours_in_reference_000000_png_bgr"]) == 12
+    if "reference_0002_png" in info:                      # the README's SegNet output sample: net resolution, palette colours only
+        r = info["reference_0002_png"]
+        assert r["size_wh"] == [480, 360] and r["all_colours_in_palette"] and sum(r["label_histogram"].values()) == 480 * 360
 
 
 # ---------------------------------------------------------------- ORB pieces and the whole extractor
