@@ -311,7 +311,7 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
 #define FT_SW (FT_W + 2)      // scored positions: tile + 1
 #define FT_SH (FT_H + 2)
 #define FT_SST 132
-#define FT_STAGE 1024
+#define FT_STAGE ((FT_PH * FT_PW) / 8)   // candidates staged per tile: as many as fit in the pixel tile they replace (680)
 __global__ void __launch_bounds__(256)
 fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax)
 {
@@ -320,7 +320,10 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     __shared__ uint16_t list[FT_SW * FT_SH];
     __shared__ int16_t cellx[FT_SW], celly[FT_SH];
     __shared__ int lmax[64];
-    __shared__ cand_t stage[FT_STAGE];
+    // occupancy is what this kernel lives on (LDS-limited: 27.5 KB gave 5 blocks per CU, 19.4 KB gives 8 = the 32-wave limit; 3.42 -> 2.7 us/frame),
+    // so the candidate staging area reuses the pixel tile: px is dead once every position is scored, and the NMS pass that fills
+    // `stage` starts behind the barrier that ends the scoring loop
+    cand_t* stage = reinterpret_cast<cand_t*>(px);
     __shared__ int nlist, nstage, gbase;
     const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
