@@ -413,6 +413,9 @@ __device__ __forceinline__ uint32_t label_hash_entry(int k)
     return 0xFF000001u;
 }
 #define MS_SLOTS 256
+#ifndef MS_MINB
+#define MS_MINB 4        // blocks per CU the register allocation is held to (16 waves per CU)
+#endif
 #define MS_CH 3                // 4096-pixel chunks (consecutive rows of one frame) a block accumulates in its LDS table before the flush
 struct LdsVox { long long key, sx, sy, sz; unsigned r, g, b, n; unsigned hist[6]; };
 __device__ __forceinline__ uint32_t label_of_bgr24(uint32_t bgr)     // b | g<<8 | r<<16
@@ -475,7 +478,7 @@ __device__ __forceinline__ double markstein_div(double n, double f, double r)
     return fma(fma(-q, f, n), r, q);
 }
 template <bool FASTDIV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MS_MINB)
 map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
                   const uint16_t* __restrict__ vbits, const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
                   float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints)
