@@ -23,7 +23,8 @@ W, H = 640, 480
 CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
 SEED = 0x5EED0000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-VALU_LANEOPS_PEAK = 36.0e12    # measured on this part: scripts/ubench/valu_rate.hip (integer VALU: one wave64 op / 4 clk / SIMD)
+VALU_LANEOPS_PEAK = 39.3e12    # 1024 SIMDs x 16 lanes per clock x 2.4 GHz (one wave64 integer op / 4 clk / SIMD); scripts/ubench/valu_rate.hip measures
+                               # 36 T at the ~2.2 GHz the chip holds under that load, and these kernels run at 2.2-2.3 GHz
 
 
 def algorithmic_bytes(stage, P, nkp):
