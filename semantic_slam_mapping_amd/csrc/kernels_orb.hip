@@ -522,12 +522,12 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     __shared__ QNode    nd[2][NODES];
     __shared__ uint32_t cnt[2][NODES];
     __shared__ uint32_t sq[2][NODES];
-    __shared__ uint32_t cc[NODES][4];
+    __shared__ __attribute__((aligned(8))) uint32_t cc[NODES][4];
     __shared__ short    newpos[NODES];
     __shared__ short    childpos[NODES][4];
     __shared__ short    order[NODES];
-    __shared__ unsigned long long best[NODES];
-    __shared__ cand_t   lkeys[OT_KCAP];
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(&cc[0][0]);   // final selection only, when the split passes (cc) are over: 40.5 KB -> 4 blocks per CU at NODES = 256
+    __shared__ uint32_t lkx[OT_KCAP];                                   // position + response word of every key; the cell word is read from global where needed
     __shared__ uint16_t lnof[OT_KCAP];
     __shared__ uint16_t cumn[NODES];
     __shared__ uint32_t sscan[OT_T / 64];
@@ -540,8 +540,9 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     const cand_t* gkeys = cand + (size_t)f * g.cand_total + L.cand_off;
     uint16_t* gnof = node_of + (size_t)f * g.cand_total + L.cand_off;
     const bool in_lds = nc <= OT_KCAP;                      // block-uniform
-    if (in_lds) for (int i = tid; i < nc; i += OT_T) lkeys[i] = gkeys[i];
-#define KEY(i) (in_lds ? lkeys[i] : gkeys[i])
+    if (in_lds) for (int i = tid; i < nc; i += OT_T) lkx[i] = gkeys[i].x;
+#define KEY(i) (gkeys[i])                                /* both words: key load and final selection only (global, coalesced) */
+#define KEYX(i) (in_lds ? lkx[i] : gkeys[i].x)           /* the word the split passes work on: LDS (the block is latency-bound and lives on how many fit a CU) */
 #define NOF(i) (in_lds ? lnof[i] : gnof[i])
 #define SETNOF(i, v) do { if (in_lds) lnof[i] = (uint16_t)(v); else gnof[i] = (uint16_t)(v); } while (0)
     uint32_t* out = sel + (size_t)f * g.sel_total + L.sel_off;
@@ -592,7 +593,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             const int ni = NOF(i);
             if (ni != DROPPED && ccnt[ni] > 1) {
                 const QNode q = cn[ni];
-                const uint32_t kx = KEY(i).x;
+                const uint32_t kx = KEYX(i);
                 const int x = kx & 4095, y = (kx >> 12) & 4095;
                 const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
@@ -735,7 +736,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             if (ni == DROPPED) continue;
             if (newpos[ni] == -2) {
                 const QNode q = cn[ni];
-                const uint32_t kx = KEY(i).x;
+                const uint32_t kx = KEYX(i);
                 const int x = kx & 4095, y = (kx >> 12) & 4095;
                 const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
@@ -771,7 +772,8 @@ hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* 
     int need = 0;
     for (int l = 0; l < g.nlevels; l++) need = need > g.L[l].nfeat + 3 ? need : g.L[l].nfeat + 3;
     for (int l = 0; l < g.nlevels; l++) need = need > 4 * g.L[l].nIni + 8 ? need : 4 * g.L[l].nIni + 8;
-    if (need <= 512 - 8) octree_kernel<512><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    if (need <= 256 - 8) octree_kernel<256><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
+    else if (need <= 512 - 8) octree_kernel<512><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
     else                 octree_kernel<1024><<<dim3(n, g.nlevels), OT_T, 0, s>>>(g, cand, ncand, cellmax, node_of, sel, nsel, status);
     return hipGetLastError();
 }
