@@ -419,3 +419,21 @@ def test_two_chain_mode_equals_single_stream():
         for p in bufs:
             c.dev_free(p)
         c.close()
+
+
+@pytest.mark.parametrize("nfeat", [2000, 4500])
+def test_orb_more_features_use_the_larger_quadtree_variants(oracle, frames, nfeat):
+    """the quad-tree kernel has 256-, 512- and 1024-node instantiations chosen by the feature count (1000 features: 256);
+    2000 and 4500 features exercise the other two"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=nfeat, max_batch=1, voxel_capacity_log2=12, camera=CAM)
+    try:
+        bgr = frames[3][0]
+        gk, gd, _ = c.detect_features(bgr)
+        ok, od = oracle.orb_extract(oracle.bgr2gray(bgr), nfeatures=nfeat)
+        assert len(gk) == len(ok) and len(ok) > nfeat * 0.8
+        for f in ("x", "y", "size", "response", "octave", "class_id", "angle"):
+            assert np.array_equal(gk[f], ok[f]), f
+        assert np.array_equal(gd, od)
+    finally:
+        c.close()
