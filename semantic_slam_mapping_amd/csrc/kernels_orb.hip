@@ -3,6 +3,7 @@
 // batched over frames (grid.y = frame).  Integer / byte work, HBM- and LDS-bound: no MFMA here by design.
 // Contracts (rounding rules, tie-breaks) are those of oracle/orb.c; compile with -ffp-contract=off.
 #include "ssm_internal.h"
+#include <cstdlib>
 
 #define WAVE 64
 
@@ -313,7 +314,7 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
 #define FT_SST 132
 #define FT_STAGE ((FT_PH * FT_PW) / 8)   // candidates staged per tile: as many as fit in the pixel tile they replace (680)
 __global__ void __launch_bounds__(256)
-fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax)
+fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t px[FT_PH * FT_PW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[FT_SH * FT_SST];
@@ -461,13 +462,13 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
                 cand_t c;
                 c.x = (uint32_t)(gx - L.minBX) | ((uint32_t)(gy - L.minBY) << 12) | ((uint32_t)(S - 1) << 24);
                 c.y = ((uint32_t)(ci * L.nCols + cj) << 14) | ((uint32_t)(gy - L.minBY - ci * L.hCell) << 7) | (uint32_t)(gx - L.minBX - cj * L.wCell);
-                if (k < FT_STAGE) stage[k] = c;
+                if (k < stage_cap) stage[k] = c;
                 else { const int kg = atomicAdd(nc, 1); if (kg < L.cand_cap) out[kg] = c; }     // tile with > FT_STAGE maxima: rare
             }
         }
     }
     __syncthreads();
-    const int ns = min(nstage, FT_STAGE);
+    const int ns = min(nstage, stage_cap);
     if (tid == 0 && ns) gbase = atomicAdd(nc, ns);
     __syncthreads();
     for (int k = tid; k < ns; k += 256) if (gbase + k < L.cand_cap) out[gbase + k] = stage[k];
@@ -482,7 +483,9 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(cellmax, 0, sizeof(int32_t) * (size_t)n * g.cells_total, s);
     if (e != hipSuccess) return e;
-    fast_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, g, cand, ncand, cellmax);
+    // SSM_FAST_STAGE_CAP (tests): a smaller staging area forces the per-candidate global path that tiles with more than FT_STAGE maxima take
+    static const int stage_cap = [] { const char* e = getenv("SSM_FAST_STAGE_CAP"); const int v = e ? atoi(e) : FT_STAGE; return v < 0 ? 0 : (v > FT_STAGE ? FT_STAGE : v); }();
+    fast_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap);
     return hipGetLastError();
 }
 

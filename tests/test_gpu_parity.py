@@ -437,3 +437,17 @@ def test_orb_more_features_use_the_larger_quadtree_variants(oracle, frames, nfea
         assert np.array_equal(gd, od)
     finally:
         c.close()
+
+
+def test_fast_stage_overflow_path_in_subprocess():
+    """a FAST tile stages its local maxima in LDS (680 of them) and reserves their place in the global list once; more than
+    that go to the list one by one.  No test image has such a tile (noise: 452 at most), so the path is forced with a
+    16-entry staging area (SSM_FAST_STAGE_CAP, read once per process) and the ORB parity tests are run again"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSM_FAST_STAGE_CAP="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "orb_synthetic_frames or orb_noise_image or orb_gray_input or seq_process_matches_oracle"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "deselected" in r.stdout
