@@ -451,3 +451,40 @@ def test_fast_stage_overflow_path_in_subprocess():
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "deselected" in r.stdout
+
+
+def test_sequence_path_small_leaf_and_many_keypoints(oracle):
+    """two fallbacks of the sequence path: (1) a 1 cm leaf gives far more voxels per 12 K pixels than the block-local LDS table of
+    map_stream_kernel holds (256), so most updates take the direct global path; (2) 1500 features per frame means train sets
+    above the matcher's 1024-descriptor LDS chunk (two chunks per pair, in both halves of the split pair).  Both against the oracle."""
+    import semantic_slam_mapping_amd as ssm
+    W, H, n = 640, 480, 4
+    c = ssm.Context(0, orb_features=1500, max_batch=2, voxel_capacity_log2=22, camera=CAM, mapper_resolution=0.01)
+    R = c.R
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    try:
+        c.synth_frames_dev(SEED, 300, n, *bufs)
+        fr = [oracle.synth_frame(SEED, 300 + i) for i in range(n)]
+        c.map_clear()
+        out = c.seq_process(*bufs, n); c.sync()
+        res = c.seq_fetch(out, n)
+        descs, clouds = [], []
+        for i in range(n):
+            ok, od = oracle.orb_extract(oracle.bgr2gray(fr[i][0]), nfeatures=1500)
+            k = int(res["nkp"][i])
+            assert k == len(ok) and k > 1100 and same_struct(res["kps"][i, :k], ok) and np.array_equal(res["desc"][i, :k], od)
+            descs.append(od)
+            for r in range(R):
+                ref = i - R + r
+                if ref < 0:
+                    continue
+                om = oracle.match(descs[ref], od, c.cfg.knn_match_ratio)
+                assert res["nmatch"][i, r] == len(om) and same_struct(res["matches"][i, r, :len(om)], om)
+            clouds.append(oracle.backproject(fr[i][1], fr[i][0], fr[i][2], oracle.moving_mask(fr[i][2]), CAM, fr[i][4], 40.0))
+        ref_map = oracle.voxel_filter(np.concatenate(clouds), np.float32(0.01))
+        got = c.map_export()
+        assert len(ref_map) > 50000 and same_struct(got, ref_map)
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
