@@ -174,8 +174,8 @@ def stereo_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (configs[1]: 1000)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("SSM_BATCH", "250")), help="frames per batched launch (a tuning knob: 5 MB of workspace per frame; "
                     "125 -> 250..500 is +5 % from fuller grids and fewer launch tails)")
