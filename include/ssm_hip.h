@@ -29,7 +29,8 @@ typedef enum {
     SSM_E_CAPACITY = -4,     /* caller buffer or internal table too small */
     SSM_E_TOO_FEW_TRAIN = -5,/* matcher needs >= 2 train descriptors (src/orb.cpp:25 indexes [1] unguarded) */
     SSM_E_VOXEL_RANGE = -6,  /* PCL VoxelGrid index-overflow guard would trip: output == input in the reference */
-    SSM_E_NODEVICE = -7
+    SSM_E_NODEVICE = -7,
+    SSM_E_COMM = -8          /* RCCL error (ssm_last_error has ncclGetErrorString) */
 } ssm_status;
 
 /* layout-identical to cv::KeyPoint (OpenCV 2.4), 28 bytes */
@@ -111,6 +112,24 @@ int ssm_map_merge_table(ssm_ctx* ctx, const ssm_voxel* tab, int n);            /
  * (it needs the voxel count on the host), merge is enqueued on the context stream */
 int ssm_map_export_table_dev(ssm_ctx* ctx, ssm_voxel* out_dev, int cap, int* n_out);
 int ssm_map_merge_table_dev(ssm_ctx* ctx, const ssm_voxel* tab_dev, int n);
+
+/* ---- multi-GPU (BASELINE.json configs[4]).  The reference is one process (experiment/exp_mapping.cpp:18-59), so these have no
+ * counterpart there.  One process per GPU; frames shard by contiguous block (each rank first runs its tracker_ref_frames halo frames with
+ * stages = SSM_STAGE_ORB, then its block with continue_sequence = 1, so that the match tables equal the single-GPU ones, src/track.cpp:150-152);
+ * every rank fuses its frames into its own context map; ssm_voxel_allgather merges the maps with ONE RCCL all-gather over xGMI.
+ * Bootstrap without any framework: rank 0 calls ssm_comm_get_unique_id and ships the SSM_COMM_ID_BYTES bytes to the other ranks (file, pipe,
+ * MPI, torch.distributed ...); every rank calls ssm_comm_init_rank (= ncclCommInitRank on the context's device). */
+#define SSM_COMM_ID_BYTES 128
+int ssm_comm_get_unique_id(void* id /* SSM_COMM_ID_BYTES */);
+int ssm_comm_init_rank(ssm_ctx* ctx, int nranks, int rank, const void* id);
+int ssm_comm_finalize(ssm_ctx* ctx);
+int ssm_comm_rank(const ssm_ctx* ctx);
+int ssm_comm_size(const ssm_ctx* ctx);
+/* rccl_comm: a ncclComm_t the caller created for this context's device, or NULL = the context's own communicator.  Afterwards the context
+ * map of EVERY rank holds the union of all ranks' maps (exact integer sums: bit-identical on every rank and to the single-GPU map).
+ * On the context stream: all-gather of the voxel counts, one in-place all-gather of the tables padded to the longest, re-insertion of the
+ * nranks - 1 remote tables.  Waits on the host once (for the counts); the merge kernels are enqueued, not waited for. */
+int ssm_voxel_allgather(ssm_ctx* ctx, void* rccl_comm);
 
 /* ---- device-resident batched path (the benchmarked one): n frames of a sequence, packed, all DEVICE pointers.
  * Runs detectFeatures for every frame, match(ref, cur) against the <= tracker_ref_frames preceding frames (the

@@ -1,45 +1,240 @@
-// micro-benchmark: issue rate of v_bcnt_u32_b32 vs v_xor_b32 vs v_add3 on gfx950 (decides the matcher's VALU roofline)
+// valu_rate.hip -- issue rate of every VALU instruction class the integer kernels of this repo use, on gfx950, at 1 / 2 / 4 / 8 waves
+// per SIMD.  Decides the VALU roofline of bench.py: the MI355X guide lists `v_fma_f32` at 2 cycles per wave64
+// instruction with several waves resident (4 for one wave alone); round 1 measured 4 cycles for xor / bcnt / add / max with an
+// un-controlled occupancy.  Every op is issued from inline asm (the compiler cannot fuse, re-associate or drop it) on 8 independent
+// register chains, 64 instructions per loop trip; the grid is exactly (CUs x blocks) co-resident workgroups.
+//   cycles per instruction per SIMD = (s_memtime delta of a wave) / (instructions per wave x waves per SIMD)
+//   T lane-op/s                     = instructions x 64 / wall time (hipEvents)
+// build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip ; run: ./valu_rate [csv]
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
-template <int OP>
-__global__ void k(unsigned* out, int iters)
-{
-    unsigned a[8];
-    for (int i = 0; i < 8; i++) a[i] = threadIdx.x * 2654435761u + i * 40503u + blockIdx.x;
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (OP == 0) a[i] = __builtin_popcount(a[i] ^ 0x5bd1e995u) + a[(i + 1) & 7];     // xor + bcnt(acc)
-                if (OP == 1) a[i] = (a[i] ^ a[(i + 1) & 7]) ^ 0x5bd1e995u;                         // 2 xor (or one xor3?)
-                if (OP == 2) a[i] = __builtin_popcount(a[i]) + a[(i + 3) & 7];                      // bcnt(acc) only
-                if (OP == 3) a[i] = max(a[i] + 7u, a[(i + 1) & 7]) ;                                // add + max
-            }
-        }
+#include <cstring>
+#include <vector>
+
+#define ASM_xor_b32(D, B) "v_xor_b32 " D ", " D ", " B "\n\t"
+#define ASM_add_u32(D, B) "v_add_u32 " D ", " D ", " B "\n\t"
+#define ASM_bcnt_acc(D, B) "v_bcnt_u32_b32 " D ", " B ", " D "\n\t"
+#define ASM_max_u32(D, B) "v_max_u32 " D ", " D ", " B "\n\t"
+#define ASM_min3_u32(D, B) "v_min3_u32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_med3_i32(D, B) "v_med3_i32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_and_or_b32(D, B) "v_and_or_b32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_lshl_add_u32(D, B) "v_lshl_add_u32 " D ", " D ", 1, " B "\n\t"
+#define ASM_add3_u32(D, B) "v_add3_u32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_bfe_u32(D, B) "v_bfe_u32 " D ", " D ", 3, 9\n\t"
+#define ASM_perm_b32(D, B) "v_perm_b32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_alignbyte_b32(D, B) "v_alignbyte_b32 " D ", " D ", " B ", 1\n\t"
+#define ASM_sad_u8(D, B) "v_sad_u8 " D ", " D ", " B ", " D "\n\t"
+#define ASM_msad_u8(D, B) "v_msad_u8 " D ", " D ", " B ", " D "\n\t"
+#define ASM_sad_u32(D, B) "v_sad_u32 " D ", " D ", " B ", " D "\n\t"
+#define ASM_dot4_u32_u8(D, B) "v_dot4_u32_u8 " D ", " D ", " B ", " D "\n\t"
+#define ASM_dot2_u32_u16(D, B) "v_dot2_u32_u16 " D ", " D ", " B ", " D "\n\t"
+#define ASM_pk_add_u16(D, B) "v_pk_add_u16 " D ", " D ", " B "\n\t"
+#define ASM_pk_sub_i16(D, B) "v_pk_sub_i16 " D ", " D ", " B "\n\t"
+#define ASM_pk_min_u16(D, B) "v_pk_min_u16 " D ", " D ", " B "\n\t"
+#define ASM_pk_max_i16(D, B) "v_pk_max_i16 " D ", " D ", " B "\n\t"
+#define ASM_pk_mad_u16(D, B) "v_pk_mad_u16 " D ", " D ", " B ", " D "\n\t"
+#define ASM_pk_mul_lo_u16(D, B) "v_pk_mul_lo_u16 " D ", " D ", " B "\n\t"
+#define ASM_pk_lshrrev_b16(D, B) "v_pk_lshrrev_b16 " D ", 1, " D "\n\t"
+#define ASM_mad_u32_u24(D, B) "v_mad_u32_u24 " D ", " D ", " B ", " D "\n\t"
+#define ASM_mul_u32_u24(D, B) "v_mul_u32_u24 " D ", " D ", " B "\n\t"
+#define ASM_mul_lo_u32(D, B) "v_mul_lo_u32 " D ", " D ", " B "\n\t"
+#define ASM_mul_hi_u32(D, B) "v_mul_hi_u32 " D ", " D ", " B "\n\t"
+#define ASM_cndmask_b32(D, B) "v_cndmask_b32 " D ", " D ", " B ", vcc\n\t"
+#define ASM_cmp_lt_u32(D, B) "v_cmp_lt_u32 vcc, " D ", " B "\n\t"
+#define ASM_mov_dpp_shr1(D, B) "v_mov_b32_dpp " D ", " D " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define ASM_add_dpp_shr1(D, B) "v_add_u32_dpp " D ", " D ", " B " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define ASM_cvt_f32_u32(D, B) "v_cvt_f32_u32 " D ", " D "\n\t"
+#define ASM_cvt_pk_u8_f32(D, B) "v_cvt_pk_u8_f32 " D ", " D ", 1, " B "\n\t"
+#define ASM_add_f32(D, B) "v_add_f32 " D ", " D ", " B "\n\t"
+#define ASM_fma_f32(D, B) "v_fma_f32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_max3_f32(D, B) "v_max3_f32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_rcp_f32(D, B) "v_rcp_f32 " D ", " D "\n\t"
+#define ASM_pk_fma_f32(D, B) "v_pk_fma_f32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_pk_add_f32(D, B) "v_pk_add_f32 " D ", " D ", " B "\n\t"
+#define ASM_add_f64(D, B) "v_add_f64 " D ", " D ", " B "\n\t"
+#define ASM_mul_f64(D, B) "v_mul_f64 " D ", " D ", " B "\n\t"
+#define ASM_fma_f64(D, B) "v_fma_f64 " D ", " D ", " B ", " B "\n\t"
+#define ASM_lshlrev_b64(D, B) "v_lshlrev_b64 " D ", 1, " D "\n\t"
+#define ASM_add_co_u32(D, B) "v_add_co_u32 " D ", vcc, " D ", " B "\n\t"
+#define ASM_mbcnt_lo(D, B) "v_mbcnt_lo_u32_b32 " D ", " B ", " D "\n\t"
+#define ASM_and_b32(D, B) "v_and_b32 " D ", " D ", " B "\n\t"
+#define ASM_or_b32(D, B) "v_or_b32 " D ", " D ", " B "\n\t"
+#define ASM_not_b32(D, B) "v_not_b32 " D ", " D "\n\t"
+#define ASM_mov_b32(D, B) "v_mov_b32 " D ", " B "\n\t"
+#define ASM_sub_u32(D, B) "v_sub_u32 " D ", " D ", " B "\n\t"
+#define ASM_subrev_u32(D, B) "v_subrev_u32 " D ", " D ", " B "\n\t"
+#define ASM_lshlrev_b32(D, B) "v_lshlrev_b32 " D ", 1, " D "\n\t"
+#define ASM_lshrrev_b32(D, B) "v_lshrrev_b32 " D ", 1, " D "\n\t"
+#define ASM_ashrrev_i32(D, B) "v_ashrrev_i32 " D ", 1, " D "\n\t"
+#define ASM_min_u32(D, B) "v_min_u32 " D ", " D ", " B "\n\t"
+#define ASM_max_i32(D, B) "v_max_i32 " D ", " D ", " B "\n\t"
+#define ASM_or3_b32(D, B) "v_or3_b32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_xad_u32(D, B) "v_xad_u32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_bfi_b32(D, B) "v_bfi_b32 " D ", " D ", " B ", " B "\n\t"
+#define ASM_add_u16(D, B) "v_add_u16 " D ", " D ", " B "\n\t"
+#define ASM_cndmask_e32(D, B) "v_cndmask_b32_e32 " D ", " D ", " B ", vcc\n\t"
+#define ASM_cndmask_sgpr(D, B) "v_cndmask_b32_e64 " D ", " D ", " B ", s[20:21]\n\t"
+#define ASM_cmp_e64_sgpr(D, B) "v_cmp_lt_u32_e64 s[20:21], " D ", " B "\n\t"
+#define ASM_mul_f32(D, B) "v_mul_f32 " D ", " D ", " B "\n\t"
+#define ASM_sub_f32(D, B) "v_sub_f32 " D ", " D ", " B "\n\t"
+#define ASM_max_f32(D, B) "v_max_f32 " D ", " D ", " B "\n\t"
+#define ASM_mac_f32(D, B) "v_fmac_f32 " D ", " B ", " B "\n\t"
+#define ASM_add_f16(D, B) "v_add_f16 " D ", " D ", " B "\n\t"
+#define ASM_pk_add_f16(D, B) "v_pk_add_f16 " D ", " D ", " B "\n\t"
+#define ASM_mix_xor_bcnt(D, B) "v_xor_b32 " D ", " D ", " B "\n\tv_bcnt_u32_b32 " D ", " B ", " D "\n\t"
+#define ASM_mix_add_max(D, B) "v_add_u32 " D ", " D ", " B "\n\tv_max_u32 " D ", " D ", " B "\n\t"
+#define ASM_mix_xor_xor_bcnt(D, B) "v_xor_b32 " D ", " D ", " B "\n\tv_xor_b32 " D ", " D ", " B "\n\tv_bcnt_u32_b32 " D ", " B ", " D "\n\t"
+#define OPS(X) \
+    X(xor_b32, uint32_t) \
+    X(add_u32, uint32_t) \
+    X(bcnt_acc, uint32_t) \
+    X(max_u32, uint32_t) \
+    X(min3_u32, uint32_t) \
+    X(med3_i32, uint32_t) \
+    X(and_or_b32, uint32_t) \
+    X(lshl_add_u32, uint32_t) \
+    X(add3_u32, uint32_t) \
+    X(bfe_u32, uint32_t) \
+    X(perm_b32, uint32_t) \
+    X(alignbyte_b32, uint32_t) \
+    X(sad_u8, uint32_t) \
+    X(msad_u8, uint32_t) \
+    X(sad_u32, uint32_t) \
+    X(dot4_u32_u8, uint32_t) \
+    X(dot2_u32_u16, uint32_t) \
+    X(pk_add_u16, uint32_t) \
+    X(pk_sub_i16, uint32_t) \
+    X(pk_min_u16, uint32_t) \
+    X(pk_max_i16, uint32_t) \
+    X(pk_mad_u16, uint32_t) \
+    X(pk_mul_lo_u16, uint32_t) \
+    X(pk_lshrrev_b16, uint32_t) \
+    X(mad_u32_u24, uint32_t) \
+    X(mul_u32_u24, uint32_t) \
+    X(mul_lo_u32, uint32_t) \
+    X(mul_hi_u32, uint32_t) \
+    X(cndmask_b32, uint32_t) \
+    X(cmp_lt_u32, uint32_t) \
+    X(mov_dpp_shr1, uint32_t) \
+    X(add_dpp_shr1, uint32_t) \
+    X(cvt_f32_u32, uint32_t) \
+    X(cvt_pk_u8_f32, uint32_t) \
+    X(add_f32, float) \
+    X(fma_f32, float) \
+    X(max3_f32, float) \
+    X(rcp_f32, float) \
+    X(pk_fma_f32, double) \
+    X(pk_add_f32, double) \
+    X(add_f64, double) \
+    X(mul_f64, double) \
+    X(fma_f64, double) \
+    X(lshlrev_b64, double) \
+    X(add_co_u32, uint32_t) \
+    X(mbcnt_lo, uint32_t) \
+    X(and_b32, uint32_t) \
+    X(or_b32, uint32_t) \
+    X(not_b32, uint32_t) \
+    X(mov_b32, uint32_t) \
+    X(sub_u32, uint32_t) \
+    X(subrev_u32, uint32_t) \
+    X(lshlrev_b32, uint32_t) \
+    X(lshrrev_b32, uint32_t) \
+    X(ashrrev_i32, uint32_t) \
+    X(min_u32, uint32_t) \
+    X(max_i32, uint32_t) \
+    X(or3_b32, uint32_t) \
+    X(xad_u32, uint32_t) \
+    X(bfi_b32, uint32_t) \
+    X(add_u16, uint32_t) \
+    X(cndmask_e32, uint32_t) \
+    X(cndmask_sgpr, uint32_t) \
+    X(cmp_e64_sgpr, uint32_t) \
+    X(mul_f32, float) \
+    X(sub_f32, float) \
+    X(max_f32, float) \
+    X(mac_f32, float) \
+    X(add_f16, float) \
+    X(pk_add_f16, float) \
+    X(mix_xor_bcnt, uint32_t) \
+    X(mix_add_max, uint32_t) \
+    X(mix_xor_xor_bcnt, uint32_t)
+
+enum { TRIPS = 4000, CHAINS = 8, REPS = 8 };
+
+#define CH8(OP) OP("%0", "%8") OP("%1", "%8") OP("%2", "%8") OP("%3", "%8") OP("%4", "%8") OP("%5", "%8") OP("%6", "%8") OP("%7", "%8")
+#define DEF_KERNEL(NAME, T)                                                                                       \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long* stamps, T* sink, int trips)                  \
+    {                                                                                                                  \
+        T a[CHAINS];                                                                                                   \
+        T b;                                                                                                           \
+        { unsigned u = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;                                      \
+          if (sizeof(T) == 8) { unsigned long long w = ((unsigned long long)(0x3FF00000u | (u & 0xFFFFFu)) << 32) | u; memcpy(&b, &w, sizeof(T)); } \
+          else if (sizeof(T) == 4 && (T)0.5 != (T)0) { unsigned w = 0x3F800000u | (u & 0x7FFFFFu); memcpy(&b, &w, sizeof(T)); } \
+          else { memcpy(&b, &u, sizeof(T)); } }                                                                        \
+        for (int i = 0; i < CHAINS; i++) a[i] = b;                                                                     \
+        unsigned long long t0, t1, r0, r1;                                                                             \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0) :: "memory");                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");                                   \
+        for (int it = 0; it < trips; it++) {                                                                           \
+            /* ONE asm statement = 64 instructions: hipcc pads separate asm statements with s_nop */                  \
+            asm volatile(CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) CH8(ASM_##NAME) \
+                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b) : "vcc", "s20", "s21"); \
+        }                                                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1) :: "memory");                               \
+        T s = a[0];                                                                                                    \
+        for (int i = 1; i < CHAINS; i++) { unsigned long long x = 0, y = 0; memcpy(&x, &s, sizeof(T)); memcpy(&y, &a[i], sizeof(T)); x ^= y; memcpy(&s, &x, sizeof(T)); } \
+        sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;                                                       \
+        if ((threadIdx.x & 63) == 0) { const size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; stamps[2 * wv] = t1 - t0; stamps[2 * wv + 1] = r1 - r0; } \
     }
-    unsigned s = 0;
-    for (int i = 0; i < 8; i++) s += a[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-template <int OP> void run(const char* name, int vops_per_inner)
+OPS(DEF_KERNEL)
+
+struct Row { const char* name; double cyc[4], tl[4], ghz[4]; };
+
+template <class T, class K> static void run_one(K kern, Row& row, int cus, bool csv)
 {
-    unsigned* d; hipMalloc(&d, 256 * 8 * 4 * 256 * 4);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int iters = 2000, blocks = 256 * 8;
-    k<OP><<<blocks, 256>>>(d, 10);
-    hipDeviceSynchronize();
-    hipEventRecord(a); k<OP><<<blocks, 256>>>(d, iters); hipEventRecord(b); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b);
-    double laneops = (double)blocks * 256 * iters * 64.0 * vops_per_inner;
-    printf("%-28s %8.3f ms  %7.2f T lane-op/s (counting %d VALU per element)\n", name, ms, laneops / ms / 1e9, vops_per_inner);
-    hipFree(d);
+    const int wps[4] = {1, 2, 4, 8};
+    for (int w = 0; w < 4; w++) {
+        const int threads = wps[w] >= 4 ? 1024 : 256 * wps[w], blocks_per_cu = wps[w] == 8 ? 2 : 1, blocks = cus * blocks_per_cu;
+        const size_t nthreads = (size_t)threads * blocks, nwaves = nthreads / 64;
+        unsigned long long* st; T* sink;
+        hipMalloc(&st, nwaves * 16); hipMalloc(&sink, nthreads * sizeof(T));
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, st, sink, 50);
+        hipDeviceSynchronize();
+        float best = 1e30f; std::vector<unsigned long long> h2(2 * nwaves), h(nwaves); std::vector<double> clk(nwaves);
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, st, sink, (int)TRIPS); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) { best = ms; hipMemcpy(h2.data(), st, nwaves * 16, hipMemcpyDeviceToHost); }
+        }
+        for (size_t i = 0; i < nwaves; i++) { h[i] = h2[2 * i]; clk[i] = (double)h2[2 * i] / (double)h2[2 * i + 1] * 0.1; }   // s_memrealtime: 100 MHz
+        std::sort(h.begin(), h.end()); std::sort(clk.begin(), clk.end());
+        const double insts = (double)TRIPS * CHAINS * REPS;
+        row.ghz[w] = clk[nwaves / 2];
+        // by wall time at the measured shader clock: robust against workgroups of a CU that do not run at the same time
+        row.cyc[w] = (best * 1e-3) * row.ghz[w] * 1e9 / (insts * wps[w]) / ((double)nwaves / (cus * 4.0 * wps[w]));
+        row.tl[w] = insts * 64.0 * nwaves / (best * 1e-3) / 1e12;
+        hipFree(st); hipFree(sink); hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    if (csv) printf("%s,%.3f,%.3f,%.3f,%.3f,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f\n", row.name, row.cyc[0], row.cyc[1], row.cyc[2], row.cyc[3], row.tl[0], row.tl[1], row.tl[2], row.tl[3], row.ghz[0], row.ghz[3]);
+    else printf("| `v_%s` | %.2f | %.2f | %.2f | %.2f | %.1f | %.1f | %.1f | %.1f | %.2f / %.2f |\n", row.name, row.cyc[0], row.cyc[1], row.cyc[2], row.cyc[3], row.tl[0], row.tl[1], row.tl[2], row.tl[3], row.ghz[0], row.ghz[3]);
+    fflush(stdout);
 }
-int main()
+
+int main(int argc, char** argv)
 {
-    run<0>("xor + bcnt_acc", 2);
-    run<1>("xor + xor", 2);
-    run<2>("bcnt_acc", 1);
-    run<3>("add + max", 2);
+    const bool csv = argc > 1 && !strcmp(argv[1], "csv");
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    if (csv) printf("op,cyc_w1,cyc_w2,cyc_w4,cyc_w8,T_w1,T_w2,T_w4,T_w8,ghz_w1,ghz_w8\n");
+    else {
+        printf("# VALU issue rate per instruction class, %s (%d CUs), %d wave-instructions per wave on %d independent chains\n\n", p.gcnArchName, cus, TRIPS * CHAINS * REPS, CHAINS);
+        printf("cyc = kernel wall time x shader clock / (wave-instructions per SIMD): cycles one SIMD spends per wave64 instruction; shader clock = s_memtime / s_memrealtime (100 MHz), median wave; "
+               "T = 10^12 lane-ops/s over the whole chip by wall time.  `mix_*` rows issue 2 (xor+bcnt, add+max) or 3 (xor+xor+bcnt) instructions per counted slot.\n\n");
+        printf("| instruction | cyc @1 wave/SIMD | @2 | @4 | @8 | T lane-op/s @1 | @2 | @4 | @8 | GHz @1 / @8 |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n");
+    }
+#define RUN(NAME, T) { Row r; r.name = #NAME; run_one<T>(k_##NAME, r, cus, csv); }
+    OPS(RUN)
     return 0;
 }

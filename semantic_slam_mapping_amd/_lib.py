@@ -58,6 +58,12 @@ SYMBOLS = {
     "ssm_map_merge_table": (_I, [_P, _P, _I]),
     "ssm_map_export_table_dev": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_merge_table_dev": (_I, [_P, _P, _I]),
+    "ssm_comm_get_unique_id": (_I, [_P]),
+    "ssm_comm_init_rank": (_I, [_P, _I, _I, _P]),
+    "ssm_comm_finalize": (_I, [_P]),
+    "ssm_comm_rank": (_I, [_P]),
+    "ssm_comm_size": (_I, [_P]),
+    "ssm_voxel_allgather": (_I, [_P, _P]),
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
     "ssm_quad_track": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),

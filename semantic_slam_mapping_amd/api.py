@@ -24,6 +24,7 @@ assert PMATCH_DTYPE.itemsize == 52
 assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
 
 STAGE_ORB, STAGE_MATCH, STAGE_MAP, STAGE_SEGNET = 1, 2, 4, 8
+COMM_ID_BYTES = 128
 SEG_NET_W, SEG_NET_H, SEG_CLASSES = 480, 360, 12
 
 
@@ -314,6 +315,25 @@ class Context:
 
     def map_merge_table_dev(self, dptr, n):
         self._chk(self.lib.ssm_map_merge_table_dev(self.h, dptr, n))
+
+    # ---- multi-GPU: the communicator lives in the context (RCCL inside libssm_hip.so, no torch on the data path)
+    def comm_unique_id(self):
+        """rank 0: ncclGetUniqueId as SSM_COMM_ID_BYTES bytes, to be shipped to every rank"""
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        self._chk(self.lib.ssm_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, nranks, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self.lib.ssm_comm_init_rank(self.h, nranks, rank, buf))
+
+    def comm_finalize(self):
+        self._chk(self.lib.ssm_comm_finalize(self.h))
+
+    def voxel_allgather(self, rccl_comm=None):
+        """merge the context maps of all ranks: one RCCL all-gather of the voxel tables + re-insertion of the remote ones"""
+        self._chk(self.lib.ssm_voxel_allgather(self.h, rccl_comm))
 
     # ---- device-resident sequence path
     def dev_alloc(self, nbytes):

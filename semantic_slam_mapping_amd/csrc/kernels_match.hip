@@ -26,9 +26,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)   
     return r;
 }
 // T threads work on the queries [qb, qe).  pend == nullptr: the block owns the whole pair.  Otherwise the pair is split over two
-// blocks (the sequence kernel: 5 pairs per frame are too few, and too coarse, to balance 256 CUs): role 1 (queries from 0) publishes
-// its match count in *pend when its matches are written; role 2 (the rest) computes, then waits for that count, appends its matches
-// behind it and writes the total.  Role 1 has the lower block index, so it is dispatched no later than role 2: the wait cannot starve it.
+// blocks (the sequence kernel: 5 pairs per frame are too few, and too coarse, to balance 256 CUs) and NEITHER block waits for the
+// other: a query yields at most one match, so role 1 (queries [0, split)) writes its matches from slot 0 and role 2 (queries
+// [split, nq)) from slot split without overlap.  Each block publishes its count with one atomic exchange on *pend (-1 before); the
+// block that finds the other's count there arrived second and closes the gap (moves role 2's segment down to role 1's count) and
+// writes the total.  Forward progress needs no dispatch order; visibility follows the guide's release / acquire recipe.
 template <int T>
 __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
                                            double ratio, int cap, ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout,
@@ -40,8 +42,7 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
     __shared__ int base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (qe < 0) qe = nq;
-    if (tid == 0) base = 0;
-    bool waited = role != 2;
+    if (tid == 0) base = role == 2 ? qb : 0;        // role 2 writes behind the slots role 1 can fill
     for (int q0 = qb; q0 < qe; q0 += T * QPL) {
         uint4 a[QPL], b[QPL]; uint32_t k0[QPL], k1[QPL];
 #pragma unroll
@@ -86,10 +87,6 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
             // ratio test exactly as orb.cpp:25: float distance < double ratio * float distance, compared in double
             const bool keep = (qi < qe) && ((double)(float)d0 < ratio * (double)(float)d1);
             const unsigned long long bal = __ballot(keep);
-            if (!waited) {                                      // role 2, first compaction: the matches of the first half come first
-                if (tid == 0) { int v; while ((v = atomicAdd(pend, 0)) < 0) __builtin_amdgcn_s_sleep(8); base = v; }
-                waited = true;
-            }
             __syncthreads();
             if (lane == 0) wcnt[wv] = __popcll(bal);
             __syncthreads();
@@ -103,10 +100,31 @@ __device__ __forceinline__ void match_pair(const uint8_t* __restrict__ q, int nq
             if (tid == 0) { int s = 0; for (int w = 0; w < T / 64; w++) s += wcnt[w]; base += s; }
         }
     }
+    __syncthreads();                                    // (every wave's stores are complete: the barrier's fence waits for them)
+    if (role == 0) { if (tid == 0 && nout) *nout = base; return; }
+    __shared__ int other;
+    const int split = role == 1 ? qe : qb, mine = base - (role == 2 ? qb : 0);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // this block's matches reach memory before its count
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        other = __hip_atomic_exchange(pend, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other >= 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
     __syncthreads();
-    if (role == 1) { __threadfence(); if (tid == 0) atomicExch(pend, base); return; }     // matches visible, then the count
-    if (!waited && tid == 0) { int v; while ((v = atomicAdd(pend, 0)) < 0) __builtin_amdgcn_s_sleep(8); base = v; }   // role 2 without queries
-    if (tid == 0 && nout) *nout = base;
+    if (other < 0) return;                              // arrived first: the other block finishes the pair
+    const int n0 = role == 1 ? mine : other, n1 = role == 1 ? other : mine;
+    if (n0 != split) {                                  // close the gap; dst < src, chunks in ascending order, read-all-then-write-all
+        uint4* o = reinterpret_cast<uint4*>(out);
+        for (int i0 = 0; i0 < n1; i0 += T) {
+            const int i = i0 + tid;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < n1) v = o[split + i];
+            __syncthreads();
+            if (i < n1) o[n0 + i] = v;
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && nout) *nout = n0 + n1;
 }
 
 __global__ void __launch_bounds__(MT)

@@ -3,6 +3,7 @@
 // moves caller data and enqueues the kernels of kernels_*.hip on the context stream.  There is NO CPU fallback: if
 // HIP is unusable ssm_create fails with SSM_E_NODEVICE / SSM_E_HIP.
 #include "ssm_internal.h"
+#include <rccl/rccl.h>
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -97,6 +98,8 @@ struct ssm_ctx {
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
     // voxel tables
     VoxTable map, tmp;
+    // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1; int32_t* d_comm_counts = nullptr; int comm_counts_cap = 0;
     // SegNet
     struct SegNetState* seg = nullptr;
     // quad matcher
@@ -360,6 +363,8 @@ extern "C" void ssm_destroy(ssm_ctx* c)
         delete g;
     }
     if (c->quad) { quad_free(c->quad); delete c->quad; }
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    if (c->d_comm_counts) hipFree(c->d_comm_counts);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -671,6 +676,81 @@ extern "C" int ssm_map_merge_table_dev(ssm_ctx* c, const ssm_voxel* tab, int n)
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
     HIPCHK(c, k_voxel_merge(tab, n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    return SSM_OK;
+}
+// ---------------------------------------------------------------- multi-GPU: one process per GPU, the voxel-map merge is the only collective
+#define NCCLCHK(ctx, expr) do { ncclResult_t e__ = (expr); if (e__ != ncclSuccess) { (ctx)->err = std::string(#expr) + ": " + ncclGetErrorString(e__); return SSM_E_COMM; } } while (0)
+extern "C" int ssm_comm_get_unique_id(void* id)
+{
+    static_assert(sizeof(ncclUniqueId) == SSM_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return SSM_E_INVAL;
+    ncclUniqueId u;
+    ncclResult_t e = ncclGetUniqueId(&u);
+    if (e != ncclSuccess) { g_create_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(e); return SSM_E_COMM; }
+    memcpy(id, &u, sizeof(u));
+    return SSM_OK;
+}
+extern "C" int ssm_comm_init_rank(ssm_ctx* c, int nranks, int rank, const void* id)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) FAIL(c, SSM_E_INVAL, "bad communicator arguments");
+    if (c->comm) FAIL(c, SSM_E_INVAL, "the context already has a communicator (ssm_comm_finalize first)");
+    ncclUniqueId u; memcpy(&u, id, sizeof(u));
+    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, u, rank));
+    c->comm_rank = rank; c->comm_size = nranks;
+    return SSM_OK;
+}
+extern "C" int ssm_comm_finalize(ssm_ctx* c)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (c->comm) { HIPCHK(c, hipStreamSynchronize(c->stream)); NCCLCHK(c, ncclCommDestroy(c->comm)); c->comm = nullptr; }
+    c->comm_rank = 0; c->comm_size = 1;
+    return SSM_OK;
+}
+extern "C" int ssm_comm_rank(const ssm_ctx* c) { return c ? c->comm_rank : 0; }
+extern "C" int ssm_comm_size(const ssm_ctx* c) { return c ? c->comm_size : 1; }
+// SURVEY.md s.8e "collective": (1) all-gather of the per-rank voxel counts, (2) ONE all-gather of the tables padded to the longest
+// (in place: a rank compacts its own table straight into its slot of the receive buffer), (3) every rank re-inserts the nranks-1
+// remote tables.  Everything runs on the context stream; the one host wait is for the counts (they size the buffer).  Exact integer
+// sums (DESIGN.md "voxel sums") make the result independent of rank order: every rank ends with the bit-identical 1-GPU map.
+extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    ncclComm_t comm = rccl_comm ? reinterpret_cast<ncclComm_t>(rccl_comm) : c->comm;
+    if (!comm) FAIL(c, SSM_E_INVAL, "no communicator: pass a ncclComm_t or call ssm_comm_init_rank");
+    int world = 0, rank = 0;
+    NCCLCHK(c, ncclCommCount(comm, &world)); NCCLCHK(c, ncclCommUserRank(comm, &rank));
+    if (world > c->comm_counts_cap) {
+        if (c->d_comm_counts) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_comm_counts); c->d_comm_counts = nullptr; c->comm_counts_cap = 0; }
+        DALLOC(c, c->d_comm_counts, (size_t)world); c->comm_counts_cap = world;
+    }
+    hipStream_t s = c->stream;
+    prof_begin(c, "allgather");
+    // (1) counts: counters[0] of the map table is the number of occupied voxels, already on the device
+    NCCLCHK(c, ncclAllGather(c->map.counters, c->d_comm_counts, 1, ncclInt32, comm, s));
+    std::vector<int32_t> counts(world);
+    int32_t full = 0;
+    HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_comm_counts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&full, c->map.counters + 1, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (full) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    int mx = 1; for (int v : counts) { if (v < 0) FAIL(c, SSM_E_COMM, "negative voxel count received"); if (v > mx) mx = v; }
+    // (2) tables: slot r of the receive buffer = rank r's voxels, mx entries each
+    const size_t slot = (size_t)mx * sizeof(ssm_voxel);
+    int r = ensure_scratch2(c, slot * world + 256); if (r) return r;
+    uint8_t* recv = reinterpret_cast<uint8_t*>(c->d_scratch2);
+    int32_t* dn = reinterpret_cast<int32_t*>(recv + slot * world);
+    HIPCHK(c, k_voxel_compact(c->map.tab, c->map.cap_log2, reinterpret_cast<ssm_voxel*>(recv + slot * rank), dn, s));
+    NCCLCHK(c, ncclAllGather(recv + slot * rank, recv, slot, ncclUint8, comm, s));
+    // (3) merge the remote tables into the local map
+    for (int q = 0; q < world; q++) {
+        if (q == rank) continue;
+        HIPCHK(c, k_voxel_merge(reinterpret_cast<const ssm_voxel*>(recv + slot * q), counts[q], c->map.tab, c->map.cap_log2, c->map.counters, s));
+    }
+    prof_end(c);
     return SSM_OK;
 }
 static inline float ord2f(int i) { i = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; memcpy(&f, &i, 4); return f; }

@@ -198,6 +198,16 @@ int main(int argc, char** argv)
         CHECK("classifier_classify", ok && mx > 0 && sem.rows == 480 && sem.cols == 640 && sem.channels() == 3);
         bool threw2 = false; try { Classifier bad("/nonexistent.ssmw", "x"); } catch (const runtime_error&) { threw2 = true; }
         CHECK("classifier_missing_model_throws", threw2);
+        // the reference's constructor arguments (src/segnet.cpp:17-19): prototxt + caffemodel + label file; the harness wrote the SAME weights
+        // as a .caffemodel (conv bias + caffe-segnet BN blobs), so the labels must be identical
+        if (const char* cmf = getenv("SSM_TEST_CAFFEMODEL")) {
+            Classifier from_caffe("", cmf, "/nonexistent/semantic12.txt");
+            std::vector<Prediction> pc = from_caffe.Classify(f0->rgb);
+            bool same = pc.size() == pr.size(); for (size_t i = 0; same && i < pc.size(); i++) if (pc[i].second != pr[i].second || pc[i].first != pr[i].first) same = false;
+            CHECK("classifier_from_caffemodel_equals_ssmw", same);
+            bool threw3 = false; try { Classifier bad("/nonexistent.prototxt", cmf, "x"); } catch (const runtime_error&) { threw3 = true; }
+            CHECK("classifier_missing_prototxt_throws", threw3);
+        }
     }
     cout << (fails ? "FAILED " : "ALL PASSED ") << fails << endl;
     return fails;

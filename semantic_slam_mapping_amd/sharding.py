@@ -2,10 +2,11 @@
 
 The reference is single-process; this is the one place a collective exists.  Frames of a sequence are split into
 contiguous blocks, one per rank (each rank's matcher then only needs a tracker_ref_frames halo at its block start);
-every rank fuses its own frames into its own voxel table; ONE all-gather of the key-sorted tables (counts first, then
-tables padded to the longest) merges them.  Tables hold exact integer sums, so the merged map is bit-identical to the
-single-GPU map whatever the rank order.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" runs the same code on CPU
-tensors for the world_size-2 tests.
+every rank fuses its own frames into its own voxel table; ONE all-gather of the tables (counts first, then tables padded
+to the longest) merges them.  Tables hold exact integer sums, so the merged map is bit-identical to the single-GPU map
+whatever the rank order.  On the GPU the collective lives behind the C ABI (ssm_voxel_allgather: RCCL inside
+libssm_hip.so, no torch on the data path); `allgather_tables` below is the same exchange over torch.distributed, kept for
+the world_size-2 gloo tests on CPU tensors, where it checks the plan (blocks, halos, counts, padding, merge).
 """
 import numpy as np
 
@@ -17,6 +18,13 @@ def frame_block(n_frames, rank, world):
     base, rem = divmod(n_frames, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def halo_block(lo, ref_frames):
+    """the matcher halo of a block that starts at frame lo: the <= ref_frames frames [lo - ref_frames, lo) in front of it.  A rank runs them
+    through ORB only (stages = SSM_STAGE_ORB) and then its block with continue_sequence = 1: Tracker::trackRefFrame matches a frame against
+    the refFrames deque = the ref_frames preceding frames (src/track.cpp:150-152,192-196), whoever owns them."""
+    return max(0, lo - ref_frames), lo
 
 
 def allgather_tables(local_table_u8, n_local, dist, device):

@@ -94,10 +94,28 @@ def test_host_classes_on_gpu():
     subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
     wfile = "/tmp/ssm_test_segnet.ssmw"
     subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "export_ssmw.py"), wfile], check=True)
-    r = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), wfile], capture_output=True, text=True, timeout=300)
+    # the same weights as a .caffemodel: convolution (weight, bias) + caffe-segnet BN (scale, shift) blobs whose folding gives back (scale, shift)
+    import numpy as np
+    from semantic_slam_mapping_amd import caffemodel as cm
+    from semantic_slam_mapping_amd.segnet_model import make_weights
+    layers = []
+    for name, (w, sc, sh) in zip(cm.LAYER_NAMES, make_weights(1234)):
+        if name == "conv1_1_D":                     # no BN behind the classifier layer: scale must be 1 there, so fold it into the weights
+            layers.append((name, "Convolution", [(w * sc[:, None, None, None]).astype(np.float32), sh])); continue
+        layers.append((name, "Convolution", [w, np.zeros(len(sc), np.float32)])); layers.append((name + "_bn", "BN", [sc.reshape(1, -1, 1, 1), sh.reshape(1, -1, 1, 1)]))
+    cfile = "/tmp/ssm_test_segnet.caffemodel"
+    open(cfile, "wb").write(cm.encode_caffemodel(layers))
+    # conv1_1_D of the .ssmw twin gets the same folded weights, so that both files describe the same network bit for bit
+    ws = make_weights(1234); w, sc, sh = ws[-1]; ws[-1] = ((w * sc[:, None, None, None]).astype(np.float32), np.ones_like(sc), sh)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from export_ssmw import write_ssmw
+    write_ssmw(wfile, ws)
+    r = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), wfile], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SSM_TEST_CAFFEMODEL=cfile))
     print(r.stdout[-3000:], r.stderr[-2000:])
+    os.remove(cfile)
     assert "ALL PASSED" in r.stdout and r.returncode == 0
-    assert r.stdout.count("PASS ") >= 18
+    assert r.stdout.count("PASS ") >= 20 and "PASS classifier_from_caffemodel_equals_ssmw" in r.stdout
 
 
 @pytest.mark.gpu
