@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #define ASM_xor_b32(D, B) "v_xor_b32 " D ", " D ", " B "\n\t"
@@ -190,10 +191,56 @@ enum { TRIPS = 4000, CHAINS = 8, REPS = 8 };
     }
 OPS(DEF_KERNEL)
 
+
+// ---- run-length experiment: per trip 64 instructions, `run` consecutive simple ops (v_xor) then `run` consecutive 4-cycle ops (v_bcnt), on the same 8 chains
+#define XR(D) "v_xor_b32 " D ", " D ", %8\n\t"
+#define BC(D) "v_bcnt_u32_b32 " D ", %8, " D "\n\t"
+#define X8 XR("%0") XR("%1") XR("%2") XR("%3") XR("%4") XR("%5") XR("%6") XR("%7")
+#define B8 BC("%0") BC("%1") BC("%2") BC("%3") BC("%4") BC("%5") BC("%6") BC("%7")
+#define X4a XR("%0") XR("%1") XR("%2") XR("%3")
+#define X4b XR("%4") XR("%5") XR("%6") XR("%7")
+#define B4a BC("%0") BC("%1") BC("%2") BC("%3")
+#define B4b BC("%4") BC("%5") BC("%6") BC("%7")
+#define BODY_run4  X4a B4a X4b B4b X4a B4a X4b B4b X4a B4a X4b B4b X4a B4a X4b B4b
+#define BODY_run8  X8 B8 X8 B8 X8 B8 X8 B8
+#define BODY_run16 X8 X8 B8 B8 X8 X8 B8 B8
+#define BODY_run32 X8 X8 X8 X8 B8 B8 B8 B8
+// v_cmp + v_cndmask as the compiler emits them (vcc written right before it is read), and v_cndmask behind one s_mov of vcc
+#define CC(D) "v_cmp_lt_u32 vcc, " D ", %8\n\tv_cndmask_b32 " D ", " D ", %8, vcc\n\t"
+#define BODY_cmp_cndmask_vcc CC("%0") CC("%1") CC("%2") CC("%3") CC("%4") CC("%5") CC("%6") CC("%7") CC("%0") CC("%1") CC("%2") CC("%3") CC("%4") CC("%5") CC("%6") CC("%7") \
+                             CC("%0") CC("%1") CC("%2") CC("%3") CC("%4") CC("%5") CC("%6") CC("%7") CC("%0") CC("%1") CC("%2") CC("%3") CC("%4") CC("%5") CC("%6") CC("%7")
+#define CS(D) "v_cmp_lt_u32_e64 s[20:21], " D ", %8\n\tv_cndmask_b32_e64 " D ", " D ", %8, s[20:21]\n\t"
+#define BODY_cmp_cndmask_sgpr CS("%0") CS("%1") CS("%2") CS("%3") CS("%4") CS("%5") CS("%6") CS("%7") CS("%0") CS("%1") CS("%2") CS("%3") CS("%4") CS("%5") CS("%6") CS("%7") \
+                              CS("%0") CS("%1") CS("%2") CS("%3") CS("%4") CS("%5") CS("%6") CS("%7") CS("%0") CS("%1") CS("%2") CS("%3") CS("%4") CS("%5") CS("%6") CS("%7")
+#define CM(D) "v_cndmask_b32 " D ", " D ", %8, vcc\n\t"
+#define CM8 CM("%0") CM("%1") CM("%2") CM("%3") CM("%4") CM("%5") CM("%6") CM("%7")
+#define BODY_cndmask_vcc_set "s_mov_b64 vcc, 0x5555\n\t" CM8 CM8 CM8 CM8 CM8 CM8 CM8 CM8
+#define SPECIALS(X) X(run4) X(run8) X(run16) X(run32) X(cmp_cndmask_vcc) X(cmp_cndmask_sgpr) X(cndmask_vcc_set)
+#define DEF_SPECIAL(NAME)                                                                                              \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long* stamps, uint32_t* sink, int trips)            \
+    {                                                                                                                  \
+        uint32_t a[CHAINS];                                                                                            \
+        uint32_t b = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;                                         \
+        for (int i = 0; i < CHAINS; i++) a[i] = b;                                                                     \
+        unsigned long long t0, t1, r0, r1;                                                                             \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0) :: "memory");                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");                                   \
+        for (int it = 0; it < trips; it++)                                                                             \
+            asm volatile(BODY_##NAME : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b) : "vcc", "s20", "s21"); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1) :: "memory");                               \
+        uint32_t s = a[0]; for (int i = 1; i < CHAINS; i++) s ^= a[i];                                                 \
+        sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;                                                       \
+        if ((threadIdx.x & 63) == 0) { const size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; stamps[2 * wv] = t1 - t0; stamps[2 * wv + 1] = r1 - r0; } \
+    }
+SPECIALS(DEF_SPECIAL)
+
 struct Row { const char* name; double cyc[4], tl[4], ghz[4]; };
 
+static const char* g_filter = nullptr;
 template <class T, class K> static void run_one(K kern, Row& row, int cus, bool csv)
 {
+    if (g_filter) { bool hit = false; std::string f(g_filter); size_t p = 0; while (p <= f.size()) { size_t q = f.find(',', p); if (q == std::string::npos) q = f.size(); if (q > p && strstr(row.name, f.substr(p, q - p).c_str())) hit = true; p = q + 1; } if (!hit) return; }
     const int wps[4] = {1, 2, 4, 8};
     for (int w = 0; w < 4; w++) {
         const int threads = wps[w] >= 4 ? 1024 : 256 * wps[w], blocks_per_cu = wps[w] == 8 ? 2 : 1, blocks = cus * blocks_per_cu;
@@ -225,16 +272,19 @@ template <class T, class K> static void run_one(K kern, Row& row, int cus, bool 
 int main(int argc, char** argv)
 {
     const bool csv = argc > 1 && !strcmp(argv[1], "csv");
+    if (argc > 2) g_filter = argv[2];        // comma-separated substrings of the row names to run
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     if (csv) printf("op,cyc_w1,cyc_w2,cyc_w4,cyc_w8,T_w1,T_w2,T_w4,T_w8,ghz_w1,ghz_w8\n");
     else {
         printf("# VALU issue rate per instruction class, %s (%d CUs), %d wave-instructions per wave on %d independent chains\n\n", p.gcnArchName, cus, TRIPS * CHAINS * REPS, CHAINS);
         printf("cyc = kernel wall time x shader clock / (wave-instructions per SIMD): cycles one SIMD spends per wave64 instruction; shader clock = s_memtime / s_memrealtime (100 MHz), median wave; "
-               "T = 10^12 lane-ops/s over the whole chip by wall time.  `mix_*` rows issue 2 (xor+bcnt, add+max) or 3 (xor+xor+bcnt) instructions per counted slot.\n\n");
+               "T = 10^12 lane-ops/s over the whole chip by wall time.  `mix_*` rows issue 2 (xor+bcnt, add+max) or 3 (xor+xor+bcnt) instructions per counted slot; `run<N>`: 64 instructions per trip as N v_xor then N v_bcnt alternating (cyc per instruction); `cmp_cndmask_*`: 64 instructions = 32 (v_cmp, v_cndmask) pairs.\n\n");
         printf("| instruction | cyc @1 wave/SIMD | @2 | @4 | @8 | T lane-op/s @1 | @2 | @4 | @8 | GHz @1 / @8 |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n");
     }
 #define RUN(NAME, T) { Row r; r.name = #NAME; run_one<T>(k_##NAME, r, cus, csv); }
     OPS(RUN)
+#define RUNS(NAME) { Row r; r.name = #NAME; run_one<uint32_t>(k_##NAME, r, cus, csv); }
+    SPECIALS(RUNS)
     return 0;
 }

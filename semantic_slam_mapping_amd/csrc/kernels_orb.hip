@@ -825,79 +825,159 @@ __device__ __forceinline__ void contract_sincos(float angle_rad, float* s, float
     switch (k & 3) { case 0: S = sn; C = cs; break; case 1: S = cs; C = -sn; break; case 2: S = -sn; C = -cs; break; default: S = -cs; C = sn; break; }
     *s = (float)S; *c = (float)C;
 }
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// One wave per selected keypoint.  The per-CU texture-address unit charges >= 16 cycles per vector-memory instruction
-// whatever its width, and byte-granular patch reads made this kernel exactly TA-bound; so each wave first stages its two
-// patches in LDS with ALIGNED DWORD loads (31 rows of the level image for the moments, 37 rows of the blurred image for
-// the steered BRIEF reach of +-18), then works on LDS bytes.  ~12 vector-memory instructions per keypoint instead of ~60.
+// inclusive wave sum by DPP (no LDS traffic); the total is in lane 63
+__device__ __forceinline__ int wave_total(int v) { return __builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)v), 63); }
+// K5 runs as three launches (it was one kernel with one wave per keypoint doing everything: 773 VALU instructions per wave, of which
+// ~110 were the wave-uniform atan2 + double-precision sin / cos and the depth unprojection executed by all 64 lanes for one value):
+//   orient_kernel : one WAVE per selected keypoint -- intensity-centroid moments m10, m01 over the radius-15 disc
+//   angle_kernel  : one THREAD per selected keypoint -- fastAtan2, the contract sin / cos, the cv::KeyPoint record, project2dTo3d
+//   brief_kernel  : one WAVE per selected keypoint -- steered BRIEF on the blurred level
+// The per-CU texture-address unit charges >= 16 cycles per vector-memory instruction whatever its width, and byte-granular patch reads
+// made this stage TA-bound; so a wave stages its patch in LDS with ALIGNED 16-BYTE loads (rows of the level images are 16-B aligned:
+// 31 rows x 48 B for the moments, 37 rows x 64 B for the steered BRIEF reach of +-18) and then works on LDS bytes.
+struct KpAux { int32_t m10, m01; float sn, cs; };          // per (frame, slot): moments -> (sin, cos) of the keypoint angle
 #define DP_ROWS_O 31
-#define DP_DW_O 10          // dwords per staged row of the orientation patch (covers x-15 .. x+15 from an aligned base)
+#define DP_QW_O 3           // 16-byte words per staged row of the orientation patch: [(x-15) & ~15, +48) covers x-15 .. x+15
 #define DP_ROWS_B 37
-#define DP_DW_B 11          // dwords per staged row of the blurred patch (x-18 .. x+18)
-__global__ void __launch_bounds__(256)
-describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, const uint32_t* __restrict__ sel,
-                const int32_t* __restrict__ nsel, const int8_t* __restrict__ pattern, const uint16_t* __restrict__ depth, ssm_camera cam,
-                ssm_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, float* __restrict__ pos3d, int32_t* __restrict__ nkp)
+#define DP_QW_B 4           // blurred patch: [(x-18) & ~15, +64) covers x-18 .. x+18
+// slot -> (level, index in level, output index); false when the slot is empty
+__device__ __forceinline__ bool kp_slot(const OrbGeom& g, const int32_t* __restrict__ ns, int slot, int& l, int& oidx)
 {
-    __shared__ uint32_t po[4][DP_ROWS_O * DP_DW_O];
-    __shared__ uint32_t pb[4][DP_ROWS_B * DP_DW_B];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wv;
-    const int32_t* ns = nsel + f * g.nlevels;
-    if (slot == 0 && lane == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
-    if (slot >= g.sel_total) return;
-    int l = 0;
+    if (slot >= g.sel_total) return false;
+    l = 0;
     while (l + 1 < g.nlevels && slot >= g.L[l+1].sel_off) l++;
-    const LevelGeom& L = g.L[l];
-    const int i = slot - L.sel_off;
-    if (i >= ns[l]) return;
-    int oidx = i;
+    const int i = slot - g.L[l].sel_off;
+    if (i >= ns[l]) return false;
+    oidx = i;
     for (int k = 0; k < l; k++) oidx += ns[k];
-    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
-    const int x = pk & 4095, y = (pk >> 12) & 4095, score = pk >> 24;
-    // ---- stage both patches (keypoints sit >= 19 px from every border, so all rows/columns exist; rows are 16-B aligned)
-    const uint8_t* imrow = pyr + (size_t)f * g.pyr_bytes + L.img_off;
-    const uint8_t* blrow = blur + (size_t)f * g.pyr_bytes + L.img_off;
-    const int xo0 = (x - 15) & ~3, xb0 = (x - 18) & ~3;             // aligned first column of each staged patch
-    for (int e = lane; e < DP_ROWS_O * DP_DW_O; e += 64) {
-        const int r = e / DP_DW_O, c = e - r * DP_DW_O;
-        const int gx = xo0 + 4 * c;
-        po[wv][e] = gx < L.stride ? *reinterpret_cast<const uint32_t*>(imrow + (size_t)(y - 15 + r) * L.stride + gx) : 0u;
+    return true;
+}
+// orient_kernel: lane = (row v = (lane >> 1) - 15, half): the right half-row is the 16 pixels [x, x + 16), the left one [x - 16, x); ONE (unaligned)
+// 16-byte load per lane fetches the whole disc of a keypoint in a single vector-memory instruction; the disc's extent in that row (umax) becomes a
+// per-lane byte mask, the sums are v_dot4_u32_u8 with constant weights: si = sum p, sk = sum k p (k = byte index 0..15; u = k on the right,
+// u = k - 16 on the left).  A wave walks OR_KPW consecutive slots with all their loads in flight first: the stage is latency-bound, not VALU-bound.
+#define OR_KPW 4
+// (the builtin, not inline asm: hipcc cannot see an opcode inside an asm statement and then omits the wait state a dependent VALU instruction
+// needs behind a dot instruction -- scripts/ubench/orient_check.hip shows the wrong sums that gives)
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
+__global__ void __launch_bounds__(256)
+orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
+              KpAux* __restrict__ aux)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
+    const int slot0 = (blockIdx.x * 4 + wv) * OR_KPW;
+    if (slot0 >= g.sel_total) return;
+    // per-lane constants
+    const int r = lane >> 1, left = !(lane & 1);
+    const int v = r <= 2 * SSM_HALF_PATCH ? r - SSM_HALF_PATCH : 0;
+    const int d = r <= 2 * SSM_HALF_PATCH ? (int)((umax_pack >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;      // -1: lanes 62, 63 hold no row
+    uint32_t M[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int kk = 4 * j + k;
+            const bool keep = left ? (kk >= 16 - d && d > 0) : (kk <= d);       // left: u = kk - 16 in [-d, -1]; right: u = kk in [0, d]
+            m |= keep ? (0xFFu << (8 * k)) : 0u;
+        }
+        M[j] = m;
     }
-    for (int e = lane; e < DP_ROWS_B * DP_DW_B; e += 64) {
-        const int r = e / DP_DW_B, c = e - r * DP_DW_B;
-        const int gx = xb0 + 4 * c;
-        pb[wv][e] = gx < L.stride ? *reinterpret_cast<const uint32_t*>(blrow + (size_t)(y - 18 + r) * L.stride + gx) : 0u;
-    }
-    const uint8_t* ob = reinterpret_cast<const uint8_t*>(po[wv]) + 15 * (DP_DW_O * 4) + (x - xo0);      // centre pixel of the orientation patch
-    const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv]) + 18 * (DP_DW_B * 4) + (x - xb0);      // centre pixel of the blurred patch
-    __builtin_amdgcn_s_waitcnt(0);                                   // this wave's own LDS writes are complete before it reads them back
-    __builtin_amdgcn_wave_barrier();
-    // intensity centroid over the radius-15 disc: lane -> (row, half-row)
-    int m10 = 0, m01 = 0;
-    {
-        const int r = lane >> 1, v = r - SSM_HALF_PATCH;
-        if (r <= 2 * SSM_HALF_PATCH) {
-            const int d = g.umax[v < 0 ? -v : v];
-            const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-            const uint8_t* row = ob + v * (DP_DW_O * 4);
-            int si = 0, sui = 0;
-            for (int u = u0; u <= u1; u++) { const int p = row[u]; si += p; sui += u * p; }
-            m10 = sui; m01 = v * si;
+    const int koff = left ? -16 : 0;
+    const int32_t* ns = nsel + f * g.nlevels;
+    const uint8_t* fr = pyr + (size_t)f * g.pyr_bytes;
+    uint4 px[OR_KPW]; bool ok[OR_KPW];
+#pragma unroll
+    for (int q = 0; q < OR_KPW; q++) {
+        int l, oidx;
+        ok[q] = kp_slot(g, ns, slot0 + q, l, oidx);
+        px[q] = make_uint4(0, 0, 0, 0);
+        if (ok[q]) {
+            const LevelGeom& L = g.L[l];
+            const uint32_t pk = sel[(size_t)f * g.sel_total + slot0 + q];
+            const int x = pk & 4095, y = (pk >> 12) & 4095;
+            // keypoints sit >= 19 px from every border: [x - 16, x + 16) x [y - 15, y + 15] lies inside the level
+            const uint8_t* p = fr + L.img_off + (size_t)(y + v) * L.stride + (x + koff);
+            uint4 t; __builtin_memcpy(&t, p, 16);                    // unaligned 16-byte load
+            px[q] = t;
         }
     }
-    m10 = wave_sum(m10); m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+#pragma unroll
+    for (int q = 0; q < OR_KPW; q++) {
+        if (!ok[q]) continue;                                           // wave-uniform
+        const uint32_t a0 = px[q].x & M[0], a1 = px[q].y & M[1], a2 = px[q].z & M[2], a3 = px[q].w & M[3];
+        uint32_t si = udot4(a0, 0x01010101u, 0u); si = udot4(a1, 0x01010101u, si); si = udot4(a2, 0x01010101u, si); si = udot4(a3, 0x01010101u, si);
+        uint32_t sk = udot4(a0, 0x03020100u, 0u); sk = udot4(a1, 0x07060504u, sk); sk = udot4(a2, 0x0B0A0908u, sk); sk = udot4(a3, 0x0F0E0D0Cu, sk);
+        const int sui = (int)sk - (left ? 16 * (int)si : 0);
+        const int m10 = wave_total(sui), m01 = wave_total(v * (int)si);
+        if (lane == 0) { KpAux a; a.m10 = m10; a.m01 = m01; a.sn = 0.f; a.cs = 0.f; aux[(size_t)f * g.sel_total + slot0 + q] = a; }
+    }
+}
+__global__ void __launch_bounds__(256)
+angle_kernel(OrbGeom g, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel, const uint16_t* __restrict__ depth, ssm_camera cam,
+             KpAux* __restrict__ aux, ssm_keypoint* __restrict__ kps, float* __restrict__ pos3d, int32_t* __restrict__ nkp)
+{
+    const int f = blockIdx.y, slot = blockIdx.x * 256 + threadIdx.x;
+    const int32_t* ns = nsel + f * g.nlevels;
+    if (slot == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
+    int l, oidx;
+    if (!kp_slot(g, ns, slot, l, oidx)) return;
+    const LevelGeom& L = g.L[l];
+    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
+    const int x = pk & 4095, y = (pk >> 12) & 4095, score = pk >> 24;
+    KpAux a = aux[(size_t)f * g.sel_total + slot];
+    const float angle = fast_atan2_deg((float)a.m01, (float)a.m10);
+    contract_sincos(angle * (float)(3.14159265358979323846 / 180.f), &a.sn, &a.cs);
+    aux[(size_t)f * g.sel_total + slot] = a;
+    ssm_keypoint kp;
+    kp.x = (float)x; kp.y = (float)y;
+    if (l != 0) { kp.x *= L.sf; kp.y *= L.sf; }
+    kp.size = (float)SSM_PATCH * L.sf; kp.angle = angle; kp.response = (float)score; kp.octave = l; kp.class_id = -1;
+    kps[(size_t)f * g.cap + oidx] = kp;
+    if (pos3d) {
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (depth) {
+            const int u = (int)kp.x, v = (int)kp.y;            // include/orb.h:50 float -> int truncation
+            const uint16_t d = depth[(size_t)f * g.W * g.H + (size_t)v * g.W + u];
+            if (d != 0) {
+                pz = (float)((double)d / cam.scale);
+                px = (float)(((double)u - cam.cx) * (double)pz / cam.fx);
+                py = (float)(((double)v - cam.cy) * (double)pz / cam.fy);
+            }
+        }
+        float* o = pos3d + ((size_t)f * g.cap + oidx) * 3;
+        o[0] = px; o[1] = py; o[2] = pz;
+    }
+}
+// value of lane + n inside the 16-lane row (0 beyond the row): the 16 nibbles of one 64-bit descriptor word sit in one row
+#define ROW_SHL(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (n), 0xF, 0xF, true))
+__global__ void __launch_bounds__(256)
+brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
+             const int8_t* __restrict__ pattern, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc)
+{
+    __shared__ uint4 pb[4][DP_ROWS_B * DP_QW_B];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wv;
+    int l, oidx;
+    if (!kp_slot(g, nsel + f * g.nlevels, slot, l, oidx)) return;
+    const LevelGeom& L = g.L[l];
+    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
+    const int x = pk & 4095, y = (pk >> 12) & 4095;
+    const uint8_t* blrow = blur + (size_t)f * g.pyr_bytes + L.img_off;
+    const int xb0 = (x - 18) & ~15;
+    for (int e = lane; e < DP_ROWS_B * DP_QW_B; e += 64) {
+        const int r = e >> 2, c = e & 3;
+        const int gx = xb0 + 16 * c;
+        pb[wv][e] = gx < L.stride ? *reinterpret_cast<const uint4*>(blrow + (size_t)(y - 18 + r) * L.stride + gx) : make_uint4(0, 0, 0, 0);
+    }
+    const KpAux a = aux[(size_t)f * g.sel_total + slot];
+    const float sb = a.sn, ca = a.cs;
     // steered BRIEF: lane -> 4 of the 256 comparisons (its 16 pattern bytes arrive in one 16-byte load)
-    float sb, ca;
-    contract_sincos(angle * (float)(3.14159265358979323846 / 180.f), &sb, &ca);
     const uint4 pw = *reinterpret_cast<const uint4*>(pattern + lane * 16);
     const uint32_t pwv[4] = {pw.x, pw.y, pw.z, pw.w};
+    const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv]) + 18 * (DP_QW_B * 16) + (x - xb0);      // centre pixel of the blurred patch
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
     uint32_t nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -905,42 +985,26 @@ describe_kernel(OrbGeom g, const uint8_t* __restrict__ pyr, const uint8_t* __res
         const float x0 = (float)(int8_t)(q & 255), y0 = (float)(int8_t)((q >> 8) & 255), x1 = (float)(int8_t)((q >> 16) & 255), y1 = (float)(int8_t)(q >> 24);
         const int yy0 = __float2int_rn(x0 * sb + y0 * ca), xx0 = __float2int_rn(x0 * ca - y0 * sb);
         const int yy1 = __float2int_rn(x1 * sb + y1 * ca), xx1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = bb[yy0 * (DP_DW_B * 4) + xx0], t1 = bb[yy1 * (DP_DW_B * 4) + xx1];
+        const int t0 = bb[yy0 * (DP_QW_B * 16) + xx0], t1 = bb[yy1 * (DP_QW_B * 16) + xx1];
         nib |= (uint32_t)(t0 < t1) << k;
     }
-    // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word
-    uint32_t b = nib | (__shfl_down(nib, 1, 64) << 4);           // even lanes: one byte
-    b |= __shfl_down(b, 2, 64) << 8;                             // lanes %4==0: 2 bytes
-    b |= __shfl_down(b, 4, 64) << 16;                            // lanes %8==0: 4 bytes
-    const uint32_t hi = __shfl_down(b, 8, 64);
+    // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
+    uint32_t b = nib | (ROW_SHL(nib, 1) << 4);                   // even lanes: one byte
+    b |= ROW_SHL(b, 2) << 8;                                     // lanes %4==0: 2 bytes
+    b |= ROW_SHL(b, 4) << 16;                                    // lanes %8==0: 4 bytes
+    const uint32_t hi = ROW_SHL(b, 8);
     if ((lane & 15) == 0)
         reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + oidx) * 32)[lane >> 4] = make_uint2(b, hi);
-    if (lane == 0) {
-        ssm_keypoint kp;
-        kp.x = (float)x; kp.y = (float)y;
-        if (l != 0) { kp.x *= L.sf; kp.y *= L.sf; }
-        kp.size = (float)SSM_PATCH * L.sf; kp.angle = angle; kp.response = (float)score; kp.octave = l; kp.class_id = -1;
-        kps[(size_t)f * g.cap + oidx] = kp;
-        if (pos3d) {
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (depth) {
-                const int u = (int)kp.x, v = (int)kp.y;            // include/orb.h:50 float -> int truncation
-                const uint16_t d = depth[(size_t)f * g.W * g.H + (size_t)v * g.W + u];
-                if (d != 0) {
-                    pz = (float)((double)d / cam.scale);
-                    px = (float)(((double)u - cam.cx) * (double)pz / cam.fx);
-                    py = (float)(((double)v - cam.cy) * (double)pz / cam.fy);
-                }
-            }
-            float* o = pos3d + ((size_t)f * g.cap + oidx) * 3;
-            o[0] = px; o[1] = py; o[2] = pz;
-        }
-    }
 }
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
-                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam,
+                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam, void* kpaux,
                       ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp, hipStream_t s)
 {
-    describe_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, pyr, blur, sel, nsel, pattern, depth, cam, kps, desc, pos3d, nkp);
+    unsigned long long um = 0;
+    for (int v = 0; v <= SSM_HALF_PATCH; v++) um |= (unsigned long long)(g.umax[v] & 15) << (4 * v);
+    KpAux* aux = reinterpret_cast<KpAux*>(kpaux);
+    orient_kernel<<<dim3((g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW), n), 256, 0, s>>>(g, um, pyr, sel, nsel, aux);
+    angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, depth, cam, aux, kps, pos3d, nkp);
+    brief_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, blur, sel, nsel, pattern, aux, desc);
     return hipGetLastError();
 }

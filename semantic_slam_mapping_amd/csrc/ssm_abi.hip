@@ -81,10 +81,10 @@ struct ssm_ctx {
     int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
     // batch workspace (B frames)
     uint8_t *d_pyr = nullptr, *d_blur = nullptr; int32_t* d_cellmax = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
-    int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr;
+    int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr; uint4* d_kpaux = nullptr;
     // second ORB / map workspace: ssm_seq_process runs alternate sub-batches as two chains on two streams (allocated at first use)
     struct AltWork { uint8_t *pyr = nullptr, *blur = nullptr; int32_t* cellmax = nullptr; cand_t* cand = nullptr; uint16_t* nodeof = nullptr;
-                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; bool ready = false; } alt;
+                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; uint4* kpaux = nullptr; bool ready = false; } alt;
     hipEvent_t ev_orb[2] = {nullptr, nullptr};
     uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
     ssm_point* d_points = nullptr;
@@ -310,6 +310,7 @@ static int ctx_init(ssm_ctx* c)
     DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
+    DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total);
     DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
     const int chunks = backproject_chunks(W, H);
     DALLOC(c, c->d_mask, (size_t)B * W * H); DALLOC(c, c->d_chunk_cnt, (size_t)B * chunks); DALLOC(c, c->d_chunk_off, (size_t)B * chunks);
@@ -348,9 +349,9 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
-                     c->d_hist_tmp, c->map.tab, c->tmp.tab };
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux };
     for (void* p : ptrs) if (p) hipFree(p);
-    { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask };
+    { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
     for (int i = 0; i < 2; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
     for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); if (c->d_xgrp[l]) hipFree(c->d_xgrp[l]); }
@@ -412,7 +413,7 @@ static int ensure_alt(ssm_ctx* c)
     DALLOC(c, c->alt.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->alt.blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->alt.cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->alt.cand, (size_t)B * g.cand_total); DALLOC(c, c->alt.nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->alt.ncand, (size_t)B * g.nlevels); DALLOC(c, c->alt.sel, (size_t)B * g.sel_total); DALLOC(c, c->alt.nsel, (size_t)B * g.nlevels);
-    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H);
+    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H); DALLOC(c, c->alt.kpaux, (size_t)B * g.sel_total);
     c->alt.ready = true;
     return SSM_OK;
 }
@@ -420,7 +421,7 @@ struct ChainSwap {                    // chain 1 of ssm_seq_process: the helpers
     ssm_ctx* c; bool on;
     void swap_all() { std::swap(c->stream, c->stream2); std::swap(c->d_pyr, c->alt.pyr); std::swap(c->d_blur, c->alt.blur); std::swap(c->d_cellmax, c->alt.cellmax);
                       std::swap(c->d_cand, c->alt.cand); std::swap(c->d_nodeof, c->alt.nodeof); std::swap(c->d_ncand, c->alt.ncand); std::swap(c->d_sel, c->alt.sel);
-                      std::swap(c->d_nsel, c->alt.nsel); std::swap(c->d_mask, c->alt.mask); }
+                      std::swap(c->d_nsel, c->alt.nsel); std::swap(c->d_mask, c->alt.mask); std::swap(c->d_kpaux, c->alt.kpaux); }
     ChainSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) swap_all(); }
     ~ChainSwap() { if (on) swap_all(); }
 };
@@ -434,7 +435,7 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
     prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
     prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
     prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
-    prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern, d_depth, c->cfg.camera, kps, desc, pos3d, nkp, s)); prof_end(c);
+    prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern, d_depth, c->cfg.camera, c->d_kpaux, kps, desc, pos3d, nkp, s)); prof_end(c);
     return SSM_OK;
 }
 
