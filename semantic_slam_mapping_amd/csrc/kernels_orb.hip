@@ -177,7 +177,7 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
 // taps {18,34,49,55,49,34,18}; row pass fits u16 (<= 257*255); (v + 2^15) >> 16, saturate; BORDER_REFLECT_101.
 // One block per 128x32 tile of one level of one frame (all levels in one launch, same tiling as the FAST kernel):
 // tile + apron staged in LDS by dword loads (all issued before first use), 4 pixels per thread in both passes, row-pass
-// intermediate kept in LDS as u16, output written as dwords.
+// intermediate kept in LDS as u16 (the two rows of a pair interleaved per pixel), output written as dwords.
 #define BT_W 128
 #define BT_H 32
 #define BT_PW (BT_W + 8)      // staged row: [tx0-4, tx0+132)
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256)
 blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint8_t  in[BT_PH * BT_PW];
-    __shared__ __attribute__((aligned(16))) uint16_t hp[BT_PH * BT_W];
+    __shared__ uint4 hp2[(BT_PH / 2) * (BT_W / 4)];             // row-pass sums: [row pair][pixel] = (even row | odd row << 16)
     const int tid = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
@@ -206,19 +206,24 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         reinterpret_cast<uint32_t*>(in)[i] = v;
     }
     __syncthreads();
-    for (int i = tid; i < BT_PH * (BT_W / 4); i += 256) {
-        const int ly = i >> 5, lq = i & 31;
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(in + ly * BT_PW) + lq;     // dwords at x-4, x, x+4
-        const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
-        // output k (pixel x + k) is the 7-tap dot product of the bytes x+k-3 .. x+k+3 = bytes k+1 .. k+7 of (d0, d1, d2):
-        // two v_dot4_u32_u8 on the byte-aligned dwords (taps 18 34 49 55 | 49 34 18 0)
+    // row pass, two rows (2j, 2j+1) x four pixels per work item; the two rows' sums of a pixel share one dword of hp (low half = even
+    // row), so that the column pass reads whole row pairs and feeds them to v_dot2_u32_u16 without re-pairing them
+    for (int i = tid; i < (BT_PH / 2) * (BT_W / 4); i += 256) {
+        const int j = i >> 5, lq = i & 31;
         const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), TB, 0u, false), false);
-        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), TB, 0u, false), false);
-        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), TB, 0u, false), false);
-        o[3] = __builtin_amdgcn_udot4(d1, TA, __builtin_amdgcn_udot4(d2, TB, 0u, false), false);
-        reinterpret_cast<uint2*>(hp + ly * BT_W)[lq] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        uint32_t o[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t* r = reinterpret_cast<const uint32_t*>(in + (2 * j + rr) * BT_PW) + lq;     // dwords at x-4, x, x+4
+            const uint32_t d0 = r[0], d1 = r[1], d2 = r[2];
+            // output k (pixel x + k) is the 7-tap dot product of the bytes x+k-3 .. x+k+3 = bytes k+1 .. k+7 of (d0, d1, d2):
+            // two v_dot4_u32_u8 on the byte-aligned dwords (taps 18 34 49 55 | 49 34 18 0)
+            o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), TB, 0u, false), false);
+            o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), TB, 0u, false), false);
+            o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), TB, 0u, false), false);
+            o[rr][3] = __builtin_amdgcn_udot4(d1, TA, __builtin_amdgcn_udot4(d2, TB, 0u, false), false);
+        }
+        hp2[j * (BT_W / 4) + lq] = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
     }
     __syncthreads();
     uint8_t* dst = blur + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
@@ -226,26 +231,26 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         const int ly = i >> 5, lq = i & 31;
         const int gx = tx0 + 4 * lq, gy = ty0 + ly;
         if (gx >= stride || gy >= h) continue;
-        // column pass: rows are paired (k, k+1) per pixel with v_perm and reduced by v_dot2_u32_u16 (two taps per instruction)
+        // column pass over the staged rows ly .. ly+6 = the pairs m .. m+3 (m = ly >> 1): an even ly takes (18,34) (49,55) (49,34) (18,0) of them,
+        // an odd ly (0,18) (34,49) (55,49) (34,18): four v_dot2_u32_u16 per pixel, the rounding constant rides in as the first accumulator
         typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
         auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b), c, false); };
-        uint2 v[7];
-#pragma unroll
-        for (int k = 0; k < 7; k++) v[k] = reinterpret_cast<const uint2*>(hp + (ly + k) * BT_W)[lq];
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const uint32_t T2[3] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16)};       // taps of rows (0,1), (2,3), (4,5); row 6: 18
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint2 a = v[2 * k], b = v[2 * k + 1];
-            acc[0] = dot2(__builtin_amdgcn_perm(b.x, a.x, 0x05040100u), T2[k], acc[0]);         // (a.lo, b.lo)
-            acc[1] = dot2(__builtin_amdgcn_perm(b.x, a.x, 0x07060302u), T2[k], acc[1]);         // (a.hi, b.hi)
-            acc[2] = dot2(__builtin_amdgcn_perm(b.y, a.y, 0x05040100u), T2[k], acc[2]);
-            acc[3] = dot2(__builtin_amdgcn_perm(b.y, a.y, 0x07060302u), T2[k], acc[3]);
-        }
-        acc[0] += 18u * (v[6].x & 0xFFFF); acc[1] += 18u * (v[6].x >> 16); acc[2] += 18u * (v[6].y & 0xFFFF); acc[3] += 18u * (v[6].y >> 16);
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t q = min((acc[k] + 32768u) >> 16, 255u); out |= (gx + k < w ? q : 0u) << (8 * k); }
+        const bool odd = ly & 1;
+        const uint32_t T0 = odd ? (18u << 16) : (18u | (34u << 16)), T1 = odd ? (34u | (49u << 16)) : (49u | (55u << 16)),
+                       T2 = odd ? (55u | (49u << 16)) : (49u | (34u << 16)), T3 = odd ? (34u | (18u << 16)) : 18u;
+        const uint4* hq = hp2 + (ly >> 1) * (BT_W / 4) + lq;
+        const uint4 p0 = hq[0], p1 = hq[BT_W / 4], p2 = hq[2 * (BT_W / 4)], p3 = hq[3 * (BT_W / 4)];
+        const uint32_t a0 = dot2(p3.x, T3, dot2(p2.x, T2, dot2(p1.x, T1, dot2(p0.x, T0, 32768u))));
+        const uint32_t a1 = dot2(p3.y, T3, dot2(p2.y, T2, dot2(p1.y, T1, dot2(p0.y, T0, 32768u))));
+        const uint32_t a2 = dot2(p3.z, T3, dot2(p2.z, T2, dot2(p1.z, T1, dot2(p0.z, T0, 32768u))));
+        const uint32_t a3 = dot2(p3.w, T3, dot2(p2.w, T2, dot2(p1.w, T1, dot2(p0.w, T0, 32768u))));
+        // (acc >> 16) of two pixels side by side as u16, saturated to 255 by one packed min, then the four low bytes into one dword
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 lim = {255, 255};
+        const us2 q01 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm(a1, a0, 0x07060302u)), lim);
+        const us2 q23 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm(a3, a2, 0x07060302u)), lim);
+        uint32_t out = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q23), __builtin_bit_cast(uint32_t, q01), 0x06040200u);
+        if (gx + 3 >= w) out &= gx >= w ? 0u : (0xFFFFFFFFu >> (8 * (gx + 4 - w)));       // keep the padding columns zero
         *reinterpret_cast<uint32_t*>(dst + (size_t)gy * stride + gx) = out;
     }
 }
