@@ -310,6 +310,39 @@ __device__ __forceinline__ int fast_S(const uint8_t* p, int st)
     bright = max(bright, mn9[15]); dark = min(dark, mx9[15]);
     return max(bright, -dark);
 }
+// The same score for TWO positions per lane.  The ring differences of position A live in the low half of a dword and those of B in the high half,
+// as f16 DENORMALS: the bit pattern n (0..255) is the half-precision number n * 2^-24, sums and differences of such numbers are exact (|n| < 1024) and
+// kernels run with f16 denormals enabled, so v_pk_add_f16 is an exact packed 16-bit subtract whose results order like the integers -- and gfx950 has the
+// three-input packed v_pk_minimum3_f16 / v_pk_maximum3_f16 (there is no three-input packed INTEGER min / max): one instruction does what two v_min3_i32
+// did.  Result: S_A | S_B << 16 (each clamped at 0 like fast_S's callers do).
+__device__ __forceinline__ uint32_t pk_min3h(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t pk_max3h(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t pk_addh(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_maxh(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_minh(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t fast_S2(const uint8_t* pa, const uint8_t* pb, int st)
+{
+#define RING2(o) ((uint32_t)pa[o] | ((uint32_t)pb[o] << 16))
+    const uint32_t negc = RING2(0) ^ 0x80008000u;                      // -(centre) in both halves
+    uint32_t d[16];
+    d[0] = pk_addh(RING2(3*st), negc);      d[1] = pk_addh(RING2(3*st+1), negc);   d[2] = pk_addh(RING2(2*st+2), negc);   d[3] = pk_addh(RING2(st+3), negc);
+    d[4] = pk_addh(RING2(3), negc);         d[5] = pk_addh(RING2(-st+3), negc);    d[6] = pk_addh(RING2(-2*st+2), negc);  d[7] = pk_addh(RING2(-3*st+1), negc);
+    d[8] = pk_addh(RING2(-3*st), negc);     d[9] = pk_addh(RING2(-3*st-1), negc);  d[10] = pk_addh(RING2(-2*st-2), negc); d[11] = pk_addh(RING2(-st-3), negc);
+    d[12] = pk_addh(RING2(-3), negc);       d[13] = pk_addh(RING2(st-3), negc);    d[14] = pk_addh(RING2(2*st-2), negc);  d[15] = pk_addh(RING2(3*st-1), negc);
+#undef RING2
+    uint32_t mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn3[k] = pk_min3h(d[k], d[(k+1)&15], d[(k+2)&15]); mx3[k] = pk_max3h(d[k], d[(k+1)&15], d[(k+2)&15]); }
+    uint32_t mn9[16], mx9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn9[k] = pk_min3h(mn3[k], mn3[(k+3)&15], mn3[(k+6)&15]); mx9[k] = pk_max3h(mx3[k], mx3[(k+3)&15], mx3[(k+6)&15]); }
+    uint32_t bright = pk_max3h(mn9[0], mn9[1], mn9[2]), dark = pk_min3h(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) { bright = pk_max3h(bright, mn9[k], mn9[k+1]); dark = pk_min3h(dark, mx9[k], mx9[k+1]); }
+    bright = pk_maxh(bright, mn9[15]); dark = pk_minh(dark, mx9[15]);
+    // max(bright, -dark, +0): a positive denormal's bits ARE the integer
+    return pk_max3h(bright, dark ^ 0x80008000u, 0u);
+}
 #define FT_W 128
 #define FT_H 32
 #define FT_PW (FT_W + 8)      // staged pixel row: 4-px apron each side (3 for the ring + 1 for the NMS neighbours)
@@ -330,7 +363,7 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     // so the candidate staging area reuses the pixel tile: px is dead once every position is scored, and the NMS pass that fills
     // `stage` starts behind the barrier that ends the scoring loop
     cand_t* stage = reinterpret_cast<cand_t*>(px);
-    __shared__ int nlist, nstage, gbase;
+    __shared__ int nlist, nsurv, nstage, gbase;
     const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
@@ -351,7 +384,7 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     if (tid < FT_SW) { const int gx = tx0 + tid - 1 - L.minBX - 3; cellx[tid] = (int16_t)(gx >= 0 ? gx / L.wCell : -1); }
     if (tid < FT_SH) { const int gy = ty0 + tid - 1 - L.minBY - 3; celly[tid] = (int16_t)(gy >= 0 ? gy / L.hCell : -1); }
     if (tid < 64) lmax[tid] = 0;
-    if (tid == 0) { nlist = 0; nstage = 0; gbase = 0; }
+    if (tid == 0) { nlist = 0; nsurv = 0; nstage = 0; gbase = 0; }
     __syncthreads();
     // ---- quick reject + compaction of the positions worth scoring.  A position passes when two ADJACENT compass points of
     // the ring (N, E, S, W at distance 3) are both brighter than v + t or both darker than v - t (necessary for a 9-arc).
@@ -424,25 +457,46 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     }
     __syncthreads();
     const int n = nlist;
-    for (int e = tid; e < n; e += 256) {
-        const int i = list[e], sy = i >> 8, sx = i & 255;
-        const int S = fast_S(&px[(sy + 3) * FT_PW + sx + 3], FT_PW);
-        sc[sy * FT_SST + sx] = (uint8_t)max(S, 0);
+    // ---- score the listed positions, two per lane (fast_S2), and compact the ones that can become keypoints (S > minThFAST, inside the tile and the
+    // image) to the front of the same list: a chunk's entries are all read before the barrier, survivors are written behind it into slots below the
+    // chunk's end (there are never more survivors than entries processed), so the NMS pass below walks ~10 % of the positions instead of ~23 %
+    for (int e0 = 0; e0 < n; e0 += 512) {
+        const int ea = e0 + tid, eb = e0 + 256 + tid;
+        const int ia = list[min(ea, n - 1)], ib = list[min(eb, n - 1)];
+        const int sya = ia >> 8, sxa = ia & 255, syb = ib >> 8, sxb = ib & 255;
+        const uint32_t S2 = fast_S2(&px[(sya + 3) * FT_PW + sxa + 3], &px[(syb + 3) * FT_PW + sxb + 3], FT_PW);
+        const int Sa = (int)(S2 & 0xFFFFu), Sb = (int)(S2 >> 16);
+        if (ea < n) sc[sya * FT_SST + sxa] = (uint8_t)Sa;
+        if (eb < n) sc[syb * FT_SST + sxb] = (uint8_t)Sb;
+        const bool ka = ea < n && Sa > min_th && sxa >= 1 && sxa <= FT_W && sya >= 1 && sya <= FT_H && tx0 + sxa - 1 < w && ty0 + sya - 1 < h;
+        const bool kb = eb < n && Sb > min_th && sxb >= 1 && sxb <= FT_W && syb >= 1 && syb <= FT_H && tx0 + sxb - 1 < w && ty0 + syb - 1 < h;
+        __syncthreads();                                                // every entry of the chunk has been read
+        const unsigned long long ba = __ballot(ka), bb = __ballot(kb);
+        const int ca = __popcll(ba), cb = __popcll(bb);
+        if (ca + cb) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&nsurv, ca + cb);
+            base = __shfl(base, 0, 64);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (ka) list[base + __popcll(ba & below)] = (uint16_t)ia;
+            if (kb) list[base + ca + __popcll(bb & below)] = (uint16_t)ib;
+        }
     }
     __syncthreads();
+    const int n2 = nsurv;
     // ---- local maxima among same-cell neighbours; staged in LDS, ONE global reservation per tile
     const int cx0 = max((int)cellx[1], 0), cy0 = max((int)celly[1], 0);
     cand_t* out = cand + (size_t)blockIdx.y * g.cand_total + L.cand_off;
     int32_t* nc = ncand + blockIdx.y * g.nlevels + l;
-    for (int e0 = 0; e0 < n; e0 += 256) {
+    for (int e0 = 0; e0 < n2; e0 += 256) {
         const int e = e0 + tid;
         bool keep = false; int S = 0, sx = 0, sy = 0;
-        if (e < n) {
+        if (e < n2) {
             const int i = list[e]; sy = i >> 8; sx = i & 255;
-            if (sx >= 1 && sx <= FT_W && sy >= 1 && sy <= FT_H && tx0 + sx - 1 < w && ty0 + sy - 1 < h) {
+            {
                 const uint8_t* q = &sc[sy * FT_SST + sx];
                 S = q[0];
-                if (S > min_th) {
+                {
                     const int cx = cellx[sx], cy = celly[sy];
                     const bool xl = cellx[sx-1] == cx, xr = cellx[sx+1] == cx, yu = celly[sy-1] == cy, yd = celly[sy+1] == cy;
                     int nb = 0;
