@@ -180,7 +180,7 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
 // intermediate kept in LDS as u16 (the two rows of a pair interleaved per pixel), output written as dwords.
 #define BT_W 128
 #define BT_H 32
-#define BT_PW (BT_W + 8)      // staged row: [tx0-4, tx0+132)
+#define BT_PW (BT_W + 16)     // staged row: [tx0-4, tx0+140) = nine 16-byte words (the passes read [tx0-4, tx0+132))
 #define BT_PH (BT_H + 6)
 __device__ __forceinline__ int reflect101(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
 __global__ void __launch_bounds__(256)
@@ -196,14 +196,24 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
     const int tx0 = (t % L.tiles_x) * BT_W, ty0 = (t / L.tiles_x) * BT_H;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* src = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
-    for (int i = tid; i < BT_PH * (BT_PW / 4); i += 256) {
-        const int ly = i / (BT_PW / 4), lq = i - ly * (BT_PW / 4);
-        const int gx = tx0 - 4 + 4 * lq, gy = reflect101(ty0 - 3 + ly, h);
+    // nine 16-byte words per staged row; a word that lies inside the image is one (unaligned) load, a word that crosses the left or right
+    // border (two per row, in edge tiles only) is assembled from reflected bytes; rows reflect as a whole
+    for (int i = tid; i < BT_PH * (BT_PW / 16); i += 256) {
+        const int ly = (i * 7282) >> 16, c = i - ly * (BT_PW / 16);                 // i / 9 for i < 342
+        const int gx = tx0 - 4 + 16 * c, gy = reflect101(ty0 - 3 + ly, h);
         const uint8_t* row = src + (size_t)gy * stride;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < w) v = *reinterpret_cast<const uint32_t*>(row + gx);
-        else v = (uint32_t)row[reflect101(gx, w)] | ((uint32_t)row[reflect101(gx + 1, w)] << 8) | ((uint32_t)row[reflect101(gx + 2, w)] << 16) | ((uint32_t)row[reflect101(gx + 3, w)] << 24);
-        reinterpret_cast<uint32_t*>(in)[i] = v;
+        uint4 v;
+        if (gx >= 0 && gx + 16 <= w) __builtin_memcpy(&v, row + gx, 16);
+        else {
+            uint32_t d[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int x = gx + 4 * q;
+                d[q] = (uint32_t)row[reflect101(x, w)] | ((uint32_t)row[reflect101(x + 1, w)] << 8) | ((uint32_t)row[reflect101(x + 2, w)] << 16) | ((uint32_t)row[reflect101(x + 3, w)] << 24);
+            }
+            v = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        reinterpret_cast<uint4*>(in)[i] = v;
     }
     __syncthreads();
     // row pass, two rows (2j, 2j+1) x four pixels per work item; the two rows' sums of a pixel share one dword of hp (low half = even
@@ -345,7 +355,7 @@ __device__ __forceinline__ uint32_t fast_S2(const uint8_t* pa, const uint8_t* pb
 }
 #define FT_W 128
 #define FT_H 32
-#define FT_PW (FT_W + 8)      // staged pixel row: 4-px apron each side (3 for the ring + 1 for the NMS neighbours)
+#define FT_PW (FT_W + 16)     // staged pixel row [tx0 - 4, tx0 + 140) = nine 16-byte words: 4-px apron each side (3 for the ring + 1 for the NMS neighbours)
 #define FT_PH (FT_H + 8)
 #define FT_SW (FT_W + 2)      // scored positions: tile + 1
 #define FT_SH (FT_H + 2)
@@ -355,7 +365,7 @@ __global__ void __launch_bounds__(256)
 fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap)
 {
     __shared__ __attribute__((aligned(16))) uint8_t px[FT_PH * FT_PW];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_SH * FT_SST];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[(FT_SH * FT_SST + 15) / 16 * 16];
     __shared__ uint16_t list[FT_SW * FT_SH];
     __shared__ int16_t cellx[FT_SW], celly[FT_SH];
     __shared__ int lmax[64];
@@ -372,15 +382,16 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     const int tx0 = (t % L.tiles_x) * FT_W, ty0 = (t / L.tiles_x) * FT_H;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* im = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
-    // ---- stage the tile (dword loads; out-of-image dwords read as 0: no valid position ever looks at them)
-    for (int i = tid; i < FT_PH * (FT_PW / 4); i += 256) {
-        const int ly = i / (FT_PW / 4), lq = i - ly * (FT_PW / 4);
-        const int gx = tx0 - 4 + 4 * lq, gy = ty0 - 4 + ly;
-        uint32_t v = 0;
-        if (gx >= 0 && gx < stride && gy >= 0 && gy < h) v = *reinterpret_cast<const uint32_t*>(im + (size_t)gy * stride + gx);
-        reinterpret_cast<uint32_t*>(px)[i] = v;
+    // ---- stage the tile: nine (unaligned) 16-byte loads per row, 360 per tile.  Rows / words outside the image are CLAMPED into it instead of
+    // zero-filled: they then hold shifted pixels, which no valid position ever looks at (valid positions sit >= 19 px from every border, the ring and
+    // the NMS neighbours reach 4), and no address leaves the level image
+    for (int i = tid; i < FT_PH * (FT_PW / 16); i += 256) {
+        const int ly = (i * 7282) >> 16, c = i - ly * (FT_PW / 16);                 // i / 9 for i < 360
+        const int gy = min(max(ty0 - 4 + ly, 0), h - 1), gx = min(max(tx0 - 4 + 16 * c, 0), stride - 16);
+        uint4 v; __builtin_memcpy(&v, im + (size_t)gy * stride + gx, 16);
+        reinterpret_cast<uint4*>(px)[i] = v;
     }
-    for (int i = tid; i < FT_SH * FT_SST / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+    for (int i = tid; i < (FT_SH * FT_SST + 15) / 16; i += 256) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
     if (tid < FT_SW) { const int gx = tx0 + tid - 1 - L.minBX - 3; cellx[tid] = (int16_t)(gx >= 0 ? gx / L.wCell : -1); }
     if (tid < FT_SH) { const int gy = ty0 + tid - 1 - L.minBY - 3; celly[tid] = (int16_t)(gy >= 0 ? gy / L.hCell : -1); }
     if (tid < 64) lmax[tid] = 0;
