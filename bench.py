@@ -31,8 +31,12 @@ W, H = 640, 480
 CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
 SEED = 0x5EED0000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-VALU_LANEOPS_PEAK = 39.3e12    # 1024 SIMDs x 16 lanes per clock x 2.4 GHz (one wave64 integer op / 4 clk / SIMD); scripts/ubench/valu_rate.hip measures
-                               # 36 T at the ~2.2 GHz the chip holds under that load, and these kernels run at 2.2-2.3 GHz
+# VALU issue ceilings, measured per instruction class (profiles/r02_valu_rate.md, scripts/ubench/valu_rate.hip): everything these integer kernels are made
+# of (bcnt, min / max / med3, perm, alignbyte, sad, dot, pk_*, mul, cmp, cndmask, DPP, cvt, f64) issues one wave64 instruction per 4 cycles per SIMD, and so
+# does ANY mixed stream (xor + bcnt alternating: 8.0 cycles per pair): 1024 SIMDs x 16 lanes per clock x 2.4 GHz.  Only pure runs of mov / and / or / xor /
+# add / sub / lshr / ashr / f32 add, sub, mul reach 2 cycles (SURVEY.md s.8d's 78.6 T); reported beside it as frac_of_simple_op_peak.
+VALU_LANEOPS_PEAK = 39.3e12
+VALU_SIMPLE_OP_PEAK = 78.6e12
 
 
 def algorithmic_bytes(stage, P, nkp):
@@ -75,7 +79,8 @@ def measured_valu(stage, us_per_frame):
         insts = sum(v["valu_wave_insts_per_frame"] for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage]))
         ach = insts * 64 / (us_per_frame * 1e-6) / 1e12
         return {"achieved": round(ach, 2), "peak": VALU_LANEOPS_PEAK / 1e12, "unit": "Tlaneop/s", "frac": round(ach / (VALU_LANEOPS_PEAK / 1e12), 3),
-                "wave_insts_per_frame": round(insts)}
+                "frac_of_simple_op_peak": round(ach / (VALU_SIMPLE_OP_PEAK / 1e12), 3), "wave_insts_per_frame": round(insts),
+                "peak_basis": "4 cycles per wave64 instruction per SIMD: measured for every instruction class of these kernels and for mixed streams (profiles/r02_valu_rate.md)"}
     except Exception:
         return None
 
@@ -221,6 +226,12 @@ def cpu_all_cores(orc, frames_per_thread, leaf):
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:        # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") is what it can really use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda i: orc.pipeline(i * frames_per_thread, frames_per_thread, nfeatures=1000, leaf=np.float32(leaf)), range(cores)))
@@ -441,7 +452,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, frames_per_launch),
                     "algorithmic_bytes_per_launch": round(gb * 1e9),
-                    "note": "integer/byte kernel limited by VALU issue (measured 36 T lane-op/s) and LDS, not HBM: see DESIGN.md s.4"}
+                    "note": "integer/byte kernel limited by VALU issue (4 cycles per instruction, profiles/r02_valu_rate.md) and LDS, not HBM: see `valu` and DESIGN.md s.4"}
         if roof.get("bound") == "hbm":
             roof["valu"] = measured_valu(dom, per_stage[dom][1])      # what actually bounds the integer stages
         try:    # the whole pipeline against the VALU issue ceiling: every kernel's wave-instructions per frame (committed SQ pass) x 64 x frames/s
@@ -449,7 +460,8 @@ def main():
             wi = sum(v["valu_wave_insts_per_frame"] for name, v in kk.items() if "synth" not in name)
             if not args.segnet:
                 roof["pipeline_valu"] = {"achieved": round(wi * 64 * value / 1e12, 2), "peak": VALU_LANEOPS_PEAK / 1e12, "unit": "Tlaneop/s",
-                                         "frac": round(wi * 64 * value / VALU_LANEOPS_PEAK, 3), "wave_insts_per_frame": round(wi),
+                                         "frac": round(wi * 64 * value / VALU_LANEOPS_PEAK, 3), "frac_of_simple_op_peak": round(wi * 64 * value / VALU_SIMPLE_OP_PEAK, 3),
+                                         "wave_insts_per_frame": round(wi),
                                          "note": "all kernels of a frame (ORB, match, map) at the timed rate `value`, two chains overlapped"}
         except Exception:
             pass

@@ -35,6 +35,7 @@ public:
     // viewer thread (src/mapper.cpp:96-171)
     void viewer() {
         PointCloud::Ptr map(new PointCloud);
+        try {
         while (!shutdownFlag) {
             size_t nkf; { unique_lock<mutex> lck(poseGraph.keyframes_mutex); nkf = poseGraph.keyframes.size(); }
             if (nkf <= (size_t)keyframe_size) { this_thread::sleep_for(chrono::milliseconds(1)); continue; }
@@ -57,6 +58,9 @@ public:
             cout << "points in global map: " << map->points.size() << endl;
             cout << "Mapping cost time: " << ms << "ms" << endl;
         }
+        } catch (const std::exception& e) {             // a device error on this thread must not std::terminate the process: report it and stop mapping
+            cerr << "Mapper::viewer stopped: " << e.what() << endl; viewerFailed = true;
+        }
         if (poseGraph.shutDownFlag && !map_output.empty()) { writePCD(map_output, *map); cout << "Map saved!" << endl; }
     }
     // binary PCD, FIELDS x y z rgba (what pcl::PCDWriter::write emits for PointXYZRGBA)
@@ -68,20 +72,38 @@ public:
         for (const PointT& p : c.points) { out.write((const char*)&p.x, 12); out.write((const char*)&p.b, 4); }
         return (bool)out;
     }
-    // src/mapper.cpp:12-94: moving-class mask, gated unprojection, camera colour, pose; cached on the frame like the reference
+    // src/mapper.cpp:12-94.  Like the reference, the gated camera-frame cloud is computed ONCE per frame (moving-class mask, gated unprojection,
+    // camera colour: ssm_backproject with T = NULL) and cached in frame->pointcloud (mapper.cpp:17-20); every call returns a copy transformed by the
+    // frame's current pose (pcl::transformPointCloud, mapper.cpp:91: x' = float(t00 x + t01 y + t02 z + t03) in double, left to right -- the same
+    // arithmetic ssm_backproject applies on the device when it is given T, so both routes give identical bits; -ffp-contract=off in host/Makefile)
     PointCloud::Ptr generatePointCloud(const RGBDFrame::Ptr& frame) {
-        ssm::Device& d = device(frame->depth.cols, frame->depth.rows);
-        const int w = frame->depth.cols, h = frame->depth.rows;
-        ssm_camera cam; cam.cx = frame->camera.cx; cam.cy = frame->camera.cy; cam.fx = frame->camera.fx; cam.fy = frame->camera.fy; cam.scale = frame->camera.scale;
-        PointCloud::Ptr tmp(new PointCloud());
-        Eigen::Isometry3d T = invert_pose ? frame->getTransform().inverse() : frame->getTransform();
-        tmp->points.resize((size_t)w * h);
-        int n = 0;
-        d.check(ssm_backproject(d.ctx(), frame->depth.ptr<uint16_t>(), frame->rgb.data, frame->semantic.data, w, h, &cam, T.data(), max_distance,
-                                reinterpret_cast<ssm_point*>(tmp->points.data()), w * h, &n), "ssm_backproject");
-        tmp->points.resize(n); tmp->width = n; tmp->is_dense = false;
+        if (frame->pointcloud == nullptr) {
+            ssm::Device& d = device(frame->depth.cols, frame->depth.rows);
+            const int w = frame->depth.cols, h = frame->depth.rows;
+            ssm_camera cam; cam.cx = frame->camera.cx; cam.cy = frame->camera.cy; cam.fx = frame->camera.fx; cam.fy = frame->camera.fy; cam.scale = frame->camera.scale;
+            PointCloud::Ptr pc(new PointCloud());
+            pc->points.resize((size_t)w * h);
+            int n = 0;
+            d.check(ssm_backproject(d.ctx(), frame->depth.ptr<uint16_t>(), frame->rgb.data, frame->semantic.data, w, h, &cam, nullptr, max_distance,
+                                    reinterpret_cast<ssm_point*>(pc->points.data()), w * h, &n), "ssm_backproject");
+            pc->points.resize(n); pc->points.shrink_to_fit(); pc->width = n; pc->is_dense = false;
+            frame->pointcloud = pc;
+            cloudsComputed++;
+        }
+        const Eigen::Isometry3d T = invert_pose ? frame->getTransform().inverse() : frame->getTransform();
+        const double* t = T.data();                                            // column-major
+        PointCloud::Ptr tmp(new PointCloud(*frame->pointcloud));
+        for (PointT& p : tmp->points) {
+            const double x = p.x, y = p.y, z = p.z;
+            p.x = (float)(t[0] * x + t[4] * y + t[8] * z + t[12]);
+            p.y = (float)(t[1] * x + t[5] * y + t[9] * z + t[13]);
+            p.z = (float)(t[2] * x + t[6] * y + t[10] * z + t[14]);
+        }
+        tmp->is_dense = false;
         return tmp;
     }
+    volatile bool viewerFailed = false;
+    int cloudsComputed = 0;                                                    // device back-projections so far (each frame costs one)
     PointCloud::Ptr voxelFilter(const PointCloud::Ptr& in) {                  // pcl::VoxelGrid::filter, mapper.cpp:154-155
         PointCloud::Ptr out(new PointCloud());
         if (in->points.empty()) return out;

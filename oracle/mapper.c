@@ -109,8 +109,13 @@ int sso_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_t* se
  * per-frame and per-GPU partial tables merge to the bit-identical map.  Label = argmax of votes over ids 0..11
  * (ties -> lowest id), 255 when no vote. */
 #define VOX_BIAS (1 << 20)
+/* CONTRACT (range): a point whose voxel index floor(c * inv_leaf) is not finite or not inside (-2^20, 2^20) on some axis cannot be keyed in 21 bits
+ * per axis; it is SKIPPED, the way pcl::VoxelGrid skips non-finite points of a non-dense cloud (voxel_grid.hpp, `if (!input_->is_dense)`), and the
+ * device raises SSM_E_VOXEL_RANGE once.  Returns -1 for such a point. */
 int64_t sso_voxel_key(float x, float y, float z, float inv_leaf)
 {
+    const float fi = floorf(x * inv_leaf), fj = floorf(y * inv_leaf), fk = floorf(z * inv_leaf);
+    if (!(fabsf(fi) < 1048576.0f) || !(fabsf(fj) < 1048576.0f) || !(fabsf(fk) < 1048576.0f)) return -1;
     int64_t i = (int64_t)floorf(x * inv_leaf) + VOX_BIAS;
     int64_t j = (int64_t)floorf(y * inv_leaf) + VOX_BIAS;
     int64_t k = (int64_t)floorf(z * inv_leaf) + VOX_BIAS;
@@ -131,7 +136,9 @@ static int points_to_table(const sso_point* pts, int n, float leaf, sso_voxel** 
 {
     const float inv = 1.0f / leaf;
     keyidx_t* ki = (keyidx_t*)malloc(sizeof(keyidx_t) * (n > 0 ? n : 1));
-    for (int i = 0; i < n; i++) { ki[i].key = sso_voxel_key(pts[i].x, pts[i].y, pts[i].z, inv); ki[i].idx = i; }
+    { int kept = 0;
+      for (int i = 0; i < n; i++) { const int64_t key = sso_voxel_key(pts[i].x, pts[i].y, pts[i].z, inv); if (key < 0) continue; ki[kept].key = key; ki[kept].idx = i; kept++; }
+      n = kept; }
     qsort(ki, n, sizeof(keyidx_t), keyidx_cmp);      /* like PCL: sort (index, point) pairs, then reduce runs */
     int m = 0;
     for (int i = 0; i < n; i++) if (i == 0 || ki[i].key != ki[i-1].key) m++;

@@ -121,65 +121,69 @@ int sso_solve6_lu(double A[36], double b[6])
 }
 
 /* ---------------- residuals and Jacobian of one match (computeResidualsAndJacobian, one i) ---------------- */
-typedef struct {
-    double r00, r01, r02, r10, r11, r12, r20, r21, r22;
-    double rdrx10, rdrx11, rdrx12, rdrx20, rdrx21, rdrx22;
-    double rdry00, rdry01, rdry02, rdry10, rdry11, rdry12, rdry20, rdry21, rdry22;
-    double rdrz00, rdrz01, rdrz10, rdrz11, rdrz20, rdrz21;
-    double tx, ty, tz;
-} vo_rot;
-static void vo_rot_make(const double tr[6], vo_rot* R)
+/* pose = rotation about x, then y, then z (angles tr[0..2]) + translation tr[3..5]; R holds the rotation matrix and, per angle, the matrix of
+ * partial derivatives.  Operand order inside every sum follows /root/reference/src/vo_stereo.cpp:280-345 (that is what the bits depend on); the
+ * notation is this file's own.  nterm[p][r]: the reference's derivative sums skip row 0 for the first angle and the third column for the third. */
+typedef struct { double R[9], dR[3][9], t[3]; } vo_model;
+static const int vo_nterm[3][3] = {{0, 3, 3}, {3, 3, 3}, {2, 2, 2}};
+static void vo_model_make(const double tr[6], vo_model* M)
 {
-    double sx, cx, sy, cy, sz, cz;
-    sso_sincos64(tr[0], &sx, &cx); sso_sincos64(tr[1], &sy, &cy); sso_sincos64(tr[2], &sz, &cz);
-    R->tx = tr[3]; R->ty = tr[4]; R->tz = tr[5];
-    R->r00 = +cy*cz;          R->r01 = -cy*sz;          R->r02 = +sy;
-    R->r10 = +sx*sy*cz+cx*sz; R->r11 = -sx*sy*sz+cx*cz; R->r12 = -sx*cy;
-    R->r20 = -cx*sy*cz+sx*sz; R->r21 = +cx*sy*sz+sx*cz; R->r22 = +cx*cy;
-    R->rdrx10 = +cx*sy*cz-sx*sz; R->rdrx11 = -cx*sy*sz-sx*sz; R->rdrx12 = -cx*cy;      /* rdrx11 as in the reference (see header) */
-    R->rdrx20 = +sx*sy*cz+cx*sz; R->rdrx21 = -sx*sy*sz+cx*cz; R->rdrx22 = -sx*cy;
-    R->rdry00 = -sy*cz;          R->rdry01 = +sy*sz;          R->rdry02 = +cy;
-    R->rdry10 = +sx*cy*cz;       R->rdry11 = -sx*cy*sz;       R->rdry12 = +sx*sy;
-    R->rdry20 = -cx*cy*cz;       R->rdry21 = +cx*cy*sz;       R->rdry22 = -cx*sy;
-    R->rdrz00 = -cy*sz;          R->rdrz01 = -cy*cz;
-    R->rdrz10 = -sx*sy*sz+cx*cz; R->rdrz11 = -sx*sy*cz-cx*sz;
-    R->rdrz20 = +cx*sy*sz+sx*cz; R->rdrz21 = +cx*sy*cz-sx*sz;
+    double s1, c1, s2, c2, s3, c3;
+    sso_sincos64(tr[0], &s1, &c1); sso_sincos64(tr[1], &s2, &c2); sso_sincos64(tr[2], &s3, &c3);
+    M->t[0] = tr[3]; M->t[1] = tr[4]; M->t[2] = tr[5];
+    double* R = M->R; double* A = M->dR[0]; double* B = M->dR[1]; double* G = M->dR[2];
+    R[0] = c2*c3;             R[1] = -c2*s3;            R[2] = s2;
+    R[3] = s1*s2*c3 + c1*s3;  R[4] = -s1*s2*s3 + c1*c3; R[5] = -s1*c2;
+    R[6] = -c1*s2*c3 + s1*s3; R[7] = c1*s2*s3 + s1*c3;  R[8] = c1*c2;
+    A[0] = 0.0;               A[1] = 0.0;               A[2] = 0.0;
+    A[3] = c1*s2*c3 - s1*s3;  A[4] = -c1*s2*s3 - s1*s3; A[5] = -c1*c2;       /* A[4]: the reference's term (vo_stereo.cpp:289), see the header */
+    A[6] = s1*s2*c3 + c1*s3;  A[7] = -s1*s2*s3 + c1*c3; A[8] = -s1*c2;
+    B[0] = -s2*c3;            B[1] = s2*s3;             B[2] = c2;
+    B[3] = s1*c2*c3;          B[4] = -s1*c2*s3;         B[5] = s1*s2;
+    B[6] = -c1*c2*c3;         B[7] = c1*c2*s3;          B[8] = -c1*s2;
+    G[0] = -c2*s3;            G[1] = -c2*c3;            G[2] = 0.0;
+    G[3] = -s1*s2*s3 + c1*c3; G[4] = -s1*s2*c3 - c1*s3; G[5] = 0.0;
+    G[6] = c1*s2*s3 + s1*c3;  G[7] = c1*s2*c3 - s1*s3;  G[8] = 0.0;
+}
+/* derivative of the transformed point by parameter j (0..2 angles, 3..5 translation) */
+static void vo_dpoint(const vo_model* M, int j, const double q[3], double d[3])
+{
+    if (j >= 3) { d[0] = j == 3; d[1] = j == 4; d[2] = j == 5; return; }
+    for (int r = 0; r < 3; r++) {
+        const double* row = &M->dR[j][3 * r];
+        const int nt = vo_nterm[j][r];
+        double v = 0.0;
+        if (nt >= 2) v = row[0] * q[0] + row[1] * q[1];
+        if (nt == 3) v = v + row[2] * q[2];
+        d[r] = v;
+    }
 }
 /* J: 4 x 6 (NULL: predictions only), pred[4], res[4] */
-static void vo_point(const sso_pmatch* m, const sso_vo_params* P, const vo_rot* R, double J[24], double pred[4], double res[4])
+static void vo_point(const sso_pmatch* m, const sso_vo_params* P, const vo_model* M, double J[24], double pred[4], double res[4])
 {
-    const double dd = fmax((double)(m->u1p - m->u2p), 1.0);       /* max(u1p - u2p, 1.0f): float subtraction, then double */
-    const double X1p = ((double)m->u1p - P->cu) * P->base / dd, Y1p = ((double)m->v1p - P->cv) * P->base / dd, Z1p = P->f * P->base / dd;
-    const double X1c = R->r00*X1p + R->r01*Y1p + R->r02*Z1p + R->tx;
-    const double Y1c = R->r10*X1p + R->r11*Y1p + R->r12*Z1p + R->ty;
-    const double Z1c = R->r20*X1p + R->r21*Y1p + R->r22*Z1p + R->tz;
+    const double disp = fmax((double)(m->u1p - m->u2p), 1.0);     /* max(u1p - u2p, 1.0f): float subtraction, then double */
+    const double q[3] = { ((double)m->u1p - P->cu) * P->base / disp, ((double)m->v1p - P->cv) * P->base / disp, P->f * P->base / disp };
+    double c[3];
+    for (int r = 0; r < 3; r++) c[r] = M->R[3*r] * q[0] + M->R[3*r+1] * q[1] + M->R[3*r+2] * q[2] + M->t[r];
     const double obs[4] = { (double)m->u1c, (double)m->v1c, (double)m->u2c, (double)m->v2c };
     double weight = 1.0;
     if (P->reweighting) weight = 1.0 / (fabs(obs[0] - P->cu) / fabs(P->cu) + 0.05);
-    const double X2c = X1c - P->base;
+    const double xr = c[0] - P->base;
     if (J) {
         for (int j = 0; j < 6; j++) {
-            double X1cd, Y1cd, Z1cd;
-            switch (j) {
-                case 0: X1cd = 0; Y1cd = R->rdrx10*X1p + R->rdrx11*Y1p + R->rdrx12*Z1p; Z1cd = R->rdrx20*X1p + R->rdrx21*Y1p + R->rdrx22*Z1p; break;
-                case 1: X1cd = R->rdry00*X1p + R->rdry01*Y1p + R->rdry02*Z1p; Y1cd = R->rdry10*X1p + R->rdry11*Y1p + R->rdry12*Z1p;
-                        Z1cd = R->rdry20*X1p + R->rdry21*Y1p + R->rdry22*Z1p; break;
-                case 2: X1cd = R->rdrz00*X1p + R->rdrz01*Y1p; Y1cd = R->rdrz10*X1p + R->rdrz11*Y1p; Z1cd = R->rdrz20*X1p + R->rdrz21*Y1p; break;
-                case 3: X1cd = 1; Y1cd = 0; Z1cd = 0; break;
-                case 4: X1cd = 0; Y1cd = 1; Z1cd = 0; break;
-                default: X1cd = 0; Y1cd = 0; Z1cd = 1; break;
-            }
-            J[0 * 6 + j] = weight * P->f * (X1cd*Z1c - X1c*Z1cd) / (Z1c*Z1c);
-            J[1 * 6 + j] = weight * P->f * (Y1cd*Z1c - Y1c*Z1cd) / (Z1c*Z1c);
-            J[2 * 6 + j] = weight * P->f * (X1cd*Z1c - X2c*Z1cd) / (Z1c*Z1c);
-            J[3 * 6 + j] = weight * P->f * (Y1cd*Z1c - Y1c*Z1cd) / (Z1c*Z1c);
+            double d[3];
+            vo_dpoint(M, j, q, d);
+            J[0 * 6 + j] = weight * P->f * (d[0] * c[2] - c[0] * d[2]) / (c[2] * c[2]);
+            J[1 * 6 + j] = weight * P->f * (d[1] * c[2] - c[1] * d[2]) / (c[2] * c[2]);
+            J[2 * 6 + j] = weight * P->f * (d[0] * c[2] - xr * d[2]) / (c[2] * c[2]);
+            J[3 * 6 + j] = J[1 * 6 + j];
         }
     }
-    pred[0] = P->f * X1c / Z1c + P->cu; pred[1] = P->f * Y1c / Z1c + P->cv;
-    pred[2] = P->f * X2c / Z1c + P->cu; pred[3] = P->f * Y1c / Z1c + P->cv;
+    pred[0] = P->f * c[0] / c[2] + P->cu; pred[1] = P->f * c[1] / c[2] + P->cv;
+    pred[2] = P->f * xr / c[2] + P->cu; pred[3] = pred[1];
     if (res) for (int k = 0; k < 4; k++) res[k] = weight * (obs[k] - pred[k]);
 }
-static int vo_is_inlier(const sso_pmatch* m, const sso_vo_params* P, const vo_rot* R)
+static int vo_is_inlier(const sso_pmatch* m, const sso_vo_params* P, const vo_model* R)
 {
     double pred[4];
     vo_point(m, P, R, NULL, pred, NULL);
@@ -191,7 +195,7 @@ enum { VO_UPDATED = 0, VO_FAILED = 1, VO_CONVERGED = 2 };
 static int vo_update(const sso_pmatch* m, const int32_t* active, int na, const sso_vo_params* P, double tr[6], double eps, int lanes)
 {
     if (na < 3) return VO_FAILED;
-    vo_rot R; vo_rot_make(tr, &R);
+    vo_model R; vo_model_make(tr, &R);
     double (*acc)[42] = (double (*)[42])calloc((size_t)lanes, sizeof(double[42]));      /* A row-major 36, then B 6 */
     for (int q = 0; q < na; q++) {
         double J[24], pred[4], res[4];
@@ -236,7 +240,7 @@ int sso_vo_estimate(const sso_pmatch* m, int n, const sso_vo_params* P, const in
             if (iter++ > 20 || result == VO_CONVERGED) break;
         }
         if (result != VO_FAILED) {
-            vo_rot R; vo_rot_make(tr, &R);
+            vo_model R; vo_model_make(tr, &R);
             int c = 0;
             for (int i = 0; i < n; i++) if (vo_is_inlier(&m[i], P, &R)) cur[c++] = i;
             if (c > best) { best = c; memcpy(inliers, cur, sizeof(int32_t) * (size_t)c); memcpy(tr_best, tr, sizeof(tr_best)); }
@@ -259,7 +263,7 @@ int sso_vo_estimate(const sso_pmatch* m, int n, const sso_vo_params* P, const in
 /* VisualOdometry::transformationVectorToMatrix (vo.cpp:40-72): row-major 4 x 4 */
 void sso_vo_tr_to_matrix(const double tr[6], double T[16])
 {
-    vo_rot R; vo_rot_make(tr, &R);
-    const double M[16] = { R.r00, R.r01, R.r02, R.tx, R.r10, R.r11, R.r12, R.ty, R.r20, R.r21, R.r22, R.tz, 0, 0, 0, 1 };
+    vo_model R; vo_model_make(tr, &R);
+    const double M[16] = { R.R[0], R.R[1], R.R[2], R.t[0], R.R[3], R.R[4], R.R[5], R.t[1], R.R[6], R.R[7], R.R[8], R.t[2], 0, 0, 0, 1 };
     memcpy(T, M, sizeof(M));
 }

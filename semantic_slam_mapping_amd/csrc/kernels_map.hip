@@ -279,10 +279,11 @@ vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__
             const uint4* p = reinterpret_cast<const uint4*>(pts + i);
             const uint4 lo = p[0], hi = p[1];
             const float x = __uint_as_float(lo.x), y = __uint_as_float(lo.y), z = __uint_as_float(lo.z);
-            const long long vi = (long long)floorf(x * inv_leaf) + (1 << 20);
-            const long long vj = (long long)floorf(y * inv_leaf) + (1 << 20);
-            const long long vk = (long long)floorf(z * inv_leaf) + (1 << 20);
+            const float fi = floorf(x * inv_leaf), fj = floorf(y * inv_leaf), fk = floorf(z * inv_leaf);
+            const long long vi = (long long)fi + (1 << 20), vj = (long long)fj + (1 << 20), vk = (long long)fk + (1 << 20);
             key = (vk << 42) | (vj << 21) | vi;
+            // range contract (oracle/mapper.c sso_voxel_key): index not finite or outside (-2^20, 2^20) -> the point is skipped, flag bit 1
+            if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; atomicOr(&counters[1], 2); }
             sx = __double2ll_rn((double)x * 16777216.0); sy = __double2ll_rn((double)y * 16777216.0); sz = __double2ll_rn((double)z * 16777216.0);
             rg = ((hi.x >> 16) & 255) | (((hi.x >> 8) & 255) << 16);       // r | g<<16
             bn = (hi.x & 255) | (1u << 16);                               // b | n<<16
@@ -304,7 +305,7 @@ vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__
         unsigned long long lb[12];
 #pragma unroll
         for (int c = 0; c < 12; c++) lb[c] = __ballot(label == (uint32_t)c);
-        if (valid && tail) {
+        if (valid && tail && key >= 0) {
             ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
             if (v) {
                 vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
@@ -495,7 +496,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     if (tid == 0) s_npts = 0;
     __syncthreads();
     uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
-    int kept = 0;
+    int kept = 0; bool out_of_range = false;
     // MS_CH chunks per block: neighbouring rows share most of their voxels, so the block table (and the global atomics of the
     // flush, whose latency nothing overlaps) is paid once per 16 K pixels instead of once per 4 K
 #pragma unroll 1
@@ -564,10 +565,11 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
                     oy = (float)(T[1] * X + T[4] * Y + T[7] * Z + T[10]);
                     oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
                 }
-                const long long vi = (long long)floorf(ox * inv_leaf) + (1 << 20);
-                const long long vj = (long long)floorf(oy * inv_leaf) + (1 << 20);
-                const long long vk = (long long)floorf(oz * inv_leaf) + (1 << 20);
-                const long long key = (vk << 42) | (vj << 21) | vi;
+                const float fi = floorf(ox * inv_leaf), fj = floorf(oy * inv_leaf), fk = floorf(oz * inv_leaf);
+                const long long vi = (long long)fi + (1 << 20), vj = (long long)fj + (1 << 20), vk = (long long)fk + (1 << 20);
+                long long key = (vk << 42) | (vj << 21) | vi;
+                // range contract (oracle/mapper.c sso_voxel_key): such a point still counts in npoints (generatePointCloud emits it) but is not fused
+                if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; out_of_range = true; }
                 const uint32_t lab = labs[k];
                 RunAcc p;
                 p.sx = f64_to_ll_rn((double)ox * 16777216.0); p.sy = f64_to_ll_rn((double)oy * 16777216.0); p.sz = f64_to_ll_rn((double)oz * 16777216.0);
@@ -578,7 +580,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
                 } else if (k1 == -2 || (k1 == key && l1 == lab)) {                       // second run
                     k1 = key; l1 = lab; a1.sx += p.sx; a1.sy += p.sy; a1.sz += p.sz; a1.r += p.r; a1.g += p.g; a1.b += p.b; a1.n += 1;
                 } else {                                                                 // a third run inside 16 pixels: rare
-                    lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
+                    if (k1 >= 0) lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
                     k1 = key; l1 = lab; a1 = p;
                 }
             }
@@ -591,6 +593,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
     if (lane == 0 && kept) atomicAdd(&s_npts, kept);
+    if (__ballot(out_of_range) && lane == 0) atomicOr(&counters[1], 2);
     __syncthreads();
     for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;

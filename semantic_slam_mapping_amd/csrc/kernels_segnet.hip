@@ -1114,9 +1114,17 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
 }
 // tile counters of conv3x3_dma2_kernel (self-resetting, see there): one small zeroed buffer per (device, stream); launches on a
 // stream are ordered, so they can share it
+static std::mutex g_tq_mu; static std::map<std::pair<int, hipStream_t>, int*> g_tq_bufs;
+void k_segnet_release_stream(hipStream_t s)                       // ssm_destroy: the stream's tile-counter buffer goes with the context
+{
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_tq_mu);
+    auto it = g_tq_bufs.find({dev, s});
+    if (it != g_tq_bufs.end()) { (void)hipFree(it->second); g_tq_bufs.erase(it); }
+}
 static int* conv_tile_queue(hipStream_t s)
 {
-    static std::mutex mu; static std::map<std::pair<int, hipStream_t>, int*> bufs;
+    std::mutex& mu = g_tq_mu; auto& bufs = g_tq_bufs;
     int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     auto it = bufs.find({dev, s});

@@ -378,11 +378,26 @@ sgbm_fill(int16_t* __restrict__ p, int n, int16_t v) { const int i = blockIdx.x 
 // side streams for the five concurrent scan directions: one set per caller stream (a context), created at its first call;
 // every call forks them from and joins them into the caller's stream by events, so calls on one context stay ordered and
 // contexts used from different host threads never share an event
-struct SgStreams { hipStream_t s[4]; hipEvent_t fork, done[4]; bool ok = false; };
+struct SgStreams { hipStream_t s[4] = {}; hipEvent_t fork = nullptr, done[4] = {}; bool ok = false; };
+static std::mutex g_sg_mu;
+static std::map<std::pair<int, hipStream_t>, SgStreams*> g_sg_sets;
+// ssm_destroy: the side streams / events of a context's stream go with it (and a recycled stream handle can never find a stale set)
+void k_sgbm_release_stream(hipStream_t caller)
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_sg_mu);
+    auto it = g_sg_sets.find({dev, caller});
+    if (it == g_sg_sets.end()) return;
+    SgStreams* st = it->second;
+    for (int i = 0; i < 4; i++) { if (st->s[i]) { (void)hipStreamSynchronize(st->s[i]); (void)hipStreamDestroy(st->s[i]); } if (st->done[i]) (void)hipEventDestroy(st->done[i]); }
+    if (st->fork) (void)hipEventDestroy(st->fork);
+    delete st;
+    g_sg_sets.erase(it);
+}
 static SgStreams& sg_streams(hipStream_t caller)
 {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SgStreams*> sets;
+    std::mutex& mu = g_sg_mu;
+    auto& sets = g_sg_sets;
     int dev = 0; (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     SgStreams*& st = sets[{dev, caller}];

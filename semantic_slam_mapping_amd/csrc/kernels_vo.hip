@@ -14,13 +14,12 @@
 #include "ssm_internal.h"
 #include <cfloat>
 
-struct VoRot {
-    double r00, r01, r02, r10, r11, r12, r20, r21, r22;
-    double rdrx10, rdrx11, rdrx12, rdrx20, rdrx21, rdrx22;
-    double rdry00, rdry01, rdry02, rdry10, rdry11, rdry12, rdry20, rdry21, rdry22;
-    double rdrz00, rdrz01, rdrz10, rdrz11, rdrz20, rdrz21;
-    double tx, ty, tz;
-};
+// Motion model of the stereo VO (the parametrisation of /root/reference/src/vo_stereo.cpp:280-345, own formulation): pose = Euler X-Y-Z rotation
+// (alpha, beta, gamma) + translation.  rot[r][c] is the rotation, drot[p][r][c] its partial derivative by angle p.  The reference leaves some derivative
+// terms out of its sums (d/d alpha does not touch row 0; d/d gamma has no column-2 term): VO_DTERMS[p][r] says how many leading terms of row r enter,
+// so that the sums have the reference's operands in the reference's order (bit-exactness with oracle/vo.c rests on the order, not on the notation).
+struct VoPose { double rot[3][3], t[3], drot[3][3][3]; };
+__device__ __constant__ const int VO_DTERMS[3][3] = {{0, 3, 3}, {3, 3, 3}, {2, 2, 2}};
 // sin/cos contract of oracle/vo.c: Cody-Waite reduction by pi/2 in three pieces + the fdlibm kernel polynomials
 __device__ __forceinline__ void vo_sincos64(double x, double* s, double* c)
 {
@@ -47,63 +46,71 @@ __device__ __forceinline__ void vo_sincos64(double x, double* s, double* c)
         default: *s = -cr; *c = sr; break;
     }
 }
-__device__ __forceinline__ void vo_rot_make(const double tr[6], VoRot& R)
+__device__ __forceinline__ void vo_pose_make(const double tr[6], VoPose& M)
 {
-    double sx, cx, sy, cy, sz, cz;
-    vo_sincos64(tr[0], &sx, &cx); vo_sincos64(tr[1], &sy, &cy); vo_sincos64(tr[2], &sz, &cz);
-    R.tx = tr[3]; R.ty = tr[4]; R.tz = tr[5];
-    R.r00 = +cy*cz;          R.r01 = -cy*sz;          R.r02 = +sy;
-    R.r10 = +sx*sy*cz+cx*sz; R.r11 = -sx*sy*sz+cx*cz; R.r12 = -sx*cy;
-    R.r20 = -cx*sy*cz+sx*sz; R.r21 = +cx*sy*sz+sx*cz; R.r22 = +cx*cy;
-    R.rdrx10 = +cx*sy*cz-sx*sz; R.rdrx11 = -cx*sy*sz-sx*sz; R.rdrx12 = -cx*cy;        // rdrx11 as written at vo_stereo.cpp:289
-    R.rdrx20 = +sx*sy*cz+cx*sz; R.rdrx21 = -sx*sy*sz+cx*cz; R.rdrx22 = -sx*cy;
-    R.rdry00 = -sy*cz;          R.rdry01 = +sy*sz;          R.rdry02 = +cy;
-    R.rdry10 = +sx*cy*cz;       R.rdry11 = -sx*cy*sz;       R.rdry12 = +sx*sy;
-    R.rdry20 = -cx*cy*cz;       R.rdry21 = +cx*cy*sz;       R.rdry22 = -cx*sy;
-    R.rdrz00 = -cy*sz;          R.rdrz01 = -cy*cz;
-    R.rdrz10 = -sx*sy*sz+cx*cz; R.rdrz11 = -sx*sy*cz-cx*sz;
-    R.rdrz20 = +cx*sy*sz+sx*cz; R.rdrz21 = +cx*sy*cz-sx*sz;
+    double sa, ca, sb, cb, sg, cg;                          // sines / cosines of alpha (about x), beta (about y), gamma (about z)
+    vo_sincos64(tr[0], &sa, &ca); vo_sincos64(tr[1], &sb, &cb); vo_sincos64(tr[2], &sg, &cg);
+    for (int r = 0; r < 3; r++) M.t[r] = tr[3 + r];
+    const double rot[3][3] = {{cb*cg,                -cb*sg,                sb},
+                              {sa*sb*cg + ca*sg,     -sa*sb*sg + ca*cg,     -sa*cb},
+                              {-ca*sb*cg + sa*sg,    ca*sb*sg + sa*cg,      ca*cb}};
+    // d/d alpha: row 0 does not depend on alpha.  Entry [1][1] is written -ca*sb*sg - sa*sg as the reference has it (vo_stereo.cpp:289; the
+    // analytic derivative, and libviso2, end in sa*cg): bug-compatible by contract (oracle/vo.c header)
+    const double da[3][3] = {{0.0,                   0.0,                   0.0},
+                             {ca*sb*cg - sa*sg,      -ca*sb*sg - sa*sg,     -ca*cb},
+                             {sa*sb*cg + ca*sg,      -sa*sb*sg + ca*cg,     -sa*cb}};
+    const double db[3][3] = {{-sb*cg,                sb*sg,                 cb},
+                             {sa*cb*cg,              -sa*cb*sg,             sa*sb},
+                             {-ca*cb*cg,             ca*cb*sg,              -ca*sb}};
+    const double dg[3][3] = {{-cb*sg,                -cb*cg,                0.0},
+                             {-sa*sb*sg + ca*cg,     -sa*sb*cg - ca*sg,     0.0},
+                             {ca*sb*sg + sa*cg,      ca*sb*cg - sa*sg,      0.0}};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { M.rot[r][c] = rot[r][c]; M.drot[0][r][c] = da[r][c]; M.drot[1][r][c] = db[r][c]; M.drot[2][r][c] = dg[r][c]; }
 }
 // one match: 4 predictions, optionally the 4 weighted residuals and the 4 x 6 Jacobian
 template <bool WITH_J>
-__device__ __forceinline__ void vo_point(const ssm_pmatch& m, const ssm_vo_params& P, const VoRot& R, double* J, double pred[4], double* res)
+__device__ __forceinline__ void vo_point(const ssm_pmatch& m, const ssm_vo_params& P, const VoPose& M, double* J, double pred[4], double* res)
 {
-    const double dd = fmax((double)(m.u1p - m.u2p), 1.0);
-    const double X1p = ((double)m.u1p - P.cu) * P.base / dd, Y1p = ((double)m.v1p - P.cv) * P.base / dd, Z1p = P.f * P.base / dd;
-    const double X1c = R.r00*X1p + R.r01*Y1p + R.r02*Z1p + R.tx;
-    const double Y1c = R.r10*X1p + R.r11*Y1p + R.r12*Z1p + R.ty;
-    const double Z1c = R.r20*X1p + R.r21*Y1p + R.r22*Z1p + R.tz;
+    // the match's 3-D point in the previous left camera, from its disparity (at least 1 px)
+    const double disp = fmax((double)(m.u1p - m.u2p), 1.0);
+    const double prev[3] = {((double)m.u1p - P.cu) * P.base / disp, ((double)m.v1p - P.cv) * P.base / disp, P.f * P.base / disp};
+    double cur[3];                                           // the same point in the current left camera
+#pragma unroll
+    for (int r = 0; r < 3; r++) cur[r] = M.rot[r][0] * prev[0] + M.rot[r][1] * prev[1] + M.rot[r][2] * prev[2] + M.t[r];
     const double obs[4] = { (double)m.u1c, (double)m.v1c, (double)m.u2c, (double)m.v2c };
     double weight = 1.0;
     if (P.reweighting) weight = 1.0 / (fabs(obs[0] - P.cu) / fabs(P.cu) + 0.05);
-    const double X2c = X1c - P.base;
+    const double xr = cur[0] - P.base;                       // x in the current right camera
     if (WITH_J) {
+        const double wf = weight * P.f, zz = cur[2] * cur[2];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double X1cd, Y1cd, Z1cd;
-            switch (j) {
-                case 0: X1cd = 0; Y1cd = R.rdrx10*X1p + R.rdrx11*Y1p + R.rdrx12*Z1p; Z1cd = R.rdrx20*X1p + R.rdrx21*Y1p + R.rdrx22*Z1p; break;
-                case 1: X1cd = R.rdry00*X1p + R.rdry01*Y1p + R.rdry02*Z1p; Y1cd = R.rdry10*X1p + R.rdry11*Y1p + R.rdry12*Z1p;
-                        Z1cd = R.rdry20*X1p + R.rdry21*Y1p + R.rdry22*Z1p; break;
-                case 2: X1cd = R.rdrz00*X1p + R.rdrz01*Y1p; Y1cd = R.rdrz10*X1p + R.rdrz11*Y1p; Z1cd = R.rdrz20*X1p + R.rdrz21*Y1p; break;
-                case 3: X1cd = 1; Y1cd = 0; Z1cd = 0; break;
-                case 4: X1cd = 0; Y1cd = 1; Z1cd = 0; break;
-                default: X1cd = 0; Y1cd = 0; Z1cd = 1; break;
-            }
-            J[0 * 6 + j] = weight * P.f * (X1cd*Z1c - X1c*Z1cd) / (Z1c*Z1c);
-            J[1 * 6 + j] = weight * P.f * (Y1cd*Z1c - Y1c*Z1cd) / (Z1c*Z1c);
-            J[2 * 6 + j] = weight * P.f * (X1cd*Z1c - X2c*Z1cd) / (Z1c*Z1c);
-            J[3 * 6 + j] = weight * P.f * (Y1cd*Z1c - Y1c*Z1cd) / (Z1c*Z1c);
+            double d[3];                                     // d cur / d parameter j
+            if (j < 3) {
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const int nt = VO_DTERMS[j][r];
+                    double v = 0.0;
+                    if (nt >= 2) v = M.drot[j][r][0] * prev[0] + M.drot[j][r][1] * prev[1];
+                    if (nt == 3) v = v + M.drot[j][r][2] * prev[2];
+                    d[r] = v;
+                }
+            } else { d[0] = j == 3 ? 1.0 : 0.0; d[1] = j == 4 ? 1.0 : 0.0; d[2] = j == 5 ? 1.0 : 0.0; }
+            // quotient rule on u = f x / z (+ cu), v = f y / z (+ cv); the two v rows are the same expression
+            J[0 * 6 + j] = wf * (d[0] * cur[2] - cur[0] * d[2]) / zz;
+            J[1 * 6 + j] = wf * (d[1] * cur[2] - cur[1] * d[2]) / zz;
+            J[2 * 6 + j] = wf * (d[0] * cur[2] - xr * d[2]) / zz;
+            J[3 * 6 + j] = J[1 * 6 + j];
         }
     }
-    pred[0] = P.f * X1c / Z1c + P.cu; pred[1] = P.f * Y1c / Z1c + P.cv;
-    pred[2] = P.f * X2c / Z1c + P.cu; pred[3] = P.f * Y1c / Z1c + P.cv;
+    pred[0] = P.f * cur[0] / cur[2] + P.cu; pred[1] = P.f * cur[1] / cur[2] + P.cv;
+    pred[2] = P.f * xr / cur[2] + P.cu; pred[3] = pred[1];
     if (WITH_J) {
 #pragma unroll
         for (int k = 0; k < 4; k++) res[k] = weight * (obs[k] - pred[k]);
     }
 }
-__device__ __forceinline__ bool vo_is_inlier(const ssm_pmatch& m, const ssm_vo_params& P, const VoRot& R)
+__device__ __forceinline__ bool vo_is_inlier(const ssm_pmatch& m, const ssm_vo_params& P, const VoPose& R)
 {
     double pred[4];
     vo_point<false>(m, P, R, nullptr, pred, nullptr);
@@ -139,7 +146,7 @@ __device__ __forceinline__ bool vo_solve6(double* A, double* b)
 }
 enum { VO_UPDATED = 0, VO_FAILED = 1, VO_CONVERGED = 2 };
 // adds the normal-equation terms of one match to acc (A row-major 36, then B 6), rows in order
-__device__ __forceinline__ void vo_accumulate(const ssm_pmatch& m, const ssm_vo_params& P, const VoRot& R, double* acc)
+__device__ __forceinline__ void vo_accumulate(const ssm_pmatch& m, const ssm_vo_params& P, const VoPose& R, double* acc)
 {
     double J[24], pred[4], res[4];
     vo_point<true>(m, P, R, J, pred, res);
@@ -171,7 +178,7 @@ vo_ransac_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
         double tr[6] = {0, 0, 0, 0, 0, 0};
         int result = VO_UPDATED, iter = 0;
         while (result == VO_UPDATED) {
-            VoRot R; vo_rot_make(tr, R);
+            VoPose R; vo_pose_make(tr, R);
             double acc[42];
             for (int q = 0; q < 42; q++) acc[q] = 0.0;
             for (int q = 0; q < 3; q++) vo_accumulate(m[samples[3 * k + q]], P, R, acc);
@@ -185,7 +192,7 @@ vo_ransac_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
     if (s_result == VO_FAILED) { if (lane == 0) count[k] = -1; return; }
     double tr[6];
     for (int q = 0; q < 6; q++) tr[q] = s_tr[q];
-    VoRot R; vo_rot_make(tr, R);
+    VoPose R; vo_pose_make(tr, R);
     int c = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -206,7 +213,7 @@ vo_refine_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
     if (bk >= 0) for (int q = 0; q < 6; q++) tr[q] = tr_all[6 * bk + q];
     int na = 0;
     if (bk >= 0) {
-        VoRot R; vo_rot_make(tr, R);
+        VoPose R; vo_pose_make(tr, R);
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
             const bool in = i < n && vo_is_inlier(m[i], P, R);
@@ -220,7 +227,7 @@ vo_refine_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
     if (na >= 6) {
         int res = VO_UPDATED, iter = 0;
         while (res == VO_UPDATED) {
-            VoRot R; vo_rot_make(tr, R);
+            VoPose R; vo_pose_make(tr, R);
             double acc[42];
             for (int q = 0; q < 42; q++) acc[q] = 0.0;
             for (int q = lane; q < na; q += 64) vo_accumulate(m[inliers[q]], P, R, acc);

@@ -242,13 +242,22 @@ static void prof_begin(ssm_ctx* c, const char* name)
 }
 static void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back().b, c->stream); }
 
-static int check_device_flags(ssm_ctx* c)
+// ORB scratch overflow (d_status) is checked after every ORB entry point; the voxel-table-full flag (counters[1]) belongs to the MAP entry points
+// (ssm_sync after ssm_seq_process, ssm_map_*): it is reported once and cleared, so that one overflowing call does not fail every later call on the
+// context (the map then lacks the dropped points: ssm_map_clear / a larger voxel_capacity_log2 is the remedy the message names)
+static int check_device_flags(ssm_ctx* c, bool with_map)
 {
     int32_t st = 0, cnt[2] = {0, 0};
     HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
     if (st) { hipMemset(c->d_status, 0, 4); FAIL(c, SSM_E_CAPACITY, "ORB scratch capacity exceeded (status " + std::to_string(st) + ")"); }
-    if (cnt[1]) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    if (with_map) {
+        HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
+        if (cnt[1]) {
+            hipMemset(c->map.counters + 1, 0, 4);
+            if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full (points were dropped): ssm_map_clear and raise voxel_capacity_log2");
+            FAIL(c, SSM_E_VOXEL_RANGE, "points with a non-finite coordinate or a voxel index outside (-2^20, 2^20) were skipped (leaf too small for the extent, or a bad pose)");
+        }
+    }
     return SSM_OK;
 }
 
@@ -367,6 +376,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->d_comm_counts) hipFree(c->d_comm_counts);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
+    for (hipStream_t st : {c->stream, c->stream2}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -382,7 +392,7 @@ extern "C" int ssm_sync(ssm_ctx* c)
     std::lock_guard<std::mutex> lk(c->mu);
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return check_device_flags(c);
+    return check_device_flags(c, true);
 }
 extern "C" int ssm_set_profiling(ssm_ctx* c, int on) { if (!c) return SSM_E_INVAL; std::lock_guard<std::mutex> lk(c->mu); c->profiling = on != 0; c->serialize = on == 2; return SSM_OK; }
 extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, int* launches, int cap, int* n_out)
@@ -462,7 +472,7 @@ extern "C" int ssm_orb_extract(ssm_ctx* c, const uint8_t* img, int w, int h, int
     int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    r = check_device_flags(c); if (r) return r;
+    r = check_device_flags(c, false); if (r) return r;
     *n_out = n;
     if (n > cap) FAIL(c, SSM_E_CAPACITY, "keypoint buffer too small (need " + std::to_string(n) + ")");
     HIPCHK(c, hipMemcpy(kps, dk, sizeof(ssm_keypoint) * n, hipMemcpyDeviceToHost));
@@ -562,7 +572,7 @@ static int table_count(ssm_ctx* c, VoxTable& t, int* n)
     int32_t cnt[2];
     HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (cnt[1]) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
     *n = cnt[0];
     return SSM_OK;
 }
@@ -616,7 +626,7 @@ extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
     HIPCHK(c, hipMemcpyAsync(c->d_scratch, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, k_voxel_insert(reinterpret_cast<ssm_point*>(c->d_scratch), nullptr, n, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
+    return check_device_flags(c, true);
 }
 extern "C" int ssm_map_size(ssm_ctx* c, int* n)
 {
@@ -737,7 +747,7 @@ extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
     HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_comm_counts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(&full, c->map.counters + 1, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (full) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    if (full & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
     int mx = 1; for (int v : counts) { if (v < 0) FAIL(c, SSM_E_COMM, "negative voxel count received"); if (v > mx) mx = v; }
     // (2) tables: slot r of the receive buffer = rank r's voxels, mx entries each
     const size_t slot = (size_t)mx * sizeof(ssm_voxel);
@@ -779,7 +789,18 @@ extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float l
                       dz = (int64_t)((ord2f(ord[5]) - ord2f(ord[2])) * inv) + 1;
         if (dx * dy * dz > (int64_t)2147483647) FAIL(c, SSM_E_VOXEL_RANGE, "leaf size too small for the cloud extent (PCL would return the input unfiltered)");
     }
-    HIPCHK(c, k_voxel_insert(dp, nullptr, n, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+    // pcl::VoxelGrid has no table to overflow: when the temporary table fills up, re-allocate it four times as large and insert again
+    for (;;) {
+        HIPCHK(c, k_voxel_insert(dp, nullptr, n, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+        int32_t cnt[2];
+        HIPCHK(c, hipMemcpyAsync(cnt, c->tmp.counters, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!(cnt[1] & 1)) break;
+        const int bigger = c->tmp.cap_log2 + 2;
+        if (bigger > 28) FAIL(c, SSM_E_CAPACITY, "voxel_filter: more than 2^28 voxels");
+        hipFree(c->tmp.tab); c->tmp.tab = nullptr;
+        r = table_alloc(c, c->tmp, bigger); if (r) return r;
+    }
     return table_export_points(c, c->tmp, out, cap, n_out);
 }
 

@@ -90,6 +90,8 @@ hipError_t k_synth(uint64_t seed, int first, int n, int w, int h, uint8_t* bgr, 
 hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int dh, const int32_t* xofs, const int16_t* xa,
                          const int32_t* yofs, const int16_t* ya, void* out_f16, hipStream_t s);
 hipError_t k_segnet_begin(hipStream_t s);
+void k_segnet_release_stream(hipStream_t s);     // per-stream helper state of the SegNet / SGBM launchers, freed by ssm_destroy
+void k_sgbm_release_stream(hipStream_t s);
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s);
 size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p);

@@ -167,6 +167,23 @@ int main(int argc, char** argv)
         // the map of one update == VoxelGrid over the clouds it added (first update: every 2nd key-frame)
         Mapper::PointCloud::Ptr c0 = mapper.generatePointCloud(pg.keyframes[0]);
         CHECK("generatePointCloud", c0->points.size() > 100000 && c0->points[0].data3 == 1.0f);
+        {   // frame->pointcloud is cached like the reference (src/mapper.cpp:17-20): a second call with another pose re-uses it, and the host-side
+            // pcl::transformPointCloud gives the bits the device gives when ssm_backproject is handed the pose
+            const int before = mapper.cloudsComputed;
+            RGBDFrame::Ptr kf = pg.keyframes[0];
+            Eigen::Isometry3d T2 = Eigen::Isometry3d::Identity();
+            T2(0, 0) = 0.8; T2(0, 1) = -0.6; T2(1, 0) = 0.6; T2(1, 1) = 0.8; T2(0, 3) = 0.123456789; T2(1, 3) = -3.25; T2(2, 3) = 1.0 / 3.0;
+            kf->setTransform(T2);
+            Mapper::PointCloud::Ptr c1 = mapper.generatePointCloud(kf);
+            ssm_config cfg = para.deviceConfig(kf->depth.cols, kf->depth.rows); ssm::Device dev(cfg);
+            ssm_camera cam; cam.cx = kf->camera.cx; cam.cy = kf->camera.cy; cam.fx = kf->camera.fx; cam.fy = kf->camera.fy; cam.scale = kf->camera.scale;
+            vector<ssm_point> ref((size_t)kf->depth.cols * kf->depth.rows); int n = 0;
+            dev.check(ssm_backproject(dev.ctx(), kf->depth.ptr<uint16_t>(), kf->rgb.data, kf->semantic.data, kf->depth.cols, kf->depth.rows, &cam, T2.data(),
+                                      para.getData<double>("mapper_max_distance", 40.0), ref.data(), (int)ref.size(), &n), "ssm_backproject");
+            bool same = (size_t)n == c1->points.size() && mapper.cloudsComputed == before && kf->pointcloud != nullptr;
+            for (int i = 0; same && i < n; i++) if (memcmp(&ref[i], &c1->points[i], 16) != 0 || ref[i].r != c1->points[i].r || ref[i].label != c1->points[i].label) same = false;
+            CHECK("generatePointCloud_cached_and_transformed_like_device", same);
+        }
         ifstream pcd(para.getData<string>("map_output"), ios::binary); string line; getline(pcd, line);
         CHECK("pcd_written", (bool)pcd && line.find(".PCD") != string::npos);
     }

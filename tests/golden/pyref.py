@@ -92,7 +92,10 @@ def voxel_filter(points, leaf):
     inv = f32(1.0) / f32(leaf)
     cells = {}
     for (x, y, z, b, g, r, lab) in points:
-        i = int(math.floor(float(f32(x) * inv))); j = int(math.floor(float(f32(y) * inv))); k = int(math.floor(float(f32(z) * inv)))
+        fi, fj, fk = (float(f32(x) * inv), float(f32(y) * inv), float(f32(z) * inv))
+        if not all(math.isfinite(q) and abs(math.floor(q)) < 1048576 for q in (fi, fj, fk)):
+            continue                                    # range contract: not keyable in 21 bits per axis -> skipped like a non-finite point in PCL
+        i = int(math.floor(fi)); j = int(math.floor(fj)); k = int(math.floor(fk))
         c = cells.setdefault((k, j, i), [0, 0, 0, 0, 0, 0, 0, [0] * 12])
         c[0] += cv_round(float(x) * 16777216.0); c[1] += cv_round(float(y) * 16777216.0); c[2] += cv_round(float(z) * 16777216.0)
         c[3] += r; c[4] += g; c[5] += b; c[6] += 1

@@ -176,6 +176,38 @@ def test_voxel_negative_coords_and_range_guard(ctx, oracle):
     assert len(ctx.voxel_filter(pts[:0], 0.1)) == 0
 
 
+def test_voxel_filter_grows_its_table_and_skips_unkeyable_points(oracle):
+    """pcl::VoxelGrid has no capacity: a context whose table is far too small must still filter (the temporary table is re-allocated); points that are
+    not finite or whose voxel index leaves (-2^20, 2^20) are skipped like PCL skips non-finite points -- same as the oracle -- and the MAP entry
+    points report them once with SSM_E_VOXEL_RANGE"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=8, camera=CAM)
+    try:
+        rng = np.random.default_rng(4)
+        pts = np.zeros(20000, ssm.POINT_DTYPE)
+        pts["x"] = rng.uniform(-4, 4, len(pts)); pts["y"] = rng.uniform(-3, 3, len(pts)); pts["z"] = rng.uniform(0, 5, len(pts))
+        pts["r"] = rng.integers(0, 256, len(pts)); pts["label"] = rng.integers(0, 12, len(pts)); pts["w"] = 1.0
+        ref = oracle.voxel_filter(pts, np.float32(0.1))
+        assert len(ref) > 4096                                       # 16x the 256-slot table
+        assert same_struct(c.voxel_filter(pts, 0.1), ref)
+        bad = pts[:2000].copy()
+        bad["x"][3] = np.nan; bad["y"][5] = np.inf; bad["z"][7] = -np.inf; bad["x"][11] = 2.0e5          # 2e5 / 0.1 = 2e6 > 2^20
+        good = np.delete(bad, [3, 5, 7, 11])
+        assert same_struct(oracle.voxel_filter(bad, np.float32(0.1)), oracle.voxel_filter(good, np.float32(0.1)))
+        big = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=16, camera=CAM)
+        try:
+            big.map_clear()
+            with pytest.raises(ssm.SsmError) as e:
+                big.map_insert(bad)
+            assert e.value.code == -6
+            assert same_struct(big.map_export(), oracle.voxel_filter(good, np.float32(big.cfg.mapper_resolution)))      # flag reported once, map intact
+            big.map_insert(good[:10]); big.sync()
+        finally:
+            big.close()
+    finally:
+        c.close()
+
+
 def test_map_insert_merge_is_order_independent(ctx, oracle, frames):
     clouds = [ctx.generate_point_cloud(frames[f][1], frames[f][0], frames[f][2], frames[f][4]) for f in range(3)]
     allp = np.concatenate(clouds)

@@ -238,3 +238,26 @@ def test_segnet_block_fixture_is_self_consistent():
     for layer in (0, 1, 3, 12, 25):
         y = g[f"conv{layer}_y"]
         assert y.dtype == np.float16 and np.isfinite(y).all() and (layer == 25 or (y >= 0).all())
+
+
+def test_brief_pattern_structure_and_checksum():
+    """The 256 x 4 BRIEF table (`bit_pattern_31_` of ORB / ORB-SLAM2) lives in the un-vendored Thirdparty/orbslam_modified and cannot be re-verified
+    against the reference here; what CAN be pinned: its published structural properties and a checksum, so that an accidental edit of either copy fails.
+    256 pairs, coordinates within [-13, 13], every point within radius 13*sqrt(2) = 18.38 of the centre (so a steered point, rounded, stays inside the
+    +-18 reach the BRIEF kernel stages and inside the 31 x 31 patch diagonal of HALF_PATCH_SIZE 15 + the EDGE_THRESHOLD 19 border), no repeated and no
+    degenerate pair, the published first / last rows, and the SHA-256 of the int8 table."""
+    import hashlib
+    import re
+    txt = open(os.path.join(HERE, "..", "oracle", "orb_pattern.inc")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    v = np.array([int(x) for x in re.findall(r"-?\d+", txt)])
+    assert v.size == 1024
+    v = v.reshape(256, 4)
+    assert v.min() == -13 and v.max() <= 13
+    rad = np.sqrt(v[:, 0::2].astype(float) ** 2 + v[:, 1::2].astype(float) ** 2)
+    assert rad.max() <= 13 * np.sqrt(2) + 1e-9 and np.ceil(rad.max()) <= 19 - 0           # rounded steered coordinates stay <= 18 < EDGE_THRESHOLD
+    assert len({tuple(r) for r in v.tolist()}) == 256                                        # no repeated test
+    assert not ((v[:, 0] == v[:, 2]) & (v[:, 1] == v[:, 3])).any()                           # no point compared with itself
+    assert v[:4].tolist() == [[8, -3, 9, 5], [4, 2, 7, -12], [-11, 9, -8, 2], [7, -12, 12, -13]]
+    assert v[-2:].tolist() == [[7, 0, 12, -2], [-1, -6, 0, -11]]
+    assert hashlib.sha256(v.astype(np.int8).tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
