@@ -1,12 +1,15 @@
-// ssm/pnp.h -- rgbd_tutor::PnPSolver (reference include/pnp.h, src/pnp.cpp:5-118): pose-only bundle adjustment of the
-// reprojection error.  The reference drives g2o (EdgeSE3ProjectXYZOnlyPose, Levenberg, Huber delta sqrt(5.991), four
-// rounds of ten iterations, chi2 > 5.991 -> outlier, robust kernel dropped after round 3).  g2o is absent: this is a
-// from-scratch dense 6-DoF Levenberg-Marquardt with the same schedule.  It is a host-side CONSUMER of the match
-// tables, not part of the GPU path, and is not bit-identical to g2o.  The inlier bookkeeping
-// quirks of pnp.cpp:74-89,115 (mixed indices; success test on the vector length) are NOT reproduced.
+// ssm/pnp.h -- rgbd_tutor::PnPSolver (reference include/pnp.h, src/pnp.cpp): pose-only bundle adjustment of the reprojection error, the host-side
+// CONSUMER of the match tables.  The reference drives g2o (un-vendored, absent here); this header implements the algorithm
+// g2o runs for pnp.cpp's set-up -- EdgeSE3ProjectXYZOnlyPose (analytic Jacobian, update T <- exp(d) T), RobustKernelHuber with delta (float)sqrt(5.991),
+// OptimizationAlgorithmLevenberg (lambda0 = 1e-5 max diag H, gain ratio with the +1e-3 guard, lambda scaled by clamp(1 - (2 gain - 1)^3, 1/3, 2/3) or
+// multiplied by nu = 2, 4, ..., at most 10 trials per iteration), four rounds of optimize(10), chi2 > 5.991 -> outlier, kernels dropped in round 3 --
+// and keeps pnp.cpp's inlier bookkeeping AS WRITTEN (stale chi2 of edges already out, `inliers[i]` indexed by edge
+// position, success decided by the flag vector's length).  oracle/pnp.c is the C restatement it is tested against (tests/test_pnp.py); what is and is
+// not pinned is said there.  The rotation is kept as a matrix (g2o keeps a re-normalised quaternion): rounding-level difference from g2o itself.
 #pragma once
 #include "common_headers.h"
 #include "orb.h"
+#include <limits>
 namespace rgbd_tutor {
 struct PNP_INFORMATION { int numFeatureMatches = 0, numInliers = 0; Eigen::Isometry3d T = Eigen::Isometry3d::Identity(); };
 class PnPSolver {
@@ -14,48 +17,88 @@ public:
     PnPSolver(const ParameterReader& para, const OrbFeature& orbFeature) : parameterReader(para), orb(orbFeature) {
         min_inliers = para.getData<int>("pnp_min_inliers", 10); min_match = para.getData<int>("pnp_min_matches", 15);
     }
-    // img: pixels in the current frame; obj: the same points in world coordinates; transform: world -> camera (initial value in, estimate out)
+    // img: pixels in frame 2; obj: the same points in frame 1 (camera frame); transform: initial value in, estimate out (src/pnp.cpp:5-118)
     bool solvePnP(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj, const CAMERA_INTRINSIC_PARAMETERS& camera,
                   vector<int>& inliersIndex, Eigen::Isometry3d& transform) {
-        const size_t n = img.size();
-        vector<char> inlier(n, 1);
+        const double delta = (double)(float)sqrt(5.991);
+        struct Edge { int id, level; bool robust; double X[3], u, v, e0, e1; double chi2() const { return e0 * e0 + e1 * e1; } };
+        vector<Edge> edges;
+        vector<bool> inliers(img.size(), true);
         int good = 0;
-        for (size_t i = 0; i < n; i++) { if (obj[i] == cv::Point3f(0, 0, 0)) inlier[i] = 0; else good++; }
-        const double chi2_th = 5.991, delta = sqrt(5.991);
-        double R[9], t[3];
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = transform(r, c); t[r] = transform(r, 3); }
-        const Eigen::Isometry3d init = transform;
-        for (int round = 0; round < 4; round++) {
-            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = init(r, c); t[r] = init(r, 3); }      // every round restarts from the initial value (pnp.cpp:66)
-            double lambda = 1e-4;
-            for (int it = 0; it < 10; it++) {
-                double H[36] = {0}, b[6] = {0}, cost = 0;
-                accumulate(img, obj, camera, inlier, R, t, round < 3 ? delta : 0.0, H, b, &cost);
-                bool stepped = false;
-                for (int tries = 0; tries < 6 && !stepped; tries++) {
-                    double A[36], x[6];
-                    for (int i = 0; i < 36; i++) A[i] = H[i];
-                    for (int i = 0; i < 6; i++) A[i * 6 + i] += lambda * (H[i * 6 + i] + 1e-9);
-                    if (!solve6(A, b, x)) { lambda *= 10; continue; }
-                    double R2[9], t2[3]; applyUpdate(R, t, x, R2, t2);
-                    double H2[36] = {0}, b2[6] = {0}, cost2 = 0;
-                    accumulate(img, obj, camera, inlier, R2, t2, round < 3 ? delta : 0.0, H2, b2, &cost2);
-                    if (cost2 <= cost) { memcpy(R, R2, sizeof(R)); memcpy(t, t2, sizeof(t)); lambda = max(lambda * 0.1, 1e-12); stepped = true; }
-                    else lambda *= 10;
+        for (size_t i = 0; i < obj.size(); i++) {
+            if (obj[i] == cv::Point3f(0, 0, 0)) { inliers[i] = false; continue; }
+            good++;
+            Edge e; e.id = (int)i; e.level = 0; e.robust = true; e.X[0] = obj[i].x; e.X[1] = obj[i].y; e.X[2] = obj[i].z; e.u = img[i].x; e.v = img[i].y; e.e0 = e.e1 = 0;
+            edges.push_back(e);
+        }
+        Pose init; for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) init.R[3 * r + c] = transform(r, c); init.t[r] = transform(r, 3); }
+        Pose est = init;
+        auto project_error = [&](Edge& e, const Pose& P) { double p[3]; P.map(e.X, p); e.e0 = e.u - (p[0] / p[2] * camera.fx + camera.cx); e.e1 = e.v - (p[1] / p[2] * camera.fy + camera.cy); };
+        auto huber = [&](double e2, double& rho0, double& rho1) { const double d2 = delta * delta; if (e2 <= d2) { rho0 = e2; rho1 = 1.0; } else { const double s = sqrt(e2); rho0 = 2 * s * delta - d2; rho1 = delta / s; } };
+        auto active_chi2 = [&](const Pose& P) { double chi = 0; for (Edge& e : edges) { if (e.level != 0) continue; project_error(e, P); const double e2 = e.chi2();
+                                                 if (e.robust) { double r0, r1; huber(e2, r0, r1); chi += r0; } else chi += e2; } return chi; };
+        auto build = [&](const Pose& P, double* H, double* b) {
+            for (int k = 0; k < 36; k++) H[k] = 0;
+            for (int k = 0; k < 6; k++) b[k] = 0;
+            for (const Edge& e : edges) {
+                if (e.level != 0) continue;
+                double p[3]; P.map(e.X, p);
+                const double x = p[0], y = p[1], iz = 1.0 / p[2], iz2 = iz * iz;
+                const double J[2][6] = {{x * y * iz2 * camera.fx, -(1 + (x * x * iz2)) * camera.fx, y * iz * camera.fx, -iz * camera.fx, 0, x * iz2 * camera.fx},
+                                        {(1 + y * y * iz2) * camera.fy, -x * y * iz2 * camera.fy, -x * iz * camera.fy, 0, -iz * camera.fy, y * iz2 * camera.fy}};
+                double w = 1.0;
+                if (e.robust) { double r0; huber(e.chi2(), r0, w); }
+                const double er[2] = {e.e0, e.e1};
+                for (int r = 0; r < 2; r++) {
+                    const double wr = -er[r] * w;
+                    for (int a = 0; a < 6; a++) { b[a] += J[r][a] * wr; for (int c = 0; c < 6; c++) H[6 * a + c] += J[r][a] * w * J[r][c]; }
                 }
-                if (!stepped) break;
             }
-            good = 0;
-            for (size_t i = 0; i < n; i++) {
-                if (obj[i] == cv::Point3f(0, 0, 0)) { inlier[i] = 0; continue; }
-                double e[2]; if (!residual(img[i], obj[i], camera, R, t, e)) { inlier[i] = 0; continue; }
-                inlier[i] = (e[0] * e[0] + e[1] * e[1] <= chi2_th); good += inlier[i];
+        };
+        auto optimize = [&](Pose& P, int iterations) {                      // SparseOptimizer::optimize with OptimizationAlgorithmLevenberg
+            bool any = false; for (const Edge& e : edges) any = any || e.level == 0;
+            if (!any) return;
+            double lambda = 0, nu = 2;
+            for (int it = 0; it < iterations; it++) {
+                double chi = active_chi2(P), chi_new = chi, H[36], b[6];
+                build(P, H, b);
+                if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) mx = max(mx, fabs(H[7 * j])); lambda = 1e-5 * mx; nu = 2; }
+                double gain = 0; int trials = 0;
+                do {
+                    const Pose saved = P;
+                    double x[6] = {0, 0, 0, 0, 0, 0};
+                    const bool ok = solveLDLT(H, lambda, b, x);
+                    P.oplus(x);
+                    chi_new = active_chi2(P);
+                    if (!ok) chi_new = numeric_limits<double>::max();
+                    gain = chi - chi_new;
+                    double scale = 0; for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                    scale += 1e-3; gain /= scale;
+                    if (gain > 0 && std::isfinite(chi_new)) {
+                        double alpha = 1. - pow((2 * gain - 1), 3); alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                        lambda *= alpha > 1. / 3. ? alpha : 1. / 3.; nu = 2; chi = chi_new;
+                    } else { lambda *= nu; nu *= 2; P = saved; if (!std::isfinite(lambda)) break; }
+                    trials++;
+                } while (gain < 0 && trials < 10);
+                if (trials == 10 || gain == 0) break;
+            }
+            active_chi2(P);
+        };
+        for (size_t it = 0; it < 4; it++) {
+            est = init;                                                         // pnp.cpp:66: every round starts from the caller's transform
+            optimize(est, 10);
+            for (size_t i = 0; i < edges.size(); i++) {
+                Edge& e = edges[i];
+                if (inliers[e.id] == true) project_error(e, est);
+                if (e.chi2() > 5.991) { inliers[e.id] = false; e.level = 1; good--; }
+                else { inliers[i] = true; e.level = 0; }                        // [i], not [e.id]: as written at pnp.cpp:87
+                if (it == 2) e.robust = false;
             }
             if (good < 5) break;
         }
-        for (size_t i = 0; i < n; i++) if (inlier[i]) inliersIndex.push_back((int)i);
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) transform(r, c) = R[r * 3 + c]; transform(r, 3) = t[r]; }
-        return (int)inliersIndex.size() > min_inliers;
+        for (size_t i = 0; i < inliers.size(); i++) if (inliers[i]) inliersIndex.push_back((int)i);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) transform(r, c) = est.R[3 * r + c]; transform(r, 3) = est.t[r]; }
+        return (int)inliers.size() > min_inliers;                               // the vector's LENGTH, pnp.cpp:115
     }
     // match(frame1, frame2) + gather 3-D (frame1) / 2-D (frame2) + solve (reference src/pnp.cpp:120-226)
     bool solvePnPLazy(const RGBDFrame::Ptr& frame1, const RGBDFrame::Ptr frame2, PNP_INFORMATION& info, bool drawMatches = false) {
@@ -69,68 +112,46 @@ public:
             obj.push_back(p); img.push_back(frame2->features[m.trainIdx].keypoint.pt);
         }
         if ((int)img.size() <= min_match) return false;
-        vector<int> inl; Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+        vector<int> inl; Eigen::Isometry3d T = frame1->T_f_w.inverse() * frame2->T_f_w;      // init_transform, pnp.cpp:164
         bool ok = solvePnP(img, obj, frame1->camera, inl, T);
         info.numFeatureMatches = (int)img.size(); info.numInliers = (int)inl.size(); info.T = T;
-        return ok && (int)inl.size() >= min_inliers;
+        (void)ok;
+        return info.numInliers >= min_inliers;                                  // pnp.cpp:221-225 ignores solvePnP's own return value
     }
 protected:
-    static bool residual(const cv::Point2f& u, const cv::Point3f& X, const CAMERA_INTRINSIC_PARAMETERS& k, const double* R, const double* t, double e[2], double pc[3] = nullptr) {
-        double p[3];
-        for (int r = 0; r < 3; r++) p[r] = R[r * 3] * X.x + R[r * 3 + 1] * X.y + R[r * 3 + 2] * X.z + t[r];
-        if (pc) { pc[0] = p[0]; pc[1] = p[1]; pc[2] = p[2]; }
-        if (p[2] <= 1e-9) return false;
-        e[0] = u.x - (k.fx * p[0] / p[2] + k.cx); e[1] = u.y - (k.fy * p[1] / p[2] + k.cy);
-        return true;
-    }
-    static void accumulate(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj, const CAMERA_INTRINSIC_PARAMETERS& k, const vector<char>& inlier,
-                           const double* R, const double* t, double huber, double* H, double* b, double* cost) {
-        for (size_t i = 0; i < img.size(); i++) {
-            if (!inlier[i]) continue;
-            double e[2], p[3];
-            if (!residual(img[i], obj[i], k, R, t, e, p)) continue;
-            const double iz = 1.0 / p[2], iz2 = iz * iz;
-            // d(proj)/d(xi), xi = (rho, phi) left-multiplied: p' = p + rho + phi x p ;  e = u - proj  =>  J = -dproj
-            double J[2][6];
-            const double a[2][3] = {{k.fx * iz, 0, -k.fx * p[0] * iz2}, {0, k.fy * iz, -k.fy * p[1] * iz2}};
-            for (int r = 0; r < 2; r++) {
-                J[r][0] = -a[r][0]; J[r][1] = -a[r][1]; J[r][2] = -a[r][2];
-                J[r][3] = -(a[r][2] * p[1] - a[r][1] * p[2]);       // d/dphi_x :  (phi x p) = (phi_y p_z - phi_z p_y, phi_z p_x - phi_x p_z, phi_x p_y - phi_y p_x)
-                J[r][4] = -(a[r][0] * p[2] - a[r][2] * p[0]);
-                J[r][5] = -(a[r][1] * p[0] - a[r][0] * p[1]);
+    struct Pose {                                                               // x_cam = R X + t, R row-major
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+        void map(const double* X, double* p) const { for (int r = 0; r < 3; r++) p[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r]; }
+        static void mul(const double* A, const double* B, double* C) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c]; }
+        void oplus(const double* d) {                                           // T <- exp(d) T, d = (omega, upsilon): g2o::SE3Quat::exp
+            const double th = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const double W[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+            double W2[9], dR[9], V[9]; mul(W, W, W2);
+            if (th < 0.00001) { for (int k = 0; k < 9; k++) { dR[k] = (k % 4 == 0 ? 1.0 : 0.0) + W[k] + W2[k]; V[k] = dR[k]; } }
+            else {
+                const double a = sin(th) / th, b = (1 - cos(th)) / (th * th), c = (th - sin(th)) / (th * th * th);
+                for (int k = 0; k < 9; k++) { dR[k] = (k % 4 == 0 ? 1.0 : 0.0) + a * W[k] + b * W2[k]; V[k] = (k % 4 == 0 ? 1.0 : 0.0) + b * W[k] + c * W2[k]; }
             }
-            const double e2 = e[0] * e[0] + e[1] * e[1], en = sqrt(e2);
-            double w = 1.0, rho = e2;
-            if (huber > 0 && en > huber) { w = huber / en; rho = 2 * huber * en - huber * huber; }
-            *cost += rho;
-            for (int r = 0; r < 2; r++) for (int c = 0; c < 6; c++) { b[c] -= w * J[r][c] * e[r]; for (int d = 0; d < 6; d++) H[c * 6 + d] += w * J[r][c] * J[r][d]; }
+            double nR[9], nt[3]; mul(dR, R, nR);
+            for (int r = 0; r < 3; r++) { const double vt = V[3 * r] * d[3] + V[3 * r + 1] * d[4] + V[3 * r + 2] * d[5]; nt[r] = dR[3 * r] * t[0] + dR[3 * r + 1] * t[1] + dR[3 * r + 2] * t[2] + vt; }
+            for (int k = 0; k < 9; k++) R[k] = nR[k];
+            for (int k = 0; k < 3; k++) t[k] = nt[k];
         }
-    }
-    static bool solve6(double* A, const double* b, double* x) {                     // Cholesky, 6x6 SPD
-        double L[36] = {0};
-        for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) {
-            double s = A[i * 6 + j];
-            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-            if (i == j) { if (s <= 1e-18) return false; L[i * 6 + i] = sqrt(s); } else L[i * 6 + j] = s / L[j * 6 + j];
+    };
+    static bool solveLDLT(const double* Hin, double lambda, const double* b, double* x) {     // (H + lambda I) x = b, un-pivoted L D L^T
+        double A[36], L[36] = {0}, D[6], y[6];
+        for (int k = 0; k < 36; k++) A[k] = Hin[k];
+        for (int i = 0; i < 6; i++) A[7 * i] += lambda;
+        for (int j = 0; j < 6; j++) {
+            double d = A[6 * j + j]; for (int k = 0; k < j; k++) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+            if (!(d > 0)) return false;
+            D[j] = d; L[6 * j + j] = 1.0;
+            for (int i = j + 1; i < 6; i++) { double s = A[6 * i + j]; for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k] * D[k]; L[6 * i + j] = s / d; }
         }
-        double y[6];
-        for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
-        for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+        for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k]; y[i] = s; }
+        for (int i = 0; i < 6; i++) y[i] /= D[i];
+        for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k]; x[i] = s; }
         return true;
-    }
-    static void applyUpdate(const double* R, const double* t, const double* x, double* R2, double* t2) {   // T <- exp(xi) * T (first order in rho, Rodrigues in phi)
-        const double th = sqrt(x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-        double dR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (th > 1e-12) {
-            const double kx = x[3] / th, ky = x[4] / th, kz = x[5] / th, c = cos(th), s = sin(th), v = 1 - c;
-            const double M[9] = {c + kx * kx * v, kx * ky * v - kz * s, kx * kz * v + ky * s, ky * kx * v + kz * s, c + ky * ky * v, ky * kz * v - kx * s,
-                                 kz * kx * v - ky * s, kz * ky * v + kx * s, c + kz * kz * v};
-            memcpy(dR, M, sizeof(M));
-        }
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) R2[r * 3 + c] = dR[r * 3] * R[c] + dR[r * 3 + 1] * R[3 + c] + dR[r * 3 + 2] * R[6 + c];
-            t2[r] = dR[r * 3] * t[0] + dR[r * 3 + 1] * t[1] + dR[r * 3 + 2] * t[2] + x[r];
-        }
     }
     const ParameterReader& parameterReader;
     const OrbFeature& orb;

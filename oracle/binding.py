@@ -337,6 +337,16 @@ class Oracle:
         tr = np.ascontiguousarray(tr, np.float64); T = np.zeros((4, 4), np.float64)
         self.L.sso_vo_tr_to_matrix(tr.ctypes.data, T.ctypes.data); return T
 
+    def pnp_solve(self, img, obj, cam, T_init, min_inliers=10):
+        """PnPSolver::solvePnP (oracle/pnp.c): img n x 2 float32, obj n x 3 float32, T_init 4 x 4 (row-major numpy) -> (success, T 4 x 4, inlier indices)"""
+        img = np.ascontiguousarray(img, np.float32).reshape(-1, 2); obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+        T = np.ascontiguousarray(np.asarray(T_init, np.float64).reshape(4, 4).T)       # column-major for the C side
+        inl = np.zeros(max(len(img), 1), np.int32); n = C.c_int(0); c = Cam(*cam)
+        self.L.sso_pnp_solve.restype = C.c_int
+        ok = self.L.sso_pnp_solve(C.c_void_p(img.ctypes.data), C.c_void_p(obj.ctypes.data), len(img), C.byref(c), int(min_inliers), C.c_void_p(T.ctypes.data),
+                                  C.c_void_p(inl.ctypes.data), C.byref(n))
+        return bool(ok), T.T.copy(), inl[:n.value].copy()
+
     def pipeline(self, first, count, w=640, h=480, nfeatures=1000, nlevels=8, ini=20, mn=7, ref_frames=5, scale=1.2,
                  leaf=0.1, ratio=0.8, max_distance=40.0, cam=(318.6, 255.3, 517.3, 516.5, 1000.0), seed=0x5EED0000):
         cfg = PipeCfg(w, h, nfeatures, nlevels, ini, mn, ref_frames, scale, leaf, ratio, max_distance, Cam(*cam), seed)

@@ -164,6 +164,8 @@ typedef struct {
 } sso_pipeline_stats;
 /* runs frames [first, first+count): synth -> orb -> match vs <=ref_frames previous -> mask -> backproject -> voxel */
 int sso_pipeline_run(const sso_pipeline_cfg* cfg, int first, int count, sso_pipeline_stats* st);
+/* PnPSolver::solvePnP (/root/reference/src/pnp.cpp:5-118) with g2o's Levenberg restated: see pnp.c */
+int sso_pnp_solve(const float* img, const float* obj, int n, const sso_camera* cam, int min_inliers, double T[16], int* inliers_out, int* n_inliers);
 
 #ifdef __cplusplus
 }

@@ -3,18 +3,55 @@
 // finally shut the graph and the mapper down.  Differences: no cv::imshow; the frame source is selected by `dataset`
 // (synthetic | raw | tum | kitti; the reference hard-codes its FrameReader type); with tum / kitti the poses come from the
 // tracker (use_stream_pose defaults to 0 there); prints frames/s at the end.
+//
+// `exp_mapping <parameters> --ranks N`: the multi-GPU form (BASELINE.json configs[4]; the reference is one process).  The parent forks
+// N ranks BEFORE anything touches HIP; rank r drives GPU r, owns the contiguous frame block [lo, hi) of [start_index, end_index), feeds the
+// tracker_ref_frames frames in front of its block to the tracker only (the matcher halo: Tracker::trackRefFrame matches against the refFrames deque,
+// src/track.cpp:150-152), maps its key-frames as usual, then inserts their clouds into one context map and calls ssm_voxel_allgather (ONE RCCL
+// all-gather behind the C ABI).  Every rank ends with the map of the whole sequence; rank 0 prints it.  The ncclUniqueId travels through a page of
+// shared memory the parent mapped before forking.
 #include "ssm/rgbdframe.h"
 #include "ssm/track.h"
 #include "ssm/pose_graph.h"
 #include "ssm/common_headers.h"
 #include "ssm/mapper.h"
 #include "ssm/vo_stereo.hpp"
+#include <atomic>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 using namespace std;
 using namespace rgbd_tutor;
+
+struct RankShared { std::atomic<int> id_ready; unsigned char id[SSM_COMM_ID_BYTES]; std::atomic<int> failed; };
+static int run_rank(ParameterReader& parameterReader, int rank, int nranks, RankShared* sh);
 
 int main(int argc, char** argv)
 {
     ParameterReader parameterReader(argc > 1 ? argv[1] : "./parameters.txt");
+    int nranks = 1;
+    for (int i = 2; i + 1 < argc; i++) if (string(argv[i]) == "--ranks") nranks = atoi(argv[i + 1]);
+    if (nranks > 1 || parameterReader.getData<int>("force_rank_path", 0)) {
+        // no HIP call has happened in this process yet: fork is safe; the children never exec
+        RankShared* sh = (RankShared*)mmap(nullptr, sizeof(RankShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (sh == MAP_FAILED) { perror("mmap"); return 2; }
+        new (sh) RankShared(); sh->id_ready = 0; sh->failed = 0;
+        vector<pid_t> kids;
+        for (int r = 0; r < nranks; r++) {
+            pid_t p = fork();
+            if (p < 0) { perror("fork"); return 2; }
+            if (p == 0) {
+                int rc = 2;
+                try { rc = run_rank(parameterReader, r, nranks, sh); } catch (const exception& e) { cerr << RED << "rank " << r << ": " << e.what() << RESET << endl; }
+                if (rc) sh->failed = 1;
+                _exit(rc);
+            }
+            kids.push_back(p);
+        }
+        int rc = 0;
+        for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1; }
+        return rc;
+    }
     VisualOdometryStereo::parameters voparam;
     double f = parameterReader.getData<double>("camera.fx");
     double c_u = parameterReader.getData<double>("camera.cx");
@@ -50,5 +87,67 @@ int main(int argc, char** argv)
         cout << "frames " << nframes << " keyframes " << poseGraph.keyframes.size() << " map_updates " << mapper.updates()
              << " map_points " << (mapper.getGlobalMap() ? mapper.getGlobalMap()->points.size() : 0) << " host_loop_fps " << nframes / s << endl;
     } catch (const exception& e) { cerr << RED << "exp_mapping: " << e.what() << RESET << endl; return 2; }
+    return 0;
+}
+
+// one rank of `--ranks N` (its own process, its own GPU)
+static int run_rank(ParameterReader& parameterReader, int rank, int nranks, RankShared* sh)
+{
+    ssm::default_device() = rank;
+    VisualOdometryStereo::parameters voparam;
+    voparam.calib.f = parameterReader.getData<double>("camera.fx"); voparam.calib.cu = parameterReader.getData<double>("camera.cx");
+    voparam.calib.cv = parameterReader.getData<double>("camera.cy"); voparam.base = parameterReader.getData<double>("camera.baseline", 0.0);
+    voparam.inlier_threshold = parameterReader.getData<double>("inlier_threshold", 6.0);
+    const int first = parameterReader.getData<int>("start_index", 0), last = parameterReader.getData<int>("end_index", 100), total = last - first;
+    const int R = parameterReader.getData<int>("tracker_ref_frames", 5);
+    const int base = total / nranks, rem = total % nranks;                       // contiguous blocks, earlier ranks take the remainder (sharding.frame_block)
+    const int lo = first + rank * base + min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
+    const int halo_lo = max(first, lo - R);
+    Tracker::Ptr tracker(new Tracker(parameterReader, voparam));
+    FrameReader frameReader(parameterReader, FrameReader::SYNTHETIC);
+    PoseGraph poseGraph(parameterReader, tracker);
+    Mapper mapper(parameterReader, poseGraph);
+    auto t0 = chrono::steady_clock::now();
+    int nframes = 0;
+    for (int i = halo_lo; i < hi; i++) {
+        RGBDFrame::Ptr frame = frameReader.get(i);
+        if (!frame) break;
+        Eigen::Isometry3d gt = frame->T_f_w;
+        tracker->updateFrame(frame);
+        frame->setTransform(gt);
+        if (i < lo) continue;                                                   // halo frame: the previous rank maps it
+        poseGraph.tryInsertKeyFrame(frame);
+        nframes++;
+    }
+    const double loop_s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+    poseGraph.shutdown();
+    this_thread::sleep_for(chrono::milliseconds(parameterReader.getData<int>("mapper_drain_ms", 300)));
+    mapper.shutdown();
+    // ---- the merge: this rank's key-frame clouds into one context map, then ONE all-gather of the voxel tables
+    ssm_config cfg = parameterReader.deviceConfig(frameReader.width, frameReader.height);
+    ssm::Device dev(cfg);
+    if (rank == 0) { dev.check(ssm_comm_get_unique_id(sh->id), "ssm_comm_get_unique_id"); sh->id_ready.store(1, std::memory_order_release); }
+    else while (!sh->id_ready.load(std::memory_order_acquire)) { if (sh->failed) return 3; this_thread::sleep_for(chrono::milliseconds(1)); }
+    dev.check(ssm_comm_init_rank(dev.ctx(), nranks, rank, sh->id), "ssm_comm_init_rank");
+    size_t local_points = 0;
+    for (RGBDFrame::Ptr& kf : poseGraph.keyframes) {
+        Mapper::PointCloud::Ptr c = mapper.generatePointCloud(kf);
+        local_points += c->points.size();
+        dev.check(ssm_map_insert(dev.ctx(), reinterpret_cast<const ssm_point*>(c->points.data()), (int)c->points.size()), "ssm_map_insert");
+    }
+    dev.check(ssm_voxel_allgather(dev.ctx(), nullptr), "ssm_voxel_allgather");
+    int nvox = 0; dev.check(ssm_map_size(dev.ctx(), &nvox), "ssm_map_size");
+    vector<ssm_point> merged((size_t)max(nvox, 1));
+    dev.check(ssm_map_export(dev.ctx(), merged.data(), (int)merged.size(), &nvox), "ssm_map_export");
+    uint64_t h = 0xCBF29CE484222325ull;                                          // FNV-1a of the merged map: identical on every rank and for every N
+    for (int i = 0; i < nvox; i++) { const unsigned char* b = (const unsigned char*)&merged[i]; for (int k = 0; k < 24; k++) { h ^= b[k]; h *= 0x100000001B3ull; } }
+    dev.check(ssm_comm_finalize(dev.ctx()), "ssm_comm_finalize");
+    cout << "rank " << rank << "/" << nranks << " frames [" << lo << "," << hi << ") halo " << lo - halo_lo << " keyframes " << poseGraph.keyframes.size() << " local_points " << local_points
+         << " merged_voxels " << nvox << " map_fnv " << hex << h << dec << " host_loop_fps " << nframes / loop_s << endl;
+    const string out = parameterReader.getData<string>("map_output", string(""));
+    if (rank == 0 && !out.empty()) {
+        Mapper::PointCloud pc; pc.points.resize(nvox); memcpy((void*)pc.points.data(), merged.data(), (size_t)nvox * sizeof(ssm_point)); pc.width = nvox;
+        Mapper::writePCD(out, pc);
+    }
     return 0;
 }

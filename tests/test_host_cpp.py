@@ -126,3 +126,39 @@ def test_exp_mapping_driver_on_gpu():
     last = [l for l in r.stdout.splitlines() if l.startswith("frames ")][-1].split()
     stats = dict(zip(last[0::2], last[1::2]))
     assert int(stats["frames"]) == 8 and int(stats["keyframes"]) == 8 and int(stats["map_updates"]) >= 1 and int(stats["map_points"]) > 500
+
+
+@pytest.mark.gpu
+def test_exp_mapping_rank_path_on_gpu(tmp_path):
+    """`exp_mapping --ranks N` (C++ host, RCCL behind the C ABI): on this 1-GPU box the rank path runs with one rank (force_rank_path): fork before HIP,
+    halo + block loop, key-frame clouds into a context map, ssm_voxel_allgather through a 1-rank communicator.  The FNV of the merged map must equal
+    the one of the same eight frames fused through the python mirror of the C ABI."""
+    import numpy as np
+    import semantic_slam_mapping_amd as ssm
+    from conftest import CAM, SEED
+    prm = tmp_path / "p.txt"
+    prm.write_text(open(os.path.join(HOST, "parameters_test.txt")).read() + "\nforce_rank_path=1\nmap_output=\n")
+    r = subprocess.run([os.path.join(HOST, "exp_mapping"), str(prm), "--ranks", "1"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    line = [l for l in r.stdout.splitlines() if l.startswith("rank 0/1 ")][-1].split()
+    st = dict(zip(line[2::2], line[3::2]))
+    assert st["frames"] == "[0,8)" and st["halo"] == "0" and int(st["keyframes"]) == 8
+    c = ssm.Context(0, orb_features=1000, max_batch=1, voxel_capacity_log2=18, camera=CAM)
+    try:
+        W, H = 640, 480
+        bufs = [c.dev_alloc(W * H * 3), c.dev_alloc(W * H * 2), c.dev_alloc(W * H * 3), c.dev_alloc(128)]
+        c.map_clear(); total = 0
+        for f in range(8):
+            c.synth_frames_dev(SEED, f, 1, *bufs)
+            bgr = c.d2h(bufs[0], (H, W, 3), np.uint8); dep = c.d2h(bufs[1], (H, W), np.uint16); sem = c.d2h(bufs[2], (H, W, 3), np.uint8)
+            T = c.d2h(bufs[3], 16, np.float64).reshape(4, 4).T
+            pts = c.generate_point_cloud(dep, bgr, sem, T); total += len(pts)
+            c.map_insert(pts)
+        m = c.map_export()
+        h = 0xCBF29CE484222325
+        for b in m.view(np.uint8).reshape(len(m), 32)[:, :24].reshape(-1).tolist():
+            h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        assert int(st["local_points"]) == total and int(st["merged_voxels"]) == len(m) and int(st["map_fnv"], 16) == h
+    finally:
+        c.close()

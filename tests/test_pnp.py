@@ -1,0 +1,79 @@
+"""PnP consumer of the match table: rgbd_tutor::PnPSolver::solvePnP of include/ssm/pnp.h against oracle/pnp.c, the C restatement of
+/root/reference/src/pnp.cpp:5-118 with g2o's Levenberg / Huber / SE3-exp algorithms restated (g2o is absent: PARITY UNPINNED, see oracle/pnp.c).  Both sides
+run the same operations in the same order, so the comparison is exact: identical inlier lists and return values, pose equal to 1e-12.  Also pins what the
+algorithm must do on data with a known answer, and the reference's bookkeeping quirks (Appendix A quirk 14).  CPU only."""
+import os
+import struct
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "semantic_slam_mapping_amd", "host")
+CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
+
+
+def _pose(rx, ry, rz, t):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return T
+
+
+def _case(seed, n, outlier_every=10, zero_every=0, noise=0.0):
+    rng = np.random.default_rng(seed)
+    Tgt = _pose(0.03, -0.05, 0.02, (0.04, -0.03, 0.06))
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(1.0, 4.0, n)], 1).astype(np.float32)
+    p = (Tgt[:3, :3] @ X.astype(np.float64).T).T + Tgt[:3, 3]
+    uv = np.stack([CAM[2] * p[:, 0] / p[:, 2] + CAM[0], CAM[3] * p[:, 1] / p[:, 2] + CAM[1]], 1) + noise * rng.standard_normal((n, 2))
+    if outlier_every:
+        uv[::outlier_every] += rng.uniform(25, 60, (len(uv[::outlier_every]), 2))
+    if zero_every:
+        X[3::zero_every] = 0                                                      # correspondences without depth (project2dTo3d's (0,0,0) sentinel)
+    return uv.astype(np.float32), X, Tgt
+
+
+def _host(tmp_path, img, obj, T_init):
+    subprocess.run(["make", "-C", HOST, "test_pnp"], check=True, capture_output=True)
+    cf, rf = tmp_path / "case.bin", tmp_path / "res.bin"
+    with open(cf, "wb") as f:
+        f.write(struct.pack("<ii", len(img), 0) + np.asarray(CAM, "<f8").tobytes() + np.ascontiguousarray(np.asarray(T_init, "<f8").T).tobytes()
+                + np.ascontiguousarray(img, "<f4").tobytes() + np.ascontiguousarray(obj, "<f4").tobytes())
+    r = subprocess.run([os.path.join(HOST, "test_pnp"), os.path.join(HOST, "parameters_test.txt"), str(cf), str(rf)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    buf = open(rf, "rb").read()
+    ok, m = struct.unpack_from("<ii", buf, 0)
+    T = np.frombuffer(buf, "<f8", 16, 8).reshape(4, 4).T
+    return bool(ok), T.copy(), np.frombuffer(buf, "<i4", m, 8 + 128).copy()
+
+
+@pytest.mark.parametrize("seed,n,outlier_every,zero_every,noise", [(1, 200, 10, 0, 0.0), (2, 300, 7, 5, 0.3), (3, 40, 3, 4, 0.5), (4, 12, 0, 0, 0.0), (5, 8, 2, 3, 0.0), (6, 0, 0, 0, 0.0)])
+def test_host_pnp_equals_oracle(oracle, tmp_path, seed, n, outlier_every, zero_every, noise):
+    img, obj, Tgt = _case(seed, n, outlier_every, zero_every, noise)
+    T0 = _pose(0.0, 0.0, 0.0, (0.0, 0.0, 0.0)) if seed % 2 else _pose(0.01, 0.0, -0.01, (0.01, 0.0, 0.02))
+    ok_o, T_o, inl_o = oracle.pnp_solve(img, obj, CAM, T0, min_inliers=10)
+    ok_h, T_h, inl_h = _host(tmp_path, img, obj, T0)
+    assert ok_o == ok_h == (n > 10)                                               # success = LENGTH of the flag vector > pnp_min_inliers (pnp.cpp:115)
+    assert inl_o.tolist() == inl_h.tolist()
+    assert np.allclose(T_o, T_h, rtol=0, atol=1e-12)
+    if seed == 1:                                                                 # exact data, 10 % gross outliers: the known answer
+        assert np.abs(T_o - Tgt).max() < 1e-4 and len(inl_o) == 180 and not (set(inl_o.tolist()) & set(range(0, 200, 10)))
+
+
+def test_oracle_pnp_quirks(oracle):
+    """the bookkeeping of pnp.cpp:74-89 as written: a passing edge marks inliers[POSITION in the edge list]; behind a correspondence without depth the mark
+    lands one entry early, so the depth-less entry itself is reported as an inlier and the last passing edge's own entry is not"""
+    img, obj, Tgt = _case(11, 60, 0, 0, 0.0)
+    obj[0] = 0                                                                    # one depth-less correspondence in front: ids shift by one
+    ok, T, inl = oracle.pnp_solve(img, obj, CAM, np.eye(4), min_inliers=10)
+    assert ok and np.abs(T - Tgt).max() < 1e-4
+    # 59 edges (ids 1..59) all pass: position i = id - 1 gets marked, ids stay marked from the initial all-true vector -> every entry incl. 0 is set
+    assert inl.tolist() == list(range(60))
+    img2, obj2, _ = _case(12, 60, 0, 0, 0.0)
+    obj2[0] = 0; img2[59] += 80                                                   # the LAST edge is an outlier: its id 59 is cleared, nobody re-marks it; entry 0 is marked by edge id 1
+    ok, T, inl = oracle.pnp_solve(img2, obj2, CAM, np.eye(4), min_inliers=10)
+    assert inl.tolist() == list(range(59))
+    img3, obj3, _ = _case(13, 60, 0, 0, 0.0)
+    obj3[0] = 0; img3[30] += 80                                                   # outlier id 30 (position 29): cleared, then re-marked by the passing edge at position 30 (id 31)
+    ok, T, inl = oracle.pnp_solve(img3, obj3, CAM, np.eye(4), min_inliers=10)
+    assert 30 in inl.tolist() and len(inl) == 60                                  # the reference reports the outlier as an inlier
