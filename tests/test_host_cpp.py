@@ -137,13 +137,14 @@ def test_exp_mapping_rank_path_on_gpu(tmp_path):
     import semantic_slam_mapping_amd as ssm
     from conftest import CAM, SEED
     prm = tmp_path / "p.txt"
-    prm.write_text(open(os.path.join(HOST, "parameters_test.txt")).read() + "\nforce_rank_path=1\nmap_output=\n")
+    prm.write_text(open(os.path.join(HOST, "parameters_test.txt")).read().replace("map_output=/tmp/ssm_test_map.pcd", f"map_output={tmp_path}/merged.pcd") + "\nforce_rank_path=1\n")
     r = subprocess.run([os.path.join(HOST, "exp_mapping"), str(prm), "--ranks", "1"], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0
     line = [l for l in r.stdout.splitlines() if l.startswith("rank 0/1 ")][-1].split()
     st = dict(zip(line[2::2], line[3::2]))
     assert st["frames"] == "[0,8)" and st["halo"] == "0" and int(st["keyframes"]) == 8
+    assert os.path.getsize(tmp_path / "merged.pcd") > 1000                    # rank 0 wrote the merged map as binary PCD
     c = ssm.Context(0, orb_features=1000, max_batch=1, voxel_capacity_log2=18, camera=CAM)
     try:
         W, H = 640, 480
