@@ -15,7 +15,7 @@ if [ "$1" = "stats" ]; then
 else
   export SSM_BENCH_H2D=0
   rm -rf $O/p_sq $O/p_fetch $O/p_write
-  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_sq.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_sq.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_write.log 2>&1
   tail -3 $O/p_sq.log | cut -c1-300

@@ -166,6 +166,28 @@ def g_segnet():
     np.savez_compressed(os.path.join(HERE, "segnet.npz"), **out)
 
 
+def g_sgbm():
+    """cv::StereoSGBM vectors from pyref.sgbm_raw / sgbm (volume-form restatement): the reference's parameters (80 disparities, SAD 11, stereo.cpp:11-30) on a
+    96 x 320 pair, and a second set with other parameters incl. a negative minDisparity"""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from test_sgbm import stereo_pair
+    out = {}
+    cases = {"ref": (96, 320, 0, dict(ndisp=80, SAD=11), ((20, None), (45, (0.3, 0.75, 0.3, 0.7))), 0),
+             "alt": (50, 200, 5, dict(ndisp=48, SAD=7, uniquenessRatio=5, disp12MaxDiff=2), ((12, None), (30, (0.2, 0.9, 0.4, 0.8))), 6),
+             "neg": (30, 100, 7, dict(ndisp=32, SAD=3, minD=-8), ((4, None), (10, (0.2, 0.8, 0.2, 0.8))), 4)}
+    for name, (h, w, seed, kw, planes, noise) in cases.items():
+        left, right, _ = stereo_pair(h, w, seed, planes=planes, noise=noise)
+        raw = pyref.sgbm_raw(left, right, **kw)
+        out[name + "_left"] = left; out[name + "_right"] = right; out[name + "_raw"] = raw
+        out[name + "_disp"] = pyref.filter_speckles(pyref.median3_s16(raw), (kw.get("minD", 0) - 1) * 16, 100, 16 * 32)
+        out[name + "_params"] = np.array([kw.get("minD", 0), kw["ndisp"], kw["SAD"], kw.get("uniquenessRatio", 10), kw.get("disp12MaxDiff", 1)], np.int32)
+    np.savez_compressed(os.path.join(HERE, "sgbm.npz"), **out)
+
+
 if __name__ == "__main__":
-    g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad(); g_segnet()
+    if len(sys.argv) > 1:                           # e.g. `make_golden.py sgbm`: only the named fixtures
+        for n in sys.argv[1:]:
+            globals()["g_" + n]()
+    else:
+        g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad(); g_segnet(); g_sgbm()
     print("golden fixtures written to", HERE)

@@ -732,3 +732,156 @@ def vo_estimate(ms, P, samples):
     else:
         ok = False
     return ok, tr_best, best
+
+
+# ---------------------------------------------------------------- cv::StereoSGBM (OpenCV 2.4, single-pass mode), second restatement
+# Written from the algorithm's definition in VOLUME form (whole cost volumes, numpy over the disparity axis), sharing no code and no structure
+# with oracle/sgbm.c, which follows OpenCV's row-by-row ring buffers: prefilter -> Birchfield-Tomasi pixel cost -> SADWindow box sums -> the
+# five scan directions -> winner / uniqueness / sub-pixel / left-right check -> medianBlur(3) -> filterSpeckles.  Contract: oracle/sgbm.c header.
+def _sgbm_prefiltered(img, ftzero):
+    """two channels per image: the x-Sobel (rows above / below replicated) clipped to +-ftzero and shifted to [0, 2 ftzero], and the raw intensity;
+    the first and last column of BOTH channels hold ftzero (the clip-table entry of 0, as OpenCV initialises them)"""
+    a = img.astype(np.int64); h, w = a.shape
+    up = np.vstack([a[:1], a[:-1]]); dn = np.vstack([a[1:], a[-1:]])
+    sob = np.zeros_like(a)
+    sob[:, 1:-1] = (a[:, 2:] - a[:, :-2]) * 2 + (up[:, 2:] - up[:, :-2]) + (dn[:, 2:] - dn[:, :-2])
+    c0 = np.clip(sob, -ftzero, ftzero) + ftzero
+    c1 = a.copy()
+    for c in (c0, c1):
+        c[:, 0] = ftzero; c[:, -1] = ftzero
+    return c0, c1
+
+
+def _sgbm_interp_range(ch):
+    """per pixel the min / max of the value and its two half-way interpolations to the horizontal neighbours (Birchfield-Tomasi)"""
+    lo = ch.copy(); hi = ch.copy()
+    l = (ch[:, 1:] + ch[:, :-1]) // 2
+    lo[:, 1:] = np.minimum(lo[:, 1:], l); hi[:, 1:] = np.maximum(hi[:, 1:], l)       # neighbour on the left
+    lo[:, :-1] = np.minimum(lo[:, :-1], l); hi[:, :-1] = np.maximum(hi[:, :-1], l)   # neighbour on the right
+    return lo, hi
+
+
+def _trunc_div(a, b):
+    """C integer division (towards zero), b > 0"""
+    return np.where(a >= 0, a // b, -((-a) // b))
+
+
+def sgbm_raw(left, right, minD=0, ndisp=80, SAD=11, P1=None, P2=None, disp12MaxDiff=1, preFilterCap=63, uniquenessRatio=10):
+    left = np.asarray(left, np.uint8); right = np.asarray(right, np.uint8)
+    h, w = left.shape
+    P1 = 4 * SAD * SAD if P1 is None else P1; P2 = 32 * SAD * SAD if P2 is None else P2
+    P2 = max(P2, P1 + 1)
+    D = ndisp; maxD = minD + D
+    ftzero = max(preFilterCap, 15) | 1
+    INV = (minD - 1) * 16
+    minX1 = max(maxD, 0); maxX1 = w + min(minD, 0); W1 = maxX1 - minX1
+    out = np.full((h, w), INV, np.int64)
+    if W1 <= 0:
+        return out.astype(np.int16)
+    half = SAD // 2
+    # ---- pixel cost volume pix[y, x', d], x' = x - minX1, right pixel x - (d + minD)
+    pix = np.zeros((h, W1, D), np.int64)
+    for ch, (lc, rc) in enumerate(zip(_sgbm_prefiltered(left, ftzero), _sgbm_prefiltered(right, ftzero))):
+        u0, u1 = _sgbm_interp_range(lc); v0, v1 = _sgbm_interp_range(rc)
+        xs = np.arange(minX1, maxX1)
+        for d in range(D):
+            xr = xs - (d + minD)
+            ok = (xr >= 0) & (xr < w)
+            xr = np.clip(xr, 0, w - 1)
+            u = lc[:, xs]; v = rc[:, xr]
+            ca = np.maximum(0, np.maximum(u - v1[:, xr], v0[:, xr] - u))
+            cb = np.maximum(0, np.maximum(v - u1[:, xs], u0[:, xs] - v))
+            pix[:, :, d] += np.where(ok, np.minimum(ca, cb) >> (2 if ch else 0), 0)
+    # ---- SAD window: horizontal box with replicated columns, then vertical box with the top row replicated; OpenCV 2.4 freezes column x' = 0 after
+    # row 0 and stops updating once the window would need rows >= h (see oracle/sgbm.c header)
+    xi = np.clip(np.arange(W1)[:, None] + np.arange(-half, half + 1)[None, :], 0, W1 - 1)
+    hs = pix[:, xi, :].sum(axis=2)                                  # [h, W1, D]
+    C = np.zeros((h, W1, D), np.int64)
+    C[0] = P2 + sum(hs[min(k, h - 1)] * (half + 1 if k == 0 else 1) for k in range(half + 1))
+    for y in range(1, h):
+        C[y] = C[y - 1]
+        if y + half < h:
+            C[y, 1:] = C[y - 1, 1:] + hs[y + half, 1:] - hs[max(y - half - 1, 0), 1:]
+    BIG = 32767
+
+    def step(prev, prev_min, cost):
+        """L(d) = cost(d) + min(prev(d), prev(d-1) + P1, prev(d+1) + P1, prev_min + P2) - (prev_min + P2); cost carries the P2 (it is C)"""
+        lo = np.concatenate([[BIG], prev[:-1]]) + P1; hi = np.concatenate([prev[1:], [BIG]]) + P1
+        delta = prev_min + P2
+        return cost + np.minimum(np.minimum(prev, lo), np.minimum(hi, delta)) - delta
+
+    zeros = np.zeros(D, np.int64)
+    prevL = [np.zeros((W1, D), np.int64) for _ in range(4)]; prevMin = [np.zeros(W1, np.int64) for _ in range(4)]   # previous row, directions 0..3
+    for y in range(h):
+        L = [np.zeros((W1, D), np.int64) for _ in range(4)]
+        # directions from the previous row: up-left, up, up-right (a neighbour outside the image is an all-zero path with minimum 0)
+        for k, dx in ((1, -1), (2, 0), (3, 1)):
+            for x in range(W1):
+                xp = x + dx
+                if 0 <= xp < W1:
+                    L[k][x] = step(prevL[k][xp], prevMin[k][xp], C[y, x])
+                else:
+                    L[k][x] = step(zeros, 0, C[y, x])
+        for x in range(W1):                                           # from the left neighbour, sequential in x
+            L[0][x] = step(L[0][x - 1], L[0][x - 1].min(), C[y, x]) if x > 0 else step(zeros, 0, C[y, x])
+        S = np.minimum(L[0] + L[1] + L[2] + L[3], BIG)                # saturating int16 sum, term by term it never goes negative
+        mins = [l.min(axis=1) for l in L]
+        prevL, prevMin = L, mins
+        # from the right neighbour, sequential from the right; winner selection on the way
+        disp2cost = np.full(w, BIG, np.int64); disp2 = np.full(w, INV, np.int64)
+        row = np.full(w, INV, np.int64)
+        R = zeros; Rmin = 0
+        for x in range(W1 - 1, -1, -1):
+            R = step(R, Rmin, C[y, x]) if x < W1 - 1 else step(zeros, 0, C[y, x])
+            Rmin = R.min()
+            Sx = np.minimum(S[x] + R, BIG)
+            best = int(np.argmin(Sx)); minS = int(Sx[best])          # first minimum
+            far = np.abs(np.arange(D) - best) > 1
+            if (far & (Sx * (100 - uniquenessRatio) < minS * 100)).any():
+                continue
+            x2 = x + minX1 - best - minD
+            if disp2cost[x2] > minS:
+                disp2cost[x2] = minS; disp2[x2] = best + minD
+            if 0 < best < D - 1:
+                den = max(int(Sx[best - 1] + Sx[best + 1] - 2 * Sx[best]), 1)
+                dsub = best * 16 + int(_trunc_div(np.int64((Sx[best - 1] - Sx[best + 1]) * 16 + den), den * 2))
+            else:
+                dsub = best * 16
+            row[x + minX1] = dsub + minD * 16
+        for x in range(minX1, maxX1):                                 # left-right consistency on both roundings of the sub-pixel disparity
+            d1 = int(row[x])
+            if d1 == INV:
+                continue
+            dlo, dhi = d1 >> 4, (d1 + 15) >> 4
+            xa, xb = x - dlo, x - dhi
+            if 0 <= xa < w and disp2[xa] >= minD and abs(int(disp2[xa]) - dlo) > disp12MaxDiff and \
+               0 <= xb < w and disp2[xb] >= minD and abs(int(disp2[xb]) - dhi) > disp12MaxDiff:
+                row[x] = INV
+        out[y] = row
+    return out.astype(np.int16)
+
+
+def median3_s16(img):
+    p = np.pad(np.asarray(img, np.int16), 1, mode="edge"); h, w = img.shape
+    return np.sort(np.stack([p[i:i + h, j:j + w] for i in range(3) for j in range(3)]), axis=0)[4].astype(np.int16)
+
+
+def filter_speckles(img, new_val, max_size, max_diff):
+    """components of the graph whose nodes are the pixels != new_val and whose edges join 4-neighbours differing by <= max_diff; small ones become new_val"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    a = np.asarray(img, np.int64); h, w = a.shape; idx = np.arange(h * w).reshape(h, w); valid = a != new_val
+    eh = valid[:, 1:] & valid[:, :-1] & (np.abs(a[:, 1:] - a[:, :-1]) <= max_diff)
+    ev = valid[1:, :] & valid[:-1, :] & (np.abs(a[1:, :] - a[:-1, :]) <= max_diff)
+    r = np.concatenate([idx[:, 1:][eh], idx[1:, :][ev]]); c = np.concatenate([idx[:, :-1][eh], idx[:-1, :][ev]])
+    n, lab = connected_components(coo_matrix((np.ones(len(r)), (r, c)), shape=(h * w, h * w)), directed=False)
+    size = np.bincount(lab, minlength=n)
+    out = a.copy()
+    out[valid & (size[lab].reshape(h, w) <= max_size)] = new_val
+    return out.astype(np.int16)
+
+
+def sgbm(left, right, speckle_window=100, speckle_range=32, **kw):
+    raw = sgbm_raw(left, right, **kw)
+    d = median3_s16(raw)
+    return filter_speckles(d, (kw.get("minD", 0) - 1) * 16, speckle_window, 16 * speckle_range) if speckle_window > 0 else d

@@ -261,3 +261,28 @@ def test_brief_pattern_structure_and_checksum():
     assert v[:4].tolist() == [[8, -3, 9, 5], [4, 2, 7, -12], [-11, 9, -8, 2], [7, -12, 12, -13]]
     assert v[-2:].tolist() == [[7, 0, 12, -2], [-1, -6, 0, -11]]
     assert hashlib.sha256(v.astype(np.int8).tobytes()).hexdigest() == "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+
+
+# ---------------------------------------------------------------- cv::StereoSGBM
+@pytest.mark.parametrize("name", ["ref", "alt", "neg"])
+def test_sgbm_golden(oracle, name):
+    """oracle/sgbm.c (OpenCV's row-by-row ring-buffer form) against vectors minted by the volume-form numpy restatement pyref.sgbm_raw: raw disparities
+    and the image after medianBlur(3) + filterSpeckles, bit for bit"""
+    g = load("sgbm.npz")
+    minD, nd, sad, uniq, d12 = [int(v) for v in g[name + "_params"]]
+    p = oracle.sgbm_params(num_disp=nd, sad=sad, min_disp=minD, uniqueness=uniq, disp12=d12)
+    left, right = g[name + "_left"], g[name + "_right"]
+    assert np.array_equal(oracle.sgbm(left, right, p, raw=True), g[name + "_raw"])
+    assert np.array_equal(oracle.sgbm(left, right, p), g[name + "_disp"])
+    assert (g[name + "_raw"] != (minD - 1) * 16).mean() > 0.5                    # the vectors are not trivially empty
+
+
+def test_sgbm_live_restatement(oracle):
+    """a fresh pair (not in the fixture) through both restatements"""
+    import pyref
+    from test_sgbm import stereo_pair
+    left, right, _ = stereo_pair(36, 150, 99, planes=((7, None), (21, (0.25, 0.8, 0.3, 0.75))), noise=5)
+    p = oracle.sgbm_params(num_disp=32, sad=9)
+    raw = pyref.sgbm_raw(left, right, ndisp=32, SAD=9)
+    assert np.array_equal(oracle.sgbm(left, right, p, raw=True), raw)
+    assert np.array_equal(oracle.sgbm(left, right, p), pyref.filter_speckles(pyref.median3_s16(raw), -16, 100, 512))
