@@ -30,7 +30,7 @@ def main():
     json.dump(js, open(dst.rsplit(".", 1)[0] + ".json", "w"), indent=1)
     with open(dst, "w") as o:
         o.write(f"# {title}\n\nper-wave averages; clock = SQ_BUSY_CYCLES / 32 / duration; `VALU IPC/SIMD` = SQ_INSTS_VALU / (duration x clock x 1024 SIMDs); "
-                "the issue ceiling measured by scripts/ubench/valu_rate.hip is ~0.25 (one wave64 integer op per 4 clk per SIMD)\n\n")
+                "the issue ceiling for these instruction mixes is 0.25 (one wave64 instruction per 4 clk per SIMD: profiles/r02_valu_rate.md)\n\n")
         o.write("| kernel | ms | waves | VALU/wave | LDS/wave | SALU/wave | VMEM_RD/wave | cycles/wave | clock GHz | VALU IPC/SIMD |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
         for k, c in sorted(agg.items(), key=lambda kv: -ns[kv[0]]):
             w = max(c["SQ_WAVES"], 1.0); t = ns[k] * 1e-9
