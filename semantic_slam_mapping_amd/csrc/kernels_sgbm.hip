@@ -144,11 +144,12 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, i
     for (int k = 0; k < K; k++) L[k] = 0;
     const int steps = ROW ? w1 : h;
     if (ROW) {
-        // a row path walks contiguous memory: the costs of SG_UNR steps are loaded together, then the SG_UNR dependent steps
-        // run from registers (one memory latency per group instead of one per step)
+        // a row path walks contiguous memory: the costs of SG_UNR steps are loaded together and the SG_UNR dependent steps run from registers; the
+        // loads of the NEXT group are issued before the current group's steps (two register sets), so that a path pays the memory latency once, not once
+        // per group: the recurrence (a chain of ~100 cycles per step) is then what a row scan costs
         constexpr int SG_UNR = 8;
-        for (int t0 = 0; t0 < steps; t0 += SG_UNR) {
-            int Cq[SG_UNR][K];
+        int Ca[SG_UNR][K], Cb[SG_UNR][K];
+        auto load_group = [&](int (&Cq)[SG_UNR][K], int t0) {
 #pragma unroll
             for (int u = 0; u < SG_UNR; u++) {
                 const int t = min(t0 + u, steps - 1), x = MODE == 0 ? t : w1 - 1 - t;
@@ -156,6 +157,8 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, i
 #pragma unroll
                 for (int k = 0; k < K; k++) Cq[u][k] = C[base + k];
             }
+        };
+        auto run_group = [&](const int (&Cq)[SG_UNR][K], int t0) {
 #pragma unroll
             for (int u = 0; u < SG_UNR; u++) {
                 const int t = t0 + u;
@@ -167,34 +170,64 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, i
                     for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)L[k];
                 }
             }
+        };
+        load_group(Ca, 0);
+        for (int t0 = 0; t0 < steps; t0 += 2 * SG_UNR) {
+            load_group(Cb, t0 + SG_UNR);                         // (clamped to the last pixel when it starts past the end)
+            run_group(Ca, t0);
+            if (t0 + SG_UNR >= steps) break;
+            load_group(Ca, t0 + 2 * SG_UNR);
+            run_group(Cb, t0 + SG_UNR);
         }
         return;
     }
-    for (int t = 0; t < steps; t++) {
-        const int y = ROW ? gp : t, x = MODE == 0 ? t : MODE == 4 ? w1 - 1 - t : o + rx * t;
-        const bool in = x >= 0 && x < w1;
-        if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
+    // column / diagonal paths: the same two-register-set pipeline (the addresses of a path are known in advance: x(t) = o + rx t)
+    constexpr int SG_UNC = 8;
+    int Ca[SG_UNC][K], Cb[SG_UNC][K];
+    auto load_group = [&](int (&Cq)[SG_UNC][K], int t0) {
 #pragma unroll
-            for (int k = 0; k < K; k++) L[k] = 0;
-            minPrev = 0;
+        for (int u = 0; u < SG_UNC; u++) {
+            const int t = min(t0 + u, steps - 1), x = o + rx * t;
+            const size_t base = ((size_t)t * w1 + (x >= 0 && x < w1 ? x : 0)) * D + li * K;
+#pragma unroll
+            for (int k = 0; k < K; k++) Cq[u][k] = C[base + k];
         }
-        const size_t base = ((size_t)y * w1 + (in ? x : 0)) * D + li * K;
-        int Cp[K];
+    };
+    auto run_group = [&](const int (&Cq)[SG_UNC][K], int t0) {
 #pragma unroll
-        for (int k = 0; k < K; k++) Cp[k] = C[base + k];
-        int Lc[K], mp = minPrev;
+        for (int u = 0; u < SG_UNC; u++) {
+            const int t = t0 + u;
+            if (t >= steps) break;                                // wave-uniform
+            const int x = o + rx * t;
+            const bool in = x >= 0 && x < w1;
+            if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
 #pragma unroll
-        for (int k = 0; k < K; k++) Lc[k] = L[k];
-        sg_step<K>(Lc, mp, Cp, P1, P2);
-        if (in) {
+                for (int k = 0; k < K; k++) L[k] = 0;
+                minPrev = 0;
+            }
+            int Lc[K], mp = minPrev;
 #pragma unroll
-            for (int k = 0; k < K; k++) L[k] = Lc[k];
-            minPrev = mp;
-            if (live) {
+            for (int k = 0; k < K; k++) Lc[k] = L[k];
+            sg_step<K>(Lc, mp, Cq[u], P1, P2);
+            if (in) {
 #pragma unroll
-                for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)Lc[k];
+                for (int k = 0; k < K; k++) L[k] = Lc[k];
+                minPrev = mp;
+                if (live) {
+                    const size_t base = ((size_t)t * w1 + x) * D + li * K;
+#pragma unroll
+                    for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)Lc[k];
+                }
             }
         }
+    };
+    load_group(Ca, 0);
+    for (int t0 = 0; t0 < steps; t0 += 2 * SG_UNC) {
+        load_group(Cb, t0 + SG_UNC);
+        run_group(Ca, t0);
+        if (t0 + SG_UNC >= steps) break;
+        load_group(Ca, t0 + 2 * SG_UNC);
+        run_group(Cb, t0 + SG_UNC);
     }
 }
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
