@@ -193,7 +193,8 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
     const LevelGeom& L = g.L[l];
     const int t = blockIdx.x - L.tile_off;
-    const int tx0 = (t % L.tiles_x) * BT_W, ty0 = (t / L.tiles_x) * BT_H;
+    const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);   // t / tiles_x without the division sequence (every wave would run it); 2^32 / 1 does not fit the multiplier
+    const int tx0 = (t - trow * L.tiles_x) * BT_W, ty0 = trow * BT_H;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* src = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
     // nine 16-byte words per staged row; a word that lies inside the image is one (unaligned) load, a word that crosses the left or right
@@ -379,7 +380,8 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
     const LevelGeom& L = g.L[l];
     const int t = blockIdx.x - L.tile_off;
-    const int tx0 = (t % L.tiles_x) * FT_W, ty0 = (t / L.tiles_x) * FT_H;
+    const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);
+    const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* im = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
     // ---- stage the tile: nine (unaligned) 16-byte loads per row, 360 per tile.  Rows / words outside the image are CLAMPED into it instead of
@@ -392,8 +394,9 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
         reinterpret_cast<uint4*>(px)[i] = v;
     }
     for (int i = tid; i < (FT_SH * FT_SST + 15) / 16; i += 256) reinterpret_cast<uint4*>(sc)[i] = make_uint4(0, 0, 0, 0);
-    if (tid < FT_SW) { const int gx = tx0 + tid - 1 - L.minBX - 3; cellx[tid] = (int16_t)(gx >= 0 ? gx / L.wCell : -1); }
-    if (tid < FT_SH) { const int gy = ty0 + tid - 1 - L.minBY - 3; celly[tid] = (int16_t)(gy >= 0 ? gy / L.hCell : -1); }
+    // (cell index by multiplication with the host's reciprocal: the two integer divisions cost every wave ~70 instructions)
+    if (tid < FT_SW) { const int gx = tx0 + tid - 1 - L.minBX - 3; cellx[tid] = (int16_t)(gx >= 0 ? (int)__umulhi((uint32_t)gx, L.mulW) : -1); }
+    if (tid < FT_SH) { const int gy = ty0 + tid - 1 - L.minBY - 3; celly[tid] = (int16_t)(gy >= 0 ? (int)__umulhi((uint32_t)gy, L.mulH) : -1); }
     if (tid < 64) lmax[tid] = 0;
     if (tid == 0) { nlist = 0; nsurv = 0; nstage = 0; gbase = 0; }
     __syncthreads();

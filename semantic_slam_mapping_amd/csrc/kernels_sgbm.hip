@@ -124,6 +124,50 @@ __device__ __forceinline__ void sg_step(int (&L)[K], int& minPrev, const int (&C
 #pragma unroll
     for (int k = 0; k < K; k++) L[k] = Ln[k];
 }
+// The same step on PACKED pairs: a lane's K disparities live two per dword as u16 (every quantity of the recurrence stays below 2^16: costs < 2^15,
+// MAX_COST + P1 = 33251), so one v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_u16 serves two disparities, the neighbour pairs (d-1, d+1) are one v_alignbyte /
+// v_perm each, and the costs arrive from memory already in this form (K u16 = one 8-byte load + one 2-byte load for K = 5).  A scan path is ONE wave
+// alone on its SIMD -- it issues an instruction every ~6 cycles whatever the instruction does (profiles/r02_valu_rate.md, column "@1 wave/SIMD") -- so
+// a path's time is its instruction count: ~45 per step here against ~95 for the 32-bit form.  Odd K: the pad slot of the last pair is kept at 0xFFFF.
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) + __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) - __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b))); }
+template <int K>
+__device__ __forceinline__ void sg_step_pk(uint32_t (&L)[(K + 1) / 2], int& minPrev, const uint32_t (&Cp)[(K + 1) / 2], uint32_t P1P1, int P2)
+{
+    constexpr int NP = (K + 1) / 2;
+    constexpr bool ODD = (K & 1) != 0;
+    constexpr uint32_t MAXMAX = (uint32_t)SG_MAXC | ((uint32_t)SG_MAXC << 16);
+    // the left lane's last pair and the right lane's first pair (MAX_COST beyond the ends of the disparity range)
+    const uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXMAX, (int)L[NP - 1]);        // row_shr:1
+    const uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);             // row_shl:1
+    const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
+    uint32_t Ln[NP], m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        // (slot 2j-1, slot 2j) and (slot 2j+1, slot 2j+2)
+        const uint32_t lm = j > 0 ? __builtin_amdgcn_alignbyte(L[j], L[j - 1], 2)
+                                  : (ODD ? __builtin_amdgcn_perm(L[0], lft, 0x05040100u) : __builtin_amdgcn_alignbyte(L[0], lft, 2));
+        const uint32_t lp = j < NP - 1 ? __builtin_amdgcn_alignbyte(L[j + 1], L[j], 2)
+                                       : (ODD ? rgt : __builtin_amdgcn_alignbyte(rgt, L[j], 2));
+        const uint32_t t = pk_min16(pk_min16(L[j], pk_add16(lm, P1P1)), pk_min16(pk_add16(lp, P1P1), dd));
+        Ln[j] = pk_sub16(pk_add16(Cp[j], t), dd);
+        if (ODD && j == NP - 1) Ln[j] |= 0xFFFF0000u;             // the pad slot never wins a minimum
+        m = pk_min16(m, Ln[j]);
+    }
+    minPrev = sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
+#pragma unroll
+    for (int j = 0; j < NP; j++) L[j] = Ln[j];
+}
+// K consecutive u16 <-> packed pairs (exact sizes: nothing beyond the lane's own K values is touched)
+template <int K> __device__ __forceinline__ void sg_load_pk(uint32_t (&d)[(K + 1) / 2], const uint16_t* p)
+{
+#pragma unroll
+    for (int j = 0; j < (K + 1) / 2; j++) d[j] = 0;
+    __builtin_memcpy(d, p, 2 * K);
+}
+template <int K> __device__ __forceinline__ void sg_store_pk(uint16_t* p, const uint32_t (&d)[(K + 1) / 2]) { __builtin_memcpy(p, d, 2 * K); }
 // MODE 0: r = (-1, 0): path = row y, steps x = 0 .. w1-1        MODE 4: r = (+1, 0): path = row y, steps x = w1-1 .. 0
 // MODE 1..3: r = (-1,-1), (0,-1), (+1,-1): path = diagonal / column, steps y = 0 .. h-1
 // Every direction writes its own L volume: the five launches share nothing but C and run concurrently on five streams.
@@ -139,95 +183,56 @@ sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, i
     const int gp = live ? g : 0;
     const int rx = MODE == 1 ? 1 : MODE == 3 ? -1 : 0;        // x(y) = o + rx * y
     const int o = MODE == 1 ? gp - (h - 1) : gp;
-    int L[K], minPrev = 0;
+    constexpr int NP = (K + 1) / 2;
+    constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;   // L = 0 with the pad slot parked at 0xFFFF
+    uint32_t L[NP]; int minPrev = 0;
 #pragma unroll
-    for (int k = 0; k < K; k++) L[k] = 0;
+    for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
     const int steps = ROW ? w1 : h;
-    if (ROW) {
-        // a row path walks contiguous memory: the costs of SG_UNR steps are loaded together and the SG_UNR dependent steps run from registers; the
-        // loads of the NEXT group are issued before the current group's steps (two register sets), so that a path pays the memory latency once, not once
-        // per group: the recurrence (a chain of ~100 cycles per step) is then what a row scan costs
-        constexpr int SG_UNR = 8;
-        int Ca[SG_UNR][K], Cb[SG_UNR][K];
-        auto load_group = [&](int (&Cq)[SG_UNR][K], int t0) {
+    // the costs of SG_UN steps are loaded together and the next group's loads are issued before the current group's steps run (two register sets):
+    // a path pays the memory latency once per 2 SG_UN steps at most, and the addresses of every path are known in advance (x(t) = o + rx t)
+    constexpr int SG_UN = 16;
+    uint32_t Ca[SG_UN][NP], Cb[SG_UN][NP];
+    auto pix_of = [&](int t, int& x, int& y) { if (ROW) { y = gp; x = MODE == 0 ? t : w1 - 1 - t; } else { y = t; x = o + rx * t; } };
+    auto load_group = [&](uint32_t (&Cq)[SG_UN][NP], int t0) {
 #pragma unroll
-            for (int u = 0; u < SG_UNR; u++) {
-                const int t = min(t0 + u, steps - 1), x = MODE == 0 ? t : w1 - 1 - t;
-                const size_t base = ((size_t)gp * w1 + x) * D + li * K;
-#pragma unroll
-                for (int k = 0; k < K; k++) Cq[u][k] = C[base + k];
-            }
-        };
-        auto run_group = [&](const int (&Cq)[SG_UNR][K], int t0) {
-#pragma unroll
-            for (int u = 0; u < SG_UNR; u++) {
-                const int t = t0 + u;
-                sg_step<K>(L, minPrev, Cq[u], P1, P2);           // (steps past the end recompute the last pixel; nothing is stored)
-                if (live && t < steps) {
-                    const int x = MODE == 0 ? t : w1 - 1 - t;
-                    const size_t base = ((size_t)gp * w1 + x) * D + li * K;
-#pragma unroll
-                    for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)L[k];
-                }
-            }
-        };
-        load_group(Ca, 0);
-        for (int t0 = 0; t0 < steps; t0 += 2 * SG_UNR) {
-            load_group(Cb, t0 + SG_UNR);                         // (clamped to the last pixel when it starts past the end)
-            run_group(Ca, t0);
-            if (t0 + SG_UNR >= steps) break;
-            load_group(Ca, t0 + 2 * SG_UNR);
-            run_group(Cb, t0 + SG_UNR);
-        }
-        return;
-    }
-    // column / diagonal paths: the same two-register-set pipeline (the addresses of a path are known in advance: x(t) = o + rx t)
-    constexpr int SG_UNC = 8;
-    int Ca[SG_UNC][K], Cb[SG_UNC][K];
-    auto load_group = [&](int (&Cq)[SG_UNC][K], int t0) {
-#pragma unroll
-        for (int u = 0; u < SG_UNC; u++) {
-            const int t = min(t0 + u, steps - 1), x = o + rx * t;
-            const size_t base = ((size_t)t * w1 + (x >= 0 && x < w1 ? x : 0)) * D + li * K;
-#pragma unroll
-            for (int k = 0; k < K; k++) Cq[u][k] = C[base + k];
+        for (int u = 0; u < SG_UN; u++) {
+            int x, y; pix_of(min(t0 + u, steps - 1), x, y);
+            sg_load_pk<K>(Cq[u], C + ((size_t)y * w1 + (x >= 0 && x < w1 ? x : 0)) * D + li * K);
         }
     };
-    auto run_group = [&](const int (&Cq)[SG_UNC][K], int t0) {
+    auto run_group = [&](const uint32_t (&Cq)[SG_UN][NP], int t0) {
 #pragma unroll
-        for (int u = 0; u < SG_UNC; u++) {
+        for (int u = 0; u < SG_UN; u++) {
             const int t = t0 + u;
             if (t >= steps) break;                                // wave-uniform
-            const int x = o + rx * t;
-            const bool in = x >= 0 && x < w1;
+            int x, y; pix_of(t, x, y);
+            const bool in = ROW || (x >= 0 && x < w1);
             if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
 #pragma unroll
-                for (int k = 0; k < K; k++) L[k] = 0;
+                for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
                 minPrev = 0;
             }
-            int Lc[K], mp = minPrev;
+            uint32_t Lc[NP]; int mp = minPrev;
 #pragma unroll
-            for (int k = 0; k < K; k++) Lc[k] = L[k];
-            sg_step<K>(Lc, mp, Cq[u], P1, P2);
+            for (int j = 0; j < NP; j++) Lc[j] = L[j];
+            sg_step_pk<K>(Lc, mp, Cq[u], P1P1, P2);
             if (in) {
 #pragma unroll
-                for (int k = 0; k < K; k++) L[k] = Lc[k];
+                for (int j = 0; j < NP; j++) L[j] = Lc[j];
                 minPrev = mp;
-                if (live) {
-                    const size_t base = ((size_t)t * w1 + x) * D + li * K;
-#pragma unroll
-                    for (int k = 0; k < K; k++) Lout[base + k] = (uint16_t)Lc[k];
-                }
+                if (live) sg_store_pk<K>(Lout + ((size_t)y * w1 + x) * D + li * K, Lc);
             }
         }
     };
     load_group(Ca, 0);
-    for (int t0 = 0; t0 < steps; t0 += 2 * SG_UNC) {
-        load_group(Cb, t0 + SG_UNC);
+    for (int t0 = 0; t0 < steps; t0 += 2 * SG_UN) {
+        load_group(Cb, t0 + SG_UN);
         run_group(Ca, t0);
-        if (t0 + SG_UNC >= steps) break;
-        load_group(Ca, t0 + 2 * SG_UNC);
-        run_group(Cb, t0 + SG_UNC);
+        if (t0 + SG_UN >= steps) break;
+        load_group(Ca, t0 + 2 * SG_UN);
+        run_group(Cb, t0 + SG_UN);
     }
 }
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel

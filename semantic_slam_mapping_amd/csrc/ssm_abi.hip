@@ -159,8 +159,9 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
         L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
         if (L.wCell < 17 || L.hCell < 5) { err = "FAST cell too small"; return SSM_E_INVAL; }   /* <= 8x8 cells per 128x32 tile */
+        L.mulW = (uint32_t)(((1ull << 32) + L.wCell - 1) / L.wCell); L.mulH = (uint32_t)(((1ull << 32) + L.hCell - 1) / L.hCell);
         L.cell_off = cells; cells += L.nCols * L.nRows;
-        L.tiles_x = (L.w + 127) / 128; L.tile_off = tiles; tiles += L.tiles_x * ((L.h + 31) / 32);
+        L.tiles_x = (L.w + 127) / 128; L.mulTX = (uint32_t)(((1ull << 32) + L.tiles_x - 1) / L.tiles_x); L.tile_off = tiles; tiles += L.tiles_x * ((L.h + 31) / 32);
         if (L.nCols * L.nRows >= (1 << 17)) { err = "too many FAST cells"; return SSM_E_INVAL; }
         L.nfeat = feat[l];
         if (L.nfeat + 3 > SSM_MAX_NODES - 8) { err = "too many features per level for the LDS quad-tree (max 1013 per level)"; return SSM_E_INVAL; }

@@ -24,6 +24,8 @@ struct LevelGeom {
     int nIni;                  // quad-tree root nodes
     float hX;                  // root node width
     float sf;                  // mvScaleFactor[level]
+    uint32_t mulTX;            // ceil(2^32 / tiles_x), same use
+    uint32_t mulW, mulH;       // ceil(2^32 / wCell), ceil(2^32 / hCell): floor(n / cell) == __umulhi(n, mul) for n < 4096 (exact: n * (mul * cell - 2^32) < 2^32)
 };
 struct OrbGeom {
     int nlevels, W, H;
