@@ -925,6 +925,27 @@ __device__ __forceinline__ bool kp_slot(const OrbGeom& g, const int32_t* __restr
     for (int k = 0; k < l; k++) oidx += ns[k];
     return true;
 }
+// kp_prepare_kernel: one THREAD per slot resolves the slot once -- level, output index, byte offset of the keypoint's pixel inside the frame's pyramid -- so
+// that the wave-per-keypoint kernels below start from ONE 16-byte record instead of each walking the level table and the per-level counts (that walk
+// was a chain of three dependent memory round trips and ~40 % of their instructions)
+struct KpRec { uint32_t off; uint32_t stride_level; int32_t oidx; uint32_t pk; };      // off = img_off + y stride + x; stride | level << 16; oidx < 0: empty slot
+__global__ void __launch_bounds__(256)
+kp_prepare_kernel(OrbGeom g, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel, KpRec* __restrict__ recs, int32_t* __restrict__ nkp)
+{
+    const int f = blockIdx.y, slot = blockIdx.x * 256 + threadIdx.x;
+    const int32_t* ns = nsel + f * g.nlevels;
+    if (slot == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
+    if (slot >= g.sel_total) return;
+    int l, oidx;
+    KpRec r; r.off = 0; r.stride_level = 0; r.oidx = -1; r.pk = 0;
+    if (kp_slot(g, ns, slot, l, oidx)) {
+        const LevelGeom& L = g.L[l];
+        r.pk = sel[(size_t)f * g.sel_total + slot];
+        const int x = r.pk & 4095, y = (r.pk >> 12) & 4095;
+        r.off = (uint32_t)(L.img_off + y * L.stride + x); r.stride_level = (uint32_t)L.stride | ((uint32_t)l << 16); r.oidx = oidx;
+    }
+    recs[(size_t)f * g.sel_total + slot] = r;
+}
 // orient_kernel: lane = (row v = (lane >> 1) - 15, half): the right half-row is the 16 pixels [x, x + 16), the left one [x - 16, x); ONE (unaligned)
 // 16-byte load per lane fetches the whole disc of a keypoint in a single vector-memory instruction; the disc's extent in that row (umax) becomes a
 // per-lane byte mask, the sums are v_dot4_u32_u8 with constant weights: si = sum p, sk = sum k p (k = byte index 0..15; u = k on the right,
@@ -934,8 +955,7 @@ __device__ __forceinline__ bool kp_slot(const OrbGeom& g, const int32_t* __restr
 // needs behind a dot instruction -- scripts/ubench/orient_check.hip shows the wrong sums that gives)
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
 __global__ void __launch_bounds__(256)
-orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict__ pyr, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
-              KpAux* __restrict__ aux)
+orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict__ pyr, const KpRec* __restrict__ recs, KpAux* __restrict__ aux)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
     const int slot0 = (blockIdx.x * 4 + wv) * OR_KPW;
@@ -957,22 +977,20 @@ orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict
         M[j] = m;
     }
     const int koff = left ? -16 : 0;
-    const int32_t* ns = nsel + f * g.nlevels;
     const uint8_t* fr = pyr + (size_t)f * g.pyr_bytes;
     uint4 px[OR_KPW]; bool ok[OR_KPW];
 #pragma unroll
     for (int q = 0; q < OR_KPW; q++) {
-        int l, oidx;
-        ok[q] = kp_slot(g, ns, slot0 + q, l, oidx);
-        px[q] = make_uint4(0, 0, 0, 0);
-        if (ok[q]) {
-            const LevelGeom& L = g.L[l];
-            const uint32_t pk = sel[(size_t)f * g.sel_total + slot0 + q];
-            const int x = pk & 4095, y = (pk >> 12) & 4095;
-            // keypoints sit >= 19 px from every border: [x - 16, x + 16) x [y - 15, y + 15] lies inside the level
-            const uint8_t* p = fr + L.img_off + (size_t)(y + v) * L.stride + (x + koff);
-            uint4 t; __builtin_memcpy(&t, p, 16);                    // unaligned 16-byte load
-            px[q] = t;
+        ok[q] = false; px[q] = make_uint4(0, 0, 0, 0);
+        if (slot0 + q < g.sel_total) {
+            const KpRec rec = recs[(size_t)f * g.sel_total + slot0 + q];
+            ok[q] = rec.oidx >= 0;
+            if (ok[q]) {
+                // keypoints sit >= 19 px from every border: [x - 16, x + 16) x [y - 15, y + 15] lies inside the level
+                const uint8_t* p = fr + rec.off + v * (int)(rec.stride_level & 0xFFFFu) + koff;
+                uint4 t; __builtin_memcpy(&t, p, 16);                    // unaligned 16-byte load
+                px[q] = t;
+            }
         }
     }
 #pragma unroll
@@ -987,16 +1005,16 @@ orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict
     }
 }
 __global__ void __launch_bounds__(256)
-angle_kernel(OrbGeom g, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel, const uint16_t* __restrict__ depth, ssm_camera cam,
-             KpAux* __restrict__ aux, ssm_keypoint* __restrict__ kps, float* __restrict__ pos3d, int32_t* __restrict__ nkp)
+angle_kernel(OrbGeom g, const KpRec* __restrict__ recs, const uint16_t* __restrict__ depth, ssm_camera cam,
+             KpAux* __restrict__ aux, ssm_keypoint* __restrict__ kps, float* __restrict__ pos3d)
 {
     const int f = blockIdx.y, slot = blockIdx.x * 256 + threadIdx.x;
-    const int32_t* ns = nsel + f * g.nlevels;
-    if (slot == 0) { int t = 0; for (int l = 0; l < g.nlevels; l++) t += ns[l]; nkp[f] = t; }
-    int l, oidx;
-    if (!kp_slot(g, ns, slot, l, oidx)) return;
+    if (slot >= g.sel_total) return;
+    const KpRec rec = recs[(size_t)f * g.sel_total + slot];
+    if (rec.oidx < 0) return;
+    const int l = (int)(rec.stride_level >> 16), oidx = rec.oidx;
     const LevelGeom& L = g.L[l];
-    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
+    const uint32_t pk = rec.pk;
     const int x = pk & 4095, y = (pk >> 12) & 4095, score = pk >> 24;
     KpAux a = aux[(size_t)f * g.sel_total + slot];
     const float angle = fast_atan2_deg((float)a.m01, (float)a.m10);
@@ -1025,40 +1043,47 @@ angle_kernel(OrbGeom g, const uint32_t* __restrict__ sel, const int32_t* __restr
 // value of lane + n inside the 16-lane row (0 beyond the row): the 16 nibbles of one 64-bit descriptor word sit in one row
 #define ROW_SHL(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (n), 0xF, 0xF, true))
 __global__ void __launch_bounds__(256)
-brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const uint32_t* __restrict__ sel, const int32_t* __restrict__ nsel,
-             const int8_t* __restrict__ pattern, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc)
+brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restrict__ recs,
+             const float* __restrict__ pattern_f, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc)
 {
     __shared__ uint4 pb[4][DP_ROWS_B * DP_QW_B];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
     const int slot = blockIdx.x * 4 + wv;
-    int l, oidx;
-    if (!kp_slot(g, nsel + f * g.nlevels, slot, l, oidx)) return;
-    const LevelGeom& L = g.L[l];
-    const uint32_t pk = sel[(size_t)f * g.sel_total + slot];
-    const int x = pk & 4095, y = (pk >> 12) & 4095;
-    const uint8_t* blrow = blur + (size_t)f * g.pyr_bytes + L.img_off;
+    if (slot >= g.sel_total) return;
+    const KpRec rec = recs[(size_t)f * g.sel_total + slot];
+    if (rec.oidx < 0) return;
+    const int oidx = rec.oidx, stride = (int)(rec.stride_level & 0xFFFFu);
+    const int x = rec.pk & 4095;
+    const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + rec.off;            // the keypoint's pixel in the blurred level
     const int xb0 = (x - 18) & ~15;
     for (int e = lane; e < DP_ROWS_B * DP_QW_B; e += 64) {
         const int r = e >> 2, c = e & 3;
         const int gx = xb0 + 16 * c;
-        pb[wv][e] = gx < L.stride ? *reinterpret_cast<const uint4*>(blrow + (size_t)(y - 18 + r) * L.stride + gx) : make_uint4(0, 0, 0, 0);
+        pb[wv][e] = gx < stride ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(r - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
     }
     const KpAux a = aux[(size_t)f * g.sel_total + slot];
     const float sb = a.sn, ca = a.cs;
-    // steered BRIEF: lane -> 4 of the 256 comparisons (its 16 pattern bytes arrive in one 16-byte load)
-    const uint4 pw = *reinterpret_cast<const uint4*>(pattern + lane * 16);
-    const uint32_t pwv[4] = {pw.x, pw.y, pw.z, pw.w};
+    // steered BRIEF: lane -> 4 of the 256 comparisons.  The pattern arrives as floats (converted once on the host); the rotation runs on packed
+    // pairs -- (x0, x1) and (y0, y1) of a comparison through v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiplies and adds in the same order as the
+    // scalar form (no contraction) -- and cvRound is the 1.5 * 2^23 trick: adding 12582912.0f rounds to nearest-even in the adder and leaves the
+    // integer in the low mantissa bits (|value| <= 18.4)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float4* pf = reinterpret_cast<const float4*>(pattern_f) + lane * 4;
+    const float4 pq[4] = {pf[0], pf[1], pf[2], pf[3]};
     const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv]) + 18 * (DP_QW_B * 16) + (x - xb0);      // centre pixel of the blurred patch
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
+    const f2 s2 = {sb, sb}, c2 = {ca, ca}, magic = {12582912.0f, 12582912.0f};
     uint32_t nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t q = pwv[k];
-        const float x0 = (float)(int8_t)(q & 255), y0 = (float)(int8_t)((q >> 8) & 255), x1 = (float)(int8_t)((q >> 16) & 255), y1 = (float)(int8_t)(q >> 24);
-        const int yy0 = __float2int_rn(x0 * sb + y0 * ca), xx0 = __float2int_rn(x0 * ca - y0 * sb);
-        const int yy1 = __float2int_rn(x1 * sb + y1 * ca), xx1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = bb[yy0 * (DP_QW_B * 16) + xx0], t1 = bb[yy1 * (DP_QW_B * 16) + xx1];
+        const f2 X = {pq[k].x, pq[k].z}, Y = {pq[k].y, pq[k].w};
+        const f2 xs = X * s2, yc = Y * c2, xc = X * c2, ys = Y * s2;
+        const f2 yy = (xs + yc) + magic, xx = (xc - ys) + magic;
+        // index = yy * 64 + xx with both integers still biased by 0x4B400000: one shift-add, the bias leaves as a constant (mod 2^32)
+        const uint32_t i0 = (__float_as_uint(yy.x) << 6) + __float_as_uint(xx.x) - 0x4B400000u * 65u;
+        const uint32_t i1 = (__float_as_uint(yy.y) << 6) + __float_as_uint(xx.y) - 0x4B400000u * 65u;
+        const int t0 = bb[(int)i0], t1 = bb[(int)i1];
         nib |= (uint32_t)(t0 < t1) << k;
     }
     // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
@@ -1070,14 +1095,16 @@ brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const uint32_t* __rest
         reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + oidx) * 32)[lane >> 4] = make_uint2(b, hi);
 }
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
-                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam, void* kpaux,
+                      const int32_t* nsel, const float* pattern_f, const uint16_t* depth, ssm_camera cam, void* kpaux,
                       ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp, hipStream_t s)
 {
     unsigned long long um = 0;
     for (int v = 0; v <= SSM_HALF_PATCH; v++) um |= (unsigned long long)(g.umax[v] & 15) << (4 * v);
     KpAux* aux = reinterpret_cast<KpAux*>(kpaux);
-    orient_kernel<<<dim3((g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW), n), 256, 0, s>>>(g, um, pyr, sel, nsel, aux);
-    angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, depth, cam, aux, kps, pos3d, nkp);
-    brief_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, blur, sel, nsel, pattern, aux, desc);
+    KpRec* recs = reinterpret_cast<KpRec*>(aux + (size_t)n * g.sel_total);       // second half of the buffer
+    kp_prepare_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, recs, nkp);
+    orient_kernel<<<dim3((g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW), n), 256, 0, s>>>(g, um, pyr, recs, aux);
+    angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, recs, depth, cam, aux, kps, pos3d);
+    brief_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc);
     return hipGetLastError();
 }

@@ -75,7 +75,7 @@ struct ssm_ctx {
     std::string err;
     int B = 1, R = 5;
     // constant tables
-    int8_t* d_pattern = nullptr;
+    int8_t* d_pattern = nullptr; float* d_pattern_f = nullptr;      // the BRIEF table as given, and as floats for brief_kernel
     int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
     void* d_xgrp[SSM_MAX_LEVELS] = {};       // resize4_kernel's per-group constants (null: the level uses the general resize kernel)
     int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
@@ -285,6 +285,10 @@ static int ctx_init(ssm_ctx* c)
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[1], hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
+    {   float pf[1024]; const int8_t* src = cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern;
+        for (int i = 0; i < 1024; i++) pf[i] = (float)src[i];
+        DALLOC(c, c->d_pattern_f, 1024);
+        HIPCHK(c, hipMemcpy(c->d_pattern_f, pf, sizeof(pf), hipMemcpyHostToDevice)); }
     for (int l = 1; l < g.nlevels; l++) {
         std::vector<int32_t> xo, yo; std::vector<int16_t> xa, ya;
         resize_tables(g.L[l-1].w, g.L[l].w, xo, xa); resize_tables(g.L[l-1].h, g.L[l].h, yo, ya);
@@ -320,7 +324,7 @@ static int ctx_init(ssm_ctx* c)
     DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
-    DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total);
+    DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total * 2);          // KpAux + KpRec per slot
     DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
     const int chunks = backproject_chunks(W, H);
     DALLOC(c, c->d_mask, (size_t)B * W * H); DALLOC(c, c->d_chunk_cnt, (size_t)B * chunks); DALLOC(c, c->d_chunk_off, (size_t)B * chunks);
@@ -359,7 +363,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
-                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux };
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f };
     for (void* p : ptrs) if (p) hipFree(p);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
@@ -424,7 +428,7 @@ static int ensure_alt(ssm_ctx* c)
     DALLOC(c, c->alt.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->alt.blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->alt.cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->alt.cand, (size_t)B * g.cand_total); DALLOC(c, c->alt.nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->alt.ncand, (size_t)B * g.nlevels); DALLOC(c, c->alt.sel, (size_t)B * g.sel_total); DALLOC(c, c->alt.nsel, (size_t)B * g.nlevels);
-    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H); DALLOC(c, c->alt.kpaux, (size_t)B * g.sel_total);
+    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H); DALLOC(c, c->alt.kpaux, (size_t)B * g.sel_total * 2);
     c->alt.ready = true;
     return SSM_OK;
 }
@@ -446,7 +450,7 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
     prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
     prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
     prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
-    prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern, d_depth, c->cfg.camera, c->d_kpaux, kps, desc, pos3d, nkp, s)); prof_end(c);
+    prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern_f, d_depth, c->cfg.camera, c->d_kpaux, kps, desc, pos3d, nkp, s)); prof_end(c);
     return SSM_OK;
 }
 

@@ -49,7 +49,7 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s);
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
-                      const int32_t* nsel, const int8_t* pattern, const uint16_t* depth, ssm_camera cam, void* kpaux /* n * sel_total * 16 B */,
+                      const int32_t* nsel, const float* pattern_f /* the 256 x 4 BRIEF table as floats */, const uint16_t* depth, ssm_camera cam, void* kpaux /* n * sel_total * 32 B */,
                       ssm_keypoint* kps, uint8_t* desc, float* pos3d, int32_t* nkp, hipStream_t s);
 
 // matcher.  pair p: query = desc + qoff[p]*32 (nq[p] rows), train = desc + toff[p]*32 (nt[p] rows)
