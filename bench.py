@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--leaf", type=float, default=0.1)
     ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--first-frame", type=int, default=0, help="stream offset of rank 0 (testing aid: > 0 makes rank 0 run a matcher halo too, like ranks > 0 do)")
     ap.add_argument("--no-halo", action="store_true", help="N>1: skip the matcher halo (the first tracker_ref_frames frames of a block then lack their references)")
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
@@ -296,6 +297,7 @@ def main():
         lo, hi = sharding.frame_block(args.total_frames, rank, world); scaling = "strong"
     else:
         lo, hi = rank * args.frames, (rank + 1) * args.frames; scaling = "weak"
+    lo += args.first_frame; hi += args.first_frame
     F = hi - lo
     ctx = ssm.Context(local_rank, orb_features=1000, max_batch=args.batch, voxel_capacity_log2=20,
                       mapper_resolution=args.leaf, camera=CAM)
@@ -513,13 +515,22 @@ def main():
             "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if world > 1 or force_merge:
         ctx.comm_finalize()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if line is not None:
+        # RCCL prints a version banner through C stdio when a communicator is created; flush it first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
