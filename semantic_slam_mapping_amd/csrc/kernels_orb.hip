@@ -123,16 +123,17 @@ resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int
 struct XGroup { uint32_t a[4]; uint32_t base, offs, pad0, pad1; };   // a[k] = a0 | a1 << 16; base = byte offset of the window; offs = 4 bits per pixel
 __global__ void __launch_bounds__(256)
 resize4_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sh, int sstride, int dst_off, int dh, int dstride,
-               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya, int nframes)
 {
     const int groups = dstride >> 2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= groups * dh) return;
+    const int frame = blockIdx.x;                                       // frame-fastest: see the launch-order note at blur_kernel
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (frame >= nframes || i >= groups * dh) return;
     const int y = i / groups, g = i - y * groups;
     const uint4 A = reinterpret_cast<const uint4*>(xg)[2 * g], Q = reinterpret_cast<const uint4*>(xg)[2 * g + 1];
     const int syA = yofs[y], syB = min(syA + 1, sh - 1);
     const uint32_t b0 = (uint32_t)(uint16_t)ya[2 * y] << 16, b1 = (uint32_t)(uint16_t)ya[2 * y + 1] << 16;
-    const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_bytes + src_off;
+    const uint8_t* src = pyr + (size_t)frame * pyr_bytes + src_off;
     const uint32_t* r0 = reinterpret_cast<const uint32_t*>(src + (size_t)syA * sstride + Q.x);
     const uint32_t* r1 = reinterpret_cast<const uint32_t*>(src + (size_t)syB * sstride + Q.x);
     const uint32_t d00 = r0[0], d01 = r0[1], d02 = r0[2], d10 = r1[0], d11 = r1[1], d12 = r1[2];
@@ -151,7 +152,7 @@ resize4_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sh, in
         const uint32_t v = (__umulhi(b0, h0 >> 4) + __umulhi(b1, h1 >> 4) + 2u) >> 2;
         o |= (v & 255u) << (8 * k);
     }
-    *reinterpret_cast<uint32_t*>(pyr + (size_t)blockIdx.y * pyr_bytes + dst_off + (size_t)y * dstride + 4 * g) = o;
+    *reinterpret_cast<uint32_t*>(pyr + (size_t)frame * pyr_bytes + dst_off + (size_t)y * dstride + 4 * g) = o;
 }
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
                      const int32_t* const* yofs, const int16_t* const* ya, const void* const* xgroups, hipStream_t s)
@@ -160,8 +161,8 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
         const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
         if (xgroups && xgroups[l]) {                                             // streaming form (the host found every window inside 8 bytes)
             const int items = (b.stride >> 2) * b.h;
-            resize4_kernel<<<dim3((items + 255) / 256, n), 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.h, a.stride, b.img_off, b.h, b.stride,
-                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l]);
+            resize4_kernel<<<dim3((n + 7) & ~7, (items + 255) / 256), 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.h, a.stride, b.img_off, b.h, b.stride,
+                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l], n);
             continue;
         }
         int prows = 256 / (b.stride >> 4); if (prows < 1) prows = 1; if (prows > 24) prows = 24;
@@ -184,19 +185,24 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
 #define BT_PH (BT_H + 6)
 __device__ __forceinline__ int reflect101(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
 __global__ void __launch_bounds__(256)
-blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom g)
+blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom g, int nframes)
 {
+    // XCD-aware launch order (the tile kernels of this file share it): grid = (frames rounded up to 8, tiles), FRAME fastest.  Workgroups are dealt
+    // round-robin over the 8 XCDs, so with the frame as the fast index all tiles of a frame run on ONE XCD, and tiles t, t+1, ... of a frame are
+    // dispatched close in time: the apron rows / columns that neighbouring tiles share are then served by that XCD's L2 instead of HBM again
+    const int frame = blockIdx.x, tile_id = blockIdx.y;
+    if (frame >= nframes) return;
     __shared__ __attribute__((aligned(16))) uint8_t  in[BT_PH * BT_PW];
     __shared__ uint4 hp2[(BT_PH / 2) * (BT_W / 4)];             // row-pass sums: [row pair][pixel] = (even row | odd row << 16)
     const int tid = threadIdx.x;
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
+    while (l + 1 < g.nlevels && tile_id >= g.L[l+1].tile_off) l++;
     const LevelGeom& L = g.L[l];
-    const int t = blockIdx.x - L.tile_off;
+    const int t = tile_id - L.tile_off;
     const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);   // t / tiles_x without the division sequence (every wave would run it); 2^32 / 1 does not fit the multiplier
     const int tx0 = (t - trow * L.tiles_x) * BT_W, ty0 = trow * BT_H;
     const int w = L.w, h = L.h, stride = L.stride;
-    const uint8_t* src = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    const uint8_t* src = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
     // nine 16-byte words per staged row; a word that lies inside the image is one (unaligned) load, a word that crosses the left or right
     // border (two per row, in edge tiles only) is assembled from reflected bytes; rows reflect as a whole
     for (int i = tid; i < BT_PH * (BT_PW / 16); i += 256) {
@@ -237,7 +243,7 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         hp2[j * (BT_W / 4) + lq] = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
     }
     __syncthreads();
-    uint8_t* dst = blur + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    uint8_t* dst = blur + (size_t)frame * g.pyr_bytes + L.img_off;
     for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
         const int ly = i >> 5, lq = i & 31;
         const int gx = tx0 + 4 * lq, gy = ty0 + ly;
@@ -267,7 +273,7 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
 }
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s)
 {
-    blur_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, blur, g);
+    blur_kernel<<<dim3((n + 7) & ~7, g.tiles_total), 256, 0, s>>>(pyr, blur, g, n);
     return hipGetLastError();
 }
 
@@ -363,8 +369,10 @@ __device__ __forceinline__ uint32_t fast_S2(const uint8_t* pa, const uint8_t* pb
 #define FT_SST 132
 #define FT_STAGE ((FT_PH * FT_PW) / 8)   // candidates staged per tile: as many as fit in the pixel tile they replace (680)
 __global__ void __launch_bounds__(256)
-fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap)
+fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap, int nframes)
 {
+    const int frame = blockIdx.x, tile_id = blockIdx.y;          // frame-fastest launch order: see blur_kernel
+    if (frame >= nframes) return;
     __shared__ __attribute__((aligned(16))) uint8_t px[FT_PH * FT_PW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(FT_SH * FT_SST + 15) / 16 * 16];
     __shared__ uint16_t list[FT_SW * FT_SH];
@@ -377,13 +385,13 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     __shared__ int nlist, nsurv, nstage, gbase;
     const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.L[l+1].tile_off) l++;
+    while (l + 1 < g.nlevels && tile_id >= g.L[l+1].tile_off) l++;
     const LevelGeom& L = g.L[l];
-    const int t = blockIdx.x - L.tile_off;
+    const int t = tile_id - L.tile_off;
     const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);
     const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
     const int w = L.w, h = L.h, stride = L.stride;
-    const uint8_t* im = pyr + (size_t)blockIdx.y * g.pyr_bytes + L.img_off;
+    const uint8_t* im = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
     // ---- stage the tile: nine (unaligned) 16-byte loads per row, 360 per tile.  Rows / words outside the image are CLAMPED into it instead of
     // zero-filled: they then hold shifted pixels, which no valid position ever looks at (valid positions sit >= 19 px from every border, the ring and
     // the NMS neighbours reach 4), and no address leaves the level image
@@ -500,8 +508,8 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     const int n2 = nsurv;
     // ---- local maxima among same-cell neighbours; staged in LDS, ONE global reservation per tile
     const int cx0 = max((int)cellx[1], 0), cy0 = max((int)celly[1], 0);
-    cand_t* out = cand + (size_t)blockIdx.y * g.cand_total + L.cand_off;
-    int32_t* nc = ncand + blockIdx.y * g.nlevels + l;
+    cand_t* out = cand + (size_t)frame * g.cand_total + L.cand_off;
+    int32_t* nc = ncand + frame * g.nlevels + l;
     for (int e0 = 0; e0 < n2; e0 += 256) {
         const int e = e0 + tid;
         bool keep = false; int S = 0, sx = 0, sy = 0;
@@ -547,7 +555,7 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     for (int k = tid; k < ns; k += 256) if (gbase + k < L.cand_cap) out[gbase + k] = stage[k];
     if (tid < 64 && lmax[tid] > 0) {
         const int ci = cy0 + (tid >> 3), cj = cx0 + (tid & 7);
-        atomicMax(&cellmax[(size_t)blockIdx.y * g.cells_total + L.cell_off + ci * L.nCols + cj], lmax[tid]);
+        atomicMax(&cellmax[(size_t)frame * g.cells_total + L.cell_off + ci * L.nCols + cj], lmax[tid]);
     }
 }
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s)
@@ -558,7 +566,7 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
     if (e != hipSuccess) return e;
     // SSM_FAST_STAGE_CAP (tests): a smaller staging area forces the per-candidate global path that tiles with more than FT_STAGE maxima take
     static const int stage_cap = [] { const char* e = getenv("SSM_FAST_STAGE_CAP"); const int v = e ? atoi(e) : FT_STAGE; return v < 0 ? 0 : (v > FT_STAGE ? FT_STAGE : v); }();
-    fast_kernel<<<dim3(g.tiles_total, n), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap);
+    fast_kernel<<<dim3((n + 7) & ~7, g.tiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
     return hipGetLastError();
 }
 
@@ -955,11 +963,11 @@ kp_prepare_kernel(OrbGeom g, const uint32_t* __restrict__ sel, const int32_t* __
 // needs behind a dot instruction -- scripts/ubench/orient_check.hip shows the wrong sums that gives)
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_udot4(a, b, acc, false); }
 __global__ void __launch_bounds__(256)
-orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict__ pyr, const KpRec* __restrict__ recs, KpAux* __restrict__ aux)
+orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict__ pyr, const KpRec* __restrict__ recs, KpAux* __restrict__ aux, int nframes)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
-    const int slot0 = (blockIdx.x * 4 + wv) * OR_KPW;
-    if (slot0 >= g.sel_total) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.x;       // frame-fastest launch order: see blur_kernel
+    const int slot0 = (blockIdx.y * 4 + wv) * OR_KPW;
+    if (f >= nframes || slot0 >= g.sel_total) return;
     // per-lane constants
     const int r = lane >> 1, left = !(lane & 1);
     const int v = r <= 2 * SSM_HALF_PATCH ? r - SSM_HALF_PATCH : 0;
@@ -1044,12 +1052,12 @@ angle_kernel(OrbGeom g, const KpRec* __restrict__ recs, const uint16_t* __restri
 #define ROW_SHL(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (n), 0xF, 0xF, true))
 __global__ void __launch_bounds__(256)
 brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restrict__ recs,
-             const float* __restrict__ pattern_f, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc)
+             const float* __restrict__ pattern_f, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc, int nframes)
 {
     __shared__ uint4 pb[4][DP_ROWS_B * DP_QW_B];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wv;
-    if (slot >= g.sel_total) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.x;       // frame-fastest launch order: see blur_kernel
+    const int slot = blockIdx.y * 4 + wv;
+    if (f >= nframes || slot >= g.sel_total) return;
     const KpRec rec = recs[(size_t)f * g.sel_total + slot];
     if (rec.oidx < 0) return;
     const int oidx = rec.oidx, stride = (int)(rec.stride_level & 0xFFFFu);
@@ -1103,8 +1111,8 @@ hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t
     KpAux* aux = reinterpret_cast<KpAux*>(kpaux);
     KpRec* recs = reinterpret_cast<KpRec*>(aux + (size_t)n * g.sel_total);       // second half of the buffer
     kp_prepare_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, recs, nkp);
-    orient_kernel<<<dim3((g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW), n), 256, 0, s>>>(g, um, pyr, recs, aux);
+    orient_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW)), 256, 0, s>>>(g, um, pyr, recs, aux, n);
     angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, recs, depth, cam, aux, kps, pos3d);
-    brief_kernel<<<dim3((g.sel_total + 3) / 4, n), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc);
+    brief_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 3) / 4), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc, n);
     return hipGetLastError();
 }
