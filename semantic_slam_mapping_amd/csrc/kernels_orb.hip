@@ -123,12 +123,12 @@ resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int
 struct XGroup { uint32_t a[4]; uint32_t base, offs, pad0, pad1; };   // a[k] = a0 | a1 << 16; base = byte offset of the window; offs = 4 bits per pixel
 __global__ void __launch_bounds__(256)
 resize4_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sh, int sstride, int dst_off, int dh, int dstride,
-               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya, int nframes)
+               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
 {
     const int groups = dstride >> 2;
-    const int frame = blockIdx.x;                                       // frame-fastest: see the launch-order note at blur_kernel
-    const int i = blockIdx.y * 256 + threadIdx.x;
-    if (frame >= nframes || i >= groups * dh) return;
+    const int frame = blockIdx.y;                                       // (frame-fastest order measured 5 % slower here: pure streaming, nothing to share)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= groups * dh) return;
     const int y = i / groups, g = i - y * groups;
     const uint4 A = reinterpret_cast<const uint4*>(xg)[2 * g], Q = reinterpret_cast<const uint4*>(xg)[2 * g + 1];
     const int syA = yofs[y], syB = min(syA + 1, sh - 1);
@@ -161,8 +161,8 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
         const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
         if (xgroups && xgroups[l]) {                                             // streaming form (the host found every window inside 8 bytes)
             const int items = (b.stride >> 2) * b.h;
-            resize4_kernel<<<dim3((n + 7) & ~7, (items + 255) / 256), 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.h, a.stride, b.img_off, b.h, b.stride,
-                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l], n);
+            resize4_kernel<<<dim3((items + 255) / 256, n), 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.h, a.stride, b.img_off, b.h, b.stride,
+                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l]);
             continue;
         }
         int prows = 256 / (b.stride >> 4); if (prows < 1) prows = 1; if (prows > 24) prows = 24;
