@@ -168,3 +168,180 @@ hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, i
     match_seq_kernel<<<dim3(2 * R, n), MT / 2, 0, s>>>(desc, nkp, f0, R, hist, ratio, cap, out, nout, pend);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------ the matcher on the matrix cores (sequence path)
+// The Hamming distance matrix of two descriptor sets IS a matrix product: with the query bits expanded to bytes q = -1 / +1 (bit set / clear) and the
+// train bits to t = +16 / -16, sum_k q_k t_k = 16 (H - (256 - H)) = 32 H - 4096, an exact i32 result of v_mfma_i32_32x32x32_i8 (8 K-steps per
+// 256-bit descriptor).  The accumulator is not started at zero but at C[row][col] = 4096 + row, so that a finished 32 x 32 tile holds
+// 32 H + (train index inside the tile): a key whose order is "smaller distance first, equal distances by the lower trainIdx", i.e. the strict '<'
+// scan of oracle/match.c, with no VALU work to build it.  Per value the VALU only keeps the two smallest keys (v_min + v_med3); a tile's two best are
+// widened to (H << 16 | trainIdx) and merged into the running pair.  Integer arithmetic throughout: bit-exact with the VALU matcher above.
+//
+// Layout of an expanded descriptor row (one frame): capT = cap rounded up to 32 descriptors, 256 B each, stored per tile of 32 descriptors in MFMA
+// fragment order [K-step s: 8][lane half h: 2][descriptor r: 32][16 B] -- lane (h, r) of a wave takes the 16 bytes k = 32 s + 16 h .. + 15 of
+// descriptor r as its A (train) or B (query) fragment, so a tile is one contiguous 8 KB block and a fragment load is lane * 16 B (A and B use
+// the same k order, whatever the hardware's, so the sum is over matching k).  Descriptors at or past nkp expand from zero bits; padded trains are
+// excluded by the last tile's C (below), padded queries are never read back.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define MM_QB 256                       // queries per block: 4 waves x 64 (two 32-column accumulators per wave)
+#define MM_TILE 8192                    // bytes of one expanded 32-descriptor tile
+#define MM_PAD_KEY (1023u << 5)         // C of a padded train row: a distance no descriptor reaches
+
+__global__ void __launch_bounds__(256)
+match_expand_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int row0, int cap, int capT,
+                    uint8_t* __restrict__ eq, uint8_t* __restrict__ et)
+{
+    const int row = row0 + blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;                       // one 16-byte fragment: i = (tile * 16 + s * 2 + h) * 32 + r
+    if (i >= capT * 16) return;
+    const int r = i & 31, c = (i >> 5) & 15, d = (i >> 9) * 32 + r;
+    uint32_t bits = 0;
+    if (d < nkp[row]) bits = *reinterpret_cast<const uint16_t*>(desc + ((size_t)row * cap + d) * 32 + 2 * c);
+    uint32_t q[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v = (((bits >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;     // bit j of the nibble -> byte j = 0 / 1
+        q[k] = v * 0xFEu + 0x01010101u;                                  // 1 -> 0xFF (-1), 0 -> 0x01 (+1)
+        t[k] = (v ^ 0x01010101u) * 0xE0u + 0x10101010u;                  // 1 -> 0x10 (+16), 0 -> 0xF0 (-16)
+    }
+    const size_t o = (size_t)row * capT * 256 + (size_t)i * 16;
+    *reinterpret_cast<uint4*>(eq + o) = make_uint4(q[0], q[1], q[2], q[3]);
+    *reinterpret_cast<uint4*>(et + o) = make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+// the two smallest of a finished tile (keys 32 H + row), widened and merged into the running pair g0 <= g1 of keys (H << 16 | trainIdx).
+// The first reads of acc are compiler-visible min / max: the wait states an MFMA result needs before a VALU read are inserted there, and the inline
+// v_med3 that follow depend on them.
+__device__ __forceinline__ void mm_track(const v16i& acc, uint32_t t32, uint32_t& g0, uint32_t& g1)
+{
+    uint32_t l0 = min((uint32_t)acc[0], (uint32_t)acc[1]), l1 = max((uint32_t)acc[0], (uint32_t)acc[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i++) { l1 = umed3((uint32_t)acc[i], l0, l1); l0 = min((uint32_t)acc[i], l0); }
+    const uint32_t G0 = ((l0 >> 5) << 16) | ((l0 & 31u) | t32), G1 = ((l1 >> 5) << 16) | ((l1 & 31u) | t32);
+    const uint32_t m = max(g0, G0);
+    g0 = min(g0, G0);
+    g1 = min(min(m, g1), G1);
+}
+
+// Block (frame, ref r, query block qb): queries [256 qb, +256) of reference frame `ref` against every descriptor of the current frame.
+// Grid = (frames rounded up to 8, R x query blocks), frame fastest: the blocks of one current frame share its train tiles in one XCD's L2.
+__global__ void __launch_bounds__(256)
+match_mfma_kernel(const uint8_t* __restrict__ eq, const uint8_t* __restrict__ et, const int32_t* __restrict__ nkp,
+                  int f0, int n, int R, int hist, int capT, int qblocks, uint2* __restrict__ knn)
+{
+    __shared__ uint4 tile[2][MM_TILE / 16];
+    const int frame = blockIdx.x;
+    if (frame >= n) return;
+    const int r = blockIdx.y / qblocks, qb = blockIdx.y - r * qblocks;
+    const int f = f0 + frame, cur = hist + f, ref = cur - R + r;
+    const int nq = ref >= 0 ? nkp[ref] : -1, nt = nkp[cur];
+    if (nq < 0 || nt < 2 || qb * MM_QB >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+    const int q0 = qb * MM_QB + wv * 64;
+    // B fragments: the wave's 64 queries, all 8 K-steps, stay in registers
+    v4i b[2][8];
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(eq + ((size_t)ref * capT + q0) * 256) + lane;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (q0 + u * 32 < capT) v = qp[(u * MM_TILE + s * 1024) / 16];
+                b[u][s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+    }
+    v16i cc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) cc[i] = 4096 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const int ntile = (nt + 31) >> 5;
+    const uint4* tp = reinterpret_cast<const uint4*>(et + (size_t)cur * capT * 256);
+    uint4 p0 = tp[tid], p1 = tp[256 + tid];
+    uint32_t g0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int T = 0; T < ntile; T++) {
+        uint4* buf = tile[T & 1];
+        buf[tid] = p0; buf[256 + tid] = p1;
+        if (T + 1 < ntile) { p0 = tp[(T + 1) * 512 + tid]; p1 = tp[(T + 1) * 512 + 256 + tid]; }
+        __syncthreads();                                                // one barrier per tile: the buffer written now was last read two tiles ago
+        v16i c0 = cc;
+        if (T == ntile - 1) {                                           // padded train rows of the last tile never win
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (T * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = (int)MM_PAD_KEY + (i & 3) + 8 * (i >> 2) + 4 * h;
+        }
+        v4i a[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { const uint4 v = buf[s * 64 + lane]; a[s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+        v16i acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][0], c0, 0, 0, 0);
+        v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[1][0], c0, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 8; s++) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[1][s], acc1, 0, 0, 0);
+        }
+        mm_track(acc0, (uint32_t)T << 5, g0[0], g1[0]);
+        mm_track(acc1, (uint32_t)T << 5, g0[1], g1[1]);
+    }
+    // the lane halves hold different train rows of the same query: merge lane l with lane l ^ 32, then lanes 0..31 write accumulator 0's
+    // queries and lanes 32..63 accumulator 1's
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t o0 = __shfl_xor(g0[u], 32), o1 = __shfl_xor(g1[u], 32);
+        const uint32_t m = max(g0[u], o0);
+        g0[u] = min(g0[u], o0);
+        g1[u] = min(min(m, g1[u]), o1);
+    }
+    const uint32_t k0 = h ? g0[1] : g0[0], k1 = h ? g1[1] : g1[0];
+    const int qi = q0 + lane;                                            // lane 32 + j: column j of accumulator 1 = query q0 + 32 + j
+    const int slot = f * R + r;
+    if (qi < nq) knn[(size_t)slot * capT + qi] = make_uint2(k0, k1);
+}
+
+// ratio test + compaction in ascending queryIdx of one (frame, ref) pair from its knn keys (one block per pair)
+__global__ void __launch_bounds__(256)
+match_compact_kernel(const uint2* __restrict__ knn, const int32_t* __restrict__ nkp, int f0, int R, int hist, int capT, double ratio, int cap,
+                     ssm_dmatch* __restrict__ out, int32_t* __restrict__ nout)
+{
+    __shared__ int wcnt[4];
+    const int slot = (f0 + blockIdx.x / R) * R + blockIdx.x % R;
+    const int cur = hist + f0 + blockIdx.x / R, ref = cur - R + blockIdx.x % R;
+    const int nq = ref >= 0 ? nkp[ref] : -1, nt = nkp[cur];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (nq < 0 || nt < 2) { if (tid == 0) nout[slot] = -1; return; }
+    const uint2* kk = knn + (size_t)slot * capT;
+    ssm_dmatch* o = out + (size_t)slot * cap;
+    int base = 0;
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int qi = q0 + tid;
+        uint2 k = make_uint2(0, 0);
+        if (qi < nq) k = kk[qi];
+        const int d0 = k.x >> 16, i0 = k.x & 0xFFFF, d1 = k.y >> 16;
+        const bool keep = (qi < nq) && ((double)(float)d0 < ratio * (double)(float)d1);      // orb.cpp:25
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; w++) off += wcnt[w];
+        if (keep) {
+            const int kpos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (kpos < cap) { ssm_dmatch mm; mm.queryIdx = qi; mm.trainIdx = i0; mm.imgIdx = 0; mm.distance = (float)d0; o[kpos] = mm; }
+        }
+        base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) nout[slot] = base;
+}
+hipError_t k_match_expand(const uint8_t* desc, const int32_t* nkp, int row0, int nrows, int cap, int capT, uint8_t* eq, uint8_t* et, hipStream_t s)
+{
+    if (nrows <= 0) return hipSuccess;
+    match_expand_kernel<<<dim3((capT * 16 + 255) / 256, nrows), 256, 0, s>>>(desc, nkp, row0, cap, capT, eq, et);
+    return hipGetLastError();
+}
+hipError_t k_match_seq_mfma(const uint8_t* eq, const uint8_t* et, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap, int capT,
+                            void* knn, ssm_dmatch* out, int32_t* nout, hipStream_t s)
+{
+    const int qblocks = (capT + MM_QB - 1) / MM_QB;
+    match_mfma_kernel<<<dim3((n + 7) & ~7, R * qblocks), 256, 0, s>>>(eq, et, nkp, f0, n, R, hist, capT, qblocks, reinterpret_cast<uint2*>(knn));
+    match_compact_kernel<<<n * R, 256, 0, s>>>(reinterpret_cast<const uint2*>(knn), nkp, f0, R, hist, capT, ratio, cap, out, nout);
+    return hipGetLastError();
+}

@@ -96,6 +96,7 @@ struct ssm_ctx {
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
+    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
     VoxTable map, tmp;
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
@@ -345,6 +346,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SSM_E_HIP; }
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
+    { const char* e = getenv("SSM_MATCH_VARIANT"); c->match_mfma = !(e && atoi(e) == 0); }      // 0: the VALU matcher in the sequence path (A/B runs)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
     int r = build_geometry(*cfg, c->g, c->err);
     if (!r && (cfg->voxel_capacity_log2 < 8 || cfg->voxel_capacity_log2 > 28)) { c->err = "voxel_capacity_log2 must be 8..28"; r = SSM_E_INVAL; }
@@ -363,7 +365,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
-                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f };
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn };
     for (void* p : ptrs) if (p) hipFree(p);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
@@ -819,9 +821,14 @@ static int ensure_seq(ssm_ctx* c, int n)
     // keep the history rows across the re-allocation
     uint8_t* old_desc = c->d_desc_all; int32_t* old_nkp = c->d_nkp_all; const int old_prev = c->prev_n;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    void* olds[] = { c->d_kps, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints, c->d_match_pend };
+    void* olds[] = { c->d_kps, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_npoints, c->d_match_pend, c->d_exp_q, c->d_exp_t, c->d_knn };
     for (void* p : olds) if (p) hipFree(p);
     c->d_kps = nullptr; c->d_pos3d = nullptr; c->d_matches = nullptr; c->d_nmatch = nullptr; c->d_npoints = nullptr; c->d_match_pend = nullptr;
+    c->d_exp_q = nullptr; c->d_exp_t = nullptr; c->d_knn = nullptr;
+    c->capT = (g.cap + 31) & ~31;
+    if (c->match_mfma) {       // expanded rows are rebuilt from the bit descriptors at the start of every call (history) and after every ORB sub-batch
+        DALLOC(c, c->d_exp_q, (size_t)(n + R) * c->capT * 256); DALLOC(c, c->d_exp_t, (size_t)(n + R) * c->capT * 256); DALLOC(c, c->d_knn, (size_t)n * R * c->capT * 8);
+    }
     DALLOC(c, c->d_kps, (size_t)n * g.cap); DALLOC(c, c->d_pos3d, (size_t)n * g.cap * 3);
     DALLOC(c, c->d_matches, (size_t)n * R * g.cap); DALLOC(c, c->d_nmatch, (size_t)n * R); DALLOC(c, c->d_match_pend, (size_t)n * R); DALLOC(c, c->d_npoints, (size_t)n);
     uint8_t* nd; int32_t* nn;
@@ -860,6 +867,8 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         HIPCHK(c, hipMemsetAsync(c->d_nkp_all, 0xFF, (size_t)R * 4, s));     // -1: no such reference frame
     }
     uint8_t* desc = c->d_desc_all + (size_t)R * row; int32_t* nkp = c->d_nkp_all + R;
+    const bool mfma = c->match_mfma && (stages & SSM_STAGE_MATCH);
+    if (mfma) HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, 0, R, g.cap, c->capT, c->d_exp_q, c->d_exp_t, s));      // the history rows
     // Two streams: the ORB -> match chain of a sub-batch and its (SegNet ->) map stage share no data, only the inputs, so the
     // map side runs on stream2.  The chain's latency-bound kernels (pyramid, octree, describe) then overlap VALU/MFMA-bound
     // map / SegNet work.  stream2 starts behind everything already queued on the context stream and is joined at the end.
@@ -886,6 +895,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
                         c->d_kps + (size_t)f0 * g.cap, desc + (size_t)f0 * row, c->d_pos3d + (size_t)f0 * g.cap * 3, nkp + f0);
             if (r) return r;
+            if (mfma) { prof_begin(c, "match"); HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream)); prof_end(c); }
             if (two_chains) {
                 HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
                 if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[chain ^ 1], 0));     // the previous sub-batch's descriptors
@@ -893,7 +903,11 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         }
         if (stages & SSM_STAGE_MATCH) {
             prof_begin(c, "match");
-            HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend + (size_t)f0 * R, c->stream));
+            if (mfma) {
+                if (!(stages & SSM_STAGE_ORB)) HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream));
+                HIPCHK(c, k_match_seq_mfma(c->d_exp_q, c->d_exp_t, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->capT, c->d_knn, c->d_matches, c->d_nmatch, c->stream));
+            } else
+                HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend + (size_t)f0 * R, c->stream));
             prof_end(c);
         }
         if (!side_work) continue;

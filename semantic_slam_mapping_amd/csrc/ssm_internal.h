@@ -60,6 +60,12 @@ hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs
 hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
                        ssm_dmatch* out, int32_t* nout, int32_t* pend /* n * R ints of scratch */, hipStream_t s);
 
+// the matcher on the matrix cores: descriptors expanded to i8 rows (capT = cap rounded up to 32 descriptors, 256 B each, tile-fragment order), then
+// v_mfma_i32_32x32x32_i8 distance tiles -> knn keys -> ratio test + ordered compaction.  Same results as k_match_seq.
+hipError_t k_match_expand(const uint8_t* desc, const int32_t* nkp, int row0, int nrows, int cap, int capT, uint8_t* eq, uint8_t* et, hipStream_t s);
+hipError_t k_match_seq_mfma(const uint8_t* eq, const uint8_t* et, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap, int capT,
+                            void* knn /* n * R * capT * 8 B */, ssm_dmatch* out, int32_t* nout, hipStream_t s);
+
 // mapper front half
 hipError_t k_moving_mask(const uint8_t* sem, int n, int w, int h, uint8_t* mask, hipStream_t s);
 hipError_t k_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const uint8_t* mask,
