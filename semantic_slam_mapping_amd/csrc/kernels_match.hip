@@ -184,9 +184,12 @@ hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, i
 // excluded by the last tile's C (below), padded queries are never read back.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define MM_QB 256                       // queries per block: 4 waves x 64 (two 32-column accumulators per wave)
 #define MM_TILE 8192                    // bytes of one expanded 32-descriptor tile
-#define MM_PAD_KEY (1023u << 5)         // C of a padded train row: a distance no descriptor reaches
+#ifndef MM_ABLATE
+#define MM_ABLATE 0                     // scripts/ubench/match_bench.hip only (wrong results): 1 no key tracking, 2 no LDS staging / barrier, 4 no train prefetch, 8 no MFMA
+#endif
 
 __global__ void __launch_bounds__(256)
 match_expand_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp, int row0, int cap, int capT,
@@ -211,29 +214,44 @@ match_expand_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict_
 }
 
 // the two smallest of a finished tile (keys 32 H + row), widened and merged into the running pair g0 <= g1 of keys (H << 16 | trainIdx).
-// The first reads of acc are compiler-visible min / max: the wait states an MFMA result needs before a VALU read are inserted there, and the inline
-// v_med3 that follow depend on them.
+// A tournament of plain min / max / min3 (37 instructions for 16 values): no inline assembly, so the compiler places the wait states an MFMA result
+// needs before its first VALU read, and the scheduler can interleave these instructions with the next tile's MFMAs.
+__device__ __forceinline__ void mm_merge2(uint32_t& a0, uint32_t& a1, uint32_t b0, uint32_t b1)     // (a0 <= a1), (b0 <= b1) -> the two smallest of the four
+{
+    const uint32_t m = max(a0, b0);
+    a0 = min(a0, b0);
+    a1 = min(min(m, a1), b1);
+}
 __device__ __forceinline__ void mm_track(const v16i& acc, uint32_t t32, uint32_t& g0, uint32_t& g1)
 {
-    uint32_t l0 = min((uint32_t)acc[0], (uint32_t)acc[1]), l1 = max((uint32_t)acc[0], (uint32_t)acc[1]);
+    uint32_t lo[8], hi[8];
 #pragma unroll
-    for (int i = 2; i < 16; i++) { l1 = umed3((uint32_t)acc[i], l0, l1); l0 = min((uint32_t)acc[i], l0); }
-    const uint32_t G0 = ((l0 >> 5) << 16) | ((l0 & 31u) | t32), G1 = ((l1 >> 5) << 16) | ((l1 & 31u) | t32);
-    const uint32_t m = max(g0, G0);
-    g0 = min(g0, G0);
-    g1 = min(min(m, g1), G1);
+    for (int i = 0; i < 8; i++) { lo[i] = min((uint32_t)acc[2 * i], (uint32_t)acc[2 * i + 1]); hi[i] = max((uint32_t)acc[2 * i], (uint32_t)acc[2 * i + 1]); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) mm_merge2(lo[i], hi[i], lo[i + 4], hi[i + 4]);
+    mm_merge2(lo[0], hi[0], lo[2], hi[2]); mm_merge2(lo[1], hi[1], lo[3], hi[3]);
+    mm_merge2(lo[0], hi[0], lo[1], hi[1]);
+    const uint32_t G0 = ((lo[0] >> 5) << 16) | ((lo[0] & 31u) | t32), G1 = ((hi[0] >> 5) << 16) | ((hi[0] & 31u) | t32);
+    mm_merge2(g0, g1, G0, G1);
 }
 
 // Block (frame, ref r, query block qb): queries [256 qb, +256) of reference frame `ref` against every descriptor of the current frame.
-// Grid = (frames rounded up to 8, R x query blocks), frame fastest: the blocks of one current frame share its train tiles in one XCD's L2.
-__global__ void __launch_bounds__(256)
+// XCD-aware 1-D grid: workgroup i runs on XCD i % 8, and the i / 8-th workgroup of an XCD is block (frame = XCD's first frame + (i / 8) / Y, y = (i / 8) % Y),
+// Y = R x query blocks: an XCD owns a contiguous run of frames and walks it frame by frame, so the Y blocks that stream one frame's train tiles are
+// resident together, and the reference rows (queries) a frame needs were the previous frames' -- both come from that XCD's L2, not from HBM again
+// (with the frame as the fast grid index the kernel moved 1.6 GB per 250 frames and was memory bound at half the matrix rate).
+__global__ void __launch_bounds__(256, 2)
 match_mfma_kernel(const uint8_t* __restrict__ eq, const uint8_t* __restrict__ et, const int32_t* __restrict__ nkp,
-                  int f0, int n, int R, int hist, int capT, int qblocks, uint2* __restrict__ knn)
+                  int f0, int n, int R, int hist, int capT, int qblocks, int frames_per_xcd, uint2* __restrict__ knn)
 {
-    __shared__ uint4 tile[2][MM_TILE / 16];
-    const int frame = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) uint4 ring0[MM_TILE / 16];       // the ring as four objects: the compiler then knows that a DMA into one
+    __shared__ __attribute__((aligned(16))) uint4 ring1[MM_TILE / 16];       // slot does not alias the fragment reads of another
+    __shared__ __attribute__((aligned(16))) uint4 ring2[MM_TILE / 16];
+    __shared__ __attribute__((aligned(16))) uint4 ring3[MM_TILE / 16];
+    const int Y = R * qblocks, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int frame = xcd * frames_per_xcd + j / Y, y = j % Y;
     if (frame >= n) return;
-    const int r = blockIdx.y / qblocks, qb = blockIdx.y - r * qblocks;
+    const int r = y / qblocks, qb = y - r * qblocks;
     const int f = f0 + frame, cur = hist + f, ref = cur - R + r;
     const int nq = ref >= 0 ? nkp[ref] : -1, nt = nkp[cur];
     if (nq < 0 || nt < 2 || qb * MM_QB >= nq) return;
@@ -252,36 +270,86 @@ match_mfma_kernel(const uint8_t* __restrict__ eq, const uint8_t* __restrict__ et
                 b[u][s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
     }
-    v16i cc;
+    v16i cc;                                                            // C of every tile: 4096 + the train row inside the tile
 #pragma unroll
     for (int i = 0; i < 16; i++) cc[i] = 4096 + (i & 3) + 8 * (i >> 2) + 4 * h;
     const int ntile = (nt + 31) >> 5;
-    const uint4* tp = reinterpret_cast<const uint4*>(et + (size_t)cur * capT * 256);
-    uint4 p0 = tp[tid], p1 = tp[256 + tid];
     uint32_t g0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (int T = 0; T < ntile; T++) {
-        uint4* buf = tile[T & 1];
-        buf[tid] = p0; buf[256 + tid] = p1;
-        if (T + 1 < ntile) { p0 = tp[(T + 1) * 512 + tid]; p1 = tp[(T + 1) * 512 + 256 + tid]; }
-        __syncthreads();                                                // one barrier per tile: the buffer written now was last read two tiles ago
-        v16i c0 = cc;
-        if (T == ntile - 1) {                                           // padded train rows of the last tile never win
-#pragma unroll
-            for (int i = 0; i < 16; i++) if (T * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= nt) c0[i] = (int)MM_PAD_KEY + (i & 3) + 8 * (i >> 2) + 4 * h;
-        }
-        v4i a[8];
+    // Train tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write) through a ring of four 8 KB slots, up to four tiles ahead of the MFMAs:
+    // with a register-staged double buffer the L2 latency of the next tile was exposed at every barrier and the kernel ran at half the matrix
+    // rate.  Every thread issues exactly two DMA instructions per tile (clamped to the last tile past the end: same bytes, a slot nobody reads),
+    // so "tile T has landed" is always vmcnt(4) + the barrier.
+    const auto rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(et + (size_t)cur * capT * 256), 0, (unsigned)capT * 256u, 0x00020000);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    auto dma = [&](int T, uint4* ring) {
+        if (MM_ABLATE & 4) return;
+        const unsigned o = (unsigned)min(T, ntile - 1) * MM_TILE + (unsigned)(wvu * 64 + lane) * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)&ring[wvu * 64], 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)&ring[(wvu + 4) * 64], 16, o + 4096u, 0, 0, 0);
+    };
+    // the eight A fragments of a tile, LDS -> registers
+    auto frags = [&](const uint4* buf, v4i (&a)[8]) {
 #pragma unroll
         for (int s = 0; s < 8; s++) { const uint4 v = buf[s * 64 + lane]; a[s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
-        v16i acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][0], c0, 0, 0, 0);
-        v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[1][0], c0, 0, 0, 0);
+    };
+    // the 16 MFMAs of a tile whose fragments are in registers, into (x0, x1)
+    auto issue = [&](const v4i (&a)[8], v16i& x0, v16i& x1) {
+        if (MM_ABLATE & 8) { x0 = cc; x1 = cc; for (int s = 0; s < 8; s++) { x0[s] += a[s][0]; x1[s] += a[s][1]; } return; }
+        x0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][0], cc, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[1][0], cc, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < 8; s++) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[1][s], acc1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[0][s], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[1][s], x1, 0, 0, 0);
         }
-        mm_track(acc0, (uint32_t)T << 5, g0[0], g1[0]);
-        mm_track(acc1, (uint32_t)T << 5, g0[1], g1[1]);
+    };
+    // the MFMAs of a tile are issued first and the key tracking of the tile before it (VALU only, other registers) runs under them
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+    };
+    auto track = [&](const v16i& x0, const v16i& x1, int T) {
+        if (MM_ABLATE & 1) { g0[0] = min(g0[0], (uint32_t)x0[0]); g0[1] = min(g0[1], (uint32_t)x1[0]); return; }
+        mm_track(x0, (uint32_t)T << 5, g0[0], g1[0]); mm_track(x1, (uint32_t)T << 5, g0[1], g1[1]);
+    };
+    auto track_last = [&](v16i x0, v16i x1, int T) {                    // the last tile: its padded train rows (>= nt) never win
+        const int valid = nt - T * 32;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if ((i & 3) + 8 * (i >> 2) + 4 * h >= valid) { x0[i] = -1; x1[i] = -1; }
+        track(x0, x1, T);
+    };
+    // Step T: tile T + 1 has landed (vmcnt(4): the DMAs of T + 2 and T + 3 stay in flight) and this wave holds the fragments of tile T
+    // (lgkmcnt(0)); after the barrier that is true of every wave, so slot T & 3 is free for the DMA of tile T + 4.  The fragments of tile T + 1
+    // are read into the other register set, then the MFMAs of tile T are issued from registers -- no LDS latency in front of them -- with the key
+    // tracking of tile T - 1 under them.
+#define MM_STEP(T_, rd_, wr_, acur, anxt, xn0, xn1, TRACK) { \
+        __builtin_amdgcn_s_waitcnt((MM_ABLATE & 4) ? 0x007F : 0x0074);    /* vmcnt(4) lgkmcnt(0) */ \
+        if (!(MM_ABLATE & 2)) __builtin_amdgcn_s_barrier();              /* bare: __syncthreads' fence would drain every DMA in flight */ \
+        frags(rd_, anxt); \
+        dma((T_) + 4, wr_); \
+        __builtin_amdgcn_sched_barrier(0); \
+        issue(acur, xn0, xn1); TRACK; interleave(); \
+        __builtin_amdgcn_sched_barrier(0); }
+    v16i A0, A1, B0, B1;
+    v4i aA[8], aB[8];
+    dma(0, ring0); dma(1, ring1); dma(2, ring2); dma(3, ring3);
+    if (!(MM_ABLATE & 4)) __builtin_amdgcn_s_waitcnt(0x0F76);           // vmcnt(6): tile 0
+    if (!(MM_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+    frags(ring0, aA);
+    MM_STEP(0, ring1, ring0, aA, aB, A0, A1, (void)0)
+    int T = 1;                                                          // the next tile; T = 1 (mod 4) here and after the loop
+    for (; T + 3 < ntile; T += 4) {
+        MM_STEP(T, ring2, ring1, aB, aA, B0, B1, track(A0, A1, T - 1))
+        MM_STEP(T + 1, ring3, ring2, aA, aB, A0, A1, track(B0, B1, T))
+        MM_STEP(T + 2, ring0, ring3, aB, aA, B0, B1, track(A0, A1, T + 1))
+        MM_STEP(T + 3, ring1, ring0, aA, aB, A0, A1, track(B0, B1, T + 2))
     }
+    if (T < ntile) MM_STEP(T, ring2, ring1, aB, aA, B0, B1, track(A0, A1, T - 1))
+    if (T + 1 < ntile) MM_STEP(T + 1, ring3, ring2, aA, aB, A0, A1, track(B0, B1, T))
+    if (T + 2 < ntile) MM_STEP(T + 2, ring0, ring3, aB, aA, B0, B1, track(A0, A1, T + 1))
+#undef MM_STEP
+    if ((ntile - 1) & 1) track_last(B0, B1, ntile - 1); else track_last(A0, A1, ntile - 1);
+    __builtin_amdgcn_s_waitcnt(0x0070);                                 // the surplus DMA and fragment reads of the tail are done before the block's LDS is released
     // the lane halves hold different train rows of the same query: merge lane l with lane l ^ 32, then lanes 0..31 write accumulator 0's
     // queries and lanes 32..63 accumulator 1's
 #pragma unroll
@@ -341,7 +409,8 @@ hipError_t k_match_seq_mfma(const uint8_t* eq, const uint8_t* et, const int32_t*
                             void* knn, ssm_dmatch* out, int32_t* nout, hipStream_t s)
 {
     const int qblocks = (capT + MM_QB - 1) / MM_QB;
-    match_mfma_kernel<<<dim3((n + 7) & ~7, R * qblocks), 256, 0, s>>>(eq, et, nkp, f0, n, R, hist, capT, qblocks, reinterpret_cast<uint2*>(knn));
+    const int fpx = (n + 7) >> 3;
+    match_mfma_kernel<<<8 * fpx * R * qblocks, 256, 0, s>>>(eq, et, nkp, f0, n, R, hist, capT, qblocks, fpx, reinterpret_cast<uint2*>(knn));
     match_compact_kernel<<<n * R, 256, 0, s>>>(reinterpret_cast<const uint2*>(knn), nkp, f0, R, hist, capT, ratio, cap, out, nout);
     return hipGetLastError();
 }
