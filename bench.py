@@ -57,16 +57,17 @@ def algorithmic_bytes(stage, P, nkp):
 
 
 STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
-                 "blur": ["blur_kernel"], "describe": ["describe_kernel"], "match": ["match_seq_kernel"],
+                 "blur": ["blur_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
+                 "match": ["match_expand_kernel", "match_mfma_kernel", "match_compact_kernel"],
                  "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel"]}
 
 
 def measured_traffic(stage, frames_per_launch):
-    """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
-    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None"""
+    """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes;
+    FETCH_SIZE x 2 on gfx950 for the kernels that read 16 B per lane, raw for the others: scripts/pmc_traffic.py), or None"""
     try:
         k = json.load(open(latest_profile("traffic.json")))["kernels"]
-        return round(sum(v["total_bytes_per_frame_fetch_x2"] for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage])) * frames_per_launch)
+        return round(sum(v.get("total_bytes_per_frame", v["total_bytes_per_frame_fetch_x2"]) for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage])) * frames_per_launch)
     except Exception:
         return None
 
@@ -444,20 +445,14 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv3x3_dma2_kernel + conv3x3_first_kernel (26 conv layers with fused pool / un-pool / ArgMax, prep, colouring: whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
         elif dom == "match":
-            # K6 is VALU-bound by design (the descriptors live in LDS): the contract's HBM figure is computed like for every other stage
-            # (algorithmic bytes: per (ref, cur) pair 32 KB + 32 KB of descriptors in, 16 KB of matches out), and the informative one is `valu`:
-            # 19 VALU instructions per descriptor pair (8 xor, 8 accumulating bcnt, key, med3, min) against the 4-cycle issue ceiling
-            npairs = sum(1 for f in range(F) for r in range(R) if m[f, r] >= 0) / F
+            # K6 runs on the matrix cores (v_mfma_i32_32x32x32_i8 on descriptors expanded to +-1 / +-16 bytes): 2 x 256 integer operations per
+            # descriptor pair, tiles padded to 32 x 64, against the dense i8 peak (2 x the bf16 rate: MI355X_MICROARCH.md, Matrix cores)
             pairs = sum(int(res["nkp"][max(f - R + r, 0)]) * int(res["nkp"][f]) for f in range(F) for r in range(R) if m[f, r] >= 0) / F
-            gb = npairs * (2 * nkp * 32 + nkp * 16) * frames_per_launch / 1e9
-            ach = gb / (ms_per_launch * 1e-3)
-            ops = pairs * 19 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
-            roof = {"bound": "hbm", "kernel": "match_seq_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(dom, frames_per_launch), "algorithmic_bytes_per_launch": round(gb * 1e9),
-                    "note": "brute-force Hamming matcher: data stays in LDS, the bound is VALU issue, not HBM (see `valu`, `match_ops`); DESIGN.md s.4",
-                    "match_ops": {"achieved": round(ops, 2), "peak": VALU_LANEOPS_PEAK / 1e12, "unit": "Tlaneop/s", "frac": round(ops / (VALU_LANEOPS_PEAK / 1e12), 4),
-                                  "frac_of_simple_op_peak": round(ops / (VALU_SIMPLE_OP_PEAK / 1e12), 4), "ops_per_descriptor_pair": 19,
-                                  "descriptor_pairs_per_frame": round(pairs)}}
+            tops = pairs * 512 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "match_mfma_kernel (+ match_expand_kernel, match_compact_kernel)", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (i8)",
+                    "frac": round(tops / 5000.0, 4), "traffic": measured_traffic(dom, frames_per_launch),
+                    "note": "Hamming distance matrix as an exact i8 matrix product; algorithmic operations only (the padding of 1000 descriptors to 1024 is not counted); DESIGN.md s.4",
+                    "descriptor_pairs_per_frame": round(pairs)}
         else:
             gb = algorithmic_bytes(dom, P, nkp) * frames_per_launch / 1e9
             ach = gb / (ms_per_launch * 1e-3)

@@ -23,12 +23,18 @@ def load(d, counter):
     return tot, calls
 
 
+# Calibration (scripts/ubench/fetch_calib.hip, 1 GiB streams, profiles/r02_fetch_calib.md): FETCH_SIZE reports 0.500 of the bytes for EVERY read pattern
+# these kernels use (contiguous / 32-B / 48-B strided 16-byte loads, dwords, 12-B strided dwords; 0.516 for unaligned 16-byte loads), WRITE_SIZE is exact
+# for dword and 16-byte stores: so fetch x 2 + write, for every kernel.
+
+
 def main():
     fd, wd, out = sys.argv[1:4]
     fpl = int(sys.argv[4]) if len(sys.argv) > 4 else 125
-    frames_total = int(sys.argv[5]) if len(sys.argv) > 5 else 1000      # frames processed in the profiled run (steps x frames)
     fetch, fc = load(fd, "FETCH_SIZE")
     write, wc = load(wd, "WRITE_SIZE")
+    # frames processed in the profiled run: every sub-batch launches fast_kernel once (bench.py runs the steps twice: the timed pass and the serialised pass)
+    frames_total = int(sys.argv[5]) if len(sys.argv) > 5 else fpl * max(fc.get("fast_kernel", 0), wc.get("fast_kernel", 0), 1)
     res = {}
     for k in sorted(set(fetch) | set(write)):
         if "rocprim" in k or "rocclr" in k:
@@ -40,10 +46,12 @@ def main():
                   "bytes_per_frame_raw": (f_kib + w_kib) * 1024 / fpl, "bytes_per_frame_fetch_x2": (2 * f_kib + w_kib) * 1024 / fpl,
                   "total_bytes_per_frame_fetch_x2": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / frames_total,
                   "total_bytes_per_frame_raw": (fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / frames_total}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 under-reports wide coalesced reads by 2x "
-                       "(MI355X_MICROARCH.md s.HBM): *_x2 applies that correction, narrow (<16 B/lane) access patterns are uncalibrated",
+        res[k]["total_bytes_per_frame"] = res[k]["total_bytes_per_frame_fetch_x2"]
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 reports half of the bytes read "
+                       "(MI355X_MICROARCH.md s.HBM; calibrated for this repo's access patterns by scripts/ubench/fetch_calib.hip): total = fetch x 2 + write",
+               "frames_in_profiled_run": frames_total,
                "kernels": res}, open(out, "w"), indent=1)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["total_bytes_per_frame_fetch_x2"]):
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["total_bytes_per_frame"]):
         print(f"{k[:36]:36s} launches {v['launches']:4d}  HBM bytes per frame (all launches): raw {v['total_bytes_per_frame_raw'] / 1e6:8.3f} MB   fetch x2 {v['total_bytes_per_frame_fetch_x2'] / 1e6:8.3f} MB")
 
 
