@@ -70,6 +70,7 @@ struct ssm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;      // ssm_seq_process: the SegNet + map stage of a sub-batch runs here, beside the ORB + match chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr; uint8_t* d_mask3 = nullptr; int map_stream = 1;   // two-chain mode: the map stage on a stream of its own (SSM_MAP_STREAM=0: on the chain's stream)
     ssm_config cfg{};
     OrbGeom g{};
     std::string err;
@@ -96,7 +97,7 @@ struct ssm_ctx {
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
-    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
+    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
     VoxTable map, tmp;
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
@@ -282,6 +283,7 @@ static int ctx_init(ssm_ctx* c)
     const ssm_config& cfg = c->cfg; const OrbGeom& g = c->g; const int B = c->B, W = g.W, H = g.H;
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[1], hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
@@ -346,6 +348,8 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SSM_E_HIP; }
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
+    { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
+    { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
     { const char* e = getenv("SSM_MATCH_VARIANT"); c->match_mfma = !(e && atoi(e) == 0); }      // 0: the VALU matcher in the sequence path (A/B runs)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
     int r = build_geometry(*cfg, c->g, c->err);
@@ -387,6 +391,9 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream3) hipStreamDestroy(c->stream3);
+    if (c->ev_join3) hipEventDestroy(c->ev_join3);
+    if (c->d_mask3) hipFree(c->d_mask3);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     delete c;
@@ -431,6 +438,7 @@ static int ensure_alt(ssm_ctx* c)
     DALLOC(c, c->alt.cand, (size_t)B * g.cand_total); DALLOC(c, c->alt.nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->alt.ncand, (size_t)B * g.nlevels); DALLOC(c, c->alt.sel, (size_t)B * g.sel_total); DALLOC(c, c->alt.nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H); DALLOC(c, c->alt.kpaux, (size_t)B * g.sel_total * 2);
+    DALLOC(c, c->d_mask3, (size_t)B * g.W * g.H);
     c->alt.ready = true;
     return SSM_OK;
 }
@@ -881,6 +889,8 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     const bool side = side_work && !c->serialize && !two_chains;
     if (two_chains) { r = ensure_alt(c); if (r) return r; }
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    const bool map3 = two_chains && c->map_stream == 1;
+    if (map3) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
     struct StreamSwap {               // the helpers below launch on c->stream; point it at stream2 for the side work
         ssm_ctx* c; bool on;
         StreamSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) std::swap(c->stream, c->stream2); }
@@ -891,58 +901,73 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         const int nb = (n - f0 < c->B) ? n - f0 : c->B;
         const int chain = two_chains ? (bi & 1) : 0;
         ChainSwap cs(c, chain == 1);                                      // from here c->stream / c->d_* are this chain's
-        if (stages & SSM_STAGE_ORB) {
-            r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
-                        c->d_kps + (size_t)f0 * g.cap, desc + (size_t)f0 * row, c->d_pos3d + (size_t)f0 * g.cap * 3, nkp + f0);
-            if (r) return r;
-            if (mfma) { prof_begin(c, "match"); HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream)); prof_end(c); }
-            if (two_chains) {
-                HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
-                if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[chain ^ 1], 0));     // the previous sub-batch's descriptors
+        auto front = [&]() -> int {                                       // ORB -> match of this sub-batch
+            if (stages & SSM_STAGE_ORB) {
+                r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
+                            c->d_kps + (size_t)f0 * g.cap, desc + (size_t)f0 * row, c->d_pos3d + (size_t)f0 * g.cap * 3, nkp + f0);
+                if (r) return r;
+                if (mfma) { prof_begin(c, "match"); HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream)); prof_end(c); }
+                if (two_chains) {
+                    HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
+                    if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[chain ^ 1], 0));     // the previous sub-batch's descriptors
+                }
             }
-        }
-        if (stages & SSM_STAGE_MATCH) {
-            prof_begin(c, "match");
-            if (mfma) {
-                if (!(stages & SSM_STAGE_ORB)) HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream));
-                HIPCHK(c, k_match_seq_mfma(c->d_exp_q, c->d_exp_t, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->capT, c->d_knn, c->d_matches, c->d_nmatch, c->stream));
-            } else
-                HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend + (size_t)f0 * R, c->stream));
-            prof_end(c);
-        }
-        if (!side_work) continue;
-        StreamSwap sw(c, side);
-        hipStream_t s = c->stream;                                    // = stream2 inside this scope (unless serialised)
-        const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
-        if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
-            r = seg_init(c); if (r) return r;
-            prof_begin(c, "segnet");
-            r = seg_forward_dev(c, in->bgr + (size_t)f0 * npix * 3, nb, nullptr, c->seg->d_sem_gen, 0); if (r) return r;
-            prof_end(c);
-            sem_src = c->seg->d_sem_gen;
-        }
-        if (stages & SSM_STAGE_MAP) {
-            if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
-                prof_begin(c, "map_fuse");
-                HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src,
-                                     in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                     (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(c->d_mask), reinterpret_cast<uint16_t*>(c->d_mask) + (size_t)nb * (W >> 4) * H,
-                                     c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
-                prof_end(c);
-            } else {                     // odd widths: mask -> ordered back-projection -> insert
-                prof_begin(c, "mask");
-                HIPCHK(c, k_moving_mask(sem_src, nb, W, H, c->d_mask, s)); prof_end(c);
-                prof_begin(c, "backproject");
-                HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src, c->d_mask,
-                                        in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                        c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
-                prof_begin(c, "voxel_insert");
-                HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nb * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
+            if (stages & SSM_STAGE_MATCH) {
+                prof_begin(c, "match");
+                if (mfma) {
+                    if (!(stages & SSM_STAGE_ORB)) HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream));
+                    HIPCHK(c, k_match_seq_mfma(c->d_exp_q, c->d_exp_t, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->capT, c->d_knn, c->d_matches, c->d_nmatch, c->stream));
+                } else
+                    HIPCHK(c, k_match_seq(c->d_desc_all, c->d_nkp_all, f0, nb, R, R, c->cfg.knn_match_ratio, g.cap, c->d_matches, c->d_nmatch, c->d_match_pend + (size_t)f0 * R, c->stream));
                 prof_end(c);
             }
-        }
+            return SSM_OK;
+        };
+        auto back = [&]() -> int {                                        // (SegNet ->) map of this sub-batch
+            if (!side_work) return SSM_OK;
+            StreamSwap sw(c, side);
+            hipStream_t s = map3 ? c->stream3 : c->stream;                // = stream2 inside this scope (unless serialised)
+            uint8_t* mask_ws = map3 ? c->d_mask3 : c->d_mask;
+            const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
+            if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
+                r = seg_init(c); if (r) return r;
+                prof_begin(c, "segnet");
+                r = seg_forward_dev(c, in->bgr + (size_t)f0 * npix * 3, nb, nullptr, c->seg->d_sem_gen, 0); if (r) return r;
+                prof_end(c);
+                sem_src = c->seg->d_sem_gen;
+            }
+            if (stages & SSM_STAGE_MAP) {
+                if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
+                    prof_begin(c, "map_fuse");
+                    HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src,
+                                         in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                         (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(mask_ws), reinterpret_cast<uint16_t*>(mask_ws) + (size_t)nb * (W >> 4) * H,
+                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
+                    prof_end(c);
+                } else {                     // odd widths: mask -> ordered back-projection -> insert
+                    prof_begin(c, "mask");
+                    HIPCHK(c, k_moving_mask(sem_src, nb, W, H, c->d_mask, s)); prof_end(c);
+                    prof_begin(c, "backproject");
+                    HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src, c->d_mask,
+                                            in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                            c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
+                    prof_begin(c, "voxel_insert");
+                    HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nb * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
+                    prof_end(c);
+                }
+            }
+            return SSM_OK;
+        };
+        // The map stage shares no data with the ORB -> match chain: in two-chain mode it runs on a third stream (all sub-batches in order, one workspace),
+        // so that the chains' latency-bound kernels (pyramid, quad-tree, orientation / BRIEF gathers) always have VALU-bound map work beside them
+        // (+4 % over map-after-match on the chain's own stream).  With SSM_MAP_STREAM=0 chain 1 runs it FIRST instead, which puts the two chains half a
+        // sub-batch out of step (+2.4 %)
+        const bool map_first = two_chains && chain == 1 && c->map_first;
+        if (map_first) { r = back(); if (r) return r; r = front(); if (r) return r; }
+        else           { r = front(); if (r) return r; r = back(); if (r) return r; }
     }
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (map3) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
     c->prev_n = n;
     if (out) {
         out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;
