@@ -277,6 +277,167 @@ hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ K5a on the matrix cores
+// The same 7x7 fixed-point Gaussian as two exact integer matrix products per 32-column unit (v_mfma_i32_32x32x32_i8):
+//   row pass     R[y][x'] = sum_k (p[y][c0 - 16 + k] - 128) * T[k][x'] + 128 * 257        A = pixels (lane = image row, 16 consecutive bytes per K half),
+//                                                                                       B = a banded matrix of the taps (constant per unit column; it also folds
+//                                                                                       BORDER_REFLECT_101 of the columns in: a tap that falls outside the image
+//                                                                                       is added to the coefficient of the column it reflects to) -> R is the exact
+//                                                                                       u16 row sum, lane = column x', registers = rows
+//   column pass  Z[x'][y'] = sum_i R[i][x'] * tc[i - y']                                 the accumulator tile is the A operand as it stands (X^T B form: the sum
+//                                                                                       runs over its register index), split into its low and high bytes (two
+//                                                                                       products, v = 256 ZH + ZL), B = the banded tap matrix in the accumulator's
+//                                                                                       own row order -> lane = output row, registers = 4 x 4 consecutive columns
+// Rows reflect as whole rows when the block stages its 64 input rows (58 output rows + 6) in LDS (coalesced 16-byte loads, p - 128 applied there); the
+// output leaves through an LDS tile as whole 128-byte rows.  Per pixel the VALU only repacks bytes (v_perm) and shifts / saturates the result: about a
+// quarter of the instructions of blur_kernel, which is VALU-issue bound.  Bit-exact with it (all sums are exact integers).
+// Coefficient table (built on the host by blur_mfma_tables): [F_same: 64 x 16 B][F_next: 64 x 16 B] then per level and 32-column unit [K half s: 2][lane: 64] x 16 B.
+#define BM_IN_RS 176      // bytes between staged input rows (160 used: columns [X0 - 16, X0 + 144))
+#define BM_OUT_RS 144     // bytes between rows of the output tile (128 used)
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+typedef int bm_v16i __attribute__((ext_vector_type(16)));
+size_t blur_mfma_table_bytes(const OrbGeom& g) { return (size_t)(128 + 128 * g.bt_units_total) * 16; }
+void blur_mfma_tables(const OrbGeom& g, void* host_out)
+{
+    static const int tc[7] = {18, 34, 49, 55, 49, 34, 18};
+    int8_t* o = reinterpret_cast<int8_t*>(host_out);
+    auto refl = [](int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return i < 0 ? 0 : (i >= n ? n - 1 : i); };
+    for (int which = 0; which < 2; which++)                       // column pass: B[k][n], k in the accumulator's row order: element j of lane half h = row 8 (j >> 2) + 4 h + (j & 3)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 16; j++) {
+                const int n = lane & 31, h = lane >> 5, k = 8 * (j >> 2) + 4 * h + (j & 3) + 32 * which, d = k - n;
+                o[(which * 64 + lane) * 16 + j] = (int8_t)((d >= 0 && d <= 6) ? tc[d] : 0);
+            }
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.L[l];
+        for (int u = 0; u < (L.stride + 31) / 32; u++)
+            for (int s = 0; s < 2; s++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 16; j++) {
+                        const int n = lane & 31, h = lane >> 5, k = 32 * s + 16 * h + j;
+                        const int x_in = 32 * u - 16 + k, x_out = 32 * u + n;
+                        int coef = 0;
+                        if (x_out < L.w) for (int t = 0; t < 7; t++) if (refl(x_out + t - 3, L.w) == x_in) coef += tc[t];
+                        o[((size_t)(128 + (L.bt_units_off + u) * 128 + s * 64 + lane)) * 16 + j] = (int8_t)coef;
+                    }
+    }
+}
+__global__ void __launch_bounds__(256, 4)                    // 128 registers: four blocks per CU
+blur_mfma_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom g, const uint4* __restrict__ tab, int nframes)
+{
+    // One block = one 128-column strip of one level of one frame, walked top to bottom in steps of 58 output rows: the 64 input rows of the next step are
+    // loaded (into registers) before the current step computes, so only the first step of a strip waits for memory.  blockIdx.y = strip over all levels.
+    const int frame = blockIdx.x, strip = blockIdx.y;            // frame-fastest launch order: see blur_kernel
+    if (frame >= nframes) return;
+    __shared__ __attribute__((aligned(16))) uint8_t sin[64 * BM_IN_RS];
+    __shared__ __attribute__((aligned(16))) uint8_t sout[64 * BM_OUT_RS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, hh = lane >> 5;
+    int l = 0;
+    while (l + 1 < g.nlevels && strip >= g.L[l+1].bt_off) l++;
+    const LevelGeom& L = g.L[l];
+    const int X0 = (strip - L.bt_off) * 128;
+    const int w = L.w, h = L.h, stride = L.stride;
+    const uint8_t* src = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
+    uint8_t* dst = blur + (size_t)frame * g.pyr_bytes + L.img_off;
+    auto ld = [](const uint4* p) { const uint4 v = *p; return bm_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
+    const int c0 = X0 + 32 * wv;
+    const bool active = c0 < stride;
+    const uint4* T1 = tab + 128 + (size_t)(L.bt_units_off + (active ? (c0 >> 5) : 0)) * 128 + lane;
+    const bm_v4i B0 = ld(T1), B1 = ld(T1 + 64), Fs = ld(tab + lane), Fn = ld(tab + 64 + lane);
+    uint32_t cmask[4];                                                   // the padding columns [w, stride) stay zero: dword q of a lane holds columns c0 + 8 q + 4 hh .. + 3
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int left = w - (c0 + 8 * q + 4 * hh); cmask[q] = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - left)))); }
+    // a thread's staging slots: words i = tid, tid + 256, tid + 512 (< 640) of the 64 x 10 input words; (row, q) are the same in every step
+    int srow[3], sq[3]; bool sok[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = tid + 256 * k;
+        srow[k] = (i * 6554) >> 16; sq[k] = i - srow[k] * 10;             // i / 10 for i < 640
+        const int gx = X0 - 16 + 16 * sq[k];
+        sok[k] = i < 640 && gx >= 0 && gx < stride;                        // words outside [0, stride) are never multiplied by a non-zero coefficient
+    }
+    uint4 pre[3];
+    auto fetch = [&](int y0) {                                            // rows y0 - 3 .. y0 + 60, reflected as whole rows
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pre[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+            if (sok[k]) pre[k] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(y0 - 3 + srow[k], h) * stride + (X0 - 16 + 16 * sq[k]));
+        }
+    };
+    fetch(0);
+    for (int y0 = 0; y0 < h; y0 += BLUR_ROWS) {
+        // stage p - 128 (the fetch was issued one step ago), then start the next step's loads
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (tid + 256 * k < 640)
+                *reinterpret_cast<uint4*>(sin + srow[k] * BM_IN_RS + 16 * sq[k]) = make_uint4(pre[k].x ^ 0x80808080u, pre[k].y ^ 0x80808080u, pre[k].z ^ 0x80808080u, pre[k].w ^ 0x80808080u);
+        if (y0 + BLUR_ROWS < h) fetch(y0 + BLUR_ROWS);
+        __syncthreads();
+        if (active) {
+            const uint8_t* ap = sin + r * BM_IN_RS + 32 * wv + 16 * hh;
+            bm_v16i CL, CH;                                               // 32 registers of constants: the row pass shares CH (its padding columns are masked at the end instead)
+#pragma unroll
+            for (int i = 0; i < 16; i++) { CL[i] = 128 * 257 + 32768; CH[i] = 128 * 257; }
+            // the row sums (< 65536) as two planes of signed bytes, 16 registers -> 4 + 4: element j of the fragment = register j
+            auto planes = [](const bm_v16i& R, bm_v4i& lo, bm_v4i& hi) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t a = (uint32_t)R[4*q], b = (uint32_t)R[4*q+1], c = (uint32_t)R[4*q+2], d = (uint32_t)R[4*q+3];
+                    const uint32_t l01 = __builtin_amdgcn_perm(b, a, 0x0C0C0400u), l23 = __builtin_amdgcn_perm(d, c, 0x0C0C0400u);
+                    const uint32_t h01 = __builtin_amdgcn_perm(b, a, 0x0C0C0501u), h23 = __builtin_amdgcn_perm(d, c, 0x0C0C0501u);
+                    lo[q] = (int)(__builtin_amdgcn_perm(l23, l01, 0x05040100u) ^ 0x80808080u);
+                    hi[q] = (int)(__builtin_amdgcn_perm(h23, h01, 0x05040100u) ^ 0x80808080u);
+                }
+            };
+            // one 32-row tile of row sums at a time (fences: the second tile's fragments and accumulator re-use the first one's registers)
+            bm_v4i L0, H0, L1, H1;
+            {   const bm_v4i A0 = ld(reinterpret_cast<const uint4*>(ap)), A1 = ld(reinterpret_cast<const uint4*>(ap + 32));
+                bm_v16i R = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, CH, 0, 0, 0);
+                R = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B1, R, 0, 0, 0);
+                planes(R, L0, H0); }
+            __builtin_amdgcn_sched_barrier(0);
+            {   const bm_v4i A0 = ld(reinterpret_cast<const uint4*>(ap + 32 * BM_IN_RS)), A1 = ld(reinterpret_cast<const uint4*>(ap + 32 * BM_IN_RS + 32));
+                bm_v16i R = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, CH, 0, 0, 0);
+                R = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B1, R, 0, 0, 0);
+                planes(R, L1, H1); }
+            __builtin_amdgcn_sched_barrier(0);
+            // v = 256 ZH + ZL (the rounding constant rode in with CL); (v >> 16) saturated = byte 2 of min(v, 0xFFFFFF); registers 4q .. 4q + 3 of a lane
+            // are four consecutive columns of output row (lane & 31): one dword of the output tile
+            auto emit = [&](const bm_v16i& ZL, const bm_v16i& ZH, int tile) {
+                uint8_t* o = sout + (32 * tile + r) * BM_OUT_RS + 32 * wv + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = min(((uint32_t)ZH[4*q+k] << 8) + (uint32_t)ZL[4*q+k], 0xFFFFFFu);
+                    const uint32_t p01 = __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0602u), p23 = __builtin_amdgcn_perm(v[3], v[2], 0x0C0C0602u);
+                    *reinterpret_cast<uint32_t*>(o + 8 * q) = __builtin_amdgcn_perm(p23, p01, 0x05040100u) & cmask[q];
+                }
+            };
+            // output rows 0..31 take input rows 0..37 (both tiles), output rows 32..57 input rows 32..63 (the second tile only)
+            bm_v16i ZL = __builtin_amdgcn_mfma_i32_32x32x32_i8(L0, Fs, CL, 0, 0, 0);
+            bm_v16i ZH = __builtin_amdgcn_mfma_i32_32x32x32_i8(H0, Fs, CH, 0, 0, 0);
+            ZL = __builtin_amdgcn_mfma_i32_32x32x32_i8(L1, Fn, ZL, 0, 0, 0);
+            ZH = __builtin_amdgcn_mfma_i32_32x32x32_i8(H1, Fn, ZH, 0, 0, 0);
+            emit(ZL, ZH, 0);
+            __builtin_amdgcn_sched_barrier(0);                           // the second output tile re-uses the first one's registers
+            ZL = __builtin_amdgcn_mfma_i32_32x32x32_i8(L1, Fs, CL, 0, 0, 0);
+            ZH = __builtin_amdgcn_mfma_i32_32x32x32_i8(H1, Fs, CH, 0, 0, 0);
+            emit(ZL, ZH, 1);
+        }
+        __syncthreads();
+        for (int i = tid; i < BLUR_ROWS * 8; i += 256) {
+            const int row = i >> 3, q = i & 7, gx = X0 + 16 * q, gy = y0 + row;
+            if (gx < stride && gy < h) *reinterpret_cast<uint4*>(dst + (size_t)gy * stride + gx) = *reinterpret_cast<const uint4*>(sout + row * BM_OUT_RS + 16 * q);
+        }
+    }
+}
+hipError_t k_blur_mfma(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, const void* tab, hipStream_t s)
+{
+    blur_mfma_kernel<<<dim3((n + 7) & ~7, g.bt_total), 256, 0, s>>>(pyr, blur, g, reinterpret_cast<const uint4*>(tab), n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ K3: per-cell FAST-9/16 + NMS
 // ORBextractor runs cv::FAST on every cell of a 30-px grid (sub-image = cell + 3-px margin): S = max over the 16 arcs of
 // 9 of the arc-min of (ring - v) / (v - ring); corner at t iff S > t; response = S - 1; NMS keeps a corner whose

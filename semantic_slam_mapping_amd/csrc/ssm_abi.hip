@@ -76,6 +76,7 @@ struct ssm_ctx {
     std::string err;
     int B = 1, R = 5;
     // constant tables
+    void* d_blur_tab = nullptr; bool blur_mfma = true;                 // blur_mfma_kernel's coefficient fragments (kernels_orb.hip); SSM_BLUR_VARIANT=0: the VALU kernel
     int8_t* d_pattern = nullptr; float* d_pattern_f = nullptr;      // the BRIEF table as given, and as floats for brief_kernel
     int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
     void* d_xgrp[SSM_MAX_LEVELS] = {};       // resize4_kernel's per-group constants (null: the level uses the general resize kernel)
@@ -150,7 +151,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         for (int v = SSM_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
         for (int v = 0; v <= SSM_HALF_PATCH; v++) g.umax[v] = um[v];
     }
-    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0;
+    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0, btiles = 0, bunits = 0;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.L[l];
         L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
@@ -164,6 +165,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         L.mulW = (uint32_t)(((1ull << 32) + L.wCell - 1) / L.wCell); L.mulH = (uint32_t)(((1ull << 32) + L.hCell - 1) / L.hCell);
         L.cell_off = cells; cells += L.nCols * L.nRows;
         L.tiles_x = (L.w + 127) / 128; L.mulTX = (uint32_t)(((1ull << 32) + L.tiles_x - 1) / L.tiles_x); L.tile_off = tiles; tiles += L.tiles_x * ((L.h + 31) / 32);
+        L.bt_x = (L.stride + 127) / 128; L.bt_off = btiles; btiles += L.bt_x; L.bt_units_off = bunits; bunits += (L.stride + 31) / 32;
         if (L.nCols * L.nRows >= (1 << 17)) { err = "too many FAST cells"; return SSM_E_INVAL; }
         L.nfeat = feat[l];
         if (L.nfeat + 3 > SSM_MAX_NODES - 8) { err = "too many features per level for the LDS quad-tree (max 1013 per level)"; return SSM_E_INVAL; }
@@ -175,6 +177,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         if (4 * nIni + 8 > SSM_MAX_NODES) { err = "aspect ratio too extreme"; return SSM_E_INVAL; }
         L.sf = sf[l];
     }
+    g.bt_total = btiles; g.bt_units_total = bunits;
     g.pyr_bytes = off; g.tiles_total = tiles; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
     g.cap = c.orb_features + 3 * g.nlevels;
     return SSM_OK;
@@ -290,6 +293,10 @@ static int ctx_init(ssm_ctx* c)
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
     {   float pf[1024]; const int8_t* src = cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern;
         for (int i = 0; i < 1024; i++) pf[i] = (float)src[i];
+        { const char* e = getenv("SSM_BLUR_VARIANT"); c->blur_mfma = !(e && atoi(e) == 0); }
+        { std::vector<uint8_t> bt(blur_mfma_table_bytes(c->g)); blur_mfma_tables(c->g, bt.data());
+          uint8_t* dbt; DALLOC(c, dbt, bt.size()); c->d_blur_tab = dbt;
+          HIPCHK(c, hipMemcpy(c->d_blur_tab, bt.data(), bt.size(), hipMemcpyHostToDevice)); }
         DALLOC(c, c->d_pattern_f, 1024);
         HIPCHK(c, hipMemcpy(c->d_pattern_f, pf, sizeof(pf), hipMemcpyHostToDevice)); }
     for (int l = 1; l < g.nlevels; l++) {
@@ -369,7 +376,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
-                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn };
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn, c->d_blur_tab };
     for (void* p : ptrs) if (p) hipFree(p);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
@@ -459,7 +466,7 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
     prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(nb, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, c->d_xgrp, s)); prof_end(c);
     prof_begin(c, "fast");      HIPCHK(c, k_fast(nb, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
     prof_begin(c, "octree");    HIPCHK(c, k_octree(nb, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
-    prof_begin(c, "blur");      HIPCHK(c, k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
+    prof_begin(c, "blur");      HIPCHK(c, c->blur_mfma ? k_blur_mfma(nb, g, c->d_pyr, c->d_blur, c->d_blur_tab, s) : k_blur(nb, g, c->d_pyr, c->d_blur, s)); prof_end(c);
     prof_begin(c, "describe");  HIPCHK(c, k_describe(nb, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern_f, d_depth, c->cfg.camera, c->d_kpaux, kps, desc, pos3d, nkp, s)); prof_end(c);
     return SSM_OK;
 }

@@ -25,12 +25,14 @@ struct LevelGeom {
     float hX;                  // root node width
     float sf;                  // mvScaleFactor[level]
     uint32_t mulTX;            // ceil(2^32 / tiles_x), same use
+    int bt_off, bt_x, bt_units_off;   // blur_mfma_kernel: first 128-column strip of the level, strips of the level, first 32-column unit table
     uint32_t mulW, mulH;       // ceil(2^32 / wCell), ceil(2^32 / hCell): floor(n / cell) == __umulhi(n, mul) for n < 4096 (exact: n * (mul * cell - 2^32) < 2^32)
 };
 struct OrbGeom {
     int nlevels, W, H;
     int pyr_bytes;             // one frame's pyramid (all levels)
     int cells_total, cand_total, sel_total, tiles_total;
+    int bt_total, bt_units_total;   // blur_mfma_kernel strips (= blocks) per frame, 32-column unit tables
     int cap;                   // output keypoints per frame (orb_features + 3*levels)
     int ini_th, min_th;
     int umax[SSM_HALF_PATCH + 1];
@@ -45,6 +47,11 @@ hipError_t k_copy_gray_strided(const uint8_t* img, int stride, const OrbGeom& g,
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
                      const int32_t* const* yofs, const int16_t* const* ya, const void* const* xgroups, hipStream_t s);
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s);
+// the same blur on the matrix cores; tab = blur_mfma_tables() on the device
+#define BLUR_ROWS 58           // output rows of one blur_mfma block (64 input rows)
+hipError_t k_blur_mfma(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, const void* tab, hipStream_t s);
+size_t blur_mfma_table_bytes(const OrbGeom& g);
+void blur_mfma_tables(const OrbGeom& g, void* host_out);
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s);
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s);
