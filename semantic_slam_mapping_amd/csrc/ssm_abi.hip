@@ -511,6 +511,37 @@ static int match_host(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, in
     if (nt < 2) FAIL(c, SSM_E_TOO_FEW_TRAIN, "knnMatch(k=2) needs at least 2 train descriptors");
     if (nt > 65535) FAIL(c, SSM_E_INVAL, "at most 65535 train descriptors per call");
     if (nq == 0) { if (n_out) *n_out = 0; return SSM_OK; }
+    if (c->match_mfma) {
+        // the matrix-core matcher of the sequence path on a two-row "sequence": row 0 = the query set (reference frame), row 1 = the train set
+        const int capm = nq > nt ? nq : nt, capT = (capm + 31) & ~31;
+        const size_t rowb = (size_t)capm * 32, expb = (size_t)2 * capT * 256;
+        const size_t need = 2 * rowb + 16 + 2 * expb + (size_t)capT * 8 + (size_t)nq * sizeof(ssm_dmatch) + 64;
+        int r = ensure_scratch(c, need); if (r) return r;
+        uint8_t* dd = reinterpret_cast<uint8_t*>(c->d_scratch);
+        int32_t* dnk = reinterpret_cast<int32_t*>(dd + 2 * rowb);
+        uint8_t* eq = reinterpret_cast<uint8_t*>(dnk) + 16; uint8_t* et = eq + expb;
+        uint2* knn = reinterpret_cast<uint2*>(et + expb);
+        ssm_dmatch* dm = reinterpret_cast<ssm_dmatch*>(knn + capT); int32_t* dn = reinterpret_cast<int32_t*>(dm + nq);
+        const int32_t hn[2] = {nq, nt};
+        HIPCHK(c, hipMemcpyAsync(dd, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dd + rowb, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dnk, hn, 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, k_match_expand(dd, dnk, 0, 2, capm, capT, eq, et, c->stream));
+        HIPCHK(c, k_match_seq_mfma(eq, et, dnk, 0, 1, 1, 1, ratio, capm, capT, knn, dm, dn, c->stream));
+        int n = 0;
+        HIPCHK(c, hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (want_knn) {
+            std::vector<uint2> hk((size_t)nq);
+            HIPCHK(c, hipMemcpy(hk.data(), knn, (size_t)nq * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < nq; i++) { idx[2*i] = hk[i].x & 0xFFFF; idx[2*i+1] = hk[i].y & 0xFFFF; dist[2*i] = hk[i].x >> 16; dist[2*i+1] = hk[i].y >> 16; }
+        } else {
+            *n_out = n;
+            if (n > cap) FAIL(c, SSM_E_CAPACITY, "match buffer too small (need " + std::to_string(n) + ")");
+            HIPCHK(c, hipMemcpy(out, dm, sizeof(ssm_dmatch) * n, hipMemcpyDeviceToHost));
+        }
+        return SSM_OK;
+    }
     const size_t need = (size_t)(nq + nt) * 32 + sizeof(MatchPair) + (size_t)nq * (16 + 16) + 64;
     int r = ensure_scratch(c, need); if (r) return r;
     uint8_t* dd = reinterpret_cast<uint8_t*>(c->d_scratch);

@@ -559,3 +559,61 @@ def test_sequence_with_sparse_and_empty_frames(oracle):
         for p in bufs:
             c.dev_free(p)
         c.close()
+
+
+def test_valu_variants_of_matcher_and_blur(oracle, frames, monkeypatch):
+    """The matcher and the blur have two implementations each: matrix cores (default) and VALU (SSM_MATCH_VARIANT=0 / SSM_BLUR_VARIANT=0, read when a
+    context is created).  The rest of this file runs the default; this runs the VALU pair through the same checks: host matcher API, ORB of one
+    frame (the descriptors depend on the blur), and a short sequence (match tables) against the oracle."""
+    import semantic_slam_mapping_amd as ssm
+    monkeypatch.setenv("SSM_MATCH_VARIANT", "0")
+    monkeypatch.setenv("SSM_BLUR_VARIANT", "0")
+    c = ssm.Context(0, orb_features=1000, max_batch=4, voxel_capacity_log2=18, camera=CAM)
+    try:
+        rng = np.random.default_rng(77)
+        base = rand_desc(rng, 300)
+        t = np.concatenate([base, base[:50], rand_desc(rng, 683)])      # ties inside, 1033 rows: one partial tile in the matrix-core layout
+        q = np.concatenate([base[:100], rand_desc(rng, 400)])
+        gi, gd = c.knn2(q, t)
+        oi, od = oracle.knn2(q, t)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+        assert same_struct(c.match(q, t, 0.8), oracle.match(q, t, 0.8))
+        check_orb(c, oracle, frames[0][0], frames[0][1])
+        n, W, H, R = 6, 640, 480, c.R
+        bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+        try:
+            c.synth_frames_dev(SEED, 20, n, *bufs)
+            out = c.seq_process(*bufs, n, stages=3)
+            c.sync()
+            res = c.seq_fetch(out, n)
+            descs = []
+            for i in range(n):
+                fr = oracle.synth_frame(SEED, 20 + i)
+                ok, od = oracle.orb_extract(oracle.bgr2gray(fr[0]), nfeatures=1000)
+                k = res["nkp"][i]
+                assert k == len(ok) and np.array_equal(res["desc"][i, :k], od)
+                descs.append(od)
+                for r in range(R):
+                    ref = i - R + r
+                    if ref < 0:
+                        assert res["nmatch"][i, r] == -1
+                        continue
+                    om = oracle.match(descs[ref], od, c.cfg.knn_match_ratio)
+                    assert res["nmatch"][i, r] == len(om) and same_struct(res["matches"][i, r, :len(om)], om)
+        finally:
+            for b in bufs:
+                c.dev_free(b)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(5, 33), (31, 32), (300, 31), (256, 257), (513, 4097)])
+def test_knn2_tile_boundaries(ctx, oracle, nq, nt):
+    """train counts around the 32-row tiles and query counts around the 64 / 256-query blocks of the matrix-core matcher, with many exact ties"""
+    rng = np.random.default_rng(nq * 31 + nt)
+    few = rand_desc(rng, 7)
+    t = few[rng.integers(0, 7, size=nt)]                     # only 7 distinct train rows: every query has large tie groups
+    q = np.concatenate([few, rand_desc(rng, nq)])[:nq]
+    gi, gd = ctx.knn2(q, t)
+    oi, od = oracle.knn2(q, t)
+    assert np.array_equal(gd, od) and np.array_equal(gi, oi)
