@@ -57,7 +57,7 @@ def algorithmic_bytes(stage, P, nkp):
 
 
 STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
-                 "blur": ["blur_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
+                 "blur": ["blur_kernel", "blur_mfma_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
                  "match": ["match_expand_kernel", "match_mfma_kernel", "match_compact_kernel"],
                  "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel"]}
 
