@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
-    ap.add_argument("--stereo-workers", type=int, default=int(os.environ.get("SSM_STEREO_WORKERS", "4")), help="configs[3]: frame pairs in flight (host threads, one context each)")
+    ap.add_argument("--stereo-workers", type=int, default=int(os.environ.get("SSM_STEREO_WORKERS", "8")), help="configs[3]: frame pairs in flight (host threads, one context each)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
