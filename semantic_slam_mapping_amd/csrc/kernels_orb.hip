@@ -120,39 +120,52 @@ resize_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sw, int
 // resident) -- no LDS staging, no barrier, no byte-granular LDS reads.  Per pixel: pick the dword pair, v_alignbyte to bring
 // the two neighbours to the low bytes, v_perm to spread them into 16-bit lanes, v_dot2_u32_u16 with the (a0, a1) pair, then
 // the vertical blend with umulhi on coefficients pre-shifted by 16.  The per-group constants (XGroup) come from the host.
-struct XGroup { uint32_t a[4]; uint32_t base, offs, pad0, pad1; };   // a[k] = a0 | a1 << 16; base = byte offset of the window; offs = 4 bits per pixel
+struct XGroup { uint32_t a[4]; uint32_t base, offs, pad0, pad1; };   // a[k] = a0 | a1 << 16; base = byte offset of pixel 0's left neighbour (any alignment); offs = 4 bits per pixel: its left neighbour's offset from base (<= 6)
 __global__ void __launch_bounds__(256)
 resize4_kernel(uint8_t* __restrict__ pyr, int pyr_bytes, int src_off, int sh, int sstride, int dst_off, int dh, int dstride,
-               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya)
+               const XGroup* __restrict__ xg, const int32_t* __restrict__ yofs, const int16_t* __restrict__ ya, uint32_t mul_groups)
 {
+    // one thread = one 4-pixel column group x FOUR consecutive output rows: the group's constants and the rows' tables are loaded once (two + two 16-byte
+    // loads; the y tables are padded to a multiple of four rows by the host), then the eight source windows are all in flight before the first is used --
+    // with one row per thread every output dword paid two dependent memory latencies (tables, then pixels) and the kernel ran at 2 TB/s
     const int groups = dstride >> 2;
     const int frame = blockIdx.y;                                       // (frame-fastest order measured 5 % slower here: pure streaming, nothing to share)
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= groups * dh) return;
-    const int y = i / groups, g = i - y * groups;
+    if (i >= groups * ((dh + 3) >> 2)) return;
+    const int y4 = (int)__umulhi((uint32_t)i, mul_groups), g = i - y4 * groups, y0 = 4 * y4;       // i / groups by the host's reciprocal (exact: i * groups < 2^32)
     const uint4 A = reinterpret_cast<const uint4*>(xg)[2 * g], Q = reinterpret_cast<const uint4*>(xg)[2 * g + 1];
-    const int syA = yofs[y], syB = min(syA + 1, sh - 1);
-    const uint32_t b0 = (uint32_t)(uint16_t)ya[2 * y] << 16, b1 = (uint32_t)(uint16_t)ya[2 * y + 1] << 16;
-    const uint8_t* src = pyr + (size_t)frame * pyr_bytes + src_off;
-    const uint32_t* r0 = reinterpret_cast<const uint32_t*>(src + (size_t)syA * sstride + Q.x);
-    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(src + (size_t)syB * sstride + Q.x);
-    const uint32_t d00 = r0[0], d01 = r0[1], d02 = r0[2], d10 = r1[0], d11 = r1[1], d12 = r1[2];
-    const uint32_t av[4] = {A.x, A.y, A.z, A.w};
-    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    uint32_t o = 0;
+    const uint4 YO = *reinterpret_cast<const uint4*>(yofs + y0), YA = *reinterpret_cast<const uint4*>(ya + 2 * y0);
+    const uint32_t yo[4] = {YO.x, YO.y, YO.z, YO.w}, yc[4] = {YA.x, YA.y, YA.z, YA.w};
+    const uint8_t* src = pyr + (size_t)frame * pyr_bytes + src_off + Q.x;
+    // the eight bytes that hold the four pixels' neighbour pairs, one (unaligned) 8-byte load per source row; a pixel's pair then comes out of ONE v_perm
+    // whose selector is its offset replicated
+    uint2 r0[4], r1[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t off = (Q.y >> (4 * k)) & 15u;
-        const bool q = off >= 4;
-        const uint32_t w0 = __builtin_amdgcn_alignbyte(q ? d02 : d01, q ? d01 : d00, off & 3u);
-        const uint32_t w1 = __builtin_amdgcn_alignbyte(q ? d12 : d11, q ? d11 : d10, off & 3u);
-        const uint32_t p0 = __builtin_amdgcn_perm(0u, w0, 0x0C010C00u), p1 = __builtin_amdgcn_perm(0u, w1, 0x0C010C00u);   // byte0 | byte1 << 16
-        ushort2v c2, x0, x1; memcpy(&c2, &av[k], 4); memcpy(&x0, &p0, 4); memcpy(&x1, &p1, 4);
-        const uint32_t h0 = __builtin_amdgcn_udot2(x0, c2, 0u, false), h1 = __builtin_amdgcn_udot2(x1, c2, 0u, false);
-        const uint32_t v = (__umulhi(b0, h0 >> 4) + __umulhi(b1, h1 >> 4) + 2u) >> 2;
-        o |= (v & 255u) << (8 * k);
+    for (int j = 0; j < 4; j++) {
+        const int syA = (int)yo[j], syB = min(syA + 1, sh - 1);
+        __builtin_memcpy(&r0[j], src + (size_t)syA * sstride, 8);
+        __builtin_memcpy(&r1[j], src + (size_t)syB * sstride, 8);
     }
-    *reinterpret_cast<uint32_t*>(pyr + (size_t)frame * pyr_bytes + dst_off + (size_t)y * dstride + 4 * g) = o;
+    const uint32_t av[4] = {A.x, A.y, A.z, A.w};
+    uint32_t sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) sel[k] = ((Q.y >> (4 * k)) & 15u) * 0x00010001u + 0x0C010C00u;      // bytes (off, zero, off + 1, zero)
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    uint8_t* dst = pyr + (size_t)frame * pyr_bytes + dst_off + (size_t)y0 * dstride + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t b0 = yc[j] << 16, b1 = yc[j] & 0xFFFF0000u;      // (b0, b1) of the row as u16, pre-shifted by 16
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p0 = __builtin_amdgcn_perm(r0[j].y, r0[j].x, sel[k]), p1 = __builtin_amdgcn_perm(r1[j].y, r1[j].x, sel[k]);
+            ushort2v c2, x0, x1; memcpy(&c2, &av[k], 4); memcpy(&x0, &p0, 4); memcpy(&x1, &p1, 4);
+            const uint32_t h0 = __builtin_amdgcn_udot2(x0, c2, 0u, false), h1 = __builtin_amdgcn_udot2(x1, c2, 0u, false);
+            const uint32_t v = (__umulhi(b0, h0 >> 4) + __umulhi(b1, h1 >> 4) + 2u) >> 2;
+            o |= (v & 255u) << (8 * k);
+        }
+        if (y0 + j < dh) *reinterpret_cast<uint32_t*>(dst + (size_t)j * dstride) = o;
+    }
 }
 hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const* xofs, const int16_t* const* xa,
                      const int32_t* const* yofs, const int16_t* const* ya, const void* const* xgroups, hipStream_t s)
@@ -160,9 +173,10 @@ hipError_t k_pyramid(int n, const OrbGeom& g, uint8_t* pyr, const int32_t* const
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& a = g.L[l-1]; const LevelGeom& b = g.L[l];
         if (xgroups && xgroups[l]) {                                             // streaming form (the host found every window inside 8 bytes)
-            const int items = (b.stride >> 2) * b.h;
+            const int items = (b.stride >> 2) * ((b.h + 3) >> 2);
+            const int groups = b.stride >> 2;
             resize4_kernel<<<dim3((items + 255) / 256, n), 256, 0, s>>>(pyr, g.pyr_bytes, a.img_off, a.h, a.stride, b.img_off, b.h, b.stride,
-                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l]);
+                                                                        reinterpret_cast<const XGroup*>(xgroups[l]), yofs[l], ya[l], (uint32_t)(((1ull << 32) + groups - 1) / groups));
             continue;
         }
         int prows = 256 / (b.stride >> 4); if (prows < 1) prows = 1; if (prows > 24) prows = 24;

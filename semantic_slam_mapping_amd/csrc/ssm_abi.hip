@@ -302,24 +302,25 @@ static int ctx_init(ssm_ctx* c)
     for (int l = 1; l < g.nlevels; l++) {
         std::vector<int32_t> xo, yo; std::vector<int16_t> xa, ya;
         resize_tables(g.L[l-1].w, g.L[l].w, xo, xa); resize_tables(g.L[l-1].h, g.L[l].h, yo, ya);
+        while (yo.size() & 3) { yo.push_back(yo.back()); ya.push_back(ya[ya.size() - 2]); ya.push_back(ya[ya.size() - 2]); }   // resize4_kernel reads the y tables four rows at a time
         DALLOC(c, c->d_xofs[l], xo.size()); DALLOC(c, c->d_xa[l], xa.size()); DALLOC(c, c->d_yofs[l], yo.size()); DALLOC(c, c->d_ya[l], ya.size());
         HIPCHK(c, hipMemcpy(c->d_xofs[l], xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_xa[l], xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_ya[l], ya.data(), ya.size() * 2, hipMemcpyHostToDevice));
-        // per 4-pixel group: the (a0, a1) pairs, the 4-byte-aligned start of the source window and each pixel's byte offset in
-        // it; the streaming kernel needs every offset + 1 inside the first 8 bytes
+        // per 4-pixel group: the (a0, a1) pairs, the byte offset of the first pixel's left neighbour and each pixel's offset from it; the streaming
+        // kernel takes the group's source bytes with one 8-byte load per row, so every offset + 1 must lie inside those 8 bytes
         const int groups = g.L[l].stride / 4, dw = g.L[l].w;
         std::vector<uint32_t> xg((size_t)groups * 8, 0u); bool fits = true;
         for (int q = 0; q < groups; q++) {
             uint32_t* e = &xg[(size_t)q * 8];
             const int x0 = 4 * q;
             if (x0 >= dw) continue;                                               // padding group: coefficients 0 -> zeros, window at 0
-            const int base = (xo[x0] >> 2) << 2;
+            const int base = xo[x0];
             e[4] = (uint32_t)base;
             for (int k = 0; k < 4 && x0 + k < dw; k++) {
                 const int off = xo[x0 + k] - base;
-                if (off < 0 || off > 7) fits = false;
+                if (off < 0 || off > 6) fits = false;
                 e[k] = (uint32_t)(uint16_t)xa[2 * (x0 + k)] | ((uint32_t)(uint16_t)xa[2 * (x0 + k) + 1] << 16);
                 e[5] |= (uint32_t)(off & 15) << (4 * k);
             }
@@ -330,7 +331,7 @@ static int ctx_init(ssm_ctx* c)
             c->d_xgrp[l] = d;
         }
     }
-    // d_pyr + 16: resize4_kernel's 12-byte windows may end past the last row
+    // d_pyr + 16: resize4_kernel's 8-byte windows may end past the last row
     DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
