@@ -1225,27 +1225,39 @@ angle_kernel(OrbGeom g, const KpRec* __restrict__ recs, const uint16_t* __restri
 }
 // value of lane + n inside the 16-lane row (0 beyond the row): the 16 nibbles of one 64-bit descriptor word sit in one row
 #define ROW_SHL(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (n), 0xF, 0xF, true))
+#define BR_KPW 2               // keypoints per wave: the lane's 64 bytes of pattern are loaded once for both, and both patches are in flight together (4 measured slower: LDS halves the occupancy)
 __global__ void __launch_bounds__(256)
 brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restrict__ recs,
              const float* __restrict__ pattern_f, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc, int nframes)
 {
-    __shared__ uint4 pb[4][DP_ROWS_B * DP_QW_B];
+    __shared__ uint4 pb[4][BR_KPW][DP_ROWS_B * DP_QW_B];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.x;       // frame-fastest launch order: see blur_kernel
-    const int slot = blockIdx.y * 4 + wv;
-    if (f >= nframes || slot >= g.sel_total) return;
-    const KpRec rec = recs[(size_t)f * g.sel_total + slot];
-    if (rec.oidx < 0) return;
-    const int oidx = rec.oidx, stride = (int)(rec.stride_level & 0xFFFFu);
-    const int x = rec.pk & 4095;
-    const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + rec.off;            // the keypoint's pixel in the blurred level
-    const int xb0 = (x - 18) & ~15;
-    for (int e = lane; e < DP_ROWS_B * DP_QW_B; e += 64) {
-        const int r = e >> 2, c = e & 3;
-        const int gx = xb0 + 16 * c;
-        pb[wv][e] = gx < stride ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(r - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
+    const int slot0 = (blockIdx.y * 4 + wv) * BR_KPW;
+    if (f >= nframes || slot0 >= g.sel_total) return;
+    KpRec rec[BR_KPW];
+#pragma unroll
+    for (int j = 0; j < BR_KPW; j++) {
+        rec[j].oidx = -1;
+        if (slot0 + j < g.sel_total) rec[j] = recs[(size_t)f * g.sel_total + slot0 + j];
     }
-    const KpAux a = aux[(size_t)f * g.sel_total + slot];
-    const float sb = a.sn, ca = a.cs;
+    int xoff[BR_KPW];
+#pragma unroll
+    for (int j = 0; j < BR_KPW; j++) {
+        xoff[j] = 0;
+        if (rec[j].oidx < 0) continue;
+        const int stride = (int)(rec[j].stride_level & 0xFFFFu), x = rec[j].pk & 4095;
+        const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + rec[j].off;      // the keypoint's pixel in the blurred level
+        const int xb0 = (x - 18) & ~15;
+        xoff[j] = x - xb0;
+        for (int e = lane; e < DP_ROWS_B * DP_QW_B; e += 64) {
+            const int r = e >> 2, c = e & 3;
+            const int gx = xb0 + 16 * c;
+            pb[wv][j][e] = gx < stride ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(r - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    KpAux a[BR_KPW];
+#pragma unroll
+    for (int j = 0; j < BR_KPW; j++) if (rec[j].oidx >= 0) a[j] = aux[(size_t)f * g.sel_total + slot0 + j];
     // steered BRIEF: lane -> 4 of the 256 comparisons.  The pattern arrives as floats (converted once on the host); the rotation runs on packed
     // pairs -- (x0, x1) and (y0, y1) of a comparison through v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiplies and adds in the same order as the
     // scalar form (no contraction) -- and cvRound is the 1.5 * 2^23 trick: adding 12582912.0f rounds to nearest-even in the adder and leaves the
@@ -1253,29 +1265,34 @@ brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restric
     typedef float f2 __attribute__((ext_vector_type(2)));
     const float4* pf = reinterpret_cast<const float4*>(pattern_f) + lane * 4;
     const float4 pq[4] = {pf[0], pf[1], pf[2], pf[3]};
-    const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv]) + 18 * (DP_QW_B * 16) + (x - xb0);      // centre pixel of the blurred patch
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    const f2 s2 = {sb, sb}, c2 = {ca, ca}, magic = {12582912.0f, 12582912.0f};
-    uint32_t nib = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const f2 X = {pq[k].x, pq[k].z}, Y = {pq[k].y, pq[k].w};
-        const f2 xs = X * s2, yc = Y * c2, xc = X * c2, ys = Y * s2;
-        const f2 yy = (xs + yc) + magic, xx = (xc - ys) + magic;
-        // index = yy * 64 + xx with both integers still biased by 0x4B400000: one shift-add, the bias leaves as a constant (mod 2^32)
-        const uint32_t i0 = (__float_as_uint(yy.x) << 6) + __float_as_uint(xx.x) - 0x4B400000u * 65u;
-        const uint32_t i1 = (__float_as_uint(yy.y) << 6) + __float_as_uint(xx.y) - 0x4B400000u * 65u;
-        const int t0 = bb[(int)i0], t1 = bb[(int)i1];
-        nib |= (uint32_t)(t0 < t1) << k;
+    for (int j = 0; j < BR_KPW; j++) {
+        if (rec[j].oidx < 0) continue;
+        const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv][j]) + 18 * (DP_QW_B * 16) + xoff[j];      // centre pixel of the blurred patch
+        const float sb = a[j].sn, ca = a[j].cs;
+        const f2 s2 = {sb, sb}, c2 = {ca, ca}, magic = {12582912.0f, 12582912.0f};
+        uint32_t nib = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f2 X = {pq[k].x, pq[k].z}, Y = {pq[k].y, pq[k].w};
+            const f2 xs = X * s2, yc = Y * c2, xc = X * c2, ys = Y * s2;
+            const f2 yy = (xs + yc) + magic, xx = (xc - ys) + magic;
+            // index = yy * 64 + xx with both integers still biased by 0x4B400000: one shift-add, the bias leaves as a constant (mod 2^32)
+            const uint32_t i0 = (__float_as_uint(yy.x) << 6) + __float_as_uint(xx.x) - 0x4B400000u * 65u;
+            const uint32_t i1 = (__float_as_uint(yy.y) << 6) + __float_as_uint(xx.y) - 0x4B400000u * 65u;
+            const int t0 = bb[(int)i0], t1 = bb[(int)i1];
+            nib |= (uint32_t)(t0 < t1) << k;
+        }
+        // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
+        uint32_t b = nib | (ROW_SHL(nib, 1) << 4);                   // even lanes: one byte
+        b |= ROW_SHL(b, 2) << 8;                                     // lanes %4==0: 2 bytes
+        b |= ROW_SHL(b, 4) << 16;                                    // lanes %8==0: 4 bytes
+        const uint32_t hi = ROW_SHL(b, 8);
+        if ((lane & 15) == 0)
+            reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + rec[j].oidx) * 32)[lane >> 4] = make_uint2(b, hi);
     }
-    // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
-    uint32_t b = nib | (ROW_SHL(nib, 1) << 4);                   // even lanes: one byte
-    b |= ROW_SHL(b, 2) << 8;                                     // lanes %4==0: 2 bytes
-    b |= ROW_SHL(b, 4) << 16;                                    // lanes %8==0: 4 bytes
-    const uint32_t hi = ROW_SHL(b, 8);
-    if ((lane & 15) == 0)
-        reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + oidx) * 32)[lane >> 4] = make_uint2(b, hi);
 }
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
                       const int32_t* nsel, const float* pattern_f, const uint16_t* depth, ssm_camera cam, void* kpaux,
@@ -1288,6 +1305,6 @@ hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t
     kp_prepare_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, recs, nkp);
     orient_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW)), 256, 0, s>>>(g, um, pyr, recs, aux, n);
     angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, recs, depth, cam, aux, kps, pos3d);
-    brief_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 3) / 4), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc, n);
+    brief_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * BR_KPW - 1) / (4 * BR_KPW)), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc, n);
     return hipGetLastError();
 }
