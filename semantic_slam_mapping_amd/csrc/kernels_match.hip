@@ -170,23 +170,30 @@ hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, i
 }
 
 // ------------------------------------------------------------------ the matcher on the matrix cores (sequence path)
-// The Hamming distance matrix of two descriptor sets IS a matrix product: with the query bits expanded to bytes q = -1 / +1 (bit set / clear) and the
-// train bits to t = +16 / -16, sum_k q_k t_k = 16 (H - (256 - H)) = 32 H - 4096, an exact i32 result of v_mfma_i32_32x32x32_i8 (8 K-steps per
-// 256-bit descriptor).  The accumulator is not started at zero but at C[row][col] = 4096 + row, so that a finished 32 x 32 tile holds
-// 32 H + (train index inside the tile): a key whose order is "smaller distance first, equal distances by the lower trainIdx", i.e. the strict '<'
-// scan of oracle/match.c, with no VALU work to build it.  Per value the VALU only keeps the two smallest keys (v_min + v_med3); a tile's two best are
-// widened to (H << 16 | trainIdx) and merged into the running pair.  Integer arithmetic throughout: bit-exact with the VALU matcher above.
+// The Hamming distance matrix of two descriptor sets IS a matrix product: with the query bits expanded to q = -1 / +1 (bit set / clear) and the
+// train bits to t = +16 / -16, sum_k q_k t_k = 16 (H - (256 - H)) = 32 H - 4096.  The elements are FP4 (E2M1: +-1.0 are the nibbles 0x2 / 0xA; the
+// train side's 16 is its block scale 2^4) and the product runs on v_mfma_scale_f32_32x32x64_f8f6f4: 4 K-steps per 256-bit descriptor at the cycles
+// of a bf16 32x32x16, half the matrix time and half the operand bytes of the i8 form (v_mfma_i32_32x32x32_i8, 8 K-steps) this kernel started with;
+// every partial sum is an integer of magnitude <= 4096 + 31, exact in the f32 accumulator whatever the summation order.  The accumulator is not
+// started at zero but at C[row][col] = 4096 + row, so that a finished 32 x 32 tile holds 32 H + (train index inside the tile): a key whose order is
+// "smaller distance first, equal distances by the lower trainIdx", i.e. the strict '<' scan of oracle/match.c, with no VALU work to build it -- and
+// as the keys are non-negative floats, their BIT PATTERNS order like the values: the VALU keeps the two smallest with unsigned integer min / max on
+// the raw registers, and only a tile's two winners are converted (v_cvt_u32_f32), widened to (H << 16 | trainIdx) and merged into the running
+// pair.  Bit-exact with the VALU matcher above.
 //
-// Layout of an expanded descriptor row (one frame): capT = cap rounded up to 32 descriptors, 256 B each, stored per tile of 32 descriptors in MFMA
-// fragment order [K-step s: 8][lane half h: 2][descriptor r: 32][16 B] -- lane (h, r) of a wave takes the 16 bytes k = 32 s + 16 h .. + 15 of
-// descriptor r as its A (train) or B (query) fragment, so a tile is one contiguous 8 KB block and a fragment load is lane * 16 B (A and B use
+// Layout of an expanded descriptor row (one frame): capT = cap rounded up to 32 descriptors, 128 B each, stored per tile of 32 descriptors in MFMA
+// fragment order [K-step s: 4][lane half h: 2][descriptor r: 32][16 B] -- lane (h, r) of a wave takes the 32 nibbles k = 64 s + 32 h .. + 31 of
+// descriptor r as its A (train) or B (query) fragment, so a tile is one contiguous 4 KB block and a fragment load is lane * 16 B (A and B use
 // the same k order, whatever the hardware's, so the sum is over matching k).  Descriptors at or past nkp expand from zero bits; padded trains are
-// excluded by the last tile's C (below), padded queries are never read back.
+// masked in the last tile's tracking pass, padded queries are never read back.
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define MM_QB 256                       // queries per block: 4 waves x 64 (two 32-column accumulators per wave)
-#define MM_TILE 8192                    // bytes of one expanded 32-descriptor tile
+#define MM_DB SSM_MATCH_DESC_BYTES      // bytes of one expanded descriptor (256 FP4 elements)
+#define MM_KS 4                         // K-steps (MFMAs) per 32 x 32 tile
+#define MM_TILE (32 * MM_DB)            // bytes of one expanded 32-descriptor tile
 #ifndef MM_ABLATE
 #define MM_ABLATE 0                     // scripts/ubench/match_bench.hip only (wrong results): 1 no key tracking, 2 no LDS staging / barrier, 4 no train prefetch, 8 no MFMA
 #endif
@@ -196,42 +203,44 @@ match_expand_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict_
                     uint8_t* __restrict__ eq, uint8_t* __restrict__ et)
 {
     const int row = row0 + blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;                       // one 16-byte fragment: i = (tile * 16 + s * 2 + h) * 32 + r
-    if (i >= capT * 16) return;
-    const int r = i & 31, c = (i >> 5) & 15, d = (i >> 9) * 32 + r;
+    const int i = blockIdx.x * 256 + threadIdx.x;                       // one 16-byte fragment (32 bits of a descriptor): i = (tile * 8 + s * 2 + h) * 32 + r
+    if (i >= capT * 8) return;
+    const int r = i & 31, c = (i >> 5) & 7, d = (i >> 8) * 32 + r;
     uint32_t bits = 0;
-    if (d < nkp[row]) bits = *reinterpret_cast<const uint16_t*>(desc + ((size_t)row * cap + d) * 32 + 2 * c);
+    if (d < nkp[row]) bits = *reinterpret_cast<const uint32_t*>(desc + ((size_t)row * cap + d) * 32 + 4 * c);
     uint32_t q[4], t[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t v = (((bits >> (4 * k)) & 15u) * 0x00204081u) & 0x01010101u;     // bit j of the nibble -> byte j = 0 / 1
-        q[k] = v * 0xFEu + 0x01010101u;                                  // 1 -> 0xFF (-1), 0 -> 0x01 (+1)
-        t[k] = (v ^ 0x01010101u) * 0xE0u + 0x10101010u;                  // 1 -> 0x10 (+16), 0 -> 0xF0 (-16)
+        uint32_t v = (bits >> (8 * k)) & 255u;                           // 8 bits -> the low bit of 8 nibbles
+        v = (v | (v << 12)) & 0x000F000Fu;
+        v = (v | (v << 6)) & 0x03030303u;
+        v = (v | (v << 3)) & 0x11111111u;
+        q[k] = (v << 3) + 0x22222222u;                                   // 1 -> 0xA (-1.0), 0 -> 0x2 (+1.0)
+        t[k] = (v << 3) ^ 0xAAAAAAAAu;                                   // 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0); x 16 by the block scale
     }
-    const size_t o = (size_t)row * capT * 256 + (size_t)i * 16;
+    const size_t o = (size_t)row * capT * MM_DB + (size_t)i * 16;
     *reinterpret_cast<uint4*>(eq + o) = make_uint4(q[0], q[1], q[2], q[3]);
     *reinterpret_cast<uint4*>(et + o) = make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // the two smallest of a finished tile (keys 32 H + row), widened and merged into the running pair g0 <= g1 of keys (H << 16 | trainIdx).
-// A tournament of plain min / max / min3 (37 instructions for 16 values): no inline assembly, so the compiler places the wait states an MFMA result
-// needs before its first VALU read, and the scheduler can interleave these instructions with the next tile's MFMAs.
+// Compiler-visible instructions only (v_min_f32 / v_med3_f32; the Makefile builds this file with -fno-honor-nans, otherwise every operand is
+// canonicalised by an extra v_max first): the compiler then places the wait states an MFMA result needs before its first VALU read, and the
+// scheduler can interleave these instructions with the next tile's MFMAs.
 __device__ __forceinline__ void mm_merge2(uint32_t& a0, uint32_t& a1, uint32_t b0, uint32_t b1)     // (a0 <= a1), (b0 <= b1) -> the two smallest of the four
 {
     const uint32_t m = max(a0, b0);
     a0 = min(a0, b0);
     a1 = min(min(m, a1), b1);
 }
-__device__ __forceinline__ void mm_track(const v16i& acc, uint32_t t32, uint32_t& g0, uint32_t& g1)
+__device__ __forceinline__ void mm_track(const v16f& acc, uint32_t t32, uint32_t& g0, uint32_t& g1)
 {
-    uint32_t lo[8], hi[8];
+    // the two smallest of 16 non-negative floats by the sequential form: (l0, l1) <- (min(x, l0), med3(x, l0, l1)), 2 instructions per value
+    float l0 = __builtin_fminf(acc[0], acc[1]), l1 = __builtin_fmaxf(acc[0], acc[1]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { lo[i] = min((uint32_t)acc[2 * i], (uint32_t)acc[2 * i + 1]); hi[i] = max((uint32_t)acc[2 * i], (uint32_t)acc[2 * i + 1]); }
-#pragma unroll
-    for (int i = 0; i < 4; i++) mm_merge2(lo[i], hi[i], lo[i + 4], hi[i + 4]);
-    mm_merge2(lo[0], hi[0], lo[2], hi[2]); mm_merge2(lo[1], hi[1], lo[3], hi[3]);
-    mm_merge2(lo[0], hi[0], lo[1], hi[1]);
-    const uint32_t G0 = ((lo[0] >> 5) << 16) | ((lo[0] & 31u) | t32), G1 = ((hi[0] >> 5) << 16) | ((hi[0] & 31u) | t32);
+    for (int i = 2; i < 16; i++) { l1 = __builtin_amdgcn_fmed3f(acc[i], l0, l1); l0 = __builtin_fminf(acc[i], l0); }
+    const uint32_t k0 = (uint32_t)l0, k1 = (uint32_t)l1;               // v_cvt_u32_f32 (a masked row's 2^20 widens to distance 0x8000)
+    const uint32_t G0 = ((k0 >> 5) << 16) | ((k0 & 31u) | t32), G1 = ((k1 >> 5) << 16) | ((k1 & 31u) | t32);
     mm_merge2(g0, g1, G0, G1);
 }
 
@@ -257,83 +266,86 @@ match_mfma_kernel(const uint8_t* __restrict__ eq, const uint8_t* __restrict__ et
     if (nq < 0 || nt < 2 || qb * MM_QB >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
     const int q0 = qb * MM_QB + wv * 64;
-    // B fragments: the wave's 64 queries, all 8 K-steps, stay in registers
-    v4i b[2][8];
+    // B fragments: the wave's 64 queries, all 4 K-steps, stay in registers
+    v4i b[2][MM_KS];
     {
-        const uint4* qp = reinterpret_cast<const uint4*>(eq + ((size_t)ref * capT + q0) * 256) + lane;
+        const uint4* qp = reinterpret_cast<const uint4*>(eq + ((size_t)ref * capT + q0) * MM_DB) + lane;
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
+            for (int s = 0; s < MM_KS; s++) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (q0 + u * 32 < capT) v = qp[(u * MM_TILE + s * 1024) / 16];
                 b[u][s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
     }
-    v16i cc;                                                            // C of every tile: 4096 + the train row inside the tile
+    v16f cc;                                                            // C of every tile: 4096 + the train row inside the tile
 #pragma unroll
-    for (int i = 0; i < 16; i++) cc[i] = 4096 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    for (int i = 0; i < 16; i++) cc[i] = (float)(4096 + (i & 3) + 8 * (i >> 2) + 4 * h);
     const int ntile = (nt + 31) >> 5;
     uint32_t g0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, g1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-    // Train tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write) through a ring of four 8 KB slots, up to four tiles ahead of the MFMAs:
+    // Train tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write) through a ring of four 4 KB slots, up to four tiles ahead of the MFMAs:
     // with a register-staged double buffer the L2 latency of the next tile was exposed at every barrier and the kernel ran at half the matrix
-    // rate.  Every thread issues exactly two DMA instructions per tile (clamped to the last tile past the end: same bytes, a slot nobody reads),
-    // so "tile T has landed" is always vmcnt(4) + the barrier.
-    const auto rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(et + (size_t)cur * capT * 256), 0, (unsigned)capT * 256u, 0x00020000);
+    // rate.  Every thread issues exactly one DMA instruction per tile (clamped to the last tile past the end: same bytes, a slot nobody reads),
+    // so "tile T has landed" is always vmcnt(2) + the barrier.
+    const auto rsT = __builtin_amdgcn_make_buffer_rsrc((void*)(et + (size_t)cur * capT * MM_DB), 0, (unsigned)capT * MM_DB, 0x00020000);
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     auto dma = [&](int T, uint4* ring) {
         if (MM_ABLATE & 4) return;
         const unsigned o = (unsigned)min(T, ntile - 1) * MM_TILE + (unsigned)(wvu * 64 + lane) * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)&ring[wvu * 64], 16, o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)&ring[(wvu + 4) * 64], 16, o + 4096u, 0, 0, 0);
     };
-    // the eight A fragments of a tile, LDS -> registers
-    auto frags = [&](const uint4* buf, v4i (&a)[8]) {
+    // the four A fragments of a tile, LDS -> registers
+    auto frags = [&](const uint4* buf, v4i (&a)[MM_KS]) {
 #pragma unroll
-        for (int s = 0; s < 8; s++) { const uint4 v = buf[s * 64 + lane]; a[s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+        for (int s = 0; s < MM_KS; s++) { const uint4 v = buf[s * 64 + lane]; a[s] = v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
     };
-    // the 16 MFMAs of a tile whose fragments are in registers, into (x0, x1)
-    auto issue = [&](const v4i (&a)[8], v16i& x0, v16i& x1) {
-        if (MM_ABLATE & 8) { x0 = cc; x1 = cc; for (int s = 0; s < 8; s++) { x0[s] += a[s][0]; x1[s] += a[s][1]; } return; }
-        x0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][0], cc, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[1][0], cc, 0, 0, 0);
+    // the 8 MFMAs of a tile whose fragments are in registers, into (x0, x1): A = train nibbles with block scale 2^4 (E8M0 131), B = query nibbles, scale 1 (127)
+    auto mfma4 = [](const v4i& a, const v4i& bq, const v16f& c) {
+        const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {bq[0], bq[1], bq[2], bq[3], 0, 0, 0, 0};          // FP4 operands are the low four registers
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0x83838383, 0, 0x7F7F7F7F);
+    };
+    auto issue = [&](const v4i (&a)[MM_KS], v16f& x0, v16f& x1) {
+        if (MM_ABLATE & 8) { x0 = cc; x1 = cc; for (int s = 0; s < MM_KS; s++) { x0[s] += (float)a[s][0]; x1[s] += (float)a[s][1]; } return; }
+        x0 = mfma4(a[0], b[0][0], cc);
+        x1 = mfma4(a[0], b[1][0], cc);
 #pragma unroll
-        for (int s = 1; s < 8; s++) {
-            x0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[0][s], x0, 0, 0, 0);
-            x1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[1][s], x1, 0, 0, 0);
+        for (int s = 1; s < MM_KS; s++) {
+            x0 = mfma4(a[s], b[0][s], x0);
+            x1 = mfma4(a[s], b[1][s], x1);
         }
     };
     // the MFMAs of a tile are issued first and the key tracking of the tile before it (VALU only, other registers) runs under them
     auto interleave = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+        for (int i = 0; i < 2 * MM_KS; i++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); }
     };
-    auto track = [&](const v16i& x0, const v16i& x1, int T) {
-        if (MM_ABLATE & 1) { g0[0] = min(g0[0], (uint32_t)x0[0]); g0[1] = min(g0[1], (uint32_t)x1[0]); return; }
+    auto track = [&](const v16f& x0, const v16f& x1, int T) {
+        if (MM_ABLATE & 1) { g0[0] = min(g0[0], __float_as_uint(x0[0])); g0[1] = min(g0[1], __float_as_uint(x1[0])); return; }
         mm_track(x0, (uint32_t)T << 5, g0[0], g1[0]); mm_track(x1, (uint32_t)T << 5, g0[1], g1[1]);
     };
-    auto track_last = [&](v16i x0, v16i x1, int T) {                    // the last tile: its padded train rows (>= nt) never win
+    auto track_last = [&](v16f x0, v16f x1, int T) {                    // the last tile: its padded train rows (>= nt) never win
         const int valid = nt - T * 32;
 #pragma unroll
-        for (int i = 0; i < 16; i++) if ((i & 3) + 8 * (i >> 2) + 4 * h >= valid) { x0[i] = -1; x1[i] = -1; }
+        for (int i = 0; i < 16; i++) if ((i & 3) + 8 * (i >> 2) + 4 * h >= valid) { x0[i] = 1048576.0f; x1[i] = 1048576.0f; }       // a key no descriptor reaches (and finite: this file is built with -fno-honor-nans)
         track(x0, x1, T);
     };
-    // Step T: tile T + 1 has landed (vmcnt(4): the DMAs of T + 2 and T + 3 stay in flight) and this wave holds the fragments of tile T
+    // Step T: tile T + 1 has landed (vmcnt(2): the DMAs of T + 2 and T + 3 stay in flight) and this wave holds the fragments of tile T
     // (lgkmcnt(0)); after the barrier that is true of every wave, so slot T & 3 is free for the DMA of tile T + 4.  The fragments of tile T + 1
     // are read into the other register set, then the MFMAs of tile T are issued from registers -- no LDS latency in front of them -- with the key
     // tracking of tile T - 1 under them.
 #define MM_STEP(T_, rd_, wr_, acur, anxt, xn0, xn1, TRACK) { \
-        __builtin_amdgcn_s_waitcnt((MM_ABLATE & 4) ? 0x007F : 0x0074);    /* vmcnt(4) lgkmcnt(0) */ \
+        __builtin_amdgcn_s_waitcnt((MM_ABLATE & 4) ? 0x007F : 0x0072);    /* vmcnt(2) lgkmcnt(0) */ \
         if (!(MM_ABLATE & 2)) __builtin_amdgcn_s_barrier();              /* bare: __syncthreads' fence would drain every DMA in flight */ \
         frags(rd_, anxt); \
         dma((T_) + 4, wr_); \
         __builtin_amdgcn_sched_barrier(0); \
         issue(acur, xn0, xn1); TRACK; interleave(); \
         __builtin_amdgcn_sched_barrier(0); }
-    v16i A0, A1, B0, B1;
-    v4i aA[8], aB[8];
+    v16f A0, A1, B0, B1;
+    v4i aA[MM_KS], aB[MM_KS];
     dma(0, ring0); dma(1, ring1); dma(2, ring2); dma(3, ring3);
-    if (!(MM_ABLATE & 4)) __builtin_amdgcn_s_waitcnt(0x0F76);           // vmcnt(6): tile 0
+    if (!(MM_ABLATE & 4)) __builtin_amdgcn_s_waitcnt(0x0F73);           // vmcnt(3): tile 0
     if (!(MM_ABLATE & 2)) __builtin_amdgcn_s_barrier();
     frags(ring0, aA);
     MM_STEP(0, ring1, ring0, aA, aB, A0, A1, (void)0)
@@ -402,7 +414,7 @@ match_compact_kernel(const uint2* __restrict__ knn, const int32_t* __restrict__ 
 hipError_t k_match_expand(const uint8_t* desc, const int32_t* nkp, int row0, int nrows, int cap, int capT, uint8_t* eq, uint8_t* et, hipStream_t s)
 {
     if (nrows <= 0) return hipSuccess;
-    match_expand_kernel<<<dim3((capT * 16 + 255) / 256, nrows), 256, 0, s>>>(desc, nkp, row0, cap, capT, eq, et);
+    match_expand_kernel<<<dim3((capT * 8 + 255) / 256, nrows), 256, 0, s>>>(desc, nkp, row0, cap, capT, eq, et);
     return hipGetLastError();
 }
 hipError_t k_match_seq_mfma(const uint8_t* eq, const uint8_t* et, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap, int capT,

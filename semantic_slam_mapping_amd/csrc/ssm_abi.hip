@@ -515,7 +515,7 @@ static int match_host(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, in
     if (c->match_mfma) {
         // the matrix-core matcher of the sequence path on a two-row "sequence": row 0 = the query set (reference frame), row 1 = the train set
         const int capm = nq > nt ? nq : nt, capT = (capm + 31) & ~31;
-        const size_t rowb = (size_t)capm * 32, expb = (size_t)2 * capT * 256;
+        const size_t rowb = (size_t)capm * 32, expb = (size_t)2 * capT * SSM_MATCH_DESC_BYTES;
         const size_t need = 2 * rowb + 16 + 2 * expb + (size_t)capT * 8 + (size_t)nq * sizeof(ssm_dmatch) + 64;
         int r = ensure_scratch(c, need); if (r) return r;
         uint8_t* dd = reinterpret_cast<uint8_t*>(c->d_scratch);
@@ -874,7 +874,7 @@ static int ensure_seq(ssm_ctx* c, int n)
     c->d_exp_q = nullptr; c->d_exp_t = nullptr; c->d_knn = nullptr;
     c->capT = (g.cap + 31) & ~31;
     if (c->match_mfma) {       // expanded rows are rebuilt from the bit descriptors at the start of every call (history) and after every ORB sub-batch
-        DALLOC(c, c->d_exp_q, (size_t)(n + R) * c->capT * 256); DALLOC(c, c->d_exp_t, (size_t)(n + R) * c->capT * 256); DALLOC(c, c->d_knn, (size_t)n * R * c->capT * 8);
+        DALLOC(c, c->d_exp_q, (size_t)(n + R) * c->capT * SSM_MATCH_DESC_BYTES); DALLOC(c, c->d_exp_t, (size_t)(n + R) * c->capT * SSM_MATCH_DESC_BYTES); DALLOC(c, c->d_knn, (size_t)n * R * c->capT * 8);
     }
     DALLOC(c, c->d_kps, (size_t)n * g.cap); DALLOC(c, c->d_pos3d, (size_t)n * g.cap * 3);
     DALLOC(c, c->d_matches, (size_t)n * R * g.cap); DALLOC(c, c->d_nmatch, (size_t)n * R); DALLOC(c, c->d_match_pend, (size_t)n * R); DALLOC(c, c->d_npoints, (size_t)n);

@@ -67,8 +67,9 @@ hipError_t k_match_pairs(const uint8_t* desc, const MatchPair* pairs, int npairs
 hipError_t k_match_seq(const uint8_t* desc, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap,
                        ssm_dmatch* out, int32_t* nout, int32_t* pend /* n * R ints of scratch */, hipStream_t s);
 
-// the matcher on the matrix cores: descriptors expanded to i8 rows (capT = cap rounded up to 32 descriptors, 256 B each, tile-fragment order), then
-// v_mfma_i32_32x32x32_i8 distance tiles -> knn keys -> ratio test + ordered compaction.  Same results as k_match_seq.
+// the matcher on the matrix cores: descriptors expanded to FP4 rows (capT = cap rounded up to 32 descriptors, SSM_MATCH_DESC_BYTES each, tile-fragment
+// order), then v_mfma_scale_f32_32x32x64_f8f6f4 distance tiles -> knn keys -> ratio test + ordered compaction.  Same results as k_match_seq.
+#define SSM_MATCH_DESC_BYTES 128
 hipError_t k_match_expand(const uint8_t* desc, const int32_t* nkp, int row0, int nrows, int cap, int capT, uint8_t* eq, uint8_t* et, hipStream_t s);
 hipError_t k_match_seq_mfma(const uint8_t* eq, const uint8_t* et, const int32_t* nkp, int f0, int n, int R, int hist, double ratio, int cap, int capT,
                             void* knn /* n * R * capT * 8 B */, ssm_dmatch* out, int32_t* nout, hipStream_t s);
