@@ -445,13 +445,14 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv3x3_dma2_kernel + conv3x3_first_kernel (26 conv layers with fused pool / un-pool / ArgMax, prep, colouring: whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
         elif dom == "match":
-            # K6 runs on the matrix cores (v_mfma_i32_32x32x32_i8 on descriptors expanded to +-1 / +-16 bytes): 2 x 256 integer operations per
-            # descriptor pair, tiles padded to 32 x 64, against the dense i8 peak (2 x the bf16 rate: MI355X_MICROARCH.md, Matrix cores)
+            # K6 runs on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4 on descriptors expanded to +-1 FP4 elements): 2 x 256 operations per
+            # descriptor pair, against the dense FP4 peak (4 x the bf16 rate: MI355X_MICROARCH.md, Matrix cores)
             pairs = sum(int(res["nkp"][max(f - R + r, 0)]) * int(res["nkp"][f]) for f in range(F) for r in range(R) if m[f, r] >= 0) / F
             tops = pairs * 512 * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "match_mfma_kernel (+ match_expand_kernel, match_compact_kernel)", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (i8)",
-                    "frac": round(tops / 5000.0, 4), "traffic": measured_traffic(dom, frames_per_launch),
-                    "note": "Hamming distance matrix as an exact i8 matrix product; algorithmic operations only (the padding of 1000 descriptors to 1024 is not counted); DESIGN.md s.4",
+            roof = {"bound": "mfma", "kernel": "match_mfma_kernel (+ match_expand_kernel, match_compact_kernel)", "achieved": round(tops, 1), "peak": 10000.0, "unit": "TOP/s (fp4)",
+                    "frac": round(tops / 10000.0, 4), "traffic": measured_traffic(dom, frames_per_launch),
+                    "note": "Hamming distance matrix as an exact FP4 matrix product; algorithmic operations only (the padding of 1000 descriptors to 1024 is not counted); "
+                            "the kernel's longer side is the VALU top-2 tracking of the distance tiles: DESIGN.md s.4.1",
                     "descriptor_pairs_per_frame": round(pairs)}
         else:
             gb = algorithmic_bytes(dom, P, nkp) * frames_per_launch / 1e9
