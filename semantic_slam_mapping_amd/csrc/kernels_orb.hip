@@ -1225,39 +1225,19 @@ angle_kernel(OrbGeom g, const KpRec* __restrict__ recs, const uint16_t* __restri
 }
 // value of lane + n inside the 16-lane row (0 beyond the row): the 16 nibbles of one 64-bit descriptor word sit in one row
 #define ROW_SHL(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x100 + (n), 0xF, 0xF, true))
-#define BR_KPW 2               // keypoints per wave: the lane's 64 bytes of pattern are loaded once for both, and both patches are in flight together (4 measured slower: LDS halves the occupancy)
+#define BR_KPW 2               // keypoints per step: the lane's 64 bytes of pattern serve both, and both patches are in flight together (4 measured slower: LDS halves the occupancy)
+#define BR_NIT 4               // steps per wave: the patches of step k + 1 are loaded (into registers) while step k computes
+#define BR_PW ((DP_ROWS_B * DP_QW_B + 63) / 64)      // 16-byte patch words per lane per keypoint (3)
 __global__ void __launch_bounds__(256)
 brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restrict__ recs,
              const float* __restrict__ pattern_f, const KpAux* __restrict__ aux, uint8_t* __restrict__ desc, int nframes)
 {
     __shared__ uint4 pb[4][BR_KPW][DP_ROWS_B * DP_QW_B];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.x;       // frame-fastest launch order: see blur_kernel
-    const int slot0 = (blockIdx.y * 4 + wv) * BR_KPW;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = blockIdx.x;       // frame-fastest launch order: see blur_kernel
+    const int slot0 = (blockIdx.y * 4 + wv) * (BR_KPW * BR_NIT);
     if (f >= nframes || slot0 >= g.sel_total) return;
-    KpRec rec[BR_KPW];
-#pragma unroll
-    for (int j = 0; j < BR_KPW; j++) {
-        rec[j].oidx = -1;
-        if (slot0 + j < g.sel_total) rec[j] = recs[(size_t)f * g.sel_total + slot0 + j];
-    }
-    int xoff[BR_KPW];
-#pragma unroll
-    for (int j = 0; j < BR_KPW; j++) {
-        xoff[j] = 0;
-        if (rec[j].oidx < 0) continue;
-        const int stride = (int)(rec[j].stride_level & 0xFFFFu), x = rec[j].pk & 4095;
-        const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + rec[j].off;      // the keypoint's pixel in the blurred level
-        const int xb0 = (x - 18) & ~15;
-        xoff[j] = x - xb0;
-        for (int e = lane; e < DP_ROWS_B * DP_QW_B; e += 64) {
-            const int r = e >> 2, c = e & 3;
-            const int gx = xb0 + 16 * c;
-            pb[wv][j][e] = gx < stride ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(r - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
-        }
-    }
-    KpAux a[BR_KPW];
-#pragma unroll
-    for (int j = 0; j < BR_KPW; j++) if (rec[j].oidx >= 0) a[j] = aux[(size_t)f * g.sel_total + slot0 + j];
+    const KpRec* rp = recs + (size_t)f * g.sel_total;
+    const KpAux* ap = aux + (size_t)f * g.sel_total;
     // steered BRIEF: lane -> 4 of the 256 comparisons.  The pattern arrives as floats (converted once on the host); the rotation runs on packed
     // pairs -- (x0, x1) and (y0, y1) of a comparison through v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiplies and adds in the same order as the
     // scalar form (no contraction) -- and cvRound is the 1.5 * 2^23 trick: adding 12582912.0f rounds to nearest-even in the adder and leaves the
@@ -1265,33 +1245,78 @@ brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restric
     typedef float f2 __attribute__((ext_vector_type(2)));
     const float4* pf = reinterpret_cast<const float4*>(pattern_f) + lane * 4;
     const float4 pq[4] = {pf[0], pf[1], pf[2], pf[3]};
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
+    // a step's patch words, global -> registers (a wave walks BR_NIT steps: the next step's words are in flight while this one computes, so a wave
+    // pays the record -> patch latency chain once, not per keypoint)
+    uint4 pw[BR_KPW][BR_PW];
+    KpRec rec[BR_KPW], nrec[BR_KPW];
+    auto load_recs = [&](int it, KpRec (&r)[BR_KPW]) {
 #pragma unroll
-    for (int j = 0; j < BR_KPW; j++) {
-        if (rec[j].oidx < 0) continue;
-        const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv][j]) + 18 * (DP_QW_B * 16) + xoff[j];      // centre pixel of the blurred patch
-        const float sb = a[j].sn, ca = a[j].cs;
-        const f2 s2 = {sb, sb}, c2 = {ca, ca}, magic = {12582912.0f, 12582912.0f};
-        uint32_t nib = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const f2 X = {pq[k].x, pq[k].z}, Y = {pq[k].y, pq[k].w};
-            const f2 xs = X * s2, yc = Y * c2, xc = X * c2, ys = Y * s2;
-            const f2 yy = (xs + yc) + magic, xx = (xc - ys) + magic;
-            // index = yy * 64 + xx with both integers still biased by 0x4B400000: one shift-add, the bias leaves as a constant (mod 2^32)
-            const uint32_t i0 = (__float_as_uint(yy.x) << 6) + __float_as_uint(xx.x) - 0x4B400000u * 65u;
-            const uint32_t i1 = (__float_as_uint(yy.y) << 6) + __float_as_uint(xx.y) - 0x4B400000u * 65u;
-            const int t0 = bb[(int)i0], t1 = bb[(int)i1];
-            nib |= (uint32_t)(t0 < t1) << k;
+        for (int j = 0; j < BR_KPW; j++) {
+            const int slot = slot0 + it * BR_KPW + j;
+            r[j].oidx = -1;
+            if (it < BR_NIT && slot < g.sel_total) r[j] = rp[slot];
         }
-        // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
-        uint32_t b = nib | (ROW_SHL(nib, 1) << 4);                   // even lanes: one byte
-        b |= ROW_SHL(b, 2) << 8;                                     // lanes %4==0: 2 bytes
-        b |= ROW_SHL(b, 4) << 16;                                    // lanes %8==0: 4 bytes
-        const uint32_t hi = ROW_SHL(b, 8);
-        if ((lane & 15) == 0)
-            reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + rec[j].oidx) * 32)[lane >> 4] = make_uint2(b, hi);
+    };
+    auto fetch = [&](const KpRec (&r)[BR_KPW]) {
+#pragma unroll
+        for (int j = 0; j < BR_KPW; j++) {
+            if (r[j].oidx < 0) continue;
+            const int stride = (int)(r[j].stride_level & 0xFFFFu), x = r[j].pk & 4095;
+            const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + r[j].off;        // the keypoint's pixel in the blurred level
+            const int xb0 = (x - 18) & ~15;
+#pragma unroll
+            for (int q = 0; q < BR_PW; q++) {
+                const int e = lane + 64 * q, rr = e >> 2, c = e & 3, gx = xb0 + 16 * c;
+                pw[j][q] = (e < DP_ROWS_B * DP_QW_B && gx < stride) ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(rr - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    load_recs(0, rec);
+    fetch(rec);
+    for (int it = 0; it < BR_NIT; it++) {
+        load_recs(it + 1, nrec);
+        KpAux a[BR_KPW];
+#pragma unroll
+        for (int j = 0; j < BR_KPW; j++) if (rec[j].oidx >= 0) a[j] = ap[slot0 + it * BR_KPW + j];
+        // this step's words into the wave's LDS patches (every lane is past the previous step's reads: a wave runs in lock step between the barriers)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < BR_KPW; j++) {
+            if (rec[j].oidx < 0) continue;
+#pragma unroll
+            for (int q = 0; q < BR_PW; q++) { const int e = lane + 64 * q; if (e < DP_ROWS_B * DP_QW_B) pb[wv][j][e] = pw[j][q]; }
+        }
+        fetch(nrec);                                                    // the next step's patches are in flight during this step's comparisons
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < BR_KPW; j++) {
+            if (rec[j].oidx < 0) continue;
+            const int x = rec[j].pk & 4095, xb0 = (x - 18) & ~15;
+            const uint8_t* bb = reinterpret_cast<const uint8_t*>(pb[wv][j]) + 18 * (DP_QW_B * 16) + (x - xb0);      // centre pixel of the blurred patch
+            const float sb = a[j].sn, ca = a[j].cs;
+            const f2 s2 = {sb, sb}, c2 = {ca, ca}, magic = {12582912.0f, 12582912.0f};
+            uint32_t nib = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f2 X = {pq[k].x, pq[k].z}, Y = {pq[k].y, pq[k].w};
+                const f2 xs = X * s2, yc = Y * c2, xc = X * c2, ys = Y * s2;
+                const f2 yy = (xs + yc) + magic, xx = (xc - ys) + magic;
+                // index = yy * 64 + xx with both integers still biased by 0x4B400000: one shift-add, the bias leaves as a constant (mod 2^32)
+                const uint32_t i0 = (__float_as_uint(yy.x) << 6) + __float_as_uint(xx.x) - 0x4B400000u * 65u;
+                const uint32_t i1 = (__float_as_uint(yy.y) << 6) + __float_as_uint(xx.y) - 0x4B400000u * 65u;
+                const int t0 = bb[(int)i0], t1 = bb[(int)i1];
+                nib |= (uint32_t)(t0 < t1) << k;
+            }
+            // 16 nibbles (lanes 16j..16j+15) -> one 64-bit word, by DPP inside the row
+            uint32_t b = nib | (ROW_SHL(nib, 1) << 4);                   // even lanes: one byte
+            b |= ROW_SHL(b, 2) << 8;                                     // lanes %4==0: 2 bytes
+            b |= ROW_SHL(b, 4) << 16;                                    // lanes %8==0: 4 bytes
+            const uint32_t hi = ROW_SHL(b, 8);
+            if ((lane & 15) == 0)
+                reinterpret_cast<uint2*>(desc + ((size_t)f * g.cap + rec[j].oidx) * 32)[lane >> 4] = make_uint2(b, hi);
+        }
+#pragma unroll
+        for (int j = 0; j < BR_KPW; j++) rec[j] = nrec[j];
     }
 }
 hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t* blur, const uint32_t* sel,
@@ -1305,6 +1330,6 @@ hipError_t k_describe(int n, const OrbGeom& g, const uint8_t* pyr, const uint8_t
     kp_prepare_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, sel, nsel, recs, nkp);
     orient_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * OR_KPW - 1) / (4 * OR_KPW)), 256, 0, s>>>(g, um, pyr, recs, aux, n);
     angle_kernel<<<dim3((g.sel_total + 255) / 256, n), 256, 0, s>>>(g, recs, depth, cam, aux, kps, pos3d);
-    brief_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * BR_KPW - 1) / (4 * BR_KPW)), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc, n);
+    brief_kernel<<<dim3((n + 7) & ~7, (g.sel_total + 4 * BR_KPW * BR_NIT - 1) / (4 * BR_KPW * BR_NIT)), 256, 0, s>>>(g, blur, recs, pattern_f, aux, desc, n);
     return hipGetLastError();
 }
