@@ -280,7 +280,7 @@ vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__
             const uint4 lo = p[0], hi = p[1];
             const float x = __uint_as_float(lo.x), y = __uint_as_float(lo.y), z = __uint_as_float(lo.z);
             const float fi = floorf(x * inv_leaf), fj = floorf(y * inv_leaf), fk = floorf(z * inv_leaf);
-            const long long vi = (long long)fi + (1 << 20), vj = (long long)fj + (1 << 20), vk = (long long)fk + (1 << 20);
+            const long long vi = (long long)(int)fi + (1 << 20), vj = (long long)(int)fj + (1 << 20), vk = (long long)(int)fk + (1 << 20);     // v_cvt_i32_f32 (saturating): an index the range check below rejects may be anything; float -> int64 costs ~8 instructions each
             key = (vk << 42) | (vj << 21) | vi;
             // range contract (oracle/mapper.c sso_voxel_key): index not finite or outside (-2^20, 2^20) -> the point is skipped, flag bit 1
             if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; atomicOr(&counters[1], 2); }
@@ -566,7 +566,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
                     oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
                 }
                 const float fi = floorf(ox * inv_leaf), fj = floorf(oy * inv_leaf), fk = floorf(oz * inv_leaf);
-                const long long vi = (long long)fi + (1 << 20), vj = (long long)fj + (1 << 20), vk = (long long)fk + (1 << 20);
+                const long long vi = (long long)(int)fi + (1 << 20), vj = (long long)(int)fj + (1 << 20), vk = (long long)(int)fk + (1 << 20);     // v_cvt_i32_f32 (saturating): an index the range check below rejects may be anything; float -> int64 costs ~8 instructions each
                 long long key = (vk << 42) | (vj << 21) | vi;
                 // range contract (oracle/mapper.c sso_voxel_key): such a point still counts in npoints (generatePointCloud emits it) but is not fused
                 if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; out_of_range = true; }
@@ -589,6 +589,172 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     // two wave-wide merges (first runs, second runs); waves of a block are independent until the final flush
     if (__ballot(k0 != -2)) wave_flush(lt, k0, l0, a0, lane, tab, cap_log2, counters, occ);
     if (__ballot(k1 != -2)) wave_flush(lt, k1, l1, a1, lane, tab, cap_log2, counters, occ);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
+    if (lane == 0 && kept) atomicAdd(&s_npts, kept);
+    if (__ballot(out_of_range) && lane == 0) atomicOr(&counters[1], 2);
+    __syncthreads();
+    for (int i = tid; i < MS_SLOTS; i += 256) {
+        if (lt[i].key == SSM_VOX_EMPTY) continue;
+        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
+        if (!v) continue;
+        vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
+#pragma unroll
+        for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
+    }
+    if (tid == 0 && s_npts) atomicAdd(&npoints[blockIdx.y], s_npts);
+}
+// ---- map_stream2_kernel: the same fusion with the kept pixels COMPACTED before the expensive part.
+// map_stream_kernel runs unprojection / pose transform / voxel key (about 170 of its 250 VALU instructions per pixel, most of them f64) for all 16
+// pixels of a lane as soon as any lane of the wave keeps that pixel; on the configs[1] stream 59 % of the pixels pass the gates, so 41 % of that work
+// is masked out.  Here a wave first decides (labels, depth range, class gates, moving mask: ~15 instructions per pixel), writes its lanes' depth and
+// kept pixels as 14-bit entries (source lane, pixel in the lane, label) to an LDS list in wave-scan order; then lane i takes the
+// list entries [i P, (i + 1) P), P = ceil(kept / 64): every lane works on kept pixels only, still consecutive in scan order, so the register run
+// accumulation works as before.  Exact integer sums: the map is bit-identical.
+#define MS2_MINB 4
+template <bool FASTDIV>
+__global__ void __launch_bounds__(256, MS2_MINB)
+map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
+                   const uint16_t* __restrict__ vbits, const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
+                   float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints, uint32_t mul_wpr)
+{
+    __shared__ LdsVox lt[MS_SLOTS];
+    __shared__ int s_npts;
+    __shared__ uint16_t vlist[4][1024];                                 // per wave: kept pixels in scan order: lane << 4 | pixel | label << 10
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wpr = w >> 4, words = wpr * h;
+    for (int i = tid; i < MS_SLOTS; i += 256) {
+        lt[i].key = SSM_VOX_EMPTY; lt[i].sx = 0; lt[i].sy = 0; lt[i].sz = 0; lt[i].r = lt[i].g = lt[i].b = lt[i].n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) lt[i].hist[k] = 0;
+    }
+    if (tid == 0) s_npts = 0;
+    __syncthreads();
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    int kept = 0; bool out_of_range = false;
+    double T[12];
+    const bool hasT = pose != nullptr;
+    if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
+    const uint32_t tab_entry = label_hash_entry(lane & 15);
+    const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
+#pragma unroll 1
+    for (int ch = 0; ch < MS_CH; ch++) {
+    const int wbase = (blockIdx.x * MS_CH + ch) * 256 + wv * 64;    // the wave's first 16-pixel word of this frame
+    const int wi = wbase + lane;
+    uint32_t keepbits = 0; uint32_t lab4[2] = {0u, 0u};             // 4-bit labels (15 = none of the palette) of the lane's 16 pixels
+    if (wi < words) {
+        const size_t gw = (size_t)blockIdx.y * words + wi;
+        const int gy = (int)__umulhi((uint32_t)wi, mul_wpr), xw = wi - gy * wpr;
+        const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
+        const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
+        const uint4 D0 = pd[0], D1 = pd[1], S0 = ps[0], S1 = ps[1], S2 = ps[2];
+        const uint16_t* vb = vbits + (size_t)blockIdx.y * words + (size_t)gy * wpr;
+        const unsigned long long win = ((unsigned long long)(xw > 0 ? vb[xw - 1] : 0)) | ((unsigned long long)vb[xw] << 16) |
+                                       ((unsigned long long)(xw + 1 < wpr ? vb[xw + 1] : 0) << 32);
+        const uint32_t moving = (uint32_t)((win >> 14) | (win >> 15) | (win >> 16) | (win >> 17) | (win >> 18)) & 0xFFFFu;   // 5-wide OR
+        const uint32_t dd[8] = {D0.x, D0.y, D0.z, D0.w, D1.x, D1.y, D1.z, D1.w};
+        const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+            const int o = 3 * k;
+            const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
+            const uint32_t ent = (uint32_t)__shfl((int)tab_entry, (int)((sbgr * 0x7589a82bu) >> 28), 64);
+            const uint32_t lab = (ent & 0xFFFFFFu) == sbgr ? ent >> 24 : 15u;          // 0..11, or 15
+            lab4[k >> 3] |= lab << (4 * (k & 7));
+            const bool gated = (0x805u >> lab) & 1u;                                  // sky 0, pole 2, cyclist 11 (bit 15 is clear)
+            keepbits |= (uint32_t)(d != 0 && d <= dmax && !gated) << k;
+        }
+        keepbits &= ~moving;                                          // mapper.cpp:32
+    }
+    // the wave's kept pixels, in scan order
+    const uint32_t cnt = __popc(keepbits);
+    uint32_t incl = cnt;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);     // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);     // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);     // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);     // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    const int V = __builtin_amdgcn_readlane((int)incl, 63);
+    kept += (int)cnt;
+    {
+        int base = (int)(incl - cnt);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if ((keepbits >> k) & 1u) vlist[wv][base++] = (uint16_t)((lane << 4) | k | (((lab4[k >> 3] >> (4 * (k & 7))) & 15u) << 10));
+    }
+    const int P = (V + 63) >> 6;                                    // wave-uniform
+    long long k0 = -2, k1 = -2; uint32_t l0 = 255, l1 = 255; RunAcc a0, a1;
+    a0.sx = a0.sy = a0.sz = 0; a0.r = a0.g = a0.b = a0.n = 0; a1 = a0;
+    __builtin_amdgcn_wave_barrier();                                // (LDS operations of a wave execute in order: the reads below see the writes above)
+    // one kept pixel: list entry -> (voxel key, label, fixed-point sums + colour); straight-line code, so that the MS2_UN pixels of a loop trip interleave
+    // (one pixel alone is a chain of ~60 dependent f64 instructions)
+    auto pixel = [&](int e, long long& key, uint32_t& lab, RunAcc& p) {
+        const uint32_t ent = vlist[wv][min(e, V - 1)];
+        const int sl = (ent >> 4) & 63, k = ent & 15;
+        lab = (ent >> 10) == 15u ? 255u : (ent >> 10);
+        // the pixel's depth and colour again from global memory (the wave read these lines in the gate pass: cache hits); an LDS copy would hold the
+        // block to three per CU
+        const int wip = wbase + sl;
+        const size_t gp = ((size_t)blockIdx.y * words + wip) * 16 + k;
+        const int d = depth[gp];
+        uint16_t c01; __builtin_memcpy(&c01, rgb + gp * 3, 2);
+        const uint32_t cbgr = (uint32_t)c01 | ((uint32_t)rgb[gp * 3 + 2] << 16);
+        const int gy = (int)__umulhi((uint32_t)wip, mul_wpr), gx = ((wip - gy * wpr) << 4) + k;
+        const double yf = (double)gy - cam.cy;
+        float x, y, z;
+        if (FASTDIV) {
+            z = (float)markstein_div((double)d, cam.scale, md.rscale);
+            x = (float)markstein_div(((double)gx - cam.cx) * (double)z, cam.fx, md.rfx);
+            y = (float)markstein_div(yf * (double)z, cam.fy, md.rfy);
+        } else {
+            z = (float)((double)d / cam.scale);
+            x = (float)(((double)gx - cam.cx) * (double)z / cam.fx);
+            y = (float)(yf * (double)z / cam.fy);
+        }
+        float ox = x, oy = y, oz = z;
+        if (hasT) {
+            const double X = x, Y = y, Z = z;
+            ox = (float)(T[0] * X + T[3] * Y + T[6] * Z + T[9]);
+            oy = (float)(T[1] * X + T[4] * Y + T[7] * Z + T[10]);
+            oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
+        }
+        const float fi = floorf(ox * inv_leaf), fj = floorf(oy * inv_leaf), fk = floorf(oz * inv_leaf);
+        const long long vi = (long long)(int)fi + (1 << 20), vj = (long long)(int)fj + (1 << 20), vk = (long long)(int)fk + (1 << 20);     // v_cvt_i32_f32 (saturating): an index the range check below rejects may be anything; float -> int64 costs ~8 instructions each
+        key = (vk << 42) | (vj << 21) | vi;
+        // range contract (oracle/mapper.c sso_voxel_key): such a point still counts in npoints (generatePointCloud emits it) but is not fused
+        if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; if (e < V) out_of_range = true; }
+        p.sx = f64_to_ll_rn((double)ox * 16777216.0); p.sy = f64_to_ll_rn((double)oy * 16777216.0); p.sz = f64_to_ll_rn((double)oz * 16777216.0);
+        p.b = cbgr & 255; p.g = (cbgr >> 8) & 255; p.r = cbgr >> 16; p.n = 1;
+    };
+    auto accumulate = [&](long long key, uint32_t lab, const RunAcc& p) {
+        if (k1 == -2 && (k0 == -2 || (k0 == key && l0 == lab))) {                 // still in the first run
+            k0 = key; l0 = lab; a0.sx += p.sx; a0.sy += p.sy; a0.sz += p.sz; a0.r += p.r; a0.g += p.g; a0.b += p.b; a0.n += 1;
+        } else if (k1 == -2 || (k1 == key && l1 == lab)) {                       // second run
+            k1 = key; l1 = lab; a1.sx += p.sx; a1.sy += p.sy; a1.sz += p.sz; a1.r += p.r; a1.g += p.g; a1.b += p.b; a1.n += 1;
+        } else {                                                                 // a third run inside the lane's share: rare
+            if (k1 >= 0) lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
+            k1 = key; l1 = lab; a1 = p;
+        }
+    };
+    constexpr int MS2_UN = 2;
+#pragma unroll 1
+    for (int i = 0; i < P; i += MS2_UN) {
+        long long kk[MS2_UN]; uint32_t ll[MS2_UN]; RunAcc pp[MS2_UN];
+#pragma unroll
+        for (int u = 0; u < MS2_UN; u++) pixel(lane * P + i + u, kk[u], ll[u], pp[u]);
+#pragma unroll
+        for (int u = 0; u < MS2_UN; u++) if (i + u < P && lane * P + i + u < V) accumulate(kk[u], ll[u], pp[u]);
+    }
+    // every lane's (at most two) runs straight into the block table: with ~10 kept pixels per lane the wave-wide segmented scans that merged neighbouring
+    // lanes first (map_stream_kernel: two scans of ten dwords, ~700 instructions per chunk) cost more than the LDS atomics they saved
+    if (k0 >= 0) lds_vox_update(lt, k0, l0, a0, tab, cap_log2, counters, occ);
+    if (k1 >= 0) lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
+    __builtin_amdgcn_wave_barrier();                                // the next chunk overwrites this wave's pix / vlist
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
@@ -635,10 +801,16 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
         }
         fast = seen_ok;
     }
-    if (fast) map_stream_kernel<true><<<dim3((words + 256 * MS_CH - 1) / (256 * MS_CH), n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
-                                                                                  1.0f / leaf, tab, cap_log2, counters, npoints);
-    else map_stream_kernel<false><<<dim3((words + 256 * MS_CH - 1) / (256 * MS_CH), n), 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale,
-                                                                               1.0f / leaf, tab, cap_log2, counters, npoints);
+    static const bool compact = [] { const char* e = getenv("SSM_MAP_VARIANT"); return !(e && atoi(e) == 0); }();     // 0: map_stream_kernel (every pixel through the full arithmetic)
+    const dim3 grid((words + 256 * MS_CH - 1) / (256 * MS_CH), n);
+    const uint32_t mul_wpr = (uint32_t)(((1ull << 32) + wpr - 1) / wpr);           // floor(i / wpr) = umulhi(i, mul) for i < words (i * wpr < 2^32)
+    if (compact && (long long)words * wpr < (1ll << 32)) {
+        if (fast) map_stream2_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
+        else map_stream2_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
+    } else {
+        if (fast) map_stream_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
+        else map_stream_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
+    }
     return hipGetLastError();
 }
 
