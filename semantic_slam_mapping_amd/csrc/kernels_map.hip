@@ -773,7 +773,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
 }
 hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
                       ssm_camera cam, double max_distance, float leaf, uint16_t* bits_raw, uint16_t* bits_v,
-                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s)
+                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, bool compact)
 {
     hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return e;
@@ -801,7 +801,6 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
         }
         fast = seen_ok;
     }
-    static const bool compact = [] { const char* e = getenv("SSM_MAP_VARIANT"); return !(e && atoi(e) == 0); }();     // 0: map_stream_kernel (every pixel through the full arithmetic)
     const dim3 grid((words + 256 * MS_CH - 1) / (256 * MS_CH), n);
     const uint32_t mul_wpr = (uint32_t)(((1ull << 32) + wpr - 1) / wpr);           // floor(i / wpr) = umulhi(i, mul) for i < words (i * wpr < 2^32)
     if (compact && (long long)words * wpr < (1ll << 32)) {

@@ -98,7 +98,7 @@ struct ssm_ctx {
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
-    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
+    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true; bool map_compact = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
     VoxTable map, tmp;
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
@@ -357,6 +357,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
+    { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
     { const char* e = getenv("SSM_MATCH_VARIANT"); c->match_mfma = !(e && atoi(e) == 0); }      // 0: the VALU matcher in the sequence path (A/B runs)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
@@ -981,7 +982,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                     HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src,
                                          in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
                                          (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(mask_ws), reinterpret_cast<uint16_t*>(mask_ws) + (size_t)nb * (W >> 4) * H,
-                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s));
+                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s, c->map_compact));
                     prof_end(c);
                 } else {                     // odd widths: mask -> ordered back-projection -> insert
                     prof_begin(c, "mask");

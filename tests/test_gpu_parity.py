@@ -562,12 +562,14 @@ def test_sequence_with_sparse_and_empty_frames(oracle):
 
 
 def test_valu_variants_of_matcher_and_blur(oracle, frames, monkeypatch):
-    """The matcher and the blur have two implementations each: matrix cores (default) and VALU (SSM_MATCH_VARIANT=0 / SSM_BLUR_VARIANT=0, read when a
-    context is created).  The rest of this file runs the default; this runs the VALU pair through the same checks: host matcher API, ORB of one
-    frame (the descriptors depend on the blur), and a short sequence (match tables) against the oracle."""
+    """The matcher, the blur and the map fusion have two implementations each: the default (matrix cores; compacting map kernel) and the earlier one
+    (SSM_MATCH_VARIANT=0 / SSM_BLUR_VARIANT=0 / SSM_MAP_VARIANT=0, read when a context is created).  The rest of this file runs the defaults; this runs
+    the earlier kernels through the same checks: host matcher API, ORB of one frame (the descriptors depend on the blur), and a short sequence (match
+    tables, point counts and the fused map) against the oracle."""
     import semantic_slam_mapping_amd as ssm
     monkeypatch.setenv("SSM_MATCH_VARIANT", "0")
     monkeypatch.setenv("SSM_BLUR_VARIANT", "0")
+    monkeypatch.setenv("SSM_MAP_VARIANT", "0")          # map_stream_kernel instead of the compacting map_stream2_kernel
     c = ssm.Context(0, orb_features=1000, max_batch=4, voxel_capacity_log2=18, camera=CAM)
     try:
         rng = np.random.default_rng(77)
@@ -583,12 +585,16 @@ def test_valu_variants_of_matcher_and_blur(oracle, frames, monkeypatch):
         bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
         try:
             c.synth_frames_dev(SEED, 20, n, *bufs)
-            out = c.seq_process(*bufs, n, stages=3)
+            c.map_clear()
+            out = c.seq_process(*bufs, n)
             c.sync()
             res = c.seq_fetch(out, n)
-            descs = []
+            descs, clouds = [], []
             for i in range(n):
                 fr = oracle.synth_frame(SEED, 20 + i)
+                cl = oracle.backproject(fr[1], fr[0], fr[2], oracle.moving_mask(fr[2]), CAM, fr[4], 40.0)
+                assert res["npoints"][i] == len(cl)
+                clouds.append(cl)
                 ok, od = oracle.orb_extract(oracle.bgr2gray(fr[0]), nfeatures=1000)
                 k = res["nkp"][i]
                 assert k == len(ok) and np.array_equal(res["desc"][i, :k], od)
@@ -600,6 +606,7 @@ def test_valu_variants_of_matcher_and_blur(oracle, frames, monkeypatch):
                         continue
                     om = oracle.match(descs[ref], od, c.cfg.knn_match_ratio)
                     assert res["nmatch"][i, r] == len(om) and same_struct(res["matches"][i, r, :len(om)], om)
+            assert same_struct(c.map_export(), oracle.voxel_filter(np.concatenate(clouds), np.float32(c.cfg.mapper_resolution)))
         finally:
             for b in bufs:
                 c.dev_free(b)
