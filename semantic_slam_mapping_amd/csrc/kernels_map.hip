@@ -693,17 +693,24 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     __builtin_amdgcn_wave_barrier();                                // (LDS operations of a wave execute in order: the reads below see the writes above)
     // one kept pixel: list entry -> (voxel key, label, fixed-point sums + colour); straight-line code, so that the MS2_UN pixels of a loop trip interleave
     // (one pixel alone is a chain of ~60 dependent f64 instructions)
-    auto pixel = [&](int e, long long& key, uint32_t& lab, RunAcc& p) {
-        const uint32_t ent = vlist[wv][min(e, V - 1)];
+    // a kept pixel's list entry and its depth / colour from global memory (the wave read these lines in the gate pass: cache hits; an LDS copy would hold
+    // the block to three per CU); fetched one loop trip ahead of the arithmetic
+    struct PixIn { uint32_t ent; int d; uint32_t c01, c2; };
+    auto fetch = [&](int e, PixIn& q) {
+        q.ent = vlist[wv][min(e, V - 1)];                               // (only called with V >= 1; entries past the end repeat the last one)
+        const int sl = (q.ent >> 4) & 63, k = q.ent & 15;
+        const size_t gp = ((size_t)blockIdx.y * words + wbase + sl) * 16 + k;
+        q.d = depth[gp];
+        uint16_t c01; __builtin_memcpy(&c01, rgb + gp * 3, 2);
+        q.c01 = c01; q.c2 = rgb[gp * 3 + 2];
+    };
+    auto pixel = [&](int e, const PixIn& q, long long& key, uint32_t& lab, RunAcc& p) {
+        const uint32_t ent = q.ent;
         const int sl = (ent >> 4) & 63, k = ent & 15;
         lab = (ent >> 10) == 15u ? 255u : (ent >> 10);
-        // the pixel's depth and colour again from global memory (the wave read these lines in the gate pass: cache hits); an LDS copy would hold the
-        // block to three per CU
+        const int d = q.d;
+        const uint32_t cbgr = q.c01 | (q.c2 << 16);
         const int wip = wbase + sl;
-        const size_t gp = ((size_t)blockIdx.y * words + wip) * 16 + k;
-        const int d = depth[gp];
-        uint16_t c01; __builtin_memcpy(&c01, rgb + gp * 3, 2);
-        const uint32_t cbgr = (uint32_t)c01 | ((uint32_t)rgb[gp * 3 + 2] << 16);
         const int gy = (int)__umulhi((uint32_t)wip, mul_wpr), gx = ((wip - gy * wpr) << 4) + k;
         const double yf = (double)gy - cam.cy;
         float x, y, z;
@@ -742,11 +749,18 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
         }
     };
     constexpr int MS2_UN = 2;
+    PixIn cur[MS2_UN], nxt[MS2_UN];
+    if (P > 0) {
+#pragma unroll
+        for (int u = 0; u < MS2_UN; u++) fetch(lane * P + u, nxt[u]);
+    }
 #pragma unroll 1
     for (int i = 0; i < P; i += MS2_UN) {
         long long kk[MS2_UN]; uint32_t ll[MS2_UN]; RunAcc pp[MS2_UN];
 #pragma unroll
-        for (int u = 0; u < MS2_UN; u++) pixel(lane * P + i + u, kk[u], ll[u], pp[u]);
+        for (int u = 0; u < MS2_UN; u++) { cur[u] = nxt[u]; fetch(lane * P + i + MS2_UN + u, nxt[u]); }
+#pragma unroll
+        for (int u = 0; u < MS2_UN; u++) pixel(lane * P + i + u, cur[u], kk[u], ll[u], pp[u]);
 #pragma unroll
         for (int u = 0; u < MS2_UN; u++) if (i + u < P && lane * P + i + u < V) accumulate(kk[u], ll[u], pp[u]);
     }
