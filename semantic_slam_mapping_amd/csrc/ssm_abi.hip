@@ -968,6 +968,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             StreamSwap sw(c, side);
             hipStream_t s = map3 ? c->stream3 : c->stream;                // = stream2 inside this scope (unless serialised)
             uint8_t* mask_ws = map3 ? c->d_mask3 : c->d_mask;
+            struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } onmap(c, s);   // the stage events follow the kernels
             const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
             if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
                 r = seg_init(c); if (r) return r;
