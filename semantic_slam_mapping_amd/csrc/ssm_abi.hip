@@ -86,8 +86,9 @@ struct ssm_ctx {
     int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr; uint4* d_kpaux = nullptr;
     // second ORB / map workspace: ssm_seq_process runs alternate sub-batches as two chains on two streams (allocated at first use)
     struct AltWork { uint8_t *pyr = nullptr, *blur = nullptr; int32_t* cellmax = nullptr; cand_t* cand = nullptr; uint16_t* nodeof = nullptr;
-                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; uint4* kpaux = nullptr; bool ready = false; } alt;
-    hipEvent_t ev_orb[2] = {nullptr, nullptr};
+                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; uint4* kpaux = nullptr; bool ready = false; } alt, alt2;
+    hipEvent_t ev_orb[3] = {nullptr, nullptr, nullptr};
+    hipStream_t stream4 = nullptr; hipEvent_t ev_join4 = nullptr; int nchains = 3;      // a third ORB -> match chain (workspace alt2, stream4) when a call has more than two sub-batches; SSM_CHAINS=2: two
     uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
     ssm_point* d_points = nullptr;
     // staging for the host-pointer entry points (one frame) + generic scratch
@@ -288,7 +289,8 @@ static int ctx_init(ssm_ctx* c)
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[1], hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[i], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
     {   float pf[1024]; const int8_t* src = cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern;
@@ -356,6 +358,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SSM_E_HIP; }
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
+    { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
@@ -382,7 +385,11 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     for (void* p : ptrs) if (p) hipFree(p);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
-    for (int i = 0; i < 2; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
+    for (int i = 0; i < 3; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
+    { void* ap2[] = { c->alt2.pyr, c->alt2.blur, c->alt2.cellmax, c->alt2.cand, c->alt2.nodeof, c->alt2.ncand, c->alt2.sel, c->alt2.nsel, c->alt2.mask, c->alt2.kpaux };
+      for (void* p : ap2) if (p) hipFree(p); }
+    if (c->stream4) hipStreamDestroy(c->stream4);
+    if (c->ev_join4) hipEventDestroy(c->ev_join4);
     for (int l = 0; l < SSM_MAX_LEVELS; l++) { if (c->d_xofs[l]) hipFree(c->d_xofs[l]); if (c->d_xa[l]) hipFree(c->d_xa[l]); if (c->d_yofs[l]) hipFree(c->d_yofs[l]); if (c->d_ya[l]) hipFree(c->d_ya[l]); if (c->d_xgrp[l]) hipFree(c->d_xgrp[l]); }
     if (c->seg) {
         SegNetState* g = c->seg;
@@ -439,25 +446,32 @@ extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, in
 }
 
 // second workspace for the two-chain mode of ssm_seq_process (same sizes as ctx_init's)
-static int ensure_alt(ssm_ctx* c)
+static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
 {
-    if (c->alt.ready) return SSM_OK;
+    if (a.ready) return SSM_OK;
     const OrbGeom& g = c->g; const int B = c->B;
-    DALLOC(c, c->alt.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->alt.blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->alt.cellmax, (size_t)B * g.cells_total);
-    DALLOC(c, c->alt.cand, (size_t)B * g.cand_total); DALLOC(c, c->alt.nodeof, (size_t)B * g.cand_total);
-    DALLOC(c, c->alt.ncand, (size_t)B * g.nlevels); DALLOC(c, c->alt.sel, (size_t)B * g.sel_total); DALLOC(c, c->alt.nsel, (size_t)B * g.nlevels);
-    DALLOC(c, c->alt.mask, (size_t)B * g.W * g.H); DALLOC(c, c->alt.kpaux, (size_t)B * g.sel_total * 2);
-    DALLOC(c, c->d_mask3, (size_t)B * g.W * g.H);
-    c->alt.ready = true;
+    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.pyr_bytes); DALLOC(c, a.cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, a.cand, (size_t)B * g.cand_total); DALLOC(c, a.nodeof, (size_t)B * g.cand_total);
+    DALLOC(c, a.ncand, (size_t)B * g.nlevels); DALLOC(c, a.sel, (size_t)B * g.sel_total); DALLOC(c, a.nsel, (size_t)B * g.nlevels);
+    DALLOC(c, a.mask, (size_t)B * g.W * g.H); DALLOC(c, a.kpaux, (size_t)B * g.sel_total * 2);
+    a.ready = true;
     return SSM_OK;
 }
-struct ChainSwap {                    // chain 1 of ssm_seq_process: the helpers use c->stream and the c->d_* workspace; point both at the second set
-    ssm_ctx* c; bool on;
-    void swap_all() { std::swap(c->stream, c->stream2); std::swap(c->d_pyr, c->alt.pyr); std::swap(c->d_blur, c->alt.blur); std::swap(c->d_cellmax, c->alt.cellmax);
-                      std::swap(c->d_cand, c->alt.cand); std::swap(c->d_nodeof, c->alt.nodeof); std::swap(c->d_ncand, c->alt.ncand); std::swap(c->d_sel, c->alt.sel);
-                      std::swap(c->d_nsel, c->alt.nsel); std::swap(c->d_mask, c->alt.mask); std::swap(c->d_kpaux, c->alt.kpaux); }
-    ChainSwap(ssm_ctx* c_, bool on_) : c(c_), on(on_) { if (on) swap_all(); }
-    ~ChainSwap() { if (on) swap_all(); }
+static int ensure_alt(ssm_ctx* c)
+{
+    int r = ensure_alt_ws(c, c->alt); if (r) return r;
+    if (c->nchains >= 3) { r = ensure_alt_ws(c, c->alt2); if (r) return r; }
+    if (!c->d_mask3) DALLOC(c, c->d_mask3, (size_t)c->B * c->g.W * c->g.H);
+    return SSM_OK;
+}
+struct ChainSwap {                    // chains 1, 2 of ssm_seq_process: the helpers use c->stream and the c->d_* workspace; point both at that chain's set
+    ssm_ctx* c; int chain;
+    void swap_all() { ssm_ctx::AltWork& a = chain == 1 ? c->alt : c->alt2;
+                      std::swap(c->stream, chain == 1 ? c->stream2 : c->stream4); std::swap(c->d_pyr, a.pyr); std::swap(c->d_blur, a.blur); std::swap(c->d_cellmax, a.cellmax);
+                      std::swap(c->d_cand, a.cand); std::swap(c->d_nodeof, a.nodeof); std::swap(c->d_ncand, a.ncand); std::swap(c->d_sel, a.sel);
+                      std::swap(c->d_nsel, a.nsel); std::swap(c->d_mask, a.mask); std::swap(c->d_kpaux, a.kpaux); }
+    ChainSwap(ssm_ctx* c_, int chain_) : c(c_), chain(chain_) { if (chain) swap_all(); }
+    ~ChainSwap() { if (chain) swap_all(); }
 };
 // ---------------------------------------------------------------- the ORB front end for nb frames already on the device
 static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_t* d_depth, int nb,
@@ -929,6 +943,8 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     const bool side = side_work && !c->serialize && !two_chains;
     if (two_chains) { r = ensure_alt(c); if (r) return r; }
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    const int nch = two_chains ? (c->nchains >= 3 && n > 2 * c->B ? 3 : 2) : 1;
+    if (nch == 3) HIPCHK(c, hipStreamWaitEvent(c->stream4, c->ev_fork, 0));
     const bool map3 = two_chains && c->map_stream == 1;
     if (map3) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
     struct StreamSwap {               // the helpers below launch on c->stream; point it at stream2 for the side work
@@ -939,8 +955,8 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     int bi = 0;
     for (int f0 = 0; f0 < n; f0 += c->B, bi++) {
         const int nb = (n - f0 < c->B) ? n - f0 : c->B;
-        const int chain = two_chains ? (bi & 1) : 0;
-        ChainSwap cs(c, chain == 1);                                      // from here c->stream / c->d_* are this chain's
+        const int chain = bi % nch, prev_chain = (bi + nch - 1) % nch;
+        ChainSwap cs(c, chain);                                      // from here c->stream / c->d_* are this chain's
         auto front = [&]() -> int {                                       // ORB -> match of this sub-batch
             if (stages & SSM_STAGE_ORB) {
                 r = run_orb(c, in->bgr + (size_t)f0 * npix * 3, 3, in->depth ? in->depth + (size_t)f0 * npix : nullptr, nb,
@@ -949,7 +965,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                 if (mfma) { prof_begin(c, "match"); HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream)); prof_end(c); }
                 if (two_chains) {
                     HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
-                    if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[chain ^ 1], 0));     // the previous sub-batch's descriptors
+                    if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[prev_chain], 0));     // the previous sub-batch's descriptors
                 }
             }
             if (stages & SSM_STAGE_MATCH) {
@@ -1008,6 +1024,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
         else           { r = front(); if (r) return r; r = back(); if (r) return r; }
     }
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (nch == 3) { HIPCHK(c, hipEventRecord(c->ev_join4, c->stream4)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0)); }
     if (map3) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
     c->prev_n = n;
     if (out) {
