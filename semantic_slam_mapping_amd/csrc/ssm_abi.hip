@@ -286,11 +286,6 @@ static int ctx_init(ssm_ctx* c)
 {
     const ssm_config& cfg = c->cfg; const OrbGeom& g = c->g; const int B = c->B, W = g.W, H = g.H;
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    for (int i = 0; i < 3; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[i], hipEventDisableTiming));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming));
     DALLOC(c, c->d_pattern, 1024);
     HIPCHK(c, hipMemcpy(c->d_pattern, cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern, 1024, hipMemcpyHostToDevice));
     {   float pf[1024]; const int8_t* src = cfg.brief_pattern ? cfg.brief_pattern : k_default_pattern;
@@ -446,6 +441,20 @@ extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, in
 }
 
 // second workspace for the two-chain mode of ssm_seq_process (same sizes as ctx_init's)
+// The side streams of ssm_seq_process (stream2: second chain / SegNet + map side; stream3: map stage; stream4: third chain) are created at first use, not
+// with the context: HIP spreads streams over a few hardware queues in creation order, and a context that only serves per-frame calls (the stereo bench
+// runs eight of them) should take ONE slot of that rotation -- with four streams per context every context's main stream landed on the same queue
+// (configs[3]: 233 instead of 346-386 frame pairs/s).
+static int ensure_side_streams(ssm_ctx* c)
+{
+    if (c->stream2) return SSM_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[i], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming));
+    return SSM_OK;
+}
 static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
 {
     if (a.ready) return SSM_OK;
@@ -941,6 +950,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     // dependence between neighbours is the matcher's: the reference descriptors of sub-batch b - 1 (an event per chain).
     const bool two_chains = !c->serialize && !(stages & SSM_STAGE_SEGNET) && n > c->B && (stages & SSM_STAGE_ORB) && (W & 15) == 0;
     const bool side = side_work && !c->serialize && !two_chains;
+    if (side || two_chains) { r = ensure_side_streams(c); if (r) return r; }
     if (two_chains) { r = ensure_alt(c); if (r) return r; }
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     const int nch = two_chains ? (c->nchains >= 3 && n > 2 * c->B ? 3 : 2) : 1;
