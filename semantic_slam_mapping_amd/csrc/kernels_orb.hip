@@ -257,7 +257,7 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         hp2[j * (BT_W / 4) + lq] = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
     }
     __syncthreads();
-    uint8_t* dst = blur + (size_t)frame * g.pyr_bytes + L.img_off;
+    uint8_t* dst = blur + (size_t)frame * g.blur_bytes;                // tiled layout: blur_off()
     for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
         const int ly = i >> 5, lq = i & 31;
         const int gx = tx0 + 4 * lq, gy = ty0 + ly;
@@ -282,7 +282,7 @@ blur_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, OrbGeom
         const us2 q23 = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm(a3, a2, 0x07060302u)), lim);
         uint32_t out = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q23), __builtin_bit_cast(uint32_t, q01), 0x06040200u);
         if (gx + 3 >= w) out &= gx >= w ? 0u : (0xFFFFFFFFu >> (8 * (gx + 4 - w)));       // keep the padding columns zero
-        *reinterpret_cast<uint32_t*>(dst + (size_t)gy * stride + gx) = out;
+        *reinterpret_cast<uint32_t*>(dst + blur_off(L.boff, stride, gx, gy)) = out;
     }
 }
 hipError_t k_blur(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blur, hipStream_t s)
@@ -352,7 +352,7 @@ blur_mfma_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Or
     const int X0 = (strip - L.bt_off) * 128;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* src = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
-    uint8_t* dst = blur + (size_t)frame * g.pyr_bytes + L.img_off;
+    uint8_t* dst = blur + (size_t)frame * g.blur_bytes;                  // tiled layout: blur_off()
     auto ld = [](const uint4* p) { const uint4 v = *p; return bm_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; };
     const int c0 = X0 + 32 * wv;
     const bool active = c0 < stride;
@@ -442,7 +442,7 @@ blur_mfma_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Or
         __syncthreads();
         for (int i = tid; i < BLUR_ROWS * 8; i += 256) {
             const int row = i >> 3, q = i & 7, gx = X0 + 16 * q, gy = y0 + row;
-            if (gx < stride && gy < h) *reinterpret_cast<uint4*>(dst + (size_t)gy * stride + gx) = *reinterpret_cast<const uint4*>(sout + row * BM_OUT_RS + 16 * q);
+            if (gx < stride && gy < h) *reinterpret_cast<uint4*>(dst + blur_off(L.boff, stride, gx, gy)) = *reinterpret_cast<const uint4*>(sout + row * BM_OUT_RS + 16 * q);
         }
     }
 }
@@ -1261,13 +1261,14 @@ brief_kernel(OrbGeom g, const uint8_t* __restrict__ blur, const KpRec* __restric
 #pragma unroll
         for (int j = 0; j < BR_KPW; j++) {
             if (r[j].oidx < 0) continue;
-            const int stride = (int)(r[j].stride_level & 0xFFFFu), x = r[j].pk & 4095;
-            const uint8_t* ctr = blur + (size_t)f * g.pyr_bytes + r[j].off;        // the keypoint's pixel in the blurred level
+            const int stride = (int)(r[j].stride_level & 0xFFFFu), x = r[j].pk & 4095, y = (r[j].pk >> 12) & 4095;
+            const uint8_t* lv = blur + (size_t)f * g.blur_bytes;                 // the blurred pyramid is tiled (blur_off): a 37-row patch covers ~25 lines, not ~47
+            const int boff = g.L[r[j].stride_level >> 16].boff;
             const int xb0 = (x - 18) & ~15;
 #pragma unroll
             for (int q = 0; q < BR_PW; q++) {
                 const int e = lane + 64 * q, rr = e >> 2, c = e & 3, gx = xb0 + 16 * c;
-                pw[j][q] = (e < DP_ROWS_B * DP_QW_B && gx < stride) ? *reinterpret_cast<const uint4*>(ctr + (ptrdiff_t)(rr - 18) * stride + (gx - x)) : make_uint4(0, 0, 0, 0);
+                pw[j][q] = (e < DP_ROWS_B * DP_QW_B && gx < stride) ? *reinterpret_cast<const uint4*>(lv + blur_off(boff, stride, gx, y + rr - 18)) : make_uint4(0, 0, 0, 0);
             }
         }
     };

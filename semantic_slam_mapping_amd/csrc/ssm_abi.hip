@@ -152,12 +152,12 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         for (int v = SSM_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
         for (int v = 0; v <= SSM_HALF_PATCH; v++) g.umax[v] = um[v];
     }
-    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0, btiles = 0, bunits = 0;
+    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0, btiles = 0, bunits = 0, boff = 0;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.L[l];
         L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
         if (L.w < 2 * SSM_EDGE + 8 + 30 || L.h < 2 * SSM_EDGE + 8 + 30) { err = "pyramid level too small for the ORB border; lower orb_levels"; return SSM_E_INVAL; }
-        L.stride = (L.w + 15) & ~15; L.img_off = off; off += L.stride * L.h;      /* rows 16-B aligned: wide loads/stores everywhere */
+        L.stride = (L.w + 15) & ~15; L.img_off = off; off += L.stride * L.h; L.boff = boff; boff += L.stride * ((L.h + 7) & ~7);      /* rows 16-B aligned: wide loads/stores everywhere */
         L.minBX = SSM_EDGE - 3; L.minBY = SSM_EDGE - 3; L.maxBX = L.w - SSM_EDGE + 3; L.maxBY = L.h - SSM_EDGE + 3;
         const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
@@ -178,7 +178,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         if (4 * nIni + 8 > SSM_MAX_NODES) { err = "aspect ratio too extreme"; return SSM_E_INVAL; }
         L.sf = sf[l];
     }
-    g.bt_total = btiles; g.bt_units_total = bunits;
+    g.bt_total = btiles; g.bt_units_total = bunits; g.blur_bytes = boff;
     g.pyr_bytes = off; g.tiles_total = tiles; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
     g.cap = c.orb_features + 3 * g.nlevels;
     return SSM_OK;
@@ -329,7 +329,7 @@ static int ctx_init(ssm_ctx* c)
         }
     }
     // d_pyr + 16: resize4_kernel's 8-byte windows may end past the last row
-    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.pyr_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.blur_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total * 2);          // KpAux + KpRec per slot
@@ -459,7 +459,7 @@ static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
 {
     if (a.ready) return SSM_OK;
     const OrbGeom& g = c->g; const int B = c->B;
-    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.pyr_bytes); DALLOC(c, a.cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.blur_bytes); DALLOC(c, a.cellmax, (size_t)B * g.cells_total);
     DALLOC(c, a.cand, (size_t)B * g.cand_total); DALLOC(c, a.nodeof, (size_t)B * g.cand_total);
     DALLOC(c, a.ncand, (size_t)B * g.nlevels); DALLOC(c, a.sel, (size_t)B * g.sel_total); DALLOC(c, a.nsel, (size_t)B * g.nlevels);
     DALLOC(c, a.mask, (size_t)B * g.W * g.H); DALLOC(c, a.kpaux, (size_t)B * g.sel_total * 2);

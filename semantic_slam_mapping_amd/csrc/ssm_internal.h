@@ -25,13 +25,19 @@ struct LevelGeom {
     float hX;                  // root node width
     float sf;                  // mvScaleFactor[level]
     uint32_t mulTX;            // ceil(2^32 / tiles_x), same use
+    int boff;                  // byte offset of the level inside one frame's BLURRED pyramid (tiled: see blur_off)
     int bt_off, bt_x, bt_units_off;   // blur_mfma_kernel: first 128-column strip of the level, strips of the level, first 32-column unit table
     uint32_t mulW, mulH;       // ceil(2^32 / wCell), ceil(2^32 / hCell): floor(n / cell) == __umulhi(n, mul) for n < 4096 (exact: n * (mul * cell - 2^32) < 2^32)
 };
+// The blurred pyramid is stored in tiles of 8 rows x 16 columns (128 bytes = one cache line): its only reader, brief_kernel, gathers 37 x 37 patches,
+// and a patch covers ~25 such lines instead of the ~47 it touches in a row-major image (a 37-byte row segment drags in a whole 128-byte line).
+// Offset of the 16-byte word that holds (x, y): rows padded to a multiple of 8.
+__host__ __device__ inline int blur_off(int boff, int stride, int x, int y) { return boff + (((y >> 3) * (stride >> 4) + (x >> 4)) << 7) + ((y & 7) << 4) + (x & 15); }
 struct OrbGeom {
     int nlevels, W, H;
     int pyr_bytes;             // one frame's pyramid (all levels)
     int cells_total, cand_total, sel_total, tiles_total;
+    int blur_bytes;            // one frame's blurred pyramid
     int bt_total, bt_units_total;   // blur_mfma_kernel strips (= blocks) per frame, 32-column unit tables
     int cap;                   // output keypoints per frame (orb_features + 3*levels)
     int ini_th, min_th;
