@@ -256,8 +256,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU per step (configs[1]: 1000); weak scaling")
     ap.add_argument("--total-frames", type=int, default=0, help="strong scaling: ONE stream of this many frames split into contiguous blocks over the GPUs "
                     "(BASELINE configs[4]: --gpus 8 --total-frames 10000)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSM_BATCH", "125")), help="frames per batched launch (a tuning knob: 5 MB of workspace per frame; "
-                    "with three ORB chains and the map stream the rate is flat from 84 to 500 frames; 125 measured best)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSM_BATCH", "250")), help="frames per batched launch (a tuning knob: 5 MB of workspace per frame; "
+                    "with three ORB chains and the map stream the rate is flat (+-2 %%) from 200 to 500 frames and ~3 %% lower at 125)")
     ap.add_argument("--leaf", type=float, default=0.1)
     ap.add_argument("--cpu-frames", type=int, default=int(os.environ.get("SSM_CPU_FRAMES", "150")))
     ap.add_argument("--no-cpu", action="store_true")

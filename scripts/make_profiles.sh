@@ -6,8 +6,8 @@ R=${1:-r02}; O=gpurun_out
 python3 scripts/prof_summary.py $O/p_stats profiles/${R}_kernel_stats.md $O/p_stats.log > /dev/null
 python3 scripts/prof_summary.py $O/p_seg profiles/${R}_segnet_kernel_stats.md $O/p_seg.log > /dev/null
 python3 scripts/prof_summary.py $O/p_st profiles/${R}_stereo_kernel_stats.md $O/p_st.log > /dev/null
-python3 scripts/sq_summary.py $O/p_sq profiles/${R}_sq_counters.md "${R}: rocprofv3 --pmc SQ_* per kernel (bench.py --steps 1 --warmup 0, SSM_BENCH_H2D=0: two passes of 1000 frames, batch 125)" 2000
-python3 scripts/pmc_traffic.py $O/p_fetch $O/p_write profiles/${R}_traffic.json 125 > /dev/null
+python3 scripts/sq_summary.py $O/p_sq profiles/${R}_sq_counters.md "${R}: rocprofv3 --pmc SQ_* per kernel (bench.py --steps 1 --warmup 0, SSM_BENCH_H2D=0: two passes of 1000 frames, batch 250)" 2000
+python3 scripts/pmc_traffic.py $O/p_fetch $O/p_write profiles/${R}_traffic.json 250 > /dev/null
 tail -1 $O/line_default.json > profiles/${R}_bench_line.json
 tail -1 $O/line_segnet.json > profiles/${R}_bench_line_segnet.json
 tail -1 $O/line_stereo.json > profiles/${R}_bench_line_stereo.json
