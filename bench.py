@@ -59,7 +59,7 @@ def algorithmic_bytes(stage, P, nkp):
 STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
                  "blur": ["blur_kernel", "blur_mfma_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
                  "match": ["match_expand_kernel", "match_mfma_kernel", "match_compact_kernel"],
-                 "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel"]}
+                 "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel", "map_stream2_kernel"]}
 
 
 def measured_traffic(stage, frames_per_launch):
@@ -73,7 +73,7 @@ def measured_traffic(stage, frames_per_launch):
 
 
 def measured_valu(stage, us_per_frame):
-    """VALU issue rate of a stage: wave-instructions per frame from the committed rocprofv3 SQ pass (profiles/r01_sq_counters.json)
+    """VALU issue rate of a stage: wave-instructions per frame from the newest committed rocprofv3 SQ pass (profiles/rNN_sq_counters.json)
     x 64 lanes / the stage time measured now, against the measured integer issue ceiling (VALU_LANEOPS_PEAK), or None"""
     try:
         k = json.load(open(latest_profile("sq_counters.json")))["kernels"]
@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
     ap.add_argument("--stereo-workers", type=int, default=int(os.environ.get("SSM_STEREO_WORKERS", "8")), help="configs[3]: frame pairs in flight (host threads, one context each)")
+    ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
+                    "map is compared with byte for byte (the cross-rank CRC check always runs)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -411,6 +413,39 @@ def main():
             del hbuf
         except Exception:
             h2d_fps = None
+    # ---- self-validation of the merge (N > 1, or the 1-rank communicator of SSM_FORCE_MERGE): one more, untimed step in which every rank reads its
+    # local voxel count before the all-gather, then hashes the merged table it exports; the hashes must agree on every rank.  With --verify-whole
+    # (default for strong scaling, where the stream is one) rank 0 also rebuilds the map of the WHOLE stream by itself (map stage only, block by
+    # block through its own buffers) and compares the tables byte for byte: merged == single-GPU.
+    res = ctx.seq_fetch(out, F)                  # the last timed / serialised step's outputs (the validation below overwrites the device buffers)
+    merge_info = None
+    if world > 1 or force_merge:
+        ctx.map_clear()
+        if HN:
+            ctx.seq_process(hb[0].data_ptr(), None, None, None, HN, stages=ssm.api.STAGE_ORB)
+        ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None if args.segnet else sem.data_ptr(), pose.data_ptr(), F, continue_sequence=HN > 0, stages=stages)
+        ctx.sync()
+        n_local = ctx.map_size()
+        ctx.voxel_allgather()
+        n_merged = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
+        merged_bytes = tab_buf[: n_merged * sharding.VOXEL_BYTES].cpu().numpy().tobytes()
+        merge_info = sharding.merge_check(merged_bytes, n_merged, n_local, dist if world > 1 else None, dev)
+        if args.verify_whole and not args.segnet:
+            whole_ok = None
+            if rank == 0:
+                ctx.map_clear()
+                blocks = [sharding.frame_block(args.total_frames, r, world) if args.total_frames > 0 else (r * args.frames, (r + 1) * args.frames) for r in range(world)]
+                for blo, bhi in blocks:
+                    blo += args.first_frame; bhi += args.first_frame
+                    for a in range(blo, bhi, F):
+                        nfr = min(F, bhi - a)
+                        ctx.synth_frames_dev(SEED, a, nfr, bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr())
+                        ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr(), nfr, stages=ssm.api.STAGE_MAP)
+                n_whole = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
+                whole_ok = n_whole == n_merged and tab_buf[: n_whole * sharding.VOXEL_BYTES].cpu().numpy().tobytes() == merged_bytes
+            merge_info["equals_single_gpu_map"] = whole_ok
+            if rank == 0:
+                merge_info["verified"] = bool(merge_info["verified"] and whole_ok)
     frames_all = F
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -420,7 +455,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         frames_all = int(t.item())
 
-    res = ctx.seq_fetch(out, F)
     P_total = int(res["npoints"].sum()); kp_total = int(res["nkp"].sum())
     m = res["nmatch"]; match_total = int(m[m > 0].sum())
     P_all = P_total
@@ -511,6 +545,9 @@ def main():
             "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if merge_info is not None:
+            line["merge_verified"] = merge_info["verified"]
+            line["merge"] = merge_info
     else:
         line = None
     if world > 1 or force_merge:

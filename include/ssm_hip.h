@@ -101,7 +101,10 @@ int ssm_backproject(ssm_ctx* ctx, const uint16_t* depth, const uint8_t* rgb_bgr,
 
 /* ---- pcl::VoxelGrid::filter as used in Mapper::viewer (src/mapper.cpp:106-107,154-155) */
 int ssm_voxel_filter(ssm_ctx* ctx, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out);
-/* the persistent map of the context: table of exact sums keyed by voxel */
+/* the persistent map of the context: table of exact sums keyed by voxel.  A full table DROPS points: the entry point that notices (ssm_map_insert,
+ * ssm_sync after ssm_seq_process) returns SSM_E_CAPACITY once, and from then on ssm_map_size / ssm_map_export* / ssm_voxel_allgather keep returning
+ * SSM_E_CAPACITY for this map -- it is incomplete -- until ssm_map_clear.  Skipped points (non-finite, or outside the 21-bit voxel index range) are
+ * reported once as SSM_E_VOXEL_RANGE and leave the map usable (pcl::VoxelGrid skips such points too). */
 int ssm_map_clear(ssm_ctx* ctx);
 int ssm_map_insert(ssm_ctx* ctx, const ssm_point* pts, int n);                 /* globalMap += cloud */
 int ssm_map_size(ssm_ctx* ctx, int* n_voxels);
@@ -125,7 +128,10 @@ int ssm_comm_init_rank(ssm_ctx* ctx, int nranks, int rank, const void* id);
 int ssm_comm_finalize(ssm_ctx* ctx);
 int ssm_comm_rank(const ssm_ctx* ctx);
 int ssm_comm_size(const ssm_ctx* ctx);
-/* rccl_comm: a ncclComm_t the caller created for this context's device, or NULL = the context's own communicator.  Afterwards the context
+/* COLLECTIVE: every rank of the communicator must call it, and every rank gets the same return code -- the voxel counts travel together with each
+ * rank's table-full flag, and an allocation failure of the receive buffer is agreed on by a second 4-byte all-gather, so no rank can leave between two
+ * collectives while its peers wait in the next one (on any failure no rank has merged anything).
+ * rccl_comm: a ncclComm_t the caller created for this context's device, or NULL = the context's own communicator.  Afterwards the context
  * map of EVERY rank holds the union of all ranks' maps (exact integer sums: bit-identical on every rank and to the single-GPU map).
  * On the context stream: all-gather of the voxel counts, one in-place all-gather of the tables padded to the longest, re-insertion of the
  * nranks - 1 remote tables.  Waits on the host once (for the counts); the merge kernels are enqueued, not waited for. */

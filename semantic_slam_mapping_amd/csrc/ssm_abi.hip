@@ -68,6 +68,7 @@ struct ssm_ctx {
     std::mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool side_ready = false;            // ensure_side_streams completed
     hipStream_t stream2 = nullptr;      // ssm_seq_process: the SegNet + map stage of a sub-batch runs here, beside the ORB + match chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr; uint8_t* d_mask3 = nullptr; int map_stream = 1;   // two-chain mode: the map stage on a stream of its own (SSM_MAP_STREAM=0: on the chain's stream)
@@ -101,7 +102,7 @@ struct ssm_ctx {
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
     uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true; bool map_compact = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
-    VoxTable map, tmp;
+    VoxTable map, tmp; bool map_full_reported = false;   // table-full already reported by check_device_flags (reset by ssm_map_clear)
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1; int32_t* d_comm_counts = nullptr; int comm_counts_cap = 0;
     // SegNet
@@ -250,7 +251,7 @@ static void prof_begin(ssm_ctx* c, const char* name)
 static void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back().b, c->stream); }
 
 // ORB scratch overflow (d_status) is checked after every ORB entry point; the voxel-table-full flag (counters[1]) belongs to the MAP entry points
-// (ssm_sync after ssm_seq_process, ssm_map_*): it is reported once and cleared, so that one overflowing call does not fail every later call on the
+// (ssm_sync after ssm_seq_process, ssm_map_*): it is reported once, so that one overflowing call does not fail every later call on the
 // context (the map then lacks the dropped points: ssm_map_clear / a larger voxel_capacity_log2 is the remedy the message names)
 static int check_device_flags(ssm_ctx* c, bool with_map)
 {
@@ -260,9 +261,15 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
     if (with_map) {
         HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
         if (cnt[1]) {
-            hipMemset(c->map.counters + 1, 0, 4);
-            if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full (points were dropped): ssm_map_clear and raise voxel_capacity_log2");
-            FAIL(c, SSM_E_VOXEL_RANGE, "points with a non-finite coordinate or a voxel index outside (-2^20, 2^20) were skipped (leaf too small for the extent, or a bad pose)");
+            // bit 1 (skipped points: a defined contract, DESIGN.md "voxel key range") is reported once and cleared.  Bit 0 (table full: points were DROPPED,
+            // the map is incomplete) stays set on the device until ssm_map_clear, so that ssm_map_size / ssm_map_export* / ssm_voxel_allgather keep
+            // refusing the incomplete map (and every rank of an all-gather sees it); this function reports it once per fill.
+            if (cnt[1] & 2) { const int32_t keep = cnt[1] & 1; hipMemcpy(c->map.counters + 1, &keep, 4, hipMemcpyHostToDevice); }
+            if ((cnt[1] & 1) && !c->map_full_reported) {
+                c->map_full_reported = true;
+                FAIL(c, SSM_E_CAPACITY, "voxel table full (points were dropped): ssm_map_clear and raise voxel_capacity_log2");
+            }
+            if (cnt[1] & 2) FAIL(c, SSM_E_VOXEL_RANGE, "points with a non-finite coordinate or a voxel index outside (-2^20, 2^20) were skipped (leaf too small for the extent, or a bad pose)");
         }
     }
     return SSM_OK;
@@ -447,12 +454,16 @@ extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, in
 // (configs[3]: 233 instead of 346-386 frame pairs/s).
 static int ensure_side_streams(ssm_ctx* c)
 {
-    if (c->stream2) return SSM_OK;
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    for (int i = 0; i < 3; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_orb[i], hipEventDisableTiming));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming));
+    if (c->side_ready) return SSM_OK;
+    // each handle is created only if it is still missing: a call that failed half-way leaves side_ready false and the next call resumes
+    auto mk_stream = [&](hipStream_t* st) -> hipError_t { return *st ? hipSuccess : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    auto mk_event = [&](hipEvent_t* ev) -> hipError_t { return *ev ? hipSuccess : hipEventCreateWithFlags(ev, hipEventDisableTiming); };
+    HIPCHK(c, mk_stream(&c->stream2));
+    HIPCHK(c, mk_stream(&c->stream3)); HIPCHK(c, mk_event(&c->ev_join3));
+    HIPCHK(c, mk_event(&c->ev_fork)); HIPCHK(c, mk_event(&c->ev_join));
+    for (int i = 0; i < 3; i++) HIPCHK(c, mk_event(&c->ev_orb[i]));
+    HIPCHK(c, mk_stream(&c->stream4)); HIPCHK(c, mk_event(&c->ev_join4));
+    c->side_ready = true;
     return SSM_OK;
 }
 static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
@@ -692,6 +703,7 @@ extern "C" int ssm_map_clear(ssm_ctx* c)
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    c->map_full_reported = false;
     return SSM_OK;
 }
 extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
@@ -812,24 +824,38 @@ extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
     if (!comm) FAIL(c, SSM_E_INVAL, "no communicator: pass a ncclComm_t or call ssm_comm_init_rank");
     int world = 0, rank = 0;
     NCCLCHK(c, ncclCommCount(comm, &world)); NCCLCHK(c, ncclCommUserRank(comm, &rank));
-    if (world > c->comm_counts_cap) {
+    if (world > c->comm_counts_cap) {     // 2 ints per rank + one word of this rank's own flag
         if (c->d_comm_counts) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_comm_counts); c->d_comm_counts = nullptr; c->comm_counts_cap = 0; }
-        DALLOC(c, c->d_comm_counts, (size_t)world); c->comm_counts_cap = world;
+        DALLOC(c, c->d_comm_counts, (size_t)2 * world + 4); c->comm_counts_cap = world;
     }
     hipStream_t s = c->stream;
     prof_begin(c, "allgather");
-    // (1) counts: counters[0] of the map table is the number of occupied voxels, already on the device
-    NCCLCHK(c, ncclAllGather(c->map.counters, c->d_comm_counts, 1, ncclInt32, comm, s));
-    std::vector<int32_t> counts(world);
-    int32_t full = 0;
-    HIPCHK(c, hipMemcpyAsync(counts.data(), c->d_comm_counts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&full, c->map.counters + 1, 4, hipMemcpyDeviceToHost, s));
+    // Every decision that can end the call is taken COLLECTIVELY: a rank that returned between two collectives would leave its peers blocked in the
+    // next one.  (1) all-gather {voxel count, flag word} per rank -- counters[0..1] of the map table, already on the device.
+    NCCLCHK(c, ncclAllGather(c->map.counters, c->d_comm_counts, 2, ncclInt32, comm, s));
+    std::vector<int32_t> cf((size_t)2 * world);
+    HIPCHK(c, hipMemcpyAsync(cf.data(), c->d_comm_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (full & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
-    int mx = 1; for (int v : counts) { if (v < 0) FAIL(c, SSM_E_COMM, "negative voxel count received"); if (v > mx) mx = v; }
-    // (2) tables: slot r of the receive buffer = rank r's voxels, mx entries each
+    std::vector<int32_t> counts(world);
+    int mx = 1, bad_rank = -1, neg_rank = -1;
+    for (int q = 0; q < world; q++) { counts[q] = cf[2 * q]; if (cf[2 * q + 1] & 1) bad_rank = q; if (counts[q] < 0) neg_rank = q; if (counts[q] > mx) mx = counts[q]; }
+    if (bad_rank >= 0) { prof_end(c); FAIL(c, SSM_E_CAPACITY, "voxel table of rank " + std::to_string(bad_rank) + " is full (points were dropped): raise voxel_capacity_log2; no rank merged"); }
+    if (neg_rank >= 0) { prof_end(c); FAIL(c, SSM_E_COMM, "negative voxel count received from rank " + std::to_string(neg_rank)); }
+    // (2) the receive buffer: slot r = rank r's voxels, mx entries each.  An allocation failure on one rank is agreed on by a second tiny all-gather.
     const size_t slot = (size_t)mx * sizeof(ssm_voxel);
-    int r = ensure_scratch2(c, slot * world + 256); if (r) return r;
+    const int r_alloc = ensure_scratch2(c, slot * world + 256);
+    {
+        const int32_t ok = r_alloc == SSM_OK ? 0 : 1;
+        HIPCHK(c, hipMemcpyAsync(c->d_comm_counts + 2 * world, &ok, 4, hipMemcpyHostToDevice, s));
+        NCCLCHK(c, ncclAllGather(c->d_comm_counts + 2 * world, c->d_comm_counts, 1, ncclInt32, comm, s));
+        HIPCHK(c, hipMemcpyAsync(cf.data(), c->d_comm_counts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (int q = 0; q < world; q++) if (cf[q]) {
+            prof_end(c);
+            if (r_alloc) return r_alloc;
+            FAIL(c, SSM_E_NOMEM, "rank " + std::to_string(q) + " could not allocate the all-gather buffer; no rank merged");
+        }
+    }
     uint8_t* recv = reinterpret_cast<uint8_t*>(c->d_scratch2);
     int32_t* dn = reinterpret_cast<int32_t*>(recv + slot * world);
     HIPCHK(c, k_voxel_compact(c->map.tab, c->map.cap_log2, reinterpret_cast<ssm_voxel*>(recv + slot * rank), dn, s));
@@ -965,7 +991,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     int bi = 0;
     for (int f0 = 0; f0 < n; f0 += c->B, bi++) {
         const int nb = (n - f0 < c->B) ? n - f0 : c->B;
-        const int chain = bi % nch, prev_chain = (bi + nch - 1) % nch;
+        const int chain = bi % nch;
         ChainSwap cs(c, chain);                                      // from here c->stream / c->d_* are this chain's
         auto front = [&]() -> int {                                       // ORB -> match of this sub-batch
             if (stages & SSM_STAGE_ORB) {
@@ -974,8 +1000,11 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                 if (r) return r;
                 if (mfma) { prof_begin(c, "match"); HIPCHK(c, k_match_expand(c->d_desc_all, c->d_nkp_all, R + f0, nb, g.cap, c->capT, c->d_exp_q, c->d_exp_t, c->stream)); prof_end(c); }
                 if (two_chains) {
+                    // The matcher of sub-batch bi reads the descriptor rows of the R preceding FRAMES, i.e. (max_batch < tracker_ref_frames) of several
+                    // preceding sub-batches.  Every other chain's newest event is the ORB + expand of one of bi-1 .. bi-(nch-1); an older sub-batch sits on
+                    // one of those streams (or on this one) in front of that record, so waiting on all of them orders the matcher behind every row it reads.
                     HIPCHK(c, hipEventRecord(c->ev_orb[chain], c->stream));
-                    if (bi > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[prev_chain], 0));     // the previous sub-batch's descriptors
+                    for (int k = 1; k < nch && k <= bi; k++) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_orb[(bi - k) % nch], 0));
                 }
             }
             if (stages & SSM_STAGE_MATCH) {

@@ -4,52 +4,86 @@
 // (synthetic | raw | tum | kitti; the reference hard-codes its FrameReader type); with tum / kitti the poses come from the
 // tracker (use_stream_pose defaults to 0 there); prints frames/s at the end.
 //
-// `exp_mapping <parameters> --ranks N`: the multi-GPU form (BASELINE.json configs[4]; the reference is one process).  The parent forks
-// N ranks BEFORE anything touches HIP; rank r drives GPU r, owns the contiguous frame block [lo, hi) of [start_index, end_index), feeds the
-// tracker_ref_frames frames in front of its block to the tracker only (the matcher halo: Tracker::trackRefFrame matches against the refFrames deque,
-// src/track.cpp:150-152), maps its key-frames as usual, then inserts their clouds into one context map and calls ssm_voxel_allgather (ONE RCCL
-// all-gather behind the C ABI).  Every rank ends with the map of the whole sequence; rank 0 prints it.  The ncclUniqueId travels through a page of
-// shared memory the parent mapped before forking.
+// `exp_mapping <parameters> --ranks N`: the multi-GPU form (BASELINE.json configs[4]; the reference is one process).  The parent starts
+// N FRESH processes of itself (`--rank r`, fork + exec of /proc/self/exe) before anything touches HIP -- a forked copy of a process whose HIP / RCCL
+// static constructors have already run is not a state either library is tested in; rank r drives GPU r, owns the contiguous frame block [lo, hi) of
+// [start_index, end_index), feeds the tracker_ref_frames frames in front of its block to the tracker only (the matcher halo: Tracker::trackRefFrame
+// matches against the refFrames deque, src/track.cpp:150-152), maps its key-frames as usual, then inserts their clouds into one context map and calls
+// ssm_voxel_allgather (ONE RCCL all-gather behind the C ABI).  Every rank ends with the map of the whole sequence; rank 0 prints it.  The ncclUniqueId
+// travels through a file in a private temporary directory (written under another name, then renamed).  The parent reaps with waitpid(-1): the first
+// rank that fails (or `rank_timeout_s`, default 900) gets the others killed, so a rank blocked in ncclCommInitRank never outlives its failed peer.
 #include "ssm/rgbdframe.h"
 #include "ssm/track.h"
 #include "ssm/pose_graph.h"
 #include "ssm/common_headers.h"
 #include "ssm/mapper.h"
 #include "ssm/vo_stereo.hpp"
-#include <atomic>
-#include <sys/mman.h>
+#include <signal.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 using namespace std;
 using namespace rgbd_tutor;
 
-struct RankShared { std::atomic<int> id_ready; unsigned char id[SSM_COMM_ID_BYTES]; std::atomic<int> failed; };
-static int run_rank(ParameterReader& parameterReader, int rank, int nranks, RankShared* sh);
+static int run_rank(ParameterReader& parameterReader, int rank, int nranks, const string& id_dir);
+static FrameReader::DATASET dataset_type(const ParameterReader& pr)
+{
+    const string ds = pr.getData<string>("dataset", string("synthetic"));
+    return ds == "raw" ? FrameReader::RAW : ds == "tum" ? FrameReader::TUM : ds == "kitti" ? FrameReader::KITTI : FrameReader::SYNTHETIC;
+}
 
 int main(int argc, char** argv)
 {
     ParameterReader parameterReader(argc > 1 ? argv[1] : "./parameters.txt");
-    int nranks = 1;
-    for (int i = 2; i + 1 < argc; i++) if (string(argv[i]) == "--ranks") nranks = atoi(argv[i + 1]);
+    int nranks = 1, my_rank = -1; string id_dir;
+    for (int i = 2; i + 1 < argc; i++) {
+        if (string(argv[i]) == "--ranks") nranks = atoi(argv[i + 1]);
+        if (string(argv[i]) == "--rank") my_rank = atoi(argv[i + 1]);
+        if (string(argv[i]) == "--id-dir") id_dir = argv[i + 1];
+    }
+    if (my_rank >= 0) {                                   // a rank process started by the parent below
+        if (nranks < 1 || my_rank >= nranks || id_dir.empty()) { cerr << "exp_mapping: --rank needs --ranks N and --id-dir" << endl; return 2; }
+        try { return run_rank(parameterReader, my_rank, nranks, id_dir); }
+        catch (const exception& e) { cerr << RED << "rank " << my_rank << ": " << e.what() << RESET << endl; return 2; }
+    }
     if (nranks > 1 || parameterReader.getData<int>("force_rank_path", 0)) {
-        // no HIP call has happened in this process yet: fork is safe; the children never exec
-        RankShared* sh = (RankShared*)mmap(nullptr, sizeof(RankShared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
-        if (sh == MAP_FAILED) { perror("mmap"); return 2; }
-        new (sh) RankShared(); sh->id_ready = 0; sh->failed = 0;
+        char tmpl[] = "/tmp/ssm_ranks_XXXXXX";
+        if (!mkdtemp(tmpl)) { perror("mkdtemp"); return 2; }
+        const string dir = tmpl, ranks_s = to_string(nranks);
         vector<pid_t> kids;
         for (int r = 0; r < nranks; r++) {
-            pid_t p = fork();
-            if (p < 0) { perror("fork"); return 2; }
+            pid_t p = fork();                                 // no HIP call has happened in this process; the child execs at once
+            if (p < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 2; }
             if (p == 0) {
-                int rc = 2;
-                try { rc = run_rank(parameterReader, r, nranks, sh); } catch (const exception& e) { cerr << RED << "rank " << r << ": " << e.what() << RESET << endl; }
-                if (rc) sh->failed = 1;
-                _exit(rc);
+                const string rs = to_string(r);
+                const char* av[] = { argv[0], argv[1], "--ranks", ranks_s.c_str(), "--rank", rs.c_str(), "--id-dir", dir.c_str(), nullptr };
+                execv("/proc/self/exe", const_cast<char* const*>(av));
+                perror("execv"); _exit(127);
             }
             kids.push_back(p);
         }
-        int rc = 0;
-        for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1; }
+        const int timeout_s = parameterReader.getData<int>("rank_timeout_s", 900);
+        const auto t0 = chrono::steady_clock::now();
+        int rc = 0; size_t alive = kids.size();
+        while (alive) {
+            int st = 0; const pid_t p = waitpid(-1, &st, WNOHANG);
+            if (p > 0) {
+                alive--;
+                for (pid_t& k : kids) if (k == p) k = -1;
+                if (!WIFEXITED(st) || WEXITSTATUS(st)) {
+                    if (!rc) { cerr << RED << "exp_mapping: a rank failed (status " << st << "); stopping the others" << RESET << endl; for (pid_t k : kids) if (k > 0) kill(k, SIGKILL); }
+                    rc = 1;
+                }
+                continue;
+            }
+            if (p < 0 && errno != EINTR) break;
+            if (chrono::duration<double>(chrono::steady_clock::now() - t0).count() > timeout_s) {
+                if (!rc) { cerr << RED << "exp_mapping: ranks still running after " << timeout_s << " s; killing them" << RESET << endl; for (pid_t k : kids) if (k > 0) kill(k, SIGKILL); }
+                rc = 1;
+            }
+            this_thread::sleep_for(chrono::milliseconds(5));
+        }
+        unlink((dir + "/nccl_id").c_str()); rmdir(dir.c_str());
         return rc;
     }
     VisualOdometryStereo::parameters voparam;
@@ -63,8 +97,7 @@ int main(int argc, char** argv)
     voparam.inlier_threshold = inlier_threshold;
     try {
         Tracker::Ptr tracker(new Tracker(parameterReader, voparam));
-        const string ds = parameterReader.getData<string>("dataset", string("synthetic"));
-        const FrameReader::DATASET type = ds == "raw" ? FrameReader::RAW : ds == "tum" ? FrameReader::TUM : ds == "kitti" ? FrameReader::KITTI : FrameReader::SYNTHETIC;
+        const FrameReader::DATASET type = dataset_type(parameterReader);
         FrameReader frameReader(parameterReader, type);
         PoseGraph poseGraph(parameterReader, tracker);
         Mapper mapper(parameterReader, poseGraph);
@@ -91,7 +124,7 @@ int main(int argc, char** argv)
 }
 
 // one rank of `--ranks N` (its own process, its own GPU)
-static int run_rank(ParameterReader& parameterReader, int rank, int nranks, RankShared* sh)
+static int run_rank(ParameterReader& parameterReader, int rank, int nranks, const string& id_dir)
 {
     ssm::default_device() = rank;
     VisualOdometryStereo::parameters voparam;
@@ -104,7 +137,9 @@ static int run_rank(ParameterReader& parameterReader, int rank, int nranks, Rank
     const int lo = first + rank * base + min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
     const int halo_lo = max(first, lo - R);
     Tracker::Ptr tracker(new Tracker(parameterReader, voparam));
-    FrameReader frameReader(parameterReader, FrameReader::SYNTHETIC);
+    const FrameReader::DATASET type = dataset_type(parameterReader);
+    FrameReader frameReader(parameterReader, type);
+    const bool use_gt_pose = parameterReader.getData<int>("use_stream_pose", (type == FrameReader::TUM || type == FrameReader::KITTI) ? 0 : 1) != 0;
     PoseGraph poseGraph(parameterReader, tracker);
     Mapper mapper(parameterReader, poseGraph);
     auto t0 = chrono::steady_clock::now();
@@ -114,7 +149,7 @@ static int run_rank(ParameterReader& parameterReader, int rank, int nranks, Rank
         if (!frame) break;
         Eigen::Isometry3d gt = frame->T_f_w;
         tracker->updateFrame(frame);
-        frame->setTransform(gt);
+        if (use_gt_pose) frame->setTransform(gt);
         if (i < lo) continue;                                                   // halo frame: the previous rank maps it
         poseGraph.tryInsertKeyFrame(frame);
         nframes++;
@@ -126,9 +161,21 @@ static int run_rank(ParameterReader& parameterReader, int rank, int nranks, Rank
     // ---- the merge: this rank's key-frame clouds into one context map, then ONE all-gather of the voxel tables
     ssm_config cfg = parameterReader.deviceConfig(frameReader.width, frameReader.height);
     ssm::Device dev(cfg);
-    if (rank == 0) { dev.check(ssm_comm_get_unique_id(sh->id), "ssm_comm_get_unique_id"); sh->id_ready.store(1, std::memory_order_release); }
-    else while (!sh->id_ready.load(std::memory_order_acquire)) { if (sh->failed) return 3; this_thread::sleep_for(chrono::milliseconds(1)); }
-    dev.check(ssm_comm_init_rank(dev.ctx(), nranks, rank, sh->id), "ssm_comm_init_rank");
+    unsigned char id[SSM_COMM_ID_BYTES];
+    const string id_path = id_dir + "/nccl_id";
+    if (rank == 0) {
+        dev.check(ssm_comm_get_unique_id(id), "ssm_comm_get_unique_id");
+        const string tmp = id_path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id) || fclose(f) || rename(tmp.c_str(), id_path.c_str())) throw runtime_error("cannot publish the communicator id in " + id_dir);
+    } else {
+        for (;;) {                                                               // the parent kills this process if rank 0 dies first
+            FILE* f = fopen(id_path.c_str(), "rb");
+            if (f) { const size_t got = fread(id, 1, sizeof(id), f); fclose(f); if (got == sizeof(id)) break; }
+            this_thread::sleep_for(chrono::milliseconds(2));
+        }
+    }
+    dev.check(ssm_comm_init_rank(dev.ctx(), nranks, rank, id), "ssm_comm_init_rank");
     size_t local_points = 0;
     for (RGBDFrame::Ptr& kf : poseGraph.keyframes) {
         Mapper::PointCloud::Ptr c = mapper.generatePointCloud(kf);

@@ -62,3 +62,25 @@ def merge_tables_numpy(tables):
         out[f] = np.add.reduceat(allv[f], start)
     out["hist"] = np.add.reduceat(allv["hist"], start, axis=0)
     return out
+
+
+def merge_check(table_bytes, n_voxels, n_local_before_merge, dist, device):
+    """Self-validation of the multi-GPU merge (bench.py prints it as `merge_verified`): after ssm_voxel_allgather every rank must hold the
+    bit-identical key-sorted table.  Each rank hashes its exported merged table (CRC-32 of the raw 112-byte records); the (crc, voxel count,
+    local count before the merge) triples are all-gathered and compared.  Returns a dict: verified (every rank has the same crc and count and the
+    merged map is at least as large as the largest local one), crc, voxels_merged, voxels_per_rank (before the merge)."""
+    import zlib
+    import torch
+    crc = zlib.crc32(bytes(table_bytes)) & 0xFFFFFFFF
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    mine = torch.tensor([crc, int(n_voxels), int(n_local_before_merge)], dtype=torch.int64, device=device)
+    if world > 1:
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rows = [[int(v) for v in t.cpu().tolist()] for t in every]
+    else:
+        rows = [[int(v) for v in mine.cpu().tolist()]]
+    same = all(r[0] == rows[0][0] and r[1] == rows[0][1] for r in rows)
+    sane = rows[0][1] >= max(r[2] for r in rows) and rows[0][1] <= sum(r[2] for r in rows)
+    return {"verified": bool(same and sane), "crc": "%08x" % rows[0][0], "voxels_merged": rows[0][1], "voxels_per_rank": [r[2] for r in rows],
+            "ranks_agree": bool(same)}

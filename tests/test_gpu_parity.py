@@ -208,6 +208,30 @@ def test_voxel_filter_grows_its_table_and_skips_unkeyable_points(oracle):
         c.close()
 
 
+def test_full_map_table_is_reported_once_and_stays_refused_until_cleared():
+    """round-2 advisor finding: after ssm_sync / ssm_map_insert had reported a full table, later exports treated the incomplete map as complete"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=8, camera=CAM)
+    try:
+        rng = np.random.default_rng(7)
+        pts = np.zeros(20000, ssm.POINT_DTYPE)
+        pts["x"] = rng.uniform(-4, 4, len(pts)); pts["y"] = rng.uniform(-3, 3, len(pts)); pts["z"] = rng.uniform(0, 5, len(pts)); pts["w"] = 1.0
+        c.map_clear()
+        with pytest.raises(ssm.SsmError) as e:
+            c.map_insert(pts)
+        assert e.value.code == -4
+        c.sync()                                                     # reported once: a later sync is clean ...
+        for call in (c.map_size, c.map_export, c.map_export_table):  # ... but the incomplete map is not handed out
+            with pytest.raises(ssm.SsmError) as e:
+                call()
+            assert e.value.code == -4
+        c.map_clear()
+        c.map_insert(pts[:50]); c.sync()
+        assert 0 < c.map_size() <= 50
+    finally:
+        c.close()
+
+
 def test_map_insert_merge_is_order_independent(ctx, oracle, frames):
     clouds = [ctx.generate_point_cloud(frames[f][1], frames[f][0], frames[f][2], frames[f][4]) for f in range(3)]
     allp = np.concatenate(clouds)
@@ -451,6 +475,42 @@ def test_two_chain_mode_equals_single_stream(monkeypatch, map_stream, map_first)
                         assert same_struct(x["matches"][f, r, :m], y["matches"][f, r, :m])
         assert same_struct(m1, m2) and len(m1) > 1000
         assert (b1["nmatch"][0] > 0).all()                       # the continued call saw the previous call's frames as references
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
+
+
+@pytest.mark.parametrize("max_batch,n", [(2, 9), (1, 7), (3, 11)])
+def test_three_chains_with_sub_batches_shorter_than_the_reference_window(max_batch, n):
+    """max_batch < tracker_ref_frames: the matcher of a sub-batch reads descriptor rows of SEVERAL preceding sub-batches, which run on the other two
+    chains' streams -- it must wait for every chain's newest ORB event, not only its predecessor's (round-2 advisor finding).  Ten repetitions of the
+    three-chain run against the serialised run (profiling mode 2: one stream, one workspace)."""
+    import semantic_slam_mapping_amd as ssm
+    W, H = 640, 480
+    c = ssm.Context(0, orb_features=500, max_batch=max_batch, voxel_capacity_log2=18, camera=CAM)
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    try:
+        c.synth_frames_dev(SEED, 300, n, *bufs)
+        def run(mode):
+            c.set_profiling(mode); c.map_clear()
+            out = c.seq_process(*bufs, n); c.sync(); a = c.seq_fetch(out, n)
+            c.set_profiling(0)
+            return a, c.map_export()
+        ref, mref = run(2)
+        assert (ref["nmatch"][c.R:] > 0).all()
+        for rep in range(10):
+            a, m = run(0)
+            for k in ("nkp", "nmatch", "npoints"):
+                assert np.array_equal(a[k], ref[k]), (rep, k)
+            for f in range(n):
+                kk = int(ref["nkp"][f])
+                assert np.array_equal(a["desc"][f, :kk], ref["desc"][f, :kk]), (rep, f)
+                for r in range(c.R):
+                    mm = int(ref["nmatch"][f, r])
+                    if mm > 0:
+                        assert same_struct(a["matches"][f, r, :mm], ref["matches"][f, r, :mm]), (rep, f, r)
+            assert same_struct(m, mref)
     finally:
         for p in bufs:
             c.dev_free(p)

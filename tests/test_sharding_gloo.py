@@ -38,7 +38,10 @@ def _worker(rank, world, port, q):
         got = sharding.allgather_tables(buf, len(tab), dist, dev)
         tabs = [np.frombuffer(t.numpy().tobytes(), VOXEL_DTYPE)[:n] for t, n in got]
         merged = sharding.merge_tables_numpy(tabs)
-        q.put((rank, lo, hi, [len(t) for t in tabs], merged.tobytes()))
+        # bench.py's self-validation of the merge: the CRC of every rank's merged table must agree (and a rank that differs must be caught)
+        info = sharding.merge_check(merged.tobytes(), len(merged), len(tab), dist, dev)
+        bad = sharding.merge_check(merged.tobytes() + (b"x" if rank == 1 else b""), len(merged), len(tab), dist, dev)
+        q.put((rank, lo, hi, [len(t) for t in tabs], merged.tobytes(), info, bad))
     finally:
         dist.destroy_process_group()
 
@@ -62,6 +65,11 @@ def test_two_rank_merge_equals_single_process(oracle):
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 3, 3, 5)
     assert res[0][3] == res[1][3] and len(single) > 100
     assert res[0][4] == single.tobytes() and res[1][4] == single.tobytes()
+    import zlib
+    for r in res:
+        assert r[5]["verified"] and r[5]["ranks_agree"] and r[5]["voxels_merged"] == len(single) and r[5]["voxels_per_rank"] == res[0][3]
+        assert r[5]["crc"] == "%08x" % (zlib.crc32(single.tobytes()) & 0xFFFFFFFF)
+        assert not r[6]["verified"] and not r[6]["ranks_agree"]
 
 
 def test_block_plan_and_halo():
