@@ -86,16 +86,47 @@ def measured_valu(stage, us_per_frame):
         return None
 
 
+def stereo_sequence(n, w, h, seed, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), flow=(3, 1), noise=4):
+    """synthetic rectified stereo SEQUENCE (configs[3] shape): a smooth random texture seen through fronto-parallel planes of constant disparity; the
+    camera pans by `flow` pixels per frame, so consecutive frames track (quad matcher) and every pair has a dense disparity (SGBM)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    H, W = h + 64, w + 160 + 256
+    tex = rng.integers(0, 256, (H, W)).astype(np.float32)
+    k = np.array([1, 4, 6, 4, 1], np.float32) / 16.0
+    for ax in (0, 1):                                          # separable 5-tap smoothing (wrap-around borders: the canvas is cropped anyway)
+        tex = sum(k[i] * np.roll(tex, i - 2, axis=ax) for i in range(5))
+    tex = ((tex - tex.min()) / (tex.max() - tex.min()) * 255).astype(np.uint8)
+    dmap = np.zeros((h, w), np.int32)
+    for d, box in planes:
+        if box is None:
+            dmap[:] = d
+        else:
+            y0, y1, x0, x1 = int(box[0] * h), int(box[1] * h), int(box[2] * w), int(box[3] * w)
+            dmap[y0:y1, x0:x1] = d
+    L = np.empty((n, h, w), np.uint8); R = np.empty((n, h, w), np.uint8)
+    for f in range(n):
+        ox, oy = 80 + (f * flow[0]) % 256, (f * flow[1]) % 64
+        win = tex[oy:oy + h, :]
+        R[f] = win[:, ox:ox + w]
+        L[f] = np.take_along_axis(win, np.arange(w)[None, :] - dmap + ox, axis=1)
+        if noise:
+            L[f] = np.clip(L[f].astype(np.int32) + rng.integers(-noise, noise + 1, (h, w)), 0, 255).astype(np.uint8)
+    return L, R
+
+
+KITTI = dict(baseline=0.532331858, cu=607.1928, cv=185.2157, f=718.856, roix=20.0, roiy=5.0, roiz=40.0, scale=1000.0)   # parameters.txt:37-63
+
+
 def stereo_main(args):
-    """configs[3]: KITTI-geometry stereo (1241 x 376, synthetic rectified pairs): per frame the quad matcher on (lc, rc, lp, rp),
-    SGBM depth on (lc, rc) and the stereo visual odometry on the quad matches.  These stages take host images (the reference
-    hands cv::Mat to them), so `value` is a host-to-host rate; the roofline object is for the SGBM kernels (device time by
-    hipEvents, algorithmic bytes = the u16 cost volume written once and read once per scan direction)."""
+    """configs[3]: KITTI-geometry stereo (1241 x 376, synthetic rectified sequence) through the batched device-resident path: a step = one
+    ssm_stereo_seq_process call over F frame pairs resident in HBM -- per frame the quad matcher against the previous frame (GFTT + 4 x pyramidal LK +
+    filteringTracks), SGBM depth (80 disparities, SAD 11) + the ROI depth conversion, and the stereo VO (200 RANSAC hypotheses) on the quad matches.
+    The roofline object is for the SGBM kernels (algorithmic bytes = the u16 cost volume written once and read once per scan direction)."""
     import numpy as np
     import torch
     import semantic_slam_mapping_amd as ssm
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-    from test_sgbm import stereo_pair, KITTI
+    from semantic_slam_mapping_amd.api import GlibcRand
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -104,83 +135,81 @@ def stereo_main(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    Wd, Hd, D = 1241, 376, 80
-    F = min(args.frames, 16) if args.frames != 1000 else 8            # frame pairs per step (replicas on every rank: the stages do not shard below a frame)
-    # frame pairs are independent (each needs only its own four images), so K host threads with one context each keep K pairs
-    # in flight: the stages are chains of small latency-bound kernels and one pair leaves most of the chip idle
-    K = max(1, args.stereo_workers)
-    ctxs = [ssm.Context(local_rank, width=640, height=480) for _ in range(K)]
-    ctx = ctxs[0]
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=K) if K > 1 else None
-    pairs = [stereo_pair(Hd, Wd, 100 + rank * 1000 + i, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), noise=4) for i in range(F + 1)]
-    from oracle.binding import Oracle
-    orc = Oracle()
-    samples = None
-    stage_ms = {"quad_track": 0.0, "sgbm": 0.0, "vo": 0.0}
+    Wd, Hd, D, ITERS = 1241, 376, 80, 200
+    F = args.frames if args.frames != 1000 else 256           # frame pairs per step, resident in HBM (replicas on every rank: the sequence of a rank is its own)
+    B = max(1, args.stereo_batch)
+    os.environ["SSM_STEREO_BATCH"] = str(B)
+    ctx = ssm.Context(local_rank, width=640, height=480, max_batch=1)
+    L, R = stereo_sequence(F, Wd, Hd, 100 + rank)
+    dl = ctx.dev_alloc(L.nbytes); dr = ctx.dev_alloc(R.nbytes); ds = ctx.dev_alloc(F * ITERS * 3 * 4)
+    ctx.h2d(dl, L); ctx.h2d(dr, R); ctx.h2d(ds, GlibcRand(0).draws(F * ITERS * 3))
+    vo = (KITTI["f"], KITTI["cu"], KITTI["cv"], KITTI["baseline"], 2.0, True)
 
-    def one_pair(ctx, i, record):
-        if True:
-            lc, rc, _ = pairs[i]; lp, rp, _ = pairs[i - 1]
-            qm = ctx.quad_track(lc, rc, lp, rp)
-            if record: stage_ms["quad_track"] += ctx.stage_times().get("quad_track", (0.0, 0))[0]
-            depth, disp = ctx.stereo_depth(lc, rc, **KITTI)
-            if record: stage_ms["sgbm"] += ctx.stage_times().get("sgbm", (0.0, 0))[0]
-            if len(qm) >= 6:
-                smp = (np.arange(600, dtype=np.int64).reshape(200, 3) * 7919 + i) % len(qm)        # fixed sample indices (the host class draws them from rand())
-                smp[:, 1] = (smp[:, 0] + 1 + smp[:, 1] % (len(qm) - 1)) % len(qm); smp[:, 2] = (smp[:, 0] + 1 + (smp[:, 1] - smp[:, 0] - 1) % (len(qm) - 1) + 1) % len(qm)
-                ctx.vo_estimate(qm, KITTI["f"], KITTI["cu"], KITTI["cv"], KITTI["baseline"], smp.astype(np.int32))
-                if record: stage_ms["vo"] += ctx.stage_times().get("vo", (0.0, 0))[0]
-            return len(qm)
+    def step():
+        out = ctx.stereo_seq_process(dl, dr, F, Wd, Hd, vo=vo, ransac_iters=ITERS, rand_stream_dev=ds, **KITTI)
+        ctx.sync()
+        return out
 
-    def step(record):
-        if record or pool is None:                      # the per-stage device times come from one context, one pair at a time
-            return sum(one_pair(ctx, i, record) for i in range(1, F + 1))
-        return sum(pool.map(lambda i: one_pair(ctxs[i % K], i, False), range(1, F + 1)))
+    def fence():
+        torch.cuda.synchronize(); ctx.sync()
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
+        step()
+    ctx.set_profiling(2 if args.serial_only else 1)
+    fence()
     t0 = time.perf_counter()
+    stage_ovl = {}
     for _ in range(args.steps):
-        nm = step(False)
-    torch.cuda.synchronize()
-    if world > 1: dist.barrier()
+        out = step()
+        for k, (ms, ln) in ctx.stage_times().items():
+            a = stage_ovl.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += ln
+    fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank)); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-    ctx.set_profiling(1)
-    for _ in range(args.steps):
-        step(True)
+    # undisturbed stage durations: the same steps with SGBM on the chain's stream (profiling mode 2)
+    stage_acc = {k: list(v) for k, v in stage_ovl.items()} if args.serial_only else {}
+    ctx.set_profiling(2)
+    for _ in range(0 if args.serial_only else max(1, min(args.steps, 3))):
+        step()
+        for k, (ms, ln) in ctx.stage_times().items():
+            a = stage_acc.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += ln
     ctx.set_profiling(0)
+    res = ctx.stereo_seq_fetch(out, F, Wd, Hd, 1 | 4)
     if rank != 0:
         return
+    nser = args.steps if args.serial_only else max(1, min(args.steps, 3))
     frames = world * F * args.steps
-    sg_ms = stage_ms["sgbm"] / (F * args.steps)
+    sg_ms_launch = stage_acc["sgbm"][0] / max(stage_acc["sgbm"][1], 1)
+    fpl = F * nser / max(stage_acc["sgbm"][1], 1)            # frame pairs per SGBM launch group
     vol = (Wd - D) * Hd * D
-    alg = 6 * vol * 2                                       # u16 cost volume: written once, read once by each of the 5 scan directions
-    ach = alg / (sg_ms * 1e-3) / 1e9
+    alg = 6 * vol * 2 * fpl                                 # u16 cost volume: written once, read once by each of the 5 scan directions
+    ach = alg / (sg_ms_launch * 1e-3) / 1e9
     cpu = None
     if world == 1 and not args.no_cpu:
-        lc, rc, _ = pairs[1]
-        t1 = time.perf_counter(); ref = orc.sgbm(lc, rc, orc.sgbm_params()); orc.disparity_to_depth(ref, **KITTI); tc = time.perf_counter() - t1
-        lp, rp, _ = pairs[0]
-        t1 = time.perf_counter(); orc.quad_track(lc, rc, lp, rp); tq = time.perf_counter() - t1
+        from oracle.binding import Oracle                   # the checker, here only as the timed CPU baseline
+        orc = Oracle()
+        t1 = time.perf_counter(); ref = orc.sgbm(L[1], R[1], orc.sgbm_params()); orc.disparity_to_depth(ref, **KITTI); tc = time.perf_counter() - t1
+        t1 = time.perf_counter(); qm = orc.quad_track(L[1], R[1], L[0], R[0]); tq = time.perf_counter() - t1
         cpu = {"value": round(1.0 / (tc + tq), 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "one frame pair of the same stream: oracle/ quad matcher + SGBM + depth conversion (C, 1 thread); the VO is below a millisecond",
-               "ms_per_frame": {"sgbm": round(tc * 1e3, 2), "quad_track": round(tq * 1e3, 2)}}
+               "sample": "one frame pair of the same sequence: oracle/ quad matcher + SGBM + depth conversion (C, 1 thread); the VO is below a millisecond",
+               "ms_per_frame": {"sgbm": round(tc * 1e3, 2), "quad_track": round(tq * 1e3, 2)},
+               "quad_matches_equal_gpu": bool(int(res["nquad"][1]) == len(qm) and res["quad"][1, :len(qm)].tobytes() == qm.tobytes())}
+    nq = res["nquad"][1:]
     line = {"metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i16", "data": "synthetic",
-            "config": {"workload": "configs[3] stages: synthetic rectified stereo 1241x376 (seeded textured planes), per frame pair: quad matcher (GFTT + 4x LK), "
-                                   "SGBM depth (80 disparities, SAD 11) + ROI depth conversion, stereo VO (200 RANSAC hypotheses); host images in, host results out",
-                       "frame_pairs_per_gpu": F, "pairs_in_flight": K, "parallelism": "replicas" if world > 1 else "single GPU"},
-            "per_frame": {"quad_matches": round(nm / F, 1)},
-            "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle: all kernels of ssm_sgbm)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
-                         "note": "first version: the scan recurrences are latency chains (16 lanes per path), see DESIGN.md s.4",
-                         "stages_ms_per_frame": {k: round(v / (F * args.steps), 3) for k, v in stage_ms.items()}},
+            "config": {"workload": "configs[3] stages: synthetic rectified stereo sequence 1241x376 (seeded textured planes, 3 px/frame pan), per frame pair: quad matcher "
+                                   "against the previous frame (GFTT + 4x LK), SGBM depth (80 disparities, SAD 11) + ROI depth conversion, stereo VO (200 RANSAC "
+                                   "hypotheses); %d frame pairs resident in HBM per step, ssm_stereo_seq_process" % F,
+                       "frame_pairs_per_gpu": F, "frame_pairs_per_launch": B, "parallelism": "replicas" if world > 1 else "single GPU"},
+            "per_frame": {"quad_matches": round(float(nq.mean()), 1), "vo_success_rate": round(float(res["vo_result"][1:, 1].mean()), 3)},
+            "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle, depth: all kernels of the SGBM stage)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(alg),
+                         "stages_ms_per_frame": {k: round(v[0] / (F * nser), 4) for k, v in stage_acc.items()},
+                         "stages_ms_per_frame_overlapped": {k: round(v[0] / (F * args.steps), 4) for k, v in stage_ovl.items()}},
             "cpu_baseline": cpu}
     print(json.dumps(line))
 
@@ -266,7 +295,7 @@ def main():
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
-    ap.add_argument("--stereo-workers", type=int, default=int(os.environ.get("SSM_STEREO_WORKERS", "8")), help="configs[3]: frame pairs in flight (host threads, one context each)")
+    ap.add_argument("--stereo-batch", type=int, default=int(os.environ.get("SSM_STEREO_BATCH", "32")), help="configs[3]: frame pairs per launch of the batched stereo path (0.45 GB of SGBM workspace each)")
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")

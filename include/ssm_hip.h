@@ -214,6 +214,48 @@ typedef struct { double f, cu, cv, base, inlier_threshold; int32_t reweighting, 
 int ssm_vo_estimate(ssm_ctx* ctx, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
                     double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success);
 
+/* ---- device-resident batched stereo path (BASELINE.json configs[3]): n frames of a rectified stereo sequence, all DEVICE pointers.
+ * The reference walks the KITTI sequence one frame at a time: FrameReader::next() computes the depth of the current pair with SGBM
+ * (src/rgbdframe.cpp:64-116, src/stereo.cpp:11-30), Tracker::estimateVO builds a QuadFeatureMatch on (current left, current right, previous left,
+ * previous right), runs detectFeature + circularMatching (src/track.cpp:45-59, src/quadmatcher.cpp:388-417,548-588) and hands the quad matches to
+ * VisualOdometryStereo::Process (src/track.cpp:62, src/vo_stereo.cpp:18-152).  Frame pairs are independent of each other (the pose chain only
+ * multiplies the per-frame motions), so this entry point runs those three stages for EVERY frame of the sequence in bulk: frame f is "current",
+ * frame f - 1 "previous" (frame 0: the last frame of the previous call when continue_sequence = 1, else it has no quad matches: nquad = -1).
+ * The per-pair entry points above (ssm_quad_track, ssm_gftt, ssm_lk_track, ssm_sgbm, ssm_stereo_depth) run the same kernels with one frame. */
+enum { SSM_STEREO_QUAD = 1, SSM_STEREO_DEPTH = 2, SSM_STEREO_VO = 4 /* needs SSM_STEREO_QUAD */ };
+typedef struct {
+    const uint8_t* left;      /* n x h x w, 8-bit gray, packed */
+    const uint8_t* right;     /* n x h x w */
+    int n, w, h;
+    int continue_sequence;    /* 1: frame 0's previous pair is the last frame of the previous call on this context (same w, h; a per-pair stereo call in between ends the sequence) */
+    int stages;               /* bit mask of SSM_STEREO_*, 0 = all */
+    int max_corners;          /* cv::goodFeaturesToTrack maxCorners; QuadFeatureMatch uses the OpenCV default 1000 */
+    ssm_sgbm_params sgbm;     /* ssm_sgbm_params_default = src/stereo.cpp:16-27 */
+    double baseline, cu, cv, f, roix, roiy, roiz, scale;      /* the depth conversion, as in ssm_stereo_depth */
+    ssm_vo_params vo;
+    int ransac_iters;         /* VisualOdometryStereo::parameters::ransac_iters (200) */
+    /* n * ransac_iters * 3 RAW rand() outputs, in the order VisualOdometry::getRandomSample (src/vo.cpp:74-93) would draw them: the host class owns
+     * the stream (srand(0) in its constructor).  A frame with >= 6 quad matches consumes 3 * ransac_iters draws (r % N, r % (N-1), r % (N-2) per
+     * hypothesis), a frame with fewer consumes none (src/vo_stereo.cpp:61-63); *rand_draws_used of the output says how far the stream advanced. */
+    const uint32_t* rand_stream;
+} ssm_stereo_frames_dev;
+typedef struct {              /* DEVICE pointers owned by the context, valid until the next ssm_stereo_seq_process / per-pair stereo call / destroy */
+    const ssm_pmatch* quad;   /* n x max_corners: QuadFeatureMatch::quadmatches of frame f */
+    const int32_t* nquad;     /* n ; -1 = frame without a previous frame */
+    const float*   corners;   /* n x max_corners x 2: the GFTT corners of the current-left image (strength order) */
+    const int32_t* ncorners;  /* n */
+    const int16_t* disp;      /* n x h x w: cv::StereoSGBM output (x16 fixed point) */
+    const uint16_t* depth;    /* n x h x w: FrameReader's depth image */
+    const double*  tr;        /* n x 6: (rx, ry, rz, tx, ty, tz) as ssm_vo_estimate */
+    const int32_t* inliers;   /* n x max_corners: consensus set in index order */
+    const int32_t* vo_result; /* n x 2: {n_inliers, success} */
+    const int32_t* rand_draws_used;   /* 1 int: draws of rand_stream consumed by this call */
+    int max_corners;
+} ssm_stereo_out_dev;
+int ssm_stereo_seq_process(ssm_ctx* ctx, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out);
+/* frames per launch of the stereo path: min(config max_batch, 64), or the environment variable SSM_STEREO_BATCH */
+int ssm_stereo_batch(const ssm_ctx* ctx);
+
 /* ---- Classifier (include/segnet.h:22-46, src/segnet.cpp): SegNet driving_webdemo forward, fp16 MFMA, on the device.
  * Topology is fixed (VGG-16 encoder / mirrored decoder, 26 conv3x3 layers, 12 classes, 480x360 net input); weights
  * are DATA: the .caffemodel is not in the reference tree (README.md:25-32), so the caller supplies every layer.

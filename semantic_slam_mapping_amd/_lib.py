@@ -33,6 +33,28 @@ class SeqOutDev(C.Structure):
                 ("cap", C.c_int), ("R", C.c_int)]
 
 
+class SgbmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("minDisparity", "numberOfDisparities", "SADWindowSize", "P1", "P2", "disp12MaxDiff", "preFilterCap",
+                                         "uniquenessRatio", "speckleWindowSize", "speckleRange")]
+
+
+class VoParams(C.Structure):
+    _fields_ = [("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("base", C.c_double), ("inlier_threshold", C.c_double),
+                ("reweighting", C.c_int32), ("pad", C.c_int32)]
+
+
+class StereoFramesDev(C.Structure):
+    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p), ("n", C.c_int), ("w", C.c_int), ("h", C.c_int), ("continue_sequence", C.c_int),
+                ("stages", C.c_int), ("max_corners", C.c_int), ("sgbm", SgbmParams)] + \
+               [(n, C.c_double) for n in ("baseline", "cu", "cv", "f", "roix", "roiy", "roiz", "scale")] + \
+               [("vo", VoParams), ("ransac_iters", C.c_int), ("rand_stream", C.c_void_p)]
+
+
+class StereoOutDev(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("quad", "nquad", "corners", "ncorners", "disp", "depth", "tr", "inliers", "vo_result", "rand_draws_used")] + \
+               [("max_corners", C.c_int)]
+
+
 # every symbol include/ssm_hip.h declares: name -> (restype, argtypes)
 _P, _I, _D, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_uint64, C.c_size_t
 SYMBOLS = {
@@ -65,6 +87,8 @@ SYMBOLS = {
     "ssm_comm_size": (_I, [_P]),
     "ssm_voxel_allgather": (_I, [_P, _P]),
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
+    "ssm_stereo_seq_process": (_I, [_P, C.POINTER(StereoFramesDev), C.POINTER(StereoOutDev)]),
+    "ssm_stereo_batch": (_I, [_P]),
     "ssm_quad_track": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),
     "ssm_lk_track": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _D, _D]),

@@ -8,7 +8,7 @@ used in Mapper::viewer (src/mapper.cpp:154-155).
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._lib import Camera, Config, FramesDev, SeqOutDev
+from ._lib import Camera, Config, FramesDev, SeqOutDev, SgbmParams, VoParams, StereoFramesDev, StereoOutDev
 
 KEYPOINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
                            ("octave", "i4"), ("class_id", "i4")])
@@ -24,8 +24,49 @@ assert PMATCH_DTYPE.itemsize == 52
 assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16 and POINT_DTYPE.itemsize == 32 and VOXEL_DTYPE.itemsize == 112
 
 STAGE_ORB, STAGE_MATCH, STAGE_MAP, STAGE_SEGNET = 1, 2, 4, 8
+STEREO_QUAD, STEREO_DEPTH, STEREO_VO = 1, 2, 4
 COMM_ID_BYTES = 128
 SEG_NET_W, SEG_NET_H, SEG_CLASSES = 480, 360, 12
+
+
+class GlibcRand:
+    """The rand() stream VisualOdometry::getRandomSample draws from (srand(0) in the constructor, src/vo.cpp:17): glibc's TYPE_3 additive
+    feedback generator, private to the object like in include/ssm/vo_stereo.hpp.  `draws(k)` returns the next k raw outputs (what the batched
+    stereo path takes as rand_stream); `rewind(k)` gives unused draws back (frames with fewer than 6 quad matches draw nothing)."""
+
+    def __init__(self, seed=0):
+        seed = seed or 1
+        r = [seed & 0xFFFFFFFF]
+        for i in range(1, 31):
+            hi, lo = divmod(r[i - 1] if r[i - 1] < 2 ** 31 else r[i - 1] - 2 ** 32, 127773)
+            w = 16807 * lo - 2836 * hi
+            if w < 0:
+                w += 2147483647
+            r.append(w & 0xFFFFFFFF)
+        for i in range(31, 34):
+            r.append(r[i - 31])
+        self._r = r                      # the whole history is kept: rewinding is an index move
+        self._pos = 34
+        for _ in range(310):
+            self._step()
+        self._out = []                   # outputs from position _base on
+        self._taken = 0
+
+    def _step(self):
+        r = self._r
+        r.append((r[-3] + r[-31]) & 0xFFFFFFFF)
+        return r[-1] >> 1
+
+    def draws(self, k):
+        while len(self._out) < self._taken + k:
+            self._out.append(self._step())
+        a = np.array(self._out[self._taken:self._taken + k], np.uint32)
+        self._taken += k
+        return a
+
+    def rewind(self, k):
+        assert 0 <= k <= self._taken
+        self._taken -= k
 
 
 class SsmError(RuntimeError):
@@ -122,6 +163,43 @@ class Context:
         out = np.zeros(max_corners, PMATCH_DTYPE); n = C.c_int(0)
         self._chk(self.lib.ssm_quad_track(self.h, _ptr(ims[0]), _ptr(ims[1]), _ptr(ims[2]), _ptr(ims[3]), w, h, w, max_corners, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    # ---- device-resident batched stereo path (configs[3])
+    def stereo_batch(self):
+        return self.lib.ssm_stereo_batch(self.h)
+
+    def stereo_seq_process(self, left_dev, right_dev, n, w, h, continue_sequence=False, stages=0, max_corners=1000, sgbm=None,
+                           baseline=0.0, cu=0.0, cv=0.0, f=1.0, roix=0.0, roiy=0.0, roiz=0.0, scale=1.0,
+                           vo=None, ransac_iters=200, rand_stream_dev=None):
+        """ssm_stereo_seq_process on n device frame pairs: quad matcher (frame f against f - 1), SGBM depth, stereo VO.  vo = (f, cu, cv, base,
+        inlier_threshold, reweighting); rand_stream_dev = device pointer to n * ransac_iters * 3 raw rand() draws (GlibcRand.draws)."""
+        fr = StereoFramesDev()
+        fr.left, fr.right, fr.n, fr.w, fr.h = left_dev, right_dev, n, w, h
+        fr.continue_sequence, fr.stages, fr.max_corners = int(continue_sequence), stages, max_corners
+        sp = self.sgbm_params() if sgbm is None else np.ascontiguousarray(sgbm, np.int32)
+        fr.sgbm = SgbmParams(*[int(v) for v in sp])
+        fr.baseline, fr.cu, fr.cv, fr.f, fr.roix, fr.roiy, fr.roiz, fr.scale = baseline, cu, cv, f, roix, roiy, roiz, scale
+        if vo is not None:
+            fr.vo = VoParams(vo[0], vo[1], vo[2], vo[3], vo[4], int(vo[5]), 0)
+        fr.ransac_iters = ransac_iters
+        fr.rand_stream = rand_stream_dev
+        out = StereoOutDev()
+        self._chk(self.lib.ssm_stereo_seq_process(self.h, C.byref(fr), C.byref(out)))
+        return out
+
+    def stereo_seq_fetch(self, out, n, w, h, stages=7):
+        """Copy the outputs of stereo_seq_process back to the host (test helper)."""
+        mc = out.max_corners
+        res = {}
+        if stages & STEREO_QUAD:
+            res["nquad"] = self.d2h(out.nquad, n, np.int32); res["quad"] = self.d2h(out.quad, (n, mc), PMATCH_DTYPE)
+            res["ncorners"] = self.d2h(out.ncorners, n, np.int32); res["corners"] = self.d2h(out.corners, (n, mc, 2), np.float32)
+        if stages & STEREO_DEPTH:
+            res["disp"] = self.d2h(out.disp, (n, h, w), np.int16); res["depth"] = self.d2h(out.depth, (n, h, w), np.uint16)
+        if stages & STEREO_VO:
+            res["tr"] = self.d2h(out.tr, (n, 6), np.float64); res["inliers"] = self.d2h(out.inliers, (n, mc), np.int32)
+            res["vo_result"] = self.d2h(out.vo_result, (n, 2), np.int32); res["rand_draws_used"] = int(self.d2h(out.rand_draws_used, 1, np.int32)[0])
+        return res
 
     @staticmethod
     def sgbm_params(**kw):

@@ -12,15 +12,25 @@
 __device__ __forceinline__ int refl101d(int i, int n) { i = i < 0 ? -i : i; i = i >= n ? 2 * n - 2 - i : i; return min(max(i, 0), n - 1); }
 __device__ __forceinline__ int f2ordq(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 
+// Every kernel below takes a FRAME dimension (blockIdx.y or .z): the batched stereo path (ssm_stereo_seq_process) runs them over the nb frame pairs of a
+// sub-batch in one launch, the per-pair entry points (ssm_quad_track, ssm_gftt, ssm_lk_track) are the same launches with nb = 1.
+// Images live in SLOTS: slot s of side 0 (left) / side 1 (right) holds the 4-level LK pyramid of one frame (level l at byte off[l], packed rows) and,
+// in `der`, its Scharr derivatives at the same element offsets.  Slot 0 is the carried previous frame, slot 1 + f is frame f of the sub-batch.
+__device__ __forceinline__ const uint8_t* q_img(const QuadBatch& q, int side, int slot, int level) { return q.pyr + (size_t)(side * q.B1 + slot) * q.slot_elems + q.off[level]; }
+__device__ __forceinline__ const short2* q_der(const QuadBatch& q, int side, int slot, int level) { return reinterpret_cast<const short2*>(q.der) + (size_t)(side * q.B1 + slot) * q.slot_elems + q.off[level]; }
+
 // ------------------------------------------------------------------ cornerMinEigenVal(block 3, ksize 3) on exact integers
 #define ME_W 64
 #define ME_H 16
 __global__ void __launch_bounds__(256)
-mineig_kernel(const uint8_t* __restrict__ img, int w, int h, int stride, float* __restrict__ eig, int* __restrict__ maxord)
+mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord_all)
 {
     __shared__ uint8_t px[ME_H + 4][ME_W + 4];
     __shared__ int16_t dx[ME_H + 2][ME_W + 2], dy[ME_H + 2][ME_W + 2];
     __shared__ int smax;
+    const int w = q.w[0], h = q.h[0], stride = w, f = blockIdx.y;
+    const uint8_t* img = q_img(q, 0, 1 + f, 0);
+    float* eig = eig_all + (size_t)f * w * h; int* maxord = maxord_all + f;
     const int tiles_x = (w + ME_W - 1) / ME_W;
     const int tx0 = (blockIdx.x % tiles_x) * ME_W, ty0 = (blockIdx.x / tiles_x) * ME_H;
     if (threadIdx.x == 0) smax = (int)0x80000000;
@@ -67,13 +77,16 @@ mineig_kernel(const uint8_t* __restrict__ img, int w, int h, int stride, float* 
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(maxord, smax);
 }
-// candidates: v > thr and v equals the 3x3 max of the thresholded map, interior pixels only.  key = value bits << 32 | ~index (sorted descending)
+// candidates: v > thr and v equals the 3x3 max of the thresholded map, interior pixels only.  key = value bits << 32 | ~index: a larger key is a
+// STRONGER corner in cv::goodFeaturesToTrack's walk (value descending, then raster index ascending)
 __global__ void __launch_bounds__(256)
-gftt_collect_kernel(const float* __restrict__ eig, int w, int h, const int* __restrict__ maxord, double quality, unsigned long long* __restrict__ keys,
-                    int* __restrict__ count, int cap)
+gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* __restrict__ maxord_all, double quality, unsigned long long* __restrict__ keys_all,
+                    int* __restrict__ count_all, int cap)
 {
+    const int f = blockIdx.y;
+    const float* eig = eig_all + (size_t)f * w * h; unsigned long long* keys = keys_all + (size_t)f * cap; int* count = count_all + f;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int mo = *maxord; const float mx = __int_as_float(mo >= 0 ? mo : mo ^ 0x7FFFFFFF);
+    const int mo = maxord_all[f]; const float mx = __int_as_float(mo >= 0 ? mo : mo ^ 0x7FFFFFFF);
     const float thr = (float)((double)fmaxf(mx, 0.f) * quality);
     bool keep = false; float v = 0.f;
     const int y = i / w, x = i - y * w;
@@ -84,7 +97,7 @@ gftt_collect_kernel(const float* __restrict__ eig, int w, int h, const int* __re
 #pragma unroll
             for (int j = -1; j <= 1; j++)
 #pragma unroll
-                for (int k = -1; k <= 1; k++) { float q = eig[i + j * w + k]; q = q > thr ? q : 0.f; m = fmaxf(m, q); }
+                for (int k = -1; k <= 1; k++) { float qv = eig[i + j * w + k]; qv = qv > thr ? qv : 0.f; m = fmaxf(m, qv); }
             keep = v == m;
         }
     }
@@ -97,88 +110,106 @@ gftt_collect_kernel(const float* __restrict__ eig, int w, int h, const int* __re
         if (keep) { const int k = base + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); }
     }
 }
-// minDistance selection over the sorted candidates (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one
-// unless an already kept corner lies closer than minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds
-// of local decisions, because a corner's fate depends only on STRONGER corners within minDistance:
+// minDistance selection (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one unless an already kept corner lies closer than
+// minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds of local decisions, because a corner's fate depends only on
+// STRONGER corners within minDistance:
 //   rejected  as soon as a kept corner is that close,
 //   kept      once no stronger corner that close is still undecided (and none is kept),
-// so every round decides at least the strongest undecided corner and most corners settle in the first few rounds.  States only
-// move undecided -> kept / rejected and a decision never reads a weaker corner, so updating in place during a round is safe.
-// The first maxCorners kept corners in strength order are the reference's result (a kept corner never depends on weaker ones).
-// rank_at: per-pixel rank of the candidate sitting there (-1 none); state: 0 undecided, 1 kept, 2 rejected.
-__global__ void __launch_bounds__(256)
-gftt_rank_kernel(const unsigned long long* __restrict__ keys, int nc, int* __restrict__ rank_at, uint8_t* __restrict__ state)
+// so every round decides at least the strongest undecided corner and most corners settle in the first few rounds.  States only move
+// undecided -> kept / rejected and a decision never reads a weaker corner, so updating in place during a round is safe.  The first maxCorners
+// kept corners in strength order are the reference's result (a kept corner never depends on weaker ones).
+// ONE BLOCK PER FRAME runs everything: it marks the candidates in a per-pixel state map (0 none, 1 undecided, 2 kept, 3 rejected; a neighbour's
+// strength is its eig value + position, so no sorted list and no rank map is needed), loops the rounds until nothing is pending (block barrier
+// per round, no host round trip, no fixed round count), then orders the kept corners by COUNTING: a kept corner's output slot is the number of
+// kept corners with a larger key (keys staged in LDS and read as broadcasts; global memory when there are more than GFTT_LDS_KEYS of them).
+#define GFTT_LDS_KEYS 6144
+__global__ void __launch_bounds__(1024)
+gftt_select_kernel(const float* __restrict__ eig_all, int w, int h, const unsigned long long* __restrict__ keys_all, const int* __restrict__ count_all, int cap,
+                   float min_distance, int max_corners, uint8_t* __restrict__ state_all, unsigned long long* __restrict__ kept_all,
+                   float* __restrict__ pts_all, int pts_stride, int* __restrict__ nout_all, int* __restrict__ overflow)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc) return;
-    rank_at[0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu)] = i;
-    state[i] = 0;
-}
-__global__ void __launch_bounds__(256)
-gftt_round_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int h, float min_distance, const int* __restrict__ rank_at,
-                  uint8_t* __restrict__ state, int* __restrict__ pending, int round)
-{
-    if (round > 0 && pending[round] == 0) return;             // everything was decided in an earlier round
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc || state[i] != 0) return;
-    const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
-    const int y = idx / w, x = idx - y * w;
+    __shared__ unsigned long long skeys[GFTT_LDS_KEYS];
+    __shared__ int s_pending, s_nkept;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const size_t np = (size_t)w * h;
+    const float* eig = eig_all + f * np; uint8_t* state = state_all + f * np;
+    const unsigned long long* keys = keys_all + (size_t)f * cap; unsigned long long* kept = kept_all + (size_t)f * cap;
+    float* pts = pts_all + (size_t)f * pts_stride * 2;
+    int nc = count_all[f];
+    if (nc > cap) { nc = cap; if (tid == 0) atomicOr(overflow, 1); }       // candidate buffer too small: reported by the host
+    for (int i = tid; i < nc; i += 1024) state[0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu)] = 1;
+    if (tid == 0) { s_pending = 0; s_nkept = 0; }
+    __syncthreads();
     const float md2 = min_distance * min_distance;
     const int rad = (int)ceilf(min_distance);                 // |dx|, |dy| < minDistance
-    bool blocked = false, rejected = false;
-    for (int dy = -rad; dy <= rad && !rejected; dy++) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= h) continue;
-        for (int dx = -rad; dx <= rad; dx++) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
-            if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
-            const int j = rank_at[yy * w + xx];
-            if (j < 0 || j > i) continue;                     // no candidate there, or a weaker one
-            const int sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
-            if (sj == 1) { rejected = true; break; }
-            if (sj == 0) blocked = true;
+    for (;;) {
+        for (int i = tid; i < nc; i += 1024) {
+            const unsigned long long key = keys[i];
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+            if (__atomic_load_n(&state[idx], __ATOMIC_RELAXED) != 1) continue;
+            const int y = idx / w, x = idx - y * w;
+            bool blocked = false, rejected = false;
+            for (int dy = -rad; dy <= rad && !rejected; dy++) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= h) continue;
+                for (int dx = -rad; dx <= rad; dx++) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+                    if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+                    const int sj = __atomic_load_n(&state[yy * w + xx], __ATOMIC_RELAXED);
+                    if (sj == 0 || sj == 3) continue;         // no candidate there, or a rejected one
+                    const unsigned nidx = (unsigned)(yy * w + xx);
+                    const unsigned long long nkey = ((unsigned long long)__float_as_uint(eig[nidx]) << 32) | (0xFFFFFFFFu - nidx);
+                    if (nkey < key) continue;                 // a weaker corner
+                    if (sj == 2) { rejected = true; break; }
+                    blocked = true;
+                }
+            }
+            if (rejected) __atomic_store_n(&state[idx], (uint8_t)3, __ATOMIC_RELAXED);
+            else if (!blocked) __atomic_store_n(&state[idx], (uint8_t)2, __ATOMIC_RELAXED);
+            else s_pending = 1;
+        }
+        __syncthreads();
+        const int pending = s_pending;
+        __syncthreads();
+        if (!pending) break;
+        if (tid == 0) s_pending = 0;
+        __syncthreads();
+    }
+    // kept corners (any order) -> LDS / global list
+    for (int i = tid; i < nc; i += 1024) {
+        const unsigned long long key = keys[i];
+        if (state[0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)] == 2) {
+            const int k = atomicAdd(&s_nkept, 1);
+            if (k < GFTT_LDS_KEYS) skeys[k] = key;
+            kept[k] = key;
         }
     }
-    if (rejected) state[i] = 2;
-    else if (!blocked) state[i] = 1;
-    else atomicOr(&pending[round + 1], 1);
-}
-// kept corners in strength order, the first max_corners of them: (x, y) float pairs + count
-__global__ void __launch_bounds__(1024)
-gftt_emit_kernel(const unsigned long long* __restrict__ keys, int nc, int w, int max_corners, const uint8_t* __restrict__ state,
-                 float* __restrict__ pts, int* __restrict__ nout)
-{
-    __shared__ int wsum[16];
-    __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < nc; i0 += 1024) {
-        const int i = i0 + tid;
-        const bool keep = i < nc && state[i] == 1;
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) wsum[wv] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wv; k++) off += wsum[k];
-        const int n = off + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && (max_corners <= 0 || n < max_corners)) {
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu);
-            pts[2 * n] = (float)(idx % (unsigned)w); pts[2 * n + 1] = (float)(idx / (unsigned)w);
+    const int nk = s_nkept;
+    const bool in_lds = nk <= GFTT_LDS_KEYS;
+    for (int i = tid; i < nk; i += 1024) {
+        const unsigned long long key = in_lds ? skeys[i] : kept[i];
+        int r = 0;
+        if (in_lds) { for (int j = 0; j < nk; j++) r += skeys[j] > key; }
+        else        { for (int j = 0; j < nk; j++) r += kept[j] > key; }
+        if (max_corners <= 0 || r < max_corners) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+            pts[2 * r] = (float)(idx % (unsigned)w); pts[2 * r + 1] = (float)(idx / (unsigned)w);
         }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wsum[k]; base += t; }
-        __syncthreads();
-        if (max_corners > 0 && base >= max_corners) break;
     }
-    if (tid == 0) *nout = (max_corners > 0 && base > max_corners) ? max_corners : base;
+    if (tid == 0) nout_all[f] = (max_corners > 0 && nk > max_corners) ? max_corners : nk;
 }
 
-// ------------------------------------------------------------------ pyramid + Scharr for LK
+// ------------------------------------------------------------------ pyramid + Scharr for LK (all frames and both sides of a sub-batch per launch)
+// blockIdx.y = f * 2 + side
 __global__ void __launch_bounds__(256)
-pyrdown_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int dw, int dh)
+pyrdown_kernel(QuadBatch q, uint8_t* __restrict__ pyr, int level)
 {
+    const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
+    const int w = q.w[level - 1], h = q.h[level - 1], dw = q.w[level], dh = q.h[level];
+    const size_t sl = (size_t)(side * q.B1 + 1 + f) * q.slot_elems;
+    const uint8_t* src = pyr + sl + q.off[level - 1]; uint8_t* dst = pyr + sl + q.off[level];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= dw * dh) return;
     const int y = i / dw, x = i - y * dw;
@@ -189,27 +220,32 @@ pyrdown_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restric
         const uint8_t* r = src + (size_t)refl101d(2 * y + j, h) * w;
         int rs = 0;
 #pragma unroll
-        for (int q = -2; q <= 2; q++) rs += k[q + 2] * r[refl101d(2 * x + q, w)];
+        for (int qq = -2; qq <= 2; qq++) rs += k[qq + 2] * r[refl101d(2 * x + qq, w)];
         s += k[j + 2] * rs;
     }
     dst[i] = (uint8_t)((s + 128) >> 8);
 }
+// all four levels of a slot in one launch: thread i = element i of the slot
 __global__ void __launch_bounds__(256)
-scharr_kernel(const uint8_t* __restrict__ src, int w, int h, short2* __restrict__ d)
+scharr_kernel(QuadBatch q, short2* __restrict__ der)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w * h) return;
+    const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int)q.slot_elems) return;
+    const int level = e >= q.off[3] ? 3 : e >= q.off[2] ? 2 : e >= q.off[1] ? 1 : 0;
+    const int w = q.w[level], h = q.h[level], i = e - q.off[level];
+    const size_t sl = (size_t)(side * q.B1 + 1 + f) * q.slot_elems;
+    const uint8_t* src = q.pyr + sl + q.off[level];
     const int y = i / w, x = i - y * w;
     const uint8_t *r0 = src + (size_t)refl101d(y - 1, h) * w, *r1 = src + (size_t)y * w, *r2 = src + (size_t)refl101d(y + 1, h) * w;
     const int xm = refl101d(x - 1, w), xp = refl101d(x + 1, w);
-    d[i] = make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
-                       (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[x] - r0[x]) + 3 * (r2[xp] - r0[xp])));
+    der[sl + e] = make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
+                              (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[x] - r0[x]) + 3 * (r2[xp] - r0[xp])));
 }
 
 // ------------------------------------------------------------------ pyramidal LK, one wave per point, all levels in one launch
 #define LKW 11
 #define LKL 4
-struct LkPyr { const uint8_t* P[LKL]; const uint8_t* N[LKL]; const short2* D[LKL]; int w[LKL], h[LKL]; };
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll
@@ -217,24 +253,20 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 #define DESCALE(v, n) (((v) + (1 << ((n) - 1))) >> (n))
-__global__ void __launch_bounds__(256)
-lk_kernel(LkPyr py, const float* __restrict__ prev_pts, int n, float* __restrict__ next_pts, uint8_t* __restrict__ status, float* __restrict__ err,
-          int max_count, float eps2, float min_eig_thr)
+// cv::calcOpticalFlowPyrLK for ONE point by one wave: previous image (ps, pslot), next image (ns, nslot), derivatives of the previous image
+__device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, int ns, int nslot, float p0x, float p0y, int lane,
+                                         int max_count, float eps2, float min_eig_thr, float& nx, float& ny, int& st, float& er)
 {
-    const int lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pi >= n) return;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (LKW - 1) * 0.5f;
-    const float p0x = prev_pts[2*pi], p0y = prev_pts[2*pi+1];
-    float nx = 0.f, ny = 0.f; int st = 1; float er = 0.f;
+    nx = 0.f; ny = 0.f; st = 1; er = 0.f;
     // this lane's two window pixels: e0 = lane, e1 = lane + 64 (valid when < 121)
     const int e0 = lane, e1 = lane + 64;
     const int wy0 = e0 / LKW, wx0 = e0 - wy0 * LKW, wy1 = e1 / LKW, wx1 = e1 - wy1 * LKW;
     const bool v1 = e1 < LKW * LKW;
     for (int level = LKL - 1; level >= 0; level--) {
-        const int W = py.w[level], H = py.h[level];
-        const uint8_t* P = py.P[level]; const uint8_t* N = py.N[level]; const short2* D = py.D[level];
+        const int W = q.w[level], H = q.h[level];
+        const uint8_t* P = q_img(q, ps, pslot, level); const uint8_t* N = q_img(q, ns, nslot, level); const short2* D = q_der(q, ps, pslot, level);
         float ppx = p0x * (float)(1. / (1 << level)), ppy = p0y * (float)(1. / (1 << level));
         if (level == LKL - 1) { nx = ppx; ny = ppy; } else { nx *= 2.f; ny *= 2.f; }
         ppx -= half; ppy -= half;
@@ -296,19 +328,55 @@ lk_kernel(LkPyr py, const float* __restrict__ prev_pts, int n, float* __restrict
             pdx = ddx; pdy = ddy;
         }
     }
+}
+// one pass (ssm_lk_track): previous = (side 0, slot 1), next = (side 1, slot 1)
+__global__ void __launch_bounds__(256)
+lk_kernel(QuadBatch q, const float* __restrict__ prev_pts, int n, float* __restrict__ next_pts, uint8_t* __restrict__ status, float* __restrict__ err,
+          int max_count, float eps2, float min_eig_thr)
+{
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= n) return;
+    float nx, ny, er; int st;
+    lk_point(q, 0, 1, 1, 1, prev_pts[2*pi], prev_pts[2*pi+1], lane, max_count, eps2, min_eig_thr, nx, ny, st, er);
     if (lane == 0) { next_pts[2*pi] = nx; next_pts[2*pi+1] = ny; status[pi] = (uint8_t)st; if (err) err[pi] = er; }
 }
+// the four passes of QuadFeatureMatch::circularMatching in tracking mode (quadmatcher.cpp:566-576) for one GFTT corner of frame f by one wave:
+// lc -> rc, rc -> rp, rp -> lp and lc -> lp (direct); current frame = slot 1 + f, previous = slot f.  LK status vectors are ignored downstream
+// (SURVEY.md quirk 10), so only the positions leave the kernel.  pts: [5][nb][stride] (x, y) pairs = lc, rc, rp, lp, lp_direct.
+__global__ void __launch_bounds__(256)
+lk_quad_kernel(QuadBatch q, float* __restrict__ pts, int stride, const int* __restrict__ ncorner, const int* __restrict__ has_prev, int nb,
+               int max_count, float eps2, float min_eig_thr)
+{
+    const int lane = threadIdx.x & 63, f = blockIdx.y;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (!has_prev[f] || pi >= ncorner[f]) return;
+    const size_t set = (size_t)nb * stride * 2;
+    float* p = pts + ((size_t)f * stride + pi) * 2;
+    const float x0 = p[0], y0 = p[1];
+    float x1, y1, x2, y2, x3, y3, x4, y4, er; int st;
+    lk_point(q, 0, 1 + f, 1, 1 + f, x0, y0, lane, max_count, eps2, min_eig_thr, x1, y1, st, er);      // lc -> rc
+    lk_point(q, 1, 1 + f, 1, f, x1, y1, lane, max_count, eps2, min_eig_thr, x2, y2, st, er);          // rc -> rp
+    lk_point(q, 1, f, 0, f, x2, y2, lane, max_count, eps2, min_eig_thr, x3, y3, st, er);              // rp -> lp
+    lk_point(q, 0, 1 + f, 0, f, x0, y0, lane, max_count, eps2, min_eig_thr, x4, y4, st, er);          // lc -> lp
+    if (lane == 0) { p[set] = x1; p[set + 1] = y1; p[2 * set] = x2; p[2 * set + 1] = y2; p[3 * set] = x3; p[3 * set + 1] = y3; p[4 * set] = x4; p[4 * set + 1] = y4; }
+}
 
-// ------------------------------------------------------------------ filteringTracks (quadmatcher.cpp:420-503), ordered compaction, one block
+// ------------------------------------------------------------------ filteringTracks (quadmatcher.cpp:420-503), ordered compaction, one block per frame
 struct QPmatch { float u1p, v1p; int i1p; float u2p, v2p; int i2p; float u1c, v1c; int i1c; float u2c, v2c; int i2c; short dis_c, dis_p; };
 __device__ __forceinline__ bool within_region(float x, float y) { return x < 1280 && x > 0.0f && y < 960 && y > 0.0f; }
 __global__ void __launch_bounds__(1024)
-filter_tracks_kernel(const float* __restrict__ lc, const float* __restrict__ rc, const float* __restrict__ lp, const float* __restrict__ rp,
-                     const float* __restrict__ ld, int n, QPmatch* __restrict__ out, int* __restrict__ nout)
+filter_tracks_kernel(const float* __restrict__ pts, int stride, const int* __restrict__ ncorner, const int* __restrict__ has_prev, int nb,
+                     QPmatch* __restrict__ out_all, int* __restrict__ nout_all)
 {
     __shared__ int wcnt[16];
     __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, f = blockIdx.x;
+    if (!has_prev[f]) { if (tid == 0) nout_all[f] = -1; return; }      // no previous frame: no quad matches (first frame of a sequence)
+    const int n = ncorner[f];
+    const size_t set = (size_t)nb * stride * 2;
+    const float *lc = pts + (size_t)f * stride * 2, *rc = lc + set, *rp = lc + 2 * set, *lp = lc + 3 * set, *ld = lc + 4 * set;
+    QPmatch* out = out_all + (size_t)f * stride;
     if (tid == 0) base = 0;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + tid;
@@ -337,7 +405,7 @@ filter_tracks_kernel(const float* __restrict__ lc, const float* __restrict__ rc,
         if (tid == 0) { int s = 0; for (int k = 0; k < 16; k++) s += wcnt[k]; base += s; }
     }
     __syncthreads();
-    if (tid == 0) *nout = base;
+    if (tid == 0) nout_all[f] = base;
 }
 
 // ------------------------------------------------------------------ QuadFeatureMatch::matching on binary descriptors (:41-83)
@@ -364,66 +432,45 @@ window_match_kernel(const float* __restrict__ kp1, const uint8_t* __restrict__ d
     out[i] = m;
 }
 
-// ------------------------------------------------------------------ launchers
-hipError_t k_quad_mineig(const uint8_t* img, int w, int h, int stride, float* eig, int* maxord, hipStream_t s)
+// ------------------------------------------------------------------ launchers (nb frames per launch)
+// level 0 of frames [0, nb) of both sides is in place (slots 1 .. nb): the three pyrDown levels, then the Scharr derivatives of every level
+hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(maxord, 0x80, 4, s);          // 0x80808080: below any real value in the ordered-int encoding
+    if (nb <= 0) return hipSuccess;
+    uint8_t* pyr = const_cast<uint8_t*>(q.pyr);
+    for (int l = 1; l < 4; l++) pyrdown_kernel<<<dim3((q.w[l] * q.h[l] + 255) / 256, nb * 2), 256, 0, s>>>(q, pyr, l);
+    scharr_kernel<<<dim3(((int)q.slot_elems + 255) / 256, nb * 2), 256, 0, s>>>(q, reinterpret_cast<short2*>(const_cast<int16_t*>(q.der)));
+    return hipGetLastError();
+}
+// cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  eig: nb*w*h floats; state: nb*w*h bytes;
+// keys / kept: nb*cap u64; maxord / count: nb ints; overflow: 1 int (set when a frame has more than cap candidates)
+hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, float* eig, int* maxord, unsigned long long* keys,
+                       unsigned long long* kept, int* count, int cap, uint8_t* state, float* pts, int stride, int* ncorner, int* overflow, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    const int w = q.w[0], h = q.h[0];
+    hipError_t e = hipMemsetAsync(maxord, 0x80, 4 * (size_t)nb, s);          // 0x80808080: below any real value in the ordered-int encoding
+    if (e == hipSuccess) e = hipMemsetAsync(count, 0, 4 * (size_t)nb, s);
+    if (e == hipSuccess) e = hipMemsetAsync(state, 0, (size_t)nb * w * h, s);
     if (e != hipSuccess) return e;
     const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
-    mineig_kernel<<<tx * ty, 256, 0, s>>>(img, w, h, stride, eig, maxord);
+    mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, eig, maxord);
+    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(eig, w, h, maxord, quality, keys, count, cap);
+    gftt_select_kernel<<<nb, 1024, 0, s>>>(eig, w, h, keys, count, cap, (float)min_distance, max_corners, state, kept, pts, stride, ncorner, overflow);
     return hipGetLastError();
 }
-hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, double quality, unsigned long long* keys, int* count, int cap, hipStream_t s)
-{
-    hipError_t e = hipMemsetAsync(count, 0, 4, s);
-    if (e != hipSuccess) return e;
-    gftt_collect_kernel<<<(w * h + 255) / 256, 256, 0, s>>>(eig, w, h, maxord, quality, keys, count, cap);
-    return hipGetLastError();
-}
-// rank_at: w*h ints; state: nc bytes; pending: GFTT_ROUNDS + 1 ints.  *more = 1 when corners are still undecided after
-// GFTT_ROUNDS rounds (the caller runs another batch); the emit kernel runs when everything is decided.
-hipError_t k_quad_select_begin(const unsigned long long* keys, int nc, int w, int h, int* rank_at, uint8_t* state, hipStream_t s)
-{
-    hipError_t e = hipMemsetAsync(rank_at, 0xFF, sizeof(int) * (size_t)w * h, s);
-    if (e != hipSuccess) return e;
-    gftt_rank_kernel<<<(nc + 255) / 256, 256, 0, s>>>(keys, nc, rank_at, state);
-    return hipGetLastError();
-}
-hipError_t k_quad_select_rounds(const unsigned long long* keys, int nc, int w, int h, float min_distance, const int* rank_at, uint8_t* state, int* pending, hipStream_t s)
-{
-    hipError_t e = hipMemsetAsync(pending, 0, sizeof(int) * (GFTT_ROUNDS + 1), s);
-    if (e != hipSuccess) return e;
-    for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<(nc + 255) / 256, 256, 0, s>>>(keys, nc, w, h, min_distance, rank_at, state, pending, r);
-    return hipGetLastError();
-}
-hipError_t k_quad_select_emit(const unsigned long long* keys, int nc, int w, int max_corners, const uint8_t* state, float* pts, int* nout, hipStream_t s)
-{
-    gftt_emit_kernel<<<1, 1024, 0, s>>>(keys, nc, w, max_corners, state, pts, nout);
-    return hipGetLastError();
-}
-hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s)
-{
-    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    pyrdown_kernel<<<(dw * dh + 255) / 256, 256, 0, s>>>(src, w, h, dst, dw, dh);
-    return hipGetLastError();
-}
-hipError_t k_quad_scharr(const uint8_t* src, int w, int h, int16_t* d, hipStream_t s)
-{
-    scharr_kernel<<<(w * h + 255) / 256, 256, 0, s>>>(src, w, h, reinterpret_cast<short2*>(d));
-    return hipGetLastError();
-}
-hipError_t k_quad_lk(const uint8_t* const* P, const uint8_t* const* N, const int16_t* const* D, const int* lw, const int* lh, const float* prev_pts, int n,
-                     float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s)
+hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    LkPyr py;
-    for (int l = 0; l < LKL; l++) { py.P[l] = P[l]; py.N[l] = N[l]; py.D[l] = reinterpret_cast<const short2*>(D[l]); py.w[l] = lw[l]; py.h[l] = lh[l]; }
-    lk_kernel<<<(n + 3) / 4, 256, 0, s>>>(py, prev_pts, n, next_pts, status, err, max_count, eps2, min_eig_thr);
+    lk_kernel<<<(n + 3) / 4, 256, 0, s>>>(q, prev_pts, n, next_pts, status, err, max_count, eps2, min_eig_thr);
     return hipGetLastError();
 }
-hipError_t k_quad_filter(const float* lc, const float* rc, const float* lp, const float* rp, const float* ld, int n, void* out, int* nout, hipStream_t s)
+// the four LK passes + filteringTracks for frames [0, nb): pts = [5][nb][stride] (set 0 = the GFTT corners), out[f][stride], nout[f] (-1 without a previous frame)
+hipError_t k_quad_track(const QuadBatch& q, int nb, float* pts, int stride, const int* ncorner, const int* has_prev, void* out, int* nout, hipStream_t s)
 {
-    filter_tracks_kernel<<<1, 1024, 0, s>>>(lc, rc, lp, rp, ld, n, reinterpret_cast<QPmatch*>(out), nout);
+    if (nb <= 0) return hipSuccess;
+    lk_quad_kernel<<<dim3((stride + 3) / 4, nb), 256, 0, s>>>(q, pts, stride, ncorner, has_prev, nb, 200, (float)(0.01 * 0.01), 1e-6f);
+    filter_tracks_kernel<<<nb, 1024, 0, s>>>(pts, stride, ncorner, has_prev, nb, reinterpret_cast<QPmatch*>(out), nout);
     return hipGetLastError();
 }
 hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,

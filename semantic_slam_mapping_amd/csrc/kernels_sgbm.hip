@@ -34,11 +34,15 @@
 // ------------------------------------------------------------------ pre-filter + BT intervals
 // planes (u8, [h][w]): 0 = value, 1 = min(value, half-sample neighbours), 2 = max(...); gradient planes first, then raw
 __global__ void __launch_bounds__(256)
-sgbm_prefilter(const uint8_t* __restrict__ img, int w, int h, int ftzero, uint8_t* __restrict__ planes)
+sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int w, int h, int ftzero, uint8_t* __restrict__ planes_all)
 {
+    // blockIdx.z = frame * 2 + side; a frame's 12 planes: left 0..5, right 6..11
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const size_t np = (size_t)w * h;
+    const int f = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const uint8_t* img = (side ? right : left) + (size_t)f * np;
+    uint8_t* planes = planes_all + ((size_t)f * 12 + (size_t)side * 6) * np;
     const uint8_t* row = img + (size_t)y * w;
     const int n1 = y > 0 ? -w : 0, s1 = y < h - 1 ? w : 0;
     auto grad = [&](int xx) -> int {            // prow[x]: tab[...] for 1 <= x <= w-2, tab[0] = ftzero at the two border columns
@@ -57,10 +61,12 @@ sgbm_prefilter(const uint8_t* __restrict__ img, int w, int h, int ftzero, uint8_
 }
 // BT cost of left pixel x (image column) against right pixel x - d; thread = (d, x); volume index ((y * w1 + x - minX1) * D + d - minD)
 __global__ void __launch_bounds__(256)
-sgbm_pixcost(const uint8_t* __restrict__ pl1, const uint8_t* __restrict__ pl2, int w, int h, int minD, int D, int minX1, int w1, uint8_t* __restrict__ pix)
+sgbm_pixcost(const uint8_t* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, uint8_t* __restrict__ pix_all)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
     if (i >= w1 * D) return;
+    const uint8_t* pl1 = planes_all + (size_t)f * 12 * w * h; const uint8_t* pl2 = pl1 + (size_t)6 * w * h;
+    uint8_t* pix = pix_all + (size_t)f * w1 * h * D;
     const int xi = i / D, d = i - xi * D + minD, x = xi + minX1;
     const size_t np = (size_t)w * h, o1 = (size_t)y * w + x, o2 = (size_t)y * w + (x - d);
     int cost = 0;
@@ -74,10 +80,11 @@ sgbm_pixcost(const uint8_t* __restrict__ pl1, const uint8_t* __restrict__ pl2, i
     pix[((size_t)y * w1 + xi) * D + (d - minD)] = (uint8_t)cost;
 }
 __global__ void __launch_bounds__(256)
-sgbm_hbox(const uint8_t* __restrict__ pix, int w1, int D, int SW2, uint16_t* __restrict__ hs)
+sgbm_hbox(const uint8_t* __restrict__ pix_all, int w1, int h, int D, int SW2, uint16_t* __restrict__ hs_all)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (i >= w1 * D) return;
+    const uint8_t* pix = pix_all + (size_t)blockIdx.z * w1 * h * D; uint16_t* hs = hs_all + (size_t)blockIdx.z * w1 * h * D;
     const int x = i / D, d = i - x * D;
     const uint8_t* r = pix + (size_t)y * w1 * D + d;
     int s = 0;
@@ -85,10 +92,11 @@ sgbm_hbox(const uint8_t* __restrict__ pix, int w1, int D, int SW2, uint16_t* __r
     hs[(size_t)y * w1 * D + i] = (uint16_t)s;
 }
 __global__ void __launch_bounds__(256)
-sgbm_vbox(const uint16_t* __restrict__ hs, int w1, int h, int D, int SH2, int P2, uint16_t* __restrict__ C)
+sgbm_vbox(const uint16_t* __restrict__ hs_all, int w1, int h, int D, int SH2, int P2, uint16_t* __restrict__ C_all)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (i >= w1 * D) return;
+    const uint16_t* hs = hs_all + (size_t)blockIdx.z * w1 * h * D; uint16_t* C = C_all + (size_t)blockIdx.z * w1 * h * D;
     const int x = i / D;
     const int yy = x == 0 ? 0 : min(y, h - 1 - SH2);          // OpenCV 2.4: column 0 and the bottom rows stop being updated
     int s = P2;
@@ -173,9 +181,10 @@ template <int K> __device__ __forceinline__ void sg_store_pk(uint16_t* p, const 
 // Every direction writes its own L volume: the five launches share nothing but C and run concurrently on five streams.
 template <int K, int MODE>
 __global__ void __launch_bounds__(256)
-sgbm_path(const uint16_t* __restrict__ C, uint16_t* __restrict__ Lout, int w1, int h, int P1, int P2)
+sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, int w1, int h, int P1, int P2)
 {
     constexpr int D = 16 * K;
+    const uint16_t* C = C_all + (size_t)blockIdx.y * w1 * h * D; uint16_t* Lout = Lout_all + (size_t)blockIdx.y * w1 * h * D;      // blockIdx.y = frame
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
     constexpr bool ROW = MODE == 0 || MODE == 4;
     const int npaths = ROW ? h : (MODE == 2 ? w1 : w1 + h - 1);
@@ -245,6 +254,8 @@ sgbm_wta(const uint16_t* __restrict__ L0, const uint16_t* __restrict__ L1, const
          const uint16_t* __restrict__ L4, int w, int w1, int h, int minD, int minX1, int uniquenessRatio, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key)
 {
     constexpr int D = 16 * K;
+    {   const size_t fv = (size_t)blockIdx.y * w1 * h * D, fp = (size_t)blockIdx.y * w * h;      // blockIdx.y = frame
+        L0 += fv; L1 += fv; L2 += fv; L3 += fv; L4 += fv; disp1 += fp; disp2key += fp; }
     __shared__ uint16_t srow[16][D];                          // S of the group's pixel, for the three sub-pixel taps
     const int gl = threadIdx.x >> 4, li = threadIdx.x & 15;
     const long long gid = (long long)blockIdx.x * 16 + gl, npix = (long long)w1 * h;
@@ -280,10 +291,11 @@ sgbm_wta(const uint16_t* __restrict__ L0, const uint16_t* __restrict__ L1, const
 }
 // left-right check: the disparity rounded down and up must both disagree with the right-image table to be dropped
 __global__ void __launch_bounds__(256)
-sgbm_lrcheck(const int16_t* __restrict__ disp1, const unsigned* __restrict__ disp2key, int w, int w1, int minD, int minX1, int disp12MaxDiff, int16_t* __restrict__ out)
+sgbm_lrcheck(const int16_t* __restrict__ disp1, const unsigned* __restrict__ disp2key, int w, int h, int w1, int minD, int minX1, int disp12MaxDiff, int16_t* __restrict__ out)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    { const size_t fp = (size_t)blockIdx.z * w * h; disp1 += fp; disp2key += fp; out += fp; }
     const int INVALID = (minD - 1) * SG_DISP_SCALE;
     const unsigned* k2 = disp2key + (size_t)y * w;
     auto disp2 = [&](int xx) -> int {                          // the disparity the winning pixel assigned to right-image column xx
@@ -308,6 +320,7 @@ sgbm_median3(const int16_t* __restrict__ src, int w, int h, int16_t* __restrict_
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
+    { const size_t fp = (size_t)blockIdx.z * w * h; src += fp; dst += fp; }
     int v[9];
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)
@@ -347,6 +360,7 @@ __global__ void __launch_bounds__(256)
 sgbm_speckle_init(int n, int* __restrict__ parent, int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    { const size_t fp = (size_t)blockIdx.y * n; parent += fp; count += fp; }        // blockIdx.y = frame: every frame has its own forest (indices inside the frame)
     if (i < n) { parent[i] = i; count[i] = 0; }
 }
 __global__ void __launch_bounds__(256)
@@ -354,6 +368,7 @@ sgbm_speckle_link(const int16_t* __restrict__ img, int w, int h, int newVal, int
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w * h) return;
+    { const size_t fp = (size_t)blockIdx.y * w * h; img += fp; parent += fp; }
     const int v = img[i];
     if (v == newVal) return;
     const int x = i % w, y = i / w;
@@ -364,6 +379,7 @@ __global__ void __launch_bounds__(256)
 sgbm_speckle_count(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ parent, int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    { const size_t fp = (size_t)blockIdx.y * n; img += fp; parent += fp; count += fp; }
     const bool on = i < n && img[i] != newVal;
     int r = -1;
     if (on) { r = uf_find(parent, i); parent[i] = r; }
@@ -381,6 +397,7 @@ __global__ void __launch_bounds__(256)
 sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleSize, const int* __restrict__ parent, const int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    { const size_t fp = (size_t)blockIdx.y * n; img += fp; parent += fp; count += fp; }
     if (i >= n || img[i] == newVal) return;
     if (count[parent[i]] <= maxSpeckleSize) img[i] = (int16_t)newVal;
 }
@@ -388,6 +405,7 @@ sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleS
 __global__ void __launch_bounds__(256)
 sgbm_min_kernel(const int16_t* __restrict__ disp, int n, int* __restrict__ out)
 {
+    disp += (size_t)blockIdx.y * n; out += blockIdx.y;
     int m = INT_MAX;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = min(m, (int)disp[i]);
 #pragma unroll
@@ -400,6 +418,7 @@ sgbm_depth(const int16_t* __restrict__ disp, int w, int h, const int* __restrict
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
     if (u >= w) return;
+    { const size_t fp = (size_t)blockIdx.z * w * h; disp += fp; depth += fp; min_disp += blockIdx.z; }
     const int d = disp[(size_t)v * w + u];
     uint16_t out = 0;
     if (d != 0 && d != *min_disp) {                           // |d| > FLT_EPSILON and |d - min| > FLT_EPSILON on integers
@@ -449,7 +468,7 @@ static SgStreams& sg_streams(hipStream_t caller)
     return *st;
 }
 template <int K>
-static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, const ssm_sgbm_params& p, int minX1, int P1, int P2,
+static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
                                  int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, hipStream_t s)
 {
     auto blocks = [](int paths) { return (paths * 16 + 255) / 256; };
@@ -458,47 +477,49 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     hipError_t e = hipEventRecord(st.fork, s);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st.s[i], st.fork, 0);
     if (e != hipSuccess) return e;
-    sgbm_path<K, 0><<<blocks(h), 256, 0, s>>>(C, Lv[0], w1, h, P1, P2);
-    sgbm_path<K, 4><<<blocks(h), 256, 0, st.s[0]>>>(C, Lv[4], w1, h, P1, P2);
-    sgbm_path<K, 1><<<blocks(w1 + h - 1), 256, 0, st.s[1]>>>(C, Lv[1], w1, h, P1, P2);
-    sgbm_path<K, 2><<<blocks(w1), 256, 0, st.s[2]>>>(C, Lv[2], w1, h, P1, P2);
-    sgbm_path<K, 3><<<blocks(w1 + h - 1), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
+    sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, s>>>(C, Lv[0], w1, h, P1, P2);
+    sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[4], w1, h, P1, P2);
+    sgbm_path<K, 1><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[1]>>>(C, Lv[1], w1, h, P1, P2);
+    sgbm_path<K, 2><<<dim3(blocks(w1), nb), 256, 0, st.s[2]>>>(C, Lv[2], w1, h, P1, P2);
+    sgbm_path<K, 3><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
     for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipEventRecord(st.done[i], st.s[i]); if (e == hipSuccess) e = hipStreamWaitEvent(s, st.done[i], 0); }
     if (e != hipSuccess) return e;
-    const size_t np = (size_t)w * h;
-    sgbm_fill<<<(int)((np + 255) / 256), 256, 0, s>>>(disp_tmp, (int)np, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
-    e = hipMemsetAsync(disp2key, 0xFF, np * 4, s);
+    const size_t np = (size_t)w * h, npb = np * nb;
+    sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
+    e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
     if (e != hipSuccess) return e;
     const long long npix = (long long)w1 * h;
-    sgbm_wta<K><<<(unsigned)((npix + 15) / 16), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
-    sgbm_lrcheck<<<dim3((w + 255) / 256, h), 256, 0, s>>>(disp_tmp, disp2key, w, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
+    sgbm_wta<K><<<dim3((unsigned)((npix + 15) / 16), nb), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
+    sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
-size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p)
+// workspace for nb frames per launch
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb)
 {
     const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
-    const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities, np = (size_t)w * h;
+    const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities * nb, np = (size_t)w * h * nb;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return al(12 * np) + al(vol) + 7 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256;
 }
-// left / right: device u8 images [h][w]; disp_out: device int16 [h][w] (x16 fixed point, (minD-1)*16 = invalid)
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
+// left / right: device u8 images [nb][h][w]; disp_out: device int16 [nb][h][w] (x16 fixed point, (minD-1)*16 = invalid)
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
 {
+    if (nb <= 0) return hipSuccess;
     const int minD = p.minDisparity, D = p.numberOfDisparities, maxD = minD + D;
     const int SW = p.SADWindowSize > 0 ? p.SADWindowSize : 5, SW2 = SW / 2;
     const int ftzero = (p.preFilterCap > 15 ? p.preFilterCap : 15) | 1;
     const int P1 = p.P1 > 0 ? p.P1 : 2, P2 = (p.P2 > 0 ? p.P2 : 5) > P1 + 1 ? (p.P2 > 0 ? p.P2 : 5) : P1 + 1;
     const int minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (minD < 0 ? minD : 0), w1 = maxX1 - minX1;
     const int INVALID = (minD - 1) * SG_DISP_SCALE;
-    const size_t np = (size_t)w * h;
+    const size_t np1 = (size_t)w * h, np = np1 * nb;
     if (w1 <= 0) {                                            // no valid column: everything invalid (OpenCV's early return)
-        sgbm_fill<<<(int)((np + 255) / 256), 256, 0, s>>>(disp_out, (int)np, (int16_t)INVALID);
+        sgbm_fill<<<(unsigned)((np + 255) / 256), 256, 0, s>>>(disp_out, (int)np, (int16_t)INVALID);
         return hipGetLastError();
     }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     uint8_t* q = (uint8_t*)workspace;
-    uint8_t* pl1 = q; uint8_t* pl2 = q + 6 * np; q += al(12 * np);
-    const size_t vol = (size_t)w1 * h * D;
+    uint8_t* planes = q; q += al(12 * np);
+    const size_t vol = (size_t)w1 * h * D * nb;
     uint8_t* pix = q; q += al(vol);
     uint16_t* hs = (uint16_t*)q; q += al(vol * 2);
     uint16_t* C = (uint16_t*)q; q += al(vol * 2);
@@ -509,41 +530,42 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const
     unsigned* d2key = (unsigned*)q; q += al(np * 4);
     int* parent = (int*)q; q += al(np * 4);
     int* count = (int*)q; q += al(np * 4);
-    const dim3 gimg((w + 255) / 256, h), gvol((w1 * D + 255) / 256, h);
-    sgbm_prefilter<<<gimg, 256, 0, s>>>(left, w, h, ftzero, pl1);
-    sgbm_prefilter<<<gimg, 256, 0, s>>>(right, w, h, ftzero, pl2);
-    sgbm_pixcost<<<gvol, 256, 0, s>>>(pl1, pl2, w, h, minD, D, minX1, w1, pix);
-    sgbm_hbox<<<gvol, 256, 0, s>>>(pix, w1, D, SW2, hs);
+    const dim3 gimg((w + 255) / 256, h, nb), gvol((w1 * D + 255) / 256, h, nb);
+    sgbm_prefilter<<<dim3((w + 255) / 256, h, nb * 2), 256, 0, s>>>(left, right, w, h, ftzero, planes);
+    sgbm_pixcost<<<gvol, 256, 0, s>>>(planes, w, h, minD, D, minX1, w1, pix);
+    sgbm_hbox<<<gvol, 256, 0, s>>>(pix, w1, h, D, SW2, hs);
     sgbm_vbox<<<gvol, 256, 0, s>>>(hs, w1, h, D, SW2, P2, C);
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
     switch (D / 16) {
-        case 1: e = sgbm_aggregate<1>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 2: e = sgbm_aggregate<2>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 3: e = sgbm_aggregate<3>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 4: e = sgbm_aggregate<4>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 5: e = sgbm_aggregate<5>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 6: e = sgbm_aggregate<6>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 8: e = sgbm_aggregate<8>(C, Lv, w, w1, h, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 1: e = sgbm_aggregate<1>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 2: e = sgbm_aggregate<2>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 3: e = sgbm_aggregate<3>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 4: e = sgbm_aggregate<4>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 5: e = sgbm_aggregate<5>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 6: e = sgbm_aggregate<6>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+        case 8: e = sgbm_aggregate<8>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess || raw_only == 1) return e;
     sgbm_median3<<<gimg, 256, 0, s>>>(d_raw, w, h, disp_out);
     if (p.speckleWindowSize > 0 && raw_only != 2) {
-        const int n = (int)np, nb = (n + 255) / 256;
-        sgbm_speckle_init<<<nb, 256, 0, s>>>(n, parent, count);
-        sgbm_speckle_link<<<nb, 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
-        sgbm_speckle_count<<<nb, 256, 0, s>>>(disp_out, n, INVALID, parent, count);
-        sgbm_speckle_apply<<<nb, 256, 0, s>>>(disp_out, n, INVALID, p.speckleWindowSize, parent, count);
+        const int n = (int)np1; const dim3 gb((n + 255) / 256, nb);
+        sgbm_speckle_init<<<gb, 256, 0, s>>>(n, parent, count);
+        sgbm_speckle_link<<<gb, 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
+        sgbm_speckle_count<<<gb, 256, 0, s>>>(disp_out, n, INVALID, parent, count);
+        sgbm_speckle_apply<<<gb, 256, 0, s>>>(disp_out, n, INVALID, p.speckleWindowSize, parent, count);
     }
     return hipGetLastError();
 }
-hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+// min_scratch: nb ints
+hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, int nb, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
                         int* min_scratch, uint16_t* depth, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(min_scratch, 0x7F, 4, s);         // 0x7F7F7F7F: above any int16
+    if (nb <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(min_scratch, 0x7F, 4 * (size_t)nb, s);         // 0x7F7F7F7F: above any int16
     if (e != hipSuccess) return e;
-    sgbm_min_kernel<<<64, 256, 0, s>>>(disp, w * h, min_scratch);
-    sgbm_depth<<<dim3((w + 255) / 256, h), 256, 0, s>>>(disp, w, h, min_scratch, baseline, cu, cv, f, roix, roiy, roiz, scale, depth);
+    sgbm_min_kernel<<<dim3(64, nb), 256, 0, s>>>(disp, w * h, min_scratch);
+    sgbm_depth<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp, w, h, min_scratch, baseline, cu, cv, f, roix, roiy, roiz, scale, depth);
     return hipGetLastError();
 }

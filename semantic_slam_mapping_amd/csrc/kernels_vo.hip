@@ -167,21 +167,49 @@ __device__ __forceinline__ int vo_finish_step(double* acc, double tr[6], double 
     return converged ? VO_CONVERGED : VO_UPDATED;
 }
 
+// Batched form: blockIdx.y = frame f of a sub-batch; its matches are m_all + f * stride, their number n_all[f] (n_all == nullptr: n_fixed, the
+// per-call entry point).  The three sample indices of hypothesis k come either from an explicit table (samples, ssm_vo_estimate) or from the RAW
+// rand() stream the way VisualOdometry::getRandomSample (src/vo.cpp:74-93) uses it: three draws r0, r1, r2 -> r0 % N of {0..N-1}, then r1 % (N-1)
+// and r2 % (N-2) of what is left (erase() keeps the pool sorted, so "what is left" is the identity with the taken values skipped).  A frame's
+// draws start at rand_off[f] of the stream: frames with fewer than 6 matches draw nothing (vo_stereo.cpp:61-63), which vo_offsets_kernel accounts for.
+struct VoBatch {
+    const ssm_pmatch* m_all; int stride; const int32_t* n_all; int n_fixed;
+    const int32_t* samples; const uint32_t* rand_stream; const int32_t* rand_off; int iters;
+};
+__global__ void vo_offsets_kernel(const int32_t* __restrict__ n_all, int nb, int draws_per_frame, int32_t* __restrict__ consumed /* running draw count */, int32_t* __restrict__ rand_off)
+{
+    int c = *consumed;
+    for (int f = 0; f < nb; f++) { rand_off[f] = c; if (n_all[f] >= 6) c += draws_per_frame; }
+    *consumed = c;
+}
 __global__ void __launch_bounds__(64)
-vo_ransac_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const int32_t* __restrict__ samples,
-                 double* __restrict__ tr_all, int32_t* __restrict__ count)
+vo_ransac_kernel(VoBatch B, ssm_vo_params P, double* __restrict__ tr_all, int32_t* __restrict__ count)
 {
     __shared__ double s_tr[6];
     __shared__ int s_result;
-    const int k = blockIdx.x, lane = threadIdx.x;
+    const int k = blockIdx.x, lane = threadIdx.x, f = blockIdx.y;
+    const ssm_pmatch* m = B.m_all + (size_t)f * B.stride;
+    const int n = B.n_all ? B.n_all[f] : B.n_fixed;
+    if (n < 6) return;                                       // no estimate for this frame (vo_refine_kernel writes the empty result)
+    tr_all += (size_t)f * B.iters * 6; count += (size_t)f * B.iters;
     if (lane == 0) {
+        int smp[3];
+        if (B.samples) { smp[0] = B.samples[3 * k]; smp[1] = B.samples[3 * k + 1]; smp[2] = B.samples[3 * k + 2]; }
+        else {
+            const uint32_t* r = B.rand_stream + B.rand_off[f] + 3 * k;
+            const int v0 = (int)(r[0] % (uint32_t)n);
+            int v1 = (int)(r[1] % (uint32_t)(n - 1)); v1 += v1 >= v0;
+            const int lo = min(v0, v1), hi = max(v0, v1);
+            int v2 = (int)(r[2] % (uint32_t)(n - 2)); v2 += v2 >= lo; v2 += v2 >= hi;
+            smp[0] = v0; smp[1] = v1; smp[2] = v2;
+        }
         double tr[6] = {0, 0, 0, 0, 0, 0};
         int result = VO_UPDATED, iter = 0;
         while (result == VO_UPDATED) {
             VoPose R; vo_pose_make(tr, R);
             double acc[42];
             for (int q = 0; q < 42; q++) acc[q] = 0.0;
-            for (int q = 0; q < 3; q++) vo_accumulate(m[samples[3 * k + q]], P, R, acc);
+            for (int q = 0; q < 3; q++) vo_accumulate(m[smp[q]], P, R, acc);
             result = vo_finish_step(acc, tr, 1e-6);
             if (iter++ > 20 || result == VO_CONVERGED) break;
         }
@@ -201,11 +229,19 @@ vo_ransac_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
     }
     if (lane == 0) count[k] = c;
 }
+// blockIdx.x = frame
 __global__ void __launch_bounds__(64)
-vo_refine_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const double* __restrict__ tr_all, const int32_t* __restrict__ count, int iters,
-                 double* __restrict__ tr_out, int32_t* __restrict__ inliers, int32_t* __restrict__ result /* [0] = n_inliers, [1] = success */)
+vo_refine_kernel(VoBatch B, ssm_vo_params P, const double* __restrict__ tr_all, const int32_t* __restrict__ count,
+                 double* __restrict__ tr_out, int32_t* __restrict__ inliers, int32_t* __restrict__ result /* per frame: [0] = n_inliers, [1] = success */)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, f = blockIdx.x, iters = B.iters;
+    const ssm_pmatch* m = B.m_all + (size_t)f * B.stride;
+    const int n = B.n_all ? B.n_all[f] : B.n_fixed;
+    tr_all += (size_t)f * iters * 6; count += (size_t)f * iters; tr_out += (size_t)f * 6; inliers += (size_t)f * B.stride; result += (size_t)f * 2;
+    if (n < 6) {                                             // estimateMotion returns an empty vector (vo_stereo.cpp:61-63); also the frames without a previous frame (n = -1)
+        if (lane == 0) { for (int q = 0; q < 6; q++) tr_out[q] = 0.0; result[0] = 0; result[1] = 0; }
+        return;
+    }
     // the first hypothesis with the largest consensus (the reference replaces only on a strictly larger set)
     int best = 0, bk = -1;
     for (int k = 0; k < iters; k++) { const int c = count[k]; if (c > best) { best = c; bk = k; } }
@@ -243,10 +279,25 @@ vo_refine_kernel(const ssm_pmatch* __restrict__ m, int n, ssm_vo_params P, const
         result[0] = na; result[1] = success;
     }
 }
+// one call (ssm_vo_estimate): explicit samples, n on the host
 hipError_t k_vo_estimate(const ssm_pmatch* m, int n, const ssm_vo_params& P, const int32_t* samples, int iters,
                          double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s)
 {
-    vo_ransac_kernel<<<iters, 64, 0, s>>>(m, n, P, samples, tr_all, count);
-    vo_refine_kernel<<<1, 64, 0, s>>>(m, n, P, tr_all, count, iters, tr_out, inliers, result);
+    VoBatch B; B.m_all = m; B.stride = n; B.n_all = nullptr; B.n_fixed = n; B.samples = samples; B.rand_stream = nullptr; B.rand_off = nullptr; B.iters = iters;
+    if (iters > 0) vo_ransac_kernel<<<dim3(iters, 1), 64, 0, s>>>(B, P, tr_all, count);
+    vo_refine_kernel<<<1, 64, 0, s>>>(B, P, tr_all, count, tr_out, inliers, result);
+    return hipGetLastError();
+}
+// nb frames of the batched stereo path: matches m_all[f][stride] with n_all[f] entries (device), samples drawn from rand_stream as the host class
+// would (consumed: running number of draws taken from the stream, updated); tr_all: nb*iters*6 doubles, count: nb*iters ints, rand_off: nb ints;
+// outputs tr_out[f][6], inliers[f][stride], result[f][2]
+hipError_t k_vo_estimate_batch(const ssm_pmatch* m_all, int stride, const int32_t* n_all, int nb, const ssm_vo_params& P, const uint32_t* rand_stream, int iters,
+                               int32_t* consumed, int32_t* rand_off, double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    VoBatch B; B.m_all = m_all; B.stride = stride; B.n_all = n_all; B.n_fixed = 0; B.samples = nullptr; B.rand_stream = rand_stream; B.rand_off = rand_off; B.iters = iters;
+    vo_offsets_kernel<<<1, 1, 0, s>>>(n_all, nb, 3 * iters, consumed, rand_off);
+    if (iters > 0) vo_ransac_kernel<<<dim3(iters, nb), 64, 0, s>>>(B, P, tr_all, count);
+    vo_refine_kernel<<<nb, 64, 0, s>>>(B, P, tr_all, count, tr_out, inliers, result);
     return hipGetLastError();
 }

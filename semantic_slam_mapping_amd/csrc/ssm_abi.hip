@@ -41,15 +41,22 @@ static const SegLayerDef k_seg_layers[SEG_LAYERS] = {
 };
 
 } // namespace
-struct QuadState {          // buffers of the stereo quad matcher for one image geometry
-    int w = 0, h = 0, maxc = 0;
-    int lw[4], lh[4];
-    uint8_t* pyr[4][4] = {};                // [image lc,rc,lp,rp][level]
-    int16_t* der[4][4] = {};                // Scharr derivatives (used for lc, rc, rp)
-    float* eig = nullptr; int* maxord = nullptr; int* count = nullptr; unsigned long long *keys = nullptr, *keys2 = nullptr; void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0; int keycap = 0;
-    int* rank_at = nullptr; uint8_t* sel_state = nullptr; int* pending = nullptr;      // minDistance selection (k_quad_select_*)
-    float* pts[5] = {};                     // lc, rc, rp, lp, lp_direct
-    uint8_t* status = nullptr; float* err = nullptr; int* next = nullptr; int* nout = nullptr; void* pm = nullptr;
+struct StereoState {        // workspace of the stereo path (quad matcher, SGBM depth, stereo VO) for one image geometry, B frames per launch
+    int w = 0, h = 0, maxc = 0, B = 0;
+    QuadBatch qb{};                          // image slots: 2 sides x (B + 1) pyramids + Scharr derivatives
+    uint8_t* pyr = nullptr; int16_t* der = nullptr;
+    float* eig = nullptr; uint8_t* state = nullptr; unsigned long long *keys = nullptr, *kept = nullptr; int keycap = 0;
+    int *maxord = nullptr, *count = nullptr, *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
+    float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
+    uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
+    double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
+    void* sg_ws = nullptr; size_t sg_ws_bytes = 0; int* dmin = nullptr;       // SGBM workspace (sized for the frames per launch actually used)
+    // sequence outputs (seq_cap frames)
+    int seq_cap = 0;
+    ssm_pmatch* quad = nullptr; int32_t* nquad = nullptr; float* corners = nullptr; int32_t* ncorners = nullptr; int16_t* disp = nullptr; uint16_t* depth = nullptr;
+    double* tr = nullptr; int32_t *inliers = nullptr, *vo_result = nullptr;
+    bool have_prev = false;                  // slot 0 holds the last frame of the previous sequence call
+    uint8_t* in_stage = nullptr; size_t in_stage_bytes = 0;     // device staging of the per-pair host-pointer entry points
 };
 struct SegNetState {
     bool set[SEG_LAYERS] = {};
@@ -62,7 +69,7 @@ struct SegNetState {
     uint8_t* d_sem_gen = nullptr;       // generated colour labels for the sequence path (max_batch frames)
 };
 
-static void quad_free(QuadState* q);
+static void stereo_free(StereoState* q);
 
 struct ssm_ctx {
     std::mutex mu;
@@ -108,7 +115,7 @@ struct ssm_ctx {
     // SegNet
     struct SegNetState* seg = nullptr;
     // quad matcher
-    struct QuadState* quad = nullptr;
+    struct StereoState* stereo = nullptr; int stereo_B = 16;
     // profiling
     bool profiling = false;
     uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
@@ -258,6 +265,11 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
     int32_t st = 0, cnt[2] = {0, 0};
     HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
     if (st) { hipMemset(c->d_status, 0, 4); FAIL(c, SSM_E_CAPACITY, "ORB scratch capacity exceeded (status " + std::to_string(st) + ")"); }
+    if (c->stereo) {
+        int32_t ov = 0;
+        HIPCHK(c, hipMemcpy(&ov, c->stereo->overflow, 4, hipMemcpyDeviceToHost));
+        if (ov) { hipMemset(c->stereo->overflow, 0, 4); FAIL(c, SSM_E_CAPACITY, "goodFeaturesToTrack: more corner candidates than the buffer holds (w*h/4 + 1024)"); }
+    }
     if (with_map) {
         HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
         if (cnt[1]) {
@@ -361,6 +373,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
+    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 64 ? 64 : b; }
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
@@ -401,7 +414,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
         for (int l = 0; l < SEG_LAYERS; l++) { if (g->w[l]) hipFree(g->w[l]); if (g->scale[l]) hipFree(g->scale[l]); if (g->shift[l]) hipFree(g->shift[l]); }
         delete g;
     }
-    if (c->quad) { quad_free(c->quad); delete c->quad; }
+    if (c->stereo) { stereo_free(c->stereo); delete c->stereo; }
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->d_comm_counts) hipFree(c->d_comm_counts);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -1350,76 +1363,183 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 }
 
 
-// ---------------------------------------------------------------- QuadFeatureMatch
-static void quad_free(QuadState* q)
+// ---------------------------------------------------------------- stereo path: QuadFeatureMatch, StereoSGBM depth, VisualOdometryStereo
+static void stereo_free(StereoState* q)
 {
-    for (int i = 0; i < 4; i++) for (int l = 0; l < 4; l++) { if (q->pyr[i][l]) hipFree(q->pyr[i][l]); if (q->der[i][l]) hipFree(q->der[i][l]); q->pyr[i][l] = nullptr; q->der[i][l] = nullptr; }
-    void* p[] = { q->eig, q->maxord, q->count, q->keys, q->keys2, q->sort_tmp, q->pts[0], q->pts[1], q->pts[2], q->pts[3], q->pts[4], q->status, q->err, q->next, q->nout, q->pm, q->rank_at, q->sel_state, q->pending };
+    void* p[] = { q->pyr, q->der, q->eig, q->state, q->keys, q->kept, q->maxord, q->count, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
+                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
+                  q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
 }
-static int quad_init(ssm_ctx* c, int w, int h, int maxc)
+// exact: the row stride of the sequence outputs is max_corners, so the sequence path wants exactly that many; the per-call entry points take any workspace that is large enough
+static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
 {
-    if (c->quad && c->quad->w == w && c->quad->h == h && c->quad->maxc >= maxc) return SSM_OK;
-    if (w < 32 || h < 32 || w > 4096 || h > 4096) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
-    if (((w + 7) / 8) * ((h + 7) / 8) > 65536) FAIL(c, SSM_E_INVAL, "quad matcher: image too large for the minDistance grid");
-    if (c->quad) { hipStreamSynchronize(c->stream); quad_free(c->quad); delete c->quad; c->quad = nullptr; }
-    QuadState* q = new QuadState(); c->quad = q;
-    q->w = w; q->h = h; q->maxc = maxc;
-    for (int l = 0; l < 4; l++) { q->lw[l] = l ? (q->lw[l-1] + 1) / 2 : w; q->lh[l] = l ? (q->lh[l-1] + 1) / 2 : h; }
-    for (int i = 0; i < 4; i++) for (int l = 0; l < 4; l++) { DALLOC(c, q->pyr[i][l], (size_t)q->lw[l] * q->lh[l]); if (i != 2) DALLOC(c, q->der[i][l], (size_t)q->lw[l] * q->lh[l] * 2); }
-    q->keycap = w * h / 4 + 1024;
-    DALLOC(c, q->eig, (size_t)w * h); DALLOC(c, q->maxord, 1); DALLOC(c, q->count, 1); DALLOC(c, q->keys, q->keycap); DALLOC(c, q->keys2, q->keycap);
-    HIPCHK(c, sort_keys_desc_u64(nullptr, &q->sort_tmp_bytes, q->keys, q->keys2, q->keycap, c->stream));
-    uint8_t* t; int r = dalloc(c, &t, q->sort_tmp_bytes + 256); if (r) return r; q->sort_tmp = t;
-    for (int i = 0; i < 5; i++) DALLOC(c, q->pts[i], (size_t)2 * maxc);
-    DALLOC(c, q->rank_at, (size_t)w * h); DALLOC(c, q->sel_state, q->keycap); DALLOC(c, q->pending, GFTT_ROUNDS + 1);
-    DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc); DALLOC(c, q->next, maxc); DALLOC(c, q->nout, 1);
-    uint8_t* pm; r = dalloc(c, &pm, (size_t)maxc * sizeof(ssm_pmatch)); if (r) return r; q->pm = pm;
+    if (c->stereo && c->stereo->w == w && c->stereo->h == h && (exact ? c->stereo->maxc == maxc : c->stereo->maxc >= maxc)) return SSM_OK;
+    if (w < 4 || h < 2 || w > 4096 || h > 4096) FAIL(c, SSM_E_INVAL, "stereo path: image size must be at most 4096 x 4096");
+    if (maxc < 1 || maxc > 32767) FAIL(c, SSM_E_INVAL, "max_corners must be 1..32767");
+    if (c->stereo) { hipDeviceSynchronize(); stereo_free(c->stereo); delete c->stereo; c->stereo = nullptr; }
+    StereoState* q = new StereoState(); c->stereo = q;
+    q->w = w; q->h = h; q->maxc = maxc; q->B = c->stereo_B;
+    const int B = q->B;
+    QuadBatch& b = q->qb;
+    int off = 0;
+    for (int l = 0; l < 4; l++) { b.w[l] = l ? (b.w[l-1] + 1) / 2 : w; b.h[l] = l ? (b.h[l-1] + 1) / 2 : h; b.off[l] = off; off += b.w[l] * b.h[l]; off = (off + 15) & ~15; }
+    b.slot_elems = (size_t)off; b.B1 = B + 1;
+    DALLOC(c, q->pyr, (size_t)2 * b.B1 * b.slot_elems); DALLOC(c, q->der, (size_t)2 * b.B1 * b.slot_elems * 2);
+    b.pyr = q->pyr; b.der = q->der;
+    const size_t np = (size_t)w * h;
+    q->keycap = w * h / 4 + 1024;                            // 3x3 local maxima: at most one per 2x2 pixels
+    DALLOC(c, q->eig, (size_t)B * np); DALLOC(c, q->state, (size_t)B * np); DALLOC(c, q->keys, (size_t)B * q->keycap); DALLOC(c, q->kept, (size_t)B * q->keycap);
+    DALLOC(c, q->maxord, B); DALLOC(c, q->count, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
+    HIPCHK(c, hipMemset(q->overflow, 0, 4));
+    DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
+    DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1); DALLOC(c, q->dmin, B);
     return SSM_OK;
 }
-// image i (0 lc, 1 rc, 2 lp, 3 rp) from the host: level 0 packed + 3 pyrDown levels (+ Scharr when asked)
-static int quad_upload(ssm_ctx* c, int i, const uint8_t* img, int stride, bool deriv)
+static int stereo_ensure_seq(ssm_ctx* c, int n)
 {
-    QuadState* q = c->quad; hipStream_t s = c->stream;
-    // image i goes through slot i of the pinned staging buffer (a pageable hipMemcpy2D of a 1241x376 image costs ~1 ms each)
+    StereoState* q = c->stereo;
+    if (n <= q->seq_cap) return SSM_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    void* olds[] = { q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr, q->inliers, q->vo_result };
+    for (void* p : olds) if (p) hipFree(p);
+    q->quad = nullptr; q->nquad = nullptr; q->corners = nullptr; q->ncorners = nullptr; q->disp = nullptr; q->depth = nullptr; q->tr = nullptr; q->inliers = nullptr; q->vo_result = nullptr;
+    q->seq_cap = 0;
     const size_t np = (size_t)q->w * q->h;
-    int r = ensure_pinned(c, 4 * np); if (r) return r;
-    if (i == 0) HIPCHK(c, hipStreamSynchronize(s));               // the previous call's copies out of the staging buffer are done
-    uint8_t* hp = c->h_pinned + (size_t)i * np;
-    for (int y = 0; y < q->h; y++) memcpy(hp + (size_t)y * q->w, img + (size_t)y * stride, q->w);
-    HIPCHK(c, hipMemcpyAsync(q->pyr[i][0], hp, np, hipMemcpyHostToDevice, s));
-    for (int l = 1; l < 4; l++) HIPCHK(c, k_quad_pyrdown(q->pyr[i][l-1], q->lw[l-1], q->lh[l-1], q->pyr[i][l], s));
-    if (deriv) for (int l = 0; l < 4; l++) HIPCHK(c, k_quad_scharr(q->pyr[i][l], q->lw[l], q->lh[l], q->der[i][l], s));
+    DALLOC(c, q->quad, (size_t)n * q->maxc); DALLOC(c, q->nquad, n); DALLOC(c, q->corners, (size_t)n * q->maxc * 2); DALLOC(c, q->ncorners, n);
+    DALLOC(c, q->disp, (size_t)n * np); DALLOC(c, q->depth, (size_t)n * np);
+    DALLOC(c, q->tr, (size_t)n * 6); DALLOC(c, q->inliers, (size_t)n * q->maxc); DALLOC(c, q->vo_result, (size_t)n * 2);
+    q->seq_cap = n;
     return SSM_OK;
 }
-static int quad_gftt(ssm_ctx* c, int img, int max_corners, double quality, double min_distance, float* d_pts, int* n_out)
+static int stereo_ensure_vo(ssm_ctx* c, int iters)
 {
-    QuadState* q = c->quad; hipStream_t s = c->stream;
-    HIPCHK(c, k_quad_mineig(q->pyr[img][0], q->w, q->h, q->w, q->eig, q->maxord, s));
-    HIPCHK(c, k_quad_collect(q->eig, q->w, q->h, q->maxord, quality, q->keys, q->count, q->keycap, s));
-    int nc = 0;
-    HIPCHK(c, hipMemcpyAsync(&nc, q->count, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (nc > q->keycap) FAIL(c, SSM_E_CAPACITY, "corner candidate buffer too small");
-    *n_out = 0;
-    if (nc == 0) return SSM_OK;
-    HIPCHK(c, sort_keys_desc_u64(q->sort_tmp, &q->sort_tmp_bytes, q->keys, q->keys2, nc, s));
-    HIPCHK(c, k_quad_select_begin(q->keys2, nc, q->w, q->h, q->rank_at, q->sel_state, s));
-    for (int more = 1, batch = 0; more; batch++) {               // GFTT_ROUNDS decision rounds per batch; one batch is the normal case
-        if (batch > nc) FAIL(c, SSM_E_HIP, "corner selection did not converge");
-        HIPCHK(c, k_quad_select_rounds(q->keys2, nc, q->w, q->h, (float)min_distance, q->rank_at, q->sel_state, q->pending, s));
-        HIPCHK(c, hipMemcpyAsync(&more, q->pending + GFTT_ROUNDS, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+    StereoState* q = c->stereo;
+    if (iters <= q->vo_iters) return SSM_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (q->tr_all) hipFree(q->tr_all); if (q->vcount) hipFree(q->vcount);
+    q->tr_all = nullptr; q->vcount = nullptr; q->vo_iters = 0;
+    DALLOC(c, q->tr_all, (size_t)q->B * iters * 6); DALLOC(c, q->vcount, (size_t)q->B * iters);
+    q->vo_iters = iters;
+    return SSM_OK;
+}
+static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb)
+{
+    StereoState* q = c->stereo;
+    const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
+    if (need <= q->sg_ws_bytes) return SSM_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (q->sg_ws) hipFree(q->sg_ws);
+    q->sg_ws = nullptr; q->sg_ws_bytes = 0;
+    uint8_t* p8; int r = dalloc(c, &p8, need); if (r) return r;
+    q->sg_ws = p8; q->sg_ws_bytes = need;
+    return SSM_OK;
+}
+static int sgbm_check_params(ssm_ctx* c, const ssm_sgbm_params* params, int w, int h)
+{
+    if (!params) FAIL(c, SSM_E_INVAL, "null SGBM parameters");
+    const int D = params->numberOfDisparities, SW = params->SADWindowSize > 0 ? params->SADWindowSize : 5;
+    if (D <= 0 || D % 16 || D > 128 || D / 16 == 7) FAIL(c, SSM_E_INVAL, "numberOfDisparities must be 16, 32, 48, 64, 80, 96 or 128");
+    if (!(SW & 1) || h <= SW || w <= SW) FAIL(c, SSM_E_INVAL, "SADWindowSize must be odd and smaller than the image");
+    if ((long long)w * h >= (1ll << 30)) FAIL(c, SSM_E_INVAL, "image too large");
+    return SSM_OK;
+}
+// the sequence path on device images; the caller holds the context lock
+static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out)
+{
+    const int n = in->n, w = in->w, h = in->h;
+    const int stages = in->stages ? in->stages : (SSM_STEREO_QUAD | SSM_STEREO_DEPTH | SSM_STEREO_VO);
+    if (n < 0 || !in->left || !in->right) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if ((stages & SSM_STEREO_VO) && !(stages & SSM_STEREO_QUAD)) FAIL(c, SSM_E_INVAL, "SSM_STEREO_VO needs SSM_STEREO_QUAD");
+    if ((stages & SSM_STEREO_VO) && (in->ransac_iters < 0 || (in->ransac_iters > 0 && !in->rand_stream))) FAIL(c, SSM_E_INVAL, "the VO stage needs rand_stream (n * ransac_iters * 3 draws)");
+    const int maxc = in->max_corners > 0 ? in->max_corners : 1000;
+    if ((stages & SSM_STEREO_QUAD) && (w < 32 || h < 32)) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
+    int r = stereo_init(c, w, h, maxc, true); if (r) return r;
+    StereoState* q = c->stereo;
+    if (stages & SSM_STEREO_DEPTH) { r = sgbm_check_params(c, &in->sgbm, w, h); if (r) return r; }
+    r = stereo_ensure_seq(c, n > 0 ? n : 1); if (r) return r;
+    if (stages & SSM_STEREO_VO) { r = stereo_ensure_vo(c, in->ransac_iters > 0 ? in->ransac_iters : 1); if (r) return r; }
+    const int B = q->B;
+    if (stages & SSM_STEREO_DEPTH) { r = stereo_ensure_sgbm(c, in->sgbm, n < B ? (n > 0 ? n : 1) : B); if (r) return r; }
+    const size_t np = (size_t)w * h;
+    const QuadBatch& qb = q->qb;
+    hipStream_t sq = c->stream, sd = c->stream;
+    // the quad matcher + VO chain (many small latency-bound kernels) and SGBM (volume kernels) of a sub-batch share nothing but the input images:
+    // SGBM runs on the second context stream beside the chain; sub-batches follow each other on both streams without a join in between
+    const bool two = (stages & SSM_STEREO_DEPTH) && (stages & SSM_STEREO_QUAD) && !c->serialize;
+    if (two) { r = ensure_side_streams(c); if (r) return r; sd = c->stream2; HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
+    const bool prev0 = in->continue_sequence && q->have_prev;
+    if (stages & SSM_STEREO_VO) HIPCHK(c, hipMemsetAsync(q->consumed, 0, 4, sq));
+    for (int f0 = 0; f0 < n; f0 += B) {
+        const int nb = n - f0 < B ? n - f0 : B;
+        if (stages & SSM_STEREO_QUAD) {
+            prof_begin(c, "quad_track");
+            // level 0 of the nb frames into slots 1 .. nb of both sides, then the pyramids and derivatives
+            HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(0 * qb.B1 + 1) * qb.slot_elems, qb.slot_elems, in->left + (size_t)f0 * np, np, np, nb, hipMemcpyDeviceToDevice, sq));
+            HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(1 * qb.B1 + 1) * qb.slot_elems, qb.slot_elems, in->right + (size_t)f0 * np, np, np, nb, hipMemcpyDeviceToDevice, sq));
+            HIPCHK(c, k_quad_pyramids(qb, nb, sq));
+            HIPCHK(c, hipMemsetAsync(q->has_prev, 1, 4 * (size_t)nb, sq));                      // non-zero = true
+            if (f0 == 0 && !prev0) HIPCHK(c, hipMemsetAsync(q->has_prev, 0, 4, sq));
+            HIPCHK(c, k_quad_gftt(qb, nb, maxc, 0.04, 8.0, q->eig, q->maxord, q->keys, q->kept, q->count, q->keycap, q->state, q->pts, maxc, q->ncorner, q->overflow, sq));      // quadmatcher.cpp:301-308
+            HIPCHK(c, k_quad_track(qb, nb, q->pts, maxc, q->ncorner, q->has_prev, q->quad + (size_t)f0 * maxc, q->nquad + f0, sq));
+            HIPCHK(c, hipMemcpyAsync(q->corners + (size_t)f0 * maxc * 2, q->pts, (size_t)nb * maxc * 8, hipMemcpyDeviceToDevice, sq));
+            HIPCHK(c, hipMemcpyAsync(q->ncorners + f0, q->ncorner, (size_t)nb * 4, hipMemcpyDeviceToDevice, sq));
+            // carry: the last frame of the sub-batch becomes slot 0 (images and derivatives, both sides)
+            for (int side = 0; side < 2; side++) {
+                HIPCHK(c, hipMemcpyAsync(q->pyr + (size_t)(side * qb.B1) * qb.slot_elems, q->pyr + (size_t)(side * qb.B1 + nb) * qb.slot_elems, qb.slot_elems, hipMemcpyDeviceToDevice, sq));
+                HIPCHK(c, hipMemcpyAsync(q->der + (size_t)(side * qb.B1) * qb.slot_elems * 2, q->der + (size_t)(side * qb.B1 + nb) * qb.slot_elems * 2, qb.slot_elems * 4, hipMemcpyDeviceToDevice, sq));
+            }
+            prof_end(c);
+        }
+        if (stages & SSM_STEREO_VO) {
+            prof_begin(c, "vo");
+            HIPCHK(c, k_vo_estimate_batch(q->quad + (size_t)f0 * maxc, maxc, q->nquad + f0, nb, in->vo, in->rand_stream, in->ransac_iters, q->consumed, q->rand_off,
+                                          q->tr_all, q->vcount, q->tr + (size_t)f0 * 6, q->inliers + (size_t)f0 * maxc, q->vo_result + (size_t)f0 * 2, sq));
+            prof_end(c);
+        }
+        if (stages & SSM_STEREO_DEPTH) {
+            struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sd);   // stage events on SGBM's stream
+            prof_begin(c, "sgbm");
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_ws, q->disp + (size_t)f0 * np, 0, sd));
+            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dmin, q->depth + (size_t)f0 * np, sd));
+            prof_end(c);
+        }
     }
-    HIPCHK(c, k_quad_select_emit(q->keys2, nc, q->w, max_corners, q->sel_state, d_pts, q->nout, s));
-    HIPCHK(c, hipMemcpyAsync(n_out, q->nout, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (two) { HIPCHK(c, hipEventRecord(c->ev_join, sd)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (n > 0) q->have_prev = (stages & SSM_STEREO_QUAD) != 0;
+    if (out) {
+        out->quad = q->quad; out->nquad = q->nquad; out->corners = q->corners; out->ncorners = q->ncorners; out->disp = q->disp; out->depth = q->depth;
+        out->tr = q->tr; out->inliers = q->inliers; out->vo_result = q->vo_result; out->rand_draws_used = q->consumed; out->max_corners = maxc;
+    }
     return SSM_OK;
 }
-static int quad_lk(ssm_ctx* c, int prev, int next, const float* p_prev, int n, float* p_next, int max_count, double eps, double min_eig)
+extern "C" int ssm_stereo_batch(const ssm_ctx* c) { return c ? c->stereo_B : 0; }
+extern "C" int ssm_stereo_seq_process(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out)
 {
-    QuadState* q = c->quad;
-    HIPCHK(c, k_quad_lk(q->pyr[prev], q->pyr[next], q->der[prev], q->lw, q->lh, p_prev, n, p_next, q->status, q->err, max_count, (float)(eps * eps), (float)min_eig, c->stream));
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!in) FAIL(c, SSM_E_INVAL, "null argument");
+    return stereo_seq_run(c, in, out);
+}
+// host images -> packed device staging: slot k of the staging area holds image k ([h][w] bytes each); through pinned memory (a pageable copy of a
+// 1241x376 image costs ~1 ms)
+static int stereo_stage_images(ssm_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, uint8_t** dev_out)
+{
+    StereoState* q = c->stereo;
+    const size_t np = (size_t)w * h;
+    int r = ensure_pinned(c, np * 6 > (size_t)nimg * np ? np * 6 : (size_t)nimg * np); if (r) return r;
+    if ((size_t)nimg * np > q->in_stage_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (q->in_stage) hipFree(q->in_stage);
+        q->in_stage = nullptr; q->in_stage_bytes = 0;
+        DALLOC(c, q->in_stage, (size_t)4 * np); q->in_stage_bytes = (size_t)4 * np;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));               // the previous call's copies out of the staging buffer are done
+    for (int k = 0; k < nimg; k++)
+        for (int y = 0; y < h; y++) memcpy(c->h_pinned + (size_t)k * np + (size_t)y * w, imgs[k] + (size_t)y * stride, w);
+    HIPCHK(c, hipMemcpyAsync(q->in_stage, c->h_pinned, (size_t)nimg * np, hipMemcpyHostToDevice, c->stream));
+    *dev_out = q->in_stage;
     return SSM_OK;
 }
 extern "C" int ssm_quad_track(ssm_ctx* c, const uint8_t* lc, const uint8_t* rc, const uint8_t* lp, const uint8_t* rp, int w, int h, int stride,
@@ -1428,28 +1548,23 @@ extern "C" int ssm_quad_track(ssm_ctx* c, const uint8_t* lc, const uint8_t* rc, 
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!lc || !rc || !lp || !rp || !n_out || stride < w || max_corners < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
-    int r = quad_init(c, w, h, max_corners); if (r) return r;
-    QuadState* q = c->quad;
-    if ((r = quad_upload(c, 0, lc, stride, true)) || (r = quad_upload(c, 1, rc, stride, true)) || (r = quad_upload(c, 2, lp, stride, false)) || (r = quad_upload(c, 3, rp, stride, true))) return r;
-    int n = 0;
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
-    prof_begin(c, "quad_track");
-    r = quad_gftt(c, 0, max_corners, 0.04, 8.0, q->pts[0], &n);                             // quadmatcher.cpp:301-308
-    if (r || n == 0) prof_end(c);
-    if (r) return r;
-    *n_out = 0;
-    if (n == 0) return SSM_OK;
-    // quadmatcher.cpp:566-576: lc->rc, rc->rp, rp->lp, lc->lp(direct); pts: 0 lc, 1 rc, 2 rp, 3 lp, 4 lp_direct; images: 0 lc, 1 rc, 2 lp, 3 rp
-    if ((r = quad_lk(c, 0, 1, q->pts[0], n, q->pts[1], 200, 0.01, 1e-6)) || (r = quad_lk(c, 1, 3, q->pts[1], n, q->pts[2], 200, 0.01, 1e-6)) ||
-        (r = quad_lk(c, 3, 2, q->pts[2], n, q->pts[3], 200, 0.01, 1e-6)) || (r = quad_lk(c, 0, 2, q->pts[0], n, q->pts[4], 200, 0.01, 1e-6))) return r;
-    HIPCHK(c, k_quad_filter(q->pts[0], q->pts[1], q->pts[3], q->pts[2], q->pts[4], n, q->pm, q->nout, c->stream));
-    prof_end(c);
+    int r = stereo_init(c, w, h, max_corners, true); if (r) return r;
+    // a two-frame sequence: frame 0 = the previous pair, frame 1 = the current pair (left images first, then the right ones)
+    const uint8_t* imgs[4] = { lp, lc, rp, rc };
+    uint8_t* dev = nullptr;
+    r = stereo_stage_images(c, imgs, 4, w, h, stride, &dev); if (r) return r;
+    ssm_stereo_frames_dev in; memset(&in, 0, sizeof(in));
+    in.left = dev; in.right = dev + (size_t)2 * w * h; in.n = 2; in.w = w; in.h = h; in.stages = SSM_STEREO_QUAD; in.max_corners = max_corners;
+    ssm_stereo_out_dev o;
+    r = stereo_seq_run(c, &in, &o); if (r) return r;
+    c->stereo->have_prev = false;                                // a per-pair call is not part of a sequence
     int m = 0;
-    HIPCHK(c, hipMemcpyAsync(&m, q->nout, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&m, o.nquad + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    r = check_device_flags(c, false); if (r) return r;
     *n_out = m;
     if (m > cap) FAIL(c, SSM_E_CAPACITY, "pmatch buffer too small (need " + std::to_string(m) + ")");
-    if (m) HIPCHK(c, hipMemcpy(out, q->pm, (size_t)m * sizeof(ssm_pmatch), hipMemcpyDeviceToHost));
+    if (m > 0) HIPCHK(c, hipMemcpy(out, o.quad + o.max_corners, (size_t)m * sizeof(ssm_pmatch), hipMemcpyDeviceToHost));
     return SSM_OK;
 }
 extern "C" int ssm_gftt(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance,
@@ -1458,16 +1573,20 @@ extern "C" int ssm_gftt(ssm_ctx* c, const uint8_t* img, int w, int h, int stride
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!img || !pts || !n_out || stride < w || max_corners < 1 || !(min_distance >= 1.0)) FAIL(c, SSM_E_INVAL, "bad arguments (max_corners >= 1, min_distance >= 1)");
-    { const int cell = (int)lrint(min_distance) > 0 ? (int)lrint(min_distance) : 1;
-      if ((long long)((w + cell - 1) / cell) * ((h + cell - 1) / cell) > 65536) FAIL(c, SSM_E_INVAL, "min_distance too small for this image size (grid > 65536 cells)"); }
+    if (min_distance > 64.0) FAIL(c, SSM_E_INVAL, "min_distance must be <= 64");
+    if (w < 32 || h < 32) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
     if (max_corners > 32767) FAIL(c, SSM_E_INVAL, "max_corners must be <= 32767");
-    int r = quad_init(c, w, h, max_corners); if (r) return r;
-    HIPCHK(c, hipMemcpy2DAsync(c->quad->pyr[0][0], w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    int r = stereo_init(c, w, h, max_corners); if (r) return r;
+    StereoState* q = c->stereo; const QuadBatch& qb = q->qb;
+    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)1 * qb.slot_elems, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));        // side 0, slot 1, level 0
+    HIPCHK(c, k_quad_gftt(qb, 1, max_corners, quality, min_distance, q->eig, q->maxord, q->keys, q->kept, q->count, q->keycap, q->state, q->pts, q->maxc, q->ncorner, q->overflow, c->stream));
     int n = 0;
-    r = quad_gftt(c, 0, max_corners, quality, min_distance, c->quad->pts[0], &n); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(&n, q->ncorner, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    r = check_device_flags(c, false); if (r) return r;
     *n_out = n;
     if (n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small");
-    if (n) HIPCHK(c, hipMemcpy(pts, c->quad->pts[0], (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (n) HIPCHK(c, hipMemcpy(pts, q->pts, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SSM_OK;
 }
 extern "C" int ssm_lk_track(ssm_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
@@ -1477,15 +1596,21 @@ extern "C" int ssm_lk_track(ssm_ctx* c, const uint8_t* prev, const uint8_t* next
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!prev || !next || n < 0 || (n && (!prev_pts || !next_pts)) || stride < w || max_count < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
     if (n == 0) return SSM_OK;
-    int r = quad_init(c, w, h, n > 1000 ? n : 1000); if (r) return r;
-    QuadState* q = c->quad;
-    if ((r = quad_upload(c, 0, prev, stride, true)) || (r = quad_upload(c, 1, next, stride, false))) return r;
-    HIPCHK(c, hipMemcpyAsync(q->pts[0], prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    r = quad_lk(c, 0, 1, q->pts[0], n, q->pts[1], max_count, epsilon, min_eig_threshold); if (r) return r;
-    HIPCHK(c, hipMemcpyAsync(next_pts, q->pts[1], (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (w < 32 || h < 32) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
+    int r = stereo_init(c, w, h, n > 1000 ? n : 1000); if (r) return r;
+    StereoState* q = c->stereo; const QuadBatch& qb = q->qb;
+    // previous image = (side 0, slot 1), next image = (side 1, slot 1)
+    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)1 * qb.slot_elems, w, prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(qb.B1 + 1) * qb.slot_elems, w, next, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_quad_pyramids(qb, 1, c->stream));
+    float* d_in = q->pts; float* d_out = q->pts + (size_t)2 * q->maxc;
+    HIPCHK(c, hipMemcpyAsync(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_quad_lk(qb, d_in, n, d_out, q->status, q->err, max_count, (float)(epsilon * epsilon), (float)min_eig_threshold, c->stream));
+    HIPCHK(c, hipMemcpyAsync(next_pts, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, q->status, n, hipMemcpyDeviceToHost, c->stream));
     if (err) HIPCHK(c, hipMemcpyAsync(err, q->err, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stereo->have_prev = false;
     return SSM_OK;
 }
 extern "C" int ssm_window_match(ssm_ctx* c, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
@@ -1514,31 +1639,24 @@ extern "C" void ssm_sgbm_params_default(ssm_sgbm_params* p)
     p->minDisparity = 0; p->numberOfDisparities = 80; p->SADWindowSize = 11; p->P1 = 4 * 11 * 11; p->P2 = 32 * 11 * 11;       // src/stereo.cpp:16-27
     p->disp12MaxDiff = 1; p->preFilterCap = 63; p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32;
 }
+// one host pair through the batched kernels (nb = 1): images staged on the device, disparity (and depth) left in the sequence output buffers
 static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage,
-                    int16_t** d_disp_out, uint8_t** d_tail_out)
+                    int16_t** d_disp_out, uint16_t** d_depth_out)
 {
     if (!left || !right || !params || w < 3 || h < 1 || stride < w) FAIL(c, SSM_E_INVAL, "bad arguments");
-    const int D = params->numberOfDisparities, SW = params->SADWindowSize > 0 ? params->SADWindowSize : 5;
-    if (D <= 0 || D % 16 || D > 128 || D / 16 == 7) FAIL(c, SSM_E_INVAL, "numberOfDisparities must be 16, 32, 48, 64, 80, 96 or 128");
-    if (!(SW & 1) || h <= SW || w <= SW) FAIL(c, SSM_E_INVAL, "SADWindowSize must be odd and smaller than the image");
-    if ((long long)w * h >= (1ll << 30)) FAIL(c, SSM_E_INVAL, "image too large");
-    const size_t np = (size_t)w * h, ws = k_sgbm_workspace_bytes(w, h, *params);
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    int r = ensure_scratch(c, al(np) * 2 + al(np * 2) * 2 + 256 + ws); if (r) return r;
-    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
-    uint8_t* dl = p; p += al(np); uint8_t* dr = p; p += al(np);
-    int16_t* dd = (int16_t*)p; p += al(np * 2);
-    uint8_t* tail = p; p += al(np * 2) + 256;                  // depth image + the min-disparity word, for ssm_stereo_depth
-    r = ensure_pinned(c, np * 6); if (r) return r;               // 2 images in; disparity + depth out
-    HIPCHK(c, hipStreamSynchronize(s));                           // the staging buffer may still be in flight from the previous call
-    for (int y = 0; y < h; y++) { memcpy(c->h_pinned + (size_t)y * w, left + (size_t)y * stride, w); memcpy(c->h_pinned + np + (size_t)y * w, right + (size_t)y * stride, w); }
-    HIPCHK(c, hipMemcpyAsync(dl, c->h_pinned, np, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dr, c->h_pinned + np, np, hipMemcpyHostToDevice, s));
+    int r = sgbm_check_params(c, params, w, h); if (r) return r;
+    r = stereo_init(c, w, h, c->stereo && c->stereo->w == w && c->stereo->h == h ? c->stereo->maxc : 1000); if (r) return r;
+    r = stereo_ensure_seq(c, 1); if (r) return r;
+    r = stereo_ensure_sgbm(c, *params, 1); if (r) return r;
+    StereoState* q = c->stereo;
+    const uint8_t* imgs[2] = { left, right };
+    uint8_t* dev = nullptr;
+    r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
     prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dl, dr, w, h, *params, p, dd, stage, s));
+    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_ws, q->disp, stage, c->stream));
     prof_end(c);
-    *d_disp_out = dd; *d_tail_out = tail;
+    *d_disp_out = q->disp; *d_depth_out = q->depth;
     return SSM_OK;
 }
 extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp)
@@ -1546,8 +1664,8 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
-    int16_t* dd; uint8_t* tail;
-    int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &tail); if (r) return r;
+    int16_t* dd; uint16_t* ddepth;
+    int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1561,11 +1679,10 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!depth) FAIL(c, SSM_E_INVAL, "null argument");
-    int16_t* dd; uint8_t* tail;
-    int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &tail); if (r) return r;
+    int16_t* dd; uint16_t* ddepth;
+    int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
-    uint16_t* ddepth = (uint16_t*)tail; int* dmin = (int*)(tail + ((np * 2 + 255) & ~(size_t)255));
-    HIPCHK(c, k_sgbm_depth(dd, w, h, baseline, cu, cv, f, roix, roiy, roiz, scale, dmin, ddepth, c->stream));
+    HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dmin, ddepth, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
     if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -116,12 +116,15 @@ void k_segnet_release_stream(hipStream_t s);     // per-stream helper state of t
 void k_sgbm_release_stream(hipStream_t s);
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s);
-size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p);
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s);
-hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
-                        int* min_scratch, uint16_t* depth, hipStream_t s);
+// nb frames per launch: left / right [nb][h][w], disp_out [nb][h][w]
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb);
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s);
+hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, int nb, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
+                        int* min_scratch /* nb ints */, uint16_t* depth, hipStream_t s);
 hipError_t k_vo_estimate(const ssm_pmatch* m, int n, const ssm_vo_params& P, const int32_t* samples, int iters,
                          double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s);
+hipError_t k_vo_estimate_batch(const ssm_pmatch* m_all, int stride, const int32_t* n_all, int nb, const ssm_vo_params& P, const uint32_t* rand_stream, int iters,
+                               int32_t* consumed, int32_t* rand_off, double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s);
 hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* scale, const float* shift, uint8_t* labels, int n, int H, int W,
                                 int CinPad, int Cout, hipStream_t s);
 hipError_t k_segnet_conv_pool(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
@@ -135,18 +138,14 @@ hipError_t k_segnet_argmax(const void* logits, int n, int npix, int Cstore, int 
 hipError_t k_segnet_color(const uint8_t* ids, int n, int sw, int sh, int dw, int dh, const int32_t* xofs, const int16_t* xa,
                           const int32_t* yofs, const int16_t* ya, int pavement_to_road, int nearest, uint8_t* sem_bgr, uint8_t* ids_out, hipStream_t s);
 
-// quad matcher (kernels_quad.hip)
-hipError_t k_quad_mineig(const uint8_t* img, int w, int h, int stride, float* eig, int* maxord, hipStream_t s);
-hipError_t k_quad_collect(const float* eig, int w, int h, const int* maxord, double quality, unsigned long long* keys, int* count, int cap, hipStream_t s);
-#define GFTT_ROUNDS 24
-hipError_t k_quad_select_begin(const unsigned long long* keys, int nc, int w, int h, int* rank_at, uint8_t* state, hipStream_t s);
-hipError_t k_quad_select_rounds(const unsigned long long* keys, int nc, int w, int h, float min_distance, const int* rank_at, uint8_t* state, int* pending, hipStream_t s);
-hipError_t k_quad_select_emit(const unsigned long long* keys, int nc, int w, int max_corners, const uint8_t* state, float* pts, int* nout, hipStream_t s);
-hipError_t k_quad_pyrdown(const uint8_t* src, int w, int h, uint8_t* dst, hipStream_t s);
-hipError_t k_quad_scharr(const uint8_t* src, int w, int h, int16_t* d, hipStream_t s);
-hipError_t k_quad_lk(const uint8_t* const* P, const uint8_t* const* N, const int16_t* const* D, const int* lw, const int* lh, const float* prev_pts, int n,
-                     float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s);
-hipError_t k_quad_filter(const float* lc, const float* rc, const float* lp, const float* rp, const float* ld, int n, void* out, int* nout, hipStream_t s);
+// quad matcher (kernels_quad.hip).  Images of the stereo path live in SLOTS: 2 sides x B1 slots, a slot = the 4-level LK pyramid of one image
+// (level l at element offset off[l], packed rows) in `pyr` and its Scharr derivatives (x, y int16 pairs) at the same element offsets in `der`.
+// Slot 0 = the carried previous frame, slot 1 + f = frame f of the sub-batch.
+struct QuadBatch { const uint8_t* pyr; const int16_t* der; size_t slot_elems; int B1; int w[4], h[4], off[4]; };
+hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s);
+hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, float* eig, int* maxord, unsigned long long* keys,
+                       unsigned long long* kept, int* count, int cap, uint8_t* state, float* pts, int stride, int* ncorner, int* overflow, hipStream_t s);
+hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s);
+hipError_t k_quad_track(const QuadBatch& q, int nb, float* pts, int stride, const int* ncorner, const int* has_prev, void* out, int* nout, hipStream_t s);
 hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,
                                ssm_dmatch* out, hipStream_t s);
-hipError_t sort_keys_desc_u64(void* tmp, size_t* tmp_bytes, unsigned long long* in, unsigned long long* out, int n, hipStream_t s);

@@ -19,9 +19,3 @@ hipError_t voxel_sort_pairs(void* tmp, size_t* tmp_bytes, const ssm_voxel* compa
     vox_keys_kernel<<<(n + 255) / 256, 256, 0, s>>>(compact, n, keys_a, idx_a);
     return rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_a, keys_b, idx_a, idx_b, (size_t)n, 0, 63, s);
 }
-
-// corner candidates of goodFeaturesToTrack: (value, ~index) keys, descending
-hipError_t sort_keys_desc_u64(void* tmp, size_t* tmp_bytes, unsigned long long* in, unsigned long long* out, int n, hipStream_t s)
-{
-    return rocprim::radix_sort_keys_desc(tmp, *tmp_bytes, in, out, (size_t)n, 0, 64, s);
-}
