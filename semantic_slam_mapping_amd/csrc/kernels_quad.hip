@@ -81,10 +81,11 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
 // STRONGER corner in cv::goodFeaturesToTrack's walk (value descending, then raster index ascending)
 __global__ void __launch_bounds__(256)
 gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* __restrict__ maxord_all, double quality, unsigned long long* __restrict__ keys_all,
-                    int* __restrict__ count_all, int cap)
+                    int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all)
 {
     const int f = blockIdx.y;
     const float* eig = eig_all + (size_t)f * w * h; unsigned long long* keys = keys_all + (size_t)f * cap; int* count = count_all + f;
+    int* cand_at = cand_at_all + (size_t)f * w * h;          // per-pixel candidate index + 1 (0 = none; zero on entry, gftt_finish_kernel zeroes it again)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int mo = maxord_all[f]; const float mx = __int_as_float(mo >= 0 ? mo : mo ^ 0x7FFFFFFF);
     const float thr = (float)((double)fmaxf(mx, 0.f) * quality);
@@ -101,72 +102,138 @@ gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* 
             keep = v == m;
         }
     }
+    // one reservation per BLOCK (the list order is free: the selection compares keys, it does not walk a sorted list): waves take their offsets from an LDS
+    // counter, one global atomic per block instead of one per wave on the frame's single counter
+    __shared__ int s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const unsigned long long bal = __ballot(keep);
-    if (bal) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(count, __popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (keep) { const int k = base + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); }
-    }
+    const int lane = threadIdx.x & 63;
+    int woff = 0;
+    if (bal && lane == 0) woff = atomicAdd(&s_cnt, __popcll(bal));
+    woff = __shfl(woff, 0, 64);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(count, s_cnt);
+    __syncthreads();
+    if (keep) { const int k = s_base + woff + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) { keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); cand_at[i] = k + 1; } }
 }
 // minDistance selection (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one unless an already kept corner lies closer than
 // minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds of local decisions, because a corner's fate depends only on
 // STRONGER corners within minDistance:
 //   rejected  as soon as a kept corner is that close,
 //   kept      once no stronger corner that close is still undecided (and none is kept),
-// so every round decides at least the strongest undecided corner and most corners settle in the first few rounds.  States only move
-// undecided -> kept / rejected and a decision never reads a weaker corner, so updating in place during a round is safe.  The first maxCorners
-// kept corners in strength order are the reference's result (a kept corner never depends on weaker ones).
-// ONE BLOCK PER FRAME runs everything: it marks the candidates in a per-pixel state map (0 none, 1 undecided, 2 kept, 3 rejected; a neighbour's
-// strength is its eig value + position, so no sorted list and no rank map is needed), loops the rounds until nothing is pending (block barrier
-// per round, no host round trip, no fixed round count), then orders the kept corners by COUNTING: a kept corner's output slot is the number of
-// kept corners with a larger key (keys staged in LDS and read as broadcasts; global memory when there are more than GFTT_LDS_KEYS of them).
-#define GFTT_LDS_KEYS 6144
-__global__ void __launch_bounds__(1024)
-gftt_select_kernel(const float* __restrict__ eig_all, int w, int h, const unsigned long long* __restrict__ keys_all, const int* __restrict__ count_all, int cap,
-                   float min_distance, int max_corners, uint8_t* __restrict__ state_all, unsigned long long* __restrict__ kept_all,
-                   float* __restrict__ pts_all, int pts_stride, int* __restrict__ nout_all, int* __restrict__ overflow)
+// so every round decides at least the strongest undecided corner and most corners settle in the first few rounds.  States (1 undecided, 2 kept,
+// 3 rejected) only move undecided -> kept / rejected and a decision never reads a weaker corner, so updating in place during a round is safe.  The
+// first maxCorners kept corners in strength order are the reference's result (a kept corner never depends on weaker ones).  A neighbour's strength is
+// its key (value bits, then position), so no sorted list exists anywhere.
+//   gftt_deps_kernel    thread per candidate: scans the (2 rad + 1)^2 window of the per-pixel candidate map ONCE and stores the stronger candidates
+//                       within minDistance (<= GFTT_DEPS; more: the count says so and the finish kernel re-scans the window); a candidate without any
+//                       is kept at once (round 1)
+//   gftt_round_kernel   thread per undecided candidate, GFTT_ROUNDS launches: reads the states of its few dependencies
+//   gftt_finish_kernel  one block per frame: loops further rounds until nothing is pending (normally zero iterations), collects the kept keys and
+//                       zeroes the candidate map for the next call
+//   gftt_rank_kernel    thread per kept corner: its output slot = the number of kept corners with a larger key (counting rank, keys read as broadcasts)
+#define GFTT_DEPS 32
+#define GFTT_ROUNDS 12
+__global__ void __launch_bounds__(256)
+gftt_deps_kernel(int w, int h, const unsigned long long* __restrict__ keys_all, const int* __restrict__ count_all, int cap, float min_distance,
+                 const int* __restrict__ cand_at_all, uint32_t* __restrict__ deps_all, uint8_t* __restrict__ depn_all, uint8_t* __restrict__ state_all)
 {
-    __shared__ unsigned long long skeys[GFTT_LDS_KEYS];
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = min(count_all[f], cap);
+    if (i >= nc) return;
+    const int* cand_at = cand_at_all + (size_t)f * w * h; const unsigned long long* keys = keys_all + (size_t)f * cap;
+    uint32_t* deps = deps_all + ((size_t)f * cap + i) * GFTT_DEPS;
+    const unsigned long long key = keys[i];
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+    const int y = idx / w, x = idx - y * w;
+    const float md2 = min_distance * min_distance;
+    const int rad = (int)ceilf(min_distance);                 // |dx|, |dy| < minDistance
+    int n = 0;
+    for (int dy = -rad; dy <= rad; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -rad; dx <= rad; dx++) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+            if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+            const int j = cand_at[yy * w + xx] - 1;
+            if (j < 0 || keys[j] < key) continue;             // no candidate there, or a weaker one
+            if (n < GFTT_DEPS) deps[n] = (uint32_t)j;
+            n++;
+        }
+    }
+    depn_all[(size_t)f * cap + i] = (uint8_t)min(n, 255);
+    state_all[(size_t)f * cap + i] = n == 0 ? 2 : 1;
+}
+__global__ void __launch_bounds__(256)
+gftt_round_kernel(const int* __restrict__ count_all, int cap, const uint32_t* __restrict__ deps_all, const uint8_t* __restrict__ depn_all, uint8_t* __restrict__ state_all)
+{
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = min(count_all[f], cap);
+    if (i >= nc) return;
+    uint8_t* state = state_all + (size_t)f * cap;
+    if (__atomic_load_n(&state[i], __ATOMIC_RELAXED) != 1) return;
+    const int n = depn_all[(size_t)f * cap + i];
+    if (n > GFTT_DEPS) return;                               // list truncated: the finish kernel decides this one
+    const uint32_t* deps = deps_all + ((size_t)f * cap + i) * GFTT_DEPS;
+    bool blocked = false, rejected = false;
+    for (int k = 0; k < n; k++) {
+        const int sj = __atomic_load_n(&state[deps[k]], __ATOMIC_RELAXED);
+        if (sj == 2) { rejected = true; break; }
+        if (sj == 1) blocked = true;
+    }
+    if (rejected) __atomic_store_n(&state[i], (uint8_t)3, __ATOMIC_RELAXED);
+    else if (!blocked) __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED);
+}
+__global__ void __launch_bounds__(1024)
+gftt_finish_kernel(int w, int h, const unsigned long long* __restrict__ keys_all, const int* __restrict__ count_all, int cap, float min_distance,
+                   int* __restrict__ cand_at_all, const uint32_t* __restrict__ deps_all, const uint8_t* __restrict__ depn_all, uint8_t* __restrict__ state_all,
+                   unsigned long long* __restrict__ kept_all, int* __restrict__ nkept_all, int* __restrict__ overflow)
+{
     __shared__ int s_pending, s_nkept;
     const int f = blockIdx.x, tid = threadIdx.x;
-    const size_t np = (size_t)w * h;
-    const float* eig = eig_all + f * np; uint8_t* state = state_all + f * np;
+    int* cand_at = cand_at_all + (size_t)f * w * h; uint8_t* state = state_all + (size_t)f * cap;
     const unsigned long long* keys = keys_all + (size_t)f * cap; unsigned long long* kept = kept_all + (size_t)f * cap;
-    float* pts = pts_all + (size_t)f * pts_stride * 2;
     int nc = count_all[f];
     if (nc > cap) { nc = cap; if (tid == 0) atomicOr(overflow, 1); }       // candidate buffer too small: reported by the host
-    for (int i = tid; i < nc; i += 1024) state[0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFu)] = 1;
     if (tid == 0) { s_pending = 0; s_nkept = 0; }
     __syncthreads();
     const float md2 = min_distance * min_distance;
-    const int rad = (int)ceilf(min_distance);                 // |dx|, |dy| < minDistance
+    const int rad = (int)ceilf(min_distance);
     for (;;) {
         for (int i = tid; i < nc; i += 1024) {
-            const unsigned long long key = keys[i];
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
-            if (__atomic_load_n(&state[idx], __ATOMIC_RELAXED) != 1) continue;
-            const int y = idx / w, x = idx - y * w;
+            if (__atomic_load_n(&state[i], __ATOMIC_RELAXED) != 1) continue;
+            const int n = depn_all[(size_t)f * cap + i];
             bool blocked = false, rejected = false;
-            for (int dy = -rad; dy <= rad && !rejected; dy++) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= h) continue;
-                for (int dx = -rad; dx <= rad; dx++) {
-                    const int xx = x + dx;
-                    if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
-                    if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
-                    const int sj = __atomic_load_n(&state[yy * w + xx], __ATOMIC_RELAXED);
-                    if (sj == 0 || sj == 3) continue;         // no candidate there, or a rejected one
-                    const unsigned nidx = (unsigned)(yy * w + xx);
-                    const unsigned long long nkey = ((unsigned long long)__float_as_uint(eig[nidx]) << 32) | (0xFFFFFFFFu - nidx);
-                    if (nkey < key) continue;                 // a weaker corner
+            if (n <= GFTT_DEPS) {
+                const uint32_t* deps = deps_all + ((size_t)f * cap + i) * GFTT_DEPS;
+                for (int k = 0; k < n; k++) {
+                    const int sj = __atomic_load_n(&state[deps[k]], __ATOMIC_RELAXED);
                     if (sj == 2) { rejected = true; break; }
-                    blocked = true;
+                    if (sj == 1) blocked = true;
+                }
+            } else {                                          // more stronger neighbours than the list holds: scan the window
+                const unsigned long long key = keys[i];
+                const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+                const int y = idx / w, x = idx - y * w;
+                for (int dy = -rad; dy <= rad && !rejected; dy++) {
+                    const int yy = y + dy;
+                    if (yy < 0 || yy >= h) continue;
+                    for (int dx = -rad; dx <= rad; dx++) {
+                        const int xx = x + dx;
+                        if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+                        if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+                        const int j = cand_at[yy * w + xx] - 1;
+                        if (j < 0 || keys[j] < key) continue;
+                        const int sj = __atomic_load_n(&state[j], __ATOMIC_RELAXED);
+                        if (sj == 2) { rejected = true; break; }
+                        if (sj == 1) blocked = true;
+                    }
                 }
             }
-            if (rejected) __atomic_store_n(&state[idx], (uint8_t)3, __ATOMIC_RELAXED);
-            else if (!blocked) __atomic_store_n(&state[idx], (uint8_t)2, __ATOMIC_RELAXED);
+            if (rejected) __atomic_store_n(&state[i], (uint8_t)3, __ATOMIC_RELAXED);
+            else if (!blocked) __atomic_store_n(&state[i], (uint8_t)2, __ATOMIC_RELAXED);
             else s_pending = 1;
         }
         __syncthreads();
@@ -176,29 +243,32 @@ gftt_select_kernel(const float* __restrict__ eig_all, int w, int h, const unsign
         if (tid == 0) s_pending = 0;
         __syncthreads();
     }
-    // kept corners (any order) -> LDS / global list
+    // kept corners (any order) -> list; the map goes back to zero
     for (int i = tid; i < nc; i += 1024) {
         const unsigned long long key = keys[i];
-        if (state[0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)] == 2) {
-            const int k = atomicAdd(&s_nkept, 1);
-            if (k < GFTT_LDS_KEYS) skeys[k] = key;
-            kept[k] = key;
-        }
+        cand_at[0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)] = 0;
+        if (state[i] == 2) kept[atomicAdd(&s_nkept, 1)] = key;
     }
     __syncthreads();
-    const int nk = s_nkept;
-    const bool in_lds = nk <= GFTT_LDS_KEYS;
-    for (int i = tid; i < nk; i += 1024) {
-        const unsigned long long key = in_lds ? skeys[i] : kept[i];
-        int r = 0;
-        if (in_lds) { for (int j = 0; j < nk; j++) r += skeys[j] > key; }
-        else        { for (int j = 0; j < nk; j++) r += kept[j] > key; }
-        if (max_corners <= 0 || r < max_corners) {
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
-            pts[2 * r] = (float)(idx % (unsigned)w); pts[2 * r + 1] = (float)(idx / (unsigned)w);
-        }
+    if (tid == 0) nkept_all[f] = s_nkept;
+}
+__global__ void __launch_bounds__(256)
+gftt_rank_kernel(const unsigned long long* __restrict__ kept_all, const int* __restrict__ nkept_all, int cap, int w, int max_corners,
+                 float* __restrict__ pts_all, int pts_stride, int* __restrict__ nout_all)
+{
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nk = nkept_all[f];
+    if (i == 0) nout_all[f] = (max_corners > 0 && nk > max_corners) ? max_corners : nk;
+    if (i >= nk) return;
+    const unsigned long long* kept = kept_all + (size_t)f * cap;
+    const unsigned long long key = kept[i];
+    int r = 0;
+    for (int j = 0; j < nk; j++) r += kept[j] > key;
+    if (max_corners <= 0 || r < max_corners) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+        float* pts = pts_all + (size_t)f * pts_stride * 2;
+        pts[2 * r] = (float)(idx % (unsigned)w); pts[2 * r + 1] = (float)(idx / (unsigned)w);
     }
-    if (tid == 0) nout_all[f] = (max_corners > 0 && nk > max_corners) ? max_corners : nk;
 }
 
 // ------------------------------------------------------------------ pyramid + Scharr for LK (all frames and both sides of a sub-batch per launch)
@@ -442,21 +512,25 @@ hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
     scharr_kernel<<<dim3(((int)q.slot_elems + 255) / 256, nb * 2), 256, 0, s>>>(q, reinterpret_cast<short2*>(const_cast<int16_t*>(q.der)));
     return hipGetLastError();
 }
-// cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  eig: nb*w*h floats; state: nb*w*h bytes;
-// keys / kept: nb*cap u64; maxord / count: nb ints; overflow: 1 int (set when a frame has more than cap candidates)
-hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, float* eig, int* maxord, unsigned long long* keys,
-                       unsigned long long* kept, int* count, int cap, uint8_t* state, float* pts, int stride, int* ncorner, int* overflow, hipStream_t s)
+// cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  Workspace (GfttWork): eig nb*w*h floats; cand_at
+// nb*w*h ints, ZERO on entry (left zeroed); keys / kept nb*cap u64; deps nb*cap*GFTT_DEPS u32; depn / state nb*cap bytes; maxord / count / nkept nb ints;
+// overflow 1 int (set when a frame has more than cap candidates)
+size_t k_quad_gftt_deps_per_candidate() { return GFTT_DEPS; }
+hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
-    const int w = q.w[0], h = q.h[0];
-    hipError_t e = hipMemsetAsync(maxord, 0x80, 4 * (size_t)nb, s);          // 0x80808080: below any real value in the ordered-int encoding
-    if (e == hipSuccess) e = hipMemsetAsync(count, 0, 4 * (size_t)nb, s);
-    if (e == hipSuccess) e = hipMemsetAsync(state, 0, (size_t)nb * w * h, s);
+    const int w = q.w[0], h = q.h[0], cap = g.cap;
+    hipError_t e = hipMemsetAsync(g.maxord, 0x80, 4 * (size_t)nb, s);          // 0x80808080: below any real value in the ordered-int encoding
+    if (e == hipSuccess) e = hipMemsetAsync(g.count, 0, 4 * (size_t)nb, s);
     if (e != hipSuccess) return e;
     const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
-    mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, eig, maxord);
-    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(eig, w, h, maxord, quality, keys, count, cap);
-    gftt_select_kernel<<<nb, 1024, 0, s>>>(eig, w, h, keys, count, cap, (float)min_distance, max_corners, state, kept, pts, stride, ncorner, overflow);
+    mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, g.eig, g.maxord);
+    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at);
+    const dim3 gc((cap + 255) / 256, nb);
+    gftt_deps_kernel<<<gc, 256, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.deps, g.depn, g.state);
+    for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<gc, 256, 0, s>>>(g.count, cap, g.deps, g.depn, g.state);
+    gftt_finish_kernel<<<nb, 1024, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.deps, g.depn, g.state, g.kept, g.nkept, g.overflow);
+    gftt_rank_kernel<<<gc, 256, 0, s>>>(g.kept, g.nkept, cap, w, max_corners, pts, stride, ncorner);
     return hipGetLastError();
 }
 hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s)

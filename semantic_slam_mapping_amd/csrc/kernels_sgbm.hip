@@ -26,23 +26,26 @@
 #include <mutex>
 #include <map>
 #include <utility>
+#include <type_traits>
 
 #define SG_MAXC 32767
 #define SG_DISP_SHIFT 4
 #define SG_DISP_SCALE 16
 
 // ------------------------------------------------------------------ pre-filter + BT intervals
-// planes (u8, [h][w]): 0 = value, 1 = min(value, half-sample neighbours), 2 = max(...); gradient planes first, then raw
+// per image one plane of uint4 per pixel: .x = the value, .y = min(value, half-sample neighbours), .z = max(...), each word (clipped x-Sobel | raw
+// intensity << 16); .w = 0.  The two cost terms of a pixel pair are then the two 16-bit halves of the same packed subtract / max / min instructions,
+// and a pixel's three words are ONE 16-byte LDS read in the cost kernel.
 __global__ void __launch_bounds__(256)
-sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int w, int h, int ftzero, uint8_t* __restrict__ planes_all)
+sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int w, int h, int ftzero, uint4* __restrict__ planes_all)
 {
-    // blockIdx.z = frame * 2 + side; a frame's 12 planes: left 0..5, right 6..11
+    // blockIdx.z = frame * 2 + side; a frame's 2 planes: left, right
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const size_t np = (size_t)w * h;
     const int f = blockIdx.z >> 1, side = blockIdx.z & 1;
     const uint8_t* img = (side ? right : left) + (size_t)f * np;
-    uint8_t* planes = planes_all + ((size_t)f * 12 + (size_t)side * 6) * np;
+    uint4* planes = planes_all + ((size_t)f * 2 + (size_t)side) * np;
     const uint8_t* row = img + (size_t)y * w;
     const int n1 = y > 0 ? -w : 0, s1 = y < h - 1 ? w : 0;
     auto grad = [&](int xx) -> int {            // prow[x]: tab[...] for 1 <= x <= w-2, tab[0] = ftzero at the two border columns
@@ -51,57 +54,124 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
         return min(max(g, -ftzero), ftzero) + ftzero;
     };
     auto raw = [&](int xx) -> int { return (xx < 1 || xx > w - 2) ? ftzero : (int)row[xx]; };     // the border columns of the raw plane hold tab[0] too
+    uint32_t pv = 0, pmin = 0, pmax = 0;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int v = c ? raw(x) : grad(x);
         const int vl = x > 0 ? (v + (c ? raw(x - 1) : grad(x - 1))) / 2 : v, vr = x < w - 1 ? (v + (c ? raw(x + 1) : grad(x + 1))) / 2 : v;
-        uint8_t* p = planes + (size_t)(3 * c) * np + (size_t)y * w + x;
-        p[0] = (uint8_t)v; p[np] = (uint8_t)min(min(vl, vr), v); p[2 * np] = (uint8_t)max(max(vl, vr), v);
+        pv |= (uint32_t)v << (16 * c); pmin |= (uint32_t)min(min(vl, vr), v) << (16 * c); pmax |= (uint32_t)max(max(vl, vr), v) << (16 * c);
     }
+    planes[(size_t)y * w + x] = make_uint4(pv, pmin, pmax, 0u);
 }
-// BT cost of left pixel x (image column) against right pixel x - d; thread = (d, x); volume index ((y * w1 + x - minX1) * D + d - minD)
-__global__ void __launch_bounds__(256)
-sgbm_pixcost(const uint8_t* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, uint8_t* __restrict__ pix_all)
+// The matching cost C(y, x, d) = P2 + sum over the SAD window of the Birchfield-Tomasi pixel cost, in ONE streaming kernel (it was three volume kernels:
+// pixel cost -> u8 volume, horizontal box -> u16 volume, vertical box -> C; 8 bytes of HBM traffic per volume entry instead of 2).
+// A block owns a strip of TX cost-volume columns x all D disparities of one frame and walks the image rows top to bottom, like OpenCV's row loop:
+//   stage   the pixel words of row r that the strip needs (left: TX + 2 SW2 columns, right: D - 1 more) into LDS -- fetched into registers one row
+//           ahead, so the loads of row r + 1 fly during the arithmetic of row r;
+//   pixel   thread (d, chunk) computes the BT cost of its disparity for every column of the strip + apron (the left pixel is an LDS broadcast, the right
+//           pixels of consecutive d are consecutive 16-byte words; both cost terms in one set of packed 16-bit operations) -> u8 row in LDS;
+//   hbox    the same thread slides the SW-wide window over its run of columns (replicate borders at the ends of the cost volume) -> hs(r, x, d);
+//   vbox    a ring of the last SW hs rows in LDS (each (x, d) is read and written by its owner only: no barrier) gives the running vertical sum:
+//           C(y) = C(y - 1) + hs(y + SH2) - hs(max(y - SH2 - 1, 0)), C(0) = P2 + (SH2 + 1) hs(0) + hs(1) + ... + hs(SH2) (replicated top border).
+// The two OpenCV 2.4 quirks of the contract: cost-volume column 0 keeps row 0's value, rows below h - 1 - SH2 repeat the last full window.
+// Two barriers per row.  Dynamic LDS: ring u16 [SW][TX][D] | pixrow u8 [TX + 2 SW2][D] | lrow uint4 [TX + 2 SW2] | rrow uint4 [TX + 2 SW2 + D - 1].
+// CD / CSW2 / CTX: compile-time D, SW2, TX of the instantiation for stereo.cpp's configuration (80 disparities, SAD 11); 0 = run-time values.
+#define SGC_THREADS 512
+typedef short sg_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sg_s2 sg_as_s2(uint32_t v) { return __builtin_bit_cast(sg_s2, v); }
+template <bool EDGE, int CD, int CSW2, int CTX, int MAXCW>
+__device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes_all, int w, int h, int minD, int Drt, int minX1, int w1, int SW2rt, int P2, int TXrt, uint16_t* __restrict__ C_all)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
-    if (i >= w1 * D) return;
-    const uint8_t* pl1 = planes_all + (size_t)f * 12 * w * h; const uint8_t* pl2 = pl1 + (size_t)6 * w * h;
-    uint8_t* pix = pix_all + (size_t)f * w1 * h * D;
-    const int xi = i / D, d = i - xi * D + minD, x = xi + minX1;
-    const size_t np = (size_t)w * h, o1 = (size_t)y * w + x, o2 = (size_t)y * w + (x - d);
-    int cost = 0;
+    extern __shared__ __align__(16) uint8_t sg_smem[];
+    const int D = CD ? CD : Drt, SW2 = CD ? CSW2 : SW2rt, TX = CD ? CTX : TXrt;
+    const int f = blockIdx.y, xs = blockIdx.x * TX, tid = threadIdx.x;
+    const int SW = 2 * SW2 + 1, AW = TX + 2 * SW2, RW = AW + D - 1;
+    uint16_t* ring = reinterpret_cast<uint16_t*>(sg_smem);
+    uint8_t* pixrow = sg_smem + (size_t)SW * TX * D * 2;
+    uint4* lrow = reinterpret_cast<uint4*>(pixrow + (((size_t)AW * D + 15) & ~(size_t)15));
+    uint4* rrow = lrow + AW;
+    const size_t np = (size_t)w * h;
+    // (d, chunk) decomposition of the block
+    const int nchunk = SGC_THREADS / D, d = tid % D, chunk = tid / D;
+    const bool active = chunk < nchunk;
+    const int cw = (TX + nchunk - 1) / nchunk;                  // <= MAXCW by the launcher's choice of TX
+    const int cx0 = chunk * cw, cx1 = min(min(cx0 + cw, TX), w1 - xs);      // this thread's strip columns [cx0, cx1)
+    const int ncol = active ? max(cx1 - cx0, 0) : 0;
+    // staging: thread k < AW + RW fetches one pixel word of the left / right row
+    const uint4* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
+    if (tid < AW + RW) {
+        const bool isl = tid < AW;
+        const int xi = min(max(isl ? xs - SW2 + minX1 + tid : xs - SW2 + minX1 - minD - (D - 1) + (tid - AW), 0), w - 1);   // columns outside the image are never used by a valid cost
+        src = planes_all + ((size_t)f * 2 + (isl ? 0 : 1)) * np + xi;
+    }
+    int Cacc[MAXCW]; uint32_t hs0[MAXCW];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const uint8_t *a = pl1 + (size_t)(3 * c) * np + o1, *b = pl2 + (size_t)(3 * c) * np + o2;
-        const int u = a[0], u0 = a[np], u1 = a[2 * np], v = b[0], v0 = b[np], v1 = b[2 * np];
-        const int c0 = max(max(0, u - v1), v0 - u), c1 = max(max(0, v - u1), u0 - v);
-        cost += min(c0, c1) >> (c ? 2 : 0);
+    for (int k = 0; k < MAXCW; k++) { Cacc[k] = P2; hs0[k] = 0; }
+    const int SH2 = SW2, ylast = h - 1 - SH2;
+    uint16_t* Cp = C_all + ((size_t)f * w1 * h + xs + cx0) * D + d;           // C(0, xs + cx0, d); + y * w1 * D per row, + D per column
+    const size_t crow = (size_t)w1 * D;
+    const uint8_t* pxd = pixrow + d;
+    const int lo = SW2 - xs, hi = w1 - 1 - xs + SW2;            // pixrow index of cost-volume columns 0 and w1 - 1 (replicate beyond them; only in EDGE strips)
+    auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
+    // one image row: stage, pixel costs, horizontal sums -> sum[k] of this thread's columns (PHASE 0: r = 0, 1: 1 .. SH2, 2: beyond)
+    auto row = [&](int r, auto phase) {
+        constexpr int PHASE = decltype(phase)::value;
+        if (src) lrow[tid] = pre;                               // rrow follows lrow: one linear array
+        __syncthreads();
+        if (src && r + 1 < h) pre = src[(size_t)(r + 1) * w];
+        if (active) {
+            const sg_s2 zero = {0, 0};
+            for (int i = chunk; i < AW; i += nchunk) {
+                const uint4 L = lrow[i], R = rrow[i + (D - 1) - d];      // right pixel: image column of i minus the disparity
+                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z), v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
+                const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
+                const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
+                const sg_s2 m = __builtin_elementwise_min(c0, c1);
+                pixrow[i * D + d] = (uint8_t)((int)m.x + ((int)m.y >> 2));
+            }
+        }
+        __syncthreads();
+        if (ncol > 0) {
+            int sum = 0;
+            for (int j = -SW2; j <= SW2; j++) sum += px(cx0 + j);
+            uint16_t* rg = ring + ((size_t)(r % SW) * TX + cx0) * D + d;
+            uint16_t* Cr = Cp + (ptrdiff_t)(r - SH2) * (ptrdiff_t)crow;
+#pragma unroll
+            for (int k = 0; k < MAXCW; k++) {
+                if (k < ncol) {
+                    if (k > 0) sum += px(cx0 + k + SW2) - px(cx0 + k - SW2 - 1);
+                    if (PHASE == 0) { hs0[k] = (uint32_t)sum; Cacc[k] += (SH2 + 1) * sum; rg[k * D] = (uint16_t)sum; }
+                    else if (PHASE == 1) { Cacc[k] += sum; rg[k * D] = (uint16_t)sum; }
+                    else {
+                        const int old = r - SW >= 0 ? (int)rg[k * D] : (int)hs0[k];      // hs(r - SW, x, d): the slot this row overwrites
+                        rg[k * D] = (uint16_t)sum;
+                        const int delta = sum - old;
+                        Cacc[k] += (EDGE && xs + cx0 + k == 0) ? 0 : delta;              // cost-volume column 0 keeps C(0)
+                    }
+                    if (PHASE == 2 || r == SH2) Cr[k * D] = (uint16_t)Cacc[k];
+                }
+            }
+        }
+    };
+    if (src) pre = src[0];
+    row(0, std::integral_constant<int, 0>());
+    for (int r = 1; r <= SH2; r++) row(r, std::integral_constant<int, 1>());
+    for (int r = SH2 + 1; r < h; r++) row(r, std::integral_constant<int, 2>());
+    // rows below h - 1 - SH2 repeat the last full window
+    if (ncol > 0) {
+        for (int y = ylast + 1; y < h; y++)
+#pragma unroll
+            for (int k = 0; k < MAXCW; k++) if (k < ncol) Cp[(size_t)y * crow + k * D] = (uint16_t)Cacc[k];
     }
-    pix[((size_t)y * w1 + xi) * D + (d - minD)] = (uint8_t)cost;
 }
-__global__ void __launch_bounds__(256)
-sgbm_hbox(const uint8_t* __restrict__ pix_all, int w1, int h, int D, int SW2, uint16_t* __restrict__ hs_all)
+// the first strip and the last `tail` strips replicate the cost-volume border columns (and strip 0 holds the frozen column 0): they run the EDGE
+// instantiation; the strips between them read their apron without clamps.  One launch for all strips (block-uniform branch).
+template <int CD, int CSW2, int CTX, int MAXCW>
+__global__ void __launch_bounds__(SGC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+sgbm_cost_kernel(const uint4* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, int SW2, int P2, int TX, int tail, uint16_t* __restrict__ C_all)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (i >= w1 * D) return;
-    const uint8_t* pix = pix_all + (size_t)blockIdx.z * w1 * h * D; uint16_t* hs = hs_all + (size_t)blockIdx.z * w1 * h * D;
-    const int x = i / D, d = i - x * D;
-    const uint8_t* r = pix + (size_t)y * w1 * D + d;
-    int s = 0;
-    for (int j = -SW2; j <= SW2; j++) s += r[(size_t)min(max(x + j, 0), w1 - 1) * D];
-    hs[(size_t)y * w1 * D + i] = (uint16_t)s;
-}
-__global__ void __launch_bounds__(256)
-sgbm_vbox(const uint16_t* __restrict__ hs_all, int w1, int h, int D, int SH2, int P2, uint16_t* __restrict__ C_all)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (i >= w1 * D) return;
-    const uint16_t* hs = hs_all + (size_t)blockIdx.z * w1 * h * D; uint16_t* C = C_all + (size_t)blockIdx.z * w1 * h * D;
-    const int x = i / D;
-    const int yy = x == 0 ? 0 : min(y, h - 1 - SH2);          // OpenCV 2.4: column 0 and the bottom rows stop being updated
-    int s = P2;
-    for (int k = -SH2; k <= SH2; k++) s += hs[(size_t)min(max(yy + k, 0), h - 1) * w1 * D + i];
-    C[(size_t)y * w1 * D + i] = (uint16_t)s;
+    if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip<true, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
+    else sgbm_cost_strip<false, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
 }
 
 // ------------------------------------------------------------------ one aggregation step on a 16-lane row (K disparities per lane)
@@ -356,24 +426,72 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b)
         if (atomicCAS(&parent[a], a, b) == a) return;          // (otherwise somebody hooked a first: find again and retry)
     }
 }
-__global__ void __launch_bounds__(256)
-sgbm_speckle_init(int n, int* __restrict__ parent, int* __restrict__ count)
+// Two levels: a block first resolves its 64 x 16 tile in LDS (local forest, LDS atomics), flattens it and writes every pixel's parent = the GLOBAL index of
+// its tile-local root (the smallest index of the local component: row-major order is the same inside the tile and in the image, so the invariant "parents
+// point to smaller indices" holds globally); then only the pixels on tile edges are united across the edges in global memory.  The global forest sees
+// ~1/13 of the unions the one-level version made, and none of the long hot chains inside large planes.
+#define SPK_TW 64
+#define SPK_TH 16
+__device__ __forceinline__ int lds_find(int* parent, int i)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    { const size_t fp = (size_t)blockIdx.y * n; parent += fp; count += fp; }        // blockIdx.y = frame: every frame has its own forest (indices inside the frame)
-    if (i < n) { parent[i] = i; count[i] = 0; }
+    int root = i;
+    while (true) { const int p = parent[root]; if (p == root) break; root = p; }
+    while (i > root) { const int p = parent[i]; if (p > root) atomicMin(&parent[i], root); i = p; }
+    return root;
+}
+__device__ __forceinline__ void lds_union(int* parent, int a, int b)
+{
+    while (true) {
+        a = lds_find(parent, a); b = lds_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        if (atomicCAS(&parent[a], a, b) == a) return;
+    }
 }
 __global__ void __launch_bounds__(256)
-sgbm_speckle_link(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* __restrict__ parent)
+sgbm_speckle_tile(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* __restrict__ parent, int* __restrict__ count)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w * h) return;
+    __shared__ int lp[SPK_TW * SPK_TH];
+    __shared__ int16_t val[SPK_TH][SPK_TW];
+    { const size_t fp = (size_t)blockIdx.z * w * h; img += fp; parent += fp; count += fp; }        // blockIdx.z = frame: every frame has its own forest (indices inside the frame)
+    const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH;
+    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) {
+        const int ly = i / SPK_TW, lx = i - ly * SPK_TW, gx = tx0 + lx, gy = ty0 + ly;
+        val[ly][lx] = (gx < w && gy < h) ? img[(size_t)gy * w + gx] : (int16_t)newVal;
+        lp[i] = i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) {
+        const int ly = i / SPK_TW, lx = i - ly * SPK_TW;
+        const int v = val[ly][lx];
+        if (v == newVal) continue;
+        if (lx < SPK_TW - 1) { const int r = val[ly][lx + 1]; if (r != newVal && abs(v - r) <= maxDiff) lds_union(lp, i, i + 1); }
+        if (ly < SPK_TH - 1) { const int b = val[ly + 1][lx]; if (b != newVal && abs(v - b) <= maxDiff) lds_union(lp, i, i + SPK_TW); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) {
+        const int ly = i / SPK_TW, lx = i - ly * SPK_TW, gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= w || gy >= h) continue;
+        const int root = lds_find(lp, i), ry = root / SPK_TW, rx = root - ry * SPK_TW;
+        const int g = gy * w + gx;
+        parent[g] = (ty0 + ry) * w + tx0 + rx; count[g] = 0;
+    }
+}
+// the unions across tile edges: thread = one pixel of a tile's last column (links to x + 1) or last row (links to y + 1)
+__global__ void __launch_bounds__(256)
+sgbm_speckle_edges(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* __restrict__ parent)
+{
     { const size_t fp = (size_t)blockIdx.y * w * h; img += fp; parent += fp; }
-    const int v = img[i];
-    if (v == newVal) return;
-    const int x = i % w, y = i / w;
-    if (x < w - 1) { const int r = img[i + 1]; if (r != newVal && abs(v - r) <= maxDiff) uf_union(parent, i, i + 1); }
-    if (y < h - 1) { const int b = img[i + w]; if (b != newVal && abs(v - b) <= maxDiff) uf_union(parent, i, i + w); }
+    const int ncx = (w - 1) / SPK_TW, ncy = (h - 1) / SPK_TH;          // interior vertical / horizontal edge lines
+    const int nv = ncx * h, nh = ncy * w;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nv + nh) return;
+    int x, y, dx, dy;
+    if (t < nv) { const int e = t / h; y = t - e * h; x = (e + 1) * SPK_TW - 1; dx = 1; dy = 0; }
+    else { const int u = t - nv, e = u / w; x = u - e * w; y = (e + 1) * SPK_TH - 1; dx = 0; dy = 1; }
+    const int i = y * w + x, j = (y + dy) * w + x + dx;
+    const int v = img[i], q = img[j];
+    if (v != newVal && q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, j);
 }
 __global__ void __launch_bounds__(256)
 sgbm_speckle_count(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ parent, int* __restrict__ count)
@@ -493,13 +611,25 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
+// strip width of sgbm_cost_kernel and its dynamic LDS: the widest TX whose ring fits (and whose per-thread column run fits the register arrays)
+bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out)
+{
+    const int SW2 = SW / 2, nchunk = SGC_THREADS / D;
+    for (int TX = 32; TX >= 4; TX >>= 1) {
+        const int AW = TX + 2 * SW2, RW = AW + D - 1;
+        const size_t lds = (size_t)SW * TX * D * 2 + (((size_t)AW * D + 15) & ~(size_t)15) + (size_t)(AW + RW) * 16;
+        // the interior (clamp-free) strips must not touch the volume's border columns: SW2 <= TX
+        if (lds <= 150 * 1024 && (TX + nchunk - 1) / nchunk <= 16 && AW + RW <= SGC_THREADS && SW2 <= TX) { *TX_out = TX; *lds_out = lds; return true; }
+    }
+    return false;
+}
 // workspace for nb frames per launch
 size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb)
 {
     const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
     const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities * nb, np = (size_t)w * h * nb;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(12 * np) + al(vol) + 7 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256;
+    return al(32 * np) + 6 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256;
 }
 // left / right: device u8 images [nb][h][w]; disp_out: device int16 [nb][h][w] (x16 fixed point, (minD-1)*16 = invalid)
 hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
@@ -518,10 +648,8 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     uint8_t* q = (uint8_t*)workspace;
-    uint8_t* planes = q; q += al(12 * np);
+    uint4* planes = (uint4*)q; q += al(32 * np);
     const size_t vol = (size_t)w1 * h * D * nb;
-    uint8_t* pix = q; q += al(vol);
-    uint16_t* hs = (uint16_t*)q; q += al(vol * 2);
     uint16_t* C = (uint16_t*)q; q += al(vol * 2);
     uint16_t* Lv[5];
     for (int i = 0; i < 5; i++) { Lv[i] = (uint16_t*)q; q += al(vol * 2); }
@@ -530,11 +658,21 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     unsigned* d2key = (unsigned*)q; q += al(np * 4);
     int* parent = (int*)q; q += al(np * 4);
     int* count = (int*)q; q += al(np * 4);
-    const dim3 gimg((w + 255) / 256, h, nb), gvol((w1 * D + 255) / 256, h, nb);
+    const dim3 gimg((w + 255) / 256, h, nb);
     sgbm_prefilter<<<dim3((w + 255) / 256, h, nb * 2), 256, 0, s>>>(left, right, w, h, ftzero, planes);
-    sgbm_pixcost<<<gvol, 256, 0, s>>>(planes, w, h, minD, D, minX1, w1, pix);
-    sgbm_hbox<<<gvol, 256, 0, s>>>(pix, w1, h, D, SW2, hs);
-    sgbm_vbox<<<gvol, 256, 0, s>>>(hs, w1, h, D, SW2, P2, C);
+    {
+        int TX = 0; size_t lds = 0;
+        if (!sgbm_cost_geometry(D, SW, &TX, &lds)) return hipErrorInvalidValue;
+        const int nstrips = (w1 + TX - 1) / TX;
+        const int tail = nstrips > 1 ? ((w1 - (nstrips - 1) * TX < SW2 && nstrips > 2) ? 2 : 1) : 0;     // a last strip narrower than the half window: the one before it reaches the border too
+        auto launch = [&](auto kern) {
+            static bool attr_set = false;       // the ring of a wide window needs more than the 64 KB default of dynamic LDS
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
+            kern<<<dim3(nstrips, nb), SGC_THREADS, lds, s>>>(planes, w, h, minD, D, minX1, w1, SW2, P2, TX, tail, C);
+        };
+        if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);       // src/stereo.cpp:16-27
+        else launch(sgbm_cost_kernel<0, 0, 0, 16>);
+    }
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
     switch (D / 16) {
@@ -551,8 +689,9 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     sgbm_median3<<<gimg, 256, 0, s>>>(d_raw, w, h, disp_out);
     if (p.speckleWindowSize > 0 && raw_only != 2) {
         const int n = (int)np1; const dim3 gb((n + 255) / 256, nb);
-        sgbm_speckle_init<<<gb, 256, 0, s>>>(n, parent, count);
-        sgbm_speckle_link<<<gb, 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
+        sgbm_speckle_tile<<<dim3((w + SPK_TW - 1) / SPK_TW, (h + SPK_TH - 1) / SPK_TH, nb), 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent, count);
+        const int nedge = ((w - 1) / SPK_TW) * h + ((h - 1) / SPK_TH) * w;
+        if (nedge > 0) sgbm_speckle_edges<<<dim3((nedge + 255) / 256, nb), 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
         sgbm_speckle_count<<<gb, 256, 0, s>>>(disp_out, n, INVALID, parent, count);
         sgbm_speckle_apply<<<gb, 256, 0, s>>>(disp_out, n, INVALID, p.speckleWindowSize, parent, count);
     }

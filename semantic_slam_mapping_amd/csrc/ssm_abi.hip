@@ -45,8 +45,8 @@ struct StereoState {        // workspace of the stereo path (quad matcher, SGBM 
     int w = 0, h = 0, maxc = 0, B = 0;
     QuadBatch qb{};                          // image slots: 2 sides x (B + 1) pyramids + Scharr derivatives
     uint8_t* pyr = nullptr; int16_t* der = nullptr;
-    float* eig = nullptr; uint8_t* state = nullptr; unsigned long long *keys = nullptr, *kept = nullptr; int keycap = 0;
-    int *maxord = nullptr, *count = nullptr, *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
+    GfttWork gw{};                           // goodFeaturesToTrack workspace (kernels_quad.hip)
+    int keycap = 0; int *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
     float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
     uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
     double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
@@ -1366,7 +1366,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 // ---------------------------------------------------------------- stereo path: QuadFeatureMatch, StereoSGBM depth, VisualOdometryStereo
 static void stereo_free(StereoState* q)
 {
-    void* p[] = { q->pyr, q->der, q->eig, q->state, q->keys, q->kept, q->maxord, q->count, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
+    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
                   q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
                   q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
@@ -1389,8 +1389,12 @@ static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
     b.pyr = q->pyr; b.der = q->der;
     const size_t np = (size_t)w * h;
     q->keycap = w * h / 4 + 1024;                            // 3x3 local maxima: at most one per 2x2 pixels
-    DALLOC(c, q->eig, (size_t)B * np); DALLOC(c, q->state, (size_t)B * np); DALLOC(c, q->keys, (size_t)B * q->keycap); DALLOC(c, q->kept, (size_t)B * q->keycap);
-    DALLOC(c, q->maxord, B); DALLOC(c, q->count, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
+    GfttWork& g = q->gw; g.cap = q->keycap;
+    DALLOC(c, g.eig, (size_t)B * np); DALLOC(c, g.cand_at, (size_t)B * np); DALLOC(c, g.keys, (size_t)B * q->keycap); DALLOC(c, g.kept, (size_t)B * q->keycap);
+    DALLOC(c, g.deps, (size_t)B * q->keycap * k_quad_gftt_deps_per_candidate()); DALLOC(c, g.depn, (size_t)B * q->keycap); DALLOC(c, g.state, (size_t)B * q->keycap);
+    HIPCHK(c, hipMemset(g.cand_at, 0, (size_t)B * np * 4));      // gftt_finish_kernel keeps the map zeroed between calls
+    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
+    g.overflow = q->overflow;
     HIPCHK(c, hipMemset(q->overflow, 0, 4));
     DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
     DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1); DALLOC(c, q->dmin, B);
@@ -1442,6 +1446,7 @@ static int sgbm_check_params(ssm_ctx* c, const ssm_sgbm_params* params, int w, i
     if (D <= 0 || D % 16 || D > 128 || D / 16 == 7) FAIL(c, SSM_E_INVAL, "numberOfDisparities must be 16, 32, 48, 64, 80, 96 or 128");
     if (!(SW & 1) || h <= SW || w <= SW) FAIL(c, SSM_E_INVAL, "SADWindowSize must be odd and smaller than the image");
     if ((long long)w * h >= (1ll << 30)) FAIL(c, SSM_E_INVAL, "image too large");
+    { int tx; size_t lds; if (!sgbm_cost_geometry(D, SW, &tx, &lds)) FAIL(c, SSM_E_INVAL, "SADWindowSize too large for this numberOfDisparities (the cost kernel keeps SADWindowSize rows of 4 columns x D sums in LDS)"); }
     return SSM_OK;
 }
 // the sequence path on device images; the caller holds the context lock
@@ -1481,7 +1486,7 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             HIPCHK(c, k_quad_pyramids(qb, nb, sq));
             HIPCHK(c, hipMemsetAsync(q->has_prev, 1, 4 * (size_t)nb, sq));                      // non-zero = true
             if (f0 == 0 && !prev0) HIPCHK(c, hipMemsetAsync(q->has_prev, 0, 4, sq));
-            HIPCHK(c, k_quad_gftt(qb, nb, maxc, 0.04, 8.0, q->eig, q->maxord, q->keys, q->kept, q->count, q->keycap, q->state, q->pts, maxc, q->ncorner, q->overflow, sq));      // quadmatcher.cpp:301-308
+            HIPCHK(c, k_quad_gftt(qb, nb, maxc, 0.04, 8.0, q->gw, q->pts, maxc, q->ncorner, sq));      // quadmatcher.cpp:301-308
             HIPCHK(c, k_quad_track(qb, nb, q->pts, maxc, q->ncorner, q->has_prev, q->quad + (size_t)f0 * maxc, q->nquad + f0, sq));
             HIPCHK(c, hipMemcpyAsync(q->corners + (size_t)f0 * maxc * 2, q->pts, (size_t)nb * maxc * 8, hipMemcpyDeviceToDevice, sq));
             HIPCHK(c, hipMemcpyAsync(q->ncorners + f0, q->ncorner, (size_t)nb * 4, hipMemcpyDeviceToDevice, sq));
@@ -1579,7 +1584,7 @@ extern "C" int ssm_gftt(ssm_ctx* c, const uint8_t* img, int w, int h, int stride
     int r = stereo_init(c, w, h, max_corners); if (r) return r;
     StereoState* q = c->stereo; const QuadBatch& qb = q->qb;
     HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)1 * qb.slot_elems, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));        // side 0, slot 1, level 0
-    HIPCHK(c, k_quad_gftt(qb, 1, max_corners, quality, min_distance, q->eig, q->maxord, q->keys, q->kept, q->count, q->keycap, q->state, q->pts, q->maxc, q->ncorner, q->overflow, c->stream));
+    HIPCHK(c, k_quad_gftt(qb, 1, max_corners, quality, min_distance, q->gw, q->pts, q->maxc, q->ncorner, c->stream));
     int n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, q->ncorner, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

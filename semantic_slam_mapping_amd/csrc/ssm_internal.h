@@ -118,6 +118,7 @@ hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, con
                          int CinPad, int Cout, int relu, hipStream_t s);
 // nb frames per launch: left / right [nb][h][w], disp_out [nb][h][w]
 size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb);
+bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out);      // false: SADWindowSize too wide for the streaming cost kernel
 hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s);
 hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, int nb, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
                         int* min_scratch /* nb ints */, uint16_t* depth, hipStream_t s);
@@ -143,8 +144,9 @@ hipError_t k_segnet_color(const uint8_t* ids, int n, int sw, int sh, int dw, int
 // Slot 0 = the carried previous frame, slot 1 + f = frame f of the sub-batch.
 struct QuadBatch { const uint8_t* pyr; const int16_t* der; size_t slot_elems; int B1; int w[4], h[4], off[4]; };
 hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s);
-hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, float* eig, int* maxord, unsigned long long* keys,
-                       unsigned long long* kept, int* count, int cap, uint8_t* state, float* pts, int stride, int* ncorner, int* overflow, hipStream_t s);
+struct GfttWork { float* eig; int* cand_at; unsigned long long *keys, *kept; uint32_t* deps; uint8_t *depn, *state; int *maxord, *count, *nkept, *overflow; int cap; };
+size_t k_quad_gftt_deps_per_candidate();
+hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s);
 hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s);
 hipError_t k_quad_track(const QuadBatch& q, int nb, float* pts, int stride, const int* ncorner, const int* has_prev, void* out, int* nout, hipStream_t s);
 hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,
