@@ -22,7 +22,13 @@
  *     and scales lambda by clamp(1 - (2 gain - 1)^3, 1/3, 2/3); otherwise the step is undone, lambda *= nu, nu *= 2; optimize(10) stops early when an
  *     iteration used up its 10 trials or ended with gain == 0;
  *   - LinearSolverDense: Eigen's LDLT; restated as an un-pivoted L D L^T (fails on a non-positive pivot).
- * The host class include/ssm/pnp.h implements the same algorithm; tests/test_pnp.py compares the two.
+ * NUMERIC CONTRACT shared with the product (include/ssm/pnp_core.h: host class, bulk tracker, device chain), chosen so that a CPU and a 1024-thread
+ * GPU block produce the same bits (g2o itself adds the edges one after the other and calls libm: rounding-level differences):
+ *   - every sum over the edges (chi2, H, b) is a LANE sum: edge i of the edge list goes to lane i mod 1024, a lane adds its edges in list order, the 64
+ *     lanes of a group are added as a neighbour-first binary tree, the 16 groups in group order (lane_reduce below);
+ *   - sin / cos = sso_sincos64 (the stereo VO's polynomial routine, vo.c); (2 gain - 1)^3 = t * t * t;
+ *   - only the lower triangle of H is formed (the L D L^T solve reads nothing else).
+ * The host class include/ssm/pnp.h implements the same algorithm; tests/test_pnp.py compares the two; tests/golden/pyref.py is a second restatement.
  */
 #include "ssm_oracle.h"
 #include <float.h>
@@ -58,7 +64,8 @@ static void pose_oplus(pose_t* P, const double d[6])
         for (int k = 0; k < 9; k++) dR[k] = (k % 4 == 0 ? 1.0 : 0.0) + W[k] + W2[k];
         memcpy(V, dR, sizeof(V));
     } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        double sn, cs; sso_sincos64(theta, &sn, &cs);
+        const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / (theta * theta * theta);
         for (int k = 0; k < 9; k++) { dR[k] = (k % 4 == 0 ? 1.0 : 0.0) + a * W[k] + b * W2[k]; V[k] = (k % 4 == 0 ? 1.0 : 0.0) + b * W[k] + c * W2[k]; }
     }
     double nR[9], nt[3];
@@ -86,24 +93,43 @@ static void huber(double e2, double delta, double rho[2])
     if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.0; }
     else { const double s = sqrt(e2); rho[0] = 2 * s * delta - dsqr; rho[1] = delta / s; }
 }
+/* the lane sum of the contract: v[lane][nval] -> out[nval]; lanes >= the number of edges hold 0 */
+#define PNP_LANES 1024
+#define PNP_GROUP 64
+static void lane_reduce(double* v, int nval, double* out)
+{
+    double grp[(PNP_LANES / PNP_GROUP) * 32];
+    for (int g = 0; g < PNP_LANES / PNP_GROUP; g++) {
+        double* base = v + (size_t)g * PNP_GROUP * nval;
+        for (int s = 1; s < PNP_GROUP; s <<= 1)
+            for (int l = 0; l < PNP_GROUP; l += 2 * s)
+                for (int q = 0; q < nval; q++) base[l * nval + q] = base[l * nval + q] + base[(l + s) * nval + q];
+        for (int q = 0; q < nval; q++) grp[g * nval + q] = base[q];
+    }
+    for (int q = 0; q < nval; q++) { double s = grp[q]; for (int g = 1; g < PNP_LANES / PNP_GROUP; g++) s = s + grp[g * nval + q]; out[q] = s; }
+}
 static double active_chi2(edge_t* E, int ne, const pose_t* P, const sso_camera* k, double delta)
 {
-    double chi = 0;
+    static double lane[PNP_LANES];
+    memset(lane, 0, sizeof(lane));
     for (int i = 0; i < ne; i++) {
         if (E[i].level != 0) continue;
         edge_error(&E[i], P, k);
         const double e2 = edge_chi2(&E[i]);
-        if (E[i].robust) { double rho[2]; huber(e2, delta, rho); chi += rho[0]; } else chi += e2;
+        if (E[i].robust) { double rho[2]; huber(e2, delta, rho); lane[i % PNP_LANES] += rho[0]; } else lane[i % PNP_LANES] += e2;
     }
+    double chi; lane_reduce(lane, 1, &chi);
     return chi;
 }
-/* H (6 x 6 row-major), b from the active edges at P (their err[] is current) */
+/* H (6 x 6 row-major, lower triangle filled) and b from the active edges at P (their err[] is current) */
 static void build_system(const edge_t* E, int ne, const pose_t* P, const sso_camera* k, double delta, double H[36], double b[6])
 {
-    memset(H, 0, 36 * sizeof(double)); memset(b, 0, 6 * sizeof(double));
+    static double lane[PNP_LANES * 27];
+    memset(lane, 0, sizeof(lane));
     for (int i = 0; i < ne; i++) {
         const edge_t* e = &E[i];
         if (e->level != 0) continue;
+        double* acc = lane + (size_t)(i % PNP_LANES) * 27;
         double p[3]; edge_map(e, P, p);
         const double x = p[0], y = p[1], iz = 1.0 / p[2], iz2 = iz * iz;
         const double J[2][6] = {
@@ -113,9 +139,14 @@ static void build_system(const edge_t* E, int ne, const pose_t* P, const sso_cam
         if (e->robust) { double rho[2]; huber(edge_chi2(e), delta, rho); w = rho[1]; }
         for (int r = 0; r < 2; r++) {
             const double wr = -e->err[r] * w;                       /* omega_r = -information * error, robustified */
-            for (int a = 0; a < 6; a++) { b[a] += J[r][a] * wr; for (int c = 0; c < 6; c++) H[6 * a + c] += J[r][a] * w * J[r][c]; }
+            int q = 0;
+            for (int a = 0; a < 6; a++) { acc[21 + a] += J[r][a] * wr; for (int c = 0; c <= a; c++) acc[q++] += J[r][a] * w * J[r][c]; }
         }
     }
+    double tot[27]; lane_reduce(lane, 27, tot);
+    memset(H, 0, 36 * sizeof(double));
+    { int q = 0; for (int a = 0; a < 6; a++) for (int c = 0; c <= a; c++) H[6 * a + c] = tot[q++]; }
+    for (int a = 0; a < 6; a++) b[a] = tot[21 + a];
 }
 static int solve_ldlt(const double Hin[36], double lambda, const double b[6], double x[6])
 {
@@ -166,7 +197,8 @@ static void lm_optimize(edge_t* E, int ne, pose_t* P, const sso_camera* k, doubl
             scale += 1e-3;
             gain /= scale;
             if (gain > 0 && isfinite(chi_new)) {
-                double alpha = 1. - pow((2 * gain - 1), 3);
+                const double t3 = 2 * gain - 1;
+                double alpha = 1. - t3 * t3 * t3;
                 alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
                 const double f = alpha > 1. / 3. ? alpha : 1. / 3.;
                 lambda *= f; nu = 2; chi = chi_new;

@@ -184,10 +184,40 @@ def g_sgbm():
     np.savez_compressed(os.path.join(HERE, "sgbm.npz"), **out)
 
 
+def g_pnp():
+    """PnPSolver::solvePnP vectors from pyref.pnp_solve: exact and noisy correspondences, gross outliers, depth-less rows (the reference's index mix-up),
+    more than 1024 edges (the lane order of the numeric contract wraps), too few points, a poor initial transform"""
+    def pose(rx, ry, rz, t):
+        cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+        R = np.array([[cy * cz, -cy * sz, sy], [sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy], [-cx * sy * cz + sx * sz, cx * sy * sz + sx * cz, cx * cy]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        return T
+    out = {}
+    cases = {"exact": (21, 120, 0, 0, 0.0, (0, 0, 0, (0, 0, 0))), "outliers": (22, 260, 9, 0, 0.2, (0.01, 0.0, -0.01, (0.01, 0.0, 0.02))),
+             "nodepth": (23, 90, 6, 4, 0.3, (0, 0, 0, (0, 0, 0))), "lanes": (24, 1300, 11, 7, 0.4, (0.005, -0.004, 0.003, (0.02, -0.01, 0.0))),
+             "few": (25, 7, 0, 3, 0.0, (0, 0, 0, (0, 0, 0))), "farinit": (26, 150, 8, 0, 0.1, (0.08, -0.05, 0.06, (0.3, -0.2, 0.25)))}
+    for name, (seed, n, oe, ze, noise, init) in cases.items():
+        rng = np.random.default_rng(seed)
+        X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.0, 6.0, n)], 1).astype(np.float32)
+        Tgt = pose(0.02, -0.03, 0.015, (0.05, -0.02, 0.08))
+        Pc = (Tgt[:3, :3] @ X.astype(np.float64).T).T + Tgt[:3, 3]
+        uv = np.stack([Pc[:, 0] / Pc[:, 2] * CAM[2] + CAM[0], Pc[:, 1] / Pc[:, 2] * CAM[3] + CAM[1]], 1)
+        if noise:
+            uv += rng.normal(0, noise, uv.shape)
+        if oe:
+            uv[::oe] += rng.uniform(25, 60, (len(uv[::oe]), 2))
+        if ze:
+            X[3::ze] = 0
+        img = uv.astype(np.float32); T0 = pose(*init)
+        ok, T, inl = pyref.pnp_solve(img, X, CAM, T0)
+        out[name + "_img"] = img; out[name + "_obj"] = X; out[name + "_T0"] = T0; out[name + "_T"] = T; out[name + "_inl"] = inl; out[name + "_ok"] = np.array([int(ok)], np.int32)
+    np.savez_compressed(os.path.join(HERE, "pnp.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                           # e.g. `make_golden.py sgbm`: only the named fixtures
         for n in sys.argv[1:]:
             globals()["g_" + n]()
     else:
-        g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad(); g_segnet(); g_sgbm()
+        g_palette(); g_matcher(); g_mapper(); g_orb(); g_quad(); g_segnet(); g_sgbm(); g_pnp()
     print("golden fixtures written to", HERE)

@@ -885,3 +885,222 @@ def sgbm(left, right, speckle_window=100, speckle_range=32, **kw):
     raw = sgbm_raw(left, right, **kw)
     d = median3_s16(raw)
     return filter_speckles(d, (kw.get("minD", 0) - 1) * 16, speckle_window, 16 * speckle_range) if speckle_window > 0 else d
+
+
+# ---------------------------------------------------------------- PnPSolver::solvePnP (/root/reference/src/pnp.cpp:5-118), second restatement
+# g2o's pose-only bundle adjustment as the reference sets it up (EdgeSE3ProjectXYZOnlyPose, Huber kernel with delta = float(sqrt(5.991)), Levenberg
+# with the dense 6 x 6 LDL^T solve, four rounds of optimize(10)) and pnp.cpp's inlier bookkeeping as written.  Written from the algorithm's published
+# description in plain Python floats (IEEE double, no fused operations); shares no code with oracle/pnp.c or include/ssm/pnp_core.h.  The numeric contract
+# of the product is followed where it defines the bits: sums over edges run over 1024 "lanes" (edge i -> lane i % 1024, in list order), a lane group of
+# 64 is added pairwise (neighbours first), the 16 groups in order; sin / cos = vo_sincos; the cube in Levenberg's lambda rule is t * t * t.
+def _pnp_tree(vals):
+    """vals: 1024 floats (one per lane) -> the contract's sum"""
+    groups = []
+    for g in range(16):
+        a = list(vals[64 * g:64 * g + 64])
+        while len(a) > 1:
+            a = [a[i] + a[i + 1] for i in range(0, len(a), 2)]
+        groups.append(a[0])
+    s = groups[0]
+    for g in groups[1:]:
+        s = s + g
+    return s
+
+
+class _PnpEdge:
+    __slots__ = ("id", "level", "robust", "X", "u", "v", "e")
+
+
+def _pnp_map(R, t, X):
+    return [R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r] for r in range(3)]
+
+
+def _pnp_error(e, R, t, cam):
+    cx, cy, fx, fy = cam[0], cam[1], cam[2], cam[3]
+    p = _pnp_map(R, t, e.X)
+    e.e = (e.u - (p[0] / p[2] * fx + cx), e.v - (p[1] / p[2] * fy + cy))
+
+
+def _pnp_huber(e2, delta):
+    d2 = delta * delta
+    if e2 <= d2:
+        return e2, 1.0
+    s = math.sqrt(e2)
+    return 2 * s * delta - d2, delta / s
+
+
+def _pnp_chi(edges, R, t, cam, delta):
+    lanes = [0.0] * 1024
+    for i, e in enumerate(edges):
+        if e.level != 0:
+            continue
+        _pnp_error(e, R, t, cam)
+        e2 = e.e[0] * e.e[0] + e.e[1] * e.e[1]
+        lanes[i % 1024] += _pnp_huber(e2, delta)[0] if e.robust else e2
+    return _pnp_tree(lanes)
+
+
+def _pnp_system(edges, R, t, cam, delta):
+    fx, fy = cam[2], cam[3]
+    lanes = [[0.0] * 27 for _ in range(1024)]
+    for i, e in enumerate(edges):
+        if e.level != 0:
+            continue
+        acc = lanes[i % 1024]
+        x, y, z = _pnp_map(R, t, e.X)
+        iz = 1.0 / z; iz2 = iz * iz
+        J = ((x * y * iz2 * fx, -(1 + (x * x * iz2)) * fx, y * iz * fx, -iz * fx, 0.0, x * iz2 * fx),
+             ((1 + y * y * iz2) * fy, -x * y * iz2 * fy, -x * iz * fy, 0.0, -iz * fy, y * iz2 * fy))
+        w = _pnp_huber(e.e[0] * e.e[0] + e.e[1] * e.e[1], delta)[1] if e.robust else 1.0
+        for r in range(2):
+            wr = -e.e[r] * w
+            q = 0
+            for a in range(6):
+                acc[21 + a] += J[r][a] * wr
+                for c in range(a + 1):
+                    acc[q] += J[r][a] * w * J[r][c]; q += 1
+    tot = [_pnp_tree([lanes[l][q] for l in range(1024)]) for q in range(27)]
+    H = [[0.0] * 6 for _ in range(6)]
+    q = 0
+    for a in range(6):
+        for c in range(a + 1):
+            H[a][c] = tot[q]; q += 1
+    return H, tot[21:]
+
+
+def _pnp_ldlt(H, lam, b):
+    A = [[H[i][j] + (lam if i == j else 0.0) for j in range(6)] for i in range(6)]
+    L = [[0.0] * 6 for _ in range(6)]; D = [0.0] * 6
+    for j in range(6):
+        d = A[j][j]
+        for k in range(j):
+            d -= L[j][k] * L[j][k] * D[k]
+        if not d > 0:
+            return None
+        D[j] = d; L[j][j] = 1.0
+        for i in range(j + 1, 6):
+            s = A[i][j]
+            for k in range(j):
+                s -= L[i][k] * L[j][k] * D[k]
+            L[i][j] = s / d
+    y = [0.0] * 6
+    for i in range(6):
+        s = b[i]
+        for k in range(i):
+            s -= L[i][k] * y[k]
+        y[i] = s
+    y = [y[i] / D[i] for i in range(6)]
+    x = [0.0] * 6
+    for i in range(5, -1, -1):
+        s = y[i]
+        for k in range(i + 1, 6):
+            s -= L[k][i] * x[k]
+        x[i] = s
+    return x
+
+
+def _pnp_mm(A, B):
+    return [A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c] for r in range(3) for c in range(3)]
+
+
+def _pnp_oplus(R, t, d):
+    th = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    W = [0.0, -d[2], d[1], d[2], 0.0, -d[0], -d[1], d[0], 0.0]
+    W2 = _pnp_mm(W, W)
+    I = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+    if th < 0.00001:
+        dR = [I[k] + W[k] + W2[k] for k in range(9)]; V = list(dR)
+    else:
+        sn, cs = vo_sincos(th)
+        a = sn / th; b = (1 - cs) / (th * th); c = (th - sn) / (th * th * th)
+        dR = [I[k] + a * W[k] + b * W2[k] for k in range(9)]; V = [I[k] + b * W[k] + c * W2[k] for k in range(9)]
+    nR = _pnp_mm(dR, R)
+    nt = []
+    for r in range(3):
+        vt = V[3 * r] * d[3] + V[3 * r + 1] * d[4] + V[3 * r + 2] * d[5]
+        nt.append(dR[3 * r] * t[0] + dR[3 * r + 1] * t[1] + dR[3 * r + 2] * t[2] + vt)
+    return nR, nt
+
+
+def _pnp_optimize(edges, R, t, cam, delta, iterations):
+    if not any(e.level == 0 for e in edges):
+        return R, t
+    lam, nu = 0.0, 2.0
+    for it in range(iterations):
+        chi = _pnp_chi(edges, R, t, cam, delta)
+        H, b = _pnp_system(edges, R, t, cam, delta)
+        if it == 0:
+            lam = 1e-5 * max(abs(H[j][j]) for j in range(6)); nu = 2.0
+        gain, trials = 0.0, 0
+        while True:
+            sR, st = R, t
+            x = _pnp_ldlt(H, lam, b)
+            ok = x is not None
+            if not ok:
+                x = [0.0] * 6
+            R, t = _pnp_oplus(R, t, x)
+            chi_new = _pnp_chi(edges, R, t, cam, delta)
+            if not ok:
+                chi_new = 1.7976931348623157e308
+            gain = chi - chi_new
+            scale = 0.0
+            for j in range(6):
+                scale += x[j] * (lam * x[j] + b[j])
+            scale += 1e-3
+            gain /= scale
+            if gain > 0 and math.isfinite(chi_new):
+                tt = 2 * gain - 1
+                alpha = 1.0 - tt * tt * tt
+                alpha = alpha if alpha < 2.0 / 3.0 else 2.0 / 3.0
+                lam *= alpha if alpha > 1.0 / 3.0 else 1.0 / 3.0
+                nu = 2.0; chi = chi_new
+            else:
+                lam *= nu; nu *= 2; R, t = sR, st
+                if not math.isfinite(lam):
+                    break
+            trials += 1
+            if not (gain < 0 and trials < 10):
+                break
+        if trials == 10 or gain == 0:
+            break
+    _pnp_chi(edges, R, t, cam, delta)
+    return R, t
+
+
+def pnp_solve(img, obj, cam, T, min_inliers=10):
+    """img n x 2 float32, obj n x 3 float32 (all-zero row = no depth), cam (cx, cy, fx, fy, ...), T 4 x 4 initial transform.
+    Returns (success, T 4 x 4, inlier indices)."""
+    n = len(img)
+    delta = float(np.float32(math.sqrt(5.991)))
+    inl = [True] * n
+    edges = []; good = 0
+    for i in range(n):
+        if float(obj[i][0]) == 0.0 and float(obj[i][1]) == 0.0 and float(obj[i][2]) == 0.0:
+            inl[i] = False
+            continue
+        good += 1
+        e = _PnpEdge(); e.id = i; e.level = 0; e.robust = True
+        e.X = [float(obj[i][0]), float(obj[i][1]), float(obj[i][2])]; e.u = float(img[i][0]); e.v = float(img[i][1]); e.e = (0.0, 0.0)
+        edges.append(e)
+    T = np.asarray(T, np.float64)
+    R0 = [float(T[r, c]) for r in range(3) for c in range(3)]; t0 = [float(T[r, 3]) for r in range(3)]
+    R, t = R0, t0
+    for it in range(4):
+        R, t = _pnp_optimize(edges, R0, t0, cam, delta, 10)
+        for i, e in enumerate(edges):
+            if inl[e.id]:
+                _pnp_error(e, R, t, cam)
+            if e.e[0] * e.e[0] + e.e[1] * e.e[1] > 5.991:
+                inl[e.id] = False; e.level = 1; good -= 1
+            else:
+                inl[i] = True; e.level = 0
+            if it == 2:
+                e.robust = False
+        if good < 5:
+            break
+    out = np.eye(4)
+    for r in range(3):
+        for c in range(3):
+            out[r, c] = R[3 * r + c]
+        out[r, 3] = t[r]
+    return n > min_inliers, out, np.array([i for i in range(n) if inl[i]], np.int32)

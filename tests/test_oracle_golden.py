@@ -286,3 +286,14 @@ def test_sgbm_live_restatement(oracle):
     raw = pyref.sgbm_raw(left, right, ndisp=32, SAD=9)
     assert np.array_equal(oracle.sgbm(left, right, p, raw=True), raw)
     assert np.array_equal(oracle.sgbm(left, right, p), pyref.filter_speckles(pyref.median3_s16(raw), -16, 100, 512))
+
+
+@pytest.mark.parametrize("name", ["exact", "outliers", "nodepth", "lanes", "few", "farinit"])
+def test_pnp_golden(oracle, name):
+    """oracle/pnp.c against the committed vectors of the independent Python restatement (tests/golden/pyref.py::pnp_solve): pose and inlier list, bit for bit"""
+    g = load("pnp.npz")
+    ok, T, inl = oracle.pnp_solve(g[name + "_img"], g[name + "_obj"], (318.6, 255.3, 517.3, 516.5, 1000.0), g[name + "_T0"], min_inliers=10)
+    assert int(ok) == int(g[name + "_ok"][0]) and inl.tolist() == g[name + "_inl"].tolist()
+    assert T.tobytes() == g[name + "_T"].tobytes()
+    if name in ("exact", "outliers", "lanes"):                      # the known answer: the pose the vectors were projected with
+        assert abs(T[0, 3] - 0.05) < 2e-3 and abs(T[2, 3] - 0.08) < 2e-3 and len(inl) > 0.8 * len(g[name + "_img"])

@@ -55,7 +55,7 @@ def test_host_pnp_equals_oracle(oracle, tmp_path, seed, n, outlier_every, zero_e
     ok_h, T_h, inl_h = _host(tmp_path, img, obj, T0)
     assert ok_o == ok_h == (n > 10)                                               # success = LENGTH of the flag vector > pnp_min_inliers (pnp.cpp:115)
     assert inl_o.tolist() == inl_h.tolist()
-    assert np.allclose(T_o, T_h, rtol=0, atol=1e-12)
+    assert T_o.tobytes() == T_h.tobytes()                                         # one numeric contract (include/ssm/pnp_core.h): the same bits
     if seed == 1:                                                                 # exact data, 10 % gross outliers: the known answer
         assert np.abs(T_o - Tgt).max() < 1e-4 and len(inl_o) == 180 and not (set(inl_o.tolist()) & set(range(0, 200, 10)))
 
@@ -77,3 +77,11 @@ def test_oracle_pnp_quirks(oracle):
     obj3[0] = 0; img3[30] += 80                                                   # outlier id 30 (position 29): cleared, then re-marked by the passing edge at position 30 (id 31)
     ok, T, inl = oracle.pnp_solve(img3, obj3, CAM, np.eye(4), min_inliers=10)
     assert 30 in inl.tolist() and len(inl) == 60                                  # the reference reports the outlier as an inlier
+
+
+@pytest.mark.parametrize("name", ["exact", "outliers", "nodepth", "lanes", "few", "farinit"])
+def test_host_pnp_equals_committed_vectors(tmp_path, name):
+    """rgbd_tutor::PnPSolver (include/ssm/pnp.h over pnp_core.h) against the vectors minted from the independent Python restatement"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pnp.npz"))
+    ok, T, inl = _host(tmp_path, g[name + "_img"], g[name + "_obj"], g[name + "_T0"])
+    assert int(ok) == int(g[name + "_ok"][0]) and inl.tolist() == g[name + "_inl"].tolist() and T.tobytes() == g[name + "_T"].tobytes()
