@@ -30,7 +30,7 @@ public:
     vector<cv::DMatch> match(const RGBDFrame::Ptr& frame1, const RGBDFrame::Ptr& frame2) const {
         vector<cv::DMatch> matches;
         cv::Mat d1 = frame1->getAllDescriptors(), d2 = frame2->getAllDescriptors();
-        if (d1.rows == 0) return matches;
+        if (d1.rows == 0 || d2.rows < 2) return matches;      // knnMatch(k = 2) on fewer than two train descriptors: the reference indexes [1] unguarded (src/orb.cpp:25, UB); no matches here
         ssm::Device& d = device(frame2->rgb.cols, frame2->rgb.rows);
         matches.resize(d1.rows);
         int n = 0;

@@ -158,7 +158,6 @@ SSM_HD void pose_to_iso(const Pose& P, double* T)
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[c * 4 + r] = P.R[3 * r + c]; T[12 + r] = P.t[r]; }
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 // ---- host side: the lane tree walked by one thread, and the whole solve
 // sum of `nval` quantities over the edges: term(i, out) writes edge i's contribution (or returns false: no contribution)
 template <int NVAL, class Term> inline void lane_sum(int ne, Term term, double* result)
@@ -250,5 +249,4 @@ inline int solve(const float* img, const float* obj, int n, const Camera& cam, i
     if (success) *success = n > min_inliers;
     return m;
 }
-#endif
 }  // namespace ssm_pnp

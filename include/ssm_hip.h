@@ -164,6 +164,36 @@ typedef struct {              /* DEVICE pointers owned by the context, valid unt
 } ssm_seq_out_dev;
 int ssm_seq_process(ssm_ctx* ctx, const ssm_frames_dev* in, ssm_seq_out_dev* out);
 
+/* ---- Tracker::updateFrame in bulk (src/track.cpp:8-36,140-212): the consumer of ssm_seq_process's match tables that closes the pose loop.
+ * ssm_seq_process computes features and match tables for whole sub-sequences ahead of the pose chain; ssm_tracker_run then walks the frames of that
+ * call in order and does, per frame, what Tracker::updateFrame does in RGB-D mode: initFirstFrame / trackRefFrame / lostRecover -- the refFrames deque
+ * (<= tracker_ref_frames successfully tracked frames), for every reference frame the matches (reference -> current), the 3-D points of the matched
+ * reference features moved to the world by the inverse reference pose (track.cpp:150-163), PnPSolver::solvePnP (src/pnp.cpp:5-118) from
+ * speed * lastPose, the < 15 correspondences / < 15 inliers tests, cntLost / max_lost_frame -> LOST -> lostRecover.  A reference frame that is one of
+ * the tracker_ref_frames frames in front of the current one uses the precomputed table slot; after a tracking failure the deque holds older frames,
+ * and those pairs are matched on demand (OrbFeature::match through the same matcher kernels), so the result is the per-frame Tracker's, bit for bit
+ * (one numeric contract: include/ssm/pnp_core.h).  The solved poses go back into a stages = SSM_STAGE_MAP pass of ssm_seq_process.
+ * The tracker object keeps the state between calls (speed, lastPose, cntLost, the deque with the features of its frames). */
+typedef struct ssm_tracker ssm_tracker;
+typedef struct {
+    int32_t max_lost_frame;   /* tracker_max_lost_frame (include/track.h:69; 10) */
+    int32_t ref_frames;       /* tracker_ref_frames (:70; 5) -- must equal the context's */
+    int32_t pnp_min_inliers;  /* pnp_min_inliers (include/pnp.h; 10): only PnPSolver's unused return value depends on it */
+    int32_t use_device;       /* 1: solve the pose chain of regular frames on the GPU (one block, kernels_pnp.hip); 0: on the host.  Same bits. */
+    double  first_pose[16];   /* T_f_w the first frame arrives with (initFirstFrame leaves it alone), column-major */
+} ssm_tracker_params;
+typedef struct { int32_t state; /* Tracker::getState() after the frame: 1 OK, 2 LOST */ int32_t tracked; /* 1: the frame joined refFrames */
+                 int32_t n_matches; /* correspondences handed to solvePnP (-1: none gathered) */ int32_t n_inliers; } ssm_track_info;
+void ssm_tracker_params_default(ssm_tracker_params* p);
+int  ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm_tracker** out);
+void ssm_tracker_destroy(ssm_tracker* t);
+int  ssm_tracker_reset(ssm_tracker* t);                       /* back to NOT_READY */
+/* seq: the output of the most recent ssm_seq_process on the tracker's context (stages ORB | MATCH at least), n its frame count.  The frames are taken
+ * as the continuation of the frames of the previous ssm_tracker_run.  pose_out: n x 16 doubles (HOST, column-major): RGBDFrame::T_f_w of every frame as
+ * updateFrame leaves it (a frame that fails to track keeps the prediction speed * refFrames.back()); info_out: n entries (HOST, may be NULL). */
+int  ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n, double* pose_out, ssm_track_info* info_out);
+const char* ssm_tracker_last_error(const ssm_tracker* t);
+
 /* ---- QuadFeatureMatch (include/quadmatcher.hpp:51-136, src/quadmatcher.cpp): the stereo quad matcher of the KITTI path
  * (Tracker::estimateVO, src/track.cpp:45-55).  Images are 8-bit gray, any size (buffers are re-sized on demand). */
 /* layout-identical to struct pmatch (include/quadmatcher.hpp:33-49), 52 bytes */

@@ -55,6 +55,10 @@ class StereoOutDev(C.Structure):
                [("max_corners", C.c_int)]
 
 
+class TrackerParams(C.Structure):
+    _fields_ = [("max_lost_frame", C.c_int32), ("ref_frames", C.c_int32), ("pnp_min_inliers", C.c_int32), ("use_device", C.c_int32), ("first_pose", C.c_double * 16)]
+
+
 # every symbol include/ssm_hip.h declares: name -> (restype, argtypes)
 _P, _I, _D, _F, _U64, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_uint64, C.c_size_t
 SYMBOLS = {
@@ -89,6 +93,12 @@ SYMBOLS = {
     "ssm_seq_process": (_I, [_P, C.POINTER(FramesDev), C.POINTER(SeqOutDev)]),
     "ssm_stereo_seq_process": (_I, [_P, C.POINTER(StereoFramesDev), C.POINTER(StereoOutDev)]),
     "ssm_stereo_batch": (_I, [_P]),
+    "ssm_tracker_params_default": (None, [C.POINTER(TrackerParams)]),
+    "ssm_tracker_create": (_I, [_P, C.POINTER(TrackerParams), C.POINTER(_P)]),
+    "ssm_tracker_destroy": (None, [_P]),
+    "ssm_tracker_reset": (_I, [_P]),
+    "ssm_tracker_run": (_I, [_P, C.POINTER(SeqOutDev), _I, _P, _P]),
+    "ssm_tracker_last_error": (C.c_char_p, [_P]),
     "ssm_quad_track": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),
     "ssm_lk_track": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _D, _D]),

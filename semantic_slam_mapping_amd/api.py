@@ -8,7 +8,7 @@ used in Mapper::viewer (src/mapper.cpp:154-155).
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._lib import Camera, Config, FramesDev, SeqOutDev, SgbmParams, VoParams, StereoFramesDev, StereoOutDev
+from ._lib import Camera, Config, FramesDev, SeqOutDev, SgbmParams, VoParams, StereoFramesDev, StereoOutDev, TrackerParams
 
 KEYPOINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
                            ("octave", "i4"), ("class_id", "i4")])
@@ -91,6 +91,49 @@ def default_config(**kw):
 
 def _ptr(a):
     return a.ctypes.data if a is not None else None
+
+
+TRACK_INFO_DTYPE = np.dtype([("state", "i4"), ("tracked", "i4"), ("n_matches", "i4"), ("n_inliers", "i4")])
+
+
+class Tracker:
+    """ssm_tracker: Tracker::updateFrame (RGB-D mode, src/track.cpp:8-36,140-212) for all frames of a seq_process call -- the bulk consumer of the
+    match tables.  run(out, n) -> (poses n x 4 x 4 = T_f_w per frame, info structured array)."""
+
+    def __init__(self, ctx, max_lost_frame=10, pnp_min_inliers=10, use_device=False, first_pose=None):
+        self.ctx = ctx; self.lib = ctx.lib
+        p = TrackerParams()
+        self.lib.ssm_tracker_params_default(C.byref(p))
+        p.max_lost_frame = max_lost_frame; p.ref_frames = ctx.R; p.pnp_min_inliers = pnp_min_inliers; p.use_device = int(use_device)
+        if first_pose is not None:
+            fp = np.ascontiguousarray(np.asarray(first_pose, np.float64).reshape(4, 4).T).reshape(16)       # column-major
+            for i in range(16):
+                p.first_pose[i] = float(fp[i])
+        h = C.c_void_p()
+        rc = self.lib.ssm_tracker_create(ctx.h, C.byref(p), C.byref(h))
+        if rc != 0:
+            raise SsmError(rc, "ssm_tracker_create")
+        self.h = h
+
+    def reset(self):
+        self.lib.ssm_tracker_reset(self.h)
+
+    def run(self, seq_out, n):
+        poses = np.zeros((max(n, 1), 16), np.float64); info = np.zeros(max(n, 1), TRACK_INFO_DTYPE)
+        rc = self.lib.ssm_tracker_run(self.h, C.byref(seq_out), n, _ptr(poses), _ptr(info))
+        if rc != 0:
+            raise SsmError(rc, (self.lib.ssm_tracker_last_error(self.h) or b"").decode())
+        return poses[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), info[:n]
+
+    def close(self):
+        if self.h:
+            self.lib.ssm_tracker_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

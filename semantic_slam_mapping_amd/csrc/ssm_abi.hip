@@ -429,6 +429,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->ev_join) hipEventDestroy(c->ev_join);
     delete c;
 }
+void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out) { *out = c->cfg; }
 extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
 extern "C" void* ssm_stream(ssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int ssm_sync(ssm_ctx* c)

@@ -151,3 +151,6 @@ hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* ne
 hipError_t k_quad_track(const QuadBatch& q, int nb, float* pts, int stride, const int* ncorner, const int* has_prev, void* out, int* nout, hipStream_t s);
 hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2, int sw, int sh, float thr,
                                ssm_dmatch* out, hipStream_t s);
+
+// for the translation units that only use the public ABI (ssm_track.hip): the configuration a context was created with
+void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out);

@@ -1,0 +1,155 @@
+// ssm_track.hip -- ssm_tracker_*: rgbd_tutor::Tracker::updateFrame (reference src/track.cpp:8-36, 140-212) for all frames of an ssm_seq_process call.
+// Host orchestration of the pose chain (the chain is serial by nature: frame f's initial value and its reference poses are frame f-1's results); the PnP
+// arithmetic is include/ssm/pnp_core.h, the code the per-frame host class (include/ssm/pnp.h) runs, so both give the same bits.  Written against the
+// public C ABI (ssm_match for the on-demand pairs, ssm_memcpy_d2h) -- no access to the context's internals.
+#include "ssm_internal.h"
+#include "../../include/ssm/pnp_core.h"
+#include <deque>
+#include <string>
+#include <vector>
+#include <cstring>
+
+namespace {
+struct RefFrame {                         // a member of Tracker::refFrames: what trackRefFrame reads of it
+    int64_t gidx = 0; int nkp = 0; double pose[16];
+    std::vector<float> pos3d; std::vector<uint8_t> desc;
+};
+}
+struct ssm_tracker {
+    ssm_ctx* ctx = nullptr; ssm_tracker_params prm{}; ssm_camera cam{}; double ratio = 0.8;
+    std::string err;
+    int state = 0, cnt_lost = 0;          // Tracker::trackerState: 0 NOT_READY, 1 OK, 2 LOST
+    double speed[16], last_pose[16];
+    std::deque<RefFrame> refs;
+    int64_t next_gidx = 0;
+    // host copies of one call's outputs
+    std::vector<int32_t> nkp, nmatch; std::vector<ssm_keypoint> kps; std::vector<float> pos3d; std::vector<uint8_t> desc; std::vector<ssm_dmatch> matches;
+    std::vector<float> img, obj; std::vector<unsigned char> inl; std::vector<ssm_pnp::Edge> edges; std::vector<ssm_dmatch> tmp_matches;
+};
+static void iso_identity(double* T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+
+extern "C" void ssm_tracker_params_default(ssm_tracker_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->max_lost_frame = 10; p->ref_frames = 5; p->pnp_min_inliers = 10; p->use_device = 0;
+    iso_identity(p->first_pose);
+}
+extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm_tracker** out)
+{
+    if (!ctx || !p || !out) return SSM_E_INVAL;
+    *out = nullptr;
+    if (p->ref_frames < 1 || p->ref_frames > 64 || p->max_lost_frame < 0) return SSM_E_INVAL;
+    ssm_tracker* t = new ssm_tracker();
+    t->ctx = ctx; t->prm = *p;
+    ssm_config cfg; ssm_internal_get_config(ctx, &cfg);
+    t->cam = cfg.camera; t->ratio = cfg.knn_match_ratio;
+    if (cfg.tracker_ref_frames != p->ref_frames) { delete t; return SSM_E_INVAL; }
+    ssm_tracker_reset(t);
+    *out = t;
+    return SSM_OK;
+}
+extern "C" void ssm_tracker_destroy(ssm_tracker* t) { delete t; }
+extern "C" const char* ssm_tracker_last_error(const ssm_tracker* t) { return t ? t->err.c_str() : "null tracker"; }
+extern "C" int ssm_tracker_reset(ssm_tracker* t)
+{
+    if (!t) return SSM_E_INVAL;
+    t->state = 0; t->cnt_lost = 0; t->refs.clear(); t->next_gidx = 0;
+    iso_identity(t->speed); iso_identity(t->last_pose);
+    return SSM_OK;
+}
+#define TFAIL(t, code, msg) do { (t)->err = (msg); return (code); } while (0)
+#define TCHK(t, expr) do { int r__ = (expr); if (r__ != SSM_OK) { (t)->err = std::string(#expr) + ": " + ssm_last_error((t)->ctx); return r__; } } while (0)
+
+extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n, double* pose_out, ssm_track_info* info_out)
+{
+    if (!t) return SSM_E_INVAL;
+    if (!seq || n < 0 || (n && !pose_out)) TFAIL(t, SSM_E_INVAL, "bad arguments");
+    if (n == 0) return SSM_OK;
+    const int cap = seq->cap, R = seq->R;
+    if (R != t->prm.ref_frames) TFAIL(t, SSM_E_INVAL, "the sequence was matched with another tracker_ref_frames");
+    // ---- the call's outputs on the host
+    t->nkp.resize(n); t->nmatch.resize((size_t)n * R); t->kps.resize((size_t)n * cap); t->pos3d.resize((size_t)n * cap * 3); t->desc.resize((size_t)n * cap * 32);
+    t->matches.resize((size_t)n * R * cap);
+    TCHK(t, ssm_sync(t->ctx));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->nkp.data(), seq->nkp, (size_t)n * 4));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->nmatch.data(), seq->nmatch, (size_t)n * R * 4));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->kps.data(), seq->kps, (size_t)n * cap * sizeof(ssm_keypoint)));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->pos3d.data(), seq->pos3d, (size_t)n * cap * 12));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->desc.data(), seq->desc, (size_t)n * cap * 32));
+    TCHK(t, ssm_memcpy_d2h(t->ctx, t->matches.data(), seq->matches, (size_t)n * R * cap * sizeof(ssm_dmatch)));
+    const size_t maxcorr = (size_t)R * cap;
+    t->img.resize(2 * maxcorr + 2); t->obj.resize(3 * maxcorr + 3); t->inl.resize(maxcorr + 1); t->edges.resize(maxcorr + 1); t->tmp_matches.resize(cap);
+    ssm_pnp::Camera cam; cam.fx = t->cam.fx; cam.fy = t->cam.fy; cam.cx = t->cam.cx; cam.cy = t->cam.cy;
+
+    auto push_ref = [&](int f, const double* pose) {        // refFrames.push_back(currentFrame); while (size > refFramesSize) pop_front()
+        RefFrame r; r.gidx = t->next_gidx + f; r.nkp = t->nkp[f]; memcpy(r.pose, pose, sizeof(r.pose));
+        r.pos3d.assign(t->pos3d.begin() + (size_t)f * cap * 3, t->pos3d.begin() + (size_t)f * cap * 3 + (size_t)r.nkp * 3);
+        r.desc.assign(t->desc.begin() + (size_t)f * cap * 32, t->desc.begin() + (size_t)f * cap * 32 + (size_t)r.nkp * 32);
+        t->refs.push_back(std::move(r));
+        while ((int)t->refs.size() > t->prm.ref_frames) t->refs.pop_front();
+    };
+    for (int f = 0; f < n; f++) {
+        double* T_frame = pose_out + (size_t)f * 16;
+        ssm_track_info info; info.state = 1; info.tracked = 0; info.n_matches = -1; info.n_inliers = 0;
+        const int64_t G = t->next_gidx + f;
+        if (t->state == 0) {                                 // initFirstFrame (track.cpp:30-36)
+            memcpy(T_frame, t->prm.first_pose, 128);                    // the frame keeps the T_f_w it arrived with; lastPose is not touched (nor by lostRecover)
+            push_ref(f, T_frame);
+            iso_identity(t->speed);
+            t->state = 1; info.tracked = 1;
+        } else if (t->state == 2) {                          // lostRecover (track.cpp:202-212)
+            memcpy(T_frame, t->refs.back().pose, 128);
+            t->refs.clear();
+            push_ref(f, T_frame);
+            t->state = 1; t->cnt_lost = 0; info.tracked = 1;
+        } else {                                             // trackRefFrame (track.cpp:140-200)
+            ssm_pnp::iso_mul(t->speed, t->refs.back().pose, T_frame);          // currentFrame->setTransform(speed * refFrames.back()->getTransform())
+            int nc = 0;
+            for (const RefFrame& ref : t->refs) {
+                // orb->match(pFrame, currentFrame): the precomputed table when pFrame is one of the R frames in front of the current one
+                const ssm_dmatch* m = nullptr; int nm = 0;
+                const int64_t back = G - ref.gidx;           // 1 .. R: slot R - back
+                if (back >= 1 && back <= R && t->nmatch[(size_t)f * R + (R - back)] >= 0) {
+                    nm = t->nmatch[(size_t)f * R + (R - back)]; m = t->matches.data() + ((size_t)f * R + (R - back)) * cap;
+                } else if (ref.nkp >= 1 && t->nkp[f] >= 2) {  // an older reference frame (the deque after tracking failures): match the pair now
+                    TCHK(t, ssm_match(t->ctx, ref.desc.data(), ref.nkp, t->desc.data() + (size_t)f * cap * 32, t->nkp[f], t->ratio, t->tmp_matches.data(), cap, &nm));
+                    m = t->tmp_matches.data();
+                }
+                double inv[16]; ssm_pnp::iso_inverse(ref.pose, inv);
+                for (int k = 0; k < nm; k++) {
+                    const float* p = ref.pos3d.data() + (size_t)m[k].queryIdx * 3;
+                    if (p[0] == 0.f && p[1] == 0.f && p[2] == 0.f) continue;
+                    double v[3]; ssm_pnp::iso_apply(inv, (double)p[0], (double)p[1], (double)p[2], v);
+                    t->obj[3 * nc] = (float)v[0]; t->obj[3 * nc + 1] = (float)v[1]; t->obj[3 * nc + 2] = (float)v[2];
+                    const ssm_keypoint& kp = t->kps[(size_t)f * cap + m[k].trainIdx];
+                    t->img[2 * nc] = kp.x; t->img[2 * nc + 1] = kp.y;
+                    nc++;
+                }
+            }
+            info.n_matches = nc;
+            bool ok = nc >= 15;
+            double T[16];
+            if (ok) {
+                ssm_pnp::iso_mul(t->speed, t->last_pose, T);                    // T = speed * lastPose
+                int success = 0;
+                info.n_inliers = ssm_pnp::solve(t->img.data(), t->obj.data(), nc, cam, t->prm.pnp_min_inliers, T, t->inl.data(), t->edges.data(), &success);
+                ok = info.n_inliers >= 15;
+            }
+            if (!ok) { t->cnt_lost++; if (t->cnt_lost > t->prm.max_lost_frame) t->state = 2; }
+            else {
+                memcpy(T_frame, T, 128);
+                t->cnt_lost = 0;
+                double linv[16]; ssm_pnp::iso_inverse(t->last_pose, linv);
+                ssm_pnp::iso_mul(T, linv, t->speed);                            // speed = T * lastPose.inverse()
+                memcpy(t->last_pose, T, 128);
+                push_ref(f, T);
+                info.tracked = 1;
+            }
+        }
+        info.state = t->state;
+        if (info_out) info_out[f] = info;
+    }
+    t->next_gidx += n;
+    return SSM_OK;
+}

@@ -4,6 +4,10 @@
 // (synthetic | raw | tum | kitti; the reference hard-codes its FrameReader type); with tum / kitti the poses come from the
 // tracker (use_stream_pose defaults to 0 there); prints frames/s at the end.
 //
+// `exp_mapping <parameters> --batched` (or tracker_batched=1): the same loop with the pose chain in bulk -- frames are queued in chunks of tracker_chunk,
+// BatchTracker runs ORB + the match tables for a whole chunk in batched launches and then the Tracker state machine + PnP over it (ssm_tracker_run:
+// the poses of the per-frame Tracker, bit for bit), after which the chunk's frames go through tryInsertKeyFrame like in the per-frame loop.
+//
 // `exp_mapping <parameters> --ranks N`: the multi-GPU form (BASELINE.json configs[4]; the reference is one process).  The parent starts
 // N FRESH processes of itself (`--rank r`, fork + exec of /proc/self/exe) before anything touches HIP -- a forked copy of a process whose HIP / RCCL
 // static constructors have already run is not a state either library is tested in; rank r drives GPU r, owns the contiguous frame block [lo, hi) of
@@ -18,6 +22,7 @@
 #include "ssm/common_headers.h"
 #include "ssm/mapper.h"
 #include "ssm/vo_stereo.hpp"
+#include "ssm/batch_tracker.h"
 #include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -32,10 +37,25 @@ static FrameReader::DATASET dataset_type(const ParameterReader& pr)
     return ds == "raw" ? FrameReader::RAW : ds == "tum" ? FrameReader::TUM : ds == "kitti" ? FrameReader::KITTI : FrameReader::SYNTHETIC;
 }
 
+// every frame's final T_f_w, in frame order: FNV-1a over the 128 bytes (printed as pose_fnv) and, with trajectory_output=<file>, one text line per frame
+// (id, then the 16 column-major doubles as C99 hex floats: exact)
+struct Trajectory {
+    uint64_t h = 0xCBF29CE484222325ull; ofstream out;
+    explicit Trajectory(const string& path) { if (!path.empty()) out.open(path); }
+    void add(const RGBDFrame::Ptr& f) {
+        const Eigen::Isometry3d T = f->getTransform();
+        const unsigned char* b = (const unsigned char*)T.data();
+        for (int k = 0; k < 128; k++) { h ^= b[k]; h *= 0x100000001B3ull; }
+        if (out.is_open()) { char buf[64]; out << f->id; for (int k = 0; k < 16; k++) { snprintf(buf, sizeof(buf), " %a", T.data()[k]); out << buf; } out << "\n"; }
+    }
+};
+
 int main(int argc, char** argv)
 {
     ParameterReader parameterReader(argc > 1 ? argv[1] : "./parameters.txt");
     int nranks = 1, my_rank = -1; string id_dir;
+    bool batched = parameterReader.getData<int>("tracker_batched", 0) != 0;
+    for (int i = 2; i < argc; i++) if (string(argv[i]) == "--batched") batched = true;
     for (int i = 2; i + 1 < argc; i++) {
         if (string(argv[i]) == "--ranks") nranks = atoi(argv[i + 1]);
         if (string(argv[i]) == "--rank") my_rank = atoi(argv[i + 1]);
@@ -103,11 +123,34 @@ int main(int argc, char** argv)
         Mapper mapper(parameterReader, poseGraph);
         const bool use_gt_pose = parameterReader.getData<int>("use_stream_pose", (type == FrameReader::TUM || type == FrameReader::KITTI) ? 0 : 1) != 0;
         int nframes = 0;
+        Trajectory traj(parameterReader.getData<string>("trajectory_output", string("")));
         auto t0 = chrono::steady_clock::now();
+        if (batched && parameterReader.getData<string>("tracker_mode", string("rgbd")) == "rgbd") {
+            unique_ptr<BatchTracker> bt; map<int, Eigen::Isometry3d> gt; int lost = 0;
+            auto handle = [&](const vector<RGBDFrame::Ptr>& done) {
+                for (size_t i = 0; i < done.size(); i++) {
+                    const RGBDFrame::Ptr& f = done[i];
+                    if (use_gt_pose) f->setTransform(gt[f->id]);
+                    gt.erase(f->id);
+                    traj.add(f);
+                    poseGraph.tryInsertKeyFrame(const_cast<RGBDFrame::Ptr&>(f));
+                    if (bt->infos[i].state == Tracker::LOST) { cout << "tracker is lost" << endl; lost++; }
+                    nframes++;
+                }
+            };
+            while (RGBDFrame::Ptr frame = frameReader.next()) {
+                if (!bt) bt.reset(new BatchTracker(parameterReader, frame->rgb.cols, frame->rgb.rows, frame->T_f_w));
+                gt[frame->id] = frame->T_f_w;
+                handle(bt->push(frame));
+            }
+            if (bt) handle(bt->flush());
+            cout << "batched tracker: chunk " << (bt ? bt->chunk() : 0) << " lost " << lost << endl;
+        } else
         while (RGBDFrame::Ptr frame = frameReader.next()) {
             Eigen::Isometry3d gt = frame->T_f_w;
             tracker->updateFrame(frame);
             if (use_gt_pose) frame->setTransform(gt);           // synthetic stream: poses are given, the tracker only produces features/matches
+            traj.add(frame);
             poseGraph.tryInsertKeyFrame(frame);
             if (tracker->getState() == Tracker::LOST) cout << "tracker is lost" << endl;
             nframes++;
@@ -118,7 +161,7 @@ int main(int argc, char** argv)
         this_thread::sleep_for(chrono::milliseconds(parameterReader.getData<int>("mapper_drain_ms", 300)));
         mapper.shutdown();
         cout << "frames " << nframes << " keyframes " << poseGraph.keyframes.size() << " map_updates " << mapper.updates()
-             << " map_points " << (mapper.getGlobalMap() ? mapper.getGlobalMap()->points.size() : 0) << " host_loop_fps " << nframes / s << endl;
+             << " map_points " << (mapper.getGlobalMap() ? mapper.getGlobalMap()->points.size() : 0) << " pose_fnv " << hex << traj.h << dec << " host_loop_fps " << nframes / s << endl;
     } catch (const exception& e) { cerr << RED << "exp_mapping: " << e.what() << RESET << endl; return 2; }
     return 0;
 }

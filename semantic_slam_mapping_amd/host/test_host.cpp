@@ -8,6 +8,7 @@
 #include "ssm/quadmatcher.hpp"
 #include "ssm/vo_stereo.hpp"
 #include "ssm/stereo.h"
+#include "ssm/batch_tracker.h"
 using namespace std;
 using namespace rgbd_tutor;
 static int fails = 0;
@@ -146,6 +147,35 @@ int main(int argc, char** argv)
         double dev = 0; for (int r = 0; r < 3; r++) for (int cc = 0; cc < 4; cc++) dev = max(dev, fabs(T1(r, cc) - (r == cc ? 1.0 : 0.0)));
         cout << "  static scene: state " << tracker.getState() << " dev " << dev << " matches " << tracker.lastMatches << " inliers " << tracker.lastInliers << " refs " << tracker.referenceFrames().size() << endl;
         CHECK("tracker_static_scene", tracker.getState() == Tracker::OK && dev < 5e-3 && tracker.lastInliers > 100 && tracker.referenceFrames().size() == 3);
+    }
+
+    // The bulk pose chain (ssm_seq_process + ssm_tracker_run behind BatchTracker) against the per-frame Tracker: 50 frames of the synthetic stream with
+    // three flat frames inside.  One flat frame fails to track (the deque then holds a frame older than the match-table window: matched on demand);
+    // two in a row exceed tracker_max_lost_frame = 1 -> LOST -> lostRecover on the next frame.  Every T_f_w must be the same bits.
+    {
+        ParameterReader pt = para; pt.set("tracker_max_lost_frame", "1"); pt.set("ssm_max_batch", "8");
+        const int NF = 50;
+        auto make = [&](int i) { RGBDFrame::Ptr f = reader.get(i); if (i == 12 || i == 30 || i == 31) { memset(f->rgb.data, 100, (size_t)f->rgb.rows * f->rgb.step); } return f; };
+        VisualOdometryStereo::parameters vo;
+        Tracker per(pt, vo);
+        vector<Eigen::Isometry3d> Tper; vector<int> st_per;
+        for (int i = 0; i < NF; i++) { RGBDFrame::Ptr f = make(i); per.updateFrame(f); Tper.push_back(f->getTransform()); st_per.push_back((int)per.getState()); }
+        RGBDFrame::Ptr f00 = make(0);
+        BatchTracker bulk(pt, f00->rgb.cols, f00->rgb.rows, f00->T_f_w, 17);      // chunks of 17: the chain crosses chunk borders (and sub-batches of 8 inside)
+        vector<RGBDFrame::Ptr> done; vector<ssm_track_info> infos;
+        for (int i = 0; i < NF; i++) { for (auto& f : bulk.push(make(i))) done.push_back(f); if (done.size() > infos.size()) infos.insert(infos.end(), bulk.infos.begin(), bulk.infos.end()); }
+        for (auto& f : bulk.flush()) done.push_back(f);
+        if (done.size() > infos.size()) infos.insert(infos.end(), bulk.infos.begin(), bulk.infos.end());
+        bool same = done.size() == (size_t)NF && infos.size() == (size_t)NF; int first_bad = -1, lost = 0, untracked = 0;
+        for (int i = 0; same && i < NF; i++) {
+            if (memcmp(done[i]->getTransform().data(), Tper[i].data(), 128) != 0 || infos[i].state != st_per[i]) { same = false; first_bad = i; }
+            lost += infos[i].state == 2; untracked += !infos[i].tracked;
+        }
+        double drift = 0; if (same) drift = fabs(Tper[NF - 1](0, 3));
+        cout << "  bulk tracker: first mismatch " << first_bad << " lost-frames " << lost << " untracked " << untracked << " |tx| of the last pose " << drift << endl;
+        // (the synthetic stream is not a rigid scene -- its depth pattern stays put while the texture pans -- so PnP also fails on its own now and then:
+        // more LOST / lostRecover events than the three flat frames force, all of them compared)
+        CHECK("bulk_tracker_equals_per_frame_tracker", same && lost >= 1 && untracked >= 3 && !infos[12].tracked && !infos[30].tracked && !infos[31].tracked);
     }
 
     // PoseGraph key-frame gate + Mapper viewer thread
