@@ -296,6 +296,10 @@ def main():
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
     ap.add_argument("--stereo-batch", type=int, default=int(os.environ.get("SSM_STEREO_BATCH", "32")), help="configs[3]: frame pairs per launch of the batched stereo path (0.45 GB of SGBM workspace each)")
+    ap.add_argument("--solve-poses", action="store_true", help="also time the closed pose loop: ORB + match tables -> ssm_tracker_run (Tracker::updateFrame for every frame: "
+                    "the serial PnP chain) -> the solved poses into the map stage; reported as `solve_poses` beside `value` (whose poses are the stream's)")
+    ap.add_argument("--pose-frames", type=int, default=200, help="frames of the --solve-poses leg")
+    ap.add_argument("--pnp-device", type=int, default=0, help="--solve-poses: 1 = the pose chain on the GPU (one block), 0 = on one host core; same bits")
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
@@ -475,6 +479,27 @@ def main():
             merge_info["equals_single_gpu_map"] = whole_ok
             if rank == 0:
                 merge_info["verified"] = bool(merge_info["verified"] and whole_ok)
+    # ---- the closed pose loop (reported beside `value`): poses from the pipeline instead of the stream's ground truth
+    solve_info = None
+    if args.solve_poses and world == 1 and not args.segnet:
+        PF = min(args.pose_frames, F)
+        trk = ssm.Tracker(ctx, use_device=bool(args.pnp_device))
+        t1 = time.perf_counter()
+        ctx.map_clear()
+        o2 = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None, None, PF, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
+        ctx.sync(); t2 = time.perf_counter()
+        poses_s, info_s = trk.run(o2, PF)
+        t3 = time.perf_counter()
+        pdev = torch.from_numpy(np.ascontiguousarray(poses_s.transpose(0, 2, 1)).reshape(PF * 16)).to(dev)
+        ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pdev.data_ptr(), PF, stages=ssm.api.STAGE_MAP)
+        nv = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
+        t4 = time.perf_counter()
+        trk.close()
+        solve_info = {"frames": PF, "frames_per_s": round(PF / (t4 - t1), 1), "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)",
+                      "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
+                      "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
+                      "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}
+        ctx.map_clear()
     frames_all = F
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -574,6 +599,8 @@ def main():
             "per_frame": {"keypoints": round(nkp, 1), "matches": round(match_total / F, 1), "points": round(P, 1), "voxels_in_map": int(n_vox)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if solve_info is not None:
+            line["solve_poses"] = solve_info
         if merge_info is not None:
             line["merge_verified"] = merge_info["verified"]
             line["merge"] = merge_info

@@ -461,8 +461,13 @@ hipError_t k_blur_mfma(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blu
 //     with S(n) >= S(p) > t is itself a corner at t), so ONE local-maximum flag serves both thresholds;
 //   * a 9-arc always contains two adjacent compass points, so pixels failing that test at minThFAST are dropped before
 //     scoring (about 3/4 of a textured image); survivors are compacted in LDS and scored densely;
-//   * the kernel emits every local maximum with S > minThFAST plus max S per cell; the consumer (quad-tree kernel)
-//     keeps a maximum iff S > (cellmax > iniThFAST ? iniThFAST : minThFAST)  ==  "retry the cell at minThFAST".
+//   * the consumer (quad-tree kernel) keeps a maximum iff S > (cellmax > iniThFAST ? iniThFAST : minThFAST)  ==  "retry the cell at minThFAST";
+//   * TWO PASSES (round 3).  In a cell that has a corner at iniThFAST only maxima with S > ini survive, and a neighbour with S <= ini can neither be
+//     one nor suppress one (suppression needs S(n) >= S(p) > ini), so such a cell only needs the positions that pass the quick test AT ini: pass 1
+//     quick-tests, scores and emits at iniThFAST everywhere (about a third of the positions the min threshold lets through) and leaves max S per cell;
+//     pass 2 -- a second launch, because a cell spans tiles -- looks at the cells its tile touches, returns at once unless one of them stayed empty
+//     (cellmax <= ini), and otherwise runs the same steps at minThFAST on the positions of the empty cells only (their same-cell neighbours are in
+//     the same empty cell).  What pass 2 adds to cellmax is <= ini, so the consumer's rule and the emptiness test of other pass-2 tiles are unaffected.
 // One block per 128x32 tile of one level of one frame (all levels in one launch), tile + 4-px apron staged in LDS by
 // dword loads.
 // inclusive scan of a u32 across a wave64 (DPP Hillis-Steele inside the 16-lane rows, then row broadcasts)
@@ -543,11 +548,11 @@ __device__ __forceinline__ uint32_t fast_S2(const uint8_t* pa, const uint8_t* pb
 #define FT_SH (FT_H + 2)
 #define FT_SST 132
 #define FT_STAGE ((FT_PH * FT_PW) / 8)   // candidates staged per tile: as many as fit in the pixel tile they replace (680)
-__global__ void __launch_bounds__(256)
-fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap, int nframes)
+template <int PASS>
+__device__ __forceinline__ void fast_tile(const int frame, const int tile_id, const uint8_t* __restrict__ pyr, const OrbGeom& g, cand_t* __restrict__ cand,
+                                          int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap)
 {
-    const int frame = blockIdx.x, tile_id = blockIdx.y;          // frame-fastest launch order: see blur_kernel
-    if (frame >= nframes) return;
+    __shared__ uint32_t emptyrow[8];                             // pass 2: bit j of word i = cell (cy0 + i, cx0 + j) had no corner at iniThFAST
     __shared__ __attribute__((aligned(16))) uint8_t px[FT_PH * FT_PW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[(FT_SH * FT_SST + 15) / 16 * 16];
     __shared__ uint16_t list[FT_SW * FT_SH];
@@ -567,6 +572,20 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* im = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
+    if (PASS == 2) {
+        // the cells this tile touches: cells of its first and last scored position in x and y (at most 8 x 8: build_geometry)
+        auto cell_of = [](int gpos, int origin, uint32_t mul) { const int v = gpos - origin - 3; return v >= 0 ? (int)__umulhi((uint32_t)v, mul) : 0; };
+        const int cx0 = cell_of(tx0, L.minBX, L.mulW), cy0 = cell_of(ty0, L.minBY, L.mulH);
+        const int cx1 = min(cell_of(min(tx0 + FT_W - 1, w - 1), L.minBX, L.mulW), L.nCols - 1), cy1 = min(cell_of(min(ty0 + FT_H - 1, h - 1), L.minBY, L.mulH), L.nRows - 1);
+        bool mine = false;
+        if (tid < 64) {
+            const int ci = cy0 + (tid >> 3), cj = cx0 + (tid & 7);
+            if (ci <= cy1 && cj <= cx1) mine = cellmax[(size_t)frame * g.cells_total + L.cell_off + ci * L.nCols + cj] <= g.ini_th;
+        }
+        const unsigned long long bal = __ballot(mine);           // wave 0 holds all 64 cells
+        if (tid < 8) emptyrow[tid] = (uint32_t)((bal >> (8 * tid)) & 0xFFull);
+        if (!__syncthreads_or(mine ? 1 : 0)) return;             // every cell of the tile has its corners from pass 1 (block-uniform)
+    }
     // ---- stage the tile: nine (unaligned) 16-byte loads per row, 360 per tile.  Rows / words outside the image are CLAMPED into it instead of
     // zero-filled: they then hold shifted pixels, which no valid position ever looks at (valid positions sit >= 19 px from every border, the ring and
     // the NMS neighbours reach 4), and no address leaves the level image
@@ -589,10 +608,14 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
     // the dwords 3 rows up/down), bytes widened to packed u16 pairs, then packed 16-bit min/max:
     //   bright = max over adjacent pairs of min(x - v, y - v),  dark = max over pairs of min(v - x, v - y) = -min over pairs of max
     // thread = (group of 4 columns g = tid & 31, row tid >> 5 + 8k): no division, conflict-free rows.
-    const int min_th = g.min_th;
+    const int min_th = PASS == 1 ? g.ini_th : g.min_th;         // the threshold of this pass
+    const int pcx0 = max((int)cellx[1], 0), pcy0 = max((int)celly[1], 0);
     {
         const uint32_t* pxw = reinterpret_cast<const uint32_t*>(px);
         const int gq = tid & 31, r0 = tid >> 5;
+        int cjs[4];                                                     // pass 2: the cell columns of this thread's four positions, relative to the tile's first cell
+#pragma unroll
+        for (int j = 0; j < 4; j++) cjs[j] = PASS == 2 ? ((int)cellx[4 * gq + 1 + j] - pcx0) & 7 : 0;
         const uint32_t t1 = (uint32_t)(min_th + 1) * 0x00010001u;
         const int gx0 = tx0 + 4 * gq;                                   // first of the 4 positions; sx = 4 gq + 1 + j
         unsigned xvalid = 0;                                            // positions inside the FAST window of the level, in x (the same for every row)
@@ -626,6 +649,13 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
             }
             // positions outside the FAST window of the level never pass
             passbits &= (gy >= SSM_EDGE && gy < h - SSM_EDGE) ? xvalid : 0u;
+            if (PASS == 2) {                                            // only the cells that stayed empty at iniThFAST are retried
+                const uint32_t er = emptyrow[((int)celly[sy] - pcy0) & 7];
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) m |= ((er >> cjs[j]) & 1u) << j;
+                passbits &= m;
+            }
             // compaction: wave scan of the per-thread counts, one LDS reservation per wave
             const uint32_t cntp = __popc(passbits);
             const uint32_t incl = wave_incl_scan_u32(cntp);
@@ -642,7 +672,8 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
         if (tid < 2 * FT_SH) {
             const int sy = tid >> 1, sx = (tid & 1) ? FT_W + 1 : 0;
             const int gx = tx0 + sx - 1, gy = ty0 + sy - 1;
-            if (gx >= SSM_EDGE && gx < w - SSM_EDGE && gy >= SSM_EDGE && gy < h - SSM_EDGE) {
+            if (gx >= SSM_EDGE && gx < w - SSM_EDGE && gy >= SSM_EDGE && gy < h - SSM_EDGE &&
+                (PASS == 1 || ((emptyrow[((int)celly[sy] - pcy0) & 7] >> (((int)cellx[sx] - pcx0) & 7)) & 1u))) {
                 const uint8_t* p = &px[(sy + 3) * FT_PW + sx + 3];
                 const int v = p[0];
                 const int a = p[3 * FT_PW] - v, b = p[3] - v, c = p[-3 * FT_PW] - v, d = p[-3] - v;
@@ -733,6 +764,57 @@ fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ can
         atomicMax(&cellmax[(size_t)frame * g.cells_total + L.cell_off + ci * L.nCols + cj], lmax[tid]);
     }
 }
+// pass 1: one block per (frame, tile)
+__global__ void __launch_bounds__(256)
+fast_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap, int nframes)
+{
+    const int frame = blockIdx.x, tile_id = blockIdx.y;          // frame-fastest launch order: see blur_kernel
+    if (frame >= nframes) return;
+    fast_tile<1>(frame, tile_id, pyr, g, cand, ncand, cellmax, stage_cap);
+}
+// which (frame, tile) pairs touch a cell that pass 1 left empty?  One thread per pair -> work list (tile << 16 | frame), count in work[-1].
+// A pair costs a thread here instead of a block in the retry launch: on a textured stream most tiles need no retry.
+__global__ void __launch_bounds__(256)
+fast_need_kernel(OrbGeom g, const int32_t* __restrict__ cellmax, int nframes, int32_t* __restrict__ work)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = i % ((nframes + 7) & ~7), tile_id = i / ((nframes + 7) & ~7);      // frame-fastest, like the tile launch
+    bool need = false;
+    if (frame < nframes && tile_id < g.tiles_total) {
+        int l = 0;
+        while (l + 1 < g.nlevels && tile_id >= g.L[l+1].tile_off) l++;
+        const LevelGeom& L = g.L[l];
+        const int t = tile_id - L.tile_off;
+        const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);
+        const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
+        auto cell_of = [](int gpos, int origin, uint32_t mul) { const int v = gpos - origin - 3; return v >= 0 ? (int)__umulhi((uint32_t)v, mul) : 0; };
+        const int cx0 = cell_of(tx0, L.minBX, L.mulW), cy0 = cell_of(ty0, L.minBY, L.mulH);
+        const int cx1 = min(cell_of(min(tx0 + FT_W - 1, L.w - 1), L.minBX, L.mulW), L.nCols - 1), cy1 = min(cell_of(min(ty0 + FT_H - 1, L.h - 1), L.minBY, L.mulH), L.nRows - 1);
+        const int32_t* cm = cellmax + (size_t)frame * g.cells_total + L.cell_off;
+        for (int ci = cy0; ci <= cy1 && !need; ci++) for (int cj = cx0; cj <= cx1; cj++) if (cm[ci * L.nCols + cj] <= g.ini_th) { need = true; break; }
+    }
+    const unsigned long long bal = __ballot(need);
+    if (bal) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(work - 1, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (need) work[base + __popcll(bal & ((1ull << lane) - 1ull))] = (tile_id << 16) | frame;
+    }
+}
+// pass 2: a fixed grid walks the work list
+__global__ void __launch_bounds__(256)
+fast_retry_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict__ cand, int32_t* __restrict__ ncand, int32_t* __restrict__ cellmax, int stage_cap,
+                  const int32_t* __restrict__ work)
+{
+    const int nwork = work[-1];
+    for (int i = blockIdx.x; i < nwork; i += gridDim.x) {
+        const int item = work[i];
+        fast_tile<2>(item & 65535, item >> 16, pyr, g, cand, ncand, cellmax, stage_cap);
+        __syncthreads();                                         // the next item re-initialises the tile's LDS state
+    }
+}
+size_t k_fast_cellmax_ints(int nframes, const OrbGeom& g) { return (size_t)nframes * (g.cells_total + g.tiles_total) + 16; }
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s);
@@ -741,7 +823,15 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
     if (e != hipSuccess) return e;
     // SSM_FAST_STAGE_CAP (tests): a smaller staging area forces the per-candidate global path that tiles with more than FT_STAGE maxima take
     static const int stage_cap = [] { const char* e = getenv("SSM_FAST_STAGE_CAP"); const int v = e ? atoi(e) : FT_STAGE; return v < 0 ? 0 : (v > FT_STAGE ? FT_STAGE : v); }();
-    fast_kernel<<<dim3((n + 7) & ~7, g.tiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
+    // the retry work list lives behind the n frames' cell maxima (the buffer is sized for it: k_fast_cellmax_ints)
+    int32_t* work = cellmax + (size_t)n * g.cells_total + 4;
+    e = hipMemsetAsync(work - 1, 0, 4, s);
+    if (e != hipSuccess) return e;
+    const int n8 = (n + 7) & ~7;
+    fast_kernel<<<dim3(n8, g.tiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
+    fast_need_kernel<<<(n8 * g.tiles_total + 255) / 256, 256, 0, s>>>(g, cellmax, n, work);
+    const int pairs = n * g.tiles_total;
+    fast_retry_kernel<<<pairs < 4096 ? pairs : 4096, 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, work);
     return hipGetLastError();
 }
 

@@ -348,7 +348,7 @@ static int ctx_init(ssm_ctx* c)
         }
     }
     // d_pyr + 16: resize4_kernel's 8-byte windows may end past the last row
-    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.blur_bytes); DALLOC(c, c->d_cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.blur_bytes); DALLOC(c, c->d_cellmax, k_fast_cellmax_ints(B, g));
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
     DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total * 2);          // KpAux + KpRec per slot
@@ -382,6 +382,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     int r = build_geometry(*cfg, c->g, c->err);
     if (!r && (cfg->voxel_capacity_log2 < 8 || cfg->voxel_capacity_log2 > 28)) { c->err = "voxel_capacity_log2 must be 8..28"; r = SSM_E_INVAL; }
     if (!r && !(cfg->mapper_resolution > 0)) { c->err = "mapper_resolution must be > 0"; r = SSM_E_INVAL; }
+    if (!r && c->B > 16384) { c->err = "max_batch must be <= 16384"; r = SSM_E_INVAL; }
     if (!r) r = ctx_init(c);
     if (r) { g_create_err = c->err; ssm_destroy(c); return r; }
     c->cfg.brief_pattern = nullptr;
@@ -484,7 +485,7 @@ static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
 {
     if (a.ready) return SSM_OK;
     const OrbGeom& g = c->g; const int B = c->B;
-    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.blur_bytes); DALLOC(c, a.cellmax, (size_t)B * g.cells_total);
+    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.blur_bytes); DALLOC(c, a.cellmax, k_fast_cellmax_ints(B, g));
     DALLOC(c, a.cand, (size_t)B * g.cand_total); DALLOC(c, a.nodeof, (size_t)B * g.cand_total);
     DALLOC(c, a.ncand, (size_t)B * g.nlevels); DALLOC(c, a.sel, (size_t)B * g.sel_total); DALLOC(c, a.nsel, (size_t)B * g.nlevels);
     DALLOC(c, a.mask, (size_t)B * g.W * g.H); DALLOC(c, a.kpaux, (size_t)B * g.sel_total * 2);
