@@ -612,18 +612,46 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
 // kept pixels as 14-bit entries (source lane, pixel in the lane, label) to an LDS list in wave-scan order; then lane i takes the
 // list entries [i P, (i + 1) P), P = ceil(kept / 64): every lane works on kept pixels only, still consecutive in scan order, so the register run
 // accumulation works as before.  Exact integer sums: the map is bit-identical.
+// Round 3: the moving-class bits are made HERE (class_bits_kernel + vdilate_bits_kernel and their bit images are gone from this path): the block first
+// classifies the semantic rows of its three chunks plus two rows above and below (the vertical reach of the 5 x 5 dilate) into an LDS bit image -- the same
+// cache lines its gate pass reads right after -- and the gate pass ORs five rows x three words of it instead of loading three pre-dilated words.
 #define MS2_MINB 4
+#define MS2_CB_WORDS (MS_CH * 256 + 6 * 256)      // 16-pixel words of (rows of the block + 4 halo rows + partial first / last row) for widths up to 4096
 template <bool FASTDIV>
 __global__ void __launch_bounds__(256, MS2_MINB)
 map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
-                   const uint16_t* __restrict__ vbits, const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
+                   const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
                    float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints, uint32_t mul_wpr)
 {
     __shared__ LdsVox lt[MS_SLOTS];
     __shared__ int s_npts;
     __shared__ uint16_t vlist[4][1024];                                 // per wave: kept pixels in scan order: lane << 4 | pixel | label << 10
+    __shared__ uint16_t cbits[MS2_CB_WORDS];                            // pedestrian | cyclist bit per pixel, rows ry0 .. of this frame, wpr words per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wpr = w >> 4, words = wpr * h;
+    // ---- the class bits of the block's rows + 2 above and below (rows outside the image: no moving pixel)
+    const int bw0 = blockIdx.x * MS_CH * 256;
+    const int ry0 = (int)__umulhi((uint32_t)bw0, mul_wpr) - 2;
+    {
+        const int ry1 = (int)__umulhi((uint32_t)(min(bw0 + MS_CH * 256, words) - 1), mul_wpr) + 2;
+        const int ncw = (ry1 - ry0 + 1) * wpr;
+        for (int i = tid; i < ncw; i += 256) {
+            const int rr = (int)__umulhi((uint32_t)i, mul_wpr), gy = ry0 + rr;
+            uint32_t bits = 0;
+            if (gy >= 0 && gy < h) {
+                const uint4* p = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + (size_t)((long long)ry0 * wpr + i)) * 48);
+                const uint4 a = p[0], b = p[1], c = p[2];
+                const uint32_t d[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int o = 3 * k;
+                    const uint32_t bgr = ((o & 3) ? __builtin_amdgcn_alignbyte(d[(o >> 2) + 1], d[o >> 2], o & 3) : d[o >> 2]) & 0xFFFFFFu;
+                    bits |= (uint32_t)(bgr == (0u | (64u << 8) | (64u << 16)) || bgr == (192u | (128u << 8) | (0u << 16))) << k;   // (0,64,64) | (192,128,0) BGR
+                }
+            }
+            cbits[i] = (uint16_t)bits;
+        }
+    }
     for (int i = tid; i < MS_SLOTS; i += 256) {
         lt[i].key = SSM_VOX_EMPTY; lt[i].sx = 0; lt[i].sy = 0; lt[i].sz = 0; lt[i].r = lt[i].g = lt[i].b = lt[i].n = 0;
 #pragma unroll
@@ -651,9 +679,12 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
         const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
         const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
         const uint4 D0 = pd[0], D1 = pd[1], S0 = ps[0], S1 = ps[1], S2 = ps[2];
-        const uint16_t* vb = vbits + (size_t)blockIdx.y * words + (size_t)gy * wpr;
-        const unsigned long long win = ((unsigned long long)(xw > 0 ? vb[xw - 1] : 0)) | ((unsigned long long)vb[xw] << 16) |
-                                       ((unsigned long long)(xw + 1 < wpr ? vb[xw + 1] : 0) << 32);
+        // vertical OR of rows gy - 2 .. gy + 2 for the word and its two neighbours, then the 5-wide horizontal OR
+        const uint16_t* cb = cbits + (gy - ry0 - 2) * wpr + xw;
+        uint32_t vl = 0, vc = 0, vr = 0;
+#pragma unroll
+        for (int r5 = 0; r5 < 5; r5++) { vc |= cb[r5 * wpr]; if (xw > 0) vl |= cb[r5 * wpr - 1]; if (xw + 1 < wpr) vr |= cb[r5 * wpr + 1]; }
+        const unsigned long long win = (unsigned long long)vl | ((unsigned long long)vc << 16) | ((unsigned long long)vr << 32);
         const uint32_t moving = (uint32_t)((win >> 14) | (win >> 15) | (win >> 16) | (win >> 17) | (win >> 18)) & 0xFFFFu;   // 5-wide OR
         const uint32_t dd[8] = {D0.x, D0.y, D0.z, D0.w, D1.x, D1.y, D1.z, D1.w};
         const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
@@ -792,8 +823,11 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
     hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s);
     if (e != hipSuccess) return e;
     const int wpr = w >> 4, words = wpr * h;
-    class_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(sem, words, bits_raw);
-    vdilate_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(bits_raw, wpr, h, bits_v);
+    const bool use2 = compact && (long long)words * wpr < (1ll << 32) && wpr <= 256;
+    if (!use2) {
+        class_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(sem, words, bits_raw);
+        vdilate_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(bits_raw, wpr, h, bits_v);
+    }
     // reciprocal form of the three divisions when the divisors allow it (see MapDiv); the check is cached per camera
     static std::mutex mu; static ssm_camera seen = {0, 0, 0, 0, 0}; static bool seen_ok = false;
     MapDiv md; md.rscale = 1.0 / cam.scale; md.rfx = 1.0 / cam.fx; md.rfy = 1.0 / cam.fy;
@@ -817,9 +851,9 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
     }
     const dim3 grid((words + 256 * MS_CH - 1) / (256 * MS_CH), n);
     const uint32_t mul_wpr = (uint32_t)(((1ull << 32) + wpr - 1) / wpr);           // floor(i / wpr) = umulhi(i, mul) for i < words (i * wpr < 2^32)
-    if (compact && (long long)words * wpr < (1ll << 32)) {
-        if (fast) map_stream2_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
-        else map_stream2_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
+    if (use2) {
+        if (fast) map_stream2_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
+        else map_stream2_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
     } else {
         if (fast) map_stream_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
         else map_stream_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
