@@ -9,6 +9,7 @@
 // mapper_fix_incremental=1.
 #pragma once
 #include "common_headers.h"
+#include <atomic>
 #include "device.h"
 #include "pose_graph.h"
 #include "rgbdframe.h"
@@ -30,7 +31,7 @@ public:
     void shutdown() { shutdownFlag = true; if (viewerThread != nullptr && viewerThread->joinable()) viewerThread->join(); }
     void SaveMap() {}                                                          // empty in the reference too (mapper.cpp:179-187)
     PointCloud::Ptr getGlobalMap() { unique_lock<mutex> lck(mapMutex); return globalMap; }
-    int updates() const { return cntGlobalUpdate; }
+    int updates() const { return cntGlobalUpdate.load(); }
 
     // viewer thread (src/mapper.cpp:96-171)
     void viewer() {
@@ -102,7 +103,7 @@ public:
         tmp->is_dense = false;
         return tmp;
     }
-    volatile bool viewerFailed = false;
+    std::atomic<bool> viewerFailed{false};
     int cloudsComputed = 0;                                                    // device back-projections so far (each frame costs one)
     PointCloud::Ptr voxelFilter(const PointCloud::Ptr& in) {                  // pcl::VoxelGrid::filter, mapper.cpp:154-155
         PointCloud::Ptr out(new PointCloud());
@@ -127,9 +128,9 @@ protected:
     PoseGraph& poseGraph;
     unique_ptr<ssm::Device> dev;
     PointCloud::Ptr globalMap; mutex mapMutex;
-    int keyframe_size = 0, cntGlobalUpdate = 0;
+    int keyframe_size = 0; std::atomic<int> cntGlobalUpdate{0};       // read by other threads (updates()): atomic -- the reference's plain int is a data race
     double resolution = 0.8, max_distance = 8.0;
-    volatile bool shutdownFlag = false;
+    std::atomic<bool> shutdownFlag{false};                           // set by shutdown() on another thread (ThreadSanitizer finding, profiles/r03_sanitizers.log)
     bool fix_incremental = false, invert_pose = false;
     int area_thres = 1000; double overlay_portion_thres = 0.143;
     string map_output;

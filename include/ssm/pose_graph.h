@@ -3,6 +3,7 @@
 // and loop closure are out of scope (SURVEY.md s.2 #11,#12); shutdown() only sets the flag Mapper::viewer reads.
 #pragma once
 #include "common_headers.h"
+#include <atomic>
 #include "track.h"
 namespace rgbd_tutor {
 class PoseGraph {
@@ -25,7 +26,7 @@ public:
     void shutdown() { shutDownFlag = true; }
     vector<RGBDFrame::Ptr> keyframes;
     mutex keyframes_mutex;
-    bool shutDownFlag = false;
+    std::atomic<bool> shutDownFlag{false};          // read by Mapper::viewer on its thread
 protected:
     const ParameterReader& parameterReader;
     shared_ptr<Tracker> tracker;

@@ -110,7 +110,7 @@ static void lane_reduce(double* v, int nval, double* out)
 }
 static double active_chi2(edge_t* E, int ne, const pose_t* P, const sso_camera* k, double delta)
 {
-    static double lane[PNP_LANES];
+    static _Thread_local double lane[PNP_LANES];
     memset(lane, 0, sizeof(lane));
     for (int i = 0; i < ne; i++) {
         if (E[i].level != 0) continue;
@@ -124,7 +124,7 @@ static double active_chi2(edge_t* E, int ne, const pose_t* P, const sso_camera* 
 /* H (6 x 6 row-major, lower triangle filled) and b from the active edges at P (their err[] is current) */
 static void build_system(const edge_t* E, int ne, const pose_t* P, const sso_camera* k, double delta, double H[36], double b[6])
 {
-    static double lane[PNP_LANES * 27];
+    static _Thread_local double lane[PNP_LANES * 27];
     memset(lane, 0, sizeof(lane));
     for (int i = 0; i < ne; i++) {
         const edge_t* e = &E[i];

@@ -51,7 +51,7 @@ void sso_synth_frame(uint64_t seed, int frame_id, int w, int h, uint8_t* bgr, ui
             for (int k = 0; k < 4; k++) {
                 uint64_t H = hash3(seed, 2 + (uint64_t)k, bx, by);
                 srect_t* r = &rects[(j * nbx + i) * 4 + k];
-                r->x0 = (bx << 5) + (int64_t)(H & 31); r->y0 = (by << 5) + (int64_t)((H >> 5) & 31);
+                r->x0 = bx * 32 + (int64_t)(H & 31); r->y0 = by * 32 + (int64_t)((H >> 5) & 31);      /* (not << 5: by is -1 in the first block row) */
                 r->rw = 4 + (int)((H >> 10) % 21); r->rh = 4 + (int)((H >> 20) % 21);
                 r->B = (int)((H >> 32) & 255); r->G = (int)((H >> 40) & 255); r->R = (int)((H >> 48) & 255);
             }

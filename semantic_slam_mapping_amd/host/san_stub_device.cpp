@@ -1,0 +1,35 @@
+// san_stub_device.cpp -- TEST INFRASTRUCTURE for the CPU sanitizer builds of the host layer (make SAN=asan|ubsan|tsan): a stand-in for the handful of
+// libssm_hip.so entry points that Mapper / PoseGraph reach, so that the THREADING of the host classes (Mapper::viewer on its own thread against the main
+// thread's tryInsertKeyFrame: the place of the reference's unlocked reads, /root/reference/src/mapper.cpp:114-136) can run under ThreadSanitizer in the
+// build container, which has no GPU and where sanitizer runtimes and the HIP runtime do not mix.  It computes nothing of the product: the numbers it
+// returns are placeholders.  It is linked into test_threads / test_pnp / test_png of a SAN build ONLY -- never into exp_mapping or the library.
+#include "ssm_hip.h"
+#include <cstring>
+#include <string>
+struct ssm_ctx { ssm_config cfg; std::string err; };
+extern "C" {
+void ssm_config_default(ssm_config* c) { memset(c, 0, sizeof(*c)); c->width = 640; c->height = 480; c->orb_features = 1000; c->orb_scale = 1.2f; c->orb_levels = 8;
+    c->orb_iniThFAST = 20; c->orb_minThFAST = 7; c->knn_match_ratio = 0.8; c->tracker_ref_frames = 5; c->mapper_resolution = 0.1; c->mapper_max_distance = 40;
+    c->camera.cx = 318.6; c->camera.cy = 255.3; c->camera.fx = 517.3; c->camera.fy = 516.5; c->camera.scale = 1000.0; c->max_batch = 1; c->voxel_capacity_log2 = 16; }
+int ssm_create(int, const ssm_config* cfg, ssm_ctx** out) { *out = new ssm_ctx(); (*out)->cfg = *cfg; return SSM_OK; }
+void ssm_destroy(ssm_ctx* c) { delete c; }
+const char* ssm_last_error(const ssm_ctx* c) { return c ? c->err.c_str() : "stub"; }
+int ssm_orb_capacity(const ssm_ctx*) { return 1024; }
+int ssm_backproject(ssm_ctx*, const uint16_t* depth, const uint8_t* rgb, const uint8_t*, int w, int h, const ssm_camera*, const double*, double, ssm_point* out, int cap, int* n_out)
+{
+    int n = 0;
+    for (int v = 0; v < h; v += 4) for (int u = 0; u < w; u += 4) {
+        const uint16_t d = depth[(size_t)v * w + u];
+        if (!d || n >= cap) continue;
+        ssm_point p; memset(&p, 0, sizeof(p)); p.x = u * 0.01f; p.y = v * 0.01f; p.z = d * 0.001f; p.w = 1.f; p.b = rgb[((size_t)v * w + u) * 3]; p.label = 255;
+        out[n++] = p;
+    }
+    *n_out = n; return SSM_OK;
+}
+int ssm_voxel_filter(ssm_ctx*, const ssm_point* pts, int n, float, ssm_point* out, int cap, int* n_out)
+{
+    int m = 0;
+    for (int i = 0; i < n && m < cap; i += 3) out[m++] = pts[i];
+    *n_out = m; return SSM_OK;
+}
+}

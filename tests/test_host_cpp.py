@@ -256,3 +256,16 @@ def test_exp_mapping_tum_end_to_end_on_gpu(tmp_path):
         assert mine <= vox and len(mine) > 0.3 * len(vox)
     finally:
         c.close()
+
+
+def test_sanitizer_builds_of_oracle_and_host_layer(tmp_path):
+    """CPU sanitizers (SURVEY.md s.5): the oracle's driver under ASan + UBSan, and the host layer's thread test (PoseGraph + Mapper::viewer + a polling
+    thread, device calls into host/san_stub_device.cpp) under ThreadSanitizer.  scripts/run_sanitizers.sh runs the full matrix and writes
+    profiles/r03_sanitizers.log; this keeps the two most telling legs in the CPU suite."""
+    ORACLE = os.path.join(ROOT, "oracle")
+    for san in ("asan", "ubsan"):
+        r = subprocess.run(["make", "-s", "-C", ORACLE, f"SAN={san}", "san"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "san_check OK" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout[-800:] + r.stderr[-2000:]
+    subprocess.run(["make", "-s", "-C", HOST, "SAN=tsan", "test_threads_tsan"], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([os.path.join(HOST, "test_threads_tsan"), os.path.join(HOST, "parameters_test.txt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
