@@ -193,6 +193,9 @@ int  ssm_tracker_reset(ssm_tracker* t);                       /* back to NOT_REA
  * updateFrame leaves it (a frame that fails to track keeps the prediction speed * refFrames.back()); info_out: n entries (HOST, may be NULL). */
 int  ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n, double* pose_out, ssm_track_info* info_out);
 const char* ssm_tracker_last_error(const ssm_tracker* t);
+/* frames solved by the device chain / by the host path so far (use_device = 1: the host path takes the first frame, lostRecover, and the frames whose
+ * refFrames deque reaches behind the match-table window after a tracking failure) */
+int  ssm_tracker_stats(const ssm_tracker* t, int64_t* device_frames, int64_t* host_frames);
 
 /* ---- QuadFeatureMatch (include/quadmatcher.hpp:51-136, src/quadmatcher.cpp): the stereo quad matcher of the KITTI path
  * (Tracker::estimateVO, src/track.cpp:45-55).  Images are 8-bit gray, any size (buffers are re-sized on demand). */

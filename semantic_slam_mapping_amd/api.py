@@ -125,6 +125,12 @@ class Tracker:
             raise SsmError(rc, (self.lib.ssm_tracker_last_error(self.h) or b"").decode())
         return poses[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), info[:n]
 
+    def stats(self):
+        """(frames solved by the device chain, frames solved by the host path)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.lib.ssm_tracker_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def close(self):
         if self.h:
             self.lib.ssm_tracker_destroy(self.h); self.h = None

@@ -1,0 +1,240 @@
+// kernels_pnp.hip -- the RGB-D pose chain on the device: Tracker::trackRefFrame (reference src/track.cpp:140-200) + PnPSolver::solvePnP (src/pnp.cpp:5-118)
+// for a run of consecutive frames of an ssm_seq_process call, ONE block of 1024 threads walking the frames in order.
+// The chain is serial by construction (frame f starts from frame f-1's pose and un-projects its reference frames' features with their solved poses);
+// what parallelism there is lives inside a frame: the correspondences of the <= tracker_ref_frames match tables (ordered compaction by block scans), and
+// every pass over the edges of the Levenberg iterations (chi2 pass, normal-equation pass) -- thread i owns edges i, i + 1024, ... and the sums follow the
+// LANE ORDER of include/ssm/pnp_core.h (wave butterfly, then the 16 wave totals in order), which is what makes the result the same bits as the host
+// class and the oracle.  The small dense algebra (6 x 6 L D L^T, exp map, Levenberg bookkeeping) is executed redundantly by every thread from the same
+// totals: no broadcast, no extra barrier.  All matches / features stay on the device; the host orchestrator (ssm_track.hip) only moves the tracker state.
+// The kernel handles the REGULAR case -- state OK and the refFrames deque = the frames directly in front of the current one, all inside the match-table
+// window -- and stops behind the first frame that fails to track; the host path (same arithmetic) takes over until the deque is regular again.
+#include "pnp_chain.h"
+#include <cfloat>
+
+using namespace ssm_pnp;
+#define PC_T 1024
+
+struct PcShared {
+    double red[NGROUP][NACC + 1];
+    double Tinv[16];
+    int wcnt[NGROUP];
+    int flag;
+};
+// exclusive position of `flag` among the block's threads in thread order, and the block total
+__device__ __forceinline__ int pc_scan(bool flag, PcShared& sh, int& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0) sh.wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NGROUP; k++) { const int c = sh.wcnt[k]; if (k < wv) off += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + __popcll(bal & ((1ull << lane) - 1ull));
+}
+// lane sums of pnp_core.h: this thread's partial sums acc[NV] -> the totals, identical in every thread
+template <int NV>
+__device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int s = 1; s < GROUP; s <<= 1)
+#pragma unroll
+        for (int v = 0; v < NV; v++) acc[v] = acc[v] + __shfl_xor(acc[v], s, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) sh.red[wv][v] = acc[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; v++) { double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; acc[v] = s; }
+    __syncthreads();
+}
+__device__ __forceinline__ double pc_chi(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+{
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) acc[0] += edge_rho(E[i], P, k, delta);
+    pc_lane_sum<1>(acc, sh);
+    return acc[0];
+}
+__device__ __forceinline__ void pc_build(const Edge* E, int ne, const Pose& P, const Camera& k, double delta, double* Hl, double* b, PcShared& sh)
+{
+    double acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) edge_accumulate(E[i], P, k, delta, acc);
+    pc_lane_sum<NACC>(acc, sh);
+    for (int q = 0; q < 21; q++) Hl[q] = acc[q];
+    for (int q = 0; q < 6; q++) b[q] = acc[21 + q];
+}
+// lm_optimize of pnp_core.h, every thread in lock step
+__device__ __forceinline__ void pc_optimize(Edge* E, int ne, Pose& P, const Camera& k, double delta, int iterations, PcShared& sh)
+{
+    int any = 0;
+    for (int i = threadIdx.x; i < ne; i += PC_T) any |= E[i].level == 0;
+    if (!__syncthreads_or(any)) return;
+    LmState st; st.lambda = 0; st.nu = 2;
+    for (int it = 0; it < iterations; it++) {
+        double chi = pc_chi(E, ne, P, k, delta, sh), Hl[21], b[6];
+        pc_build(E, ne, P, k, delta, Hl, b, sh);
+        if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) { const double dg = fabs(Hl[j * (j + 1) / 2 + j]); if (dg > mx) mx = dg; } st.lambda = 1e-5 * mx; st.nu = 2; }
+        double gain = 0; int trials = 0;
+        do {
+            const Pose saved = P;
+            double x[6] = {0, 0, 0, 0, 0, 0};
+            const bool ok = solve_ldlt(Hl, st.lambda, b, x);
+            pose_oplus(P, x);
+            const double chi_new = pc_chi(E, ne, P, k, delta, sh);
+            if (lm_update(st, chi, chi_new, ok, x, b, gain)) chi = chi_new;
+            else { P = saved; if (!isfinite(st.lambda)) break; }
+            trials++;
+        } while (gain < 0 && trials < 10);
+        if (trials == 10 || gain == 0) break;
+    }
+    pc_chi(E, ne, P, k, delta, sh);
+}
+// ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (identical in every thread); returns the number of set flags
+__device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, Edge* E, uint8_t* dec, PcShared& sh)
+{
+    const double delta = (double)(float)sqrt(5.991);
+    // edge list: the correspondences with depth, in order
+    int ne = 0;
+    for (int i0 = 0; i0 < n; i0 += PC_T) {
+        const int i = i0 + threadIdx.x;
+        const bool has = i < n && !(obj[3 * i] == 0.f && obj[3 * i + 1] == 0.f && obj[3 * i + 2] == 0.f);
+        int tot; const int pos = ne + pc_scan(has, sh, tot);
+        if (i < n) inl[i] = has ? 1 : 0;
+        if (has) { Edge e; e.id = i; e.level = 0; e.robust = 1; e.pad = 0; e.X[0] = obj[3 * i]; e.X[1] = obj[3 * i + 1]; e.X[2] = obj[3 * i + 2]; e.u = img[2 * i]; e.v = img[2 * i + 1]; e.e0 = e.e1 = 0; E[pos] = e; }
+        ne += tot;
+    }
+    __syncthreads();
+    int good = ne;
+    Pose init, P; pose_from_iso(T, init); P = init;
+    for (int it = 0; it < 4; it++) {
+        P = init;
+        pc_optimize(E, ne, P, cam, delta, 10, sh);
+        // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
+        // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
+        // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
+        int nout = 0;
+        for (int i = threadIdx.x; i < ne; i += PC_T) {
+            Edge e = E[i];
+            if (inl[e.id]) edge_error(e, P, cam);
+            const bool out = edge_chi2(e) > 5.991;
+            e.level = out ? 1 : 0;
+            if (it == 2) e.robust = 0;
+            E[i] = e; dec[i] = out ? 1 : 0; nout += out;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[E[i].id] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ne; i += PC_T) if (!dec[i]) inl[i] = 1;
+        __syncthreads();
+        // good -= the number of failing edges (block sum of nout)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nout += __shfl_xor(nout, o, 64);
+        if ((threadIdx.x & 63) == 0) sh.wcnt[threadIdx.x >> 6] = nout;
+        __syncthreads();
+        int allout = 0; for (int k = 0; k < NGROUP; k++) allout += sh.wcnt[k];
+        __syncthreads();
+        good -= allout;
+        if (good < 5) break;
+    }
+    pose_to_iso(P, T);
+    int m = 0;
+    for (int i = threadIdx.x; i < n; i += PC_T) m += inl[i] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0) sh.wcnt[threadIdx.x >> 6] = m;
+    __syncthreads();
+    int mm = 0; for (int k = 0; k < NGROUP; k++) mm += sh.wcnt[k];
+    __syncthreads();
+    return mm;
+}
+
+__global__ void __launch_bounds__(PC_T)
+pnp_chain_kernel(PnpChainArgs a)
+{
+    __shared__ PcShared sh;
+    const int tid = threadIdx.x;
+    // the tracker state, identical in every thread's registers
+    double speed[16], last[16];
+    for (int k = 0; k < 16; k++) { speed[k] = a.state->speed[k]; last[k] = a.state->last_pose[k]; }
+    int nref = a.state->nref, cnt_lost = a.state->cnt_lost;
+    // the deque lives in global memory (a.state->ref_idx / ref_pose); every thread tracks nref
+    int f = a.f_begin;
+    int stopped = a.f_end;
+    for (; f < a.f_end; f++) {
+        ssm_track_info info; info.state = 1; info.tracked = 0; info.n_matches = -1; info.n_inliers = 0;
+        double Tpred[16];
+        iso_mul(speed, a.state->ref_pose[nref - 1], Tpred);                     // currentFrame->setTransform(speed * refFrames.back()->getTransform())
+        // ---- the correspondences of every reference frame, in deque order then match order (track.cpp:150-163)
+        int nc = 0;
+        for (int r = 0; r < nref; r++) {
+            const int ridx = a.state->ref_idx[r];                              // local frame index of the reference (negative: a frame of the previous call)
+            const int slot = a.R - (f - ridx);
+            const int nm = max(a.nmatch[(size_t)f * a.R + slot], 0);
+            const ssm_dmatch* m = a.matches + ((size_t)f * a.R + slot) * a.cap;
+            const float* rpos = ridx >= 0 ? a.pos3d + (size_t)ridx * a.cap * 3 : a.hist_pos3d + (size_t)(ridx + a.R) * a.cap * 3;
+            double inv[16]; iso_inverse(a.state->ref_pose[r], inv);
+            for (int k0 = 0; k0 < nm; k0 += PC_T) {
+                const int k = k0 + tid;
+                bool keep = false; float p0 = 0, p1 = 0, p2 = 0; int ti = 0;
+                if (k < nm) { const ssm_dmatch d = m[k]; const float* p = rpos + (size_t)d.queryIdx * 3; p0 = p[0]; p1 = p[1]; p2 = p[2]; ti = d.trainIdx; keep = !(p0 == 0.f && p1 == 0.f && p2 == 0.f); }
+                int tot; const int pos = nc + pc_scan(keep, sh, tot);
+                if (keep) {
+                    double v[3]; iso_apply(inv, (double)p0, (double)p1, (double)p2, v);
+                    a.obj[3 * pos] = (float)v[0]; a.obj[3 * pos + 1] = (float)v[1]; a.obj[3 * pos + 2] = (float)v[2];
+                    const ssm_keypoint kp = a.kps[(size_t)f * a.cap + ti];
+                    a.img[2 * pos] = kp.x; a.img[2 * pos + 1] = kp.y;
+                }
+                nc += tot;
+            }
+        }
+        __syncthreads();
+        info.n_matches = nc;
+        bool ok = nc >= 15;
+        double T[16];
+        if (ok) {
+            iso_mul(speed, last, T);                                            // T = speed * lastPose
+            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, T, a.inl, a.edges, a.dec, sh);
+            ok = info.n_inliers >= 15;
+        }
+        if (!ok) {
+            cnt_lost++;
+            if (cnt_lost > a.max_lost) info.state = 2;
+            if (tid == 0) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = Tpred[k]; a.info_out[f] = info; }
+            stopped = f + 1;                                                    // the deque now trails behind the match-table window: the host path goes on
+            break;
+        }
+        cnt_lost = 0;
+        double linv[16]; iso_inverse(last, linv);
+        iso_mul(T, linv, speed);                                                // speed = T * lastPose.inverse()
+        for (int k = 0; k < 16; k++) last[k] = T[k];
+        info.tracked = 1;
+        __syncthreads();                                                        // every thread has read the deque of this frame
+        if (tid == 0) {
+            for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = T[k];
+            a.info_out[f] = info;
+            // refFrames.push_back(currentFrame); pop_front beyond tracker_ref_frames
+            if (nref == a.R) { for (int r = 1; r < nref; r++) { a.state->ref_idx[r - 1] = a.state->ref_idx[r]; for (int k = 0; k < 16; k++) a.state->ref_pose[r - 1][k] = a.state->ref_pose[r][k]; } }
+            const int slot = nref == a.R ? nref - 1 : nref;
+            a.state->ref_idx[slot] = f;
+            for (int k = 0; k < 16; k++) a.state->ref_pose[slot][k] = T[k];
+        }
+        if (nref < a.R) nref++;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int k = 0; k < 16; k++) { a.state->speed[k] = speed[k]; a.state->last_pose[k] = last[k]; }
+        a.state->nref = nref; a.state->cnt_lost = cnt_lost; a.state->stopped_at = stopped;
+    }
+}
+hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s)
+{
+    pnp_chain_kernel<<<1, PC_T, 0, s>>>(a);
+    return hipGetLastError();
+}

@@ -1,0 +1,21 @@
+// pnp_chain.h -- interface between the tracker's host orchestration (ssm_track.hip) and the device pose chain (kernels_pnp.hip).  Not installed.
+#pragma once
+#include "ssm_internal.h"
+#include "../../include/ssm/pnp_core.h"
+#define SSM_TRACK_MAXREF 64
+// the Tracker's state while the chain runs on the device (device memory; the host uploads it before a run and reads it back after)
+struct PnpState {
+    double speed[16], last_pose[16];                 // column-major 4 x 4
+    double ref_pose[SSM_TRACK_MAXREF][16];           // refFrames deque, oldest first
+    int32_t ref_idx[SSM_TRACK_MAXREF];               // their frame indices relative to the current ssm_seq_process call (negative: frames of the previous call)
+    int32_t nref, cnt_lost, stopped_at, pad;
+};
+struct PnpChainArgs {
+    const ssm_keypoint* kps; const float* pos3d; const ssm_dmatch* matches; const int32_t* nmatch;     // the call's outputs (device)
+    const float* hist_pos3d;                         // R x cap x 3: positions of the deque members that precede the call, row idx + R
+    int cap, R, f_begin, f_end, max_lost;
+    ssm_pnp::Camera cam;
+    PnpState* state; double* pose_out; ssm_track_info* info_out;
+    float *img, *obj; uint8_t *inl, *dec; ssm_pnp::Edge* edges;                                        // scratch for R * cap correspondences
+};
+hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s);

@@ -2,8 +2,7 @@
 // Host orchestration of the pose chain (the chain is serial by nature: frame f's initial value and its reference poses are frame f-1's results); the PnP
 // arithmetic is include/ssm/pnp_core.h, the code the per-frame host class (include/ssm/pnp.h) runs, so both give the same bits.  Written against the
 // public C ABI (ssm_match for the on-demand pairs, ssm_memcpy_d2h) -- no access to the context's internals.
-#include "ssm_internal.h"
-#include "../../include/ssm/pnp_core.h"
+#include "pnp_chain.h"
 #include <deque>
 #include <string>
 #include <vector>
@@ -25,6 +24,11 @@ struct ssm_tracker {
     // host copies of one call's outputs
     std::vector<int32_t> nkp, nmatch; std::vector<ssm_keypoint> kps; std::vector<float> pos3d; std::vector<uint8_t> desc; std::vector<ssm_dmatch> matches;
     std::vector<float> img, obj; std::vector<unsigned char> inl; std::vector<ssm_pnp::Edge> edges; std::vector<ssm_dmatch> tmp_matches;
+    std::vector<uint8_t> have;            // per frame of the current call: bit 0 = features on the host, bit 1 = match tables on the host
+    // device chain (use_device): scratch + the state block, allocated at first use
+    PnpState* d_state = nullptr; double* d_pose = nullptr; ssm_track_info* d_info = nullptr; float *d_img = nullptr, *d_obj = nullptr, *d_hist = nullptr;
+    uint8_t *d_inl = nullptr, *d_dec = nullptr; ssm_pnp::Edge* d_edges = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
+    long device_frames = 0, host_frames = 0;
 };
 static void iso_identity(double* T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
 
@@ -49,7 +53,14 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
     *out = t;
     return SSM_OK;
 }
-extern "C" void ssm_tracker_destroy(ssm_tracker* t) { delete t; }
+static void tracker_free_device(ssm_tracker* t)
+{
+    void* p[] = { t->d_state, t->d_pose, t->d_info, t->d_img, t->d_obj, t->d_hist, t->d_inl, t->d_dec, t->d_edges };
+    for (void* x : p) if (x) hipFree(x);
+    t->d_state = nullptr; t->d_pose = nullptr; t->d_info = nullptr; t->d_img = t->d_obj = t->d_hist = nullptr; t->d_inl = t->d_dec = nullptr; t->d_edges = nullptr;
+    t->d_cap = t->d_R = t->d_n = 0;
+}
+extern "C" void ssm_tracker_destroy(ssm_tracker* t) { if (t) { tracker_free_device(t); delete t; } }
 extern "C" const char* ssm_tracker_last_error(const ssm_tracker* t) { return t ? t->err.c_str() : "null tracker"; }
 extern "C" int ssm_tracker_reset(ssm_tracker* t)
 {
@@ -61,49 +72,140 @@ extern "C" int ssm_tracker_reset(ssm_tracker* t)
 #define TFAIL(t, code, msg) do { (t)->err = (msg); return (code); } while (0)
 #define TCHK(t, expr) do { int r__ = (expr); if (r__ != SSM_OK) { (t)->err = std::string(#expr) + ": " + ssm_last_error((t)->ctx); return r__; } } while (0)
 
+static int tracker_ensure_device(ssm_tracker* t, int cap, int R, int n)
+{
+    if (t->d_state && t->d_cap == cap && t->d_R == R && t->d_n >= n) return SSM_OK;
+    ssm_sync(t->ctx);
+    tracker_free_device(t);
+    const size_t mc = (size_t)R * cap;
+    bool ok = hipMalloc((void**)&t->d_state, sizeof(PnpState)) == hipSuccess && hipMalloc((void**)&t->d_pose, (size_t)n * 128) == hipSuccess &&
+              hipMalloc((void**)&t->d_info, (size_t)n * sizeof(ssm_track_info)) == hipSuccess && hipMalloc((void**)&t->d_img, mc * 8) == hipSuccess &&
+              hipMalloc((void**)&t->d_obj, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_hist, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_inl, mc) == hipSuccess &&
+              hipMalloc((void**)&t->d_dec, mc) == hipSuccess && hipMalloc((void**)&t->d_edges, mc * sizeof(ssm_pnp::Edge)) == hipSuccess;
+    if (!ok) { tracker_free_device(t); t->err = "device allocation for the pose chain failed"; return SSM_E_NOMEM; }
+    t->d_cap = cap; t->d_R = R; t->d_n = n;
+    return SSM_OK;
+}
 extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n, double* pose_out, ssm_track_info* info_out)
 {
     if (!t) return SSM_E_INVAL;
     if (!seq || n < 0 || (n && !pose_out)) TFAIL(t, SSM_E_INVAL, "bad arguments");
     if (n == 0) return SSM_OK;
     const int cap = seq->cap, R = seq->R;
-    if (R != t->prm.ref_frames) TFAIL(t, SSM_E_INVAL, "the sequence was matched with another tracker_ref_frames");
-    // ---- the call's outputs on the host
+    if (R != t->prm.ref_frames || R > SSM_TRACK_MAXREF) TFAIL(t, SSM_E_INVAL, "the sequence was matched with another tracker_ref_frames");
+    const bool on_device = t->prm.use_device != 0;
+    // ---- the call's outputs on the host: counts always; features and match tables in bulk (host chain) or per frame when the host path needs one
     t->nkp.resize(n); t->nmatch.resize((size_t)n * R); t->kps.resize((size_t)n * cap); t->pos3d.resize((size_t)n * cap * 3); t->desc.resize((size_t)n * cap * 32);
-    t->matches.resize((size_t)n * R * cap);
+    t->matches.resize((size_t)n * R * cap); t->have.assign(n, 0);
     TCHK(t, ssm_sync(t->ctx));
     TCHK(t, ssm_memcpy_d2h(t->ctx, t->nkp.data(), seq->nkp, (size_t)n * 4));
     TCHK(t, ssm_memcpy_d2h(t->ctx, t->nmatch.data(), seq->nmatch, (size_t)n * R * 4));
-    TCHK(t, ssm_memcpy_d2h(t->ctx, t->kps.data(), seq->kps, (size_t)n * cap * sizeof(ssm_keypoint)));
-    TCHK(t, ssm_memcpy_d2h(t->ctx, t->pos3d.data(), seq->pos3d, (size_t)n * cap * 12));
-    TCHK(t, ssm_memcpy_d2h(t->ctx, t->desc.data(), seq->desc, (size_t)n * cap * 32));
-    TCHK(t, ssm_memcpy_d2h(t->ctx, t->matches.data(), seq->matches, (size_t)n * R * cap * sizeof(ssm_dmatch)));
+    if (!on_device) {
+        TCHK(t, ssm_memcpy_d2h(t->ctx, t->kps.data(), seq->kps, (size_t)n * cap * sizeof(ssm_keypoint)));
+        TCHK(t, ssm_memcpy_d2h(t->ctx, t->pos3d.data(), seq->pos3d, (size_t)n * cap * 12));
+        TCHK(t, ssm_memcpy_d2h(t->ctx, t->desc.data(), seq->desc, (size_t)n * cap * 32));
+        TCHK(t, ssm_memcpy_d2h(t->ctx, t->matches.data(), seq->matches, (size_t)n * R * cap * sizeof(ssm_dmatch)));
+        t->have.assign(n, 3);
+    }
+    auto need_features = [&](int f) -> int {
+        if (t->have[f] & 1) return SSM_OK;
+        const size_t k = (size_t)(t->nkp[f] > 0 ? t->nkp[f] : 0);
+        if (k) {
+            TCHK(t, ssm_memcpy_d2h(t->ctx, t->kps.data() + (size_t)f * cap, seq->kps + (size_t)f * cap, k * sizeof(ssm_keypoint)));
+            TCHK(t, ssm_memcpy_d2h(t->ctx, t->pos3d.data() + (size_t)f * cap * 3, seq->pos3d + (size_t)f * cap * 3, k * 12));
+            TCHK(t, ssm_memcpy_d2h(t->ctx, t->desc.data() + (size_t)f * cap * 32, seq->desc + (size_t)f * cap * 32, k * 32));
+        }
+        t->have[f] |= 1; return SSM_OK;
+    };
+    auto need_matches = [&](int f) -> int {
+        if (t->have[f] & 2) return SSM_OK;
+        TCHK(t, ssm_memcpy_d2h(t->ctx, t->matches.data() + (size_t)f * R * cap, seq->matches + (size_t)f * R * cap, (size_t)R * cap * sizeof(ssm_dmatch)));
+        t->have[f] |= 2; return SSM_OK;
+    };
     const size_t maxcorr = (size_t)R * cap;
     t->img.resize(2 * maxcorr + 2); t->obj.resize(3 * maxcorr + 3); t->inl.resize(maxcorr + 1); t->edges.resize(maxcorr + 1); t->tmp_matches.resize(cap);
     ssm_pnp::Camera cam; cam.fx = t->cam.fx; cam.fy = t->cam.fy; cam.cx = t->cam.cx; cam.cy = t->cam.cy;
 
-    auto push_ref = [&](int f, const double* pose) {        // refFrames.push_back(currentFrame); while (size > refFramesSize) pop_front()
+    auto push_ref = [&](int f, const double* pose) -> int {  // refFrames.push_back(currentFrame); while (size > refFramesSize) pop_front()
+        int r_ = need_features(f); if (r_) return r_;
         RefFrame r; r.gidx = t->next_gidx + f; r.nkp = t->nkp[f]; memcpy(r.pose, pose, sizeof(r.pose));
         r.pos3d.assign(t->pos3d.begin() + (size_t)f * cap * 3, t->pos3d.begin() + (size_t)f * cap * 3 + (size_t)r.nkp * 3);
         r.desc.assign(t->desc.begin() + (size_t)f * cap * 32, t->desc.begin() + (size_t)f * cap * 32 + (size_t)r.nkp * 32);
         t->refs.push_back(std::move(r));
         while ((int)t->refs.size() > t->prm.ref_frames) t->refs.pop_front();
+        return SSM_OK;
     };
-    for (int f = 0; f < n; f++) {
+    // the deque is REGULAR at frame f when it is the run of frames directly in front of it: every member then has its precomputed match-table slot
+    auto regular = [&](int f) {
+        if (t->state != 1 || t->refs.empty()) return false;
+        const int64_t G = t->next_gidx + f; const int k = (int)t->refs.size();
+        for (int r = 0; r < k; r++) { if (t->refs[r].gidx != G - k + r) return false; if (t->nmatch[(size_t)f * R + (R - (k - r))] < 0 && t->nkp[f] >= 2) return false; }
+        return true;
+    };
+    int f = 0;
+    while (f < n) {
+        if (on_device && regular(f)) {
+            // ---- a run of frames on the device: state up, one launch, state and the run's poses down
+            int rc = tracker_ensure_device(t, cap, R, n); if (rc) return rc;
+            PnpState hs; memset(&hs, 0, sizeof(hs));
+            memcpy(hs.speed, t->speed, 128); memcpy(hs.last_pose, t->last_pose, 128);
+            hs.nref = (int)t->refs.size(); hs.cnt_lost = t->cnt_lost; hs.stopped_at = n;
+            hipStream_t st = (hipStream_t)ssm_stream(t->ctx);
+            for (int r = 0; r < hs.nref; r++) {
+                const int idx = (int)(t->refs[r].gidx - t->next_gidx);
+                hs.ref_idx[r] = idx; memcpy(hs.ref_pose[r], t->refs[r].pose, 128);
+                if (idx < 0 && t->refs[r].nkp > 0)            // a frame of the previous call: its positions are no longer on the device
+                    if (hipMemcpyAsync(t->d_hist + (size_t)(idx + R) * cap * 3, t->refs[r].pos3d.data(), (size_t)t->refs[r].nkp * 12, hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the reference positions failed");
+            }
+            if (hipMemcpyAsync(t->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the tracker state failed");
+            PnpChainArgs a; a.kps = seq->kps; a.pos3d = seq->pos3d; a.matches = seq->matches; a.nmatch = seq->nmatch; a.hist_pos3d = t->d_hist;
+            a.cap = cap; a.R = R; a.f_begin = f; a.f_end = n; a.max_lost = t->prm.max_lost_frame; a.cam = cam;
+            a.state = t->d_state; a.pose_out = t->d_pose; a.info_out = t->d_info; a.img = t->d_img; a.obj = t->d_obj; a.inl = t->d_inl; a.dec = t->d_dec; a.edges = t->d_edges;
+            if (k_pnp_chain(a, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain launch failed");
+            if (hipMemcpyAsync(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain failed");
+            const int stop = hs.stopped_at;
+            if (stop <= f || stop > n) TFAIL(t, SSM_E_HIP, "pose chain returned an invalid frame range");
+            if (hipMemcpy(pose_out + (size_t)f * 16, t->d_pose + (size_t)f * 16, (size_t)(stop - f) * 128, hipMemcpyDeviceToHost) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose download failed");
+            std::vector<ssm_track_info> inf(stop - f);
+            if (hipMemcpy(inf.data(), t->d_info + f, (size_t)(stop - f) * sizeof(ssm_track_info), hipMemcpyDeviceToHost) != hipSuccess) TFAIL(t, SSM_E_HIP, "info download failed");
+            if (info_out) memcpy(info_out + f, inf.data(), inf.size() * sizeof(ssm_track_info));
+            // the host copy of the state: speed, lastPose, cntLost, state, and the deque (the features of its new members come down now)
+            memcpy(t->speed, hs.speed, 128); memcpy(t->last_pose, hs.last_pose, 128); t->cnt_lost = hs.cnt_lost; t->state = inf.back().state;
+            std::deque<RefFrame> nd;
+            for (int r = 0; r < hs.nref; r++) {
+                const int idx = hs.ref_idx[r]; const int64_t g = t->next_gidx + idx;
+                bool found = false;
+                for (RefFrame& o : t->refs) if (o.gidx == g) { nd.push_back(std::move(o)); found = true; break; }
+                if (!found) {
+                    rc = need_features(idx); if (rc) return rc;
+                    RefFrame nr; nr.gidx = g; nr.nkp = t->nkp[idx]; memcpy(nr.pose, hs.ref_pose[r], 128);
+                    nr.pos3d.assign(t->pos3d.begin() + (size_t)idx * cap * 3, t->pos3d.begin() + (size_t)idx * cap * 3 + (size_t)nr.nkp * 3);
+                    nr.desc.assign(t->desc.begin() + (size_t)idx * cap * 32, t->desc.begin() + (size_t)idx * cap * 32 + (size_t)nr.nkp * 32);
+                    nd.push_back(std::move(nr));
+                }
+            }
+            t->refs.swap(nd);
+            t->device_frames += stop - f;
+            f = stop;
+            continue;
+        }
+        // ---- one frame on the host (the general case: first frame, lostRecover, a deque that reaches behind the match-table window)
         double* T_frame = pose_out + (size_t)f * 16;
         ssm_track_info info; info.state = 1; info.tracked = 0; info.n_matches = -1; info.n_inliers = 0;
         const int64_t G = t->next_gidx + f;
+        t->host_frames++;
         if (t->state == 0) {                                 // initFirstFrame (track.cpp:30-36)
             memcpy(T_frame, t->prm.first_pose, 128);                    // the frame keeps the T_f_w it arrived with; lastPose is not touched (nor by lostRecover)
-            push_ref(f, T_frame);
+            int rc = push_ref(f, T_frame); if (rc) return rc;
             iso_identity(t->speed);
             t->state = 1; info.tracked = 1;
         } else if (t->state == 2) {                          // lostRecover (track.cpp:202-212)
             memcpy(T_frame, t->refs.back().pose, 128);
             t->refs.clear();
-            push_ref(f, T_frame);
+            int rc = push_ref(f, T_frame); if (rc) return rc;
             t->state = 1; t->cnt_lost = 0; info.tracked = 1;
         } else {                                             // trackRefFrame (track.cpp:140-200)
+            int rc = need_features(f); if (rc) return rc;
             ssm_pnp::iso_mul(t->speed, t->refs.back().pose, T_frame);          // currentFrame->setTransform(speed * refFrames.back()->getTransform())
             int nc = 0;
             for (const RefFrame& ref : t->refs) {
@@ -111,6 +213,7 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
                 const ssm_dmatch* m = nullptr; int nm = 0;
                 const int64_t back = G - ref.gidx;           // 1 .. R: slot R - back
                 if (back >= 1 && back <= R && t->nmatch[(size_t)f * R + (R - back)] >= 0) {
+                    rc = need_matches(f); if (rc) return rc;
                     nm = t->nmatch[(size_t)f * R + (R - back)]; m = t->matches.data() + ((size_t)f * R + (R - back)) * cap;
                 } else if (ref.nkp >= 1 && t->nkp[f] >= 2) {  // an older reference frame (the deque after tracking failures): match the pair now
                     TCHK(t, ssm_match(t->ctx, ref.desc.data(), ref.nkp, t->desc.data() + (size_t)f * cap * 32, t->nkp[f], t->ratio, t->tmp_matches.data(), cap, &nm));
@@ -143,13 +246,21 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
                 double linv[16]; ssm_pnp::iso_inverse(t->last_pose, linv);
                 ssm_pnp::iso_mul(T, linv, t->speed);                            // speed = T * lastPose.inverse()
                 memcpy(t->last_pose, T, 128);
-                push_ref(f, T);
+                rc = push_ref(f, T); if (rc) return rc;
                 info.tracked = 1;
             }
         }
         info.state = t->state;
         if (info_out) info_out[f] = info;
+        f++;
     }
     t->next_gidx += n;
+    return SSM_OK;
+}
+extern "C" int ssm_tracker_stats(const ssm_tracker* t, int64_t* device_frames, int64_t* host_frames)
+{
+    if (!t) return SSM_E_INVAL;
+    if (device_frames) *device_frames = t->device_frames;
+    if (host_frames) *host_frames = t->host_frames;
     return SSM_OK;
 }

@@ -176,6 +176,16 @@ int main(int argc, char** argv)
         // (the synthetic stream is not a rigid scene -- its depth pattern stays put while the texture pans -- so PnP also fails on its own now and then:
         // more LOST / lostRecover events than the three flat frames force, all of them compared)
         CHECK("bulk_tracker_equals_per_frame_tracker", same && lost >= 1 && untracked >= 3 && !infos[12].tracked && !infos[30].tracked && !infos[31].tracked);
+        // the same chain with the regular stretches solved on the GPU (one block of 1024 threads per frame run: kernels_pnp.hip): still the same bits
+        pt.set("tracker_pnp_on_device", "1");
+        BatchTracker bulkd(pt, f00->rgb.cols, f00->rgb.rows, f00->T_f_w, 23);
+        vector<RGBDFrame::Ptr> dd;
+        for (int i = 0; i < NF; i++) for (auto& f : bulkd.push(make(i))) dd.push_back(f);
+        for (auto& f : bulkd.flush()) dd.push_back(f);
+        bool same_d = dd.size() == (size_t)NF; int bad_d = -1;
+        for (int i = 0; same_d && i < NF; i++) if (memcmp(dd[i]->getTransform().data(), Tper[i].data(), 128) != 0) { same_d = false; bad_d = i; }
+        cout << "  device chain: first mismatch " << bad_d << endl;
+        CHECK("device_pose_chain_equals_per_frame_tracker", same_d);
     }
 
     // PoseGraph key-frame gate + Mapper viewer thread

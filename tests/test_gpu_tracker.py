@@ -88,7 +88,7 @@ def reference_walk(oracle, frames, ref_frames, max_lost, ratio, nfeat):
     return poses, infos
 
 
-@pytest.mark.parametrize("use_device", [False])
+@pytest.mark.parametrize("use_device", [False, True])
 def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device):
     """14 frames of 640 x 480 (500 features): a rigid plane scene that tracks, one flat frame (fails: the deque then reaches behind the match-table window,
     so the following frames need on-demand matches), later two flat frames in a row with tracker_max_lost_frame = 1 (LOST, then lostRecover)"""
@@ -118,6 +118,8 @@ def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device):
             assert poses[f].tobytes() == np.asarray(wposes[f], np.float64).tobytes(), f
         assert [int(i["tracked"]) for i in info] == [1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1]
         assert int(info[10]["state"]) == 2 and int(info[11]["state"]) == 1 and info[5]["n_inliers"] > 100
+        dev_frames, host_frames = trk.stats()
+        assert dev_frames + host_frames == n and (dev_frames >= 5 if use_device else dev_frames == 0)     # the regular stretches ran as one-block chains on the GPU
         # the solved poses feed the map stage
         dp = c.dev_alloc(n * 128)
         try:
