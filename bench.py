@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--solve-poses", action="store_true", help="also time the closed pose loop: ORB + match tables -> ssm_tracker_run (Tracker::updateFrame for every frame: "
                     "the serial PnP chain) -> the solved poses into the map stage; reported as `solve_poses` beside `value` (whose poses are the stream's)")
     ap.add_argument("--pose-frames", type=int, default=200, help="frames of the --solve-poses leg")
+    ap.add_argument("--pose-stream", default="rigid", choices=["rigid", "synthetic"], help="--solve-poses: 'rigid' = frame 0 of the stream seen by a panning camera (a "
+                    "fronto-parallel plane at 2 m, 2 x 1 px per frame: every frame tracks); 'synthetic' = the configs[1] stream itself (its depth pattern does not move "
+                    "with the texture, so PnP loses track often: exercises LOST / lostRecover)")
     ap.add_argument("--pnp-device", type=int, default=0, help="--solve-poses: 1 = the pose chain on the GPU (one block), 0 = on one host core; same bits")
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
@@ -484,18 +487,41 @@ def main():
     if args.solve_poses and world == 1 and not args.segnet:
         PF = min(args.pose_frames, F)
         trk = ssm.Tracker(ctx, use_device=bool(args.pnp_device))
+        if args.pose_stream == "rigid":                # overwrite the first PF frames of the resident stream with the panning view of frame 0
+            b0 = bgr[: H * W * 3].view(H, W, 3).clone(); s0 = sem[: H * W * 3].view(H, W, 3).clone()
+            for k in range(PF):
+                bgr[k * H * W * 3:(k + 1) * H * W * 3] = torch.roll(b0, shifts=(k, 2 * k), dims=(0, 1)).reshape(-1)
+                sem[k * H * W * 3:(k + 1) * H * W * 3] = torch.roll(s0, shifts=(k, 2 * k), dims=(0, 1)).reshape(-1)
+            dep[: PF * H * W] = 2000
+            torch.cuda.synchronize()
         t1 = time.perf_counter()
         ctx.map_clear()
         o2 = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None, None, PF, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
         ctx.sync(); t2 = time.perf_counter()
-        poses_s, info_s = trk.run(o2, PF)
+        if args.pose_stream == "rigid":
+            # the reference's odometry chain is not stable on a planar scene (depth error feeds back through the reference poses: it diverges after ~25
+            # frames, host class and bulk tracker alike), so the rigid stream is tracked as independent 20-frame sequences: views of the call's outputs at
+            # a frame offset, the tracker reset in between (its first frame is then an initFirstFrame)
+            from semantic_slam_mapping_amd._lib import SeqOutDev
+            CH = 20; ps, ins = [], []
+            for a0 in range(0, PF, CH):
+                nn = min(CH, PF - a0); cap_, R_ = o2.cap, o2.R
+                v = SeqOutDev(o2.kps + a0 * cap_ * 28, o2.desc + a0 * cap_ * 32, o2.pos3d + a0 * cap_ * 12, o2.nkp + a0 * 4, o2.matches + a0 * R_ * cap_ * 16,
+                              o2.nmatch + a0 * R_ * 4, o2.npoints + a0 * 4, cap_, R_)
+                trk.reset()
+                p_, i_ = trk.run(v, nn); ps.append(p_); ins.append(i_)
+            poses_s, info_s = np.concatenate(ps), np.concatenate(ins)
+        else:
+            poses_s, info_s = trk.run(o2, PF)
         t3 = time.perf_counter()
         pdev = torch.from_numpy(np.ascontiguousarray(poses_s.transpose(0, 2, 1)).reshape(PF * 16)).to(dev)
         ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pdev.data_ptr(), PF, stages=ssm.api.STAGE_MAP)
         nv = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
         t4 = time.perf_counter()
+        trk_stats = trk.stats()
         trk.close()
-        solve_info = {"frames": PF, "frames_per_s": round(PF / (t4 - t1), 1), "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)",
+        dvf, hsf = trk_stats
+        solve_info = {"frames": PF, "stream": args.pose_stream, "frames_per_s": round(PF / (t4 - t1), 1), "frames_on_device_chain": dvf, "frames_on_host_path": hsf, "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)",
                       "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
                       "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
                       "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}

@@ -16,6 +16,7 @@ using namespace ssm_pnp;
 
 struct PcShared {
     double red[NGROUP][NACC + 1];
+    double tot[NACC + 1];
     double Tinv[16];
     int wcnt[NGROUP];
     int flag;
@@ -48,8 +49,11 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         for (int v = 0; v < NV; v++) sh.red[wv][v] = acc[v];
     }
     __syncthreads();
+    // the 16 wave totals in wave order: thread v < NV adds column v once, everybody reads the NV results as LDS broadcasts
+    if (threadIdx.x < NV) { double s = sh.red[0][threadIdx.x]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][threadIdx.x]; sh.tot[threadIdx.x] = s; }
+    __syncthreads();
 #pragma unroll
-    for (int v = 0; v < NV; v++) { double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; acc[v] = s; }
+    for (int v = 0; v < NV; v++) acc[v] = sh.tot[v];
     __syncthreads();
 }
 __device__ __forceinline__ double pc_chi(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
