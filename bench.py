@@ -56,7 +56,7 @@ def algorithmic_bytes(stage, P, nkp):
     }.get(stage, 0)
 
 
-STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel"], "octree": ["octree_kernel"],
+STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel", "fast_need_kernel", "fast_retry_kernel"], "octree": ["octree_kernel"],
                  "blur": ["blur_kernel", "blur_mfma_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
                  "match": ["match_expand_kernel", "match_mfma_kernel", "match_compact_kernel"],
                  "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel", "map_stream2_kernel"]}
@@ -197,6 +197,12 @@ def stereo_main(args):
                "sample": "one frame pair of the same sequence: oracle/ quad matcher + SGBM + depth conversion (C, 1 thread); the VO is below a millisecond",
                "ms_per_frame": {"sgbm": round(tc * 1e3, 2), "quad_track": round(tq * 1e3, 2)},
                "quad_matches_equal_gpu": bool(int(res["nquad"][1]) == len(qm) and res["quad"][1, :len(qm)].tobytes() == qm.tobytes())}
+    traffic = None
+    try:        # HBM bytes of the SGBM kernels per launch from the committed PMC passes (profiles/rNN_stereo_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE)
+        kk = json.load(open(latest_profile("stereo_traffic.json")))["kernels"]
+        traffic = round(sum(v["total_bytes_per_frame"] for name, v in kk.items() if name.startswith("sgbm_")) * fpl)
+    except Exception:
+        pass
     nq = res["nquad"][1:]
     line = {"metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -207,7 +213,7 @@ def stereo_main(args):
                        "frame_pairs_per_gpu": F, "frame_pairs_per_launch": B, "parallelism": "replicas" if world > 1 else "single GPU"},
             "per_frame": {"quad_matches": round(float(nq.mean()), 1), "vo_success_rate": round(float(res["vo_result"][1:, 1].mean()), 3)},
             "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle, depth: all kernels of the SGBM stage)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": round(alg),
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg),
                          "stages_ms_per_frame": {k: round(v[0] / (F * nser), 4) for k, v in stage_acc.items()},
                          "stages_ms_per_frame_overlapped": {k: round(v[0] / (F * args.steps), 4) for k, v in stage_ovl.items()}},
             "cpu_baseline": cpu}

@@ -1,17 +1,26 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the three bench lines and the rocprofv3 runs the summaries under profiles/ are made from.
-# Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc'
+# Runs on the GPU box (gpurun): the bench lines and the rocprofv3 runs the summaries under profiles/ are made from.
+# Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc|pmc_stereo'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 if [ "$1" = "stats" ]; then
   timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err
   timeout 300 python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 > $O/line_segnet.json 2> $O/line_segnet.err
   timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 > $O/line_stereo.json 2> $O/line_stereo.err
+  timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 0 > $O/line_poses_host.json 2> $O/line_poses_host.err
+  timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 1 > $O/line_poses_dev.json 2> $O/line_poses_dev.err
   rm -rf $O/p_stats $O/p_seg $O/p_st
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --stereo-workers 1 > $O/p_st.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --serial-only > $O/p_st.log 2>&1
   tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
+elif [ "$1" = "pmc_stereo" ]; then
+  rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
+  A="--stereo --frames 64 --steps 1 --warmup 0 --no-cpu --serial-only"
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq_st -o runc -- python3 bench.py $A > $O/p_sq_st.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_st -o runc -- python3 bench.py $A > $O/p_fetch_st.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_st -o runc -- python3 bench.py $A > $O/p_write_st.log 2>&1
+  tail -2 $O/p_sq_st.log | cut -c1-300
 else
   export SSM_BENCH_H2D=0
   rm -rf $O/p_sq $O/p_fetch $O/p_write
