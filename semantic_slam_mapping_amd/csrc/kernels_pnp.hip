@@ -17,9 +17,10 @@ using namespace ssm_pnp;
 struct PcShared {
     double red[NGROUP][NACC + 1];
     double tot[NACC + 1];
-    double Tinv[16];
+    Pose P, saved, init;          // the estimate wave 0 publishes for the next pass; the one before the trial; the round's start value
+    double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
-    int flag;
+    int cont, term;               // loop controls of the Levenberg iteration, decided by wave 0
 };
 // exclusive position of `flag` among the block's threads in thread order, and the block total
 __device__ __forceinline__ int pc_scan(bool flag, PcShared& sh, int& total)
@@ -35,8 +36,9 @@ __device__ __forceinline__ int pc_scan(bool flag, PcShared& sh, int& total)
     total = tot;
     return off + __popcll(bal & ((1ull << lane) - 1ull));
 }
-// lane sums of pnp_core.h: this thread's partial sums acc[NV] -> the totals, identical in every thread
-template <int NV>
+// lane sums of pnp_core.h: this thread's partial sums acc[NV] -> sh.tot[OFF .. OFF + NV), visible to the whole block when the function returns.
+// Wave butterfly (every lane ends with the group's tree sum), lane 0 of each wave publishes it, threads 0 .. NV-1 add the 16 group sums in group order.
+template <int NV, int OFF>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -46,60 +48,78 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         for (int v = 0; v < NV; v++) acc[v] = acc[v] + __shfl_xor(acc[v], s, 64);
     if (lane == 0) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) sh.red[wv][v] = acc[v];
+        for (int v = 0; v < NV; v++) sh.red[wv][OFF + v] = acc[v];
     }
     __syncthreads();
-    // the 16 wave totals in wave order: thread v < NV adds column v once, everybody reads the NV results as LDS broadcasts
-    if (threadIdx.x < NV) { double s = sh.red[0][threadIdx.x]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][threadIdx.x]; sh.tot[threadIdx.x] = s; }
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < NV; v++) acc[v] = sh.tot[v];
+    if (threadIdx.x < NV) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
     __syncthreads();
 }
-__device__ __forceinline__ double pc_chi(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+// the robustified chi2 of the active edges at P (leaves every active edge's error in the edge) -> sh.tot[NACC] (H and b in sh.tot[0 .. 26] stay)
+__device__ __forceinline__ void pc_chi(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[1] = {0.0};
     for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) acc[0] += edge_rho(E[i], P, k, delta);
-    pc_lane_sum<1>(acc, sh);
-    return acc[0];
+    pc_lane_sum<1, NACC>(acc, sh);
 }
-__device__ __forceinline__ void pc_build(const Edge* E, int ne, const Pose& P, const Camera& k, double delta, double* Hl, double* b, PcShared& sh)
+// chi2 and the normal equations at P in ONE pass over the edges (the host evaluates active_chi2 and build_system one after the other at the same
+// estimate: the same per-edge values, the same lane sums) -> sh.tot[0 .. 26] = H (lower triangle) and b, sh.tot[27] = chi2
+__device__ __forceinline__ void pc_chi_build(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
-    double acc[NACC];
+    double acc[NACC + 1];
 #pragma unroll
-    for (int q = 0; q < NACC; q++) acc[q] = 0.0;
-    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) edge_accumulate(E[i], P, k, delta, acc);
-    pc_lane_sum<NACC>(acc, sh);
-    for (int q = 0; q < 21; q++) Hl[q] = acc[q];
-    for (int q = 0; q < 6; q++) b[q] = acc[21 + q];
+    for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
+    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) { acc[NACC] += edge_rho(E[i], P, k, delta); edge_accumulate(E[i], P, k, delta, acc); }
+    pc_lane_sum<NACC + 1, 0>(acc, sh);
 }
-// lm_optimize of pnp_core.h, every thread in lock step
-__device__ __forceinline__ void pc_optimize(Edge* E, int ne, Pose& P, const Camera& k, double delta, int iterations, PcShared& sh)
+// lm_optimize of pnp_core.h.  The passes over the edges are the whole block's; the 6 x 6 algebra between them (L D L^T, exp map, Levenberg's bookkeeping)
+// is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
+// controls through LDS.
+__device__ __forceinline__ void pc_optimize(Edge* E, int ne, const Camera& k, double delta, int iterations, PcShared& sh)
 {
+    const Pose& P = sh.P;                                                        // in / out: the estimate lives in LDS (uniform reads; 24 registers saved)
     int any = 0;
     for (int i = threadIdx.x; i < ne; i += PC_T) any |= E[i].level == 0;
     if (!__syncthreads_or(any)) return;
-    LmState st; st.lambda = 0; st.nu = 2;
+    const bool w0 = threadIdx.x < 64;
+    LmState st; st.lambda = 0; st.nu = 2;                                        // (meaningful in wave 0 only)
+    double chi = 0, x[6], gain = 0; int trials = 0; bool solved = false;
+    const double* Hl = sh.tot; const double* b = sh.tot + 21;                 // the system stays in LDS over the trials (registers are short here)
     for (int it = 0; it < iterations; it++) {
-        double chi = pc_chi(E, ne, P, k, delta, sh), Hl[21], b[6];
-        pc_build(E, ne, P, k, delta, Hl, b, sh);
-        if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) { const double dg = fabs(Hl[j * (j + 1) / 2 + j]); if (dg > mx) mx = dg; } st.lambda = 1e-5 * mx; st.nu = 2; }
-        double gain = 0; int trials = 0;
-        do {
-            const Pose saved = P;
-            double x[6] = {0, 0, 0, 0, 0, 0};
-            const bool ok = solve_ldlt(Hl, st.lambda, b, x);
-            pose_oplus(P, x);
-            const double chi_new = pc_chi(E, ne, P, k, delta, sh);
-            if (lm_update(st, chi, chi_new, ok, x, b, gain)) chi = chi_new;
-            else { P = saved; if (!isfinite(st.lambda)) break; }
-            trials++;
-        } while (gain < 0 && trials < 10);
-        if (trials == 10 || gain == 0) break;
+        pc_chi_build(E, ne, P, k, delta, sh);
+        if (w0) {
+            chi = sh.tot[NACC];
+            if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) { const double dg = fabs(Hl[j * (j + 1) / 2 + j]); if (dg > mx) mx = dg; } st.lambda = 1e-5 * mx; st.nu = 2; }
+            gain = 0; trials = 0;
+        }
+        for (;;) {
+            if (w0) {
+                for (int q = 0; q < 6; q++) x[q] = 0;
+                solved = solve_ldlt(Hl, st.lambda, b, x);
+                Pose Pn = sh.P;
+                pose_oplus(Pn, x);
+                if (threadIdx.x == 0) { sh.saved = sh.P; sh.P = Pn; }
+            }
+            __syncthreads();
+            pc_chi(E, ne, P, k, delta, sh);
+            if (w0) {
+                const double chi_new = sh.tot[NACC];
+                bool brk = false;
+                if (lm_update(st, chi, chi_new, solved, x, b, gain)) chi = chi_new;
+                else { if (threadIdx.x == 0) sh.P = sh.saved; if (!isfinite(st.lambda)) brk = true; }
+                if (!brk) trials++;
+                const bool cont = !brk && gain < 0 && trials < 10;
+                if (threadIdx.x == 0) { sh.cont = cont ? 1 : 0; sh.term = (!cont && (trials == 10 || gain == 0)) ? 1 : 0; }
+            }
+            __syncthreads();
+            if (!sh.cont) break;
+        }
+        const int term = sh.term;
+        __syncthreads();                                                         // (sh.cont / sh.term are rewritten by the next iteration)
+        if (term) break;
     }
     pc_chi(E, ne, P, k, delta, sh);
 }
-// ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (identical in every thread); returns the number of set flags
+// ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
 __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, Edge* E, uint8_t* dec, PcShared& sh)
 {
     const double delta = (double)(float)sqrt(5.991);
@@ -115,10 +135,13 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
     }
     __syncthreads();
     int good = ne;
-    Pose init, P; pose_from_iso(T, init); P = init;
+    if (threadIdx.x == 0) { Pose i0; pose_from_iso(T, i0); sh.init = i0; }
+    const Pose& P = sh.P;
     for (int it = 0; it < 4; it++) {
-        P = init;
-        pc_optimize(E, ne, P, cam, delta, 10, sh);
+        __syncthreads();
+        if (threadIdx.x == 0) sh.P = sh.init;
+        __syncthreads();
+        pc_optimize(E, ne, cam, delta, 10, sh);
         // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
         // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
@@ -146,7 +169,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         good -= allout;
         if (good < 5) break;
     }
-    pose_to_iso(P, T);
+    if (threadIdx.x == 0) { const Pose Pf = sh.P; pose_to_iso(Pf, T); }
     int m = 0;
     for (int i = threadIdx.x; i < n; i += PC_T) m += inl[i] != 0;
 #pragma unroll
@@ -163,17 +186,16 @@ pnp_chain_kernel(PnpChainArgs a)
 {
     __shared__ PcShared sh;
     const int tid = threadIdx.x;
-    // the tracker state, identical in every thread's registers
-    double speed[16], last[16];
-    for (int k = 0; k < 16; k++) { speed[k] = a.state->speed[k]; last[k] = a.state->last_pose[k]; }
+    // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
+    if (tid == 0) for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; }
     int nref = a.state->nref, cnt_lost = a.state->cnt_lost;
     // the deque lives in global memory (a.state->ref_idx / ref_pose); every thread tracks nref
     int f = a.f_begin;
     int stopped = a.f_end;
+    __syncthreads();
     for (; f < a.f_end; f++) {
         ssm_track_info info; info.state = 1; info.tracked = 0; info.n_matches = -1; info.n_inliers = 0;
-        double Tpred[16];
-        iso_mul(speed, a.state->ref_pose[nref - 1], Tpred);                     // currentFrame->setTransform(speed * refFrames.back()->getTransform())
+        if (tid == 0) iso_mul(sh.speed, a.state->ref_pose[nref - 1], sh.Tpred); // currentFrame->setTransform(speed * refFrames.back()->getTransform())
         // ---- the correspondences of every reference frame, in deque order then match order (track.cpp:150-163)
         int nc = 0;
         for (int r = 0; r < nref; r++) {
@@ -182,14 +204,16 @@ pnp_chain_kernel(PnpChainArgs a)
             const int nm = max(a.nmatch[(size_t)f * a.R + slot], 0);
             const ssm_dmatch* m = a.matches + ((size_t)f * a.R + slot) * a.cap;
             const float* rpos = ridx >= 0 ? a.pos3d + (size_t)ridx * a.cap * 3 : a.hist_pos3d + (size_t)(ridx + a.R) * a.cap * 3;
-            double inv[16]; iso_inverse(a.state->ref_pose[r], inv);
+            __syncthreads();
+            if (tid == 0) iso_inverse(a.state->ref_pose[r], sh.inv);
+            __syncthreads();
             for (int k0 = 0; k0 < nm; k0 += PC_T) {
                 const int k = k0 + tid;
                 bool keep = false; float p0 = 0, p1 = 0, p2 = 0; int ti = 0;
                 if (k < nm) { const ssm_dmatch d = m[k]; const float* p = rpos + (size_t)d.queryIdx * 3; p0 = p[0]; p1 = p[1]; p2 = p[2]; ti = d.trainIdx; keep = !(p0 == 0.f && p1 == 0.f && p2 == 0.f); }
                 int tot; const int pos = nc + pc_scan(keep, sh, tot);
                 if (keep) {
-                    double v[3]; iso_apply(inv, (double)p0, (double)p1, (double)p2, v);
+                    double v[3]; iso_apply(sh.inv, (double)p0, (double)p1, (double)p2, v);
                     a.obj[3 * pos] = (float)v[0]; a.obj[3 * pos + 1] = (float)v[1]; a.obj[3 * pos + 2] = (float)v[2];
                     const ssm_keypoint kp = a.kps[(size_t)f * a.cap + ti];
                     a.img[2 * pos] = kp.x; a.img[2 * pos + 1] = kp.y;
@@ -200,40 +224,41 @@ pnp_chain_kernel(PnpChainArgs a)
         __syncthreads();
         info.n_matches = nc;
         bool ok = nc >= 15;
-        double T[16];
         if (ok) {
-            iso_mul(speed, last, T);                                            // T = speed * lastPose
-            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, T, a.inl, a.edges, a.dec, sh);
+            if (tid == 0) iso_mul(sh.speed, sh.last, sh.T);                     // T = speed * lastPose
+            __syncthreads();
+            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, sh.T, a.inl, a.edges, a.dec, sh);
             ok = info.n_inliers >= 15;
         }
         if (!ok) {
             cnt_lost++;
             if (cnt_lost > a.max_lost) info.state = 2;
-            if (tid == 0) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = Tpred[k]; a.info_out[f] = info; }
+            if (tid == 0) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.Tpred[k]; a.info_out[f] = info; }
             stopped = f + 1;                                                    // the deque now trails behind the match-table window: the host path goes on
             break;
         }
         cnt_lost = 0;
-        double linv[16]; iso_inverse(last, linv);
-        iso_mul(T, linv, speed);                                                // speed = T * lastPose.inverse()
-        for (int k = 0; k < 16; k++) last[k] = T[k];
         info.tracked = 1;
-        __syncthreads();                                                        // every thread has read the deque of this frame
+        __syncthreads();                                                        // every thread has read the deque of this frame; sh.T is written
         if (tid == 0) {
-            for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = T[k];
+            double linv[16], sp[16]; iso_inverse(sh.last, linv);
+            iso_mul(sh.T, linv, sp);                                            // speed = T * lastPose.inverse()
+            for (int k = 0; k < 16; k++) { sh.speed[k] = sp[k]; sh.last[k] = sh.T[k]; }
+            for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.T[k];
             a.info_out[f] = info;
             // refFrames.push_back(currentFrame); pop_front beyond tracker_ref_frames
             if (nref == a.R) { for (int r = 1; r < nref; r++) { a.state->ref_idx[r - 1] = a.state->ref_idx[r]; for (int k = 0; k < 16; k++) a.state->ref_pose[r - 1][k] = a.state->ref_pose[r][k]; } }
             const int slot = nref == a.R ? nref - 1 : nref;
             a.state->ref_idx[slot] = f;
-            for (int k = 0; k < 16; k++) a.state->ref_pose[slot][k] = T[k];
+            for (int k = 0; k < 16; k++) a.state->ref_pose[slot][k] = sh.T[k];
         }
         if (nref < a.R) nref++;
         __threadfence_block();
         __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
-        for (int k = 0; k < 16; k++) { a.state->speed[k] = speed[k]; a.state->last_pose[k] = last[k]; }
+        for (int k = 0; k < 16; k++) { a.state->speed[k] = sh.speed[k]; a.state->last_pose[k] = sh.last[k]; }
         a.state->nref = nref; a.state->cnt_lost = cnt_lost; a.state->stopped_at = stopped;
     }
 }
