@@ -4,8 +4,9 @@
 // what parallelism there is lives inside a frame: the correspondences of the <= tracker_ref_frames match tables (ordered compaction by block scans), and
 // every pass over the edges of the Levenberg iterations (chi2 pass, normal-equation pass) -- thread i owns edges i, i + 1024, ... and the sums follow the
 // LANE ORDER of include/ssm/pnp_core.h (wave butterfly, then the 16 wave totals in order), which is what makes the result the same bits as the host
-// class and the oracle.  The small dense algebra (6 x 6 L D L^T, exp map, Levenberg bookkeeping) is executed redundantly by every thread from the same
-// totals: no broadcast, no extra barrier.  All matches / features stay on the device; the host orchestrator (ssm_track.hip) only moves the tracker state.
+// class and the oracle.  The small dense algebra (6 x 6 L D L^T, exp map, Levenberg bookkeeping) is wave 0's; the estimate, the system and the tracker's
+// state live in LDS, and so does the edge list (24 bytes per edge: the measurement and the point are floats to begin with) when it fits.
+// All matches / features stay on the device; the host orchestrator (ssm_track.hip) only moves the tracker state.
 // The kernel handles the REGULAR case -- state OK and the refFrames deque = the frames directly in front of the current one, all inside the match-table
 // window -- and stops behind the first frame that fails to track; the host path (same arithmetic) takes over until the deque is regular again.
 #include "pnp_chain.h"
@@ -13,8 +14,30 @@
 
 using namespace ssm_pnp;
 #define PC_T 1024
+// an edge as the passes read it: 24 bytes (the Edge of pnp_core.h is 72; its error lives in a separate global array).  meta = id | level << 16 | robust << 17
+struct LEdge { float X[3], u, v; uint32_t meta; };
+#define LE_LEVEL (1u << 16)
+#define LE_ROBUST (1u << 17)
+__device__ __forceinline__ Edge pc_expand(const LEdge& l)
+{
+    Edge e; e.id = (int32_t)(l.meta & 0xFFFFu); e.level = (l.meta & LE_LEVEL) ? 1 : 0; e.robust = (l.meta & LE_ROBUST) ? 1 : 0; e.pad = 0;
+    e.X[0] = l.X[0]; e.X[1] = l.X[1]; e.X[2] = l.X[2]; e.u = l.u; e.v = l.v; e.e0 = e.e1 = 0;
+    return e;
+}
 
+#ifdef SSM_PNP_PROF
+#define PROF_T0 long long pt_ = clock64();
+#define PROF(k) { const long long n_ = clock64(); if (threadIdx.x == 0) sh.prof[k] += n_ - pt_; pt_ = n_; }
+#define PROF_CNT(k) { if (threadIdx.x == 0) sh.prof[k] += 1; }
+#else
+#define PROF_T0
+#define PROF(k)
+#define PROF_CNT(k)
+#endif
 struct PcShared {
+#ifdef SSM_PNP_PROF
+    long long prof[8];
+#endif
     double red[NGROUP][NACC + 1];
     double tot[NACC + 1];
     Pose P, saved, init;          // the estimate wave 0 publishes for the next pass; the one before the trial; the round's start value
@@ -36,56 +59,104 @@ __device__ __forceinline__ int pc_scan(bool flag, PcShared& sh, int& total)
     total = tot;
     return off + __popcll(bal & ((1ull << lane) - 1ull));
 }
+// the value `v` holds in lane ^ S.  S = 1, 2: DPP quad_perm (a VALU move, no LDS round trip).  TREE: the caller is the full butterfly, where every lane
+// of an aligned 4- (8-) lane group already holds the same sum, so any lane of the sibling group serves: row_half_mirror (lane ^ 7) / row_mirror (lane ^ 15)
+template <int S, bool TREE>
+__device__ __forceinline__ double pc_xor_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (S == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); }
+    else if constexpr (S == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); }
+    else if constexpr (S == 4 && TREE) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); }
+    else if constexpr (S == 8 && TREE) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); }
+    else { lo = __shfl_xor(lo, S, 64); hi = __shfl_xor(hi, S, 64); }
+    return __hiloint2double(hi, lo);
+}
+// one halving step of the reduce-scatter: lanes with bit S clear keep a[0 .. H), the others a[H .. 2H), and add the partner's copy of what they keep
+template <int S, int H>
+__device__ __forceinline__ void pc_rs_step(double* a, bool up)
+{
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const double keep = up ? a[j + H] : a[j], send = up ? a[j] : a[j + H];
+        a[j] = keep + pc_xor_f64<S, false>(send);
+    }
+}
 // lane sums of pnp_core.h: this thread's partial sums acc[NV] -> sh.tot[OFF .. OFF + NV), visible to the whole block when the function returns.
-// Wave butterfly (every lane ends with the group's tree sum), lane 0 of each wave publishes it, threads 0 .. NV-1 add the 16 group sums in group order.
+// The group (= wave) tree of one value adds sibling sub-tree sums level by level; floating-point addition commutes, so WHICH lane of a sub-tree does an
+// addition does not matter.  One value: the plain butterfly.  28 values: a reduce-scatter -- at level k a lane keeps only the half of its values that its
+// bit k selects (28 -> 14 -> 7 (+ 1 pad) -> 4 -> 2 -> 1) -- 29 additions and 31 exchanges per lane instead of 168 and 168 (the butterfly was 45 % of the
+// fused pass's instructions and kept the LDS pipe busy with 336 ds_bpermute per wave).  Lane 0 of each wave (one value) / the lane that ends up with value v
+// publishes the group sum, threads 0 .. NV-1 add the 16 group sums in group order.
 template <int NV, int OFF>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if constexpr (NV == 1) {
+        double a = acc[0];
+        a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
+        a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
+        if (lane == 0) sh.red[wv][OFF] = a;
+    } else {
+        static_assert(NV == 28, "the halving sequence below is written for 28 values");
+        double a[28];
 #pragma unroll
-    for (int s = 1; s < GROUP; s <<= 1)
-#pragma unroll
-        for (int v = 0; v < NV; v++) acc[v] = acc[v] + __shfl_xor(acc[v], s, 64);
-    if (lane == 0) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) sh.red[wv][OFF + v] = acc[v];
+        for (int v = 0; v < 28; v++) a[v] = acc[v];
+        pc_rs_step<1, 14>(a, lane & 1);
+        pc_rs_step<2, 7>(a, lane & 2);
+        a[7] = 0.0;                                                              // pad: 7 -> 8
+        pc_rs_step<4, 4>(a, lane & 4);
+        pc_rs_step<8, 2>(a, lane & 8);
+        pc_rs_step<16, 1>(a, lane & 16);
+        const double t = a[0] + pc_xor_f64<32, false>(a[0]);
+        const int sub = ((lane >> 2) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);
+        const int v = (lane & 1) * 14 + ((lane >> 1) & 1) * 7 + sub;
+        if (lane < 32 && sub < 7) sh.red[wv][OFF + v] = t;
     }
     __syncthreads();
     if (threadIdx.x < NV) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
     __syncthreads();
 }
 // the robustified chi2 of the active edges at P (leaves every active edge's error in the edge) -> sh.tot[NACC] (H and b in sh.tot[0 .. 26] stay)
-__device__ __forceinline__ void pc_chi(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+__device__ __forceinline__ void pc_chi(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[1] = {0.0};
-    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) acc[0] += edge_rho(E[i], P, k, delta);
+    for (int i = threadIdx.x; i < ne; i += PC_T) {
+        const LEdge l = L[i];
+        if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[0] += edge_rho(e, P, k, delta); err[i] = make_double2(e.e0, e.e1); }
+    }
     pc_lane_sum<1, NACC>(acc, sh);
 }
 // chi2 and the normal equations at P in ONE pass over the edges (the host evaluates active_chi2 and build_system one after the other at the same
 // estimate: the same per-edge values, the same lane sums) -> sh.tot[0 .. 26] = H (lower triangle) and b, sh.tot[27] = chi2
-__device__ __forceinline__ void pc_chi_build(Edge* E, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+__device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[NACC + 1];
 #pragma unroll
     for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
-    for (int i = threadIdx.x; i < ne; i += PC_T) if (E[i].level == 0) { acc[NACC] += edge_rho(E[i], P, k, delta); edge_accumulate(E[i], P, k, delta, acc); }
+    for (int i = threadIdx.x; i < ne; i += PC_T) {
+        const LEdge l = L[i];
+        if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
+    }
     pc_lane_sum<NACC + 1, 0>(acc, sh);
 }
 // lm_optimize of pnp_core.h.  The passes over the edges are the whole block's; the 6 x 6 algebra between them (L D L^T, exp map, Levenberg's bookkeeping)
 // is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
 // controls through LDS.
-__device__ __forceinline__ void pc_optimize(Edge* E, int ne, const Camera& k, double delta, int iterations, PcShared& sh)
+__device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne, const Camera& k, double delta, int iterations, PcShared& sh)
 {
     const Pose& P = sh.P;                                                        // in / out: the estimate lives in LDS (uniform reads; 24 registers saved)
     int any = 0;
-    for (int i = threadIdx.x; i < ne; i += PC_T) any |= E[i].level == 0;
+    for (int i = threadIdx.x; i < ne; i += PC_T) any |= !(L[i].meta & LE_LEVEL);
     if (!__syncthreads_or(any)) return;
     const bool w0 = threadIdx.x < 64;
     LmState st; st.lambda = 0; st.nu = 2;                                        // (meaningful in wave 0 only)
     double chi = 0, x[6], gain = 0; int trials = 0; bool solved = false;
     const double* Hl = sh.tot; const double* b = sh.tot + 21;                 // the system stays in LDS over the trials (registers are short here)
+    PROF_T0
     for (int it = 0; it < iterations; it++) {
-        pc_chi_build(E, ne, P, k, delta, sh);
+        pc_chi_build(L, err, ne, P, k, delta, sh);
+        PROF(1) PROF_CNT(6)
         if (w0) {
             chi = sh.tot[NACC];
             if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) { const double dg = fabs(Hl[j * (j + 1) / 2 + j]); if (dg > mx) mx = dg; } st.lambda = 1e-5 * mx; st.nu = 2; }
@@ -100,7 +171,9 @@ __device__ __forceinline__ void pc_optimize(Edge* E, int ne, const Camera& k, do
                 if (threadIdx.x == 0) { sh.saved = sh.P; sh.P = Pn; }
             }
             __syncthreads();
-            pc_chi(E, ne, P, k, delta, sh);
+            PROF(2)
+            pc_chi(L, err, ne, P, k, delta, sh);
+            PROF(3) PROF_CNT(7)
             if (w0) {
                 const double chi_new = sh.tot[NACC];
                 bool brk = false;
@@ -111,16 +184,17 @@ __device__ __forceinline__ void pc_optimize(Edge* E, int ne, const Camera& k, do
                 if (threadIdx.x == 0) { sh.cont = cont ? 1 : 0; sh.term = (!cont && (trials == 10 || gain == 0)) ? 1 : 0; }
             }
             __syncthreads();
+            PROF(4)
             if (!sh.cont) break;
         }
         const int term = sh.term;
         __syncthreads();                                                         // (sh.cont / sh.term are rewritten by the next iteration)
         if (term) break;
     }
-    pc_chi(E, ne, P, k, delta, sh);
+    pc_chi(L, err, ne, P, k, delta, sh);
 }
 // ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
-__device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, Edge* E, uint8_t* dec, PcShared& sh)
+__device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, LEdge* L, double2* err, uint8_t* dec, PcShared& sh)
 {
     const double delta = (double)(float)sqrt(5.991);
     // edge list: the correspondences with depth, in order
@@ -130,7 +204,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         const bool has = i < n && !(obj[3 * i] == 0.f && obj[3 * i + 1] == 0.f && obj[3 * i + 2] == 0.f);
         int tot; const int pos = ne + pc_scan(has, sh, tot);
         if (i < n) inl[i] = has ? 1 : 0;
-        if (has) { Edge e; e.id = i; e.level = 0; e.robust = 1; e.pad = 0; e.X[0] = obj[3 * i]; e.X[1] = obj[3 * i + 1]; e.X[2] = obj[3 * i + 2]; e.u = img[2 * i]; e.v = img[2 * i + 1]; e.e0 = e.e1 = 0; E[pos] = e; }
+        if (has) { LEdge l; l.meta = (uint32_t)i | LE_ROBUST; l.X[0] = obj[3 * i]; l.X[1] = obj[3 * i + 1]; l.X[2] = obj[3 * i + 2]; l.u = img[2 * i]; l.v = img[2 * i + 1]; L[pos] = l; err[pos] = make_double2(0.0, 0.0); }
         ne += tot;
     }
     __syncthreads();
@@ -141,21 +215,23 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         __syncthreads();
         if (threadIdx.x == 0) sh.P = sh.init;
         __syncthreads();
-        pc_optimize(E, ne, cam, delta, 10, sh);
+        pc_optimize(L, err, ne, cam, delta, 10, sh);
         // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
         // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
         int nout = 0;
         for (int i = threadIdx.x; i < ne; i += PC_T) {
-            Edge e = E[i];
-            if (inl[e.id]) edge_error(e, P, cam);
+            LEdge l = L[i];
+            Edge e = pc_expand(l);
+            const double2 er = err[i]; e.e0 = er.x; e.e1 = er.y;
+            if (inl[e.id]) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); }
             const bool out = edge_chi2(e) > 5.991;
-            e.level = out ? 1 : 0;
-            if (it == 2) e.robust = 0;
-            E[i] = e; dec[i] = out ? 1 : 0; nout += out;
+            l.meta = (l.meta & ~LE_LEVEL) | (out ? LE_LEVEL : 0u);
+            if (it == 2) l.meta &= ~LE_ROBUST;
+            L[i] = l; dec[i] = out ? 1 : 0; nout += out;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[E[i].id] = 0;
+        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[L[i].meta & 0xFFFFu] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < ne; i += PC_T) if (!dec[i]) inl[i] = 1;
         __syncthreads();
@@ -185,9 +261,14 @@ __global__ void __launch_bounds__(PC_T)
 pnp_chain_kernel(PnpChainArgs a)
 {
     __shared__ PcShared sh;
+    extern __shared__ __align__(16) unsigned char pc_dyn[];
+    LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;    // (a generic pointer: the passes are the same code for both)
     const int tid = threadIdx.x;
     // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
     if (tid == 0) for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; }
+#ifdef SSM_PNP_PROF
+    if (tid == 0) for (int k = 0; k < 8; k++) sh.prof[k] = 0;
+#endif
     int nref = a.state->nref, cnt_lost = a.state->cnt_lost;
     // the deque lives in global memory (a.state->ref_idx / ref_pose); every thread tracks nref
     int f = a.f_begin;
@@ -195,6 +276,7 @@ pnp_chain_kernel(PnpChainArgs a)
     __syncthreads();
     for (; f < a.f_end; f++) {
         ssm_track_info info; info.state = 1; info.tracked = 0; info.n_matches = -1; info.n_inliers = 0;
+        PROF_T0
         if (tid == 0) iso_mul(sh.speed, a.state->ref_pose[nref - 1], sh.Tpred); // currentFrame->setTransform(speed * refFrames.back()->getTransform())
         // ---- the correspondences of every reference frame, in deque order then match order (track.cpp:150-163)
         int nc = 0;
@@ -222,13 +304,15 @@ pnp_chain_kernel(PnpChainArgs a)
             }
         }
         __syncthreads();
+        PROF(0)
         info.n_matches = nc;
         bool ok = nc >= 15;
         if (ok) {
             if (tid == 0) iso_mul(sh.speed, sh.last, sh.T);                     // T = speed * lastPose
             __syncthreads();
-            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, sh.T, a.inl, a.edges, a.dec, sh);
+            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
             ok = info.n_inliers >= 15;
+            PROF(5)
         }
         if (!ok) {
             cnt_lost++;
@@ -260,10 +344,26 @@ pnp_chain_kernel(PnpChainArgs a)
     if (tid == 0) {
         for (int k = 0; k < 16; k++) { a.state->speed[k] = sh.speed[k]; a.state->last_pose[k] = sh.last[k]; }
         a.state->nref = nref; a.state->cnt_lost = cnt_lost; a.state->stopped_at = stopped;
+#ifdef SSM_PNP_PROF
+        for (int k = 0; k < 8; k++) a.state->prof[k] = sh.prof[k];
+#endif
     }
 }
-hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s)
+size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
+hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
-    pnp_chain_kernel<<<1, PC_T, 0, s>>>(a);
+    // the edge list in LDS when R * cap edges fit beside the static part (160 KB per CU); ids are 16-bit in LEdge::meta
+    PnpChainArgs a = a_in;
+    if ((size_t)a.R * a.cap > 65535) return hipErrorInvalidValue;
+    const size_t need = (size_t)a.R * a.cap * sizeof(LEdge);
+    a.edges_in_lds = need + sizeof(PcShared) + 1024 <= 160 * 1024 ? 1 : 0;
+    const size_t dyn = a.edges_in_lds ? need : 0;
+    static size_t dyn_set = 0;
+    if (dyn > dyn_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
+        dyn_set = dyn;
+    }
+    pnp_chain_kernel<<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();
 }

@@ -9,6 +9,9 @@ struct PnpState {
     double ref_pose[SSM_TRACK_MAXREF][16];           // refFrames deque, oldest first
     int32_t ref_idx[SSM_TRACK_MAXREF];               // their frame indices relative to the current ssm_seq_process call (negative: frames of the previous call)
     int32_t nref, cnt_lost, stopped_at, pad;
+#ifdef SSM_PNP_PROF
+    long long prof[8];                               // shader clocks per section (thread 0), ablation builds only
+#endif
 };
 struct PnpChainArgs {
     const ssm_keypoint* kps; const float* pos3d; const ssm_dmatch* matches; const int32_t* nmatch;     // the call's outputs (device)
@@ -16,6 +19,9 @@ struct PnpChainArgs {
     int cap, R, f_begin, f_end, max_lost;
     ssm_pnp::Camera cam;
     PnpState* state; double* pose_out; ssm_track_info* info_out;
-    float *img, *obj; uint8_t *inl, *dec; ssm_pnp::Edge* edges;                                        // scratch for R * cap correspondences
+    float *img, *obj; uint8_t *inl, *dec;                                                              // scratch for R * cap correspondences
+    struct LEdge* ledges; double2* err;              // the edge list when it does not fit in LDS (k_pnp_edge_bytes() each), and every edge's error
+    int edges_in_lds;                                // set by k_pnp_chain
 };
 hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s);
+size_t k_pnp_edge_bytes(void);

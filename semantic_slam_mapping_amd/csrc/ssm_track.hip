@@ -27,7 +27,7 @@ struct ssm_tracker {
     std::vector<uint8_t> have;            // per frame of the current call: bit 0 = features on the host, bit 1 = match tables on the host
     // device chain (use_device): scratch + the state block, allocated at first use
     PnpState* d_state = nullptr; double* d_pose = nullptr; ssm_track_info* d_info = nullptr; float *d_img = nullptr, *d_obj = nullptr, *d_hist = nullptr;
-    uint8_t *d_inl = nullptr, *d_dec = nullptr; ssm_pnp::Edge* d_edges = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
+    uint8_t *d_inl = nullptr, *d_dec = nullptr; void* d_edges = nullptr; double2* d_err = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
     long device_frames = 0, host_frames = 0;
 };
 static void iso_identity(double* T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
@@ -55,9 +55,9 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
 }
 static void tracker_free_device(ssm_tracker* t)
 {
-    void* p[] = { t->d_state, t->d_pose, t->d_info, t->d_img, t->d_obj, t->d_hist, t->d_inl, t->d_dec, t->d_edges };
+    void* p[] = { t->d_state, t->d_pose, t->d_info, t->d_img, t->d_obj, t->d_hist, t->d_inl, t->d_dec, t->d_edges, t->d_err };
     for (void* x : p) if (x) hipFree(x);
-    t->d_state = nullptr; t->d_pose = nullptr; t->d_info = nullptr; t->d_img = t->d_obj = t->d_hist = nullptr; t->d_inl = t->d_dec = nullptr; t->d_edges = nullptr;
+    t->d_state = nullptr; t->d_pose = nullptr; t->d_info = nullptr; t->d_img = t->d_obj = t->d_hist = nullptr; t->d_inl = t->d_dec = nullptr; t->d_edges = nullptr; t->d_err = nullptr;
     t->d_cap = t->d_R = t->d_n = 0;
 }
 extern "C" void ssm_tracker_destroy(ssm_tracker* t) { if (t) { tracker_free_device(t); delete t; } }
@@ -81,7 +81,7 @@ static int tracker_ensure_device(ssm_tracker* t, int cap, int R, int n)
     bool ok = hipMalloc((void**)&t->d_state, sizeof(PnpState)) == hipSuccess && hipMalloc((void**)&t->d_pose, (size_t)n * 128) == hipSuccess &&
               hipMalloc((void**)&t->d_info, (size_t)n * sizeof(ssm_track_info)) == hipSuccess && hipMalloc((void**)&t->d_img, mc * 8) == hipSuccess &&
               hipMalloc((void**)&t->d_obj, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_hist, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_inl, mc) == hipSuccess &&
-              hipMalloc((void**)&t->d_dec, mc) == hipSuccess && hipMalloc((void**)&t->d_edges, mc * sizeof(ssm_pnp::Edge)) == hipSuccess;
+              hipMalloc((void**)&t->d_dec, mc) == hipSuccess && hipMalloc(&t->d_edges, mc * k_pnp_edge_bytes()) == hipSuccess && hipMalloc((void**)&t->d_err, mc * sizeof(double2)) == hipSuccess;
     if (!ok) { tracker_free_device(t); t->err = "device allocation for the pose chain failed"; return SSM_E_NOMEM; }
     t->d_cap = cap; t->d_R = R; t->d_n = n;
     return SSM_OK;
@@ -160,10 +160,13 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             if (hipMemcpyAsync(t->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the tracker state failed");
             PnpChainArgs a; a.kps = seq->kps; a.pos3d = seq->pos3d; a.matches = seq->matches; a.nmatch = seq->nmatch; a.hist_pos3d = t->d_hist;
             a.cap = cap; a.R = R; a.f_begin = f; a.f_end = n; a.max_lost = t->prm.max_lost_frame; a.cam = cam;
-            a.state = t->d_state; a.pose_out = t->d_pose; a.info_out = t->d_info; a.img = t->d_img; a.obj = t->d_obj; a.inl = t->d_inl; a.dec = t->d_dec; a.edges = t->d_edges;
+            a.state = t->d_state; a.pose_out = t->d_pose; a.info_out = t->d_info; a.img = t->d_img; a.obj = t->d_obj; a.inl = t->d_inl; a.dec = t->d_dec; a.ledges = (LEdge*)t->d_edges; a.err = t->d_err; a.edges_in_lds = 0;
             if (k_pnp_chain(a, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain launch failed");
             if (hipMemcpyAsync(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain failed");
             const int stop = hs.stopped_at;
+#ifdef SSM_PNP_PROF
+            fprintf(stderr, "pnp chain %d frames: clocks gather %lld fused %lld algebra %lld chi %lld update %lld solve(total) %lld; fused passes %lld chi passes %lld\n", stop - f, hs.prof[0], hs.prof[1], hs.prof[2], hs.prof[3], hs.prof[4], hs.prof[5], hs.prof[6], hs.prof[7]);
+#endif
             if (stop <= f || stop > n) TFAIL(t, SSM_E_HIP, "pose chain returned an invalid frame range");
             if (hipMemcpy(pose_out + (size_t)f * 16, t->d_pose + (size_t)f * 16, (size_t)(stop - f) * 128, hipMemcpyDeviceToHost) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose download failed");
             std::vector<ssm_track_info> inf(stop - f);
