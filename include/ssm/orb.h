@@ -44,8 +44,11 @@ public:
         auto key = make_pair((const void*)this, make_pair(w, h));
         auto it = devs.find(key);
         if (it == devs.end()) it = devs.emplace(key, unique_ptr<ssm::Device>(new ssm::Device(parameterReader.deviceConfig(w, h)))).first;
+        lastDevice() = it->second.get();
         return *it->second;
     }
+    // the context this thread used last (nullptr before its first detectFeatures / match): PnPSolver::solvePnP runs on it
+    static ssm::Device*& lastDevice() { thread_local ssm::Device* d = nullptr; return d; }
 protected:
     const ParameterReader& parameterReader;
     double knn_match_ratio = 0.8;

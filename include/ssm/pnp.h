@@ -18,6 +18,7 @@ class PnPSolver {
 public:
     PnPSolver(const ParameterReader& para, const OrbFeature& orbFeature) : parameterReader(para), orb(orbFeature) {
         min_inliers = para.getData<int>("pnp_min_inliers", 10); min_match = para.getData<int>("pnp_min_matches", 15);
+        on_device = para.getData<int>("pnp_device", 1) != 0;                  // (not a reference parameter) 0: always solve on the host; same bits either way
     }
     // img: pixels in frame 2; obj: the same points in frame 1 (camera frame); transform: initial value in, estimate out (src/pnp.cpp:5-118)
     bool solvePnP(const vector<cv::Point2f>& img, const vector<cv::Point3f>& obj, const CAMERA_INTRINSIC_PARAMETERS& camera,
@@ -26,11 +27,18 @@ public:
         const int n = (int)img.size();
         vector<float> im((size_t)2 * n + 2), ob((size_t)3 * n + 3);
         for (int i = 0; i < n; i++) { im[2 * i] = img[i].x; im[2 * i + 1] = img[i].y; ob[3 * i] = obj[i].x; ob[3 * i + 1] = obj[i].y; ob[3 * i + 2] = obj[i].z; }
-        vector<unsigned char> inl((size_t)n + 1); vector<ssm_pnp::Edge> edges((size_t)n + 1);
+        vector<unsigned char> inl((size_t)n + 1);
         ssm_pnp::Camera cam; cam.fx = camera.fx; cam.fy = camera.fy; cam.cx = camera.cx; cam.cy = camera.cy;
         double T[16]; for (int k = 0; k < 16; k++) T[k] = transform.data()[k];
         int success = 0;
-        ssm_pnp::solve(im.data(), ob.data(), n, cam, min_inliers, T, inl.data(), edges.data(), &success);
+        ssm::Device* dev = on_device ? OrbFeature::lastDevice() : nullptr;
+        if (dev) {                                                               // one 1024-thread block of libssm_hip.so (kernels_pnp.hip): ~3 x the host core
+            const double kc[4] = {camera.fx, camera.fy, camera.cx, camera.cy}; int m = 0;
+            dev->check(ssm_pnp_solve(dev->ctx(), im.data(), ob.data(), n, kc, min_inliers, T, inl.data(), &m, &success), "ssm_pnp_solve");
+        } else {
+            vector<ssm_pnp::Edge> edges((size_t)n + 1);
+            ssm_pnp::solve(im.data(), ob.data(), n, cam, min_inliers, T, inl.data(), edges.data(), &success);
+        }
         for (int i = 0; i < n; i++) if (inl[i]) inliersIndex.push_back(i);
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) transform(r, c) = T[c * 4 + r];
         return success != 0;
@@ -56,6 +64,6 @@ public:
 protected:
     const ParameterReader& parameterReader;
     const OrbFeature& orb;
-    int min_inliers = 10, min_match = 30;
+    int min_inliers = 10, min_match = 30; bool on_device = true;
 };
 }  // namespace rgbd_tutor

@@ -247,6 +247,16 @@ typedef struct { double f, cu, cv, base, inlier_threshold; int32_t reweighting, 
 int ssm_vo_estimate(ssm_ctx* ctx, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
                     double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success);
 
+/* ---- PnPSolver::solvePnP (reference src/pnp.cpp:5-118) for ONE correspondence list, on the device -----------------------------------
+ * The per-frame caller's entry point (Tracker::trackRefFrame, src/track.cpp:166-175; PnPSolver::solvePnPLazy, src/pnp.cpp:120-226): img = n x 2
+ * pixels in frame 2, obj = n x 3 points in frame 1's camera frame ((0,0,0) = no depth: skipped as pnp.cpp:34 does), cam = (fx, fy, cx, cy),
+ * T = column-major 4 x 4, initial value in, estimate out.  inliers (n bytes, may be NULL) = the flag vector as pnp.cpp keeps it (SURVEY.md
+ * Appendix A quirk 14), *n_inliers = the number of set flags, *success (may be NULL) = the reference's return value (n > min_inliers: the
+ * vector's LENGTH is what pnp.cpp:115 tests).  One 1024-thread block of kernels_pnp.hip; the result is the same bits as ssm_pnp::solve of
+ * include/ssm/pnp_core.h on the host (lane-ordered sums, polynomial sin / cos) and as oracle/pnp.c.  n <= 65535. */
+int ssm_pnp_solve(ssm_ctx* ctx, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16],
+                  uint8_t* inliers, int* n_inliers, int* success);
+
 /* ---- device-resident batched stereo path (BASELINE.json configs[3]): n frames of a rectified stereo sequence, all DEVICE pointers.
  * The reference walks the KITTI sequence one frame at a time: FrameReader::next() computes the depth of the current pair with SGBM
  * (src/rgbdframe.cpp:64-116, src/stereo.cpp:11-30), Tracker::estimateVO builds a QuadFeatureMatch on (current left, current right, previous left,

@@ -38,6 +38,13 @@ def main():
     rows.append(("ssm_moving_mask", *timeit(lambda: ctx.moving_mask(sem))))
     rows.append((f"ssm_backproject (depth + rgb + semantic in, {len(cloud)} points out)", *timeit(lambda: ctx.generate_point_cloud(dep, bgr, sem, T))))
     rows.append((f"ssm_voxel_filter ({len(cloud)} points, leaf 0.1)", *timeit(lambda: ctx.voxel_filter(cloud, 0.1))))
+    # solvePnP on a tracker frame's correspondence list: 5 reference frames x ~600 matches with depth, 10 % outliers (tests/test_pnp.py's generator)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_pnp import _case, _pose                                   # noqa: E402
+    pimg, pobj, _ = _case(10, 3000, 10, 7, 0.5)
+    kcam = (CAM[2], CAM[3], CAM[0], CAM[1]); T0 = _pose(0.01, 0.0, -0.01, (0.01, 0.0, 0.02))
+    rows.append(("ssm_pnp_solve (3000 correspondences: PnPSolver::solvePnP, four rounds of optimize(10))", *timeit(lambda: ctx.pnp_solve(pimg, pobj, kcam, T0), n=10, warm=2)))
+    pnp_row = len(rows) - 1
     try:
         from semantic_slam_mapping_amd import segnet_model
         for l, (wt, sc, sh) in enumerate(segnet_model.make_weights(1234)):
@@ -46,15 +53,17 @@ def main():
     except Exception as e:                       # pragma: no cover
         rows.append((f"ssm_segnet_forward: {e}", float("nan"), float("nan")))
     per_frame = rows[0][1] + 5 * rows[1][1] + rows[3][1]
+    with_pnp = per_frame + rows[pnp_row][1]
     with open(out, "w") as f:
-        f.write("# r02: latency of the synchronous host-pointer calls (INTEGRATION.md s.1), one 640x480 frame, MI355X\n\n"
+        f.write("# r03: latency of the synchronous host-pointer calls (INTEGRATION.md s.1), one 640x480 frame, MI355X\n\n"
                 "Each call copies its inputs over PCIe, launches its kernels, waits and copies the results back: this is what the reference's per-frame classes\n"
                 "(`OrbFeature::detectFeatures`, `OrbFeature::match`, `Mapper::generatePointCloud`, `pcl::VoxelGrid`) pay when they call once per frame.  The batched\n"
                 "device-resident path (`ssm_seq_process`, what bench.py measures) amortises all of it.\n\n| call | median ms | best ms |\n|---|---:|---:|\n")
         for name, med, best in rows:
             f.write(f"| {name} | {med:.3f} | {best:.3f} |\n")
         f.write(f"\nA tracker frame = detectFeatures + 5 x match + generatePointCloud = **{per_frame:.2f} ms** through these calls "
-                f"({1e3 / per_frame:.0f} frames/s per host thread); the voxel filter runs on the mapper's own thread.\n")
+                f"({1e3 / per_frame:.0f} frames/s per host thread), **{with_pnp:.2f} ms** with the frame's solvePnP on the device "
+                f"({1e3 / with_pnp:.0f} frames/s); the voxel filter runs on the mapper's own thread.\n")
     ctx.close()
 
 

@@ -108,6 +108,7 @@ SYMBOLS = {
     "ssm_sgbm": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "ssm_stereo_depth": (_I, [_P, _P, _P, _I, _I, _I, _P] + [_D] * 8 + [_P, _P]),
     "ssm_vo_estimate": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P]),
+    "ssm_pnp_solve": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P]),
     "ssm_segnet_num_layers": (_I, []),
     "ssm_segnet_layer_shape": (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ssm_segnet_set_layer": (_I, [_P, _I, _P, _P, _P]),

@@ -286,6 +286,17 @@ class Context:
         self._chk(self.lib.ssm_vo_estimate(self.h, _ptr(m), len(m), _ptr(prm), _ptr(samples), len(samples), _ptr(tr), _ptr(inl), len(inl), C.byref(n), C.byref(ok)))
         return bool(ok.value), tr, inl[:n.value].copy()
 
+    def pnp_solve(self, img, obj, cam, T0, min_inliers=10):
+        """PnPSolver::solvePnP (src/pnp.cpp:5-118) on the device: img n x 2 pixels in frame 2, obj n x 3 points in frame 1's camera frame, cam = (fx, fy, cx, cy),
+        T0 = 4 x 4 initial transform.  Returns (success, T 4 x 4, inlier flags uint8[n] as pnp.cpp keeps them, number of set flags)."""
+        img = np.ascontiguousarray(img, np.float32).reshape(-1, 2); obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+        assert len(img) == len(obj)
+        camv = np.ascontiguousarray(cam, np.float64).reshape(4)
+        T = np.ascontiguousarray(np.asarray(T0, np.float64).reshape(4, 4).T).copy()          # column-major
+        inl = np.zeros(max(len(img), 1), np.uint8); n = C.c_int(0); ok = C.c_int(0)
+        self._chk(self.lib.ssm_pnp_solve(self.h, _ptr(img), _ptr(obj), len(img), _ptr(camv), int(min_inliers), _ptr(T), _ptr(inl), C.byref(n), C.byref(ok)))
+        return bool(ok.value), T.T.copy(), inl[:len(img)].copy(), n.value
+
     def gftt(self, img, max_corners=1000, quality=0.04, min_distance=8.0):
         img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
         pts = np.zeros((max_corners, 2), np.float32); n = C.c_int(0)

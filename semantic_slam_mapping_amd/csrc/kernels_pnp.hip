@@ -349,21 +349,47 @@ pnp_chain_kernel(PnpChainArgs a)
 #endif
     }
 }
+// ---- PnPSolver::solvePnP alone (ssm_pnp_solve): the same pc_solve on a caller's correspondence list
+__global__ void __launch_bounds__(PC_T)
+pnp_solve_kernel(PnpSolveArgs a)
+{
+    __shared__ PcShared sh;
+    extern __shared__ __align__(16) unsigned char pc_dyn[];
+    LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;
+    if (threadIdx.x < 16) sh.T[threadIdx.x] = a.T[threadIdx.x];
+    __syncthreads();
+    const int m = pc_solve(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
+    __syncthreads();
+    if (threadIdx.x < 16) a.T[threadIdx.x] = sh.T[threadIdx.x];
+    if (threadIdx.x == 0) *a.n_inliers = m;
+}
+static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const void* fn, size_t* dyn_set)
+{
+    if (nedges > 65535) return hipErrorInvalidValue;                             // ids are 16-bit in LEdge::meta
+    const size_t need = nedges * sizeof(LEdge);
+    *in_lds = need + sizeof(PcShared) + 1024 <= 160 * 1024 ? 1 : 0;              // the edge list in LDS when it fits beside the static part (160 KB per CU)
+    *dyn = *in_lds ? need : 0;
+    if (*dyn > *dyn_set) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn);
+        if (e != hipSuccess) return e;
+        *dyn_set = *dyn;
+    }
+    return hipSuccess;
+}
+hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
+{
+    PnpSolveArgs a = a_in; size_t dyn; static size_t dyn_set = 0;
+    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel), &dyn_set);
+    if (e != hipSuccess) return e;
+    pnp_solve_kernel<<<1, PC_T, dyn, s>>>(a);
+    return hipGetLastError();
+}
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
 hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
-    // the edge list in LDS when R * cap edges fit beside the static part (160 KB per CU); ids are 16-bit in LEdge::meta
-    PnpChainArgs a = a_in;
-    if ((size_t)a.R * a.cap > 65535) return hipErrorInvalidValue;
-    const size_t need = (size_t)a.R * a.cap * sizeof(LEdge);
-    a.edges_in_lds = need + sizeof(PcShared) + 1024 <= 160 * 1024 ? 1 : 0;
-    const size_t dyn = a.edges_in_lds ? need : 0;
-    static size_t dyn_set = 0;
-    if (dyn > dyn_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        dyn_set = dyn;
-    }
+    PnpChainArgs a = a_in; size_t dyn; static size_t dyn_set = 0;
+    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_chain_kernel), &dyn_set);
+    if (e != hipSuccess) return e;
     pnp_chain_kernel<<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();
 }

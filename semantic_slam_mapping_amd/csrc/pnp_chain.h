@@ -24,4 +24,10 @@ struct PnpChainArgs {
     int edges_in_lds;                                // set by k_pnp_chain
 };
 hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s);
+// one solvePnP on the device (ssm_pnp_solve): n correspondences, T (16 doubles, device) in / out
+struct PnpSolveArgs {
+    const float *img, *obj; int n; ssm_pnp::Camera cam; double* T; uint8_t *inl, *dec; struct LEdge* ledges; double2* err; int32_t* n_inliers;
+    int edges_in_lds;                                // set by k_pnp_solve
+};
+hipError_t k_pnp_solve(const PnpSolveArgs& a, hipStream_t s);
 size_t k_pnp_edge_bytes(void);

@@ -3,6 +3,7 @@
 // moves caller data and enqueues the kernels of kernels_*.hip on the context stream.  There is NO CPU fallback: if
 // HIP is unusable ssm_create fails with SSM_E_NODEVICE / SSM_E_HIP.
 #include "ssm_internal.h"
+#include "pnp_chain.h"
 #include <rccl/rccl.h>
 #include <cmath>
 #include <cfloat>
@@ -1730,6 +1731,39 @@ extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, con
         if (res[0] > cap) FAIL(c, SSM_E_CAPACITY, "inlier buffer too small (need " + std::to_string(res[0]) + ")");
         HIPCHK(c, hipMemcpy(inliers, p + o_inl, (size_t)res[0] * 4, hipMemcpyDeviceToHost));
     }
+    return SSM_OK;
+}
+
+// PnPSolver::solvePnP (reference src/pnp.cpp:5-118) for one correspondence list: the block of kernels_pnp.hip that the pose chain runs per frame
+extern "C" int ssm_pnp_solve(ssm_ctx* c, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16],
+                             uint8_t* inliers, int* n_inliers, int* success)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || !cam || !T || !n_inliers || (n && (!img || !obj))) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (n > 65535) FAIL(c, SSM_E_CAPACITY, "at most 65535 correspondences");
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t ne = (size_t)(n > 0 ? n : 1);
+    const size_t o_img = 0, o_obj = o_img + al(ne * 8), o_T = o_obj + al(ne * 12), o_inl = o_T + 256, o_dec = o_inl + al(ne), o_le = o_dec + al(ne),
+                 o_err = o_le + al(ne * k_pnp_edge_bytes()), o_n = o_err + al(ne * 16), total = o_n + 256;
+    int r = ensure_scratch(c, total); if (r) return r;
+    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
+    if (n) { HIPCHK(c, hipMemcpyAsync(p + o_img, img, (size_t)n * 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipMemcpyAsync(p + o_obj, obj, (size_t)n * 12, hipMemcpyHostToDevice, s)); }
+    HIPCHK(c, hipMemcpyAsync(p + o_T, T, 128, hipMemcpyHostToDevice, s));
+    PnpSolveArgs a; a.img = (const float*)(p + o_img); a.obj = (const float*)(p + o_obj); a.n = n;
+    a.cam.fx = cam[0]; a.cam.fy = cam[1]; a.cam.cx = cam[2]; a.cam.cy = cam[3];
+    a.T = (double*)(p + o_T); a.inl = p + o_inl; a.dec = p + o_dec; a.ledges = (LEdge*)(p + o_le); a.err = (double2*)(p + o_err); a.n_inliers = (int32_t*)(p + o_n); a.edges_in_lds = 0;
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
+    prof_begin(c, "pnp");
+    HIPCHK(c, k_pnp_solve(a, s));
+    prof_end(c);
+    int32_t m = 0;
+    HIPCHK(c, hipMemcpyAsync(T, p + o_T, 128, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&m, p + o_n, 4, hipMemcpyDeviceToHost, s));
+    if (inliers && n) HIPCHK(c, hipMemcpyAsync(inliers, p + o_inl, (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_inliers = m;
+    if (success) *success = n > min_inliers;                   // pnp.cpp:115 tests the flag vector's LENGTH (quirk 14)
     return SSM_OK;
 }
 

@@ -1,0 +1,57 @@
+"""ssm_pnp_solve: PnPSolver::solvePnP (/root/reference/src/pnp.cpp:5-118) as one 1024-thread block on the device -- the kernel the bulk tracker's pose chain
+runs per frame, exposed for the per-frame caller (Tracker::trackRefFrame, src/track.cpp:166-175).  One numeric contract (include/ssm/pnp_core.h: lane-ordered
+sums, polynomial sin / cos), so the comparison with oracle/pnp.c and with the committed vectors of the independent Python restatement is byte for byte."""
+import os
+import numpy as np
+import pytest
+from test_pnp import CAM, _case, _pose, ROOT
+
+pytestmark = pytest.mark.gpu
+KCAM = (CAM[2], CAM[3], CAM[0], CAM[1])            # (fx, fy, cx, cy)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, width=640, height=480, max_batch=1)
+    yield c
+    c.close()
+
+
+def _check(c, oracle, img, obj, T0, min_inliers=10):
+    ok_o, T_o, inl_o = oracle.pnp_solve(img, obj, CAM, T0, min_inliers=min_inliers)
+    ok_d, T_d, flags, m = c.pnp_solve(img, obj, KCAM, T0, min_inliers=min_inliers)
+    assert ok_d == ok_o and m == len(inl_o)
+    assert np.flatnonzero(flags).tolist() == inl_o.tolist()
+    assert T_d.tobytes() == T_o.tobytes()
+    return T_d, inl_o
+
+
+@pytest.mark.parametrize("seed,n,outlier_every,zero_every,noise", [(1, 200, 10, 0, 0.0), (2, 300, 7, 5, 0.3), (3, 40, 3, 4, 0.5), (4, 12, 0, 0, 0.0), (5, 8, 2, 3, 0.0),
+                                                                   (6, 0, 0, 0, 0.0), (7, 1, 0, 0, 0.0), (8, 1024, 9, 11, 0.4), (9, 1025, 9, 0, 0.4), (10, 3100, 6, 7, 0.8)])
+def test_device_pnp_equals_oracle(ctx, oracle, seed, n, outlier_every, zero_every, noise):
+    img, obj, Tgt = _case(seed, n, outlier_every, zero_every, noise)
+    T0 = _pose(0.0, 0.0, 0.0, (0.0, 0.0, 0.0)) if seed % 2 else _pose(0.01, 0.0, -0.01, (0.01, 0.0, 0.02))
+    T, inl = _check(ctx, oracle, img, obj, T0)
+    if seed == 1:
+        assert np.abs(T - Tgt).max() < 1e-4 and len(inl) == 180
+
+
+def test_edge_list_in_global_memory_when_it_does_not_fit_in_lds(ctx, oracle):
+    """6250 edges of 24 bytes fit beside the static LDS; 9000 do not: the same passes run on the list in global memory"""
+    img, obj, Tgt = _case(21, 9000, 8, 13, 0.5)
+    T, inl = _check(ctx, oracle, img, obj, np.eye(4))
+    assert np.abs(T - Tgt).max() < 5e-3 and len(inl) > 7000
+
+
+@pytest.mark.parametrize("name", ["exact", "outliers", "nodepth", "lanes", "few", "farinit"])
+def test_device_pnp_equals_committed_vectors(ctx, name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pnp.npz"))
+    ok, T, flags, m = ctx.pnp_solve(g[name + "_img"], g[name + "_obj"], KCAM, g[name + "_T0"])
+    assert int(ok) == int(g[name + "_ok"][0]) and np.flatnonzero(flags).tolist() == g[name + "_inl"].tolist() and T.tobytes() == g[name + "_T"].tobytes()
+
+
+def test_bad_arguments(ctx):
+    from semantic_slam_mapping_amd.api import SsmError
+    with pytest.raises(SsmError):
+        ctx.pnp_solve(np.zeros((70000, 2), np.float32), np.zeros((70000, 3), np.float32), KCAM, np.eye(4))
