@@ -363,23 +363,19 @@ pnp_solve_kernel(PnpSolveArgs a)
     if (threadIdx.x < 16) a.T[threadIdx.x] = sh.T[threadIdx.x];
     if (threadIdx.x == 0) *a.n_inliers = m;
 }
-static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const void* fn, size_t* dyn_set)
+static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const void* fn)
 {
     if (nedges > 65535) return hipErrorInvalidValue;                             // ids are 16-bit in LEdge::meta
     const size_t need = nedges * sizeof(LEdge);
     *in_lds = need + sizeof(PcShared) + 1024 <= 160 * 1024 ? 1 : 0;              // the edge list in LDS when it fits beside the static part (160 KB per CU)
     *dyn = *in_lds ? need : 0;
-    if (*dyn > *dyn_set) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn);
-        if (e != hipSuccess) return e;
-        *dyn_set = *dyn;
-    }
-    return hipSuccess;
+    // (set on every launch: the attribute belongs to the current device's copy of the function, and a process may hold contexts on several devices)
+    return *dyn > 48 * 1024 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn) : hipSuccess;
 }
 hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
 {
-    PnpSolveArgs a = a_in; size_t dyn; static size_t dyn_set = 0;
-    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel), &dyn_set);
+    PnpSolveArgs a = a_in; size_t dyn;
+    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel));
     if (e != hipSuccess) return e;
     pnp_solve_kernel<<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();
@@ -387,8 +383,8 @@ hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
 hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
-    PnpChainArgs a = a_in; size_t dyn; static size_t dyn_set = 0;
-    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_chain_kernel), &dyn_set);
+    PnpChainArgs a = a_in; size_t dyn;
+    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_chain_kernel));
     if (e != hipSuccess) return e;
     pnp_chain_kernel<<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();

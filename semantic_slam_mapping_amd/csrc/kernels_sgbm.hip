@@ -318,45 +318,65 @@ sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, i
 // S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
 // disparity table OpenCV fills while walking x from right to left, replacing an entry only by a strictly smaller cost) becomes
 // an atomicMin on the key (cost << 16 | 65535 - x): smallest cost, then the larger x, i.e. the entry the walk would have kept.
+// A 16-lane group takes WTA_PX consecutive pixels; D / 8 of its lanes are active, each with EIGHT disparities = one aligned 16-byte load per volume (a pixel's
+// D costs are D / 8 such words; the K = D / 16 u16 per lane of the path kernels would be 10-byte loads at 2-byte alignment for D = 80).  The 5 x WTA_PX loads of a
+// lane are issued together, then the pixels are reduced one after the other.
+#define WTA_PX 4
 template <int K>
 __global__ void __launch_bounds__(256)
 sgbm_wta(const uint16_t* __restrict__ L0, const uint16_t* __restrict__ L1, const uint16_t* __restrict__ L2, const uint16_t* __restrict__ L3,
          const uint16_t* __restrict__ L4, int w, int w1, int h, int minD, int minX1, int uniquenessRatio, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key)
 {
-    constexpr int D = 16 * K;
+    constexpr int D = 16 * K, NL = D / 8;                     // NL active lanes of a group
     {   const size_t fv = (size_t)blockIdx.y * w1 * h * D, fp = (size_t)blockIdx.y * w * h;      // blockIdx.y = frame
         L0 += fv; L1 += fv; L2 += fv; L3 += fv; L4 += fv; disp1 += fp; disp2key += fp; }
     __shared__ uint16_t srow[16][D];                          // S of the group's pixel, for the three sub-pixel taps
     const int gl = threadIdx.x >> 4, li = threadIdx.x & 15;
-    const long long gid = (long long)blockIdx.x * 16 + gl, npix = (long long)w1 * h;
-    const bool live = gid < npix;
-    const long long pid = live ? gid : 0;
-    const int y = (int)(pid / w1), x = (int)(pid - (long long)y * w1);
-    const size_t base = (size_t)pid * D + li * K;
-    int Sv[K], best = INT_MAX;                                 // (S << 8 | d): smallest S, then smallest d ("Sval < minS" scanning d upwards)
+    const bool act = li < NL;
+    const int lc = act ? li : 0;
+    const long long npix = (long long)w1 * h;
+    const long long p0 = ((long long)blockIdx.x * 16 + gl) * WTA_PX;
+    uint4 v[WTA_PX][5];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        Sv[k] = min((int)L0[base + k] + L1[base + k] + L2[base + k] + L3[base + k] + L4[base + k], SG_MAXC);
-        best = min(best, (Sv[k] << 8) | (li * K + k));
-        srow[gl][li * K + k] = (uint16_t)Sv[k];
+    for (int q = 0; q < WTA_PX; q++) {
+        const long long pid = p0 + q < npix ? p0 + q : npix - 1;
+        const size_t base = (size_t)pid * D + lc * 8;
+        v[q][0] = *reinterpret_cast<const uint4*>(L0 + base); v[q][1] = *reinterpret_cast<const uint4*>(L1 + base); v[q][2] = *reinterpret_cast<const uint4*>(L2 + base);
+        v[q][3] = *reinterpret_cast<const uint4*>(L3 + base); v[q][4] = *reinterpret_cast<const uint4*>(L4 + base);
     }
-    best = sg_rowmin(best);
-    const int minS = best >> 8, bestDisp = best & 255;
-    bool bad = false;
 #pragma unroll
-    for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
-    const unsigned long long bal = __ballot(bad);
-    const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;           // any lane of my 16-lane group
-    if (live && !rejected && li == 0) {
-        int d = bestDisp;
-        const int x2 = x + minX1 - d - minD;
-        if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));     // "disp2cost > minS" from MAX_COST
-        if (0 < d && d < D - 1) {
-            const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
-            const int denom2 = max(sm + sp - 2 * s0, 1);
-            d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
-        } else d *= SG_DISP_SCALE;
-        disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+    for (int q = 0; q < WTA_PX; q++) {
+        const bool live = p0 + q < npix;
+        const long long pid = live ? p0 + q : npix - 1;
+        const int y = (int)(pid / w1), x = (int)(pid - (long long)y * w1);
+        int Sv[8], best = INT_MAX;                             // (S << 8 | d): smallest S, then smallest d ("Sval < minS" scanning d upwards)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sh = 16 * (k & 1), j = k >> 1;
+            auto word = [&](const uint4& u) { return j == 0 ? u.x : j == 1 ? u.y : j == 2 ? u.z : u.w; };
+            Sv[k] = min((int)((word(v[q][0]) >> sh) & 0xFFFFu) + (int)((word(v[q][1]) >> sh) & 0xFFFFu) + (int)((word(v[q][2]) >> sh) & 0xFFFFu) +
+                        (int)((word(v[q][3]) >> sh) & 0xFFFFu) + (int)((word(v[q][4]) >> sh) & 0xFFFFu), SG_MAXC);
+            if (act) { best = min(best, (Sv[k] << 8) | (li * 8 + k)); srow[gl][li * 8 + k] = (uint16_t)Sv[k]; }
+        }
+        best = sg_rowmin(best);
+        const int minS = best >> 8, bestDisp = best & 255;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 8; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * 8 + k)) > 1;
+        const unsigned long long bal = __ballot(bad && act);
+        const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;           // any lane of my 16-lane group
+        if (live && !rejected && li == 0) {
+            int d = bestDisp;
+            const int x2 = x + minX1 - d - minD;
+            if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));     // "disp2cost > minS" from MAX_COST
+            if (0 < d && d < D - 1) {
+                const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
+                const int denom2 = max(sm + sp - 2 * s0, 1);
+                d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+            } else d *= SG_DISP_SCALE;
+            disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+        }
+        __builtin_amdgcn_wave_barrier();                       // (the group's next pixel overwrites srow: LDS operations of a wave execute in order)
     }
 }
 // left-right check: the disparity rounded down and up must both disagree with the right-image table to be dropped
@@ -607,7 +627,7 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
     if (e != hipSuccess) return e;
     const long long npix = (long long)w1 * h;
-    sgbm_wta<K><<<dim3((unsigned)((npix + 15) / 16), nb), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
+    sgbm_wta<K><<<dim3((unsigned)((npix + 16 * WTA_PX - 1) / (16 * WTA_PX)), nb), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
