@@ -565,11 +565,11 @@ __device__ __forceinline__ void fast_tile(const int frame, const int tile_id, co
     __shared__ int nlist, nsurv, nstage, gbase;
     const int tid = threadIdx.x, lane = tid & 63;
     int l = 0;
-    while (l + 1 < g.nlevels && tile_id >= g.L[l+1].tile_off) l++;
+    while (l + 1 < g.nlevels && tile_id >= g.L[l+1].ftile_off) l++;
     const LevelGeom& L = g.L[l];
-    const int t = tile_id - L.tile_off;
-    const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);
-    const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
+    const int t = tile_id - L.ftile_off;
+    const int trow = L.ftiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.fmulTX);
+    const int tx0 = SSM_EDGE + (t - trow * L.ftiles_x) * FT_W, ty0 = SSM_EDGE + trow * FT_H;      // the grid starts at the first position FAST may report
     const int w = L.w, h = L.h, stride = L.stride;
     const uint8_t* im = pyr + (size_t)frame * g.pyr_bytes + L.img_off;
     if (PASS == 2) {
@@ -780,13 +780,13 @@ fast_need_kernel(OrbGeom g, const int32_t* __restrict__ cellmax, int nframes, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int frame = i % ((nframes + 7) & ~7), tile_id = i / ((nframes + 7) & ~7);      // frame-fastest, like the tile launch
     bool need = false;
-    if (frame < nframes && tile_id < g.tiles_total) {
+    if (frame < nframes && tile_id < g.ftiles_total) {
         int l = 0;
-        while (l + 1 < g.nlevels && tile_id >= g.L[l+1].tile_off) l++;
+        while (l + 1 < g.nlevels && tile_id >= g.L[l+1].ftile_off) l++;
         const LevelGeom& L = g.L[l];
-        const int t = tile_id - L.tile_off;
-        const int trow = L.tiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.mulTX);
-        const int tx0 = (t - trow * L.tiles_x) * FT_W, ty0 = trow * FT_H;
+        const int t = tile_id - L.ftile_off;
+        const int trow = L.ftiles_x == 1 ? t : (int)__umulhi((uint32_t)t, L.fmulTX);
+        const int tx0 = SSM_EDGE + (t - trow * L.ftiles_x) * FT_W, ty0 = SSM_EDGE + trow * FT_H;      // the grid starts at the first position FAST may report
         auto cell_of = [](int gpos, int origin, uint32_t mul) { const int v = gpos - origin - 3; return v >= 0 ? (int)__umulhi((uint32_t)v, mul) : 0; };
         const int cx0 = cell_of(tx0, L.minBX, L.mulW), cy0 = cell_of(ty0, L.minBY, L.mulH);
         const int cx1 = min(cell_of(min(tx0 + FT_W - 1, L.w - 1), L.minBX, L.mulW), L.nCols - 1), cy1 = min(cell_of(min(ty0 + FT_H - 1, L.h - 1), L.minBY, L.mulH), L.nRows - 1);
@@ -814,7 +814,7 @@ fast_retry_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict
         __syncthreads();                                         // the next item re-initialises the tile's LDS state
     }
 }
-size_t k_fast_cellmax_ints(int nframes, const OrbGeom& g) { return (size_t)nframes * (g.cells_total + g.tiles_total) + 16; }
+size_t k_fast_cellmax_ints(int nframes, const OrbGeom& g) { return (size_t)nframes * (g.cells_total + g.ftiles_total) + 16; }
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s);
@@ -828,9 +828,9 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
     e = hipMemsetAsync(work - 1, 0, 4, s);
     if (e != hipSuccess) return e;
     const int n8 = (n + 7) & ~7;
-    fast_kernel<<<dim3(n8, g.tiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
-    fast_need_kernel<<<(n8 * g.tiles_total + 255) / 256, 256, 0, s>>>(g, cellmax, n, work);
-    const int pairs = n * g.tiles_total;
+    fast_kernel<<<dim3(n8, g.ftiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
+    fast_need_kernel<<<(n8 * g.ftiles_total + 255) / 256, 256, 0, s>>>(g, cellmax, n, work);
+    const int pairs = n * g.ftiles_total;
     fast_retry_kernel<<<pairs < 4096 ? pairs : 4096, 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, work);
     return hipGetLastError();
 }

@@ -161,7 +161,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         for (int v = SSM_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (um[v0] == um[v0 + 1]) ++v0; um[v] = v0; ++v0; }
         for (int v = 0; v <= SSM_HALF_PATCH; v++) g.umax[v] = um[v];
     }
-    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0, btiles = 0, bunits = 0, boff = 0;
+    int off = 0, cells = 0, cands = 0, sels = 0, tiles = 0, ftiles = 0, btiles = 0, bunits = 0, boff = 0;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.L[l];
         L.w = cv_round_f((float)c.width * inv[l]); L.h = cv_round_f((float)c.height * inv[l]);
@@ -175,6 +175,8 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         L.mulW = (uint32_t)(((1ull << 32) + L.wCell - 1) / L.wCell); L.mulH = (uint32_t)(((1ull << 32) + L.hCell - 1) / L.hCell);
         L.cell_off = cells; cells += L.nCols * L.nRows;
         L.tiles_x = (L.w + 127) / 128; L.mulTX = (uint32_t)(((1ull << 32) + L.tiles_x - 1) / L.tiles_x); L.tile_off = tiles; tiles += L.tiles_x * ((L.h + 31) / 32);
+        /* FAST reports nothing within SSM_EDGE of the border: its tile grid starts there (640x480, 8 levels: 233 tiles instead of 278) */
+        L.ftiles_x = (L.w - 2 * SSM_EDGE + 127) / 128; L.fmulTX = (uint32_t)(((1ull << 32) + L.ftiles_x - 1) / L.ftiles_x); L.ftile_off = ftiles; ftiles += L.ftiles_x * ((L.h - 2 * SSM_EDGE + 31) / 32);
         L.bt_x = (L.stride + 127) / 128; L.bt_off = btiles; btiles += L.bt_x; L.bt_units_off = bunits; bunits += (L.stride + 31) / 32;
         if (L.nCols * L.nRows >= (1 << 17)) { err = "too many FAST cells"; return SSM_E_INVAL; }
         L.nfeat = feat[l];
@@ -188,7 +190,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
         L.sf = sf[l];
     }
     g.bt_total = btiles; g.bt_units_total = bunits; g.blur_bytes = boff;
-    g.pyr_bytes = off; g.tiles_total = tiles; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
+    g.pyr_bytes = off; g.tiles_total = tiles; g.ftiles_total = ftiles; g.cells_total = cells; g.cand_total = cands; g.sel_total = sels;
     g.cap = c.orb_features + 3 * g.nlevels;
     return SSM_OK;
 }

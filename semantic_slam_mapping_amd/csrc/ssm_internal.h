@@ -16,7 +16,8 @@ struct LevelGeom {
     int img_off;               // byte offset inside one frame's pyramid buffer (16-B aligned)
     int nCols, nRows, wCell, hCell;   // FAST cell grid (ComputeKeyPointsOctTree, W = 30)
     int cell_off;              // first flattened cell id of this level
-    int tile_off, tiles_x;     // FAST tiles (128x32) of this level in the flattened grid
+    int tile_off, tiles_x;     // 128x32 tiles of the whole level image in the flattened grid (blur_kernel)
+    int ftile_off, ftiles_x;   // FAST tiles (128x32) of this level: they cover [SSM_EDGE, w - SSM_EDGE) x [SSM_EDGE, h - SSM_EDGE) only, the positions FAST may report
     int nfeat;                 // mnFeaturesPerLevel
     int cand_off, cand_cap;    // entries inside one frame's candidate buffer
     int sel_off, sel_cap;      // slots inside one frame's selected-keypoint staging (nfeat + 3)
@@ -24,7 +25,7 @@ struct LevelGeom {
     int nIni;                  // quad-tree root nodes
     float hX;                  // root node width
     float sf;                  // mvScaleFactor[level]
-    uint32_t mulTX;            // ceil(2^32 / tiles_x), same use
+    uint32_t mulTX, fmulTX;    // ceil(2^32 / tiles_x), ceil(2^32 / ftiles_x): same use
     int boff;                  // byte offset of the level inside one frame's BLURRED pyramid (tiled: see blur_off)
     int bt_off, bt_x, bt_units_off;   // blur_mfma_kernel: first 128-column strip of the level, strips of the level, first 32-column unit table
     uint32_t mulW, mulH;       // ceil(2^32 / wCell), ceil(2^32 / hCell): floor(n / cell) == __umulhi(n, mul) for n < 4096 (exact: n * (mul * cell - 2^32) < 2^32)
@@ -36,7 +37,7 @@ __host__ __device__ inline int blur_off(int boff, int stride, int x, int y) { re
 struct OrbGeom {
     int nlevels, W, H;
     int pyr_bytes;             // one frame's pyramid (all levels)
-    int cells_total, cand_total, sel_total, tiles_total;
+    int cells_total, cand_total, sel_total, tiles_total, ftiles_total;
     int blur_bytes;            // one frame's blurred pyramid
     int bt_total, bt_units_total;   // blur_mfma_kernel strips (= blocks) per frame, 32-column unit tables
     int cap;                   // output keypoints per frame (orb_features + 3*levels)
