@@ -472,6 +472,7 @@ __global__ void __launch_bounds__(256)
 sgbm_speckle_tile(const int16_t* __restrict__ img, int w, int h, int newVal, int maxDiff, int* __restrict__ parent, int* __restrict__ count)
 {
     __shared__ int lp[SPK_TW * SPK_TH];
+    __shared__ int lcnt[SPK_TW * SPK_TH];
     __shared__ int16_t val[SPK_TH][SPK_TW];
     { const size_t fp = (size_t)blockIdx.z * w * h; img += fp; parent += fp; count += fp; }        // blockIdx.z = frame: every frame has its own forest (indices inside the frame)
     const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH;
@@ -489,12 +490,27 @@ sgbm_speckle_tile(const int16_t* __restrict__ img, int w, int h, int newVal, int
         if (ly < SPK_TH - 1) { const int b = val[ly + 1][lx]; if (b != newVal && abs(v - b) <= maxDiff) lds_union(lp, i, i + SPK_TW); }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) {
-        const int ly = i / SPK_TW, lx = i - ly * SPK_TW, gx = tx0 + lx, gy = ty0 + ly;
+    // flatten; the size of every tile-local component is counted HERE (LDS atomics) and lands on its root pixel: the global pass that follows the edge
+    // unions then moves one number per tile-local root instead of chasing and counting every pixel
+    int myroot[(SPK_TW * SPK_TH) / 256];
+#pragma unroll
+    for (int k = 0; k < (SPK_TW * SPK_TH) / 256; k++) myroot[k] = lds_find(lp, threadIdx.x + 256 * k);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) lcnt[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (SPK_TW * SPK_TH) / 256; k++) {
+        const int i = threadIdx.x + 256 * k, ly = i / SPK_TW, lx = i - ly * SPK_TW;
+        if (tx0 + lx < w && ty0 + ly < h && val[ly][lx] != newVal) atomicAdd(&lcnt[myroot[k]], 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (SPK_TW * SPK_TH) / 256; k++) {
+        const int i = threadIdx.x + 256 * k, ly = i / SPK_TW, lx = i - ly * SPK_TW, gx = tx0 + lx, gy = ty0 + ly;
         if (gx >= w || gy >= h) continue;
-        const int root = lds_find(lp, i), ry = root / SPK_TW, rx = root - ry * SPK_TW;
+        const int root = myroot[k], ry = root / SPK_TW, rx = root - ry * SPK_TW;
         const int g = gy * w + gx;
-        parent[g] = (ty0 + ry) * w + tx0 + rx; count[g] = 0;
+        parent[g] = (ty0 + ry) * w + tx0 + rx; count[g] = root == i ? lcnt[i] : 0;          // > 0 exactly on the tile-local roots of valid components
     }
 }
 // the unions across tile edges: thread = one pixel of a tile's last column (links to x + 1) or last row (links to y + 1)
@@ -513,23 +529,18 @@ sgbm_speckle_edges(const int16_t* __restrict__ img, int w, int h, int newVal, in
     const int v = img[i], q = img[j];
     if (v != newVal && q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, j);
 }
+// after the edge unions: a tile-local root that was hooked under another root hands its count to the component's final root (only final roots receive, so a
+// hooked root's own count never changes while it is read), and points straight at it
 __global__ void __launch_bounds__(256)
-sgbm_speckle_count(const int16_t* __restrict__ img, int n, int newVal, int* __restrict__ parent, int* __restrict__ count)
+sgbm_speckle_count(int n, int* __restrict__ parent, int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    { const size_t fp = (size_t)blockIdx.y * n; img += fp; parent += fp; count += fp; }
-    const bool on = i < n && img[i] != newVal;
-    int r = -1;
-    if (on) { r = uf_find(parent, i); parent[i] = r; }
-    // neighbouring pixels mostly share a root: one atomic per distinct root of the wave, not per pixel
-    unsigned long long todo = __ballot(on);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lr = __shfl(r, leader, 64);
-        const unsigned long long same = __ballot(on && r == lr) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&count[lr], __popcll(same));
-        todo &= ~same;
-    }
+    { const size_t fp = (size_t)blockIdx.y * n; parent += fp; count += fp; }
+    if (i >= n) return;
+    const int c = count[i];
+    if (c == 0) return;                                       // not a tile-local root
+    const int r = uf_find(parent, i);
+    if (r != i) atomicAdd(&count[r], c);
 }
 __global__ void __launch_bounds__(256)
 sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleSize, const int* __restrict__ parent, const int* __restrict__ count)
@@ -537,7 +548,9 @@ sgbm_speckle_apply(int16_t* __restrict__ img, int n, int newVal, int maxSpeckleS
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     { const size_t fp = (size_t)blockIdx.y * n; img += fp; parent += fp; count += fp; }
     if (i >= n || img[i] == newVal) return;
-    if (count[parent[i]] <= maxSpeckleSize) img[i] = (int16_t)newVal;
+    int r = parent[i];                                        // the tile-local root, then (at most a few hops, compressed by the pass above) the final one
+    while (true) { const int p = parent[r]; if (p == r) break; r = p; }
+    if (count[r] <= maxSpeckleSize) img[i] = (int16_t)newVal;
 }
 // ------------------------------------------------------------------ disparity -> depth (rgbdframe.cpp:81-116)
 __global__ void __launch_bounds__(256)
@@ -712,7 +725,7 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
         sgbm_speckle_tile<<<dim3((w + SPK_TW - 1) / SPK_TW, (h + SPK_TH - 1) / SPK_TH, nb), 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent, count);
         const int nedge = ((w - 1) / SPK_TW) * h + ((h - 1) / SPK_TH) * w;
         if (nedge > 0) sgbm_speckle_edges<<<dim3((nedge + 255) / 256, nb), 256, 0, s>>>(disp_out, w, h, INVALID, SG_DISP_SCALE * p.speckleRange, parent);
-        sgbm_speckle_count<<<gb, 256, 0, s>>>(disp_out, n, INVALID, parent, count);
+        sgbm_speckle_count<<<gb, 256, 0, s>>>(n, parent, count);
         sgbm_speckle_apply<<<gb, 256, 0, s>>>(disp_out, n, INVALID, p.speckleWindowSize, parent, count);
     }
     return hipGetLastError();
