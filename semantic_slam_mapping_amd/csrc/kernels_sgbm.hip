@@ -527,7 +527,17 @@ sgbm_speckle_edges(const int16_t* __restrict__ img, int w, int h, int newVal, in
     else { const int u = t - nv, e = u / w; x = u - e * w; y = (e + 1) * SPK_TH - 1; dx = 0; dy = 1; }
     const int i = y * w + x, j = (y + dy) * w + x + dx;
     const int v = img[i], q = img[j];
-    if (v != newVal && q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, j);
+    if (!(v != newVal && q != newVal && abs(v - q) <= maxDiff)) return;
+    // Along an edge line most links repeat their neighbour's: if the previous pixel pair of the line (same two tiles) is linked too and both of this pair's
+    // pixels are connected to the previous pair's inside their tiles (adjacent along the line: the tile kernel has united them), this union is implied by that
+    // one.  Only the first link of every such run goes to the global forest (the long CAS / find chains on large planes came from the repeats).
+    const int along = dy ? x % SPK_TW : y % SPK_TH;           // position inside the tile along the line: 0 = the previous pair belongs to other tiles
+    if (along != 0) {
+        const int ip = dy ? i - 1 : i - w, jp = dy ? j - 1 : j - w;
+        const int vp = img[ip], qp = img[jp];
+        if (vp != newVal && qp != newVal && abs(vp - qp) <= maxDiff && abs(v - vp) <= maxDiff && abs(q - qp) <= maxDiff) return;
+    }
+    uf_union(parent, i, j);
 }
 // after the edge unions: a tile-local root that was hooked under another root hands its count to the component's final root (only final roots receive, so a
 // hooked root's own count never changes while it is read), and points straight at it
