@@ -52,6 +52,7 @@ struct StereoState {        // workspace of the stereo path (quad matcher, SGBM 
     uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
     double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
     void* sg_ws = nullptr; size_t sg_ws_bytes = 0; int* dmin = nullptr;       // SGBM workspace (sized for the frames per launch actually used)
+    void* sg_ws2 = nullptr; size_t sg_ws2_bytes = 0; int* dmin2 = nullptr;    // a second one: alternate sub-batches of a sequence run SGBM on two streams
     // sequence outputs (seq_cap frames)
     int seq_cap = 0;
     ssm_pmatch* quad = nullptr; int32_t* nquad = nullptr; float* corners = nullptr; int32_t* ncorners = nullptr; int16_t* disp = nullptr; uint16_t* depth = nullptr;
@@ -116,7 +117,7 @@ struct ssm_ctx {
     // SegNet
     struct SegNetState* seg = nullptr;
     // quad matcher
-    struct StereoState* stereo = nullptr; int stereo_B = 16;
+    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // SSM_SGBM_STREAMS=1: SGBM of all sub-batches on one stream
     // profiling
     bool profiling = false;
     uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
@@ -377,6 +378,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
     { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 64 ? 64 : b; }
+    { const char* e = getenv("SSM_SGBM_STREAMS"); if (e) c->stereo_sgbm_streams = atoi(e) >= 2 ? 2 : 1; }
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
@@ -422,7 +424,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->d_comm_counts) hipFree(c->d_comm_counts);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
-    for (hipStream_t st : {c->stream, c->stream2}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
+    for (hipStream_t st : {c->stream, c->stream2, c->stream3}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1372,7 +1374,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 static void stereo_free(StereoState* q)
 {
     void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
-                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
+                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->sg_ws2, q->dmin2, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
                   q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
 }
@@ -1432,16 +1434,18 @@ static int stereo_ensure_vo(ssm_ctx* c, int iters)
     q->vo_iters = iters;
     return SSM_OK;
 }
-static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb)
+static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, bool second = false)
 {
     StereoState* q = c->stereo;
     const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
-    if (need <= q->sg_ws_bytes) return SSM_OK;
+    void*& ws = second ? q->sg_ws2 : q->sg_ws; size_t& have = second ? q->sg_ws2_bytes : q->sg_ws_bytes;
+    if (second && !q->dmin2) DALLOC(c, q->dmin2, 64);
+    if (need <= have) return SSM_OK;
     HIPCHK(c, hipDeviceSynchronize());
-    if (q->sg_ws) hipFree(q->sg_ws);
-    q->sg_ws = nullptr; q->sg_ws_bytes = 0;
+    if (ws) hipFree(ws);
+    ws = nullptr; have = 0;
     uint8_t* p8; int r = dalloc(c, &p8, need); if (r) return r;
-    q->sg_ws = p8; q->sg_ws_bytes = need;
+    ws = p8; have = need;
     return SSM_OK;
 }
 static int sgbm_check_params(ssm_ctx* c, const ssm_sgbm_params* params, int w, int h)
@@ -1478,6 +1482,10 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
     // SGBM runs on the second context stream beside the chain; sub-batches follow each other on both streams without a join in between
     const bool two = (stages & SSM_STEREO_DEPTH) && (stages & SSM_STEREO_QUAD) && !c->serialize;
     if (two) { r = ensure_side_streams(c); if (r) return r; sd = c->stream2; HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
+    // ... and with more than one sub-batch SGBM alternates between TWO streams with a workspace each: the cost kernel and the small kernels of one
+    // sub-batch (LDS / latency-bound) run beside the scan-direction and winner-takes-all kernels of the other (HBM-bound)
+    const bool sg2 = two && n > B && c->stereo_sgbm_streams >= 2;
+    if (sg2) { r = stereo_ensure_sgbm(c, in->sgbm, B, true); if (r) return r; HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); }
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
     const bool prev0 = in->continue_sequence && q->have_prev;
     if (stages & SSM_STEREO_VO) HIPCHK(c, hipMemsetAsync(q->consumed, 0, 4, sq));
@@ -1509,14 +1517,17 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             prof_end(c);
         }
         if (stages & SSM_STEREO_DEPTH) {
-            struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sd);   // stage events on SGBM's stream
+            const bool alt = sg2 && ((f0 / B) & 1);
+            hipStream_t sg = alt ? c->stream3 : sd;
+            struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
             prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_ws, q->disp + (size_t)f0 * np, 0, sd));
-            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dmin, q->depth + (size_t)f0 * np, sd));
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, alt ? q->sg_ws2 : q->sg_ws, q->disp + (size_t)f0 * np, 0, sg));
+            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, alt ? q->dmin2 : q->dmin, q->depth + (size_t)f0 * np, sg));
             prof_end(c);
         }
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, sd)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
+    if (sg2) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
     if (n > 0) q->have_prev = (stages & SSM_STEREO_QUAD) != 0;
     if (out) {
         out->quad = q->quad; out->nquad = q->nquad; out->corners = q->corners; out->ncorners = q->ncorners; out->disp = q->disp; out->depth = q->depth;
