@@ -314,6 +314,85 @@ sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, i
         run_group(Cb, t0 + SG_UN);
     }
 }
+// ------------------------------------------------------------------ the column direction with the winner pass inside
+// sgbm_path<K, 2> that does not write its L volume: it runs behind the other four directions, reads their L at the pixel it has just aggregated, and does
+// sgbm_wta's work for that pixel on the spot (every pixel of the volume lies on exactly one column path).  The L volume of this direction is never written
+// and the winner pass reads four volumes instead of five: 140 MB of 1.22 GB per 1241 x 376 x 80 frame.
+#define SGW_UN 6
+template <int K>
+__global__ void __launch_bounds__(256)
+sgbm_col_wta(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ L0, const uint16_t* __restrict__ L1, const uint16_t* __restrict__ L3,
+             const uint16_t* __restrict__ L4, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
+             int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key)
+{
+    constexpr int D = 16 * K, NP = (K + 1) / 2;
+    {   const size_t fv = (size_t)blockIdx.y * w1 * h * D, fp = (size_t)blockIdx.y * w * h;      // blockIdx.y = frame
+        C_all += fv; L0 += fv; L1 += fv; L3 += fv; L4 += fv; disp1 += fp; disp2key += fp; }
+    __shared__ uint16_t srow[16][D];                          // S of the group's pixel, for the three sub-pixel taps
+    const int gl = threadIdx.x >> 4, li = threadIdx.x & 15;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = g < w1;
+    const int x = live ? g : 0;
+    constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;
+    uint32_t L[NP]; int minPrev = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    uint32_t Va[SGW_UN][5][NP], Vb[SGW_UN][5][NP];           // [step][C, L0, L1, L3, L4][pairs]
+    auto load_group = [&](uint32_t (&V)[SGW_UN][5][NP], int t0) {
+#pragma unroll
+        for (int u = 0; u < SGW_UN; u++) {
+            const size_t off = ((size_t)min(t0 + u, h - 1) * w1 + x) * D + li * K;
+            sg_load_pk<K>(V[u][0], C_all + off); sg_load_pk<K>(V[u][1], L0 + off); sg_load_pk<K>(V[u][2], L1 + off);
+            sg_load_pk<K>(V[u][3], L3 + off); sg_load_pk<K>(V[u][4], L4 + off);
+        }
+    };
+    auto run_group = [&](const uint32_t (&V)[SGW_UN][5][NP], int t0) {
+#pragma unroll
+        for (int u = 0; u < SGW_UN; u++) {
+            const int y = t0 + u;
+            if (y >= h) break;                                    // wave-uniform
+            sg_step_pk<K>(L, minPrev, V[u][0], P1P1, P2);
+            // ---- the winner pass for pixel (y, x): S = min(32767, L0 + L1 + L2 + L3 + L4)
+            int Sv[K], best = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int sh = 16 * (k & 1), j = k >> 1;
+                Sv[k] = min((int)((L[j] >> sh) & 0xFFFFu) + (int)((V[u][1][j] >> sh) & 0xFFFFu) + (int)((V[u][2][j] >> sh) & 0xFFFFu) +
+                            (int)((V[u][3][j] >> sh) & 0xFFFFu) + (int)((V[u][4][j] >> sh) & 0xFFFFu), SG_MAXC);
+                best = min(best, (Sv[k] << 8) | (li * K + k));
+                srow[gl][li * K + k] = (uint16_t)Sv[k];
+            }
+            best = sg_rowmin(best);
+            const int minS = best >> 8, bestDisp = best & 255;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
+            const unsigned long long bal = __ballot(bad);
+            const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;       // any lane of my 16-lane group
+            if (live && !rejected && li == 0) {
+                int d = bestDisp;
+                const int x2 = x + minX1 - d - minD;
+                if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));
+                if (0 < d && d < D - 1) {
+                    const int sm = srow[gl][d - 1], s0 = srow[gl][d], sp = srow[gl][d + 1];
+                    const int denom2 = max(sm + sp - 2 * s0, 1);
+                    d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+                } else d *= SG_DISP_SCALE;
+                disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+            }
+            __builtin_amdgcn_wave_barrier();                   // (the next step overwrites srow: LDS operations of a wave execute in order)
+        }
+    };
+    load_group(Va, 0);
+    for (int t0 = 0; t0 < h; t0 += 2 * SGW_UN) {
+        load_group(Vb, t0 + SGW_UN);
+        run_group(Va, t0);
+        if (t0 + SGW_UN >= h) break;
+        load_group(Va, t0 + 2 * SGW_UN);
+        run_group(Vb, t0 + SGW_UN);
+    }
+}
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
 // S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
 // disparity table OpenCV fills while walking x from right to left, replacing an entry only by a strictly smaller cost) becomes
@@ -638,19 +717,34 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     hipError_t e = hipEventRecord(st.fork, s);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipStreamWaitEvent(st.s[i], st.fork, 0);
     if (e != hipSuccess) return e;
-    sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, s>>>(C, Lv[0], w1, h, P1, P2);
-    sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[4], w1, h, P1, P2);
-    sgbm_path<K, 1><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[1]>>>(C, Lv[1], w1, h, P1, P2);
-    sgbm_path<K, 2><<<dim3(blocks(w1), nb), 256, 0, st.s[2]>>>(C, Lv[2], w1, h, P1, P2);
-    sgbm_path<K, 3><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipEventRecord(st.done[i], st.s[i]); if (e == hipSuccess) e = hipStreamWaitEvent(s, st.done[i], 0); }
-    if (e != hipSuccess) return e;
     const size_t np = (size_t)w * h, npb = np * nb;
-    sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
-    e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
-    if (e != hipSuccess) return e;
     const long long npix = (long long)w1 * h;
-    sgbm_wta<K><<<dim3((unsigned)((npix + 16 * WTA_PX - 1) / (16 * WTA_PX)), nb), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10, disp_tmp, disp2key);
+    const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
+    static const bool fuse = [] { const char* v = getenv("SSM_SGBM_FUSE_WTA"); return !(v && atoi(v) == 0); }();      // SSM_SGBM_FUSE_WTA=0: five L volumes + sgbm_wta
+    if (fuse) {
+        // four directions on the four side streams; the column direction follows on `s` with the winner pass inside (sgbm_col_wta)
+        sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[0], w1, h, P1, P2);
+        sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[1]>>>(C, Lv[4], w1, h, P1, P2);
+        sgbm_path<K, 1><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[2]>>>(C, Lv[1], w1, h, P1, P2);
+        sgbm_path<K, 3><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
+        sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
+        e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipEventRecord(st.done[i], st.s[i]); if (e == hipSuccess) e = hipStreamWaitEvent(s, st.done[i], 0); }
+        if (e != hipSuccess) return e;
+        sgbm_col_wta<K><<<dim3(blocks(w1), nb), 256, 0, s>>>(C, Lv[0], Lv[1], Lv[3], Lv[4], w, w1, h, P1, P2, p.minDisparity, minX1, uniq, disp_tmp, disp2key);
+    } else {
+        sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, s>>>(C, Lv[0], w1, h, P1, P2);
+        sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[4], w1, h, P1, P2);
+        sgbm_path<K, 1><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[1]>>>(C, Lv[1], w1, h, P1, P2);
+        sgbm_path<K, 2><<<dim3(blocks(w1), nb), 256, 0, st.s[2]>>>(C, Lv[2], w1, h, P1, P2);
+        sgbm_path<K, 3><<<dim3(blocks(w1 + h - 1), nb), 256, 0, st.s[3]>>>(C, Lv[3], w1, h, P1, P2);
+        for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipEventRecord(st.done[i], st.s[i]); if (e == hipSuccess) e = hipStreamWaitEvent(s, st.done[i], 0); }
+        if (e != hipSuccess) return e;
+        sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
+        e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
+        if (e != hipSuccess) return e;
+        sgbm_wta<K><<<dim3((unsigned)((npix + 16 * WTA_PX - 1) / (16 * WTA_PX)), nb), 256, 0, s>>>(Lv[0], Lv[1], Lv[2], Lv[3], Lv[4], w, w1, h, p.minDisparity, minX1, uniq, disp_tmp, disp2key);
+    }
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
