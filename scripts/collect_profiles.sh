@@ -16,7 +16,7 @@ if [ "$1" = "stats" ]; then
   tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
 elif [ "$1" = "pmc_stereo" ]; then
   rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
-  A="--stereo --frames 64 --steps 1 --warmup 0 --no-cpu --serial-only"
+  A="--stereo --stereo-batch 32 --frames 64 --steps 1 --warmup 0 --no-cpu --serial-only"
   timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq_st -o runc -- python3 bench.py $A > $O/p_sq_st.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_st -o runc -- python3 bench.py $A > $O/p_fetch_st.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_st -o runc -- python3 bench.py $A > $O/p_write_st.log 2>&1

@@ -81,7 +81,7 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
 // STRONGER corner in cv::goodFeaturesToTrack's walk (value descending, then raster index ascending)
 __global__ void __launch_bounds__(256)
 gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* __restrict__ maxord_all, double quality, unsigned long long* __restrict__ keys_all,
-                    int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all)
+                    int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all, uint32_t* __restrict__ bits_all, int bits_words)
 {
     const int f = blockIdx.y;
     const float* eig = eig_all + (size_t)f * w * h; unsigned long long* keys = keys_all + (size_t)f * cap; int* count = count_all + f;
@@ -115,7 +115,12 @@ gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* 
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(count, s_cnt);
     __syncthreads();
-    if (keep) { const int k = s_base + woff + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) { keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); cand_at[i] = k + 1; } }
+    bool listed = false;
+    if (keep) { const int k = s_base + woff + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) { keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); cand_at[i] = k + 1; listed = true; } }
+    // the same map as one bit per pixel (bit i of the frame's bit image; a wave covers 64 consecutive pixels = two whole words, written whether set or not):
+    // gftt_deps_kernel looks at 17 x 17 pixels per candidate and ~97 % of them hold nothing
+    const unsigned long long lb = __ballot(listed);
+    if (lane == 0) { uint32_t* bw = bits_all + (size_t)f * bits_words + (i >> 5); bw[0] = (uint32_t)lb; bw[1] = (uint32_t)(lb >> 32); }
 }
 // minDistance selection (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one unless an already kept corner lies closer than
 // minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds of local decisions, because a corner's fate depends only on
@@ -137,12 +142,14 @@ gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* 
 #define GFTT_ROUNDS 12
 __global__ void __launch_bounds__(256)
 gftt_deps_kernel(int w, int h, const unsigned long long* __restrict__ keys_all, const int* __restrict__ count_all, int cap, float min_distance,
-                 const int* __restrict__ cand_at_all, uint32_t* __restrict__ deps_all, uint8_t* __restrict__ depn_all, uint8_t* __restrict__ state_all)
+                 const int* __restrict__ cand_at_all, const uint32_t* __restrict__ bits_all, int bits_words, uint32_t* __restrict__ deps_all,
+                 uint8_t* __restrict__ depn_all, uint8_t* __restrict__ state_all)
 {
     const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nc = min(count_all[f], cap);
     if (i >= nc) return;
     const int* cand_at = cand_at_all + (size_t)f * w * h; const unsigned long long* keys = keys_all + (size_t)f * cap;
+    const uint32_t* bits = bits_all + (size_t)f * bits_words;
     uint32_t* deps = deps_all + ((size_t)f * cap + i) * GFTT_DEPS;
     const unsigned long long key = keys[i];
     const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
@@ -150,17 +157,41 @@ gftt_deps_kernel(int w, int h, const unsigned long long* __restrict__ keys_all, 
     const float md2 = min_distance * min_distance;
     const int rad = (int)ceilf(min_distance);                 // |dx|, |dy| < minDistance
     int n = 0;
-    for (int dy = -rad; dy <= rad; dy++) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= h) continue;
-        for (int dx = -rad; dx <= rad; dx++) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
-            if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
-            const int j = cand_at[yy * w + xx] - 1;
-            if (j < 0 || keys[j] < key) continue;             // no candidate there, or a weaker one
-            if (n < GFTT_DEPS) deps[n] = (uint32_t)j;
-            n++;
+    if (rad <= 15) {
+        // a row of the window is <= 31 consecutive bits of the frame's bit image (two words); pixels outside the row or the disc are masked off, the set bits
+        // are visited in ascending dx: the same candidates in the same order as the full scan below
+        for (int dy = -rad; dy <= rad; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= h) continue;
+            const int x0 = x - rad, base = yy * w + x0;           // (may be negative at the first pixels of the image: those bits are masked)
+            const int wq = base >> 5, sh = base & 31;
+            const uint32_t w0 = wq >= 0 ? bits[wq] : 0u, w1 = wq + 1 >= 0 && wq + 1 < bits_words ? bits[wq + 1] : 0u;
+            uint32_t m = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh);
+            m &= (2 * rad + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (2 * rad + 1)) - 1u);
+            while (m) {
+                const int b = __ffs((int)m) - 1; m &= m - 1;
+                const int dx = b - rad, xx = x + dx;
+                if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+                if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+                const int j = cand_at[yy * w + xx] - 1;
+                if (j < 0 || keys[j] < key) continue;         // (j < 0 cannot happen: the bit says there is one) a weaker one
+                if (n < GFTT_DEPS) deps[n] = (uint32_t)j;
+                n++;
+            }
+        }
+    } else {
+        for (int dy = -rad; dy <= rad; dy++) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= h) continue;
+            for (int dx = -rad; dx <= rad; dx++) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= w || (dx == 0 && dy == 0)) continue;
+                if ((float)dx * (float)dx + (float)dy * (float)dy >= md2) continue;
+                const int j = cand_at[yy * w + xx] - 1;
+                if (j < 0 || keys[j] < key) continue;         // no candidate there, or a weaker one
+                if (n < GFTT_DEPS) deps[n] = (uint32_t)j;
+                n++;
+            }
         }
     }
     depn_all[(size_t)f * cap + i] = (uint8_t)min(n, 255);
@@ -515,6 +546,7 @@ hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
 // cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  Workspace (GfttWork): eig nb*w*h floats; cand_at
 // nb*w*h ints, ZERO on entry (left zeroed); keys / kept nb*cap u64; deps nb*cap*GFTT_DEPS u32; depn / state nb*cap bytes; maxord / count / nkept nb ints;
 // overflow 1 int (set when a frame has more than cap candidates)
+size_t k_quad_gftt_bits_words(int w, int h) { return ((size_t)w * h + 255) / 256 * 8 + 2; }      // whole blocks of gftt_collect_kernel + the word a window may read past the end
 size_t k_quad_gftt_deps_per_candidate() { return GFTT_DEPS; }
 hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s)
 {
@@ -525,9 +557,10 @@ hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quali
     if (e != hipSuccess) return e;
     const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
     mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, g.eig, g.maxord);
-    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at);
+    const int bw = (int)k_quad_gftt_bits_words(w, h);
+    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at, g.cand_bits, bw);
     const dim3 gc((cap + 255) / 256, nb);
-    gftt_deps_kernel<<<gc, 256, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.deps, g.depn, g.state);
+    gftt_deps_kernel<<<gc, 256, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.cand_bits, bw, g.deps, g.depn, g.state);
     for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<gc, 256, 0, s>>>(g.count, cap, g.deps, g.depn, g.state);
     gftt_finish_kernel<<<nb, 1024, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.deps, g.depn, g.state, g.kept, g.nkept, g.overflow);
     gftt_rank_kernel<<<gc, 256, 0, s>>>(g.kept, g.nkept, cap, w, max_corners, pts, stride, ncorner);

@@ -1373,7 +1373,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 // ---------------------------------------------------------------- stereo path: QuadFeatureMatch, StereoSGBM depth, VisualOdometryStereo
 static void stereo_free(StereoState* q)
 {
-    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
+    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.cand_bits, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
                   q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->sg_ws2, q->dmin2, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
                   q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
@@ -1400,6 +1400,7 @@ static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
     DALLOC(c, g.eig, (size_t)B * np); DALLOC(c, g.cand_at, (size_t)B * np); DALLOC(c, g.keys, (size_t)B * q->keycap); DALLOC(c, g.kept, (size_t)B * q->keycap);
     DALLOC(c, g.deps, (size_t)B * q->keycap * k_quad_gftt_deps_per_candidate()); DALLOC(c, g.depn, (size_t)B * q->keycap); DALLOC(c, g.state, (size_t)B * q->keycap);
     HIPCHK(c, hipMemset(g.cand_at, 0, (size_t)B * np * 4));      // gftt_finish_kernel keeps the map zeroed between calls
+    DALLOC(c, g.cand_bits, (size_t)B * k_quad_gftt_bits_words(w, h));
     DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
     g.overflow = q->overflow;
     HIPCHK(c, hipMemset(q->overflow, 0, 4));

@@ -146,8 +146,9 @@ hipError_t k_segnet_color(const uint8_t* ids, int n, int sw, int sh, int dw, int
 // Slot 0 = the carried previous frame, slot 1 + f = frame f of the sub-batch.
 struct QuadBatch { const uint8_t* pyr; const int16_t* der; size_t slot_elems; int B1; int w[4], h[4], off[4]; };
 hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s);
-struct GfttWork { float* eig; int* cand_at; unsigned long long *keys, *kept; uint32_t* deps; uint8_t *depn, *state; int *maxord, *count, *nkept, *overflow; int cap; };
+struct GfttWork { float* eig; int* cand_at; uint32_t* cand_bits; /* one bit per pixel: cand_at != 0; k_quad_gftt_bits_words(w, h) words per frame */ unsigned long long *keys, *kept; uint32_t* deps; uint8_t *depn, *state; int *maxord, *count, *nkept, *overflow; int cap; };
 size_t k_quad_gftt_deps_per_candidate();
+size_t k_quad_gftt_bits_words(int w, int h);
 hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s);
 hipError_t k_quad_lk(const QuadBatch& q, const float* prev_pts, int n, float* next_pts, uint8_t* status, float* err, int max_count, float eps2, float min_eig_thr, hipStream_t s);
 hipError_t k_quad_track(const QuadBatch& q, int nb, float* pts, int stride, const int* ncorner, const int* has_prev, void* out, int* nout, hipStream_t s);

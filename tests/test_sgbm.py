@@ -106,3 +106,22 @@ def test_gpu_sgbm_kitti_size(ctx, oracle):
     left, right, _ = stereo_pair(376, 1241, 11, planes=((12, None), (30, (0.4, 0.9, 0.2, 0.5)), (60, (0.5, 0.95, 0.6, 0.8))), noise=5)
     g = ctx.sgbm(left, right)
     assert np.array_equal(g, oracle.sgbm(left, right, oracle.sgbm_params()))
+
+
+@pytest.mark.gpu
+def test_gpu_sgbm_five_volume_form_stays_equal(oracle, tmp_path):
+    """SSM_SGBM_FUSE_WTA=0 (read once per process): the five scan directions write their own L volumes and sgbm_wta reads them -- the form the fused
+    column + winner kernel replaced; it stays in the library for A/B runs and must keep producing the oracle's bits"""
+    import os, subprocess, sys
+    left, right, _ = stereo_pair(72, 260, 5, noise=4)
+    ref = oracle.sgbm(left, right, oracle.sgbm_params(64, 7))
+    np.savez(tmp_path / "in.npz", left=left, right=right)
+    code = ("import numpy as np, semantic_slam_mapping_amd as ssm\n"
+            f"g = np.load(r'{tmp_path / 'in.npz'}')\n"
+            "c = ssm.Context(0, width=640, height=480, max_batch=1)\n"
+            "d = c.sgbm(g['left'], g['right'], c.sgbm_params(numberOfDisparities=64, SADWindowSize=7))\n"
+            f"np.save(r'{tmp_path / 'out.npy'}', d); c.close()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSM_SGBM_FUSE_WTA="0", PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "out.npy"), ref)
