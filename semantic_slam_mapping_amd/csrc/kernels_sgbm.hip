@@ -269,6 +269,18 @@ sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, i
     for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
     const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
     const int steps = ROW ? w1 : h;
+    // a diagonal is inside the image only for part of the rows (x(y) = o + rx y in [0, w1)): the wave walks the union of its four paths' ranges -- neighbouring
+    // offsets, so nearly the same range -- instead of all h rows (1616 diagonals x 376 rows is 30 % more steps than the image has pixels); a path still
+    // outside the image inside that range starts from the zeroed border as before
+    int t_lo = 0, t_hi = steps;
+    if (MODE == 1 || MODE == 3) {
+        const int g0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4;      // the wave's first path
+        const int oa = (MODE == 1 ? g0 - (h - 1) : g0), ob = oa + 3;              // offsets of its first and last path (paths beyond npaths: clamped later, any range is fine)
+        if (MODE == 1) { t_lo = max(0, -ob); t_hi = min(h, w1 - oa); }
+        else { t_lo = max(0, oa - (w1 - 1)); t_hi = min(h, ob + 1); }
+        if (g0 + 3 >= npaths) { t_lo = 0; t_hi = steps; }                         // a wave with clamped (dead) groups: path 0's range
+        t_lo = __builtin_amdgcn_readfirstlane(t_lo); t_hi = __builtin_amdgcn_readfirstlane(max(t_hi, t_lo));
+    }
     // the costs of SG_UN steps are loaded together and the next group's loads are issued before the current group's steps run (two register sets):
     // a path pays the memory latency once per 2 SG_UN steps at most, and the addresses of every path are known in advance (x(t) = o + rx t)
     constexpr int SG_UN = 16;
@@ -285,7 +297,7 @@ sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, i
 #pragma unroll
         for (int u = 0; u < SG_UN; u++) {
             const int t = t0 + u;
-            if (t >= steps) break;                                // wave-uniform
+            if (t >= t_hi) break;                                 // wave-uniform
             int x, y; pix_of(t, x, y);
             const bool in = ROW || (x >= 0 && x < w1);
             if (!in) {                                            // outside the image the predecessor is OpenCV's zeroed border
@@ -305,11 +317,11 @@ sgbm_path(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ Lout_all, i
             }
         }
     };
-    load_group(Ca, 0);
-    for (int t0 = 0; t0 < steps; t0 += 2 * SG_UN) {
+    load_group(Ca, t_lo);
+    for (int t0 = t_lo; t0 < t_hi; t0 += 2 * SG_UN) {
         load_group(Cb, t0 + SG_UN);
         run_group(Ca, t0);
-        if (t0 + SG_UN >= steps) break;
+        if (t0 + SG_UN >= t_hi) break;
         load_group(Ca, t0 + 2 * SG_UN);
         run_group(Cb, t0 + SG_UN);
     }
