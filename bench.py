@@ -309,6 +309,7 @@ def main():
                     "fronto-parallel plane at 2 m, 2 x 1 px per frame: every frame tracks); 'synthetic' = the configs[1] stream itself (its depth pattern does not move "
                     "with the texture, so PnP loses track often: exercises LOST / lostRecover)")
     ap.add_argument("--pnp-device", type=int, default=0, help="--solve-poses: 1 = the pose chain on the GPU (one block), 0 = on one host core; same bits")
+    ap.add_argument("--pose-threads", type=int, default=1, help="--solve-poses with the rigid stream: its independent 20-frame sequences are tracked by this many trackers from as many host threads (device chains on their own streams: one CU each)")
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
@@ -317,6 +318,10 @@ def main():
         sys.exit(spawn_ranks(args.gpus))              # nothing below has run: no torch import, no HIP call in this process
     if args.stereo:
         return stereo_main(args)
+    if args.solve_poses and args.pose_threads > 1:
+        # HIP multiplexes streams onto 4 hardware queues by default and two chains that share a queue run one after the other (scripts/tracker_concurrency.py):
+        # the runtime reads this before its first call, so it is set before torch is imported
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
     import numpy as np
     import torch
@@ -500,37 +505,58 @@ def main():
                 sem[k * H * W * 3:(k + 1) * H * W * 3] = torch.roll(s0, shifts=(k, 2 * k), dims=(0, 1)).reshape(-1)
             dep[: PF * H * W] = 2000
             torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ctx.map_clear()
-        o2 = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None, None, PF, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
-        ctx.sync(); t2 = time.perf_counter()
-        if args.pose_stream == "rigid":
-            # the reference's odometry chain is not stable on a planar scene (depth error feeds back through the reference poses: it diverges after ~25
-            # frames, host class and bulk tracker alike), so the rigid stream is tracked as independent 20-frame sequences: views of the call's outputs at
-            # a frame offset, the tracker reset in between (its first frame is then an initFirstFrame)
-            from semantic_slam_mapping_amd._lib import SeqOutDev
-            CH = 20; ps, ins = [], []
-            for a0 in range(0, PF, CH):
-                nn = min(CH, PF - a0); cap_, R_ = o2.cap, o2.R
-                v = SeqOutDev(o2.kps + a0 * cap_ * 28, o2.desc + a0 * cap_ * 32, o2.pos3d + a0 * cap_ * 12, o2.nkp + a0 * 4, o2.matches + a0 * R_ * cap_ * 16,
-                              o2.nmatch + a0 * R_ * 4, o2.npoints + a0 * 4, cap_, R_)
+        extra = None
+        for rep in range(2):                             # pass 0 warms (tracker scratch, first-use costs), pass 1 is reported
+            t1 = time.perf_counter()
+            ctx.map_clear()
+            o2 = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None, None, PF, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
+            ctx.sync(); t2 = time.perf_counter()
+            if args.pose_stream == "rigid":
+                # the reference's odometry chain is not stable on a planar scene (depth error feeds back through the reference poses: it diverges after ~25
+                # frames, host class and bulk tracker alike), so the rigid stream is tracked as independent 20-frame sequences: views of the call's outputs at
+                # a frame offset, the tracker reset in between (its first frame is then an initFirstFrame)
+                from semantic_slam_mapping_amd._lib import SeqOutDev
+                CH = 20
+                def view(a0):
+                    cap_, R_ = o2.cap, o2.R
+                    return SeqOutDev(o2.kps + a0 * cap_ * 28, o2.desc + a0 * cap_ * 32, o2.pos3d + a0 * cap_ * 12, o2.nkp + a0 * 4, o2.matches + a0 * R_ * cap_ * 16,
+                                     o2.nmatch + a0 * R_ * 4, o2.npoints + a0 * 4, cap_, R_)
+                starts = list(range(0, PF, CH)); walked = {}
+                def walk(tr, mine):
+                    for a0 in mine:
+                        tr.reset()
+                        walked[a0] = tr.run(view(a0), min(CH, PF - a0))
+                NT = max(1, min(args.pose_threads, len(starts)))
+                if NT == 1:
+                    walk(trk, starts)
+                else:
+                    # independent sequences side by side: a tracker per host thread, each chain (one block = one CU) on a stream of its own
+                    import threading
+                    if extra is None:
+                        extra = [ssm.Tracker(ctx, use_device=bool(args.pnp_device), own_stream=True) for _ in range(NT)]
+                    th = [threading.Thread(target=walk, args=(extra[k], starts[k::NT])) for k in range(NT)]
+                    for t_ in th: t_.start()
+                    for t_ in th: t_.join()
+                    pose_stats = [e.stats() for e in extra]
+                poses_s, info_s = np.concatenate([walked[a0][0] for a0 in starts]), np.concatenate([walked[a0][1] for a0 in starts])
+            else:
                 trk.reset()
-                p_, i_ = trk.run(v, nn); ps.append(p_); ins.append(i_)
-            poses_s, info_s = np.concatenate(ps), np.concatenate(ins)
-        else:
-            poses_s, info_s = trk.run(o2, PF)
-        t3 = time.perf_counter()
-        pdev = torch.from_numpy(np.ascontiguousarray(poses_s.transpose(0, 2, 1)).reshape(PF * 16)).to(dev)
-        ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pdev.data_ptr(), PF, stages=ssm.api.STAGE_MAP)
-        nv = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
-        t4 = time.perf_counter()
-        trk_stats = trk.stats()
+                poses_s, info_s = trk.run(o2, PF)
+            t3 = time.perf_counter()
+            pdev = torch.from_numpy(np.ascontiguousarray(poses_s.transpose(0, 2, 1)).reshape(PF * 16)).to(dev)
+            ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pdev.data_ptr(), PF, stages=ssm.api.STAGE_MAP)
+            nv = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
+            t4 = time.perf_counter()
+            dvf, hsf = trk.stats()
+            if args.pose_stream == "rigid" and NT > 1:
+                dvf, hsf = sum(a for a, _ in pose_stats), sum(b for _, b in pose_stats)
+            dvf, hsf = dvf // (rep + 1), hsf // (rep + 1)                # the counters run over both passes
+            solve_info = {"frames": PF, "stream": args.pose_stream, "frames_per_s": round(PF / (t4 - t1), 1), "frames_on_device_chain": dvf, "frames_on_host_path": hsf, "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)", "sequences_in_flight": (NT if args.pose_stream == "rigid" else 1),
+                          "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
+                          "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
+                          "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}
         trk.close()
-        dvf, hsf = trk_stats
-        solve_info = {"frames": PF, "stream": args.pose_stream, "frames_per_s": round(PF / (t4 - t1), 1), "frames_on_device_chain": dvf, "frames_on_host_path": hsf, "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)",
-                      "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
-                      "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
-                      "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}
+        for e in (extra or []): e.close()
         ctx.map_clear()
     frames_all = F
     if world > 1:

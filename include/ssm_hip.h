@@ -181,6 +181,10 @@ typedef struct {
     int32_t pnp_min_inliers;  /* pnp_min_inliers (include/pnp.h; 10): only PnPSolver's unused return value depends on it */
     int32_t use_device;       /* 1: solve the pose chain of regular frames on the GPU (one block, kernels_pnp.hip); 0: on the host.  Same bits. */
     double  first_pose[16];   /* T_f_w the first frame arrives with (initFirstFrame leaves it alone), column-major */
+    int32_t own_stream;       /* 1: the device chain of this tracker runs on a stream of its own (behind what the context's stream holds at the time of the
+                                 call), so that trackers of independent sequences, driven from different host threads, solve side by side -- a chain is one
+                                 block = one CU of 256.  0: on the context's stream */
+    int32_t pad;
 } ssm_tracker_params;
 typedef struct { int32_t state; /* Tracker::getState() after the frame: 1 OK, 2 LOST */ int32_t tracked; /* 1: the frame joined refFrames */
                  int32_t n_matches; /* correspondences handed to solvePnP (-1: none gathered) */ int32_t n_inliers; } ssm_track_info;

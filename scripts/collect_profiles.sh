@@ -9,6 +9,8 @@ if [ "$1" = "stats" ]; then
   timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 > $O/line_stereo.json 2> $O/line_stereo.err
   timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 0 > $O/line_poses_host.json 2> $O/line_poses_host.err
   timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 1 > $O/line_poses_dev.json 2> $O/line_poses_dev.err
+  timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 1 --pose-threads 16 > $O/line_poses_dev16.json 2> $O/line_poses_dev16.err
+  timeout 120 python3 scripts/tracker_concurrency.py 1 2 4 8 16 > $O/tracker_concurrency.txt 2>&1
   rm -rf $O/p_stats $O/p_seg $O/p_st
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1

@@ -17,5 +17,7 @@ tail -1 $O/line_segnet.json > profiles/${R}_bench_line_segnet.json
 tail -1 $O/line_stereo.json > profiles/${R}_bench_line_stereo.json
 [ -s $O/line_poses_host.json ] && tail -1 $O/line_poses_host.json > profiles/${R}_bench_line_poses_host.json
 [ -s $O/line_poses_dev.json ] && tail -1 $O/line_poses_dev.json > profiles/${R}_bench_line_poses_device.json
+[ -s $O/line_poses_dev16.json ] && tail -1 $O/line_poses_dev16.json > profiles/${R}_bench_line_poses_device_16seq.json
+[ -s $O/tracker_concurrency.txt ] && cp $O/tracker_concurrency.txt profiles/${R}_tracker_concurrency.txt
 [ -s $O/per_call.md ] && cp $O/per_call.md profiles/${R}_per_call_latency.md
 echo "profiles/${R}_* regenerated"

@@ -56,7 +56,7 @@ class StereoOutDev(C.Structure):
 
 
 class TrackerParams(C.Structure):
-    _fields_ = [("max_lost_frame", C.c_int32), ("ref_frames", C.c_int32), ("pnp_min_inliers", C.c_int32), ("use_device", C.c_int32), ("first_pose", C.c_double * 16)]
+    _fields_ = [("max_lost_frame", C.c_int32), ("ref_frames", C.c_int32), ("pnp_min_inliers", C.c_int32), ("use_device", C.c_int32), ("first_pose", C.c_double * 16), ("own_stream", C.c_int32), ("pad", C.c_int32)]
 
 
 # every symbol include/ssm_hip.h declares: name -> (restype, argtypes)

@@ -100,11 +100,11 @@ class Tracker:
     """ssm_tracker: Tracker::updateFrame (RGB-D mode, src/track.cpp:8-36,140-212) for all frames of a seq_process call -- the bulk consumer of the
     match tables.  run(out, n) -> (poses n x 4 x 4 = T_f_w per frame, info structured array)."""
 
-    def __init__(self, ctx, max_lost_frame=10, pnp_min_inliers=10, use_device=False, first_pose=None):
+    def __init__(self, ctx, max_lost_frame=10, pnp_min_inliers=10, use_device=False, first_pose=None, own_stream=False):
         self.ctx = ctx; self.lib = ctx.lib
         p = TrackerParams()
         self.lib.ssm_tracker_params_default(C.byref(p))
-        p.max_lost_frame = max_lost_frame; p.ref_frames = ctx.R; p.pnp_min_inliers = pnp_min_inliers; p.use_device = int(use_device)
+        p.max_lost_frame = max_lost_frame; p.ref_frames = ctx.R; p.pnp_min_inliers = pnp_min_inliers; p.use_device = int(use_device); p.own_stream = int(own_stream)
         if first_pose is not None:
             fp = np.ascontiguousarray(np.asarray(first_pose, np.float64).reshape(4, 4).T).reshape(16)       # column-major
             for i in range(16):

@@ -11,6 +11,9 @@
 // window -- and stops behind the first frame that fails to track; the host path (same arithmetic) takes over until the deque is regular again.
 #include "pnp_chain.h"
 #include <cfloat>
+#include <mutex>
+#include <set>
+#include <utility>
 
 using namespace ssm_pnp;
 #define PC_T 1024
@@ -369,8 +372,17 @@ static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const voi
     const size_t need = nedges * sizeof(LEdge);
     *in_lds = need + sizeof(PcShared) + 1024 <= 160 * 1024 ? 1 : 0;              // the edge list in LDS when it fits beside the static part (160 KB per CU)
     *dyn = *in_lds ? need : 0;
-    // (set on every launch: the attribute belongs to the current device's copy of the function, and a process may hold contexts on several devices)
-    return *dyn > 48 * 1024 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn) : hipSuccess;
+    // the attribute belongs to the current device's copy of the function (a process may hold contexts on several devices): set once per device and kernel, to
+    // the largest size any list in LDS can have -- not per launch: the call can serialise against kernels in flight, and trackers on their own streams launch
+    // while other chains run
+    if (*dyn <= 48 * 1024) return hipSuccess;
+    static std::mutex mu; static std::set<std::pair<int, const void*>> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PcShared) - 1024);
+    if (e == hipSuccess) done.insert({dev, fn});
+    return e;
 }
 hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
 {

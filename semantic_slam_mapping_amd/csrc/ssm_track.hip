@@ -29,6 +29,7 @@ struct ssm_tracker {
     PnpState* d_state = nullptr; double* d_pose = nullptr; ssm_track_info* d_info = nullptr; float *d_img = nullptr, *d_obj = nullptr, *d_hist = nullptr;
     uint8_t *d_inl = nullptr, *d_dec = nullptr; void* d_edges = nullptr; double2* d_err = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
     long device_frames = 0, host_frames = 0;
+    hipStream_t own = nullptr; hipEvent_t ev = nullptr;      // own_stream: the chain's stream and the event that orders it behind the context's stream
 };
 static void iso_identity(double* T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
 
@@ -49,6 +50,10 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
     ssm_config cfg; ssm_internal_get_config(ctx, &cfg);
     t->cam = cfg.camera; t->ratio = cfg.knn_match_ratio;
     if (cfg.tracker_ref_frames != p->ref_frames) { delete t; return SSM_E_INVAL; }
+    if (p->own_stream && (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess)) {
+        if (t->own) hipStreamDestroy(t->own);
+        delete t; return SSM_E_HIP;
+    }
     ssm_tracker_reset(t);
     *out = t;
     return SSM_OK;
@@ -60,7 +65,13 @@ static void tracker_free_device(ssm_tracker* t)
     t->d_state = nullptr; t->d_pose = nullptr; t->d_info = nullptr; t->d_img = t->d_obj = t->d_hist = nullptr; t->d_inl = t->d_dec = nullptr; t->d_edges = nullptr; t->d_err = nullptr;
     t->d_cap = t->d_R = t->d_n = 0;
 }
-extern "C" void ssm_tracker_destroy(ssm_tracker* t) { if (t) { tracker_free_device(t); delete t; } }
+extern "C" void ssm_tracker_destroy(ssm_tracker* t)
+{
+    if (!t) return;
+    if (t->own) { hipStreamSynchronize(t->own); hipStreamDestroy(t->own); }
+    if (t->ev) hipEventDestroy(t->ev);
+    tracker_free_device(t); delete t;
+}
 extern "C" const char* ssm_tracker_last_error(const ssm_tracker* t) { return t ? t->err.c_str() : "null tracker"; }
 extern "C" int ssm_tracker_reset(ssm_tracker* t)
 {
@@ -151,6 +162,12 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             memcpy(hs.speed, t->speed, 128); memcpy(hs.last_pose, t->last_pose, 128);
             hs.nref = (int)t->refs.size(); hs.cnt_lost = t->cnt_lost; hs.stopped_at = n;
             hipStream_t st = (hipStream_t)ssm_stream(t->ctx);
+            if (t->own) {                                     // behind everything the context's stream holds now (the call that made `seq`), then on its own
+                // (an idle context stream needs no hand-over -- and a marker in its hardware queue would wait behind another tracker's chain whenever the
+                // runtime multiplexes the two streams onto one queue)
+                if (hipStreamQuery(st) != hipSuccess && (hipEventRecord(t->ev, st) != hipSuccess || hipStreamWaitEvent(t->own, t->ev, 0) != hipSuccess)) TFAIL(t, SSM_E_HIP, "stream hand-over failed");
+                st = t->own;
+            }
             for (int r = 0; r < hs.nref; r++) {
                 const int idx = (int)(t->refs[r].gidx - t->next_gidx);
                 hs.ref_idx[r] = idx; memcpy(hs.ref_pose[r], t->refs[r].pose, 128);

@@ -131,3 +131,47 @@ def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device):
             c.dev_free(dp)
     finally:
         c.dev_free(db); c.dev_free(dd); trk.close(); c.close()
+
+
+def test_trackers_on_their_own_streams_from_two_threads(oracle):
+    """own_stream = 1: two trackers driven from two host threads walk two independent sequences (views of one seq_process call) side by side, each chain on
+    a stream of its own; the poses are those of one tracker walking them one after the other"""
+    import threading
+    import semantic_slam_mapping_amd as ssm
+    from semantic_slam_mapping_amd._lib import SeqOutDev
+    c = ssm.Context(0, width=640, height=480, max_batch=8, camera=CAM)
+    try:
+        n, half = 16, 8
+        frames = [oracle.synth_frame(SEED, f) for f in range(2)]
+        base = frames[0][0]
+        bgr = np.stack([np.roll(base, (k % half, 2 * (k % half)), (0, 1)) for k in range(n)])      # two identical 8-frame panning sequences
+        dep = np.full((n, 480, 640), 2000, np.uint16)
+        db = c.dev_alloc(bgr.nbytes); dd = c.dev_alloc(dep.nbytes)
+        try:
+            c.h2d(db, bgr); c.h2d(dd, dep)
+            o = c.seq_process(db, dd, None, None, n, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
+            c.sync()
+            def view(a0):
+                return SeqOutDev(o.kps + a0 * o.cap * 28, o.desc + a0 * o.cap * 32, o.pos3d + a0 * o.cap * 12, o.nkp + a0 * 4, o.matches + a0 * o.R * o.cap * 16,
+                                 o.nmatch + a0 * o.R * 4, o.npoints + a0 * 4, o.cap, o.R)
+            one = ssm.Tracker(c, use_device=True)
+            ref = []
+            for a0 in (0, half):
+                one.reset(); ref.append(one.run(view(a0), half))
+            one.close()
+            trk = [ssm.Tracker(c, use_device=True, own_stream=True) for _ in range(2)]
+            got = [None, None]
+            def walk(k):
+                got[k] = trk[k].run(view(k * half), half)
+            th = [threading.Thread(target=walk, args=(k,)) for k in range(2)]
+            for t in th: t.start()
+            for t in th: t.join()
+            for k in range(2):
+                assert got[k] is not None and got[k][0].tobytes() == ref[k][0].tobytes() and got[k][1].tobytes() == ref[k][1].tobytes()
+                assert trk[k].stats()[0] >= half - 2                                # the chains ran on the device
+                trk[k].close()
+            assert ref[0][1]["tracked"].sum() >= half - 1
+        finally:
+            c.dev_free(db); c.dev_free(dd)
+    finally:
+        c.close()
