@@ -2,6 +2,7 @@
 """How far do pose chains of independent sequences overlap?  T trackers (own_stream = 1) from T host threads, one 20-frame sequence each.
 Usage (GPU box): python scripts/tracker_concurrency.py [T ...]"""
 import os, sys, time, threading
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # HIP multiplexes streams onto 4 hardware queues by default; two chains on one queue run one after the other.  GPU_MAX_HW_QUEUES=4 shows that
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
