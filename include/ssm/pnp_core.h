@@ -89,10 +89,27 @@ SSM_HD void edge_accumulate(const Edge& e, const Pose& P, const Camera& k, doubl
     double w = 1.0;
     if (e.robust) { double r0; huber(edge_chi2(e), delta, r0, w); }
     const double er[2] = {e.e0, e.e1};
+    // J[0][4] and J[1][3] are the literal zero: their products are +-0 and adding +-0 to a sum that started at +0 never changes it, so those 14 of the 54
+    // accumulations are skipped (the compiler may not: x * 0 is not 0 for every x); everything else in the order written
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int r = 0; r < 2; r++) {
         const double wr = -er[r] * w;
+        const int z = r == 0 ? 4 : 3;
         int q = 0;
-        for (int a = 0; a < 6; a++) { acc[21 + a] += J[r][a] * wr; for (int c = 0; c <= a; c++) acc[q++] += J[r][a] * w * J[r][c]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int a = 0; a < 6; a++) {
+            if (a == z) { q += a + 1; continue; }
+            acc[21 + a] += J[r][a] * wr;
+            const double jw = J[r][a] * w;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int c = 0; c <= a; c++) { if (c != z) acc[q] += jw * J[r][c]; q++; }
+        }
     }
 }
 // (H + lambda I) x = b with H given by its lower triangle, un-pivoted L D L^T (g2o: Eigen LDLT); false on a non-positive pivot
