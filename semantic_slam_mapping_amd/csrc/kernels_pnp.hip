@@ -2,8 +2,8 @@
 // for a run of consecutive frames of an ssm_seq_process call, ONE block of 1024 threads walking the frames in order.
 // The chain is serial by construction (frame f starts from frame f-1's pose and un-projects its reference frames' features with their solved poses);
 // what parallelism there is lives inside a frame: the correspondences of the <= tracker_ref_frames match tables (ordered compaction by block scans), and
-// every pass over the edges of the Levenberg iterations (chi2 pass, normal-equation pass) -- thread i owns edges i, i + 1024, ... and the sums follow the
-// LANE ORDER of include/ssm/pnp_core.h (wave butterfly, then the 16 wave totals in order), which is what makes the result the same bits as the host
+// every pass over the edges of the Levenberg iterations (chi2 pass; chi2 + normal equations in one pass) -- thread i owns edges i, i + 1024, ... and the sums
+// follow the LANE ORDER of include/ssm/pnp_core.h (64-lane neighbour-first tree, then the 16 group totals in order), which is what makes the result the same bits as the host
 // class and the oracle.  The small dense algebra (6 x 6 L D L^T, exp map, Levenberg bookkeeping) is wave 0's; the estimate, the system and the tracker's
 // state live in LDS, and so does the edge list (24 bytes per edge: the measurement and the point are floats to begin with) when it fits.
 // All matches / features stay on the device; the host orchestrator (ssm_track.hip) only moves the tracker state.
