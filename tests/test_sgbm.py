@@ -70,7 +70,8 @@ def test_oracle_depth_conversion(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,w,num_disp,sad,seed,noise", [(96, 320, 80, 11, 0, 0), (64, 200, 64, 5, 1, 6), (50, 150, 32, 3, 2, 0),
-                                                          (120, 400, 80, 11, 3, 10), (37, 181, 48, 7, 4, 3), (30, 140, 128, 9, 5, 2)])
+                                                          (120, 400, 80, 11, 3, 10), (37, 181, 48, 7, 4, 3), (30, 140, 128, 9, 5, 2),
+                                                          (40, 120, 16, 5, 6, 0), (44, 230, 96, 7, 7, 4)])
 def test_gpu_sgbm_bit_exact(ctx, oracle, h, w, num_disp, sad, seed, noise):
     left, right, _ = stereo_pair(h, w, seed, planes=((num_disp // 4, None), (num_disp // 2 + 3, (0.3, 0.75, 0.3, 0.7))), noise=noise)
     po = oracle.sgbm_params(num_disp=num_disp, sad=sad)
