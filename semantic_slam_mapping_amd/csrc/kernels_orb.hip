@@ -844,12 +844,16 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
 //   [n4..n1 of p_m] ... [n4..n1 of p_1] ++ (old list without the split parents).
 struct QNode { short x0, y0, x1, y1; };
 #define DROPPED 0xFFFF
-// NODES = LDS node capacity (512 covers 2000 features / 8 levels); keys (8 B) and their node ids (2 B) are copied into LDS
-// when the level has <= OT_KCAP candidates (always, in practice): the split passes then never touch global memory.
-#define OT_KCAP 4096
+// NODES = LDS node capacity (512 covers 2000 features / 8 levels).  The node id of every key (2 B) lives in LDS when the level has <= OT_KCAP candidates;
+// the key words are read from global memory (coalesced, L2-resident, four in flight per thread).  What is kept in LDS is sized so that EIGHT blocks fit a CU at
+// NODES = 256 (20.0 KB): the blocks of a launch all take about the same time whatever their level (a split pass is a chain of barriers and LDS latencies:
+// 40 - 52 us per block, scripts/octree_prof.py), so a launch lasts ceil(blocks / resident slots) block times -- with the key words and 4096 node ids in
+// LDS (40.5 KB, 4 blocks per CU) the 2000 blocks of a 250-frame batch took two rounds.
+#define OT_KCAP 2048
 // exclusive scan over the OT_T threads of a block (thread order), `total` = the block sum; sw = OT_T/64 words of LDS.
 // Contains two barriers; every thread of the block must call it.
 #define OT_T 256                              // threads per octree block (1024 measured 6 % slower: the passes are barrier chains)
+#define OT_UN 4                               // keys per thread and trip of the two sweeps of a split pass
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sw, uint32_t& total)
 {
     const uint32_t inc = wave_incl_scan_u32(v);
@@ -863,8 +867,18 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* sw
     total = tot;
     return inc - v + base;
 }
+#ifdef SSM_OT_PROF
+__device__ unsigned long long ot_prof[8][8];              // [level][section]: shader clocks of thread 0, summed over blocks; section 7 = passes
+#define OTP_T0 long long otp_ = clock64();
+#define OTP(k) { const long long n_ = clock64(); if (threadIdx.x == 0) atomicAdd(&ot_prof[blockIdx.y & 7][k], (unsigned long long)(n_ - otp_)); otp_ = n_; }
+#define OTP_CNT(k) { if (threadIdx.x == 0) atomicAdd(&ot_prof[blockIdx.y & 7][k], 1ull); }
+#else
+#define OTP_T0
+#define OTP(k)
+#define OTP_CNT(k)
+#endif
 template <int NODES>
-__global__ void __launch_bounds__(OT_T)
+__global__ void __launch_bounds__(OT_T, NODES == 256 ? 8 : 1)      // NODES = 256: eight waves per SIMD (64 registers), so that eight 20 KB blocks share a CU
 octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restrict__ ncand, const int32_t* __restrict__ cellmax,
               uint16_t* __restrict__ node_of, uint32_t* __restrict__ sel, int32_t* __restrict__ nsel, int32_t* __restrict__ status)
 {
@@ -873,15 +887,15 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     __shared__ uint32_t sq[2][NODES];
     __shared__ __attribute__((aligned(8))) uint32_t cc[NODES][4];
     __shared__ short    newpos[NODES];
-    __shared__ short    childpos[NODES][4];
+    __shared__ __attribute__((aligned(8))) short childpos[NODES][4];
     __shared__ short    order[NODES];
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(&cc[0][0]);   // final selection only, when the split passes (cc) are over: 40.5 KB -> 4 blocks per CU at NODES = 256
-    __shared__ uint32_t lkx[OT_KCAP];                                   // position + response word of every key; the cell word is read from global where needed
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(&cc[0][0]);   // final selection only, when the split passes (cc) are over
     __shared__ uint16_t lnof[OT_KCAP];
     __shared__ uint16_t cumn[NODES];
     __shared__ uint32_t sscan[OT_T / 64];
     __shared__ int sL, sFinish, sMode, sErr, sValid, sFirst;
     const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;        // level-major launch order: the long level-0 blocks start first
+    OTP_T0
     const LevelGeom& L = g.L[l];
     const int N = L.nfeat;
     int nc = ncand[f * g.nlevels + l];
@@ -889,9 +903,13 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     const cand_t* gkeys = cand + (size_t)f * g.cand_total + L.cand_off;
     uint16_t* gnof = node_of + (size_t)f * g.cand_total + L.cand_off;
     const bool in_lds = nc <= OT_KCAP;                      // block-uniform
-    if (in_lds) for (int i = tid; i < nc; i += OT_T) lkx[i] = gkeys[i].x;
+    // the position + response word of the thread's own keys (i = tid + u * OT_T) stays in registers over the passes: a sweep then makes no global load
+    constexpr int KPT = OT_KCAP / OT_T;
+    uint32_t kxr[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; u++) kxr[u] = 0u;
 #define KEY(i) (gkeys[i])                                /* both words: key load and final selection only (global, coalesced) */
-#define KEYX(i) (in_lds ? lkx[i] : gkeys[i].x)           /* the word the split passes work on: LDS (the block is latency-bound and lives on how many fit a CU) */
+#define KEYX(i) (gkeys[i].x)                             /* the word the split passes work on (position + response) */
 #define NOF(i) (in_lds ? lnof[i] : gnof[i])
 #define SETNOF(i, v) do { if (in_lds) lnof[i] = (uint16_t)(v); else gnof[i] = (uint16_t)(v); } while (0)
     uint32_t* out = sel + (size_t)f * g.sel_total + L.sel_off;
@@ -907,14 +925,33 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     // keys are the local maxima at minThFAST; a cell that has one above iniThFAST keeps only those (DROPPED otherwise)
     const int32_t* cm = cellmax + (size_t)f * g.cells_total + L.cell_off;
     int nvalid = 0;
-    for (int i = tid; i < nc; i += OT_T) {
-        const cand_t k = KEY(i);
-        const int S = (int)(k.x >> 24) + 1;
-        const int th = cm[k.y >> 14] > g.ini_th ? g.ini_th : g.min_th;
-        if (S <= th) { SETNOF(i, DROPPED); continue; }
-        const int x = k.x & 4095;
-        int b = (int)((float)x / hX); b = min(b, nIni - 1);
-        SETNOF(i, b); atomicAdd(&cnt[0][b], 1u); nvalid++;
+    // (four keys per trip: their key loads, then their cell-maximum loads, issued together -- two dependent global latencies per trip, not per key)
+    auto init_trip = [&](int i0, cand_t (&k)[OT_UN]) {
+        int cmv[OT_UN];
+#pragma unroll
+        for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; k[u] = i < nc ? KEY(i) : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < OT_UN; u++) cmv[u] = i0 + u * OT_T < nc ? cm[k[u].y >> 14] : 0;
+#pragma unroll
+        for (int u = 0; u < OT_UN; u++) {
+            const int i = i0 + u * OT_T;
+            if (i >= nc) continue;
+            const int S = (int)(k[u].x >> 24) + 1;
+            const int th = cmv[u] > g.ini_th ? g.ini_th : g.min_th;
+            if (S <= th) { SETNOF(i, DROPPED); continue; }
+            const int x = k[u].x & 4095;
+            int b = (int)((float)x / hX); b = min(b, nIni - 1);
+            SETNOF(i, b); atomicAdd(&cnt[0][b], 1u); nvalid++;
+        }
+    };
+    if (in_lds) {
+#pragma unroll
+        for (int t = 0; t < KPT / OT_UN; t++) {
+            const int i0 = tid + t * OT_UN * OT_T;
+            if (i0 < nc) { cand_t k[OT_UN]; init_trip(i0, k); for (int u = 0; u < OT_UN; u++) kxr[t * OT_UN + u] = k[u].x; }
+        }
+    } else {
+        for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) { cand_t k[OT_UN]; init_trip(i0, k); }
     }
     if (nvalid) atomicAdd(&sValid, nvalid);
     __syncthreads();
@@ -931,37 +968,68 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     for (int i = tid; i < nc; i += OT_T) { const int o = NOF(i); if (o != DROPPED) SETNOF(i, newpos[o]); }
     int cur = 1;      // buffer holding the current list
     __syncthreads();
+    OTP(0)
     // ---- split passes
     while (!sFinish) {
         const int Lsz = sL;
         QNode* cn = nd[cur]; uint32_t* ccnt = cnt[cur]; uint32_t* csq = sq[cur];
         QNode* nn = nd[cur ^ 1]; uint32_t* ncnt = cnt[cur ^ 1]; uint32_t* nsq = sq[cur ^ 1];
-        for (int i = tid; i < Lsz; i += OT_T) { cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0; }
+        // (okey: the second phase's ordering key of every node -- size, then creation sequence, + 1; 0 = not expandable -- in the bytes of childpos, which
+        // is dead between the relabel sweep of one pass and the rebuild of the next)
+        unsigned long long* okey = reinterpret_cast<unsigned long long*>(&childpos[0][0]);
+        for (int i = tid; i < Lsz; i += OT_T) {
+            cc[i][0] = cc[i][1] = cc[i][2] = cc[i][3] = 0;
+            const uint32_t ci = ccnt[i];
+            okey[i] = ci > 1 ? (((unsigned long long)ci << 32) | csq[i]) + 1ull : 0ull;
+        }
         __syncthreads();
-        for (int i = tid; i < nc; i += OT_T) {
-            const int ni = NOF(i);
-            if (ni != DROPPED && ccnt[ni] > 1) {
-                const QNode q = cn[ni];
-                const uint32_t kx = KEYX(i);
-                const int x = kx & 4095, y = (kx >> 12) & 4095;
-                const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-                const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                atomicAdd(&cc[ni][qd], 1u);
+        // (four keys per trip, each step of the dependent chain key -> node id -> node -> counter issued for all four before the next: a block is a chain
+        // of LDS latencies, and one key per trip paid every one of them in full)
+        auto count_trip = [&](int i0, const uint32_t (&kx)[OT_UN]) {
+            int ni[OT_UN]; uint32_t cn_[OT_UN]; QNode q[OT_UN];
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; }
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) cn_[u] = ni[u] != DROPPED ? ccnt[ni[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) q[u] = cn[ni[u] != DROPPED ? ni[u] : 0];
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) {
+                if (cn_[u] > 1) {
+                    const int x = kx[u] & 4095, y = (kx[u] >> 12) & 4095;
+                    const int mx = q[u].x0 + ((q[u].x1 - q[u].x0 + 1) >> 1), my = q[u].y0 + ((q[u].y1 - q[u].y0 + 1) >> 1);
+                    const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                    atomicAdd(&cc[ni[u]][qd], 1u);
+                }
+            }
+        };
+        if (in_lds) {
+#pragma unroll
+            for (int t = 0; t < KPT / OT_UN; t++) {
+                const int i0 = tid + t * OT_UN * OT_T;
+                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; count_trip(i0, kx); }
+            }
+        } else {
+            for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
+                uint32_t kx[OT_UN];
+#pragma unroll
+                for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; kx[u] = i < nc ? KEYX(i) : 0u; }
+                count_trip(i0, kx);
             }
         }
+        OTP(1)
         // processing order for the second phase only: rank among expandable nodes by (size desc, creation seq desc)
         if (sMode == 1) for (int i = tid; i < Lsz; i += OT_T) {
-            if (ccnt[i] > 1) {
-                const uint32_t ci = ccnt[i], si = csq[i];
+            const unsigned long long ki = okey[i];
+            if (ki) {
                 int r = 0;
-                for (int j = 0; j < Lsz; j++) {
-                    const uint32_t cj = ccnt[j];
-                    if (cj > 1 && (cj > ci || (cj == ci && csq[j] > si))) r++;
-                }
+#pragma unroll 8
+                for (int j = 0; j < Lsz; j++) r += okey[j] > ki ? 1 : 0;      // (one broadcast LDS read per node, no branch: the loop was a chain of LDS latencies)
                 order[r] = (short)i;
             }
         }
         __syncthreads();
+        OTP(2)
         // ---- rebuild of the node list, all threads (thread t owns nodes / ranks t*IPT .. t*IPT+IPT-1, so block scans
         // run in list order).  The list semantics are ORB-SLAM2's std::list with push_front: the children of the split nodes
         // come first -- parents in reverse processing order, each as n4, n3, n2, n1 -- then the nodes that were not split,
@@ -1080,32 +1148,58 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
             sL = pos_total;
         }
         __syncthreads();
-        for (int i = tid; i < nc; i += OT_T) {
-            const int ni = NOF(i);
-            if (ni == DROPPED) continue;
-            if (newpos[ni] == -2) {
-                const QNode q = cn[ni];
-                const uint32_t kx = KEYX(i);
-                const int x = kx & 4095, y = (kx >> 12) & 4095;
-                const int mx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), my = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-                const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
-                SETNOF(i, childpos[ni][qd]);
-            } else SETNOF(i, newpos[ni]);
+        OTP(3)
+        auto relabel_trip = [&](int i0, const uint32_t (&kx)[OT_UN]) {
+            int ni[OT_UN]; int np_[OT_UN]; QNode q[OT_UN];
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; }
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) { const int n_ = ni[u] != DROPPED ? ni[u] : 0; np_[u] = newpos[n_]; q[u] = cn[n_]; }
+#pragma unroll
+            for (int u = 0; u < OT_UN; u++) {
+                if (ni[u] == DROPPED) continue;
+                const int i = i0 + u * OT_T;
+                if (np_[u] == -2) {
+                    const int x = kx[u] & 4095, y = (kx[u] >> 12) & 4095;
+                    const int mx = q[u].x0 + ((q[u].x1 - q[u].x0 + 1) >> 1), my = q[u].y0 + ((q[u].y1 - q[u].y0 + 1) >> 1);
+                    const int qd = (x < mx) ? (y < my ? 0 : 2) : (y < my ? 1 : 3);
+                    SETNOF(i, childpos[ni[u]][qd]);
+                } else SETNOF(i, np_[u]);
+            }
+        };
+        if (in_lds) {
+#pragma unroll
+            for (int t = 0; t < KPT / OT_UN; t++) {
+                const int i0 = tid + t * OT_UN * OT_T;
+                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; relabel_trip(i0, kx); }
+            }
+        } else {
+            for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
+                uint32_t kx[OT_UN];
+#pragma unroll
+                for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; kx[u] = i < nc ? KEYX(i) : 0u; }
+                relabel_trip(i0, kx);
+            }
         }
         cur ^= 1;
         __syncthreads();
+        OTP(4) OTP_CNT(7)
     }
     // ---- best response per node (ties: first in detection order == lowest rank)
     const int Lf = sL;
     if (sErr && tid == 0) atomicOr(status, 2);
     for (int i = tid; i < Lf; i += OT_T) best[i] = 0ull;
     __syncthreads();
-    for (int i = tid; i < nc; i += OT_T) {
-        const int ni = NOF(i);
-        if (ni == DROPPED) continue;
-        const cand_t k = KEY(i);
-        const unsigned long long v = ((unsigned long long)(k.x >> 24) << 56) | ((unsigned long long)(0xFFFFFFFFu - k.y) << 24) | (k.x & 0xFFFFFFu);
-        atomicMax(&best[ni], v);
+    for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
+        int ni[OT_UN]; cand_t k[OT_UN];
+#pragma unroll
+        for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; k[u] = i < nc ? KEY(i) : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < OT_UN; u++) {
+            if (ni[u] == DROPPED) continue;
+            const unsigned long long v = ((unsigned long long)(k[u].x >> 24) << 56) | ((unsigned long long)(0xFFFFFFFFu - k[u].y) << 24) | (k[u].x & 0xFFFFFFu);
+            atomicMax(&best[ni[u]], v);
+        }
     }
     __syncthreads();
     for (int i = tid; i < Lf && i < L.sel_cap; i += OT_T) {
@@ -1114,7 +1208,18 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         out[i] = x | (y << 12) | (s << 24);
     }
     if (tid == 0) { nsel[f * g.nlevels + l] = min(Lf, L.sel_cap); if (Lf > L.sel_cap) atomicOr(status, 4); }
+    OTP(5)
 }
+#ifdef SSM_OT_PROF
+extern "C" void ssm_debug_octree_prof(void)
+{
+    unsigned long long h[8][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ot_prof), sizeof(h)) != hipSuccess) return;
+    for (int l = 0; l < 8; l++) fprintf(stderr, "octree level %d: init %llu count-sweep %llu order %llu rebuild %llu relabel %llu best %llu | passes %llu\n", l, h[l][0], h[l][1], h[l][2], h[l][3], h[l][4], h[l][5], h[l][7]);
+    for (auto& r_ : h) for (auto& v_ : r_) v_ = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ot_prof), h, sizeof(h));
+}
+#endif
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s)
 {
