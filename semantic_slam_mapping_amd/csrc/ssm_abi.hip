@@ -51,8 +51,7 @@ struct StereoState {        // workspace of the stereo path (quad matcher, SGBM 
     float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
     uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
     double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
-    void* sg_ws = nullptr; size_t sg_ws_bytes = 0; int* dmin = nullptr;       // SGBM workspace (sized for the frames per launch actually used)
-    void* sg_ws2 = nullptr; size_t sg_ws2_bytes = 0; int* dmin2 = nullptr;    // a second one: alternate sub-batches of a sequence run SGBM on two streams
+    void* sg_wsN[3] = {nullptr, nullptr, nullptr}; size_t sg_ws_bytesN[3] = {0, 0, 0}; int* dminN[3] = {nullptr, nullptr, nullptr};   // SGBM workspaces (sized for the frames per launch actually used): successive sub-batches of a sequence run SGBM on up to three streams, one workspace each
     // sequence outputs (seq_cap frames)
     int seq_cap = 0;
     ssm_pmatch* quad = nullptr; int32_t* nquad = nullptr; float* corners = nullptr; int32_t* ncorners = nullptr; int16_t* disp = nullptr; uint16_t* depth = nullptr;
@@ -378,7 +377,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
     { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 64 ? 64 : b; }
-    { const char* e = getenv("SSM_SGBM_STREAMS"); if (e) c->stereo_sgbm_streams = atoi(e) >= 2 ? 2 : 1; }
+    { const char* e = getenv("SSM_SGBM_STREAMS"); if (e) { const int v = atoi(e); c->stereo_sgbm_streams = v < 1 ? 1 : v > 3 ? 3 : v; } }
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
@@ -424,7 +423,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     if (c->d_comm_counts) hipFree(c->d_comm_counts);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
-    for (hipStream_t st : {c->stream, c->stream2, c->stream3}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
+    for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -1374,7 +1373,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 static void stereo_free(StereoState* q)
 {
     void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.cand_bits, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
-                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_ws, q->dmin, q->sg_ws2, q->dmin2, q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
+                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_wsN[0], q->dminN[0], q->sg_wsN[1], q->dminN[1], q->sg_wsN[2], q->dminN[2], q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
                   q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
 }
@@ -1405,7 +1404,7 @@ static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
     g.overflow = q->overflow;
     HIPCHK(c, hipMemset(q->overflow, 0, 4));
     DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
-    DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1); DALLOC(c, q->dmin, B);
+    DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1);
     return SSM_OK;
 }
 static int stereo_ensure_seq(ssm_ctx* c, int n)
@@ -1435,12 +1434,12 @@ static int stereo_ensure_vo(ssm_ctx* c, int iters)
     q->vo_iters = iters;
     return SSM_OK;
 }
-static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, bool second = false)
+static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, int which = 0)
 {
     StereoState* q = c->stereo;
     const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
-    void*& ws = second ? q->sg_ws2 : q->sg_ws; size_t& have = second ? q->sg_ws2_bytes : q->sg_ws_bytes;
-    if (second && !q->dmin2) DALLOC(c, q->dmin2, 64);
+    void*& ws = q->sg_wsN[which]; size_t& have = q->sg_ws_bytesN[which];
+    if (!q->dminN[which]) DALLOC(c, q->dminN[which], 64);
     if (need <= have) return SSM_OK;
     HIPCHK(c, hipDeviceSynchronize());
     if (ws) hipFree(ws);
@@ -1485,8 +1484,10 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
     if (two) { r = ensure_side_streams(c); if (r) return r; sd = c->stream2; HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
     // ... and with more than one sub-batch SGBM alternates between TWO streams with a workspace each: the cost kernel and the small kernels of one
     // sub-batch (LDS / latency-bound) run beside the scan-direction and winner-takes-all kernels of the other (HBM-bound)
-    const bool sg2 = two && n > B && c->stereo_sgbm_streams >= 2;
-    if (sg2) { r = stereo_ensure_sgbm(c, in->sgbm, B, true); if (r) return r; HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0)); }
+    const int nsub = (n + B - 1) / B;
+    const int nsg = two ? (c->stereo_sgbm_streams < nsub ? c->stereo_sgbm_streams : nsub) : 1;
+    hipStream_t sgs[3] = {sd, two ? c->stream3 : sd, two ? c->stream4 : sd};
+    for (int k = 1; k < nsg; k++) { r = stereo_ensure_sgbm(c, in->sgbm, B, k); if (r) return r; HIPCHK(c, hipStreamWaitEvent(sgs[k], c->ev_fork, 0)); }
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
     const bool prev0 = in->continue_sequence && q->have_prev;
     if (stages & SSM_STEREO_VO) HIPCHK(c, hipMemsetAsync(q->consumed, 0, 4, sq));
@@ -1518,17 +1519,18 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             prof_end(c);
         }
         if (stages & SSM_STEREO_DEPTH) {
-            const bool alt = sg2 && ((f0 / B) & 1);
-            hipStream_t sg = alt ? c->stream3 : sd;
+            const int alt = (f0 / B) % nsg;
+            hipStream_t sg = sgs[alt];
             struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
             prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, alt ? q->sg_ws2 : q->sg_ws, q->disp + (size_t)f0 * np, 0, sg));
-            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, alt ? q->dmin2 : q->dmin, q->depth + (size_t)f0 * np, sg));
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg));
+            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dminN[alt], q->depth + (size_t)f0 * np, sg));
             prof_end(c);
         }
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, sd)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
-    if (sg2) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
+    if (nsg > 1) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
+    if (nsg > 2) { HIPCHK(c, hipEventRecord(c->ev_join4, c->stream4)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0)); }
     if (n > 0) q->have_prev = (stages & SSM_STEREO_QUAD) != 0;
     if (out) {
         out->quad = q->quad; out->nquad = q->nquad; out->corners = q->corners; out->ncorners = q->ncorners; out->disp = q->disp; out->depth = q->depth;
@@ -1676,7 +1678,7 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
     prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_ws, q->disp, stage, c->stream));
+    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream));
     prof_end(c);
     *d_disp_out = q->disp; *d_depth_out = q->depth;
     return SSM_OK;
@@ -1704,7 +1706,7 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     int16_t* dd; uint16_t* ddepth;
     int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
-    HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dmin, ddepth, c->stream));
+    HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
     if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
