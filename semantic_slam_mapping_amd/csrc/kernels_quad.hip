@@ -411,11 +411,15 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
             iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)); iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)); iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
             iw11 = (1 << 14) - iw00 - iw01 - iw10;
             long long sb1 = 0, sb2 = 0;
+            // (a window that lies inside the image with its +1 taps -- wave-uniform, and the usual case -- needs no border reflection: eight of them per
+            // lane and iteration otherwise)
+            const bool inside = inx >= 0 && iny >= 0 && inx + LKW < W && iny + LKW < H;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
                 if (t == 1 && !v1) continue;
                 const int gx = inx + (t ? wx1 : wx0), gy = iny + (t ? wy1 : wy0);
-                const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
+                int x0 = gx, x1 = gx + 1, y0 = gy, y1 = gy + 1;
+                if (!inside) { x0 = refl101d(gx, W); x1 = refl101d(gx + 1, W); y0 = refl101d(gy, H); y1 = refl101d(gy + 1, H); }
                 const int diff = DESCALE(N[(size_t)y0 * W + x0] * iw00 + N[(size_t)y0 * W + x1] * iw01 + N[(size_t)y1 * W + x0] * iw10 + N[(size_t)y1 * W + x1] * iw11, 14 - 5) - I[t];
                 sb1 += (long long)diff * Ix[t]; sb2 += (long long)diff * Iy[t];
             }
