@@ -9,7 +9,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import semantic_slam_mapping_amd as ssm          # noqa: E402
-from oracle.binding import Oracle                # noqa: E402  (only to make the synthetic frames; nothing of the oracle is timed)
 
 CAM = (318.6, 255.3, 517.3, 516.5, 1000.0)
 
@@ -26,10 +25,14 @@ def timeit(fn, n=30, warm=3):
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
-    orc = Oracle()
     ctx = ssm.Context(0, orb_features=1000, max_batch=1, voxel_capacity_log2=18, camera=CAM)
-    frames = [orc.synth_frame(0x5EED0000, f) for f in range(2)]
-    (bgr, dep, sem, _, T), (bgr1, dep1, sem1, _, T1) = frames
+    # two frames of the bench's synthetic stream, made on the device and copied to the host (the calls timed below take host pointers)
+    H, W = 480, 640
+    tb = ctx.dev_alloc(2 * H * W * 3); td = ctx.dev_alloc(2 * H * W * 2); ts = ctx.dev_alloc(2 * H * W * 3); tp = ctx.dev_alloc(2 * 128)
+    ctx.synth_frames_dev(0x5EED0000, 0, 2, tb, td, ts, tp); ctx.sync()
+    B2 = ctx.d2h(tb, (2, H, W, 3), np.uint8); D2 = ctx.d2h(td, (2, H, W), np.uint16); S2 = ctx.d2h(ts, (2, H, W, 3), np.uint8)
+    P2 = ctx.d2h(tp, (2, 4, 4), np.float64).transpose(0, 2, 1).copy()       # column-major on the device
+    bgr, dep, sem, T = B2[0], D2[0], S2[0], P2[0]; bgr1, dep1 = B2[1], D2[1]
     k0, d0, _ = ctx.detect_features(bgr, dep); k1, d1, _ = ctx.detect_features(bgr1, dep1)
     cloud = ctx.generate_point_cloud(dep, bgr, sem, T)
     rows = []
