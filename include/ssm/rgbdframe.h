@@ -104,6 +104,8 @@ protected:
             f->img_rc = ssm::imreadPNG(dataset_dir + "image_3/" + rgbFiles[index + 1], 0); f->img_rp = ssm::imreadPNG(dataset_dir + "image_3/" + rgbFiles[index], 0);
             if (f->rgb.empty() || f->img_lc.empty() || f->img_rc.empty() || f->img_lp.empty() || f->img_rp.empty()) return nullptr;
             // depth from the current stereo pair: calDisparity_SGBM + the ROI-gated conversion (rgbdframe.cpp:81-116), on the GPU
+            // (kitti_reader_depth = 0: left to the bulk stereo tracker, which computes it for a whole chunk of frames per launch)
+            if (parameterReader.getData<int>("kitti_reader_depth", 1) != 0)
             stereoDepth(f->img_lc, f->img_rc, parameterReader.getData<double>("camera.baseline"), camera.cx, camera.cy, camera.fx,
                         parameterReader.getData<double>("camera.roix", 20.0), parameterReader.getData<double>("camera.roiy", 5.0),
                         parameterReader.getData<double>("camera.roiz", 40.0), camera.scale, f->depth, f->disparity);

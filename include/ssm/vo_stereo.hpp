@@ -22,6 +22,12 @@ public:
     int getNumberOfInliers() { return (int)inliers.size(); }
     std::vector<int> getInlierIndices() { return inliers; }
     std::vector<pmatch> quadmatches, quadmatches_inlier, quadmatches_outlier;
+    // the rand() stream as an object (the bulk path, ssm_stereo_seq_process, is handed the RAW draws this object would make and reports how many it used:
+    // include/ssm/batch_stereo_tracker.h)
+    struct RandState { int32_t r[31]; int f, b; };
+    RandState saveRand() const { RandState s; for (int i = 0; i < 31; i++) s.r[i] = r_[i]; s.f = f_; s.b = b_; return s; }
+    void restoreRand(const RandState& s) { for (int i = 0; i < 31; i++) r_[i] = s.r[i]; f_ = s.f; b_ = s.b; }
+    uint32_t rawRand() { return next_rand(); }
 protected:
     bool updateMotion() {                                               // vo.cpp:23-38
         std::vector<double> tr = estimateMotion(quadmatches);
@@ -105,6 +111,10 @@ public:
         ctx_ = quadmatcher.deviceContext();                             // the matcher's device context, when it has one
         return updateMotion();
     }
+    // the same on a list of quad matches (u/v fields only), on the given device context
+    bool ProcessMatches(const std::vector<pmatch>& qm, ssm_ctx* ctx) { quadmatches = qm; ctx_ = ctx; return updateMotion(); }
+    const parameters& stereoParameters() const { return param; }
+    static cv::Mat motionMatrix(const double tr[6]) { return transformationVectorToMatrix(std::vector<double>(tr, tr + 6)); }
 private:
     std::vector<double> estimateMotion(std::vector<pmatch>& qm) override {
         const int N = (int)qm.size();

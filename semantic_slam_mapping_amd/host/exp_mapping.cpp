@@ -22,6 +22,7 @@
 #include "ssm/common_headers.h"
 #include "ssm/mapper.h"
 #include "ssm/vo_stereo.hpp"
+#include "ssm/batch_stereo_tracker.h"
 #include "ssm/batch_tracker.h"
 #include <signal.h>
 #include <sys/stat.h>
@@ -118,6 +119,8 @@ int main(int argc, char** argv)
     try {
         Tracker::Ptr tracker(new Tracker(parameterReader, voparam));
         const FrameReader::DATASET type = dataset_type(parameterReader);
+        const bool batched_stereo = batched && parameterReader.getData<string>("tracker_mode", string("rgbd")) == "stereo";
+        if (batched_stereo) parameterReader.set("kitti_reader_depth", "0");     // the bulk stereo tracker computes the depth images, a chunk of frames per launch
         FrameReader frameReader(parameterReader, type);
         PoseGraph poseGraph(parameterReader, tracker);
         Mapper mapper(parameterReader, poseGraph);
@@ -145,6 +148,24 @@ int main(int argc, char** argv)
             }
             if (bt) handle(bt->flush());
             cout << "batched tracker: chunk " << (bt ? bt->chunk() : 0) << " lost " << lost << endl;
+        } else if (batched_stereo) {
+            // Tracker::estimateVO + FrameReader's SGBM depth in bulk (include/ssm/batch_stereo_tracker.h): quad matcher, depth and ego-motion of a chunk per launch
+            unique_ptr<BatchStereoTracker> bs; int lost = 0;
+            auto handle = [&](const vector<RGBDFrame::Ptr>& done) {
+                for (size_t i = 0; i < done.size(); i++) {
+                    const RGBDFrame::Ptr& f = done[i];
+                    traj.add(f);
+                    poseGraph.tryInsertKeyFrame(const_cast<RGBDFrame::Ptr&>(f));
+                    if (bs->infos[i].state == Tracker::LOST) { cout << "tracker is lost" << endl; lost++; }
+                    nframes++;
+                }
+            };
+            while (RGBDFrame::Ptr frame = frameReader.next()) {
+                if (!bs) bs.reset(new BatchStereoTracker(parameterReader, voparam, frame->img_lc.cols, frame->img_lc.rows));
+                handle(bs->push(frame));
+            }
+            if (bs) handle(bs->flush());
+            cout << "batched stereo tracker: chunk " << (bs ? bs->chunk() : 0) << " lost " << lost << endl;
         } else
         while (RGBDFrame::Ptr frame = frameReader.next()) {
             Eigen::Isometry3d gt = frame->T_f_w;

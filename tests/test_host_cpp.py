@@ -85,8 +85,16 @@ def test_frame_reader_tum_and_kitti_layouts(tmp_path):
     for i in range(3):
         left, right, _ = stereo_pair(120, 400, 20 + i, planes=((24, None),))
         Image.fromarray(left, "L").save(kitti / "image_2" / f"{i:06d}.png"); Image.fromarray(right, "L").save(kitti / "image_3" / f"{i:06d}.png")
-    out = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), str(tum), str(kitti)], capture_output=True, text=True)
+    # a coherent stereo sequence for the bulk stereo tracker: one textured plane (disparity 24) moving by 2 px per image, with a 150-px jump at image 4
+    seq = tmp_path / "kitti_seq"; (seq / "image_2").mkdir(parents=True); (seq / "image_3").mkdir()
+    left, right, _ = stereo_pair(120, 400 + 400, 31, planes=((24, None),))
+    for i in range(9):
+        s0 = 2 * i + (150 if i >= 4 else 0)
+        Image.fromarray(np.ascontiguousarray(left[:, s0:s0 + 400]), "L").save(seq / "image_2" / f"{i:06d}.png")
+        Image.fromarray(np.ascontiguousarray(right[:, s0:s0 + 400]), "L").save(seq / "image_3" / f"{i:06d}.png")
+    out = subprocess.run([os.path.join(HOST, "test_host"), os.path.join(HOST, "parameters_test.txt"), str(tum), str(kitti), str(seq)], capture_output=True, text=True)
     assert "PASS frame_reader_tum" in out.stdout and "PASS frame_reader_kitti" in out.stdout and "PASS tracker_stereo_mode_runs_estimateVO" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "PASS bulk_stereo_tracker_equals_per_frame_tracker" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 @pytest.mark.gpu
@@ -187,6 +195,34 @@ def test_exp_mapping_batched_equals_per_frame_on_gpu(tmp_path):
     ta, tb = open(tmp_path / "per_frame.txt").read(), open(tmp_path / "batched.txt").read()
     assert len(ta.splitlines()) == 26 and ta == tb
     assert a["pose_fnv"] == b["pose_fnv"] and a["keyframes"] == b["keyframes"] and int(a["frames"]) == int(b["frames"]) == 26
+
+
+@pytest.mark.gpu
+def test_exp_mapping_batched_stereo_equals_per_frame_on_gpu(tmp_path):
+    """exp_mapping --batched with tracker_mode = stereo on a KITTI-layout directory (BatchStereoTracker: quad matcher, SGBM depth and stereo VO of a chunk of
+    frames per launch, the reader leaves the depth to it) against the per-frame loop (FrameReader::KITTI computes the depth, Tracker::estimateVO per frame):
+    identical trajectory files, key-frames and map"""
+    import numpy as np
+    from PIL import Image
+    subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sgbm import stereo_pair
+    seq = tmp_path / "kitti"; (seq / "image_2").mkdir(parents=True); (seq / "image_3").mkdir()
+    left, right, _ = stereo_pair(120, 800, 41, planes=((24, None),))
+    n_img = 12
+    for i in range(n_img):
+        s0 = 3 * i
+        L = np.ascontiguousarray(left[:, s0:s0 + 400]); R = np.ascontiguousarray(right[:, s0:s0 + 400])
+        Image.fromarray(np.stack([L, L, L], -1), "RGB").save(seq / "image_2" / f"{i:06d}.png"); Image.fromarray(R, "L").save(seq / "image_3" / f"{i:06d}.png")
+    base = open(os.path.join(HOST, "parameters_test.txt")).read().replace("end_index=8", "end_index=50").replace("dataset=synthetic", "dataset=kitti")
+    base = base.replace("map_output=/tmp/ssm_test_map.pcd", f"map_output={tmp_path}/map.pcd")
+    base += (f"\ndata_source={seq}\ntracker_mode=stereo\nimage_width=400\nimage_height=120\norb_levels=3\norb_features=300\ncamera.baseline=0.532331858\n"
+             "camera.roix=2000\ncamera.roiy=2000\ncamera.roiz=4000\ninlier_threshold=2.0\ntracker_chunk=4\nssm_max_batch=3\nmapper_drain_ms=1000\n")
+    a = _run_exp_mapping(base + f"trajectory_output={tmp_path}/per_frame.txt\n", tmp_path, "a")
+    b = _run_exp_mapping(base + f"trajectory_output={tmp_path}/batched.txt\n", tmp_path, "b", "--batched")
+    ta, tb = open(tmp_path / "per_frame.txt").read(), open(tmp_path / "batched.txt").read()
+    assert len(ta.splitlines()) == n_img - 1 and ta == tb
+    assert a["pose_fnv"] == b["pose_fnv"] and a["keyframes"] == b["keyframes"] and int(a["frames"]) == int(b["frames"]) == n_img - 1
 
 
 @pytest.mark.gpu
