@@ -9,6 +9,8 @@
 // raw draws and reports how many it used.  One case breaks the bulk call's assumption that every frame with a previous frame runs the VO: a frame that arrives
 // while the tracker is LOST goes through lostRecover and draws nothing -- from that frame to the end of the chunk the VO is redone per frame on the chunk's
 // quad matches (VisualOdometryStereo::ProcessMatches), with the stream where the per-frame walk would have it.
+// Not done here: estimateVO's orb->detectFeatures(currentFrame) (track.cpp:42) -- the ORB features of a stereo frame feed only the pose graph's loop closure
+// (out of scope); a caller that wants them runs OrbFeature::detectFeatures on the frames this class returns (their depth is set).
 #pragma once
 #include "common_headers.h"
 #include "device.h"
