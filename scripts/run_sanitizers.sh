@@ -7,6 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 LOG=${1:-$ROOT/profiles/r03_sanitizers.log}
 HOST=$ROOT/semantic_slam_mapping_amd/host
 TMP=$(mktemp -d)
+export SSM_ROOT=$ROOT
 python3 - "$TMP" <<'PY'
 import sys, os, struct, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(sys.argv[0])), "."))
