@@ -54,11 +54,14 @@ int main(int argc, char** argv)
                 Tracker tracker(para, vp); FrameReader rd(para, FrameReader::KITTI);
                 while (RGBDFrame::Ptr f = rd.next()) { tracker.updateFrame(f); Ta.push_back(f->getTransform()); Da.push_back(f->depth); Sa.push_back((int)tracker.getState()); }
             }
+            // chunks of 3 (the LOST frame opens a chunk, the recovering frame sits inside it), 4 (the recovering frame opens a chunk) and 8 (one chunk)
+            bool all_chunks = true;
+            for (int chunk : {3, 4, 8}) {
             vector<Eigen::Isometry3d> Tb; vector<cv::Mat> Db; vector<int> Sb; int tracked = 0;
             {
                 para.set("kitti_reader_depth", "0");
                 FrameReader rd(para, FrameReader::KITTI);
-                BatchStereoTracker bs(para, vp, 400, 120, 3);
+                BatchStereoTracker bs(para, vp, 400, 120, chunk);
                 auto take = [&](const vector<RGBDFrame::Ptr>& done) { for (size_t i = 0; i < done.size(); i++) { Tb.push_back(done[i]->getTransform()); Db.push_back(done[i]->depth); Sb.push_back(bs.infos[i].state); tracked += bs.infos[i].tracked; } };
                 while (RGBDFrame::Ptr f = rd.next()) take(bs.push(f));
                 take(bs.flush());
@@ -71,13 +74,15 @@ int main(int argc, char** argv)
                 lost += Sa[i] == Tracker::LOST; moved = max(moved, fabs(Ta[i](0, 3)));
             }
             if (!(same && lost >= 1 && tracked >= 5 && moved > 1e-3)) {
-                cout << "  frames " << Ta.size() << " / " << Tb.size() << " lost " << lost << " tracked " << tracked << " moved " << moved << endl;
+                cout << "  chunk " << chunk << " frames " << Ta.size() << " / " << Tb.size() << " lost " << lost << " tracked " << tracked << " moved " << moved << endl;
                 for (size_t i = 0; i < Ta.size() && i < Tb.size(); i++)
                     cout << "  frame " << i << ": state " << Sa[i] << " / " << Sb[i] << " tx " << Ta[i](0, 3) << " / " << Tb[i](0, 3) << " pose equal " << (memcmp(Ta[i].matrix().data(), Tb[i].matrix().data(), 128) == 0)
                          << " depth equal " << (Da[i].rows == Db[i].rows && Da[i].rows > 0 && memcmp(Da[i].data, Db[i].data, (size_t)Da[i].rows * Da[i].cols * 2) == 0)
                          << " (" << Da[i].rows << "x" << Da[i].cols << " type " << Da[i].type() << " / " << Db[i].rows << "x" << Db[i].cols << " type " << Db[i].type() << "; [60,200] " << (Da[i].rows ? Da[i].at<ushort>(60, 200) : 0) << " / " << (Db[i].rows ? Db[i].at<ushort>(60, 200) : 0) << ")" << endl;
             }
-            CHECK("bulk_stereo_tracker_equals_per_frame_tracker", same && lost >= 1 && tracked >= 5 && moved > 1e-3);
+            all_chunks = all_chunks && same && lost >= 1 && tracked >= 5 && moved > 1e-3;
+            }
+            CHECK("bulk_stereo_tracker_equals_per_frame_tracker", all_chunks);
         }
         cout << (fails ? "FAILED" : "ALL PASSED") << endl;
         return fails;
