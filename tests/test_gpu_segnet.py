@@ -227,3 +227,23 @@ def test_other_conv_kernels_pass_the_same_tests(variant):
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "deselected" in r.stdout
+
+
+def test_label_colouring_on_a_width_that_is_no_multiple_of_four(oracle, seg):
+    """label_color_kernel stores four pixels per thread as aligned dwords when every row starts on a multiple of four pixels; other widths take the one-pixel
+    stores: a 322 x 242 frame against the same oracle resize + palette"""
+    import json, os
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, width=322, height=242, max_batch=1, orb_levels=3)
+    try:
+        for l, (wt, sc, sh) in enumerate(seg):
+            c.segnet_set_layer(l, wt, sc, sh)
+        bgr = oracle.synth_frame(SEED, 3)[0][:242, :322].copy()
+        labels, sem = c.classify(bgr)
+        ids = labels.copy(); ids[ids == 5] = 4
+        up = oracle.resize(ids, 322, 242)
+        pal = np.zeros((256, 3), np.uint8)
+        pal[:12] = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "palette.json")))["palette_bgr"], np.uint8)
+        assert sem.shape == (242, 322, 3) and np.array_equal(sem, pal[up])
+    finally:
+        c.close()
