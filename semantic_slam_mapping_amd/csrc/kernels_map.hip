@@ -629,13 +629,41 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     __shared__ uint16_t cbits[MS2_CB_WORDS];                            // pedestrian | cyclist bit per pixel, rows ry0 .. of this frame, wpr words per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wpr = w >> 4, words = wpr * h;
-    // ---- the class bits of the block's rows + 2 above and below (rows outside the image: no moving pixel)
+    // ---- labels and class bits.  The wave classifies the semantic words of its three chunks ONCE: the 4-bit labels stay in registers for the gate pass, the
+    // moving-class bit of every pixel goes to the LDS bit image.  The rest of the bit image -- 2 rows above and below the block's rows and the parts of its
+    // first / last row that belong to the neighbouring blocks -- is classified by all threads with the two compares the bit needs (rows outside the image: no
+    // moving pixel).  (Before: every row of the block was read and classified here and read and hashed again in the gate pass.)
     const int bw0 = blockIdx.x * MS_CH * 256;
     const int ry0 = (int)__umulhi((uint32_t)bw0, mul_wpr) - 2;
+    const int own0 = bw0 - ry0 * wpr, own1 = min(bw0 + MS_CH * 256, words) - ry0 * wpr;      // the block's own words inside the bit image
+    const uint32_t tab_entry = label_hash_entry(lane & 15);
+    uint32_t labs[MS_CH][2];                                            // 4-bit labels (15 = none of the palette) of the lane's 16 pixels, per chunk
+#pragma unroll
+    for (int ch = 0; ch < MS_CH; ch++) {
+        labs[ch][0] = labs[ch][1] = 0u;
+        const int wi = (blockIdx.x * MS_CH + ch) * 256 + wv * 64 + lane;
+        if (wi < words) {
+            const uint4* ps = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + wi) * 48);
+            const uint4 S0 = ps[0], S1 = ps[1], S2 = ps[2];
+            const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int o = 3 * k;
+                const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
+                const uint32_t ent = (uint32_t)__shfl((int)tab_entry, (int)((sbgr * 0x7589a82bu) >> 28), 64);
+                const uint32_t lab = (ent & 0xFFFFFFu) == sbgr ? ent >> 24 : 15u;          // 0..11, or 15
+                labs[ch][k >> 3] |= lab << (4 * (k & 7));
+                bits |= (uint32_t)(lab == 10u || lab == 11u) << k;                          // pedestrian (0,64,64) | cyclist (192,128,0) BGR
+            }
+            cbits[wi - ry0 * wpr] = (uint16_t)bits;
+        }
+    }
     {
         const int ry1 = (int)__umulhi((uint32_t)(min(bw0 + MS_CH * 256, words) - 1), mul_wpr) + 2;
-        const int ncw = (ry1 - ry0 + 1) * wpr;
-        for (int i = tid; i < ncw; i += 256) {
+        const int ncw = (ry1 - ry0 + 1) * wpr, nhalo = ncw - (own1 - own0);
+        for (int j = tid; j < nhalo; j += 256) {
+            const int i = j < own0 ? j : j + (own1 - own0);              // the bit-image words that are not the block's own
             const int rr = (int)__umulhi((uint32_t)i, mul_wpr), gy = ry0 + rr;
             uint32_t bits = 0;
             if (gy >= 0 && gy < h) {
@@ -666,19 +694,19 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
 #pragma unroll
         for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
-    const uint32_t tab_entry = label_hash_entry(lane & 15);
     const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
+    static_assert(MS_CH == 3, "the label registers of the three chunks are selected by hand below");
 #pragma unroll 1
     for (int ch = 0; ch < MS_CH; ch++) {
     const int wbase = (blockIdx.x * MS_CH + ch) * 256 + wv * 64;    // the wave's first 16-pixel word of this frame
     const int wi = wbase + lane;
-    uint32_t keepbits = 0; uint32_t lab4[2] = {0u, 0u};             // 4-bit labels (15 = none of the palette) of the lane's 16 pixels
+    uint32_t keepbits = 0;
+    const uint32_t lab4[2] = {ch == 0 ? labs[0][0] : ch == 1 ? labs[1][0] : labs[2][0], ch == 0 ? labs[0][1] : ch == 1 ? labs[1][1] : labs[2][1]};
     if (wi < words) {
         const size_t gw = (size_t)blockIdx.y * words + wi;
         const int gy = (int)__umulhi((uint32_t)wi, mul_wpr), xw = wi - gy * wpr;
         const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
-        const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
-        const uint4 D0 = pd[0], D1 = pd[1], S0 = ps[0], S1 = ps[1], S2 = ps[2];
+        const uint4 D0 = pd[0], D1 = pd[1];
         // vertical OR of rows gy - 2 .. gy + 2 for the word and its two neighbours, then the 5-wide horizontal OR
         const uint16_t* cb = cbits + (gy - ry0 - 2) * wpr + xw;
         uint32_t vl = 0, vc = 0, vr = 0;
@@ -687,15 +715,10 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
         const unsigned long long win = (unsigned long long)vl | ((unsigned long long)vc << 16) | ((unsigned long long)vr << 32);
         const uint32_t moving = (uint32_t)((win >> 14) | (win >> 15) | (win >> 16) | (win >> 17) | (win >> 18)) & 0xFFFFu;   // 5-wide OR
         const uint32_t dd[8] = {D0.x, D0.y, D0.z, D0.w, D1.x, D1.y, D1.z, D1.w};
-        const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-            const int o = 3 * k;
-            const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
-            const uint32_t ent = (uint32_t)__shfl((int)tab_entry, (int)((sbgr * 0x7589a82bu) >> 28), 64);
-            const uint32_t lab = (ent & 0xFFFFFFu) == sbgr ? ent >> 24 : 15u;          // 0..11, or 15
-            lab4[k >> 3] |= lab << (4 * (k & 7));
+            const uint32_t lab = (lab4[k >> 3] >> (4 * (k & 7))) & 15u;
             const bool gated = (0x805u >> lab) & 1u;                                  // sky 0, pole 2, cyclist 11 (bit 15 is clear)
             keepbits |= (uint32_t)(d != 0 && d <= dmax && !gated) << k;
         }
