@@ -695,13 +695,14 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
     const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
-    static_assert(MS_CH == 3, "the label registers of the three chunks are selected by hand below");
 #pragma unroll 1
     for (int ch = 0; ch < MS_CH; ch++) {
     const int wbase = (blockIdx.x * MS_CH + ch) * 256 + wv * 64;    // the wave's first 16-pixel word of this frame
     const int wi = wbase + lane;
     uint32_t keepbits = 0;
-    const uint32_t lab4[2] = {ch == 0 ? labs[0][0] : ch == 1 ? labs[1][0] : labs[2][0], ch == 0 ? labs[0][1] : ch == 1 ? labs[1][1] : labs[2][1]};
+    uint32_t lab4[2] = {labs[0][0], labs[0][1]};                     // (the chunk loop is not unrolled: the chunk's label registers by selects)
+#pragma unroll
+    for (int c_ = 1; c_ < MS_CH; c_++) { lab4[0] = ch == c_ ? labs[c_][0] : lab4[0]; lab4[1] = ch == c_ ? labs[c_][1] : lab4[1]; }
     if (wi < words) {
         const size_t gw = (size_t)blockIdx.y * words + wi;
         const int gy = (int)__umulhi((uint32_t)wi, mul_wpr), xw = wi - gy * wpr;
