@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box helper for development runs: gpurun -- 'bash scripts/gpu_try.sh <what>'
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+O=gpurun_out; mkdir -p $O
+case "$1" in
+  sgbm)
+    timeout 900 python3 -m pytest tests/test_sgbm.py tests/test_gpu_stereo_seq.py -x -q -m gpu 2>&1 | tail -15
+    for F in 1 2; do
+      echo "== form $F"; SSM_SGBM_FORM=$F timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 --no-cpu 2>$O/st_form$F.err | tee $O/st_form$F.json | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline'].get('stages_ms_per_frame'), d['roofline'].get('frac'))"
+    done
+    bash scripts/stereo_profile.sh 64 256 2>&1 | tail -40
+    ;;
+esac

@@ -25,6 +25,7 @@
 #include <climits>
 #include <mutex>
 #include <map>
+#include <set>
 #include <utility>
 #include <type_traits>
 
@@ -405,6 +406,313 @@ sgbm_col_wta(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ L0
         run_group(Vb, t0 + SGW_UN);
     }
 }
+// ------------------------------------------------------------------ round 4: TWO volumes (C and the row sum) instead of C + four L volumes
+// The five directions as two kernels that leave no per-direction volume behind (1.11 GB -> ~0.55 GB of HBM traffic per 1241 x 376 x 80 pair):
+//   sgbm_rows   both horizontal directions of a row by the same 16 lanes -> S04 = min(32767, L0 + L4), ONE volume.  L0 of a whole row (w1 x D x 2 B =
+//               186 KB) fits neither registers nor a CU's LDS, so the row is cut into segments of SGR_SEG columns: pass 1 walks the row left to right and
+//               keeps only L0 at the segment starts (a checkpoint volume of 1 / SGR_SEG of C); pass 2 walks the segments right to left -- the segment's
+//               costs are loaded once into registers, L0 is re-run forward from the checkpoint into registers, then L4 runs backward over the same
+//               registers and the saturated sum is stored.  Three recurrence steps per pixel instead of two, no L volume written or read.
+//   sgbm_sweep  the three directions that come from the previous row, (-1,-1), (0,-1), (+1,-1), AND the winner pass in one top-down sweep: a block owns a
+//               strip of TX columns of one frame, a 16-lane group CPG neighbouring columns, and the states L1, L2, L3 of the previous row live in registers.
+//               The diagonal predecessors cross groups through LDS (one barrier per row) and cross STRIPS through mailboxes in global memory: 8-byte
+//               {row tag, two costs} granules written by one agent-scope (sc1) store each -- the data is the flag, no fence (cdna_hip_programming.md G16
+//               R2) -- that the edge group of the neighbouring strip polls at the start of the next row; they are published right after the row's steps,
+//               before its winner pass, so a hand-off has most of a row time to land.  S = min(32767, S04 + L1 + L2 + L3) never leaves registers.
+//               Forward progress: the strips of a frame wait for each other, so a block takes its (frame, strip) from a TICKET (atomic counter) -- blocks
+//               that run hold the lowest tickets whatever order the hardware starts them in, so every frame whose strips all run finishes and frees its CUs;
+//               every spin is bounded and a time-out sets a flag the host reports (SSM_E_HIP) instead of hanging.
+// Saturation: every L is >= 0, so min(32767, a + b + ...) may be taken after every addition (exact), and partial sums of two values < 2^16 ... are kept
+// below 2^16 by clamping each operand to 32767 first.
+typedef unsigned long long sg_u64;
+#define SG_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define SGR_SEG 8
+#define SGS_SLOTS 4
+#define SGS_SPIN_LIMIT (1u << 20)
+template <int NP> __device__ __forceinline__ int sg_min_of(const uint32_t (&L)[NP])
+{
+    uint32_t m = L[0];
+#pragma unroll
+    for (int j = 1; j < NP; j++) m = pk_min16(m, L[j]);
+    return sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
+}
+// min(32767, a + b) on packed pairs, a and b any u16
+__device__ __forceinline__ uint32_t pk_addsat15(uint32_t a, uint32_t b)
+{
+    constexpr uint32_t MM = 0x7FFF7FFFu;
+    return pk_min16(pk_add16(pk_min16(a, MM), pk_min16(b, MM)), MM);
+}
+template <int K>
+__global__ void __launch_bounds__(256)
+sgbm_rows(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int P1, int P2)
+{
+    constexpr int D = 16 * K, NP = (K + 1) / 2, SEG = SGR_SEG;
+    constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
+    const bool live = g < h;                                  // dead groups run row 0 without stores (DPP wants the whole wave)
+    const int y = live ? g : 0;
+    const int nseg = (w1 + SEG - 1) / SEG;
+    const size_t rowi = (size_t)blockIdx.y * h + y;           // blockIdx.y = frame
+    const uint16_t* Crow = C_all + rowi * w1 * D + li * K;
+    uint16_t* Srow = S_all + rowi * w1 * D + li * K;
+    uint16_t* ck = ck_all + rowi * nseg * D + li * K;         // ck[s]: L0 in front of segment s (s >= 1)
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    uint32_t Ca[SEG][NP], Cb[SEG][NP];
+    auto load_seg = [&](uint32_t (&Cq)[SEG][NP], int s) {
+#pragma unroll
+        for (int u = 0; u < SEG; u++) sg_load_pk<K>(Cq[u], Crow + (size_t)min(s * SEG + u, w1 - 1) * D);
+    };
+    // ---- pass 1: L0 left to right, checkpoints only
+    if (nseg > 1) {
+        uint32_t L[NP]; int mp = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
+        auto fwd_seg = [&](const uint32_t (&Cq)[SEG][NP], int s) {
+#pragma unroll
+            for (int u = 0; u < SEG; u++) sg_step_pk<K>(L, mp, Cq[u], P1P1, P2);
+            if (live) sg_store_pk<K>(ck + (size_t)(s + 1) * D, L);
+        };
+        load_seg(Ca, 0);
+        for (int s = 0; s < nseg - 1; s += 2) {
+            if (s + 1 < nseg - 1) load_seg(Cb, s + 1);
+            fwd_seg(Ca, s);
+            if (s + 1 >= nseg - 1) break;
+            if (s + 2 < nseg - 1) load_seg(Ca, s + 2);
+            fwd_seg(Cb, s + 1);
+        }
+    }
+    // ---- pass 2: segments right to left; L0 forward from the checkpoint, L4 backward, the sum out
+    uint32_t R[NP]; int mpr = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) R[j] = j == NP - 1 ? LZERO_LAST : 0u;
+    uint32_t Fa[NP], Fb[NP];
+    auto load_ck = [&](uint32_t (&F)[NP], int s) {
+        if (s > 0) { sg_load_pk<K>(F, ck + (size_t)s * D); F[NP - 1] |= LZERO_LAST; }
+        else {
+#pragma unroll
+            for (int j = 0; j < NP; j++) F[j] = j == NP - 1 ? LZERO_LAST : 0u;
+        }
+    };
+    auto seg_run = [&](const uint32_t (&Cq)[SEG][NP], uint32_t (&F)[NP], int s) {
+        int mpf = sg_min_of<NP>(F);
+        uint32_t L0[SEG][NP];
+#pragma unroll
+        for (int u = 0; u < SEG; u++) {
+            if (s * SEG + u < w1) sg_step_pk<K>(F, mpf, Cq[u], P1P1, P2);          // (wave-uniform; false only in the last segment)
+#pragma unroll
+            for (int j = 0; j < NP; j++) L0[u][j] = F[j];
+        }
+#pragma unroll
+        for (int u = SEG - 1; u >= 0; u--) {
+            const int x = s * SEG + u;
+            if (x < w1) {
+                sg_step_pk<K>(R, mpr, Cq[u], P1P1, P2);
+                uint32_t S[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) S[j] = pk_addsat15(L0[u][j], R[j]);
+                if (live) sg_store_pk<K>(Srow + (size_t)x * D, S);
+            }
+        }
+    };
+    load_seg(Ca, nseg - 1); load_ck(Fa, nseg - 1);
+    for (int s = nseg - 1; s >= 0; s -= 2) {
+        if (s - 1 >= 0) { load_seg(Cb, s - 1); load_ck(Fb, s - 1); }
+        seg_run(Ca, Fa, s);
+        if (s - 1 < 0) break;
+        if (s - 2 >= 0) { load_seg(Ca, s - 2); load_ck(Fa, s - 2); }
+        seg_run(Cb, Fb, s - 1);
+    }
+}
+// mailbox of one (frame, seam, direction): [SGS_SLOTS][NP + 1][16 lanes] granules; granule j < NP = the lane's packed pair j, granule NP = the path's minimum
+template <int NG> __device__ __forceinline__ bool sg_mbox_wait(const sg_u64* g, unsigned epoch, uint32_t (&v)[NG], unsigned* flags)
+{
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NG; j++) { const sg_u64 x = __hip_atomic_load(g + j * 16, SG_RLX_AGENT); v[j] = (uint32_t)x; ok &= (unsigned)(x >> 32) == epoch; }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;                   // (the lanes of the polling group only: the others are masked off)
+        if (spins >= SGS_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(flags + 1, SG_RLX_AGENT) != 0u)) return false;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+#define SGS_UN 1
+template <int K, int CPG>
+__global__ void __launch_bounds__(1024)
+sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
+           int NS, int TX, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key, unsigned* flags /* [0] ticket counter, [1] time-out */, sg_u64* mbox_all, int* fail_out)
+{
+    constexpr int D = 16 * K, NP = (K + 1) / 2, NG = NP + 1;
+    constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;
+    extern __shared__ __align__(16) uint8_t sw_smem[];
+    __shared__ unsigned s_ticket; __shared__ int s_fail[2];
+    const int ng = blockDim.x >> 4, g = threadIdx.x >> 4, li = threadIdx.x & 15;
+    uint32_t* xch = reinterpret_cast<uint32_t*>(sw_smem);     // [parity 2][direction 2][ng][NG][16]: the state a group hands to its right (dir 0: L1 of its last column) / left (dir 1: L3 of its first column) neighbour
+    uint16_t* srow = reinterpret_cast<uint16_t*>(xch + (size_t)4 * ng * NG * 16) + (size_t)g * D;      // [ng][D]: S of the group's pixel for the sub-pixel taps
+    auto xslot = [&](int par, int dir, int gg) -> uint32_t* { return xch + ((size_t)((par * 2 + dir) * ng + gg) * NG) * 16 + li; };
+    if (threadIdx.x == 0) { s_ticket = atomicAdd(&flags[0], 1u); s_fail[0] = 0; s_fail[1] = 0; }
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {                       // "row -1": OpenCV's zeroed border
+        uint32_t* p = xslot(1, dir, g);
+#pragma unroll
+        for (int j = 0; j < NP; j++) p[j * 16] = j == NP - 1 ? LZERO_LAST : 0u;
+        p[NP * 16] = 0u;
+    }
+    __syncthreads();
+    const int t = (int)s_ticket, f = t / NS, strip = t - f * NS;
+    const int ngu = TX / CPG;                                 // groups of the block that own columns
+    const int x0 = strip * TX + g * CPG, xend = min((strip + 1) * TX, w1);
+    const uint16_t* Cf = C_all + (size_t)f * w1 * h * D + li * K; const uint16_t* Sf = S_all + (size_t)f * w1 * h * D + li * K;
+    disp1 += (size_t)f * w * h; disp2key += (size_t)f * w * h;
+    sg_u64* mb = mbox_all + (size_t)f * (NS - 1) * 2 * SGS_SLOTS * NG * 16 + li;
+    auto mslot = [&](int seam, int dir, int slot) -> sg_u64* { return mb + (size_t)(((seam * 2 + dir) * SGS_SLOTS + slot) * NG) * 16; };
+    const bool usedg = g < ngu;
+    const bool edgeL = g == 0 && strip > 0, edgeR = g == ngu - 1 && strip < NS - 1;
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    uint32_t L1[CPG][NP], L2[CPG][NP], L3[CPG][NP]; int m1[CPG], m2[CPG], m3[CPG];
+#pragma unroll
+    for (int c = 0; c < CPG; c++) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) L1[c][j] = L2[c][j] = L3[c][j] = j == NP - 1 ? LZERO_LAST : 0u;
+        m1[c] = m2[c] = m3[c] = 0;
+    }
+    uint32_t Va[SGS_UN][CPG][2][NP], Vb[SGS_UN][CPG][2][NP];       // [row][column][C, S04][pairs]
+    auto load_rows = [&](uint32_t (&V)[SGS_UN][CPG][2][NP], int y0) {
+#pragma unroll
+        for (int u = 0; u < SGS_UN; u++)
+#pragma unroll
+            for (int c = 0; c < CPG; c++) {
+                const size_t off = ((size_t)min(y0 + u, h - 1) * w1 + min(x0 + c, w1 - 1)) * D;
+                sg_load_pk<K>(V[u][c][0], Cf + off); sg_load_pk<K>(V[u][c][1], Sf + off);
+            }
+    };
+    bool stop = false;
+    auto run_rows = [&](const uint32_t (&V)[SGS_UN][CPG][2][NP], int y0) {
+#pragma unroll
+        for (int u = 0; u < SGS_UN; u++) {
+            const int y = y0 + u;
+            if (y >= h || stop) break;                            // block-uniform
+            // ---- the diagonal predecessors from outside the group (row y - 1)
+            uint32_t nl[NG], nr[NG];
+            const int pp = (y + 1) & 1;
+            {   const uint32_t* p = xslot(pp, 0, g > 0 ? g - 1 : 0);
+#pragma unroll
+                for (int j = 0; j < NG; j++) nl[j] = p[j * 16];
+                const uint32_t* q = xslot(pp, 1, g < ng - 1 ? g + 1 : g);
+#pragma unroll
+                for (int j = 0; j < NG; j++) nr[j] = q[j * 16];
+            }
+            if (g == 0 || g >= ngu - 1) {                         // strip borders: the neighbouring strip's mailbox, or the zeroed image border
+                bool okl = true, okr = true;
+                if (g == 0) {
+                    if (edgeL && y > 0) okl = sg_mbox_wait<NG>(mslot(strip - 1, 0, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nl, flags);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < NG; j++) nl[j] = j == NP - 1 ? LZERO_LAST : 0u;
+                    }
+                }
+                if (g >= ngu - 1) {
+                    if (edgeR && y > 0) okr = sg_mbox_wait<NG>(mslot(strip, 1, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nr, flags);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < NG; j++) nr[j] = j == NP - 1 ? LZERO_LAST : 0u;
+                    }
+                }
+                if (!(okl && okr)) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
+            }
+            // ---- the three steps of every column (L1 takes its left neighbour's previous state: columns right to left; L3 its right neighbour's: left to right)
+#pragma unroll
+            for (int c = CPG - 1; c >= 0; c--) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) L1[c][j] = c > 0 ? L1[c - 1][j] : nl[j];
+                m1[c] = c > 0 ? m1[c - 1] : (int)nl[NP];
+                sg_step_pk<K>(L1[c], m1[c], V[u][c][0], P1P1, P2);
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; c++) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) L3[c][j] = c < CPG - 1 ? L3[c + 1][j] : nr[j];
+                m3[c] = c < CPG - 1 ? m3[c + 1] : (int)nr[NP];
+                sg_step_pk<K>(L3[c], m3[c], V[u][c][0], P1P1, P2);
+                sg_step_pk<K>(L2[c], m2[c], V[u][c][0], P1P1, P2);
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; c++)
+                if (!(usedg && x0 + c < xend)) {                  // a column outside the strip / image: its neighbours see the zeroed border
+#pragma unroll
+                    for (int j = 0; j < NP; j++) L1[c][j] = L2[c][j] = L3[c][j] = j == NP - 1 ? LZERO_LAST : 0u;
+                    m1[c] = m2[c] = m3[c] = 0;
+                }
+            // ---- hand the border states on: LDS for the neighbouring groups, mailboxes for the neighbouring strips
+            {   uint32_t* p = xslot(y & 1, 0, g);
+#pragma unroll
+                for (int j = 0; j < NP; j++) p[j * 16] = L1[CPG - 1][j];
+                p[NP * 16] = (uint32_t)m1[CPG - 1];
+                uint32_t* q = xslot(y & 1, 1, g);
+#pragma unroll
+                for (int j = 0; j < NP; j++) q[j * 16] = L3[0][j];
+                q[NP * 16] = (uint32_t)m3[0];
+            }
+            if (edgeR) {
+                sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L1[CPG - 1][j], SG_RLX_AGENT);
+                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m1[CPG - 1], SG_RLX_AGENT);
+            }
+            if (edgeL) {
+                sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L3[0][j], SG_RLX_AGENT);
+                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3[0], SG_RLX_AGENT);
+            }
+            // ---- the winner pass of the group's pixels (sgbm_wta's arithmetic on S = min(32767, S04 + L1 + L2 + L3))
+#pragma unroll
+            for (int c = 0; c < CPG; c++) {
+                const bool live = usedg && x0 + c < xend;
+                const int x = x0 + c;
+                uint32_t sp2[NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) sp2[j] = pk_addsat15(pk_addsat15(pk_addsat15(L1[c][j], L2[c][j]), L3[c][j]), V[u][c][1][j]);
+                int Sv[K], best = INT_MAX;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int sh = 16 * (k & 1), j = k >> 1;
+                    Sv[k] = (int)((sp2[j] >> sh) & 0xFFFFu);
+                    best = min(best, (Sv[k] << 8) | (li * K + k));
+                    srow[li * K + k] = (uint16_t)Sv[k];
+                }
+                best = sg_rowmin(best);
+                const int minS = best >> 8, bestDisp = best & 255;
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
+                const unsigned long long bal = __ballot(bad);
+                const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;       // any lane of my 16-lane group
+                if (live && !rejected && li == 0) {
+                    int d = bestDisp;
+                    const int x2 = x + minX1 - d - minD;
+                    if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));
+                    if (0 < d && d < D - 1) {
+                        const int sm = srow[d - 1], s0 = srow[d], sp = srow[d + 1];
+                        const int denom2 = max(sm + sp - 2 * s0, 1);
+                        d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+                    } else d *= SG_DISP_SCALE;
+                    disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+                }
+                __builtin_amdgcn_wave_barrier();               // (the next pixel overwrites srow: LDS operations of a wave execute in order)
+            }
+            __syncthreads();
+            if (s_fail[y & 1]) stop = true;                       // a hand-off timed out: every wave leaves at the same row
+        }
+    };
+    load_rows(Va, 0);
+    for (int y0 = 0; y0 < h && !stop; y0 += 2 * SGS_UN) {
+        load_rows(Vb, y0 + SGS_UN);
+        run_rows(Va, y0);
+        if (y0 + SGS_UN >= h || stop) break;
+        load_rows(Va, y0 + 2 * SGS_UN);
+        run_rows(Vb, y0 + SGS_UN);
+    }
+}
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
 // S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
 // disparity table OpenCV fills while walking x from right to left, replacing an entry only by a strictly smaller cost) becomes
@@ -719,6 +1027,67 @@ static SgStreams& sg_streams(hipStream_t caller)
     }
     return *st;
 }
+// dynamic LDS above the 64 KB default needs the attribute on the current device's copy of the function: once per (device, kernel)
+static hipError_t sg_allow_lds(const void* fn, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    static std::mutex mu; static std::set<std::pair<int, const void*>> done;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return hipSuccess;
+    int lim = 0;
+    if (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lim <= 0) lim = 160 * 1024;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lim - 1024);
+    if (e == hipSuccess) done.insert({dev, fn});
+    return e;
+}
+// SSM_SGBM_FORM (read once per process): 2 = sgbm_rows + sgbm_sweep (default), 1 = four L volumes + sgbm_col_wta (round 3), 0 = five L volumes + sgbm_wta
+// (SSM_SGBM_FUSE_WTA=0, the older spelling of form 0, still works).  SSM_SGBM_STRIP: columns per sweep strip (tests: many seams on small images).
+static int sgbm_form()
+{
+    static const int form = [] {
+        const char* v = getenv("SSM_SGBM_FORM"); if (v) { const int f = atoi(v); return f < 0 ? 0 : f > 2 ? 2 : f; }
+        const char* u = getenv("SSM_SGBM_FUSE_WTA"); if (u && atoi(u) == 0) return 0;
+        return 2;
+    }();
+    return form;
+}
+#define SGS_CPG 2
+// per frame: mailbox granules of the sweep (every seam x 2 directions x SGS_SLOTS x (NP + 1) x 16 lanes); strips are at least 2 SGS_CPG columns wide
+static size_t sgbm_mbox_bytes_per_frame(int w1, int D)
+{
+    const int K = D / 16, NG = (K + 1) / 2 + 1, maxNS = (w1 + 2 * SGS_CPG - 1) / (2 * SGS_CPG);
+    return (size_t)(maxNS > 1 ? maxNS - 1 : 0) * 2 * SGS_SLOTS * NG * 16 * 8;
+}
+template <int K>
+static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck, unsigned* flags, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
+                                  int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int* fail_out, hipStream_t s)
+{
+    constexpr int NG = (K + 1) / 2 + 1, D = 16 * K;
+    const size_t np = (size_t)w * h, npb = np * nb;
+    const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
+    static const int strip_env = [] { const char* v = getenv("SSM_SGBM_STRIP"); return v ? atoi(v) : 0; }();
+    int cap = 64 * SGS_CPG;                                   // columns of a 1024-thread block
+    if (strip_env >= 2 * SGS_CPG && strip_env < cap) cap = strip_env / SGS_CPG * SGS_CPG;
+    int NS = (w1 + cap - 1) / cap;
+    const int TX = ((w1 + NS - 1) / NS + SGS_CPG - 1) / SGS_CPG * SGS_CPG;
+    NS = (w1 + TX - 1) / TX;
+    const int threads = (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
+    const size_t lds = (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;
+    hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sgbm_sweep<K, SGS_CPG>), lds);
+    if (e != hipSuccess) return e;
+    sgbm_rows<K><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
+    sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
+    e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
+    if (e != hipSuccess) return e;
+    const size_t mbytes = (size_t)nb * (NS - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
+    e = hipMemsetAsync(flags, 0, 256 + mbytes, s);           // ticket counter, time-out word, every granule's tag
+    if (e != hipSuccess) return e;
+    sgbm_sweep<K, SGS_CPG><<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
+                                                        reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
+    sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
+    return hipGetLastError();
+}
 template <int K>
 static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
                                  int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, hipStream_t s)
@@ -732,8 +1101,7 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     const size_t np = (size_t)w * h, npb = np * nb;
     const long long npix = (long long)w1 * h;
     const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
-    static const bool fuse = [] { const char* v = getenv("SSM_SGBM_FUSE_WTA"); return !(v && atoi(v) == 0); }();      // SSM_SGBM_FUSE_WTA=0: five L volumes + sgbm_wta
-    if (fuse) {
+    if (sgbm_form() == 1) {
         // four directions on the four side streams; the column direction follows on `s` with the winner pass inside (sgbm_col_wta)
         sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[0], w1, h, P1, P2);
         sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[1]>>>(C, Lv[4], w1, h, P1, P2);
@@ -778,10 +1146,10 @@ size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb)
     const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
     const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities * nb, np = (size_t)w * h * nb;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(32 * np) + 6 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256;
+    return al(32 * np) + 6 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256 + al(256 + (size_t)nb * sgbm_mbox_bytes_per_frame((int)w1, p.numberOfDisparities));
 }
 // left / right: device u8 images [nb][h][w]; disp_out: device int16 [nb][h][w] (x16 fixed point, (minD-1)*16 = invalid)
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s)
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag)
 {
     if (nb <= 0) return hipSuccess;
     const int minD = p.minDisparity, D = p.numberOfDisparities, maxD = minD + D;
@@ -807,6 +1175,7 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     unsigned* d2key = (unsigned*)q; q += al(np * 4);
     int* parent = (int*)q; q += al(np * 4);
     int* count = (int*)q; q += al(np * 4);
+    unsigned* sweep_flags = (unsigned*)q;                     // 256 bytes of flags, then the sweep's mailboxes
     const dim3 gimg((w + 255) / 256, h, nb);
     sgbm_prefilter<<<dim3((w + 255) / 256, h, nb * 2), 256, 0, s>>>(left, right, w, h, ftzero, planes);
     {
@@ -815,8 +1184,7 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
         const int nstrips = (w1 + TX - 1) / TX;
         const int tail = nstrips > 1 ? ((w1 - (nstrips - 1) * TX < SW2 && nstrips > 2) ? 2 : 1) : 0;     // a last strip narrower than the half window: the one before it reaches the border too
         auto launch = [&](auto kern) {
-            static bool attr_set = false;       // the ring of a wide window needs more than the 64 KB default of dynamic LDS
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
+            (void)sg_allow_lds(reinterpret_cast<const void*>(kern), lds);       // the ring of a wide window needs more than the 64 KB default of dynamic LDS
             kern<<<dim3(nstrips, nb), SGC_THREADS, lds, s>>>(planes, w, h, minD, D, minX1, w1, SW2, P2, TX, tail, C);
         };
         if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);       // src/stereo.cpp:16-27
@@ -824,7 +1192,13 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     }
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
-    switch (D / 16) {
+    if (sgbm_form() == 2) switch (D / 16) {
+#define SG_AGG2(KK) case KK: e = sgbm_aggregate2<KK>(C, Lv[0], Lv[1], sweep_flags, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, fail_flag, s); break;
+        SG_AGG2(1) SG_AGG2(2) SG_AGG2(3) SG_AGG2(4) SG_AGG2(5) SG_AGG2(6) SG_AGG2(8)
+#undef SG_AGG2
+        default: return hipErrorInvalidValue;
+    }
+    else switch (D / 16) {
         case 1: e = sgbm_aggregate<1>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
         case 2: e = sgbm_aggregate<2>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
         case 3: e = sgbm_aggregate<3>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;

@@ -48,6 +48,7 @@ struct StereoState {        // workspace of the stereo path (quad matcher, SGBM 
     uint8_t* pyr = nullptr; int16_t* der = nullptr;
     GfttWork gw{};                           // goodFeaturesToTrack workspace (kernels_quad.hip)
     int keycap = 0; int *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
+    int* sg_fail = nullptr;                  // set by sgbm_sweep when a strip hand-off times out (kernels_sgbm.hip)
     float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
     uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
     double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
@@ -272,6 +273,11 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
         int32_t ov = 0;
         HIPCHK(c, hipMemcpy(&ov, c->stereo->overflow, 4, hipMemcpyDeviceToHost));
         if (ov) { hipMemset(c->stereo->overflow, 0, 4); FAIL(c, SSM_E_CAPACITY, "goodFeaturesToTrack: more corner candidates than the buffer holds (w*h/4 + 1024)"); }
+        if (c->stereo->sg_fail) {
+            int32_t sf = 0;
+            HIPCHK(c, hipMemcpy(&sf, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost));
+            if (sf) { hipMemset(c->stereo->sg_fail, 0, 4); FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out (the disparities of this call are incomplete)"); }
+        }
     }
     if (with_map) {
         HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
@@ -1372,7 +1378,7 @@ extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
 // ---------------------------------------------------------------- stereo path: QuadFeatureMatch, StereoSGBM depth, VisualOdometryStereo
 static void stereo_free(StereoState* q)
 {
-    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.cand_bits, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->ncorner, q->has_prev, q->pts, q->status, q->err,
+    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.cand_bits, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->sg_fail, q->ncorner, q->has_prev, q->pts, q->status, q->err,
                   q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_wsN[0], q->dminN[0], q->sg_wsN[1], q->dminN[1], q->sg_wsN[2], q->dminN[2], q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
                   q->inliers, q->vo_result, q->in_stage };
     for (void* x : p) if (x) hipFree(x);
@@ -1400,9 +1406,10 @@ static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
     DALLOC(c, g.deps, (size_t)B * q->keycap * k_quad_gftt_deps_per_candidate()); DALLOC(c, g.depn, (size_t)B * q->keycap); DALLOC(c, g.state, (size_t)B * q->keycap);
     HIPCHK(c, hipMemset(g.cand_at, 0, (size_t)B * np * 4));      // gftt_finish_kernel keeps the map zeroed between calls
     DALLOC(c, g.cand_bits, (size_t)B * k_quad_gftt_bits_words(w, h));
-    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
+    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->sg_fail, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
     g.overflow = q->overflow;
     HIPCHK(c, hipMemset(q->overflow, 0, 4));
+    HIPCHK(c, hipMemset(q->sg_fail, 0, 4));
     DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
     DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1);
     return SSM_OK;
@@ -1523,7 +1530,7 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             hipStream_t sg = sgs[alt];
             struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
             prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg));
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail));
             HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dminN[alt], q->depth + (size_t)f0 * np, sg));
             prof_end(c);
         }
@@ -1678,10 +1685,18 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
     prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream));
+    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream, q->sg_fail));
     prof_end(c);
     *d_disp_out = q->disp; *d_depth_out = q->depth;
     return SSM_OK;
+}
+// the sweep kernel's time-out word, copied to the front of the pinned area with the results of a host-pointer call
+static int sgbm_fail_check(ssm_ctx* c)
+{
+    int32_t sf; memcpy(&sf, c->h_pinned, 4);
+    if (!sf) return SSM_OK;
+    hipMemset(c->stereo->sg_fail, 0, 4);
+    FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out (the disparities of this call are incomplete)");
 }
 extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp)
 {
@@ -1692,9 +1707,10 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));      // (the staged input images at the front of the pinned area are consumed)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    return SSM_OK;
+    return sgbm_fail_check(c);
 }
 extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
                                 double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
@@ -1709,10 +1725,11 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
     if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     memcpy(depth, c->h_pinned + 4 * np, np * 2);
     if (disp) memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    return SSM_OK;
+    return sgbm_fail_check(c);
 }
 
 // ---------------------------------------------------------------- VisualOdometryStereo::estimateMotion

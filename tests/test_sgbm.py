@@ -109,20 +109,41 @@ def test_gpu_sgbm_kitti_size(ctx, oracle):
     assert np.array_equal(g, oracle.sgbm(left, right, oracle.sgbm_params()))
 
 
-@pytest.mark.gpu
-def test_gpu_sgbm_five_volume_form_stays_equal(oracle, tmp_path):
-    """SSM_SGBM_FUSE_WTA=0 (read once per process): the five scan directions write their own L volumes and sgbm_wta reads them -- the form the fused
-    column + winner kernel replaced; it stays in the library for A/B runs and must keep producing the oracle's bits"""
+def _sgbm_in_subprocess(tmp_path, env, cases):
+    """the SGBM form / strip width are read once per process: run the library in a child with the given environment"""
     import os, subprocess, sys
-    left, right, _ = stereo_pair(72, 260, 5, noise=4)
-    ref = oracle.sgbm(left, right, oracle.sgbm_params(64, 7))
-    np.savez(tmp_path / "in.npz", left=left, right=right)
+    np.savez(tmp_path / "in.npz", **{f"{k}{i}": v for i, (l, r, _, _) in enumerate(cases) for k, v in (("l", l), ("r", r))})
     code = ("import numpy as np, semantic_slam_mapping_amd as ssm\n"
             f"g = np.load(r'{tmp_path / 'in.npz'}')\n"
             "c = ssm.Context(0, width=640, height=480, max_batch=1)\n"
-            "d = c.sgbm(g['left'], g['right'], c.sgbm_params(numberOfDisparities=64, SADWindowSize=7))\n"
-            f"np.save(r'{tmp_path / 'out.npy'}', d); c.close()\n")
+            f"P = {[(nd, sad) for _, _, nd, sad in cases]!r}\n"
+            "out = {}\n"
+            "for i, (nd, sad) in enumerate(P):\n"
+            "    out[f'd{i}'] = c.sgbm(g[f'l{i}'], g[f'r{i}'], c.sgbm_params(numberOfDisparities=nd, SADWindowSize=sad))\n"
+            "    out[f'raw{i}'] = c.sgbm(g[f'l{i}'], g[f'r{i}'], c.sgbm_params(numberOfDisparities=nd, SADWindowSize=sad), raw=True)\n"
+            "c.sync()\n"
+            f"np.savez(r'{tmp_path / 'out.npz'}', **out); c.close()\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSM_SGBM_FUSE_WTA="0", PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert np.array_equal(np.load(tmp_path / "out.npy"), ref)
+    return np.load(tmp_path / "out.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(SSM_SGBM_FUSE_WTA="0"), dict(SSM_SGBM_FORM="1"), dict(SSM_SGBM_FORM="2", SSM_SGBM_STRIP="8"), dict(SSM_SGBM_FORM="2", SSM_SGBM_STRIP="34")])
+def test_gpu_sgbm_forms_stay_equal(oracle, tmp_path, env):
+    """Three formulations of the five scan directions live in the library (kernels_sgbm.hip, SSM_SGBM_FORM): 0 = five L volumes + sgbm_wta
+    (SSM_SGBM_FUSE_WTA=0 is its older spelling), 1 = four L volumes + the column direction with the winner pass inside (round 3), 2 = the default:
+    sgbm_rows (both row directions -> one summed volume) + sgbm_sweep (three directions + winner pass, strips of columns handing their diagonal states
+    on through mailboxes).  All must produce the oracle's bits; SSM_SGBM_STRIP narrows the sweep's strips so that small images have many seams
+    (8 columns: 4 groups per block, every wave holds both strip edges; 34: strips that do not divide the width)."""
+    cases = []
+    for (h, w, nd, sad, seed, noise) in [(72, 260, 64, 7, 5, 4), (50, 150, 32, 3, 2, 0), (61, 333, 80, 11, 9, 6), (40, 120, 16, 5, 6, 0), (44, 300, 128, 9, 8, 3), (33, 170, 48, 5, 3, 2)]:
+        l, r, _ = stereo_pair(h, w, seed, planes=((nd // 4, None), (nd // 2 + 3, (0.3, 0.75, 0.3, 0.7))), noise=noise)
+        cases.append((l, r, nd, sad))
+    got = _sgbm_in_subprocess(tmp_path, env, cases)
+    for i, (l, r, nd, sad) in enumerate(cases):
+        po = oracle.sgbm_params(num_disp=nd, sad=sad)
+        raw_o = oracle.sgbm(l, r, po, raw=True)
+        assert np.array_equal(got[f"raw{i}"], raw_o), f"case {i} ({env}): {(got[f'raw{i}'] != raw_o).sum()} of {raw_o.size} raw disparities differ"
+        assert np.array_equal(got[f"d{i}"], oracle.sgbm(l, r, po)), f"case {i} ({env})"
