@@ -138,8 +138,7 @@ def stereo_main(args):
     Wd, Hd, D, ITERS = 1241, 376, 80, 200
     F = args.frames if args.frames != 1000 else 256           # frame pairs per step, resident in HBM (replicas on every rank: the sequence of a rank is its own)
     B = max(1, args.stereo_batch)
-    os.environ["SSM_STEREO_BATCH"] = str(B)
-    ctx = ssm.Context(local_rank, width=640, height=480, max_batch=1)
+    ctx = ssm.Context(local_rank, width=640, height=480, max_batch=B)      # the stereo path launches min(max_batch, 64) frame pairs at a time (ssm_stereo_batch)
     L, R = stereo_sequence(F, Wd, Hd, 100 + rank)
     dl = ctx.dev_alloc(L.nbytes); dr = ctx.dev_alloc(R.nbytes); ds = ctx.dev_alloc(F * ITERS * 3 * 4)
     ctx.h2d(dl, L); ctx.h2d(dr, R); ctx.h2d(ds, GlibcRand(0).draws(F * ITERS * 3))
@@ -233,6 +232,10 @@ def spawn_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # watchdog: a collective that hangs with every rank alive would otherwise wait for the driver's kill.  SSM_RANKS_TIMEOUT seconds of wall clock for the
+    # whole job (default 900), then every rank is stopped by PID (terminate, then kill) and the run fails with 124 -- never a re-exec
+    limit = float(os.environ.get("SSM_RANKS_TIMEOUT", "900"))
+    t_end = time.monotonic() + limit
     rc = 0
     alive = list(procs)
     while alive:
@@ -246,6 +249,17 @@ def spawn_ranks(n):
                 rc = code
                 for q in alive:
                     q.terminate()
+        if alive and time.monotonic() > t_end:
+            sys.stderr.write("bench.py: %d of %d ranks still running after %.0f s (SSM_RANKS_TIMEOUT): stopping them\n" % (len(alive), n, limit))
+            for q in alive:
+                q.terminate()
+            t_kill = time.monotonic() + 10
+            for q in alive:
+                try:
+                    q.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    q.kill(); q.wait()
+            return 124
     return rc
 
 
@@ -490,6 +504,7 @@ def main():
                         ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr(), nfr, stages=ssm.api.STAGE_MAP)
                 n_whole = ctx.map_export_table_dev(tab_buf.data_ptr(), tab_cap)
                 whole_ok = n_whole == n_merged and tab_buf[: n_whole * sharding.VOXEL_BYTES].cpu().numpy().tobytes() == merged_bytes
+                ctx.synth_frames_dev(SEED, lo, F, bgr.data_ptr(), dep.data_ptr(), sem.data_ptr(), pose.data_ptr())      # the resident buffers hold this rank's own block again
             merge_info["equals_single_gpu_map"] = whole_ok
             if rank == 0:
                 merge_info["verified"] = bool(merge_info["verified"] and whole_ok)

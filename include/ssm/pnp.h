@@ -32,6 +32,7 @@ public:
         double T[16]; for (int k = 0; k < 16; k++) T[k] = transform.data()[k];
         int success = 0;
         ssm::Device* dev = on_device ? OrbFeature::lastDevice() : nullptr;
+        if (dev && n > 65535) dev = nullptr;                                     // the device block numbers its edges with 16 bits: larger lists are solved on the host (same bits)
         if (dev) {                                                               // one 1024-thread block of libssm_hip.so (kernels_pnp.hip): ~3 x the host core
             const double kc[4] = {camera.fx, camera.fy, camera.cx, camera.cy}; int m = 0;
             dev->check(ssm_pnp_solve(dev->ctx(), im.data(), ob.data(), n, kc, min_inliers, T, inl.data(), &m, &success), "ssm_pnp_solve");

@@ -442,11 +442,11 @@ __device__ __forceinline__ uint32_t pk_addsat15(uint32_t a, uint32_t b)
     constexpr uint32_t MM = 0x7FFF7FFFu;
     return pk_min16(pk_add16(pk_min16(a, MM), pk_min16(b, MM)), MM);
 }
-template <int K>
+template <int K, int SEG>
 __global__ void __launch_bounds__(256)
 sgbm_rows(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int P1, int P2)
 {
-    constexpr int D = 16 * K, NP = (K + 1) / 2, SEG = SGR_SEG;
+    constexpr int D = 16 * K, NP = (K + 1) / 2;
     constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
     const bool live = g < h;                                  // dead groups run row 0 without stores (DPP wants the whole wave)
@@ -536,7 +536,20 @@ template <int NG> __device__ __forceinline__ bool sg_mbox_wait(const sg_u64* g, 
     }
 }
 #define SGS_UN 1
-template <int K, int CPG>
+// exact n / d (C's truncating division) for |n| < 2^22, 0 < d < 2^22 without the ~40-instruction integer division sequence: the float quotient is within one
+// of the true one, the remainder test repairs it
+__device__ __forceinline__ int sg_div_small(int n, int d)
+{
+    const int an = abs(n);
+    int q = (int)((float)an * __builtin_amdgcn_rcpf((float)d));
+    int r = an - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) q++;
+    return n < 0 ? -q : q;
+}
+// FAST: the launcher has checked that no cost can reach 2^15 (C <= P2 + SADWindowSize^2 x the largest pixel cost), so every L is below 2^15 and a sum of two
+// cannot wrap: three packed operations per addition less
+template <int K, int CPG, bool FAST>
 __global__ void __launch_bounds__(1024)
 sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
            int NS, int TX, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key, unsigned* flags /* [0] ticket counter, [1] time-out */, sg_u64* mbox_all, int* fail_out)
@@ -568,6 +581,7 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
     const bool usedg = g < ngu;
     const bool edgeL = g == 0 && strip > 0, edgeR = g == ngu - 1 && strip < NS - 1;
     const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    const int udiv = 100 - uniquenessRatio;
     uint32_t L1[CPG][NP], L2[CPG][NP], L3[CPG][NP]; int m1[CPG], m2[CPG], m3[CPG];
 #pragma unroll
     for (int c = 0; c < CPG; c++) {
@@ -591,7 +605,41 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
         for (int u = 0; u < SGS_UN; u++) {
             const int y = y0 + u;
             if (y >= h || stop) break;                            // block-uniform
-            // ---- the diagonal predecessors from outside the group (row y - 1)
+            // ---- the steps whose predecessor lives in this group's registers first: L1 of columns 1 .. CPG-1 (from the column to the left), L3 of columns
+            // 0 .. CPG-2 (from the column to the right), L2 of every column.  L1 and L3 are independent recurrences -- L1 flows left to right, L3 right to left --
+            // so what a strip hands to its right neighbour (L1 of its last column) never depends on what it receives from it (L3), and is published BEFORE
+            // the incoming mailboxes are polled: a hand-off has a whole row time to land instead of gating the neighbour's next publish (polling first made
+            // every row a round trip, poll -> steps -> publish -> latency: 5.5 - 6.9 us per row against 3.8 us of VALU issue)
+            static_assert(CPG >= 2, "the strip edges publish states computed from the group's own registers");
+#pragma unroll
+            for (int c = CPG - 1; c >= 1; c--) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) L1[c][j] = L1[c - 1][j];
+                m1[c] = m1[c - 1];
+                sg_step_pk<K>(L1[c], m1[c], V[u][c][0], P1P1, P2);
+            }
+#pragma unroll
+            for (int c = 0; c < CPG - 1; c++) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) L3[c][j] = L3[c + 1][j];
+                m3[c] = m3[c + 1];
+                sg_step_pk<K>(L3[c], m3[c], V[u][c][0], P1P1, P2);
+            }
+            if (edgeR) {                                          // (all columns of a strip that has a right neighbour are inside the image)
+                sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L1[CPG - 1][j], SG_RLX_AGENT);
+                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m1[CPG - 1], SG_RLX_AGENT);
+            }
+            if (edgeL) {
+                sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L3[0][j], SG_RLX_AGENT);
+                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3[0], SG_RLX_AGENT);
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; c++) sg_step_pk<K>(L2[c], m2[c], V[u][c][0], P1P1, P2);
+            // ---- the diagonal predecessors from outside the group (row y - 1): the neighbouring groups' through LDS, the neighbouring strips' through the mailboxes
             uint32_t nl[NG], nr[NG];
             const int pp = (y + 1) & 1;
             {   const uint32_t* p = xslot(pp, 0, g > 0 ? g - 1 : 0);
@@ -619,21 +667,12 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                 }
                 if (!(okl && okr)) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
             }
-            // ---- the three steps of every column (L1 takes its left neighbour's previous state: columns right to left; L3 its right neighbour's: left to right)
+            {
 #pragma unroll
-            for (int c = CPG - 1; c >= 0; c--) {
-#pragma unroll
-                for (int j = 0; j < NP; j++) L1[c][j] = c > 0 ? L1[c - 1][j] : nl[j];
-                m1[c] = c > 0 ? m1[c - 1] : (int)nl[NP];
-                sg_step_pk<K>(L1[c], m1[c], V[u][c][0], P1P1, P2);
-            }
-#pragma unroll
-            for (int c = 0; c < CPG; c++) {
-#pragma unroll
-                for (int j = 0; j < NP; j++) L3[c][j] = c < CPG - 1 ? L3[c + 1][j] : nr[j];
-                m3[c] = c < CPG - 1 ? m3[c + 1] : (int)nr[NP];
-                sg_step_pk<K>(L3[c], m3[c], V[u][c][0], P1P1, P2);
-                sg_step_pk<K>(L2[c], m2[c], V[u][c][0], P1P1, P2);
+                for (int j = 0; j < NP; j++) { L1[0][j] = nl[j]; L3[CPG - 1][j] = nr[j]; }
+                m1[0] = (int)nl[NP]; m3[CPG - 1] = (int)nr[NP];
+                sg_step_pk<K>(L1[0], m1[0], V[u][0][0], P1P1, P2);
+                sg_step_pk<K>(L3[CPG - 1], m3[CPG - 1], V[u][CPG - 1][0], P1P1, P2);
             }
 #pragma unroll
             for (int c = 0; c < CPG; c++)
@@ -642,7 +681,7 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                     for (int j = 0; j < NP; j++) L1[c][j] = L2[c][j] = L3[c][j] = j == NP - 1 ? LZERO_LAST : 0u;
                     m1[c] = m2[c] = m3[c] = 0;
                 }
-            // ---- hand the border states on: LDS for the neighbouring groups, mailboxes for the neighbouring strips
+            // ---- the border states for the neighbouring groups
             {   uint32_t* p = xslot(y & 1, 0, g);
 #pragma unroll
                 for (int j = 0; j < NP; j++) p[j * 16] = L1[CPG - 1][j];
@@ -652,18 +691,6 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                 for (int j = 0; j < NP; j++) q[j * 16] = L3[0][j];
                 q[NP * 16] = (uint32_t)m3[0];
             }
-            if (edgeR) {
-                sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
-#pragma unroll
-                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L1[CPG - 1][j], SG_RLX_AGENT);
-                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m1[CPG - 1], SG_RLX_AGENT);
-            }
-            if (edgeL) {
-                sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
-#pragma unroll
-                for (int j = 0; j < NP; j++) __hip_atomic_store(o + j * 16, ((sg_u64)(unsigned)(y + 1) << 32) | L3[0][j], SG_RLX_AGENT);
-                __hip_atomic_store(o + NP * 16, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3[0], SG_RLX_AGENT);
-            }
             // ---- the winner pass of the group's pixels (sgbm_wta's arithmetic on S = min(32767, S04 + L1 + L2 + L3))
 #pragma unroll
             for (int c = 0; c < CPG; c++) {
@@ -671,7 +698,12 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                 const int x = x0 + c;
                 uint32_t sp2[NP];
 #pragma unroll
-                for (int j = 0; j < NP; j++) sp2[j] = pk_addsat15(pk_addsat15(pk_addsat15(L1[c][j], L2[c][j]), L3[c][j]), V[u][c][1][j]);
+                for (int j = 0; j < NP; j++) {
+                    if (FAST) {                                   // L < 2^15, S04 <= 32767: pair sums stay below 2^16
+                        constexpr uint32_t MM = 0x7FFF7FFFu;
+                        sp2[j] = pk_min16(pk_add16(pk_min16(pk_add16(L1[c][j], L2[c][j]), MM), pk_min16(pk_add16(L3[c][j], V[u][c][1][j]), MM)), MM);
+                    } else sp2[j] = pk_addsat15(pk_addsat15(pk_addsat15(L1[c][j], L2[c][j]), L3[c][j]), V[u][c][1][j]);
+                }
                 int Sv[K], best = INT_MAX;
 #pragma unroll
                 for (int k = 0; k < K; k++) {
@@ -682,9 +714,16 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                 }
                 best = sg_rowmin(best);
                 const int minS = best >> 8, bestDisp = best & 255;
+                // "S (100 - u) < 100 minS and |d - best| > 1": for 0 <= u < 100 the first test is S <= floor((100 minS - 1) / (100 - u)), one division per pixel
                 bool bad = false;
+                if (udiv > 0) {                                   // (uniform)
+                    const int uth = minS > 0 ? sg_div_small(100 * minS - 1, udiv) : -1;
 #pragma unroll
-                for (int k = 0; k < K; k++) bad |= Sv[k] * (100 - uniquenessRatio) < minS * 100 && abs(bestDisp - (li * K + k)) > 1;
+                    for (int k = 0; k < K; k++) bad |= Sv[k] <= uth && (unsigned)(li * K + k - bestDisp + 1) > 2u;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; k++) bad |= Sv[k] * udiv < minS * 100 && (unsigned)(li * K + k - bestDisp + 1) > 2u;
+                }
                 const unsigned long long bal = __ballot(bad);
                 const bool rejected = ((bal >> (threadIdx.x & 48)) & 0xFFFFull) != 0;       // any lane of my 16-lane group
                 if (live && !rejected && li == 0) {
@@ -694,7 +733,7 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
                     if (0 < d && d < D - 1) {
                         const int sm = srow[d - 1], s0 = srow[d], sp = srow[d + 1];
                         const int denom2 = max(sm + sp - 2 * s0, 1);
-                        d = d * SG_DISP_SCALE + ((sm - sp) * SG_DISP_SCALE + denom2) / (denom2 * 2);
+                        d = d * SG_DISP_SCALE + sg_div_small((sm - sp) * SG_DISP_SCALE + denom2, denom2 * 2);
                     } else d *= SG_DISP_SCALE;
                     disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
                 }
@@ -1059,32 +1098,49 @@ static size_t sgbm_mbox_bytes_per_frame(int w1, int D)
     const int K = D / 16, NG = (K + 1) / 2 + 1, maxNS = (w1 + 2 * SGS_CPG - 1) / (2 * SGS_CPG);
     return (size_t)(maxNS > 1 ? maxNS - 1 : 0) * 2 * SGS_SLOTS * NG * 16 * 8;
 }
+static int sg_num_cus()
+{
+    static std::mutex mu; static std::map<int, int> cus;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    int& n = cus[dev];
+    if (n <= 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)) n = 256;
+    return n;
+}
 template <int K>
 static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck, unsigned* flags, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
-                                  int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int* fail_out, hipStream_t s)
+                                  bool costs_below_2_15, int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int* fail_out, hipStream_t s)
 {
     constexpr int NG = (K + 1) / 2 + 1, D = 16 * K;
     const size_t np = (size_t)w * h, npb = np * nb;
     const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
     static const int strip_env = [] { const char* v = getenv("SSM_SGBM_STRIP"); return v ? atoi(v) : 0; }();
-    int cap = 64 * SGS_CPG;                                   // columns of a 1024-thread block
+    static const int seg_env = [] { const char* v = getenv("SSM_SGBM_SEG"); return v ? atoi(v) : 0; }();
+    // strips: at most 64 groups x SGS_CPG columns per block, and as few strips as that allows (the widest blocks: a row costs every block the same barrier and
+    // hand-off whatever its width).  Measured at 64 pairs per launch: 10 strips of 118 columns 5.6 ms, 19 of 62 (two blocks per CU) the same, 12 of 98 7.4 ms --
+    // 768 blocks are exactly three rounds on 256 CUs, but the strips of the frame that straddles a round boundary wait a whole round for their neighbours to
+    // start, and the blocks they displace make a fourth round.  A launch that would leave most CUs empty (few frames) takes narrower strips, down to 32 columns.
+    int cap = 64 * SGS_CPG;
     if (strip_env >= 2 * SGS_CPG && strip_env < cap) cap = strip_env / SGS_CPG * SGS_CPG;
+    else { const int cus = sg_num_cus(); while (cap > 32 && (long)nb * ((w1 + cap - 1) / cap) * 2 <= cus) cap /= 2; }
     int NS = (w1 + cap - 1) / cap;
     const int TX = ((w1 + NS - 1) / NS + SGS_CPG - 1) / SGS_CPG * SGS_CPG;
     NS = (w1 + TX - 1) / TX;
     const int threads = (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
     const size_t lds = (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;
-    hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sgbm_sweep<K, SGS_CPG>), lds);
+    auto sweep = costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>;
+    hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sweep), lds);
     if (e != hipSuccess) return e;
-    sgbm_rows<K><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
+    if (seg_env == 6) sgbm_rows<K, 6><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
+    else sgbm_rows<K, SGR_SEG><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
     sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
     e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
     if (e != hipSuccess) return e;
     const size_t mbytes = (size_t)nb * (NS - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
     e = hipMemsetAsync(flags, 0, 256 + mbytes, s);           // ticket counter, time-out word, every granule's tag
     if (e != hipSuccess) return e;
-    sgbm_sweep<K, SGS_CPG><<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
-                                                        reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
+    sweep<<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
+                                       reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
@@ -1192,8 +1248,10 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     }
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
+    // the largest value C can take: P2 + SADWindowSize^2 x (gradient term <= 2 ftzero, raw term <= 255 / 4); every L is <= its C
+    const long cmax = (long)P2 + (long)SW * SW * (2 * ftzero + 63);
     if (sgbm_form() == 2) switch (D / 16) {
-#define SG_AGG2(KK) case KK: e = sgbm_aggregate2<KK>(C, Lv[0], Lv[1], sweep_flags, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, fail_flag, s); break;
+#define SG_AGG2(KK) case KK: e = sgbm_aggregate2<KK>(C, Lv[0], Lv[1], sweep_flags, w, w1, h, nb, p, minX1, P1, P2, cmax < 32768, d_tmp, d2key, wta_out, fail_flag, s); break;
         SG_AGG2(1) SG_AGG2(2) SG_AGG2(3) SG_AGG2(4) SG_AGG2(5) SG_AGG2(6) SG_AGG2(8)
 #undef SG_AGG2
         default: return hipErrorInvalidValue;

@@ -4,8 +4,10 @@
 // build container, which has no GPU and where sanitizer runtimes and the HIP runtime do not mix.  It computes nothing of the product: the numbers it
 // returns are placeholders.  It is linked into test_threads / test_pnp / test_png of a SAN build ONLY -- never into exp_mapping or the library.
 #include "ssm_hip.h"
+#include "ssm/pnp_core.h"
 #include <cstring>
 #include <string>
+#include <vector>
 struct ssm_ctx { ssm_config cfg; std::string err; };
 extern "C" {
 void ssm_config_default(ssm_config* c) { memset(c, 0, sizeof(*c)); c->width = 640; c->height = 480; c->orb_features = 1000; c->orb_scale = 1.2f; c->orb_levels = 8;
@@ -25,6 +27,21 @@ int ssm_backproject(ssm_ctx*, const uint16_t* depth, const uint8_t* rgb, const u
         out[n++] = p;
     }
     *n_out = n; return SSM_OK;
+}
+// PnPSolver::solvePnP goes to the device block whenever its thread has a context (include/ssm/pnp.h): under the sanitizers the same contract arithmetic
+// (pnp_core.h) runs on the host in its place
+int ssm_pnp_solve(ssm_ctx*, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16], uint8_t* inliers, int* n_inliers, int* success)
+{
+    if (n < 0 || n > 65535) return SSM_E_CAPACITY;
+    ssm_pnp::Camera c; c.fx = cam[0]; c.fy = cam[1]; c.cx = cam[2]; c.cy = cam[3];
+    std::vector<ssm_pnp::Edge> edges((size_t)n + 1); std::vector<unsigned char> inl((size_t)n + 1);
+    int ok = 0;
+    ssm_pnp::solve(img, obj, n, c, min_inliers, T, inl.data(), edges.data(), &ok);
+    int m = 0;
+    for (int i = 0; i < n; i++) { if (inliers) inliers[i] = inl[i]; m += inl[i] != 0; }
+    if (n_inliers) *n_inliers = m;
+    if (success) *success = ok;
+    return SSM_OK;
 }
 int ssm_voxel_filter(ssm_ctx*, const ssm_point* pts, int n, float, ssm_point* out, int cap, int* n_out)
 {
