@@ -21,4 +21,12 @@ case "$1" in
     run SSM_SGBM_STREAMS=3
     bash scripts/stereo_profile.sh 64 256 2>&1 | tail -12
     ;;
+  segpmc)
+    rm -rf $O/p_seg_pmc
+    timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_seg_pmc -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg_pmc.log 2>&1
+    python3 scripts/segnet_layers.py $O/p_seg_pmc 64 $O/segnet_layers.md; tail -3 $O/segnet_layers.md
+    ;;
+  alltests)
+    timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -15
+    ;;
 esac

@@ -24,8 +24,40 @@ STAGES = [  # (stage name, regex on the short kernel name); first match wins
 ]
 
 
+def demangle(n):
+    """rocprofv3's trace holds mangled names for template kernels, and binutils' c++filt stops at _Float16 parameters (DF16_): the kernel name and its
+    literal template arguments (bool / int) are all that is needed"""
+    m = re.match(r"_Z(\d+)", n)
+    if not m:
+        return n
+    ln = int(m.group(1)); p = m.end()
+    name, rest = n[p:p + ln], n[p + ln:]
+    if not rest.startswith("I"):
+        return name
+    args, q = [], 1
+    while q < len(rest) and rest[q] != "E":
+        a = re.match(r"L([a-z])(n?)(\d+)E", rest[q:])
+        if not a:
+            return name + "<...>"
+        v = ("-" if a.group(2) else "") + a.group(3)
+        args.append({"0": "false", "1": "true"}.get(v, v) if a.group(1) == "b" else v)
+        q += a.end()
+    return name + "<" + ", ".join(args) + ">"
+
+
+_SHORT = {}
+
+
 def short(n):
-    n = n.strip()
+    if n in _SHORT:
+        return _SHORT[n]
+    r = _short(n)
+    _SHORT[n] = r
+    return r
+
+
+def _short(n):
+    n = demangle(n.strip())
     if "rocprim" in n:
         m = re.search(r"wrapped_(\w+?)_config", n)
         return "rocprim::" + (m.group(1) if m else "kernel")

@@ -1,0 +1,190 @@
+"""Differential fuzzing of the HIP path against the CPU oracle (SURVEY.md s.4 lists property tests as the reference's missing test strategy; the
+hand-picked shapes of tests/test_gpu_parity.py cannot see what they do not name).  hypothesis draws the STRUCTURE of a case (sizes, duplicate density,
+strides, leaf, sub-batch size ...) and one integer `seed`; all bulk data comes from numpy.random.default_rng(seed), so a failing case is reproduced by
+its printed arguments alone and shrinks towards small sizes.
+
+Counter-example format (what a failure prints, and what to paste into a regression test):
+    FUZZ <test name> seed=<int> <name>=<value> ...      e.g.  FUZZ matcher seed=1234 nq=3 nt=2 pool=1 ratio=0.8
+followed by hypothesis' own `@reproduce_failure(...)` blob (settings(print_blob=True)).  Every drawn case is also appended to
+$SSM_FUZZ_LOG (default gpurun_out/fuzz_cases.log under the repo) BEFORE it runs, so the last line of that file names the case that crashed a process.
+Budget: about a minute for the whole file on an MI355X box (max_examples below), no deadline per example (the first example pays context creation)."""
+import os
+import numpy as np
+import pytest
+
+hyp = pytest.importorskip("hypothesis")
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+from conftest import CAM, SEED                                          # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+COMMON = dict(deadline=None, print_blob=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+def log_case(name, **kw):
+    line = "FUZZ " + name + " " + " ".join(f"{k}={v}" for k, v in kw.items())
+    path = os.environ.get("SSM_FUZZ_LOG", os.path.join(ROOT, "gpurun_out", "fuzz_cases.log"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    return line
+
+
+def same_struct(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+# ---------------------------------------------------------------- matcher: random sizes, duplicate rows (ties, zero distances), ratios
+@settings(max_examples=40, **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), nq=st.integers(1, 700), nt=st.integers(2, 900), pool=st.integers(1, 64),
+       dup=st.floats(0.0, 1.0), ratio=st.sampled_from([0.5, 0.7, 0.8, 0.95, 1.0]), flips=st.integers(0, 3))
+def test_fuzz_matcher(ctx, oracle, seed, nq, nt, pool, dup, ratio, flips):
+    """OrbFeature::match (/root/reference/src/orb.cpp:16-29): a fraction `dup` of the rows of both sets comes from a small pool of descriptors (exact
+    duplicates: equal distances, zero distances, ties that must go to the lower trainIdx), each copy with up to `flips` flipped bits (near ties)"""
+    msg = log_case("matcher", seed=seed, nq=nq, nt=nt, pool=pool, dup=round(dup, 3), ratio=ratio, flips=flips)
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (pool, 32), dtype=np.uint8)
+
+    def make(n):
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        pick = rng.random(n) < dup
+        d[pick] = base[rng.integers(0, pool, int(pick.sum()))]
+        for _ in range(flips):
+            rows = rng.integers(0, n, max(1, n // 4)); bits = rng.integers(0, 256, len(rows))
+            d[rows, bits >> 3] ^= (1 << (bits & 7)).astype(np.uint8)
+        return d
+    q, t = make(nq), make(nt)
+    gi, gd = ctx.knn2(q, t); oi, od = oracle.knn2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od), msg
+    assert same_struct(ctx.match(q, t, ratio), oracle.match(q, t, ratio)), msg
+
+
+# ---------------------------------------------------------------- voxel filter: random clouds, leaves, voxel-boundary coordinates, labels
+@settings(max_examples=25, **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 6000), leaf=st.sampled_from([0.02, 0.05, 0.1, 0.25, 0.5, 1.0]), extent=st.sampled_from([0.3, 2.0, 15.0, 60.0]),
+       on_grid=st.floats(0.0, 0.5), clones=st.floats(0.0, 0.5))
+def test_fuzz_voxel_filter(ctx, oracle, seed, n, leaf, extent, on_grid, clones):
+    """pcl::VoxelGrid as Mapper::viewer uses it (/root/reference/src/mapper.cpp:106-107,154-155): points around the origin (negative coordinates), a fraction
+    exactly ON voxel boundaries (multiples of the leaf in float: floor() decides), a fraction exact clones (many points per voxel), random colours / labels"""
+    from oracle.binding import POINT_DTYPE
+    msg = log_case("voxel_filter", seed=seed, n=n, leaf=leaf, extent=extent, on_grid=round(on_grid, 3), clones=round(clones, 3))
+    rng = np.random.default_rng(seed)
+    pts = np.zeros(n, POINT_DTYPE)
+    xyz = ((rng.random((n, 3)) - 0.5) * 2 * extent).astype(np.float32)
+    g = rng.random(n) < on_grid
+    xyz[g] = (np.round(xyz[g] / np.float32(leaf)) * np.float32(leaf)).astype(np.float32)
+    c = rng.random(n) < clones
+    if c.any():
+        xyz[c] = xyz[rng.integers(0, n, int(c.sum()))]
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["w"] = 1.0
+    for ch in "bgr":
+        pts[ch] = rng.integers(0, 256, n)
+    pts["a"] = 255
+    pts["label"] = rng.choice(np.array([0, 1, 4, 9, 11, 255], np.uint32), n)
+    got = ctx.voxel_filter(pts, leaf=leaf); ref = oracle.voxel_filter(pts, np.float32(leaf))
+    assert same_struct(got, ref), msg + f" ({len(got)} vs {len(ref)} voxels)"
+
+
+# ---------------------------------------------------------------- fused map stage of the sequence path: geometry, depth holes, label layouts, pose
+PALETTE = np.array([[128, 128, 128], [0, 0, 128], [128, 192, 192], [0, 69, 255], [128, 64, 128], [222, 40, 60], [0, 128, 128], [128, 128, 192],
+                    [128, 64, 64], [128, 0, 64], [0, 64, 64], [192, 128, 0]], np.uint8)      # BGR, tests/golden/palette.json
+
+
+@settings(max_examples=12, **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), w16=st.integers(4, 26), h=st.integers(64, 150), n=st.integers(1, 4), holes=st.floats(0.0, 0.9),
+       block=st.sampled_from([1, 3, 8, 32]), stray=st.floats(0.0, 0.2), far=st.floats(0.0, 0.3), leaf=st.sampled_from([0.02, 0.1, 0.4]), batch=st.integers(1, 3))
+def test_fuzz_sequence_map_stage(oracle, seed, w16, h, n, holes, block, stray, far, leaf, batch):
+    """Mapper::generatePointCloud + semantic_motion_fuse + the map fusion (/root/reference/src/mapper.cpp:12-94,189-216,96-171) through ssm_seq_process (stage
+    SSM_STAGE_MAP: map_stream2_kernel): width a multiple of 16, random height, `holes` of the depth zero, `far` beyond mapper_max_distance, labels in blocks of
+    `block` pixels (1 = per-pixel noise: the 5 x 5 dilate of single moving pixels), a fraction `stray` of colours outside the palette, a random rigid pose per
+    frame, sub-batches of `batch` frames"""
+    import semantic_slam_mapping_amd as ssm
+    W, H = 16 * w16, h
+    msg = log_case("sequence_map_stage", seed=seed, W=W, H=H, n=n, holes=round(holes, 3), block=block, stray=round(stray, 3), far=round(far, 3), leaf=leaf, batch=batch)
+    rng = np.random.default_rng(seed)
+    cam = (W / 2 - 0.4 + rng.random(), H / 2 + 0.3 - rng.random(), 400.0 + 200 * rng.random(), 410.0 + 180 * rng.random(), 1000.0)
+    c = ssm.Context(0, width=W, height=H, orb_features=200, orb_levels=3, max_batch=batch, voxel_capacity_log2=18, camera=cam, mapper_resolution=leaf)
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    try:
+        bgr = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        dep = rng.integers(300, 9000, (n, H, W)).astype(np.uint16)
+        dep[rng.random((n, H, W)) < holes] = 0
+        dep[rng.random((n, H, W)) < far] = rng.integers(40001, 65536)
+        ids = rng.integers(0, 12, (n, (H + block - 1) // block, (W + block - 1) // block))
+        ids = np.repeat(np.repeat(ids, block, axis=1), block, axis=2)[:, :H, :W]
+        sem = PALETTE[ids]
+        s = rng.random((n, H, W)) < stray
+        sem[s] = rng.integers(0, 256, (int(s.sum()), 3), dtype=np.uint8)
+        poses = []
+        for _ in range(n):
+            a = rng.normal(size=3); a /= np.linalg.norm(a); th = rng.random() * 0.6
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            T = np.eye(4); T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K; T[:3, 3] = rng.normal(size=3) * 2
+            poses.append(T)
+        c.h2d(bufs[0], bgr); c.h2d(bufs[1], dep); c.h2d(bufs[2], np.ascontiguousarray(sem)); c.h2d(bufs[3], np.stack([T.T.reshape(16) for T in poses]))
+        c.map_clear()
+        out = c.seq_process(*bufs, n, stages=ssm.api.STAGE_MAP)
+        c.sync()
+        res = c.seq_fetch(out, n)
+        clouds = []
+        for i in range(n):
+            cl = oracle.backproject(dep[i], bgr[i], sem[i], oracle.moving_mask(sem[i]), cam, poses[i], 40.0)
+            assert int(res["npoints"][i]) == len(cl), msg + f" frame {i}: {int(res['npoints'][i])} vs {len(cl)} points"
+            clouds.append(cl)
+        ref = oracle.voxel_filter(np.concatenate(clouds), np.float32(leaf)) if sum(map(len, clouds)) else np.zeros(0, clouds[0].dtype)
+        got = c.map_export()
+        assert same_struct(got, ref), msg + f" ({len(got)} vs {len(ref)} voxels)"
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
+
+
+# ---------------------------------------------------------------- sub-batch size against tracker_ref_frames: the match tables of a sequence
+@settings(max_examples=6, **COMMON)
+@given(first=st.integers(0, 500), n=st.integers(2, 8), R=st.integers(1, 5), batch=st.integers(1, 4), cont=st.integers(0, 3))
+def test_fuzz_sub_batches_against_ref_window(oracle, first, n, R, batch, cont):
+    """Tracker::trackRefFrame matches a frame against the tracker_ref_frames frames before it (/root/reference/src/track.cpp:150-152,192-196).  The sequence
+    path cuts a call into sub-batches (up to three chains on three streams) and carries the reference descriptors across sub-batches AND across calls
+    (continue_sequence): any (n, R, batch, split of the sequence into two calls at frame `cont`) must give the oracle's per-pair match lists"""
+    import semantic_slam_mapping_amd as ssm
+    W, H, NF = 320, 240, 300
+    msg = log_case("sub_batches", first=first, n=n, R=R, batch=batch, cont=cont)
+    c = ssm.Context(0, width=W, height=H, orb_features=NF, orb_levels=4, max_batch=batch, tracker_ref_frames=R, voxel_capacity_log2=16, camera=CAM)
+    assert c.R == R
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    try:
+        fr = [oracle.synth_frame(SEED, first + i, W, H) for i in range(n)]
+        c.h2d(bufs[0], np.stack([f[0] for f in fr])); c.h2d(bufs[1], np.stack([f[1] for f in fr])); c.h2d(bufs[2], np.stack([f[2] for f in fr]))
+        c.h2d(bufs[3], np.stack([f[4].T.reshape(16) for f in fr]))
+        split = min(cont, n - 1)                                  # frames [0, split) in a first call, the rest in a second with continue_sequence
+        parts = [(0, split), (split, n)] if split > 0 else [(0, n)]
+        nmatch, matches, nkp, desc = [], [], [], []
+        for a, b in parts:
+            out = c.seq_process(bufs[0] + a * W * H * 3, bufs[1] + a * W * H * 2, bufs[2] + a * W * H * 3, bufs[3] + a * 128, b - a, continue_sequence=a > 0, stages=3)
+            c.sync()
+            res = c.seq_fetch(out, b - a)
+            nmatch.append(res["nmatch"]); matches.append(res["matches"]); nkp.append(res["nkp"]); desc.append(res["desc"])
+        nmatch = np.concatenate(nmatch); matches = np.concatenate(matches); nkp = np.concatenate(nkp); desc = np.concatenate(desc)
+        od = []
+        for i in range(n):
+            ok, d = oracle.orb_extract(oracle.bgr2gray(fr[i][0]), nfeatures=NF, nlevels=4)
+            assert int(nkp[i]) == len(ok) and np.array_equal(desc[i, :len(ok)], d), msg + f" frame {i}: descriptors"
+            od.append(d)
+        for i in range(n):
+            for r in range(R):
+                ref = i - R + r
+                if ref < 0 or len(od[i]) < 2:
+                    assert nmatch[i, r] == -1, msg + f" pair ({ref}, {i})"
+                    continue
+                om = oracle.match(od[ref], od[i], c.cfg.knn_match_ratio) if len(od[ref]) else np.zeros(0, matches.dtype)
+                assert nmatch[i, r] == len(om) and same_struct(matches[i, r, :len(om)], om), msg + f" pair ({ref}, {i})"
+    finally:
+        for p in bufs:
+            c.dev_free(p)
+        c.close()
