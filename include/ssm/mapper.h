@@ -7,9 +7,15 @@
 // instead of a hard-coded absolute path (mapper.cpp:167).  The unsigned wrap of `i > keyframes.size()-6`
 // (mapper.cpp:134: with fewer than 6 key-frames the incremental branch adds nothing) IS reproduced unless
 // mapper_fix_incremental=1.
+// Round 4: the viewer's map lives on the DEVICE (mapper_device_map, default 1).  The reference (and this class before) makes a host copy of every chosen
+// key-frame's cloud, transforms it in a host loop, concatenates on the host and pushes the WHOLE map through the filter on every update.  Now a key-frame's
+// camera-frame cloud is made once and stays in HBM (ssm_backproject_dev: the device form of frame->pointcloud, mapper.cpp:17-20), an update transforms
+// the chosen clouds by their current poses, adds the previous centroids and filters, all on the device (ssm_viewer_map_update), and only the map that is
+// published (globalMap / the PCD) is downloaded.  Same bytes: the filter's sums are exact integers, independent of the order of the points.
 #pragma once
 #include "common_headers.h"
 #include <atomic>
+#include <unordered_map>
 #include "device.h"
 #include "pose_graph.h"
 #include "rgbdframe.h"
@@ -26,6 +32,7 @@ public:
         fix_incremental = para.getData<int>("mapper_fix_incremental", 0) != 0;
         invert_pose = para.getData<int>("mapper_invert_pose", 0) != 0;          // the commented alternative at mapper.cpp:89
         map_output = para.getData<string>("map_output", string(""));
+        device_map = para.getData<int>("mapper_device_map", 1) != 0;
         viewerThread = make_shared<thread>(bind(&Mapper::viewer, this));
     }
     void shutdown() { shutdownFlag = true; if (viewerThread != nullptr && viewerThread->joinable()) viewerThread->join(); }
@@ -42,18 +49,36 @@ public:
             if (nkf <= (size_t)keyframe_size) { this_thread::sleep_for(chrono::milliseconds(1)); continue; }
             vector<RGBDFrame::Ptr> kfs; { unique_lock<mutex> lck(poseGraph.keyframes_mutex); kfs = poseGraph.keyframes; }
             auto t0 = chrono::steady_clock::now();
-            if (cntGlobalUpdate % 15 == 0) {
-                map->clear();
-                for (size_t i = 0; i < kfs.size(); i += 2) *map += *generatePointCloud(kfs[i]);
-            } else if (fix_incremental) {
-                for (int i = (int)kfs.size() - 1; i >= 0 && i > (int)kfs.size() - 6; i--) *map += *generatePointCloud(kfs[i]);
+            // the key-frames this update adds (mapper.cpp:121-141)
+            vector<RGBDFrame::Ptr> sel; const bool rebuild = cntGlobalUpdate % 15 == 0;
+            if (rebuild) { for (size_t i = 0; i < kfs.size(); i += 2) sel.push_back(kfs[i]); }
+            else if (fix_incremental) { for (int i = (int)kfs.size() - 1; i >= 0 && i > (int)kfs.size() - 6; i--) sel.push_back(kfs[i]); }
+            else { for (int i = (int)kfs.size() - 1; i >= 0 && (size_t)i > kfs.size() - 6; i--) sel.push_back(kfs[i]); }      // size_t wrap as in mapper.cpp:134
+            if (device_map) {
+                // clouds stay in HBM; transform + concatenation + VoxelGrid on the device, one download of the filtered map
+                ssm::Device& d = device(sel.empty() ? 0 : sel[0]->depth.cols, sel.empty() ? 0 : sel[0]->depth.rows);
+                vector<ssm_cloud*> cl; vector<double> poses;
+                for (const RGBDFrame::Ptr& f : sel) {
+                    cl.push_back(deviceCloud(f));
+                    const Eigen::Isometry3d T = invert_pose ? f->getTransform().inverse() : f->getTransform();
+                    poses.insert(poses.end(), T.data(), T.data() + 16);
+                }
+                int nmap = 0;
+                d.check(ssm_viewer_map_update(d.ctx(), rebuild ? 1 : 0, cl.data(), poses.data(), (int)cl.size(), (float)resolution, &nmap), "ssm_viewer_map_update");
+                cntGlobalUpdate++;
+                keyframe_size = (int)kfs.size();
+                map->points.resize((size_t)nmap);
+                int got = 0;
+                d.check(ssm_viewer_map_fetch(d.ctx(), reinterpret_cast<ssm_point*>(map->points.data()), nmap, &got), "ssm_viewer_map_fetch");
+                map->points.resize((size_t)got); map->width = got;
             } else {
-                for (int i = (int)kfs.size() - 1; i >= 0 && (size_t)i > kfs.size() - 6; i--) *map += *generatePointCloud(kfs[i]);   // size_t wrap as in mapper.cpp:134
+                if (rebuild) map->clear();
+                for (const RGBDFrame::Ptr& f : sel) *map += *generatePointCloud(f);
+                cntGlobalUpdate++;
+                PointCloud::Ptr tmp = voxelFilter(map);
+                keyframe_size = (int)kfs.size();
+                map->swap(*tmp);
             }
-            cntGlobalUpdate++;
-            PointCloud::Ptr tmp = voxelFilter(map);
-            keyframe_size = (int)kfs.size();
-            map->swap(*tmp);
             { unique_lock<mutex> lck(mapMutex); globalMap.reset(new PointCloud(*map)); }
             const double ms = chrono::duration<double, milli>(chrono::steady_clock::now() - t0).count();
             cout << "points in global map: " << map->points.size() << endl;
@@ -63,6 +88,21 @@ public:
             cerr << "Mapper::viewer stopped: " << e.what() << endl; viewerFailed = true;
         }
         if (poseGraph.shutDownFlag && !map_output.empty()) { writePCD(map_output, *map); cout << "Map saved!" << endl; }
+        for (auto& kv : devClouds) ssm_cloud_free(dev ? dev->ctx() : nullptr, kv.second);      // the device clouds belong to this thread's context
+        devClouds.clear();
+    }
+    // the device form of frame->pointcloud: made once per key-frame, kept in HBM (viewer thread only)
+    ssm_cloud* deviceCloud(const RGBDFrame::Ptr& frame) {
+        auto it = devClouds.find(frame.get());
+        if (it != devClouds.end()) return it->second;
+        ssm::Device& d = device(frame->depth.cols, frame->depth.rows);
+        const int w = frame->depth.cols, h = frame->depth.rows;
+        ssm_camera cam; cam.cx = frame->camera.cx; cam.cy = frame->camera.cy; cam.fx = frame->camera.fx; cam.fy = frame->camera.fy; cam.scale = frame->camera.scale;
+        ssm_cloud* cl = nullptr;
+        d.check(ssm_backproject_dev(d.ctx(), frame->depth.ptr<uint16_t>(), frame->rgb.data, frame->semantic.data, w, h, &cam, max_distance, &cl), "ssm_backproject_dev");
+        devClouds[frame.get()] = cl;
+        cloudsComputed++;
+        return cl;
     }
     // binary PCD, FIELDS x y z rgba (what pcl::PCDWriter::write emits for PointXYZRGBA)
     static bool writePCD(const string& path, const PointCloud& c) {
@@ -131,7 +171,8 @@ protected:
     int keyframe_size = 0; std::atomic<int> cntGlobalUpdate{0};       // read by other threads (updates()): atomic -- the reference's plain int is a data race
     double resolution = 0.8, max_distance = 8.0;
     std::atomic<bool> shutdownFlag{false};                           // set by shutdown() on another thread (ThreadSanitizer finding, profiles/r03_sanitizers.log)
-    bool fix_incremental = false, invert_pose = false;
+    bool fix_incremental = false, invert_pose = false, device_map = true;
+    std::unordered_map<const RGBDFrame*, ssm_cloud*> devClouds;       // key-frame -> its camera-frame cloud in device memory (held until the viewer ends)
     int area_thres = 1000; double overlay_portion_thres = 0.143;
     string map_output;
 };

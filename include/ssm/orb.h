@@ -2,6 +2,7 @@
 // methods.  The ORB_SLAM2 extractor + cv::BFMatcher pair is replaced by libssm_hip.so (ssm_orb_extract / ssm_match).
 #pragma once
 #include "common_headers.h"
+#include <deque>
 #include "device.h"
 #include "rgbdframe.h"
 namespace rgbd_tutor {
@@ -38,6 +39,25 @@ public:
         d.check(ssm_match(d.ctx(), d1.data, d1.rows, d2.data, d2.rows, knn_match_ratio, reinterpret_cast<ssm_dmatch*>(matches.data()), d1.rows, &n), "ssm_match");
         matches.resize(n);
         return matches;
+    }
+    // match(ref, frame) for every reference frame, as Tracker::trackRefFrame's loop makes them (src/track.cpp:150-152) -- the same calls, enqueued back to
+    // back (ssm_match_async) and completed by ONE wait: the kernels of the five pairs run without a host round trip between them.  Same lists as match().
+    vector<vector<cv::DMatch>> matchMany(const std::deque<RGBDFrame::Ptr>& refs, const RGBDFrame::Ptr& frame) const {
+        vector<vector<cv::DMatch>> all(refs.size());
+        cv::Mat d2 = frame->getAllDescriptors();
+        if (d2.rows < 2 || refs.empty()) return all;
+        ssm::Device& d = device(frame->rgb.cols, frame->rgb.rows);
+        vector<int> n(refs.size(), 0);
+        vector<cv::Mat> d1(refs.size());
+        for (size_t i = 0; i < refs.size(); i++) {
+            d1[i] = refs[i]->getAllDescriptors();
+            if (d1[i].rows == 0) continue;
+            all[i].resize(d1[i].rows);
+            d.check(ssm_match_async(d.ctx(), d1[i].data, d1[i].rows, d2.data, d2.rows, knn_match_ratio, reinterpret_cast<ssm_dmatch*>(all[i].data()), d1[i].rows, &n[i]), "ssm_match_async");
+        }
+        d.check(ssm_wait(d.ctx()), "ssm_wait");
+        for (size_t i = 0; i < refs.size(); i++) all[i].resize(n[i]);
+        return all;
     }
     ssm::Device& device(int w, int h) const {     // one context per calling thread and frame geometry
         thread_local map<pair<const void*, pair<int, int>>, unique_ptr<ssm::Device>> devs;

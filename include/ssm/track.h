@@ -90,8 +90,10 @@ protected:
         currentFrame->setTransform(speed * refFrames.back()->getTransform());
         orb->detectFeatures(currentFrame);
         vector<cv::Point3f> obj; vector<cv::Point2f> img;
+        const vector<vector<cv::DMatch>> allMatches = orb->matchMany(refFrames, currentFrame);      // orb->match(pFrame, currentFrame) for every pFrame, one wait
+        size_t ri = 0;
         for (auto pFrame : refFrames) {
-            vector<cv::DMatch> matches = orb->match(pFrame, currentFrame);
+            const vector<cv::DMatch>& matches = allMatches[ri++];
             Eigen::Isometry3d invPose = pFrame->getTransform().inverse();
             for (auto m : matches) {
                 cv::Point3f pObj = pFrame->features[m.queryIdx].position;

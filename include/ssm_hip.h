@@ -90,6 +90,15 @@ int ssm_hamming_knn2(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, i
 /* ---- OrbFeature::match (src/orb.cpp:16-29): knn + ratio test, ascending queryIdx */
 int ssm_match(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
               ssm_dmatch* out, int cap, int* n_out);
+/* ---- asynchronous forms of the two calls a tracker frame makes (Tracker::trackRefFrame, src/track.cpp:140-163: detectFeatures, then one match per
+ * reference frame).  The call stages its inputs in the context's pinned ring, enqueues the copies and kernels on the context stream and returns; the
+ * results (and *n_out) are written into the caller's buffers by ssm_wait, which completes every pending call in the order it was made and returns the first
+ * error.  Input buffers may be reused at once (they have been copied); OUTPUT buffers and n_out must stay valid until ssm_wait.  ssm_orb_extract / ssm_match
+ * are these + ssm_wait; any other entry point of the context may be called in between (same stream: it runs behind the pending work). */
+int ssm_orb_extract_async(ssm_ctx* ctx, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+                          ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out);
+int ssm_match_async(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, ssm_dmatch* out, int cap, int* n_out);
+int ssm_wait(ssm_ctx* ctx);
 
 /* ---- Mapper::semantic_motion_fuse (src/mapper.cpp:189-216): sem = BGR class-colour image, mask = w*h bytes */
 int ssm_moving_mask(ssm_ctx* ctx, const uint8_t* sem_bgr, int w, int h, int stride, uint8_t* mask);
@@ -101,6 +110,21 @@ int ssm_backproject(ssm_ctx* ctx, const uint16_t* depth, const uint8_t* rgb_bgr,
 
 /* ---- pcl::VoxelGrid::filter as used in Mapper::viewer (src/mapper.cpp:106-107,154-155) */
 int ssm_voxel_filter(ssm_ctx* ctx, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out);
+/* ---- the device-resident form of the two calls above, for Mapper::viewer (src/mapper.cpp:96-171): a key-frame's gated camera-frame cloud is made ONCE
+ * (mapper.cpp:17-20 caches frame->pointcloud) and STAYS in device memory as an ssm_cloud; a map update transforms the chosen clouds by their current
+ * poses, adds them to the previous filtered map and runs the VoxelGrid pass, all on the device -- the viewer's `*map += *generatePointCloud(kf)` loop and
+ * its `voxel.filter(*tmp)` without the key-frame clouds or the whole global map crossing PCIe on every update; only the published map is downloaded.
+ * Results are the bytes ssm_backproject + host transform + ssm_voxel_filter give (exact integer sums: independent of the order points are added in). */
+typedef struct ssm_cloud ssm_cloud;
+int  ssm_backproject_dev(ssm_ctx* ctx, const uint16_t* depth, const uint8_t* rgb_bgr, const uint8_t* sem_bgr, int w, int h,
+                         const ssm_camera* cam, double max_distance, ssm_cloud** cloud_out);      /* host images in; camera-frame cloud left on the device */
+int  ssm_cloud_size(const ssm_cloud* cloud);
+int  ssm_cloud_fetch(ssm_ctx* ctx, const ssm_cloud* cloud, const double* T, ssm_point* out, int cap, int* n_out);   /* transformed copy to the host (T = NULL: as stored) */
+void ssm_cloud_free(ssm_ctx* ctx, ssm_cloud* cloud);
+/* map <- VoxelGrid(leaf)( (rebuild ? nothing : the previous map's centroids) + sum over i of poses[i] * clouds[i] ); poses: n x 16 doubles, column-major, HOST.
+ * A cloud extent PCL's VoxelGrid refuses (dx dy dz > INT_MAX) leaves the unfiltered concatenation as the map, like mapper.h's `*out = *in`. */
+int  ssm_viewer_map_update(ssm_ctx* ctx, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out);
+int  ssm_viewer_map_fetch(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);                       /* the map after the last update (sorted by voxel index) */
 /* the persistent map of the context: table of exact sums keyed by voxel.  A full table DROPS points: the entry point that notices (ssm_map_insert,
  * ssm_sync after ssm_seq_process) returns SSM_E_CAPACITY once, and from then on ssm_map_size / ssm_map_export* / ssm_voxel_allgather keep returning
  * SSM_E_CAPACITY for this map -- it is incomplete -- until ssm_map_clear.  Skipped points (non-finite, or outside the 21-bit voxel index range) are

@@ -26,6 +26,16 @@ case "$1" in
     timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_seg_pmc -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg_pmc.log 2>&1
     python3 scripts/segnet_layers.py $O/p_seg_pmc 64 $O/segnet_layers.md; tail -3 $O/segnet_layers.md
     ;;
+  mapper)
+    timeout 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "viewer_map or generate_point or voxel" 2>&1 | tail -5
+    timeout 900 python3 -m pytest tests/test_host_cpp.py -x -q -m gpu 2>&1 | tail -5
+    timeout 600 python3 scripts/mapper_update_cost.py 150 2>&1 | tail -8 | tee $O/mapper_update_cost.md
+    ;;
+  fuzz)
+    rm -f $O/fuzz_cases.log
+    (time timeout 900 python3 -m pytest tests/test_gpu_fuzz.py -x -q -m gpu) 2>&1 | tail -25
+    wc -l $O/fuzz_cases.log
+    ;;
   alltests)
     timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -15
     ;;

@@ -71,11 +71,20 @@ SYMBOLS = {
     "ssm_sync": (_I, [_P]),
     "ssm_stream": (_P, [_P]),
     "ssm_orb_extract": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
+    "ssm_orb_extract_async": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
+    "ssm_match_async": (_I, [_P, _P, _I, _P, _I, _D, _P, _I, C.POINTER(_I)]),
+    "ssm_wait": (_I, [_P]),
     "ssm_hamming_knn2": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "ssm_match": (_I, [_P, _P, _I, _P, _I, _D, _P, _I, C.POINTER(_I)]),
     "ssm_moving_mask": (_I, [_P, _P, _I, _I, _I, _P]),
     "ssm_backproject": (_I, [_P, _P, _P, _P, _I, _I, C.POINTER(Camera), _P, _D, _P, _I, C.POINTER(_I)]),
     "ssm_voxel_filter": (_I, [_P, _P, _I, _F, _P, _I, C.POINTER(_I)]),
+    "ssm_backproject_dev": (_I, [_P, _P, _P, _P, _I, _I, C.POINTER(Camera), _D, C.POINTER(_P)]),
+    "ssm_cloud_size": (_I, [_P]),
+    "ssm_cloud_fetch": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I)]),
+    "ssm_cloud_free": (None, [_P, _P]),
+    "ssm_viewer_map_update": (_I, [_P, _I, _P, _P, _I, _F, C.POINTER(_I)]),
+    "ssm_viewer_map_fetch": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_clear": (_I, [_P]),
     "ssm_map_insert": (_I, [_P, _P, _I]),
     "ssm_map_size": (_I, [_P, C.POINTER(_I)]),

@@ -188,6 +188,27 @@ class Context:
                                            _ptr(pos), self.cap, C.byref(n)))
         return kps[:n.value], desc[:n.value], pos[:n.value]
 
+    # ---- asynchronous per-frame calls: results are in the returned holders after wait()
+    def detect_features_async(self, img, depth=None):
+        """ssm_orb_extract_async: returns a holder h; after ctx.wait(), h() gives (keypoints, descriptors, positions)"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]; ch = 1 if img.ndim == 2 else img.shape[2]
+        depth = None if depth is None else np.ascontiguousarray(depth, np.uint16)
+        kps = np.zeros(self.cap, KEYPOINT_DTYPE); desc = np.zeros((self.cap, 32), np.uint8); pos = np.zeros((self.cap, 3), np.float32)
+        n = C.c_int(-1)
+        self._chk(self.lib.ssm_orb_extract_async(self.h, _ptr(img), w, h, img.strides[0], ch, _ptr(depth), _ptr(kps), _ptr(desc), _ptr(pos), self.cap, C.byref(n)))
+        return lambda: (kps[:n.value], desc[:n.value], pos[:n.value])
+
+    def match_async(self, q, t, ratio=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(q), 1), DMATCH_DTYPE); n = C.c_int(-1)
+        r = self.cfg.knn_match_ratio if ratio is None else ratio
+        self._chk(self.lib.ssm_match_async(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
+        return lambda: out[:n.value]
+
+    def wait(self):
+        self._chk(self.lib.ssm_wait(self.h))
+
     def knn2(self, q, t):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
         t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
@@ -409,6 +430,44 @@ class Context:
         self._chk(self.lib.ssm_backproject(self.h, _ptr(depth), _ptr(rgb), _ptr(sem), w, h, C.byref(cam), _ptr(Tc), md,
                                            _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    # ---- device-resident Mapper: key-frame clouds and the viewer's map stay in HBM (ssm_backproject_dev / ssm_viewer_map_*)
+    def backproject_dev(self, depth, rgb, sem, camera=None, max_distance=None):
+        """camera-frame cloud of one frame, left on the device: returns an opaque handle (cloud_free it)"""
+        depth = np.ascontiguousarray(depth, np.uint16); rgb = np.ascontiguousarray(rgb, np.uint8); sem = np.ascontiguousarray(sem, np.uint8)
+        h, w = depth.shape
+        cam = Camera(*camera) if camera is not None else self.cfg.camera
+        md = self.cfg.mapper_max_distance if max_distance is None else max_distance
+        cl = C.c_void_p()
+        self._chk(self.lib.ssm_backproject_dev(self.h, _ptr(depth), _ptr(rgb), _ptr(sem), w, h, C.byref(cam), md, C.byref(cl)))
+        return cl.value
+
+    def cloud_size(self, cloud):
+        return self.lib.ssm_cloud_size(cloud)
+
+    def cloud_fetch(self, cloud, T=None):
+        n = self.cloud_size(cloud)
+        out = np.zeros(max(n, 1), POINT_DTYPE); m = C.c_int(0)
+        Tc = None if T is None else np.ascontiguousarray(np.asarray(T, np.float64).reshape(4, 4).T)
+        self._chk(self.lib.ssm_cloud_fetch(self.h, cloud, _ptr(Tc), _ptr(out), len(out), C.byref(m)))
+        return out[:m.value]
+
+    def cloud_free(self, cloud):
+        self.lib.ssm_cloud_free(self.h, cloud)
+
+    def viewer_map_update(self, clouds, poses, rebuild=False, leaf=None):
+        """Mapper::viewer's update on the device: map <- VoxelGrid((rebuild ? nothing : previous map) + sum poses[i] * clouds[i]); returns the voxel count"""
+        leaf = self.cfg.mapper_resolution if leaf is None else leaf
+        arr = (C.c_void_p * max(len(clouds), 1))(*clouds)
+        P = np.ascontiguousarray(np.stack([np.asarray(T, np.float64).reshape(4, 4).T.reshape(16) for T in poses]) if len(poses) else np.zeros((1, 16)))
+        n = C.c_int(0)
+        self._chk(self.lib.ssm_viewer_map_update(self.h, int(rebuild), arr, _ptr(P), len(clouds), leaf, C.byref(n)))
+        return n.value
+
+    def viewer_map_fetch(self, n):
+        out = np.zeros(max(n, 1), POINT_DTYPE); m = C.c_int(0)
+        self._chk(self.lib.ssm_viewer_map_fetch(self.h, _ptr(out), len(out), C.byref(m)))
+        return out[:m.value]
 
     def voxel_filter(self, pts, leaf=None, cap=None):
         pts = np.ascontiguousarray(pts, POINT_DTYPE)

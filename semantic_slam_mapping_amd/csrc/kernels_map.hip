@@ -987,3 +987,30 @@ hipError_t k_voxel_bounds(const ssm_point* pts, int n, float* minmax6, hipStream
     if (n > 0) vox_bounds_kernel<<<min((n + 255) / 256, 1024), 256, 0, s>>>(pts, n, reinterpret_cast<int*>(minmax6));
     return hipGetLastError();
 }
+
+// ---- pcl::transformPointCloud on a device-resident cloud (Mapper::generatePointCloud, /root/reference/src/mapper.cpp:89-91): dst[i] = T src[i] with
+// x' = float(t00 x + t01 y + t02 z + t03) in double, left to right -- the arithmetic of k_backproject's pose step and of include/ssm/mapper.h's host loop
+struct PoseArg { double t[12]; };                                 // column-major 3 x 4: t[3 c + r]
+__global__ void __launch_bounds__(256)
+cloud_transform_kernel(const ssm_point* __restrict__ src, int n, PoseArg P, ssm_point* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ssm_point p = src[i];
+    const double x = p.x, y = p.y, z = p.z;
+    p.x = (float)(P.t[0] * x + P.t[3] * y + P.t[6] * z + P.t[9]);
+    p.y = (float)(P.t[1] * x + P.t[4] * y + P.t[7] * z + P.t[10]);
+    p.z = (float)(P.t[2] * x + P.t[5] * y + P.t[8] * z + P.t[11]);
+    dst[i] = p;
+}
+// T: 16 doubles, column-major 4 x 4 (HOST pointer: the pose travels as a kernel argument); nullptr = copy
+hipError_t k_cloud_transform(const ssm_point* src, int n, const double* T, ssm_point* dst, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    if (!T) return hipMemcpyAsync(dst, src, (size_t)n * sizeof(ssm_point), hipMemcpyDeviceToDevice, s);
+    PoseArg P;
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) P.t[3 * c + r] = T[4 * c + r];
+    cloud_transform_kernel<<<(n + 255) / 256, 256, 0, s>>>(src, n, P, dst);
+    return hipGetLastError();
+}
+

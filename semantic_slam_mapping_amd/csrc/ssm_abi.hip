@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,8 @@ struct ssm_ctx {
     hipStream_t stream4 = nullptr; hipEvent_t ev_join4 = nullptr; int nchains = 3;      // a third ORB -> match chain (workspace alt2, stream4) when a call has more than two sub-batches; SSM_CHAINS=2: two
     uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
     ssm_point* d_points = nullptr;
+    ssm_point* d_vmap = nullptr; int vmap_n = 0; size_t vmap_cap = 0;      // Mapper::viewer's filtered map, device-resident (ssm_viewer_map_update)
+    ssm_point* d_vcat = nullptr; size_t vcat_cap = 0;                        // its concatenation buffer
     // staging for the host-pointer entry points (one frame) + generic scratch
     uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
@@ -121,6 +124,10 @@ struct ssm_ctx {
     // profiling
     bool profiling = false;
     uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
+    // the per-frame entry points (ssm_orb_extract[_async], ssm_match[_async]): a ring of pinned host memory (inputs staged, results landed) and a ring of
+    // device memory (result blocks), bump-allocated per call and released by ssm_wait; `pending` = what ssm_wait still has to hand to the callers
+    uint8_t* h_ring = nullptr; uint8_t* d_ring = nullptr; size_t ring_bytes = 0, h_ring_off = 0, d_ring_off = 0;
+    std::vector<std::function<int(ssm_ctx*)>> pending;
     bool serialize = false;             // profiling mode 2: keep the side work of ssm_seq_process on the context stream (clean per-stage times)
     std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
     std::vector<std::string> stage_names; std::vector<float> stage_ms; std::vector<int> stage_launches;
@@ -407,7 +414,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
-                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn, c->d_blur_tab };
+                     c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn, c->d_blur_tab, c->d_vmap, c->d_vcat };
     for (void* p : ptrs) if (p) hipFree(p);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
@@ -432,6 +439,8 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_ring) hipHostFree(c->h_ring);
+    if (c->d_ring) hipFree(c->d_ring);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->ev_join3) hipEventDestroy(c->ev_join3);
@@ -443,11 +452,13 @@ extern "C" void ssm_destroy(ssm_ctx* c)
 void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out) { *out = c->cfg; }
 extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
 extern "C" void* ssm_stream(ssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+static int wait_pending(ssm_ctx* c);
 extern "C" int ssm_sync(ssm_ctx* c)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     hipSetDevice(c->device);
+    { int r = wait_pending(c); if (r) return r; }                 // asynchronous per-frame calls still in flight are completed (their results delivered) too
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_device_flags(c, true);
 }
@@ -532,36 +543,102 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
     return SSM_OK;
 }
 
-extern "C" int ssm_orb_extract(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+// ---- the per-frame calls of the reference's unchanged loop (Tracker::trackRefFrame: detectFeatures, then match against every reference frame,
+// /root/reference/src/track.cpp:140-163).  Each call: inputs into the pinned ring (one memcpy per image), ONE host-to-device copy per image, the kernels, ONE
+// device-to-host copy of a result block that carries the count with the payload (capacity-sized: no round trip to learn the count first), and a finisher that
+// ssm_wait runs after the stream has drained.  The synchronous forms are the asynchronous ones + ssm_wait.
+static int wait_pending(ssm_ctx* c)
+{
+    if (c->pending.empty()) return SSM_OK;
+    int rc = SSM_OK;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { c->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = SSM_E_HIP; }
+    std::vector<std::function<int(ssm_ctx*)>> fins; fins.swap(c->pending);
+    for (auto& f : fins) { if (rc == SSM_OK) { const int r = f(c); if (r != SSM_OK) rc = r; } }      // after a failure the later calls' outputs stay untouched
+    c->h_ring_off = 0; c->d_ring_off = 0;
+    return rc;
+}
+static int ring_take(ssm_ctx* c, size_t hbytes, size_t dbytes, uint8_t** hp, uint8_t** dp)
+{
+    hbytes = (hbytes + 255) & ~(size_t)255; dbytes = (dbytes + 255) & ~(size_t)255;
+    if (c->h_ring_off + hbytes > c->ring_bytes || c->d_ring_off + dbytes > c->ring_bytes) {
+        int r = wait_pending(c); if (r) return r;                                // out of room: finish what is in flight (its results are delivered now)
+        const size_t need = hbytes > dbytes ? hbytes : dbytes;
+        if (need > c->ring_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_ring) hipHostFree(c->h_ring); if (c->d_ring) hipFree(c->d_ring);
+            c->h_ring = nullptr; c->d_ring = nullptr; c->ring_bytes = 0;
+            const size_t nb = need * 4 > ((size_t)8 << 20) ? need * 4 : ((size_t)8 << 20);
+            void* hp_ = nullptr;
+            if (hipHostMalloc(&hp_, nb, hipHostMallocDefault) != hipSuccess) FAIL(c, SSM_E_HIP, "hipHostMalloc of the staging ring failed");
+            c->h_ring = (uint8_t*)hp_;
+            if (hipMalloc((void**)&c->d_ring, nb) != hipSuccess) { hipHostFree(c->h_ring); c->h_ring = nullptr; FAIL(c, SSM_E_HIP, "hipMalloc of the result ring failed"); }
+            c->ring_bytes = nb;
+        }
+    }
+    *hp = c->h_ring + c->h_ring_off; *dp = c->d_ring + c->d_ring_off;
+    c->h_ring_off += hbytes; c->d_ring_off += dbytes;
+    return SSM_OK;
+}
+static int orb_extract_enqueue(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
                                ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out)
 {
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu);
-    hipSetDevice(c->device);
     if (!img || !kps || !desc || !n_out) FAIL(c, SSM_E_INVAL, "null argument");
     if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
     if (channels != 1 && channels != 3) FAIL(c, SSM_E_INVAL, "channels must be 1 or 3");
     if (stride < w * channels) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
     const int ocap = c->g.cap;
-    size_t need = (size_t)ocap * (sizeof(ssm_keypoint) + 32 + 12) + 64;
-    int r = ensure_scratch(c, need); if (r) return r;
-    ssm_keypoint* dk = reinterpret_cast<ssm_keypoint*>(c->d_scratch);
+    const size_t row = (size_t)w * channels, ib = row * h, db = depth ? (size_t)w * h * 2 : 0;
+    // result block: [n, status, pad][keypoints][descriptors][positions]
+    const size_t blk = 64 + (size_t)ocap * (sizeof(ssm_keypoint) + 32 + 12);
+    uint8_t *hp, *dp;
+    int r = ring_take(c, ib + db + 64 + blk, blk, &hp, &dp); if (r) return r;
+    uint8_t* h_in = hp; uint8_t* h_out = hp + ((ib + db + 63) & ~(size_t)63);
+    if ((size_t)stride == row) memcpy(h_in, img, ib);
+    else for (int y = 0; y < h; y++) memcpy(h_in + (size_t)y * row, img + (size_t)y * stride, row);
+    if (depth) memcpy(h_in + ib, depth, db);
+    HIPCHK(c, hipMemcpyAsync(c->d_in_img, h_in, ib, hipMemcpyHostToDevice, c->stream));
+    if (depth) HIPCHK(c, hipMemcpyAsync(c->d_in_depth, h_in + ib, db, hipMemcpyHostToDevice, c->stream));
+    int32_t* dn = reinterpret_cast<int32_t*>(dp);
+    ssm_keypoint* dk = reinterpret_cast<ssm_keypoint*>(dp + 64);
     uint8_t* dd = reinterpret_cast<uint8_t*>(dk + ocap);
-    float* dp = reinterpret_cast<float*>(dd + (size_t)ocap * 32);
-    int32_t* dn = reinterpret_cast<int32_t*>(dp + (size_t)ocap * 3);
-    HIPCHK(c, hipMemcpy2DAsync(c->d_in_img, (size_t)w * channels, img, stride, (size_t)w * channels, h, hipMemcpyHostToDevice, c->stream));
-    if (depth) HIPCHK(c, hipMemcpyAsync(c->d_in_depth, depth, (size_t)w * h * 2, hipMemcpyHostToDevice, c->stream));
-    r = run_orb(c, c->d_in_img, channels, depth ? c->d_in_depth : nullptr, 1, dk, dd, dp, dn); if (r) return r;
-    int n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, dn, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    r = check_device_flags(c, false); if (r) return r;
-    *n_out = n;
-    if (n > cap) FAIL(c, SSM_E_CAPACITY, "keypoint buffer too small (need " + std::to_string(n) + ")");
-    HIPCHK(c, hipMemcpy(kps, dk, sizeof(ssm_keypoint) * n, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(desc, dd, (size_t)n * 32, hipMemcpyDeviceToHost));
-    if (pos3d) HIPCHK(c, hipMemcpy(pos3d, dp, (size_t)n * 12, hipMemcpyDeviceToHost));
+    float* dps = reinterpret_cast<float*>(dd + (size_t)ocap * 32);
+    r = run_orb(c, c->d_in_img, channels, depth ? c->d_in_depth : nullptr, 1, dk, dd, dps, dn); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(dn + 1, c->d_status, 4, hipMemcpyDeviceToDevice, c->stream));          // the ORB scratch-overflow word travels in the block's header
+    HIPCHK(c, hipMemcpyAsync(h_out, dp, blk, hipMemcpyDeviceToHost, c->stream));
+    c->pending.push_back([=](ssm_ctx* cc) -> int {
+        int32_t hdr[2]; memcpy(hdr, h_out, 8);
+        if (hdr[1]) { hipMemset(cc->d_status, 0, 4); FAIL(cc, SSM_E_CAPACITY, "ORB scratch capacity exceeded (status " + std::to_string(hdr[1]) + ")"); }
+        const int n = hdr[0];
+        *n_out = n;
+        if (n > cap) FAIL(cc, SSM_E_CAPACITY, "keypoint buffer too small (need " + std::to_string(n) + ")");
+        memcpy(kps, h_out + 64, sizeof(ssm_keypoint) * (size_t)n);
+        memcpy(desc, h_out + 64 + (size_t)ocap * sizeof(ssm_keypoint), (size_t)n * 32);
+        if (pos3d) memcpy(pos3d, h_out + 64 + (size_t)ocap * (sizeof(ssm_keypoint) + 32), (size_t)n * 12);
+        return SSM_OK;
+    });
     return SSM_OK;
+}
+extern "C" int ssm_orb_extract_async(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+                                     ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    return orb_extract_enqueue(c, img, w, h, stride, channels, depth, kps, desc, pos3d, cap, n_out);
+}
+extern "C" int ssm_orb_extract(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
+                               ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    int r = orb_extract_enqueue(c, img, w, h, stride, channels, depth, kps, desc, pos3d, cap, n_out); if (r) return r;
+    return wait_pending(c);
+}
+extern "C" int ssm_wait(ssm_ctx* c)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    return wait_pending(c);
 }
 
 // ---------------------------------------------------------------- matcher, host pointers
@@ -572,6 +649,35 @@ static int match_host(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, in
     if (nt < 2) FAIL(c, SSM_E_TOO_FEW_TRAIN, "knnMatch(k=2) needs at least 2 train descriptors");
     if (nt > 65535) FAIL(c, SSM_E_INVAL, "at most 65535 train descriptors per call");
     if (nq == 0) { if (n_out) *n_out = 0; return SSM_OK; }
+    if (c->match_mfma && !want_knn) {
+        // the matrix-core matcher on a two-row "sequence" (row 0 = query set, row 1 = train set) through the rings: one upload, one result block
+        const int capm = nq > nt ? nq : nt, capT = (capm + 31) & ~31;
+        const size_t rowb = (size_t)capm * 32, expb = (size_t)2 * capT * SSM_MATCH_DESC_BYTES;
+        const size_t inb = 2 * rowb + 16, outb = 64 + (size_t)nq * sizeof(ssm_dmatch);
+        const size_t devb = ((inb + 255) & ~(size_t)255) + 2 * expb + (((size_t)capT * 8 + 255) & ~(size_t)255) + outb;
+        uint8_t *hp, *dp;
+        int r = ring_take(c, inb + 64 + outb, devb, &hp, &dp); if (r) return r;
+        uint8_t* h_out = hp + ((inb + 63) & ~(size_t)63);
+        memcpy(hp, q, (size_t)nq * 32); memcpy(hp + rowb, t, (size_t)nt * 32);
+        const int32_t hn[2] = {nq, nt}; memcpy(hp + 2 * rowb, hn, 8);
+        uint8_t* dd = dp; int32_t* dnk = reinterpret_cast<int32_t*>(dd + 2 * rowb);
+        uint8_t* eq = dp + ((inb + 255) & ~(size_t)255); uint8_t* et = eq + expb;
+        uint2* knn = reinterpret_cast<uint2*>(et + expb);
+        uint8_t* dout = reinterpret_cast<uint8_t*>(knn) + (((size_t)capT * 8 + 255) & ~(size_t)255);
+        int32_t* dn = reinterpret_cast<int32_t*>(dout); ssm_dmatch* dm = reinterpret_cast<ssm_dmatch*>(dout + 64);
+        HIPCHK(c, hipMemcpyAsync(dd, hp, inb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, k_match_expand(dd, dnk, 0, 2, capm, capT, eq, et, c->stream));
+        HIPCHK(c, k_match_seq_mfma(eq, et, dnk, 0, 1, 1, 1, ratio, capm, capT, knn, dm, dn, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_out, dout, outb, hipMemcpyDeviceToHost, c->stream));
+        c->pending.push_back([=](ssm_ctx* cc) -> int {
+            int32_t n; memcpy(&n, h_out, 4);
+            *n_out = n;
+            if (n > cap) FAIL(cc, SSM_E_CAPACITY, "match buffer too small (need " + std::to_string(n) + ")");
+            memcpy(out, h_out + 64, sizeof(ssm_dmatch) * (size_t)n);
+            return SSM_OK;
+        });
+        return SSM_OK;
+    }
     if (c->match_mfma) {
         // the matrix-core matcher of the sequence path on a two-row "sequence": row 0 = the query set (reference frame), row 1 = the train set
         const int capm = nq > nt ? nq : nt, capT = (capm + 31) & ~31;
@@ -639,7 +745,15 @@ extern "C" int ssm_match(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t,
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!n_out || (cap > 0 && !out)) FAIL(c, SSM_E_INVAL, "null output");
-    return match_host(c, q, nq, t, nt, ratio, false, nullptr, nullptr, out, cap, n_out);
+    int r = match_host(c, q, nq, t, nt, ratio, false, nullptr, nullptr, out, cap, n_out); if (r) return r;
+    return wait_pending(c);
+}
+extern "C" int ssm_match_async(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, ssm_dmatch* out, int cap, int* n_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!n_out || (cap > 0 && !out)) FAIL(c, SSM_E_INVAL, "null output");
+    return match_host(c, q, nq, t, nt, ratio, false, nullptr, nullptr, out, cap, n_out);       // the VALU variant (SSM_MATCH_VARIANT=0) completes inside the call
 }
 
 // ---------------------------------------------------------------- mapper front half, host pointers
@@ -931,6 +1045,139 @@ extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float l
         r = table_alloc(c, c->tmp, bigger); if (r) return r;
     }
     return table_export_points(c, c->tmp, out, cap, n_out);
+}
+
+// ---------------------------------------------------------------- device-resident Mapper (ssm_backproject_dev, ssm_viewer_map_*)
+struct ssm_cloud { ssm_point* d = nullptr; int n = 0; int device = 0; };
+extern "C" int ssm_backproject_dev(ssm_ctx* c, const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, int w, int h,
+                                   const ssm_camera* cam, double max_distance, ssm_cloud** cloud_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (!depth || !rgb || !sem || !cam || !cloud_out) FAIL(c, SSM_E_INVAL, "null argument");
+    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
+    *cloud_out = nullptr;
+    const size_t np = (size_t)w * h;
+    // one pinned staging area, one host-to-device copy for the three images (a pageable copy is staged by the runtime in small pieces)
+    int r = ensure_pinned(c, np * 8); if (r) return r;
+    memcpy(c->h_pinned, depth, np * 2); memcpy(c->h_pinned + np * 2, rgb, np * 3); memcpy(c->h_pinned + np * 5, sem, np * 3);
+    r = ensure_scratch(c, np * 8); if (r) return r;
+    uint8_t* din = reinterpret_cast<uint8_t*>(c->d_scratch);
+    HIPCHK(c, hipMemcpyAsync(din, c->h_pinned, np * 8, hipMemcpyHostToDevice, c->stream));
+    const uint16_t* dd = reinterpret_cast<const uint16_t*>(din); const uint8_t* drgb = din + np * 2; const uint8_t* dsem = din + np * 5;
+    HIPCHK(c, k_moving_mask(dsem, 1, w, h, c->d_mask, c->stream));
+    HIPCHK(c, k_backproject(dd, drgb, dsem, c->d_mask, nullptr, 1, w, h, *cam, max_distance,
+                            c->d_chunk_cnt, c->d_chunk_off, reinterpret_cast<int32_t*>(c->d_total + 1), c->d_total, c->d_points, c->stream));
+    int64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ssm_cloud* cl = new ssm_cloud(); cl->n = (int)total; cl->device = c->device;
+    if (total > 0) {
+        if (hipMalloc(&cl->d, (size_t)total * sizeof(ssm_point)) != hipSuccess) { delete cl; FAIL(c, SSM_E_HIP, "hipMalloc of a key-frame cloud failed"); }
+        HIPCHK(c, hipMemcpyAsync(cl->d, c->d_points, (size_t)total * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *cloud_out = cl;
+    return SSM_OK;
+}
+extern "C" int ssm_cloud_size(const ssm_cloud* cl) { return cl ? cl->n : 0; }
+extern "C" void ssm_cloud_free(ssm_ctx* c, ssm_cloud* cl)
+{
+    if (!cl) return;
+    if (c) { std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(cl->device); hipStreamSynchronize(c->stream); if (cl->d) hipFree(cl->d); }
+    else { hipSetDevice(cl->device); if (cl->d) hipFree(cl->d); }
+    delete cl;
+}
+extern "C" int ssm_cloud_fetch(ssm_ctx* c, const ssm_cloud* cl, const double* T, ssm_point* out, int cap, int* n_out)
+{
+    if (!c || !cl || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    *n_out = cl->n;
+    if (cl->n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(cl->n) + ")");
+    if (cl->n == 0) return SSM_OK;
+    if (!out) FAIL(c, SSM_E_INVAL, "null argument");
+    int r = ensure_scratch(c, (size_t)cl->n * sizeof(ssm_point)); if (r) return r;
+    HIPCHK(c, k_cloud_transform(cl->d, cl->n, T, reinterpret_cast<ssm_point*>(c->d_scratch), c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)cl->n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+static int grow_points(ssm_ctx* c, ssm_point*& p, size_t& cap, size_t need, size_t keep)
+{
+    if (need <= cap) return SSM_OK;
+    const size_t ncap = need + need / 2 + 1024;
+    ssm_point* q = nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hipMalloc(&q, ncap * sizeof(ssm_point)) != hipSuccess) FAIL(c, SSM_E_HIP, "hipMalloc of the viewer map failed");
+    if (p && keep) HIPCHK(c, hipMemcpy(q, p, keep * sizeof(ssm_point), hipMemcpyDeviceToDevice));
+    if (p) hipFree(p);
+    p = q; cap = ncap;
+    return SSM_OK;
+}
+extern "C" int ssm_viewer_map_update(ssm_ctx* c, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (n < 0 || (n && (!clouds || !poses)) || !(leaf > 0)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    size_t total = rebuild ? 0 : (size_t)c->vmap_n;
+    for (int i = 0; i < n; i++) { if (!clouds[i]) FAIL(c, SSM_E_INVAL, "null cloud"); if (clouds[i]->device != c->device) FAIL(c, SSM_E_INVAL, "cloud of another device"); total += (size_t)clouds[i]->n; }
+    if (total > (size_t)0x7FFFFFFF) FAIL(c, SSM_E_CAPACITY, "more than 2^31 points in one map update");
+    if (total == 0) { c->vmap_n = 0; if (n_map_out) *n_map_out = 0; return SSM_OK; }
+    int r = grow_points(c, c->d_vcat, c->vcat_cap, total + 8, 0); if (r) return r;       // (+ 8 points: the bounds words behind the data)
+    // previous centroids, then every cloud transformed by its pose: the viewer's `*map += *generatePointCloud(kf)`
+    size_t off = 0;
+    if (!rebuild && c->vmap_n) { HIPCHK(c, hipMemcpyAsync(c->d_vcat, c->d_vmap, (size_t)c->vmap_n * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream)); off = (size_t)c->vmap_n; }
+    for (int i = 0; i < n; i++) { HIPCHK(c, k_cloud_transform(clouds[i]->d, clouds[i]->n, poses + (size_t)16 * i, c->d_vcat + off, c->stream)); off += (size_t)clouds[i]->n; }
+    const int N = (int)total;
+    if (!c->tmp.tab) { r = table_alloc(c, c->tmp, c->cfg.voxel_capacity_log2); if (r) return r; }
+    else HIPCHK(c, k_voxel_clear(c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+    float* mm = reinterpret_cast<float*>(c->d_vcat + total);
+    HIPCHK(c, k_voxel_bounds(c->d_vcat, N, mm, c->stream));
+    int ord[6];
+    HIPCHK(c, hipMemcpyAsync(ord, mm, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {   // pcl::VoxelGrid::applyFilter overflow guard (as in ssm_voxel_filter): the map is then the unfiltered concatenation
+        const float inv = 1.0f / leaf;
+        const int64_t dx = (int64_t)((ord2f(ord[3]) - ord2f(ord[0])) * inv) + 1, dy = (int64_t)((ord2f(ord[4]) - ord2f(ord[1])) * inv) + 1,
+                      dz = (int64_t)((ord2f(ord[5]) - ord2f(ord[2])) * inv) + 1;
+        if (dx * dy * dz > (int64_t)2147483647) {
+            r = grow_points(c, c->d_vmap, c->vmap_cap, total, 0); if (r) return r;
+            HIPCHK(c, hipMemcpyAsync(c->d_vmap, c->d_vcat, total * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->vmap_n = N; if (n_map_out) *n_map_out = N;
+            return SSM_OK;
+        }
+    }
+    for (;;) {
+        HIPCHK(c, k_voxel_insert(c->d_vcat, nullptr, N, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
+        int32_t cnt[2];
+        HIPCHK(c, hipMemcpyAsync(cnt, c->tmp.counters, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!(cnt[1] & 1)) break;
+        const int bigger = c->tmp.cap_log2 + 2;
+        if (bigger > 28) FAIL(c, SSM_E_CAPACITY, "viewer map: more than 2^28 voxels");
+        hipFree(c->tmp.tab); c->tmp.tab = nullptr;
+        r = table_alloc(c, c->tmp, bigger); if (r) return r;
+    }
+    int nv; ssm_voxel* comp; uint32_t* order;
+    r = table_sorted(c, c->tmp, &nv, &comp, &order); if (r) return r;
+    r = grow_points(c, c->d_vmap, c->vmap_cap, (size_t)nv, 0); if (r) return r;
+    if (nv) HIPCHK(c, k_voxel_gather_points(comp, order, nv, c->d_vmap, c->stream));
+    c->vmap_n = nv;
+    if (n_map_out) *n_map_out = nv;
+    return SSM_OK;
+}
+extern "C" int ssm_viewer_map_fetch(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
+{
+    if (!c || !n_out) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    *n_out = c->vmap_n;
+    if (c->vmap_n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(c->vmap_n) + ")");
+    if (c->vmap_n == 0) return SSM_OK;
+    if (!out) FAIL(c, SSM_E_INVAL, "null argument");
+    HIPCHK(c, hipMemcpyAsync(out, c->d_vmap, (size_t)c->vmap_n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
 }
 
 // ---------------------------------------------------------------- device-resident sequence path

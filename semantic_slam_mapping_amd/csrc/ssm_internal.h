@@ -102,6 +102,8 @@ hipError_t k_voxel_compact(const ssm_voxel* tab, int cap_log2, ssm_voxel* out, i
 hipError_t k_voxel_gather_points(const ssm_voxel* compact, const uint32_t* order, int n, ssm_point* out, hipStream_t s);
 hipError_t k_voxel_gather_table(const ssm_voxel* compact, const uint32_t* order, int n, ssm_voxel* out, hipStream_t s);
 hipError_t k_voxel_bounds(const ssm_point* pts, int n, float* minmax6, hipStream_t s);
+// dst[i] = T src[i] (T: HOST pointer to a column-major 4 x 4, or nullptr = copy); pcl::transformPointCloud's arithmetic
+hipError_t k_cloud_transform(const ssm_point* src, int n, const double* T, ssm_point* dst, hipStream_t s);
 // sort n (key,index) pairs by key; tmp storage managed by caller via size query (tmp==nullptr)
 hipError_t voxel_sort_pairs(void* tmp, size_t* tmp_bytes, const ssm_voxel* compact, int n, uint64_t* keys_a, uint64_t* keys_b,
                             uint32_t* idx_a, uint32_t* idx_b, hipStream_t s);

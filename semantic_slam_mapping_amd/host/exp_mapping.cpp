@@ -126,6 +126,7 @@ int main(int argc, char** argv)
         Mapper mapper(parameterReader, poseGraph);
         const bool use_gt_pose = parameterReader.getData<int>("use_stream_pose", (type == FrameReader::TUM || type == FrameReader::KITTI) ? 0 : 1) != 0;
         int nframes = 0;
+        const int frame_period_ms = parameterReader.getData<int>("frame_period_ms", 0);
         Trajectory traj(parameterReader.getData<string>("trajectory_output", string("")));
         auto t0 = chrono::steady_clock::now();
         if (batched && parameterReader.getData<string>("tracker_mode", string("rgbd")) == "rgbd") {
@@ -175,6 +176,7 @@ int main(int argc, char** argv)
             poseGraph.tryInsertKeyFrame(frame);
             if (tracker->getState() == Tracker::LOST) cout << "tracker is lost" << endl;
             nframes++;
+            if (frame_period_ms > 0) this_thread::sleep_for(chrono::milliseconds(frame_period_ms));      // a camera's frame period (measurements of the viewer thread under a paced stream)
         }
         const double s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
         mapper.SaveMap();

@@ -43,6 +43,30 @@ int ssm_pnp_solve(ssm_ctx*, const float* img, const float* obj, int n, const dou
     if (success) *success = ok;
     return SSM_OK;
 }
+// device-resident Mapper entry points: a "cloud" is a host vector here, the map update the same placeholder thinning as ssm_voxel_filter below
+struct ssm_cloud { std::vector<ssm_point> p; };
+static std::vector<ssm_point> g_vmap;
+int ssm_backproject_dev(ssm_ctx* c, const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, int w, int h, const ssm_camera* cam, double md, ssm_cloud** out)
+{
+    ssm_cloud* cl = new ssm_cloud(); cl->p.resize((size_t)w * h / 16 + 1); int n = 0;
+    ssm_backproject(c, depth, rgb, sem, w, h, cam, nullptr, md, cl->p.data(), (int)cl->p.size(), &n);
+    cl->p.resize(n); *out = cl; return SSM_OK;
+}
+int ssm_cloud_size(const ssm_cloud* cl) { return cl ? (int)cl->p.size() : 0; }
+void ssm_cloud_free(ssm_ctx*, ssm_cloud* cl) { delete cl; }
+int ssm_cloud_fetch(ssm_ctx*, const ssm_cloud* cl, const double*, ssm_point* out, int cap, int* n_out)
+{ *n_out = (int)cl->p.size(); if (*n_out > cap) return SSM_E_CAPACITY; memcpy(out, cl->p.data(), cl->p.size() * sizeof(ssm_point)); return SSM_OK; }
+int ssm_viewer_map_update(ssm_ctx*, int rebuild, ssm_cloud* const* clouds, const double*, int n, float, int* n_out)
+{
+    std::vector<ssm_point> all; if (!rebuild) all = g_vmap;
+    for (int i = 0; i < n; i++) all.insert(all.end(), clouds[i]->p.begin(), clouds[i]->p.end());
+    g_vmap.clear();
+    for (size_t i = 0; i < all.size(); i += 3) g_vmap.push_back(all[i]);
+    if (n_out) *n_out = (int)g_vmap.size();
+    return SSM_OK;
+}
+int ssm_viewer_map_fetch(ssm_ctx*, ssm_point* out, int cap, int* n_out)
+{ *n_out = (int)g_vmap.size(); if (*n_out > cap) return SSM_E_CAPACITY; if (*n_out) memcpy(out, g_vmap.data(), g_vmap.size() * sizeof(ssm_point)); return SSM_OK; }
 int ssm_voxel_filter(ssm_ctx*, const ssm_point* pts, int n, float, ssm_point* out, int cap, int* n_out)
 {
     int m = 0;

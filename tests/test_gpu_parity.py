@@ -688,3 +688,90 @@ def test_knn2_tile_boundaries(ctx, oracle, nq, nt):
     gi, gd = ctx.knn2(q, t)
     oi, od = oracle.knn2(q, t)
     assert np.array_equal(gd, od) and np.array_equal(gi, oi)
+
+
+# ---------------------------------------------------------------- device-resident Mapper (round 4)
+def test_viewer_map_on_device_equals_the_host_schedule(ctx, oracle, frames):
+    """Mapper::viewer (/root/reference/src/mapper.cpp:96-171) with the key-frame clouds and the map in HBM: ssm_backproject_dev keeps a frame's gated camera-frame
+    cloud on the device (frame->pointcloud, mapper.cpp:17-20), ssm_viewer_map_update transforms the chosen clouds by their CURRENT poses, adds the previous
+    centroids and runs the VoxelGrid pass.  A viewer schedule (rebuild from every 2nd key-frame at update 0 and 15, the last <= 5 key-frames otherwise, poses that
+    change between updates like a pose-graph correction) must give, update by update, the bytes of the host form: ssm_backproject (T = NULL) -> transform in
+    double on the host (pcl::transformPointCloud's arithmetic) -> concatenate -> ssm_voxel_filter; and the oracle's filter of the same points."""
+    rng = np.random.default_rng(7)
+    host_clouds = [ctx.generate_point_cloud(f[1], f[0], f[2]) for f in frames]
+    dev_clouds = [ctx.backproject_dev(f[1], f[0], f[2]) for f in frames]
+    try:
+        assert [ctx.cloud_size(c) for c in dev_clouds] == [len(h) for h in host_clouds]
+        assert same_struct(ctx.cloud_fetch(dev_clouds[0]), host_clouds[0])
+
+        def transform(cl, T):
+            out = cl.copy(); x, y, z = (cl[k].astype(np.float64) for k in "xyz")
+            for i, k in enumerate("xyz"):
+                out[k] = (T[i, 0] * x + T[i, 1] * y + T[i, 2] * z + T[i, 3]).astype(np.float32)      # left to right, every product and sum rounded to double
+            return out
+
+        def pose(k, jitter):
+            T = frames[k][4].copy(); a = 0.02 * jitter
+            R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            T[:3, :3] = R @ T[:3, :3]; T[:3, 3] += 0.013 * jitter
+            return T
+        assert same_struct(ctx.cloud_fetch(dev_clouds[3], pose(3, 2)), transform(host_clouds[3], pose(3, 2)))
+        host_map = np.zeros(0, host_clouds[0].dtype)
+        for upd in range(18):
+            nkf = min(len(frames), 2 + upd // 2)                                  # key-frames known at this update
+            rebuild = upd % 15 == 0
+            sel = list(range(0, nkf, 2)) if rebuild else list(range(nkf - 1, max(nkf - 6, -1), -1))
+            poses = [pose(k, upd % 4) for k in sel]                               # the pose graph moves key-frames between updates
+            parts = ([] if rebuild else [host_map]) + [transform(host_clouds[k], T) for k, T in zip(sel, poses)]
+            allp = np.concatenate(parts)
+            host_map = ctx.voxel_filter(allp, leaf=0.1)
+            n = ctx.viewer_map_update([dev_clouds[k] for k in sel], poses, rebuild=rebuild, leaf=0.1)
+            dev_map = ctx.viewer_map_fetch(n)
+            assert n == len(host_map) and same_struct(dev_map, host_map), f"update {upd}: {n} vs {len(host_map)} voxels"
+            if upd in (0, 7):
+                assert same_struct(dev_map, oracle.voxel_filter(allp, np.float32(0.1)))
+        # an update that adds nothing (the reference's size_t wrap with fewer than 6 key-frames, mapper.cpp:134) re-filters the previous centroids
+        n = ctx.viewer_map_update([], [], rebuild=False, leaf=0.1)
+        assert same_struct(ctx.viewer_map_fetch(n), ctx.voxel_filter(host_map, leaf=0.1))
+        # rebuild from nothing: empty map
+        assert ctx.viewer_map_update([], [], rebuild=True, leaf=0.1) == 0 and len(ctx.viewer_map_fetch(0)) == 0
+    finally:
+        for c in dev_clouds:
+            ctx.cloud_free(c)
+
+
+# ---------------------------------------------------------------- asynchronous per-frame calls (round 4)
+def test_async_per_frame_calls_equal_the_synchronous_ones(ctx, oracle, frames):
+    """ssm_orb_extract_async / ssm_match_async + ssm_wait (the calls of Tracker::trackRefFrame, /root/reference/src/track.cpp:140-163, enqueued back to back):
+    the same bytes as the synchronous forms and as the oracle; many calls pending at once, in call order; more pending matcher calls than the staging ring
+    holds (the call that finds it full completes the earlier ones first); a failing call (one train descriptor) leaves the pending ones intact"""
+    from semantic_slam_mapping_amd.api import SsmError
+    sync = [ctx.detect_features(f[0], f[1]) for f in frames[:4]]
+    hold = [ctx.detect_features_async(f[0], f[1]) for f in frames[:4]]            # four extractions in flight on one workspace: stream order keeps them apart
+    ctx.wait()
+    for (k, d, p), h in zip(sync, hold):
+        ak, ad, ap = h()
+        assert same_struct(ak, k) and np.array_equal(ad, d) and np.array_equal(ap, p)
+    ok, od = oracle.orb_extract(oracle.bgr2gray(frames[0][0]), nfeatures=1000)
+    assert same_struct(sync[0][0], ok) and np.array_equal(sync[0][1], od)
+    # a tracker frame: the current frame against its reference frames, one wait
+    cur = sync[3][1]
+    hm = [ctx.match_async(sync[i][1], cur) for i in range(3)]
+    ctx.wait()
+    for i in range(3):
+        assert same_struct(hm[i](), oracle.match(sync[i][1], cur, 0.8)) and same_struct(hm[i](), ctx.match(sync[i][1], cur))
+    # 40 matcher calls pending: far more than the 8 MB rings hold; mixed sizes and ratios
+    rng = np.random.default_rng(3)
+    sets = [rng.integers(0, 256, (int(n), 32), dtype=np.uint8) for n in rng.integers(2, 1100, 12)]
+    jobs = [(sets[int(a)], sets[int(b)], float(r)) for a, b, r in zip(rng.integers(0, 12, 40), rng.integers(0, 12, 40), rng.choice([0.6, 0.8, 1.0], 40))]
+    hs = [ctx.match_async(q, t, r) for q, t, r in jobs]
+    ctx.wait()
+    for h, (q, t, r) in zip(hs, jobs):
+        assert same_struct(h(), oracle.match(q, t, r))
+    # an invalid call between pending ones is refused at once and does not disturb them
+    h0 = ctx.match_async(sets[0], sets[1])
+    with pytest.raises(SsmError):
+        ctx.match_async(sets[0], sets[1][:1])
+    h1 = ctx.match_async(sets[2], sets[3])
+    ctx.sync()                                                                   # ssm_sync completes pending calls too
+    assert same_struct(h0(), oracle.match(sets[0], sets[1], 0.8)) and same_struct(h1(), oracle.match(sets[2], sets[3], 0.8))
