@@ -504,9 +504,13 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     const int wi = (blockIdx.x * MS_CH + ch) * 256 + tid;       // 16-pixel word of this frame
     long long k0 = -2, k1 = -2; uint32_t l0 = 255, l1 = 255; RunAcc a0, a1;
     a0.sx = a0.sy = a0.sz = 0; a0.r = a0.g = a0.b = a0.n = 0; a1 = a0;
-    if (wi < words) {
-        const size_t gw = (size_t)blockIdx.y * words + wi;
-        const int gy = wi / wpr, xw = wi - gy * wpr, gx0 = xw << 4;
+    // (wave-uniform condition: a lane past the frame's last word runs the body on that last word with nothing kept -- the palette table below is read with a
+    // wave shuffle from lanes 0 .. 15, which must stay active when the frame ends inside this wave)
+    if (wi - (tid & 63) < words) {
+        const bool inw = wi < words;
+        const int wic = inw ? wi : words - 1;
+        const size_t gw = (size_t)blockIdx.y * words + wic;
+        const int gy = wic / wpr, xw = wic - gy * wpr, gx0 = xw << 4;
         const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
         const uint4* pc = reinterpret_cast<const uint4*>(rgb + gw * 48);
         const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
@@ -542,6 +546,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
             keepbits |= (uint32_t)(d != 0 && d <= dmax && !gated) << k;
         }
         keepbits &= ~moving;                                          // mapper.cpp:32
+        if (!inw) keepbits = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             if ((keepbits >> k) & 1u) {
@@ -642,8 +647,12 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     for (int ch = 0; ch < MS_CH; ch++) {
         labs[ch][0] = labs[ch][1] = 0u;
         const int wi = (blockIdx.x * MS_CH + ch) * 256 + wv * 64 + lane;
-        if (wi < words) {
-            const uint4* ps = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + wi) * 48);
+        // EVERY lane of the wave runs the classification (a lane past the frame's last word re-reads that word and stores nothing): the palette table is
+        // read with a wave shuffle from lanes 0 .. 15, which must not be masked off when the frame's words end inside this wave (found by
+        // tests/test_gpu_fuzz.py at 176 x 88: 968 words, the last wave has 8 live lanes and lanes 8 .. 15 returned stale table entries)
+        const bool inw = wi < words;
+        if ((blockIdx.x * MS_CH + ch) * 256 + wv * 64 < words) {      // wave-uniform
+            const uint4* ps = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + (inw ? wi : words - 1)) * 48);
             const uint4 S0 = ps[0], S1 = ps[1], S2 = ps[2];
             const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
             uint32_t bits = 0;
@@ -656,7 +665,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
                 labs[ch][k >> 3] |= lab << (4 * (k & 7));
                 bits |= (uint32_t)(lab == 10u || lab == 11u) << k;                          // pedestrian (0,64,64) | cyclist (192,128,0) BGR
             }
-            cbits[wi - ry0 * wpr] = (uint16_t)bits;
+            if (inw) cbits[wi - ry0 * wpr] = (uint16_t)bits;
         }
     }
     {

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 hyp = pytest.importorskip("hypothesis")
-from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+from hypothesis import HealthCheck, example, given, settings, strategies as st   # noqa: E402
 
 from conftest import CAM, SEED                                          # noqa: E402
 
@@ -39,7 +39,7 @@ def same_struct(a, b):
 
 
 # ---------------------------------------------------------------- matcher: random sizes, duplicate rows (ties, zero distances), ratios
-@settings(max_examples=40, **COMMON)
+@settings(max_examples=150, **COMMON)
 @given(seed=st.integers(0, 2**31 - 1), nq=st.integers(1, 700), nt=st.integers(2, 900), pool=st.integers(1, 64),
        dup=st.floats(0.0, 1.0), ratio=st.sampled_from([0.5, 0.7, 0.8, 0.95, 1.0]), flips=st.integers(0, 3))
 def test_fuzz_matcher(ctx, oracle, seed, nq, nt, pool, dup, ratio, flips):
@@ -64,7 +64,7 @@ def test_fuzz_matcher(ctx, oracle, seed, nq, nt, pool, dup, ratio, flips):
 
 
 # ---------------------------------------------------------------- voxel filter: random clouds, leaves, voxel-boundary coordinates, labels
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=80, **COMMON)
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 6000), leaf=st.sampled_from([0.02, 0.05, 0.1, 0.25, 0.5, 1.0]), extent=st.sampled_from([0.3, 2.0, 15.0, 60.0]),
        on_grid=st.floats(0.0, 0.5), clones=st.floats(0.0, 0.5))
 def test_fuzz_voxel_filter(ctx, oracle, seed, n, leaf, extent, on_grid, clones):
@@ -103,8 +103,10 @@ PALETTE = np.array([[128, 128, 128], [0, 0, 128], [128, 192, 192], [0, 69, 255],
                     [128, 64, 64], [128, 0, 64], [0, 64, 64], [192, 128, 0]], np.uint8)      # BGR, tests/golden/palette.json
 
 
-@settings(max_examples=12, **COMMON)
-@given(seed=st.integers(0, 2**31 - 1), w16=st.integers(4, 26), h=st.integers(64, 150), n=st.integers(1, 4), holes=st.floats(0.0, 0.9),
+@settings(max_examples=60, **COMMON)
+@example(seed=0, w16=11, h=88, n=1, holes=0.0, block=1, stray=0.0, far=0.0, leaf=0.02, batch=1)     # round 4 finding: 968 words = 15 waves + 8 lanes; the palette
+@example(seed=0, w16=11, h=88, n=1, holes=0.0, block=32, stray=0.0, far=0.0, leaf=0.02, batch=1)    # table shuffle read masked-off lanes 8 .. 15 (wrong labels, one extra point)
+@given(seed=st.integers(0, 2**31 - 1), w16=st.integers(5, 26), h=st.integers(80, 150), n=st.integers(1, 4), holes=st.floats(0.0, 0.9),
        block=st.sampled_from([1, 3, 8, 32]), stray=st.floats(0.0, 0.2), far=st.floats(0.0, 0.3), leaf=st.sampled_from([0.02, 0.1, 0.4]), batch=st.integers(1, 3))
 def test_fuzz_sequence_map_stage(oracle, seed, w16, h, n, holes, block, stray, far, leaf, batch):
     """Mapper::generatePointCloud + semantic_motion_fuse + the map fusion (/root/reference/src/mapper.cpp:12-94,189-216,96-171) through ssm_seq_process (stage
@@ -154,7 +156,7 @@ def test_fuzz_sequence_map_stage(oracle, seed, w16, h, n, holes, block, stray, f
 
 
 # ---------------------------------------------------------------- sub-batch size against tracker_ref_frames: the match tables of a sequence
-@settings(max_examples=6, **COMMON)
+@settings(max_examples=20, **COMMON)
 @given(first=st.integers(0, 500), n=st.integers(2, 8), R=st.integers(1, 5), batch=st.integers(1, 4), cont=st.integers(0, 3))
 def test_fuzz_sub_batches_against_ref_window(oracle, first, n, R, batch, cont):
     """Tracker::trackRefFrame matches a frame against the tracker_ref_frames frames before it (/root/reference/src/track.cpp:150-152,192-196).  The sequence
