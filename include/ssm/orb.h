@@ -40,23 +40,22 @@ public:
         matches.resize(n);
         return matches;
     }
-    // match(ref, frame) for every reference frame, as Tracker::trackRefFrame's loop makes them (src/track.cpp:150-152) -- the same calls, enqueued back to
-    // back (ssm_match_async) and completed by ONE wait: the kernels of the five pairs run without a host round trip between them.  Same lists as match().
+    // match(ref, frame) for every reference frame, as Tracker::trackRefFrame's loop makes them (src/track.cpp:150-152), in ONE device call (ssm_match_refs:
+    // one upload, one matrix-core launch for all pairs, one download).  Same lists as match().
     vector<vector<cv::DMatch>> matchMany(const std::deque<RGBDFrame::Ptr>& refs, const RGBDFrame::Ptr& frame) const {
         vector<vector<cv::DMatch>> all(refs.size());
         cv::Mat d2 = frame->getAllDescriptors();
         if (d2.rows < 2 || refs.empty()) return all;
         ssm::Device& d = device(frame->rgb.cols, frame->rgb.rows);
-        vector<int> n(refs.size(), 0);
-        vector<cv::Mat> d1(refs.size());
-        for (size_t i = 0; i < refs.size(); i++) {
+        const size_t k = refs.size();
+        vector<cv::Mat> d1(k); vector<const uint8_t*> pr(k); vector<int> nr(k), caps(k), n(k, 0); vector<ssm_dmatch*> po(k);
+        for (size_t i = 0; i < k; i++) {
             d1[i] = refs[i]->getAllDescriptors();
-            if (d1[i].rows == 0) continue;
             all[i].resize(d1[i].rows);
-            d.check(ssm_match_async(d.ctx(), d1[i].data, d1[i].rows, d2.data, d2.rows, knn_match_ratio, reinterpret_cast<ssm_dmatch*>(all[i].data()), d1[i].rows, &n[i]), "ssm_match_async");
+            pr[i] = d1[i].data; nr[i] = d1[i].rows; caps[i] = d1[i].rows; po[i] = reinterpret_cast<ssm_dmatch*>(all[i].data());
         }
-        d.check(ssm_wait(d.ctx()), "ssm_wait");
-        for (size_t i = 0; i < refs.size(); i++) all[i].resize(n[i]);
+        d.check(ssm_match_refs(d.ctx(), pr.data(), nr.data(), (int)k, d2.data, d2.rows, knn_match_ratio, po.data(), caps.data(), n.data()), "ssm_match_refs");
+        for (size_t i = 0; i < k; i++) all[i].resize(n[i]);
         return all;
     }
     ssm::Device& device(int w, int h) const {     // one context per calling thread and frame geometry

@@ -99,6 +99,13 @@ int ssm_orb_extract_async(ssm_ctx* ctx, const uint8_t* img, int w, int h, int st
                           ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out);
 int ssm_match_async(ssm_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, ssm_dmatch* out, int cap, int* n_out);
 int ssm_wait(ssm_ctx* ctx);
+/* the loop `for (pFrame : refFrames) orb.match(pFrame, currentFrame)` of Tracker::trackRefFrame (src/track.cpp:150-152) as one call: refs[i] (nrefs[i] x 32
+ * bytes) are the query sets, cur (ncur x 32) the train set of every pair; outs[i] (caps[i] entries) / n_outs[i] receive what ssm_match(refs[i], cur) gives.
+ * One upload, one matrix-core launch for all pairs, one download.  ncur < 2: SSM_E_TOO_FEW_TRAIN; nrefs[i] == 0: n_outs[i] = 0. */
+int ssm_match_refs(ssm_ctx* ctx, const uint8_t* const* refs, const int* nrefs, int nref, const uint8_t* cur, int ncur, double ratio,
+                   ssm_dmatch* const* outs, const int* caps, int* n_outs);
+int ssm_match_refs_async(ssm_ctx* ctx, const uint8_t* const* refs, const int* nrefs, int nref, const uint8_t* cur, int ncur, double ratio,
+                         ssm_dmatch* const* outs, const int* caps, int* n_outs);          /* completed by ssm_wait */
 
 /* ---- Mapper::semantic_motion_fuse (src/mapper.cpp:189-216): sem = BGR class-colour image, mask = w*h bytes */
 int ssm_moving_mask(ssm_ctx* ctx, const uint8_t* sem_bgr, int w, int h, int stride, uint8_t* mask);

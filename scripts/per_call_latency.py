@@ -48,7 +48,8 @@ def main():
         hs = [ctx.match_async(r, d1) for r in refs]
         ctx.wait()
         return hs
-    rows.append(("5 x ssm_match_async + ssm_wait (Tracker::trackRefFrame's five reference frames)", *timeit(five)))
+    rows.append(("5 x ssm_match_async + ssm_wait (five reference frames, one wait)", *timeit(five)))
+    rows.append(("ssm_match_refs (Tracker::trackRefFrame's five reference frames in one launch: OrbFeature::matchMany)", *timeit(lambda: ctx.match_refs(refs, d1))))
     five_row = len(rows) - 1
 
     def cloud_dev():
@@ -84,7 +85,7 @@ def main():
         for name, med, best in rows:
             f.write(f"| {name} | {med:.3f} | {best:.3f} |\n")
         r4 = rows[0][1] + rows[five_row][1] + rows[dev_row][1]
-        f.write(f"\nRound 4: a tracker frame = detectFeatures + the five matches with one wait + the key-frame cloud left on the device = **{r4:.2f} ms** "
+        f.write(f"\nRound 4: a tracker frame = detectFeatures + the five matches in one launch + the key-frame cloud left on the device = **{r4:.2f} ms** "
                 f"({1e3 / r4:.0f} frames/s per host thread; the cloud belongs to the mapper's thread).  The round-3 accounting, every call synchronous and the cloud downloaded:\n")
         f.write(f"\nA tracker frame = detectFeatures + 5 x match + generatePointCloud = **{per_frame:.2f} ms** through these calls "
                 f"({1e3 / per_frame:.0f} frames/s per host thread), **{with_pnp:.2f} ms** with the frame's solvePnP on the device "

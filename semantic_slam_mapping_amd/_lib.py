@@ -74,6 +74,8 @@ SYMBOLS = {
     "ssm_orb_extract_async": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
     "ssm_match_async": (_I, [_P, _P, _I, _P, _I, _D, _P, _I, C.POINTER(_I)]),
     "ssm_wait": (_I, [_P]),
+    "ssm_match_refs": (_I, [_P, _P, _P, _I, _P, _I, _D, _P, _P, _P]),
+    "ssm_match_refs_async": (_I, [_P, _P, _P, _I, _P, _I, _D, _P, _P, _P]),
     "ssm_hamming_knn2": (_I, [_P, _P, _I, _P, _I, _P, _P]),
     "ssm_match": (_I, [_P, _P, _I, _P, _I, _D, _P, _I, C.POINTER(_I)]),
     "ssm_moving_mask": (_I, [_P, _P, _I, _I, _I, _P]),

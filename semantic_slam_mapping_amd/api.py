@@ -206,6 +206,16 @@ class Context:
         self._chk(self.lib.ssm_match_async(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
         return lambda: out[:n.value]
 
+    def match_refs(self, refs, cur, ratio=None):
+        """ssm_match_refs: [match(r, cur) for r in refs] in one launch"""
+        refs = [np.ascontiguousarray(r, np.uint8).reshape(-1, 32) for r in refs]; cur = np.ascontiguousarray(cur, np.uint8).reshape(-1, 32)
+        k = len(refs)
+        outs = [np.zeros(max(len(r), 1), DMATCH_DTYPE) for r in refs]
+        pr = (C.c_void_p * max(k, 1))(*[r.ctypes.data for r in refs]); po = (C.c_void_p * max(k, 1))(*[o.ctypes.data for o in outs])
+        nr = (C.c_int * max(k, 1))(*[len(r) for r in refs]); caps = (C.c_int * max(k, 1))(*[len(o) for o in outs]); n = (C.c_int * max(k, 1))()
+        self._chk(self.lib.ssm_match_refs(self.h, pr, nr, k, _ptr(cur), len(cur), self.cfg.knn_match_ratio if ratio is None else ratio, po, caps, n))
+        return [o[:n[i]] for i, o in enumerate(outs)]
+
     def wait(self):
         self._chk(self.lib.ssm_wait(self.h))
 

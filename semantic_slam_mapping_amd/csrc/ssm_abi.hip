@@ -104,6 +104,8 @@ struct ssm_ctx {
     ssm_point* d_points = nullptr;
     ssm_point* d_vmap = nullptr; int vmap_n = 0; size_t vmap_cap = 0;      // Mapper::viewer's filtered map, device-resident (ssm_viewer_map_update)
     ssm_point* d_vcat = nullptr; size_t vcat_cap = 0;                        // its concatenation buffer
+    struct CloudSlab { ssm_point* d = nullptr; size_t cap = 0, used = 0; int live = 0; };
+    std::vector<CloudSlab> cloud_slabs;                                      // key-frame clouds (ssm_backproject_dev) are carved from slabs: no hipMalloc per cloud
     // staging for the host-pointer entry points (one frame) + generic scratch
     uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
@@ -439,6 +441,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     for (hipStream_t st : {c->stream, c->stream2, c->stream3, c->stream4}) if (st) { k_sgbm_release_stream(st); k_segnet_release_stream(st); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    for (auto& sl : c->cloud_slabs) if (sl.d) hipFree(sl.d);
     if (c->h_ring) hipHostFree(c->h_ring);
     if (c->d_ring) hipFree(c->d_ring);
     if (c->stream2) hipStreamDestroy(c->stream2);
@@ -748,6 +751,72 @@ extern "C" int ssm_match(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t,
     int r = match_host(c, q, nq, t, nt, ratio, false, nullptr, nullptr, out, cap, n_out); if (r) return r;
     return wait_pending(c);
 }
+// Tracker::trackRefFrame's loop `for (pFrame : refFrames) matches = orb.match(pFrame, currentFrame)` (/root/reference/src/track.cpp:150-152) as ONE call: the
+// reference frames' descriptor sets and the current frame's are the rows of a short "sequence" (refs oldest first, the current frame last) for the sequence
+// matcher -- one upload, one expansion, ONE matrix-core launch for all pairs, one result block; list i is exactly ssm_match(refs[i], cur).
+static int match_refs_enqueue(ssm_ctx* c, const uint8_t* const* refs, const int* nrefs, int nref, const uint8_t* cur, int ncur, double ratio,
+                              ssm_dmatch* const* outs, const int* caps, int* n_outs)
+{
+    if (nref < 0 || (nref && (!refs || !nrefs || !outs || !caps || !n_outs)) || ncur < 0 || (ncur && !cur)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (nref == 0) return SSM_OK;
+    if (ncur < 2) FAIL(c, SSM_E_TOO_FEW_TRAIN, "knnMatch(k=2) needs at least 2 train descriptors");
+    if (ncur > 65535) FAIL(c, SSM_E_INVAL, "at most 65535 train descriptors per call");
+    int capm = ncur;
+    for (int i = 0; i < nref; i++) { if (nrefs[i] < 0 || (nrefs[i] && !refs[i]) || (caps[i] > 0 && !outs[i])) FAIL(c, SSM_E_INVAL, "bad reference set"); if (nrefs[i] > capm) capm = nrefs[i]; }
+    if (!c->match_mfma || nref > 16) {                                         // the VALU variant (SSM_MATCH_VARIANT=0): pair by pair through the same entry
+        for (int i = 0; i < nref; i++) {
+            if (nrefs[i] == 0) { n_outs[i] = 0; continue; }
+            int r = match_host(c, refs[i], nrefs[i], cur, ncur, ratio, false, nullptr, nullptr, outs[i], caps[i], &n_outs[i]); if (r) return r;
+        }
+        return SSM_OK;
+    }
+    const int rows = nref + 1, capT = (capm + 31) & ~31;
+    const size_t rowb = (size_t)capm * 32, inb = (size_t)rows * rowb + 128;
+    const size_t expb = (size_t)rows * capT * SSM_MATCH_DESC_BYTES, knnb = ((size_t)nref * capT * 8 + 255) & ~(size_t)255;
+    const size_t outb = 256 + (size_t)nref * capm * sizeof(ssm_dmatch);
+    uint8_t *hp, *dp;
+    int r = ring_take(c, inb + 64 + outb, ((inb + 255) & ~(size_t)255) + 2 * expb + knnb + outb, &hp, &dp); if (r) return r;
+    uint8_t* h_out = hp + ((inb + 63) & ~(size_t)63);
+    int32_t hn[32] = {0};
+    for (int i = 0; i < nref; i++) { if (nrefs[i]) memcpy(hp + (size_t)i * rowb, refs[i], (size_t)nrefs[i] * 32); hn[i] = nrefs[i]; }
+    memcpy(hp + (size_t)nref * rowb, cur, (size_t)ncur * 32); hn[nref] = ncur;
+    memcpy(hp + (size_t)rows * rowb, hn, 128);
+    uint8_t* dd = dp; int32_t* dnk = reinterpret_cast<int32_t*>(dd + (size_t)rows * rowb);
+    uint8_t* eq = dp + ((inb + 255) & ~(size_t)255); uint8_t* et = eq + expb;
+    uint8_t* knn = et + expb; uint8_t* dout = knn + knnb;
+    int32_t* dn = reinterpret_cast<int32_t*>(dout); ssm_dmatch* dm = reinterpret_cast<ssm_dmatch*>(dout + 256);
+    HIPCHK(c, hipMemcpyAsync(dd, hp, inb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, k_match_expand(dd, dnk, 0, rows, capm, capT, eq, et, c->stream));
+    HIPCHK(c, k_match_seq_mfma(eq, et, dnk, 0, 1, nref, nref, ratio, capm, capT, knn, dm, dn, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_out, dout, outb, hipMemcpyDeviceToHost, c->stream));
+    std::vector<ssm_dmatch*> vo(outs, outs + nref); std::vector<int> vc(caps, caps + nref);
+    c->pending.push_back([=](ssm_ctx* cc) -> int {
+        for (int i = 0; i < nref; i++) {
+            int32_t n; memcpy(&n, h_out + 4 * (size_t)i, 4);
+            if (n < 0) n = 0;
+            n_outs[i] = n;
+            if (n > vc[i]) FAIL(cc, SSM_E_CAPACITY, "match buffer too small (need " + std::to_string(n) + ")");
+            memcpy(vo[i], h_out + 256 + (size_t)i * capm * sizeof(ssm_dmatch), sizeof(ssm_dmatch) * (size_t)n);
+        }
+        return SSM_OK;
+    });
+    return SSM_OK;
+}
+extern "C" int ssm_match_refs_async(ssm_ctx* c, const uint8_t* const* refs, const int* nrefs, int nref, const uint8_t* cur, int ncur, double ratio,
+                                    ssm_dmatch* const* outs, const int* caps, int* n_outs)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    return match_refs_enqueue(c, refs, nrefs, nref, cur, ncur, ratio, outs, caps, n_outs);
+}
+extern "C" int ssm_match_refs(ssm_ctx* c, const uint8_t* const* refs, const int* nrefs, int nref, const uint8_t* cur, int ncur, double ratio,
+                              ssm_dmatch* const* outs, const int* caps, int* n_outs)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    int r = match_refs_enqueue(c, refs, nrefs, nref, cur, ncur, ratio, outs, caps, n_outs); if (r) return r;
+    return wait_pending(c);
+}
 extern "C" int ssm_match_async(ssm_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, ssm_dmatch* out, int cap, int* n_out)
 {
     if (!c) return SSM_E_INVAL;
@@ -1048,7 +1117,7 @@ extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float l
 }
 
 // ---------------------------------------------------------------- device-resident Mapper (ssm_backproject_dev, ssm_viewer_map_*)
-struct ssm_cloud { ssm_point* d = nullptr; int n = 0; int device = 0; };
+struct ssm_cloud { ssm_point* d = nullptr; int n = 0; int device = 0; int slab = -1; };
 extern "C" int ssm_backproject_dev(ssm_ctx* c, const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, int w, int h,
                                    const ssm_camera* cam, double max_distance, ssm_cloud** cloud_out)
 {
@@ -1065,18 +1134,26 @@ extern "C" int ssm_backproject_dev(ssm_ctx* c, const uint16_t* depth, const uint
     uint8_t* din = reinterpret_cast<uint8_t*>(c->d_scratch);
     HIPCHK(c, hipMemcpyAsync(din, c->h_pinned, np * 8, hipMemcpyHostToDevice, c->stream));
     const uint16_t* dd = reinterpret_cast<const uint16_t*>(din); const uint8_t* drgb = din + np * 2; const uint8_t* dsem = din + np * 5;
+    // the cloud is written straight into a slab of device memory (room for the worst case, w h points; only the n points made are kept): no allocation, no
+    // device-to-device copy and ONE wait per key-frame
+    int si = -1;
+    for (size_t i = 0; i < c->cloud_slabs.size(); i++) if (c->cloud_slabs[i].cap - c->cloud_slabs[i].used >= np) { si = (int)i; break; }
+    if (si < 0) {
+        ssm_ctx::CloudSlab sl; sl.cap = np * 8 > ((size_t)2 << 20) ? np * 8 : ((size_t)2 << 20);          // >= 64 MB of points
+        if (hipMalloc((void**)&sl.d, sl.cap * sizeof(ssm_point)) != hipSuccess) FAIL(c, SSM_E_HIP, "hipMalloc of a key-frame cloud slab failed");
+        c->cloud_slabs.push_back(sl); si = (int)c->cloud_slabs.size() - 1;
+    }
+    ssm_ctx::CloudSlab& sl = c->cloud_slabs[si];
+    ssm_point* dst = sl.d + sl.used;
     HIPCHK(c, k_moving_mask(dsem, 1, w, h, c->d_mask, c->stream));
     HIPCHK(c, k_backproject(dd, drgb, dsem, c->d_mask, nullptr, 1, w, h, *cam, max_distance,
-                            c->d_chunk_cnt, c->d_chunk_off, reinterpret_cast<int32_t*>(c->d_total + 1), c->d_total, c->d_points, c->stream));
-    int64_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
+                            c->d_chunk_cnt, c->d_chunk_off, reinterpret_cast<int32_t*>(c->d_total + 1), c->d_total, dst, c->stream));
+    int64_t* h_total = reinterpret_cast<int64_t*>(c->h_pinned);                  // (the staged images at the front of the pinned area are consumed by then: stream order)
+    HIPCHK(c, hipMemcpyAsync(h_total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    ssm_cloud* cl = new ssm_cloud(); cl->n = (int)total; cl->device = c->device;
-    if (total > 0) {
-        if (hipMalloc(&cl->d, (size_t)total * sizeof(ssm_point)) != hipSuccess) { delete cl; FAIL(c, SSM_E_HIP, "hipMalloc of a key-frame cloud failed"); }
-        HIPCHK(c, hipMemcpyAsync(cl->d, c->d_points, (size_t)total * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
+    const int64_t total = *h_total;
+    ssm_cloud* cl = new ssm_cloud(); cl->n = (int)total; cl->device = c->device; cl->slab = si; cl->d = dst;
+    sl.used += ((size_t)total + 7) & ~(size_t)7; sl.live++;
     *cloud_out = cl;
     return SSM_OK;
 }
@@ -1084,9 +1161,11 @@ extern "C" int ssm_cloud_size(const ssm_cloud* cl) { return cl ? cl->n : 0; }
 extern "C" void ssm_cloud_free(ssm_ctx* c, ssm_cloud* cl)
 {
     if (!cl) return;
-    if (c) { std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(cl->device); hipStreamSynchronize(c->stream); if (cl->d) hipFree(cl->d); }
-    else { hipSetDevice(cl->device); if (cl->d) hipFree(cl->d); }
-    delete cl;
+    if (c) {                                                                   // a slab whose clouds are all freed is reused from its start
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (cl->slab >= 0 && cl->slab < (int)c->cloud_slabs.size()) { ssm_ctx::CloudSlab& sl = c->cloud_slabs[cl->slab]; if (--sl.live == 0) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); sl.used = 0; } }
+    }
+    delete cl;                                                                  // (without a context the slab goes with ssm_destroy)
 }
 extern "C" int ssm_cloud_fetch(ssm_ctx* c, const ssm_cloud* cl, const double* T, ssm_point* out, int cap, int* n_out)
 {
