@@ -14,10 +14,8 @@ case "$1" in
     timeout 900 python3 -m pytest tests/test_sgbm.py tests/test_gpu_stereo_seq.py -x -q -m gpu 2>&1 | tail -5
     run() { echo "== $*"; env "$@" timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 --no-cpu 2>>$O/st_try.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline'].get('stages_ms_per_frame'), d['roofline'].get('frac'))"; }
     run SSM_SGBM_FORM=2
-    run SSM_SGBM_SEG=6
+    run SSM_SGBM_SWEEP_LANES=16
     run SSM_SGBM_STRIP=64
-    run SSM_SGBM_STRIP=118
-    run SSM_SGBM_STREAMS=1
     run SSM_SGBM_STREAMS=3
     bash scripts/stereo_profile.sh 64 256 2>&1 | tail -12
     ;;

@@ -79,27 +79,41 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
 }
 // candidates: v > thr and v equals the 3x3 max of the thresholded map, interior pixels only.  key = value bits << 32 | ~index: a larger key is a
 // STRONGER corner in cv::goodFeaturesToTrack's walk (value descending, then raster index ascending)
+// Round 4: a block takes 1024 consecutive pixels (a wave 256: lane l looks at pixels l, l + 64, l + 128, l + 192 of them, so each of its four ballots is
+// 64 consecutive pixels = two whole words of the bit image), row / column of a pixel by a reciprocal multiplication: the thread-per-pixel version spent its
+// time on three barriers, one division sequence and two atomics per 256 pixels of almost no work (0.017 VALU instructions per clock, 19 us per 1241 x 376 frame)
+#define GC_PX 4
 __global__ void __launch_bounds__(256)
 gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* __restrict__ maxord_all, double quality, unsigned long long* __restrict__ keys_all,
-                    int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all, uint32_t* __restrict__ bits_all, int bits_words)
+                    int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all, uint32_t* __restrict__ bits_all, int bits_words, uint32_t mul_w)
 {
     const int f = blockIdx.y;
     const float* eig = eig_all + (size_t)f * w * h; unsigned long long* keys = keys_all + (size_t)f * cap; int* count = count_all + f;
     int* cand_at = cand_at_all + (size_t)f * w * h;          // per-pixel candidate index + 1 (0 = none; zero on entry, gftt_finish_kernel zeroes it again)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 4 + wv) * (64 * GC_PX) + lane;         // the lane's first pixel; + 64 j
+    const int np = w * h;
     const int mo = maxord_all[f]; const float mx = __int_as_float(mo >= 0 ? mo : mo ^ 0x7FFFFFFF);
     const float thr = (float)((double)fmaxf(mx, 0.f) * quality);
-    bool keep = false; float v = 0.f;
-    const int y = i / w, x = i - y * w;
-    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-        v = eig[i];
-        if (v > thr) {
-            float m = 0.f;
+    bool keep[GC_PX]; float v[GC_PX];
 #pragma unroll
-            for (int j = -1; j <= 1; j++)
+    for (int j = 0; j < GC_PX; j++) {
+        const int i = i0 + 64 * j;
+        keep[j] = false; v[j] = 0.f;
+        if (i < np) {
+            int y = (int)__umulhi((uint32_t)i, mul_w); int x = i - y * w;        // floor(i / w): mul_w = ceil(2^32 / w) is exact for i w < 2^32 up to one correction step
+            if (x < 0) { y--; x += w; }
+            if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
+                v[j] = eig[i];
+                if (v[j] > thr) {
+                    float m = 0.f;
 #pragma unroll
-                for (int k = -1; k <= 1; k++) { float qv = eig[i + j * w + k]; qv = qv > thr ? qv : 0.f; m = fmaxf(m, qv); }
-            keep = v == m;
+                    for (int a = -1; a <= 1; a++)
+#pragma unroll
+                        for (int k = -1; k <= 1; k++) { float qv = eig[i + a * w + k]; qv = qv > thr ? qv : 0.f; m = fmaxf(m, qv); }
+                    keep[j] = v[j] == m;
+                }
+            }
         }
     }
     // one reservation per BLOCK (the list order is free: the selection compares keys, it does not walk a sorted list): waves take their offsets from an LDS
@@ -107,20 +121,27 @@ gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* 
     __shared__ int s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const unsigned long long bal = __ballot(keep);
-    const int lane = threadIdx.x & 63;
+    unsigned long long bal[GC_PX]; int wcount = 0;
+#pragma unroll
+    for (int j = 0; j < GC_PX; j++) { bal[j] = __ballot(keep[j]); wcount += __popcll(bal[j]); }
     int woff = 0;
-    if (bal && lane == 0) woff = atomicAdd(&s_cnt, __popcll(bal));
+    if (wcount && lane == 0) woff = atomicAdd(&s_cnt, wcount);
     woff = __shfl(woff, 0, 64);
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(count, s_cnt);
     __syncthreads();
-    bool listed = false;
-    if (keep) { const int k = s_base + woff + __popcll(bal & ((1ull << lane) - 1ull)); if (k < cap) { keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i); cand_at[i] = k + 1; listed = true; } }
-    // the same map as one bit per pixel (bit i of the frame's bit image; a wave covers 64 consecutive pixels = two whole words, written whether set or not):
-    // gftt_deps_kernel looks at 17 x 17 pixels per candidate and ~97 % of them hold nothing
-    const unsigned long long lb = __ballot(listed);
-    if (lane == 0) { uint32_t* bw = bits_all + (size_t)f * bits_words + (i >> 5); bw[0] = (uint32_t)lb; bw[1] = (uint32_t)(lb >> 32); }
+    int before = 0;                                                             // kept pixels of the wave's earlier 64-pixel groups
+#pragma unroll
+    for (int j = 0; j < GC_PX; j++) {
+        const int i = i0 + 64 * j;
+        bool listed = false;
+        if (keep[j]) { const int k = s_base + woff + before + __popcll(bal[j] & ((1ull << lane) - 1ull)); if (k < cap) { keys[k] = ((unsigned long long)__float_as_uint(v[j]) << 32) | (0xFFFFFFFFu - (unsigned)i); cand_at[i] = k + 1; listed = true; } }
+        before += __popcll(bal[j]);
+        // the same map as one bit per pixel (bit i of the frame's bit image; a ballot covers 64 consecutive pixels = two whole words, written whether set or not):
+        // gftt_deps_kernel looks at 17 x 17 pixels per candidate and ~97 % of them hold nothing
+        const unsigned long long lb = __ballot(listed);
+        if (lane == 0) { uint32_t* bw = bits_all + (size_t)f * bits_words + ((i0 + 64 * j) >> 5); bw[0] = (uint32_t)lb; bw[1] = (uint32_t)(lb >> 32); }
+    }
 }
 // minDistance selection (cv::goodFeaturesToTrack: walk the corners from the strongest, keep one unless an already kept corner lies closer than
 // minDistance, stop at maxCorners).  The sequential walk is equivalent to rounds of local decisions, because a corner's fate depends only on
@@ -550,7 +571,7 @@ hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
 // cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  Workspace (GfttWork): eig nb*w*h floats; cand_at
 // nb*w*h ints, ZERO on entry (left zeroed); keys / kept nb*cap u64; deps nb*cap*GFTT_DEPS u32; depn / state nb*cap bytes; maxord / count / nkept nb ints;
 // overflow 1 int (set when a frame has more than cap candidates)
-size_t k_quad_gftt_bits_words(int w, int h) { return ((size_t)w * h + 255) / 256 * 8 + 2; }      // whole blocks of gftt_collect_kernel + the word a window may read past the end
+size_t k_quad_gftt_bits_words(int w, int h) { return ((size_t)w * h + 1023) / 1024 * 32 + 2; }      // whole blocks of gftt_collect_kernel (1024 pixels) + the word a window may read past the end
 size_t k_quad_gftt_deps_per_candidate() { return GFTT_DEPS; }
 hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s)
 {
@@ -562,7 +583,7 @@ hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quali
     const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
     mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, g.eig, g.maxord);
     const int bw = (int)k_quad_gftt_bits_words(w, h);
-    gftt_collect_kernel<<<dim3((w * h + 255) / 256, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at, g.cand_bits, bw);
+    gftt_collect_kernel<<<dim3((w * h + 1023) / 1024, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at, g.cand_bits, bw, (uint32_t)(((1ull << 32) + w - 1) / w));
     const dim3 gc((cap + 255) / 256, nb);
     gftt_deps_kernel<<<gc, 256, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.cand_bits, bw, g.deps, g.depn, g.state);
     for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<gc, 256, 0, s>>>(g.count, cap, g.deps, g.depn, g.state);

@@ -752,6 +752,237 @@ sgbm_sweep(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_al
         run_rows(Vb, y0 + SGS_UN);
     }
 }
+// ------------------------------------------------------------------ the sweep with EIGHT lanes per pixel (default)
+// sgbm_sweep gives a pixel 16 lanes (one DPP row) with D / 16 disparities each -- 45 instructions per recurrence step for the 4 pixels of a wave at D = 80.
+// With 8 lanes per pixel a lane holds D / 8 disparities = K packed pairs (never an odd count: no pad slot) and a wave 8 pixels: 14 + 10 K - 1 = 63
+// instructions per step for twice the pixels (the d +- 1 neighbours cross lanes by row_shr / row_shl with the lane at a group's edge repaired by a select,
+// min over d by quad_perm x 2 + row_half_mirror = three steps instead of four), and the fixed part of the winner pass (selection, uniqueness vote, division,
+// atomics: per wave instruction, whatever the number of pixels) is paid once per 8 pixels.  A block is 128 groups = 128 columns (CPG = 1), every column's
+// diagonal predecessors come from the neighbouring groups through LDS; the strip hand-off (mailboxes, tickets, publish-before-poll) is sgbm_sweep's.
+template <int K>
+__device__ __forceinline__ void sg_step8(uint32_t (&L)[K], int& minPrev, const uint32_t (&Cp)[K], uint32_t P1P1, int P2, bool first, bool last)
+{
+    constexpr uint32_t MAXMAX = (uint32_t)SG_MAXC | ((uint32_t)SG_MAXC << 16);
+    uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXMAX, (int)L[K - 1]);          // row_shr:1: the left lane's last pair
+    uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);              // row_shl:1: the right lane's first pair
+    lft = first ? MAXMAX : lft;                                                   // lane 0 of the GROUP (lane 8 of the DPP row would see the other group's lane 7)
+    rgt = last ? MAXMAX : rgt;
+    const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
+    uint32_t Ln[K], m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint32_t lm = __builtin_amdgcn_alignbyte(L[j], j > 0 ? L[j - 1] : lft, 2);             // (slot 2j-1, slot 2j)
+        const uint32_t lp = __builtin_amdgcn_alignbyte(j < K - 1 ? L[j + 1] : rgt, L[j], 2);         // (slot 2j+1, slot 2j+2)
+        const uint32_t t = pk_min16(pk_min16(L[j], pk_add16(lm, P1P1)), pk_min16(pk_add16(lp, P1P1), dd));
+        Ln[j] = pk_sub16(pk_add16(Cp[j], t), dd);
+        m = pk_min16(m, Ln[j]);
+    }
+    int v = (int)min(m & 0xFFFFu, m >> 16);
+    v = min(v, sg_dpp<0xB1>(v, v));       // quad_perm [1,0,3,2]
+    v = min(v, sg_dpp<0x4E>(v, v));       // quad_perm [2,3,0,1]
+    v = min(v, sg_dpp<0x141>(v, v));      // row_half_mirror: lane i <-> 7 - i of its 8-lane half
+    minPrev = v;
+#pragma unroll
+    for (int j = 0; j < K; j++) L[j] = Ln[j];
+}
+__device__ __forceinline__ int sg_min8(int v)
+{
+    v = min(v, sg_dpp<0xB1>(v, v)); v = min(v, sg_dpp<0x4E>(v, v)); v = min(v, sg_dpp<0x141>(v, v));
+    return v;
+}
+template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], const uint16_t* p) { __builtin_memcpy(d, p, 4 * K); }      // 2 K u16, 4-byte aligned
+template <int K, bool FAST>
+__global__ void __launch_bounds__(1024)
+sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
+            int NS, int TX, int16_t* __restrict__ disp1, unsigned* __restrict__ disp2key, unsigned* flags /* [0] ticket counter, [1] time-out */, sg_u64* mbox_all, int* fail_out)
+{
+    constexpr int D = 16 * K, NG = K + 1;                      // a lane: 2 K disparities = K pairs; a message: K pairs + the path minimum
+    extern __shared__ __align__(16) uint8_t sw_smem[];
+    __shared__ unsigned s_ticket; __shared__ int s_fail[2];
+    const int ng = blockDim.x >> 3, g = threadIdx.x >> 3, li = threadIdx.x & 7;
+    uint32_t* xch = reinterpret_cast<uint32_t*>(sw_smem);     // [parity 2][direction 2][ng][NG][8]: dir 0 = L1 of the column (for its right neighbour), dir 1 = L3 (for its left neighbour)
+    uint16_t* srow = reinterpret_cast<uint16_t*>(xch + (size_t)4 * ng * NG * 8) + (size_t)g * D;
+    auto xslot = [&](int par, int dir, int gg) -> uint32_t* { return xch + ((size_t)((par * 2 + dir) * ng + gg) * NG) * 8 + li; };
+    if (threadIdx.x == 0) { s_ticket = atomicAdd(&flags[0], 1u); s_fail[0] = 0; s_fail[1] = 0; }
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {                       // "row -1": OpenCV's zeroed border
+        uint32_t* p = xslot(1, dir, g);
+#pragma unroll
+        for (int j = 0; j < NG; j++) p[j * 8] = 0u;
+    }
+    __syncthreads();
+    const int t = (int)s_ticket, f = t / NS, strip = t - f * NS;
+    const int x = strip * TX + g, xend = min((strip + 1) * TX, w1);
+    const bool live = g < TX && x < xend;
+    const uint16_t* Cf = C_all + (size_t)f * w1 * h * D + li * 2 * K; const uint16_t* Sf = S_all + (size_t)f * w1 * h * D + li * 2 * K;
+    disp1 += (size_t)f * w * h; disp2key += (size_t)f * w * h;
+    sg_u64* mb = mbox_all + (size_t)f * (NS - 1) * 2 * SGS_SLOTS * NG * 8 + li;
+    auto mslot = [&](int seam, int dir, int slot) -> sg_u64* { return mb + (size_t)(((seam * 2 + dir) * SGS_SLOTS + slot) * NG) * 8; };
+    const bool edgeL = g == 0 && strip > 0, edgeR = g == TX - 1 && strip < NS - 1;
+    const bool first = li == 0, last = li == 7;
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    const int udiv = 100 - uniquenessRatio;
+    uint32_t L1[K], L2[K], L3[K]; int m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) L1[j] = L2[j] = L3[j] = 0u;
+    uint32_t Va[2][K], Vb[2][K];                              // [C, S04][pairs] of the row in work and of the next one
+    auto load_row = [&](uint32_t (&V)[2][K], int y) {
+        const size_t off = ((size_t)min(y, h - 1) * w1 + min(x, w1 - 1)) * D;
+        sg_load8<K>(V[0], Cf + off); sg_load8<K>(V[1], Sf + off);
+    };
+    bool stop = false;
+    auto mbox_wait8 = [&](const sg_u64* gq, unsigned epoch, uint32_t (&v)[NG]) -> bool {
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < NG; j++) { const sg_u64 q = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT); v[j] = (uint32_t)q; ok &= (unsigned)(q >> 32) == epoch; }
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
+            if (spins >= SGS_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(flags + 1, SG_RLX_AGENT) != 0u)) return false;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
+    auto run_row = [&](const uint32_t (&V)[2][K], int y) {
+        // ---- the neighbouring columns' states of row y - 1 (LDS; the strip's outermost columns: the mailbox or the zeroed border, below)
+        uint32_t nl[NG], nr[NG];
+        const int pp = (y + 1) & 1;
+        {   const uint32_t* p = xslot(pp, 0, g > 0 ? g - 1 : 0);
+#pragma unroll
+            for (int j = 0; j < NG; j++) nl[j] = p[j * 8];
+            const uint32_t* q = xslot(pp, 1, g < ng - 1 ? g + 1 : g);
+#pragma unroll
+            for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
+        }
+        // ---- what a strip hands on never depends on what it receives in the same row (L1 flows right, L3 flows left): the edge columns compute and publish
+        // their outgoing state BEFORE the incoming mailbox is polled (sgbm_sweep)
+        const bool outL = g == 0, outR = g >= TX - 1;
+        if (!outL) {                                              // L1 from the left neighbour in LDS
+#pragma unroll
+            for (int j = 0; j < K; j++) L1[j] = nl[j];
+            m1 = (int)nl[K];
+        }
+        if (!outR) {
+#pragma unroll
+            for (int j = 0; j < K; j++) L3[j] = nr[j];
+            m3 = (int)nr[K];
+        }
+        // (the steps run for the whole wave -- DPP -- with the outermost columns' missing direction done after the poll)
+        uint32_t T1[K], T3[K]; int t1 = m1, t3 = m3;
+#pragma unroll
+        for (int j = 0; j < K; j++) { T1[j] = L1[j]; T3[j] = L3[j]; }
+        sg_step8<K>(T1, t1, V[0], P1P1, P2, first, last);
+        sg_step8<K>(T3, t3, V[0], P1P1, P2, first, last);
+        sg_step8<K>(L2, m2, V[0], P1P1, P2, first, last);
+        if (edgeR) {                                              // its L1 came from LDS: final
+            sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
+#pragma unroll
+            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | T1[j], SG_RLX_AGENT);
+            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)t1, SG_RLX_AGENT);
+        }
+        if (edgeL) {
+            sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
+#pragma unroll
+            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | T3[j], SG_RLX_AGENT);
+            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)t3, SG_RLX_AGENT);
+        }
+        // ---- the outermost columns: the direction that comes from outside the strip
+        const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
+        if (wave_has_edge) {
+            bool okl = true, okr = true;
+            if (outL) {
+                if (edgeL && y > 0) okl = mbox_wait8(mslot(strip - 1, 0, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nl);
+                else {
+#pragma unroll
+                    for (int j = 0; j < NG; j++) nl[j] = 0u;
+                }
+            }
+            if (outR) {
+                if (edgeR && y > 0) okr = mbox_wait8(mslot(strip, 1, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nr);
+                else {
+#pragma unroll
+                    for (int j = 0; j < NG; j++) nr[j] = 0u;
+                }
+            }
+            if (!(okl && okr)) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
+            // redo the two steps for the wave with the received states in the outermost columns (the other columns of the wave repeat theirs: same values)
+            uint32_t U1[K], U3[K]; int u1 = outL ? (int)nl[K] : m1, u3 = outR ? (int)nr[K] : m3;
+#pragma unroll
+            for (int j = 0; j < K; j++) { U1[j] = outL ? nl[j] : L1[j]; U3[j] = outR ? nr[j] : L3[j]; }
+            sg_step8<K>(U1, u1, V[0], P1P1, P2, first, last);
+            sg_step8<K>(U3, u3, V[0], P1P1, P2, first, last);
+#pragma unroll
+            for (int j = 0; j < K; j++) { T1[j] = U1[j]; T3[j] = U3[j]; }
+            t1 = u1; t3 = u3;
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) { L1[j] = T1[j]; L3[j] = T3[j]; }
+        m1 = t1; m3 = t3;
+        if (!live) {                                              // a column outside the strip / image: its neighbours see the zeroed border
+#pragma unroll
+            for (int j = 0; j < K; j++) L1[j] = L2[j] = L3[j] = 0u;
+            m1 = m2 = m3 = 0;
+        }
+        {   uint32_t* p = xslot(y & 1, 0, g);
+#pragma unroll
+            for (int j = 0; j < K; j++) p[j * 8] = L1[j];
+            p[K * 8] = (uint32_t)m1;
+            uint32_t* q = xslot(y & 1, 1, g);
+#pragma unroll
+            for (int j = 0; j < K; j++) q[j * 8] = L3[j];
+            q[K * 8] = (uint32_t)m3;
+        }
+        // ---- the winner pass of the group's pixel: S = min(32767, S04 + L1 + L2 + L3)
+        {
+            uint32_t sp2[K];
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                if (FAST) { constexpr uint32_t MM = 0x7FFF7FFFu; sp2[j] = pk_min16(pk_add16(pk_min16(pk_add16(L1[j], L2[j]), MM), pk_min16(pk_add16(L3[j], V[1][j]), MM)), MM); }
+                else sp2[j] = pk_addsat15(pk_addsat15(pk_addsat15(L1[j], L2[j]), L3[j]), V[1][j]);
+            }
+            int Sv[2 * K], best = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < 2 * K; k++) {
+                Sv[k] = (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+                best = min(best, (Sv[k] << 8) | (li * 2 * K + k));
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) reinterpret_cast<uint32_t*>(srow)[li * K + j] = sp2[j];       // (every value <= 32767: the pairs are the u16 table as it stands)
+            best = sg_min8(best);
+            const int minS = best >> 8, bestDisp = best & 255;
+            bool bad = false;
+            if (udiv > 0) {                                       // (uniform)
+                const int uth = minS > 0 ? sg_div_small(100 * minS - 1, udiv) : -1;
+#pragma unroll
+                for (int k = 0; k < 2 * K; k++) bad |= Sv[k] <= uth && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2 * K; k++) bad |= Sv[k] * udiv < minS * 100 && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
+            }
+            const unsigned long long bal = __ballot(bad);
+            const bool rejected = ((bal >> (threadIdx.x & 56)) & 0xFFull) != 0;          // any lane of my 8-lane group
+            if (live && !rejected && li == 0) {
+                int d = bestDisp;
+                const int x2 = x + minX1 - d - minD;
+                if (minS < SG_MAXC) atomicMin(&disp2key[(size_t)y * w + x2], ((unsigned)minS << 16) | (unsigned)(65535 - x));
+                if (0 < d && d < D - 1) {
+                    const int sm = srow[d - 1], s0 = srow[d], sp = srow[d + 1];
+                    const int denom2 = max(sm + sp - 2 * s0, 1);
+                    d = d * SG_DISP_SCALE + sg_div_small((sm - sp) * SG_DISP_SCALE + denom2, denom2 * 2);
+                } else d *= SG_DISP_SCALE;
+                disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
+            }
+        }
+        __syncthreads();
+        if (s_fail[y & 1]) stop = true;                           // a hand-off timed out: every wave leaves at the same row
+    };
+    load_row(Va, 0);
+    for (int y = 0; y < h && !stop; y += 2) {
+        load_row(Vb, y + 1);
+        run_row(Va, y);
+        if (y + 1 >= h || stop) break;
+        load_row(Va, y + 2);
+        run_row(Vb, y + 1);
+    }
+}
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
 // S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
 // disparity table OpenCV fills while walking x from right to left, replacing an entry only by a strictly smaller cost) becomes
@@ -1126,9 +1357,14 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     int NS = (w1 + cap - 1) / cap;
     const int TX = ((w1 + NS - 1) / NS + SGS_CPG - 1) / SGS_CPG * SGS_CPG;
     NS = (w1 + TX - 1) / TX;
-    const int threads = (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
-    const size_t lds = (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;
-    auto sweep = costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>;
+    // eight lanes per pixel (sgbm_sweep8) unless its exchange buffers do not fit a CU's LDS (D = 128) or SSM_SGBM_SWEEP_LANES=16 asks for the 16-lane kernel
+    static const int lanes_env = [] { const char* v = getenv("SSM_SGBM_SWEEP_LANES"); return v ? atoi(v) : 8; }();
+    const int threads8 = (TX * 8 + 63) / 64 * 64, ng8 = threads8 / 8;
+    const size_t lds8 = (size_t)4 * ng8 * (K + 1) * 8 * 4 + (size_t)ng8 * D * 2;
+    const bool use8 = lanes_env != 16 && lds8 <= 150 * 1024;
+    const int threads = use8 ? threads8 : (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
+    const size_t lds = use8 ? lds8 : (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;
+    auto sweep = use8 ? (costs_below_2_15 ? sgbm_sweep8<K, true> : sgbm_sweep8<K, false>) : (costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>);
     hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sweep), lds);
     if (e != hipSuccess) return e;
     if (seg_env == 6) sgbm_rows<K, 6><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
