@@ -212,7 +212,9 @@ def stereo_main(args):
                        "frame_pairs_per_gpu": F, "frame_pairs_per_launch": B, "parallelism": "replicas" if world > 1 else "single GPU"},
             "per_frame": {"quad_matches": round(float(nq.mean()), 1), "vo_success_rate": round(float(res["vo_result"][1:, 1].mean()), 3)},
             "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle, depth: all kernels of the SGBM stage)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg),
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": None if traffic is None else os.path.relpath(latest_profile("stereo_traffic.json"), ROOT) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)",
+                         "algorithmic_bytes_per_launch": round(alg),
                          "stages_ms_per_frame": {k: round(v[0] / (F * nser), 4) for k, v in stage_acc.items()},
                          "stages_ms_per_frame_overlapped": {k: round(v[0] / (F * args.steps), 4) for k, v in stage_ovl.items()}},
             "cpu_baseline": cpu}
@@ -634,6 +636,8 @@ def main():
                                          "note": "all kernels of a frame (ORB, match, map) at the timed rate `value`, two chains overlapped"}
         except Exception:
             pass
+        if roof.get("traffic") is not None:     # `traffic` is NOT measured in this run: it is this kernel's figure from the committed counter passes of the same command
+            roof["traffic_source"] = os.path.relpath(latest_profile("traffic.json"), ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/collect_profiles.sh pmc; per frame x frames per launch)"
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
         roof["stages_us_per_frame_overlapped"] = {k: round(v[0] / args.steps / F * 1e3, 3) for k, v in sorted(stage_ovl.items(), key=lambda kv: -kv[1][0])}
         roof["timing"] = ("achieved / stages_us_per_frame: hipEvents around each stage in a second pass of the same K steps with all stages "

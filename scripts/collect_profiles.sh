@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the bench lines and the rocprofv3 runs the summaries under profiles/ are made from.
-# Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc|pmc_stereo'
+# Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc|pmc_stereo|pmc_segnet'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 if [ "$1" = "stats" ]; then
@@ -11,11 +11,17 @@ if [ "$1" = "stats" ]; then
   timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 1 > $O/line_poses_dev.json 2> $O/line_poses_dev.err
   timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 1 --pose-threads 16 > $O/line_poses_dev16.json 2> $O/line_poses_dev16.err
   timeout 120 python3 scripts/tracker_concurrency.py 1 2 4 8 16 > $O/tracker_concurrency.txt 2>&1
+  timeout 300 python3 scripts/per_call_latency.py $O/per_call.md > /dev/null 2>&1
+  timeout 600 python3 scripts/mapper_update_cost.py 150 > $O/mapper_update_cost.md 2>&1
   rm -rf $O/p_stats $O/p_seg $O/p_st
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --serial-only > $O/p_st.log 2>&1
   tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
+elif [ "$1" = "pmc_segnet" ]; then
+  rm -rf $O/p_seg_pmc
+  timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_seg_pmc -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg_pmc.log 2>&1
+  python3 scripts/segnet_layers.py $O/p_seg_pmc 64 $O/segnet_layers.md; tail -2 $O/segnet_layers.md
 elif [ "$1" = "pmc_stereo" ]; then
   rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
   A="--stereo --stereo-batch 32 --frames 64 --steps 1 --warmup 0 --no-cpu --serial-only"

@@ -1,9 +1,11 @@
-// kernels_match.hip -- K6: OrbFeature::match (/root/reference/src/orb.cpp:16-29) = cv::BFMatcher(NORM_HAMMING)
-// knnMatch(k=2) + Lowe ratio test, for gfx950.  One block per (query frame, train frame) pair (two in the sequence kernel): the train
-// descriptors are staged in LDS (32 B each, read back as wave-wide broadcasts), every lane owns one query descriptor
-// in 8 VGPRs, distance = 8 x (v_xor + v_bcnt accumulate); the kept matches are compacted in ascending queryIdx with
-// wave ballots.  Integer work, VALU-bound: no MFMA by design.  Tie rule = oracle/match.c (strict '<' scan in train
-// order, so equal distances resolve to the lower trainIdx).
+// kernels_match.hip -- K6: OrbFeature::match (/root/reference/src/orb.cpp:16-29) = cv::BFMatcher(NORM_HAMMING) knnMatch(k=2) + Lowe ratio test, for gfx950.
+// Two formulations live here, bit-equal to each other and to oracle/match.c (strict '<' scan in train order: equal distances resolve to the lower trainIdx):
+//   * the DEFAULT (second half of the file: match_expand_kernel / match_mfma_kernel / match_compact_kernel): the Hamming distance matrix as an exact matrix
+//     product on the matrix cores -- descriptors expanded to +-1 FP4 elements, v_mfma_scale_f32_32x32x64_f8f6f4 tiles with the (distance, trainIdx) key built in
+//     the accumulator, VALU top-2 tracking;
+//   * the VALU form (first half: match_pairs / match_seq_kernel, SSM_MATCH_VARIANT=0 and the knn entry points): one block per (query frame, train frame) pair, train
+//     descriptors staged in LDS (32 B each, read back as wave-wide broadcasts), every lane owns query descriptors in VGPRs, distance = 8 x (v_xor + v_bcnt
+//     accumulate), matches compacted in ascending queryIdx with wave ballots.
 #include "ssm_internal.h"
 
 #define MT 512           // threads per block; each lane owns 2 queries -> 1024 queries per pass
