@@ -453,6 +453,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     delete c;
 }
 void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out) { *out = c->cfg; }
+int ssm_internal_get_device(const ssm_ctx* c) { return c->device; }
 extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
 extern "C" void* ssm_stream(ssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 static int wait_pending(ssm_ctx* c);

@@ -160,3 +160,4 @@ hipError_t k_quad_window_match(const float* kp1, const uint8_t* d1, int n1, cons
 
 // for the translation units that only use the public ABI (ssm_track.hip): the configuration a context was created with
 void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out);
+int ssm_internal_get_device(const ssm_ctx* c);      // the HIP device the context lives on: raw HIP calls of another translation unit select it first

@@ -50,6 +50,7 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
     ssm_config cfg; ssm_internal_get_config(ctx, &cfg);
     t->cam = cfg.camera; t->ratio = cfg.knn_match_ratio;
     if (cfg.tracker_ref_frames != p->ref_frames) { delete t; return SSM_E_INVAL; }
+    (void)hipSetDevice(ssm_internal_get_device(ctx));              // the raw HIP calls of this file act on the context's device, whatever the calling thread used last
     if (p->own_stream && (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess)) {
         if (t->own) hipStreamDestroy(t->own);
         delete t; return SSM_E_HIP;
@@ -68,6 +69,7 @@ static void tracker_free_device(ssm_tracker* t)
 extern "C" void ssm_tracker_destroy(ssm_tracker* t)
 {
     if (!t) return;
+    (void)hipSetDevice(ssm_internal_get_device(t->ctx));
     if (t->own) { hipStreamSynchronize(t->own); hipStreamDestroy(t->own); }
     if (t->ev) hipEventDestroy(t->ev);
     tracker_free_device(t); delete t;
@@ -102,6 +104,7 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
     if (!t) return SSM_E_INVAL;
     if (!seq || n < 0 || (n && !pose_out)) TFAIL(t, SSM_E_INVAL, "bad arguments");
     if (n == 0) return SSM_OK;
+    (void)hipSetDevice(ssm_internal_get_device(t->ctx));
     const int cap = seq->cap, R = seq->R;
     if (R != t->prm.ref_frames || R > SSM_TRACK_MAXREF) TFAIL(t, SSM_E_INVAL, "the sequence was matched with another tracker_ref_frames");
     const bool on_device = t->prm.use_device != 0;

@@ -72,6 +72,9 @@ int main(int argc, char** argv)
         if (!mkdtemp(tmpl)) { perror("mkdtemp"); return 2; }
         const string dir = tmpl, ranks_s = to_string(nranks);
         vector<pid_t> kids;
+        // INVARIANT: nothing above this point creates an ssm::Device (ParameterReader only parses the file): the parent forks and the children exec BEFORE any HIP
+        // call.  Never move device work in front of this loop; the counter makes a violation fail here instead of on the node.
+        if (ssm::devices_created().load() != 0) { cerr << RED << "exp_mapping: internal error: a device context exists before the ranks are started" << RESET << endl; return 2; }
         for (int r = 0; r < nranks; r++) {
             pid_t p = fork();                                 // no HIP call has happened in this process; the child execs at once
             if (p < 0) { perror("fork"); for (pid_t k : kids) kill(k, SIGKILL); return 2; }
