@@ -88,9 +88,9 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
     const int f = blockIdx.y, xs = blockIdx.x * TX, tid = threadIdx.x;
     const int SW = 2 * SW2 + 1, AW = TX + 2 * SW2, RW = AW + D - 1;
     uint16_t* ring = reinterpret_cast<uint16_t*>(sg_smem);
-    uint8_t* pixrow = sg_smem + (size_t)SW * TX * D * 2;
-    uint4* lrow = reinterpret_cast<uint4*>(pixrow + (((size_t)AW * D + 15) & ~(size_t)15));
-    uint4* rrow = lrow + AW;
+    const size_t pixb = ((size_t)AW * D + 15) & ~(size_t)15;
+    uint8_t* pixrow2 = sg_smem + (size_t)SW * TX * D * 2;                // two pixel-cost rows and two staged pixel rows (row parity): ONE barrier per row
+    uint4* lrow2 = reinterpret_cast<uint4*>(pixrow2 + 2 * pixb);
     const size_t np = (size_t)w * h;
     // (d, chunk) decomposition of the block
     const int nchunk = SGC_THREADS / D, d = tid % D, chunk = tid / D;
@@ -111,15 +111,17 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
     const int SH2 = SW2, ylast = h - 1 - SH2;
     uint16_t* Cp = C_all + ((size_t)f * w1 * h + xs + cx0) * D + d;           // C(0, xs + cx0, d); + y * w1 * D per row, + D per column
     const size_t crow = (size_t)w1 * D;
-    const uint8_t* pxd = pixrow + d;
     const int lo = SW2 - xs, hi = w1 - 1 - xs + SW2;            // pixrow index of cost-volume columns 0 and w1 - 1 (replicate beyond them; only in EDGE strips)
-    auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
-    // one image row: stage, pixel costs, horizontal sums -> sum[k] of this thread's columns (PHASE 0: r = 0, 1: 1 .. SH2, 2: beyond)
+    // one image row: pixel costs of row r (staged by the previous trip), stage row r + 1, ONE barrier, horizontal sums -> sum[k] of this thread's columns
+    // (PHASE 0: r = 0, 1: 1 .. SH2, 2: beyond).  Everything a trip writes for others lives in the buffers of ITS row parity: the next trip's pixel pass
+    // (other parity) may start while slower waves still sum this row, and a buffer is rewritten two trips later, behind the barrier in between.
     auto row = [&](int r, auto phase) {
         constexpr int PHASE = decltype(phase)::value;
-        if (src) lrow[tid] = pre;                               // rrow follows lrow: one linear array
-        __syncthreads();
-        if (src && r + 1 < h) pre = src[(size_t)(r + 1) * w];
+        uint8_t* pixrow = pixrow2 + (size_t)(r & 1) * pixb;
+        const uint4* lrow = lrow2 + (size_t)(r & 1) * (AW + RW); const uint4* rrow = lrow + AW;
+        const uint8_t* pxd = pixrow + d;
+        auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
+        if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = src[(size_t)(r + 2) * w]; }      // row r + 1 for the next trip; row r + 2 on its way
         if (active) {
             const sg_s2 zero = {0, 0};
             for (int i = chunk; i < AW; i += nchunk) {
@@ -154,7 +156,8 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
             }
         }
     };
-    if (src) pre = src[0];
+    if (src) { lrow2[tid] = src[0]; if (h > 1) pre = src[(size_t)w]; }      // row 0 staged, row 1 in registers
+    __syncthreads();
     row(0, std::integral_constant<int, 0>());
     for (int r = 1; r <= SH2; r++) row(r, std::integral_constant<int, 1>());
     for (int r = SH2 + 1; r < h; r++) row(r, std::integral_constant<int, 2>());
@@ -1426,7 +1429,7 @@ bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out)
     const int SW2 = SW / 2, nchunk = SGC_THREADS / D;
     for (int TX = 32; TX >= 4; TX >>= 1) {
         const int AW = TX + 2 * SW2, RW = AW + D - 1;
-        const size_t lds = (size_t)SW * TX * D * 2 + (((size_t)AW * D + 15) & ~(size_t)15) + (size_t)(AW + RW) * 16;
+        const size_t lds = (size_t)SW * TX * D * 2 + 2 * (((size_t)AW * D + 15) & ~(size_t)15) + 2 * (size_t)(AW + RW) * 16;
         // the interior (clamp-free) strips must not touch the volume's border columns: SW2 <= TX
         if (lds <= 150 * 1024 && (TX + nchunk - 1) / nchunk <= 16 && AW + RW <= SGC_THREADS && SW2 <= TX) { *TX_out = TX; *lds_out = lds; return true; }
     }
