@@ -19,6 +19,7 @@ from conftest import CAM, SEED                                          # noqa: 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
+SCALE = float(os.environ.get("SSM_FUZZ_SCALE", "1"))      # a one-off long hunt: SSM_FUZZ_SCALE=20 python -m pytest tests/test_gpu_fuzz.py -m gpu
 COMMON = dict(deadline=None, print_blob=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
@@ -39,7 +40,7 @@ def same_struct(a, b):
 
 
 # ---------------------------------------------------------------- matcher: random sizes, duplicate rows (ties, zero distances), ratios
-@settings(max_examples=150, **COMMON)
+@settings(max_examples=int(150 * SCALE), **COMMON)
 @given(seed=st.integers(0, 2**31 - 1), nq=st.integers(1, 700), nt=st.integers(2, 900), pool=st.integers(1, 64),
        dup=st.floats(0.0, 1.0), ratio=st.sampled_from([0.5, 0.7, 0.8, 0.95, 1.0]), flips=st.integers(0, 3))
 def test_fuzz_matcher(ctx, oracle, seed, nq, nt, pool, dup, ratio, flips):
@@ -64,7 +65,7 @@ def test_fuzz_matcher(ctx, oracle, seed, nq, nt, pool, dup, ratio, flips):
 
 
 # ---------------------------------------------------------------- voxel filter: random clouds, leaves, voxel-boundary coordinates, labels
-@settings(max_examples=80, **COMMON)
+@settings(max_examples=int(80 * SCALE), **COMMON)
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 6000), leaf=st.sampled_from([0.02, 0.05, 0.1, 0.25, 0.5, 1.0]), extent=st.sampled_from([0.3, 2.0, 15.0, 60.0]),
        on_grid=st.floats(0.0, 0.5), clones=st.floats(0.0, 0.5))
 def test_fuzz_voxel_filter(ctx, oracle, seed, n, leaf, extent, on_grid, clones):
@@ -103,7 +104,7 @@ PALETTE = np.array([[128, 128, 128], [0, 0, 128], [128, 192, 192], [0, 69, 255],
                     [128, 64, 64], [128, 0, 64], [0, 64, 64], [192, 128, 0]], np.uint8)      # BGR, tests/golden/palette.json
 
 
-@settings(max_examples=60, **COMMON)
+@settings(max_examples=int(60 * SCALE), **COMMON)
 @example(seed=0, w16=11, h=88, n=1, holes=0.0, block=1, stray=0.0, far=0.0, leaf=0.02, batch=1)     # round 4 finding: 968 words = 15 waves + 8 lanes; the palette
 @example(seed=0, w16=11, h=88, n=1, holes=0.0, block=32, stray=0.0, far=0.0, leaf=0.02, batch=1)    # table shuffle read masked-off lanes 8 .. 15 (wrong labels, one extra point)
 @given(seed=st.integers(0, 2**31 - 1), w16=st.integers(5, 26), h=st.integers(80, 150), n=st.integers(1, 4), holes=st.floats(0.0, 0.9),
@@ -156,7 +157,7 @@ def test_fuzz_sequence_map_stage(oracle, seed, w16, h, n, holes, block, stray, f
 
 
 # ---------------------------------------------------------------- sub-batch size against tracker_ref_frames: the match tables of a sequence
-@settings(max_examples=20, **COMMON)
+@settings(max_examples=int(20 * SCALE), **COMMON)
 @given(first=st.integers(0, 500), n=st.integers(2, 8), R=st.integers(1, 5), batch=st.integers(1, 4), cont=st.integers(0, 3))
 def test_fuzz_sub_batches_against_ref_window(oracle, first, n, R, batch, cont):
     """Tracker::trackRefFrame matches a frame against the tracker_ref_frames frames before it (/root/reference/src/track.cpp:150-152,192-196).  The sequence
