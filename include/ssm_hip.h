@@ -259,7 +259,9 @@ int ssm_window_match(ssm_ctx* ctx, const float* kp1, const uint8_t* d1, int n1, 
  * 80 disparities, SAD window 11, P1 = 4*11*11, P2 = 32*11*11, uniqueness 10, speckle window 100 / range 32, disp12MaxDiff 1,
  * preFilterCap 63.  left / right: rectified 8-bit images.  disp: int16 per pixel, fixed point with 4 fractional bits,
  * (minDisparity - 1) * 16 where no disparity was accepted (what cv::StereoSGBM::operator() writes).  stage 1 stops after
- * computeDisparitySGBM (no medianBlur / filterSpeckles), for tests.  numberOfDisparities: a multiple of 16, <= 128. */
+ * computeDisparitySGBM (no medianBlur / filterSpeckles), for tests.  numberOfDisparities: a multiple of 16, <= 128.  minDisparity >= 2: OpenCV 2.4 reads its half-sample
+ * interval buffers outside the range it filled there (calcPixelCostBT); this library uses the intervals of the pixels actually compared -- the
+ * reference sets minDisparity = 0. */
 typedef struct { int32_t minDisparity, numberOfDisparities, SADWindowSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
                  speckleWindowSize, speckleRange; } ssm_sgbm_params;
 void ssm_sgbm_params_default(ssm_sgbm_params* p);

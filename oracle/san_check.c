@@ -49,6 +49,13 @@ int main(void)
     sso_sgbm_params sp = {0, 32, 7, 4 * 49, 32 * 49, 1, 63, 10, 100, 32};
     int16_t* disp = malloc((size_t)W * H * 2); uint16_t* dep2 = malloc((size_t)W * H * 2);
     sso_sgbm(gray, rc, W, H, &sp, disp);
+    {   /* a cost volume narrower than half the SAD window + 1 (34 columns, 32 disparities, window 9: 2 columns): OpenCV 2.4 reads past its cost row here; the contract replicates the border */
+        sso_sgbm_params sn = {0, 32, 9, 4 * 81, 32 * 81, 1, 63, 10, 0, 32};
+        uint8_t *nl = malloc(34 * 20), *nr = malloc(34 * 20); int16_t* nd = malloc(34 * 20 * 2);
+        for (int i = 0; i < 34 * 20; i++) { nl[i] = gray[i]; nr[i] = rc[i]; }
+        sso_sgbm(nl, nr, 34, 20, &sn, nd);
+        free(nl); free(nr); free(nd);
+    }
     sso_disparity_to_depth(disp, W, H, 0.5323, 159.3, 127.6, 258.6, 20, 5, 40, 1000.0, dep2);
     int vo_ok = 0;
     if (nq >= 6) {

@@ -114,9 +114,13 @@ int sso_sgbm_raw(const uint8_t* img1, const uint8_t* img2, int width, int height
             if (k < height) {
                 pixel_cost_bt(img1, img2, width, height, k, minD, maxD, pixDiff, tempBuf, clipTab + TAB_OFS);
                 memset(hsumAdd, 0, sizeof(CostType) * D);
+                /* OpenCV 2.4 reads pixDiff[x + d] here for columns 0 .. SW2 without a bound: when the cost volume is narrower than half the window + 1
+                   (width1 <= SW2) that is a read past the row (undefined; found by tests/test_gpu_fuzz.py + ASan, round 4).  The contract replicates the last column,
+                   as the running sums below do with imin(x + SW2 * D, (width1 - 1) * D). */
                 for (int x = 0; x <= SW2 * D; x += D) {
                     const int scale = x == 0 ? SW2 + 1 : 1;
-                    for (int d = 0; d < D; d++) hsumAdd[d] = (CostType)(hsumAdd[d] + pixDiff[x + d] * scale);
+                    const CostType* pd = pixDiff + imin(x, (width1 - 1) * D);
+                    for (int d = 0; d < D; d++) hsumAdd[d] = (CostType)(hsumAdd[d] + pd[d] * scale);
                 }
                 if (y > 0) {
                     const CostType* hsumSub = hsumBuf + (size_t)(imax(y - SH2 - 1, 0) % hsumBufNRows) * costBufSize;

@@ -199,3 +199,137 @@ def test_fuzz_sub_batches_against_ref_window(oracle, first, n, R, batch, cont):
         for p in bufs:
             c.dev_free(p)
         c.close()
+
+
+# ---------------------------------------------------------------- SGBM: sizes (strip seams of the sweep), parameters, image content
+def _texture(rng, h, w, smooth):
+    t = rng.integers(0, 256, (h, w)).astype(np.float32)
+    k = np.ones(smooth, np.float32) / smooth
+    for ax in (0, 1):
+        t = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), ax, t)
+    t -= t.min(); t *= 255.0 / max(float(t.max()), 1e-6)
+    return t.astype(np.uint8)
+
+
+@settings(max_examples=int(24 * SCALE), **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), h=st.integers(14, 70), w=st.integers(40, 420), nd=st.sampled_from([16, 32, 48, 64, 80, 96, 128]), sad=st.sampled_from([3, 5, 7, 9, 11]),
+       min_d=st.sampled_from([0, 0, 0, -16, -5, 1]), uniq=st.sampled_from([0, 5, 10, 15, 40]), disp12=st.sampled_from([1, 2, 4]), cap=st.sampled_from([15, 31, 63]),
+       p_scale=st.sampled_from([1, 2, 8]), spw=st.sampled_from([0, 20, 100]), smooth=st.sampled_from([1, 3, 7]), planes=st.integers(1, 4), noise=st.integers(0, 12))
+def test_fuzz_sgbm(ctx, oracle, seed, h, w, nd, sad, min_d, uniq, disp12, cap, p_scale, spw, smooth, planes, noise):
+    """cv::StereoSGBM as calDisparity_SGBM configures it (/root/reference/src/stereo.cpp:11-30) with every parameter drawn: image sizes from fewer columns than
+    disparities (everything invalid) to several strips of the sweep kernel, 16 .. 128 disparities (both sweep kernels), negative / positive minDisparity, window,
+    uniqueness, disp12MaxDiff, preFilterCap, P1 / P2 scales, speckle window; textured planes at random disparities + noise, or white noise (smooth = 1).
+    minDisparity >= 2 is NOT drawn: there OpenCV 2.4's calcPixelCostBT reads its half-sample interval buffers outside the range it filled (found by this test's first
+    run; DESIGN.md s.2, SGBM row) -- the oracle restates those reads literally, the GPU and tests/golden/pyref.py use the intervals of the actual pixels
+    (test_sgbm_positive_min_disparity_is_the_clean_definition pins that); the reference sets minDisparity = 0 (/root/reference/src/stereo.cpp:19)"""
+    from semantic_slam_mapping_amd.api import SsmError
+    if h <= sad or w <= sad:
+        return
+    msg = log_case("sgbm", seed=seed, h=h, w=w, nd=nd, sad=sad, min_d=min_d, uniq=uniq, disp12=disp12, cap=cap, p_scale=p_scale, spw=spw, smooth=smooth, planes=planes, noise=noise)
+    rng = np.random.default_rng(seed)
+    tex = _texture(rng, h, w + 2 * nd + 40, smooth)
+    dmap = np.zeros((h, w), np.int32)
+    for _ in range(planes):
+        y0, y1 = sorted(rng.integers(0, h + 1, 2)); x0, x1 = sorted(rng.integers(0, w + 1, 2))
+        dmap[y0:y1, x0:x1] = rng.integers(0, nd)
+    right = tex[:, nd + 20:nd + 20 + w].copy()
+    xs = np.arange(w)[None, :] - dmap - min_d + nd + 20
+    left = np.take_along_axis(tex, np.clip(xs, 0, tex.shape[1] - 1), axis=1)
+    if noise:
+        left = np.clip(left.astype(np.int32) + rng.integers(-noise, noise + 1, left.shape), 0, 255).astype(np.uint8)
+    p1, p2 = 4 * sad * sad // p_scale + 1, 32 * sad * sad // p_scale + 2
+    po = oracle.sgbm_params(num_disp=nd, sad=sad, min_disp=min_d, uniqueness=uniq, speckle_window=spw, speckle_range=2, disp12=disp12, prefilter_cap=cap, p1=p1, p2=p2)
+    pg = ctx.sgbm_params(minDisparity=min_d, numberOfDisparities=nd, SADWindowSize=sad, P1=p1, P2=p2, disp12MaxDiff=disp12, preFilterCap=cap, uniquenessRatio=uniq,
+                         speckleWindowSize=spw, speckleRange=2)
+    assert np.array_equal(po, pg), msg
+    try:
+        raw_g = ctx.sgbm(left, right, pg, raw=True); full_g = ctx.sgbm(left, right, pg)
+    except SsmError as e:                                     # a window too wide for the streaming cost kernel at this D is refused (documented), never wrong
+        assert e.code == -1, msg + f": {e}"
+        return
+    raw_o = oracle.sgbm(left, right, po, raw=True)
+    assert np.array_equal(raw_g, raw_o), msg + f": {(raw_g != raw_o).sum()} of {raw_o.size} raw disparities differ"
+    assert np.array_equal(full_g, oracle.sgbm(left, right, po)), msg + " (median / speckle stage)"
+
+
+# ---------------------------------------------------------------- the stereo quad matcher: goodFeaturesToTrack, LK, the track filter
+@settings(max_examples=int(10 * SCALE), **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), h=st.integers(48, 200), w=st.integers(64, 400), disp=st.integers(0, 20), fx=st.integers(-6, 6), fy=st.integers(-4, 4),
+       smooth=st.sampled_from([1, 3, 5, 9]), mc=st.sampled_from([50, 300, 1000]), q=st.sampled_from([0.01, 0.04, 0.2]), md=st.sampled_from([1.0, 3.0, 8.0, 15.0]))
+def test_fuzz_quad_matcher(ctx, oracle, seed, h, w, disp, fx, fy, smooth, mc, q, md):
+    """QuadFeatureMatch (/root/reference/src/quadmatcher.cpp:219-362,388-417,548-664,420-503): cv::goodFeaturesToTrack with drawn (maxCorners, quality, minDistance) on drawn
+    image sizes and textures, pyramidal LK on a stereo / temporal shift, and the whole circular match"""
+    msg = log_case("quad", seed=seed, h=h, w=w, disp=disp, fx=fx, fy=fy, smooth=smooth, mc=mc, q=q, md=md)
+    rng = np.random.default_rng(seed)
+    big = _texture(rng, h + 16, w + 64, smooth)
+    lc = big[8:8 + h, 32:32 + w].copy(); rc = big[8:8 + h, 32 + disp:32 + disp + w].copy()
+    lp = big[8 - fy:8 - fy + h, 32 - fx:32 - fx + w].copy(); rp = big[8 - fy:8 - fy + h, 32 - fx + disp:32 - fx + disp + w].copy()
+    g = ctx.gftt(lc, mc, q, md); o = oracle.gftt(lc, mc, q, md)
+    assert len(g) == len(o) and np.array_equal(g, o), msg + f" gftt {len(g)} vs {len(o)}"
+    if len(o):
+        gp, gs, ge = ctx.lk_track(lc, rc, o); op, os_, oe = oracle.lk_track(lc, rc, o)
+        assert np.array_equal(gs, os_) and gp.tobytes() == op.tobytes() and ge.tobytes() == oe.tobytes(), msg + " lk"
+    if h >= 32 and w >= 32:
+        gq = ctx.quad_track(lc, rc, lp, rp, max_corners=1000); oq = oracle.quad_track(lc, rc, lp, rp)
+        assert len(gq) == len(oq) and gq.tobytes() == oq.tobytes(), msg + f" quad {len(gq)} vs {len(oq)}"
+
+
+# ---------------------------------------------------------------- ORB extraction on drawn image content
+@settings(max_examples=int(10 * SCALE), **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(["noise", "smooth", "rects", "flat_patch", "gradient"]), contrast=st.integers(4, 255), depth_holes=st.floats(0.0, 1.0))
+def test_fuzz_orb(ctx, oracle, seed, kind, contrast, depth_holes):
+    """OrbFeature::detectFeatures (/root/reference/include/orb.h:32-53): image content the synthetic stream never shows -- white noise (every cell full of candidates), low
+    contrast (the minThFAST retry everywhere), rectangles (exact ties along edges), one textured patch in a flat image (almost empty quad-tree), a ramp -- and depth maps with
+    a drawn fraction of holes (project2dTo3d's (0, 0, 0) sentinel)"""
+    msg = log_case("orb", seed=seed, kind=kind, contrast=contrast, depth_holes=round(depth_holes, 3))
+    rng = np.random.default_rng(seed)
+    H, W = 480, 640
+    if kind == "noise":
+        g = rng.integers(0, contrast + 1, (H, W)).astype(np.uint8)
+    elif kind == "smooth":
+        g = (_texture(rng, H, W, 5).astype(np.int32) * contrast // 255).astype(np.uint8)
+    elif kind == "rects":
+        g = np.full((H, W), 128 - contrast // 2, np.int32)
+        for _ in range(300):
+            y, x = rng.integers(0, H - 4), rng.integers(0, W - 4); hh, ww = rng.integers(4, 40, 2)
+            g[y:y + hh, x:x + ww] = rng.integers(0, contrast + 1)
+        g = np.clip(g, 0, 255).astype(np.uint8)
+    elif kind == "flat_patch":
+        g = np.full((H, W), 90, np.uint8); y, x = rng.integers(30, H - 110), rng.integers(30, W - 130)
+        g[y:y + 80, x:x + 100] = _texture(rng, 80, 100, 3)
+    else:
+        g = ((np.arange(W)[None, :] * contrast // W + np.arange(H)[:, None] // 7) % 256).astype(np.uint8) + (rng.integers(0, 3, (H, W))).astype(np.uint8)
+    bgr = np.stack([g, g, g], -1)
+    dep = rng.integers(200, 8000, (H, W)).astype(np.uint16); dep[rng.random((H, W)) < depth_holes] = 0
+    k, d, p = ctx.detect_features(bgr, dep)
+    ok, od = oracle.orb_extract(oracle.bgr2gray(bgr), nfeatures=1000)
+    assert len(k) == len(ok) and same_struct(k, ok) and np.array_equal(d, od), msg + f" ({len(k)} vs {len(ok)} keypoints)"
+    # positions: project2dTo3d at the truncated pixel (include/orb.h:50, include/rgbdframe.h:63-75)
+    u = k["x"].astype(np.int32); v = k["y"].astype(np.int32); dd = dep[v, u].astype(np.float64)
+    z = (dd / CAM[4]).astype(np.float32)
+    x = ((u - CAM[0]) * z.astype(np.float64) / CAM[2]).astype(np.float32); y = ((v - CAM[1]) * z.astype(np.float64) / CAM[3]).astype(np.float32)
+    ref = np.stack([x, y, z], 1); ref[dd == 0] = 0
+    assert np.array_equal(p, ref), msg + " positions"
+
+
+def test_sgbm_positive_min_disparity_is_the_clean_definition(ctx, oracle):
+    """minDisparity >= 2: OpenCV 2.4 fills the right image's half-sample intervals for reversed indices [0, width - minD) only, but its disparity loop reaches index
+    width - 2, i.e. right-image columns 1 .. minD - 1 take their interval from whatever lies behind the filled range (modules/calib3d/src/stereosgbm.cpp,
+    calcPixelCostBT: `maxX2 = min(maxX1 - minD, width)` against `buffer[width - x - 1 + d]`).  oracle/sgbm.c restates those reads literally; the GPU path and the independent
+    python restatement compute the interval of the pixel that is actually compared.  They agree everywhere except where such a column enters the cost, the reference's
+    own configuration (minDisparity = 0) is not affected"""
+    sys_path = __import__("sys").path; sys_path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import pyref
+    rng = np.random.default_rng(0)
+    h, w, nd, sad = 14, 145, 32, 3
+    tex = _texture(rng, h, w + 2 * nd + 40, 3)
+    right = tex[:, nd + 20:nd + 20 + w].copy(); left = tex[:, 20 + 6:20 + 6 + w].copy()       # a uniform disparity of nd - 6 = 26, inside [16, 48)
+    for min_d in (16, 2):
+        pg = ctx.sgbm_params(minDisparity=min_d, numberOfDisparities=nd, SADWindowSize=sad, uniquenessRatio=0, speckleWindowSize=0)
+        g = ctx.sgbm(left, right, pg, raw=True)
+        ref = pyref.sgbm_raw(left, right, minD=min_d, ndisp=nd, SAD=sad, uniquenessRatio=0)
+        assert np.array_equal(g, ref), f"minDisparity {min_d}: {(g != ref).sum()} of {g.size} differ from the clean definition"
+        o = oracle.sgbm(left, right, oracle.sgbm_params(num_disp=nd, sad=sad, min_disp=min_d, uniqueness=0, speckle_window=0), raw=True)
+        diff = np.argwhere(g != o)
+        assert len(diff) < 0.02 * g.size                       # OpenCV's stale intervals touch a handful of pixels (none at all on many images)
+
