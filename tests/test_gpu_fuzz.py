@@ -408,3 +408,43 @@ def test_fuzz_window_match(ctx, oracle, seed, n1, n2, sw, sh, thr, dup):
     k1, d1 = make(n1); k2, d2 = make(n2)
     g = ctx.window_match(k1, d1, k2, d2, sw, sh, thr); o = oracle.window_match(k1, d1, k2, d2, sw, sh, thr)
     assert same_struct(g, o), msg
+
+
+# ---------------------------------------------------------------- SegNet building blocks on drawn shapes (integer data: fp16 storage + fp32 accumulation are exact)
+@settings(max_examples=int(20 * SCALE), **COMMON)
+@given(seed=st.integers(0, 2**31 - 1), layer=st.integers(0, 25), h=st.integers(2, 70), w=st.integers(2, 70), amp=st.sampled_from([1, 2, 4]))
+def test_fuzz_segnet_ops(ctx, seed, layer, h, w, amp):
+    """Classifier's network (/root/reference/src/segnet.cpp:87-108 runs it as one opaque Caffe forward): every conv3x3 + scale / shift (+ ReLU) layer shape of the net on a drawn
+    image size against torch-CPU fp32, bit for bit on integer data (odd sizes: partial 16 x 32 pixel tiles, one-pixel images' worth of halo); the fused conv + max-pool epilogue and
+    the fused un-pool-on-load against the separate kernels; the pooling itself (ceil mode, first maximum) against torch"""
+    import torch
+    import torch.nn.functional as F
+    msg = log_case("segnet_ops", seed=seed, layer=layer, h=h, w=w, amp=amp)
+    rng = np.random.default_rng(seed)
+    cin, cout, _, _ = ctx.segnet_layers()[layer]
+    wt = rng.integers(-1, 2, (cout, cin, 3, 3)).astype(np.float32)
+    sc = (2.0 ** rng.integers(-7, -4, cout)).astype(np.float32); sh = rng.integers(-3, 4, cout).astype(np.float32)
+    ctx.segnet_set_layer(layer, wt, sc, sh)
+    x = rng.integers(-amp, amp + 1, (h, w, cin)).astype(np.float32)
+    xp = np.zeros((h, w, (cin + 15) // 16 * 16), np.float16); xp[:, :, :cin] = x
+    got = ctx.segnet_debug_conv(layer, xp)
+    y = F.conv2d(torch.from_numpy(x.transpose(2, 0, 1))[None], torch.from_numpy(wt), padding=1)[0].numpy() * sc[:, None, None] + sh[:, None, None]
+    if layer != 25:
+        y = np.maximum(y, 0)
+    assert np.array_equal(got, y.transpose(1, 2, 0).astype(np.float16)), msg + " conv"
+    if layer in (1, 3, 6, 9, 12):                                 # the encoder's conv + pool pairs: fused epilogue == conv -> pool, and pool == torch (ceil mode, first maximum)
+        p_ref, c_ref = ctx.segnet_debug_pool(got)
+        p, c = ctx.segnet_debug_conv_pool(layer, xp)
+        assert np.array_equal(p, p_ref) and np.array_equal(c, c_ref), msg + " conv+pool"
+        tp, ti = F.max_pool2d(torch.from_numpy(got.astype(np.float32).transpose(2, 0, 1))[None], 2, 2, ceil_mode=True, return_indices=True)
+        assert np.array_equal(p_ref.astype(np.float32), tp[0].numpy().transpose(1, 2, 0)), msg + " pool values"
+        ti = ti[0].numpy().transpose(1, 2, 0)                     # (the arg-max code layout is the kernels' own: the un-pool round trip below is the contract)
+        up = ctx.segnet_debug_unpool(p_ref, c_ref, h, w)
+        tu = F.max_unpool2d(tp, torch.from_numpy(ti.transpose(2, 0, 1))[None], 2, 2, output_size=(h, w))[0].numpy().transpose(1, 2, 0)
+        assert np.array_equal(up.astype(np.float32), tu), msg + " unpool round trip"
+    if layer in (13, 16, 19, 22, 24) and h >= 2 and w >= 2:       # the decoder's un-pool -> conv pairs
+        full = rng.integers(-2, 6, (h, w, xp.shape[2])).astype(np.float16); full[:, :, cin:] = 0
+        pooled, code = ctx.segnet_debug_pool(full)
+        ref = ctx.segnet_debug_conv(layer, ctx.segnet_debug_unpool(pooled, code, h, w))
+        out = ctx.segnet_debug_unpool_conv(layer, pooled, code, h, w)
+        assert np.array_equal(out, ref), msg + " unpool+conv"
