@@ -172,3 +172,15 @@ def test_stage_selection_and_errors(oracle):
             c.dev_free(dl)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_sweep_strip_handoffs_soak():
+    """scripts/sgbm_soak.py: the whole batched stereo path (quad matcher, VO and the second SGBM stream running beside the sweep) over 128 KITTI-size pairs, four rounds per
+    sweep kernel: every disparity image must hash to what the four-volume form of round 3 (no strips, no hand-offs) gives -- a stale or torn granule between two strips of a
+    frame (kernels_sgbm.hip: sc1 tagged granules, 9 seams x 376 rows x 2 directions per frame) would change a disparity somewhere"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "sgbm_soak.py"), "4", "128"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode == 0 and r.stdout.count("4 rounds identical to the four-volume form") == 2
