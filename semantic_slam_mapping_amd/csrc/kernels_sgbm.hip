@@ -858,34 +858,24 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
         // ---- what a strip hands on never depends on what it receives in the same row (L1 flows right, L3 flows left): the edge columns compute and publish
         // their outgoing state BEFORE the incoming mailbox is polled (sgbm_sweep)
         const bool outL = g == 0, outR = g >= TX - 1;
-        if (!outL) {                                              // L1 from the left neighbour in LDS
+        // (the steps run for the whole wave -- DPP -- in place on L1 / L3; the strip's outermost columns step a placeholder first and are redone behind the poll)
 #pragma unroll
-            for (int j = 0; j < K; j++) L1[j] = nl[j];
-            m1 = (int)nl[K];
-        }
-        if (!outR) {
-#pragma unroll
-            for (int j = 0; j < K; j++) L3[j] = nr[j];
-            m3 = (int)nr[K];
-        }
-        // (the steps run for the whole wave -- DPP -- with the outermost columns' missing direction done after the poll)
-        uint32_t T1[K], T3[K]; int t1 = m1, t3 = m3;
-#pragma unroll
-        for (int j = 0; j < K; j++) { T1[j] = L1[j]; T3[j] = L3[j]; }
-        sg_step8<K>(T1, t1, V[0], P1P1, P2, first, last);
-        sg_step8<K>(T3, t3, V[0], P1P1, P2, first, last);
+        for (int j = 0; j < K; j++) { L1[j] = nl[j]; L3[j] = nr[j]; }
+        m1 = (int)nl[K]; m3 = (int)nr[K];
+        sg_step8<K>(L1, m1, V[0], P1P1, P2, first, last);
+        sg_step8<K>(L3, m3, V[0], P1P1, P2, first, last);
         sg_step8<K>(L2, m2, V[0], P1P1, P2, first, last);
         if (edgeR) {                                              // its L1 came from LDS: final
             sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
 #pragma unroll
-            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | T1[j], SG_RLX_AGENT);
-            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)t1, SG_RLX_AGENT);
+            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L1[j], SG_RLX_AGENT);
+            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m1, SG_RLX_AGENT);
         }
         if (edgeL) {
             sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
 #pragma unroll
-            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | T3[j], SG_RLX_AGENT);
-            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)t3, SG_RLX_AGENT);
+            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L3[j], SG_RLX_AGENT);
+            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3, SG_RLX_AGENT);
         }
         // ---- the outermost columns: the direction that comes from outside the strip
         const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
@@ -906,19 +896,14 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
                 }
             }
             if (!(okl && okr)) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
-            // redo the two steps for the wave with the received states in the outermost columns (the other columns of the wave repeat theirs: same values)
-            uint32_t U1[K], U3[K]; int u1 = outL ? (int)nl[K] : m1, u3 = outR ? (int)nr[K] : m3;
+            // redo the two steps for the wave from the states of row y - 1 (nl / nr still hold them: LDS for the inner columns, the mailbox / the zeroed border for the
+            // outermost ones; the inner columns repeat their result)
 #pragma unroll
-            for (int j = 0; j < K; j++) { U1[j] = outL ? nl[j] : L1[j]; U3[j] = outR ? nr[j] : L3[j]; }
-            sg_step8<K>(U1, u1, V[0], P1P1, P2, first, last);
-            sg_step8<K>(U3, u3, V[0], P1P1, P2, first, last);
-#pragma unroll
-            for (int j = 0; j < K; j++) { T1[j] = U1[j]; T3[j] = U3[j]; }
-            t1 = u1; t3 = u3;
+            for (int j = 0; j < K; j++) { L1[j] = nl[j]; L3[j] = nr[j]; }
+            m1 = (int)nl[K]; m3 = (int)nr[K];
+            sg_step8<K>(L1, m1, V[0], P1P1, P2, first, last);
+            sg_step8<K>(L3, m3, V[0], P1P1, P2, first, last);
         }
-#pragma unroll
-        for (int j = 0; j < K; j++) { L1[j] = T1[j]; L3[j] = T3[j]; }
-        m1 = t1; m3 = t3;
         if (!live) {                                              // a column outside the strip / image: its neighbours see the zeroed border
 #pragma unroll
             for (int j = 0; j < K; j++) L1[j] = L2[j] = L3[j] = 0u;
