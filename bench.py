@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--pose-stream", default="rigid", choices=["rigid", "synthetic"], help="--solve-poses: 'rigid' = frame 0 of the stream seen by a panning camera (a "
                     "fronto-parallel plane at 2 m, 2 x 1 px per frame: every frame tracks); 'synthetic' = the configs[1] stream itself (its depth pattern does not move "
                     "with the texture, so PnP loses track often: exercises LOST / lostRecover)")
-    ap.add_argument("--pnp-device", type=int, default=0, help="--solve-poses: 1 = the pose chain on the GPU (one block), 0 = on one host core; same bits")
+    ap.add_argument("--pnp-device", type=int, default=0, help="--solve-poses: 1 = the pose chain on the GPU (a cluster of eight blocks; one block per chain with --pose-threads > 1), 0 = on one host core; same bits")
     ap.add_argument("--pose-threads", type=int, default=1, help="--solve-poses with the rigid stream: its independent 20-frame sequences are tracked by this many trackers from as many host threads (device chains on their own streams: one CU each)")
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
@@ -568,7 +568,7 @@ def main():
             if args.pose_stream == "rigid" and NT > 1:
                 dvf, hsf = sum(a for a, _ in pose_stats), sum(b for _, b in pose_stats)
             dvf, hsf = dvf // (rep + 1), hsf // (rep + 1)                # the counters run over both passes
-            solve_info = {"frames": PF, "stream": args.pose_stream, "frames_per_s": round(PF / (t4 - t1), 1), "frames_on_device_chain": dvf, "frames_on_host_path": hsf, "pnp_on": "gpu (one block)" if args.pnp_device else "host (1 core)", "sequences_in_flight": (NT if args.pose_stream == "rigid" else 1),
+            solve_info = {"frames": PF, "stream": args.pose_stream, "frames_per_s": round(PF / (t4 - t1), 1), "frames_on_device_chain": dvf, "frames_on_host_path": hsf, "pnp_on": ("gpu (one block per chain)" if (args.pose_stream == "rigid" and NT > 1) else "gpu (%s blocks per chain)" % os.environ.get("SSM_PNP_BLOCKS", "8")) if args.pnp_device else "host (1 core)", "sequences_in_flight": (NT if args.pose_stream == "rigid" else 1),
                           "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
                           "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
                           "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}

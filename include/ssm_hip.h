@@ -210,7 +210,7 @@ typedef struct {
     int32_t max_lost_frame;   /* tracker_max_lost_frame (include/track.h:69; 10) */
     int32_t ref_frames;       /* tracker_ref_frames (:70; 5) -- must equal the context's */
     int32_t pnp_min_inliers;  /* pnp_min_inliers (include/pnp.h; 10): only PnPSolver's unused return value depends on it */
-    int32_t use_device;       /* 1: solve the pose chain of regular frames on the GPU (one block, kernels_pnp.hip); 0: on the host.  Same bits. */
+    int32_t use_device;       /* 1: solve the pose chain of regular frames on the GPU (kernels_pnp.hip: a cluster of eight blocks per chain, one block for an own_stream tracker; SSM_PNP_BLOCKS overrides); 0: on the host.  Same bits. */
     double  first_pose[16];   /* T_f_w the first frame arrives with (initFirstFrame leaves it alone), column-major */
     int32_t own_stream;       /* 1: the device chain of this tracker runs on a stream of its own (behind what the context's stream holds at the time of the
                                  call), so that trackers of independent sequences, driven from different host threads, solve side by side -- a chain is one

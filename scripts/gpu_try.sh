@@ -34,6 +34,13 @@ case "$1" in
     (time timeout 900 python3 -m pytest tests/test_gpu_fuzz.py -x -q -m gpu) 2>&1 | tail -25
     wc -l $O/fuzz_cases.log
     ;;
+  pnp)
+    for G in 4 1 2 8; do
+      echo "== blocks $G"; SSM_PNP_BLOCKS=$G timeout 600 python3 -m pytest tests/test_gpu_pnp.py tests/test_gpu_tracker.py -x -q -m gpu 2>&1 | tail -3
+      SSM_PNP_BLOCKS=$G timeout 300 python3 bench.py --solve-poses --pose-frames 400 --pnp-device 1 --steps 3 --warmup 1 --no-cpu 2>$O/pnp_g$G.err | tee $O/pnp_g$G.json | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); si=[v for v in (d.get('solve_poses'), d.get('config',{}).get('solve_poses')) if v]; print(d['value'], si[0]['frames_per_s'] if si else None, si[0]['ms'] if si else d.keys())"
+    done
+    SSM_FUZZ_SCALE=1 timeout 600 python3 -m pytest tests/test_gpu_fuzz.py -x -q -m gpu -k "pnp or stereo_vo" 2>&1 | tail -3
+    ;;
   alltests)
     timeout 2400 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -15
     ;;

@@ -47,6 +47,9 @@ struct PcShared {
     double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
     int cont, term;               // loop controls of the Levenberg iteration, decided by wave 0
+    // the cluster form (round 4, gridDim.x = G > 1 blocks per chain): this block evaluates the edges of lanes [b 1024 / G, (b + 1) 1024 / G) only and the G blocks
+    // trade their groups' partial sums through tagged granules in global memory (pc_lane_sum)
+    unsigned long long* xmb; unsigned* xfail; unsigned xseq;
 };
 // exclusive position of `flag` among the block's threads in thread order, and the block total
 __device__ __forceinline__ int pc_scan(bool flag, PcShared& sh, int& total)
@@ -91,7 +94,7 @@ __device__ __forceinline__ void pc_rs_step(double* a, bool up)
 // bit k selects (28 -> 14 -> 7 (+ 1 pad) -> 4 -> 2 -> 1) -- 29 additions and 31 exchanges per lane instead of 168 and 168 (the butterfly was 45 % of the
 // fused pass's instructions and kept the LDS pipe busy with 336 ds_bpermute per wave).  Lane 0 of each wave (one value) / the lane that ends up with value v
 // publishes the group sum, threads 0 .. NV-1 add the 16 group sums in group order.
-template <int NV, int OFF>
+template <int NV, int OFF, bool CL>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -117,35 +120,76 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         if (lane < 32 && sub < 7) sh.red[wv][OFF + v] = t;
     }
     __syncthreads();
+    if constexpr (CL) {
+        // every block holds the group sums of its own waves; a sum is published as two 8-byte {pass tag, 32 bits} granules (one agent-scope store each: the data is the
+        // flag, cdna_hip_programming.md G16 R2) and every block polls all sixteen groups' granules, so that the ordered sum below sees the same sixteen numbers everywhere.
+        // Four ring slots by pass number; a block can be at most one pass ahead of another (it needs everybody's sums to finish a pass).
+        const int gpb = NGROUP / (int)gridDim.x, g = threadIdx.x >> 5, v = threadIdx.x & 31;
+        const unsigned seq = sh.xseq; const unsigned long long tag = (unsigned long long)(seq + 1) << 32;
+        typedef __attribute__((address_space(1))) unsigned long long gu64;          // (global_load / global_store, not flat: the ring is device memory)
+        gu64* slot = (gu64*)sh.xmb + (size_t)(seq & 3u) * NGROUP * 32 * 2;
+        if (g < gpb && v < NV) {
+            const int gg = (int)blockIdx.x * gpb + g;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + v]);
+            __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (g < NGROUP && v < NV) {
+            // two polls in flight, half a round trip apart (a poll that leaves just before the granule lands costs a whole round trip of ~1.2 k clocks otherwise):
+            // the second leaves ~600 clocks behind the first, after that each is re-issued when its answer is in, which keeps the spacing
+            const gu64* q = slot + (size_t)(g * 32 + v) * 2;
+            unsigned long long lo = 0, hi = 0; bool ok = false;
+            unsigned long long lo_a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi_a = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(9);
+            for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+                const unsigned long long lo_b = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi_b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((lo_a >> 32) == (tag >> 32) && (hi_a >> 32) == (tag >> 32)) { lo = lo_a; hi = hi_a; ok = true; break; }
+                lo_a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hi_a = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((lo_b >> 32) == (tag >> 32) && (hi_b >> 32) == (tag >> 32)) { lo = lo_b; hi = hi_b; ok = true; break; }
+                if ((spins & 1023u) == 1023u && __hip_atomic_load(sh.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            }
+            if (!ok) __hip_atomic_store(sh.xfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (bounded: the chain then reports an invalid range instead of hanging)
+            sh.red[g][OFF + v] = __longlong_as_double((long long)((lo & 0xFFFFFFFFull) | (hi << 32)));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh.xseq = seq + 1;
+    }
     if (threadIdx.x < NV) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
     __syncthreads();
 }
+// the lanes whose edges this block evaluates (all of them in the one-block form)
+template <bool CL> __device__ __forceinline__ bool pc_mine() { if constexpr (CL) return (int)(threadIdx.x / (PC_T / gridDim.x)) == (int)blockIdx.x; else return true; }
 // the robustified chi2 of the active edges at P (leaves every active edge's error in the edge) -> sh.tot[NACC] (H and b in sh.tot[0 .. 26] stay)
+template <bool CL>
 __device__ __forceinline__ void pc_chi(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[1] = {0.0};
+    if (pc_mine<CL>())
     for (int i = threadIdx.x; i < ne; i += PC_T) {
         const LEdge l = L[i];
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[0] += edge_rho(e, P, k, delta); err[i] = make_double2(e.e0, e.e1); }
     }
-    pc_lane_sum<1, NACC>(acc, sh);
+    pc_lane_sum<1, NACC, CL>(acc, sh);
 }
 // chi2 and the normal equations at P in ONE pass over the edges (the host evaluates active_chi2 and build_system one after the other at the same
 // estimate: the same per-edge values, the same lane sums) -> sh.tot[0 .. 26] = H (lower triangle) and b, sh.tot[27] = chi2
+template <bool CL>
 __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[NACC + 1];
 #pragma unroll
     for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
+    if (pc_mine<CL>())
     for (int i = threadIdx.x; i < ne; i += PC_T) {
         const LEdge l = L[i];
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
     }
-    pc_lane_sum<NACC + 1, 0>(acc, sh);
+    pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
 }
 // lm_optimize of pnp_core.h.  The passes over the edges are the whole block's; the 6 x 6 algebra between them (L D L^T, exp map, Levenberg's bookkeeping)
 // is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
 // controls through LDS.
+template <bool CL>
 __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne, const Camera& k, double delta, int iterations, PcShared& sh)
 {
     const Pose& P = sh.P;                                                        // in / out: the estimate lives in LDS (uniform reads; 24 registers saved)
@@ -158,7 +202,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
     const double* Hl = sh.tot; const double* b = sh.tot + 21;                 // the system stays in LDS over the trials (registers are short here)
     PROF_T0
     for (int it = 0; it < iterations; it++) {
-        pc_chi_build(L, err, ne, P, k, delta, sh);
+        pc_chi_build<CL>(L, err, ne, P, k, delta, sh);
         PROF(1) PROF_CNT(6)
         if (w0) {
             chi = sh.tot[NACC];
@@ -175,7 +219,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
             }
             __syncthreads();
             PROF(2)
-            pc_chi(L, err, ne, P, k, delta, sh);
+            pc_chi<CL>(L, err, ne, P, k, delta, sh);
             PROF(3) PROF_CNT(7)
             if (w0) {
                 const double chi_new = sh.tot[NACC];
@@ -194,9 +238,10 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
         __syncthreads();                                                         // (sh.cont / sh.term are rewritten by the next iteration)
         if (term) break;
     }
-    pc_chi(L, err, ne, P, k, delta, sh);
+    pc_chi<CL>(L, err, ne, P, k, delta, sh);
 }
 // ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
+template <bool CL>
 __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, LEdge* L, double2* err, uint8_t* dec, PcShared& sh)
 {
     const double delta = (double)(float)sqrt(5.991);
@@ -218,7 +263,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         __syncthreads();
         if (threadIdx.x == 0) sh.P = sh.init;
         __syncthreads();
-        pc_optimize(L, err, ne, cam, delta, 10, sh);
+        pc_optimize<CL>(L, err, ne, cam, delta, 10, sh);
         // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
         // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
@@ -227,7 +272,10 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
             LEdge l = L[i];
             Edge e = pc_expand(l);
             const double2 er = err[i]; e.e0 = er.x; e.e1 = er.y;
-            if (inl[e.id]) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); }
+            // (an ACTIVE edge's stored error is edge_error at this P already -- lm_optimize ends with a chi2 pass over the active edges -- so recomputing it changes
+            // nothing in the one-block form; in the cluster form only the block that owns the edge's lane has stored it)
+            if constexpr (CL) { if (inl[e.id] || !(l.meta & LE_LEVEL)) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); } }
+            else { if (inl[e.id]) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); } }
             const bool out = edge_chi2(e) > 5.991;
             l.meta = (l.meta & ~LE_LEVEL) | (out ? LE_LEVEL : 0u);
             if (it == 2) l.meta &= ~LE_ROBUST;
@@ -260,13 +308,22 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
     return mm;
 }
 
+template <bool CL>
 __global__ void __launch_bounds__(PC_T)
 pnp_chain_kernel(PnpChainArgs a)
 {
     __shared__ PcShared sh;
     extern __shared__ __align__(16) unsigned char pc_dyn[];
+    // the cluster form: G blocks run this SAME program on the same inputs -- state, scratch and results are private to a block (slice blockIdx.x of every array), so
+    // the blocks agree by construction; they differ only in which lanes' edges they evaluate in a pass, and trade the partial sums (pc_lane_sum)
+    if constexpr (CL) {
+        const size_t mc = (size_t)a.R * a.cap, b = blockIdx.x;
+        a.state += b; a.img += b * mc * 2; a.obj += b * mc * 3; a.inl += b * mc; a.dec += b * mc; a.err += b * mc;
+        a.ledges = reinterpret_cast<LEdge*>(reinterpret_cast<unsigned char*>(a.ledges) + b * mc * sizeof(LEdge)); }
+    const bool lead = !CL || blockIdx.x == 0;                                          // its copies of pose_out / info_out are the call's results
     LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;    // (a generic pointer: the passes are the same code for both)
     const int tid = threadIdx.x;
+    if (CL && tid == 0) { sh.xmb = a.xchg; sh.xfail = a.xfail; sh.xseq = 0; }
     // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
     if (tid == 0) for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; }
 #ifdef SSM_PNP_PROF
@@ -313,14 +370,14 @@ pnp_chain_kernel(PnpChainArgs a)
         if (ok) {
             if (tid == 0) iso_mul(sh.speed, sh.last, sh.T);                     // T = speed * lastPose
             __syncthreads();
-            info.n_inliers = pc_solve(a.img, a.obj, nc, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
+            info.n_inliers = pc_solve<CL>(a.img, a.obj, nc, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
             ok = info.n_inliers >= 15;
             PROF(5)
         }
         if (!ok) {
             cnt_lost++;
             if (cnt_lost > a.max_lost) info.state = 2;
-            if (tid == 0) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.Tpred[k]; a.info_out[f] = info; }
+            if (tid == 0 && lead) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.Tpred[k]; a.info_out[f] = info; }
             stopped = f + 1;                                                    // the deque now trails behind the match-table window: the host path goes on
             break;
         }
@@ -331,8 +388,7 @@ pnp_chain_kernel(PnpChainArgs a)
             double linv[16], sp[16]; iso_inverse(sh.last, linv);
             iso_mul(sh.T, linv, sp);                                            // speed = T * lastPose.inverse()
             for (int k = 0; k < 16; k++) { sh.speed[k] = sp[k]; sh.last[k] = sh.T[k]; }
-            for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.T[k];
-            a.info_out[f] = info;
+            if (lead) { for (int k = 0; k < 16; k++) a.pose_out[(size_t)f * 16 + k] = sh.T[k]; a.info_out[f] = info; }
             // refFrames.push_back(currentFrame); pop_front beyond tracker_ref_frames
             if (nref == a.R) { for (int r = 1; r < nref; r++) { a.state->ref_idx[r - 1] = a.state->ref_idx[r]; for (int k = 0; k < 16; k++) a.state->ref_pose[r - 1][k] = a.state->ref_pose[r][k]; } }
             const int slot = nref == a.R ? nref - 1 : nref;
@@ -347,6 +403,7 @@ pnp_chain_kernel(PnpChainArgs a)
     if (tid == 0) {
         for (int k = 0; k < 16; k++) { a.state->speed[k] = sh.speed[k]; a.state->last_pose[k] = sh.last[k]; }
         a.state->nref = nref; a.state->cnt_lost = cnt_lost; a.state->stopped_at = stopped;
+        if (CL && __hip_atomic_load(a.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) a.state->stopped_at = -1;     // an exchange timed out: the host rejects the range
 #ifdef SSM_PNP_PROF
         for (int k = 0; k < 8; k++) a.state->prof[k] = sh.prof[k];
 #endif
@@ -361,7 +418,7 @@ pnp_solve_kernel(PnpSolveArgs a)
     LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;
     if (threadIdx.x < 16) sh.T[threadIdx.x] = a.T[threadIdx.x];
     __syncthreads();
-    const int m = pc_solve(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
+    const int m = pc_solve<false>(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
     __syncthreads();
     if (threadIdx.x < 16) a.T[threadIdx.x] = sh.T[threadIdx.x];
     if (threadIdx.x == 0) *a.n_inliers = m;
@@ -393,11 +450,17 @@ hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
     return hipGetLastError();
 }
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
+size_t k_pnp_xchg_bytes(void) { return (size_t)4 * NGROUP * 32 * 2 * 8 + 64; }      // four ring slots x 16 groups x 32 values x two granules, + the time-out word
 hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
     PnpChainArgs a = a_in; size_t dyn;
-    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_chain_kernel));
+    const int G = a.blocks > 0 ? a.blocks : 1;
+    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, G > 1 ? reinterpret_cast<const void*>(pnp_chain_kernel<true>) : reinterpret_cast<const void*>(pnp_chain_kernel<false>));
     if (e != hipSuccess) return e;
-    pnp_chain_kernel<<<1, PC_T, dyn, s>>>(a);
+    if (G > 1) {                                               // the exchange ring and the time-out word: zero before every launch (tags count passes within a launch)
+        e = hipMemsetAsync(a.xchg, 0, k_pnp_xchg_bytes(), s);
+        if (e != hipSuccess) return e;
+        pnp_chain_kernel<true><<<G, PC_T, dyn, s>>>(a);
+    } else pnp_chain_kernel<false><<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();
 }

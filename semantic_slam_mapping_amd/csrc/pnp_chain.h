@@ -22,7 +22,11 @@ struct PnpChainArgs {
     float *img, *obj; uint8_t *inl, *dec;                                                              // scratch for R * cap correspondences
     struct LEdge* ledges; double2* err;              // the edge list when it does not fit in LDS (k_pnp_edge_bytes() each), and every edge's error
     int edges_in_lds;                                // set by k_pnp_chain
+    // the cluster form: `blocks` (1, 2, 4 or 8) blocks run the chain together; state, img / obj / inl / dec / ledges / err hold `blocks` slices (slice b is block b's
+    // private copy; the host fills every state slice and reads slice 0); xchg: k_pnp_xchg_bytes() of device memory, xfail = the word behind its ring
+    int blocks; unsigned long long* xchg; unsigned* xfail;
 };
+size_t k_pnp_xchg_bytes(void);
 hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s);
 // one solvePnP on the device (ssm_pnp_solve): n correspondences, T (16 doubles, device) in / out
 struct PnpSolveArgs {

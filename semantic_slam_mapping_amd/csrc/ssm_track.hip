@@ -28,6 +28,7 @@ struct ssm_tracker {
     // device chain (use_device): scratch + the state block, allocated at first use
     PnpState* d_state = nullptr; double* d_pose = nullptr; ssm_track_info* d_info = nullptr; float *d_img = nullptr, *d_obj = nullptr, *d_hist = nullptr;
     uint8_t *d_inl = nullptr, *d_dec = nullptr; void* d_edges = nullptr; double2* d_err = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
+    unsigned long long* d_xchg = nullptr; int blocks = 1;      // the cluster form of the device chain (SSM_PNP_BLOCKS, kernels_pnp.hip): blocks per chain, their exchange ring
     long device_frames = 0, host_frames = 0;
     hipStream_t own = nullptr; hipEvent_t ev = nullptr;      // own_stream: the chain's stream and the event that orders it behind the context's stream
 };
@@ -50,6 +51,10 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
     ssm_config cfg; ssm_internal_get_config(ctx, &cfg);
     t->cam = cfg.camera; t->ratio = cfg.knn_match_ratio;
     if (cfg.tracker_ref_frames != p->ref_frames) { delete t; return SSM_E_INVAL; }
+    // blocks per device chain (kernels_pnp.hip, the cluster form): eight for a chain that has the GPU to itself (latency: -6.5 % per frame; four: -3.4 %); ONE for an
+    // own_stream tracker -- those exist to run many chains side by side, where a CU per chain is the efficient form and the blocks of several clusters would
+    // have to be resident together.  SSM_PNP_BLOCKS = 1 | 2 | 4 | 8 overrides (same bits in every form).
+    { const char* e = getenv("SSM_PNP_BLOCKS"); const int d = p->own_stream ? 1 : 8, g = e ? atoi(e) : d; t->blocks = (g == 1 || g == 2 || g == 4 || g == 8) ? g : d; }
     (void)hipSetDevice(ssm_internal_get_device(ctx));              // the raw HIP calls of this file act on the context's device, whatever the calling thread used last
     if (p->own_stream && (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess)) {
         if (t->own) hipStreamDestroy(t->own);
@@ -61,7 +66,8 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
 }
 static void tracker_free_device(ssm_tracker* t)
 {
-    void* p[] = { t->d_state, t->d_pose, t->d_info, t->d_img, t->d_obj, t->d_hist, t->d_inl, t->d_dec, t->d_edges, t->d_err };
+    void* p[] = { t->d_state, t->d_pose, t->d_info, t->d_img, t->d_obj, t->d_hist, t->d_inl, t->d_dec, t->d_edges, t->d_err, t->d_xchg };
+    t->d_xchg = nullptr;
     for (void* x : p) if (x) hipFree(x);
     t->d_state = nullptr; t->d_pose = nullptr; t->d_info = nullptr; t->d_img = t->d_obj = t->d_hist = nullptr; t->d_inl = t->d_dec = nullptr; t->d_edges = nullptr; t->d_err = nullptr;
     t->d_cap = t->d_R = t->d_n = 0;
@@ -90,11 +96,12 @@ static int tracker_ensure_device(ssm_tracker* t, int cap, int R, int n)
     if (t->d_state && t->d_cap == cap && t->d_R == R && t->d_n >= n) return SSM_OK;
     ssm_sync(t->ctx);
     tracker_free_device(t);
-    const size_t mc = (size_t)R * cap;
-    bool ok = hipMalloc((void**)&t->d_state, sizeof(PnpState)) == hipSuccess && hipMalloc((void**)&t->d_pose, (size_t)n * 128) == hipSuccess &&
-              hipMalloc((void**)&t->d_info, (size_t)n * sizeof(ssm_track_info)) == hipSuccess && hipMalloc((void**)&t->d_img, mc * 8) == hipSuccess &&
-              hipMalloc((void**)&t->d_obj, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_hist, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_inl, mc) == hipSuccess &&
-              hipMalloc((void**)&t->d_dec, mc) == hipSuccess && hipMalloc(&t->d_edges, mc * k_pnp_edge_bytes()) == hipSuccess && hipMalloc((void**)&t->d_err, mc * sizeof(double2)) == hipSuccess;
+    const size_t mc = (size_t)R * cap, G = (size_t)t->blocks;          // G private slices of the state and of every scratch array (the cluster form)
+    bool ok = hipMalloc((void**)&t->d_state, G * sizeof(PnpState)) == hipSuccess && hipMalloc((void**)&t->d_pose, (size_t)n * 128) == hipSuccess &&
+              hipMalloc((void**)&t->d_info, (size_t)n * sizeof(ssm_track_info)) == hipSuccess && hipMalloc((void**)&t->d_img, G * mc * 8) == hipSuccess &&
+              hipMalloc((void**)&t->d_obj, G * mc * 12) == hipSuccess && hipMalloc((void**)&t->d_hist, mc * 12) == hipSuccess && hipMalloc((void**)&t->d_inl, G * mc) == hipSuccess &&
+              hipMalloc((void**)&t->d_dec, G * mc) == hipSuccess && hipMalloc(&t->d_edges, G * mc * k_pnp_edge_bytes()) == hipSuccess && hipMalloc((void**)&t->d_err, G * mc * sizeof(double2)) == hipSuccess &&
+              hipMalloc((void**)&t->d_xchg, k_pnp_xchg_bytes()) == hipSuccess;
     if (!ok) { tracker_free_device(t); t->err = "device allocation for the pose chain failed"; return SSM_E_NOMEM; }
     t->d_cap = cap; t->d_R = R; t->d_n = n;
     return SSM_OK;
@@ -177,10 +184,12 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
                 if (idx < 0 && t->refs[r].nkp > 0)            // a frame of the previous call: its positions are no longer on the device
                     if (hipMemcpyAsync(t->d_hist + (size_t)(idx + R) * cap * 3, t->refs[r].pos3d.data(), (size_t)t->refs[r].nkp * 12, hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the reference positions failed");
             }
-            if (hipMemcpyAsync(t->d_state, &hs, sizeof(hs), hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the tracker state failed");
+            for (int b = 0; b < t->blocks; b++)
+                if (hipMemcpyAsync(t->d_state + b, &hs, sizeof(hs), hipMemcpyHostToDevice, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "upload of the tracker state failed");
             PnpChainArgs a; a.kps = seq->kps; a.pos3d = seq->pos3d; a.matches = seq->matches; a.nmatch = seq->nmatch; a.hist_pos3d = t->d_hist;
             a.cap = cap; a.R = R; a.f_begin = f; a.f_end = n; a.max_lost = t->prm.max_lost_frame; a.cam = cam;
             a.state = t->d_state; a.pose_out = t->d_pose; a.info_out = t->d_info; a.img = t->d_img; a.obj = t->d_obj; a.inl = t->d_inl; a.dec = t->d_dec; a.ledges = (LEdge*)t->d_edges; a.err = t->d_err; a.edges_in_lds = 0;
+            a.blocks = t->blocks; a.xchg = t->d_xchg; a.xfail = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(t->d_xchg) + k_pnp_xchg_bytes() - 64);
             if (k_pnp_chain(a, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain launch failed");
             if (hipMemcpyAsync(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain failed");
             const int stop = hs.stopped_at;
