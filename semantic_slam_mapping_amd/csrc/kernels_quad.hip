@@ -368,14 +368,34 @@ scharr_kernel(QuadBatch q, short2* __restrict__ der)
 // ------------------------------------------------------------------ pyramidal LK, one wave per point, all levels in one launch
 #define LKW 11
 #define LKL 4
-__device__ __forceinline__ long long wave_sum_ll(long long v)
+// Wave sums of the window's integer terms (integers: any order gives the sum).  |Ix|, |Iy| <= 16 * 255 = 4080 (Scharr) and |I|, |J - I| <= 255 * 32, so a sum of
+// 121 derivative products fits 32 bits (121 * 4080^2 < 2^31) and so does a sum of the 64 mismatch products of lanes 0 .. 31 (64 * 8160 * 4080 < 2^31); the
+// mismatch sums of the whole window can need 33 bits: two half-wave sums, added as doubles (exact).  DPP prefix sums inside the rows of 16, then row_bcast.
+#define LK_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xF, false)
+__device__ __forceinline__ int lk_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += LK_DPP(v, 0x111, 0xF); v += LK_DPP(v, 0x112, 0xF); v += LK_DPP(v, 0x114, 0xF); v += LK_DPP(v, 0x118, 0xF);
+    v += LK_DPP(v, 0x142, 0xA); v += LK_DPP(v, 0x143, 0xC);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double lk_sum_wide(int v)
+{
+    v += LK_DPP(v, 0x111, 0xF); v += LK_DPP(v, 0x112, 0xF); v += LK_DPP(v, 0x114, 0xF); v += LK_DPP(v, 0x118, 0xF);
+    v += LK_DPP(v, 0x142, 0xA);
+    return (double)__builtin_amdgcn_readlane(v, 31) + (double)__builtin_amdgcn_readlane(v, 63);
 }
 #define DESCALE(v, n) (((v) + (1 << ((n) - 1))) >> (n))
-// cv::calcOpticalFlowPyrLK for ONE point by one wave: previous image (ps, pslot), next image (ns, nslot), derivatives of the previous image
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
+// a * w.x + b * w.y + c for two bytes (a in bits 0 .. 7, b in bits 8 .. 15 of `pair`) and two 16-bit weights: v_perm_b32 + v_dot2_i32_i16
+__device__ __forceinline__ int lk_dot_bytes(uint32_t pair, lk_s2 w, int c)
+{
+    const uint32_t sp = __builtin_amdgcn_perm(0u, pair, 0x0c010c00u);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, sp), w, c, false);
+}
+__device__ __forceinline__ uint32_t lk_load16(const uint8_t* p) { unsigned short t; __builtin_memcpy(&t, p, 2); return t; }
+// cv::calcOpticalFlowPyrLK for ONE point by one wave: previous image (ps, pslot), next image (ns, nslot), derivatives of the previous image.
+// A window that lies inside the image with its +1 taps (wave-uniform, and the usual case) needs no border reflection and no tap tests; its bilinear taps are
+// two 2-byte loads (8-byte loads for the derivative pairs) and two dot products with the packed 15-bit weights.
 __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, int ns, int nslot, float p0x, float p0y, int lane,
                                          int max_count, float eps2, float min_eig_thr, float& nx, float& ny, int& st, float& er)
 {
@@ -397,27 +417,46 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
         float a = ppx - ipx, b = ppy - ipy;
         int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)), iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)), iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
         int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+        const uint32_t woff0 = (uint32_t)(wy0 * W + wx0), woff1 = (uint32_t)(wy1 * W + wx1);      // this lane's pixels relative to the window's corner
         int I[2], Ix[2], Iy[2];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
+        int sA11 = 0, sA12 = 0, sA22 = 0;
+        if (ipx >= 0 && ipy >= 0 && ipx + LKW < W && ipy + LKW < H) {
+            const lk_s2 w0 = { (short)iw00, (short)iw01 }, w1 = { (short)iw10, (short)iw11 };
+            const uint32_t base = (uint32_t)(ipy * W + ipx);
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            I[t] = Ix[t] = Iy[t] = 0;
-            if (t == 1 && !v1) continue;
-            const int gx = ipx + (t ? wx1 : wx0), gy = ipy + (t ? wy1 : wy0);
-            const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
-            const int iv = DESCALE(P[(size_t)y0 * W + x0] * iw00 + P[(size_t)y0 * W + x1] * iw01 + P[(size_t)y1 * W + x0] * iw10 + P[(size_t)y1 * W + x1] * iw11, 14 - 5);
-            const bool i00 = gx >= 0 && gx < W && gy >= 0 && gy < H, i01 = gx + 1 >= 0 && gx + 1 < W && gy >= 0 && gy < H;
-            const bool i10 = gx >= 0 && gx < W && gy + 1 >= 0 && gy + 1 < H, i11 = gx + 1 >= 0 && gx + 1 < W && gy + 1 >= 0 && gy + 1 < H;
-            const short2 z = make_short2(0, 0);
-            const short2 d00 = i00 ? D[(size_t)gy * W + gx] : z, d01 = i01 ? D[(size_t)gy * W + gx + 1] : z;
-            const short2 d10 = i10 ? D[(size_t)(gy + 1) * W + gx] : z, d11 = i11 ? D[(size_t)(gy + 1) * W + gx + 1] : z;
-            const int ix = DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
-            const int iy = DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
-            I[t] = (short)iv; Ix[t] = (short)ix; Iy[t] = (short)iy;
-            sA11 += (long long)Ix[t] * Ix[t]; sA12 += (long long)Ix[t] * Iy[t]; sA22 += (long long)Iy[t] * Iy[t];
+            for (int t = 0; t < 2; t++) {
+                I[t] = Ix[t] = Iy[t] = 0;
+                if (t == 1 && !v1) continue;
+                const uint32_t o = base + (t ? woff1 : woff0);
+                const int iv = lk_dot_bytes(lk_load16(P + o + W), w1, lk_dot_bytes(lk_load16(P + o), w0, 1 << (14 - 5 - 1))) >> (14 - 5);
+                uint2 r0, r1; __builtin_memcpy(&r0, D + o, 8); __builtin_memcpy(&r1, D + o + W, 8);       // (dx, dy) of two neighbours each
+                const lk_s2 x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(r0.y, r0.x, 0x05040100u)), y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(r0.y, r0.x, 0x07060302u));
+                const lk_s2 x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(r1.y, r1.x, 0x05040100u)), y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(r1.y, r1.x, 0x07060302u));
+                const int ix = __builtin_amdgcn_sdot2(x1, w1, __builtin_amdgcn_sdot2(x0, w0, 1 << 13, false), false) >> 14;
+                const int iy = __builtin_amdgcn_sdot2(y1, w1, __builtin_amdgcn_sdot2(y0, w0, 1 << 13, false), false) >> 14;
+                I[t] = (short)iv; Ix[t] = (short)ix; Iy[t] = (short)iy;
+                sA11 += Ix[t] * Ix[t]; sA12 += Ix[t] * Iy[t]; sA22 += Iy[t] * Iy[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                I[t] = Ix[t] = Iy[t] = 0;
+                if (t == 1 && !v1) continue;
+                const int gx = ipx + (t ? wx1 : wx0), gy = ipy + (t ? wy1 : wy0);
+                const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
+                const int iv = DESCALE(P[(size_t)y0 * W + x0] * iw00 + P[(size_t)y0 * W + x1] * iw01 + P[(size_t)y1 * W + x0] * iw10 + P[(size_t)y1 * W + x1] * iw11, 14 - 5);
+                const bool i00 = gx >= 0 && gx < W && gy >= 0 && gy < H, i01 = gx + 1 >= 0 && gx + 1 < W && gy >= 0 && gy < H;
+                const bool i10 = gx >= 0 && gx < W && gy + 1 >= 0 && gy + 1 < H, i11 = gx + 1 >= 0 && gx + 1 < W && gy + 1 >= 0 && gy + 1 < H;
+                const short2 z = make_short2(0, 0);
+                const short2 d00 = i00 ? D[(size_t)gy * W + gx] : z, d01 = i01 ? D[(size_t)gy * W + gx + 1] : z;
+                const short2 d10 = i10 ? D[(size_t)(gy + 1) * W + gx] : z, d11 = i11 ? D[(size_t)(gy + 1) * W + gx + 1] : z;
+                const int ix = DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, 14);
+                const int iy = DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, 14);
+                I[t] = (short)iv; Ix[t] = (short)ix; Iy[t] = (short)iy;
+                sA11 += Ix[t] * Ix[t]; sA12 += Ix[t] * Iy[t]; sA22 += Iy[t] * Iy[t];
+            }
         }
-        sA11 = wave_sum_ll(sA11); sA12 = wave_sum_ll(sA12); sA22 = wave_sum_ll(sA22);
-        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        const float A11 = (float)lk_sum_i32(sA11) * FLT_SCALE, A12 = (float)lk_sum_i32(sA12) * FLT_SCALE, A22 = (float)lk_sum_i32(sA22) * FLT_SCALE;
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LKW * LKW);
         er = minEig;
@@ -431,21 +470,28 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
             a = npx - inx; b = npy - iny;
             iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)); iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)); iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
             iw11 = (1 << 14) - iw00 - iw01 - iw10;
-            long long sb1 = 0, sb2 = 0;
-            // (a window that lies inside the image with its +1 taps -- wave-uniform, and the usual case -- needs no border reflection: eight of them per
-            // lane and iteration otherwise)
-            const bool inside = inx >= 0 && iny >= 0 && inx + LKW < W && iny + LKW < H;
+            int sb1 = 0, sb2 = 0;
+            if (inx >= 0 && iny >= 0 && inx + LKW < W && iny + LKW < H) {
+                const lk_s2 w0 = { (short)iw00, (short)iw01 }, w1 = { (short)iw10, (short)iw11 };
+                const uint32_t base = (uint32_t)(iny * W + inx);
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                if (t == 1 && !v1) continue;
-                const int gx = inx + (t ? wx1 : wx0), gy = iny + (t ? wy1 : wy0);
-                int x0 = gx, x1 = gx + 1, y0 = gy, y1 = gy + 1;
-                if (!inside) { x0 = refl101d(gx, W); x1 = refl101d(gx + 1, W); y0 = refl101d(gy, H); y1 = refl101d(gy + 1, H); }
-                const int diff = DESCALE(N[(size_t)y0 * W + x0] * iw00 + N[(size_t)y0 * W + x1] * iw01 + N[(size_t)y1 * W + x0] * iw10 + N[(size_t)y1 * W + x1] * iw11, 14 - 5) - I[t];
-                sb1 += (long long)diff * Ix[t]; sb2 += (long long)diff * Iy[t];
+                for (int t = 0; t < 2; t++) {
+                    if (t == 1 && !v1) continue;
+                    const uint32_t o = base + (t ? woff1 : woff0);
+                    const int diff = (lk_dot_bytes(lk_load16(N + o + W), w1, lk_dot_bytes(lk_load16(N + o), w0, 1 << (14 - 5 - 1))) >> (14 - 5)) - I[t];
+                    sb1 += __mul24(diff, Ix[t]); sb2 += __mul24(diff, Iy[t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    if (t == 1 && !v1) continue;
+                    const int gx = inx + (t ? wx1 : wx0), gy = iny + (t ? wy1 : wy0);
+                    const int x0 = refl101d(gx, W), x1 = refl101d(gx + 1, W), y0 = refl101d(gy, H), y1 = refl101d(gy + 1, H);
+                    const int diff = DESCALE(N[(size_t)y0 * W + x0] * iw00 + N[(size_t)y0 * W + x1] * iw01 + N[(size_t)y1 * W + x0] * iw10 + N[(size_t)y1 * W + x1] * iw11, 14 - 5) - I[t];
+                    sb1 += diff * Ix[t]; sb2 += diff * Iy[t];
+                }
             }
-            sb1 = wave_sum_ll(sb1); sb2 = wave_sum_ll(sb2);
-            const float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            const float b1 = (float)lk_sum_wide(sb1) * FLT_SCALE, b2 = (float)lk_sum_wide(sb2) * FLT_SCALE;
             const float ddx = (A12 * b2 - A22 * b1) * Dt, ddy = (A12 * b1 - A11 * b2) * Dt;
             npx += ddx; npy += ddy;
             nx = npx + half; ny = npy + half;
