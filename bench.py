@@ -138,7 +138,7 @@ def stereo_main(args):
     Wd, Hd, D, ITERS = 1241, 376, 80, 200
     F = args.frames if args.frames != 1000 else 256           # frame pairs per step, resident in HBM (replicas on every rank: the sequence of a rank is its own)
     B = max(1, args.stereo_batch)
-    ctx = ssm.Context(local_rank, width=640, height=480, max_batch=B)      # the stereo path launches min(max_batch, 64) frame pairs at a time (ssm_stereo_batch)
+    ctx = ssm.Context(local_rank, width=640, height=480, max_batch=B)      # the stereo path launches min(max_batch, 128) frame pairs at a time (ssm_stereo_batch)
     L, R = stereo_sequence(F, Wd, Hd, 100 + rank)
     dl = ctx.dev_alloc(L.nbytes); dr = ctx.dev_alloc(R.nbytes); ds = ctx.dev_alloc(F * ITERS * 3 * 4)
     ctx.h2d(dl, L); ctx.h2d(dr, R); ctx.h2d(ds, GlibcRand(0).draws(F * ITERS * 3))

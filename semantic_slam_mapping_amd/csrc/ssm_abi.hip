@@ -391,7 +391,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
-    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 64 ? 64 : b; }
+    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 128 ? 128 : b; }
     { const char* e = getenv("SSM_SGBM_STREAMS"); if (e) { const int v = atoi(e); c->stereo_sgbm_streams = v < 1 ? 1 : v > 3 ? 3 : v; } }
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
@@ -1773,7 +1773,7 @@ static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, int 
     StereoState* q = c->stereo;
     const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
     void*& ws = q->sg_wsN[which]; size_t& have = q->sg_ws_bytesN[which];
-    if (!q->dminN[which]) DALLOC(c, q->dminN[which], 64);
+    if (!q->dminN[which]) DALLOC(c, q->dminN[which], 128);
     if (need <= have) return SSM_OK;
     HIPCHK(c, hipDeviceSynchronize());
     if (ws) hipFree(ws);
