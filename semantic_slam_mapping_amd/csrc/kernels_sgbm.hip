@@ -844,6 +844,12 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             __builtin_amdgcn_s_sleep(4);
         }
     };
+    // the mailbox granules an outermost column will need in the NEXT row are fetched while this row's winner pass runs (a poll is a round trip to the memory
+    // side, ~1.2 k clocks, whether the data is there or not): pfl / pfr = the incoming L1 / L3 message of row y - 1, valid when every tag says y
+    sg_u64 pfl[NG], pfr[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) pfl[j] = pfr[j] = 0;
+    const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
     auto run_row = [&](const uint32_t (&V)[2][K], int y) {
         // ---- the neighbouring columns' states of row y - 1 (LDS; the strip's outermost columns: the mailbox or the zeroed border, below)
         uint32_t nl[NG], nr[NG];
@@ -855,10 +861,35 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #pragma unroll
             for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
         }
-        // ---- what a strip hands on never depends on what it receives in the same row (L1 flows right, L3 flows left): the edge columns compute and publish
-        // their outgoing state BEFORE the incoming mailbox is polled (sgbm_sweep)
         const bool outL = g == 0, outR = g >= TX - 1;
-        // (the steps run for the whole wave -- DPP -- in place on L1 / L3; the strip's outermost columns step a placeholder first and are redone behind the poll)
+        // ---- the outermost columns: the direction that comes from outside the strip.  The usual case: the neighbour strip is not behind, its message of row
+        // y - 1 sits in the prefetch registers, and the wave steps ONCE with the real predecessors like every other wave.
+        bool direct = false;
+        if (wave_has_edge) {
+            bool have = true;
+            if (edgeL && y > 0) {
+#pragma unroll
+                for (int j = 0; j < NG; j++) have &= (unsigned)(pfl[j] >> 32) == (unsigned)y;
+            }
+            if (edgeR && y > 0) {
+#pragma unroll
+                for (int j = 0; j < NG; j++) have &= (unsigned)(pfr[j] >> 32) == (unsigned)y;
+            }
+            direct = __builtin_amdgcn_ballot_w64(!have) == 0;
+            if (direct) {
+                if (outL) {
+#pragma unroll
+                    for (int j = 0; j < NG; j++) nl[j] = (edgeL && y > 0) ? (uint32_t)pfl[j] : 0u;
+                }
+                if (outR) {
+#pragma unroll
+                    for (int j = 0; j < NG; j++) nr[j] = (edgeR && y > 0) ? (uint32_t)pfr[j] : 0u;
+                }
+            }
+        }
+        // ---- otherwise: what a strip hands on never depends on what it receives in the same row (L1 flows right, L3 flows left), so the edge columns compute and
+        // publish their outgoing state BEFORE the incoming mailbox is polled (sgbm_sweep); they step a placeholder first and are redone behind the poll
+        // (the steps run for the whole wave -- DPP -- in place on L1 / L3)
 #pragma unroll
         for (int j = 0; j < K; j++) { L1[j] = nl[j]; L3[j] = nr[j]; }
         m1 = (int)nl[K]; m3 = (int)nr[K];
@@ -877,9 +908,7 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L3[j], SG_RLX_AGENT);
             __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3, SG_RLX_AGENT);
         }
-        // ---- the outermost columns: the direction that comes from outside the strip
-        const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
-        if (wave_has_edge) {
+        if (wave_has_edge && !direct) {
             bool okl = true, okr = true;
             if (outL) {
                 if (edgeL && y > 0) okl = mbox_wait8(mslot(strip - 1, 0, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nl);
@@ -903,6 +932,19 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             m1 = (int)nl[K]; m3 = (int)nr[K];
             sg_step8<K>(L1, m1, V[0], P1P1, P2, first, last);
             sg_step8<K>(L3, m3, V[0], P1P1, P2, first, last);
+        }
+        // the neighbours' messages of THIS row (for row y + 1), on their way during the winner pass below
+        if (wave_has_edge && y + 1 < h) {
+            if (edgeL) {
+                const sg_u64* gq = mslot(strip - 1, 0, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NG; j++) pfl[j] = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT);
+            }
+            if (edgeR) {
+                const sg_u64* gq = mslot(strip, 1, y & (SGS_SLOTS - 1));
+#pragma unroll
+                for (int j = 0; j < NG; j++) pfr[j] = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT);
+            }
         }
         if (!live) {                                              // a column outside the strip / image: its neighbours see the zeroed border
 #pragma unroll
