@@ -3,9 +3,10 @@
 // error, refinement on the consensus set).  SURVEY.md s.8(f) rank 3; the contracts (sin/cos, LU, summation order of
 // the refinement, the reference's rdrx11 term) are those of oracle/vo.c and are restated here line by line, in f64
 // with -ffp-contract=off, so the result is bit-identical to the oracle.
-//   vo_ransac_kernel : one wave per hypothesis.  Lane 0 runs the <= 22 Gauss-Newton steps on its 3 matches (12 rows,
-//                      summed in row order like the reference); then the whole wave votes: every lane tests matches
-//                      lane, lane+64, ... and the ballots give the consensus size.
+//   vo_hyp_kernel    : one THREAD per hypothesis: the <= 22 Gauss-Newton steps on its 3 matches (12 rows, summed in row
+//                      order like the reference)
+//   vo_vote_kernel   : one wave per hypothesis: every lane tests matches lane, lane+64, ... and the ballots give the
+//                      consensus size.
 //   vo_refine_kernel : one wave.  Picks the first hypothesis with the largest consensus, rebuilds its inlier list in
 //                      index order (ballot prefix), then Gauss-Newton on all inliers: lane l accumulates the 42 normal-
 //                      equation sums of inliers l, l+64, ... and a butterfly over lane distance 1..32 adds the lanes up
@@ -182,44 +183,52 @@ __global__ void vo_offsets_kernel(const int32_t* __restrict__ n_all, int nb, int
     for (int f = 0; f < nb; f++) { rand_off[f] = c; if (n_all[f] >= 6) c += draws_per_frame; }
     *consumed = c;
 }
+// Round 4: the hypotheses of a frame are solved by one THREAD each (vo_hyp_kernel: the 3-point Gauss-Newton is a serial f64 chain; with one wave per hypothesis
+// 63 lanes waited for lane 0, 12 k instructions per wave for one lane's work), then voted on by one WAVE each (vo_vote_kernel) -- the same arithmetic in the same
+// order, 0.59 -> 0.1x ms per 64 frame pairs x 200 hypotheses.
 __global__ void __launch_bounds__(64)
-vo_ransac_kernel(VoBatch B, ssm_vo_params P, double* __restrict__ tr_all, int32_t* __restrict__ count)
+vo_hyp_kernel(VoBatch B, ssm_vo_params P, double* __restrict__ tr_all, int32_t* __restrict__ count)
 {
-    __shared__ double s_tr[6];
-    __shared__ int s_result;
-    const int k = blockIdx.x, lane = threadIdx.x, f = blockIdx.y;
+    const int k = blockIdx.x * 64 + threadIdx.x, f = blockIdx.y;
     const ssm_pmatch* m = B.m_all + (size_t)f * B.stride;
     const int n = B.n_all ? B.n_all[f] : B.n_fixed;
-    if (n < 6) return;                                       // no estimate for this frame (vo_refine_kernel writes the empty result)
+    if (n < 6 || k >= B.iters) return;                       // no estimate for this frame (vo_refine_kernel writes the empty result)
     tr_all += (size_t)f * B.iters * 6; count += (size_t)f * B.iters;
-    if (lane == 0) {
-        int smp[3];
-        if (B.samples) { smp[0] = B.samples[3 * k]; smp[1] = B.samples[3 * k + 1]; smp[2] = B.samples[3 * k + 2]; }
-        else {
-            const uint32_t* r = B.rand_stream + B.rand_off[f] + 3 * k;
-            const int v0 = (int)(r[0] % (uint32_t)n);
-            int v1 = (int)(r[1] % (uint32_t)(n - 1)); v1 += v1 >= v0;
-            const int lo = min(v0, v1), hi = max(v0, v1);
-            int v2 = (int)(r[2] % (uint32_t)(n - 2)); v2 += v2 >= lo; v2 += v2 >= hi;
-            smp[0] = v0; smp[1] = v1; smp[2] = v2;
-        }
-        double tr[6] = {0, 0, 0, 0, 0, 0};
-        int result = VO_UPDATED, iter = 0;
-        while (result == VO_UPDATED) {
-            VoPose R; vo_pose_make(tr, R);
-            double acc[42];
-            for (int q = 0; q < 42; q++) acc[q] = 0.0;
-            for (int q = 0; q < 3; q++) vo_accumulate(m[smp[q]], P, R, acc);
-            result = vo_finish_step(acc, tr, 1e-6);
-            if (iter++ > 20 || result == VO_CONVERGED) break;
-        }
-        for (int q = 0; q < 6; q++) { s_tr[q] = tr[q]; tr_all[6 * k + q] = tr[q]; }
-        s_result = result;
+    int smp[3];
+    if (B.samples) { smp[0] = B.samples[3 * k]; smp[1] = B.samples[3 * k + 1]; smp[2] = B.samples[3 * k + 2]; }
+    else {
+        const uint32_t* r = B.rand_stream + B.rand_off[f] + 3 * k;
+        const int v0 = (int)(r[0] % (uint32_t)n);
+        int v1 = (int)(r[1] % (uint32_t)(n - 1)); v1 += v1 >= v0;
+        const int lo = min(v0, v1), hi = max(v0, v1);
+        int v2 = (int)(r[2] % (uint32_t)(n - 2)); v2 += v2 >= lo; v2 += v2 >= hi;
+        smp[0] = v0; smp[1] = v1; smp[2] = v2;
     }
-    __syncthreads();
-    if (s_result == VO_FAILED) { if (lane == 0) count[k] = -1; return; }
+    const ssm_pmatch m0 = m[smp[0]], m1 = m[smp[1]], m2 = m[smp[2]];
+    double tr[6] = {0, 0, 0, 0, 0, 0};
+    int result = VO_UPDATED, iter = 0;
+    while (result == VO_UPDATED) {
+        VoPose R; vo_pose_make(tr, R);
+        double acc[42];
+        for (int q = 0; q < 42; q++) acc[q] = 0.0;
+        vo_accumulate(m0, P, R, acc); vo_accumulate(m1, P, R, acc); vo_accumulate(m2, P, R, acc);
+        result = vo_finish_step(acc, tr, 1e-6);
+        if (iter++ > 20 || result == VO_CONVERGED) break;
+    }
+    for (int q = 0; q < 6; q++) tr_all[6 * k + q] = tr[q];
+    count[k] = result == VO_FAILED ? -1 : 0;                 // (the vote replaces the 0)
+}
+__global__ void __launch_bounds__(256)
+vo_vote_kernel(VoBatch B, ssm_vo_params P, const double* __restrict__ tr_all, int32_t* __restrict__ count)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, f = blockIdx.y;
+    const ssm_pmatch* m = B.m_all + (size_t)f * B.stride;
+    const int n = B.n_all ? B.n_all[f] : B.n_fixed;
+    if (n < 6 || k >= B.iters) return;
+    tr_all += (size_t)f * B.iters * 6; count += (size_t)f * B.iters;
+    if (count[k] < 0) return;                                // the Gauss-Newton failed: no vote (wave-uniform)
     double tr[6];
-    for (int q = 0; q < 6; q++) tr[q] = s_tr[q];
+    for (int q = 0; q < 6; q++) tr[q] = tr_all[6 * k + q];
     VoPose R; vo_pose_make(tr, R);
     int c = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
@@ -284,7 +293,7 @@ hipError_t k_vo_estimate(const ssm_pmatch* m, int n, const ssm_vo_params& P, con
                          double* tr_all, int32_t* count, double* tr_out, int32_t* inliers, int32_t* result, hipStream_t s)
 {
     VoBatch B; B.m_all = m; B.stride = n; B.n_all = nullptr; B.n_fixed = n; B.samples = samples; B.rand_stream = nullptr; B.rand_off = nullptr; B.iters = iters;
-    if (iters > 0) vo_ransac_kernel<<<dim3(iters, 1), 64, 0, s>>>(B, P, tr_all, count);
+    if (iters > 0) { vo_hyp_kernel<<<dim3((iters + 63) / 64, 1), 64, 0, s>>>(B, P, tr_all, count); vo_vote_kernel<<<dim3((iters + 3) / 4, 1), 256, 0, s>>>(B, P, tr_all, count); }
     vo_refine_kernel<<<1, 64, 0, s>>>(B, P, tr_all, count, tr_out, inliers, result);
     return hipGetLastError();
 }
@@ -297,7 +306,7 @@ hipError_t k_vo_estimate_batch(const ssm_pmatch* m_all, int stride, const int32_
     if (nb <= 0) return hipSuccess;
     VoBatch B; B.m_all = m_all; B.stride = stride; B.n_all = n_all; B.n_fixed = 0; B.samples = nullptr; B.rand_stream = rand_stream; B.rand_off = rand_off; B.iters = iters;
     vo_offsets_kernel<<<1, 1, 0, s>>>(n_all, nb, 3 * iters, consumed, rand_off);
-    if (iters > 0) vo_ransac_kernel<<<dim3(iters, nb), 64, 0, s>>>(B, P, tr_all, count);
+    if (iters > 0) { vo_hyp_kernel<<<dim3((iters + 63) / 64, nb), 64, 0, s>>>(B, P, tr_all, count); vo_vote_kernel<<<dim3((iters + 3) / 4, nb), 256, 0, s>>>(B, P, tr_all, count); }
     vo_refine_kernel<<<nb, 64, 0, s>>>(B, P, tr_all, count, tr_out, inliers, result);
     return hipGetLastError();
 }
