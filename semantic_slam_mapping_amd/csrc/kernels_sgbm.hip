@@ -526,6 +526,104 @@ sgbm_rows(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint
         seg_run(Cb, Fb, s - 1);
     }
 }
+// sgbm_rows with EIGHT disparities per lane: a row is owned by D / 8 of a DPP row's 16 lanes (10 at D = 80), a lane's costs are ONE aligned 16-byte word.
+// sgbm_rows' five u16 per lane are an 8-byte + a 2-byte access at 2-byte alignment, for all 16 lanes: the kernel sat at 0.80 (busiest CU 0.94) of its
+// texture-address units' time (profiles/r04_stereo_ta_busy.md) with HBM at 4 TB/s; here a column is 10 lane-accesses instead of 32.  The idle lanes run along
+// (DPP wants the wave): their minimum is parked at 0xFFFF and the last active lane's d + 1 neighbour is MAX_COST, like a group's edge in sg_step8.
+__device__ __forceinline__ void sg_step_pk8(uint32_t (&L)[4], int& minPrev, const uint32_t (&Cp)[4], uint32_t P1P1, int P2, bool act, bool last)
+{
+    constexpr uint32_t MAXMAX = (uint32_t)SG_MAXC | ((uint32_t)SG_MAXC << 16);
+    const uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXMAX, (int)L[3]);           // row_shr:1 (lane 0 of the row: MAX_COST)
+    uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);                 // row_shl:1
+    rgt = last ? MAXMAX : rgt;
+    const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
+    uint32_t Ln[4], m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t lm = __builtin_amdgcn_alignbyte(L[j], j > 0 ? L[j - 1] : lft, 2);
+        const uint32_t lp = __builtin_amdgcn_alignbyte(j < 3 ? L[j + 1] : rgt, L[j], 2);
+        const uint32_t t = pk_min16(pk_min16(L[j], pk_add16(lm, P1P1)), pk_min16(pk_add16(lp, P1P1), dd));
+        Ln[j] = pk_sub16(pk_add16(Cp[j], t), dd);
+        m = pk_min16(m, Ln[j]);
+    }
+    m = act ? m : 0xFFFFFFFFu;
+    minPrev = sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
+#pragma unroll
+    for (int j = 0; j < 4; j++) L[j] = Ln[j];
+}
+template <int SEG>
+__global__ void __launch_bounds__(256)
+sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int D, int P1, int P2)
+{
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15, NL = D >> 3;
+    const bool act = li < NL, last = li == NL - 1;
+    const bool live = g < h && act;                           // dead groups run row 0 without stores (DPP wants the whole wave); idle lanes read lane 0's words
+    const int y = g < h ? g : 0, lc = act ? li : 0;
+    const int nseg = (w1 + SEG - 1) / SEG;
+    const size_t rowi = (size_t)blockIdx.y * h + y;           // blockIdx.y = frame
+    const uint4* Crow = reinterpret_cast<const uint4*>(C_all + rowi * w1 * D) + lc;       // a column = NL words
+    uint4* Srow = reinterpret_cast<uint4*>(S_all + rowi * w1 * D) + lc;
+    uint4* ck = reinterpret_cast<uint4*>(ck_all + rowi * nseg * D) + lc;                  // ck[s]: L0 in front of segment s (s >= 1)
+    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
+    uint32_t Ca[SEG][4], Cb[SEG][4];
+    auto ld = [&](uint32_t (&d)[4], const uint4* p) { const uint4 t = *p; d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; };
+    auto load_seg = [&](uint32_t (&Cq)[SEG][4], int s) {
+#pragma unroll
+        for (int u = 0; u < SEG; u++) ld(Cq[u], Crow + (size_t)min(s * SEG + u, w1 - 1) * NL);
+    };
+    // ---- pass 1: L0 left to right, checkpoints only
+    if (nseg > 1) {
+        uint32_t L[4] = {0u, 0u, 0u, 0u}; int mp = 0;
+        auto fwd_seg = [&](const uint32_t (&Cq)[SEG][4], int s) {
+#pragma unroll
+            for (int u = 0; u < SEG; u++) sg_step_pk8(L, mp, Cq[u], P1P1, P2, act, last);
+            if (live) ck[(size_t)(s + 1) * NL] = make_uint4(L[0], L[1], L[2], L[3]);
+        };
+        load_seg(Ca, 0);
+        for (int s = 0; s < nseg - 1; s += 2) {
+            if (s + 1 < nseg - 1) load_seg(Cb, s + 1);
+            fwd_seg(Ca, s);
+            if (s + 1 >= nseg - 1) break;
+            if (s + 2 < nseg - 1) load_seg(Ca, s + 2);
+            fwd_seg(Cb, s + 1);
+        }
+    }
+    // ---- pass 2: segments right to left; L0 forward from the checkpoint, L4 backward, the sum out
+    uint32_t R[4] = {0u, 0u, 0u, 0u}; int mpr = 0;
+    uint32_t Fa[4], Fb[4];
+    auto load_ck = [&](uint32_t (&F)[4], int s) {
+        if (s > 0) ld(F, ck + (size_t)s * NL);
+        else { F[0] = F[1] = F[2] = F[3] = 0u; }
+    };
+    auto seg_run = [&](const uint32_t (&Cq)[SEG][4], uint32_t (&F)[4], int s) {
+        uint32_t m = pk_min16(pk_min16(F[0], F[1]), pk_min16(F[2], F[3]));
+        m = act ? m : 0xFFFFFFFFu;
+        int mpf = sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
+        uint32_t L0[SEG][4];
+#pragma unroll
+        for (int u = 0; u < SEG; u++) {
+            if (s * SEG + u < w1) sg_step_pk8(F, mpf, Cq[u], P1P1, P2, act, last);          // (wave-uniform; false only in the last segment)
+#pragma unroll
+            for (int j = 0; j < 4; j++) L0[u][j] = F[j];
+        }
+#pragma unroll
+        for (int u = SEG - 1; u >= 0; u--) {
+            const int x = s * SEG + u;
+            if (x < w1) {
+                sg_step_pk8(R, mpr, Cq[u], P1P1, P2, act, last);
+                if (live) Srow[(size_t)x * NL] = make_uint4(pk_addsat15(L0[u][0], R[0]), pk_addsat15(L0[u][1], R[1]), pk_addsat15(L0[u][2], R[2]), pk_addsat15(L0[u][3], R[3]));
+            }
+        }
+    };
+    load_seg(Ca, nseg - 1); load_ck(Fa, nseg - 1);
+    for (int s = nseg - 1; s >= 0; s -= 2) {
+        if (s - 1 >= 0) { load_seg(Cb, s - 1); load_ck(Fb, s - 1); }
+        seg_run(Ca, Fa, s);
+        if (s - 1 < 0) break;
+        if (s - 2 >= 0) { load_seg(Ca, s - 2); load_ck(Fa, s - 2); }
+        seg_run(Cb, Fb, s - 1);
+    }
+}
 // mailbox of one (frame, seam, direction): [SGS_SLOTS][NP + 1][16 lanes] granules; granule j < NP = the lane's packed pair j, granule NP = the path's minimum
 template <int NG> __device__ __forceinline__ bool sg_mbox_wait(const sg_u64* g, unsigned epoch, uint32_t (&v)[NG], unsigned* flags)
 {
@@ -1397,7 +1495,15 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     auto sweep = use8 ? (costs_below_2_15 ? sgbm_sweep8<K, true> : sgbm_sweep8<K, false>) : (costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>);
     hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sweep), lds);
     if (e != hipSuccess) return e;
-    if (seg_env == 6) sgbm_rows<K, 6><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
+    static const int rows_lanes = [] { const char* v = getenv("SSM_SGBM_ROWS_LANES"); return v ? atoi(v) : 8; }();      // 16: sgbm_rows (D / 16 disparities per lane)
+    if (rows_lanes != 16) {
+        // checkpoints every 12 columns (SSM_SGBM_SEG = 8 | 16): 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage at 8 / 12 / 16, but 4.32 / 4.38 / 4.33 k pairs/s for
+        // the whole path -- 16 columns of costs in registers leave the kernels of the other streams less room beside it
+        if (seg_env == 8) sgbm_rows8<8><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
+        else if (seg_env == 16) sgbm_rows8<16><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
+        else sgbm_rows8<12><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
+    }
+    else if (seg_env == 6) sgbm_rows<K, 6><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
     else sgbm_rows<K, SGR_SEG><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
     sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
     e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
