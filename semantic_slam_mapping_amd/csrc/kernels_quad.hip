@@ -332,17 +332,11 @@ gftt_rank_kernel(const unsigned long long* __restrict__ kept_all, const int* __r
 }
 
 // ------------------------------------------------------------------ pyramid + Scharr for LK (all frames and both sides of a sub-batch per launch)
+// Both kernels make FOUR neighbouring outputs per thread from a few wide loads: with one output and 25 / 9 byte loads per thread they spent 0.68 / 0.56 of their
+// time in the texture-address units (profiles/r04_stereo_ta_busy.md).  Outputs next to the left / right border (reflection) take the one-by-one path.
 // blockIdx.y = f * 2 + side
-__global__ void __launch_bounds__(256)
-pyrdown_kernel(QuadBatch q, uint8_t* __restrict__ pyr, int level)
+__device__ __forceinline__ int pyrdown_px(const uint8_t* __restrict__ src, int w, int h, int x, int y)
 {
-    const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
-    const int w = q.w[level - 1], h = q.h[level - 1], dw = q.w[level], dh = q.h[level];
-    const size_t sl = (size_t)(side * q.B1 + 1 + f) * q.slot_elems;
-    const uint8_t* src = pyr + sl + q.off[level - 1]; uint8_t* dst = pyr + sl + q.off[level];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= dw * dh) return;
-    const int y = i / dw, x = i - y * dw;
     const int k[5] = {1, 4, 6, 4, 1};
     int s = 0;
 #pragma unroll
@@ -353,24 +347,81 @@ pyrdown_kernel(QuadBatch q, uint8_t* __restrict__ pyr, int level)
         for (int qq = -2; qq <= 2; qq++) rs += k[qq + 2] * r[refl101d(2 * x + qq, w)];
         s += k[j + 2] * rs;
     }
-    dst[i] = (uint8_t)((s + 128) >> 8);
+    return (s + 128) >> 8;
 }
-// all four levels of a slot in one launch: thread i = element i of the slot
+__global__ void __launch_bounds__(256)
+pyrdown_kernel(QuadBatch q, uint8_t* __restrict__ pyr, int level)
+{
+    const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
+    const int w = q.w[level - 1], h = q.h[level - 1], dw = q.w[level], dh = q.h[level];
+    const size_t sl = (size_t)(side * q.B1 + 1 + f) * q.slot_elems;
+    const uint8_t* src = pyr + sl + q.off[level - 1]; uint8_t* dst = pyr + sl + q.off[level];
+    const int groups = (dw + 3) >> 2;                        // four outputs of a row per thread
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * dh) return;
+    const int y = i / groups, x = (i - y * groups) << 2;
+    if (x + 3 < dw && 2 * x - 2 >= 0 && 2 * x + 9 <= w - 1) {
+        // source columns 2x - 2 .. 2x + 8 of five rows: 12 bytes per row
+        const int k[5] = {1, 4, 6, 4, 1};
+        int s4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = -2; j <= 2; j++) {
+            const uint8_t* r = src + (size_t)refl101d(2 * y + j, h) * w + (2 * x - 2);
+            uint32_t d[3]; __builtin_memcpy(d, r, 12);
+            int b[12];
+#pragma unroll
+            for (int t = 0; t < 12; t++) b[t] = (int)((d[t >> 2] >> (8 * (t & 3))) & 255u);
+#pragma unroll
+            for (int o = 0; o < 4; o++) s4[o] += k[j + 2] * (b[2 * o] + 4 * b[2 * o + 1] + 6 * b[2 * o + 2] + 4 * b[2 * o + 3] + b[2 * o + 4]);
+        }
+        const uint32_t out = (uint32_t)((s4[0] + 128) >> 8) | ((uint32_t)((s4[1] + 128) >> 8) << 8) | ((uint32_t)((s4[2] + 128) >> 8) << 16) | ((uint32_t)((s4[3] + 128) >> 8) << 24);
+        __builtin_memcpy(dst + (size_t)y * dw + x, &out, 4);
+    } else {
+        for (int o = 0; o < 4 && x + o < dw; o++) dst[(size_t)y * dw + x + o] = (uint8_t)pyrdown_px(src, w, h, x + o, y);
+    }
+}
+// all four levels of a slot in one launch: thread i = elements 4 i .. 4 i + 3 of the slot (a level starts at a multiple of 16 elements)
+__device__ __forceinline__ short2 scharr_px(const uint8_t* __restrict__ src, int w, int h, int x, int y)
+{
+    const uint8_t *r0 = src + (size_t)refl101d(y - 1, h) * w, *r1 = src + (size_t)y * w, *r2 = src + (size_t)refl101d(y + 1, h) * w;
+    const int xm = refl101d(x - 1, w), xp = refl101d(x + 1, w);
+    return make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
+                       (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[x] - r0[x]) + 3 * (r2[xp] - r0[xp])));
+}
 __global__ void __launch_bounds__(256)
 scharr_kernel(QuadBatch q, short2* __restrict__ der)
 {
     const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = (blockIdx.x * blockDim.x + threadIdx.x) << 2;
     if (e >= (int)q.slot_elems) return;
     const int level = e >= q.off[3] ? 3 : e >= q.off[2] ? 2 : e >= q.off[1] ? 1 : 0;
     const int w = q.w[level], h = q.h[level], i = e - q.off[level];
     const size_t sl = (size_t)(side * q.B1 + 1 + f) * q.slot_elems;
     const uint8_t* src = q.pyr + sl + q.off[level];
     const int y = i / w, x = i - y * w;
-    const uint8_t *r0 = src + (size_t)refl101d(y - 1, h) * w, *r1 = src + (size_t)y * w, *r2 = src + (size_t)refl101d(y + 1, h) * w;
-    const int xm = refl101d(x - 1, w), xp = refl101d(x + 1, w);
-    der[sl + e] = make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
-                              (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[x] - r0[x]) + 3 * (r2[xp] - r0[xp])));
+    if (y < h && x >= 1 && x + 6 <= w - 1) {                 // the four outputs and their neighbours x - 1 .. x + 4 lie in one row, and the 8-byte windows stay inside it
+        unsigned long long a0, a1, a2;
+        __builtin_memcpy(&a0, src + (size_t)refl101d(y - 1, h) * w + x - 1, 8); __builtin_memcpy(&a1, src + (size_t)y * w + x - 1, 8); __builtin_memcpy(&a2, src + (size_t)refl101d(y + 1, h) * w + x - 1, 8);
+        short2 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int m0 = (int)((a0 >> (8 * k)) & 255u), c0 = (int)((a0 >> (8 * k + 8)) & 255u), p0 = (int)((a0 >> (8 * k + 16)) & 255u);
+            const int m1 = (int)((a1 >> (8 * k)) & 255u), p1 = (int)((a1 >> (8 * k + 16)) & 255u);
+            const int m2 = (int)((a2 >> (8 * k)) & 255u), c2 = (int)((a2 >> (8 * k + 8)) & 255u), p2 = (int)((a2 >> (8 * k + 16)) & 255u);
+            o[k] = make_short2((short)(3 * (p0 - m0) + 10 * (p1 - m1) + 3 * (p2 - m2)), (short)(3 * (m2 - m0) + 10 * (c2 - c0) + 3 * (p2 - p0)));
+        }
+        uint4 out; __builtin_memcpy(&out, o, 16);
+        *reinterpret_cast<uint4*>(der + sl + e) = out;      // (sl and e are multiples of 4 elements: 16-byte aligned)
+    } else {
+        // (elements in the padding behind a level are computed like the one-element kernel did: rows past the level, values nobody reads)
+        for (int k = 0; k < 4; k++) {
+            const int ik = i + k, yk = ik / w, xk = ik - yk * w;
+            const uint8_t *r0 = src + (size_t)refl101d(yk - 1, h) * w, *r1 = src + (size_t)yk * w, *r2 = src + (size_t)refl101d(yk + 1, h) * w;
+            const int xm = refl101d(xk - 1, w), xp = refl101d(xk + 1, w);
+            der[sl + e + k] = make_short2((short)(3 * (r0[xp] - r0[xm]) + 10 * (r1[xp] - r1[xm]) + 3 * (r2[xp] - r2[xm])),
+                                          (short)(3 * (r2[xm] - r0[xm]) + 10 * (r2[xk] - r0[xk]) + 3 * (r2[xp] - r0[xp])));
+        }
+    }
 }
 
 // ------------------------------------------------------------------ pyramidal LK, one wave per point, all levels in one launch
@@ -618,8 +669,8 @@ hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
 {
     if (nb <= 0) return hipSuccess;
     uint8_t* pyr = const_cast<uint8_t*>(q.pyr);
-    for (int l = 1; l < 4; l++) pyrdown_kernel<<<dim3((q.w[l] * q.h[l] + 255) / 256, nb * 2), 256, 0, s>>>(q, pyr, l);
-    scharr_kernel<<<dim3(((int)q.slot_elems + 255) / 256, nb * 2), 256, 0, s>>>(q, reinterpret_cast<short2*>(const_cast<int16_t*>(q.der)));
+    for (int l = 1; l < 4; l++) pyrdown_kernel<<<dim3((((q.w[l] + 3) >> 2) * q.h[l] + 255) / 256, nb * 2), 256, 0, s>>>(q, pyr, l);
+    scharr_kernel<<<dim3(((int)(q.slot_elems >> 2) + 255) / 256, nb * 2), 256, 0, s>>>(q, reinterpret_cast<short2*>(const_cast<int16_t*>(q.der)));
     return hipGetLastError();
 }
 // cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  Workspace (GfttWork): eig nb*w*h floats; cand_at
