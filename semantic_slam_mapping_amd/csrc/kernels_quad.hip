@@ -186,8 +186,10 @@ gftt_deps_kernel(int w, int h, const unsigned long long* __restrict__ keys_all, 
             if (yy < 0 || yy >= h) continue;
             const int x0 = x - rad, base = yy * w + x0;           // (may be negative at the first pixels of the image: those bits are masked)
             const int wq = base >> 5, sh = base & 31;
-            const uint32_t w0 = wq >= 0 ? bits[wq] : 0u, w1 = wq + 1 >= 0 && wq + 1 < bits_words ? bits[wq + 1] : 0u;
-            uint32_t m = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> sh);
+            unsigned long long w01;                                // the two words as ONE 8-byte access (the kernel spends 0.57 of its time in the texture-address units)
+            if (wq >= 0 && wq + 1 < bits_words) __builtin_memcpy(&w01, bits + wq, 8);
+            else { const uint32_t w0 = wq >= 0 ? bits[wq] : 0u, w1 = wq + 1 >= 0 && wq + 1 < bits_words ? bits[wq + 1] : 0u; w01 = ((unsigned long long)w1 << 32) | w0; }
+            uint32_t m = (uint32_t)(w01 >> sh);
             m &= (2 * rad + 1 >= 32) ? 0xFFFFFFFFu : ((1u << (2 * rad + 1)) - 1u);
             while (m) {
                 const int b = __ffs((int)m) - 1; m &= m - 1;
