@@ -525,6 +525,9 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
         Dt = 1.f / Dt;
         float npx = nx - half, npy = ny - half;
         float pdx = 0.f, pdy = 0.f;
+        // the window's taps of the next image stay in registers while the window's integer corner does not move (a converging track moves by fractions of a
+        // pixel: only the weights change) -- the loads were the start of every iteration's dependent chain and half of the kernel's texture-address work
+        int tap_x = INT_MIN, tap_y = INT_MIN; uint32_t tapA[2] = {0u, 0u}, tapB[2] = {0u, 0u};
         for (int j = 0; j < max_count; j++) {
             const int inx = (int)floorf(npx), iny = (int)floorf(npy);
             if (inx < -LKW || inx >= W || iny < -LKW || iny >= H) { if (level == 0) st = 0; break; }
@@ -534,12 +537,20 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
             int sb1 = 0, sb2 = 0;
             if (inx >= 0 && iny >= 0 && inx + LKW < W && iny + LKW < H) {
                 const lk_s2 w0 = { (short)iw00, (short)iw01 }, w1 = { (short)iw10, (short)iw11 };
-                const uint32_t base = (uint32_t)(iny * W + inx);
+                if (inx != tap_x || iny != tap_y) {                   // (wave-uniform)
+                    const uint32_t base = (uint32_t)(iny * W + inx);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        if (t == 1 && !v1) continue;
+                        const uint32_t o = base + (t ? woff1 : woff0);
+                        tapA[t] = lk_load16(N + o); tapB[t] = lk_load16(N + o + W);
+                    }
+                    tap_x = inx; tap_y = iny;
+                }
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
                     if (t == 1 && !v1) continue;
-                    const uint32_t o = base + (t ? woff1 : woff0);
-                    const int diff = (lk_dot_bytes(lk_load16(N + o + W), w1, lk_dot_bytes(lk_load16(N + o), w0, 1 << (14 - 5 - 1))) >> (14 - 5)) - I[t];
+                    const int diff = (lk_dot_bytes(tapB[t], w1, lk_dot_bytes(tapA[t], w0, 1 << (14 - 5 - 1))) >> (14 - 5)) - I[t];
                     sb1 += __mul24(diff, Ix[t]); sb2 += __mul24(diff, Iy[t]);
                 }
             } else {
