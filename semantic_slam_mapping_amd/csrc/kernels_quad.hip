@@ -457,24 +457,30 @@ __device__ __forceinline__ uint32_t lk_load16(const uint8_t* p) { unsigned short
 // cv::calcOpticalFlowPyrLK for ONE point by one wave: previous image (ps, pslot), next image (ns, nslot), derivatives of the previous image.
 // A window that lies inside the image with its +1 taps (wave-uniform, and the usual case) needs no border reflection and no tap tests; its bilinear taps are
 // two 2-byte loads (8-byte loads for the derivative pairs) and two dot products with the packed 15-bit weights.
-__device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, int ns, int nslot, float p0x, float p0y, int lane,
-                                         int max_count, float eps2, float min_eig_thr, float& nx, float& ny, int& st, float& er)
+// NT next images tracked from the SAME previous image and point (lk_quad_kernel: the current-left corner into the current-right and into the previous-left image):
+// the per-level set-up -- the window of the previous image and of its derivatives, the 2 x 2 matrix, the minimum-eigenvalue test -- depends on neither and is made once.
+template <int NT>
+__device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, const int (&ns)[NT], const int (&nslot)[NT], float p0x, float p0y, int lane,
+                                         int max_count, float eps2, float min_eig_thr, float (&nxs)[NT], float (&nys)[NT], int (&sts)[NT], float& er)
 {
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (LKW - 1) * 0.5f;
-    nx = 0.f; ny = 0.f; st = 1; er = 0.f;
+#pragma unroll
+    for (int tr = 0; tr < NT; tr++) { nxs[tr] = 0.f; nys[tr] = 0.f; sts[tr] = 1; }
+    er = 0.f;
     // this lane's two window pixels: e0 = lane, e1 = lane + 64 (valid when < 121)
     const int e0 = lane, e1 = lane + 64;
     const int wy0 = e0 / LKW, wx0 = e0 - wy0 * LKW, wy1 = e1 / LKW, wx1 = e1 - wy1 * LKW;
     const bool v1 = e1 < LKW * LKW;
     for (int level = LKL - 1; level >= 0; level--) {
         const int W = q.w[level], H = q.h[level];
-        const uint8_t* P = q_img(q, ps, pslot, level); const uint8_t* N = q_img(q, ns, nslot, level); const short2* D = q_der(q, ps, pslot, level);
+        const uint8_t* P = q_img(q, ps, pslot, level); const short2* D = q_der(q, ps, pslot, level);
         float ppx = p0x * (float)(1. / (1 << level)), ppy = p0y * (float)(1. / (1 << level));
-        if (level == LKL - 1) { nx = ppx; ny = ppy; } else { nx *= 2.f; ny *= 2.f; }
+#pragma unroll
+        for (int tr = 0; tr < NT; tr++) { if (level == LKL - 1) { nxs[tr] = ppx; nys[tr] = ppy; } else { nxs[tr] *= 2.f; nys[tr] *= 2.f; } }
         ppx -= half; ppy -= half;
         const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-        if (ipx < -LKW || ipx >= W || ipy < -LKW || ipy >= H) { if (level == 0) { st = 0; er = 0.f; } continue; }
+        if (ipx < -LKW || ipx >= W || ipy < -LKW || ipy >= H) { if (level == 0) { for (int tr = 0; tr < NT; tr++) sts[tr] = 0; er = 0.f; } continue; }
         float a = ppx - ipx, b = ppy - ipy;
         int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (1 << 14)), iw01 = __float2int_rn(a * (1.f - b) * (1 << 14)), iw10 = __float2int_rn((1.f - a) * b * (1 << 14));
         int iw11 = (1 << 14) - iw00 - iw01 - iw10;
@@ -521,8 +527,12 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
         float Dt = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * LKW * LKW);
         er = minEig;
-        if (minEig < min_eig_thr || Dt < FLT_EPSILON) { if (level == 0) st = 0; continue; }
+        if (minEig < min_eig_thr || Dt < FLT_EPSILON) { if (level == 0) { for (int tr = 0; tr < NT; tr++) sts[tr] = 0; } continue; }
         Dt = 1.f / Dt;
+#pragma unroll
+        for (int tr = 0; tr < NT; tr++) {
+        const uint8_t* N = q_img(q, ns[tr], nslot[tr], level);
+        float& nx = nxs[tr]; float& ny = nys[tr]; int& st = sts[tr];
         float npx = nx - half, npy = ny - half;
         float pdx = 0.f, pdy = 0.f;
         // the window's taps of the next image stay in registers while the window's integer corner does not move (a converging track moves by fractions of a
@@ -571,6 +581,7 @@ __device__ __forceinline__ void lk_point(const QuadBatch& q, int ps, int pslot, 
             if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) { nx -= ddx * 0.5f; ny -= ddy * 0.5f; break; }
             pdx = ddx; pdy = ddy;
         }
+        }
     }
 }
 // one pass (ssm_lk_track): previous = (side 0, slot 1), next = (side 1, slot 1)
@@ -581,9 +592,10 @@ lk_kernel(QuadBatch q, const float* __restrict__ prev_pts, int n, float* __restr
     const int lane = threadIdx.x & 63;
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pi >= n) return;
-    float nx, ny, er; int st;
-    lk_point(q, 0, 1, 1, 1, prev_pts[2*pi], prev_pts[2*pi+1], lane, max_count, eps2, min_eig_thr, nx, ny, st, er);
-    if (lane == 0) { next_pts[2*pi] = nx; next_pts[2*pi+1] = ny; status[pi] = (uint8_t)st; if (err) err[pi] = er; }
+    float nx[1], ny[1], er; int st[1];
+    const int ns1[1] = {1}, sl1[1] = {1};
+    lk_point<1>(q, 0, 1, ns1, sl1, prev_pts[2*pi], prev_pts[2*pi+1], lane, max_count, eps2, min_eig_thr, nx, ny, st, er);
+    if (lane == 0) { next_pts[2*pi] = nx[0]; next_pts[2*pi+1] = ny[0]; status[pi] = (uint8_t)st[0]; if (err) err[pi] = er; }
 }
 // the four passes of QuadFeatureMatch::circularMatching in tracking mode (quadmatcher.cpp:566-576) for one GFTT corner of frame f by one wave:
 // lc -> rc, rc -> rp, rp -> lp and lc -> lp (direct); current frame = slot 1 + f, previous = slot f.  LK status vectors are ignored downstream
@@ -598,12 +610,14 @@ lk_quad_kernel(QuadBatch q, float* __restrict__ pts, int stride, const int* __re
     const size_t set = (size_t)nb * stride * 2;
     float* p = pts + ((size_t)f * stride + pi) * 2;
     const float x0 = p[0], y0 = p[1];
-    float x1, y1, x2, y2, x3, y3, x4, y4, er; int st;
-    lk_point(q, 0, 1 + f, 1, 1 + f, x0, y0, lane, max_count, eps2, min_eig_thr, x1, y1, st, er);      // lc -> rc
-    lk_point(q, 1, 1 + f, 1, f, x1, y1, lane, max_count, eps2, min_eig_thr, x2, y2, st, er);          // rc -> rp
-    lk_point(q, 1, f, 0, f, x2, y2, lane, max_count, eps2, min_eig_thr, x3, y3, st, er);              // rp -> lp
-    lk_point(q, 0, 1 + f, 0, f, x0, y0, lane, max_count, eps2, min_eig_thr, x4, y4, st, er);          // lc -> lp
-    if (lane == 0) { p[set] = x1; p[set + 1] = y1; p[2 * set] = x2; p[2 * set + 1] = y2; p[3 * set] = x3; p[3 * set + 1] = y3; p[4 * set] = x4; p[4 * set + 1] = y4; }
+    float er;
+    float xa[2], ya[2]; int sa[2];                           // lc -> rc and lc -> lp (direct): one set-up per level for both
+    { const int nsd[2] = {1, 0}, nsl[2] = {1 + f, f}; lk_point<2>(q, 0, 1 + f, nsd, nsl, x0, y0, lane, max_count, eps2, min_eig_thr, xa, ya, sa, er); }
+    const float x1 = xa[0], y1 = ya[0], x4 = xa[1], y4 = ya[1];
+    float x2[1], y2[1], x3[1], y3[1]; int s1[1];
+    { const int nsd[1] = {1}, nsl[1] = {f}; lk_point<1>(q, 1, 1 + f, nsd, nsl, x1, y1, lane, max_count, eps2, min_eig_thr, x2, y2, s1, er); }          // rc -> rp
+    { const int nsd[1] = {0}, nsl[1] = {f}; lk_point<1>(q, 1, f, nsd, nsl, x2[0], y2[0], lane, max_count, eps2, min_eig_thr, x3, y3, s1, er); }        // rp -> lp
+    if (lane == 0) { p[set] = x1; p[set + 1] = y1; p[2 * set] = x2[0]; p[2 * set + 1] = y2[0]; p[3 * set] = x3[0]; p[3 * set + 1] = y3[0]; p[4 * set] = x4; p[4 * set + 1] = y4; }
 }
 
 // ------------------------------------------------------------------ filteringTracks (quadmatcher.cpp:420-503), ordered compaction, one block per frame
