@@ -460,6 +460,8 @@ hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
     if (G > 1) {                                               // the exchange ring and the time-out word: zero before every launch (tags count passes within a launch)
         e = hipMemsetAsync(a.xchg, 0, k_pnp_xchg_bytes(), s);
         if (e != hipSuccess) return e;
+        const char* tv = getenv("SSM_PNP_TEST_TIMEOUT");                                        // tests: the time-out word set from the start -> the host's retry path
+        if (tv && atoi(tv) != 0) { e = hipMemsetAsync(a.xfail, 1, 4, s); if (e != hipSuccess) return e; }
         pnp_chain_kernel<true><<<G, PC_T, dyn, s>>>(a);
     } else pnp_chain_kernel<false><<<1, PC_T, dyn, s>>>(a);
     return hipGetLastError();

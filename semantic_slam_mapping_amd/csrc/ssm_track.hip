@@ -192,6 +192,13 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             a.blocks = t->blocks; a.xchg = t->d_xchg; a.xfail = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(t->d_xchg) + k_pnp_xchg_bytes() - 64);
             if (k_pnp_chain(a, st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain launch failed");
             if (hipMemcpyAsync(&hs, t->d_state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose chain failed");
+            if (hs.stopped_at == -1 && t->blocks > 1) {
+                // the blocks of the cluster did not meet within the spin bound (they need CUs at the same time: a device kept full by other work for seconds).
+                // Nothing of the tracker's host state has changed yet: the same range again with one block per chain -- same kernel arithmetic, same bits
+                fprintf(stderr, "ssm_tracker_run: the pose chain's cluster timed out; this tracker continues with one block per chain\n");
+                t->blocks = 1;
+                continue;
+            }
             const int stop = hs.stopped_at;
 #ifdef SSM_PNP_PROF
             fprintf(stderr, "pnp chain %d frames: clocks gather %lld fused %lld algebra %lld chi %lld update %lld solve(total) %lld; fused passes %lld chi passes %lld\n", stop - f, hs.prof[0], hs.prof[1], hs.prof[2], hs.prof[3], hs.prof[4], hs.prof[5], hs.prof[6], hs.prof[7]);

@@ -88,13 +88,16 @@ def reference_walk(oracle, frames, ref_frames, max_lost, ratio, nfeat):
     return poses, infos
 
 
-@pytest.mark.parametrize("use_device", [False, True, 1, 2, 4])
+@pytest.mark.parametrize("use_device", [False, True, 1, 2, 4, "timeout"])
 def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device, monkeypatch):
     """14 frames of 640 x 480 (500 features): a rigid plane scene that tracks, one flat frame (fails: the deque then reaches behind the match-table window,
     so the following frames need on-demand matches), later two flat frames in a row with tracker_max_lost_frame = 1 (LOST, then lostRecover)"""
     import semantic_slam_mapping_amd as ssm
     # use_device True: the default form of the device chain (a cluster of eight blocks per chain, kernels_pnp.hip); 1 / 2 / 4: that many blocks -- the same bits in every form
-    if use_device is not True and use_device:
+    # "timeout": the cluster's exchange reports a time-out at once (test hook) -> the tracker must fall back to one block per chain and still produce the walk
+    if use_device == "timeout":
+        monkeypatch.setenv("SSM_PNP_TEST_TIMEOUT", "1"); use_device = True
+    elif use_device is not True and use_device:
         monkeypatch.setenv("SSM_PNP_BLOCKS", str(use_device)); use_device = True
     n, W, H, nfeat = 14, 640, 480, 500
     bgr0 = oracle.synth_frame(SEED, 21)[0]
