@@ -1279,12 +1279,36 @@ sgbm_speckle_tile(const int16_t* __restrict__ img, int w, int h, int newVal, int
         lp[i] = i;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SPK_TW * SPK_TH; i += 256) {
-        const int ly = i / SPK_TW, lx = i - ly * SPK_TW;
-        const int v = val[ly][lx];
-        if (v == newVal) continue;
-        if (lx < SPK_TW - 1) { const int r = val[ly][lx + 1]; if (r != newVal && abs(v - r) <= maxDiff) lds_union(lp, i, i + 1); }
-        if (ly < SPK_TH - 1) { const int b = val[ly + 1][lx]; if (b != newVal && abs(v - b) <= maxDiff) lds_union(lp, i, i + SPK_TW); }
+    // Rows first, without a single atomic: a wave owns whole tile rows (64 pixels = its lanes), a pixel is linked to its left neighbour or starts a RUN, and the
+    // run's first pixel -- the highest start at or below the lane in the ballot of starts -- is every member's parent.  Then only runs are united downwards:
+    // a pixel with a link to the pixel below it does the union unless the column to its left has such a link too AND both pixels continue their left
+    // neighbours' runs (the same two runs: that union is the left column's).  A smooth plane is one run per row and fifteen unions per tile; the version that
+    // united every pixel with its right and lower neighbour made 2 x 1024 (LDS compare-and-swap chains: 0.61 ms per 64 frame pairs).
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        static_assert(SPK_TW == 64 && SPK_TH % 4 == 0, "a wave per tile row");
+        bool linkL[SPK_TH / 4]; int start[SPK_TH / 4];
+#pragma unroll
+        for (int k = 0; k < SPK_TH / 4; k++) {
+            const int ly = wv * (SPK_TH / 4) + k;
+            const int v = val[ly][lane];
+            linkL[k] = lane > 0 && v != newVal && val[ly][lane - 1] != newVal && abs(v - val[ly][lane - 1]) <= maxDiff;
+            const unsigned long long starts = __ballot(!linkL[k]);                       // (lane 0 always starts a run)
+            start[k] = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+            lp[ly * SPK_TW + lane] = ly * SPK_TW + start[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPK_TH / 4; k++) {
+            const int ly = wv * (SPK_TH / 4) + k;
+            if (ly >= SPK_TH - 1) continue;                                                  // (wave-uniform)
+            const int v = val[ly][lane], b = val[ly + 1][lane];
+            const bool linkV = v != newVal && b != newVal && abs(v - b) <= maxDiff;
+            const bool belowL = lane > 0 && b != newVal && val[ly + 1][lane - 1] != newVal && abs(b - val[ly + 1][lane - 1]) <= maxDiff;
+            const unsigned long long lv = __ballot(linkV);
+            const bool implied = lane > 0 && ((lv >> (lane - 1)) & 1ull) && linkL[k] && belowL;
+            if (linkV && !implied) lds_union(lp, ly * SPK_TW + start[k], lp[(ly + 1) * SPK_TW + lane]);      // (the lower pixel's entry: its run's first pixel, or already an ancestor of it)
+        }
     }
     __syncthreads();
     // flatten; the size of every tile-local component is counted HERE (LDS atomics) and lands on its root pixel: the global pass that follows the edge
