@@ -1389,10 +1389,22 @@ sgbm_min_kernel(const int16_t* __restrict__ disp, int n, int* __restrict__ out)
 {
     disp += (size_t)blockIdx.y * n; out += blockIdx.y;
     int m = INT_MAX;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = min(m, (int)disp[i]);
+    // eight disparities per 16-byte load (a frame starts at any 2-byte boundary: unaligned loads), the tail one by one: with a 2-byte load per trip a thread
+    // walked 28 dependent round trips for 56 bytes
+    const int n8 = n >> 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += gridDim.x * blockDim.x) {
+        uint4 t; __builtin_memcpy(&t, disp + (size_t)8 * i, 16);
+        const uint32_t wv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) m = min(m, min((int)(int16_t)(wv[k] & 0xFFFFu), (int)(int16_t)(wv[k] >> 16)));
+    }
+    for (int i = 8 * n8 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = min(m, (int)disp[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMin(out, m);
+    __shared__ int wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMin(out, min(min(wm[0], wm[1]), min(wm[2], wm[3])));
 }
 __global__ void __launch_bounds__(256)
 sgbm_depth(const int16_t* __restrict__ disp, int w, int h, const int* __restrict__ min_disp, double baseline, double cu, double cv, double f,
