@@ -75,14 +75,16 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
     for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&smax, lmax);
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(maxord, smax);
+    // (a block whose maximum is not above the frame's running maximum has nothing to say: the atomics on that one word are a serial chain of ~0.4 us steps,
+    // 480 blocks per 1241 x 376 frame)
+    if (threadIdx.x == 0 && smax > __atomic_load_n(maxord, __ATOMIC_RELAXED)) atomicMax(maxord, smax);
 }
 // candidates: v > thr and v equals the 3x3 max of the thresholded map, interior pixels only.  key = value bits << 32 | ~index: a larger key is a
 // STRONGER corner in cv::goodFeaturesToTrack's walk (value descending, then raster index ascending)
 // Round 4: a block takes 1024 consecutive pixels (a wave 256: lane l looks at pixels l, l + 64, l + 128, l + 192 of them, so each of its four ballots is
 // 64 consecutive pixels = two whole words of the bit image), row / column of a pixel by a reciprocal multiplication: the thread-per-pixel version spent its
 // time on three barriers, one division sequence and two atomics per 256 pixels of almost no work (0.017 VALU instructions per clock, 19 us per 1241 x 376 frame)
-#define GC_PX 4
+#define GC_PX 16      // (round 4, later: 16 pixels per thread = 4096 per block -- the block's one atomic on the frame's counter is a ~0.4 us step of a serial chain, 456 of them per 1241 x 376 frame with 1024-pixel blocks)
 __global__ void __launch_bounds__(256)
 gftt_collect_kernel(const float* __restrict__ eig_all, int w, int h, const int* __restrict__ maxord_all, double quality, unsigned long long* __restrict__ keys_all,
                     int* __restrict__ count_all, int cap, int* __restrict__ cand_at_all, uint32_t* __restrict__ bits_all, int bits_words, uint32_t mul_w)
@@ -703,7 +705,7 @@ hipError_t k_quad_pyramids(const QuadBatch& q, int nb, hipStream_t s)
 // cv::goodFeaturesToTrack on the left image of frames [0, nb): pts[f][stride] (x, y), ncorner[f].  Workspace (GfttWork): eig nb*w*h floats; cand_at
 // nb*w*h ints, ZERO on entry (left zeroed); keys / kept nb*cap u64; deps nb*cap*GFTT_DEPS u32; depn / state nb*cap bytes; maxord / count / nkept nb ints;
 // overflow 1 int (set when a frame has more than cap candidates)
-size_t k_quad_gftt_bits_words(int w, int h) { return ((size_t)w * h + 1023) / 1024 * 32 + 2; }      // whole blocks of gftt_collect_kernel (1024 pixels) + the word a window may read past the end
+size_t k_quad_gftt_bits_words(int w, int h) { return ((size_t)w * h + 256 * GC_PX - 1) / (256 * GC_PX) * (8 * GC_PX) + 2; }      // whole blocks of gftt_collect_kernel (256 x GC_PX pixels) + the word a window may read past the end
 size_t k_quad_gftt_deps_per_candidate() { return GFTT_DEPS; }
 hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quality, double min_distance, const GfttWork& g, float* pts, int stride, int* ncorner, hipStream_t s)
 {
@@ -715,7 +717,7 @@ hipError_t k_quad_gftt(const QuadBatch& q, int nb, int max_corners, double quali
     const int tx = (w + ME_W - 1) / ME_W, ty = (h + ME_H - 1) / ME_H;
     mineig_kernel<<<dim3(tx * ty, nb), 256, 0, s>>>(q, g.eig, g.maxord);
     const int bw = (int)k_quad_gftt_bits_words(w, h);
-    gftt_collect_kernel<<<dim3((w * h + 1023) / 1024, nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at, g.cand_bits, bw, (uint32_t)(((1ull << 32) + w - 1) / w));
+    gftt_collect_kernel<<<dim3((w * h + 256 * GC_PX - 1) / (256 * GC_PX), nb), 256, 0, s>>>(g.eig, w, h, g.maxord, quality, g.keys, g.count, cap, g.cand_at, g.cand_bits, bw, (uint32_t)(((1ull << 32) + w - 1) / w));
     const dim3 gc((cap + 255) / 256, nb);
     gftt_deps_kernel<<<gc, 256, 0, s>>>(w, h, g.keys, g.count, cap, (float)min_distance, g.cand_at, g.cand_bits, bw, g.deps, g.depn, g.state);
     for (int r = 0; r < GFTT_ROUNDS; r++) gftt_round_kernel<<<gc, 256, 0, s>>>(g.count, cap, g.deps, g.depn, g.state);
