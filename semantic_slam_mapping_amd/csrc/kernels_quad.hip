@@ -25,7 +25,7 @@ __device__ __forceinline__ const short2* q_der(const QuadBatch& q, int side, int
 __global__ void __launch_bounds__(256)
 mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord_all)
 {
-    __shared__ uint8_t px[ME_H + 4][ME_W + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t px[ME_H + 4][ME_W + 4];
     __shared__ int16_t dx[ME_H + 2][ME_W + 2], dy[ME_H + 2][ME_W + 2];
     __shared__ int smax;
     const int w = q.w[0], h = q.h[0], stride = w, f = blockIdx.y;
@@ -34,6 +34,24 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
     const int tiles_x = (w + ME_W - 1) / ME_W;
     const int tx0 = (blockIdx.x % tiles_x) * ME_W, ty0 = (blockIdx.x / tiles_x) * ME_H;
     if (threadIdx.x == 0) smax = (int)0x80000000;
+    // a tile whose staged pixels all lie inside the image (five tiles of six at 1241 x 376) needs no reflection anywhere: the staged pixel of (ly, lx) is the
+    // image pixel, a derivative's neighbours are its LDS neighbours.  (Block-uniform; the border tiles keep the general path: six reflections per derivative.)
+    const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + ME_W + 2 <= w && ty0 + ME_H + 2 <= h;
+    if (interior) {
+        const uint8_t* base = img + (size_t)(ty0 - 2) * stride + (tx0 - 2);
+        for (int i = threadIdx.x; i < (ME_H + 4) * ((ME_W + 4) / 4); i += 256) {           // 68 = 17 dwords per staged row (any alignment: unaligned loads)
+            const int ly = i / ((ME_W + 4) / 4), q4 = i - ly * ((ME_W + 4) / 4);
+            uint32_t t; __builtin_memcpy(&t, base + (size_t)ly * stride + 4 * q4, 4);
+            *reinterpret_cast<uint32_t*>(&px[ly][4 * q4]) = t;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < (ME_H + 2) * (ME_W + 2); i += 256) {
+            const int ly = i / (ME_W + 2), lx = i - ly * (ME_W + 2);                        // derivative position (ty0 + ly - 1, tx0 + lx - 1) = staged (ly + 1, lx + 1)
+            const int vx = (px[ly][lx + 2] - px[ly][lx]) + 2 * (px[ly + 1][lx + 2] - px[ly + 1][lx]) + (px[ly + 2][lx + 2] - px[ly + 2][lx]);
+            const int vy = (px[ly + 2][lx] - px[ly][lx]) + 2 * (px[ly + 2][lx + 1] - px[ly][lx + 1]) + (px[ly + 2][lx + 2] - px[ly][lx + 2]);
+            dx[ly][lx] = (int16_t)vx; dy[ly][lx] = (int16_t)vy;
+        }
+    } else {
     for (int i = threadIdx.x; i < (ME_H + 4) * (ME_W + 4); i += 256) {
         const int ly = i / (ME_W + 4), lx = i - ly * (ME_W + 4);
         px[ly][lx] = img[(size_t)refl101d(ty0 + ly - 2, h) * stride + refl101d(tx0 + lx - 2, w)];
@@ -53,6 +71,7 @@ mineig_kernel(QuadBatch q, float* __restrict__ eig_all, int* __restrict__ maxord
             vy = (px[yp][xm] - px[ym][xm]) + 2 * (px[yp][sx] - px[ym][sx]) + (px[yp][xp] - px[ym][xp]);
         }
         dx[ly][lx] = (int16_t)vx; dy[ly][lx] = (int16_t)vy;
+    }
     }
     __syncthreads();
     const float s = (float)(1.0 / (255.0 * 4.0 * 3.0)), s2 = s * s;
