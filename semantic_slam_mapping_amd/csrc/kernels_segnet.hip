@@ -35,12 +35,26 @@ segnet_prep_kernel(const uint8_t* __restrict__ bgr, int sw, int sh, int dw, int 
     half8 lo;
 #pragma unroll
     for (int k = 0; k < 8; k++) lo[k] = (_Float16)0.f;
+    // the two neighbours of a source row are six consecutive bytes: ONE 8-byte load per row instead of six byte loads (the kernel spent 0.70 of its time in the
+    // texture-address units); the last pixels of the frame, whose window would end past the buffer, and the clamped right border take the byte form
+    if (sx1 == sx0 + 1 && ((size_t)sy1 * sw + sx0) * 3 + 8 <= (size_t)sw * sh * 3) {
+        unsigned long long r0, r1;
+        __builtin_memcpy(&r0, src + ((size_t)sy0 * sw + sx0) * 3, 8); __builtin_memcpy(&r1, src + ((size_t)sy1 * sw + sx0) * 3, 8);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int h0 = src[((size_t)sy0 * sw + sx0) * 3 + c] * a0 + src[((size_t)sy0 * sw + sx1) * 3 + c] * a1;
-        const int h1 = src[((size_t)sy1 * sw + sx0) * 3 + c] * a0 + src[((size_t)sy1 * sw + sx1) * 3 + c] * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        lo[c] = (_Float16)(float)(v & 255);
+        for (int c = 0; c < 3; c++) {
+            const int h0 = (int)((r0 >> (8 * c)) & 255u) * a0 + (int)((r0 >> (8 * c + 24)) & 255u) * a1;
+            const int h1 = (int)((r1 >> (8 * c)) & 255u) * a0 + (int)((r1 >> (8 * c + 24)) & 255u) * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            lo[c] = (_Float16)(float)(v & 255);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int h0 = src[((size_t)sy0 * sw + sx0) * 3 + c] * a0 + src[((size_t)sy0 * sw + sx1) * 3 + c] * a1;
+            const int h1 = src[((size_t)sy1 * sw + sx0) * 3 + c] * a0 + src[((size_t)sy1 * sw + sx1) * 3 + c] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            lo[c] = (_Float16)(float)(v & 255);
+        }
     }
     *reinterpret_cast<half8*>(out + ((size_t)blockIdx.y * dw * dh + p) * 8) = lo;           // [n][H][W][8]: B, G, R, 5 zeros (conv3x3_first_kernel's input)
 }
@@ -1082,6 +1096,11 @@ label_color_kernel(const uint8_t* __restrict__ ids, int sw, int sh, int dw, int 
 {
     // four consecutive pixels of a row per thread: the 12 colour bytes and the 4 ids leave as three + one aligned dword stores (one byte store per channel and
     // pixel ran at 0.85 TB/s); rows whose width is not a multiple of four keep the one-pixel form for their last pixels
+    // the palette as 16 packed words in LDS (a lane-indexed read of __constant__ memory is a vector-memory access per byte: with the per-pixel id taps the
+    // kernel spent 0.69 of its time in the texture-address units)
+    __shared__ uint32_t pal[16];
+    if (threadIdx.x < 16) pal[threadIdx.x] = threadIdx.x < 12 ? ((uint32_t)c_seg_palette[threadIdx.x][0] | ((uint32_t)c_seg_palette[threadIdx.x][1] << 8) | ((uint32_t)c_seg_palette[threadIdx.x][2] << 16)) : 0u;
+    __syncthreads();
     const int qpr = (dw + 3) >> 2;                          // quads per row
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= qpr * dh) return;
@@ -1091,6 +1110,28 @@ label_color_kernel(const uint8_t* __restrict__ ids, int sw, int sh, int dw, int 
     int v[4] = {0, 0, 0, 0};
     const int sy0 = nearest ? min((int)((y * (long long)sh) / dh), sh - 1) : yofs[y], sy1 = min(sy0 + 1, sh - 1);
     const int b0 = nearest ? 0 : ya[2*y], b1 = nearest ? 0 : ya[2*y+1];
+    // the quad's taps lie in 8 consecutive source ids of two rows when its columns do not reach the clamped right border: two 8-byte loads + the quad's x
+    // tables as two 16-byte loads instead of 16 + 12 scattered ones
+    bool quad = false;
+    if (!nearest && x0 + 4 <= dw && (dw & 3) == 0) {
+        const int4 XO = *reinterpret_cast<const int4*>(xofs + x0); const uint4 XA = *reinterpret_cast<const uint4*>(xa + 2 * x0);
+        const int xo[4] = {XO.x, XO.y, XO.z, XO.w}; const uint32_t xw[4] = {XA.x, XA.y, XA.z, XA.w};
+        if (xo[3] + 1 <= sw - 1 && xo[3] - xo[0] <= 6 && (size_t)sy1 * sw + xo[0] + 8 <= (size_t)sw * sh) {
+            quad = true;
+            unsigned long long r0, r1;
+            __builtin_memcpy(&r0, src + (size_t)sy0 * sw + xo[0], 8); __builtin_memcpy(&r1, src + (size_t)sy1 * sw + xo[0], 8);
+            auto fix = [&](int t) { return (pavement_to_road && t == 5) ? 4 : t; };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sh8 = 8 * (xo[k] - xo[0]);
+                const int a0 = (int)(int16_t)(xw[k] & 0xFFFFu), a1 = (int)(int16_t)(xw[k] >> 16);
+                const int h0 = fix((int)((r0 >> sh8) & 255u)) * a0 + fix((int)((r0 >> (sh8 + 8)) & 255u)) * a1;
+                const int h1 = fix((int)((r1 >> sh8) & 255u)) * a0 + fix((int)((r1 >> (sh8 + 8)) & 255u)) * a1;
+                v[k] = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
+            }
+        }
+    }
+    if (!quad) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x = x0 + k;
@@ -1101,13 +1142,13 @@ label_color_kernel(const uint8_t* __restrict__ ids, int sw, int sh, int dw, int 
         const int h1 = id_at(sy1, sx0) * a0 + id_at(sy1, sx1) * a1;
         v[k] = ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 255;
     }
+    }
     const size_t o = (size_t)blockIdx.y * dw * dh + (size_t)y * dw + x0;
     uint8_t c[12];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint8_t b = 0, g = 0, r = 0;
-        if (v[k] < 12) { b = c_seg_palette[v[k]][0]; g = c_seg_palette[v[k]][1]; r = c_seg_palette[v[k]][2]; }
-        c[3*k] = b; c[3*k+1] = g; c[3*k+2] = r;
+        const uint32_t pc = pal[min(v[k], 15)];                // (ids 12 .. 255: black, like the entries 12 .. 15)
+        c[3*k] = (uint8_t)(pc & 255u); c[3*k+1] = (uint8_t)((pc >> 8) & 255u); c[3*k+2] = (uint8_t)(pc >> 16);
     }
     const bool whole = x0 + 4 <= dw && ((dw & 3) == 0);     // aligned dword stores need every row to start on a multiple of four pixels
     if (whole) {
