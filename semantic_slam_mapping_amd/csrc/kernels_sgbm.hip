@@ -34,11 +34,11 @@
 #define SG_DISP_SCALE 16
 
 // ------------------------------------------------------------------ pre-filter + BT intervals
-// per image one plane of uint4 per pixel: .x = the value, .y = min(value, half-sample neighbours), .z = max(...), each word (clipped x-Sobel | raw
-// intensity << 16); .w = 0.  The two cost terms of a pixel pair are then the two 16-bit halves of the same packed subtract / max / min instructions,
+// per image one plane of three words per pixel: .x = the value, .y = min(value, half-sample neighbours), .z = max(...), each word (clipped x-Sobel | raw
+// intensity << 16).  The two cost terms of a pixel pair are then the two 16-bit halves of the same packed subtract / max / min instructions,
 // and a pixel's three words are ONE 16-byte LDS read in the cost kernel.
 __global__ void __launch_bounds__(256)
-sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int w, int h, int ftzero, uint4* __restrict__ planes_all)
+sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int w, int h, int ftzero, uint3* __restrict__ planes_all)
 {
     // blockIdx.z = frame * 2 + side; a frame's 2 planes: left, right
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -46,7 +46,7 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
     const size_t np = (size_t)w * h;
     const int f = blockIdx.z >> 1, side = blockIdx.z & 1;
     const uint8_t* img = (side ? right : left) + (size_t)f * np;
-    uint4* planes = planes_all + ((size_t)f * 2 + (size_t)side) * np;
+    uint3* planes = planes_all + ((size_t)f * 2 + (size_t)side) * np;
     const uint8_t* row = img + (size_t)y * w;
     const int n1 = y > 0 ? -w : 0, s1 = y < h - 1 ? w : 0;
     auto grad = [&](int xx) -> int {            // prow[x]: tab[...] for 1 <= x <= w-2, tab[0] = ftzero at the two border columns
@@ -62,7 +62,7 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
         const int vl = x > 0 ? (v + (c ? raw(x - 1) : grad(x - 1))) / 2 : v, vr = x < w - 1 ? (v + (c ? raw(x + 1) : grad(x + 1))) / 2 : v;
         pv |= (uint32_t)v << (16 * c); pmin |= (uint32_t)min(min(vl, vr), v) << (16 * c); pmax |= (uint32_t)max(max(vl, vr), v) << (16 * c);
     }
-    planes[(size_t)y * w + x] = make_uint4(pv, pmin, pmax, 0u);
+    planes[(size_t)y * w + x] = make_uint3(pv, pmin, pmax);      // 12 bytes per pixel in memory; the cost kernel widens them to the 16-byte LDS words
 }
 // The matching cost C(y, x, d) = P2 + sum over the SAD window of the Birchfield-Tomasi pixel cost, in ONE streaming kernel (it was three volume kernels:
 // pixel cost -> u8 volume, horizontal box -> u16 volume, vertical box -> C; 8 bytes of HBM traffic per volume entry instead of 2).
@@ -81,7 +81,7 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
 typedef short sg_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ sg_s2 sg_as_s2(uint32_t v) { return __builtin_bit_cast(sg_s2, v); }
 template <bool EDGE, int CD, int CSW2, int CTX, int MAXCW>
-__device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes_all, int w, int h, int minD, int Drt, int minX1, int w1, int SW2rt, int P2, int TXrt, uint16_t* __restrict__ C_all)
+__device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes_all, int w, int h, int minD, int Drt, int minX1, int w1, int SW2rt, int P2, int TXrt, uint16_t* __restrict__ C_all)
 {
     extern __shared__ __align__(16) uint8_t sg_smem[];
     const int D = CD ? CD : Drt, SW2 = CD ? CSW2 : SW2rt, TX = CD ? CTX : TXrt;
@@ -99,7 +99,8 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
     const int cx0 = chunk * cw, cx1 = min(min(cx0 + cw, TX), w1 - xs);      // this thread's strip columns [cx0, cx1)
     const int ncol = active ? max(cx1 - cx0, 0) : 0;
     // staging: thread k < AW + RW fetches one pixel word of the left / right row
-    const uint4* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
+    const uint3* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
+    auto wide = [](const uint3 t) { return make_uint4(t.x, t.y, t.z, 0u); };
     if (tid < AW + RW) {
         const bool isl = tid < AW;
         const int xi = min(max(isl ? xs - SW2 + minX1 + tid : xs - SW2 + minX1 - minD - (D - 1) + (tid - AW), 0), w - 1);   // columns outside the image are never used by a valid cost
@@ -121,7 +122,7 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
         const uint4* lrow = lrow2 + (size_t)(r & 1) * (AW + RW); const uint4* rrow = lrow + AW;
         const uint8_t* pxd = pixrow + d;
         auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
-        if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = src[(size_t)(r + 2) * w]; }      // row r + 1 for the next trip; row r + 2 on its way
+        if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = wide(src[(size_t)(r + 2) * w]); }      // row r + 1 for the next trip; row r + 2 on its way
         if (active) {
             const sg_s2 zero = {0, 0};
             for (int i = chunk; i < AW; i += nchunk) {
@@ -156,7 +157,7 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
             }
         }
     };
-    if (src) { lrow2[tid] = src[0]; if (h > 1) pre = src[(size_t)w]; }      // row 0 staged, row 1 in registers
+    if (src) { lrow2[tid] = wide(src[0]); if (h > 1) pre = wide(src[(size_t)w]); }      // row 0 staged, row 1 in registers
     __syncthreads();
     row(0, std::integral_constant<int, 0>());
     for (int r = 1; r <= SH2; r++) row(r, std::integral_constant<int, 1>());
@@ -172,7 +173,7 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint4* __restrict__ planes
 // instantiation; the strips between them read their apron without clamps.  One launch for all strips (block-uniform branch).
 template <int CD, int CSW2, int CTX, int MAXCW>
 __global__ void __launch_bounds__(SGC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-sgbm_cost_kernel(const uint4* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, int SW2, int P2, int TX, int tail, uint16_t* __restrict__ C_all)
+sgbm_cost_kernel(const uint3* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, int SW2, int P2, int TX, int tail, uint16_t* __restrict__ C_all)
 {
     if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip<true, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
     else sgbm_cost_strip<false, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
@@ -1629,7 +1630,7 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     }
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     uint8_t* q = (uint8_t*)workspace;
-    uint4* planes = (uint4*)q; q += al(32 * np);
+    uint3* planes = (uint3*)q; q += al(32 * np);                 // (12 bytes per pixel and image are used)
     const size_t vol = (size_t)w1 * h * D * nb;
     uint16_t* C = (uint16_t*)q; q += al(vol * 2);
     uint16_t* Lv[5];
