@@ -59,14 +59,15 @@ def algorithmic_bytes(stage, P, nkp):
 STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "resize_kernel"], "fast": ["fast_kernel", "fast_need_kernel", "fast_retry_kernel"], "octree": ["octree_kernel"],
                  "blur": ["blur_kernel", "blur_mfma_kernel"], "describe": ["kp_prepare_kernel", "orient_kernel", "angle_kernel", "brief_kernel"],
                  "match": ["match_expand_kernel", "match_mfma_kernel", "match_compact_kernel"],
-                 "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel", "map_stream2_kernel"]}
+                 "map_fuse": ["class_bits_kernel", "vdilate_bits_kernel", "map_stream_kernel", "map_stream2_kernel"],
+                 "segnet": ["segnet_prep_kernel", "conv3x3_", "unpool2x2_kernel", "label_color_kernel", "argmax_kernel"]}
 
 
-def measured_traffic(stage, frames_per_launch):
+def measured_traffic(stage, frames_per_launch, suffix="traffic.json"):
     """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes;
     FETCH_SIZE x 2 on gfx950 for the kernels that read 16 B per lane, raw for the others: scripts/pmc_traffic.py), or None"""
     try:
-        k = json.load(open(latest_profile("traffic.json")))["kernels"]
+        k = json.load(open(latest_profile(suffix)))["kernels"]
         return round(sum(v.get("total_bytes_per_frame", v["total_bytes_per_frame_fetch_x2"]) for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage])) * frames_per_launch)
     except Exception:
         return None
@@ -178,7 +179,8 @@ def stereo_main(args):
     ctx.set_profiling(0)
     res = ctx.stereo_seq_fetch(out, F, Wd, Hd, 1 | 4)
     if rank != 0:
-        return
+        ctx.close()
+        return None
     nser = args.steps if args.serial_only else max(1, min(args.steps, 3))
     frames = world * F * args.steps
     sg_ms_launch = stage_acc["sgbm"][0] / max(stage_acc["sgbm"][1], 1)
@@ -192,7 +194,7 @@ def stereo_main(args):
         orc = Oracle()
         t1 = time.perf_counter(); ref = orc.sgbm(L[1], R[1], orc.sgbm_params()); orc.disparity_to_depth(ref, **KITTI); tc = time.perf_counter() - t1
         t1 = time.perf_counter(); qm = orc.quad_track(L[1], R[1], L[0], R[0]); tq = time.perf_counter() - t1
-        cpu = {"value": round(1.0 / (tc + tq), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+        cpu = {"value": round(1.0 / (tc + tq), 3), "unit": "frame pairs/s", "cores": 1, "kind": "port",
                "sample": "one frame pair of the same sequence: oracle/ quad matcher + SGBM + depth conversion (C, 1 thread); the VO is below a millisecond",
                "ms_per_frame": {"sgbm": round(tc * 1e3, 2), "quad_track": round(tq * 1e3, 2)},
                "quad_matches_equal_gpu": bool(int(res["nquad"][1]) == len(qm) and res["quad"][1, :len(qm)].tobytes() == qm.tobytes())}
@@ -203,7 +205,8 @@ def stereo_main(args):
     except Exception:
         pass
     nq = res["nquad"][1:]
-    line = {"metric": "frames/sec semantic-mapping, 640x480 RGB-D", "value": round(frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+    line = {"metric": "frame pairs/sec stereo front end (quad matcher + SGBM depth + stereo VO), 1241x376 rectified stereo", "value": round(frames / dt, 2), "unit": "frame pairs/s",
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i16", "data": "synthetic",
             "config": {"workload": "configs[3] stages: synthetic rectified stereo sequence 1241x376 (seeded textured planes, 3 px/frame pan), per frame pair: quad matcher "
@@ -218,7 +221,10 @@ def stereo_main(args):
                          "stages_ms_per_frame": {k: round(v[0] / (F * nser), 4) for k, v in stage_acc.items()},
                          "stages_ms_per_frame_overlapped": {k: round(v[0] / (F * args.steps), 4) for k, v in stage_ovl.items()}},
             "cpu_baseline": cpu}
-    print(json.dumps(line))
+    for p in (dl, dr, ds):
+        ctx.dev_free(p)
+    ctx.close()
+    return line
 
 
 def spawn_ranks(n):
@@ -299,7 +305,7 @@ def cpu_all_cores(orc, frames_per_thread, leaf):
             "sample": f"{cores} threads x {frames_per_thread} consecutive frames each (blocks of the same stream, synth included: {dt:.1f} s wall)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -329,11 +335,16 @@ def main():
     ap.add_argument("--no-verify-whole", dest="verify_whole", action="store_false", help="N>1: skip rank 0's rebuild of the whole-stream map that the merged "
                     "map is compared with byte for byte (the cross-rank CRC check always runs)")
     ap.add_argument("--stereo", action="store_true", help="configs[3]: the stereo stages on 1241x376 pairs (quad matcher, SGBM depth, stereo VO)")
-    args = ap.parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))              # nothing below has run: no torch import, no HIP call in this process
-    if args.stereo:
-        return stereo_main(args)
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false", help="default run (N = 1, no mode flag): skip the short configs[2] / configs[3] / "
+                    "closed-pose-loop legs that are reported as `other_configs` beside the configs[1] headline")
+    ap.add_argument("--other-scale", type=float, default=1.0, help="size factor of the `other_configs` legs (tests: 0.1 with a short headline; 1.0 = 256 SegNet frames, 256 stereo pairs, 400 pose frames)")
+    args = ap.parse_args(argv)
+    args.pose_cpu_sample = 0
+    return args
+
+
+def rgbd_main(args):
+    """configs[1] (default), configs[2] (--segnet), configs[4] (--gpus N --total-frames T): returns the JSON line (rank 0) or None"""
     if args.solve_poses and args.pose_threads > 1:
         # HIP multiplexes streams onto 4 hardware queues by default and two chains that share a queue run one after the other (scripts/tracker_concurrency.py):
         # the runtime reads this before its first call, so it is set before torch is imported
@@ -522,7 +533,7 @@ def main():
                 sem[k * H * W * 3:(k + 1) * H * W * 3] = torch.roll(s0, shifts=(k, 2 * k), dims=(0, 1)).reshape(-1)
             dep[: PF * H * W] = 2000
             torch.cuda.synchronize()
-        extra = None
+        extra = None; NT = 1
         for rep in range(2):                             # pass 0 warms (tracker scratch, first-use costs), pass 1 is reported
             t1 = time.perf_counter()
             ctx.map_clear()
@@ -572,6 +583,30 @@ def main():
                           "ms": {"orb_match": round((t2 - t1) * 1e3, 2), "pose_chain": round((t3 - t2) * 1e3, 2), "map": round((t4 - t3) * 1e3, 2)},
                           "tracked_frames": int(info_s["tracked"].sum()), "lost_events": int((info_s["state"] == 2).sum()), "voxels": int(nv),
                           "note": "Tracker::updateFrame for every frame (src/track.cpp:140-200): the PnP chain is serial by construction (frame f starts from frame f-1's pose)"}
+        # roofline of the chain: the f64 operations PnPSolver::solvePnP's passes over the edges need (include/ssm/pnp_core.h, counted from the source: an edge's chi2
+        # term = edge_map 18 + edge_error 8 + chi2 3 + Huber 2 = 31; a Levenberg iteration adds the Jacobian 22 + weights 6 + the 40 non-zero accumulations x 2 + 10 = 118)
+        # x the passes and level-0 edges the device chain counted (ssm_tracker_work), against the f64 vector rate of the CUs the chain occupies
+        if args.pnp_device and NT == 1:
+            wk = trk.work(); nblk = int(os.environ.get("SSM_PNP_BLOCKS", "8"))
+            fl = (31.0 + 118.0) * wk[2] + 31.0 * wk[3]
+            sec = solve_info["ms"]["pose_chain"] * 1e-3 * 2                      # the counters ran over both passes
+            peak = 78.6e12 * nblk / 256
+            solve_info["work"] = {"levenberg_iterations_per_frame": round(wk[0] / (2.0 * PF), 1), "chi2_passes_per_frame": round(wk[1] / (2.0 * PF), 1),
+                                  "edges_per_fused_pass": round(wk[2] / max(wk[0], 1), 1)}
+            solve_info["roofline"] = {"bound": "valu_f64", "kernel": "pnp_chain_kernel (%d blocks = %d CUs)" % (nblk, nblk), "achieved": round(fl / sec / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "GFLOP/s",
+                                      "frac": round(fl / sec / peak, 4), "traffic": None,
+                                      "note": "a serial chain: ~28 Levenberg iterations + ~54 trials per frame, each a pass over ~2700 edges followed by a 6 x 6 solve that the next pass waits for; "
+                                              "latency-bound by construction (DESIGN.md s.5.1), the peak is that of the CUs it occupies (78.6 TFLOP/s f64 vector x blocks / 256)"}
+        if args.pose_cpu_sample and args.pose_stream == "rigid":
+            # cpu_baseline of the pose loop: the same chain (include/ssm/pnp_core.h, the arithmetic oracle/pnp.c pins) on ONE host core over a bounded sample of the sequences
+            ns = min(args.pose_cpu_sample, PF)
+            o2 = ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None, None, PF, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH); ctx.sync()
+            ht = ssm.Tracker(ctx, use_device=False)
+            th0 = time.perf_counter()
+            for a0 in range(0, ns, CH):
+                ht.reset(); ht.run(view(a0), min(CH, ns - a0))
+            solve_info["host_chain_ms_per_frame"] = round((time.perf_counter() - th0) * 1e3 / ns, 3); solve_info["host_chain_sample_frames"] = ns
+            ht.close()
         trk.close()
         for e in (extra or []): e.close()
         ctx.map_clear()
@@ -606,7 +641,9 @@ def main():
             from semantic_slam_mapping_amd import segnet_model
             tf = segnet_model.flops() * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv3x3_dma2_kernel + conv3x3_first_kernel (26 conv layers with fused pool / un-pool / ArgMax, prep, colouring: whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
-                    "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None}
+                    "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": measured_traffic("segnet", frames_per_launch, "segnet_traffic.json")}
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = os.path.relpath(latest_profile("segnet_traffic.json"), ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --segnet`, scripts/collect_profiles.sh pmc_segnet; per frame x frames per launch group, not measured in this run)"
         elif dom == "match":
             # K6 runs on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4 on descriptors expanded to +-1 FP4 elements): 2 x 256 operations per
             # descriptor pair, against the dense FP4 peak (4 x the bf16 rate: MI355X_MICROARCH.md, Matrix cores)
@@ -636,7 +673,7 @@ def main():
                                          "note": "all kernels of a frame (ORB, match, map) at the timed rate `value`, two chains overlapped"}
         except Exception:
             pass
-        if roof.get("traffic") is not None:     # `traffic` is NOT measured in this run: it is this kernel's figure from the committed counter passes of the same command
+        if roof.get("traffic") is not None and "traffic_source" not in roof:     # `traffic` is NOT measured in this run: it is this kernel's figure from the committed counter passes of the same command
             roof["traffic_source"] = os.path.relpath(latest_profile("traffic.json"), ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/collect_profiles.sh pmc; per frame x frames per launch)"
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}
         roof["stages_us_per_frame_overlapped"] = {k: round(v[0] / args.steps / F * 1e3, 3) for k, v in sorted(stage_ovl.items(), key=lambda kv: -kv[1][0])}
@@ -688,7 +725,107 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    del bgr, dep, sem, pose, tab_buf
     ctx.close()
+    return line
+
+
+def segnet_cpu_baseline(pipeline_cpu):
+    """configs[2] on the host: the reference runs Caffe-SegNet's ForwardPrefilled (src/segnet.cpp:99) before the per-frame path; here one 360 x 480 forward of the same
+    topology and seeded weights through PyTorch-CPU fp32 (tests/segnet_ref.py: the checker of the SegNet kernels, timed here as the baseline) on every core the box
+    grants, + the configs[1] oracle pipeline's per-frame time"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import segnet_ref
+    from semantic_slam_mapping_amd import segnet_model
+    wts = segnet_model.make_weights(1234)
+    x = np.random.default_rng(7).integers(0, 256, (3, 360, 480)).astype(np.uint8)
+    cores = torch.get_num_threads()
+    segnet_ref.forward(x, wts)                              # first call: thread pool, allocator
+    t0 = time.perf_counter(); n = 0
+    while n < 2 or (time.perf_counter() - t0 < 6.0 and n < 8):
+        segnet_ref.forward(x, wts); n += 1
+    t_seg = (time.perf_counter() - t0) / n
+    t_pipe = 1.0 / pipeline_cpu["value"] if pipeline_cpu else 0.0
+    return {"value": round(1.0 / (t_seg + t_pipe), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d SegNet forwards (PyTorch-CPU fp32, %d threads, 213.6 GFLOP each: %.0f GFLOP/s) + the configs[1] oracle pipeline's per-frame time (1 thread)" % (n, cores, segnet_model.flops() / t_seg / 1e9),
+            "ms_per_frame": {"segnet": round(t_seg * 1e3, 1), "pipeline": round(t_pipe * 1e3, 2)}}
+
+
+def sub_line(line, **extra):
+    """what `other_configs` keeps of a full bench line"""
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "per_frame")
+    d = {k: line[k] for k in keep if k in line}
+    d.update(extra)
+    return d
+
+
+def other_configs(args, head):
+    """The default run's extra legs: configs[2] (SegNet on the GPU), configs[3] (stereo front end) and the closed pose loop, short enough
+    for the whole command to stay within ~90 s, each with its own value / ms_per_step / steps / roofline / cpu_baseline.  The headline `value` is never touched."""
+    import copy
+    sc = args.other_scale
+    out = {}
+    t_all = time.perf_counter()
+    # ---- configs[2]: the SegNet stage in front of the map stage (labels from the network instead of the precomputed masks)
+    a = copy.copy(args)
+    a.segnet, a.solve_poses, a.frames, a.batch, a.steps, a.warmup = True, False, max(16, int(256 * sc)), max(8, int(128 * sc)), 3, 1
+    a.no_cpu = True                                        # its CPU leg is segnet_cpu_baseline below (the pipeline part is the headline's sample)
+    t0 = time.perf_counter()
+    try:
+        ln = rgbd_main(a)
+        if not args.no_cpu:
+            ln["cpu_baseline"] = segnet_cpu_baseline(head.get("cpu_baseline"))
+        out["configs[2]"] = sub_line(ln, wall_s=round(time.perf_counter() - t0, 1))
+    except Exception as e:                                  # a failing leg must not take the headline with it; it is reported
+        out["configs[2]"] = {"error": repr(e)}
+    # ---- configs[3]: the stereo front end on resident 1241 x 376 pairs
+    a = copy.copy(args)
+    a.stereo, a.frames, a.steps, a.warmup, a.stereo_batch = True, max(8, int(256 * sc)), 3, 1, max(4, min(args.stereo_batch, int(64 * sc)))
+    t0 = time.perf_counter()
+    try:
+        out["configs[3]"] = sub_line(stereo_main(a), wall_s=round(time.perf_counter() - t0, 1))
+    except Exception as e:
+        out["configs[3]"] = {"error": repr(e)}
+    # ---- the closed pose loop: measured inside the headline's process on its resident stream (rgbd_main's --solve-poses leg); re-shaped here
+    sp = head.pop("solve_poses", None)
+    if sp is not None:
+        cpu = None
+        if "host_chain_ms_per_frame" in sp and head.get("cpu_baseline"):
+            c1 = head["cpu_baseline"]["ms_per_frame"]
+            t_front = (c1["orb"] + c1["match"] + c1["mask"] + c1["backproject"] + c1["voxel"]) * 1e-3
+            cpu = {"value": round(1.0 / (t_front + sp["host_chain_ms_per_frame"] * 1e-3), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "the pose chain of the first %d frames of the same sequences on one host core (include/ssm/pnp_core.h = the arithmetic of oracle/pnp.c) + the configs[1] "
+                             "oracle pipeline's per-frame time" % sp["host_chain_sample_frames"],
+                   "ms_per_frame": {"pose_chain": sp["host_chain_ms_per_frame"], "front_end": round(t_front * 1e3, 2)}}
+        ms = sp["ms"]
+        out["pose_loop"] = {"metric": "frames/sec with the poses solved by the pipeline (Tracker::updateFrame for every frame, src/track.cpp:140-200): ORB + match tables -> PnP chain -> map stage with the solved poses",
+                            "value": sp["frames_per_s"], "unit": "frames/s", "steps": 1, "warmup": 1, "ms_per_step": round(ms["orb_match"] + ms["pose_chain"] + ms["map"], 2), "dtype": "f64",
+                            "config": {"workload": "%d frames of the rigid stream (frame 0 of configs[1] seen by a panning camera: every frame tracks) as independent 20-frame sequences, one sequence in flight" % sp["frames"]},
+                            "pose_chain_ms_per_frame": round(ms["pose_chain"] / sp["frames"], 4),
+                            "roofline": sp.get("roofline"), "cpu_baseline": cpu, "detail": {k: v for k, v in sp.items() if k not in ("roofline",)}}
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))              # nothing below has run: no torch import, no HIP call in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the default run (the command the driver times: N = 1, no mode flag) also carries configs[2], configs[3] and the closed pose loop as `other_configs`
+    default_run = (world == 1 and args.other_configs and (args.frames == 1000 or args.other_scale != 1.0)
+                   and not (args.stereo or args.segnet or args.solve_poses or args.serial_only or args.total_frames > 0 or os.environ.get("SSM_FORCE_MERGE") == "1"))
+    if args.stereo:
+        line = stereo_main(args)
+    else:
+        if default_run:                               # the pose loop rides on the headline's resident stream (after its timed region and its serialised pass)
+            args.solve_poses, args.pnp_device, args.pose_frames, args.pose_stream, args.pose_threads = True, 1, max(40, int(400 * args.other_scale)), "rigid", 1
+            args.pose_cpu_sample = 0 if args.no_cpu else 100
+        line = rgbd_main(args)
+        if default_run and line is not None:
+            line["other_configs"] = other_configs(args, line)
     if line is not None:
         # RCCL prints a version banner through C stdio when a communicator is created; flush it first so that the JSON line is the LAST line of stdout
         try:

@@ -231,6 +231,9 @@ const char* ssm_tracker_last_error(const ssm_tracker* t);
 /* frames solved by the device chain / by the host path so far (use_device = 1: the host path takes the first frame, lostRecover, and the frames whose
  * refFrames deque reaches behind the match-table window after a tracking failure) */
 int  ssm_tracker_stats(const ssm_tracker* t, int64_t* device_frames, int64_t* host_frames);
+/* what the device chain has computed so far, for a roofline of PnPSolver::solvePnP (src/pnp.cpp:5-118: g2o's optimize(10) x 4 rounds): work[0] = Levenberg iterations
+ * (one pass over the edges each: chi2 + normal equations), work[1] = chi2 passes (one per trial + one per optimize), work[2] / work[3] = level-0 edges those evaluated */
+int  ssm_tracker_work(const ssm_tracker* t, int64_t work[4]);
 
 /* ---- QuadFeatureMatch (include/quadmatcher.hpp:51-136, src/quadmatcher.cpp): the stereo quad matcher of the KITTI path
  * (Tracker::estimateVO, src/track.cpp:45-55).  Images are 8-bit gray, any size (buffers are re-sized on demand). */

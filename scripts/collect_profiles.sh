@@ -22,6 +22,12 @@ elif [ "$1" = "pmc_segnet" ]; then
   rm -rf $O/p_seg_pmc
   timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p_seg_pmc -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg_pmc.log 2>&1
   python3 scripts/segnet_layers.py $O/p_seg_pmc 64 $O/segnet_layers.md; tail -2 $O/segnet_layers.md
+  # HBM traffic of the SegNet stage (roofline.traffic of configs[2]): one serialised step of 128 frames = two SegNet launch groups of 64
+  rm -rf $O/p_fetch_seg $O/p_write_seg
+  A="--segnet --frames 128 --batch 128 --steps 1 --warmup 0 --no-cpu --serial-only"
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_seg -o runc -- python3 bench.py $A > $O/p_fetch_seg.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_seg -o runc -- python3 bench.py $A > $O/p_write_seg.log 2>&1
+  tail -1 $O/p_fetch_seg.log | cut -c1-200
 elif [ "$1" = "pmc_stereo" ]; then
   rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
   A="--stereo --stereo-batch 32 --frames 64 --steps 1 --warmup 0 --no-cpu --serial-only"

@@ -111,6 +111,7 @@ SYMBOLS = {
     "ssm_tracker_run": (_I, [_P, C.POINTER(SeqOutDev), _I, _P, _P]),
     "ssm_tracker_last_error": (C.c_char_p, [_P]),
     "ssm_tracker_stats": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ssm_tracker_work": (_I, [_P, C.POINTER(C.c_int64 * 4)]),
     "ssm_quad_track": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "ssm_gftt": (_I, [_P, _P, _I, _I, _I, _I, _D, _D, _P, _I, C.POINTER(_I)]),
     "ssm_lk_track": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _D, _D]),

@@ -131,6 +131,12 @@ class Tracker:
         self.lib.ssm_tracker_stats(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def work(self):
+        """device chain so far: (Levenberg iterations, chi2 passes, edges evaluated by the iterations' fused passes, edges evaluated by the chi2 passes)"""
+        w = (C.c_int64 * 4)()
+        self.lib.ssm_tracker_work(self.h, C.byref(w))
+        return tuple(int(x) for x in w)
+
     def close(self):
         if self.h:
             self.lib.ssm_tracker_destroy(self.h); self.h = None

@@ -47,6 +47,7 @@ struct PcShared {
     double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
     int cont, term;               // loop controls of the Levenberg iteration, decided by wave 0
+    long long work[4];            // thread 0: fused passes, chi2 passes, active edges evaluated by each kind (ssm_tracker_work: the numerator of bench.py's pose-loop roofline)
     // the cluster form (round 4, gridDim.x = G > 1 blocks per chain): this block evaluates the edges of lanes [b 1024 / G, (b + 1) 1024 / G) only and the G blocks
     // trade their groups' partial sums through tagged granules in global memory (pc_lane_sum)
     unsigned long long* xmb; unsigned* xfail; unsigned xseq;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int n
 // is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
 // controls through LDS.
 template <bool CL>
-__device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne, const Camera& k, double delta, int iterations, PcShared& sh)
+__device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne, int nact, const Camera& k, double delta, int iterations, PcShared& sh)
 {
     const Pose& P = sh.P;                                                        // in / out: the estimate lives in LDS (uniform reads; 24 registers saved)
     int any = 0;
@@ -203,6 +204,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
     PROF_T0
     for (int it = 0; it < iterations; it++) {
         pc_chi_build<CL>(L, err, ne, P, k, delta, sh);
+        if (threadIdx.x == 0) { sh.work[0] += 1; sh.work[2] += nact; }
         PROF(1) PROF_CNT(6)
         if (w0) {
             chi = sh.tot[NACC];
@@ -220,6 +222,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
             __syncthreads();
             PROF(2)
             pc_chi<CL>(L, err, ne, P, k, delta, sh);
+            if (threadIdx.x == 0) { sh.work[1] += 1; sh.work[3] += nact; }
             PROF(3) PROF_CNT(7)
             if (w0) {
                 const double chi_new = sh.tot[NACC];
@@ -239,6 +242,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
         if (term) break;
     }
     pc_chi<CL>(L, err, ne, P, k, delta, sh);
+    if (threadIdx.x == 0) { sh.work[1] += 1; sh.work[3] += nact; }
 }
 // ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
 template <bool CL>
@@ -256,14 +260,14 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         ne += tot;
     }
     __syncthreads();
-    int good = ne;
+    int good = ne, nact = ne;                                                    // nact: edges at level 0 in the coming round
     if (threadIdx.x == 0) { Pose i0; pose_from_iso(T, i0); sh.init = i0; }
     const Pose& P = sh.P;
     for (int it = 0; it < 4; it++) {
         __syncthreads();
         if (threadIdx.x == 0) sh.P = sh.init;
         __syncthreads();
-        pc_optimize<CL>(L, err, ne, cam, delta, 10, sh);
+        pc_optimize<CL>(L, err, ne, nact, cam, delta, 10, sh);
         // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
         // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
@@ -293,7 +297,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         __syncthreads();
         int allout = 0; for (int k = 0; k < NGROUP; k++) allout += sh.wcnt[k];
         __syncthreads();
-        good -= allout;
+        good -= allout; nact = ne - allout;
         if (good < 5) break;
     }
     if (threadIdx.x == 0) { const Pose Pf = sh.P; pose_to_iso(Pf, T); }
@@ -325,7 +329,7 @@ pnp_chain_kernel(PnpChainArgs a)
     const int tid = threadIdx.x;
     if (CL && tid == 0) { sh.xmb = a.xchg; sh.xfail = a.xfail; sh.xseq = 0; }
     // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
-    if (tid == 0) for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; }
+    if (tid == 0) { for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; } for (int k = 0; k < 4; k++) sh.work[k] = 0; }
 #ifdef SSM_PNP_PROF
     if (tid == 0) for (int k = 0; k < 8; k++) sh.prof[k] = 0;
 #endif
@@ -403,6 +407,7 @@ pnp_chain_kernel(PnpChainArgs a)
     if (tid == 0) {
         for (int k = 0; k < 16; k++) { a.state->speed[k] = sh.speed[k]; a.state->last_pose[k] = sh.last[k]; }
         a.state->nref = nref; a.state->cnt_lost = cnt_lost; a.state->stopped_at = stopped;
+        for (int k = 0; k < 4; k++) a.state->work[k] = sh.work[k];
         if (CL && __hip_atomic_load(a.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) a.state->stopped_at = -1;     // an exchange timed out: the host rejects the range
 #ifdef SSM_PNP_PROF
         for (int k = 0; k < 8; k++) a.state->prof[k] = sh.prof[k];
@@ -417,6 +422,7 @@ pnp_solve_kernel(PnpSolveArgs a)
     extern __shared__ __align__(16) unsigned char pc_dyn[];
     LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;
     if (threadIdx.x < 16) sh.T[threadIdx.x] = a.T[threadIdx.x];
+    if (threadIdx.x < 4) sh.work[threadIdx.x] = 0;
     __syncthreads();
     const int m = pc_solve<false>(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
     __syncthreads();

@@ -9,6 +9,7 @@ struct PnpState {
     double ref_pose[SSM_TRACK_MAXREF][16];           // refFrames deque, oldest first
     int32_t ref_idx[SSM_TRACK_MAXREF];               // their frame indices relative to the current ssm_seq_process call (negative: frames of the previous call)
     int32_t nref, cnt_lost, stopped_at, pad;
+    long long work[4];                               // out: fused passes, chi2 passes, active edges evaluated by the fused / by the chi2 passes of this launch
 #ifdef SSM_PNP_PROF
     long long prof[8];                               // shader clocks per section (thread 0), ablation builds only
 #endif

@@ -30,6 +30,7 @@ struct ssm_tracker {
     uint8_t *d_inl = nullptr, *d_dec = nullptr; void* d_edges = nullptr; double2* d_err = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
     unsigned long long* d_xchg = nullptr; int blocks = 1;      // the cluster form of the device chain (SSM_PNP_BLOCKS, kernels_pnp.hip): blocks per chain, their exchange ring
     long device_frames = 0, host_frames = 0;
+    int64_t work[4] = {0, 0, 0, 0};       // the device chain's passes over the edges (ssm_tracker_work)
     hipStream_t own = nullptr; hipEvent_t ev = nullptr;      // own_stream: the chain's stream and the event that orders it behind the context's stream
 };
 static void iso_identity(double* T) { for (int k = 0; k < 16; k++) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
@@ -225,6 +226,7 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             }
             t->refs.swap(nd);
             t->device_frames += stop - f;
+            for (int k = 0; k < 4; k++) t->work[k] += hs.work[k];
             f = stop;
             continue;
         }
@@ -301,5 +303,11 @@ extern "C" int ssm_tracker_stats(const ssm_tracker* t, int64_t* device_frames, i
     if (!t) return SSM_E_INVAL;
     if (device_frames) *device_frames = t->device_frames;
     if (host_frames) *host_frames = t->host_frames;
+    return SSM_OK;
+}
+extern "C" int ssm_tracker_work(const ssm_tracker* t, int64_t work[4])
+{
+    if (!t || !work) return SSM_E_INVAL;
+    for (int k = 0; k < 4; k++) work[k] = t->work[k];
     return SSM_OK;
 }

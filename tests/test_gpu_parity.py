@@ -354,6 +354,32 @@ def test_bench_line_and_allgather_path():
     assert line["per_frame"]["voxels_in_map"] > 500
 
 
+def test_bench_default_line_carries_the_other_configs():
+    """the command the driver times (`python bench.py`, N = 1, no mode flag) also reports configs[2] (SegNet), configs[3] (stereo) and the closed pose loop as
+    `other_configs`, each with value / ms_per_step / steps / roofline (frac recomputable from achieved / peak) / cpu_baseline.  Run here at a tenth of the size."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "60", "--batch", "30", "--steps", "1", "--warmup", "1", "--cpu-frames", "3", "--other-scale", "0.1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["workload"].startswith("configs[1]") and line["unit"] == "frames/s" and "solve_poses" not in line
+    oc = line["other_configs"]
+    for name, unit, bound in (("configs[2]", "frames/s", "mfma"), ("configs[3]", "frame pairs/s", "hbm"), ("pose_loop", "frames/s", "valu_f64")):
+        leg = oc[name]
+        assert "error" not in leg, leg
+        for k in ("metric", "value", "unit", "steps", "ms_per_step", "roofline", "cpu_baseline", "config"):
+            assert k in leg, (name, k)
+        assert leg["unit"] == unit and leg["value"] > 0 and leg["steps"] >= 1 and leg["ms_per_step"] > 0
+        rf = leg["roofline"]
+        assert rf["bound"] == bound and set(("achieved", "peak", "unit", "frac", "traffic")) <= set(rf)
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 2e-3 * max(rf["frac"], 1e-3) + 1e-4
+        cb = leg["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == unit
+    assert oc["configs[3]"]["cpu_baseline"]["quad_matches_equal_gpu"] is True
+    assert oc["pose_loop"]["detail"]["tracked_frames"] == oc["pose_loop"]["detail"]["frames"]
+
+
 def test_full_size_properties_of_configs1(oracle):
     """BASELINE.json configs[1] at its full size (1000 frames of 640x480 resident in HBM, 1000 keypoints, 5 reference
     frames): size-independent properties instead of the oracle, which needs ~0.1 s per frame.
