@@ -68,7 +68,7 @@ def measured_traffic(stage, frames_per_launch, suffix="traffic.json"):
     FETCH_SIZE x 2 on gfx950 for the kernels that read 16 B per lane, raw for the others: scripts/pmc_traffic.py), or None"""
     try:
         k = json.load(open(latest_profile(suffix)))["kernels"]
-        return round(sum(v.get("total_bytes_per_frame", v["total_bytes_per_frame_fetch_x2"]) for name, v in k.items() if any(name.startswith(n) for n in STAGE_KERNELS[stage])) * frames_per_launch)
+        return round(sum(v.get("total_bytes_per_frame", v["total_bytes_per_frame_fetch_x2"]) for name, v in k.items() if any(n in name for n in STAGE_KERNELS[stage])) * frames_per_launch)      # (`in`: the fp16 kernels' names stay mangled in rocprofv3's output)
     except Exception:
         return None
 
