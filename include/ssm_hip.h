@@ -64,8 +64,15 @@ typedef struct {
     double mapper_max_distance;      /* :98 */
     ssm_camera camera;               /* :37-40,63 */
     int    max_batch;                /* frames per batched launch (device workspace is sized for this) */
-    int    voxel_capacity_log2;      /* slots of the device voxel hash table = 2^this */
+    int    voxel_capacity_log2;      /* slots the context's voxel map STARTS with = 2^this (8..28).  The map grows by itself like the reference's globalMap
+                                        (src/mapper.cpp:121-158): it is re-hashed into a larger table whenever it is a quarter full */
     const int8_t* brief_pattern;     /* NULL = built-in 256x4 table; else 1024 int8 (x0,y0,x1,y1)*256 */
+    int    voxel_max_capacity_log2;  /* the map never grows beyond 2^this slots (default and maximum 28: 30 GB); a map that needs more fails with SSM_E_CAPACITY */
+    /* the stereo path (configs[3]).  0 = the default of each */
+    int    sgbm_form;                /* SGBM formulation: 2 (default) = two volumes, top-down sweep with strip hand-offs; 1 = four path volumes, no cross-block waits
+                                        (also what a sweep that times out is repeated with); 3 = the round-3 five-volume form.  All give the same disparities */
+    int    sgbm_streams;             /* 1 | 2 | 3 streams (and workspaces) that alternate sub-batches of the batched stereo path; default 2 */
+    int    stereo_batch;             /* frame pairs per launch of ssm_stereo_seq_process; default: max_batch, at most 128 */
 } ssm_config;
 
 typedef struct ssm_ctx ssm_ctx;
@@ -215,7 +222,7 @@ typedef struct {
     int32_t own_stream;       /* 1: the device chain of this tracker runs on a stream of its own (behind what the context's stream holds at the time of the
                                  call), so that trackers of independent sequences, driven from different host threads, solve side by side -- a chain is one
                                  block = one CU of 256.  0: on the context's stream */
-    int32_t pad;
+    int32_t blocks;           /* blocks per device chain: 1, 2, 4 or 8; 0 = default (8; 1 for an own_stream tracker).  Same bits in every form */
 } ssm_tracker_params;
 typedef struct { int32_t state; /* Tracker::getState() after the frame: 1 OK, 2 LOST */ int32_t tracked; /* 1: the frame joined refFrames */
                  int32_t n_matches; /* correspondences handed to solvePnP (-1: none gathered) */ int32_t n_inliers; } ssm_track_info;

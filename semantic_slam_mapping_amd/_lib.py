@@ -19,6 +19,7 @@ class Config(C.Structure):
         ("mapper_resolution", C.c_double), ("mapper_max_distance", C.c_double),
         ("camera", Camera), ("max_batch", C.c_int), ("voxel_capacity_log2", C.c_int),
         ("brief_pattern", C.c_void_p),
+        ("voxel_max_capacity_log2", C.c_int), ("sgbm_form", C.c_int), ("sgbm_streams", C.c_int), ("stereo_batch", C.c_int),
     ]
 
 
@@ -56,7 +57,7 @@ class StereoOutDev(C.Structure):
 
 
 class TrackerParams(C.Structure):
-    _fields_ = [("max_lost_frame", C.c_int32), ("ref_frames", C.c_int32), ("pnp_min_inliers", C.c_int32), ("use_device", C.c_int32), ("first_pose", C.c_double * 16), ("own_stream", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("max_lost_frame", C.c_int32), ("ref_frames", C.c_int32), ("pnp_min_inliers", C.c_int32), ("use_device", C.c_int32), ("first_pose", C.c_double * 16), ("own_stream", C.c_int32), ("blocks", C.c_int32)]
 
 
 # every symbol include/ssm_hip.h declares: name -> (restype, argtypes)

@@ -204,7 +204,12 @@ hipError_t k_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_
 // sums make the result independent of arrival order, so plain device-scope atomics are bit-reproducible.  Points arrive
 // in row-major pixel order, so a wave's 64 points fall into a few runs of equal key: a segmented wave scan reduces each
 // run in registers and only the run's last lane touches memory.
-// counters: [0] occupied slots, [1] error flags (1 = table full), occupied-slot list follows the table.
+// counter block (32 bytes behind the occupied-slot list): [0] occupied slots, [1] flags (1 = contributions were LOST: the table had no room and the overflow list
+// was full too; 2 = points outside the key range were skipped), [2] records appended to the overflow list, [3] its capacity, [4..5] its address.
+// A table never refuses a contribution as long as its overflow list has room: when the neighbourhood of a key's home slot is taken (VOX_PROBE_LIMIT slots: a table
+// that is too full, or one the host has not grown yet), the whole contribution is appended to the list as one ssm_voxel record and the host merges the list into the
+// (grown) table the next time it settles the map (ssm_abi.hip map_settle) -- exact integer sums: when and where a contribution is added does not matter.
+#define VOX_PROBE_LIMIT 128u
 __device__ __forceinline__ uint32_t vox_hash(int64_t key)
 {
     uint64_t z = (uint64_t)key * 0x9E3779B97F4A7C15ULL;
@@ -214,8 +219,9 @@ __device__ __forceinline__ uint32_t vox_hash(int64_t key)
 __device__ __forceinline__ ssm_voxel* vox_find_or_insert(ssm_voxel* tab, int cap_log2, int64_t key, int32_t* counters, uint32_t* occ)
 {
     const uint32_t mask = (1u << cap_log2) - 1u;
+    const uint32_t limit = mask < VOX_PROBE_LIMIT - 1u ? mask : VOX_PROBE_LIMIT - 1u;
     uint32_t slot = vox_hash(key) & mask;
-    for (uint32_t probe = 0; probe <= mask; probe++, slot = (slot + 1) & mask) {
+    for (uint32_t probe = 0; probe <= limit; probe++, slot = (slot + 1) & mask) {
         unsigned long long* kp = reinterpret_cast<unsigned long long*>(&tab[slot].key);
         unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == (unsigned long long)key) return &tab[slot];
@@ -225,8 +231,25 @@ __device__ __forceinline__ ssm_voxel* vox_find_or_insert(ssm_voxel* tab, int cap
             if (prev == (unsigned long long)key) return &tab[slot];
         }
     }
-    atomicOr(&counters[1], 1);
     return nullptr;
+}
+// a fresh record of the overflow list (the caller writes all of it), or nullptr when the list is full too (flag bit 0: the contribution is lost)
+__device__ __forceinline__ ssm_voxel* vox_overflow_slot(int32_t* counters)
+{
+    const int cap = counters[3];
+    ssm_voxel* buf = *reinterpret_cast<ssm_voxel* const*>(counters + 4);
+    const int i = cap > 0 ? atomicAdd(&counters[2], 1) : cap;
+    if (i >= cap) { atomicOr(&counters[1], 1); return nullptr; }
+    return buf + i;
+}
+__device__ __forceinline__ void vox_overflow_one(int32_t* counters, long long key, long long sx, long long sy, long long sz, unsigned long long sr, unsigned long long sg,
+                                                 unsigned long long sb, unsigned long long n, uint32_t lab)
+{
+    ssm_voxel* o = vox_overflow_slot(counters);
+    if (!o) return;
+    o->key = key; o->sx = sx; o->sy = sy; o->sz = sz; o->sr = sr; o->sg = sg; o->sb = sb; o->n = n;
+#pragma unroll
+    for (int c = 0; c < 12; c++) o->hist[c] = (uint32_t)c == lab ? (uint32_t)n : 0u;
 }
 __device__ __forceinline__ void vox_add(ssm_voxel* v, long long sx, long long sy, long long sz, unsigned long long sr, unsigned long long sg,
                                         unsigned long long sb, unsigned long long n)
@@ -252,7 +275,7 @@ __global__ void vox_clear_kernel(ssm_voxel* __restrict__ tab, uint32_t* __restri
         p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
     }
 }
-__global__ void vox_reset_counters(int32_t* counters) { counters[0] = 0; counters[1] = 0; }
+__global__ void vox_reset_counters(int32_t* counters) { counters[0] = 0; counters[1] = 0; counters[2] = 0; }
 hipError_t k_voxel_clear(ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
 {
     // cap_log2 < 0  =>  full clear of 2^-cap_log2 slots (first use)
@@ -307,11 +330,15 @@ vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__
         for (int c = 0; c < 12; c++) lb[c] = __ballot(label == (uint32_t)c);
         if (valid && tail && key >= 0) {
             ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
+            const unsigned long long run = (~0ull >> (63 - lane)) & (~0ull << start);
             if (v) {
                 vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
-                const unsigned long long run = (~0ull >> (63 - lane)) & (~0ull << start);
 #pragma unroll
                 for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&v->hist[c], (uint32_t)k); }
+            } else if (ssm_voxel* o = vox_overflow_slot(counters)) {
+                o->key = key; o->sx = sx; o->sy = sy; o->sz = sz; o->sr = rg & 0xFFFF; o->sg = rg >> 16; o->sb = bn & 0xFFFF; o->n = bn >> 16;
+#pragma unroll
+                for (int c = 0; c < 12; c++) o->hist[c] = (uint32_t)__popcll(lb[c] & run);
             }
         }
     }
@@ -449,6 +476,7 @@ __device__ __forceinline__ void lds_vox_update(LdsVox* lt, long long key, uint32
     } else {                                                    // the block table is full: straight to the global table
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
         if (v) { vox_add(v, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n); if (lab < 12) atomicAdd(&v->hist[lab], f.n); }
+        else vox_overflow_one(counters, key, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n, lab);
     }
 }
 // merge equal neighbouring runs across the wave and push the tails into the block table
@@ -603,7 +631,14 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
-        if (!v) continue;
+        if (!v) {
+            if (ssm_voxel* o = vox_overflow_slot(counters)) {
+                o->key = lt[i].key; o->sx = lt[i].sx; o->sy = lt[i].sy; o->sz = lt[i].sz; o->sr = lt[i].r; o->sg = lt[i].g; o->sb = lt[i].b; o->n = lt[i].n;
+#pragma unroll
+                for (int c = 0; c < 12; c++) o->hist[c] = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF;
+            }
+            continue;
+        }
         vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
 #pragma unroll
         for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
@@ -842,7 +877,14 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
-        if (!v) continue;
+        if (!v) {
+            if (ssm_voxel* o = vox_overflow_slot(counters)) {
+                o->key = lt[i].key; o->sx = lt[i].sx; o->sy = lt[i].sy; o->sz = lt[i].sz; o->sr = lt[i].r; o->sg = lt[i].g; o->sb = lt[i].b; o->n = lt[i].n;
+#pragma unroll
+                for (int c = 0; c < 12; c++) o->hist[c] = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF;
+            }
+            continue;
+        }
         vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
 #pragma unroll
         for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
@@ -901,9 +943,30 @@ __global__ void vox_merge_kernel(const ssm_voxel* __restrict__ src, int n, ssm_v
     if (i >= n) return;
     const ssm_voxel sv = src[i];
     ssm_voxel* v = vox_find_or_insert(tab, cap_log2, sv.key, counters, occ);
-    if (!v) return;
+    if (!v) { if (ssm_voxel* o = vox_overflow_slot(counters)) *o = sv; return; }
     vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
     for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
+}
+// every occupied slot of one table into another (the host grows the map: ssm_abi.hip map_settle)
+__global__ void vox_rehash_kernel(const ssm_voxel* __restrict__ src, const uint32_t* __restrict__ src_occ, const int32_t* __restrict__ src_counters,
+                                  ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters)
+{
+    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
+    const int n = src_counters[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const ssm_voxel sv = src[src_occ[i]];
+        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, sv.key, counters, occ);
+        if (!v) { if (ssm_voxel* o = vox_overflow_slot(counters)) *o = sv; continue; }
+        vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
+        for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
+    }
+}
+hipError_t k_voxel_rehash(const ssm_voxel* src, int src_cap_log2, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
+{
+    const uint32_t* socc = reinterpret_cast<const uint32_t*>(src + ((size_t)1 << src_cap_log2));
+    const int32_t* scnt = reinterpret_cast<const int32_t*>(socc + ((size_t)1 << src_cap_log2));
+    vox_rehash_kernel<<<1024, 256, 0, s>>>(src, socc, scnt, tab, cap_log2, counters);
+    return hipGetLastError();
 }
 hipError_t k_voxel_merge(const ssm_voxel* src, int n, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
 {

@@ -21,10 +21,12 @@ static thread_local std::string g_create_err;
 
 namespace {
 
-struct VoxTable {           // tab[slots] | occ[slots] | counters[4]
+struct VoxTable {           // tab[slots] | occ[slots] | counter block (32 bytes: count, flags, overflow records, overflow capacity, overflow list address)
     ssm_voxel* tab = nullptr; uint32_t* occ = nullptr; int32_t* counters = nullptr; int cap_log2 = 0;
-    size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 16; }
+    ssm_voxel* ovf = nullptr; int ovf_cap = 0;       // the overflow list of the context map (kernels_map.hip vox_overflow_slot); the temporary tables have none
+    size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 32; }
 };
+static const int VOX_OVF_RECORDS = 1 << 18;          // 29 MB per context
 struct StageRec { const char* name; hipEvent_t a, b; };
 // SegNet driving_webdemo: 26 conv layers; op list interleaves pools / unpools
 struct SegLayerDef { int cin, cout, h, w; };
@@ -117,6 +119,8 @@ struct ssm_ctx {
     uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true; bool map_compact = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
     VoxTable map, tmp; bool map_full_reported = false;   // table-full already reported by check_device_flags (reset by ssm_map_clear)
+    // the context map grows (map_settle); between the map launches of ssm_seq_process its counters come back through a two-slot ring of asynchronous copies
+    int vox_max_log2 = 28; int32_t* h_map_snap = nullptr; hipEvent_t map_snap_ev[2] = {nullptr, nullptr}; uint64_t map_launches = 0; int map_grown = 0;
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1; int32_t* d_comm_counts = nullptr; int comm_counts_cap = 0;
     // SegNet
@@ -258,8 +262,90 @@ static int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
     const size_t slots = (size_t)1 << cap_log2;
     t.tab = reinterpret_cast<ssm_voxel*>(p); t.occ = reinterpret_cast<uint32_t*>(t.tab + slots); t.counters = reinterpret_cast<int32_t*>(t.occ + slots);
     HIPCHK(c, k_voxel_clear(t.tab, -cap_log2, t.counters, c->stream));
+    struct { int32_t cap, pad; ssm_voxel* buf; } tail = { t.ovf ? t.ovf_cap : 0, 0, t.ovf };      // counters[3], counters[4..5]
+    static_assert(sizeof(tail) == 16, "counter block tail");
+    int32_t head[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(t.counters, head, 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t.counters + 3, &tail.cap, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t.counters + 4, &tail.buf, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                   // (the sources are on this stack)
     return SSM_OK;
 }
+// The context map has no capacity of its own (the reference's globalMap grows without limit, src/mapper.cpp:121-158): voxel_capacity_log2 is where it STARTS.
+// map_settle brings the map to rest on stream s (blocking): the overflow list is merged into the table and the table is re-hashed into a larger one whenever
+// 4 x (voxels + overflow records + reserve) exceeds its slots -- `reserve` = new voxels the caller is about to add at most, so that an insert / merge of a known
+// size can never overflow.  SSM_E_CAPACITY only beyond 2^vox_max_log2 slots (28: the key's range), SSM_E_NOMEM when the larger table cannot be allocated; in both
+// cases nothing is lost: table and list stay as they are.
+static int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve)
+{
+    VoxTable& t = c->map;
+    int lo = 0;                                                   // overflow records [0, lo) are merged already
+    for (int round = 0; round < 64; round++) {
+        int32_t cnt[4];
+        HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const int64_t n = cnt[0], hi = cnt[2] < t.ovf_cap ? cnt[2] : t.ovf_cap, m = hi - lo;
+        const int64_t slots = (int64_t)1 << t.cap_log2;
+        const bool grow = 4 * (n + m + reserve) > slots && t.cap_log2 < c->vox_max_log2;
+        if (!grow && 2 * (n + m + reserve) > slots) {
+            // at voxel_max_capacity_log2 and more than half full.  A caller that announced its insert (reserve) is refused before anything is added; records
+            // waiting in the overflow list have no table to go to: the map is incomplete from here on (flag bit 0, reported until ssm_map_clear)
+            if (m > 0) { const int32_t lost[2] = { cnt[1] | 1, 0 }; HIPCHK(c, hipMemcpyAsync(t.counters + 1, lost, 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
+            FAIL(c, SSM_E_CAPACITY, "the voxel map needs more than 2^" + std::to_string(c->vox_max_log2) + " slots (voxel_max_capacity_log2)");
+        }
+        if (m <= 0 && !grow) {
+            if (cnt[2] != 0) { const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
+            return SSM_OK;
+        }
+        if (grow) {
+            int L = t.cap_log2; while (L < c->vox_max_log2 && 4 * (n + m + reserve) > ((int64_t)1 << L)) L++;
+            VoxTable nt; nt.ovf = t.ovf; nt.ovf_cap = t.ovf_cap;
+            { hipStream_t keep = c->stream; c->stream = s; const int r = table_alloc(c, nt, L); c->stream = keep; if (r) return r; }
+            // the flags travel with the map; the new counter block goes on counting overflow records where the old one stopped (the records [lo, hi) are still to
+            // merge, and the re-hash itself appends behind them should it need the list)
+            const int32_t carry[2] = { cnt[1], cnt[2] < t.ovf_cap ? cnt[2] : t.ovf_cap };
+            HIPCHK(c, hipMemcpyAsync(nt.counters + 1, carry, 8, hipMemcpyHostToDevice, s));
+            HIPCHK(c, k_voxel_rehash(t.tab, t.cap_log2, nt.tab, nt.cap_log2, nt.counters, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            hipFree(t.tab);
+            t = nt; c->map_grown++;
+            continue;                                             // (count again: the re-hash itself may have used the list)
+        }
+        HIPCHK(c, k_voxel_merge(t.ovf + lo, (int)m, t.tab, t.cap_log2, t.counters, s));
+        lo = (int)hi;
+        if (lo >= t.ovf_cap) {                                    // the list was full to the brim: empty it before anything can be appended again
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 16, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s));
+            if (cnt[2] > t.ovf_cap && !(cnt[1] & 1)) FAIL(c, SSM_E_CAPACITY, "voxel map: the overflow list overflowed while it was merged");
+            const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s));
+            lo = 0;
+        }
+    }
+    FAIL(c, SSM_E_CAPACITY, "voxel map: the overflow list did not drain");
+}
+// ssm_seq_process, in front of every launch of the map stage on stream s.  A small table (< 2^20 slots) is settled exactly every time and takes only
+// slots / 4096 frames per launch; a large one is checked against the counters of the launch before the previous one (a two-slot ring of asynchronous copies:
+// the host never waits for the launch it has just queued) and settled when it is a quarter full or its overflow list is in use.
+static int map_before_launch(ssm_ctx* c, hipStream_t s)
+{
+    VoxTable& t = c->map;
+    if (t.cap_log2 < 20) return map_settle(c, s, 0);
+    if (c->map_launches < 2) return SSM_OK;
+    const int slot = (int)(c->map_launches & 1);
+    HIPCHK(c, hipEventSynchronize(c->map_snap_ev[slot]));
+    const int32_t* cnt = c->h_map_snap + 4 * slot;
+    if (cnt[2] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2)) { c->map_launches = 0; return map_settle(c, s, 0); }
+    return SSM_OK;
+}
+static int map_after_launch(ssm_ctx* c, hipStream_t s)
+{
+    const int slot = (int)(c->map_launches & 1);
+    HIPCHK(c, hipMemcpyAsync(c->h_map_snap + 4 * slot, c->map.counters, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->map_snap_ev[slot], s));
+    c->map_launches++;
+    return SSM_OK;
+}
+static int map_frames_per_launch(const ssm_ctx* c, int nb) { const int f = c->map.cap_log2 >= 20 ? nb : (1 << c->map.cap_log2) >> 12; return f < 1 ? 1 : (f > nb ? nb : f); }
 static void prof_begin(ssm_ctx* c, const char* name)
 {
     if (!c->profiling) return;
@@ -289,6 +375,7 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
         }
     }
     if (with_map) {
+        { const int r = map_settle(c, c->stream, 0); if (r) return r; }
         HIPCHK(c, hipMemcpy(cnt, c->map.counters, 8, hipMemcpyDeviceToHost));
         if (cnt[1]) {
             // bit 1 (skipped points: a defined contract, DESIGN.md "voxel key range") is reported once and cleared.  Bit 0 (table full: points were DROPPED,
@@ -297,7 +384,7 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
             if (cnt[1] & 2) { const int32_t keep = cnt[1] & 1; hipMemcpy(c->map.counters + 1, &keep, 4, hipMemcpyHostToDevice); }
             if ((cnt[1] & 1) && !c->map_full_reported) {
                 c->map_full_reported = true;
-                FAIL(c, SSM_E_CAPACITY, "voxel table full (points were dropped): ssm_map_clear and raise voxel_capacity_log2");
+                FAIL(c, SSM_E_CAPACITY, "voxel map: contributions were dropped (table and overflow list full between two growth checks): ssm_map_clear and start from a larger voxel_capacity_log2");
             }
             if (cnt[1] & 2) FAIL(c, SSM_E_VOXEL_RANGE, "points with a non-finite coordinate or a voxel index outside (-2^20, 2^20) were skipped (leaf too small for the extent, or a bad pose)");
         }
@@ -315,6 +402,7 @@ extern "C" void ssm_config_default(ssm_config* c)
     c->mapper_resolution = 0.1; c->mapper_max_distance = 40;                                                        // :97-98
     c->camera.cx = 318.6; c->camera.cy = 255.3; c->camera.fx = 517.3; c->camera.fy = 516.5; c->camera.scale = 1000.0;
     c->max_batch = 16; c->voxel_capacity_log2 = 20; c->brief_pattern = nullptr;
+    c->voxel_max_capacity_log2 = 28; c->sgbm_form = 0; c->sgbm_streams = 0; c->stereo_batch = 0;
 }
 extern "C" const char* ssm_version(void) { return "ssm_hip 0.1 (gfx950)"; }
 extern "C" const char* ssm_last_error(const ssm_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
@@ -375,6 +463,9 @@ static int ctx_init(ssm_ctx* c)
     DALLOC(c, c->d_mask, (size_t)B * W * H); DALLOC(c, c->d_chunk_cnt, (size_t)B * chunks); DALLOC(c, c->d_chunk_off, (size_t)B * chunks);
     DALLOC(c, c->d_total, 2); DALLOC(c, c->d_points, (size_t)B * W * H);
     DALLOC(c, c->d_in_img, (size_t)W * H * 3); DALLOC(c, c->d_in_sem, (size_t)W * H * 3); DALLOC(c, c->d_in_depth, (size_t)W * H); DALLOC(c, c->d_in_pose, 16);
+    DALLOC(c, c->map.ovf, VOX_OVF_RECORDS); c->map.ovf_cap = VOX_OVF_RECORDS;
+    { void* hp = nullptr; HIPCHK(c, hipHostMalloc(&hp, 32, hipHostMallocDefault)); c->h_map_snap = (int32_t*)hp; memset(hp, 0, 32); }
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->map_snap_ev[k], hipEventDisableTiming));
     int r = table_alloc(c, c->map, cfg.voxel_capacity_log2); if (r) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SSM_OK;
@@ -400,6 +491,8 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
     int r = build_geometry(*cfg, c->g, c->err);
     if (!r && (cfg->voxel_capacity_log2 < 8 || cfg->voxel_capacity_log2 > 28)) { c->err = "voxel_capacity_log2 must be 8..28"; r = SSM_E_INVAL; }
+    if (!r && cfg->voxel_max_capacity_log2 != 0 && (cfg->voxel_max_capacity_log2 < cfg->voxel_capacity_log2 || cfg->voxel_max_capacity_log2 > 28)) { c->err = "voxel_max_capacity_log2 must be voxel_capacity_log2..28 (0: 28)"; r = SSM_E_INVAL; }
+    if (!r) c->vox_max_log2 = cfg->voxel_max_capacity_log2 ? cfg->voxel_max_capacity_log2 : 28;
     if (!r && !(cfg->mapper_resolution > 0)) { c->err = "mapper_resolution must be > 0"; r = SSM_E_INVAL; }
     if (!r && c->B > 16384) { c->err = "max_batch must be <= 16384"; r = SSM_E_INVAL; }
     if (!r) r = ctx_init(c);
@@ -418,6 +511,9 @@ extern "C" void ssm_destroy(ssm_ctx* c)
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn, c->d_blur_tab, c->d_vmap, c->d_vcat };
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->map.ovf) hipFree(c->map.ovf);
+    if (c->h_map_snap) hipHostFree(c->h_map_snap);
+    for (int k = 0; k < 2; k++) if (c->map_snap_ev[k]) hipEventDestroy(c->map_snap_ev[k]);
     { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
     for (int i = 0; i < 3; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
@@ -868,9 +964,10 @@ extern "C" int ssm_backproject(ssm_ctx* c, const uint16_t* depth, const uint8_t*
 static int table_count(ssm_ctx* c, VoxTable& t, int* n)
 {
     int32_t cnt[2];
+    if (&t == &c->map) { const int r = map_settle(c, c->stream, 0); if (r) return r; }
     HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel table full: raise voxel_capacity_log2");
+    if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel map incomplete (contributions were dropped): ssm_map_clear and start from a larger voxel_capacity_log2");
     *n = cnt[0];
     return SSM_OK;
 }
@@ -911,8 +1008,8 @@ extern "C" int ssm_map_clear(ssm_ctx* c)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
-    c->map_full_reported = false;
+    HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));       // (the capacity it has grown to stays)
+    c->map_full_reported = false; c->map_launches = 0;
     return SSM_OK;
 }
 extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
@@ -923,7 +1020,13 @@ extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
     if (n == 0) return SSM_OK;
     int r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
     HIPCHK(c, hipMemcpyAsync(c->d_scratch, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, k_voxel_insert(reinterpret_cast<ssm_point*>(c->d_scratch), nullptr, n, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+    // in chunks the table is grown for beforehand (every point of a chunk may open a voxel): nothing can overflow
+    for (int a = 0; a < n; ) {
+        int64_t chunk = ((int64_t)1 << c->map.cap_log2) / 8; if (chunk < 4096) chunk = 4096; if (chunk > n - a) chunk = n - a;
+        r = map_settle(c, c->stream, chunk); if (r) return r;
+        HIPCHK(c, k_voxel_insert(reinterpret_cast<ssm_point*>(c->d_scratch) + a, nullptr, chunk, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
+        a += (int)chunk;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_device_flags(c, true);
 }
@@ -962,6 +1065,7 @@ extern "C" int ssm_map_merge_table(ssm_ctx* c, const ssm_voxel* tab, int n)
     if (n == 0) return SSM_OK;
     int r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
     HIPCHK(c, hipMemcpyAsync(c->d_scratch, tab, (size_t)n * sizeof(ssm_voxel), hipMemcpyHostToDevice, c->stream));
+    r = map_settle(c, c->stream, n); if (r) return r;               // room for n new voxels first
     HIPCHK(c, k_voxel_merge(reinterpret_cast<ssm_voxel*>(c->d_scratch), n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SSM_OK;
@@ -985,6 +1089,7 @@ extern "C" int ssm_map_merge_table_dev(ssm_ctx* c, const ssm_voxel* tab, int n)
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    { const int r = map_settle(c, c->stream, n); if (r) return r; }
     HIPCHK(c, k_voxel_merge(tab, n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
     return SSM_OK;
 }
@@ -1038,6 +1143,10 @@ extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
         DALLOC(c, c->d_comm_counts, (size_t)2 * world + 4); c->comm_counts_cap = world;
     }
     hipStream_t s = c->stream;
+    // the local map at rest first (overflow list merged).  A rank that cannot settle must not leave before the collectives: it raises its map's LOST flag, which the
+    // count all-gather below carries to every rank
+    const int r_settle = map_settle(c, s, 0);
+    if (r_settle) { const int32_t one = 1; HIPCHK(c, hipMemcpyAsync(c->map.counters + 1, &one, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
     prof_begin(c, "allgather");
     // Every decision that can end the call is taken COLLECTIVELY: a rank that returned between two collectives would leave its peers blocked in the
     // next one.  (1) all-gather {voxel count, flag word} per rank -- counters[0..1] of the map table, already on the device.
@@ -1048,11 +1157,12 @@ extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
     std::vector<int32_t> counts(world);
     int mx = 1, bad_rank = -1, neg_rank = -1;
     for (int q = 0; q < world; q++) { counts[q] = cf[2 * q]; if (cf[2 * q + 1] & 1) bad_rank = q; if (counts[q] < 0) neg_rank = q; if (counts[q] > mx) mx = counts[q]; }
-    if (bad_rank >= 0) { prof_end(c); FAIL(c, SSM_E_CAPACITY, "voxel table of rank " + std::to_string(bad_rank) + " is full (points were dropped): raise voxel_capacity_log2; no rank merged"); }
+    if (bad_rank >= 0) { prof_end(c); FAIL(c, SSM_E_CAPACITY, "voxel table of rank " + std::to_string(bad_rank) + " is incomplete (contributions were dropped, or it could not be settled); no rank merged"); }
     if (neg_rank >= 0) { prof_end(c); FAIL(c, SSM_E_COMM, "negative voxel count received from rank " + std::to_string(neg_rank)); }
     // (2) the receive buffer: slot r = rank r's voxels, mx entries each.  An allocation failure on one rank is agreed on by a second tiny all-gather.
     const size_t slot = (size_t)mx * sizeof(ssm_voxel);
-    const int r_alloc = ensure_scratch2(c, slot * world + 256);
+    int r_alloc = ensure_scratch2(c, slot * world + 256);
+    if (r_alloc == SSM_OK) { int64_t remote = 0; for (int q = 0; q < world; q++) if (q != rank) remote += counts[q]; r_alloc = map_settle(c, s, remote); }   // room for every remote voxel: the merges below cannot overflow
     {
         const int32_t ok = r_alloc == SSM_OK ? 0 : 1;
         HIPCHK(c, hipMemcpyAsync(c->d_comm_counts + 2 * world, &ok, 4, hipMemcpyHostToDevice, s));
@@ -1384,25 +1494,32 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                 prof_end(c);
                 sem_src = c->seg->d_sem_gen;
             }
-            if (stages & SSM_STAGE_MAP) {
+            // The map of a context grows (map_settle): a launch covers all nb frames when the table is large, fewer while it is small, and the table's counters
+            // are looked at between launches (map_before_launch).  Exact integer sums: how the frames are cut into launches does not change the map.
+            for (int q0 = 0, nq; (stages & SSM_STAGE_MAP) && q0 < nb; q0 += nq) {
+                r = map_before_launch(c, s); if (r) return r;
+                nq = map_frames_per_launch(c, nb - q0);
+                const int g0 = f0 + q0;
+                const uint8_t* sem_q = sem_src + (size_t)q0 * npix * 3;
                 if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
                     prof_begin(c, "map_fuse");
-                    HIPCHK(c, k_map_fuse(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src,
-                                         in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                         (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(mask_ws), reinterpret_cast<uint16_t*>(mask_ws) + (size_t)nb * (W >> 4) * H,
-                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + f0, s, c->map_compact));
+                    HIPCHK(c, k_map_fuse(in->depth + (size_t)g0 * npix, in->bgr + (size_t)g0 * npix * 3, sem_q,
+                                         in->pose ? in->pose + (size_t)g0 * 16 : nullptr, nq, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                         (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(mask_ws), reinterpret_cast<uint16_t*>(mask_ws) + (size_t)nq * (W >> 4) * H,
+                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + g0, s, c->map_compact));
                     prof_end(c);
                 } else {                     // odd widths: mask -> ordered back-projection -> insert
                     prof_begin(c, "mask");
-                    HIPCHK(c, k_moving_mask(sem_src, nb, W, H, c->d_mask, s)); prof_end(c);
+                    HIPCHK(c, k_moving_mask(sem_q, nq, W, H, c->d_mask, s)); prof_end(c);
                     prof_begin(c, "backproject");
-                    HIPCHK(c, k_backproject(in->depth + (size_t)f0 * npix, in->bgr + (size_t)f0 * npix * 3, sem_src, c->d_mask,
-                                            in->pose ? in->pose + (size_t)f0 * 16 : nullptr, nb, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                            c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + f0, c->d_total, c->d_points, s)); prof_end(c);
+                    HIPCHK(c, k_backproject(in->depth + (size_t)g0 * npix, in->bgr + (size_t)g0 * npix * 3, sem_q, c->d_mask,
+                                            in->pose ? in->pose + (size_t)g0 * 16 : nullptr, nq, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
+                                            c->d_chunk_cnt, c->d_chunk_off, c->d_npoints + g0, c->d_total, c->d_points, s)); prof_end(c);
                     prof_begin(c, "voxel_insert");
-                    HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nb * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
+                    HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nq * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
                     prof_end(c);
                 }
+                r = map_after_launch(c, s); if (r) return r;
             }
             return SSM_OK;
         };

@@ -98,6 +98,7 @@ hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* 
                       ssm_camera cam, double max_distance, float leaf, uint16_t* bits_raw, uint16_t* bits_v,
                       ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, bool compact = true /* map_stream2_kernel; false: map_stream_kernel */);
 hipError_t k_voxel_merge(const ssm_voxel* src, int n, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
+hipError_t k_voxel_rehash(const ssm_voxel* src, int src_cap_log2, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
 hipError_t k_voxel_compact(const ssm_voxel* tab, int cap_log2, ssm_voxel* out, int32_t* n_out, hipStream_t s);
 hipError_t k_voxel_gather_points(const ssm_voxel* compact, const uint32_t* order, int n, ssm_point* out, hipStream_t s);
 hipError_t k_voxel_gather_table(const ssm_voxel* compact, const uint32_t* order, int n, ssm_voxel* out, hipStream_t s);

@@ -208,133 +208,119 @@ def test_voxel_filter_grows_its_table_and_skips_unkeyable_points(oracle):
         c.close()
 
 
-def test_full_map_table_is_reported_once_and_stays_refused_until_cleared():
-    """round-2 advisor finding: after ssm_sync / ssm_map_insert had reported a full table, later exports treated the incomplete map as complete"""
+def test_map_at_its_size_limit_refuses_before_it_loses_and_stays_refused_after_a_loss():
+    """The context map grows by itself (below); voxel_max_capacity_log2 is the one limit left.  An insert of a known size that cannot fit is refused BEFORE anything
+    is added (the map stays what it was); the sequence path cannot know in advance, so contributions that found neither a slot nor a larger table are lost, and then
+    (round-2 advisor finding) the incomplete map is reported once by ssm_sync and refused by every export until ssm_map_clear"""
     import semantic_slam_mapping_amd as ssm
-    c = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=8, camera=CAM)
+    c = ssm.Context(0, orb_features=500, max_batch=2, voxel_capacity_log2=8, voxel_max_capacity_log2=8, camera=CAM)
     try:
         rng = np.random.default_rng(7)
         pts = np.zeros(20000, ssm.POINT_DTYPE)
         pts["x"] = rng.uniform(-4, 4, len(pts)); pts["y"] = rng.uniform(-3, 3, len(pts)); pts["z"] = rng.uniform(0, 5, len(pts)); pts["w"] = 1.0
         c.map_clear()
+        c.map_insert(pts[:20]); c.sync()
+        before = c.map_export_table().tobytes()
         with pytest.raises(ssm.SsmError) as e:
             c.map_insert(pts)
+        assert e.value.code == -4 and "voxel_max_capacity_log2" in str(e.value)
+        c.sync()
+        assert c.map_export_table().tobytes() == before              # refused, nothing added, nothing lost
+        # the sequence path: two frames into 256 slots
+        W, H, n = 640, 480, 2
+        bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+        c.synth_frames_dev(SEED, 0, n, *bufs)
+        with pytest.raises(ssm.SsmError) as e:
+            c.seq_process(*bufs, n, stages=ssm.api.STAGE_MAP); c.sync()
         assert e.value.code == -4
-        c.sync()                                                     # reported once: a later sync is clean ...
-        for call in (c.map_size, c.map_export, c.map_export_table):  # ... but the incomplete map is not handed out
+        for call in (c.map_size, c.map_export, c.map_export_table):  # the incomplete map is not handed out
             with pytest.raises(ssm.SsmError) as e:
                 call()
             assert e.value.code == -4
         c.map_clear()
         c.map_insert(pts[:50]); c.sync()
         assert 0 < c.map_size() <= 50
+        for p in bufs:
+            c.dev_free(p)
     finally:
         c.close()
 
 
-def test_map_insert_merge_is_order_independent(ctx, oracle, frames):
-    clouds = [ctx.generate_point_cloud(frames[f][1], frames[f][0], frames[f][2], frames[f][4]) for f in range(3)]
-    allp = np.concatenate(clouds)
-    ref = oracle.voxel_filter(allp, np.float32(ctx.cfg.mapper_resolution))
-    ctx.map_clear()
-    for c in clouds:
-        ctx.map_insert(c)
-    assert same_struct(ctx.map_export(), ref)
-    tab_all = ctx.map_export_table()
-    assert same_struct(tab_all, oracle.voxel_table(allp, np.float32(ctx.cfg.mapper_resolution)))
-    ctx.map_clear()                                               # merge of per-shard tables == one table (multi-GPU merge)
-    ctx.map_insert(clouds[2])
-    t2 = ctx.map_export_table()
-    ctx.map_clear()
-    ctx.map_insert(clouds[1]); ctx.map_insert(clouds[0])
-    ctx.map_merge_table(t2)
-    assert same_struct(ctx.map_export_table(), tab_all)
-    ctx.map_clear()
-    assert ctx.map_size() == 0
-
-
-# ---------------------------------------------------------------- device-resident sequence path == per-frame path
-def test_seq_process_matches_oracle_per_frame(ctx, oracle):
-    n, W, H, R = 7, 640, 480, ctx.R
-    d_bgr = ctx.dev_alloc(n * W * H * 3); d_dep = ctx.dev_alloc(n * W * H * 2); d_sem = ctx.dev_alloc(n * W * H * 3); d_pose = ctx.dev_alloc(n * 128)
-    try:
-        ctx.synth_frames_dev(SEED, 10, n, d_bgr, d_dep, d_sem, d_pose)
-        hb = ctx.d2h(d_bgr, (n, H, W, 3), np.uint8); hd = ctx.d2h(d_dep, (n, H, W), np.uint16); hs = ctx.d2h(d_sem, (n, H, W, 3), np.uint8)
-        hp = ctx.d2h(d_pose, (n, 16), np.float64)
-        fr = [oracle.synth_frame(SEED, 10 + i) for i in range(n)]
-        for i in range(n):                                        # device generator == oracle generator
-            assert np.array_equal(hb[i], fr[i][0]) and np.array_equal(hd[i], fr[i][1]) and np.array_equal(hs[i], fr[i][2])
-            assert np.array_equal(hp[i].reshape(4, 4).T, fr[i][4])
-        ctx.map_clear()
-        out = ctx.seq_process(d_bgr, d_dep, d_sem, d_pose, n)
-        ctx.sync()
-        res = ctx.seq_fetch(out, n)
-        descs, clouds = [], []
-        for i in range(n):
-            ok, od = oracle.orb_extract(oracle.bgr2gray(fr[i][0]), nfeatures=ctx.cfg.orb_features)
-            k = res["nkp"][i]
-            assert k == len(ok) and same_struct(res["kps"][i, :k], ok) and np.array_equal(res["desc"][i, :k], od)
-            descs.append(od)
-            for r in range(R):
-                ref = i - R + r
-                if ref < 0:
-                    assert res["nmatch"][i, r] == -1
-                    continue
-                om = oracle.match(descs[ref], od, ctx.cfg.knn_match_ratio)
-                assert res["nmatch"][i, r] == len(om) and same_struct(res["matches"][i, r, :len(om)], om)
-            c = oracle.backproject(fr[i][1], fr[i][0], fr[i][2], oracle.moving_mask(fr[i][2]), CAM, fr[i][4], 40.0)
-            assert res["npoints"][i] == len(c)
-            clouds.append(c)
-        ref_map = oracle.voxel_filter(np.concatenate(clouds), np.float32(ctx.cfg.mapper_resolution))
-        assert same_struct(ctx.map_export(), ref_map)
-        # continuation: frames n-3.. as a second call must see the previous call's frames as references
-        out2 = ctx.seq_process(d_bgr, d_dep, d_sem, d_pose, 2, continue_sequence=True, stages=3)
-        ctx.sync()
-        res2 = ctx.seq_fetch(out2, 2)
-        om = oracle.match(descs[n - 1], descs[0], ctx.cfg.knn_match_ratio)
-        assert res2["nmatch"][0, R - 1] == len(om) and same_struct(res2["matches"][0, R - 1, :len(om)], om)
-        ctx.map_clear()
-    finally:
-        for p in (d_bgr, d_dep, d_sem, d_pose):
-            ctx.dev_free(p)
-
-
-@pytest.mark.parametrize("W,H,nfeat,levels", [(1241, 376, 1000, 8), (324, 244, 300, 5), (752, 480, 500, 8)])
-def test_other_geometries_through_the_sequence_path(oracle, W, H, nfeat, levels):
-    """widths that are not multiples of 16 (1241: the KITTI geometry; 324: rows padded, the un-fused map path) and a wide VGA
-    variant: ORB keypoints / descriptors, match tables and the fused map of a 3-frame sequence against the oracle"""
+def test_context_map_grows_from_a_tiny_table(oracle):
+    """the reference's globalMap has no capacity (src/mapper.cpp:121-158): a context that starts with 2^8 slots takes a cloud with thousands of voxels, merges a
+    table, and runs the 7-frame sequence (one frame per map launch while the table is small, the overflow list in between) -- the map equals the oracle's"""
     import semantic_slam_mapping_amd as ssm
-    cam = (W / 2 - 1.4, H / 2 + 0.7, 517.3, 516.5, 1000.0)
-    c = ssm.Context(0, width=W, height=H, orb_features=nfeat, orb_levels=levels, max_batch=2, voxel_capacity_log2=18, camera=cam)
-    n, R = 3, c.R
-    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    c = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=8, camera=CAM)
     try:
-        fr = [oracle.synth_frame(SEED, 60 + i, W, H) for i in range(n)]
-        c.h2d(bufs[0], np.stack([f[0] for f in fr])); c.h2d(bufs[1], np.stack([f[1] for f in fr])); c.h2d(bufs[2], np.stack([f[2] for f in fr]))
-        c.h2d(bufs[3], np.stack([f[4].T.reshape(16) for f in fr]))               # column-major 4x4
+        rng = np.random.default_rng(11)
+        pts = np.zeros(30000, ssm.POINT_DTYPE)
+        pts["x"] = rng.uniform(-4, 4, len(pts)); pts["y"] = rng.uniform(-3, 3, len(pts)); pts["z"] = rng.uniform(0, 5, len(pts))
+        pts["r"] = rng.integers(0, 256, len(pts)); pts["g"] = rng.integers(0, 256, len(pts)); pts["label"] = rng.integers(0, 12, len(pts)); pts["w"] = 1.0
+        leaf = np.float32(c.cfg.mapper_resolution)
+        ref = oracle.voxel_filter(pts, leaf)
+        assert len(ref) > 20 * 256
+        c.map_clear(); c.map_insert(pts[:17000]); c.map_insert(pts[17000:])
+        assert same_struct(c.map_export(), ref)
+        tab = c.map_export_table()
+        c.map_clear(); c.map_insert(pts[:100]); c.map_merge_table(tab)          # a table far larger than the (cleared, but grown) ... and than a fresh context's
+        d = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=8, camera=CAM)
+        try:
+            d.map_insert(pts[:100]); d.map_merge_table(tab)
+            assert d.map_export_table().tobytes() == c.map_export_table().tobytes()
+            assert same_struct(d.map_export(), oracle.voxel_filter(np.concatenate([pts[:100], pts]), leaf))
+        finally:
+            d.close()
+        # the sequence path from 2^8 slots
+        W, H, n = 640, 480, 7
         c.map_clear()
-        out = c.seq_process(*bufs, n)
-        c.sync()
-        res = c.seq_fetch(out, n)
-        descs, clouds = [], []
-        for i in range(n):
-            ok, od = oracle.orb_extract(oracle.bgr2gray(fr[i][0]), nfeatures=nfeat, nlevels=levels)
-            k = res["nkp"][i]
-            assert k == len(ok) and same_struct(res["kps"][i, :k], ok) and np.array_equal(res["desc"][i, :k], od)
-            descs.append(od)
-            for r in range(R):
-                ref = i - R + r
-                if ref >= 0:
-                    om = oracle.match(descs[ref], od, c.cfg.knn_match_ratio)
-                    assert res["nmatch"][i, r] == len(om) and same_struct(res["matches"][i, r, :len(om)], om)
-            cl = oracle.backproject(fr[i][1], fr[i][0], fr[i][2], oracle.moving_mask(fr[i][2]), cam, fr[i][4], 40.0)
-            assert res["npoints"][i] == len(cl)
-            clouds.append(cl)
-        assert same_struct(c.map_export(), oracle.voxel_filter(np.concatenate(clouds), np.float32(c.cfg.mapper_resolution)))
-    finally:
+        bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+        e = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=8, camera=CAM)
+        try:
+            e.synth_frames_dev(SEED, 0, n, *bufs)       # (device memory is the device's: any context can fill it)
+            e.seq_process(*bufs, n, stages=ssm.api.STAGE_MAP); e.sync()
+            clouds = []
+            for i in range(n):
+                bgr, dep, sem, _, T = oracle.synth_frame(SEED, i)
+                clouds.append(oracle.backproject(dep, bgr, sem, oracle.moving_mask(sem), CAM, T, 40.0))
+            assert same_struct(e.map_export(), oracle.voxel_filter(np.concatenate(clouds), leaf))
+        finally:
+            e.close()
         for p in bufs:
             c.dev_free(p)
-        c.close() if hasattr(c, "close") else None
+    finally:
+        c.close()
+
+
+def test_configs1_at_leaf_002_from_a_tiny_table_equals_the_large_table_run():
+    """SURVEY.md s.8(d)'s second leaf: the 1000-frame configs[1] stream at mapper_resolution 0.02 from voxel_capacity_log2 = 10 (growth by re-hashing between the map
+    launches of ssm_seq_process) gives byte for byte the table of a context that starts with 2^24 slots"""
+    import semantic_slam_mapping_amd as ssm
+    N, W, H = 1000, 640, 480
+    tabs = []
+    big = ssm.Context(0, orb_features=1000, max_batch=250, voxel_capacity_log2=24, mapper_resolution=0.02, camera=CAM)
+    bufs = [big.dev_alloc(N * W * H * 3), big.dev_alloc(N * W * H * 2), big.dev_alloc(N * W * H * 3), big.dev_alloc(N * 128)]
+    try:
+        big.synth_frames_dev(SEED, 0, N, *bufs)
+        big.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); big.sync()
+        tabs.append(big.map_export_table())
+        small = ssm.Context(0, orb_features=1000, max_batch=250, voxel_capacity_log2=10, mapper_resolution=0.02, camera=CAM)
+        try:
+            small.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); small.sync()
+            tabs.append(small.map_export_table())
+            # and in two calls with an export in between (the growth state carries over)
+            small.map_clear()
+            small.seq_process(*bufs, 400, stages=ssm.api.STAGE_MAP); assert small.map_size() > 0
+            off = (W * H * 3, W * H * 2, W * H * 3, 128)
+            small.seq_process(*[b + 400 * o for b, o in zip(bufs, off)], 600, stages=ssm.api.STAGE_MAP); small.sync()
+            tabs.append(small.map_export_table())
+        finally:
+            small.close()
+        assert len(tabs[0]) > 100000
+        assert tabs[1].tobytes() == tabs[0].tobytes() and tabs[2].tobytes() == tabs[0].tobytes()
+    finally:
+        for p in bufs:
+            big.dev_free(p)
+        big.close()
 
 
 # ---------------------------------------------------------------- bench.py contract (and its all-gather path on one GPU)
