@@ -54,23 +54,38 @@ public:
             if (rebuild) { for (size_t i = 0; i < kfs.size(); i += 2) sel.push_back(kfs[i]); }
             else if (fix_incremental) { for (int i = (int)kfs.size() - 1; i >= 0 && i > (int)kfs.size() - 6; i--) sel.push_back(kfs[i]); }
             else { for (int i = (int)kfs.size() - 1; i >= 0 && (size_t)i > kfs.size() - 6; i--) sel.push_back(kfs[i]); }      // size_t wrap as in mapper.cpp:134
+            bool on_device = false;
             if (device_map) {
-                // clouds stay in HBM; transform + concatenation + VoxelGrid on the device, one download of the filtered map
-                ssm::Device& d = device(sel.empty() ? 0 : sel[0]->depth.cols, sel.empty() ? 0 : sel[0]->depth.rows);
-                vector<ssm_cloud*> cl; vector<double> poses;
-                for (const RGBDFrame::Ptr& f : sel) {
-                    cl.push_back(deviceCloud(f));
-                    const Eigen::Isometry3d T = invert_pose ? f->getTransform().inverse() : f->getTransform();
-                    poses.insert(poses.end(), T.data(), T.data() + 16);
+                // clouds stay in HBM; transform + concatenation + VoxelGrid on the device, one download of the filtered map.  Every key-frame's cloud stays resident
+                // until the viewer ends (the reference keeps frame->pointcloud in host RAM): when the device runs out of memory on a long sequence -- or any
+                // other device error hits this path -- the update is done on the host instead, and so are all later ones: `map` holds the last published map,
+                // which is byte for byte what the host schedule would hold at this point, so the switch changes no bits
+                try {
+                    ssm::Device& d = device(sel.empty() ? 0 : sel[0]->depth.cols, sel.empty() ? 0 : sel[0]->depth.rows);
+                    vector<ssm_cloud*> cl; vector<double> poses;
+                    for (const RGBDFrame::Ptr& f : sel) {
+                        cl.push_back(deviceCloud(f));
+                        const Eigen::Isometry3d T = invert_pose ? f->getTransform().inverse() : f->getTransform();
+                        poses.insert(poses.end(), T.data(), T.data() + 16);
+                    }
+                    int nmap = 0;
+                    d.check(ssm_viewer_map_update(d.ctx(), rebuild ? 1 : 0, cl.data(), poses.data(), (int)cl.size(), (float)resolution, &nmap), "ssm_viewer_map_update");
+                    PointCloud::Ptr fetched(new PointCloud);
+                    fetched->points.resize((size_t)nmap);
+                    int got = 0;
+                    d.check(ssm_viewer_map_fetch(d.ctx(), reinterpret_cast<ssm_point*>(fetched->points.data()), nmap, &got), "ssm_viewer_map_fetch");
+                    fetched->points.resize((size_t)got); fetched->width = got;
+                    map->swap(*fetched);
+                    cntGlobalUpdate++;
+                    keyframe_size = (int)kfs.size();
+                    on_device = true;
+                } catch (const std::exception& e) {
+                    cerr << "Mapper: the device-resident map update failed (" << e.what() << "); this and the following updates run on the host path" << endl;
+                    for (auto& kv : devClouds) ssm_cloud_free(dev ? dev->ctx() : nullptr, kv.second);
+                    devClouds.clear(); device_map = false; deviceMapFellBack = true;
                 }
-                int nmap = 0;
-                d.check(ssm_viewer_map_update(d.ctx(), rebuild ? 1 : 0, cl.data(), poses.data(), (int)cl.size(), (float)resolution, &nmap), "ssm_viewer_map_update");
-                cntGlobalUpdate++;
-                keyframe_size = (int)kfs.size();
-                map->points.resize((size_t)nmap);
-                int got = 0;
-                d.check(ssm_viewer_map_fetch(d.ctx(), reinterpret_cast<ssm_point*>(map->points.data()), nmap, &got), "ssm_viewer_map_fetch");
-                map->points.resize((size_t)got); map->width = got;
+            }
+            if (on_device) {
             } else {
                 if (rebuild) map->clear();
                 for (const RGBDFrame::Ptr& f : sel) *map += *generatePointCloud(f);
@@ -144,6 +159,7 @@ public:
         return tmp;
     }
     std::atomic<bool> viewerFailed{false};
+    std::atomic<bool> deviceMapFellBack{false};                              // the device-resident map update failed once: host path since (same bits)
     int cloudsComputed = 0;                                                    // device back-projections so far (each frame costs one)
     PointCloud::Ptr voxelFilter(const PointCloud::Ptr& in) {                  // pcl::VoxelGrid::filter, mapper.cpp:154-155
         PointCloud::Ptr out(new PointCloud());

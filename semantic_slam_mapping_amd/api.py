@@ -100,11 +100,11 @@ class Tracker:
     """ssm_tracker: Tracker::updateFrame (RGB-D mode, src/track.cpp:8-36,140-212) for all frames of a seq_process call -- the bulk consumer of the
     match tables.  run(out, n) -> (poses n x 4 x 4 = T_f_w per frame, info structured array)."""
 
-    def __init__(self, ctx, max_lost_frame=10, pnp_min_inliers=10, use_device=False, first_pose=None, own_stream=False):
+    def __init__(self, ctx, max_lost_frame=10, pnp_min_inliers=10, use_device=False, first_pose=None, own_stream=False, blocks=0):
         self.ctx = ctx; self.lib = ctx.lib
         p = TrackerParams()
         self.lib.ssm_tracker_params_default(C.byref(p))
-        p.max_lost_frame = max_lost_frame; p.ref_frames = ctx.R; p.pnp_min_inliers = pnp_min_inliers; p.use_device = int(use_device); p.own_stream = int(own_stream)
+        p.max_lost_frame = max_lost_frame; p.ref_frames = ctx.R; p.pnp_min_inliers = pnp_min_inliers; p.use_device = int(use_device); p.own_stream = int(own_stream); p.blocks = int(blocks)
         if first_pose is not None:
             fp = np.ascontiguousarray(np.asarray(first_pose, np.float64).reshape(4, 4).T).reshape(16)       # column-major
             for i in range(16):
@@ -124,6 +124,10 @@ class Tracker:
         if rc != 0:
             raise SsmError(rc, (self.lib.ssm_tracker_last_error(self.h) or b"").decode())
         return poses[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), info[:n]
+
+    def last_error(self):
+        """the last call's error text, or a note (a downgrade of the device chain to one block) after a call that succeeded"""
+        return (self.lib.ssm_tracker_last_error(self.h) or b"").decode()
 
     def stats(self):
         """(frames solved by the device chain, frames solved by the host path)"""
@@ -155,6 +159,7 @@ class Context:
         self.lib = _lib.load()
         self.cfg = cfg if cfg is not None else default_config(**kw)
         self._pattern_keep = None
+        self._inflight = []                 # output buffers of asynchronous calls that have not been waited for
         h = C.c_void_p()
         rc = self.lib.ssm_create(device, C.byref(self.cfg), C.byref(h))
         if rc != 0:
@@ -202,6 +207,7 @@ class Context:
         depth = None if depth is None else np.ascontiguousarray(depth, np.uint16)
         kps = np.zeros(self.cap, KEYPOINT_DTYPE); desc = np.zeros((self.cap, 32), np.uint8); pos = np.zeros((self.cap, 3), np.float32)
         n = C.c_int(-1)
+        self._inflight.append((kps, desc, pos, n))      # the C finisher writes into these at the next wait (explicit, or implied by a full ring / ssm_sync): they must outlive the holder
         self._chk(self.lib.ssm_orb_extract_async(self.h, _ptr(img), w, h, img.strides[0], ch, _ptr(depth), _ptr(kps), _ptr(desc), _ptr(pos), self.cap, C.byref(n)))
         return lambda: (kps[:n.value], desc[:n.value], pos[:n.value])
 
@@ -209,6 +215,7 @@ class Context:
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
         out = np.zeros(max(len(q), 1), DMATCH_DTYPE); n = C.c_int(-1)
         r = self.cfg.knn_match_ratio if ratio is None else ratio
+        self._inflight.append((out, n))
         self._chk(self.lib.ssm_match_async(self.h, _ptr(q), len(q), _ptr(t), len(t), r, _ptr(out), len(out), C.byref(n)))
         return lambda: out[:n.value]
 
@@ -223,7 +230,10 @@ class Context:
         return [o[:n[i]] for i, o in enumerate(outs)]
 
     def wait(self):
-        self._chk(self.lib.ssm_wait(self.h))
+        try:
+            self._chk(self.lib.ssm_wait(self.h))
+        finally:
+            self._inflight.clear()
 
     def knn2(self, q, t):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
@@ -577,7 +587,14 @@ class Context:
         return out
 
     def sync(self):
-        self._chk(self.lib.ssm_sync(self.h))
+        try:
+            self._chk(self.lib.ssm_sync(self.h))
+        finally:
+            self._inflight.clear()
+
+    def last_error(self):
+        """ssm_last_error: the last failing call's text, or a "note: ..." a successful call left (an SGBM sweep repeated in form 1)"""
+        return (self.lib.ssm_last_error(self.h) or b"").decode()
 
     def set_profiling(self, on):
         self._chk(self.lib.ssm_set_profiling(self.h, int(on)))

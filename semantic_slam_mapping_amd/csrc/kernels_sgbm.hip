@@ -24,6 +24,7 @@
 #include "ssm_internal.h"
 #include <climits>
 #include <mutex>
+#include <tuple>
 #include <map>
 #include <set>
 #include <utility>
@@ -1505,7 +1506,7 @@ static int sg_num_cus()
 }
 template <int K>
 static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck, unsigned* flags, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
-                                  bool costs_below_2_15, int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int* fail_out, hipStream_t s)
+                                  bool costs_below_2_15, int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int* fail_out, int concurrent, hipStream_t s)
 {
     constexpr int NG = (K + 1) / 2 + 1, D = 16 * K;
     const size_t np = (size_t)w * h, npb = np * nb;
@@ -1532,6 +1533,26 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     auto sweep = use8 ? (costs_below_2_15 ? sgbm_sweep8<K, true> : sgbm_sweep8<K, false>) : (costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>);
     hipError_t e = sg_allow_lds(reinterpret_cast<const void*>(sweep), lds);
     if (e != hipSuccess) return e;
+    // Forward progress of the strips' hand-offs (an ordinary launch: nothing guarantees co-residency): the blocks that run hold the lowest tickets, so a frame
+    // advances as soon as all NS strips of the lowest unfinished frame are resident -- which needs NS block slots for this launch even when `concurrent` sweeps
+    // (the SGBM streams of the batched path) share the device.  Checked against the occupancy the runtime reports for this kernel, block size and LDS; when it
+    // does not hold the caller takes form 1 (no cross-block waits).  SSM_SGBM_TEST_TIMEOUT=2 (tests) pretends it does not.
+    {
+        static std::mutex mu; static std::map<std::tuple<int, const void*, int, size_t>, int> occ;
+        int dev = 0; (void)hipGetDevice(&dev);
+        int per_cu = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto key = std::make_tuple(dev, reinterpret_cast<const void*>(sweep), threads, lds);
+            auto it = occ.find(key);
+            if (it == occ.end()) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(sweep), threads, lds) != hipSuccess) per_cu = 0;
+                occ[key] = per_cu;
+            } else per_cu = it->second;
+        }
+        static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
+        if (test_hook == 2 || (long)per_cu * sg_num_cus() < (long)NS * (concurrent > 0 ? concurrent : 1)) return hipErrorCooperativeLaunchTooLarge;
+    }
     static const int rows_lanes = [] { const char* v = getenv("SSM_SGBM_ROWS_LANES"); return v ? atoi(v) : 8; }();      // 16: sgbm_rows (D / 16 disparities per lane)
     if (rows_lanes != 16) {
         // checkpoints every 12 columns (SSM_SGBM_SEG = 8 | 16): 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage at 8 / 12 / 16, but 4.32 / 4.38 / 4.33 k pairs/s for
@@ -1550,12 +1571,16 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     if (e != hipSuccess) return e;
     sweep<<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
                                        reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
+    {   // SSM_SGBM_TEST_TIMEOUT=1 (tests): report a hand-off time-out whatever happened, so that the caller's repeat in form 1 runs
+        static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
+        if (test_hook == 1 && fail_out) { e = hipMemsetAsync(fail_out, 1, 4, s); if (e != hipSuccess) return e; }
+    }
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
 template <int K>
 static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, int w1, int h, int nb, const ssm_sgbm_params& p, int minX1, int P1, int P2,
-                                 int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, hipStream_t s)
+                                 int16_t* disp_tmp, unsigned* disp2key, int16_t* disp1, int form, hipStream_t s)
 {
     auto blocks = [](int paths) { return (paths * 16 + 255) / 256; };
     SgStreams& st = sg_streams(s);
@@ -1566,7 +1591,7 @@ static hipError_t sgbm_aggregate(const uint16_t* C, uint16_t* const* Lv, int w, 
     const size_t np = (size_t)w * h, npb = np * nb;
     const long long npix = (long long)w1 * h;
     const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
-    if (sgbm_form() == 1) {
+    if (form == 1) {
         // four directions on the four side streams; the column direction follows on `s` with the winner pass inside (sgbm_col_wta)
         sgbm_path<K, 0><<<dim3(blocks(h), nb), 256, 0, st.s[0]>>>(C, Lv[0], w1, h, P1, P2);
         sgbm_path<K, 4><<<dim3(blocks(h), nb), 256, 0, st.s[1]>>>(C, Lv[4], w1, h, P1, P2);
@@ -1614,8 +1639,12 @@ size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb)
     return al(32 * np) + 6 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256 + al(256 + (size_t)nb * sgbm_mbox_bytes_per_frame((int)w1, p.numberOfDisparities));
 }
 // left / right: device u8 images [nb][h][w]; disp_out: device int16 [nb][h][w] (x16 fixed point, (minD-1)*16 = invalid)
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag)
+// form: 0 = the process default (2 unless SSM_SGBM_FORM says otherwise), 1 / 2 / 3 = ssm_config.sgbm_form (3: the five-volume form, SSM_SGBM_FORM=0); concurrent: launches
+// of this function that may be in flight on other streams at the same time (the occupancy check of form 2)
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag,
+                  int form_cfg, int concurrent)
 {
+    int form = form_cfg == 0 ? sgbm_form() : form_cfg == 3 ? 0 : form_cfg == 1 ? 1 : 2;
     if (nb <= 0) return hipSuccess;
     const int minD = p.minDisparity, D = p.numberOfDisparities, maxD = minD + D;
     const int SW = p.SADWindowSize > 0 ? p.SADWindowSize : 5, SW2 = SW / 2;
@@ -1659,20 +1688,20 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     hipError_t e;
     // the largest value C can take: P2 + SADWindowSize^2 x (gradient term <= 2 ftzero, raw term <= 255 / 4); every L is <= its C
     const long cmax = (long)P2 + (long)SW * SW * (2 * ftzero + 63);
-    if (sgbm_form() == 2) switch (D / 16) {
-#define SG_AGG2(KK) case KK: e = sgbm_aggregate2<KK>(C, Lv[0], Lv[1], sweep_flags, w, w1, h, nb, p, minX1, P1, P2, cmax < 32768, d_tmp, d2key, wta_out, fail_flag, s); break;
-        SG_AGG2(1) SG_AGG2(2) SG_AGG2(3) SG_AGG2(4) SG_AGG2(5) SG_AGG2(6) SG_AGG2(8)
+    e = hipSuccess;
+    if (form == 2) {
+        switch (D / 16) {
+#define SG_AGG2(KK) case KK: e = sgbm_aggregate2<KK>(C, Lv[0], Lv[1], sweep_flags, w, w1, h, nb, p, minX1, P1, P2, cmax < 32768, d_tmp, d2key, wta_out, fail_flag, concurrent, s); break;
+            SG_AGG2(1) SG_AGG2(2) SG_AGG2(3) SG_AGG2(4) SG_AGG2(5) SG_AGG2(6) SG_AGG2(8)
 #undef SG_AGG2
-        default: return hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+        if (e == hipErrorCooperativeLaunchTooLarge) { form = 1; e = hipSuccess; }      // the sweep's strips cannot all be resident: the form without cross-block waits (nothing was launched)
     }
-    else switch (D / 16) {
-        case 1: e = sgbm_aggregate<1>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 2: e = sgbm_aggregate<2>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 3: e = sgbm_aggregate<3>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 4: e = sgbm_aggregate<4>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 5: e = sgbm_aggregate<5>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 6: e = sgbm_aggregate<6>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
-        case 8: e = sgbm_aggregate<8>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, s); break;
+    if (form != 2) switch (D / 16) {
+#define SG_AGG1(KK) case KK: e = sgbm_aggregate<KK>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, form, s); break;
+        SG_AGG1(1) SG_AGG1(2) SG_AGG1(3) SG_AGG1(4) SG_AGG1(5) SG_AGG1(6) SG_AGG1(8)
+#undef SG_AGG1
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess || raw_only == 1) return e;

@@ -45,13 +45,17 @@ static const SegLayerDef k_seg_layers[SEG_LAYERS] = {
 };
 
 } // namespace
+#define SG_FAIL_WORDS 256
 struct StereoState {        // workspace of the stereo path (quad matcher, SGBM depth, stereo VO) for one image geometry, B frames per launch
     int w = 0, h = 0, maxc = 0, B = 0;
     QuadBatch qb{};                          // image slots: 2 sides x (B + 1) pyramids + Scharr derivatives
     uint8_t* pyr = nullptr; int16_t* der = nullptr;
     GfttWork gw{};                           // goodFeaturesToTrack workspace (kernels_quad.hip)
     int keycap = 0; int *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
-    int* sg_fail = nullptr;                  // set by sgbm_sweep when a strip hand-off times out (kernels_sgbm.hip)
+    int* sg_fail = nullptr;                  // SG_FAIL_WORDS words: word (sub-batch index mod SG_FAIL_WORDS) is set by that sub-batch's sgbm_sweep when a strip hand-off times out (kernels_sgbm.hip)
+    // the depth stage of the most recent sequence call, kept so that sub-batches whose sweep timed out can be repeated in form 1 once the call is known to have
+    // failed (ssm_sync / check_device_flags: the caller's input buffers must stay untouched until then, as for any asynchronous call)
+    struct { bool valid = false; ssm_stereo_frames_dev in{}; int B = 0; } sg_pending;
     float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
     uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
     double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
@@ -126,7 +130,8 @@ struct ssm_ctx {
     // SegNet
     struct SegNetState* seg = nullptr;
     // quad matcher
-    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // SSM_SGBM_STREAMS=1: SGBM of all sub-batches on one stream
+    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // ssm_config.sgbm_streams (SSM_SGBM_STREAMS overrides: ablations)
+    int sgbm_form_cfg = 0; long sgbm_fallbacks = 0;                                              // ssm_config.sgbm_form; sub-batches repeated in form 1 after a sweep time-out
     // profiling
     bool profiling = false;
     uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
@@ -359,6 +364,7 @@ static void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back
 // ORB scratch overflow (d_status) is checked after every ORB entry point; the voxel-table-full flag (counters[1]) belongs to the MAP entry points
 // (ssm_sync after ssm_seq_process, ssm_map_*): it is reported once, so that one overflowing call does not fail every later call on the
 // context (the map then lacks the dropped points: ssm_map_clear / a larger voxel_capacity_log2 is the remedy the message names)
+static int sgbm_recover(ssm_ctx* c);
 static int check_device_flags(ssm_ctx* c, bool with_map)
 {
     int32_t st = 0, cnt[2] = {0, 0};
@@ -368,11 +374,7 @@ static int check_device_flags(ssm_ctx* c, bool with_map)
         int32_t ov = 0;
         HIPCHK(c, hipMemcpy(&ov, c->stereo->overflow, 4, hipMemcpyDeviceToHost));
         if (ov) { hipMemset(c->stereo->overflow, 0, 4); FAIL(c, SSM_E_CAPACITY, "goodFeaturesToTrack: more corner candidates than the buffer holds (w*h/4 + 1024)"); }
-        if (c->stereo->sg_fail) {
-            int32_t sf = 0;
-            HIPCHK(c, hipMemcpy(&sf, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost));
-            if (sf) { hipMemset(c->stereo->sg_fail, 0, 4); FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out (the disparities of this call are incomplete)"); }
-        }
+        if (c->stereo->sg_fail) { const int r = sgbm_recover(c); if (r) return r; }
     }
     if (with_map) {
         { const int r = map_settle(c, c->stream, 0); if (r) return r; }
@@ -482,8 +484,10 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
     { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
-    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 128 ? 128 : b; }
-    { const char* e = getenv("SSM_SGBM_STREAMS"); if (e) { const int v = atoi(e); c->stereo_sgbm_streams = v < 1 ? 1 : v > 3 ? 3 : v; } }
+    // the stereo path's knobs come from the configuration (two contexts of a process may differ); the environment variables remain as overrides for ablation runs
+    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : cfg->stereo_batch > 0 ? cfg->stereo_batch : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 128 ? 128 : b; }
+    { const char* e = getenv("SSM_SGBM_STREAMS"); const int v = e ? atoi(e) : cfg->sgbm_streams; if (v > 0) c->stereo_sgbm_streams = v > 3 ? 3 : v; }
+    c->sgbm_form_cfg = cfg->sgbm_form;
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
     { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
@@ -494,6 +498,7 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     if (!r && cfg->voxel_max_capacity_log2 != 0 && (cfg->voxel_max_capacity_log2 < cfg->voxel_capacity_log2 || cfg->voxel_max_capacity_log2 > 28)) { c->err = "voxel_max_capacity_log2 must be voxel_capacity_log2..28 (0: 28)"; r = SSM_E_INVAL; }
     if (!r) c->vox_max_log2 = cfg->voxel_max_capacity_log2 ? cfg->voxel_max_capacity_log2 : 28;
     if (!r && !(cfg->mapper_resolution > 0)) { c->err = "mapper_resolution must be > 0"; r = SSM_E_INVAL; }
+    if (!r && (cfg->sgbm_form < 0 || cfg->sgbm_form > 3 || cfg->sgbm_streams < 0 || cfg->sgbm_streams > 3 || cfg->stereo_batch < 0)) { c->err = "sgbm_form must be 0..3, sgbm_streams 0..3, stereo_batch >= 0"; r = SSM_E_INVAL; }
     if (!r && c->B > 16384) { c->err = "max_batch must be <= 16384"; r = SSM_E_INVAL; }
     if (!r) r = ctx_init(c);
     if (r) { g_create_err = c->err; ssm_destroy(c); return r; }
@@ -649,7 +654,11 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
 // ssm_wait runs after the stream has drained.  The synchronous forms are the asynchronous ones + ssm_wait.
 static int wait_pending(ssm_ctx* c)
 {
-    if (c->pending.empty()) return SSM_OK;
+    if (c->pending.empty()) {
+        // (an enqueue that failed behind its ring_take has advanced the offsets without registering a finisher: drain what may still read the ring, then rewind)
+        if (c->h_ring_off || c->d_ring_off) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->h_ring_off = 0; c->d_ring_off = 0; }
+        return SSM_OK;
+    }
     int rc = SSM_OK;
     const hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { c->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = SSM_E_HIP; }
@@ -675,6 +684,7 @@ static int ring_take(ssm_ctx* c, size_t hbytes, size_t dbytes, uint8_t** hp, uin
             if (hipMalloc((void**)&c->d_ring, nb) != hipSuccess) { hipHostFree(c->h_ring); c->h_ring = nullptr; FAIL(c, SSM_E_HIP, "hipMalloc of the result ring failed"); }
             c->ring_bytes = nb;
         }
+        if (c->h_ring_off + hbytes > c->ring_bytes || c->d_ring_off + dbytes > c->ring_bytes) FAIL(c, SSM_E_HIP, "staging ring: the request does not fit after the wait");
     }
     *hp = c->h_ring + c->h_ring_off; *dp = c->d_ring + c->d_ring_off;
     c->h_ring_off += hbytes; c->d_ring_off += dbytes;
@@ -1850,10 +1860,10 @@ static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
     DALLOC(c, g.deps, (size_t)B * q->keycap * k_quad_gftt_deps_per_candidate()); DALLOC(c, g.depn, (size_t)B * q->keycap); DALLOC(c, g.state, (size_t)B * q->keycap);
     HIPCHK(c, hipMemset(g.cand_at, 0, (size_t)B * np * 4));      // gftt_finish_kernel keeps the map zeroed between calls
     DALLOC(c, g.cand_bits, (size_t)B * k_quad_gftt_bits_words(w, h));
-    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->sg_fail, 1); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
+    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->sg_fail, SG_FAIL_WORDS); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
     g.overflow = q->overflow;
     HIPCHK(c, hipMemset(q->overflow, 0, 4));
-    HIPCHK(c, hipMemset(q->sg_fail, 0, 4));
+    HIPCHK(c, hipMemset(q->sg_fail, 0, 4 * SG_FAIL_WORDS));
     DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
     DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1);
     return SSM_OK;
@@ -1974,7 +1984,8 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             hipStream_t sg = sgs[alt];
             struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
             prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail));
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail + (f0 / B) % SG_FAIL_WORDS,
+                             c->sgbm_form_cfg, nsg));
             HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dminN[alt], q->depth + (size_t)f0 * np, sg));
             prof_end(c);
         }
@@ -1983,6 +1994,8 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
     if (nsg > 1) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
     if (nsg > 2) { HIPCHK(c, hipEventRecord(c->ev_join4, c->stream4)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0)); }
     if (n > 0) q->have_prev = (stages & SSM_STEREO_QUAD) != 0;
+    q->sg_pending.valid = (stages & SSM_STEREO_DEPTH) && n > 0;
+    if (q->sg_pending.valid) { q->sg_pending.in = *in; q->sg_pending.B = B; }
     if (out) {
         out->quad = q->quad; out->nquad = q->nquad; out->corners = q->corners; out->ncorners = q->ncorners; out->disp = q->disp; out->depth = q->depth;
         out->tr = q->tr; out->inliers = q->inliers; out->vo_result = q->vo_result; out->rand_draws_used = q->consumed; out->max_corners = maxc;
@@ -2116,7 +2129,7 @@ extern "C" void ssm_sgbm_params_default(ssm_sgbm_params* p)
 }
 // one host pair through the batched kernels (nb = 1): images staged on the device, disparity (and depth) left in the sequence output buffers
 static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage,
-                    int16_t** d_disp_out, uint16_t** d_depth_out)
+                    int16_t** d_disp_out, uint16_t** d_depth_out, int form)
 {
     if (!left || !right || !params || w < 3 || h < 1 || stride < w) FAIL(c, SSM_E_INVAL, "bad arguments");
     int r = sgbm_check_params(c, params, w, h); if (r) return r;
@@ -2129,18 +2142,45 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
     prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream, q->sg_fail));
+    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream, q->sg_fail, form, 1));
     prof_end(c);
+    q->sg_pending.valid = false;                                  // (the staged pair is this call's: the host-pointer entry points repeat a timed-out sweep themselves)
     *d_disp_out = q->disp; *d_depth_out = q->depth;
     return SSM_OK;
 }
+// cv::StereoSGBM cannot fail (src/stereo.cpp:11-30); form 2's sweep can: its strips wait for each other, and when a hand-off exceeds its spin bound every block
+// leaves mid-image with the sub-batch's fail word set.  Called with the streams drained: every sub-batch of the last sequence call whose word is set is computed again
+// with form 1 (independent paths, no cross-block waits; the workspace holds its volumes anyway) from the caller's input images, so that the call's disparities and depths
+// are the oracle's after all.  Reported through ssm_last_error (a note, the call succeeds) and counted in sgbm_fallbacks.
+static int sgbm_recover(ssm_ctx* c)
+{
+    StereoState* q = c->stereo;
+    int32_t sf[SG_FAIL_WORDS];
+    HIPCHK(c, hipMemcpy(sf, q->sg_fail, sizeof(sf), hipMemcpyDeviceToHost));
+    bool any = false; for (int k = 0; k < SG_FAIL_WORDS; k++) any = any || sf[k] != 0;
+    if (!any) return SSM_OK;
+    HIPCHK(c, hipMemset(q->sg_fail, 0, sizeof(sf)));
+    if (!q->sg_pending.valid) FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out and the call that launched it is no longer known (the disparities are incomplete)");
+    const ssm_stereo_frames_dev& in = q->sg_pending.in; const int B = q->sg_pending.B, w = q->w, h = q->h; const size_t np = (size_t)w * h;
+    int redone = 0;
+    for (int f0 = 0, bi = 0; f0 < in.n; f0 += B, bi++) {
+        if (!sf[bi % SG_FAIL_WORDS]) continue;
+        const int nb = in.n - f0 < B ? in.n - f0 : B;
+        HIPCHK(c, k_sgbm(in.left + (size_t)f0 * np, in.right + (size_t)f0 * np, w, h, nb, in.sgbm, q->sg_wsN[0], q->disp + (size_t)f0 * np, 0, c->stream, q->sg_fail + bi % SG_FAIL_WORDS, 1, 1));
+        HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in.baseline, in.cu, in.cv, in.f, in.roix, in.roiy, in.roiz, in.scale, q->dminN[0], q->depth + (size_t)f0 * np, c->stream));
+        redone++;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sgbm_fallbacks += redone;
+    c->err = "note: the SGBM sweep of " + std::to_string(redone) + " sub-batch(es) timed out in a strip hand-off; they were repeated with form 1 (results complete)";
+    return SSM_OK;
+}
 // the sweep kernel's time-out word, copied to the front of the pinned area with the results of a host-pointer call
-static int sgbm_fail_check(ssm_ctx* c)
+static bool sgbm_failed(ssm_ctx* c)
 {
     int32_t sf; memcpy(&sf, c->h_pinned, 4);
-    if (!sf) return SSM_OK;
-    hipMemset(c->stereo->sg_fail, 0, 4);
-    FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out (the disparities of this call are incomplete)");
+    if (sf) hipMemset(c->stereo->sg_fail, 0, 4);
+    return sf != 0;
 }
 extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp)
 {
@@ -2148,13 +2188,19 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
     int16_t* dd; uint16_t* ddepth;
-    int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));      // (the staged input images at the front of the pinned area are consumed)
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int attempt = 0; ; attempt++) {                      // a sweep whose hand-off timed out is repeated once, in form 1 (no cross-block waits)
+        int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));      // (the staged input images at the front of the pinned area are consumed)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!sgbm_failed(c)) break;
+        if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
+        c->sgbm_fallbacks++;
+    }
     memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    return sgbm_fail_check(c);
+    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
+    return SSM_OK;
 }
 extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
                                 double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
@@ -2164,16 +2210,22 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!depth) FAIL(c, SSM_E_INVAL, "null argument");
     int16_t* dd; uint16_t* ddepth;
-    int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth); if (r) return r;
     const size_t np = (size_t)w * h;
-    HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
-    if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int attempt = 0; ; attempt++) {
+        int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
+        HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
+        if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!sgbm_failed(c)) break;
+        if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
+        c->sgbm_fallbacks++;
+    }
     memcpy(depth, c->h_pinned + 4 * np, np * 2);
     if (disp) memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    return sgbm_fail_check(c);
+    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
+    return SSM_OK;
 }
 
 // ---------------------------------------------------------------- VisualOdometryStereo::estimateMotion

@@ -30,6 +30,7 @@ struct ssm_tracker {
     uint8_t *d_inl = nullptr, *d_dec = nullptr; void* d_edges = nullptr; double2* d_err = nullptr; int d_cap = 0, d_R = 0, d_n = 0;
     unsigned long long* d_xchg = nullptr; int blocks = 1;      // the cluster form of the device chain (SSM_PNP_BLOCKS, kernels_pnp.hip): blocks per chain, their exchange ring
     long device_frames = 0, host_frames = 0;
+    bool downgraded = false;              // the cluster form timed out once: one block per chain since (reported by ssm_tracker_last_error)
     int64_t work[4] = {0, 0, 0, 0};       // the device chain's passes over the edges (ssm_tracker_work)
     hipStream_t own = nullptr; hipEvent_t ev = nullptr;      // own_stream: the chain's stream and the event that orders it behind the context's stream
 };
@@ -55,7 +56,7 @@ extern "C" int ssm_tracker_create(ssm_ctx* ctx, const ssm_tracker_params* p, ssm
     // blocks per device chain (kernels_pnp.hip, the cluster form): eight for a chain that has the GPU to itself (latency: -6.5 % per frame; four: -3.4 %); ONE for an
     // own_stream tracker -- those exist to run many chains side by side, where a CU per chain is the efficient form and the blocks of several clusters would
     // have to be resident together.  SSM_PNP_BLOCKS = 1 | 2 | 4 | 8 overrides (same bits in every form).
-    { const char* e = getenv("SSM_PNP_BLOCKS"); const int d = p->own_stream ? 1 : 8, g = e ? atoi(e) : d; t->blocks = (g == 1 || g == 2 || g == 4 || g == 8) ? g : d; }
+    { const char* e = getenv("SSM_PNP_BLOCKS"); const int d = p->own_stream ? 1 : 8, g = e ? atoi(e) : (p->blocks > 0 ? p->blocks : d); t->blocks = (g == 1 || g == 2 || g == 4 || g == 8) ? g : d; }
     (void)hipSetDevice(ssm_internal_get_device(ctx));              // the raw HIP calls of this file act on the context's device, whatever the calling thread used last
     if (p->own_stream && (hipStreamCreateWithFlags(&t->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess)) {
         if (t->own) hipStreamDestroy(t->own);
@@ -196,8 +197,7 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             if (hs.stopped_at == -1 && t->blocks > 1) {
                 // the blocks of the cluster did not meet within the spin bound (they need CUs at the same time: a device kept full by other work for seconds).
                 // Nothing of the tracker's host state has changed yet: the same range again with one block per chain -- same kernel arithmetic, same bits
-                fprintf(stderr, "ssm_tracker_run: the pose chain's cluster timed out; this tracker continues with one block per chain\n");
-                t->blocks = 1;
+                t->blocks = 1; t->downgraded = true;
                 continue;
             }
             const int stop = hs.stopped_at;
@@ -296,6 +296,8 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
         f++;
     }
     t->next_gidx += n;
+    // (a note, the call succeeded: ssm_tracker_last_error is how a downgrade of the device chain shows)
+    t->err = t->downgraded ? "note: the pose chain's cluster of blocks timed out in an exchange; this tracker continues with one block per chain (same poses)" : "";
     return SSM_OK;
 }
 extern "C" int ssm_tracker_stats(const ssm_tracker* t, int64_t* device_frames, int64_t* host_frames)

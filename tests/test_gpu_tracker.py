@@ -95,10 +95,11 @@ def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device, monkeypatch):
     import semantic_slam_mapping_amd as ssm
     # use_device True: the default form of the device chain (a cluster of eight blocks per chain, kernels_pnp.hip); 1 / 2 / 4: that many blocks -- the same bits in every form
     # "timeout": the cluster's exchange reports a time-out at once (test hook) -> the tracker must fall back to one block per chain and still produce the walk
-    if use_device == "timeout":
+    blocks, timeout = 0, use_device == "timeout"
+    if timeout:
         monkeypatch.setenv("SSM_PNP_TEST_TIMEOUT", "1"); use_device = True
     elif use_device is not True and use_device:
-        monkeypatch.setenv("SSM_PNP_BLOCKS", str(use_device)); use_device = True
+        blocks, use_device = int(use_device), True                                   # ssm_tracker_params.blocks (no environment variable, no subprocess)
     n, W, H, nfeat = 14, 640, 480, 500
     bgr0 = oracle.synth_frame(SEED, 21)[0]
     frames = []
@@ -108,7 +109,7 @@ def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device, monkeypatch):
             bgr[:] = 100
         frames.append((bgr, np.full((H, W), 2000, np.uint16)))
     c = ssm.Context(0, orb_features=nfeat, max_batch=3, voxel_capacity_log2=14, camera=CAM)
-    trk = ssm.Tracker(c, max_lost_frame=1, use_device=use_device)
+    trk = ssm.Tracker(c, max_lost_frame=1, use_device=use_device, blocks=blocks)
     db = c.dev_alloc(n * W * H * 3); dd = c.dev_alloc(n * W * H * 2)
     try:
         c.h2d(db, np.stack([f[0] for f in frames])); c.h2d(dd, np.stack([f[1] for f in frames]))
@@ -124,6 +125,7 @@ def test_bulk_tracker_equals_the_oracle_walk(oracle, use_device, monkeypatch):
             assert poses[f].tobytes() == np.asarray(wposes[f], np.float64).tobytes(), f
         assert [int(i["tracked"]) for i in info] == [1, 1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 1, 1, 1]
         assert int(info[10]["state"]) == 2 and int(info[11]["state"]) == 1 and info[5]["n_inliers"] > 100
+        assert ("one block per chain" in trk.last_error()) == timeout                 # the downgrade is visible to the caller, and only then
         dev_frames, host_frames = trk.stats()
         assert dev_frames + host_frames == n and (dev_frames >= 5 if use_device else dev_frames == 0)     # the regular stretches ran as one-block chains on the GPU
         # the solved poses feed the map stage
