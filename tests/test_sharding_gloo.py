@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_frames=N_FRAMES, stride=1, size=(160, 120)):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -27,10 +27,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         orc = Oracle()
-        lo, hi = sharding.frame_block(N_FRAMES, rank, world)
+        lo, hi = sharding.frame_block(n_frames, rank, world)
         clouds = []
-        for f in range(lo, hi):
-            bgr, dep, sem, _, T = orc.synth_frame(0x5EED0000, f, 160, 120)
+        for f in range(lo, hi, stride):
+            bgr, dep, sem, _, T = orc.synth_frame(0x5EED0000, f, *size)
             clouds.append(orc.backproject(dep, bgr, sem, orc.moving_mask(sem), CAM, T, 40.0))
         tab = orc.voxel_table(np.concatenate(clouds), np.float32(0.05))
         dev = torch.device("cpu")
@@ -70,6 +70,42 @@ def test_two_rank_merge_equals_single_process(oracle):
         assert r[5]["verified"] and r[5]["ranks_agree"] and r[5]["voxels_merged"] == len(single) and r[5]["voxels_per_rank"] == res[0][3]
         assert r[5]["crc"] == "%08x" % (zlib.crc32(single.tobytes()) & 0xFFFFFFFF)
         assert not r[6]["verified"] and not r[6]["ranks_agree"]
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_plan_of_configs4_merges_to_the_single_process_map(oracle):
+    """BASELINE configs[4] at its real rank count, on CPU: the 10 000-frame stream in 8 contiguous blocks of 1250 (5-frame matcher halos in front of ranks 1..7),
+    every rank fuses frames of ITS block (every 20th, at 96 x 72, so that the oracle stands in for the device within seconds), the tables -- uneven in size: the
+    stream moves 1 cm per frame, the blocks see different parts of the scene -- go through the padded all-gather of sharding.allgather_tables over an 8-rank gloo
+    group, and every rank's merge equals the map one process builds from the same 504 frames, byte for byte; the merge check's CRCs agree on all eight ranks"""
+    import torch.multiprocessing as mp
+    from semantic_slam_mapping_amd import sharding
+    WORLD, N, STRIDE, SIZE = 8, 10000, 20, (96, 72)
+    blocks = [sharding.frame_block(N, r, WORLD) for r in range(WORLD)]
+    assert blocks == [(1250 * r, 1250 * (r + 1)) for r in range(WORLD)]
+    assert [sharding.halo_block(lo, 5) for lo, _ in blocks] == [(0, 0)] + [(1250 * r - 5, 1250 * r) for r in range(1, WORLD)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q, N, STRIDE, SIZE)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(WORLD))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    clouds = []
+    for lo, hi in blocks:
+        for f in range(lo, hi, STRIDE):
+            bgr, dep, sem, _, T = oracle.synth_frame(0x5EED0000, f, *SIZE)
+            clouds.append(oracle.backproject(dep, bgr, sem, oracle.moving_mask(sem), CAM, T, 40.0))
+    single = oracle.voxel_table(np.concatenate(clouds), np.float32(0.05))
+    per_rank = res[0][3]
+    assert len(per_rank) == WORLD and len(set(per_rank)) > 1 and min(per_rank) > 0           # uneven tables: the all-gather pads to the longest
+    assert sum(per_rank) > len(single) > max(per_rank)                                        # neighbouring blocks share voxels: the merge really adds
+    for r in res:
+        assert (r[1], r[2]) == blocks[r[0]] and r[3] == per_rank
+        assert r[4] == single.tobytes(), r[0]
+        assert r[5]["verified"] and r[5]["ranks_agree"] and r[5]["voxels_merged"] == len(single) and r[5]["voxels_per_rank"] == per_rank
+        assert not r[6]["verified"]                                                           # rank 1's corrupted table is caught on every rank
 
 
 def test_block_plan_and_halo():
