@@ -426,6 +426,12 @@ def rgbd_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.leaf < 0.1:                                # a small leaf: millions of voxels -- the export buffer is sized from one untimed pass (the context map grows by itself)
+        ctx.map_clear()
+        ctx.seq_process(bgr.data_ptr(), dep.data_ptr(), None if args.segnet else sem.data_ptr(), pose.data_ptr(), F, stages=stages or ssm.api.STAGE_MAP)
+        ctx.sync(); tab_cap = max(tab_cap, 2 * ctx.map_size() * max(world, 1))
+        del tab_buf
+        tab_buf = torch.empty(tab_cap * sharding.VOXEL_BYTES, dtype=torch.uint8, device=dev)
     for _ in range(args.warmup):
         step()
     # ---- timed region: K steps as a user runs them (map / SegNet stage on a second stream beside the ORB -> match chain);

@@ -17,6 +17,8 @@
 
 using namespace ssm_pnp;
 #define PC_T 1024
+#define PC_SPEC 8                 // trials of a rejected streak evaluated together (pc_optimize)
+#define PC_RBUF 3072              // doubles (24 KB of LDS)
 // an edge as the passes read it: 24 bytes (the Edge of pnp_core.h is 72; its error lives in a separate global array).  meta = id | level << 16 | robust << 17
 struct LEdge { float X[3], u, v; uint32_t meta; };
 #define LE_LEVEL (1u << 16)
@@ -41,8 +43,13 @@ struct PcShared {
 #ifdef SSM_PNP_PROF
     long long prof[8];
 #endif
-    double red[NGROUP][NACC + 1];
-    double tot[NACC + 1];
+    double red[NGROUP][NACC + 1 + PC_SPEC];
+    double tot[NACC + 1 + PC_SPEC];
+    // a rejected Levenberg trial is followed by trials whose damping is known in advance (lambda <- lambda nu, nu <- 2 nu until one is accepted): wave c solves
+    // candidate c of such a streak and ONE pass over the edges evaluates all of them (pc_chi_spec)
+    struct { double x[6]; Pose P; int solved, pad; } spec[PC_SPEC];
+    double spec_lambda, spec_nu; int spec_n;
+    double rbuf[PC_RBUF];         // cluster form: the chi2 terms of (candidate, edge slot) items computed by the waves whose lanes another block owns (pc_chi_spec)
     Pose P, saved, init;          // the estimate wave 0 publishes for the next pass; the one before the trial; the round's start value
     double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
@@ -95,17 +102,30 @@ __device__ __forceinline__ void pc_rs_step(double* a, bool up)
 // bit k selects (28 -> 14 -> 7 (+ 1 pad) -> 4 -> 2 -> 1) -- 29 additions and 31 exchanges per lane instead of 168 and 168 (the butterfly was 45 % of the
 // fused pass's instructions and kept the LDS pipe busy with 336 ds_bpermute per wave).  Lane 0 of each wave (one value) / the lane that ends up with value v
 // publishes the group sum, threads 0 .. NV-1 add the 16 group sums in group order.
+template <int NV, int OFF, bool CL> __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv = NV);
 template <int NV, int OFF, bool CL>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if constexpr (NV == 1) {
+    if constexpr (NV == 8) {
+        // eight values: reduce-scatter over the first three levels (8 -> 4 -> 2 -> 1 per lane), the plain exchange for the rest; lane l < 8 ends with value
+        // (l & 1) 4 + ((l >> 1) & 1) 2 + ((l >> 2) & 1)
+        double a[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) a[v] = acc[v];
+        pc_rs_step<1, 4>(a, lane & 1);
+        pc_rs_step<2, 2>(a, lane & 2);
+        pc_rs_step<4, 1>(a, lane & 4);
+        double t = a[0];
+        t = t + pc_xor_f64<8, false>(t); t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
+        if (lane < 8) sh.red[wv][OFF + (lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)] = t;
+    } else if constexpr (NV == 1) {
         double a = acc[0];
         a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
         a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
         if (lane == 0) sh.red[wv][OFF] = a;
     } else {
-        static_assert(NV == 28, "the halving sequence below is written for 28 values");
+        static_assert(NV == 28, "the halving sequences are written for 1, 8 and 28 values");
         double a[28];
 #pragma unroll
         for (int v = 0; v < 28; v++) a[v] = acc[v];
@@ -120,6 +140,12 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         const int v = (lane & 1) * 14 + ((lane >> 1) & 1) * 7 + sub;
         if (lane < 32 && sub < 7) sh.red[wv][OFF + v] = t;
     }
+    pc_lane_finish<NV, OFF, CL>(sh);
+}
+// the block part of pc_lane_sum: sh.red[group][OFF .. OFF + NV) hold the group sums of this block's lanes (written by whoever computed them)
+template <int NV, int OFF, bool CL>
+__device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv <= NV: the values in use (block-uniform; the others are neither exchanged nor summed)
+{
     __syncthreads();
     if constexpr (CL) {
         // every block holds the group sums of its own waves; a sum is published as two 8-byte {pass tag, 32 bits} granules (one agent-scope store each: the data is the
@@ -129,13 +155,13 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         const unsigned seq = sh.xseq; const unsigned long long tag = (unsigned long long)(seq + 1) << 32;
         typedef __attribute__((address_space(1))) unsigned long long gu64;          // (global_load / global_store, not flat: the ring is device memory)
         gu64* slot = (gu64*)sh.xmb + (size_t)(seq & 3u) * NGROUP * 32 * 2;
-        if (g < gpb && v < NV) {
+        if (g < gpb && v < nv) {
             const int gg = (int)blockIdx.x * gpb + g;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + v]);
             __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (g < NGROUP && v < NV) {
+        if (g < NGROUP && v < nv) {
             // two polls in flight, half a round trip apart (a poll that leaves just before the granule lands costs a whole round trip of ~1.2 k clocks otherwise):
             // the second leaves ~600 clocks behind the first, after that each is re-issued when its answer is in, which keeps the spacing
             const gu64* q = slot + (size_t)(g * 32 + v) * 2;
@@ -155,7 +181,7 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
         __syncthreads();
         if (threadIdx.x == 0) sh.xseq = seq + 1;
     }
-    if (threadIdx.x < NV) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
+    if ((int)threadIdx.x < nv) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
     __syncthreads();
 }
 // the lanes whose edges this block evaluates (all of them in the one-block form)
@@ -171,6 +197,77 @@ __device__ __forceinline__ void pc_chi(const LEdge* L, double2* err, int ne, con
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[0] += edge_rho(e, P, k, delta); err[i] = make_double2(e.e0, e.e1); }
     }
     pc_lane_sum<1, NACC, CL>(acc, sh);
+}
+// the robustified chi2 of the active edges at the poses of candidates 0 .. n-1 (sh.spec[c].P) -> sh.tot[NACC + 1 + c].  The edges' stored errors are NOT touched: every
+// lm_optimize ends with a pc_chi at its final estimate, and nothing reads an error before that (edge_accumulate follows an edge_rho at the same estimate)
+template <bool CL>
+__device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const Camera& k, double delta, PcShared& sh)
+{
+    if constexpr (CL) {
+        // The cluster form: this block owns the lanes of gpb = 16 / G contract groups, i.e. gpb of its sixteen waves have edges and the others would idle.  Here
+        // all of them work: wave (set, gi) stands for group gi of the block and takes the items (candidate c, edge slot j) with (c J + j) mod G = set -- ONE edge
+        // of ONE candidate at a time -- and leaves the edge's chi2 term in LDS; then the set of candidate c adds a lane's terms in slot order (0 + r0 + r1 ...:
+        // the lane's running sum of pnp_core.h; an inactive or missing edge contributes +0, which changes no sum of non-negative terms) and runs the group tree.
+        const int G = (int)gridDim.x, gpb = NGROUP / G;
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
+        const int gg = (int)blockIdx.x * gpb + gi, lane0 = gg * GROUP + lane, bl = gi * GROUP + lane;       // contract group / lane; lane index inside the block
+        const int J = (ne + PC_T - 1) / PC_T, per = gpb * GROUP, room = PC_RBUF / per;                      // edge slots per lane; items the buffer holds
+        const int CC = J <= room ? room / J : 0;                                                            // candidates per filling of the buffer
+        for (int c0 = 0; c0 < n; c0 += (CC > 0 ? CC : 1)) {
+            if (CC > 0) {
+                const int nc = n - c0 < CC ? n - c0 : CC;
+                for (int it = set; it < nc * J; it += G) {
+                    const int c = it / J, j = it - c * J, i = lane0 + j * PC_T;
+                    double r = 0.0;
+                    if (i < ne) { const LEdge l = L[i]; if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); r = edge_rho(e, sh.spec[c0 + c].P, k, delta); } }
+                    sh.rbuf[it * per + bl] = r;
+                }
+                __syncthreads();
+                for (int c = set; c < nc; c += G) {
+                    double a = 0.0;
+                    for (int j = 0; j < J; j++) a += sh.rbuf[(c * J + j) * per + bl];
+                    a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
+                    a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
+                    if (lane == 0) sh.red[gg][NACC + 1 + c0 + c] = a;
+                }
+                __syncthreads();                                                    // (the buffer is refilled by the next group of candidates)
+            } else {                                                                // a list too long for the buffer: the owning waves walk their edges, one candidate at a time
+                if (set == 0) {
+                    double a = 0.0;
+                    for (int i = lane0; i < ne; i += PC_T) { const LEdge l = L[i]; if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); a += edge_rho(e, sh.spec[c0].P, k, delta); } }
+                    a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
+                    a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
+                    if (lane == 0) sh.red[gg][NACC + 1 + c0] = a;
+                }
+            }
+        }
+        pc_lane_finish<PC_SPEC, NACC + 1, CL>(sh, n);
+        return;
+    }
+    double acc[PC_SPEC];
+#pragma unroll
+    for (int c = 0; c < PC_SPEC; c++) acc[c] = 0.0;
+    {
+        // one block: every wave has edges.  Two candidates per walk over them (two independent chains, few enough registers to stay out of scratch); a walk
+        // whose candidates do not exist is skipped (n is block-uniform)
+#pragma unroll
+        for (int c0 = 0; c0 < PC_SPEC; c0 += 2) {
+            if (c0 >= n) continue;
+            const Pose Pa = sh.spec[c0].P, Pb = sh.spec[c0 + 1 < n ? c0 + 1 : c0].P;
+            const bool two = c0 + 1 < n;
+            double a0 = 0.0, a1 = 0.0;
+            for (int i = threadIdx.x; i < ne; i += PC_T) {
+                const LEdge l = L[i];
+                if (!(l.meta & LE_LEVEL)) {
+                    Edge e = pc_expand(l);
+                    a0 += edge_rho(e, Pa, k, delta);
+                    if (two) a1 += edge_rho(e, Pb, k, delta);
+                }
+            }
+            acc[c0] = a0; acc[c0 + 1] = a1;
+        }
+    }
+    pc_lane_sum<PC_SPEC, NACC + 1, CL>(acc, sh);
 }
 // chi2 and the normal equations at P in ONE pass over the edges (the host evaluates active_chi2 and build_system one after the other at the same
 // estimate: the same per-edge values, the same lane sums) -> sh.tot[0 .. 26] = H (lower triangle) and b, sh.tot[27] = chi2
@@ -211,27 +308,42 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
             if (it == 0) { double mx = 0; for (int j = 0; j < 6; j++) { const double dg = fabs(Hl[j * (j + 1) / 2 + j]); if (dg > mx) mx = dg; } st.lambda = 1e-5 * mx; st.nu = 2; }
             gain = 0; trials = 0;
         }
+        // The trials of an iteration.  The first one runs alone (it is accepted more often than not).  A rejected trial is followed by trials whose damping is
+        // known in advance (lm_update's reject branch: lambda <- lambda nu, nu <- 2 nu), so after a rejection wave c solves trial c of the coming streak (up to
+        // PC_SPEC, never beyond the tenth trial) and all their estimates go through ONE pass over the edges; wave 0 then walks the results in order with lm_update --
+        // the first accepted trial ends the walk (later candidates are dropped), a stop condition ends it too: the same decisions and the same numbers as one
+        // trial at a time.  (round 5: a converged optimize spends its time in streaks of seven or more rejections: ~54 solve -> pass -> update rounds per frame became ~36)
+        if (threadIdx.x == 0) { sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = 1; }
+        __syncthreads();
         for (;;) {
-            if (w0) {
+            const int nsp = sh.spec_n;
+            const int wv = threadIdx.x >> 6;
+            if (wv < nsp) {
+                double lam = sh.spec_lambda, nu = sh.spec_nu;
+                for (int c = 0; c < wv; c++) { lam *= nu; nu *= 2; }
                 for (int q = 0; q < 6; q++) x[q] = 0;
-                solved = solve_ldlt(Hl, st.lambda, b, x);
+                solved = solve_ldlt(Hl, lam, b, x);
                 Pose Pn = sh.P;
                 pose_oplus(Pn, x);
-                if (threadIdx.x == 0) { sh.saved = sh.P; sh.P = Pn; }
+                if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 6; q++) sh.spec[wv].x[q] = x[q]; sh.spec[wv].P = Pn; sh.spec[wv].solved = solved ? 1 : 0; }
             }
             __syncthreads();
             PROF(2)
-            pc_chi<CL>(L, err, ne, P, k, delta, sh);
-            if (threadIdx.x == 0) { sh.work[1] += 1; sh.work[3] += nact; }
+            pc_chi_spec<CL>(L, ne, nsp, k, delta, sh);
+            if (threadIdx.x == 0) { sh.work[1] += nsp; sh.work[3] += (long long)nsp * nact; }
             PROF(3) PROF_CNT(7)
             if (w0) {
-                const double chi_new = sh.tot[NACC];
-                bool brk = false;
-                if (lm_update(st, chi, chi_new, solved, x, b, gain)) chi = chi_new;
-                else { if (threadIdx.x == 0) sh.P = sh.saved; if (!isfinite(st.lambda)) brk = true; }
-                if (!brk) trials++;
-                const bool cont = !brk && gain < 0 && trials < 10;
-                if (threadIdx.x == 0) { sh.cont = cont ? 1 : 0; sh.term = (!cont && (trials == 10 || gain == 0)) ? 1 : 0; }
+                bool cont = true, brk = false;
+                for (int c = 0; c < nsp && cont; c++) {
+                    for (int q = 0; q < 6; q++) x[q] = sh.spec[c].x[q];
+                    const double chi_new = sh.tot[NACC + 1 + c];
+                    if (lm_update(st, chi, chi_new, sh.spec[c].solved != 0, x, b, gain)) { chi = chi_new; if (threadIdx.x == 0) sh.P = sh.spec[c].P; }
+                    else if (!isfinite(st.lambda)) brk = true;
+                    if (!brk) trials++;
+                    cont = !brk && gain < 0 && trials < 10;
+                }
+                if (threadIdx.x == 0) { sh.cont = cont ? 1 : 0; sh.term = (!cont && (trials == 10 || gain == 0)) ? 1 : 0;
+                                        sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = (10 - trials) < PC_SPEC ? (10 - trials) : PC_SPEC; }
             }
             __syncthreads();
             PROF(4)
@@ -241,8 +353,12 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
         __syncthreads();                                                         // (sh.cont / sh.term are rewritten by the next iteration)
         if (term) break;
     }
-    pc_chi<CL>(L, err, ne, P, k, delta, sh);
-    if (threadIdx.x == 0) { sh.work[1] += 1; sh.work[3] += nact; }
+    // "the active edges carry the error at the final estimate": in the cluster form pc_solve recomputes every active edge's error itself (a block has only
+    // stored the errors of its own lanes), so the pass -- whose sum nobody reads -- is the one-block form's only
+    if constexpr (!CL) {
+        pc_chi<CL>(L, err, ne, P, k, delta, sh);
+        if (threadIdx.x == 0) { sh.work[1] += 1; sh.work[3] += nact; }
+    }
 }
 // ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
 template <bool CL>

@@ -894,6 +894,18 @@ __device__ __forceinline__ int sg_min8(int v)
     return v;
 }
 template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], const uint16_t* p) { __builtin_memcpy(d, p, 4 * K); }      // 2 K u16, 4-byte aligned
+// SGS8_EARLY_BARRIER=1 (ablation, measured round 5: 3979 vs 3986 us per 64 pairs -- no change): the row's barrier right behind the exchange writes, the next row's
+// neighbour reads issued behind it so that their LDS latency passes under the winner pass
+#ifndef SGS8_EARLY_BARRIER
+#define SGS8_EARLY_BARRIER 0
+#endif
+// exchange slots of a column: NG x 8 dwords, padded to SGS8_XSTRIDE so that the eight columns of a wave fall into different LDS banks (48 dwords: columns g and g + 4 collide)
+#ifndef SGS8_XPAD
+#define SGS8_XPAD 8
+#endif
+#ifndef SGS8_EDGE_PRIO
+#define SGS8_EDGE_PRIO 1
+#endif
 template <int K, bool FAST>
 __global__ void __launch_bounds__(1024)
 sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
@@ -904,8 +916,9 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
     __shared__ unsigned s_ticket; __shared__ int s_fail[2];
     const int ng = blockDim.x >> 3, g = threadIdx.x >> 3, li = threadIdx.x & 7;
     uint32_t* xch = reinterpret_cast<uint32_t*>(sw_smem);     // [parity 2][direction 2][ng][NG][8]: dir 0 = L1 of the column (for its right neighbour), dir 1 = L3 (for its left neighbour)
-    uint16_t* srow = reinterpret_cast<uint16_t*>(xch + (size_t)4 * ng * NG * 8) + (size_t)g * D;
-    auto xslot = [&](int par, int dir, int gg) -> uint32_t* { return xch + ((size_t)((par * 2 + dir) * ng + gg) * NG) * 8 + li; };
+    constexpr int XS = NG * 8 + SGS8_XPAD;                     // dwords per column slot
+    uint16_t* srow = reinterpret_cast<uint16_t*>(xch + (size_t)4 * ng * XS) + (size_t)g * D;
+    auto xslot = [&](int par, int dir, int gg) -> uint32_t* { return xch + (size_t)((par * 2 + dir) * ng + gg) * XS + li; };
     if (threadIdx.x == 0) { s_ticket = atomicAdd(&flags[0], 1u); s_fail[0] = 0; s_fail[1] = 0; }
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {                       // "row -1": OpenCV's zeroed border
@@ -950,9 +963,17 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #pragma unroll
     for (int j = 0; j < NG; j++) pfl[j] = pfr[j] = 0;
     const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
+#if SGS8_EDGE_PRIO
+    // the waves that hold a strip's outermost columns do more per row (publish, poll / prefetch) and everybody waits for them at the row's barrier: they issue first
+    if (wave_has_edge) __builtin_amdgcn_s_setprio(3);
+#endif
+    // the neighbouring columns' states of the previous row: read from LDS right behind the row's barrier (SGS8_EARLY_BARRIER), i.e. one winner pass ahead of their use
+    uint32_t nl[NG], nr[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) nl[j] = nr[j] = 0u;              // "row -1": OpenCV's zeroed border
     auto run_row = [&](const uint32_t (&V)[2][K], int y) {
         // ---- the neighbouring columns' states of row y - 1 (LDS; the strip's outermost columns: the mailbox or the zeroed border, below)
-        uint32_t nl[NG], nr[NG];
+#if !SGS8_EARLY_BARRIER
         const int pp = (y + 1) & 1;
         {   const uint32_t* p = xslot(pp, 0, g > 0 ? g - 1 : 0);
 #pragma unroll
@@ -961,6 +982,7 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #pragma unroll
             for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
         }
+#endif
         const bool outL = g == 0, outR = g >= TX - 1;
         // ---- the outermost columns: the direction that comes from outside the strip.  The usual case: the neighbour strip is not behind, its message of row
         // y - 1 sits in the prefetch registers, and the wave steps ONCE with the real predecessors like every other wave.
@@ -1060,6 +1082,20 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             for (int j = 0; j < K; j++) q[j * 8] = L3[j];
             q[K * 8] = (uint32_t)m3;
         }
+#if SGS8_EARLY_BARRIER
+        // The row's ONE barrier sits here, behind the exchange writes, and the next row's neighbour states are fetched right behind it: their LDS latency (all fifteen
+        // waves read at once) passes under the winner pass instead of at the head of the next row, where nothing else was ready to issue.  The winner pass itself
+        // needs no barrier: a group's S row in LDS is written and read by one wave.  (Parity double buffering as before: row y + 1's writes land in the other half.)
+        __syncthreads();
+        if (s_fail[y & 1]) { stop = true; return; }               // a hand-off timed out: every wave leaves at the same row
+        {   const uint32_t* p = xslot(y & 1, 0, g > 0 ? g - 1 : 0);
+#pragma unroll
+            for (int j = 0; j < NG; j++) nl[j] = p[j * 8];
+            const uint32_t* q = xslot(y & 1, 1, g < ng - 1 ? g + 1 : g);
+#pragma unroll
+            for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
+        }
+#endif
         // ---- the winner pass of the group's pixel: S = min(32767, S04 + L1 + L2 + L3)
         {
             uint32_t sp2[K];
@@ -1101,8 +1137,10 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
                 disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
             }
         }
+#if !SGS8_EARLY_BARRIER
         __syncthreads();
         if (s_fail[y & 1]) stop = true;                           // a hand-off timed out: every wave leaves at the same row
+#endif
     };
     load_row(Va, 0);
     for (int y = 0; y < h && !stop; y += 2) {
@@ -1526,7 +1564,7 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     // eight lanes per pixel (sgbm_sweep8) unless its exchange buffers do not fit a CU's LDS (D = 128) or SSM_SGBM_SWEEP_LANES=16 asks for the 16-lane kernel
     static const int lanes_env = [] { const char* v = getenv("SSM_SGBM_SWEEP_LANES"); return v ? atoi(v) : 8; }();
     const int threads8 = (TX * 8 + 63) / 64 * 64, ng8 = threads8 / 8;
-    const size_t lds8 = (size_t)4 * ng8 * (K + 1) * 8 * 4 + (size_t)ng8 * D * 2;
+    const size_t lds8 = (size_t)4 * ng8 * ((K + 1) * 8 + SGS8_XPAD) * 4 + (size_t)ng8 * D * 2;
     const bool use8 = lanes_env != 16 && lds8 <= 150 * 1024;
     const int threads = use8 ? threads8 : (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
     const size_t lds = use8 ? lds8 : (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;

@@ -597,13 +597,30 @@ static int ensure_side_streams(ssm_ctx* c)
 {
     if (c->side_ready) return SSM_OK;
     // each handle is created only if it is still missing: a call that failed half-way leaves side_ready false and the next call resumes
-    auto mk_stream = [&](hipStream_t* st) -> hipError_t { return *st ? hipSuccess : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    // SSM_MAP_CUS=N (ablation): the map stage's stream is confined to N compute units (hipExtStreamCreateWithCUMask; SSM_MAP_CUS_SPREAD=1: every
+    // (256 / N)-th unit instead of the first N), and with SSM_CHAIN_CUS=1 the ORB chains' side streams get the complement -- a static split of the machine in place of
+    // the hardware's block-by-block arbitration between kernels that each fill a CU on their own
+    auto cu_mask = [&](bool map_side, uint32_t (&m)[8]) -> bool {
+        const char* e = getenv("SSM_MAP_CUS"); const int n = e ? atoi(e) : 0;
+        if (n <= 0 || n >= 256) return false;
+        const char* sp = getenv("SSM_MAP_CUS_SPREAD"); const bool spread = sp && atoi(sp) != 0;
+        for (int k = 0; k < 8; k++) m[k] = 0;
+        for (int i = 0; i < n; i++) { const int bit = spread ? (int)((long)i * 256 / n) : i; m[bit >> 5] |= 1u << (bit & 31); }
+        if (!map_side) { const char* ce = getenv("SSM_CHAIN_CUS"); if (!(ce && atoi(ce) != 0)) return false; for (int k = 0; k < 8; k++) m[k] = ~m[k]; }
+        return true;
+    };
+    auto mk_stream = [&](hipStream_t* st, int role = 0) -> hipError_t {      // role 1: the map stream, 2: a chain's side stream
+        if (*st) return hipSuccess;
+        uint32_t m[8];
+        if (role && cu_mask(role == 1, m)) return hipExtStreamCreateWithCUMask(st, 8, m);
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
     auto mk_event = [&](hipEvent_t* ev) -> hipError_t { return *ev ? hipSuccess : hipEventCreateWithFlags(ev, hipEventDisableTiming); };
-    HIPCHK(c, mk_stream(&c->stream2));
-    HIPCHK(c, mk_stream(&c->stream3)); HIPCHK(c, mk_event(&c->ev_join3));
+    HIPCHK(c, mk_stream(&c->stream2, 2));
+    HIPCHK(c, mk_stream(&c->stream3, 1)); HIPCHK(c, mk_event(&c->ev_join3));
     HIPCHK(c, mk_event(&c->ev_fork)); HIPCHK(c, mk_event(&c->ev_join));
     for (int i = 0; i < 3; i++) HIPCHK(c, mk_event(&c->ev_orb[i]));
-    HIPCHK(c, mk_stream(&c->stream4)); HIPCHK(c, mk_event(&c->ev_join4));
+    HIPCHK(c, mk_stream(&c->stream4, 2)); HIPCHK(c, mk_event(&c->ev_join4));
     c->side_ready = true;
     return SSM_OK;
 }
