@@ -79,8 +79,16 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
 // Two barriers per row.  Dynamic LDS: ring u16 [SW][TX][D] | pixrow u8 [TX + 2 SW2][D] | lrow uint4 [TX + 2 SW2] | rrow uint4 [TX + 2 SW2 + D - 1].
 // CD / CSW2 / CTX: compile-time D, SW2, TX of the instantiation for stereo.cpp's configuration (80 disparities, SAD 11); 0 = run-time values.
 #define SGC_THREADS 512
+#ifndef SGC_PIXEL_OCTETS
+#define SGC_PIXEL_OCTETS 1
+#endif
 typedef short sg_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ sg_s2 sg_as_s2(uint32_t v) { return __builtin_bit_cast(sg_s2, v); }
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) + __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) - __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_mul16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) * __builtin_bit_cast(us2v, b))); }
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b))); }
 template <bool EDGE, int CD, int CSW2, int CTX, int MAXCW>
 __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes_all, int w, int h, int minD, int Drt, int minX1, int w1, int SW2rt, int P2, int TXrt, uint16_t* __restrict__ C_all)
 {
@@ -124,6 +132,32 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes
         const uint8_t* pxd = pixrow + d;
         auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
         if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = wide(src[(size_t)(r + 2) * w]); }      // row r + 1 for the next trip; row r + 2 on its way
+#if SGC_PIXEL_OCTETS
+        {
+            // pixel costs, one thread per (strip column i, eight consecutive disparities): the left pixel's word is read ONCE for the eight, the right pixels are
+            // eight consecutive words, and the eight cost bytes leave as one 8-byte write (round 5: the (d, column chunk) layout read a left and a right word
+            // and wrote one byte per cost -- 107 KB of LDS traffic per row and block against 60 KB now; the kernel's LDS pipe was busy 0.64 of the time)
+            const sg_s2 zero = {0, 0};
+            const int NO = D >> 3;
+            for (int it = tid; it < AW * NO; it += SGC_THREADS) {
+                const int o = it / AW, i = it - o * AW;
+                const uint4 L = lrow[i];
+                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z);
+                const uint4* rp = rrow + (i + (D - 1) - 8 * o);      // right pixel of disparity 8 o + dd: image column of i minus the disparity
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int dd = 0; dd < 8; dd++) {
+                    const uint4 R = rp[-dd];
+                    const sg_s2 v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
+                    const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
+                    const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
+                    const sg_s2 m = __builtin_elementwise_min(c0, c1);
+                    pk[dd >> 2] |= (uint32_t)(uint8_t)((int)m.x + ((int)m.y >> 2)) << (8 * (dd & 3));
+                }
+                *reinterpret_cast<uint2*>(pixrow + (size_t)i * D + 8 * o) = make_uint2(pk[0], pk[1]);
+            }
+        }
+#else
         if (active) {
             const sg_s2 zero = {0, 0};
             for (int i = chunk; i < AW; i += nchunk) {
@@ -135,6 +169,7 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes
                 pixrow[i * D + d] = (uint8_t)((int)m.x + ((int)m.y >> 2));
             }
         }
+#endif
         __syncthreads();
         if (ncol > 0) {
             int sum = 0;
@@ -170,6 +205,127 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes
             for (int k = 0; k < MAXCW; k++) if (k < ncol) Cp[(size_t)y * crow + k * D] = (uint16_t)Cacc[k];
     }
 }
+// The same strip with the ring of the last SW horizontal sums in REGISTERS (round 5; stereo.cpp's configuration only: compile-time D, SW2, TX, every C below 2^16).
+// The LDS ring (SW x TX x D x 2 bytes = 56 KB of the block's 68) held a block to one per CU, i.e. eight waves = two per SIMD for a kernel that alternates between an
+// LDS-heavy and a VALU-heavy phase with a barrier per row; without it a block needs 13 KB and two (or three) blocks share a CU, one's barrier wait under the other's
+// work.  A thread's MAXCW columns travel as MAXCW / 2 packed u16 pairs (sum, ring entry, running C: one v_pk_add_u16 / v_pk_sub_u16 per pair), the ring slot
+// of a row is a compile-time index because the row loop is unrolled SW rows at a time.  Same arithmetic, same bits as sgbm_cost_strip.
+template <bool EDGE, int CD, int CSW2, int CTX, int MAXCW>
+__device__ __forceinline__ void sgbm_cost_strip_reg(const uint3* __restrict__ planes_all, int w, int h, int minD, int minX1, int w1, int P2, uint16_t* __restrict__ C_all)
+{
+    static_assert(CD > 0 && (MAXCW & 1) == 0, "compile-time geometry, an even number of columns per thread");
+    extern __shared__ __align__(16) uint8_t sg_smem[];
+    constexpr int D = CD, SW2 = CSW2, TX = CTX, SW = 2 * SW2 + 1, AW = TX + 2 * SW2, RW = AW + D - 1, NPAIR = MAXCW / 2, SH2 = SW2;
+    const int f = blockIdx.y, xs = blockIdx.x * TX, tid = threadIdx.x;
+    constexpr size_t pixb = (((size_t)(AW + MAXCW) * D) + 15) & ~(size_t)15;      // MAXCW columns of slack: a thread whose run ends before MAXCW reads (and drops) what lies behind the apron
+    uint8_t* pixrow2 = sg_smem;
+    uint4* lrow2 = reinterpret_cast<uint4*>(pixrow2 + 2 * pixb);
+    const size_t np = (size_t)w * h;
+    constexpr int nchunk = SGC_THREADS / D, cw = (TX + nchunk - 1) / nchunk;
+    static_assert(cw <= MAXCW, "columns per thread");
+    const int d = tid % D, chunk = tid / D;
+    const bool active = chunk < nchunk;
+    const int cx0 = chunk * cw, cx1 = min(min(cx0 + cw, TX), w1 - xs);
+    const int ncol = active ? max(cx1 - cx0, 0) : 0;
+    const uint3* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
+    auto wide = [](const uint3 t) { return make_uint4(t.x, t.y, t.z, 0u); };
+    if (tid < AW + RW) {
+        const bool isl = tid < AW;
+        const int xi = min(max(isl ? xs - SW2 + minX1 + tid : xs - SW2 + minX1 - minD - (D - 1) + (tid - AW), 0), w - 1);
+        src = planes_all + ((size_t)f * 2 + (isl ? 0 : 1)) * np + xi;
+    }
+    uint32_t ring[SW][NPAIR], Cacc[NPAIR], hs0[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; q++) { Cacc[q] = (uint32_t)P2 * 0x00010001u; hs0[q] = 0; }
+    const int ylast = h - 1 - SH2;
+    uint16_t* Cp = C_all + ((size_t)f * w1 * h + xs + cx0) * D + d;
+    const size_t crow = (size_t)w1 * D;
+    const int lo = SW2 - xs, hi = w1 - 1 - xs + SW2;
+    const uint32_t col0_mask = (EDGE && xs + cx0 == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;      // cost-volume column 0 keeps C(0): the low half of this thread's first pair
+    auto store_row = [&](int y) {
+        uint16_t* Cr = Cp + (size_t)y * crow;
+#pragma unroll
+        for (int k = 0; k < MAXCW; k++) if (k < ncol) Cr[k * D] = (uint16_t)(Cacc[k >> 1] >> (16 * (k & 1)));
+    };
+    auto row = [&](int r, auto phase, auto slot_c) {
+        constexpr int PHASE = decltype(phase)::value, SLOT = decltype(slot_c)::value;
+        uint8_t* pixrow = pixrow2 + (size_t)(r & 1) * pixb;
+        const uint4* lrow = lrow2 + (size_t)(r & 1) * (AW + RW); const uint4* rrow = lrow + AW;
+        const uint8_t* pxd = pixrow + d;
+        auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };
+        if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = wide(src[(size_t)(r + 2) * w]); }
+        {
+            const sg_s2 zero = {0, 0};
+            constexpr int NO = D >> 3;
+            for (int it = tid; it < AW * NO; it += SGC_THREADS) {
+                const int o = it / AW, i = it - o * AW;
+                const uint4 L = lrow[i];
+                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z);
+                const uint4* rp = rrow + (i + (D - 1) - 8 * o);
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int dd = 0; dd < 8; dd++) {
+                    const uint4 R = rp[-dd];
+                    const sg_s2 v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
+                    const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
+                    const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
+                    const sg_s2 m = __builtin_elementwise_min(c0, c1);
+                    pk[dd >> 2] |= (uint32_t)(uint8_t)((int)m.x + ((int)m.y >> 2)) << (8 * (dd & 3));
+                }
+                *reinterpret_cast<uint2*>(pixrow + (size_t)i * D + 8 * o) = make_uint2(pk[0], pk[1]);
+            }
+        }
+        __syncthreads();
+        if (ncol > 0) {
+            int sum = 0;
+#pragma unroll
+            for (int j = -SW2; j <= SW2; j++) sum += px(cx0 + j);
+            uint32_t sp[NPAIR];
+#pragma unroll
+            for (int k = 0; k < MAXCW; k++) {
+                if (k > 0) sum += px(cx0 + k + SW2) - px(cx0 + k - SW2 - 1);
+                if (k & 1) sp[k >> 1] |= (uint32_t)sum << 16; else sp[k >> 1] = (uint32_t)sum & 0xFFFFu;
+            }
+#pragma unroll
+            for (int q = 0; q < NPAIR; q++) {
+                if (PHASE == 0) { hs0[q] = sp[q]; Cacc[q] = pk_add16(Cacc[q], pk_mul16(sp[q], (uint32_t)(SH2 + 1) * 0x00010001u)); ring[SLOT][q] = sp[q]; }
+                else if (PHASE == 1) { Cacc[q] = pk_add16(Cacc[q], sp[q]); ring[SLOT][q] = sp[q]; }
+                else {
+                    const uint32_t old = PHASE == 2 ? hs0[q] : ring[SLOT][q];      // hs(r - SW, x, d): the slot this row overwrites (PHASE 2: rows SH2 + 1 .. SW - 1, above the image: row 0's)
+                    ring[SLOT][q] = sp[q];
+                    uint32_t delta = pk_sub16(sp[q], old);
+                    if (q == 0) delta &= col0_mask;
+                    Cacc[q] = pk_add16(Cacc[q], delta);
+                }
+            }
+            if (PHASE >= 2 || r == SH2) store_row(r - SH2);
+        }
+    };
+    if (src) { lrow2[tid] = wide(src[0]); if (h > 1) pre = wide(src[(size_t)w]); }
+    __syncthreads();
+    // rows 0 .. SW - 1 (ring slots 0 .. SW - 1): row 0, the rows whose window still reaches above the image, the first rows that drop row 0's replicas
+    auto first_rows = [&](auto self, auto rc) -> void {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < SW) {
+            if (R < h) {
+                row(R, std::integral_constant<int, (R == 0 ? 0 : R <= SH2 ? 1 : 2)>(), std::integral_constant<int, R>());
+                self(self, std::integral_constant<int, R + 1>());
+            }
+        }
+    };
+    first_rows(first_rows, std::integral_constant<int, 0>());
+    auto block_rows = [&](auto self, int base, auto sc) -> void {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S < SW) {
+            if (base + S < h) {
+                row(base + S, std::integral_constant<int, 3>(), std::integral_constant<int, S>());
+                self(self, base, std::integral_constant<int, S + 1>());
+            }
+        }
+    };
+    for (int base = SW; base < h; base += SW) block_rows(block_rows, base, std::integral_constant<int, 0>());
+    if (ncol > 0) for (int y = ylast + 1; y < h; y++) store_row(y);          // rows below h - 1 - SH2 repeat the last full window
+}
 // the first strip and the last `tail` strips replicate the cost-volume border columns (and strip 0 holds the frozen column 0): they run the EDGE
 // instantiation; the strips between them read their apron without clamps.  One launch for all strips (block-uniform branch).
 template <int CD, int CSW2, int CTX, int MAXCW>
@@ -178,6 +334,13 @@ sgbm_cost_kernel(const uint3* __restrict__ planes_all, int w, int h, int minD, i
 {
     if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip<true, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
     else sgbm_cost_strip<false, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, D, minX1, w1, SW2, P2, TX, C_all);
+}
+template <int CD, int CSW2, int CTX, int MAXCW>
+__global__ void __launch_bounds__(SGC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+sgbm_cost_reg_kernel(const uint3* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, int SW2, int P2, int TX, int tail, uint16_t* __restrict__ C_all)
+{
+    if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip_reg<true, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, minX1, w1, P2, C_all);
+    else sgbm_cost_strip_reg<false, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, minX1, w1, P2, C_all);
 }
 
 // ------------------------------------------------------------------ one aggregation step on a 16-lane row (K disparities per lane)
@@ -213,10 +376,6 @@ __device__ __forceinline__ void sg_step(int (&L)[K], int& minPrev, const int (&C
 // v_perm each, and the costs arrive from memory already in this form (K u16 = one 8-byte load + one 2-byte load for K = 5).  A scan path is ONE wave
 // alone on its SIMD -- it issues an instruction every ~6 cycles whatever the instruction does (profiles/r02_valu_rate.md, column "@1 wave/SIMD") -- so
 // a path's time is its instruction count: ~45 per step here against ~95 for the 32-bit form.  Odd K: the pad slot of the last pair is kept at 0xFFFF.
-typedef unsigned short us2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) + __builtin_bit_cast(us2v, b))); }
-__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) - __builtin_bit_cast(us2v, b))); }
-__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2v, a), __builtin_bit_cast(us2v, b))); }
 template <int K>
 __device__ __forceinline__ void sg_step_pk(uint32_t (&L)[(K + 1) / 2], int& minPrev, const uint32_t (&Cp)[(K + 1) / 2], uint32_t P1P1, int P2)
 {
@@ -1719,7 +1878,14 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
             (void)sg_allow_lds(reinterpret_cast<const void*>(kern), lds);       // the ring of a wide window needs more than the 64 KB default of dynamic LDS
             kern<<<dim3(nstrips, nb), SGC_THREADS, lds, s>>>(planes, w, h, minD, D, minX1, w1, SW2, P2, TX, tail, C);
         };
-        if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);       // src/stereo.cpp:16-27
+        static const int cost_variant = [] { const char* v = getenv("SSM_SGBM_COST_VARIANT"); return v ? atoi(v) : 1; }();      // 0: the LDS ring for every configuration (ablation)
+        const long cmax_c = (long)P2 + (long)SW * SW * (2 * ftzero + 63);
+        if (D == 80 && SW2 == 5 && TX == 32 && cost_variant != 0 && cmax_c < 65536) {      // src/stereo.cpp:16-27, ring in registers: 13 KB of LDS per block
+            constexpr int AWc = 32 + 10, RWc = AWc + 79;
+            lds = 2 * ((((size_t)(AWc + 6) * 80) + 15) & ~(size_t)15) + 2 * (size_t)(AWc + RWc) * 16;
+            launch(sgbm_cost_reg_kernel<80, 5, 32, 6>);
+        }
+        else if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);
         else launch(sgbm_cost_kernel<0, 0, 0, 16>);
     }
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
