@@ -617,7 +617,14 @@ def rgbd_main(args):
         for e in (extra or []): e.close()
         ctx.map_clear()
     frames_all = F
+    per_rank = None
     if world > 1:
+        # every rank's own rate and voxel count (rank order), so that a SCALE record explains itself: a slow rank, an uneven split or a long merge shows in the line
+        mine = torch.tensor([dt, float(F), float(stage_ovl.get("allgather", [0.0, 0])[0])], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"frames_per_s": [round(float(a[1]) * args.steps / float(a[0]), 1) for a in allr],
+                    "allgather_ms_per_step": [round(float(a[2]) / max(args.steps, 1), 3) for a in allr]}
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -721,6 +728,10 @@ def rgbd_main(args):
         }
         if solve_info is not None:
             line["solve_poses"] = solve_info
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+        if "allgather" in stage_ovl:
+            line["allgather_ms_per_step"] = round(stage_ovl["allgather"][0] / max(args.steps, 1), 3)      # ssm_voxel_allgather on rank 0: count all-gather + table all-gather + merge kernels (hipEvents on the context stream)
         if merge_info is not None:
             line["merge_verified"] = merge_info["verified"]
             line["merge"] = merge_info

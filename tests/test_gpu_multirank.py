@@ -53,6 +53,7 @@ def test_bench_two_ranks_merge_verified():
     assert line["merge_verified"] is True
     m = line["merge"]
     assert m["equals_single_gpu_map"] is True and len(m["voxels_per_rank"]) == 2 and all(v > 0 for v in m["voxels_per_rank"])
+    assert len(line["per_rank"]["frames_per_s"]) == 2 and all(v > 0 for v in line["per_rank"]["frames_per_s"]) and line["allgather_ms_per_step"] > 0
 
 
 @pytest.mark.gpu

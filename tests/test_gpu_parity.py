@@ -338,6 +338,7 @@ def test_bench_line_and_allgather_path():
     assert line["value"] > 1000 and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 1
     assert line["per_frame"]["voxels_in_map"] > 500
+    assert line["merge_verified"] is True and line["allgather_ms_per_step"] > 0       # SSM_FORCE_MERGE: ssm_voxel_allgather with a 1-rank communicator inside the step
 
 
 def test_bench_default_line_carries_the_other_configs():
