@@ -1734,6 +1734,7 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     // advances as soon as all NS strips of the lowest unfinished frame are resident -- which needs NS block slots for this launch even when `concurrent` sweeps
     // (the SGBM streams of the batched path) share the device.  Checked against the occupancy the runtime reports for this kernel, block size and LDS; when it
     // does not hold the caller takes form 1 (no cross-block waits).  SSM_SGBM_TEST_TIMEOUT=2 (tests) pretends it does not.
+    int per_cu_w = 0;                                        // resident blocks per CU of this (wide-strip) geometry
     {
         static std::mutex mu; static std::map<std::tuple<int, const void*, int, size_t>, int> occ;
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1749,6 +1750,7 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
         }
         static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
         if (test_hook == 2 || (long)per_cu * sg_num_cus() < (long)NS * (concurrent > 0 ? concurrent : 1)) return hipErrorCooperativeLaunchTooLarge;
+        per_cu_w = per_cu;
     }
     static const int rows_lanes = [] { const char* v = getenv("SSM_SGBM_ROWS_LANES"); return v ? atoi(v) : 8; }();      // 16: sgbm_rows (D / 16 disparities per lane)
     if (rows_lanes != 16) {
@@ -1766,8 +1768,42 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     const size_t mbytes = (size_t)nb * (NS - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
     e = hipMemsetAsync(flags, 0, 256 + mbytes, s);           // ticket counter, time-out word, every granule's tag
     if (e != hipSuccess) return e;
-    sweep<<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
+    // SSM_SGBM_TAIL_SPLIT=1 (ablation; round 5, measured and NOT the default).  The idea: nb NS blocks on `slots` block slots run in rounds, 64 pairs x 10 strips on
+    // 256 slots are 2.5 rounds of work in 3 rounds of time, so sweep the frames of the under-filled last round with a SECOND launch of half-width strips (twice the
+    // blocks, half the waves each).  The measurement says the premise is wrong: 510 wide blocks (51 pairs, "two full rounds") take 3.90 ms where 640 blocks
+    // take 3.96 ms, and the 13 remaining pairs as 260 narrow blocks take 0.97 ms -- 76 us per pair in every launch against 62 us per pair for the plain 64-pair
+    // launch.  A launch's time is proportional to its pairs, not to its rounds: the strips of a frame advance in lock step and frames start as tickets are drawn, so
+    // blocks do not finish round by round and the "empty half of the last round" is filled by the frames still in flight; a launch with fewer pairs only has fewer of
+    // them overlapping.  (Stage 0.1862 vs 0.1723 ms per pair with the split on.)
+    int n1 = nb, NS2 = 0, TX2 = 0, threads2 = 0; size_t lds2 = 0;
+    {
+        static const int split_env = [] { const char* v = getenv("SSM_SGBM_TAIL_SPLIT"); return v ? atoi(v) : 0; }();
+        const long slots = (long)per_cu_w * sg_num_cus(), total = (long)nb * NS;
+        if (split_env != 0 && use8 && strip_env == 0 && slots > 0 && total > slots && cap >= 64) {
+            const long rest = total % slots;
+            if (rest > 0 && rest * 10 < slots * 8) {
+                const int cap2 = cap / 2;
+                NS2 = (w1 + cap2 - 1) / cap2; TX2 = ((w1 + NS2 - 1) / NS2 + SGS_CPG - 1) / SGS_CPG * SGS_CPG; NS2 = (w1 + TX2 - 1) / TX2;
+                threads2 = (TX2 * 8 + 63) / 64 * 64;
+                const int ngn = threads2 / 8;
+                lds2 = (size_t)4 * ngn * ((K + 1) * 8 + SGS8_XPAD) * 4 + (size_t)ngn * D * 2;
+                int pc2 = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(sweep), threads2, lds2) != hipSuccess) pc2 = 0;
+                if ((long)pc2 * sg_num_cus() >= (long)NS2 * (concurrent > 0 ? concurrent : 1)) n1 = (int)((total - rest) / NS);      // whole frames of the complete rounds
+            }
+        }
+    }
+    sweep<<<n1 * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
                                        reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
+    if (n1 < nb) {
+        const int nb2 = nb - n1;
+        const size_t mbytes2 = (size_t)nb2 * (NS2 - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
+        e = hipMemsetAsync(flags, 0, 256 + mbytes2, s);     // (behind the first launch on the stream: its tickets and mailboxes are done with)
+        if (e != hipSuccess) return e;
+        const size_t vofs = (size_t)n1 * w1 * h * D, pofs = (size_t)n1 * np;
+        sweep<<<nb2 * NS2, threads2, lds2, s>>>(C + vofs, S04 + vofs, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS2, TX2, disp_tmp + pofs, disp2key + pofs, flags,
+                                               reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
+    }
     {   // SSM_SGBM_TEST_TIMEOUT=1 (tests): report a hand-off time-out whatever happened, so that the caller's repeat in form 1 runs
         static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
         if (test_hook == 1 && fail_out) { e = hipMemsetAsync(fail_out, 1, 4, s); if (e != hipSuccess) return e; }
