@@ -4,7 +4,8 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 if [ "$1" = "stats" ]; then
-  timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err
+  ( time timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err ) 2> $O/line_default.time      # the command the driver times: configs[1] + other_configs
+  timeout 300 python3 bench.py --leaf 0.02 --no-other-configs --steps 5 --warmup 2 > $O/line_leaf002.json 2> $O/line_leaf002.err      # SURVEY s.8(d)'s second leaf (the map grows from 2^20 slots)
   timeout 300 python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 > $O/line_segnet.json 2> $O/line_segnet.err
   timeout 300 python3 bench.py --stereo --steps 3 --warmup 1 > $O/line_stereo.json 2> $O/line_stereo.err
   timeout 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --solve-poses --pose-frames 400 --pnp-device 0 > $O/line_poses_host.json 2> $O/line_poses_host.err
@@ -14,7 +15,7 @@ if [ "$1" = "stats" ]; then
   timeout 300 python3 scripts/per_call_latency.py $O/per_call.md > /dev/null 2>&1
   timeout 600 python3 scripts/mapper_update_cost.py 150 > $O/mapper_update_cost.md 2>&1
   rm -rf $O/p_stats $O/p_seg $O/p_st
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_stats.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_stats -o runc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --serial-only --no-other-configs > $O/p_stats.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_seg -o runc -- python3 bench.py --segnet --frames 256 --batch 128 --steps 3 --warmup 1 --no-cpu --serial-only > $O/p_seg.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_st -o runc -- python3 bench.py --stereo --steps 2 --warmup 1 --no-cpu --serial-only > $O/p_st.log 2>&1
   tail -c 600 $O/line_default.json; echo; tail -c 300 $O/line_segnet.json; echo; tail -c 300 $O/line_stereo.json
@@ -38,8 +39,8 @@ elif [ "$1" = "pmc_stereo" ]; then
 else
   export SSM_BENCH_H2D=0
   rm -rf $O/p_sq $O/p_fetch $O/p_write
-  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_sq.log 2>&1
-  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_fetch.log 2>&1
-  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $O/p_write.log 2>&1
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_sq.log 2>&1
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_write.log 2>&1
   tail -3 $O/p_sq.log | cut -c1-300
 fi

@@ -16,6 +16,7 @@ if [ -d $O/p_fetch_seg ]; then
   python3 scripts/pmc_traffic.py $O/p_fetch_seg $O/p_write_seg profiles/${R}_segnet_traffic.json 64 128 > /dev/null
 fi
 tail -1 $O/line_default.json > profiles/${R}_bench_line.json
+[ -s $O/line_leaf002.json ] && tail -1 $O/line_leaf002.json > profiles/${R}_bench_line_leaf002.json
 tail -1 $O/line_segnet.json > profiles/${R}_bench_line_segnet.json
 tail -1 $O/line_stereo.json > profiles/${R}_bench_line_stereo.json
 [ -s $O/line_poses_host.json ] && tail -1 $O/line_poses_host.json > profiles/${R}_bench_line_poses_host.json

@@ -205,13 +205,35 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes
             for (int k = 0; k < MAXCW; k++) if (k < ncol) Cp[(size_t)y * crow + k * D] = (uint16_t)Cacc[k];
     }
 }
+// sgbm_prefilter's record of pixel (x, y) computed from the raw image (sgbm_cost_strip_reg: the records are made where they are staged, the 12-byte-per-pixel
+// planes are neither written nor read).  p[j][i] = img(row y - 1 + j clamped into the image, column x - 2 + i); columns outside the image may hold anything
+// (every use is guarded by the same border tests as sgbm_prefilter's).
+__device__ __forceinline__ uint4 sg_prefilter_record(const uint2 (&wr)[3], int x, int w, int ftzero)      // wr[j]: .x = the row's bytes at columns x - 2 .. x + 1, .y = column x + 2
+{
+    auto px = [&](int j, int i) -> int { return i < 4 ? (int)((wr[j].x >> (8 * i)) & 0xFFu) : (int)(wr[j].y & 0xFFu); };
+    auto grad = [&](int i) -> int {             // i = 1, 2, 3: columns x - 1, x, x + 1
+        const int xx = x - 2 + i;
+        if (xx < 1 || xx > w - 2) return ftzero;
+        const int g = (px(1, i + 1) - px(1, i - 1)) * 2 + px(0, i + 1) - px(0, i - 1) + px(2, i + 1) - px(2, i - 1);
+        return min(max(g, -ftzero), ftzero) + ftzero;
+    };
+    auto raw = [&](int i) -> int { const int xx = x - 2 + i; return (xx < 1 || xx > w - 2) ? ftzero : px(1, i); };
+    uint32_t pv = 0, pmin = 0, pmax = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int v = c ? raw(2) : grad(2);
+        const int vl = x > 0 ? (v + (c ? raw(1) : grad(1))) / 2 : v, vr = x < w - 1 ? (v + (c ? raw(3) : grad(3))) / 2 : v;
+        pv |= (uint32_t)v << (16 * c); pmin |= (uint32_t)min(min(vl, vr), v) << (16 * c); pmax |= (uint32_t)max(max(vl, vr), v) << (16 * c);
+    }
+    return make_uint4(pv, pmin, pmax, 0u);
+}
 // The same strip with the ring of the last SW horizontal sums in REGISTERS (round 5; stereo.cpp's configuration only: compile-time D, SW2, TX, every C below 2^16).
 // The LDS ring (SW x TX x D x 2 bytes = 56 KB of the block's 68) held a block to one per CU, i.e. eight waves = two per SIMD for a kernel that alternates between an
 // LDS-heavy and a VALU-heavy phase with a barrier per row; without it a block needs 13 KB and two (or three) blocks share a CU, one's barrier wait under the other's
 // work.  A thread's MAXCW columns travel as MAXCW / 2 packed u16 pairs (sum, ring entry, running C: one v_pk_add_u16 / v_pk_sub_u16 per pair), the ring slot
 // of a row is a compile-time index because the row loop is unrolled SW rows at a time.  Same arithmetic, same bits as sgbm_cost_strip.
 template <bool EDGE, int CD, int CSW2, int CTX, int MAXCW>
-__device__ __forceinline__ void sgbm_cost_strip_reg(const uint3* __restrict__ planes_all, int w, int h, int minD, int minX1, int w1, int P2, uint16_t* __restrict__ C_all)
+__device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int ftzero, int w, int h, int minD, int minX1, int w1, int P2, uint16_t* __restrict__ C_all)
 {
     static_assert(CD > 0 && (MAXCW & 1) == 0, "compile-time geometry, an even number of columns per thread");
     extern __shared__ __align__(16) uint8_t sg_smem[];
@@ -227,13 +249,32 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint3* __restrict__ pl
     const bool active = chunk < nchunk;
     const int cx0 = chunk * cw, cx1 = min(min(cx0 + cw, TX), w1 - xs);
     const int ncol = active ? max(cx1 - cx0, 0) : 0;
-    const uint3* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
-    auto wide = [](const uint3 t) { return make_uint4(t.x, t.y, t.z, 0u); };
+    // staging: thread k < AW + RW owns one pixel column of the left / right image and makes its pre-filter record (value | min | max of the clipped x-Sobel and of the raw
+    // intensity, sgbm_prefilter's arithmetic) for one row per trip from a rolling 3 x 5 window of raw pixels: one unaligned 8-byte load per row
+    const uint8_t* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
+    int xi = 0, wofs = 0; uint2 win[3]; uint2 nxt = make_uint2(0u, 0u);
+    auto row_bytes = [&](int y) -> uint2 {             // the 8 bytes at column wstart of image row y (clamped), as two dwords
+        const uint8_t* q = src + (size_t)min(max(y, 0), h - 1) * w;
+        uint2 v; __builtin_memcpy(&v, q, 8); return v;
+    };
+    auto unpack = [&](const uint2 v, uint2& o) {      // window position i = byte wofs + i of the 8 loaded (wofs -2 .. 5: positions outside the 8 bytes are columns outside the image)
+        const unsigned long long b = ((unsigned long long)v.y << 32) | v.x;
+        const unsigned long long t = wofs >= 0 ? b >> (8 * wofs) : b << (8 * -wofs);
+        o.x = (uint32_t)t; o.y = (uint32_t)(t >> 32);
+    };
     if (tid < AW + RW) {
         const bool isl = tid < AW;
-        const int xi = min(max(isl ? xs - SW2 + minX1 + tid : xs - SW2 + minX1 - minD - (D - 1) + (tid - AW), 0), w - 1);
-        src = planes_all + ((size_t)f * 2 + (isl ? 0 : 1)) * np + xi;
+        xi = min(max(isl ? xs - SW2 + minX1 + tid : xs - SW2 + minX1 - minD - (D - 1) + (tid - AW), 0), w - 1);
+        const int wstart = min(max(xi - 2, 0), w - 8);            // an 8-byte window inside the row that holds columns xi - 2 .. xi + 2 where they exist
+        wofs = xi - 2 - wstart;                                   // -2 .. 5: below 0 / above 3 at the image's first / last columns, where the window reaches outside
+        src = (isl ? left : right) + (size_t)f * np + wstart;
     }
+    // (columns xi - 2 + i that fall outside the image read a neighbouring in-row byte instead: sg_prefilter_record ignores them)
+    auto advance = [&](int ynew) {                      // the window moves one row down; row ynew (clamped) arrives from `nxt`, the load of the row behind it is issued
+        win[0] = win[1]; win[1] = win[2];
+        unpack(nxt, win[2]);
+        nxt = row_bytes(ynew + 1);
+    };
     uint32_t ring[SW][NPAIR], Cacc[NPAIR], hs0[NPAIR];
 #pragma unroll
     for (int q = 0; q < NPAIR; q++) { Cacc[q] = (uint32_t)P2 * 0x00010001u; hs0[q] = 0; }
@@ -253,7 +294,10 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint3* __restrict__ pl
         const uint4* lrow = lrow2 + (size_t)(r & 1) * (AW + RW); const uint4* rrow = lrow + AW;
         const uint8_t* pxd = pixrow + d;
         auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };
-        if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = wide(src[(size_t)(r + 2) * w]); }
+        if (src && r + 1 < h) {
+            lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre;
+            if (r + 2 < h) { advance(r + 3); pre = sg_prefilter_record(win, xi, w, ftzero); }      // the window now holds rows r + 1 .. r + 3: the record of row r + 2
+        }
         {
             const sg_s2 zero = {0, 0};
             constexpr int NO = D >> 3;
@@ -301,7 +345,14 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint3* __restrict__ pl
             if (PHASE >= 2 || r == SH2) store_row(r - SH2);
         }
     };
-    if (src) { lrow2[tid] = wide(src[0]); if (h > 1) pre = wide(src[(size_t)w]); }
+    if (src) {
+        // window = rows -1 (= 0), 0, 1 -> the record of row 0; then rows 0, 1, 2 -> row 1's, kept in `pre`
+        uint2 t0 = row_bytes(0), t1 = row_bytes(1);
+        unpack(t0, win[0]); unpack(t0, win[1]); unpack(t1, win[2]);
+        nxt = row_bytes(2);
+        lrow2[tid] = sg_prefilter_record(win, xi, w, ftzero);
+        if (h > 1) { advance(2); pre = sg_prefilter_record(win, xi, w, ftzero); }
+    }
     __syncthreads();
     // rows 0 .. SW - 1 (ring slots 0 .. SW - 1): row 0, the rows whose window still reaches above the image, the first rows that drop row 0's replicas
     auto first_rows = [&](auto self, auto rc) -> void {
@@ -337,10 +388,10 @@ sgbm_cost_kernel(const uint3* __restrict__ planes_all, int w, int h, int minD, i
 }
 template <int CD, int CSW2, int CTX, int MAXCW>
 __global__ void __launch_bounds__(SGC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-sgbm_cost_reg_kernel(const uint3* __restrict__ planes_all, int w, int h, int minD, int D, int minX1, int w1, int SW2, int P2, int TX, int tail, uint16_t* __restrict__ C_all)
+sgbm_cost_reg_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right, int ftzero, int w, int h, int minD, int minX1, int w1, int P2, int tail, uint16_t* __restrict__ C_all)
 {
-    if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip_reg<true, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, minX1, w1, P2, C_all);
-    else sgbm_cost_strip_reg<false, CD, CSW2, CTX, MAXCW>(planes_all, w, h, minD, minX1, w1, P2, C_all);
+    if (blockIdx.x == 0 || (int)blockIdx.x >= (int)gridDim.x - tail) sgbm_cost_strip_reg<true, CD, CSW2, CTX, MAXCW>(left, right, ftzero, w, h, minD, minX1, w1, P2, C_all);
+    else sgbm_cost_strip_reg<false, CD, CSW2, CTX, MAXCW>(left, right, ftzero, w, h, minD, minX1, w1, P2, C_all);
 }
 
 // ------------------------------------------------------------------ one aggregation step on a 16-lane row (K disparities per lane)
@@ -1904,7 +1955,6 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     int* count = (int*)q; q += al(np * 4);
     unsigned* sweep_flags = (unsigned*)q;                     // 256 bytes of flags, then the sweep's mailboxes
     const dim3 gimg((w + 255) / 256, h, nb);
-    sgbm_prefilter<<<dim3((w + 255) / 256, h, nb * 2), 256, 0, s>>>(left, right, w, h, ftzero, planes);
     {
         int TX = 0; size_t lds = 0;
         if (!sgbm_cost_geometry(D, SW, &TX, &lds)) return hipErrorInvalidValue;
@@ -1916,13 +1966,18 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
         };
         static const int cost_variant = [] { const char* v = getenv("SSM_SGBM_COST_VARIANT"); return v ? atoi(v) : 1; }();      // 0: the LDS ring for every configuration (ablation)
         const long cmax_c = (long)P2 + (long)SW * SW * (2 * ftzero + 63);
-        if (D == 80 && SW2 == 5 && TX == 32 && cost_variant != 0 && cmax_c < 65536) {      // src/stereo.cpp:16-27, ring in registers: 13 KB of LDS per block
+        if (D == 80 && SW2 == 5 && TX == 32 && cost_variant != 0 && cmax_c < 65536 && w >= 8) {
+            // src/stereo.cpp:16-27: the ring in registers (13 KB of LDS per block) and the pre-filter records made inside the kernel's staging (no plane pass)
             constexpr int AWc = 32 + 10, RWc = AWc + 79;
             lds = 2 * ((((size_t)(AWc + 6) * 80) + 15) & ~(size_t)15) + 2 * (size_t)(AWc + RWc) * 16;
-            launch(sgbm_cost_reg_kernel<80, 5, 32, 6>);
+            auto kern = sgbm_cost_reg_kernel<80, 5, 32, 6>;
+            (void)sg_allow_lds(reinterpret_cast<const void*>(kern), lds);
+            kern<<<dim3(nstrips, nb), SGC_THREADS, lds, s>>>(left, right, ftzero, w, h, minD, minX1, w1, P2, tail, C);
+        } else {
+            sgbm_prefilter<<<dim3((w + 255) / 256, h, nb * 2), 256, 0, s>>>(left, right, w, h, ftzero, planes);
+            if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);
+            else launch(sgbm_cost_kernel<0, 0, 0, 16>);
         }
-        else if (D == 80 && SW2 == 5 && TX == 32) launch(sgbm_cost_kernel<80, 5, 32, 6>);
-        else launch(sgbm_cost_kernel<0, 0, 0, 16>);
     }
     int16_t* wta_out = raw_only == 1 ? disp_out : d_raw;
     hipError_t e;
