@@ -278,18 +278,24 @@ def latest_profile(suffix):
     return c[-1] if c else None
 
 
-def cpu_all_cores(orc, frames_per_thread, leaf):
-    """SURVEY.md s.8d (ii): the oracle pipeline on every host core, frame-sharded like the GPU path (each thread runs its own contiguous
-    block of the stream through oracle/pipeline.c; ctypes releases the GIL during the call)"""
-    import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
+def granted_cores():
+    """host cores this process can really use: the affinity mask, capped by the container's CPU quota (cgroup v2 cpu.max = "<quota> <period>")"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:        # a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") is what it can really use
+    try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
             cores = max(1, min(cores, int(int(q) / int(per))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_all_cores(orc, frames_per_thread, leaf):
+    """SURVEY.md s.8d (ii): the oracle pipeline on every host core, frame-sharded like the GPU path (each thread runs its own contiguous
+    block of the stream through oracle/pipeline.c; ctypes releases the GIL during the call)"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    cores = granted_cores()
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda i: orc.pipeline(i * frames_per_thread, frames_per_thread, nfeatures=1000, leaf=np.float32(leaf)), range(cores)))
@@ -323,7 +329,8 @@ def parse_args(argv=None):
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
-    ap.add_argument("--stereo-batch", type=int, default=int(os.environ.get("SSM_STEREO_BATCH", "64")), help="configs[3]: frame pairs per launch of the batched stereo path (0.45 GB of SGBM workspace each, two workspaces)")
+    ap.add_argument("--stereo-batch", type=int, default=int(os.environ.get("SSM_STEREO_BATCH", "128")), help="configs[3]: frame pairs per launch of the batched stereo path (0.45 GB of SGBM workspace each, two workspaces; "
+                    "round 5: 128 instead of 64 -- the sweep's strips of more frames in flight overlap better: 4.93 k -> 5.18 k pairs/s)")
     ap.add_argument("--solve-poses", action="store_true", help="also time the closed pose loop: ORB + match tables -> ssm_tracker_run (Tracker::updateFrame for every frame: "
                     "the serial PnP chain) -> the solved poses into the map stage; reported as `solve_poses` beside `value` (whose poses are the stream's)")
     ap.add_argument("--pose-frames", type=int, default=200, help="frames of the --solve-poses leg")
@@ -758,7 +765,8 @@ def segnet_cpu_baseline(pipeline_cpu):
     from semantic_slam_mapping_amd import segnet_model
     wts = segnet_model.make_weights(1234)
     x = np.random.default_rng(7).integers(0, 256, (3, 360, 480)).astype(np.uint8)
-    cores = torch.get_num_threads()
+    cores = granted_cores()                                 # (torch would start a thread per visible core: the box shows 128, its quota is 16)
+    torch.set_num_threads(cores)
     segnet_ref.forward(x, wts)                              # first call: thread pool, allocator
     t0 = time.perf_counter(); n = 0
     while n < 2 or (time.perf_counter() - t0 < 6.0 and n < 8):
@@ -799,7 +807,7 @@ def other_configs(args, head):
         out["configs[2]"] = {"error": repr(e)}
     # ---- configs[3]: the stereo front end on resident 1241 x 376 pairs
     a = copy.copy(args)
-    a.stereo, a.frames, a.steps, a.warmup, a.stereo_batch = True, max(8, int(256 * sc)), 3, 1, max(4, min(args.stereo_batch, int(64 * sc)))
+    a.stereo, a.frames, a.steps, a.warmup, a.stereo_batch = True, max(8, int(256 * sc)), 3, 1, max(4, min(args.stereo_batch, int(128 * sc)))
     t0 = time.perf_counter()
     try:
         out["configs[3]"] = sub_line(stereo_main(a), wall_s=round(time.perf_counter() - t0, 1))

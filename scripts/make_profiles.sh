@@ -5,7 +5,7 @@ set -e
 R=${1:-r05}; O=gpurun_out
 python3 scripts/prof_summary.py $O/p_stats profiles/${R}_kernel_stats.md $O/p_stats.log --warm 0.25 --frames-per-launch 250 > /dev/null
 python3 scripts/prof_summary.py $O/p_seg profiles/${R}_segnet_kernel_stats.md $O/p_seg.log --warm 0.25 --frames-per-launch 64 > /dev/null
-python3 scripts/prof_summary.py $O/p_st profiles/${R}_stereo_kernel_stats.md $O/p_st.log --warm 0.34 --frames-per-launch 64 > /dev/null
+python3 scripts/prof_summary.py $O/p_st profiles/${R}_stereo_kernel_stats.md $O/p_st.log --warm 0.34 --frames-per-launch 128 > /dev/null
 python3 scripts/sq_summary.py $O/p_sq profiles/${R}_sq_counters.md "${R}: rocprofv3 --pmc SQ_* per kernel (bench.py --steps 1 --warmup 0, SSM_BENCH_H2D=0: two passes of 1000 frames, batch 250)" 2000
 python3 scripts/pmc_traffic.py $O/p_fetch $O/p_write profiles/${R}_traffic.json 250 > /dev/null
 if [ -d $O/p_sq_st ]; then
