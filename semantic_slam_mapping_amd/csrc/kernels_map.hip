@@ -233,19 +233,39 @@ __device__ __forceinline__ ssm_voxel* vox_find_or_insert(ssm_voxel* tab, int cap
     }
     return nullptr;
 }
-// a fresh record of the overflow list (the caller writes all of it), or nullptr when the list is full too (flag bit 0: the contribution is lost)
-__device__ __forceinline__ ssm_voxel* vox_overflow_slot(int32_t* counters)
+// a fresh record of the overflow list (the caller writes all of it), or nullptr when the list is full too (flag bit 0: the contribution is lost).
+// (round 5, measured: with a GENERIC list pointer the record went out as flat_store instructions, and their presence in map_stream2_kernel's run loop -- a flat
+// access counts against the LDS counter as well as the memory counter -- cost the kernel 4 %: 1.60 -> 1.66 us per frame; g_voxel below is what fixed it, not the
+// placement of the cold code: out of line, behind __builtin_expect or inline made no difference)
+typedef __attribute__((address_space(1))) ssm_voxel g_voxel;      // the overflow list is DEVICE memory: a pointer loaded from memory would be generic, its stores `flat_store`s,
+                                                                  // which wait on the LDS counter too -- inside map_stream2_kernel's loop that cost the kernel 4 %
+__device__ __forceinline__ g_voxel* vox_overflow_slot(int32_t* counters)
 {
     const int cap = counters[3];
-    ssm_voxel* buf = *reinterpret_cast<ssm_voxel* const*>(counters + 4);
+    g_voxel* buf = (g_voxel*)*reinterpret_cast<ssm_voxel* const*>(counters + 4);
     const int i = cap > 0 ? atomicAdd(&counters[2], 1) : cap;
     if (i >= cap) { atomicOr(&counters[1], 1); return nullptr; }
     return buf + i;
 }
-__device__ __forceinline__ void vox_overflow_one(int32_t* counters, long long key, long long sx, long long sy, long long sz, unsigned long long sr, unsigned long long sg,
-                                                 unsigned long long sb, unsigned long long n, uint32_t lab)
+__device__ __forceinline__ void vox_store_record(g_voxel* o, const ssm_voxel& sv)
 {
-    ssm_voxel* o = vox_overflow_slot(counters);
+    o->key = sv.key; o->sx = sv.sx; o->sy = sv.sy; o->sz = sv.sz; o->sr = sv.sr; o->sg = sv.sg; o->sb = sv.sb; o->n = sv.n;
+    for (int c = 0; c < 12; c++) o->hist[c] = sv.hist[c];
+}
+// the same for an entry of a block's LDS table: label votes as six packed 16-bit pairs
+__device__ __forceinline__ void vox_overflow_packed(int32_t* counters, long long key, long long sx, long long sy, long long sz, unsigned r, unsigned g, unsigned b, unsigned n, const unsigned* hist6)
+{
+    unsigned h[6];
+    for (int c = 0; c < 6; c++) h[c] = hist6[c];
+    g_voxel* o = vox_overflow_slot(counters);
+    if (!o) return;
+    o->key = key; o->sx = sx; o->sy = sy; o->sz = sz; o->sr = r; o->sg = g; o->sb = b; o->n = n;
+    for (int c = 0; c < 12; c++) o->hist[c] = (h[c >> 1] >> (16 * (c & 1))) & 0xFFFF;
+}
+__device__ __forceinline__ void vox_overflow_one(int32_t* counters, long long key, long long sx, long long sy, long long sz, unsigned long long sr, unsigned long long sg,
+                                              unsigned long long sb, unsigned long long n, uint32_t lab)
+{
+    g_voxel* o = vox_overflow_slot(counters);
     if (!o) return;
     o->key = key; o->sx = sx; o->sy = sy; o->sz = sz; o->sr = sr; o->sg = sg; o->sb = sb; o->n = n;
 #pragma unroll
@@ -335,7 +355,7 @@ vox_insert_kernel(const ssm_point* __restrict__ pts, const int64_t* __restrict__
                 vox_add(v, sx, sy, sz, rg & 0xFFFF, rg >> 16, bn & 0xFFFF, bn >> 16);
 #pragma unroll
                 for (int c = 0; c < 12; c++) { const int k = __popcll(lb[c] & run); if (k) atomicAdd(&v->hist[c], (uint32_t)k); }
-            } else if (ssm_voxel* o = vox_overflow_slot(counters)) {
+            } else if (g_voxel* o = vox_overflow_slot(counters)) {
                 o->key = key; o->sx = sx; o->sy = sy; o->sz = sz; o->sr = rg & 0xFFFF; o->sg = rg >> 16; o->sb = bn & 0xFFFF; o->n = bn >> 16;
 #pragma unroll
                 for (int c = 0; c < 12; c++) o->hist[c] = (uint32_t)__popcll(lb[c] & run);
@@ -458,6 +478,14 @@ __device__ __forceinline__ uint32_t label_of_bgr24(uint32_t bgr)     // b | g<<8
     }
     return 255;
 }
+// the block table is full (a leaf far below the pixel footprint): the run goes straight to the global table, or to the context's overflow list
+__device__ __forceinline__ void vox_direct(long long key, uint32_t lab, long long sx, long long sy, long long sz, unsigned r, unsigned g, unsigned b, unsigned n,
+                ssm_voxel* tab, int cap_log2, int32_t* counters, uint32_t* occ)
+{
+    ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
+    if (__builtin_expect(v != nullptr, 1)) { vox_add(v, sx, sy, sz, r, g, b, n); if (lab < 12) atomicAdd(&v->hist[lab], n); }
+    else vox_overflow_one(counters, key, sx, sy, sz, r, g, b, n, lab);
+}
 __device__ __forceinline__ void lds_vox_update(LdsVox* lt, long long key, uint32_t lab, const RunAcc& f,
                                                ssm_voxel* tab, int cap_log2, int32_t* counters, uint32_t* occ)
 {
@@ -467,17 +495,13 @@ __device__ __forceinline__ void lds_vox_update(LdsVox* lt, long long key, uint32
         const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&lt[slot].key), (unsigned long long)SSM_VOX_EMPTY, (unsigned long long)key);
         if (prev == (unsigned long long)SSM_VOX_EMPTY || prev == (unsigned long long)key) { e = &lt[slot]; break; }
     }
-    if (e) {
+    if (__builtin_expect(e != nullptr, 1)) {
         atomicAdd(reinterpret_cast<unsigned long long*>(&e->sx), (unsigned long long)f.sx);
         atomicAdd(reinterpret_cast<unsigned long long*>(&e->sy), (unsigned long long)f.sy);
         atomicAdd(reinterpret_cast<unsigned long long*>(&e->sz), (unsigned long long)f.sz);
         atomicAdd(&e->r, f.r); atomicAdd(&e->g, f.g); atomicAdd(&e->b, f.b); atomicAdd(&e->n, f.n);
         if (lab < 12) atomicAdd(&e->hist[lab >> 1], f.n << (16 * (lab & 1)));
-    } else {                                                    // the block table is full: straight to the global table
-        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, key, counters, occ);
-        if (v) { vox_add(v, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n); if (lab < 12) atomicAdd(&v->hist[lab], f.n); }
-        else vox_overflow_one(counters, key, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n, lab);
-    }
+    } else vox_direct(key, lab, f.sx, f.sy, f.sz, f.r, f.g, f.b, f.n, tab, cap_log2, counters, occ);
 }
 // merge equal neighbouring runs across the wave and push the tails into the block table
 __device__ __forceinline__ void wave_flush(LdsVox* lt, long long key, uint32_t lab, RunAcc f, int lane,
@@ -631,14 +655,7 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
     for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
-        if (!v) {
-            if (ssm_voxel* o = vox_overflow_slot(counters)) {
-                o->key = lt[i].key; o->sx = lt[i].sx; o->sy = lt[i].sy; o->sz = lt[i].sz; o->sr = lt[i].r; o->sg = lt[i].g; o->sb = lt[i].b; o->n = lt[i].n;
-#pragma unroll
-                for (int c = 0; c < 12; c++) o->hist[c] = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF;
-            }
-            continue;
-        }
+        if (__builtin_expect(!v, 0)) { vox_overflow_packed(counters, lt[i].key, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n, lt[i].hist); continue; }
         vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
 #pragma unroll
         for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
@@ -877,14 +894,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     for (int i = tid; i < MS_SLOTS; i += 256) {
         if (lt[i].key == SSM_VOX_EMPTY) continue;
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
-        if (!v) {
-            if (ssm_voxel* o = vox_overflow_slot(counters)) {
-                o->key = lt[i].key; o->sx = lt[i].sx; o->sy = lt[i].sy; o->sz = lt[i].sz; o->sr = lt[i].r; o->sg = lt[i].g; o->sb = lt[i].b; o->n = lt[i].n;
-#pragma unroll
-                for (int c = 0; c < 12; c++) o->hist[c] = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF;
-            }
-            continue;
-        }
+        if (__builtin_expect(!v, 0)) { vox_overflow_packed(counters, lt[i].key, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n, lt[i].hist); continue; }
         vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
 #pragma unroll
         for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
@@ -943,7 +953,7 @@ __global__ void vox_merge_kernel(const ssm_voxel* __restrict__ src, int n, ssm_v
     if (i >= n) return;
     const ssm_voxel sv = src[i];
     ssm_voxel* v = vox_find_or_insert(tab, cap_log2, sv.key, counters, occ);
-    if (!v) { if (ssm_voxel* o = vox_overflow_slot(counters)) *o = sv; return; }
+    if (!v) { if (g_voxel* o = vox_overflow_slot(counters)) vox_store_record(o, sv); return; }
     vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
     for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
 }
@@ -956,7 +966,7 @@ __global__ void vox_rehash_kernel(const ssm_voxel* __restrict__ src, const uint3
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const ssm_voxel sv = src[src_occ[i]];
         ssm_voxel* v = vox_find_or_insert(tab, cap_log2, sv.key, counters, occ);
-        if (!v) { if (ssm_voxel* o = vox_overflow_slot(counters)) *o = sv; continue; }
+        if (!v) { if (g_voxel* o = vox_overflow_slot(counters)) vox_store_record(o, sv); continue; }
         vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
         for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
     }
