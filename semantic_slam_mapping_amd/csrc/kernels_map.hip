@@ -208,7 +208,7 @@ hipError_t k_backproject(const uint16_t* depth, const uint8_t* rgb, const uint8_
 // was full too; 2 = points outside the key range were skipped), [2] records appended to the overflow list, [3] its capacity, [4..5] its address.
 // A table never refuses a contribution as long as its overflow list has room: when the neighbourhood of a key's home slot is taken (VOX_PROBE_LIMIT slots: a table
 // that is too full, or one the host has not grown yet), the whole contribution is appended to the list as one ssm_voxel record and the host merges the list into the
-// (grown) table the next time it settles the map (ssm_abi.hip map_settle) -- exact integer sums: when and where a contribution is added does not matter.
+// (grown) table the next time it settles the map (ssm_map.hip map_settle) -- exact integer sums: when and where a contribution is added does not matter.
 #define VOX_PROBE_LIMIT 128u
 __device__ __forceinline__ uint32_t vox_hash(int64_t key)
 {
@@ -957,7 +957,7 @@ __global__ void vox_merge_kernel(const ssm_voxel* __restrict__ src, int n, ssm_v
     vox_add(v, sv.sx, sv.sy, sv.sz, sv.sr, sv.sg, sv.sb, sv.n);
     for (int c = 0; c < 12; c++) if (sv.hist[c]) atomicAdd(&v->hist[c], sv.hist[c]);
 }
-// every occupied slot of one table into another (the host grows the map: ssm_abi.hip map_settle)
+// every occupied slot of one table into another (the host grows the map: ssm_map.hip map_settle)
 __global__ void vox_rehash_kernel(const ssm_voxel* __restrict__ src, const uint32_t* __restrict__ src_occ, const int32_t* __restrict__ src_counters,
                                   ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters)
 {

@@ -2,152 +2,12 @@
 // declared in include/ssm_hip.h.  No computation of the path happens on the host: this file only sizes buffers,
 // moves caller data and enqueues the kernels of kernels_*.hip on the context stream.  There is NO CPU fallback: if
 // HIP is unusable ssm_create fails with SSM_E_NODEVICE / SSM_E_HIP.
-#include "ssm_internal.h"
-#include "pnp_chain.h"
-#include <rccl/rccl.h>
-#include <cmath>
-#include <cfloat>
-#include <cstring>
-#include <cstdlib>
-#include <mutex>
-#include <functional>
-#include <string>
-#include <vector>
+#include "ssm_ctx.h"
 
 static const int8_t k_default_pattern[1024] = {
 #include "orb_pattern.inc"
 };
-static thread_local std::string g_create_err;
-
-namespace {
-
-struct VoxTable {           // tab[slots] | occ[slots] | counter block (32 bytes: count, flags, overflow records, overflow capacity, overflow list address)
-    ssm_voxel* tab = nullptr; uint32_t* occ = nullptr; int32_t* counters = nullptr; int cap_log2 = 0;
-    ssm_voxel* ovf = nullptr; int ovf_cap = 0;       // the overflow list of the context map (kernels_map.hip vox_overflow_slot); the temporary tables have none
-    size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 32; }
-};
-static const int VOX_OVF_RECORDS = 1 << 18;          // 29 MB per context
-struct StageRec { const char* name; hipEvent_t a, b; };
-// SegNet driving_webdemo: 26 conv layers; op list interleaves pools / unpools
-struct SegLayerDef { int cin, cout, h, w; };
-static const int SEG_NW = 480, SEG_NH = 360, SEG_NCLS = 12, SEG_LAYERS = 26;
-static const SegLayerDef k_seg_layers[SEG_LAYERS] = {
-    {3, 64, 360, 480}, {64, 64, 360, 480},                                   // conv1_1 conv1_2 | pool1
-    {64, 128, 180, 240}, {128, 128, 180, 240},                               // conv2_x         | pool2
-    {128, 256, 90, 120}, {256, 256, 90, 120}, {256, 256, 90, 120},           // conv3_x         | pool3
-    {256, 512, 45, 60}, {512, 512, 45, 60}, {512, 512, 45, 60},              // conv4_x         | pool4 (ceil: 23x30)
-    {512, 512, 23, 30}, {512, 512, 23, 30}, {512, 512, 23, 30},              // conv5_x         | pool5 (ceil: 12x15)
-    {512, 512, 23, 30}, {512, 512, 23, 30}, {512, 512, 23, 30},              // upsample5 | conv5_3_D conv5_2_D conv5_1_D
-    {512, 512, 45, 60}, {512, 512, 45, 60}, {512, 256, 45, 60},              // upsample4 | conv4_x_D
-    {256, 256, 90, 120}, {256, 256, 90, 120}, {256, 128, 90, 120},           // upsample3 | conv3_x_D
-    {128, 128, 180, 240}, {128, 64, 180, 240},                               // upsample2 | conv2_x_D
-    {64, 64, 360, 480}, {64, 12, 360, 480}                                   // upsample1 | conv1_2_D conv1_1_D (no BN/ReLU)
-};
-
-} // namespace
-#define SG_FAIL_WORDS 256
-struct StereoState {        // workspace of the stereo path (quad matcher, SGBM depth, stereo VO) for one image geometry, B frames per launch
-    int w = 0, h = 0, maxc = 0, B = 0;
-    QuadBatch qb{};                          // image slots: 2 sides x (B + 1) pyramids + Scharr derivatives
-    uint8_t* pyr = nullptr; int16_t* der = nullptr;
-    GfttWork gw{};                           // goodFeaturesToTrack workspace (kernels_quad.hip)
-    int keycap = 0; int *overflow = nullptr, *ncorner = nullptr, *has_prev = nullptr;
-    int* sg_fail = nullptr;                  // SG_FAIL_WORDS words: word (sub-batch index mod SG_FAIL_WORDS) is set by that sub-batch's sgbm_sweep when a strip hand-off times out (kernels_sgbm.hip)
-    // the depth stage of the most recent sequence call, kept so that sub-batches whose sweep timed out can be repeated in form 1 once the call is known to have
-    // failed (ssm_sync / check_device_flags: the caller's input buffers must stay untouched until then, as for any asynchronous call)
-    struct { bool valid = false; ssm_stereo_frames_dev in{}; int B = 0; } sg_pending;
-    float* pts = nullptr;                    // [5][B][maxc] (x, y): lc (GFTT corners), rc, rp, lp, lp_direct
-    uint8_t* status = nullptr; float* err = nullptr;        // ssm_lk_track outputs
-    double* tr_all = nullptr; int32_t *vcount = nullptr, *rand_off = nullptr, *consumed = nullptr; int vo_iters = 0;   // stereo VO scratch (B x iters hypotheses)
-    void* sg_wsN[3] = {nullptr, nullptr, nullptr}; size_t sg_ws_bytesN[3] = {0, 0, 0}; int* dminN[3] = {nullptr, nullptr, nullptr};   // SGBM workspaces (sized for the frames per launch actually used): successive sub-batches of a sequence run SGBM on up to three streams, one workspace each
-    // sequence outputs (seq_cap frames)
-    int seq_cap = 0;
-    ssm_pmatch* quad = nullptr; int32_t* nquad = nullptr; float* corners = nullptr; int32_t* ncorners = nullptr; int16_t* disp = nullptr; uint16_t* depth = nullptr;
-    double* tr = nullptr; int32_t *inliers = nullptr, *vo_result = nullptr;
-    bool have_prev = false;                  // slot 0 holds the last frame of the previous sequence call
-    uint8_t* in_stage = nullptr; size_t in_stage_bytes = 0;     // device staging of the per-pair host-pointer entry points
-};
-struct SegNetState {
-    bool set[SEG_LAYERS] = {};
-    void* w[SEG_LAYERS] = {}; float* scale[SEG_LAYERS] = {}; float* shift[SEG_LAYERS] = {};
-    int cinp[SEG_LAYERS], coutp[SEG_LAYERS], coutstore[SEG_LAYERS];
-    int batch = 0;
-    void *actA = nullptr, *actB = nullptr, *last_logits = nullptr; uint8_t* code[5] = {}; uint8_t* labels = nullptr;
-    int32_t *pre_xofs = nullptr, *pre_yofs = nullptr, *post_xofs = nullptr, *post_yofs = nullptr;
-    int16_t *pre_xa = nullptr, *pre_ya = nullptr, *post_xa = nullptr, *post_ya = nullptr;
-    uint8_t* d_sem_gen = nullptr;       // generated colour labels for the sequence path (max_batch frames)
-};
-
-static void stereo_free(StereoState* q);
-
-struct ssm_ctx {
-    std::mutex mu;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool side_ready = false;            // ensure_side_streams completed
-    hipStream_t stream2 = nullptr;      // ssm_seq_process: the SegNet + map stage of a sub-batch runs here, beside the ORB + match chain
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr; uint8_t* d_mask3 = nullptr; int map_stream = 1;   // two-chain mode: the map stage on a stream of its own (SSM_MAP_STREAM=0: on the chain's stream)
-    ssm_config cfg{};
-    OrbGeom g{};
-    std::string err;
-    int B = 1, R = 5;
-    // constant tables
-    void* d_blur_tab = nullptr; bool blur_mfma = true;                 // blur_mfma_kernel's coefficient fragments (kernels_orb.hip); SSM_BLUR_VARIANT=0: the VALU kernel
-    int8_t* d_pattern = nullptr; float* d_pattern_f = nullptr;      // the BRIEF table as given, and as floats for brief_kernel
-    int32_t* d_xofs[SSM_MAX_LEVELS] = {}; int16_t* d_xa[SSM_MAX_LEVELS] = {};
-    void* d_xgrp[SSM_MAX_LEVELS] = {};       // resize4_kernel's per-group constants (null: the level uses the general resize kernel)
-    int32_t* d_yofs[SSM_MAX_LEVELS] = {}; int16_t* d_ya[SSM_MAX_LEVELS] = {};
-    // batch workspace (B frames)
-    uint8_t *d_pyr = nullptr, *d_blur = nullptr; int32_t* d_cellmax = nullptr; cand_t* d_cand = nullptr; uint16_t* d_nodeof = nullptr;
-    int32_t* d_ncand = nullptr; uint32_t* d_sel = nullptr; int32_t* d_nsel = nullptr; int32_t* d_status = nullptr; uint4* d_kpaux = nullptr;
-    // second ORB / map workspace: ssm_seq_process runs alternate sub-batches as two chains on two streams (allocated at first use)
-    struct AltWork { uint8_t *pyr = nullptr, *blur = nullptr; int32_t* cellmax = nullptr; cand_t* cand = nullptr; uint16_t* nodeof = nullptr;
-                     int32_t* ncand = nullptr; uint32_t* sel = nullptr; int32_t* nsel = nullptr; uint8_t* mask = nullptr; uint4* kpaux = nullptr; bool ready = false; } alt, alt2;
-    hipEvent_t ev_orb[3] = {nullptr, nullptr, nullptr};
-    hipStream_t stream4 = nullptr; hipEvent_t ev_join4 = nullptr; int nchains = 3;      // a third ORB -> match chain (workspace alt2, stream4) when a call has more than two sub-batches; SSM_CHAINS=2: two
-    uint8_t* d_mask = nullptr; int32_t* d_chunk_cnt = nullptr; int64_t* d_chunk_off = nullptr; int64_t* d_total = nullptr;
-    ssm_point* d_points = nullptr;
-    ssm_point* d_vmap = nullptr; int vmap_n = 0; size_t vmap_cap = 0;      // Mapper::viewer's filtered map, device-resident (ssm_viewer_map_update)
-    ssm_point* d_vcat = nullptr; size_t vcat_cap = 0;                        // its concatenation buffer
-    struct CloudSlab { ssm_point* d = nullptr; size_t cap = 0, used = 0; int live = 0; };
-    std::vector<CloudSlab> cloud_slabs;                                      // key-frame clouds (ssm_backproject_dev) are carved from slabs: no hipMalloc per cloud
-    // staging for the host-pointer entry points (one frame) + generic scratch
-    uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
-    void* d_scratch = nullptr; size_t scratch_bytes = 0;
-    void* d_scratch2 = nullptr; size_t scratch2_bytes = 0;
-    // sequence outputs
-    int seq_cap = 0, prev_n = -1;
-    ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
-    ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
-    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true; bool map_compact = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
-    // voxel tables
-    VoxTable map, tmp; bool map_full_reported = false;   // table-full already reported by check_device_flags (reset by ssm_map_clear)
-    // the context map grows (map_settle); between the map launches of ssm_seq_process its counters come back through a two-slot ring of asynchronous copies
-    int vox_max_log2 = 28; int32_t* h_map_snap = nullptr; hipEvent_t map_snap_ev[2] = {nullptr, nullptr}; uint64_t map_launches = 0; int map_grown = 0;
-    // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
-    ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1; int32_t* d_comm_counts = nullptr; int comm_counts_cap = 0;
-    // SegNet
-    struct SegNetState* seg = nullptr;
-    // quad matcher
-    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // ssm_config.sgbm_streams (SSM_SGBM_STREAMS overrides: ablations)
-    int sgbm_form_cfg = 0; long sgbm_fallbacks = 0;                                              // ssm_config.sgbm_form; sub-batches repeated in form 1 after a sweep time-out
-    // profiling
-    bool profiling = false;
-    uint8_t* h_pinned = nullptr; size_t pinned_bytes = 0;   // host staging for the image-sized host-pointer calls (pageable hipMemcpy is ~1 GB/s)
-    // the per-frame entry points (ssm_orb_extract[_async], ssm_match[_async]): a ring of pinned host memory (inputs staged, results landed) and a ring of
-    // device memory (result blocks), bump-allocated per call and released by ssm_wait; `pending` = what ssm_wait still has to hand to the callers
-    uint8_t* h_ring = nullptr; uint8_t* d_ring = nullptr; size_t ring_bytes = 0, h_ring_off = 0, d_ring_off = 0;
-    std::vector<std::function<int(ssm_ctx*)>> pending;
-    bool serialize = false;             // profiling mode 2: keep the side work of ssm_seq_process on the context stream (clean per-stage times)
-    std::vector<StageRec> recs; std::vector<hipEvent_t> pool; size_t pool_used = 0;
-    std::vector<std::string> stage_names; std::vector<float> stage_ms; std::vector<int> stage_launches;
-};
-
-#define FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
-#define HIPCHK(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__); return SSM_E_HIP; } } while (0)
-
-static inline int cv_round_f(float v) { return (int)lrint((double)v); }
+thread_local std::string g_create_err;
 
 // ---------------------------------------------------------------- geometry (mirrors ORBextractor ctor / ComputePyramid)
 static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
@@ -213,7 +73,7 @@ static int build_geometry(const ssm_config& c, OrbGeom& g, std::string& err)
     g.cap = c.orb_features + 3 * g.nlevels;
     return SSM_OK;
 }
-static void resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<int16_t>& coef)
+void resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<int16_t>& coef)
 {
     ofs.resize(dsize); coef.resize(2 * dsize);
     const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
@@ -229,23 +89,14 @@ static void resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::
 }
 
 // ---------------------------------------------------------------- helpers
-template <class T> static int dalloc(ssm_ctx* c, T** p, size_t count)
-{
-    *p = nullptr;
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
-    if (e != hipSuccess) { c->err = std::string("hipMalloc(") + std::to_string(count * sizeof(T)) + "): " + hipGetErrorString(e); return SSM_E_NOMEM; }
-    return SSM_OK;
-}
-#define DALLOC(ctx, p, n) do { int r__ = dalloc(ctx, &(p), (size_t)(n)); if (r__) return r__; } while (0)
-static int ensure_scratch(ssm_ctx* c, size_t bytes)
+int ensure_scratch(ssm_ctx* c, size_t bytes)
 {
     if (bytes <= c->scratch_bytes) return SSM_OK;
     if (c->d_scratch) { hipStreamSynchronize(c->stream); hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
     uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
     c->d_scratch = p; c->scratch_bytes = bytes; return SSM_OK;
 }
-static int ensure_pinned(ssm_ctx* c, size_t bytes)
+int ensure_pinned(ssm_ctx* c, size_t bytes)
 {
     if (bytes <= c->pinned_bytes) return SSM_OK;
     if (c->h_pinned) { hipStreamSynchronize(c->stream); hipHostFree(c->h_pinned); c->h_pinned = nullptr; c->pinned_bytes = 0; }
@@ -253,105 +104,14 @@ static int ensure_pinned(ssm_ctx* c, size_t bytes)
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc failed"; return SSM_E_HIP; }
     c->h_pinned = (uint8_t*)p; c->pinned_bytes = bytes; return SSM_OK;
 }
-static int ensure_scratch2(ssm_ctx* c, size_t bytes)
+int ensure_scratch2(ssm_ctx* c, size_t bytes)
 {
     if (bytes <= c->scratch2_bytes) return SSM_OK;
     if (c->d_scratch2) { hipStreamSynchronize(c->stream); hipFree(c->d_scratch2); c->d_scratch2 = nullptr; c->scratch2_bytes = 0; }
     uint8_t* p; int r = dalloc(c, &p, bytes); if (r) return r;
     c->d_scratch2 = p; c->scratch2_bytes = bytes; return SSM_OK;
 }
-static int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
-{
-    t.cap_log2 = cap_log2;
-    uint8_t* p; int r = dalloc(c, &p, t.bytes()); if (r) return r;
-    const size_t slots = (size_t)1 << cap_log2;
-    t.tab = reinterpret_cast<ssm_voxel*>(p); t.occ = reinterpret_cast<uint32_t*>(t.tab + slots); t.counters = reinterpret_cast<int32_t*>(t.occ + slots);
-    HIPCHK(c, k_voxel_clear(t.tab, -cap_log2, t.counters, c->stream));
-    struct { int32_t cap, pad; ssm_voxel* buf; } tail = { t.ovf ? t.ovf_cap : 0, 0, t.ovf };      // counters[3], counters[4..5]
-    static_assert(sizeof(tail) == 16, "counter block tail");
-    int32_t head[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(t.counters, head, 12, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t.counters + 3, &tail.cap, 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(t.counters + 4, &tail.buf, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                   // (the sources are on this stack)
-    return SSM_OK;
-}
-// The context map has no capacity of its own (the reference's globalMap grows without limit, src/mapper.cpp:121-158): voxel_capacity_log2 is where it STARTS.
-// map_settle brings the map to rest on stream s (blocking): the overflow list is merged into the table and the table is re-hashed into a larger one whenever
-// 4 x (voxels + overflow records + reserve) exceeds its slots -- `reserve` = new voxels the caller is about to add at most, so that an insert / merge of a known
-// size can never overflow.  SSM_E_CAPACITY only beyond 2^vox_max_log2 slots (28: the key's range), SSM_E_NOMEM when the larger table cannot be allocated; in both
-// cases nothing is lost: table and list stay as they are.
-static int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve)
-{
-    VoxTable& t = c->map;
-    int lo = 0;                                                   // overflow records [0, lo) are merged already
-    for (int round = 0; round < 64; round++) {
-        int32_t cnt[4];
-        HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        const int64_t n = cnt[0], hi = cnt[2] < t.ovf_cap ? cnt[2] : t.ovf_cap, m = hi - lo;
-        const int64_t slots = (int64_t)1 << t.cap_log2;
-        const bool grow = 4 * (n + m + reserve) > slots && t.cap_log2 < c->vox_max_log2;
-        if (!grow && 2 * (n + m + reserve) > slots) {
-            // at voxel_max_capacity_log2 and more than half full.  A caller that announced its insert (reserve) is refused before anything is added; records
-            // waiting in the overflow list have no table to go to: the map is incomplete from here on (flag bit 0, reported until ssm_map_clear)
-            if (m > 0) { const int32_t lost[2] = { cnt[1] | 1, 0 }; HIPCHK(c, hipMemcpyAsync(t.counters + 1, lost, 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
-            FAIL(c, SSM_E_CAPACITY, "the voxel map needs more than 2^" + std::to_string(c->vox_max_log2) + " slots (voxel_max_capacity_log2)");
-        }
-        if (m <= 0 && !grow) {
-            if (cnt[2] != 0) { const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
-            return SSM_OK;
-        }
-        if (grow) {
-            int L = t.cap_log2; while (L < c->vox_max_log2 && 4 * (n + m + reserve) > ((int64_t)1 << L)) L++;
-            VoxTable nt; nt.ovf = t.ovf; nt.ovf_cap = t.ovf_cap;
-            { hipStream_t keep = c->stream; c->stream = s; const int r = table_alloc(c, nt, L); c->stream = keep; if (r) return r; }
-            // the flags travel with the map; the new counter block goes on counting overflow records where the old one stopped (the records [lo, hi) are still to
-            // merge, and the re-hash itself appends behind them should it need the list)
-            const int32_t carry[2] = { cnt[1], cnt[2] < t.ovf_cap ? cnt[2] : t.ovf_cap };
-            HIPCHK(c, hipMemcpyAsync(nt.counters + 1, carry, 8, hipMemcpyHostToDevice, s));
-            HIPCHK(c, k_voxel_rehash(t.tab, t.cap_log2, nt.tab, nt.cap_log2, nt.counters, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            hipFree(t.tab);
-            t = nt; c->map_grown++;
-            continue;                                             // (count again: the re-hash itself may have used the list)
-        }
-        HIPCHK(c, k_voxel_merge(t.ovf + lo, (int)m, t.tab, t.cap_log2, t.counters, s));
-        lo = (int)hi;
-        if (lo >= t.ovf_cap) {                                    // the list was full to the brim: empty it before anything can be appended again
-            HIPCHK(c, hipStreamSynchronize(s));
-            HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 16, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s));
-            if (cnt[2] > t.ovf_cap && !(cnt[1] & 1)) FAIL(c, SSM_E_CAPACITY, "voxel map: the overflow list overflowed while it was merged");
-            const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s));
-            lo = 0;
-        }
-    }
-    FAIL(c, SSM_E_CAPACITY, "voxel map: the overflow list did not drain");
-}
-// ssm_seq_process, in front of every launch of the map stage on stream s.  A small table (< 2^20 slots) is settled exactly every time and takes only
-// slots / 4096 frames per launch; a large one is checked against the counters of the launch before the previous one (a two-slot ring of asynchronous copies:
-// the host never waits for the launch it has just queued) and settled when it is a quarter full or its overflow list is in use.
-static int map_before_launch(ssm_ctx* c, hipStream_t s)
-{
-    VoxTable& t = c->map;
-    if (t.cap_log2 < 20) return map_settle(c, s, 0);
-    if (c->map_launches < 2) return SSM_OK;
-    const int slot = (int)(c->map_launches & 1);
-    HIPCHK(c, hipEventSynchronize(c->map_snap_ev[slot]));
-    const int32_t* cnt = c->h_map_snap + 4 * slot;
-    if (cnt[2] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2)) { c->map_launches = 0; return map_settle(c, s, 0); }
-    return SSM_OK;
-}
-static int map_after_launch(ssm_ctx* c, hipStream_t s)
-{
-    const int slot = (int)(c->map_launches & 1);
-    HIPCHK(c, hipMemcpyAsync(c->h_map_snap + 4 * slot, c->map.counters, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->map_snap_ev[slot], s));
-    c->map_launches++;
-    return SSM_OK;
-}
-static int map_frames_per_launch(const ssm_ctx* c, int nb) { const int f = c->map.cap_log2 >= 20 ? nb : (1 << c->map.cap_log2) >> 12; return f < 1 ? 1 : (f > nb ? nb : f); }
-static void prof_begin(ssm_ctx* c, const char* name)
+void prof_begin(ssm_ctx* c, const char* name)
 {
     if (!c->profiling) return;
     auto get = [&]() { if (c->pool_used == c->pool.size()) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); } return c->pool[c->pool_used++]; };
@@ -359,13 +119,12 @@ static void prof_begin(ssm_ctx* c, const char* name)
     hipEventRecord(r.a, c->stream);
     c->recs.push_back(r);
 }
-static void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back().b, c->stream); }
+void prof_end(ssm_ctx* c) { if (c->profiling) hipEventRecord(c->recs.back().b, c->stream); }
 
 // ORB scratch overflow (d_status) is checked after every ORB entry point; the voxel-table-full flag (counters[1]) belongs to the MAP entry points
 // (ssm_sync after ssm_seq_process, ssm_map_*): it is reported once, so that one overflowing call does not fail every later call on the
 // context (the map then lacks the dropped points: ssm_map_clear / a larger voxel_capacity_log2 is the remedy the message names)
-static int sgbm_recover(ssm_ctx* c);
-static int check_device_flags(ssm_ctx* c, bool with_map)
+int check_device_flags(ssm_ctx* c, bool with_map)
 {
     int32_t st = 0, cnt[2] = {0, 0};
     HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
@@ -557,7 +316,6 @@ void ssm_internal_get_config(const ssm_ctx* c, ssm_config* out) { *out = c->cfg;
 int ssm_internal_get_device(const ssm_ctx* c) { return c->device; }
 extern "C" int ssm_orb_capacity(const ssm_ctx* c) { return c ? c->g.cap : 0; }
 extern "C" void* ssm_stream(ssm_ctx* c) { return c ? (void*)c->stream : nullptr; }
-static int wait_pending(ssm_ctx* c);
 extern "C" int ssm_sync(ssm_ctx* c)
 {
     if (!c) return SSM_E_INVAL;
@@ -593,7 +351,7 @@ extern "C" int ssm_get_stage_times(ssm_ctx* c, const char** names, float* ms, in
 // with the context: HIP spreads streams over a few hardware queues in creation order, and a context that only serves per-frame calls (the stereo bench
 // runs eight of them) should take ONE slot of that rotation -- with four streams per context every context's main stream landed on the same queue
 // (configs[3]: 233 instead of 346-386 frame pairs/s).
-static int ensure_side_streams(ssm_ctx* c)
+int ensure_side_streams(ssm_ctx* c)
 {
     if (c->side_ready) return SSM_OK;
     // each handle is created only if it is still missing: a call that failed half-way leaves side_ready false and the next call resumes
@@ -669,7 +427,7 @@ static int run_orb(ssm_ctx* c, const uint8_t* d_img, int channels, const uint16_
 // /root/reference/src/track.cpp:140-163).  Each call: inputs into the pinned ring (one memcpy per image), ONE host-to-device copy per image, the kernels, ONE
 // device-to-host copy of a result block that carries the count with the payload (capacity-sized: no round trip to learn the count first), and a finisher that
 // ssm_wait runs after the stream has drained.  The synchronous forms are the asynchronous ones + ssm_wait.
-static int wait_pending(ssm_ctx* c)
+int wait_pending(ssm_ctx* c)
 {
     if (c->pending.empty()) {
         // (an enqueue that failed behind its ring_take has advanced the offsets without registering a finisher: drain what may still read the ring, then rewind)
@@ -987,419 +745,7 @@ extern "C" int ssm_backproject(ssm_ctx* c, const uint16_t* depth, const uint8_t*
     return SSM_OK;
 }
 
-// ---------------------------------------------------------------- voxel map
-static int table_count(ssm_ctx* c, VoxTable& t, int* n)
-{
-    int32_t cnt[2];
-    if (&t == &c->map) { const int r = map_settle(c, c->stream, 0); if (r) return r; }
-    HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel map incomplete (contributions were dropped): ssm_map_clear and start from a larger voxel_capacity_log2");
-    *n = cnt[0];
-    return SSM_OK;
-}
-// sorts the table's voxels by key; leaves compact array + order in scratch2.  returns pointers
-static int table_sorted(ssm_ctx* c, VoxTable& t, int* n_out, ssm_voxel** compact, uint32_t** order)
-{
-    int n = 0; int r = table_count(c, t, &n); if (r) return r;
-    *n_out = n; *compact = nullptr; *order = nullptr;
-    if (n == 0) return SSM_OK;
-    size_t tmp_bytes = 0;
-    HIPCHK(c, voxel_sort_pairs(nullptr, &tmp_bytes, nullptr, n, nullptr, nullptr, nullptr, nullptr, c->stream));
-    const size_t a = ((size_t)n * sizeof(ssm_voxel) + 255) & ~(size_t)255, kb = ((size_t)n * 8 + 255) & ~(size_t)255, ib = ((size_t)n * 4 + 255) & ~(size_t)255;
-    r = ensure_scratch2(c, a + 2 * kb + 2 * ib + tmp_bytes + 512); if (r) return r;
-    uint8_t* p = reinterpret_cast<uint8_t*>(c->d_scratch2);
-    ssm_voxel* comp = reinterpret_cast<ssm_voxel*>(p); p += a;
-    uint64_t* ka = reinterpret_cast<uint64_t*>(p); p += kb; uint64_t* kbuf = reinterpret_cast<uint64_t*>(p); p += kb;
-    uint32_t* ia = reinterpret_cast<uint32_t*>(p); p += ib; uint32_t* ibuf = reinterpret_cast<uint32_t*>(p); p += ib;
-    int32_t* dn = reinterpret_cast<int32_t*>(p); p += 256;
-    HIPCHK(c, k_voxel_compact(t.tab, t.cap_log2, comp, dn, c->stream));
-    HIPCHK(c, voxel_sort_pairs(p, &tmp_bytes, comp, n, ka, kbuf, ia, ibuf, c->stream));
-    *compact = comp; *order = ibuf;
-    return SSM_OK;
-}
-static int table_export_points(ssm_ctx* c, VoxTable& t, ssm_point* out, int cap, int* n_out)
-{
-    int n; ssm_voxel* comp; uint32_t* order;
-    int r = table_sorted(c, t, &n, &comp, &order); if (r) return r;
-    *n_out = n;
-    if (n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(n) + ")");
-    if (n == 0) return SSM_OK;
-    r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
-    HIPCHK(c, k_voxel_gather_points(comp, order, n, reinterpret_cast<ssm_point*>(c->d_scratch), c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-extern "C" int ssm_map_clear(ssm_ctx* c)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));       // (the capacity it has grown to stays)
-    c->map_full_reported = false; c->map_launches = 0;
-    return SSM_OK;
-}
-extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || (n && !pts)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if (n == 0) return SSM_OK;
-    int r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
-    HIPCHK(c, hipMemcpyAsync(c->d_scratch, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
-    // in chunks the table is grown for beforehand (every point of a chunk may open a voxel): nothing can overflow
-    for (int a = 0; a < n; ) {
-        int64_t chunk = ((int64_t)1 << c->map.cap_log2) / 8; if (chunk < 4096) chunk = 4096; if (chunk > n - a) chunk = n - a;
-        r = map_settle(c, c->stream, chunk); if (r) return r;
-        HIPCHK(c, k_voxel_insert(reinterpret_cast<ssm_point*>(c->d_scratch) + a, nullptr, chunk, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
-        a += (int)chunk;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return check_device_flags(c, true);
-}
-extern "C" int ssm_map_size(ssm_ctx* c, int* n)
-{
-    if (!c || !n) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    return table_count(c, c->map, n);
-}
-extern "C" int ssm_map_export(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
-{
-    if (!c || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    return table_export_points(c, c->map, out, cap, n_out);
-}
-extern "C" int ssm_map_export_table(ssm_ctx* c, ssm_voxel* out, int cap, int* n_out)
-{
-    if (!c || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    int n; ssm_voxel* comp; uint32_t* order;
-    int r = table_sorted(c, c->map, &n, &comp, &order); if (r) return r;
-    *n_out = n;
-    if (n > cap) FAIL(c, SSM_E_CAPACITY, "table buffer too small (need " + std::to_string(n) + ")");
-    if (n == 0) return SSM_OK;
-    r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
-    HIPCHK(c, k_voxel_gather_table(comp, order, n, reinterpret_cast<ssm_voxel*>(c->d_scratch), c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)n * sizeof(ssm_voxel), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-extern "C" int ssm_map_merge_table(ssm_ctx* c, const ssm_voxel* tab, int n)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if (n == 0) return SSM_OK;
-    int r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
-    HIPCHK(c, hipMemcpyAsync(c->d_scratch, tab, (size_t)n * sizeof(ssm_voxel), hipMemcpyHostToDevice, c->stream));
-    r = map_settle(c, c->stream, n); if (r) return r;               // room for n new voxels first
-    HIPCHK(c, k_voxel_merge(reinterpret_cast<ssm_voxel*>(c->d_scratch), n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-extern "C" int ssm_map_export_table_dev(ssm_ctx* c, ssm_voxel* out, int cap, int* n_out)
-{
-    if (!c || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    int n; ssm_voxel* comp; uint32_t* order;
-    int r = table_sorted(c, c->map, &n, &comp, &order); if (r) return r;
-    *n_out = n;
-    if (n > cap) FAIL(c, SSM_E_CAPACITY, "table buffer too small (need " + std::to_string(n) + ")");
-    if (n == 0) return SSM_OK;
-    if (!out) FAIL(c, SSM_E_INVAL, "null output");
-    HIPCHK(c, k_voxel_gather_table(comp, order, n, out, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-extern "C" int ssm_map_merge_table_dev(ssm_ctx* c, const ssm_voxel* tab, int n)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    { const int r = map_settle(c, c->stream, n); if (r) return r; }
-    HIPCHK(c, k_voxel_merge(tab, n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
-    return SSM_OK;
-}
-// ---------------------------------------------------------------- multi-GPU: one process per GPU, the voxel-map merge is the only collective
-#define NCCLCHK(ctx, expr) do { ncclResult_t e__ = (expr); if (e__ != ncclSuccess) { (ctx)->err = std::string(#expr) + ": " + ncclGetErrorString(e__); return SSM_E_COMM; } } while (0)
-extern "C" int ssm_comm_get_unique_id(void* id)
-{
-    static_assert(sizeof(ncclUniqueId) == SSM_COMM_ID_BYTES, "ncclUniqueId size");
-    if (!id) return SSM_E_INVAL;
-    ncclUniqueId u;
-    ncclResult_t e = ncclGetUniqueId(&u);
-    if (e != ncclSuccess) { g_create_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(e); return SSM_E_COMM; }
-    memcpy(id, &u, sizeof(u));
-    return SSM_OK;
-}
-extern "C" int ssm_comm_init_rank(ssm_ctx* c, int nranks, int rank, const void* id)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!id || nranks < 1 || rank < 0 || rank >= nranks) FAIL(c, SSM_E_INVAL, "bad communicator arguments");
-    if (c->comm) FAIL(c, SSM_E_INVAL, "the context already has a communicator (ssm_comm_finalize first)");
-    ncclUniqueId u; memcpy(&u, id, sizeof(u));
-    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, u, rank));
-    c->comm_rank = rank; c->comm_size = nranks;
-    return SSM_OK;
-}
-extern "C" int ssm_comm_finalize(ssm_ctx* c)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (c->comm) { HIPCHK(c, hipStreamSynchronize(c->stream)); NCCLCHK(c, ncclCommDestroy(c->comm)); c->comm = nullptr; }
-    c->comm_rank = 0; c->comm_size = 1;
-    return SSM_OK;
-}
-extern "C" int ssm_comm_rank(const ssm_ctx* c) { return c ? c->comm_rank : 0; }
-extern "C" int ssm_comm_size(const ssm_ctx* c) { return c ? c->comm_size : 1; }
-// SURVEY.md s.8e "collective": (1) all-gather of the per-rank voxel counts, (2) ONE all-gather of the tables padded to the longest
-// (in place: a rank compacts its own table straight into its slot of the receive buffer), (3) every rank re-inserts the nranks-1
-// remote tables.  Everything runs on the context stream; the one host wait is for the counts (they size the buffer).  Exact integer
-// sums (DESIGN.md "voxel sums") make the result independent of rank order: every rank ends with the bit-identical 1-GPU map.
-extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    ncclComm_t comm = rccl_comm ? reinterpret_cast<ncclComm_t>(rccl_comm) : c->comm;
-    if (!comm) FAIL(c, SSM_E_INVAL, "no communicator: pass a ncclComm_t or call ssm_comm_init_rank");
-    int world = 0, rank = 0;
-    NCCLCHK(c, ncclCommCount(comm, &world)); NCCLCHK(c, ncclCommUserRank(comm, &rank));
-    if (world > c->comm_counts_cap) {     // 2 ints per rank + one word of this rank's own flag
-        if (c->d_comm_counts) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_comm_counts); c->d_comm_counts = nullptr; c->comm_counts_cap = 0; }
-        DALLOC(c, c->d_comm_counts, (size_t)2 * world + 4); c->comm_counts_cap = world;
-    }
-    hipStream_t s = c->stream;
-    // the local map at rest first (overflow list merged).  A rank that cannot settle must not leave before the collectives: it raises its map's LOST flag, which the
-    // count all-gather below carries to every rank
-    const int r_settle = map_settle(c, s, 0);
-    if (r_settle) { const int32_t one = 1; HIPCHK(c, hipMemcpyAsync(c->map.counters + 1, &one, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
-    prof_begin(c, "allgather");
-    // Every decision that can end the call is taken COLLECTIVELY: a rank that returned between two collectives would leave its peers blocked in the
-    // next one.  (1) all-gather {voxel count, flag word} per rank -- counters[0..1] of the map table, already on the device.
-    NCCLCHK(c, ncclAllGather(c->map.counters, c->d_comm_counts, 2, ncclInt32, comm, s));
-    std::vector<int32_t> cf((size_t)2 * world);
-    HIPCHK(c, hipMemcpyAsync(cf.data(), c->d_comm_counts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    std::vector<int32_t> counts(world);
-    int mx = 1, bad_rank = -1, neg_rank = -1;
-    for (int q = 0; q < world; q++) { counts[q] = cf[2 * q]; if (cf[2 * q + 1] & 1) bad_rank = q; if (counts[q] < 0) neg_rank = q; if (counts[q] > mx) mx = counts[q]; }
-    if (bad_rank >= 0) { prof_end(c); FAIL(c, SSM_E_CAPACITY, "voxel table of rank " + std::to_string(bad_rank) + " is incomplete (contributions were dropped, or it could not be settled); no rank merged"); }
-    if (neg_rank >= 0) { prof_end(c); FAIL(c, SSM_E_COMM, "negative voxel count received from rank " + std::to_string(neg_rank)); }
-    // (2) the receive buffer: slot r = rank r's voxels, mx entries each.  An allocation failure on one rank is agreed on by a second tiny all-gather.
-    const size_t slot = (size_t)mx * sizeof(ssm_voxel);
-    int r_alloc = ensure_scratch2(c, slot * world + 256);
-    if (r_alloc == SSM_OK) { int64_t remote = 0; for (int q = 0; q < world; q++) if (q != rank) remote += counts[q]; r_alloc = map_settle(c, s, remote); }   // room for every remote voxel: the merges below cannot overflow
-    {
-        const int32_t ok = r_alloc == SSM_OK ? 0 : 1;
-        HIPCHK(c, hipMemcpyAsync(c->d_comm_counts + 2 * world, &ok, 4, hipMemcpyHostToDevice, s));
-        NCCLCHK(c, ncclAllGather(c->d_comm_counts + 2 * world, c->d_comm_counts, 1, ncclInt32, comm, s));
-        HIPCHK(c, hipMemcpyAsync(cf.data(), c->d_comm_counts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        for (int q = 0; q < world; q++) if (cf[q]) {
-            prof_end(c);
-            if (r_alloc) return r_alloc;
-            FAIL(c, SSM_E_NOMEM, "rank " + std::to_string(q) + " could not allocate the all-gather buffer; no rank merged");
-        }
-    }
-    uint8_t* recv = reinterpret_cast<uint8_t*>(c->d_scratch2);
-    int32_t* dn = reinterpret_cast<int32_t*>(recv + slot * world);
-    HIPCHK(c, k_voxel_compact(c->map.tab, c->map.cap_log2, reinterpret_cast<ssm_voxel*>(recv + slot * rank), dn, s));
-    NCCLCHK(c, ncclAllGather(recv + slot * rank, recv, slot, ncclUint8, comm, s));
-    // (3) merge the remote tables into the local map
-    for (int q = 0; q < world; q++) {
-        if (q == rank) continue;
-        HIPCHK(c, k_voxel_merge(reinterpret_cast<const ssm_voxel*>(recv + slot * q), counts[q], c->map.tab, c->map.cap_log2, c->map.counters, s));
-    }
-    prof_end(c);
-    return SSM_OK;
-}
-static inline float ord2f(int i) { i = i >= 0 ? i : i ^ 0x7FFFFFFF; float f; memcpy(&f, &i, 4); return f; }
-extern "C" int ssm_voxel_filter(ssm_ctx* c, const ssm_point* pts, int n, float leaf, ssm_point* out, int cap, int* n_out)
-{
-    if (!c || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || (n && !pts) || !(leaf > 0)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    *n_out = 0;
-    if (n == 0) return SSM_OK;
-    int r;
-    if (!c->tmp.tab) { r = table_alloc(c, c->tmp, c->cfg.voxel_capacity_log2); if (r) return r; }
-    else HIPCHK(c, k_voxel_clear(c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
-    r = ensure_scratch(c, (size_t)n * sizeof(ssm_point) + 64); if (r) return r;
-    ssm_point* dp = reinterpret_cast<ssm_point*>(c->d_scratch);
-    float* mm = reinterpret_cast<float*>(dp + n);
-    HIPCHK(c, hipMemcpyAsync(dp, pts, (size_t)n * sizeof(ssm_point), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, k_voxel_bounds(dp, n, mm, c->stream));
-    int ord[6];
-    HIPCHK(c, hipMemcpyAsync(ord, mm, 24, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    {   // pcl::VoxelGrid::applyFilter overflow guard: (dx*dy*dz) > INT_MAX -> warning, output = input
-        const float inv = 1.0f / leaf;
-        const int64_t dx = (int64_t)((ord2f(ord[3]) - ord2f(ord[0])) * inv) + 1, dy = (int64_t)((ord2f(ord[4]) - ord2f(ord[1])) * inv) + 1,
-                      dz = (int64_t)((ord2f(ord[5]) - ord2f(ord[2])) * inv) + 1;
-        if (dx * dy * dz > (int64_t)2147483647) FAIL(c, SSM_E_VOXEL_RANGE, "leaf size too small for the cloud extent (PCL would return the input unfiltered)");
-    }
-    // pcl::VoxelGrid has no table to overflow: when the temporary table fills up, re-allocate it four times as large and insert again
-    for (;;) {
-        HIPCHK(c, k_voxel_insert(dp, nullptr, n, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
-        int32_t cnt[2];
-        HIPCHK(c, hipMemcpyAsync(cnt, c->tmp.counters, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!(cnt[1] & 1)) break;
-        const int bigger = c->tmp.cap_log2 + 2;
-        if (bigger > 28) FAIL(c, SSM_E_CAPACITY, "voxel_filter: more than 2^28 voxels");
-        hipFree(c->tmp.tab); c->tmp.tab = nullptr;
-        r = table_alloc(c, c->tmp, bigger); if (r) return r;
-    }
-    return table_export_points(c, c->tmp, out, cap, n_out);
-}
-
-// ---------------------------------------------------------------- device-resident Mapper (ssm_backproject_dev, ssm_viewer_map_*)
-struct ssm_cloud { ssm_point* d = nullptr; int n = 0; int device = 0; int slab = -1; };
-extern "C" int ssm_backproject_dev(ssm_ctx* c, const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, int w, int h,
-                                   const ssm_camera* cam, double max_distance, ssm_cloud** cloud_out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!depth || !rgb || !sem || !cam || !cloud_out) FAIL(c, SSM_E_INVAL, "null argument");
-    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
-    *cloud_out = nullptr;
-    const size_t np = (size_t)w * h;
-    // one pinned staging area, one host-to-device copy for the three images (a pageable copy is staged by the runtime in small pieces)
-    int r = ensure_pinned(c, np * 8); if (r) return r;
-    memcpy(c->h_pinned, depth, np * 2); memcpy(c->h_pinned + np * 2, rgb, np * 3); memcpy(c->h_pinned + np * 5, sem, np * 3);
-    r = ensure_scratch(c, np * 8); if (r) return r;
-    uint8_t* din = reinterpret_cast<uint8_t*>(c->d_scratch);
-    HIPCHK(c, hipMemcpyAsync(din, c->h_pinned, np * 8, hipMemcpyHostToDevice, c->stream));
-    const uint16_t* dd = reinterpret_cast<const uint16_t*>(din); const uint8_t* drgb = din + np * 2; const uint8_t* dsem = din + np * 5;
-    // the cloud is written straight into a slab of device memory (room for the worst case, w h points; only the n points made are kept): no allocation, no
-    // device-to-device copy and ONE wait per key-frame
-    int si = -1;
-    for (size_t i = 0; i < c->cloud_slabs.size(); i++) if (c->cloud_slabs[i].cap - c->cloud_slabs[i].used >= np) { si = (int)i; break; }
-    if (si < 0) {
-        ssm_ctx::CloudSlab sl; sl.cap = np * 8 > ((size_t)2 << 20) ? np * 8 : ((size_t)2 << 20);          // >= 64 MB of points
-        if (hipMalloc((void**)&sl.d, sl.cap * sizeof(ssm_point)) != hipSuccess) FAIL(c, SSM_E_HIP, "hipMalloc of a key-frame cloud slab failed");
-        c->cloud_slabs.push_back(sl); si = (int)c->cloud_slabs.size() - 1;
-    }
-    ssm_ctx::CloudSlab& sl = c->cloud_slabs[si];
-    ssm_point* dst = sl.d + sl.used;
-    HIPCHK(c, k_moving_mask(dsem, 1, w, h, c->d_mask, c->stream));
-    HIPCHK(c, k_backproject(dd, drgb, dsem, c->d_mask, nullptr, 1, w, h, *cam, max_distance,
-                            c->d_chunk_cnt, c->d_chunk_off, reinterpret_cast<int32_t*>(c->d_total + 1), c->d_total, dst, c->stream));
-    int64_t* h_total = reinterpret_cast<int64_t*>(c->h_pinned);                  // (the staged images at the front of the pinned area are consumed by then: stream order)
-    HIPCHK(c, hipMemcpyAsync(h_total, c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int64_t total = *h_total;
-    ssm_cloud* cl = new ssm_cloud(); cl->n = (int)total; cl->device = c->device; cl->slab = si; cl->d = dst;
-    sl.used += ((size_t)total + 7) & ~(size_t)7; sl.live++;
-    *cloud_out = cl;
-    return SSM_OK;
-}
-extern "C" int ssm_cloud_size(const ssm_cloud* cl) { return cl ? cl->n : 0; }
-extern "C" void ssm_cloud_free(ssm_ctx* c, ssm_cloud* cl)
-{
-    if (!cl) return;
-    if (c) {                                                                   // a slab whose clouds are all freed is reused from its start
-        std::lock_guard<std::mutex> lk(c->mu);
-        if (cl->slab >= 0 && cl->slab < (int)c->cloud_slabs.size()) { ssm_ctx::CloudSlab& sl = c->cloud_slabs[cl->slab]; if (--sl.live == 0) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); sl.used = 0; } }
-    }
-    delete cl;                                                                  // (without a context the slab goes with ssm_destroy)
-}
-extern "C" int ssm_cloud_fetch(ssm_ctx* c, const ssm_cloud* cl, const double* T, ssm_point* out, int cap, int* n_out)
-{
-    if (!c || !cl || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    *n_out = cl->n;
-    if (cl->n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(cl->n) + ")");
-    if (cl->n == 0) return SSM_OK;
-    if (!out) FAIL(c, SSM_E_INVAL, "null argument");
-    int r = ensure_scratch(c, (size_t)cl->n * sizeof(ssm_point)); if (r) return r;
-    HIPCHK(c, k_cloud_transform(cl->d, cl->n, T, reinterpret_cast<ssm_point*>(c->d_scratch), c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_scratch, (size_t)cl->n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-static int grow_points(ssm_ctx* c, ssm_point*& p, size_t& cap, size_t need, size_t keep)
-{
-    if (need <= cap) return SSM_OK;
-    const size_t ncap = need + need / 2 + 1024;
-    ssm_point* q = nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (hipMalloc(&q, ncap * sizeof(ssm_point)) != hipSuccess) FAIL(c, SSM_E_HIP, "hipMalloc of the viewer map failed");
-    if (p && keep) HIPCHK(c, hipMemcpy(q, p, keep * sizeof(ssm_point), hipMemcpyDeviceToDevice));
-    if (p) hipFree(p);
-    p = q; cap = ncap;
-    return SSM_OK;
-}
-extern "C" int ssm_viewer_map_update(ssm_ctx* c, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || (n && (!clouds || !poses)) || !(leaf > 0)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    size_t total = rebuild ? 0 : (size_t)c->vmap_n;
-    for (int i = 0; i < n; i++) { if (!clouds[i]) FAIL(c, SSM_E_INVAL, "null cloud"); if (clouds[i]->device != c->device) FAIL(c, SSM_E_INVAL, "cloud of another device"); total += (size_t)clouds[i]->n; }
-    if (total > (size_t)0x7FFFFFFF) FAIL(c, SSM_E_CAPACITY, "more than 2^31 points in one map update");
-    if (total == 0) { c->vmap_n = 0; if (n_map_out) *n_map_out = 0; return SSM_OK; }
-    int r = grow_points(c, c->d_vcat, c->vcat_cap, total + 8, 0); if (r) return r;       // (+ 8 points: the bounds words behind the data)
-    // previous centroids, then every cloud transformed by its pose: the viewer's `*map += *generatePointCloud(kf)`
-    size_t off = 0;
-    if (!rebuild && c->vmap_n) { HIPCHK(c, hipMemcpyAsync(c->d_vcat, c->d_vmap, (size_t)c->vmap_n * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream)); off = (size_t)c->vmap_n; }
-    for (int i = 0; i < n; i++) { HIPCHK(c, k_cloud_transform(clouds[i]->d, clouds[i]->n, poses + (size_t)16 * i, c->d_vcat + off, c->stream)); off += (size_t)clouds[i]->n; }
-    const int N = (int)total;
-    if (!c->tmp.tab) { r = table_alloc(c, c->tmp, c->cfg.voxel_capacity_log2); if (r) return r; }
-    else HIPCHK(c, k_voxel_clear(c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
-    float* mm = reinterpret_cast<float*>(c->d_vcat + total);
-    HIPCHK(c, k_voxel_bounds(c->d_vcat, N, mm, c->stream));
-    int ord[6];
-    HIPCHK(c, hipMemcpyAsync(ord, mm, 24, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    {   // pcl::VoxelGrid::applyFilter overflow guard (as in ssm_voxel_filter): the map is then the unfiltered concatenation
-        const float inv = 1.0f / leaf;
-        const int64_t dx = (int64_t)((ord2f(ord[3]) - ord2f(ord[0])) * inv) + 1, dy = (int64_t)((ord2f(ord[4]) - ord2f(ord[1])) * inv) + 1,
-                      dz = (int64_t)((ord2f(ord[5]) - ord2f(ord[2])) * inv) + 1;
-        if (dx * dy * dz > (int64_t)2147483647) {
-            r = grow_points(c, c->d_vmap, c->vmap_cap, total, 0); if (r) return r;
-            HIPCHK(c, hipMemcpyAsync(c->d_vmap, c->d_vcat, total * sizeof(ssm_point), hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->vmap_n = N; if (n_map_out) *n_map_out = N;
-            return SSM_OK;
-        }
-    }
-    for (;;) {
-        HIPCHK(c, k_voxel_insert(c->d_vcat, nullptr, N, leaf, c->tmp.tab, c->tmp.cap_log2, c->tmp.counters, c->stream));
-        int32_t cnt[2];
-        HIPCHK(c, hipMemcpyAsync(cnt, c->tmp.counters, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!(cnt[1] & 1)) break;
-        const int bigger = c->tmp.cap_log2 + 2;
-        if (bigger > 28) FAIL(c, SSM_E_CAPACITY, "viewer map: more than 2^28 voxels");
-        hipFree(c->tmp.tab); c->tmp.tab = nullptr;
-        r = table_alloc(c, c->tmp, bigger); if (r) return r;
-    }
-    int nv; ssm_voxel* comp; uint32_t* order;
-    r = table_sorted(c, c->tmp, &nv, &comp, &order); if (r) return r;
-    r = grow_points(c, c->d_vmap, c->vmap_cap, (size_t)nv, 0); if (r) return r;
-    if (nv) HIPCHK(c, k_voxel_gather_points(comp, order, nv, c->d_vmap, c->stream));
-    c->vmap_n = nv;
-    if (n_map_out) *n_map_out = nv;
-    return SSM_OK;
-}
-extern "C" int ssm_viewer_map_fetch(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
-{
-    if (!c || !n_out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    *n_out = c->vmap_n;
-    if (c->vmap_n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small (need " + std::to_string(c->vmap_n) + ")");
-    if (c->vmap_n == 0) return SSM_OK;
-    if (!out) FAIL(c, SSM_E_INVAL, "null argument");
-    HIPCHK(c, hipMemcpyAsync(out, c->d_vmap, (size_t)c->vmap_n * sizeof(ssm_point), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-
 // ---------------------------------------------------------------- device-resident sequence path
-static int seg_init(ssm_ctx* c);
-static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags);
 static int ensure_seq(ssm_ctx* c, int n)
 {
     if (n <= c->seq_cap) return SSM_OK;
@@ -1569,749 +915,6 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     return SSM_OK;
 }
 
-
-// ---------------------------------------------------------------- SegNet (Classifier)
-static inline uint16_t f32_to_f16(float f)
-{
-    _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u;
-}
-extern "C" int ssm_segnet_num_layers(void) { return SEG_LAYERS; }
-extern "C" int ssm_segnet_layer_shape(int l, int* cin, int* cout, int* h, int* w)
-{
-    if (l < 0 || l >= SEG_LAYERS) return SSM_E_INVAL;
-    if (cin) *cin = k_seg_layers[l].cin; if (cout) *cout = k_seg_layers[l].cout; if (h) *h = k_seg_layers[l].h; if (w) *w = k_seg_layers[l].w;
-    return SSM_OK;
-}
-static int seg_init(ssm_ctx* c)
-{
-    if (c->seg) return SSM_OK;
-    SegNetState* g = new SegNetState();
-    c->seg = g;
-    for (int l = 0; l < SEG_LAYERS; l++) {
-        g->cinp[l] = k_seg_layers[l].cin <= 8 ? 8 : (k_seg_layers[l].cin + 63) & ~63;   // <= 8 channels: the first-layer kernel ([H][W][8] input)
-        g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
-        g->coutstore[l] = (k_seg_layers[l].cout + 31) & ~31;            // activations live in 32-channel chunks: [C/32][H][W][32]
-    }
-    {   // frames per SegNet launch: 64 by default (more tiles per launch: better balance in the small layers; SSM_SEGNET_BATCH for experiments; the 64-channel layers bound it to 96 by their 2^31-byte buffers)
-        const char* e = getenv("SSM_SEGNET_BATCH"); int sb = e ? atoi(e) : 64; if (sb < 1) sb = 1; if (sb > 96) sb = 96;
-        g->batch = c->B < sb ? c->B : sb;
-    }
-    const size_t act = (size_t)g->batch * SEG_NW * SEG_NH * 64 * 2;
-    uint8_t* p;
-    int r = dalloc(c, &p, act); if (r) return r; g->actA = p;
-    r = dalloc(c, &p, act); if (r) return r; g->actB = p;
-    const int ph[5] = {180, 90, 45, 23, 12}, pw[5] = {240, 120, 60, 30, 15}, pc[5] = {64, 128, 256, 512, 512};
-    for (int i = 0; i < 5; i++) DALLOC(c, g->code[i], (size_t)g->batch * ph[i] * pw[i] * pc[i]);
-    DALLOC(c, g->labels, (size_t)g->batch * SEG_NW * SEG_NH);
-    DALLOC(c, g->d_sem_gen, (size_t)c->B * c->g.W * c->g.H * 3);
-    auto up = [&](int ssize, int dsize, int32_t** o, int16_t** a) -> int {
-        std::vector<int32_t> ofs; std::vector<int16_t> co; resize_tables(ssize, dsize, ofs, co);
-        int rr = dalloc(c, o, ofs.size()); if (rr) return rr; rr = dalloc(c, a, co.size()); if (rr) return rr;
-        if (hipMemcpy(*o, ofs.data(), ofs.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(*a, co.data(), co.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { c->err = "segnet table upload"; return SSM_E_HIP; }
-        return SSM_OK;
-    };
-    if ((r = up(c->g.W, SEG_NW, &g->pre_xofs, &g->pre_xa)) || (r = up(c->g.H, SEG_NH, &g->pre_yofs, &g->pre_ya)) ||
-        (r = up(SEG_NW, c->g.W, &g->post_xofs, &g->post_xa)) || (r = up(SEG_NH, c->g.H, &g->post_yofs, &g->post_ya))) return r;
-    return SSM_OK;
-}
-extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, const float* scale, const float* shift)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (l < 0 || l >= SEG_LAYERS || !weight || !scale || !shift) FAIL(c, SSM_E_INVAL, "bad arguments");
-    int r = seg_init(c); if (r) return r;
-    SegNetState* g = c->seg;
-    const int cin = k_seg_layers[l].cin, cout = k_seg_layers[l].cout, cinp = g->cinp[l], coutp = g->coutp[l];
-    std::vector<uint16_t> w;
-    if (cinp == 8) {
-        // first-layer kernel: [Cout tile of 64][K step 5][half 2][cout in tile 64][8 channels], tap = 2 step + half (tap 9: zeros)
-        w.assign((size_t)coutp * 10 * 8, 0);
-        for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++)
-            w[((((size_t)(o / 64) * 5 + t / 2) * 2 + t % 2) * 64 + o % 64) * 8 + i] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
-    } else {
-        // LDS-DMA kernel: [Cout tile of 64][Cin chunk of 32][tap][c8 (4)][cout in tile (64)][8 channels]
-        w.assign((size_t)coutp * 9 * cinp, 0);
-        const int nck = cinp / 32;
-        for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int t = 0; t < 9; t++) {
-            const size_t idx = ((((((size_t)(o / 64) * nck + i / 32) * 9 + t) * 4 + (i % 32) / 8) * 64 + o % 64) * 8) + i % 8;
-            w[idx] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
-        }
-    }
-    if (!g->w[l]) { uint16_t* p; r = dalloc(c, &p, w.size()); if (r) return r; g->w[l] = p; DALLOC(c, g->scale[l], coutp); DALLOC(c, g->shift[l], coutp); }
-    std::vector<float> sc(coutp, 0.f), sh(coutp, 0.f);
-    for (int o = 0; o < cout; o++) { sc[o] = scale[o]; sh[o] = shift[o]; }
-    HIPCHK(c, hipMemcpy(g->w[l], w.data(), w.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g->scale[l], sc.data(), coutp * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g->shift[l], sh.data(), coutp * 4, hipMemcpyHostToDevice));
-    g->set[l] = true;
-    return SSM_OK;
-}
-// forward for nb <= seg->batch device frames already pre-processed into actA; leaves logits in the returned buffer
-// logits_out != nullptr: the class logits are materialised (returned buffer) and the caller runs the ArgMax kernel;
-// logits_out == nullptr: the last layer writes the labels (g->labels) straight from its epilogue.
-static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
-{
-    SegNetState* g = c->seg; hipStream_t s = c->stream;
-    void* cur = g->actA; void* nxt = g->actB;
-    HIPCHK(c, k_segnet_begin(s));
-    auto conv = [&](int l) -> int {
-        const SegLayerDef& d = k_seg_layers[l];
-        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s));
-        std::swap(cur, nxt); return SSM_OK;
-    };
-    auto unpool = [&](int i, int PH, int PW, int C, int H, int W) -> int { HIPCHK(c, k_segnet_unpool(cur, g->code[i], nb, PH, PW, C, nxt, H, W, s)); std::swap(cur, nxt); return SSM_OK; };
-    // un-pool + the convolution that consumes it as one kernel (the 4x sparse tensor is never written); the other conv kernels
-    // (SSM_CONV_VARIANT) run the two steps
-    const bool fused_up = k_segnet_conv_unpool_available() != 0;
-    auto unpool_conv = [&](int i, int PH, int PW, int C, int H, int W, int l) -> int {
-        // measured per layer (32 frames): the fused form wins where the un-pooled tensor is large (64 ch @360x480: 357 vs 586 us,
-        // 128 ch @180x240: 330 vs 433, 256 ch @90x120: 338 vs 354) and loses on the small 512-channel images, where the masking
-        // pass on the stage's critical path costs more than the separate un-pool (362 vs 327, 121 vs 103 us)
-        if (!fused_up || C > 256) { int r_ = unpool(i, PH, PW, C, H, W); return r_ ? r_ : conv(l); }
-        const SegLayerDef& d = k_seg_layers[l];
-        HIPCHK(c, k_segnet_conv_unpool(cur, g->code[i], g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, s));
-        std::swap(cur, nxt); return SSM_OK;
-    };
-    // conv + pool pairs run as one kernel (the full-resolution activation of the pooled layer is never written)
-    auto conv_pool = [&](int l, int i) -> int {
-        const SegLayerDef& d = k_seg_layers[l];
-        HIPCHK(c, k_segnet_conv_pool(cur, g->w[l], g->scale[l], g->shift[l], nxt, g->code[i], nb, d.h, d.w, g->cinp[l], d.cout, s));
-        std::swap(cur, nxt); return SSM_OK;
-    };
-    int r;
-    if ((r = conv(0)) || (r = conv_pool(1, 0))) return r;
-    if ((r = conv(2)) || (r = conv_pool(3, 1))) return r;
-    if ((r = conv(4)) || (r = conv(5)) || (r = conv_pool(6, 2))) return r;
-    if ((r = conv(7)) || (r = conv(8)) || (r = conv_pool(9, 3))) return r;
-    if ((r = conv(10)) || (r = conv(11)) || (r = conv_pool(12, 4))) return r;
-    if ((r = unpool_conv(4, 12, 15, 512, 23, 30, 13)) || (r = conv(14)) || (r = conv(15))) return r;
-    if ((r = unpool_conv(3, 23, 30, 512, 45, 60, 16)) || (r = conv(17)) || (r = conv(18))) return r;
-    if ((r = unpool_conv(2, 45, 60, 256, 90, 120, 19)) || (r = conv(20)) || (r = conv(21))) return r;
-    if ((r = unpool_conv(1, 90, 120, 128, 180, 240, 22)) || (r = conv(23))) return r;
-    if ((r = unpool_conv(0, 180, 240, 64, 360, 480, 24))) return r;
-    if (logits_out) { if ((r = conv(25))) return r; *logits_out = cur; }
-    else {
-        const SegLayerDef& d = k_seg_layers[25];
-        HIPCHK(c, k_segnet_conv_argmax(cur, g->w[25], g->scale[25], g->shift[25], g->labels, nb, d.h, d.w, g->cinp[25], d.cout, s));
-    }
-    return SSM_OK;
-}
-static int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags)
-{
-    int r = seg_init(c); if (r) return r;
-    SegNetState* g = c->seg;
-    for (int l = 0; l < SEG_LAYERS; l++) if (!g->set[l]) FAIL(c, SSM_E_INVAL, "SegNet layer " + std::to_string(l) + " has no weights (ssm_segnet_set_layer)");
-    const int W = c->g.W, H = c->g.H; hipStream_t s = c->stream;
-    for (int f0 = 0; f0 < n; f0 += g->batch) {
-        const int nb = n - f0 < g->batch ? n - f0 : g->batch;
-        HIPCHK(c, k_segnet_prep(bgr + (size_t)f0 * W * H * 3, nb, W, H, SEG_NW, SEG_NH, g->pre_xofs, g->pre_xa, g->pre_yofs, g->pre_ya, g->actA, s));
-        if (flags & 4) {                           // keep the class logits (ssm_segnet_forward / ssm_segnet_logits): separate ArgMax kernel
-            void* logits = nullptr;
-            r = seg_forward_core(c, nb, &logits); if (r) return r;
-            g->last_logits = logits;               // frame f0 of the last sub-batch starts the buffer
-            HIPCHK(c, k_segnet_argmax(logits, nb, SEG_NW * SEG_NH, g->coutstore[SEG_LAYERS - 1], SEG_NCLS, g->labels, s));
-        } else {
-            r = seg_forward_core(c, nb, nullptr); if (r) return r;
-            g->last_logits = nullptr;
-        }
-        if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net + (size_t)f0 * SEG_NW * SEG_NH, g->labels, (size_t)nb * SEG_NW * SEG_NH, hipMemcpyDeviceToDevice, s));
-        if (sem_bgr) HIPCHK(c, k_segnet_color(g->labels, nb, SEG_NW, SEG_NH, W, H, g->post_xofs, g->post_xa, g->post_yofs, g->post_ya,
-                                              !(flags & 2), flags & 1, sem_bgr + (size_t)f0 * W * H * 3, nullptr, s));
-    }
-    return SSM_OK;
-}
-extern "C" int ssm_segnet_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!bgr || n < 0) FAIL(c, SSM_E_INVAL, "bad arguments");
-    return seg_forward_dev(c, bgr, n, labels_net, sem_bgr, flags);
-}
-extern "C" int ssm_segnet_forward(ssm_ctx* c, const uint8_t* bgr, int w, int h, int stride, uint8_t* labels_net, uint8_t* sem_bgr)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!bgr) FAIL(c, SSM_E_INVAL, "null argument");
-    if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
-    if (stride < w * 3) FAIL(c, SSM_E_INVAL, "stride smaller than a row");
-    HIPCHK(c, hipMemcpy2DAsync(c->d_in_img, (size_t)w * 3, bgr, stride, (size_t)w * 3, h, hipMemcpyHostToDevice, c->stream));
-    int r = ensure_scratch(c, (size_t)SEG_NW * SEG_NH); if (r) return r;
-    r = seg_forward_dev(c, c->d_in_img, 1, labels_net ? (uint8_t*)c->d_scratch : nullptr, sem_bgr ? c->d_in_sem : nullptr, 4); if (r) return r;
-    if (labels_net) HIPCHK(c, hipMemcpyAsync(labels_net, c->d_scratch, (size_t)SEG_NW * SEG_NH, hipMemcpyDeviceToHost, c->stream));
-    if (sem_bgr) HIPCHK(c, hipMemcpyAsync(sem_bgr, c->d_in_sem, (size_t)w * h * 3, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* in, int H, int W, uint16_t* out, uint8_t* code)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!in || !out || H < 1 || W < 1 || (size_t)H * W > (size_t)SEG_NW * SEG_NH) FAIL(c, SSM_E_INVAL, "bad arguments");
-    int r = seg_init(c); if (r) return r;
-    SegNetState* g = c->seg; hipStream_t s = c->stream;
-    const int PH = (H + 1) / 2, PW = (W + 1) / 2;
-    if (op == 0) {
-        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg]) FAIL(c, SSM_E_INVAL, "layer not set");
-        // host tensors are NHWC with channels padded to 16; the device layout is [C/32][H][W][32]
-        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15;
-        std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)H * W * g->coutstore[arg]);
-        if (g->cinp[arg] == 8) { for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < k_seg_layers[arg].cin; ch++) hin[p * 8 + ch] = in[p * ci16 + ch]; }
-        else for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
-        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, arg != SEG_LAYERS - 1, s));
-        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < co16; ch++) out[p * co16 + ch] = hout[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32];
-    } else if (op == 1 || op == 2) {
-        const int C = arg;
-        if (C < 32 || C > 512 || (C & 31) || !code) FAIL(c, SSM_E_INVAL, "channel count must be a multiple of 32 (the activation chunk)");
-        r = ensure_scratch(c, (size_t)PH * PW * C); if (r) return r;
-        uint8_t* dcode = (uint8_t*)c->d_scratch;
-        // host NHWC <-> device [C/32][h][w][32]; the arg-max codes use the same element order as the pooled tensor
-        auto to_dev = [&](const uint16_t* src, int hh, int ww, std::vector<uint16_t>& d) { d.assign((size_t)hh * ww * C, 0); for (size_t p = 0; p < (size_t)hh * ww; p++) for (int ch = 0; ch < C; ch++) d[((size_t)(ch / 32) * hh * ww + p) * 32 + ch % 32] = src[p * C + ch]; };
-        auto to_host = [&](const std::vector<uint16_t>& d, int hh, int ww, uint16_t* dst) { for (size_t p = 0; p < (size_t)hh * ww; p++) for (int ch = 0; ch < C; ch++) dst[p * C + ch] = d[((size_t)(ch / 32) * hh * ww + p) * 32 + ch % 32]; };
-        std::vector<uint16_t> hin, hout; std::vector<uint8_t> hcode((size_t)PH * PW * C);
-        if (op == 1) {
-            to_dev(in, H, W, hin); hout.resize((size_t)PH * PW * C);
-            HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-            HIPCHK(c, k_segnet_pool(g->actA, 1, H, W, C, g->actB, dcode, s));
-            HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(hcode.data(), dcode, hcode.size(), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            to_host(hout, PH, PW, out);
-            for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < C; ch++) code[p * C + ch] = hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
-        } else {
-            to_dev(in, PH, PW, hin); hout.resize((size_t)H * W * C);
-            for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < C; ch++) hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = code[p * C + ch];
-            HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(dcode, hcode.data(), hcode.size(), hipMemcpyHostToDevice, s));
-            HIPCHK(c, k_segnet_unpool(g->actA, dcode, 1, PH, PW, C, g->actB, H, W, s));
-            HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            to_host(hout, H, W, out);
-        }
-    } else if (op == 3) {                 // conv + BN + ReLU + max-pool of layer `arg` as the network runs it (one kernel)
-        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || g->cinp[arg] == 8) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused conv+pool kernel takes");
-        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15, cs = g->coutstore[arg];
-        std::vector<uint16_t> hin((size_t)H * W * g->cinp[arg], 0), hout((size_t)PH * PW * cs);
-        std::vector<uint8_t> hcode((size_t)PH * PW * cs);
-        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
-        r = ensure_scratch(c, hcode.size()); if (r) return r;
-        uint8_t* dcode = (uint8_t*)c->d_scratch;
-        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(c, k_segnet_conv_pool(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, dcode, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, s));
-        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(hcode.data(), dcode, hcode.size(), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < co16; ch++) {
-            out[p * co16 + ch] = hout[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
-            code[p * co16 + ch] = hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32];
-        }
-    } else if (op == 4) {                 // un-pool (in = pooled PH x PW image of the layer's input channels, code = its arg-max codes) + conv + BN + ReLU of layer `arg`, one kernel
-        if (arg < 0 || arg >= SEG_LAYERS || !g->set[arg] || !code || g->cinp[arg] == 8) FAIL(c, SSM_E_INVAL, "layer not set, or not one the fused un-pool + conv kernel takes");
-        if (!k_segnet_conv_unpool_available()) FAIL(c, SSM_E_INVAL, "the selected conv kernel (SSM_CONV_VARIANT) has no un-pool-on-load form");
-        const int ci16 = (k_seg_layers[arg].cin + 15) & ~15, co16 = (k_seg_layers[arg].cout + 15) & ~15, cs = g->coutstore[arg], cip = g->cinp[arg];
-        std::vector<uint16_t> hin((size_t)PH * PW * cip, 0), hout((size_t)H * W * cs);
-        std::vector<uint8_t> hcode((size_t)PH * PW * cip, 0);
-        for (size_t p = 0; p < (size_t)PH * PW; p++) for (int ch = 0; ch < ci16; ch++) {
-            hin[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = in[p * ci16 + ch];
-            hcode[((size_t)(ch / 32) * PH * PW + p) * 32 + ch % 32] = code[p * ci16 + ch];
-        }
-        r = ensure_scratch(c, hcode.size()); if (r) return r;
-        uint8_t* dcode = (uint8_t*)c->d_scratch;
-        HIPCHK(c, k_segnet_begin(s));
-        HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(dcode, hcode.data(), hcode.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(c, k_segnet_conv_unpool(g->actA, dcode, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, cip, k_seg_layers[arg].cout, s));
-        HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < co16; ch++) out[p * co16 + ch] = hout[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32];
-    } else FAIL(c, SSM_E_INVAL, "unknown op");
-    HIPCHK(c, hipStreamSynchronize(s));
-    return SSM_OK;
-}
-extern "C" int ssm_segnet_logits(ssm_ctx* c, float* out)
-{
-    if (!c || !out) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!c->seg) FAIL(c, SSM_E_INVAL, "no forward has run");
-    if (!c->seg->last_logits) FAIL(c, SSM_E_INVAL, "no forward has run");
-    const int cs = c->seg->coutstore[SEG_LAYERS - 1];
-    std::vector<uint16_t> h((size_t)SEG_NW * SEG_NH * cs);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h.data(), c->seg->last_logits, h.size() * 2, hipMemcpyDeviceToHost));
-    for (size_t p = 0; p < (size_t)SEG_NW * SEG_NH; p++)
-        for (int k = 0; k < SEG_NCLS; k++) { _Float16 v; memcpy(&v, &h[p * cs + k], 2); out[p * SEG_NCLS + k] = (float)v; }
-    return SSM_OK;
-}
-
-
-// ---------------------------------------------------------------- stereo path: QuadFeatureMatch, StereoSGBM depth, VisualOdometryStereo
-static void stereo_free(StereoState* q)
-{
-    void* p[] = { q->pyr, q->der, q->gw.eig, q->gw.cand_at, q->gw.cand_bits, q->gw.keys, q->gw.kept, q->gw.deps, q->gw.depn, q->gw.state, q->gw.maxord, q->gw.count, q->gw.nkept, q->overflow, q->sg_fail, q->ncorner, q->has_prev, q->pts, q->status, q->err,
-                  q->tr_all, q->vcount, q->rand_off, q->consumed, q->sg_wsN[0], q->dminN[0], q->sg_wsN[1], q->dminN[1], q->sg_wsN[2], q->dminN[2], q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr,
-                  q->inliers, q->vo_result, q->in_stage };
-    for (void* x : p) if (x) hipFree(x);
-}
-// exact: the row stride of the sequence outputs is max_corners, so the sequence path wants exactly that many; the per-call entry points take any workspace that is large enough
-static int stereo_init(ssm_ctx* c, int w, int h, int maxc, bool exact = false)
-{
-    if (c->stereo && c->stereo->w == w && c->stereo->h == h && (exact ? c->stereo->maxc == maxc : c->stereo->maxc >= maxc)) return SSM_OK;
-    if (w < 4 || h < 2 || w > 4096 || h > 4096) FAIL(c, SSM_E_INVAL, "stereo path: image size must be at most 4096 x 4096");
-    if (maxc < 1 || maxc > 32767) FAIL(c, SSM_E_INVAL, "max_corners must be 1..32767");
-    if (c->stereo) { hipDeviceSynchronize(); stereo_free(c->stereo); delete c->stereo; c->stereo = nullptr; }
-    StereoState* q = new StereoState(); c->stereo = q;
-    q->w = w; q->h = h; q->maxc = maxc; q->B = c->stereo_B;
-    const int B = q->B;
-    QuadBatch& b = q->qb;
-    int off = 0;
-    for (int l = 0; l < 4; l++) { b.w[l] = l ? (b.w[l-1] + 1) / 2 : w; b.h[l] = l ? (b.h[l-1] + 1) / 2 : h; b.off[l] = off; off += b.w[l] * b.h[l]; off = (off + 15) & ~15; }
-    b.slot_elems = (size_t)off; b.B1 = B + 1;
-    DALLOC(c, q->pyr, (size_t)2 * b.B1 * b.slot_elems); DALLOC(c, q->der, (size_t)2 * b.B1 * b.slot_elems * 2);
-    b.pyr = q->pyr; b.der = q->der;
-    const size_t np = (size_t)w * h;
-    q->keycap = w * h / 4 + 1024;                            // 3x3 local maxima: at most one per 2x2 pixels
-    GfttWork& g = q->gw; g.cap = q->keycap;
-    DALLOC(c, g.eig, (size_t)B * np); DALLOC(c, g.cand_at, (size_t)B * np); DALLOC(c, g.keys, (size_t)B * q->keycap); DALLOC(c, g.kept, (size_t)B * q->keycap);
-    DALLOC(c, g.deps, (size_t)B * q->keycap * k_quad_gftt_deps_per_candidate()); DALLOC(c, g.depn, (size_t)B * q->keycap); DALLOC(c, g.state, (size_t)B * q->keycap);
-    HIPCHK(c, hipMemset(g.cand_at, 0, (size_t)B * np * 4));      // gftt_finish_kernel keeps the map zeroed between calls
-    DALLOC(c, g.cand_bits, (size_t)B * k_quad_gftt_bits_words(w, h));
-    DALLOC(c, g.maxord, B); DALLOC(c, g.count, B); DALLOC(c, g.nkept, B); DALLOC(c, q->overflow, 1); DALLOC(c, q->sg_fail, SG_FAIL_WORDS); DALLOC(c, q->ncorner, B); DALLOC(c, q->has_prev, B);
-    g.overflow = q->overflow;
-    HIPCHK(c, hipMemset(q->overflow, 0, 4));
-    HIPCHK(c, hipMemset(q->sg_fail, 0, 4 * SG_FAIL_WORDS));
-    DALLOC(c, q->pts, (size_t)5 * B * maxc * 2); DALLOC(c, q->status, maxc); DALLOC(c, q->err, maxc);
-    DALLOC(c, q->rand_off, B); DALLOC(c, q->consumed, 1);
-    return SSM_OK;
-}
-static int stereo_ensure_seq(ssm_ctx* c, int n)
-{
-    StereoState* q = c->stereo;
-    if (n <= q->seq_cap) return SSM_OK;
-    HIPCHK(c, hipDeviceSynchronize());
-    void* olds[] = { q->quad, q->nquad, q->corners, q->ncorners, q->disp, q->depth, q->tr, q->inliers, q->vo_result };
-    for (void* p : olds) if (p) hipFree(p);
-    q->quad = nullptr; q->nquad = nullptr; q->corners = nullptr; q->ncorners = nullptr; q->disp = nullptr; q->depth = nullptr; q->tr = nullptr; q->inliers = nullptr; q->vo_result = nullptr;
-    q->seq_cap = 0;
-    const size_t np = (size_t)q->w * q->h;
-    DALLOC(c, q->quad, (size_t)n * q->maxc); DALLOC(c, q->nquad, n); DALLOC(c, q->corners, (size_t)n * q->maxc * 2); DALLOC(c, q->ncorners, n);
-    DALLOC(c, q->disp, (size_t)n * np); DALLOC(c, q->depth, (size_t)n * np);
-    DALLOC(c, q->tr, (size_t)n * 6); DALLOC(c, q->inliers, (size_t)n * q->maxc); DALLOC(c, q->vo_result, (size_t)n * 2);
-    q->seq_cap = n;
-    return SSM_OK;
-}
-static int stereo_ensure_vo(ssm_ctx* c, int iters)
-{
-    StereoState* q = c->stereo;
-    if (iters <= q->vo_iters) return SSM_OK;
-    HIPCHK(c, hipDeviceSynchronize());
-    if (q->tr_all) hipFree(q->tr_all); if (q->vcount) hipFree(q->vcount);
-    q->tr_all = nullptr; q->vcount = nullptr; q->vo_iters = 0;
-    DALLOC(c, q->tr_all, (size_t)q->B * iters * 6); DALLOC(c, q->vcount, (size_t)q->B * iters);
-    q->vo_iters = iters;
-    return SSM_OK;
-}
-static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, int which = 0)
-{
-    StereoState* q = c->stereo;
-    const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
-    void*& ws = q->sg_wsN[which]; size_t& have = q->sg_ws_bytesN[which];
-    if (!q->dminN[which]) DALLOC(c, q->dminN[which], 128);
-    if (need <= have) return SSM_OK;
-    HIPCHK(c, hipDeviceSynchronize());
-    if (ws) hipFree(ws);
-    ws = nullptr; have = 0;
-    uint8_t* p8; int r = dalloc(c, &p8, need); if (r) return r;
-    ws = p8; have = need;
-    return SSM_OK;
-}
-static int sgbm_check_params(ssm_ctx* c, const ssm_sgbm_params* params, int w, int h)
-{
-    if (!params) FAIL(c, SSM_E_INVAL, "null SGBM parameters");
-    const int D = params->numberOfDisparities, SW = params->SADWindowSize > 0 ? params->SADWindowSize : 5;
-    if (D <= 0 || D % 16 || D > 128 || D / 16 == 7) FAIL(c, SSM_E_INVAL, "numberOfDisparities must be 16, 32, 48, 64, 80, 96 or 128");
-    if (!(SW & 1) || h <= SW || w <= SW) FAIL(c, SSM_E_INVAL, "SADWindowSize must be odd and smaller than the image");
-    if ((long long)w * h >= (1ll << 30)) FAIL(c, SSM_E_INVAL, "image too large");
-    { int tx; size_t lds; if (!sgbm_cost_geometry(D, SW, &tx, &lds)) FAIL(c, SSM_E_INVAL, "SADWindowSize too large for this numberOfDisparities (the cost kernel keeps SADWindowSize rows of 4 columns x D sums in LDS)"); }
-    return SSM_OK;
-}
-// the sequence path on device images; the caller holds the context lock
-static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out)
-{
-    const int n = in->n, w = in->w, h = in->h;
-    const int stages = in->stages ? in->stages : (SSM_STEREO_QUAD | SSM_STEREO_DEPTH | SSM_STEREO_VO);
-    if (n < 0 || !in->left || !in->right) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if ((stages & SSM_STEREO_VO) && !(stages & SSM_STEREO_QUAD)) FAIL(c, SSM_E_INVAL, "SSM_STEREO_VO needs SSM_STEREO_QUAD");
-    if ((stages & SSM_STEREO_VO) && (in->ransac_iters < 0 || (in->ransac_iters > 0 && !in->rand_stream))) FAIL(c, SSM_E_INVAL, "the VO stage needs rand_stream (n * ransac_iters * 3 draws)");
-    const int maxc = in->max_corners > 0 ? in->max_corners : 1000;
-    if ((stages & SSM_STEREO_QUAD) && (w < 32 || h < 32)) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
-    int r = stereo_init(c, w, h, maxc, true); if (r) return r;
-    StereoState* q = c->stereo;
-    if (stages & SSM_STEREO_DEPTH) { r = sgbm_check_params(c, &in->sgbm, w, h); if (r) return r; }
-    r = stereo_ensure_seq(c, n > 0 ? n : 1); if (r) return r;
-    if (stages & SSM_STEREO_VO) { r = stereo_ensure_vo(c, in->ransac_iters > 0 ? in->ransac_iters : 1); if (r) return r; }
-    const int B = q->B;
-    if (stages & SSM_STEREO_DEPTH) { r = stereo_ensure_sgbm(c, in->sgbm, n < B ? (n > 0 ? n : 1) : B); if (r) return r; }
-    const size_t np = (size_t)w * h;
-    const QuadBatch& qb = q->qb;
-    hipStream_t sq = c->stream, sd = c->stream;
-    // the quad matcher + VO chain (many small latency-bound kernels) and SGBM (volume kernels) of a sub-batch share nothing but the input images:
-    // SGBM runs on the second context stream beside the chain; sub-batches follow each other on both streams without a join in between
-    const bool two = (stages & SSM_STEREO_DEPTH) && (stages & SSM_STEREO_QUAD) && !c->serialize;
-    if (two) { r = ensure_side_streams(c); if (r) return r; sd = c->stream2; HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(sd, c->ev_fork, 0)); }
-    // ... and with more than one sub-batch SGBM alternates between TWO streams with a workspace each: the cost kernel and the small kernels of one
-    // sub-batch (LDS / latency-bound) run beside the scan-direction and winner-takes-all kernels of the other (HBM-bound)
-    const int nsub = (n + B - 1) / B;
-    const int nsg = two ? (c->stereo_sgbm_streams < nsub ? c->stereo_sgbm_streams : nsub) : 1;
-    hipStream_t sgs[3] = {sd, two ? c->stream3 : sd, two ? c->stream4 : sd};
-    for (int k = 1; k < nsg; k++) { r = stereo_ensure_sgbm(c, in->sgbm, B, k); if (r) return r; HIPCHK(c, hipStreamWaitEvent(sgs[k], c->ev_fork, 0)); }
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
-    const bool prev0 = in->continue_sequence && q->have_prev;
-    if (stages & SSM_STEREO_VO) HIPCHK(c, hipMemsetAsync(q->consumed, 0, 4, sq));
-    for (int f0 = 0; f0 < n; f0 += B) {
-        const int nb = n - f0 < B ? n - f0 : B;
-        if (stages & SSM_STEREO_QUAD) {
-            prof_begin(c, "quad_track");
-            // level 0 of the nb frames into slots 1 .. nb of both sides, then the pyramids and derivatives
-            HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(0 * qb.B1 + 1) * qb.slot_elems, qb.slot_elems, in->left + (size_t)f0 * np, np, np, nb, hipMemcpyDeviceToDevice, sq));
-            HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(1 * qb.B1 + 1) * qb.slot_elems, qb.slot_elems, in->right + (size_t)f0 * np, np, np, nb, hipMemcpyDeviceToDevice, sq));
-            HIPCHK(c, k_quad_pyramids(qb, nb, sq));
-            HIPCHK(c, hipMemsetAsync(q->has_prev, 1, 4 * (size_t)nb, sq));                      // non-zero = true
-            if (f0 == 0 && !prev0) HIPCHK(c, hipMemsetAsync(q->has_prev, 0, 4, sq));
-            HIPCHK(c, k_quad_gftt(qb, nb, maxc, 0.04, 8.0, q->gw, q->pts, maxc, q->ncorner, sq));      // quadmatcher.cpp:301-308
-            HIPCHK(c, k_quad_track(qb, nb, q->pts, maxc, q->ncorner, q->has_prev, q->quad + (size_t)f0 * maxc, q->nquad + f0, sq));
-            HIPCHK(c, hipMemcpyAsync(q->corners + (size_t)f0 * maxc * 2, q->pts, (size_t)nb * maxc * 8, hipMemcpyDeviceToDevice, sq));
-            HIPCHK(c, hipMemcpyAsync(q->ncorners + f0, q->ncorner, (size_t)nb * 4, hipMemcpyDeviceToDevice, sq));
-            // carry: the last frame of the sub-batch becomes slot 0 (images and derivatives, both sides)
-            for (int side = 0; side < 2; side++) {
-                HIPCHK(c, hipMemcpyAsync(q->pyr + (size_t)(side * qb.B1) * qb.slot_elems, q->pyr + (size_t)(side * qb.B1 + nb) * qb.slot_elems, qb.slot_elems, hipMemcpyDeviceToDevice, sq));
-                HIPCHK(c, hipMemcpyAsync(q->der + (size_t)(side * qb.B1) * qb.slot_elems * 2, q->der + (size_t)(side * qb.B1 + nb) * qb.slot_elems * 2, qb.slot_elems * 4, hipMemcpyDeviceToDevice, sq));
-            }
-            prof_end(c);
-        }
-        if (stages & SSM_STEREO_VO) {
-            prof_begin(c, "vo");
-            HIPCHK(c, k_vo_estimate_batch(q->quad + (size_t)f0 * maxc, maxc, q->nquad + f0, nb, in->vo, in->rand_stream, in->ransac_iters, q->consumed, q->rand_off,
-                                          q->tr_all, q->vcount, q->tr + (size_t)f0 * 6, q->inliers + (size_t)f0 * maxc, q->vo_result + (size_t)f0 * 2, sq));
-            prof_end(c);
-        }
-        if (stages & SSM_STEREO_DEPTH) {
-            const int alt = (f0 / B) % nsg;
-            hipStream_t sg = sgs[alt];
-            struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
-            prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail + (f0 / B) % SG_FAIL_WORDS,
-                             c->sgbm_form_cfg, nsg));
-            HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dminN[alt], q->depth + (size_t)f0 * np, sg));
-            prof_end(c);
-        }
-    }
-    if (two) { HIPCHK(c, hipEventRecord(c->ev_join, sd)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
-    if (nsg > 1) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
-    if (nsg > 2) { HIPCHK(c, hipEventRecord(c->ev_join4, c->stream4)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0)); }
-    if (n > 0) q->have_prev = (stages & SSM_STEREO_QUAD) != 0;
-    q->sg_pending.valid = (stages & SSM_STEREO_DEPTH) && n > 0;
-    if (q->sg_pending.valid) { q->sg_pending.in = *in; q->sg_pending.B = B; }
-    if (out) {
-        out->quad = q->quad; out->nquad = q->nquad; out->corners = q->corners; out->ncorners = q->ncorners; out->disp = q->disp; out->depth = q->depth;
-        out->tr = q->tr; out->inliers = q->inliers; out->vo_result = q->vo_result; out->rand_draws_used = q->consumed; out->max_corners = maxc;
-    }
-    return SSM_OK;
-}
-extern "C" int ssm_stereo_batch(const ssm_ctx* c) { return c ? c->stereo_B : 0; }
-extern "C" int ssm_stereo_seq_process(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!in) FAIL(c, SSM_E_INVAL, "null argument");
-    return stereo_seq_run(c, in, out);
-}
-// host images -> packed device staging: slot k of the staging area holds image k ([h][w] bytes each); through pinned memory (a pageable copy of a
-// 1241x376 image costs ~1 ms)
-static int stereo_stage_images(ssm_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, uint8_t** dev_out)
-{
-    StereoState* q = c->stereo;
-    const size_t np = (size_t)w * h;
-    int r = ensure_pinned(c, np * 6 > (size_t)nimg * np ? np * 6 : (size_t)nimg * np); if (r) return r;
-    if ((size_t)nimg * np > q->in_stage_bytes) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (q->in_stage) hipFree(q->in_stage);
-        q->in_stage = nullptr; q->in_stage_bytes = 0;
-        DALLOC(c, q->in_stage, (size_t)4 * np); q->in_stage_bytes = (size_t)4 * np;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));               // the previous call's copies out of the staging buffer are done
-    for (int k = 0; k < nimg; k++)
-        for (int y = 0; y < h; y++) memcpy(c->h_pinned + (size_t)k * np + (size_t)y * w, imgs[k] + (size_t)y * stride, w);
-    HIPCHK(c, hipMemcpyAsync(q->in_stage, c->h_pinned, (size_t)nimg * np, hipMemcpyHostToDevice, c->stream));
-    *dev_out = q->in_stage;
-    return SSM_OK;
-}
-extern "C" int ssm_quad_track(ssm_ctx* c, const uint8_t* lc, const uint8_t* rc, const uint8_t* lp, const uint8_t* rp, int w, int h, int stride,
-                              int max_corners, ssm_pmatch* out, int cap, int* n_out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!lc || !rc || !lp || !rp || !n_out || stride < w || max_corners < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
-    int r = stereo_init(c, w, h, max_corners, true); if (r) return r;
-    // a two-frame sequence: frame 0 = the previous pair, frame 1 = the current pair (left images first, then the right ones)
-    const uint8_t* imgs[4] = { lp, lc, rp, rc };
-    uint8_t* dev = nullptr;
-    r = stereo_stage_images(c, imgs, 4, w, h, stride, &dev); if (r) return r;
-    ssm_stereo_frames_dev in; memset(&in, 0, sizeof(in));
-    in.left = dev; in.right = dev + (size_t)2 * w * h; in.n = 2; in.w = w; in.h = h; in.stages = SSM_STEREO_QUAD; in.max_corners = max_corners;
-    ssm_stereo_out_dev o;
-    r = stereo_seq_run(c, &in, &o); if (r) return r;
-    c->stereo->have_prev = false;                                // a per-pair call is not part of a sequence
-    int m = 0;
-    HIPCHK(c, hipMemcpyAsync(&m, o.nquad + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    r = check_device_flags(c, false); if (r) return r;
-    *n_out = m;
-    if (m > cap) FAIL(c, SSM_E_CAPACITY, "pmatch buffer too small (need " + std::to_string(m) + ")");
-    if (m > 0) HIPCHK(c, hipMemcpy(out, o.quad + o.max_corners, (size_t)m * sizeof(ssm_pmatch), hipMemcpyDeviceToHost));
-    return SSM_OK;
-}
-extern "C" int ssm_gftt(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int max_corners, double quality, double min_distance,
-                        float* pts, int cap, int* n_out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!img || !pts || !n_out || stride < w || max_corners < 1 || !(min_distance >= 1.0)) FAIL(c, SSM_E_INVAL, "bad arguments (max_corners >= 1, min_distance >= 1)");
-    if (min_distance > 64.0) FAIL(c, SSM_E_INVAL, "min_distance must be <= 64");
-    if (w < 32 || h < 32) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
-    if (max_corners > 32767) FAIL(c, SSM_E_INVAL, "max_corners must be <= 32767");
-    int r = stereo_init(c, w, h, max_corners); if (r) return r;
-    StereoState* q = c->stereo; const QuadBatch& qb = q->qb;
-    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)1 * qb.slot_elems, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));        // side 0, slot 1, level 0
-    HIPCHK(c, k_quad_gftt(qb, 1, max_corners, quality, min_distance, q->gw, q->pts, q->maxc, q->ncorner, c->stream));
-    int n = 0;
-    HIPCHK(c, hipMemcpyAsync(&n, q->ncorner, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    r = check_device_flags(c, false); if (r) return r;
-    *n_out = n;
-    if (n > cap) FAIL(c, SSM_E_CAPACITY, "point buffer too small");
-    if (n) HIPCHK(c, hipMemcpy(pts, q->pts, (size_t)n * 8, hipMemcpyDeviceToHost));
-    return SSM_OK;
-}
-extern "C" int ssm_lk_track(ssm_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
-                            float* next_pts, uint8_t* status, float* err, int max_count, double epsilon, double min_eig_threshold)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!prev || !next || n < 0 || (n && (!prev_pts || !next_pts)) || stride < w || max_count < 1) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if (n == 0) return SSM_OK;
-    if (w < 32 || h < 32) FAIL(c, SSM_E_INVAL, "quad matcher: image size must be 32..4096");
-    int r = stereo_init(c, w, h, n > 1000 ? n : 1000); if (r) return r;
-    StereoState* q = c->stereo; const QuadBatch& qb = q->qb;
-    // previous image = (side 0, slot 1), next image = (side 1, slot 1)
-    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)1 * qb.slot_elems, w, prev, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpy2DAsync(q->pyr + (size_t)(qb.B1 + 1) * qb.slot_elems, w, next, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, k_quad_pyramids(qb, 1, c->stream));
-    float* d_in = q->pts; float* d_out = q->pts + (size_t)2 * q->maxc;
-    HIPCHK(c, hipMemcpyAsync(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, k_quad_lk(qb, d_in, n, d_out, q->status, q->err, max_count, (float)(epsilon * epsilon), (float)min_eig_threshold, c->stream));
-    HIPCHK(c, hipMemcpyAsync(next_pts, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    if (status) HIPCHK(c, hipMemcpyAsync(status, q->status, n, hipMemcpyDeviceToHost, c->stream));
-    if (err) HIPCHK(c, hipMemcpyAsync(err, q->err, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stereo->have_prev = false;
-    return SSM_OK;
-}
-extern "C" int ssm_window_match(ssm_ctx* c, const float* kp1, const uint8_t* d1, int n1, const float* kp2, const uint8_t* d2, int n2,
-                                int search_width, int search_height, float distance_threshold, ssm_dmatch* out)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n1 < 0 || n2 < 0 || (n1 && (!kp1 || !d1 || !out)) || (n2 && (!kp2 || !d2))) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if (n1 == 0) return SSM_OK;
-    const size_t a1 = ((size_t)n1 * 8 + 255) & ~(size_t)255, a2 = ((size_t)n2 * 8 + 255) & ~(size_t)255, b1 = ((size_t)n1 * 32 + 255) & ~(size_t)255, b2 = ((size_t)n2 * 32 + 255) & ~(size_t)255;
-    int r = ensure_scratch(c, a1 + a2 + b1 + b2 + (size_t)n1 * 16 + 256); if (r) return r;
-    uint8_t* p = (uint8_t*)c->d_scratch;
-    float* dk1 = (float*)p; p += a1; float* dk2 = (float*)p; p += a2; uint8_t* dd1 = p; p += b1; uint8_t* dd2 = p; p += b2; ssm_dmatch* dm = (ssm_dmatch*)p;
-    HIPCHK(c, hipMemcpyAsync(dk1, kp1, (size_t)n1 * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
-    if (n2) { HIPCHK(c, hipMemcpyAsync(dk2, kp2, (size_t)n2 * 8, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream)); }
-    HIPCHK(c, k_quad_window_match(dk1, dd1, n1, dk2, dd2, n2, search_width, search_height, distance_threshold, dm, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out, dm, (size_t)n1 * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SSM_OK;
-}
-
-// ---------------------------------------------------------------- depth from stereo (cv::StereoSGBM + FrameReader's conversion)
-extern "C" void ssm_sgbm_params_default(ssm_sgbm_params* p)
-{
-    if (!p) return;
-    p->minDisparity = 0; p->numberOfDisparities = 80; p->SADWindowSize = 11; p->P1 = 4 * 11 * 11; p->P2 = 32 * 11 * 11;       // src/stereo.cpp:16-27
-    p->disp12MaxDiff = 1; p->preFilterCap = 63; p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32;
-}
-// one host pair through the batched kernels (nb = 1): images staged on the device, disparity (and depth) left in the sequence output buffers
-static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage,
-                    int16_t** d_disp_out, uint16_t** d_depth_out, int form)
-{
-    if (!left || !right || !params || w < 3 || h < 1 || stride < w) FAIL(c, SSM_E_INVAL, "bad arguments");
-    int r = sgbm_check_params(c, params, w, h); if (r) return r;
-    r = stereo_init(c, w, h, c->stereo && c->stereo->w == w && c->stereo->h == h ? c->stereo->maxc : 1000); if (r) return r;
-    r = stereo_ensure_seq(c, 1); if (r) return r;
-    r = stereo_ensure_sgbm(c, *params, 1); if (r) return r;
-    StereoState* q = c->stereo;
-    const uint8_t* imgs[2] = { left, right };
-    uint8_t* dev = nullptr;
-    r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
-    prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream, q->sg_fail, form, 1));
-    prof_end(c);
-    q->sg_pending.valid = false;                                  // (the staged pair is this call's: the host-pointer entry points repeat a timed-out sweep themselves)
-    *d_disp_out = q->disp; *d_depth_out = q->depth;
-    return SSM_OK;
-}
-// cv::StereoSGBM cannot fail (src/stereo.cpp:11-30); form 2's sweep can: its strips wait for each other, and when a hand-off exceeds its spin bound every block
-// leaves mid-image with the sub-batch's fail word set.  Called with the streams drained: every sub-batch of the last sequence call whose word is set is computed again
-// with form 1 (independent paths, no cross-block waits; the workspace holds its volumes anyway) from the caller's input images, so that the call's disparities and depths
-// are the oracle's after all.  Reported through ssm_last_error (a note, the call succeeds) and counted in sgbm_fallbacks.
-static int sgbm_recover(ssm_ctx* c)
-{
-    StereoState* q = c->stereo;
-    int32_t sf[SG_FAIL_WORDS];
-    HIPCHK(c, hipMemcpy(sf, q->sg_fail, sizeof(sf), hipMemcpyDeviceToHost));
-    bool any = false; for (int k = 0; k < SG_FAIL_WORDS; k++) any = any || sf[k] != 0;
-    if (!any) return SSM_OK;
-    HIPCHK(c, hipMemset(q->sg_fail, 0, sizeof(sf)));
-    if (!q->sg_pending.valid) FAIL(c, SSM_E_HIP, "SGBM sweep: a strip hand-off timed out and the call that launched it is no longer known (the disparities are incomplete)");
-    const ssm_stereo_frames_dev& in = q->sg_pending.in; const int B = q->sg_pending.B, w = q->w, h = q->h; const size_t np = (size_t)w * h;
-    int redone = 0;
-    for (int f0 = 0, bi = 0; f0 < in.n; f0 += B, bi++) {
-        if (!sf[bi % SG_FAIL_WORDS]) continue;
-        const int nb = in.n - f0 < B ? in.n - f0 : B;
-        HIPCHK(c, k_sgbm(in.left + (size_t)f0 * np, in.right + (size_t)f0 * np, w, h, nb, in.sgbm, q->sg_wsN[0], q->disp + (size_t)f0 * np, 0, c->stream, q->sg_fail + bi % SG_FAIL_WORDS, 1, 1));
-        HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in.baseline, in.cu, in.cv, in.f, in.roix, in.roiy, in.roiz, in.scale, q->dminN[0], q->depth + (size_t)f0 * np, c->stream));
-        redone++;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sgbm_fallbacks += redone;
-    c->err = "note: the SGBM sweep of " + std::to_string(redone) + " sub-batch(es) timed out in a strip hand-off; they were repeated with form 1 (results complete)";
-    return SSM_OK;
-}
-// the sweep kernel's time-out word, copied to the front of the pinned area with the results of a host-pointer call
-static bool sgbm_failed(ssm_ctx* c)
-{
-    int32_t sf; memcpy(&sf, c->h_pinned, 4);
-    if (sf) hipMemset(c->stereo->sg_fail, 0, 4);
-    return sf != 0;
-}
-extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params, int stage, int16_t* disp)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
-    int16_t* dd; uint16_t* ddepth;
-    const size_t np = (size_t)w * h;
-    for (int attempt = 0; ; attempt++) {                      // a sweep whose hand-off timed out is repeated once, in form 1 (no cross-block waits)
-        int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));      // (the staged input images at the front of the pinned area are consumed)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!sgbm_failed(c)) break;
-        if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
-        c->sgbm_fallbacks++;
-    }
-    memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
-    return SSM_OK;
-}
-extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
-                                double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
-                                uint16_t* depth, int16_t* disp)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (!depth) FAIL(c, SSM_E_INVAL, "null argument");
-    int16_t* dd; uint16_t* ddepth;
-    const size_t np = (size_t)w * h;
-    for (int attempt = 0; ; attempt++) {
-        int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
-        HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned + 4 * np, ddepth, np * 2, hipMemcpyDeviceToHost, c->stream));
-        if (disp) HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->stereo->sg_fail, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (!sgbm_failed(c)) break;
-        if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
-        c->sgbm_fallbacks++;
-    }
-    memcpy(depth, c->h_pinned + 4 * np, np * 2);
-    if (disp) memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
-    return SSM_OK;
-}
-
-// ---------------------------------------------------------------- VisualOdometryStereo::estimateMotion
-extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, const ssm_vo_params* params, const int32_t* samples, int iters,
-                               double tr[6], int32_t* inliers, int cap, int* n_inliers, int* success)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || iters < 0 || !params || !tr || !n_inliers || !success || (n && !matches) || (iters && !samples)) FAIL(c, SSM_E_INVAL, "bad arguments");
-    for (int k = 0; k < 6; k++) tr[k] = 0.0;
-    *n_inliers = 0; *success = 0;
-    if (n < 6) return SSM_OK;                                 // estimateMotion returns an empty vector (vo_stereo.cpp:61-63)
-    for (int k = 0; k < 3 * iters; k++) if (samples[k] < 0 || samples[k] >= n) FAIL(c, SSM_E_INVAL, "sample index out of range");
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_m = 0, o_s = o_m + al((size_t)n * sizeof(ssm_pmatch)), o_tr = o_s + al((size_t)iters * 12 + 16), o_cnt = o_tr + al((size_t)iters * 48 + 48),
-                 o_out = o_cnt + al((size_t)iters * 4 + 16), o_inl = o_out + 256, o_res = o_inl + al((size_t)n * 4), total = o_res + 256;
-    int r = ensure_scratch(c, total); if (r) return r;
-    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(p + o_m, matches, (size_t)n * sizeof(ssm_pmatch), hipMemcpyHostToDevice, s));
-    if (iters) HIPCHK(c, hipMemcpyAsync(p + o_s, samples, (size_t)iters * 12, hipMemcpyHostToDevice, s));
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
-    prof_begin(c, "vo");
-    HIPCHK(c, k_vo_estimate((const ssm_pmatch*)(p + o_m), n, *params, (const int32_t*)(p + o_s), iters, (double*)(p + o_tr), (int32_t*)(p + o_cnt),
-                            (double*)(p + o_out), (int32_t*)(p + o_inl), (int32_t*)(p + o_res), s));
-    prof_end(c);
-    int32_t res[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(tr, p + o_out, 48, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(res, p + o_res, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    *n_inliers = res[0]; *success = res[1];
-    if (inliers && res[0] > 0) {
-        if (res[0] > cap) FAIL(c, SSM_E_CAPACITY, "inlier buffer too small (need " + std::to_string(res[0]) + ")");
-        HIPCHK(c, hipMemcpy(inliers, p + o_inl, (size_t)res[0] * 4, hipMemcpyDeviceToHost));
-    }
-    return SSM_OK;
-}
-
-// PnPSolver::solvePnP (reference src/pnp.cpp:5-118) for one correspondence list: the block of kernels_pnp.hip that the pose chain runs per frame
-extern "C" int ssm_pnp_solve(ssm_ctx* c, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16],
-                             uint8_t* inliers, int* n_inliers, int* success)
-{
-    if (!c) return SSM_E_INVAL;
-    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    if (n < 0 || !cam || !T || !n_inliers || (n && (!img || !obj))) FAIL(c, SSM_E_INVAL, "bad arguments");
-    if (n > 65535) FAIL(c, SSM_E_CAPACITY, "at most 65535 correspondences");
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t ne = (size_t)(n > 0 ? n : 1);
-    const size_t o_img = 0, o_obj = o_img + al(ne * 8), o_T = o_obj + al(ne * 12), o_inl = o_T + 256, o_dec = o_inl + al(ne), o_le = o_dec + al(ne),
-                 o_err = o_le + al(ne * k_pnp_edge_bytes()), o_n = o_err + al(ne * 16), total = o_n + 256;
-    int r = ensure_scratch(c, total); if (r) return r;
-    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
-    if (n) { HIPCHK(c, hipMemcpyAsync(p + o_img, img, (size_t)n * 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipMemcpyAsync(p + o_obj, obj, (size_t)n * 12, hipMemcpyHostToDevice, s)); }
-    HIPCHK(c, hipMemcpyAsync(p + o_T, T, 128, hipMemcpyHostToDevice, s));
-    PnpSolveArgs a; a.img = (const float*)(p + o_img); a.obj = (const float*)(p + o_obj); a.n = n;
-    a.cam.fx = cam[0]; a.cam.fy = cam[1]; a.cam.cx = cam[2]; a.cam.cy = cam[3];
-    a.T = (double*)(p + o_T); a.inl = p + o_inl; a.dec = p + o_dec; a.ledges = (LEdge*)(p + o_le); a.err = (double2*)(p + o_err); a.n_inliers = (int32_t*)(p + o_n); a.edges_in_lds = 0;
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
-    prof_begin(c, "pnp");
-    HIPCHK(c, k_pnp_solve(a, s));
-    prof_end(c);
-    int32_t m = 0;
-    HIPCHK(c, hipMemcpyAsync(T, p + o_T, 128, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&m, p + o_n, 4, hipMemcpyDeviceToHost, s));
-    if (inliers && n) HIPCHK(c, hipMemcpyAsync(inliers, p + o_inl, (size_t)n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    *n_inliers = m;
-    if (success) *success = n > min_inliers;                   // pnp.cpp:115 tests the flag vector's LENGTH (quirk 14)
-    return SSM_OK;
-}
 
 // ---------------------------------------------------------------- utilities
 extern "C" int ssm_dev_alloc(ssm_ctx* c, size_t bytes, void** out)
