@@ -50,6 +50,10 @@ public:
         c.mapper_resolution = getData<double>("mapper_resolution", c.mapper_resolution); c.mapper_max_distance = getData<double>("mapper_max_distance", c.mapper_max_distance);
         if (has("camera.fx")) { CAMERA_INTRINSIC_PARAMETERS k = getCamera(); c.camera.cx = k.cx; c.camera.cy = k.cy; c.camera.fx = k.fx; c.camera.fy = k.fy; c.camera.scale = k.scale; }
         c.max_batch = getData<int>("ssm_max_batch", 1); c.voxel_capacity_log2 = getData<int>("ssm_voxel_capacity_log2", 20);
+        // implementation knobs a parameter file may set (0 = the library's default): where the map stops growing, the SGBM formulation / streams, stereo pairs per launch
+        c.voxel_max_capacity_log2 = getData<int>("ssm_voxel_max_capacity_log2", c.voxel_max_capacity_log2);
+        c.sgbm_form = getData<int>("ssm_sgbm_form", c.sgbm_form); c.sgbm_streams = getData<int>("ssm_sgbm_streams", c.sgbm_streams);
+        c.stereo_batch = getData<int>("ssm_stereo_batch", c.stereo_batch);
         return c;
     }
     map<string, string> data;
