@@ -47,7 +47,7 @@ def _run_block(c, lo, hi, R, halo=True):
     return res
 
 
-@pytest.mark.parametrize("n_frames,world", [(12, 2), (11, 3)])
+@pytest.mark.parametrize("n_frames,world", [(12, 2), (11, 3), (43, 8)])      # (43, 8): the rank count of BASELINE configs[4] -- eight contexts on one GPU, uneven blocks of 5 and 6 frames (a block as short as the 5-frame halo)
 def test_sharded_blocks_equal_single_gpu(n_frames, world):
     single = _ctx()
     ref = _run_block(single, 0, n_frames, single.R)
