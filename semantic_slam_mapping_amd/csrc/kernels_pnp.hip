@@ -19,6 +19,10 @@ using namespace ssm_pnp;
 #define PC_T 1024
 #define PC_SPEC 8                 // trials of a rejected streak evaluated together (pc_optimize)
 #define PC_RBUF 3072              // doubles (24 KB of LDS)
+#ifndef PC_FIRST_SPEC
+#define PC_FIRST_SPEC 2           // cluster form: trials solved and evaluated with an iteration's first trial (1 = the first trial alone).  Measured, ms of chain per 400
+                                  // frames: 1: 168.4 - 170.9, 2: 166.5, 4: 167.3, 8: 184.7 -- the candidates behind an accepted first trial are wasted work
+#endif
 // an edge as the passes read it: 24 bytes (the Edge of pnp_core.h is 72; its error lives in a separate global array).  meta = id | level << 16 | robust << 17
 struct LEdge { float X[3], u, v; uint32_t meta; };
 #define LE_LEVEL (1u << 16)
@@ -313,7 +317,9 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
         // PC_SPEC, never beyond the tenth trial) and all their estimates go through ONE pass over the edges; wave 0 then walks the results in order with lm_update --
         // the first accepted trial ends the walk (later candidates are dropped), a stop condition ends it too: the same decisions and the same numbers as one
         // trial at a time.  (round 5: a converged optimize spends its time in streaks of seven or more rejections: ~54 solve -> pass -> update rounds per frame became ~36)
-        if (threadIdx.x == 0) { sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = 1; }
+        // (the cluster form has idle waves for the algebra and for the pass -- see pc_chi_spec -- so it solves the trials that WOULD follow a rejection together with the
+        // first one: PC_FIRST_SPEC candidates; the one-block form pays for every candidate with a walk over its edges and keeps the first trial alone)
+        if (threadIdx.x == 0) { sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = CL ? PC_FIRST_SPEC : 1; }
         __syncthreads();
         for (;;) {
             const int nsp = sh.spec_n;
