@@ -288,6 +288,55 @@ __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int n
     }
     pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
 }
+// solve_ldlt of pnp_core.h by the first six lanes of a wave, ONE ROW of L each: the same operations in the same order -- lane i forms
+// s = A[i][j] - sum_k (L[i][k] L[j][k]) D[k] for every column j (lane j's s is the pivot d_j: the diagonal's formula is the off-diagonal one with i = j), divides by the
+// broadcast pivot, and the forward substitution subtracts column by column, which is each row's ascending-k order; the back substitution's order (x[i] needs x[i+1]
+// before x[i+2] ...) is a chain, so it runs uniformly on broadcast values.  15 + 6 divisions and 35 multiply-subtract terms of the scalar form become 7 and 15 wave
+// instructions: ~375 instead of ~600 on a wave that is alone on its SIMD (every instruction a ~7-clock step).  Hl / b: LDS (uniform addresses per lane); x: uniform.
+__device__ __forceinline__ double pc_lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool pc_solve_ldlt_wave(const double* Hl, double lambda, const double* b, double (&x)[6])
+{
+    const int lane = threadIdx.x & 63, i = lane < 6 ? lane : 5;
+    double arow[6], Lrow[6], D[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const int hi = i > c ? i : c, lo = i > c ? c : i;
+        const double a = Hl[hi * (hi + 1) / 2 + lo];
+        arow[c] = c == i ? a + lambda : a;
+        Lrow[c] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double sacc = arow[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) { const double Ljk = pc_lane_bcast(Lrow[k], j); sacc -= Lrow[k] * Ljk * D[k]; }
+        const double d = pc_lane_bcast(sacc, j);
+        if (!(d > 0)) return false;
+        D[j] = d;
+        Lrow[j] = sacc / d;
+    }
+    double yv = b[i];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const double yk = pc_lane_bcast(yv, k); if (i > k) yv -= Lrow[k] * yk; }
+    double Di = D[0];
+#pragma unroll
+    for (int c = 1; c < 6; c++) Di = i == c ? D[c] : Di;
+    yv = yv / Di;
+    double yu[6], Lu[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) yu[c] = pc_lane_bcast(yv, c);
+#pragma unroll
+    for (int k = 1; k < 6; k++)
+#pragma unroll
+        for (int c = 0; c < k; c++) Lu[k][c] = pc_lane_bcast(Lrow[c], k);
+#pragma unroll
+    for (int r = 5; r >= 0; r--) { double sacc = yu[r]; for (int k = r + 1; k < 6; k++) sacc -= Lu[k][r] * x[k]; x[r] = sacc; }
+    return true;
+}
 // lm_optimize of pnp_core.h.  The passes over the edges are the whole block's; the 6 x 6 algebra between them (L D L^T, exp map, Levenberg's bookkeeping)
 // is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
 // controls through LDS.
@@ -328,7 +377,7 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
                 double lam = sh.spec_lambda, nu = sh.spec_nu;
                 for (int c = 0; c < wv; c++) { lam *= nu; nu *= 2; }
                 for (int q = 0; q < 6; q++) x[q] = 0;
-                solved = solve_ldlt(Hl, lam, b, x);
+                solved = pc_solve_ldlt_wave(Hl, lam, b, x);
                 Pose Pn = sh.P;
                 pose_oplus(Pn, x);
                 if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 6; q++) sh.spec[wv].x[q] = x[q]; sh.spec[wv].P = Pn; sh.spec[wv].solved = solved ? 1 : 0; }
