@@ -1116,6 +1116,9 @@ template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], cons
 #ifndef SGS8_EDGE_PRIO
 #define SGS8_EDGE_PRIO 1
 #endif
+#ifndef SGS8_PACKED_UNIQ
+#define SGS8_PACKED_UNIQ 1
+#endif
 template <int K, bool FAST>
 __global__ void __launch_bounds__(1024)
 sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
@@ -1327,8 +1330,23 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             bool bad = false;
             if (udiv > 0) {                                       // (uniform)
                 const int uth = minS > 0 ? sg_div_small(100 * minS - 1, udiv) : -1;
+#if SGS8_PACKED_UNIQ
+                // "S <= uth" for a pair at once: S - (uth + 1) borrows into bit 15 of its half exactly when S <= uth (S <= 32767; uth + 1 clamped to 32768 keeps the
+                // subtraction inside 16 bits); the three disparities around the winner are masked out by a per-lane bit pattern: 2 + 2 instructions per pair instead of 5 per value
+                const uint32_t U2 = (uint32_t)min(uth + 1, 32768) * 0x00010001u;
+                const int rel = min(max(bestDisp - 1 - li * 2 * K, -3), 2 * K);     // this lane's slot of disparity bestDisp - 1 (clamped: outside -2 .. 2 K - 1 nothing of the triple is this lane's)
+                const uint32_t excl = rel >= 0 ? (7u << rel) : (7u >> -rel);        // slots rel .. rel + 2 (bits beyond 2 K - 1 are not looked at)
+                uint32_t acc = 0u;
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint32_t keep = ((excl >> (2 * j)) & 1u ? 0u : 0x8000u) | ((excl >> (2 * j + 1)) & 1u ? 0u : 0x80000000u);
+                    acc |= pk_sub16(sp2[j], U2) & keep;
+                }
+                bad = acc != 0u;
+#else
 #pragma unroll
                 for (int k = 0; k < 2 * K; k++) bad |= Sv[k] <= uth && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
+#endif
             } else {
 #pragma unroll
                 for (int k = 0; k < 2 * K; k++) bad |= Sv[k] * udiv < minS * 100 && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
