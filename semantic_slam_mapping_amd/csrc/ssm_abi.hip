@@ -321,6 +321,7 @@ extern "C" int ssm_sync(ssm_ctx* c)
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu);
     hipSetDevice(c->device);
+    c->err.clear();                                               // (after a successful ssm_sync ssm_last_error is empty, or the note of a repeated SGBM sweep)
     { int r = wait_pending(c); if (r) return r; }                 // asynchronous per-frame calls still in flight are completed (their results delivered) too
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return check_device_flags(c, true);

@@ -360,6 +360,7 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!disp) FAIL(c, SSM_E_INVAL, "null argument");
+    c->err.clear();
     int16_t* dd; uint16_t* ddepth;
     const size_t np = (size_t)w * h;
     for (int attempt = 0; ; attempt++) {                      // a sweep whose hand-off timed out is repeated once, in form 1 (no cross-block waits)
@@ -382,6 +383,7 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (!depth) FAIL(c, SSM_E_INVAL, "null argument");
+    c->err.clear();
     int16_t* dd; uint16_t* ddepth;
     const size_t np = (size_t)w * h;
     for (int attempt = 0; ; attempt++) {
