@@ -363,6 +363,7 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
     c->err.clear();
     int16_t* dd; uint16_t* ddepth;
     const size_t np = (size_t)w * h;
+    bool repeated = false;
     for (int attempt = 0; ; attempt++) {                      // a sweep whose hand-off timed out is repeated once, in form 1 (no cross-block waits)
         int r = sgbm_run(c, left, right, w, h, stride, params, stage, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
         HIPCHK(c, hipMemcpyAsync(c->h_pinned + 2 * np, dd, np * 2, hipMemcpyDeviceToHost, c->stream));
@@ -370,10 +371,10 @@ extern "C" int ssm_sgbm(ssm_ctx* c, const uint8_t* left, const uint8_t* right, i
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!sgbm_failed(c)) break;
         if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
-        c->sgbm_fallbacks++;
+        c->sgbm_fallbacks++; repeated = true;
     }
     memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
+    if (repeated) c->err = "note: the SGBM sweep of this pair timed out in a strip hand-off and was repeated with form 1 (results complete; " + std::to_string(c->sgbm_fallbacks) + " such repeats on this context so far)";
     return SSM_OK;
 }
 extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, const ssm_sgbm_params* params,
@@ -386,6 +387,7 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
     c->err.clear();
     int16_t* dd; uint16_t* ddepth;
     const size_t np = (size_t)w * h;
+    bool repeated = false;
     for (int attempt = 0; ; attempt++) {
         int r = sgbm_run(c, left, right, w, h, stride, params, 0, &dd, &ddepth, attempt ? 1 : c->sgbm_form_cfg); if (r) return r;
         HIPCHK(c, k_sgbm_depth(dd, w, h, 1, baseline, cu, cv, f, roix, roiy, roiz, scale, c->stereo->dminN[0], ddepth, c->stream));
@@ -395,11 +397,11 @@ extern "C" int ssm_stereo_depth(ssm_ctx* c, const uint8_t* left, const uint8_t* 
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (!sgbm_failed(c)) break;
         if (attempt) FAIL(c, SSM_E_HIP, "SGBM: the time-out word is set after a form-1 run");
-        c->sgbm_fallbacks++;
+        c->sgbm_fallbacks++; repeated = true;
     }
     memcpy(depth, c->h_pinned + 4 * np, np * 2);
     if (disp) memcpy(disp, c->h_pinned + 2 * np, np * 2);
-    if (c->sgbm_fallbacks) c->err = "note: " + std::to_string(c->sgbm_fallbacks) + " SGBM sweep(s) of this context timed out in a strip hand-off and were repeated with form 1 (results complete)";
+    if (repeated) c->err = "note: the SGBM sweep of this pair timed out in a strip hand-off and was repeated with form 1 (results complete; " + std::to_string(c->sgbm_fallbacks) + " such repeats on this context so far)";
     return SSM_OK;
 }
 
