@@ -477,12 +477,14 @@ def rgbd_main(args):
             t1 = time.perf_counter()
             # copies of sub-batch b + 1 run on a side stream under the kernels of sub-batch b (the frames of a step stay resident, so
             # every sub-batch has its own region of the device buffers)
-            cstream = torch.cuda.Stream()
+            # the copies go to torch's DEFAULT stream (the context's streams are non-blocking ones: no implicit ordering with it).  A torch side stream here --
+            # torch creates its pool of 32 streams at the first request -- left the process in a state in which the stereo leg that follows in the default run lost 6 %
+            # (4.85 k instead of 5.15 k pairs/s: its four streams no longer on four hardware queues); round 5, scripts: bisected with the pass on / off
+            cstream = torch.cuda.current_stream()
             def copy_chunk(a, b):
-                with torch.cuda.stream(cstream):
-                    for src, dst, per in zip(hbuf, (bgr, dep, sem, pose), (H * W * 3, H * W, H * W * 3, 16)):      # flat tensors: elements per frame
-                        dst[a * per:b * per].copy_(src[a * per:b * per], non_blocking=True)
-                    ev = torch.cuda.Event(); ev.record(cstream)
+                for src, dst, per in zip(hbuf, (bgr, dep, sem, pose), (H * W * 3, H * W, H * W * 3, 16)):      # flat tensors: elements per frame
+                    dst[a * per:b * per].copy_(src[a * per:b * per], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(cstream)
                 return ev
             for _ in range(max(1, min(args.steps, 3))):
                 ctx.map_clear()
@@ -793,26 +795,31 @@ def other_configs(args, head):
     sc = args.other_scale
     out = {}
     t_all = time.perf_counter()
-    # ---- configs[2]: the SegNet stage in front of the map stage (labels from the network instead of the precomputed masks)
-    a = copy.copy(args)
-    a.segnet, a.solve_poses, a.frames, a.batch, a.steps, a.warmup = True, False, max(16, int(256 * sc)), max(8, int(128 * sc)), 3, 1
-    a.no_cpu = True                                        # its CPU leg is segnet_cpu_baseline below (the pipeline part is the headline's sample)
-    t0 = time.perf_counter()
-    try:
-        ln = rgbd_main(a)
-        if not args.no_cpu:
-            ln["cpu_baseline"] = segnet_cpu_baseline(head.get("cpu_baseline"))
-        out["configs[2]"] = sub_line(ln, wall_s=round(time.perf_counter() - t0, 1))
-    except Exception as e:                                  # a failing leg must not take the headline with it; it is reported
-        out["configs[2]"] = {"error": repr(e)}
-    # ---- configs[3]: the stereo front end on resident 1241 x 376 pairs
-    a = copy.copy(args)
-    a.stereo, a.frames, a.steps, a.warmup, a.stereo_batch = True, max(8, int(256 * sc)), 3, 1, max(4, min(args.stereo_batch, int(128 * sc)))
-    t0 = time.perf_counter()
-    try:
-        out["configs[3]"] = sub_line(stereo_main(a), wall_s=round(time.perf_counter() - t0, 1))
-    except Exception as e:
-        out["configs[3]"] = {"error": repr(e)}
+    legs_order = os.environ.get("SSM_BENCH_LEG_ORDER", "stereo,segnet")      # (ablation: which of the two heavy legs runs first; the second one meets a warmer chip)
+    def leg_segnet():
+        # ---- configs[2]: the SegNet stage in front of the map stage (labels from the network instead of the precomputed masks)
+        a = copy.copy(args)
+        a.segnet, a.solve_poses, a.frames, a.batch, a.steps, a.warmup = True, False, max(16, int(256 * sc)), max(8, int(128 * sc)), 3, 1
+        a.no_cpu = True                                        # its CPU leg is segnet_cpu_baseline below (the pipeline part is the headline's sample)
+        t0 = time.perf_counter()
+        try:
+            ln = rgbd_main(a)
+            if not args.no_cpu:
+                ln["cpu_baseline"] = segnet_cpu_baseline(head.get("cpu_baseline"))
+            out["configs[2]"] = sub_line(ln, wall_s=round(time.perf_counter() - t0, 1))
+        except Exception as e:                                  # a failing leg must not take the headline with it; it is reported
+            out["configs[2]"] = {"error": repr(e)}
+    def leg_stereo():
+        # ---- configs[3]: the stereo front end on resident 1241 x 376 pairs
+        a = copy.copy(args)
+        a.stereo, a.frames, a.steps, a.warmup, a.stereo_batch = True, max(8, int(256 * sc)), 3, 1, max(4, min(args.stereo_batch, int(128 * sc)))
+        t0 = time.perf_counter()
+        try:
+            out["configs[3]"] = sub_line(stereo_main(a), wall_s=round(time.perf_counter() - t0, 1))
+        except Exception as e:
+            out["configs[3]"] = {"error": repr(e)}
+    for leg in legs_order.split(","):
+        (leg_segnet if leg.strip() == "segnet" else leg_stereo)()
     # ---- the closed pose loop: measured inside the headline's process on its resident stream (rgbd_main's --solve-poses leg); re-shaped here
     sp = head.pop("solve_poses", None)
     if sp is not None:
