@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the kernels whose name contains $1, from one bench.py step (on the GPU box): gpurun -- 'bash scripts/pmc_one.sh map_stream'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-SSM_BENCH_H2D=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/p_one -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu > gpurun_out/p_one.log 2>&1
+SSM_BENCH_H2D=0 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/p_one -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > gpurun_out/p_one.log 2>&1
 python3 - "$1" <<'PY'
 import csv,glob,collections,sys
 pat=sys.argv[1]

@@ -871,8 +871,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             // The map of a context grows (map_settle): a launch covers all nb frames when the table is large, fewer while it is small, and the table's counters
             // are looked at between launches (map_before_launch).  Exact integer sums: how the frames are cut into launches does not change the map.
             for (int q0 = 0, nq; (stages & SSM_STAGE_MAP) && q0 < nb; q0 += nq) {
-                r = map_before_launch(c, s); if (r) return r;
-                nq = map_frames_per_launch(c, nb - q0);
+                r = map_before_launch(c, s, nb - q0, &nq); if (r) return r;
                 const int g0 = f0 + q0;
                 const uint8_t* sem_q = sem_src + (size_t)q0 * npix * 3;
                 if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
@@ -893,7 +892,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                     HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nq * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
                     prof_end(c);
                 }
-                r = map_after_launch(c, s); if (r) return r;
+                r = map_after_launch(c, s, nq); if (r) return r;
             }
             return SSM_OK;
         };

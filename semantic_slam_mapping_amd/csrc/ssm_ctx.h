@@ -117,6 +117,8 @@ struct ssm_ctx {
     VoxTable map, tmp; bool map_full_reported = false;   // table-full already reported by check_device_flags (reset by ssm_map_clear)
     // the context map grows (map_settle); between the map launches of ssm_seq_process its counters come back through a two-slot ring of asynchronous copies
     int vox_max_log2 = 28; int32_t* h_map_snap = nullptr; hipEvent_t map_snap_ev[2] = {nullptr, nullptr}; uint64_t map_launches = 0; int map_grown = 0;
+    double map_vpf = -1.0;                                  // voxels (+ overflow records) per fused frame, the largest rate seen on this context; < 0: none yet
+    int64_t map_frames = 0, map_snap_frames[2] = {0, 0}, map_known_total = 0, map_known_frames = 0;     // frames fused since the last clear; at the ring's snapshots; the last count the host has seen and when
     // multi-GPU: the communicator of ssm_comm_init_rank (one rank per context / GPU) and the gathered counts
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1; int32_t* d_comm_counts = nullptr; int comm_counts_cap = 0;
     // SegNet
@@ -165,9 +167,8 @@ SSM_HIDDEN int ensure_side_streams(ssm_ctx* c);
 // ssm_map.hip
 SSM_HIDDEN int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2);
 SSM_HIDDEN int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve);
-SSM_HIDDEN int map_before_launch(ssm_ctx* c, hipStream_t s);
-SSM_HIDDEN int map_after_launch(ssm_ctx* c, hipStream_t s);
-SSM_HIDDEN int map_frames_per_launch(const ssm_ctx* c, int nb);
+SSM_HIDDEN int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq);
+SSM_HIDDEN int map_after_launch(ssm_ctx* c, hipStream_t s, int frames);
 // ssm_segnet_abi.hip
 SSM_HIDDEN int seg_init(ssm_ctx* c);
 SSM_HIDDEN int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags);

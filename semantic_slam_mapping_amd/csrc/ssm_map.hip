@@ -70,29 +70,70 @@ int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve)
     }
     FAIL(c, SSM_E_CAPACITY, "voxel map: the overflow list did not drain");
 }
-// ssm_seq_process, in front of every launch of the map stage on stream s.  A small table (< 2^20 slots) is settled exactly every time and takes only
-// slots / 4096 frames per launch; a large one is checked against the counters of the launch before the previous one (a two-slot ring of asynchronous copies:
-// the host never waits for the launch it has just queued) and settled when it is a quarter full or its overflow list is in use.
-int map_before_launch(ssm_ctx* c, hipStream_t s)
+// ssm_seq_process, in front of every launch of the map stage on stream s: decides how many of the `remaining` frames of the sub-batch the launch takes (*nq) and
+// makes room for what they are expected to add.  The expectation is the stream's own rate: voxels (+ overflow records) per frame fused since the last clear, the
+// largest value seen (map_vpf); x 1.5 is what a launch is granted.
+//   * a context that has no rate yet takes ONE frame and is settled behind it (the one wait of its lifetime): a first launch of a whole sub-batch at a leaf far below
+//     the pixel footprint would add more than table + overflow list hold, and what is dropped cannot be recovered;
+//   * a small table (< 2^20 slots) is settled exactly in front of every launch, grown for the launch's expectation, and takes at most slots / 4096 frames;
+//   * a large one is looked at through the counters of the launch BEFORE the previous one (a two-slot ring of asynchronous copies: the host never waits for the
+//     launch it has just queued) and settled -- grown for the expectation -- when it is a quarter full, when its overflow list is in use, or when the frames queued
+//     since that snapshot plus this launch are expected to fill it beyond a half.
+static void map_learn_rate(ssm_ctx* c, int64_t total, int64_t frames) { if (frames > 0 && total > 0) { const double v = (double)total / (double)frames; if (v > c->map_vpf) c->map_vpf = v; } }
+static int map_settle_exact(ssm_ctx* c, hipStream_t s, int64_t reserve)
+{
+    int r = map_settle(c, s, reserve); if (r) return r;
+    int32_t cnt[4];
+    HIPCHK(c, hipMemcpyAsync(cnt, c->map.counters, 16, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s));
+    map_learn_rate(c, cnt[0], c->map_frames);
+    c->map_launches = 0;
+    return SSM_OK;
+}
+int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq)
 {
     VoxTable& t = c->map;
-    if (t.cap_log2 < 20) return map_settle(c, s, 0);
-    if (c->map_launches < 2) return SSM_OK;
+    if (c->map_vpf < 0) { *nq = 1; return map_settle(c, s, 0); }             // no rate yet (map_after_launch learns it behind this frame)
+    const double grant = c->map_vpf * 1.5;
+    if (t.cap_log2 < 20) {
+        int f = (1 << t.cap_log2) >> 12; f = f < 1 ? 1 : (f > remaining ? remaining : f);
+        *nq = f;
+        return map_settle_exact(c, s, (int64_t)(f * grant));
+    }
+    *nq = remaining;
+    if (c->map_launches < 2) {
+        // no snapshot of this run of launches yet: the table was settled when the run began (map_frames counts what has been queued since)
+        if (2.0 * ((double)c->map_known_total + (double)(c->map_frames - c->map_known_frames + remaining) * grant) > (double)((int64_t)1 << t.cap_log2))
+            return map_settle_exact(c, s, (int64_t)(remaining * grant));
+        return SSM_OK;
+    }
     const int slot = (int)(c->map_launches & 1);
     HIPCHK(c, hipEventSynchronize(c->map_snap_ev[slot]));
     const int32_t* cnt = c->h_map_snap + 4 * slot;
-    if (cnt[2] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2)) { c->map_launches = 0; return map_settle(c, s, 0); }
+    const int64_t total = (int64_t)cnt[0] + cnt[2], at = c->map_snap_frames[slot];
+    map_learn_rate(c, total, at);
+    c->map_known_total = total; c->map_known_frames = at;
+    const double expect = (double)total + (double)(c->map_frames - at + remaining) * grant;
+    if (cnt[2] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2) || 2.0 * expect > (double)((int64_t)1 << t.cap_log2))
+        return map_settle_exact(c, s, (int64_t)(remaining * grant));
     return SSM_OK;
 }
-int map_after_launch(ssm_ctx* c, hipStream_t s)
+int map_after_launch(ssm_ctx* c, hipStream_t s, int frames)
 {
+    c->map_frames += frames;
+    if (c->map_vpf < 0) {                                         // the context's first frames: wait for them once and take the rate
+        int r = map_settle_exact(c, s, 0); if (r) return r;
+        if (c->map_vpf < 0) c->map_vpf = 1.0;                     // (nothing was fused: every pixel gated; the next launches are granted little and watched)
+        int32_t cnt[4]; HIPCHK(c, hipMemcpy(cnt, c->map.counters, 16, hipMemcpyDeviceToHost));
+        c->map_known_total = cnt[0]; c->map_known_frames = c->map_frames;
+        return SSM_OK;
+    }
     const int slot = (int)(c->map_launches & 1);
     HIPCHK(c, hipMemcpyAsync(c->h_map_snap + 4 * slot, c->map.counters, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(c->map_snap_ev[slot], s));
+    c->map_snap_frames[slot] = c->map_frames;
     c->map_launches++;
     return SSM_OK;
 }
-int map_frames_per_launch(const ssm_ctx* c, int nb) { const int f = c->map.cap_log2 >= 20 ? nb : (1 << c->map.cap_log2) >> 12; return f < 1 ? 1 : (f > nb ? nb : f); }
 
 // ---------------------------------------------------------------- voxel map
 static int table_count(ssm_ctx* c, VoxTable& t, int* n)
@@ -143,7 +184,7 @@ extern "C" int ssm_map_clear(ssm_ctx* c)
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));       // (the capacity it has grown to stays)
-    c->map_full_reported = false; c->map_launches = 0;
+    c->map_full_reported = false; c->map_launches = 0; c->map_frames = 0; c->map_known_total = 0; c->map_known_frames = 0;      // (the rate map_vpf is the stream's: kept)
     return SSM_OK;
 }
 extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)

@@ -323,6 +323,34 @@ def test_configs1_at_leaf_002_from_a_tiny_table_equals_the_large_table_run():
         big.close()
 
 
+def test_map_growth_follows_the_streams_voxel_rate_at_a_leaf_below_the_pixel_footprint():
+    """leaf 4 mm: nearly every kept pixel is a voxel of its own (~10^5 new voxels per frame), so a 20-frame launch adds more than a 2^20-slot table and its overflow list hold
+    together.  The context takes its first frame alone, learns the stream's rate and grows the table for what a launch is expected to add BEFORE the launch: nothing is lost,
+    and the table equals the one of a context that starts with 2^25 slots"""
+    import semantic_slam_mapping_amd as ssm
+    N, W, H = 40, 640, 480
+    big = ssm.Context(0, orb_features=500, max_batch=20, voxel_capacity_log2=25, mapper_resolution=0.004, camera=CAM)
+    bufs = [big.dev_alloc(N * W * H * 3), big.dev_alloc(N * W * H * 2), big.dev_alloc(N * W * H * 3), big.dev_alloc(N * 128)]
+    try:
+        big.synth_frames_dev(SEED, 0, N, *bufs)
+        big.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); big.sync()
+        ref = big.map_export_table()
+        assert len(ref) > (1 << 20) + (1 << 18)                     # more than table + overflow list of the default context
+        c = ssm.Context(0, orb_features=500, max_batch=20, voxel_capacity_log2=20, mapper_resolution=0.004, camera=CAM)
+        try:
+            c.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); c.sync()
+            assert c.map_export_table().tobytes() == ref.tobytes()
+            c.map_clear()                                            # (the rate is the stream's: a second pass needs no learning frame and no growth)
+            c.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); c.sync()
+            assert c.map_export_table().tobytes() == ref.tobytes()
+        finally:
+            c.close()
+    finally:
+        for p in bufs:
+            big.dev_free(p)
+        big.close()
+
+
 # ---------------------------------------------------------------- bench.py contract (and its all-gather path on one GPU)
 def test_bench_line_and_allgather_path():
     import json, os, subprocess, sys
