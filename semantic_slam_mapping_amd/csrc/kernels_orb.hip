@@ -4,6 +4,7 @@
 // Contracts (rounding rules, tie-breaks) are those of oracle/orb.c; compile with -ffp-contract=off.
 #include "ssm_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define WAVE 64
 
@@ -926,7 +927,8 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     const int32_t* cm = cellmax + (size_t)f * g.cells_total + L.cell_off;
     int nvalid = 0;
     // (four keys per trip: their key loads, then their cell-maximum loads, issued together -- two dependent global latencies per trip, not per key)
-    auto init_trip = [&](int i0, cand_t (&k)[OT_UN]) {
+    auto init_trip = [&](auto lds_tag, int i0, cand_t (&k)[OT_UN]) {
+        constexpr bool in_lds = decltype(lds_tag)::value;      // (shadows the block-uniform flag: a pointer chosen at run time made every node-id access a flat_ instruction)
         int cmv[OT_UN];
 #pragma unroll
         for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; k[u] = i < nc ? KEY(i) : make_uint2(0u, 0u); }
@@ -948,10 +950,10 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
 #pragma unroll
         for (int t = 0; t < KPT / OT_UN; t++) {
             const int i0 = tid + t * OT_UN * OT_T;
-            if (i0 < nc) { cand_t k[OT_UN]; init_trip(i0, k); for (int u = 0; u < OT_UN; u++) kxr[t * OT_UN + u] = k[u].x; }
+            if (i0 < nc) { cand_t k[OT_UN]; init_trip(std::true_type{}, i0, k); for (int u = 0; u < OT_UN; u++) kxr[t * OT_UN + u] = k[u].x; }
         }
     } else {
-        for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) { cand_t k[OT_UN]; init_trip(i0, k); }
+        for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) { cand_t k[OT_UN]; init_trip(std::false_type{}, i0, k); }
     }
     if (nvalid) atomicAdd(&sValid, nvalid);
     __syncthreads();
@@ -965,7 +967,8 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         sL = pos; sFinish = 0; sMode = 0;
     }
     __syncthreads();
-    for (int i = tid; i < nc; i += OT_T) { const int o = NOF(i); if (o != DROPPED) SETNOF(i, newpos[o]); }
+    if (in_lds) { for (int i = tid; i < nc; i += OT_T) { const int o = lnof[i]; if (o != DROPPED) lnof[i] = (uint16_t)newpos[o]; } }
+    else        { for (int i = tid; i < nc; i += OT_T) { const int o = gnof[i]; if (o != DROPPED) gnof[i] = (uint16_t)newpos[o]; } }
     int cur = 1;      // buffer holding the current list
     __syncthreads();
     OTP(0)
@@ -985,7 +988,8 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         __syncthreads();
         // (four keys per trip, each step of the dependent chain key -> node id -> node -> counter issued for all four before the next: a block is a chain
         // of LDS latencies, and one key per trip paid every one of them in full)
-        auto count_trip = [&](int i0, const uint32_t (&kx)[OT_UN]) {
+        auto count_trip = [&](auto lds_tag, int i0, const uint32_t (&kx)[OT_UN]) {
+            constexpr bool in_lds = decltype(lds_tag)::value;
             int ni[OT_UN]; uint32_t cn_[OT_UN]; QNode q[OT_UN];
 #pragma unroll
             for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; }
@@ -1007,14 +1011,14 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
 #pragma unroll
             for (int t = 0; t < KPT / OT_UN; t++) {
                 const int i0 = tid + t * OT_UN * OT_T;
-                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; count_trip(i0, kx); }
+                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; count_trip(std::true_type{}, i0, kx); }
             }
         } else {
             for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
                 uint32_t kx[OT_UN];
 #pragma unroll
                 for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; kx[u] = i < nc ? KEYX(i) : 0u; }
-                count_trip(i0, kx);
+                count_trip(std::false_type{}, i0, kx);
             }
         }
         OTP(1)
@@ -1149,7 +1153,8 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
         }
         __syncthreads();
         OTP(3)
-        auto relabel_trip = [&](int i0, const uint32_t (&kx)[OT_UN]) {
+        auto relabel_trip = [&](auto lds_tag, int i0, const uint32_t (&kx)[OT_UN]) {
+            constexpr bool in_lds = decltype(lds_tag)::value;
             int ni[OT_UN]; int np_[OT_UN]; QNode q[OT_UN];
 #pragma unroll
             for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; }
@@ -1171,14 +1176,14 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
 #pragma unroll
             for (int t = 0; t < KPT / OT_UN; t++) {
                 const int i0 = tid + t * OT_UN * OT_T;
-                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; relabel_trip(i0, kx); }
+                if (i0 < nc) { uint32_t kx[OT_UN]; for (int u = 0; u < OT_UN; u++) kx[u] = kxr[t * OT_UN + u]; relabel_trip(std::true_type{}, i0, kx); }
             }
         } else {
             for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
                 uint32_t kx[OT_UN];
 #pragma unroll
                 for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; kx[u] = i < nc ? KEYX(i) : 0u; }
-                relabel_trip(i0, kx);
+                relabel_trip(std::false_type{}, i0, kx);
             }
         }
         cur ^= 1;
@@ -1193,7 +1198,7 @@ octree_kernel(OrbGeom g, const cand_t* __restrict__ cand, const int32_t* __restr
     for (int i0 = tid; i0 < nc; i0 += OT_UN * OT_T) {
         int ni[OT_UN]; cand_t k[OT_UN];
 #pragma unroll
-        for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (int)NOF(i) : DROPPED; k[u] = i < nc ? KEY(i) : make_uint2(0u, 0u); }
+        for (int u = 0; u < OT_UN; u++) { const int i = i0 + u * OT_T; ni[u] = i < nc ? (in_lds ? (int)lnof[i] : (int)gnof[i]) : DROPPED; k[u] = i < nc ? KEY(i) : make_uint2(0u, 0u); }
 #pragma unroll
         for (int u = 0; u < OT_UN; u++) {
             if (ni[u] == DROPPED) continue;

@@ -38,14 +38,18 @@ __device__ __forceinline__ Edge pc_expand(const LEdge& l)
 #define PROF_T0 long long pt_ = clock64();
 #define PROF(k) { const long long n_ = clock64(); if (threadIdx.x == 0) sh.prof[k] += n_ - pt_; pt_ = n_; }
 #define PROF_CNT(k) { if (threadIdx.x == 0) sh.prof[k] += 1; }
+#define PROF2_T0 long long p2_ = clock64();
+#define PROF2(k) { const long long n2_ = clock64(); if (threadIdx.x == 0) sh.prof[k] += n2_ - p2_; p2_ = n2_; }
 #else
+#define PROF2_T0
+#define PROF2(k)
 #define PROF_T0
 #define PROF(k)
 #define PROF_CNT(k)
 #endif
 struct PcShared {
 #ifdef SSM_PNP_PROF
-    long long prof[8];
+    long long prof[32];
 #endif
     double red[NGROUP][NACC + 1 + PC_SPEC];
     double tot[NACC + 1 + PC_SPEC];
@@ -150,7 +154,10 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 template <int NV, int OFF, bool CL>
 __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv <= NV: the values in use (block-uniform; the others are neither exchanged nor summed)
 {
+    PROF2_T0
+    constexpr int PB = NV == 28 ? 8 : 16;
     __syncthreads();
+    PROF2(PB + 0)
     if constexpr (CL) {
         // every block holds the group sums of its own waves; a sum is published as two 8-byte {pass tag, 32 bits} granules (one agent-scope store each: the data is the
         // flag, cdna_hip_programming.md G16 R2) and every block polls all sixteen groups' granules, so that the ordered sum below sees the same sixteen numbers everywhere.
@@ -165,6 +172,7 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
             __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        PROF2(PB + 1)
         if (g < NGROUP && v < nv) {
             // two polls in flight, half a round trip apart (a poll that leaves just before the granule lands costs a whole round trip of ~1.2 k clocks otherwise):
             // the second leaves ~600 clocks behind the first, after that each is re-issued when its answer is in, which keeps the spacing
@@ -182,11 +190,14 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
             if (!ok) __hip_atomic_store(sh.xfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (bounded: the chain then reports an invalid range instead of hanging)
             sh.red[g][OFF + v] = __longlong_as_double((long long)((lo & 0xFFFFFFFFull) | (hi << 32)));
         }
+        PROF2(PB + 2)
         __syncthreads();
+        PROF2(PB + 3)
         if (threadIdx.x == 0) sh.xseq = seq + 1;
     }
     if ((int)threadIdx.x < nv) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
     __syncthreads();
+    PROF2(PB + 4)
 }
 // the lanes whose edges this block evaluates (all of them in the one-block form)
 template <bool CL> __device__ __forceinline__ bool pc_mine() { if constexpr (CL) return (int)(threadIdx.x / (PC_T / gridDim.x)) == (int)blockIdx.x; else return true; }
@@ -217,6 +228,7 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
         const int gg = (int)blockIdx.x * gpb + gi, lane0 = gg * GROUP + lane, bl = gi * GROUP + lane;       // contract group / lane; lane index inside the block
         const int J = (ne + PC_T - 1) / PC_T, per = gpb * GROUP, room = PC_RBUF / per;                      // edge slots per lane; items the buffer holds
         const int CC = J <= room ? room / J : 0;                                                            // candidates per filling of the buffer
+        PROF2_T0
         for (int c0 = 0; c0 < n; c0 += (CC > 0 ? CC : 1)) {
             if (CC > 0) {
                 const int nc = n - c0 < CC ? n - c0 : CC;
@@ -226,7 +238,9 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
                     if (i < ne) { const LEdge l = L[i]; if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); r = edge_rho(e, sh.spec[c0 + c].P, k, delta); } }
                     sh.rbuf[it * per + bl] = r;
                 }
+                PROF2(25)
                 __syncthreads();
+                PROF2(26)
                 for (int c = set; c < nc; c += G) {
                     double a = 0.0;
                     for (int j = 0; j < J; j++) a += sh.rbuf[(c * J + j) * per + bl];
@@ -234,7 +248,9 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
                     a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
                     if (lane == 0) sh.red[gg][NACC + 1 + c0 + c] = a;
                 }
+                PROF2(27)
                 __syncthreads();                                                    // (the buffer is refilled by the next group of candidates)
+                PROF2(28)
             } else {                                                                // a list too long for the buffer: the owning waves walk their edges, one candidate at a time
                 if (set == 0) {
                     double a = 0.0;
@@ -279,6 +295,7 @@ template <bool CL>
 __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[NACC + 1];
+    PROF2_T0
 #pragma unroll
     for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
     if (pc_mine<CL>())
@@ -286,6 +303,7 @@ __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int n
         const LEdge l = L[i];
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
     }
+    PROF2(24)
     pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
 }
 // solve_ldlt of pnp_core.h by the first six lanes of a wave, ONE ROW of L each: the same operations in the same order -- lane i forms
@@ -502,7 +520,7 @@ pnp_chain_kernel(PnpChainArgs a)
     // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
     if (tid == 0) { for (int k = 0; k < 16; k++) { sh.speed[k] = a.state->speed[k]; sh.last[k] = a.state->last_pose[k]; } for (int k = 0; k < 4; k++) sh.work[k] = 0; }
 #ifdef SSM_PNP_PROF
-    if (tid == 0) for (int k = 0; k < 8; k++) sh.prof[k] = 0;
+    if (tid == 0) for (int k = 0; k < 32; k++) sh.prof[k] = 0;
 #endif
     int nref = a.state->nref, cnt_lost = a.state->cnt_lost;
     // the deque lives in global memory (a.state->ref_idx / ref_pose); every thread tracks nref
@@ -581,7 +599,7 @@ pnp_chain_kernel(PnpChainArgs a)
         for (int k = 0; k < 4; k++) a.state->work[k] = sh.work[k];
         if (CL && __hip_atomic_load(a.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) a.state->stopped_at = -1;     // an exchange timed out: the host rejects the range
 #ifdef SSM_PNP_PROF
-        for (int k = 0; k < 8; k++) a.state->prof[k] = sh.prof[k];
+        for (int k = 0; k < 32; k++) a.state->prof[k] = sh.prof[k];
 #endif
     }
 }

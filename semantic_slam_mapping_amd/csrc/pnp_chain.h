@@ -11,7 +11,7 @@ struct PnpState {
     int32_t nref, cnt_lost, stopped_at, pad;
     long long work[4];                               // out: fused passes, chi2 passes, active edges evaluated by the fused / by the chi2 passes of this launch
 #ifdef SSM_PNP_PROF
-    long long prof[8];                               // shader clocks per section (thread 0), ablation builds only
+    long long prof[32];                              // shader clocks per section (thread 0), ablation builds only
 #endif
 };
 struct PnpChainArgs {
