@@ -156,24 +156,31 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
 {
     PROF2_T0
     constexpr int PB = NV == 28 ? 8 : 16;
+    // ROWSCAN (the passes of few values: 16 nv <= 128 threads): thread (v, g) = (tid / 16, tid % 16) takes group g's sum of value v and the row adds them (below);
+    // otherwise thread (g, v) = (tid / 32, tid % 32) brings the sum to LDS and thread v walks the sixteen.  (The row form for the 28-value pass too: measured slower)
+    constexpr bool ROWSCAN = NV <= 8;
+    static_assert(NGROUP == 16, "a DPP row is the sixteen groups");
     __syncthreads();
     PROF2(PB + 0)
+    const int g = ROWSCAN ? (int)(threadIdx.x & 15) : (int)(threadIdx.x >> 5), v = ROWSCAN ? (int)(threadIdx.x >> 4) : (int)(threadIdx.x & 31);
+    const bool pollv = g < NGROUP && v < nv;
+    double r = 0.0; unsigned seq = 0;
     if constexpr (CL) {
         // every block holds the group sums of its own waves; a sum is published as two 8-byte {pass tag, 32 bits} granules (one agent-scope store each: the data is the
         // flag, cdna_hip_programming.md G16 R2) and every block polls all sixteen groups' granules, so that the ordered sum below sees the same sixteen numbers everywhere.
         // Four ring slots by pass number; a block can be at most one pass ahead of another (it needs everybody's sums to finish a pass).
-        const int gpb = NGROUP / (int)gridDim.x, g = threadIdx.x >> 5, v = threadIdx.x & 31;
-        const unsigned seq = sh.xseq; const unsigned long long tag = (unsigned long long)(seq + 1) << 32;
+        const int gpb = NGROUP / (int)gridDim.x, pg = threadIdx.x >> 5, pv = threadIdx.x & 31;
+        seq = sh.xseq; const unsigned long long tag = (unsigned long long)(seq + 1) << 32;
         typedef __attribute__((address_space(1))) unsigned long long gu64;          // (global_load / global_store, not flat: the ring is device memory)
         gu64* slot = (gu64*)sh.xmb + (size_t)(seq & 3u) * NGROUP * 32 * 2;
-        if (g < gpb && v < nv) {
-            const int gg = (int)blockIdx.x * gpb + g;
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + v]);
-            __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + (size_t)(gg * 32 + v) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pg < gpb && pv < nv) {
+            const int gg = (int)blockIdx.x * gpb + pg;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + pv]);
+            __hip_atomic_store(slot + (size_t)(gg * 32 + pv) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (size_t)(gg * 32 + pv) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PROF2(PB + 1)
-        if (g < NGROUP && v < nv) {
+        if (pollv) {
             // two polls in flight, half a round trip apart (a poll that leaves just before the granule lands costs a whole round trip of ~1.2 k clocks otherwise):
             // the second leaves ~600 clocks behind the first, after that each is re-issued when its answer is in, which keeps the spacing
             const gu64* q = slot + (size_t)(g * 32 + v) * 2;
@@ -188,15 +195,36 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
                 if ((spins & 1023u) == 1023u && __hip_atomic_load(sh.xfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
             }
             if (!ok) __hip_atomic_store(sh.xfail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (bounded: the chain then reports an invalid range instead of hanging)
-            sh.red[g][OFF + v] = __longlong_as_double((long long)((lo & 0xFFFFFFFFull) | (hi << 32)));
+            const double got = __longlong_as_double((long long)((lo & 0xFFFFFFFFull) | (hi << 32)));
+            if constexpr (ROWSCAN) r = got; else sh.red[g][OFF + v] = got;
         }
         PROF2(PB + 2)
-        __syncthreads();
+        if constexpr (!ROWSCAN) {
+            __syncthreads();
+            PROF2(PB + 3)
+            if (threadIdx.x == 0) sh.xseq = seq + 1;
+        }
+    } else if constexpr (ROWSCAN) { if (pollv) r = sh.red[g][OFF + v]; }
+    if constexpr (ROWSCAN) {
+        // the sixteen group sums of a value sit in the sixteen lanes of a DPP row: p <- row_shr:1(p) + r, fifteen times, adds them in group order (lane g is final
+        // after g steps; lane 0 receives -0.0, and -0.0 + r == r for every r) -- no trip through LDS and no barrier between the poll and the sum
+        if (pollv) {
+            double p = r;
+#pragma unroll
+            for (int k = 1; k < NGROUP; k++) {
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(p), 0x111, 0xF, 0xF, false);                   // row_shr:1; lane 0 of the row keeps `old`
+                const int hi = __builtin_amdgcn_update_dpp((int)0x80000000, __double2hiint(p), 0x111, 0xF, 0xF, false);
+                p = __hiloint2double(hi, lo) + r;
+            }
+            if (g == NGROUP - 1) sh.tot[OFF + v] = p;
+        }
         PROF2(PB + 3)
-        if (threadIdx.x == 0) sh.xseq = seq + 1;
+        __syncthreads();
+        if constexpr (CL) { if (threadIdx.x == 0) sh.xseq = seq + 1; }            // (read again behind the next call's first barrier)
+    } else {
+        if ((int)threadIdx.x < nv) { const int vv = OFF + threadIdx.x; double s = sh.red[0][vv]; for (int gq = 1; gq < NGROUP; gq++) s = s + sh.red[gq][vv]; sh.tot[vv] = s; }
+        __syncthreads();
     }
-    if ((int)threadIdx.x < nv) { const int v = OFF + threadIdx.x; double s = sh.red[0][v]; for (int g = 1; g < NGROUP; g++) s = s + sh.red[g][v]; sh.tot[v] = s; }
-    __syncthreads();
     PROF2(PB + 4)
 }
 // the lanes whose edges this block evaluates (all of them in the one-block form)
@@ -291,19 +319,95 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
 }
 // chi2 and the normal equations at P in ONE pass over the edges (the host evaluates active_chi2 and build_system one after the other at the same
 // estimate: the same per-edge values, the same lane sums) -> sh.tot[0 .. 26] = H (lower triangle) and b, sh.tot[27] = chi2
+//
+// The cluster form splits the 28 sums over four waves per contract group (round 5).  A block owns gpb = 16 / G groups, so gpb of its sixteen waves had edges and
+// walked them with 28 accumulators each (56 registers of the 128 a wave of a 1024-thread block may hold: the walk spilled) while the others idled.  Every sum is its
+// own chain of additions -- edge by edge in slot order, row 0's term then row 1's -- so WHICH wave owns a sum changes no bit: wave (part, group) walks the group's
+// edges for the sums of its part only (the error, the Jacobian and the weight are recomputed by each, the 40 products and additions of edge_accumulate are shared
+// out), and runs the eight-value reduce-scatter instead of the 28-value one.  PC_PART_Q[part][slot] = index into acc / sh.tot (-1: unused slot):
+//   part 0: H rows 0-1 + b0 b1 b2;  part 1: H rows 2-3 + b3;  part 2: H row 4 + b4 b5 + chi2 (and the edge's stored error);  part 3: H row 5
+// (balanced by the products and additions each costs: row 3 only has row 0's terms and row 4 only row 1's -- the literal zeros of J -- ; 42 / 40 / 28 / 42 with the
+// Jacobian entries each needs; rows 0-2 + b0 b1 | row 3 + b2 b3 + chi2 | row 4 + b4 | row 5 + b5 was 52 / 28 / 23 / 46)
+#define PC_CHI_PART 2
+__device__ constexpr int PC_PART_Q[4][8] = {{0, 1, 2, 21, 22, 23, -1, -1}, {3, 4, 5, 6, 7, 8, 9, 24}, {10, 11, 12, 13, 14, 25, 26, NACC}, {15, 16, 17, 18, 19, 20, -1, -1}};
+constexpr int pc_part_slot(int part, int q) { for (int k = 0; k < 8; k++) if (PC_PART_Q[part][k] == q) return k; return -1; }
+// edge_accumulate of pnp_core.h restricted to the sums of PART: the same expressions in the same order (the loops unroll, the tests on q fold away and the
+// Jacobian entries a part does not use are never computed)
+template <int PART>
+__device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+{
+    double p[3]; edge_map(e, P, p);
+    const double x = p[0], y = p[1], iz = 1.0 / p[2], iz2 = iz * iz;
+    const double J[2][6] = {{x * y * iz2 * k.fx, -(1 + (x * x * iz2)) * k.fx, y * iz * k.fx, -iz * k.fx, 0, x * iz2 * k.fx},
+                            {(1 + y * y * iz2) * k.fy, -x * y * iz2 * k.fy, -x * iz * k.fy, 0, -iz * k.fy, y * iz2 * k.fy}};
+    double w = 1.0;
+    if (e.robust) { double r0; huber(edge_chi2(e), delta, r0, w); }
+    const double er[2] = {e.e0, e.e1};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const double wr = -er[r] * w;
+        const int z = r == 0 ? 4 : 3;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            if (a == z) { q += a + 1; continue; }
+            { const int sb = pc_part_slot(PART, 21 + a); if (sb >= 0) acc[sb] += J[r][a] * wr; }
+            const double jw = J[r][a] * w;
+#pragma unroll
+            for (int c = 0; c <= a; c++) { if (c != z) { const int sq = pc_part_slot(PART, q); if (sq >= 0) acc[sq] += jw * J[r][c]; } q++; }
+        }
+    }
+}
+template <int PART>
+__device__ __forceinline__ void pc_build_part(const LEdge* L, double2* err, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+{
+    for (int i = lane0; i < ne; i += PC_T) {
+        const LEdge l = L[i];
+        if (!(l.meta & LE_LEVEL)) {
+            Edge e = pc_expand(l);
+            const double rho = edge_rho(e, P, k, delta);
+            if constexpr (PART == PC_CHI_PART) { acc[pc_part_slot(PC_CHI_PART, NACC)] += rho; err[i] = make_double2(e.e0, e.e1); }
+            pc_edge_accumulate_part<PART>(e, P, k, delta, acc);
+        }
+    }
+}
 template <bool CL>
 __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
-    double acc[NACC + 1];
     PROF2_T0
+    if constexpr (CL) {
+        const int G = (int)gridDim.x, gpb = NGROUP / G;
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
+        const int gg = (int)blockIdx.x * gpb + gi, lane0 = gg * GROUP + lane;                               // contract group / lane of this wave's edges
+        for (int part = set; part < 4; part += G) {                                                         // (G = 2: two parts per wave)
+            double a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = 0.0;
+            switch (part) {
+                case 0: pc_build_part<0>(L, err, ne, lane0, P, k, delta, a); break;
+                case 1: pc_build_part<1>(L, err, ne, lane0, P, k, delta, a); break;
+                case 2: pc_build_part<2>(L, err, ne, lane0, P, k, delta, a); break;
+                default: pc_build_part<3>(L, err, ne, lane0, P, k, delta, a); break;
+            }
+            // the group tree of eight values (pc_lane_sum, NV == 8): lane l < 8 ends with slot (l & 1) 4 + ((l >> 1) & 1) 2 + ((l >> 2) & 1)
+            pc_rs_step<1, 4>(a, lane & 1);
+            pc_rs_step<2, 2>(a, lane & 2);
+            pc_rs_step<4, 1>(a, lane & 4);
+            double t = a[0];
+            t = t + pc_xor_f64<8, false>(t); t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
+            if (lane < 8) { const int q = PC_PART_Q[part][(lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)]; if (q >= 0) sh.red[gg][q] = t; }
+        }
+        PROF2(24)
+        pc_lane_finish<NACC + 1, 0, CL>(sh);
+        return;
+    }
+    double acc[NACC + 1];
 #pragma unroll
     for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
-    if (pc_mine<CL>())
     for (int i = threadIdx.x; i < ne; i += PC_T) {
         const LEdge l = L[i];
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
     }
-    PROF2(24)
     pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
 }
 // solve_ldlt of pnp_core.h by the first six lanes of a wave, ONE ROW of L each: the same operations in the same order -- lane i forms
