@@ -27,6 +27,29 @@ using namespace ssm_pnp;
 struct LEdge { float X[3], u, v; uint32_t meta; };
 #define LE_LEVEL (1u << 16)
 #define LE_ROBUST (1u << 17)
+// the edge list of a block: in LDS when it fits (address space 3: ds_read / ds_write), else in global scratch (1).  A pointer chosen at run time is a generic one and every
+// access a flat_ instruction (both counters, the texture path's latency in front of the LDS); the kernels are instantiated per address space instead (round 5)
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+template <int AS>
+struct EdgeMem {
+    typedef __attribute__((address_space(AS))) uint32_t W;
+    typedef __attribute__((address_space(AS))) uint2v W2;
+    W* p;
+    __device__ __forceinline__ LEdge ld(int i) const
+    {   // 24 bytes at 8-byte alignment: 8 + 16 or 16 + 8
+        const W2* q = reinterpret_cast<const W2*>(p + (size_t)i * 6);
+        const uint2v a = q[0], b = q[1], c = q[2];
+        LEdge l; l.X[0] = __uint_as_float(a.x); l.X[1] = __uint_as_float(a.y); l.X[2] = __uint_as_float(b.x); l.u = __uint_as_float(b.y); l.v = __uint_as_float(c.x); l.meta = c.y;
+        return l;
+    }
+    __device__ __forceinline__ void st(int i, const LEdge& l) const
+    {
+        W2* q = reinterpret_cast<W2*>(p + (size_t)i * 6);
+        q[0] = uint2v{__float_as_uint(l.X[0]), __float_as_uint(l.X[1])}; q[1] = uint2v{__float_as_uint(l.X[2]), __float_as_uint(l.u)}; q[2] = uint2v{__float_as_uint(l.v), l.meta};
+    }
+    __device__ __forceinline__ uint32_t meta(int i) const { return p[(size_t)i * 6 + 5]; }
+    __device__ __forceinline__ void set_meta(int i, uint32_t m) const { p[(size_t)i * 6 + 5] = m; }
+};
 __device__ __forceinline__ Edge pc_expand(const LEdge& l)
 {
     Edge e; e.id = (int32_t)(l.meta & 0xFFFFu); e.level = (l.meta & LE_LEVEL) ? 1 : 0; e.robust = (l.meta & LE_ROBUST) ? 1 : 0; e.pad = 0;
@@ -230,21 +253,21 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
 // the lanes whose edges this block evaluates (all of them in the one-block form)
 template <bool CL> __device__ __forceinline__ bool pc_mine() { if constexpr (CL) return (int)(threadIdx.x / (PC_T / gridDim.x)) == (int)blockIdx.x; else return true; }
 // the robustified chi2 of the active edges at P (leaves every active edge's error in the edge) -> sh.tot[NACC] (H and b in sh.tot[0 .. 26] stay)
-template <bool CL>
-__device__ __forceinline__ void pc_chi(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+template <bool CL, class EM>
+__device__ __forceinline__ void pc_chi(const EM L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     double acc[1] = {0.0};
     if (pc_mine<CL>())
     for (int i = threadIdx.x; i < ne; i += PC_T) {
-        const LEdge l = L[i];
+        const LEdge l = L.ld(i);
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[0] += edge_rho(e, P, k, delta); err[i] = make_double2(e.e0, e.e1); }
     }
     pc_lane_sum<1, NACC, CL>(acc, sh);
 }
 // the robustified chi2 of the active edges at the poses of candidates 0 .. n-1 (sh.spec[c].P) -> sh.tot[NACC + 1 + c].  The edges' stored errors are NOT touched: every
 // lm_optimize ends with a pc_chi at its final estimate, and nothing reads an error before that (edge_accumulate follows an edge_rho at the same estimate)
-template <bool CL>
-__device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const Camera& k, double delta, PcShared& sh)
+template <bool CL, class EM>
+__device__ __forceinline__ void pc_chi_spec(const EM L, int ne, int n, const Camera& k, double delta, PcShared& sh)
 {
     if constexpr (CL) {
         // The cluster form: this block owns the lanes of gpb = 16 / G contract groups, i.e. gpb of its sixteen waves have edges and the others would idle.  Here
@@ -263,7 +286,7 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
                 for (int it = set; it < nc * J; it += G) {
                     const int c = it / J, j = it - c * J, i = lane0 + j * PC_T;
                     double r = 0.0;
-                    if (i < ne) { const LEdge l = L[i]; if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); r = edge_rho(e, sh.spec[c0 + c].P, k, delta); } }
+                    if (i < ne) { const LEdge l = L.ld(i); if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); r = edge_rho(e, sh.spec[c0 + c].P, k, delta); } }
                     sh.rbuf[it * per + bl] = r;
                 }
                 PROF2(25)
@@ -282,7 +305,7 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
             } else {                                                                // a list too long for the buffer: the owning waves walk their edges, one candidate at a time
                 if (set == 0) {
                     double a = 0.0;
-                    for (int i = lane0; i < ne; i += PC_T) { const LEdge l = L[i]; if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); a += edge_rho(e, sh.spec[c0].P, k, delta); } }
+                    for (int i = lane0; i < ne; i += PC_T) { const LEdge l = L.ld(i); if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); a += edge_rho(e, sh.spec[c0].P, k, delta); } }
                     a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
                     a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
                     if (lane == 0) sh.red[gg][NACC + 1 + c0] = a;
@@ -305,7 +328,7 @@ __device__ __forceinline__ void pc_chi_spec(const LEdge* L, int ne, int n, const
             const bool two = c0 + 1 < n;
             double a0 = 0.0, a1 = 0.0;
             for (int i = threadIdx.x; i < ne; i += PC_T) {
-                const LEdge l = L[i];
+                const LEdge l = L.ld(i);
                 if (!(l.meta & LE_LEVEL)) {
                     Edge e = pc_expand(l);
                     a0 += edge_rho(e, Pa, k, delta);
@@ -358,11 +381,11 @@ __device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pos
         }
     }
 }
-template <int PART>
-__device__ __forceinline__ void pc_build_part(const LEdge* L, double2* err, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+template <int PART, class EM>
+__device__ __forceinline__ void pc_build_part(const EM L, double2* err, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
 {
     for (int i = lane0; i < ne; i += PC_T) {
-        const LEdge l = L[i];
+        const LEdge l = L.ld(i);
         if (!(l.meta & LE_LEVEL)) {
             Edge e = pc_expand(l);
             const double rho = edge_rho(e, P, k, delta);
@@ -371,8 +394,8 @@ __device__ __forceinline__ void pc_build_part(const LEdge* L, double2* err, int 
         }
     }
 }
-template <bool CL>
-__device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
+template <bool CL, class EM>
+__device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     PROF2_T0
     if constexpr (CL) {
@@ -405,7 +428,7 @@ __device__ __forceinline__ void pc_chi_build(const LEdge* L, double2* err, int n
 #pragma unroll
     for (int q = 0; q < NACC + 1; q++) acc[q] = 0.0;
     for (int i = threadIdx.x; i < ne; i += PC_T) {
-        const LEdge l = L[i];
+        const LEdge l = L.ld(i);
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
     }
     pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
@@ -462,12 +485,12 @@ __device__ __forceinline__ bool pc_solve_ldlt_wave(const double* Hl, double lamb
 // lm_optimize of pnp_core.h.  The passes over the edges are the whole block's; the 6 x 6 algebra between them (L D L^T, exp map, Levenberg's bookkeeping)
 // is WAVE 0's alone -- run by all sixteen waves it cost four times as much, since four waves share a SIMD -- which publishes the next estimate and the loop
 // controls through LDS.
-template <bool CL>
-__device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne, int nact, const Camera& k, double delta, int iterations, PcShared& sh)
+template <bool CL, class EM>
+__device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, int nact, const Camera& k, double delta, int iterations, PcShared& sh)
 {
     const Pose& P = sh.P;                                                        // in / out: the estimate lives in LDS (uniform reads; 24 registers saved)
     int any = 0;
-    for (int i = threadIdx.x; i < ne; i += PC_T) any |= !(L[i].meta & LE_LEVEL);
+    for (int i = threadIdx.x; i < ne; i += PC_T) any |= !(L.meta(i) & LE_LEVEL);
     if (!__syncthreads_or(any)) return;
     const bool w0 = threadIdx.x < 64;
     LmState st; st.lambda = 0; st.nu = 2;                                        // (meaningful in wave 0 only)
@@ -538,8 +561,8 @@ __device__ __forceinline__ void pc_optimize(const LEdge* L, double2* err, int ne
     }
 }
 // ssm_pnp::solve for the block: img / obj (nc correspondences) in global scratch, T in / out (in LDS; thread 0 writes it); returns the number of set flags
-template <bool CL>
-__device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, LEdge* L, double2* err, uint8_t* dec, PcShared& sh)
+template <bool CL, class EM>
+__device__ __forceinline__ int pc_solve(const float* img, const float* obj, int n, const Camera& cam, double* T, uint8_t* inl, const EM L, double2* err, uint8_t* dec, PcShared& sh)
 {
     const double delta = (double)(float)sqrt(5.991);
     // edge list: the correspondences with depth, in order
@@ -549,7 +572,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         const bool has = i < n && !(obj[3 * i] == 0.f && obj[3 * i + 1] == 0.f && obj[3 * i + 2] == 0.f);
         int tot; const int pos = ne + pc_scan(has, sh, tot);
         if (i < n) inl[i] = has ? 1 : 0;
-        if (has) { LEdge l; l.meta = (uint32_t)i | LE_ROBUST; l.X[0] = obj[3 * i]; l.X[1] = obj[3 * i + 1]; l.X[2] = obj[3 * i + 2]; l.u = img[2 * i]; l.v = img[2 * i + 1]; L[pos] = l; err[pos] = make_double2(0.0, 0.0); }
+        if (has) { LEdge l; l.meta = (uint32_t)i | LE_ROBUST; l.X[0] = obj[3 * i]; l.X[1] = obj[3 * i + 1]; l.X[2] = obj[3 * i + 2]; l.u = img[2 * i]; l.v = img[2 * i + 1]; L.st(pos, l); err[pos] = make_double2(0.0, 0.0); }
         ne += tot;
     }
     __syncthreads();
@@ -566,7 +589,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
         int nout = 0;
         for (int i = threadIdx.x; i < ne; i += PC_T) {
-            LEdge l = L[i];
+            LEdge l = L.ld(i);
             Edge e = pc_expand(l);
             const double2 er = err[i]; e.e0 = er.x; e.e1 = er.y;
             // (an ACTIVE edge's stored error is edge_error at this P already -- lm_optimize ends with a chi2 pass over the active edges -- so recomputing it changes
@@ -576,10 +599,10 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
             const bool out = edge_chi2(e) > 5.991;
             l.meta = (l.meta & ~LE_LEVEL) | (out ? LE_LEVEL : 0u);
             if (it == 2) l.meta &= ~LE_ROBUST;
-            L[i] = l; dec[i] = out ? 1 : 0; nout += out;
+            L.set_meta(i, l.meta); dec[i] = out ? 1 : 0; nout += out;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[L[i].meta & 0xFFFFu] = 0;
+        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[L.meta(i) & 0xFFFFu] = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < ne; i += PC_T) if (!dec[i]) inl[i] = 1;
         __syncthreads();
@@ -605,7 +628,7 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
     return mm;
 }
 
-template <bool CL>
+template <bool CL, int AS>
 __global__ void __launch_bounds__(PC_T)
 pnp_chain_kernel(PnpChainArgs a)
 {
@@ -618,7 +641,7 @@ pnp_chain_kernel(PnpChainArgs a)
         a.state += b; a.img += b * mc * 2; a.obj += b * mc * 3; a.inl += b * mc; a.dec += b * mc; a.err += b * mc;
         a.ledges = reinterpret_cast<LEdge*>(reinterpret_cast<unsigned char*>(a.ledges) + b * mc * sizeof(LEdge)); }
     const bool lead = !CL || blockIdx.x == 0;                                          // its copies of pose_out / info_out are the call's results
-    LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;    // (a generic pointer: the passes are the same code for both)
+    EdgeMem<AS> L; if constexpr (AS == 3) L.p = (typename EdgeMem<AS>::W*)pc_dyn; else L.p = (typename EdgeMem<AS>::W*)a.ledges;
     const int tid = threadIdx.x;
     if (CL && tid == 0) { sh.xmb = a.xchg; sh.xfail = a.xfail; sh.xseq = 0; }
     // the tracker state: in LDS, written by thread 0 (sixteen waves holding five 4 x 4 transforms each in registers spilled most of them)
@@ -708,12 +731,13 @@ pnp_chain_kernel(PnpChainArgs a)
     }
 }
 // ---- PnPSolver::solvePnP alone (ssm_pnp_solve): the same pc_solve on a caller's correspondence list
+template <int AS>
 __global__ void __launch_bounds__(PC_T)
 pnp_solve_kernel(PnpSolveArgs a)
 {
     __shared__ PcShared sh;
     extern __shared__ __align__(16) unsigned char pc_dyn[];
-    LEdge* L = a.edges_in_lds ? reinterpret_cast<LEdge*>(pc_dyn) : a.ledges;
+    EdgeMem<AS> L; if constexpr (AS == 3) L.p = (typename EdgeMem<AS>::W*)pc_dyn; else L.p = (typename EdgeMem<AS>::W*)a.ledges;
     if (threadIdx.x < 16) sh.T[threadIdx.x] = a.T[threadIdx.x];
     if (threadIdx.x < 4) sh.work[threadIdx.x] = 0;
     __syncthreads();
@@ -743,9 +767,9 @@ static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const voi
 hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
 {
     PnpSolveArgs a = a_in; size_t dyn;
-    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel));
+    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel<3>));
     if (e != hipSuccess) return e;
-    pnp_solve_kernel<<<1, PC_T, dyn, s>>>(a);
+    if (a.edges_in_lds) pnp_solve_kernel<3><<<1, PC_T, dyn, s>>>(a); else pnp_solve_kernel<1><<<1, PC_T, 0, s>>>(a);
     return hipGetLastError();
 }
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
@@ -754,14 +778,14 @@ hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
     PnpChainArgs a = a_in; size_t dyn;
     const int G = a.blocks > 0 ? a.blocks : 1;
-    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, G > 1 ? reinterpret_cast<const void*>(pnp_chain_kernel<true>) : reinterpret_cast<const void*>(pnp_chain_kernel<false>));
+    hipError_t e = pc_dyn_size((size_t)a.R * a.cap, &a.edges_in_lds, &dyn, G > 1 ? reinterpret_cast<const void*>(pnp_chain_kernel<true, 3>) : reinterpret_cast<const void*>(pnp_chain_kernel<false, 3>));
     if (e != hipSuccess) return e;
     if (G > 1) {                                               // the exchange ring and the time-out word: zero before every launch (tags count passes within a launch)
         e = hipMemsetAsync(a.xchg, 0, k_pnp_xchg_bytes(), s);
         if (e != hipSuccess) return e;
         const char* tv = getenv("SSM_PNP_TEST_TIMEOUT");                                        // tests: the time-out word set from the start -> the host's retry path
         if (tv && atoi(tv) != 0) { e = hipMemsetAsync(a.xfail, 1, 4, s); if (e != hipSuccess) return e; }
-        pnp_chain_kernel<true><<<G, PC_T, dyn, s>>>(a);
-    } else pnp_chain_kernel<false><<<1, PC_T, dyn, s>>>(a);
+        if (a.edges_in_lds) pnp_chain_kernel<true, 3><<<G, PC_T, dyn, s>>>(a); else pnp_chain_kernel<true, 1><<<G, PC_T, 0, s>>>(a);
+    } else { if (a.edges_in_lds) pnp_chain_kernel<false, 3><<<1, PC_T, dyn, s>>>(a); else pnp_chain_kernel<false, 1><<<1, PC_T, 0, s>>>(a); }
     return hipGetLastError();
 }
