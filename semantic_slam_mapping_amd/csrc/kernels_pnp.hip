@@ -587,24 +587,25 @@ __device__ __forceinline__ int pc_solve(const float* img, const float* obj, int 
         // pnp.cpp:74-93 for all edges at once: the reads of inliers[e->id()] see the flags of before this loop (an earlier edge's writes never land on a
         // later edge's id: ids are unique and a position never exceeds its id); of the writes, a passing edge's inliers[position] = true comes after the
         // failing write of the edge whose id equals that position (position <= id), so: decide, clear, then set
-        int nout = 0;
-        for (int i = threadIdx.x; i < ne; i += PC_T) {
+        // (the decisions of a thread's edges -- at most 64: ne <= 65535 -- stay in a register between the three steps; `dec` is no longer written)
+        int nout = 0; unsigned long long decm = 0ull;
+        for (int i = threadIdx.x, j = 0; i < ne; i += PC_T, j++) {
             LEdge l = L.ld(i);
             Edge e = pc_expand(l);
-            const double2 er = err[i]; e.e0 = er.x; e.e1 = er.y;
             // (an ACTIVE edge's stored error is edge_error at this P already -- lm_optimize ends with a chi2 pass over the active edges -- so recomputing it changes
             // nothing in the one-block form; in the cluster form only the block that owns the edge's lane has stored it)
-            if constexpr (CL) { if (inl[e.id] || !(l.meta & LE_LEVEL)) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); } }
-            else { if (inl[e.id]) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); } }
+            const bool redo = CL ? (inl[e.id] || !(l.meta & LE_LEVEL)) : (inl[e.id] != 0);
+            if (redo) { edge_error(e, P, cam); err[i] = make_double2(e.e0, e.e1); }
+            else { const double2 er = err[i]; e.e0 = er.x; e.e1 = er.y; }
             const bool out = edge_chi2(e) > 5.991;
             l.meta = (l.meta & ~LE_LEVEL) | (out ? LE_LEVEL : 0u);
             if (it == 2) l.meta &= ~LE_ROBUST;
-            L.set_meta(i, l.meta); dec[i] = out ? 1 : 0; nout += out;
+            L.set_meta(i, l.meta); decm |= (unsigned long long)(out ? 1 : 0) << j; nout += out;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < ne; i += PC_T) if (dec[i]) inl[L.meta(i) & 0xFFFFu] = 0;
+        for (int i = threadIdx.x, j = 0; i < ne; i += PC_T, j++) if ((decm >> j) & 1ull) inl[L.meta(i) & 0xFFFFu] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < ne; i += PC_T) if (!dec[i]) inl[i] = 1;
+        for (int i = threadIdx.x, j = 0; i < ne; i += PC_T, j++) if (!((decm >> j) & 1ull)) inl[i] = 1;
         __syncthreads();
         // good -= the number of failing edges (block sum of nout)
 #pragma unroll
