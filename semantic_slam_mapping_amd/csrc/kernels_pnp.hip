@@ -19,6 +19,8 @@ using namespace ssm_pnp;
 #define PC_T 1024
 #define PC_SPEC 8                 // trials of a rejected streak evaluated together (pc_optimize)
 #define PC_RBUF 3072              // doubles (24 KB of LDS)
+#define PC_NVAL 64                // sums a block keeps per contract group
+#define PC_SYS2 (NACC + 1 + PC_SPEC)   // first column of the speculative system
 #ifndef PC_FIRST_SPEC
 #define PC_FIRST_SPEC 2           // cluster form: trials solved and evaluated with an iteration's first trial (1 = the first trial alone).  Measured, ms of chain per 400
                                   // frames: 1: 168.4 - 170.9, 2: 166.5, 4: 167.3, 8: 184.7 -- the candidates behind an accepted first trial are wasted work
@@ -74,8 +76,8 @@ struct PcShared {
 #ifdef SSM_PNP_PROF
     long long prof[32];
 #endif
-    double red[NGROUP][NACC + 1 + PC_SPEC];
-    double tot[NACC + 1 + PC_SPEC];
+    double red[NGROUP][PC_NVAL];       // [group][value]: 0 .. 27 the system at P (H, b, chi2), 28 .. 35 the chi2 of a round's candidates, 36 .. 63 the system at the first candidate (pc_chi_spec_build)
+    double tot[PC_NVAL];
     // a rejected Levenberg trial is followed by trials whose damping is known in advance (lambda <- lambda nu, nu <- 2 nu until one is accepted): wave c solves
     // candidate c of such a streak and ONE pass over the edges evaluates all of them (pc_chi_spec)
     struct { double x[6]; Pose P; int solved, pad; } spec[PC_SPEC];
@@ -84,7 +86,7 @@ struct PcShared {
     Pose P, saved, init;          // the estimate wave 0 publishes for the next pass; the one before the trial; the round's start value
     double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
-    int cont, term;               // loop controls of the Levenberg iteration, decided by wave 0
+    int cont, term, acc0;         // loop controls of the Levenberg iteration, decided by wave 0 (acc0: the iteration's first trial was accepted)
     long long work[4];            // thread 0: fused passes, chi2 passes, active edges evaluated by each kind (ssm_tracker_work: the numerator of bench.py's pose-loop roofline)
     // the cluster form (round 4, gridDim.x = G > 1 blocks per chain): this block evaluates the edges of lanes [b 1024 / G, (b + 1) 1024 / G) only and the G blocks
     // trade their groups' partial sums through tagged granules in global memory (pc_lane_sum)
@@ -133,7 +135,7 @@ __device__ __forceinline__ void pc_rs_step(double* a, bool up)
 // bit k selects (28 -> 14 -> 7 (+ 1 pad) -> 4 -> 2 -> 1) -- 29 additions and 31 exchanges per lane instead of 168 and 168 (the butterfly was 45 % of the
 // fused pass's instructions and kept the LDS pipe busy with 336 ds_bpermute per wave).  Lane 0 of each wave (one value) / the lane that ends up with value v
 // publishes the group sum, threads 0 .. NV-1 add the 16 group sums in group order.
-template <int NV, int OFF, bool CL> __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv = NV);
+template <int NV, int OFF, bool CL> __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv = NV, int skip_lo = 0, int skip_hi = 0);
 template <int NV, int OFF, bool CL>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
@@ -175,38 +177,40 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 }
 // the block part of pc_lane_sum: sh.red[group][OFF .. OFF + NV) hold the group sums of this block's lanes (written by whoever computed them)
 template <int NV, int OFF, bool CL>
-__device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv <= NV: the values in use (block-uniform; the others are neither exchanged nor summed)
+__device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv, int skip_lo, int skip_hi)      // nv <= NV: the values in use (block-uniform; the others, and those in [skip_lo, skip_hi), are neither exchanged nor summed)
 {
     PROF2_T0
     constexpr int PB = NV == 28 ? 8 : 16;
+    constexpr int VS = NV > 32 ? 6 : 5;                                          // thread (g, v) = (tid >> VS, tid & (2^VS - 1)) where a group's values share a wave
+    static_assert(NV <= 64, "a group's values: at most 64 (the exchange ring's stride)");
     // ROWSCAN (the passes of few values: 16 nv <= 128 threads): thread (v, g) = (tid / 16, tid % 16) takes group g's sum of value v and the row adds them (below);
     // otherwise thread (g, v) = (tid / 32, tid % 32) brings the sum to LDS and thread v walks the sixteen.  (The row form for the 28-value pass too: measured slower)
     constexpr bool ROWSCAN = NV <= 8;
     static_assert(NGROUP == 16, "a DPP row is the sixteen groups");
     __syncthreads();
     PROF2(PB + 0)
-    const int g = ROWSCAN ? (int)(threadIdx.x & 15) : (int)(threadIdx.x >> 5), v = ROWSCAN ? (int)(threadIdx.x >> 4) : (int)(threadIdx.x & 31);
-    const bool pollv = g < NGROUP && v < nv;
+    const int g = ROWSCAN ? (int)(threadIdx.x & 15) : (int)(threadIdx.x >> VS), v = ROWSCAN ? (int)(threadIdx.x >> 4) : (int)(threadIdx.x & ((1 << VS) - 1));
+    const bool pollv = g < NGROUP && v < nv && !(v >= skip_lo && v < skip_hi);
     double r = 0.0; unsigned seq = 0;
     if constexpr (CL) {
         // every block holds the group sums of its own waves; a sum is published as two 8-byte {pass tag, 32 bits} granules (one agent-scope store each: the data is the
         // flag, cdna_hip_programming.md G16 R2) and every block polls all sixteen groups' granules, so that the ordered sum below sees the same sixteen numbers everywhere.
         // Four ring slots by pass number; a block can be at most one pass ahead of another (it needs everybody's sums to finish a pass).
-        const int gpb = NGROUP / (int)gridDim.x, pg = threadIdx.x >> 5, pv = threadIdx.x & 31;
+        const int gpb = NGROUP / (int)gridDim.x, pg = threadIdx.x >> VS, pv = threadIdx.x & ((1 << VS) - 1);
         seq = sh.xseq; const unsigned long long tag = (unsigned long long)(seq + 1) << 32;
         typedef __attribute__((address_space(1))) unsigned long long gu64;          // (global_load / global_store, not flat: the ring is device memory)
-        gu64* slot = (gu64*)sh.xmb + (size_t)(seq & 3u) * NGROUP * 32 * 2;
-        if (pg < gpb && pv < nv) {
+        gu64* slot = (gu64*)sh.xmb + (size_t)(seq & 3u) * NGROUP * 64 * 2;
+        if (pg < gpb && pv < nv && !(pv >= skip_lo && pv < skip_hi)) {
             const int gg = (int)blockIdx.x * gpb + pg;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + pv]);
-            __hip_atomic_store(slot + (size_t)(gg * 32 + pv) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + (size_t)(gg * 32 + pv) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (size_t)(gg * 64 + pv) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + (size_t)(gg * 64 + pv) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PROF2(PB + 1)
         if (pollv) {
             // two polls in flight, half a round trip apart (a poll that leaves just before the granule lands costs a whole round trip of ~1.2 k clocks otherwise):
             // the second leaves ~600 clocks behind the first, after that each is re-issued when its answer is in, which keeps the spacing
-            const gu64* q = slot + (size_t)(g * 32 + v) * 2;
+            const gu64* q = slot + (size_t)(g * 64 + v) * 2;
             unsigned long long lo = 0, hi = 0; bool ok = false;
             unsigned long long lo_a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi_a = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_sleep(9);
@@ -245,7 +249,7 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv)      // nv 
         __syncthreads();
         if constexpr (CL) { if (threadIdx.x == 0) sh.xseq = seq + 1; }            // (read again behind the next call's first barrier)
     } else {
-        if ((int)threadIdx.x < nv) { const int vv = OFF + threadIdx.x; double s = sh.red[0][vv]; for (int gq = 1; gq < NGROUP; gq++) s = s + sh.red[gq][vv]; sh.tot[vv] = s; }
+        if ((int)threadIdx.x < nv && !((int)threadIdx.x >= skip_lo && (int)threadIdx.x < skip_hi)) { const int vv = OFF + threadIdx.x; double s = sh.red[0][vv]; for (int gq = 1; gq < NGROUP; gq++) s = s + sh.red[gq][vv]; sh.tot[vv] = s; }
         __syncthreads();
     }
     PROF2(PB + 4)
@@ -381,18 +385,41 @@ __device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pos
         }
     }
 }
+// (the edge's error is not stored: in the cluster form pc_solve recomputes every active edge's error after lm_optimize, and nothing reads one before)
 template <int PART, class EM>
-__device__ __forceinline__ void pc_build_part(const EM L, double2* err, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+__device__ __forceinline__ void pc_build_part(const EM L, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
 {
     for (int i = lane0; i < ne; i += PC_T) {
         const LEdge l = L.ld(i);
         if (!(l.meta & LE_LEVEL)) {
             Edge e = pc_expand(l);
             const double rho = edge_rho(e, P, k, delta);
-            if constexpr (PART == PC_CHI_PART) { acc[pc_part_slot(PC_CHI_PART, NACC)] += rho; err[i] = make_double2(e.e0, e.e1); }
+            if constexpr (PART == PC_CHI_PART) acc[pc_part_slot(PC_CHI_PART, NACC)] += rho;
             pc_edge_accumulate_part<PART>(e, P, k, delta, acc);
         }
     }
+}
+// the sums of `part` at P for this wave's group gg -> sh.red[gg][OFF + q] (the part's walk, then the group tree of eight values: pc_lane_sum, NV == 8)
+template <int OFF, class EM>
+__device__ __forceinline__ void pc_build_group(const EM L, int ne, int part, int gg, const Pose& P, const Camera& k, double delta, PcShared& sh)
+{
+    const int lane = threadIdx.x & 63, lane0 = gg * GROUP + lane;
+    double a[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = 0.0;
+    switch (part) {
+        case 0: pc_build_part<0>(L, ne, lane0, P, k, delta, a); break;
+        case 1: pc_build_part<1>(L, ne, lane0, P, k, delta, a); break;
+        case 2: pc_build_part<2>(L, ne, lane0, P, k, delta, a); break;
+        default: pc_build_part<3>(L, ne, lane0, P, k, delta, a); break;
+    }
+    // lane l < 8 ends with slot (l & 1) 4 + ((l >> 1) & 1) 2 + ((l >> 2) & 1)
+    pc_rs_step<1, 4>(a, lane & 1);
+    pc_rs_step<2, 2>(a, lane & 2);
+    pc_rs_step<4, 1>(a, lane & 4);
+    double t = a[0];
+    t = t + pc_xor_f64<8, false>(t); t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
+    if (lane < 8) { const int q = PC_PART_Q[part][(lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)]; if (q >= 0) sh.red[gg][OFF + q] = t; }
 }
 template <bool CL, class EM>
 __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
@@ -401,25 +428,8 @@ __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, c
     if constexpr (CL) {
         const int G = (int)gridDim.x, gpb = NGROUP / G;
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
-        const int gg = (int)blockIdx.x * gpb + gi, lane0 = gg * GROUP + lane;                               // contract group / lane of this wave's edges
-        for (int part = set; part < 4; part += G) {                                                         // (G = 2: two parts per wave)
-            double a[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) a[q] = 0.0;
-            switch (part) {
-                case 0: pc_build_part<0>(L, err, ne, lane0, P, k, delta, a); break;
-                case 1: pc_build_part<1>(L, err, ne, lane0, P, k, delta, a); break;
-                case 2: pc_build_part<2>(L, err, ne, lane0, P, k, delta, a); break;
-                default: pc_build_part<3>(L, err, ne, lane0, P, k, delta, a); break;
-            }
-            // the group tree of eight values (pc_lane_sum, NV == 8): lane l < 8 ends with slot (l & 1) 4 + ((l >> 1) & 1) 2 + ((l >> 2) & 1)
-            pc_rs_step<1, 4>(a, lane & 1);
-            pc_rs_step<2, 2>(a, lane & 2);
-            pc_rs_step<4, 1>(a, lane & 4);
-            double t = a[0];
-            t = t + pc_xor_f64<8, false>(t); t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
-            if (lane < 8) { const int q = PC_PART_Q[part][(lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)]; if (q >= 0) sh.red[gg][q] = t; }
-        }
+        const int gg = (int)blockIdx.x * gpb + gi;                                                          // contract group of this wave's edges
+        for (int part = set; part < 4; part += G) pc_build_group<0>(L, ne, part, gg, P, k, delta, sh);       // (G = 2: two parts per wave)
         PROF2(24)
         pc_lane_finish<NACC + 1, 0, CL>(sh);
         return;
@@ -432,6 +442,35 @@ __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, c
         if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); acc[NACC] += edge_rho(e, P, k, delta); edge_accumulate(e, P, k, delta, acc); err[i] = make_double2(e.e0, e.e1); }
     }
     pc_lane_sum<NACC + 1, 0, CL>(acc, sh);
+}
+// The first round of an iteration in the eight-block cluster form (round 5): the chi2 of its candidates AND the normal equations at the FIRST candidate's estimate in one
+// pass.  The first trial is accepted in two iterations out of three (68 % on the bench's stream), and the iteration that follows an accepted trial starts with exactly
+// this system -- chi2_build at the estimate the trial produced -- so building it here, on waves that a chi2 pass of two candidates leaves idle, takes a whole fused pass
+// and its exchange off the critical path of those iterations; a rejected first trial drops it.  Waves (part 0 .. 3, group) walk the group's edges at sh.spec[0].P for
+// the sums of their part -> columns PC_SYS2 + q (the part with chi2 also fills the first candidate's column NACC + 1: the same sum); waves (4 .. 7, group) walk them
+// for candidates 1 .. 4's chi2 (a lane's terms in slot order, then the group tree); ONE exchange carries all of it.  Same sums, same order, same bits as the two passes.
+template <class EM>
+__device__ __forceinline__ void pc_chi_spec_build(const EM L, int ne, int n, const Camera& k, double delta, PcShared& sh)
+{
+    PROF2_T0
+    const int gpb = NGROUP / 8;                                                  // (the caller has checked gridDim.x == 8)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
+    const int gg = (int)blockIdx.x * gpb + gi;
+    if (set < 4) {
+        pc_build_group<PC_SYS2>(L, ne, set, gg, sh.spec[0].P, k, delta, sh);
+        if (set == PC_CHI_PART && lane == 0) sh.red[gg][NACC + 1] = sh.red[gg][PC_SYS2 + NACC];      // (lane 7 of this wave wrote it a moment ago: LDS is in order within a wave)
+    } else {
+        const int c = set - 3;
+        if (c < n) {
+            double a = 0.0;
+            for (int i = gg * GROUP + lane; i < ne; i += PC_T) { const LEdge l = L.ld(i); if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); a += edge_rho(e, sh.spec[c].P, k, delta); } }
+            a = a + pc_xor_f64<1, true>(a); a = a + pc_xor_f64<2, true>(a); a = a + pc_xor_f64<4, true>(a);
+            a = a + pc_xor_f64<8, true>(a); a = a + pc_xor_f64<16, true>(a); a = a + pc_xor_f64<32, true>(a);
+            if (lane == 0) sh.red[gg][NACC + 1 + c] = a;
+        }
+    }
+    PROF2(25)
+    pc_lane_finish<PC_SPEC + NACC + 1, NACC + 1, true>(sh, PC_SPEC + NACC + 1, n, PC_SPEC);      // values 0 .. n-1 (the candidates) and 8 .. 35 (the system)
 }
 // solve_ldlt of pnp_core.h by the first six lanes of a wave, ONE ROW of L each: the same operations in the same order -- lane i forms
 // s = A[i][j] - sum_k (L[i][k] L[j][k]) D[k] for every column j (lane j's s is the pivot d_j: the diagonal's formula is the off-diagonal one with i = j), divides by the
@@ -496,10 +535,16 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
     LmState st; st.lambda = 0; st.nu = 2;                                        // (meaningful in wave 0 only)
     double chi = 0, x[6], gain = 0; int trials = 0; bool solved = false;
     const double* Hl = sh.tot; const double* b = sh.tot + 21;                 // the system stays in LDS over the trials (registers are short here)
+    // (SPECB: the first round of an iteration also builds the system at its first candidate -- pc_chi_spec_build; have_sys: sh.tot[0 .. 27] already hold the system at P)
+    const bool SPECB = CL && gridDim.x == 8 && PC_FIRST_SPEC <= 5;
+    bool have_sys = false;
     PROF_T0
     for (int it = 0; it < iterations; it++) {
-        pc_chi_build<CL>(L, err, ne, P, k, delta, sh);
-        if (threadIdx.x == 0) { sh.work[0] += 1; sh.work[2] += nact; }
+        if (!have_sys) {
+            pc_chi_build<CL>(L, err, ne, P, k, delta, sh);
+            if (threadIdx.x == 0) { sh.work[0] += 1; sh.work[2] += nact; }
+        }
+        have_sys = false;
         PROF(1) PROF_CNT(6)
         if (w0) {
             chi = sh.tot[NACC];
@@ -513,8 +558,9 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
         // trial at a time.  (round 5: a converged optimize spends its time in streaks of seven or more rejections: ~54 solve -> pass -> update rounds per frame became ~36)
         // (the cluster form has idle waves for the algebra and for the pass -- see pc_chi_spec -- so it solves the trials that WOULD follow a rejection together with the
         // first one: PC_FIRST_SPEC candidates; the one-block form pays for every candidate with a walk over its edges and keeps the first trial alone)
-        if (threadIdx.x == 0) { sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = CL ? PC_FIRST_SPEC : 1; }
+        if (threadIdx.x == 0) { sh.spec_lambda = st.lambda; sh.spec_nu = st.nu; sh.spec_n = CL ? PC_FIRST_SPEC : 1; sh.acc0 = 0; }
         __syncthreads();
+        bool first = true, built = false;
         for (;;) {
             const int nsp = sh.spec_n;
             const int wv = threadIdx.x >> 6;
@@ -529,15 +575,25 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
             }
             __syncthreads();
             PROF(2)
-            pc_chi_spec<CL>(L, ne, nsp, k, delta, sh);
-            if (threadIdx.x == 0) { sh.work[1] += nsp; sh.work[3] += (long long)nsp * nact; }
+            if constexpr (CL) {
+                if (SPECB && first && it + 1 < iterations) {
+                    pc_chi_spec_build(L, ne, nsp, k, delta, sh); built = true;
+                    if (threadIdx.x == 0) { sh.work[0] += 1; sh.work[2] += nact; sh.work[1] += nsp - 1; sh.work[3] += (long long)(nsp - 1) * nact; }
+                } else {
+                    pc_chi_spec<CL>(L, ne, nsp, k, delta, sh);
+                    if (threadIdx.x == 0) { sh.work[1] += nsp; sh.work[3] += (long long)nsp * nact; }
+                }
+            } else {
+                pc_chi_spec<CL>(L, ne, nsp, k, delta, sh);
+                if (threadIdx.x == 0) { sh.work[1] += nsp; sh.work[3] += (long long)nsp * nact; }
+            }
             PROF(3) PROF_CNT(7)
             if (w0) {
                 bool cont = true, brk = false;
                 for (int c = 0; c < nsp && cont; c++) {
                     for (int q = 0; q < 6; q++) x[q] = sh.spec[c].x[q];
                     const double chi_new = sh.tot[NACC + 1 + c];
-                    if (lm_update(st, chi, chi_new, sh.spec[c].solved != 0, x, b, gain)) { chi = chi_new; if (threadIdx.x == 0) sh.P = sh.spec[c].P; }
+                    if (lm_update(st, chi, chi_new, sh.spec[c].solved != 0, x, b, gain)) { chi = chi_new; if (threadIdx.x == 0) { sh.P = sh.spec[c].P; if (first && c == 0) sh.acc0 = 1; } }
                     else if (!isfinite(st.lambda)) brk = true;
                     if (!brk) trials++;
                     cont = !brk && gain < 0 && trials < 10;
@@ -547,11 +603,18 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
             }
             __syncthreads();
             PROF(4)
+            first = false;
             if (!sh.cont) break;
         }
         const int term = sh.term;
-        __syncthreads();                                                         // (sh.cont / sh.term are rewritten by the next iteration)
+        const bool take = built && sh.acc0 != 0;                                 // the first trial was accepted: the system built beside it is the next iteration's
+        __syncthreads();                                                         // (sh.cont / sh.term / sh.acc0 are rewritten by the next iteration)
         if (term) break;
+        if (take) {
+            if (threadIdx.x < NACC + 1) sh.tot[threadIdx.x] = sh.tot[PC_SYS2 + threadIdx.x];
+            __syncthreads();
+            have_sys = true;
+        }
     }
     // "the active edges carry the error at the final estimate": in the cluster form pc_solve recomputes every active edge's error itself (a block has only
     // stored the errors of its own lanes), so the pass -- whose sum nobody reads -- is the one-block form's only
@@ -774,7 +837,7 @@ hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
     return hipGetLastError();
 }
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }
-size_t k_pnp_xchg_bytes(void) { return (size_t)4 * NGROUP * 32 * 2 * 8 + 64; }      // four ring slots x 16 groups x 32 values x two granules, + the time-out word
+size_t k_pnp_xchg_bytes(void) { return (size_t)4 * NGROUP * 64 * 2 * 8 + 64; }      // four ring slots x 16 groups x 64 values x two granules, + the time-out word
 hipError_t k_pnp_chain(const PnpChainArgs& a_in, hipStream_t s)
 {
     PnpChainArgs a = a_in; size_t dyn;
