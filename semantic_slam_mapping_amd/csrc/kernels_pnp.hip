@@ -19,11 +19,15 @@ using namespace ssm_pnp;
 #define PC_T 1024
 #define PC_SPEC 8                 // trials of a rejected streak evaluated together (pc_optimize)
 #define PC_RBUF 3072              // doubles (24 KB of LDS)
+#ifndef PC_SB_ROWSCAN
+#define PC_SB_ROWSCAN false     // (the DPP-row sum for the 36-value exchange of pc_chi_spec_build: 148 ms against 141)
+#endif
 #define PC_NVAL 64                // sums a block keeps per contract group
 #define PC_SYS2 (NACC + 1 + PC_SPEC)   // first column of the speculative system
 #ifndef PC_FIRST_SPEC
-#define PC_FIRST_SPEC 2           // cluster form: trials solved and evaluated with an iteration's first trial (1 = the first trial alone).  Measured, ms of chain per 400
-                                  // frames: 1: 168.4 - 170.9, 2: 166.5, 4: 167.3, 8: 184.7 -- the candidates behind an accepted first trial are wasted work
+#define PC_FIRST_SPEC 3           // cluster form: trials solved and evaluated with an iteration's first trial (1 = the first trial alone).  Measured, ms of chain per 400
+                                  // frames, before the first round also built the next system: 1: 168.4 - 170.9, 2: 166.5, 4: 167.3, 8: 184.7 -- the candidates behind an
+                                  // accepted first trial are wasted work; with pc_chi_spec_build (their walks run on waves the system's parts leave idle): 2: 141.5, 3: 137.7, 4: 139.7
 #endif
 // an edge as the passes read it: 24 bytes (the Edge of pnp_core.h is 72; its error lives in a separate global array).  meta = id | level << 16 | robust << 17
 struct LEdge { float X[3], u, v; uint32_t meta; };
@@ -135,7 +139,7 @@ __device__ __forceinline__ void pc_rs_step(double* a, bool up)
 // bit k selects (28 -> 14 -> 7 (+ 1 pad) -> 4 -> 2 -> 1) -- 29 additions and 31 exchanges per lane instead of 168 and 168 (the butterfly was 45 % of the
 // fused pass's instructions and kept the LDS pipe busy with 336 ds_bpermute per wave).  Lane 0 of each wave (one value) / the lane that ends up with value v
 // publishes the group sum, threads 0 .. NV-1 add the 16 group sums in group order.
-template <int NV, int OFF, bool CL> __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv = NV, int skip_lo = 0, int skip_hi = 0);
+template <int NV, int OFF, bool CL, bool ROWSCAN = (NV <= 8)> __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv = NV, int skip_lo = 0, int skip_hi = 0);
 template <int NV, int OFF, bool CL>
 __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
 {
@@ -176,7 +180,7 @@ __device__ __forceinline__ void pc_lane_sum(double (&acc)[NV], PcShared& sh)
     pc_lane_finish<NV, OFF, CL>(sh);
 }
 // the block part of pc_lane_sum: sh.red[group][OFF .. OFF + NV) hold the group sums of this block's lanes (written by whoever computed them)
-template <int NV, int OFF, bool CL>
+template <int NV, int OFF, bool CL, bool ROWSCAN>
 __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv, int skip_lo, int skip_hi)      // nv <= NV: the values in use (block-uniform; the others, and those in [skip_lo, skip_hi), are neither exchanged nor summed)
 {
     PROF2_T0
@@ -185,7 +189,6 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv, int skip_lo
     static_assert(NV <= 64, "a group's values: at most 64 (the exchange ring's stride)");
     // ROWSCAN (the passes of few values: 16 nv <= 128 threads): thread (v, g) = (tid / 16, tid % 16) takes group g's sum of value v and the row adds them (below);
     // otherwise thread (g, v) = (tid / 32, tid % 32) brings the sum to LDS and thread v walks the sixteen.  (The row form for the 28-value pass too: measured slower)
-    constexpr bool ROWSCAN = NV <= 8;
     static_assert(NGROUP == 16, "a DPP row is the sixteen groups");
     __syncthreads();
     PROF2(PB + 0)
@@ -203,8 +206,9 @@ __device__ __forceinline__ void pc_lane_finish(PcShared& sh, int nv, int skip_lo
         if (pg < gpb && pv < nv && !(pv >= skip_lo && pv < skip_hi)) {
             const int gg = (int)blockIdx.x * gpb + pg;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.red[gg][OFF + pv]);
-            __hip_atomic_store(slot + (size_t)(gg * 64 + pv) * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + (size_t)(gg * 64 + pv) * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const size_t gi_ = (size_t)(gg * 64 + pv);
+            __hip_atomic_store(slot + gi_ * 2, tag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + gi_ * 2 + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PROF2(PB + 1)
         if (pollv) {
@@ -470,7 +474,7 @@ __device__ __forceinline__ void pc_chi_spec_build(const EM L, int ne, int n, con
         }
     }
     PROF2(25)
-    pc_lane_finish<PC_SPEC + NACC + 1, NACC + 1, true>(sh, PC_SPEC + NACC + 1, n, PC_SPEC);      // values 0 .. n-1 (the candidates) and 8 .. 35 (the system)
+    pc_lane_finish<PC_SPEC + NACC + 1, NACC + 1, true, PC_SB_ROWSCAN>(sh, PC_SPEC + NACC + 1, n, PC_SPEC);      // values 0 .. n-1 (the candidates) and 8 .. 35 (the system)
 }
 // solve_ldlt of pnp_core.h by the first six lanes of a wave, ONE ROW of L each: the same operations in the same order -- lane i forms
 // s = A[i][j] - sum_k (L[i][k] L[j][k]) D[k] for every column j (lane j's s is the pivot d_j: the diagonal's formula is the off-diagonal one with i = j), divides by the
