@@ -359,13 +359,25 @@ __device__ __forceinline__ void pc_chi_spec(const EM L, int ne, int n, const Cam
 //   part 0: H rows 0-1 + b0 b1 b2;  part 1: H rows 2-3 + b3;  part 2: H row 4 + b4 b5 + chi2 (and the edge's stored error);  part 3: H row 5
 // (balanced by the products and additions each costs: row 3 only has row 0's terms and row 4 only row 1's -- the literal zeros of J -- ; 42 / 40 / 28 / 42 with the
 // Jacobian entries each needs; rows 0-2 + b0 b1 | row 3 + b2 b3 + chi2 | row 4 + b4 | row 5 + b5 was 52 / 28 / 23 / 46)
+// PC_NPARTS = 2 (a wave's 14 sums: H rows 0-3 + b0 .. b3 | H rows 4-5 + b4 b5 + chi2; sixteen-value group tree) re-computes an edge's error, Jacobian and weight twice
+// instead of four times: the walks are bound by instruction issue once the first round's candidate walks share the SIMDs (pc_chi_spec_build).
+#ifndef PC_NPARTS
+#define PC_NPARTS 2
+#endif
+#if PC_NPARTS == 4
+#define PC_PSLOTS 8
 #define PC_CHI_PART 2
 __device__ constexpr int PC_PART_Q[4][8] = {{0, 1, 2, 21, 22, 23, -1, -1}, {3, 4, 5, 6, 7, 8, 9, 24}, {10, 11, 12, 13, 14, 25, 26, NACC}, {15, 16, 17, 18, 19, 20, -1, -1}};
-constexpr int pc_part_slot(int part, int q) { for (int k = 0; k < 8; k++) if (PC_PART_Q[part][k] == q) return k; return -1; }
+#else
+#define PC_PSLOTS 16
+#define PC_CHI_PART 1
+__device__ constexpr int PC_PART_Q[2][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, -1, -1}, {10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 25, 26, NACC, -1, -1}};
+#endif
+constexpr int pc_part_slot(int part, int q) { for (int k = 0; k < PC_PSLOTS; k++) if (PC_PART_Q[part][k] == q) return k; return -1; }
 // edge_accumulate of pnp_core.h restricted to the sums of PART: the same expressions in the same order (the loops unroll, the tests on q fold away and the
 // Jacobian entries a part does not use are never computed)
 template <int PART>
-__device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+__device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pose& P, const Camera& k, double delta, double (&acc)[PC_PSLOTS])
 {
     double p[3]; edge_map(e, P, p);
     const double x = p[0], y = p[1], iz = 1.0 / p[2], iz2 = iz * iz;
@@ -391,7 +403,7 @@ __device__ __forceinline__ void pc_edge_accumulate_part(const Edge& e, const Pos
 }
 // (the edge's error is not stored: in the cluster form pc_solve recomputes every active edge's error after lm_optimize, and nothing reads one before)
 template <int PART, class EM>
-__device__ __forceinline__ void pc_build_part(const EM L, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[8])
+__device__ __forceinline__ void pc_build_part(const EM L, int ne, int lane0, const Pose& P, const Camera& k, double delta, double (&acc)[PC_PSLOTS])
 {
     for (int i = lane0; i < ne; i += PC_T) {
         const LEdge l = L.ld(i);
@@ -403,14 +415,15 @@ __device__ __forceinline__ void pc_build_part(const EM L, int ne, int lane0, con
         }
     }
 }
-// the sums of `part` at P for this wave's group gg -> sh.red[gg][OFF + q] (the part's walk, then the group tree of eight values: pc_lane_sum, NV == 8)
+// the sums of `part` at P for this wave's group gg -> sh.red[gg][OFF + q] (the part's walk, then the group tree of its values: the halving of pc_lane_sum)
 template <int OFF, class EM>
 __device__ __forceinline__ void pc_build_group(const EM L, int ne, int part, int gg, const Pose& P, const Camera& k, double delta, PcShared& sh)
 {
     const int lane = threadIdx.x & 63, lane0 = gg * GROUP + lane;
-    double a[8];
+    double a[PC_PSLOTS];
 #pragma unroll
-    for (int q = 0; q < 8; q++) a[q] = 0.0;
+    for (int q = 0; q < PC_PSLOTS; q++) a[q] = 0.0;
+#if PC_NPARTS == 4
     switch (part) {
         case 0: pc_build_part<0>(L, ne, lane0, P, k, delta, a); break;
         case 1: pc_build_part<1>(L, ne, lane0, P, k, delta, a); break;
@@ -424,6 +437,17 @@ __device__ __forceinline__ void pc_build_group(const EM L, int ne, int part, int
     double t = a[0];
     t = t + pc_xor_f64<8, false>(t); t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
     if (lane < 8) { const int q = PC_PART_Q[part][(lane & 1) * 4 + ((lane >> 1) & 1) * 2 + ((lane >> 2) & 1)]; if (q >= 0) sh.red[gg][OFF + q] = t; }
+#else
+    if (part == 0) pc_build_part<0>(L, ne, lane0, P, k, delta, a); else pc_build_part<1>(L, ne, lane0, P, k, delta, a);
+    // lane l < 16 ends with slot (l & 1) 8 + ((l >> 1) & 1) 4 + ((l >> 2) & 1) 2 + ((l >> 3) & 1)
+    pc_rs_step<1, 8>(a, lane & 1);
+    pc_rs_step<2, 4>(a, lane & 2);
+    pc_rs_step<4, 2>(a, lane & 4);
+    pc_rs_step<8, 1>(a, lane & 8);
+    double t = a[0];
+    t = t + pc_xor_f64<16, false>(t); t = t + pc_xor_f64<32, false>(t);
+    if (lane < 16) { const int q = PC_PART_Q[part][(lane & 1) * 8 + ((lane >> 1) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1)]; if (q >= 0) sh.red[gg][OFF + q] = t; }
+#endif
 }
 template <bool CL, class EM>
 __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, const Pose& P, const Camera& k, double delta, PcShared& sh)
@@ -433,7 +457,7 @@ __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, c
         const int G = (int)gridDim.x, gpb = NGROUP / G;
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
         const int gg = (int)blockIdx.x * gpb + gi;                                                          // contract group of this wave's edges
-        for (int part = set; part < 4; part += G) pc_build_group<0>(L, ne, part, gg, P, k, delta, sh);       // (G = 2: two parts per wave)
+        for (int part = set; part < PC_NPARTS; part += G) pc_build_group<0>(L, ne, part, gg, P, k, delta, sh);       // (G = 2: two parts per wave)
         PROF2(24)
         pc_lane_finish<NACC + 1, 0, CL>(sh);
         return;
@@ -450,9 +474,9 @@ __device__ __forceinline__ void pc_chi_build(const EM L, double2* err, int ne, c
 // The first round of an iteration in the eight-block cluster form (round 5): the chi2 of its candidates AND the normal equations at the FIRST candidate's estimate in one
 // pass.  The first trial is accepted in two iterations out of three (68 % on the bench's stream), and the iteration that follows an accepted trial starts with exactly
 // this system -- chi2_build at the estimate the trial produced -- so building it here, on waves that a chi2 pass of two candidates leaves idle, takes a whole fused pass
-// and its exchange off the critical path of those iterations; a rejected first trial drops it.  Waves (part 0 .. 3, group) walk the group's edges at sh.spec[0].P for
-// the sums of their part -> columns PC_SYS2 + q (the part with chi2 also fills the first candidate's column NACC + 1: the same sum); waves (4 .. 7, group) walk them
-// for candidates 1 .. 4's chi2 (a lane's terms in slot order, then the group tree); ONE exchange carries all of it.  Same sums, same order, same bits as the two passes.
+// and its exchange off the critical path of those iterations; a rejected first trial drops it.  Waves (part, group) walk the group's edges at sh.spec[0].P for
+// the sums of their part -> columns PC_SYS2 + q (the part with chi2 also fills the first candidate's column NACC + 1: the same sum); the next sets of waves walk them
+// for the chi2 of candidates 1, 2 .. (a lane's terms in slot order, then the group tree); ONE exchange carries all of it.  Same sums, same order, same bits as the two passes.
 template <class EM>
 __device__ __forceinline__ void pc_chi_spec_build(const EM L, int ne, int n, const Camera& k, double delta, PcShared& sh)
 {
@@ -460,11 +484,11 @@ __device__ __forceinline__ void pc_chi_spec_build(const EM L, int ne, int n, con
     const int gpb = NGROUP / 8;                                                  // (the caller has checked gridDim.x == 8)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, set = wv / gpb, gi = wv - set * gpb;
     const int gg = (int)blockIdx.x * gpb + gi;
-    if (set < 4) {
+    if (set < PC_NPARTS) {
         pc_build_group<PC_SYS2>(L, ne, set, gg, sh.spec[0].P, k, delta, sh);
-        if (set == PC_CHI_PART && lane == 0) sh.red[gg][NACC + 1] = sh.red[gg][PC_SYS2 + NACC];      // (lane 7 of this wave wrote it a moment ago: LDS is in order within a wave)
+        if (set == PC_CHI_PART && lane == 0) sh.red[gg][NACC + 1] = sh.red[gg][PC_SYS2 + NACC];      // (a lane of this wave wrote it a moment ago: LDS is in order within a wave)
     } else {
-        const int c = set - 3;
+        const int c = set - (PC_NPARTS - 1);
         if (c < n) {
             double a = 0.0;
             for (int i = gg * GROUP + lane; i < ne; i += PC_T) { const LEdge l = L.ld(i); if (!(l.meta & LE_LEVEL)) { Edge e = pc_expand(l); a += edge_rho(e, sh.spec[c].P, k, delta); } }
@@ -540,7 +564,7 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
     double chi = 0, x[6], gain = 0; int trials = 0; bool solved = false;
     const double* Hl = sh.tot; const double* b = sh.tot + 21;                 // the system stays in LDS over the trials (registers are short here)
     // (SPECB: the first round of an iteration also builds the system at its first candidate -- pc_chi_spec_build; have_sys: sh.tot[0 .. 27] already hold the system at P)
-    const bool SPECB = CL && gridDim.x == 8 && PC_FIRST_SPEC <= 5;
+    const bool SPECB = CL && gridDim.x == 8 && PC_FIRST_SPEC <= 9 - PC_NPARTS;
     bool have_sys = false;
     PROF_T0
     for (int it = 0; it < iterations; it++) {
