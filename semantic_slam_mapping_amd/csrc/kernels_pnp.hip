@@ -592,16 +592,20 @@ __device__ __forceinline__ void pc_optimize(const EM L, double2* err, int ne, in
         for (;;) {
             const int nsp = sh.spec_n;
             const int wv = threadIdx.x >> 6;
+            PROF2_T0
             if (wv < nsp) {
                 double lam = sh.spec_lambda, nu = sh.spec_nu;
                 for (int c = 0; c < wv; c++) { lam *= nu; nu *= 2; }
                 for (int q = 0; q < 6; q++) x[q] = 0;
                 solved = pc_solve_ldlt_wave(Hl, lam, b, x);
+                PROF2(29)
                 Pose Pn = sh.P;
                 pose_oplus(Pn, x);
+                PROF2(30)
                 if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 6; q++) sh.spec[wv].x[q] = x[q]; sh.spec[wv].P = Pn; sh.spec[wv].solved = solved ? 1 : 0; }
             }
             __syncthreads();
+            PROF2(31)
             PROF(2)
             if constexpr (CL) {
                 if (SPECB && first && it + 1 < iterations) {

@@ -205,6 +205,7 @@ extern "C" int ssm_tracker_run(ssm_tracker* t, const ssm_seq_out_dev* seq, int n
             fprintf(stderr, "pnp chain %d frames: clocks gather %lld fused %lld algebra %lld chi %lld update %lld solve(total) %lld; fused passes %lld chi passes %lld\n", stop - f, hs.prof[0], hs.prof[1], hs.prof[2], hs.prof[3], hs.prof[4], hs.prof[5], hs.prof[6], hs.prof[7]);
             fprintf(stderr, "  fused: edges + group tree %lld | finish: barrier %lld publish %lld poll %lld barrier %lld sum %lld;  chi: items %lld barrier %lld sums %lld barrier %lld | finish: barrier %lld publish %lld poll %lld row sum %lld barrier %lld\n",
                     hs.prof[24], hs.prof[8], hs.prof[9], hs.prof[10], hs.prof[11], hs.prof[12], hs.prof[25], hs.prof[26], hs.prof[27], hs.prof[28], hs.prof[16], hs.prof[17], hs.prof[18], hs.prof[19], hs.prof[20]);
+            fprintf(stderr, "  algebra: ldlt %lld exp map %lld publish + barrier %lld\n", hs.prof[29], hs.prof[30], hs.prof[31]);
 #endif
             if (stop <= f || stop > n) TFAIL(t, SSM_E_HIP, "pose chain returned an invalid frame range");
             if (hipMemcpy(pose_out + (size_t)f * 16, t->d_pose + (size_t)f * 16, (size_t)(stop - f) * 128, hipMemcpyDeviceToHost) != hipSuccess) TFAIL(t, SSM_E_HIP, "pose download failed");
