@@ -88,7 +88,7 @@ struct PcShared {
     double spec_lambda, spec_nu; int spec_n;
     double rbuf[PC_RBUF];         // cluster form: the chi2 terms of (candidate, edge slot) items computed by the waves whose lanes another block owns (pc_chi_spec)
     Pose P, saved, init;          // the estimate wave 0 publishes for the next pass; the one before the trial; the round's start value
-    double speed[16], last[16], Tpred[16], T[16], inv[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
+    double speed[16], last[16], Tpred[16], T[16];   // the tracker's state and the frame's transforms (thread 0 writes them)
     int wcnt[NGROUP];
     int cont, term, acc0;         // loop controls of the Levenberg iteration, decided by wave 0 (acc0: the iteration's first trial was accepted)
     long long work[4];            // thread 0: fused passes, chi2 passes, active edges evaluated by each kind (ssm_tracker_work: the numerator of bench.py's pose-loop roofline)
@@ -755,29 +755,42 @@ pnp_chain_kernel(PnpChainArgs a)
         PROF_T0
         if (tid == 0) iso_mul(sh.speed, a.state->ref_pose[nref - 1], sh.Tpred); // currentFrame->setTransform(speed * refFrames.back()->getTransform())
         // ---- the correspondences of every reference frame, in deque order then match order (track.cpp:150-163)
+        // ONE walk over the concatenated match lists (round 5; before, one walk per reference frame: five trips of ~540 matches through the dependent global loads and the
+        // scan's barriers instead of three of 1024).  The inverses of the references' poses and the lists' offsets sit in sh.rbuf, which only the chi2 passes use.
         int nc = 0;
-        for (int r = 0; r < nref; r++) {
-            const int ridx = a.state->ref_idx[r];                              // local frame index of the reference (negative: a frame of the previous call)
-            const int slot = a.R - (f - ridx);
-            const int nm = max(a.nmatch[(size_t)f * a.R + slot], 0);
-            const ssm_dmatch* m = a.matches + ((size_t)f * a.R + slot) * a.cap;
-            const float* rpos = ridx >= 0 ? a.pos3d + (size_t)ridx * a.cap * 3 : a.hist_pos3d + (size_t)(ridx + a.R) * a.cap * 3;
-            __syncthreads();
-            if (tid == 0) iso_inverse(a.state->ref_pose[r], sh.inv);
-            __syncthreads();
-            for (int k0 = 0; k0 < nm; k0 += PC_T) {
-                const int k = k0 + tid;
-                bool keep = false; float p0 = 0, p1 = 0, p2 = 0; int ti = 0;
-                if (k < nm) { const ssm_dmatch d = m[k]; const float* p = rpos + (size_t)d.queryIdx * 3; p0 = p[0]; p1 = p[1]; p2 = p[2]; ti = d.trainIdx; keep = !(p0 == 0.f && p1 == 0.f && p2 == 0.f); }
-                int tot; const int pos = nc + pc_scan(keep, sh, tot);
-                if (keep) {
-                    double v[3]; iso_apply(sh.inv, (double)p0, (double)p1, (double)p2, v);
-                    a.obj[3 * pos] = (float)v[0]; a.obj[3 * pos + 1] = (float)v[1]; a.obj[3 * pos + 2] = (float)v[2];
-                    const ssm_keypoint kp = a.kps[(size_t)f * a.cap + ti];
-                    a.img[2 * pos] = kp.x; a.img[2 * pos + 1] = kp.y;
-                }
-                nc += tot;
+        double (*invs)[16] = reinterpret_cast<double (*)[16]>(sh.rbuf);
+        int* roff = reinterpret_cast<int*>(sh.rbuf + SSM_TRACK_MAXREF * 16);      // [nref + 1] offsets, then [nref] list lengths
+        static_assert(SSM_TRACK_MAXREF * 16 + SSM_TRACK_MAXREF + 2 <= PC_RBUF, "the references' inverses and offsets fit the chi2 passes' buffer");
+        __syncthreads();
+        if (tid < nref) {
+            iso_inverse(a.state->ref_pose[tid], invs[tid]);
+            const int slot = a.R - (f - a.state->ref_idx[tid]);
+            roff[SSM_TRACK_MAXREF + 1 + tid] = max(a.nmatch[(size_t)f * a.R + slot], 0);
+        }
+        __syncthreads();
+        if (tid == 0) { int o = 0; for (int r = 0; r < nref; r++) { roff[r] = o; o += roff[SSM_TRACK_MAXREF + 1 + r]; } roff[nref] = o; }
+        __syncthreads();
+        const int total = roff[nref];
+        for (int k0 = 0; k0 < total; k0 += PC_T) {
+            const int idx = k0 + tid;
+            bool keep = false; float p0 = 0, p1 = 0, p2 = 0; int ti = 0, r = 0;
+            if (idx < total) {
+                while (idx >= roff[r + 1]) r++;
+                const int k = idx - roff[r];
+                const int ridx = a.state->ref_idx[r];                          // local frame index of the reference (negative: a frame of the previous call)
+                const int slot = a.R - (f - ridx);
+                const ssm_dmatch* m = a.matches + ((size_t)f * a.R + slot) * a.cap;
+                const float* rpos = ridx >= 0 ? a.pos3d + (size_t)ridx * a.cap * 3 : a.hist_pos3d + (size_t)(ridx + a.R) * a.cap * 3;
+                const ssm_dmatch d = m[k]; const float* p = rpos + (size_t)d.queryIdx * 3; p0 = p[0]; p1 = p[1]; p2 = p[2]; ti = d.trainIdx; keep = !(p0 == 0.f && p1 == 0.f && p2 == 0.f);
             }
+            int tot; const int pos = nc + pc_scan(keep, sh, tot);
+            if (keep) {
+                double v[3]; iso_apply(invs[r], (double)p0, (double)p1, (double)p2, v);
+                a.obj[3 * pos] = (float)v[0]; a.obj[3 * pos + 1] = (float)v[1]; a.obj[3 * pos + 2] = (float)v[2];
+                const ssm_keypoint kp = a.kps[(size_t)f * a.cap + ti];
+                a.img[2 * pos] = kp.x; a.img[2 * pos + 1] = kp.y;
+            }
+            nc += tot;
         }
         __syncthreads();
         PROF(0)
