@@ -183,3 +183,46 @@ def test_trackers_on_their_own_streams_from_two_threads(oracle):
             c.dev_free(db); c.dev_free(dd)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("blocks", [8, 2, 1])
+def test_device_chain_equals_the_host_chain_on_the_panning_stream(oracle, blocks):
+    """bench.py's closed pose loop in small: frame 0 seen by a panning camera, 1000 features and five reference frames (up to five edges per contract lane), two
+    20-frame sequences with different noise in the depth.  The host chain (include/ssm/pnp_core.h on one core: the arithmetic oracle/pnp.c pins and
+    test_bulk_tracker_equals_the_oracle_walk walks) and the device chain must give the same bits -- with eight blocks that is the round-5 form: the fused pass's sums
+    over two waves per group, an iteration's first round building the next iteration's system beside its three candidates, rejected streaks in one round."""
+    import semantic_slam_mapping_amd as ssm
+    from semantic_slam_mapping_amd._lib import SeqOutDev
+    n, CH, W, H = 40, 20, 640, 480
+    c = ssm.Context(0, width=W, height=H, max_batch=8, camera=CAM)
+    try:
+        base = oracle.synth_frame(SEED, 3)[0]
+        bgr = np.stack([np.roll(base, (k % CH, 2 * (k % CH)), (0, 1)) for k in range(n)])
+        rng = np.random.default_rng(SEED + 5)
+        dep = np.full((n, H, W), 2000, np.uint16)
+        dep[CH:] += rng.integers(0, 40, (n - CH, H, W)).astype(np.uint16)                          # the second sequence: noisy depth (more rejected trials, outliers)
+        db = c.dev_alloc(bgr.nbytes); dd = c.dev_alloc(dep.nbytes)
+        try:
+            c.h2d(db, bgr); c.h2d(dd, dep)
+            o = c.seq_process(db, dd, None, None, n, stages=ssm.api.STAGE_ORB | ssm.api.STAGE_MATCH)
+            c.sync()
+            def view(a0):
+                return SeqOutDev(o.kps + a0 * o.cap * 28, o.desc + a0 * o.cap * 32, o.pos3d + a0 * o.cap * 12, o.nkp + a0 * 4, o.matches + a0 * o.R * o.cap * 16,
+                                 o.nmatch + a0 * o.R * 4, o.npoints + a0 * 4, o.cap, o.R)
+            host = ssm.Tracker(c, use_device=False); dev = ssm.Tracker(c, use_device=True, blocks=blocks)
+            try:
+                for a0 in (0, CH):
+                    host.reset(); dev.reset()
+                    ph, ih = host.run(view(a0), CH)
+                    pd, idv = dev.run(view(a0), CH)
+                    assert ih.tobytes() == idv.tobytes(), a0
+                    for f in range(CH):
+                        assert ph[f].tobytes() == pd[f].tobytes(), (a0, f)
+                    assert int(ih["tracked"].sum()) >= CH - 2 and int(ih["n_inliers"][5:].min()) > 100, a0
+                assert dev.stats()[0] >= n - 4 and dev.last_error() == ""                            # the chains ran on the device, no downgrade
+            finally:
+                host.close(); dev.close()
+        finally:
+            c.dev_free(db); c.dev_free(dd)
+    finally:
+        c.close()
