@@ -610,7 +610,7 @@ def rgbd_main(args):
                                   "edges_per_fused_pass": round(wk[2] / max(wk[0], 1), 1)}
             solve_info["roofline"] = {"bound": "valu_f64", "kernel": "pnp_chain_kernel (%d blocks = %d CUs)" % (nblk, nblk), "achieved": round(fl / sec / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "GFLOP/s",
                                       "frac": round(fl / sec / peak, 4), "traffic": None,
-                                      "note": "a serial chain: ~28 Levenberg iterations + ~54 trials per frame, each a pass over ~2700 edges followed by a 6 x 6 solve that the next pass waits for; "
+                                      "note": "a serial chain: the Levenberg iterations and trial rounds of `work` per frame, each a pass over the edges followed by a 6 x 6 solve that the next pass waits for; "
                                               "latency-bound by construction (DESIGN.md s.5.1), the peak is that of the CUs it occupies (78.6 TFLOP/s f64 vector x blocks / 256)"}
         if args.pose_cpu_sample and args.pose_stream == "rigid":
             # cpu_baseline of the pose loop: the same chain (include/ssm/pnp_core.h, the arithmetic oracle/pnp.c pins) on ONE host core over a bounded sample of the sequences
