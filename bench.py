@@ -448,12 +448,12 @@ def rgbd_main(args):
     t0 = time.perf_counter()
     stage_ovl = {}
     for _ in range(args.steps):
-        out, n_vox = step()
-        for k, (ms, ln) in ctx.stage_times().items():
-            a = stage_ovl.setdefault(k, [0.0, 0])
-            a[0] += ms; a[1] += ln
+        out, n_vox = step()                            # (ends with the map export: that waits for the MAP's stream; the ORB -> match chain of the step's last sub-batch runs on
+                                                       # into the next step -- ssm_get_stage_times would wait for it, so the stage brackets are read once, behind the fence)
     fence()
     dt = time.perf_counter() - t0
+    for k, (ms, ln) in ctx.stage_times().items():      # the last step's brackets, scaled to the K steps (the steps are identical)
+        stage_ovl[k] = [ms * args.steps, ln * args.steps]
     # ---- kernel durations for the roofline: the same K steps with every stage serialised on one stream (profiling mode 2),
     # so that a stage's hipEvent bracket is that kernel alone (this is also what profiles/*_kernel_stats.md lists)
     ctx.set_profiling(2)

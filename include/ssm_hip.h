@@ -150,7 +150,10 @@ int ssm_map_export(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);         /
 int ssm_map_export_table(ssm_ctx* ctx, ssm_voxel* out, int cap, int* n_out);   /* key-sorted table, for merging */
 int ssm_map_merge_table(ssm_ctx* ctx, const ssm_voxel* tab, int n);            /* add another rank's table */
 /* same two with DEVICE buffers (the RCCL all-gather of per-GPU tables works on device memory); export is synchronous
- * (it needs the voxel count on the host), merge is enqueued on the context stream */
+ * (it needs the voxel count on the host), merge is enqueued on the context stream.  ssm_map_size and ssm_map_export_table_dev wait for the MAP: after
+ * an ssm_seq_process whose map stage ran on a side stream they wait for that stream only, and the call's ORB -> match chain may still be running when
+ * they return (its outputs are ordered on the context stream as always; ssm_sync waits for everything).  A loop of ssm_map_clear / ssm_seq_process /
+ * ssm_map_export_table_dev per sequence therefore keeps the GPU busy across its iterations. */
 int ssm_map_export_table_dev(ssm_ctx* ctx, ssm_voxel* out_dev, int cap, int* n_out);
 int ssm_map_merge_table_dev(ssm_ctx* ctx, const ssm_voxel* tab_dev, int n);
 

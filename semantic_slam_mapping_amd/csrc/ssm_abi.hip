@@ -324,6 +324,7 @@ extern "C" int ssm_sync(ssm_ctx* c)
     c->err.clear();                                               // (after a successful ssm_sync ssm_last_error is empty, or the note of a repeated SGBM sweep)
     { int r = wait_pending(c); if (r) return r; }                 // asynchronous per-frame calls still in flight are completed (their results delivered) too
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->map_tail = nullptr;                                        // (every stream of the context is idle: the context stream joined them)
     return check_device_flags(c, true);
 }
 extern "C" int ssm_set_profiling(ssm_ctx* c, int on) { if (!c) return SSM_E_INVAL; std::lock_guard<std::mutex> lk(c->mu); c->profiling = on != 0; c->serialize = on == 2; return SSM_OK; }
@@ -907,6 +908,8 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     if (side || two_chains) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
     if (nch == 3) { HIPCHK(c, hipEventRecord(c->ev_join4, c->stream4)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join4, 0)); }
     if (map3) { HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0)); }
+    // where the map's newest work sits (ssm_ctx::map_tail): one side stream, or the context stream (serialised, no map stage, or the chains' own streams in turn)
+    if (stages & SSM_STAGE_MAP) c->map_tail = map3 ? c->stream3 : (side ? c->stream2 : nullptr);
     c->prev_n = n;
     if (out) {
         out->kps = c->d_kps; out->desc = desc; out->pos3d = c->d_pos3d; out->nkp = nkp; out->matches = c->d_matches; out->nmatch = c->d_nmatch;

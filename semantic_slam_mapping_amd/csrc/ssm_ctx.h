@@ -108,6 +108,10 @@ struct ssm_ctx {
     uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
     void* d_scratch2 = nullptr; size_t scratch2_bytes = 0;
+    // the stream that holds the newest work on the context map when that is a side stream of ssm_seq_process (joined into `stream` by an event, so everything queued
+    // on `stream` afterwards is ordered behind it): ssm_map_size / ssm_map_export_table_dev read the map there and wait for THAT stream only -- the ORB -> match chain of
+    // the call's last sub-batch keeps running.  nullptr: the map's newest work is on `stream`.
+    hipStream_t map_tail = nullptr;
     // sequence outputs
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
@@ -166,7 +170,7 @@ SSM_HIDDEN int wait_pending(ssm_ctx* c);
 SSM_HIDDEN int ensure_side_streams(ssm_ctx* c);
 // ssm_map.hip
 SSM_HIDDEN int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2);
-SSM_HIDDEN int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve);
+SSM_HIDDEN int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve, int32_t* counters_out = nullptr);
 SSM_HIDDEN int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq);
 SSM_HIDDEN int map_after_launch(ssm_ctx* c, hipStream_t s, int frames);
 // ssm_segnet_abi.hip

@@ -23,7 +23,7 @@ int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
 // 4 x (voxels + overflow records + reserve) exceeds its slots -- `reserve` = new voxels the caller is about to add at most, so that an insert / merge of a known
 // size can never overflow.  SSM_E_CAPACITY only beyond 2^vox_max_log2 slots (28: the key's range), SSM_E_NOMEM when the larger table cannot be allocated; in both
 // cases nothing is lost: table and list stay as they are.
-int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve)
+int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve, int32_t* counters_out)       // counters_out: the table's counter block as it is when the map is at rest
 {
     VoxTable& t = c->map;
     int lo = 0;                                                   // overflow records [0, lo) are merged already
@@ -41,7 +41,8 @@ int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve)
             FAIL(c, SSM_E_CAPACITY, "the voxel map needs more than 2^" + std::to_string(c->vox_max_log2) + " slots (voxel_max_capacity_log2)");
         }
         if (m <= 0 && !grow) {
-            if (cnt[2] != 0) { const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
+            if (cnt[2] != 0) { const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); cnt[2] = 0; }
+            if (counters_out) memcpy(counters_out, cnt, 16);
             return SSM_OK;
         }
         if (grow) {
@@ -136,12 +137,14 @@ int map_after_launch(ssm_ctx* c, hipStream_t s, int frames)
 }
 
 // ---------------------------------------------------------------- voxel map
+// the stream the context map is read on (ssm_ctx::map_tail) -- the scratch table lives on the context stream
+static hipStream_t table_stream(ssm_ctx* c, VoxTable& t) { return (&t == &c->map && c->map_tail) ? c->map_tail : c->stream; }
 static int table_count(ssm_ctx* c, VoxTable& t, int* n)
 {
-    int32_t cnt[2];
-    if (&t == &c->map) { const int r = map_settle(c, c->stream, 0); if (r) return r; }
-    HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t cnt[4];
+    hipStream_t s = table_stream(c, t);
+    if (&t == &c->map) { const int r = map_settle(c, s, 0, cnt); if (r) return r; }      // (its last look at the counters is the count: one round trip, not two)
+    else { HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 8, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s)); }
     if (cnt[1] & 1) FAIL(c, SSM_E_CAPACITY, "voxel map incomplete (contributions were dropped): ssm_map_clear and start from a larger voxel_capacity_log2");
     *n = cnt[0];
     return SSM_OK;
@@ -149,11 +152,12 @@ static int table_count(ssm_ctx* c, VoxTable& t, int* n)
 // sorts the table's voxels by key; leaves compact array + order in scratch2.  returns pointers
 static int table_sorted(ssm_ctx* c, VoxTable& t, int* n_out, ssm_voxel** compact, uint32_t** order)
 {
+    hipStream_t st = table_stream(c, t);
     int n = 0; int r = table_count(c, t, &n); if (r) return r;
     *n_out = n; *compact = nullptr; *order = nullptr;
     if (n == 0) return SSM_OK;
     size_t tmp_bytes = 0;
-    HIPCHK(c, voxel_sort_pairs(nullptr, &tmp_bytes, nullptr, n, nullptr, nullptr, nullptr, nullptr, c->stream));
+    HIPCHK(c, voxel_sort_pairs(nullptr, &tmp_bytes, nullptr, n, nullptr, nullptr, nullptr, nullptr, st));
     const size_t a = ((size_t)n * sizeof(ssm_voxel) + 255) & ~(size_t)255, kb = ((size_t)n * 8 + 255) & ~(size_t)255, ib = ((size_t)n * 4 + 255) & ~(size_t)255;
     r = ensure_scratch2(c, a + 2 * kb + 2 * ib + tmp_bytes + 512); if (r) return r;
     uint8_t* p = reinterpret_cast<uint8_t*>(c->d_scratch2);
@@ -161,8 +165,8 @@ static int table_sorted(ssm_ctx* c, VoxTable& t, int* n_out, ssm_voxel** compact
     uint64_t* ka = reinterpret_cast<uint64_t*>(p); p += kb; uint64_t* kbuf = reinterpret_cast<uint64_t*>(p); p += kb;
     uint32_t* ia = reinterpret_cast<uint32_t*>(p); p += ib; uint32_t* ibuf = reinterpret_cast<uint32_t*>(p); p += ib;
     int32_t* dn = reinterpret_cast<int32_t*>(p); p += 256;
-    HIPCHK(c, k_voxel_compact(t.tab, t.cap_log2, comp, dn, c->stream));
-    HIPCHK(c, voxel_sort_pairs(p, &tmp_bytes, comp, n, ka, kbuf, ia, ibuf, c->stream));
+    HIPCHK(c, k_voxel_compact(t.tab, t.cap_log2, comp, dn, st));
+    HIPCHK(c, voxel_sort_pairs(p, &tmp_bytes, comp, n, ka, kbuf, ia, ibuf, st));
     *compact = comp; *order = ibuf;
     return SSM_OK;
 }
@@ -183,6 +187,7 @@ extern "C" int ssm_map_clear(ssm_ctx* c)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));       // (the capacity it has grown to stays)
     c->map_full_reported = false; c->map_launches = 0; c->map_frames = 0; c->map_known_total = 0; c->map_known_frames = 0;      // (the rate map_vpf is the stream's: kept)
     return SSM_OK;
@@ -191,6 +196,7 @@ extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     if (n < 0 || (n && !pts)) FAIL(c, SSM_E_INVAL, "bad arguments");
     if (n == 0) return SSM_OK;
     int r = ensure_scratch(c, (size_t)n * sizeof(ssm_point)); if (r) return r;
@@ -215,12 +221,14 @@ extern "C" int ssm_map_export(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
 {
     if (!c || !n_out) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     return table_export_points(c, c->map, out, cap, n_out);
 }
 extern "C" int ssm_map_export_table(ssm_ctx* c, ssm_voxel* out, int cap, int* n_out)
 {
     if (!c || !n_out) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     int n; ssm_voxel* comp; uint32_t* order;
     int r = table_sorted(c, c->map, &n, &comp, &order); if (r) return r;
     *n_out = n;
@@ -236,6 +244,7 @@ extern "C" int ssm_map_merge_table(ssm_ctx* c, const ssm_voxel* tab, int n)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
     if (n == 0) return SSM_OK;
     int r = ensure_scratch(c, (size_t)n * sizeof(ssm_voxel)); if (r) return r;
@@ -255,14 +264,16 @@ extern "C" int ssm_map_export_table_dev(ssm_ctx* c, ssm_voxel* out, int cap, int
     if (n > cap) FAIL(c, SSM_E_CAPACITY, "table buffer too small (need " + std::to_string(n) + ")");
     if (n == 0) return SSM_OK;
     if (!out) FAIL(c, SSM_E_INVAL, "null output");
-    HIPCHK(c, k_voxel_gather_table(comp, order, n, out, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipStream_t st = table_stream(c, c->map);                            // (waits for the map's stream only: ssm_ctx::map_tail)
+    HIPCHK(c, k_voxel_gather_table(comp, order, n, out, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     return SSM_OK;
 }
 extern "C" int ssm_map_merge_table_dev(ssm_ctx* c, const ssm_voxel* tab, int n)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     if (n < 0 || (n && !tab)) FAIL(c, SSM_E_INVAL, "bad arguments");
     { const int r = map_settle(c, c->stream, n); if (r) return r; }
     HIPCHK(c, k_voxel_merge(tab, n, c->map.tab, c->map.cap_log2, c->map.counters, c->stream));
@@ -308,6 +319,7 @@ extern "C" int ssm_voxel_allgather(ssm_ctx* c, void* rccl_comm)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     ncclComm_t comm = rccl_comm ? reinterpret_cast<ncclComm_t>(rccl_comm) : c->comm;
     if (!comm) FAIL(c, SSM_E_INVAL, "no communicator: pass a ncclComm_t or call ssm_comm_init_rank");
     int world = 0, rank = 0;
