@@ -522,6 +522,60 @@ def test_two_chain_mode_equals_single_stream(monkeypatch, map_stream, map_first)
         c.close()
 
 
+def test_map_reads_on_the_map_stream_stay_ordered_with_the_calls_around_them(oracle):
+    """ssm_map_size / ssm_map_export_table_dev wait for the MAP's stream only (round 5): after an ssm_seq_process whose map stage ran on a side stream they return
+    while the call's ORB -> match chain may still be running.  Whatever is called next must still see, and be seen by, the map in call order: an export in the
+    middle of a run of sequences, a host insert right behind it, a second sequence on top, a clear, the outputs of the chain fetched last."""
+    import semantic_slam_mapping_amd as ssm
+    from semantic_slam_mapping_amd.api import VOXEL_DTYPE, POINT_DTYPE
+    W, H, n = 640, 480, 12
+    c = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=18, camera=CAM)
+    bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]
+    cap = 1 << 17
+    dtab = c.dev_alloc(cap * VOXEL_DTYPE.itemsize)
+    rng = np.random.default_rng(SEED + 11)
+    extra = np.zeros(3000, POINT_DTYPE)
+    extra["x"], extra["y"], extra["z"] = rng.uniform(-2, 2, 3000), rng.uniform(-2, 2, 3000), rng.uniform(0.5, 4, 3000)
+    extra["r"], extra["g"], extra["b"] = rng.integers(0, 256, (3, 3000))
+    try:
+        c.synth_frames_dev(SEED, 300, n, *bufs)
+        def table_dev():
+            k = c.map_export_table_dev(dtab, cap)
+            return c.d2h(dtab, k, VOXEL_DTYPE).copy()
+        # the reference: every step followed by a full ssm_sync, tables through the host export (which works on the context stream)
+        c.set_profiling(2); c.map_clear()
+        out = c.seq_process(*bufs, n); c.sync(); ref_seq = c.seq_fetch(out, n); t1 = c.map_export_table()
+        c.map_insert(extra); c.sync(); t2 = c.map_export_table()
+        c.seq_process(*bufs, n); c.sync(); t3 = c.map_export_table()
+        c.set_profiling(0)
+        # the same calls back to back, the map read on its own stream
+        c.map_clear()
+        out = c.seq_process(*bufs, n)
+        g1 = table_dev()                                         # (the chain of the last sub-batch may still be running here)
+        c.map_insert(extra)
+        assert c.map_size() == len(t2)
+        g2 = table_dev()
+        c.seq_process(*bufs, n)
+        assert c.map_size() == len(t3)
+        g3 = table_dev()
+        c.map_clear()
+        assert c.map_size() == 0
+        out = c.seq_process(*bufs, n)
+        g4 = table_dev()
+        got_seq = c.seq_fetch(out, n)                            # the chain's outputs, ordered on the context stream
+        for a, b in ((t1, g1), (t2, g2), (t3, g3), (t1, g4)):
+            assert len(a) == len(b) > 1000 and a.tobytes() == b.tobytes()
+        for k in ("nkp", "nmatch", "npoints"):
+            assert np.array_equal(ref_seq[k], got_seq[k]), k
+        for f in range(n):
+            kk = int(ref_seq["nkp"][f])
+            assert same_struct(ref_seq["kps"][f, :kk], got_seq["kps"][f, :kk]) and np.array_equal(ref_seq["desc"][f, :kk], got_seq["desc"][f, :kk])
+    finally:
+        for p in bufs + [dtab]:
+            c.dev_free(p)
+        c.close()
+
+
 @pytest.mark.parametrize("max_batch,n", [(2, 9), (1, 7), (3, 11)])
 def test_three_chains_with_sub_batches_shorter_than_the_reference_window(max_batch, n):
     """max_batch < tracker_ref_frames: the matcher of a sub-batch reads descriptor rows of SEVERAL preceding sub-batches, which run on the other two
