@@ -185,16 +185,17 @@ def test_trackers_on_their_own_streams_from_two_threads(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("blocks", [8, 2, 1])
-def test_device_chain_equals_the_host_chain_on_the_panning_stream(oracle, blocks):
+@pytest.mark.parametrize("blocks,nfeat", [(8, 1000), (2, 1000), (1, 1000), (8, 150), (8, 40)])
+def test_device_chain_equals_the_host_chain_on_the_panning_stream(oracle, blocks, nfeat):
     """bench.py's closed pose loop in small: frame 0 seen by a panning camera, 1000 features and five reference frames (up to five edges per contract lane), two
     20-frame sequences with different noise in the depth.  The host chain (include/ssm/pnp_core.h on one core: the arithmetic oracle/pnp.c pins and
     test_bulk_tracker_equals_the_oracle_walk walks) and the device chain must give the same bits -- with eight blocks that is the round-5 form: the fused pass's sums
-    over two waves per group, an iteration's first round building the next iteration's system beside its three candidates, rejected streaks in one round."""
+    over two waves per group, an iteration's first round building the next iteration's system beside its three candidates, rejected streaks in one round.
+    150 / 40 features: contract groups (and whole blocks of the cluster) without an edge, solves that fail the 15-correspondence tests."""
     import semantic_slam_mapping_amd as ssm
     from semantic_slam_mapping_amd._lib import SeqOutDev
     n, CH, W, H = 40, 20, 640, 480
-    c = ssm.Context(0, width=W, height=H, max_batch=8, camera=CAM)
+    c = ssm.Context(0, width=W, height=H, max_batch=8, camera=CAM, orb_features=nfeat)
     try:
         base = oracle.synth_frame(SEED, 3)[0]
         bgr = np.stack([np.roll(base, (k % CH, 2 * (k % CH)), (0, 1)) for k in range(n)])
@@ -218,8 +219,9 @@ def test_device_chain_equals_the_host_chain_on_the_panning_stream(oracle, blocks
                     assert ih.tobytes() == idv.tobytes(), a0
                     for f in range(CH):
                         assert ph[f].tobytes() == pd[f].tobytes(), (a0, f)
-                    assert int(ih["tracked"].sum()) >= CH - 2 and int(ih["n_inliers"][5:].min()) > 100, a0
-                assert dev.stats()[0] >= n - 4 and dev.last_error() == ""                            # the chains ran on the device, no downgrade
+                    if nfeat == 1000:
+                        assert int(ih["tracked"].sum()) >= CH - 2 and int(ih["n_inliers"][5:].min()) > 100, a0
+                assert (dev.stats()[0] >= n - 4 or nfeat < 1000) and dev.last_error() == ""          # the chains ran on the device, no downgrade
             finally:
                 host.close(); dev.close()
         finally:
