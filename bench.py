@@ -780,6 +780,90 @@ def segnet_cpu_baseline(pipeline_cpu):
             "ms_per_frame": {"segnet": round(t_seg * 1e3, 1), "pipeline": round(t_pipe * 1e3, 2)}}
 
 
+def exp_mapping_legs(scale=1.0):
+    """the PRODUCT -- semantic_slam_mapping_amd/host/exp_mapping, the C++ drop-in of the reference's experiment/exp_mapping.cpp:18-59 on the
+    rgbd_tutor classes of include/ssm/ (FrameReader::next -> Tracker::updateFrame -> PoseGraph::tryInsertKeyFrame, Mapper::viewer on its own thread) -- run as CHILD
+    processes, one after the other, BEFORE this process imports torch or makes its first HIP call (a process that has initialised the GPU must neither fork nor exec).
+    The rates are the ones the binary prints itself, timed where the reference's drivers time (experiment/run_tracker.cpp:35-48 around updateFrame,
+    experiment/match_orbfeature_tum.cpp:22-27 around detect + match), the first frames left out (context creation, code-object load).
+    Stream: 640 x 480 frames of the rigid form of the configs[1] stream (FrameReader `synthetic_rigid`: frame 0 as a plane at 2 m under a panning camera, independent
+    20-frame sequences -- the stream on which every frame tracks, the same one the pose_loop leg uses); stereo: a KITTI-layout directory of 1241 x 376 PNG pairs
+    written here (FrameReader::KITTI reads and decodes them like the reference's cv::imread calls, src/rgbdframe.cpp:34-80)."""
+    import shutil
+    import subprocess
+    import tempfile
+    host = os.path.join(ROOT, "semantic_slam_mapping_amd", "host"); exe = os.path.join(host, "exp_mapping")
+    if not os.path.exists(exe):
+        return {"error": "semantic_slam_mapping_amd/host/exp_mapping is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    t_all = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="ssm_expmap_")
+    N = max(60, int(400 * scale)); SKIP = 40
+    base = open(os.path.join(host, "parameters_test.txt")).read().replace("end_index=8", "end_index=%d" % N).replace("map_output=/tmp/ssm_test_map.pcd", "")
+    # key-frame gate: 0.03 m = every 4th frame of this stream (2 x 2 m / 517 px = 7.7 mm per frame; the reference's 5.5 is for KITTI's metres per frame)
+    base = base.replace("keyframe_min_translation=0.005", "keyframe_min_translation=0.03")
+    base += "\nsynthetic_rigid=1\nsequence_length=20\ntiming_skip_frames=%d\nfinal_map_fnv=60\nmapper_drain_ms=100\n" % SKIP
+
+    def run(name, text, *flags, timeout=240):
+        prm = os.path.join(tmp, name + ".txt")
+        open(prm, "w").write(text)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, prm, *flags], capture_output=True, text=True, timeout=timeout)
+        wall = time.perf_counter() - t0
+        rows = [l for l in r.stdout.splitlines() if l.startswith("frames ")]
+        if r.returncode != 0 or not rows:
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+        w = rows[-1].split()
+        st = dict(zip(w[0::2], w[1::2]))
+        st["wall_s"] = round(wall, 1); st["lost"] = r.stdout.count("tracker is lost")
+        return st
+
+    out = {}
+    try:
+        legs = {
+            "per_frame": run("a", base + "use_stream_pose=1\n"),
+            "per_frame_solved": run("b", base + "use_stream_pose=0\n"),
+            "batched": run("c", base + "use_stream_pose=1\ntracker_batched_chain=0\ntracker_chunk=%d\nssm_max_batch=%d\n" % (min(200, N), min(200, N)), "--batched"),
+            "batched_solved": run("c2", base + "use_stream_pose=0\ntracker_chunk=20\nssm_max_batch=20\n", "--batched"),
+        }
+        # ---- stereo: a KITTI-layout directory written here (PNG, gray), then `exp_mapping --batched` with tracker_mode = stereo (BatchStereoTracker)
+        import numpy as np
+        from PIL import Image
+        NS = max(24, int(96 * scale))
+        L, R = stereo_sequence(NS + 1, 1241, 376, 100)
+        seq = os.path.join(tmp, "kitti"); os.makedirs(os.path.join(seq, "image_2")); os.makedirs(os.path.join(seq, "image_3"))
+        for i in range(NS + 1):
+            Image.fromarray(L[i], "L").save(os.path.join(seq, "image_2", "%06d.png" % i), compress_level=1)
+            Image.fromarray(R[i], "L").save(os.path.join(seq, "image_3", "%06d.png" % i), compress_level=1)
+        st_txt = open(os.path.join(host, "parameters_test.txt")).read().replace("end_index=8", "end_index=%d" % NS).replace("dataset=synthetic", "dataset=kitti")
+        st_txt = st_txt.replace("map_output=/tmp/ssm_test_map.pcd", "").replace("image_width=640", "image_width=1241").replace("image_height=480", "image_height=376")
+        for k, v in (("camera.cx", KITTI["cu"]), ("camera.cy", KITTI["cv"]), ("camera.fx", KITTI["f"]), ("camera.fy", KITTI["f"])):
+            st_txt = "\n".join(("%s=%r" % (k, v)) if ln.startswith(k + "=") else ln for ln in st_txt.splitlines())
+        st_txt += ("\ndata_source=%s\ntracker_mode=stereo\ncamera.baseline=%r\ncamera.roix=%r\ncamera.roiy=%r\ncamera.roiz=%r\ninlier_threshold=2.0\ntracker_chunk=32\nssm_max_batch=32\n"
+                   "timing_skip_frames=32\nmapper_drain_ms=100\nkeyframe_min_translation=0.5\n" % (seq, KITTI["baseline"], KITTI["roix"], KITTI["roiy"], KITTI["roiz"]))
+        legs["batched_stereo"] = run("d", st_txt, "--batched")
+        out["runs"] = legs
+        f = lambda leg, key: (round(float(legs[leg][key]), 1) if key in legs[leg] else None)
+        out["per_frame_fps"] = f("per_frame", "tracker_fps"); out["per_frame_solved_fps"] = f("per_frame_solved", "tracker_fps")
+        out["batched_fps"] = f("batched", "tracker_fps"); out["batched_solved_fps"] = f("batched_solved", "tracker_fps"); out["batched_stereo_pairs_per_s"] = f("batched_stereo", "tracker_fps")
+        out["loop_fps_reader_included"] = {k: f(k, "loop_fps") for k in legs}
+        ok = all("error" not in v for v in legs.values())
+        # stream poses: the per-frame and the bulk loop keep the same poses, pick the same key-frames and build the same map; solved poses: the bulk chain is the per-frame Tracker, bit for bit
+        out["map_fnv_equal"] = bool(ok and legs["per_frame"].get("map_fnv") is not None and legs["per_frame"].get("map_fnv") == legs["batched"].get("map_fnv")
+                                    and legs["per_frame_solved"].get("map_fnv") == legs["batched_solved"].get("map_fnv"))
+        out["pose_fnv_equal"] = bool(ok and legs["per_frame_solved"]["pose_fnv"] == legs["batched_solved"]["pose_fnv"] and legs["per_frame"]["pose_fnv"] == legs["batched"]["pose_fnv"])
+        out["unit"] = "frames/s (stereo: frame pairs/s)"
+        out["config"] = {"workload": "exp_mapping (C++ host, include/ssm classes over the C ABI): %d frames 640x480 of the rigid configs[1] stream in 20-frame sequences, ORB 1000 kp, 5 refs, rates over the frames after "
+                                     "the first %d; stereo: %d PNG pairs 1241x376 from a KITTI-layout directory, SGBM 80 disparities" % (N, SKIP, NS),
+                         "timed": "tracker_fps = frames / wall time inside Tracker::updateFrame (per_frame*) or BatchTracker / BatchStereoTracker::push + flush (batched*): upload, kernels, download, host state machine; "
+                                  "loop_fps_reader_included adds FrameReader::next (synthetic: host roll of the base frame; stereo: five PNG decodes per frame) and PoseGraph::tryInsertKeyFrame, Mapper::viewer on its thread"}
+    except Exception as e:                      # a failing leg must not take the headline with it
+        out["error"] = repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
 def sub_line(line, **extra):
     """what `other_configs` keeps of a full bench line"""
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "per_frame")
@@ -849,6 +933,9 @@ def main():
     # the default run (the command the driver times: N = 1, no mode flag) also carries configs[2], configs[3] and the closed pose loop as `other_configs`
     default_run = (world == 1 and args.other_configs and (args.frames == 1000 or args.other_scale != 1.0)
                    and not (args.stereo or args.segnet or args.solve_poses or args.serial_only or args.total_frames > 0 or os.environ.get("SSM_FORCE_MERGE") == "1"))
+    expmap = None
+    if default_run and os.environ.get("SSM_BENCH_EXP_MAPPING", "1") != "0":
+        expmap = exp_mapping_legs(args.other_scale)   # child processes, started and finished before this process's first GPU call
     if args.stereo:
         line = stereo_main(args)
     else:
@@ -858,6 +945,12 @@ def main():
         line = rgbd_main(args)
         if default_run and line is not None:
             line["other_configs"] = other_configs(args, line)
+            if expmap is not None:
+                if "error" not in expmap and line.get("cpu_baseline"):
+                    cb = line["cpu_baseline"]
+                    expmap["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                              "sample": "the configs[1] oracle pipeline (ORB + match + mask + back-projection + voxel filter per frame, no PnP), as in the headline's cpu_baseline"}
+                line["other_configs"]["exp_mapping"] = expmap
     if line is not None:
         # RCCL prints a version banner through C stdio when a communicator is created; flush it first so that the JSON line is the LAST line of stdout
         try:

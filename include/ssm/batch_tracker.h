@@ -18,6 +18,7 @@ public:
         dev.reset(new ssm::Device(cfg));
         ssm_tracker_params p; ssm_tracker_params_default(&p);
         p.max_lost_frame = para.getData<int>("tracker_max_lost_frame", 10); p.ref_frames = cfg.tracker_ref_frames; p.pnp_min_inliers = para.getData<int>("pnp_min_inliers", 10);
+        run_chain = para.getData<int>("tracker_batched_chain", 1) != 0;     // 0: the stream supplies the poses (use_stream_pose = 1) -- features + match tables only, T_f_w stays as the frame arrived
         p.use_device = para.getData<int>("tracker_pnp_on_device", 1);      // the chain of regular frames on the GPU (0.5 ms per frame; 0: one host core, 1.6 ms; same bits)
         for (int k = 0; k < 16; k++) p.first_pose[k] = first_pose.data()[k];
         dev->check(ssm_tracker_create(dev->ctx(), &p, &trk), "ssm_tracker_create");
@@ -27,6 +28,8 @@ public:
     ~BatchTracker() { if (trk) ssm_tracker_destroy(trk); if (dev) { if (d_bgr) ssm_dev_free(dev->ctx(), d_bgr); if (d_depth) ssm_dev_free(dev->ctx(), d_depth); } }
     BatchTracker(const BatchTracker&) = delete; BatchTracker& operator=(const BatchTracker&) = delete;
     int chunk() const { return N; }
+    // the next frame pushed starts a new sequence (what is queued must have been flushed): Tracker::reset() for the bulk tracker
+    void reset() { if (!pending.empty()) throw logic_error("BatchTracker::reset with frames queued: flush() first"); dev->check(ssm_tracker_reset(trk), "ssm_tracker_reset"); fed = 0; }
     // queue a frame; when the chunk is full it is processed.  Returns the frames whose poses are now known (possibly none).
     vector<RGBDFrame::Ptr> push(const RGBDFrame::Ptr& f) { pending.push_back(f); return (int)pending.size() >= N ? flush() : vector<RGBDFrame::Ptr>(); }
     // process whatever is queued: sets T_f_w of every queued frame, fills infos (one entry per frame, in order) and returns the frames
@@ -46,20 +49,28 @@ public:
         ssm_seq_out_dev out;
         dev->check(ssm_seq_process(dev->ctx(), &in, &out), "ssm_seq_process");
         vector<double> poses((size_t)n * 16); infos.assign(n, ssm_track_info());
+        if (!run_chain) {                                  // poses are the stream's: the chunk's features and match tables are on the device (ssm_seq_out_dev), nothing to solve
+            dev->check(ssm_sync(dev->ctx()), "ssm_sync");
+            for (ssm_track_info& i : infos) { i.state = 1; i.tracked = 1; i.n_matches = -1; i.n_inliers = 0; }
+            last_out = out; fed += n;
+            vector<RGBDFrame::Ptr> done0; done0.swap(pending);
+            return done0;
+        }
         const int rc = ssm_tracker_run(trk, &out, n, poses.data(), infos.data());
         if (rc != SSM_OK) throw ssm::DeviceError(rc, string("ssm_tracker_run: ") + ssm_tracker_last_error(trk));
         for (int i = 0; i < n; i++) {
             Eigen::Isometry3d T; for (int k = 0; k < 16; k++) T.matrix().data()[k] = poses[(size_t)i * 16 + k];
             pending[i]->setTransform(T);
         }
-        fed += n;
+        last_out = out; fed += n;
         vector<RGBDFrame::Ptr> done; done.swap(pending);
         return done;
     }
     vector<ssm_track_info> infos;                 // of the most recent flush
+    ssm_seq_out_dev last_out;                     // device tables of the most recent flush (features, descriptors, 3-D positions, match tables of its frames)
     ssm::Device& device() { return *dev; }
 private:
-    int W, H, N = 64; long fed = 0;
+    int W, H, N = 64; long fed = 0; bool run_chain = true;
     unique_ptr<ssm::Device> dev; ssm_tracker* trk = nullptr; void *d_bgr = nullptr, *d_depth = nullptr;
     vector<RGBDFrame::Ptr> pending;
 };

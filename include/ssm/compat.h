@@ -61,12 +61,19 @@ public:
     template <class T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
     Mat clone() const { Mat m; if (!empty()) { m.create(rows, cols, type_); for (int r = 0; r < rows; r++) memcpy(m.ptr<uchar>(r), ptr<uchar>(r), (size_t)cols * elemSize()); } return m; }
     Mat row(int r) const { Mat m = *this; m.rows = 1; m.data = data + (size_t)r * step; return m; }       // shares storage
-    void push_back(const Mat& r) {                                                                      // append rows (getAllDescriptors)
+    void push_back(const Mat& r) {                                                                      // append rows (getAllDescriptors); amortised like cv::Mat::push_back
         if (r.empty()) return;
         if (empty()) { *this = r.clone(); return; }
+        const size_t rb = (size_t)cols * elemSize();
+        if (buf_ && buf_.use_count() == 1 && data == buf_->data() && isContinuous() && r.cols == cols) {    // sole owner of a packed buffer: grow it in place (std::vector doubles its capacity)
+            buf_->resize((size_t)(rows + r.rows) * step); data = buf_->data();
+            for (int i = 0; i < r.rows; i++) memcpy(data + (size_t)(rows + i) * step, r.ptr<uchar>(i), rb);
+            rows += r.rows;
+            return;
+        }
         Mat n(rows + r.rows, cols, type_);
-        for (int i = 0; i < rows; i++) memcpy(n.ptr<uchar>(i), ptr<uchar>(i), (size_t)cols * elemSize());
-        for (int i = 0; i < r.rows; i++) memcpy(n.ptr<uchar>(rows + i), r.ptr<uchar>(i), (size_t)cols * elemSize());
+        for (int i = 0; i < rows; i++) memcpy(n.ptr<uchar>(i), ptr<uchar>(i), rb);
+        for (int i = 0; i < r.rows; i++) memcpy(n.ptr<uchar>(rows + i), r.ptr<uchar>(i), rb);
         *this = n;
     }
 private:

@@ -18,13 +18,17 @@ public:
         const bool has_depth = !frame->depth.empty() && frame->depth.isContinuous();
         d.check(ssm_orb_extract(d.ctx(), frame->rgb.data, frame->rgb.cols, frame->rgb.rows, (int)frame->rgb.step, frame->rgb.channels(),
                                 has_depth ? frame->depth.ptr<uint16_t>() : nullptr, kps.data(), desc.data(), pos.data(), cap, &n), "ssm_orb_extract");
+        // one block for the frame's descriptors; Feature::descriptor of feature i is row i of it (cv::Mat::row shares the storage, as the extractor's output Mat does
+        // in the reference: orb.h:44-49 takes rows of `descriptors`)
+        cv::Mat all; if (n > 0) { all.create(n, 32, CV_8UC1); memcpy(all.data, desc.data(), (size_t)n * 32); }
+        frame->features.reserve(frame->features.size() + (size_t)n);
         for (int i = 0; i < n; i++) {
             Feature f;
             static_assert(sizeof(cv::KeyPoint) == sizeof(ssm_keypoint), "cv::KeyPoint layout");
             memcpy((void*)&f.keypoint, &kps[i], sizeof(ssm_keypoint));
-            f.descriptor.create(1, 32, CV_8UC1); memcpy(f.descriptor.data, &desc[(size_t)i * 32], 32);
+            f.descriptor = all.row(i);
             f.position = cv::Point3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);     // == frame->project2dTo3d(int(pt.x), int(pt.y)), orb.h:50
-            frame->features.push_back(f);
+            frame->features.push_back(std::move(f));
         }
     }
     // descriptors of frame1 = query, frame2 = train; knn(2) + ratio test (src/orb.cpp:16-29)

@@ -56,6 +56,7 @@ public:
         width = para.getData<int>("image_width", 640); height = para.getData<int>("image_height", 480);
         seed = (uint64_t)para.getData<unsigned long long>("synthetic_seed", 0x5EED0000ull);
         dataset_dir = para.getData<string>("data_source", string("./"));
+        rigid = para.getData<int>("synthetic_rigid", 0) != 0; rigid_period = max(1, para.getData<int>("sequence_length", 20));
         camera = para.getCamera(); currentIndex = start_index;
         if (dataset_type == TUM) init_tum();
         else if (dataset_type == KITTI) init_kitti();
@@ -81,6 +82,33 @@ protected:
                         dev->check(ssm_dev_alloc(x, np * 3, &d_bgr), "alloc"); dev->check(ssm_dev_alloc(x, np * 2, &d_dep), "alloc");
                         dev->check(ssm_dev_alloc(x, np * 3, &d_sem), "alloc"); dev->check(ssm_dev_alloc(x, 128, &d_pose), "alloc"); }
             ssm_ctx* x = dev->ctx();
+            if (rigid) {
+                // synthetic_rigid = 1: a RIGID scene for the closed pose loop -- frame `synthetic_rigid_base` of the stream as the texture of a fronto-parallel plane at
+                // synthetic_rigid_depth metres, seen by a camera that pans so that the image moves by (2, 1) px per frame (the stream's own depth pattern does not move
+                // with its texture, so PnP loses track on it).  The odometry chain of the reference is not stable on a plane for long (depth error feeds back through
+                // the reference poses), so the stream is a concatenation of independent sequences of `sequence_length` frames: frame k of a sequence is the base
+                // image rolled by (k rows, 2 k columns); its stream pose is x_cam = x_world + k (2 Z / fx, Z / fy, 0).  bench.py's pose leg builds the same frames.
+                if (base_bgr.empty()) {
+                    base_bgr.create(height, width, CV_8UC3); base_sem.create(height, width, CV_8UC3);
+                    dev->check(ssm_synth_frames_dev(x, seed, parameterReader.getData<int>("synthetic_rigid_base", 0), 1, width, height, (uint8_t*)d_bgr, (uint16_t*)d_dep, (uint8_t*)d_sem, nullptr, (double*)d_pose), "synth");
+                    dev->check(ssm_memcpy_d2h(x, base_bgr.data, d_bgr, np * 3), "d2h"); dev->check(ssm_memcpy_d2h(x, base_sem.data, d_sem, np * 3), "d2h");
+                }
+                const int k = index % rigid_period, sy = k % height, sx = (2 * k) % width;
+                const double Z = parameterReader.getData<double>("synthetic_rigid_depth", 2.0);
+                const uint16_t dval = (uint16_t)(Z * camera.scale);
+                for (int y = 0; y < height; y++) {
+                    const int yo = (y + sy) % height;
+                    for (int img = 0; img < 2; img++) {
+                        const uint8_t* src = (img ? base_sem : base_bgr).ptr<uint8_t>(y); uint8_t* dst = (img ? f->semantic : f->rgb).ptr<uint8_t>(yo);
+                        memcpy(dst + (size_t)sx * 3, src, (size_t)(width - sx) * 3); memcpy(dst, src + (size_t)(width - sx) * 3, (size_t)sx * 3);
+                    }
+                    uint16_t* d = f->depth.ptr<uint16_t>(y); for (int c = 0; c < width; c++) d[c] = dval;
+                }
+                f->T_f_w = Eigen::Isometry3d::Identity();
+                f->T_f_w(0, 3) = k * 2 * Z / camera.fx; f->T_f_w(1, 3) = k * Z / camera.fy;
+                f->raw_semantic = f->semantic; f->result = f->rgb;
+                return f;
+            }
             dev->check(ssm_synth_frames_dev(x, seed, index, 1, width, height, (uint8_t*)d_bgr, (uint16_t*)d_dep, (uint8_t*)d_sem, nullptr, (double*)d_pose), "synth");
             dev->check(ssm_memcpy_d2h(x, f->rgb.data, d_bgr, np * 3), "d2h"); dev->check(ssm_memcpy_d2h(x, f->depth.data, d_dep, np * 2), "d2h");
             dev->check(ssm_memcpy_d2h(x, f->semantic.data, d_sem, np * 3), "d2h");
@@ -139,6 +167,7 @@ protected:
     const ParameterReader& parameterReader;
     DATASET dataset_type; int currentIndex = 0, start_index = 0, end_index = 0; uint64_t seed = 0; string dataset_dir;
     CAMERA_INTRINSIC_PARAMETERS camera;
+    bool rigid = false; int rigid_period = 20; cv::Mat base_bgr, base_sem;
     unique_ptr<ssm::Device> dev; void *d_bgr = nullptr, *d_dep = nullptr, *d_sem = nullptr, *d_pose = nullptr;
 };
 }  // namespace rgbd_tutor

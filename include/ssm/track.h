@@ -50,6 +50,16 @@ public:
         return false;
     }
     const deque<RGBDFrame::Ptr>& referenceFrames() const { return refFrames; }
+    // a new sequence starts with the next frame: the state a freshly constructed Tracker has (not in the reference, which tracks one sequence per process;
+    // exp_mapping's `sequence_length` uses it for streams that are a concatenation of independent sequences)
+    void reset() {
+        unique_lock<mutex> lck(adjustMutex);
+        state = NOT_READY; refFrames.clear(); currentFrame = nullptr; cntLost = 0;
+        lastPose = speed = pose = Eigen::Isometry3d::Identity();
+    }
+    // wall time spent inside updateFrame so far, split the way the reference's own drivers print it (experiment/match_orbfeature_tum.cpp:22-27: detect + match;
+    // experiment/run_tracker.cpp:35-48: the whole updateFrame): milliseconds, summed over the calls
+    struct Timing { double detect_ms = 0, match_ms = 0, pnp_ms = 0; long frames = 0; } timing;
     shared_ptr<OrbFeature> orbFeature() const { return orb; }
 protected:
     void initFirstFrame() {                                             // track.cpp:30-36
@@ -88,9 +98,13 @@ protected:
     }
     void trackRefFrame() {                                              // track.cpp:140-200
         currentFrame->setTransform(speed * refFrames.back()->getTransform());
+        const auto tm0 = chrono::steady_clock::now();
         orb->detectFeatures(currentFrame);
+        const auto tm1 = chrono::steady_clock::now();
         vector<cv::Point3f> obj; vector<cv::Point2f> img;
         const vector<vector<cv::DMatch>> allMatches = orb->matchMany(refFrames, currentFrame);      // orb->match(pFrame, currentFrame) for every pFrame, one wait
+        const auto tm2 = chrono::steady_clock::now();
+        timing.detect_ms += chrono::duration<double, milli>(tm1 - tm0).count(); timing.match_ms += chrono::duration<double, milli>(tm2 - tm1).count(); timing.frames++;
         size_t ri = 0;
         for (auto pFrame : refFrames) {
             const vector<cv::DMatch>& matches = allMatches[ri++];
@@ -107,7 +121,9 @@ protected:
         if (img.size() < 15) { cntLost++; if (cntLost > max_lost_frame) state = LOST; return; }
         vector<int> inlierIndex;
         Eigen::Isometry3d T = speed * lastPose;
+        const auto tm3 = chrono::steady_clock::now();
         pnp->solvePnP(img, obj, currentFrame->camera, inlierIndex, T);
+        timing.pnp_ms += chrono::duration<double, milli>(chrono::steady_clock::now() - tm3).count();
         lastInliers = (int)inlierIndex.size();
         if (inlierIndex.size() < 15) { cntLost++; if (cntLost > max_lost_frame) state = LOST; return; }
         currentFrame->setTransform(T);

@@ -816,18 +816,20 @@ fast_retry_kernel(const uint8_t* __restrict__ pyr, OrbGeom g, cand_t* __restrict
     }
 }
 size_t k_fast_cellmax_ints(int nframes, const OrbGeom& g) { return (size_t)nframes * (g.cells_total + g.ftiles_total) + 16; }
+size_t k_fast_ncand_pad(int nframes, const OrbGeom& g) { return ((size_t)nframes * g.nlevels + 63) & ~(size_t)63; }
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(cellmax, 0, sizeof(int32_t) * (size_t)n * g.cells_total, s);
+    // zero: the candidate counters, the n frames' cell maxima and the retry list's length (the word at work - 1, right behind the maxima).  The context allocates the
+    // counters in FRONT of the maxima (k_fast_ncand_pad ints, one allocation), so that this is one fill; any other layout takes the two fills
+    hipError_t e;
+    const ptrdiff_t gap = cellmax - ncand;
+    if (gap >= (ptrdiff_t)n * g.nlevels && gap <= (ptrdiff_t)1 << 24) e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * ((size_t)gap + (size_t)n * g.cells_total + 4), s);
+    else { e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s); if (e == hipSuccess) e = hipMemsetAsync(cellmax, 0, sizeof(int32_t) * ((size_t)n * g.cells_total + 4), s); }
     if (e != hipSuccess) return e;
     // SSM_FAST_STAGE_CAP (tests): a smaller staging area forces the per-candidate global path that tiles with more than FT_STAGE maxima take
     static const int stage_cap = [] { const char* e = getenv("SSM_FAST_STAGE_CAP"); const int v = e ? atoi(e) : FT_STAGE; return v < 0 ? 0 : (v > FT_STAGE ? FT_STAGE : v); }();
     // the retry work list lives behind the n frames' cell maxima (the buffer is sized for it: k_fast_cellmax_ints)
     int32_t* work = cellmax + (size_t)n * g.cells_total + 4;
-    e = hipMemsetAsync(work - 1, 0, 4, s);
-    if (e != hipSuccess) return e;
     const int n8 = (n + 7) & ~7;
     fast_kernel<<<dim3(n8, g.ftiles_total), 256, 0, s>>>(pyr, g, cand, ncand, cellmax, stage_cap, n);
     fast_need_kernel<<<(n8 * g.ftiles_total + 255) / 256, 256, 0, s>>>(g, cellmax, n, work);

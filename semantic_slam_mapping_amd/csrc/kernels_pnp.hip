@@ -840,20 +840,28 @@ pnp_chain_kernel(PnpChainArgs a)
     }
 }
 // ---- PnPSolver::solvePnP alone (ssm_pnp_solve): the same pc_solve on a caller's correspondence list
-template <int AS>
+template <bool CL, int AS>
 __global__ void __launch_bounds__(PC_T)
 pnp_solve_kernel(PnpSolveArgs a)
 {
     __shared__ PcShared sh;
     extern __shared__ __align__(16) unsigned char pc_dyn[];
+    if constexpr (CL) {                                        // block b's private scratch (the blocks run the same program and agree by construction, like the chain's cluster)
+        const size_t b = blockIdx.x;
+        a.inl += b * a.slice; a.dec += b * a.slice; a.err += b * a.slice;
+        a.ledges = reinterpret_cast<LEdge*>(reinterpret_cast<unsigned char*>(a.ledges) + b * a.slice * sizeof(LEdge));
+        if (threadIdx.x == 0) { sh.xmb = a.xchg; sh.xfail = a.xfail; sh.xseq = a.seq_base; }
+    }
     EdgeMem<AS> L; if constexpr (AS == 3) L.p = (typename EdgeMem<AS>::W*)pc_dyn; else L.p = (typename EdgeMem<AS>::W*)a.ledges;
     if (threadIdx.x < 16) sh.T[threadIdx.x] = a.T[threadIdx.x];
     if (threadIdx.x < 4) sh.work[threadIdx.x] = 0;
     __syncthreads();
-    const int m = pc_solve<false>(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
+    const int m = pc_solve<CL>(a.img, a.obj, a.n, a.cam, sh.T, a.inl, L, a.err, a.dec, sh);
     __syncthreads();
-    if (threadIdx.x < 16) a.T[threadIdx.x] = sh.T[threadIdx.x];
-    if (threadIdx.x == 0) *a.n_inliers = m;
+    if (!CL || blockIdx.x == 0) {
+        if (threadIdx.x < 16) a.T[threadIdx.x + 16] = sh.T[threadIdx.x];          // T out sits behind T in (a block of the cluster may still be reading T in when block 0 is done)
+        if (threadIdx.x == 0) *a.n_inliers = m;
+    }
 }
 static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const void* fn)
 {
@@ -876,9 +884,15 @@ static hipError_t pc_dyn_size(size_t nedges, int* in_lds, size_t* dyn, const voi
 hipError_t k_pnp_solve(const PnpSolveArgs& a_in, hipStream_t s)
 {
     PnpSolveArgs a = a_in; size_t dyn;
-    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel<3>));
+    if (a.blocks > 1) {                                        // the cluster form (the caller owns the ring's zeroing and the time-out word: PnpSolveArgs::seq_base)
+        hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel<true, 3>));
+        if (e != hipSuccess) return e;
+        if (a.edges_in_lds) pnp_solve_kernel<true, 3><<<a.blocks, PC_T, dyn, s>>>(a); else pnp_solve_kernel<true, 1><<<a.blocks, PC_T, 0, s>>>(a);
+        return hipGetLastError();
+    }
+    hipError_t e = pc_dyn_size((size_t)(a.n > 0 ? a.n : 1), &a.edges_in_lds, &dyn, reinterpret_cast<const void*>(pnp_solve_kernel<false, 3>));
     if (e != hipSuccess) return e;
-    if (a.edges_in_lds) pnp_solve_kernel<3><<<1, PC_T, dyn, s>>>(a); else pnp_solve_kernel<1><<<1, PC_T, 0, s>>>(a);
+    if (a.edges_in_lds) pnp_solve_kernel<false, 3><<<1, PC_T, dyn, s>>>(a); else pnp_solve_kernel<false, 1><<<1, PC_T, 0, s>>>(a);
     return hipGetLastError();
 }
 size_t k_pnp_edge_bytes(void) { return sizeof(LEdge); }

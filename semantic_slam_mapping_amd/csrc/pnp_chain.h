@@ -33,6 +33,10 @@ hipError_t k_pnp_chain(const PnpChainArgs& a, hipStream_t s);
 struct PnpSolveArgs {
     const float *img, *obj; int n; ssm_pnp::Camera cam; double* T; uint8_t *inl, *dec; struct LEdge* ledges; double2* err; int32_t* n_inliers;
     int edges_in_lds;                                // set by k_pnp_solve
+    // the cluster form (round 6): `blocks` (1 or 8) blocks solve the list together like a chain's cluster does -- inl / dec / ledges / err hold `blocks` slices of
+    // `slice` entries (block b's private copy; slice 0 is the result), xchg / xfail as in PnpChainArgs; T and n_inliers are written by block 0
+    int blocks; size_t slice; unsigned long long* xchg; unsigned* xfail;
+    unsigned seq_base;                               // first pass number of this launch: the ring is NOT zeroed per launch -- pass tags keep rising from launch to launch (the caller zeroes the ring when the numbers wrap), and xfail is a word the caller uploads as 0
 };
 hipError_t k_pnp_solve(const PnpSolveArgs& a, hipStream_t s);
 size_t k_pnp_edge_bytes(void);

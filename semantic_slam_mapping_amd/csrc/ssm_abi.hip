@@ -215,9 +215,11 @@ static int ctx_init(ssm_ctx* c)
         }
     }
     // d_pyr + 16: resize4_kernel's 8-byte windows may end past the last row
-    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.blur_bytes); DALLOC(c, c->d_cellmax, k_fast_cellmax_ints(B, g));
+    DALLOC(c, c->d_pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, c->d_blur, (size_t)B * g.blur_bytes);
+    // the per-level candidate counters and the cell maxima (+ k_fast's retry list) share ONE allocation, counters first: k_fast zeroes both with one fill
+    DALLOC(c, c->d_ncand, k_fast_ncand_pad(B, g) + k_fast_cellmax_ints(B, g)); c->d_cellmax = c->d_ncand + k_fast_ncand_pad(B, g);
     DALLOC(c, c->d_cand, (size_t)B * g.cand_total); DALLOC(c, c->d_nodeof, (size_t)B * g.cand_total);
-    DALLOC(c, c->d_ncand, (size_t)B * g.nlevels); DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
+    DALLOC(c, c->d_sel, (size_t)B * g.sel_total); DALLOC(c, c->d_nsel, (size_t)B * g.nlevels);
     DALLOC(c, c->d_kpaux, (size_t)B * g.sel_total * 2);          // KpAux + KpRec per slot
     DALLOC(c, c->d_status, 1); HIPCHK(c, hipMemset(c->d_status, 0, 4));
     const int chunks = backproject_chunks(W, H);
@@ -270,18 +272,19 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, c->d_cellmax, c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
+    void* ptrs[] = { c->d_pattern, c->d_pyr, c->d_blur, /* d_cellmax: inside d_ncand's allocation */ c->d_cand, c->d_nodeof, c->d_ncand, c->d_sel, c->d_nsel, c->d_status, c->d_mask,
                      c->d_chunk_cnt, c->d_chunk_off, c->d_total, c->d_points, c->d_in_img, c->d_in_sem, c->d_in_depth, c->d_in_pose,
                      c->d_scratch, c->d_scratch2, c->d_kps, c->d_desc_all, c->d_nkp_all, c->d_pos3d, c->d_matches, c->d_nmatch, c->d_match_pend, c->d_npoints,
                      c->d_hist_tmp, c->map.tab, c->tmp.tab, c->d_kpaux, c->d_pattern_f, c->d_exp_q, c->d_exp_t, c->d_knn, c->d_blur_tab, c->d_vmap, c->d_vcat };
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->map.ovf) hipFree(c->map.ovf);
+    if (c->d_pnp_xchg) hipFree(c->d_pnp_xchg);
     if (c->h_map_snap) hipHostFree(c->h_map_snap);
     for (int k = 0; k < 2; k++) if (c->map_snap_ev[k]) hipEventDestroy(c->map_snap_ev[k]);
-    { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cellmax, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
+    { void* ap[] = { c->alt.pyr, c->alt.blur, c->alt.cand, c->alt.nodeof, c->alt.ncand, c->alt.sel, c->alt.nsel, c->alt.mask, c->alt.kpaux };
       for (void* p : ap) if (p) hipFree(p); }
     for (int i = 0; i < 3; i++) if (c->ev_orb[i]) hipEventDestroy(c->ev_orb[i]);
-    { void* ap2[] = { c->alt2.pyr, c->alt2.blur, c->alt2.cellmax, c->alt2.cand, c->alt2.nodeof, c->alt2.ncand, c->alt2.sel, c->alt2.nsel, c->alt2.mask, c->alt2.kpaux };
+    { void* ap2[] = { c->alt2.pyr, c->alt2.blur, c->alt2.cand, c->alt2.nodeof, c->alt2.ncand, c->alt2.sel, c->alt2.nsel, c->alt2.mask, c->alt2.kpaux };
       for (void* p : ap2) if (p) hipFree(p); }
     if (c->stream4) hipStreamDestroy(c->stream4);
     if (c->ev_join4) hipEventDestroy(c->ev_join4);
@@ -388,9 +391,10 @@ static int ensure_alt_ws(ssm_ctx* c, ssm_ctx::AltWork& a)
 {
     if (a.ready) return SSM_OK;
     const OrbGeom& g = c->g; const int B = c->B;
-    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.blur_bytes); DALLOC(c, a.cellmax, k_fast_cellmax_ints(B, g));
+    DALLOC(c, a.pyr, (size_t)B * g.pyr_bytes + 16); DALLOC(c, a.blur, (size_t)B * g.blur_bytes);
+    DALLOC(c, a.ncand, k_fast_ncand_pad(B, g) + k_fast_cellmax_ints(B, g)); a.cellmax = a.ncand + k_fast_ncand_pad(B, g);
     DALLOC(c, a.cand, (size_t)B * g.cand_total); DALLOC(c, a.nodeof, (size_t)B * g.cand_total);
-    DALLOC(c, a.ncand, (size_t)B * g.nlevels); DALLOC(c, a.sel, (size_t)B * g.sel_total); DALLOC(c, a.nsel, (size_t)B * g.nlevels);
+    DALLOC(c, a.sel, (size_t)B * g.sel_total); DALLOC(c, a.nsel, (size_t)B * g.nlevels);
     DALLOC(c, a.mask, (size_t)B * g.W * g.H); DALLOC(c, a.kpaux, (size_t)B * g.sel_total * 2);
     a.ready = true;
     return SSM_OK;
@@ -481,16 +485,33 @@ static int orb_extract_enqueue(ssm_ctx* c, const uint8_t* img, int w, int h, int
     uint8_t *hp, *dp;
     int r = ring_take(c, ib + db + 64 + blk, blk, &hp, &dp); if (r) return r;
     uint8_t* h_in = hp; uint8_t* h_out = hp + ((ib + db + 63) & ~(size_t)63);
+    // round 6: the call is a latency chain (20 launches of 4 - 40 us for one frame + the staging copies).  The depth image is read by the LAST kernel only, and only at
+    // the <= cap keypoints: it is staged into the pinned ring while gray .. quad-tree run (after their launches, before the describe launches) and the kernel reads it
+    // there, through the ring's device mapping -- no 0.6 MB upload, no staging time in front of the first kernel.  (Measured and dropped: the blur on a side stream
+    // beside FAST + the quad-tree -- two cross-stream events cost more than the 17 us they hide: 177 -> 223 us from first to last kernel.)
     if ((size_t)stride == row) memcpy(h_in, img, ib);
     else for (int y = 0; y < h; y++) memcpy(h_in + (size_t)y * row, img + (size_t)y * stride, row);
-    if (depth) memcpy(h_in + ib, depth, db);
     HIPCHK(c, hipMemcpyAsync(c->d_in_img, h_in, ib, hipMemcpyHostToDevice, c->stream));
-    if (depth) HIPCHK(c, hipMemcpyAsync(c->d_in_depth, h_in + ib, db, hipMemcpyHostToDevice, c->stream));
     int32_t* dn = reinterpret_cast<int32_t*>(dp);
     ssm_keypoint* dk = reinterpret_cast<ssm_keypoint*>(dp + 64);
     uint8_t* dd = reinterpret_cast<uint8_t*>(dk + ocap);
     float* dps = reinterpret_cast<float*>(dd + (size_t)ocap * 32);
-    r = run_orb(c, c->d_in_img, channels, depth ? c->d_in_depth : nullptr, 1, dk, dd, dps, dn); if (r) return r;
+    {
+        const OrbGeom& g = c->g; hipStream_t s = c->stream;
+        prof_begin(c, "gray");      HIPCHK(c, k_gray(c->d_in_img, channels, 1, g, c->d_pyr, s)); prof_end(c);
+        prof_begin(c, "pyramid");   HIPCHK(c, k_pyramid(1, g, c->d_pyr, c->d_xofs, c->d_xa, c->d_yofs, c->d_ya, c->d_xgrp, s)); prof_end(c);
+        prof_begin(c, "fast");      HIPCHK(c, k_fast(1, g, c->d_pyr, c->d_cand, c->d_ncand, c->d_cellmax, s)); prof_end(c);
+        prof_begin(c, "octree");    HIPCHK(c, k_octree(1, g, c->d_cand, c->d_ncand, c->d_cellmax, c->d_nodeof, c->d_sel, c->d_nsel, c->d_status, s)); prof_end(c);
+        prof_begin(c, "blur");      HIPCHK(c, c->blur_mfma ? k_blur_mfma(1, g, c->d_pyr, c->d_blur, c->d_blur_tab, s) : k_blur(1, g, c->d_pyr, c->d_blur, s)); prof_end(c);
+        const uint16_t* d_depth = nullptr;
+        if (depth) {
+            memcpy(h_in + ib, depth, db);                          // (the device is busy with the launches above meanwhile)
+            void* mapped = nullptr;
+            HIPCHK(c, hipHostGetDevicePointer(&mapped, h_in + ib, 0));
+            d_depth = reinterpret_cast<const uint16_t*>(mapped);
+        }
+        prof_begin(c, "describe");  HIPCHK(c, k_describe(1, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern_f, d_depth, c->cfg.camera, c->d_kpaux, dk, dd, dps, dn, s)); prof_end(c);
+    }
     HIPCHK(c, hipMemcpyAsync(dn + 1, c->d_status, 4, hipMemcpyDeviceToDevice, c->stream));          // the ORB scratch-overflow word travels in the block's header
     HIPCHK(c, hipMemcpyAsync(h_out, dp, blk, hipMemcpyDeviceToHost, c->stream));
     c->pending.push_back([=](ssm_ctx* cc) -> int {

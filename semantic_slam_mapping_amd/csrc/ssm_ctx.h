@@ -107,6 +107,8 @@ struct ssm_ctx {
     // staging for the host-pointer entry points (one frame) + generic scratch
     uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;
     void* d_scratch = nullptr; size_t scratch_bytes = 0;
+    unsigned long long* d_pnp_xchg = nullptr; unsigned pnp_epoch = 0;    // ssm_pnp_solve's cluster: the exchange ring (persistent) and the launch number its pass tags start from
+    bool pnp_solve_one_block = false;                        // ssm_pnp_solve: a cluster of eight blocks timed out once -> one block per solve from then on
     void* d_scratch2 = nullptr; size_t scratch2_bytes = 0;
     // the stream that holds the newest work on the context map when that is a side stream of ssm_seq_process (joined into `stream` by an event, so everything queued
     // on `stream` afterwards is ordered behind it): ssm_map_size / ssm_map_export_table_dev read the map there and wait for THAT stream only -- the ORB -> match chain of

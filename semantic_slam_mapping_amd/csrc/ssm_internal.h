@@ -60,6 +60,7 @@ hipError_t k_blur_mfma(int n, const OrbGeom& g, const uint8_t* pyr, uint8_t* blu
 size_t blur_mfma_table_bytes(const OrbGeom& g);
 void blur_mfma_tables(const OrbGeom& g, void* host_out);
 hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int32_t* ncand, int32_t* cellmax /* k_fast_cellmax_ints(frames) ints */, hipStream_t s);
+size_t k_fast_ncand_pad(int nframes, const OrbGeom& g);         // ints reserved for the per-level candidate counters in front of the cell maxima (one allocation, one fill)
 size_t k_fast_cellmax_ints(int nframes, const OrbGeom& g);      // per-cell maxima of nframes frames + the retry work list of k_fast behind them
 hipError_t k_octree(int n, const OrbGeom& g, const cand_t* cand, const int32_t* ncand, const int32_t* cellmax, uint16_t* node_of,
                     uint32_t* sel, int32_t* nsel, int32_t* status, hipStream_t s);

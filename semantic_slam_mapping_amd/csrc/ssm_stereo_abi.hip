@@ -440,7 +440,53 @@ extern "C" int ssm_vo_estimate(ssm_ctx* c, const ssm_pmatch* matches, int n, con
     return SSM_OK;
 }
 
-// PnPSolver::solvePnP (reference src/pnp.cpp:5-118) for one correspondence list: the block of kernels_pnp.hip that the pose chain runs per frame
+// PnPSolver::solvePnP (reference src/pnp.cpp:5-118) for one correspondence list: the solve that the pose chain of kernels_pnp.hip runs per frame.
+// Round 6: a cluster of eight blocks per call, like the chain's (every block evaluates an eighth of the lanes' edges in a pass and the blocks trade the partial sums:
+// same bits as one block, the per-frame Tracker's largest call 0.53 -> ~0.35 ms); one block after a cluster timed out once (the blocks need eight CUs at the same
+// time) or with SSM_PNP_BLOCKS=1.
+static int pnp_solve_impl(ssm_ctx* c, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16], uint8_t* inliers, int* n_inliers, int* success, int G)
+{
+    // ONE upload ([img | obj | header: T in, T out, time-out word, inlier count] staged in pinned memory) and ONE download ([T out .. count | the inlier flags]): the
+    // call was three uploads, a fill of the exchange ring and four downloads (0.09 ms of its 0.42).  The cluster's ring lives in the context and is zeroed when its
+    // pass numbers wrap, not per call.
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t ne = (size_t)(n > 0 ? n : 1), slice = al(ne);
+    const size_t o_img = 0, o_obj = o_img + ne * 8, o_hdr = (o_obj + ne * 12 + 15) & ~(size_t)15, HDR = 288 /* T in 128 | T out 128 | xfail 4, pad 4 | count 4, pad 4 | pad 16 */,
+                 o_inl = o_hdr + HDR, o_dec = o_inl + G * slice, o_le = al(o_dec + G * slice), o_err = o_le + al(G * slice * k_pnp_edge_bytes()), total = o_err + al(G * slice * 16);
+    const size_t up = o_hdr + HDR, down = HDR - 128 + (size_t)n;               // download: [T out | xfail | count | pad][inl slice 0: n bytes]
+    int r = ensure_scratch(c, total); if (r) return r;
+    r = ensure_pinned(c, al(up) + al(down)); if (r) return r;
+    if (G > 1) {
+        if (!c->d_pnp_xchg) { HIPCHK(c, hipMalloc((void**)&c->d_pnp_xchg, k_pnp_xchg_bytes())); c->pnp_epoch = 0; }
+        if (c->pnp_epoch == 0) HIPCHK(c, hipMemsetAsync(c->d_pnp_xchg, 0, k_pnp_xchg_bytes(), c->stream));
+    }
+    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
+    uint8_t* hu = c->h_pinned; uint8_t* hd = c->h_pinned + al(up);
+    if (n) { memcpy(hu + o_img, img, (size_t)n * 8); memcpy(hu + o_obj, obj, (size_t)n * 12); }
+    memset(hu + o_hdr, 0, HDR); memcpy(hu + o_hdr, T, 128);
+    { const char* tv = getenv("SSM_PNP_TEST_TIMEOUT"); if (G > 1 && tv && atoi(tv) != 0) { const unsigned one = 1; memcpy(hu + o_hdr + 256, &one, 4); } }      // tests: the time-out word set from the start -> the one-block retry
+    HIPCHK(c, hipMemcpyAsync(p, hu, up, hipMemcpyHostToDevice, s));
+    PnpSolveArgs a; a.img = (const float*)(p + o_img); a.obj = (const float*)(p + o_obj); a.n = n;
+    a.cam.fx = cam[0]; a.cam.fy = cam[1]; a.cam.cx = cam[2]; a.cam.cy = cam[3];
+    a.T = (double*)(p + o_hdr); a.inl = p + o_inl; a.dec = p + o_dec; a.ledges = (LEdge*)(p + o_le); a.err = (double2*)(p + o_err); a.n_inliers = (int32_t*)(p + o_hdr + 264); a.edges_in_lds = 0;
+    a.blocks = G; a.slice = slice; a.xchg = c->d_pnp_xchg; a.xfail = reinterpret_cast<unsigned*>(p + o_hdr + 256);
+    a.seq_base = (unsigned)c->pnp_epoch << 20;                  // a solve makes a few thousand passes at most; the ring is zeroed again when the epoch wraps
+    if (G > 1) c->pnp_epoch = (c->pnp_epoch + 1) & 4095;
+    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
+    prof_begin(c, "pnp");
+    HIPCHK(c, k_pnp_solve(a, s));
+    prof_end(c);
+    HIPCHK(c, hipMemcpyAsync(hd, p + o_hdr + 128, down, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    unsigned failed = 0; int32_t m = 0;
+    memcpy(&failed, hd + 128, 4); memcpy(&m, hd + 136, 4);
+    if (G > 1 && failed) { c->pnp_epoch = 0; return 1; }        // an exchange of the cluster timed out: nothing of this attempt is used (and the ring starts clean next time)
+    memcpy(T, hd, 128);
+    if (inliers && n) memcpy(inliers, hd + HDR - 128, (size_t)n);
+    *n_inliers = m;
+    if (success) *success = n > min_inliers;                   // pnp.cpp:115 tests the flag vector's LENGTH (quirk 14)
+    return SSM_OK;
+}
 extern "C" int ssm_pnp_solve(ssm_ctx* c, const float* img, const float* obj, int n, const double cam[4], int min_inliers, double T[16],
                              uint8_t* inliers, int* n_inliers, int* success)
 {
@@ -448,28 +494,11 @@ extern "C" int ssm_pnp_solve(ssm_ctx* c, const float* img, const float* obj, int
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (n < 0 || !cam || !T || !n_inliers || (n && (!img || !obj))) FAIL(c, SSM_E_INVAL, "bad arguments");
     if (n > 65535) FAIL(c, SSM_E_CAPACITY, "at most 65535 correspondences");
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t ne = (size_t)(n > 0 ? n : 1);
-    const size_t o_img = 0, o_obj = o_img + al(ne * 8), o_T = o_obj + al(ne * 12), o_inl = o_T + 256, o_dec = o_inl + al(ne), o_le = o_dec + al(ne),
-                 o_err = o_le + al(ne * k_pnp_edge_bytes()), o_n = o_err + al(ne * 16), total = o_n + 256;
-    int r = ensure_scratch(c, total); if (r) return r;
-    uint8_t* p = (uint8_t*)c->d_scratch; hipStream_t s = c->stream;
-    if (n) { HIPCHK(c, hipMemcpyAsync(p + o_img, img, (size_t)n * 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipMemcpyAsync(p + o_obj, obj, (size_t)n * 12, hipMemcpyHostToDevice, s)); }
-    HIPCHK(c, hipMemcpyAsync(p + o_T, T, 128, hipMemcpyHostToDevice, s));
-    PnpSolveArgs a; a.img = (const float*)(p + o_img); a.obj = (const float*)(p + o_obj); a.n = n;
-    a.cam.fx = cam[0]; a.cam.fy = cam[1]; a.cam.cx = cam[2]; a.cam.cy = cam[3];
-    a.T = (double*)(p + o_T); a.inl = p + o_inl; a.dec = p + o_dec; a.ledges = (LEdge*)(p + o_le); a.err = (double2*)(p + o_err); a.n_inliers = (int32_t*)(p + o_n); a.edges_in_lds = 0;
-    if (c->profiling) { c->recs.clear(); c->pool_used = 0; }
-    prof_begin(c, "pnp");
-    HIPCHK(c, k_pnp_solve(a, s));
-    prof_end(c);
-    int32_t m = 0;
-    HIPCHK(c, hipMemcpyAsync(T, p + o_T, 128, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&m, p + o_n, 4, hipMemcpyDeviceToHost, s));
-    if (inliers && n) HIPCHK(c, hipMemcpyAsync(inliers, p + o_inl, (size_t)n, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    *n_inliers = m;
-    if (success) *success = n > min_inliers;                   // pnp.cpp:115 tests the flag vector's LENGTH (quirk 14)
-    return SSM_OK;
+    static const int env_blocks = [] { const char* e = getenv("SSM_PNP_BLOCKS"); return e ? atoi(e) : 8; }();
+    if (env_blocks == 8 && !c->pnp_solve_one_block) {
+        const int r = pnp_solve_impl(c, img, obj, n, cam, min_inliers, T, inliers, n_inliers, success, 8);
+        if (r <= 0) return r;
+        c->pnp_solve_one_block = true;                          // (T is untouched: the retry starts from the caller's initial value)
+    }
+    return pnp_solve_impl(c, img, obj, n, cam, min_inliers, T, inliers, n_inliers, success, 1);
 }
-

@@ -131,10 +131,23 @@ int main(int argc, char** argv)
         int nframes = 0;
         const int frame_period_ms = parameterReader.getData<int>("frame_period_ms", 0);
         Trajectory traj(parameterReader.getData<string>("trajectory_output", string("")));
-        auto t0 = chrono::steady_clock::now();
+        // `sequence_length` = L > 0: the stream is a concatenation of independent sequences of L frames (synthetic_rigid streams): the tracker starts over at every
+        // multiple of L.  `timing_skip_frames`: the rates printed at the end leave out the first frames (context creation, code-object load, first-use allocations).
+        const int seq_len = parameterReader.getData<int>("sequence_length", 0), skip = parameterReader.getData<int>("timing_skip_frames", 0);
+        // where the loop's wall time goes, the way the reference's drivers time it: FrameReader::next (experiment/exp_mapping.cpp:36), Tracker::updateFrame
+        // (experiment/run_tracker.cpp:35-48) / BatchTracker::push, PoseGraph::tryInsertKeyFrame (:47)
+        double reader_s = 0, track_s = 0, kf_s = 0; int timed = 0;
+        typedef chrono::steady_clock::time_point tp;
+        auto now = [] { return chrono::steady_clock::now(); };
+        auto sec = [](tp a, tp b) { return chrono::duration<double>(b - a).count(); };
+        auto t0 = now(); tp t_timed0 = t0;
+        auto read_next = [&]() { const tp a = now(); RGBDFrame::Ptr f = frameReader.next(); if (nframes >= skip && f) reader_s += sec(a, now()); return f; };
         if (batched && parameterReader.getData<string>("tracker_mode", string("rgbd")) == "rgbd") {
-            unique_ptr<BatchTracker> bt; map<int, Eigen::Isometry3d> gt; int lost = 0;
-            auto handle = [&](const vector<RGBDFrame::Ptr>& done) {
+            unique_ptr<BatchTracker> bt; map<int, Eigen::Isometry3d> gt; int lost = 0; int pushed = 0;
+            const bool chain = parameterReader.getData<int>("tracker_batched_chain", 1) != 0;
+            if (!chain && !use_gt_pose) throw invalid_argument("tracker_batched_chain=0 needs use_stream_pose=1: without the chain nothing computes the poses");
+            // (rates: a chunk counts as a whole -- the frames of a flush that started at or after timing_skip_frames, against the time of that flush)
+            auto handle = [&](const vector<RGBDFrame::Ptr>& done, bool counted) {
                 for (size_t i = 0; i < done.size(); i++) {
                     const RGBDFrame::Ptr& f = done[i];
                     if (use_gt_pose) f->setTransform(gt[f->id]);
@@ -142,52 +155,98 @@ int main(int argc, char** argv)
                     traj.add(f);
                     poseGraph.tryInsertKeyFrame(const_cast<RGBDFrame::Ptr&>(f));
                     if (bt->infos[i].state == Tracker::LOST) { cout << "tracker is lost" << endl; lost++; }
+                    if (counted) timed++;
                     nframes++;
                 }
             };
-            while (RGBDFrame::Ptr frame = frameReader.next()) {
+            while (RGBDFrame::Ptr frame = read_next()) {
                 if (!bt) bt.reset(new BatchTracker(parameterReader, frame->rgb.cols, frame->rgb.rows, frame->T_f_w));
+                const bool count = nframes >= skip; const tp a = now();
+                if (count && timed == 0 && track_s == 0) t_timed0 = a;
+                if (seq_len > 0 && chain && pushed > 0 && pushed % seq_len == 0) { handle(bt->flush(), count); bt->reset(); }     // (without the chain a sequence boundary changes nothing: features and tables only)
                 gt[frame->id] = frame->T_f_w;
-                handle(bt->push(frame));
+                pushed++;
+                handle(bt->push(frame), count);
+                if (count) track_s += sec(a, now());
             }
-            if (bt) handle(bt->flush());
+            const tp a = now(); const bool count = nframes >= skip;
+            if (bt) handle(bt->flush(), count);
+            if (count) track_s += sec(a, now());
             cout << "batched tracker: chunk " << (bt ? bt->chunk() : 0) << " lost " << lost << endl;
         } else if (batched_stereo) {
             // Tracker::estimateVO + FrameReader's SGBM depth in bulk (include/ssm/batch_stereo_tracker.h): quad matcher, depth and ego-motion of a chunk per launch
             unique_ptr<BatchStereoTracker> bs; int lost = 0;
-            auto handle = [&](const vector<RGBDFrame::Ptr>& done) {
+            auto handle = [&](const vector<RGBDFrame::Ptr>& done, bool counted) {
                 for (size_t i = 0; i < done.size(); i++) {
                     const RGBDFrame::Ptr& f = done[i];
                     traj.add(f);
                     poseGraph.tryInsertKeyFrame(const_cast<RGBDFrame::Ptr&>(f));
                     if (bs->infos[i].state == Tracker::LOST) { cout << "tracker is lost" << endl; lost++; }
+                    if (counted) timed++;
                     nframes++;
                 }
             };
-            while (RGBDFrame::Ptr frame = frameReader.next()) {
+            while (RGBDFrame::Ptr frame = read_next()) {
                 if (!bs) bs.reset(new BatchStereoTracker(parameterReader, voparam, frame->img_lc.cols, frame->img_lc.rows));
-                handle(bs->push(frame));
+                const bool count = nframes >= skip; const tp a = now();
+                if (count && timed == 0 && track_s == 0) t_timed0 = a;
+                handle(bs->push(frame), count);
+                if (count) track_s += sec(a, now());
             }
-            if (bs) handle(bs->flush());
+            const tp a = now(); const bool count = nframes >= skip;
+            if (bs) handle(bs->flush(), count);
+            if (count) track_s += sec(a, now());
             cout << "batched stereo tracker: chunk " << (bs ? bs->chunk() : 0) << " lost " << lost << endl;
         } else
-        while (RGBDFrame::Ptr frame = frameReader.next()) {
+        while (RGBDFrame::Ptr frame = read_next()) {
+            if (nframes == skip) { t_timed0 = now(); tracker->timing = Tracker::Timing(); }
+            if (seq_len > 0 && nframes > 0 && nframes % seq_len == 0) tracker->reset();
             Eigen::Isometry3d gt = frame->T_f_w;
+            const tp a = now();
             tracker->updateFrame(frame);
+            const tp b = now();
             if (use_gt_pose) frame->setTransform(gt);           // synthetic stream: poses are given, the tracker only produces features/matches
             traj.add(frame);
             poseGraph.tryInsertKeyFrame(frame);
+            if (nframes >= skip) { track_s += sec(a, b); kf_s += sec(b, now()); timed++; }
             if (tracker->getState() == Tracker::LOST) cout << "tracker is lost" << endl;
             nframes++;
             if (frame_period_ms > 0) this_thread::sleep_for(chrono::milliseconds(frame_period_ms));      // a camera's frame period (measurements of the viewer thread under a paced stream)
         }
-        const double s = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+        const tp t1 = now();
+        const double s = sec(t0, t1), s_timed = sec(t_timed0, t1);
         mapper.SaveMap();
         poseGraph.shutdown();
         this_thread::sleep_for(chrono::milliseconds(parameterReader.getData<int>("mapper_drain_ms", 300)));
         mapper.shutdown();
         cout << "frames " << nframes << " keyframes " << poseGraph.keyframes.size() << " map_updates " << mapper.updates()
-             << " map_points " << (mapper.getGlobalMap() ? mapper.getGlobalMap()->points.size() : 0) << " pose_fnv " << hex << traj.h << dec << " host_loop_fps " << nframes / s << endl;
+             << " map_points " << (mapper.getGlobalMap() ? mapper.getGlobalMap()->points.size() : 0) << " pose_fnv " << hex << traj.h << dec << " host_loop_fps " << nframes / s;
+        // the rates of the frames after timing_skip_frames: loop_fps = the whole loop (reader included); tracker_fps = frames / time inside updateFrame (or BatchTracker::push /
+        // flush) -- what experiment/run_tracker.cpp:35-48 times; the *_ms are per frame
+        if (timed > 0) {
+            const Tracker::Timing& tt = tracker->timing; const double fr = tt.frames > 0 ? (double)tt.frames : 1.0;
+            cout << " timed_frames " << timed << " loop_fps " << timed / s_timed << " tracker_fps " << (track_s > 0 ? timed / track_s : 0.0) << " reader_ms " << reader_s * 1e3 / timed
+                 << " tracker_ms " << track_s * 1e3 / timed << " keyframe_ms " << kf_s * 1e3 / timed << " detect_ms " << tt.detect_ms / fr << " match_ms " << tt.match_ms / fr << " pnp_ms " << tt.pnp_ms / fr;
+        }
+        // final_map_fnv = K > 0: the clouds of the first K key-frames fused into ONE context map (what `globalMap += cloud` over all key-frames + one VoxelGrid pass holds,
+        // src/mapper.cpp:121-158), FNV-1a of its centroids -- unlike map_points above it does not depend on the viewer thread's update schedule, so two runs (per-frame
+        // and --batched, 1 or N ranks) can be compared by it
+        if (const int fm = parameterReader.getData<int>("final_map_fnv", 0); fm > 0 && !poseGraph.keyframes.empty()) {
+            ssm::Device dev(parameterReader.deviceConfig(frameReader.width, frameReader.height));
+            int used = 0;
+            for (RGBDFrame::Ptr& kf : poseGraph.keyframes) {
+                if (used++ >= fm) break;
+                Mapper::PointCloud::Ptr c = mapper.generatePointCloud(kf);
+                if (!c->points.empty()) dev.check(ssm_map_insert(dev.ctx(), reinterpret_cast<const ssm_point*>(c->points.data()), (int)c->points.size()), "ssm_map_insert");
+            }
+            int nvox = 0; dev.check(ssm_map_size(dev.ctx(), &nvox), "ssm_map_size");
+            vector<ssm_point> m((size_t)max(nvox, 1));
+            dev.check(ssm_map_export(dev.ctx(), m.data(), (int)m.size(), &nvox), "ssm_map_export");
+            uint64_t h = 0xCBF29CE484222325ull;
+            for (int i = 0; i < nvox; i++) { const unsigned char* b = (const unsigned char*)&m[i]; for (int k = 0; k < 24; k++) { h ^= b[k]; h *= 0x100000001B3ull; } }
+            cout << " map_voxels " << nvox << " map_fnv " << hex << h << dec;
+        }
+        cout << endl;
     } catch (const exception& e) { cerr << RED << "exp_mapping: " << e.what() << RESET << endl; return 2; }
     return 0;
 }

@@ -55,3 +55,19 @@ def test_bad_arguments(ctx):
     from semantic_slam_mapping_amd.api import SsmError
     with pytest.raises(SsmError):
         ctx.pnp_solve(np.zeros((70000, 2), np.float32), np.zeros((70000, 3), np.float32), KCAM, np.eye(4))
+
+
+def test_cluster_timeout_falls_back_to_one_block(oracle, monkeypatch):
+    """ssm_pnp_solve runs a cluster of eight blocks (round 6).  With the exchange's time-out word set from the start (test hook) the call must repeat itself with one
+    block from the caller's initial pose and give the same bytes; the context stays on one block afterwards."""
+    import semantic_slam_mapping_amd as ssm
+    monkeypatch.setenv("SSM_PNP_TEST_TIMEOUT", "1")
+    c = ssm.Context(0, width=640, height=480, max_batch=1)
+    try:
+        img, obj, _ = _case(2, 300, 7, 5, 0.3)
+        _check(c, oracle, img, obj, _pose(0.01, 0.0, -0.01, (0.01, 0.0, 0.02)))
+        monkeypatch.delenv("SSM_PNP_TEST_TIMEOUT")
+        img, obj, _ = _case(10, 3100, 6, 7, 0.8)
+        _check(c, oracle, img, obj, np.eye(4))
+    finally:
+        c.close()
