@@ -31,20 +31,22 @@ public:
     // the next frame pushed starts a new sequence (what is queued must have been flushed): Tracker::reset() for the bulk tracker
     void reset() { if (!pending.empty()) throw logic_error("BatchTracker::reset with frames queued: flush() first"); dev->check(ssm_tracker_reset(trk), "ssm_tracker_reset"); fed = 0; }
     // queue a frame; when the chunk is full it is processed.  Returns the frames whose poses are now known (possibly none).
-    vector<RGBDFrame::Ptr> push(const RGBDFrame::Ptr& f) { pending.push_back(f); return (int)pending.size() >= N ? flush() : vector<RGBDFrame::Ptr>(); }
+    // The frame's images go up when it is queued, without waiting (ssm_memcpy_h2d_async: the frame is kept in `pending`, so its buffers stay valid): the copy runs
+    // while the caller reads the next frame.  Page-locked frame buffers (FrameReader's reader_pinned) make it a plain DMA.
+    vector<RGBDFrame::Ptr> push(const RGBDFrame::Ptr& f) {
+        const size_t np = (size_t)W * H; const size_t i = pending.size();
+        if (f->rgb.cols != W || f->rgb.rows != H || f->rgb.channels() != 3 || !f->rgb.isContinuous()) throw invalid_argument("BatchTracker: frame geometry differs from the tracker's");
+        if (f->depth.empty() || !f->depth.isContinuous()) throw invalid_argument("BatchTracker: RGB-D frames need a depth image");
+        pending.push_back(f);
+        dev->check(ssm_memcpy_h2d_async(dev->ctx(), (uint8_t*)d_bgr + i * np * 3, f->rgb.data, np * 3), "ssm_memcpy_h2d_async");
+        dev->check(ssm_memcpy_h2d_async(dev->ctx(), (uint8_t*)d_depth + i * np * 2, f->depth.data, np * 2), "ssm_memcpy_h2d_async");
+        return (int)pending.size() >= N ? flush() : vector<RGBDFrame::Ptr>();
+    }
     // process whatever is queued: sets T_f_w of every queued frame, fills infos (one entry per frame, in order) and returns the frames
     vector<RGBDFrame::Ptr> flush() {
         const int n = (int)pending.size();
         if (n == 0) return vector<RGBDFrame::Ptr>();
-        const size_t np = (size_t)W * H;
-        for (int i = 0; i < n; i++) {
-            const RGBDFrame::Ptr& f = pending[i];
-            if (f->rgb.cols != W || f->rgb.rows != H || f->rgb.channels() != 3 || !f->rgb.isContinuous()) throw invalid_argument("BatchTracker: frame geometry differs from the tracker's");
-            dev->check(ssm_memcpy_h2d(dev->ctx(), (uint8_t*)d_bgr + (size_t)i * np * 3, f->rgb.data, np * 3), "ssm_memcpy_h2d");
-            if (f->depth.empty() || !f->depth.isContinuous()) throw invalid_argument("BatchTracker: RGB-D frames need a depth image");
-            dev->check(ssm_memcpy_h2d(dev->ctx(), (uint8_t*)d_depth + (size_t)i * np * 2, f->depth.data, np * 2), "ssm_memcpy_h2d");
-        }
-        ssm_frames_dev in; memset(&in, 0, sizeof(in));
+        ssm_frames_dev in;                                 // (the images were uploaded by push(), on the context's stream: the launches below run behind the copies) memset(&in, 0, sizeof(in));
         in.bgr = (const uint8_t*)d_bgr; in.depth = (const uint16_t*)d_depth; in.n = n; in.continue_sequence = fed > 0 ? 1 : 0; in.stages = SSM_STAGE_ORB | SSM_STAGE_MATCH;
         ssm_seq_out_dev out;
         dev->check(ssm_seq_process(dev->ctx(), &in, &out), "ssm_seq_process");

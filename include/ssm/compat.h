@@ -42,6 +42,11 @@ public:
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
     Mat(Size s, int type) { create(s.height, s.width, type); }
+    Mat(int r, int c, int type, void* user, size_t user_step = 0) {                 // wraps user memory (not owned), like cv::Mat(rows, cols, type, data, step)
+        type_ = type; rows = r; cols = c; step = user_step ? user_step : (size_t)c * elemSize(); data = (uchar*)user;
+    }
+    // (stand-in only) ties the lifetime of wrapped user memory to the Mat and its copies; with OpenCV the owner of the buffer outlives the Mat instead
+    void hold(std::shared_ptr<void> owner) { keep_ = std::move(owner); }
     static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
     static Mat zeros(Size s, int type) { return Mat(s, type); }
     void create(int r, int c, int type) {
@@ -77,7 +82,7 @@ public:
         *this = n;
     }
 private:
-    int type_ = 0; std::shared_ptr<std::vector<uchar>> buf_;
+    int type_ = 0; std::shared_ptr<std::vector<uchar>> buf_; std::shared_ptr<void> keep_;
 };
 template <class T> using Ptr = std::shared_ptr<T>;
 }  // namespace cv

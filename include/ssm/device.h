@@ -4,7 +4,11 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <vector>
 #include <string>
 #include "../ssm_hip.h"
 namespace ssm {
@@ -14,6 +18,20 @@ inline int& default_device() { static int d = 0; return d; }
 // contexts created by this process so far: exp_mapping --ranks forks + execs its ranks and must not have touched HIP before (a forked copy of a process whose
 // HIP runtime is initialised is not usable, and an exec from such a process takes the node down on this pool): the driver checks this counter at the fork
 inline std::atomic<int>& devices_created() { static std::atomic<int> n{0}; return n; }
+// page-locked frame buffers (ssm_host_alloc), recycled: hipHostMalloc costs far more than a frame's processing, so a buffer goes back to a free list when the last cv::Mat
+// that wraps it dies.  One pool per process; buffers are grouped by size.
+class PinnedPool {
+public:
+    static PinnedPool& instance() { static PinnedPool* p = new PinnedPool; return *p; }      // (leaked on purpose: frames may die after static destruction has begun)
+    std::shared_ptr<void> take(size_t bytes) {
+        void* p = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); auto& fl = free_[bytes]; if (!fl.empty()) { p = fl.back(); fl.pop_back(); } }
+        if (!p && ssm_host_alloc(bytes, &p) != SSM_OK) throw DeviceError(SSM_E_NOMEM, "ssm_host_alloc failed");
+        return std::shared_ptr<void>(p, [this, bytes](void* q) { std::lock_guard<std::mutex> lk(mu); free_[bytes].push_back(q); });
+    }
+private:
+    std::mutex mu; std::map<size_t, std::vector<void*>> free_;
+};
 class Device {
 public:
     explicit Device(const ssm_config& cfg, int device = -1) {

@@ -30,6 +30,7 @@ public:
             f.position = cv::Point3f(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);     // == frame->project2dTo3d(int(pt.x), int(pt.y)), orb.h:50
             frame->features.push_back(std::move(f));
         }
+        if ((int)frame->features.size() == n) frame->descriptors_all = all;
     }
     // descriptors of frame1 = query, frame2 = train; knn(2) + ratio test (src/orb.cpp:16-29)
     vector<cv::DMatch> match(const RGBDFrame::Ptr& frame1, const RGBDFrame::Ptr& frame2) const {

@@ -38,7 +38,11 @@ public:
         p.y = (float)((v - camera.cy) * p.z / camera.fy);
         return p;
     }
-    cv::Mat getAllDescriptors() const { cv::Mat desp; for (size_t i = 0; i < features.size(); i++) desp.push_back(features[i].descriptor); return desp; }
+    // (detectFeatures leaves the frame's descriptors as ONE block, of which Feature::descriptor are the rows: the block is returned when it still matches the features)
+    cv::Mat getAllDescriptors() const {
+        if (!features.empty() && descriptors_all.rows == (int)features.size() && features.front().descriptor.data == descriptors_all.data) return descriptors_all;
+        cv::Mat desp; for (size_t i = 0; i < features.size(); i++) desp.push_back(features[i].descriptor); return desp; }
+    cv::Mat descriptors_all;                             // not in the reference's struct: see getAllDescriptors
     vector<cv::Mat> getAllDescriptorsVec() const { vector<cv::Mat> d; for (auto& f : features) d.push_back(f.descriptor); return d; }
     vector<cv::KeyPoint> getAllKeypoints() const { vector<cv::KeyPoint> k; for (auto& f : features) k.push_back(f.keypoint); return k; }
     void setTransform(const Eigen::Isometry3d& T) { std::unique_lock<std::mutex> lck(mutexT); T_f_w = T; }
@@ -56,6 +60,7 @@ public:
         width = para.getData<int>("image_width", 640); height = para.getData<int>("image_height", 480);
         seed = (uint64_t)para.getData<unsigned long long>("synthetic_seed", 0x5EED0000ull);
         dataset_dir = para.getData<string>("data_source", string("./"));
+        pinned = para.getData<int>("reader_pinned", 1) != 0;
         rigid = para.getData<int>("synthetic_rigid", 0) != 0; rigid_period = max(1, para.getData<int>("sequence_length", 20));
         camera = para.getCamera(); currentIndex = start_index;
         if (dataset_type == TUM) init_tum();
@@ -75,8 +80,15 @@ protected:
     RGBDFrame::Ptr load(int index) {
         RGBDFrame::Ptr f(new RGBDFrame);
         f->id = index; f->camera = camera;
-        f->rgb.create(height, width, CV_8UC3); f->depth.create(height, width, CV_16UC1); f->semantic.create(height, width, CV_8UC3);
         const size_t np = (size_t)width * height;
+        if (pinned && (dataset_type == SYNTHETIC || dataset_type == RAW)) {
+            // frame buffers in page-locked memory (reader_pinned = 1, the default): the device reads them where they are (ssm_host_alloc in include/ssm_hip.h) -- what a
+            // capture driver that fills user buffers would hand over.  One block per frame: rgb | semantic | depth
+            std::shared_ptr<void> blk = ssm::PinnedPool::instance().take(np * 8);
+            uint8_t* b = (uint8_t*)blk.get();
+            f->rgb = cv::Mat(height, width, CV_8UC3, b); f->semantic = cv::Mat(height, width, CV_8UC3, b + np * 3); f->depth = cv::Mat(height, width, CV_16UC1, b + np * 6);
+            f->rgb.hold(blk); f->semantic.hold(blk); f->depth.hold(blk);
+        } else { f->rgb.create(height, width, CV_8UC3); f->depth.create(height, width, CV_16UC1); f->semantic.create(height, width, CV_8UC3); }
         if (dataset_type == SYNTHETIC) {
             if (!dev) { ssm_config c = parameterReader.deviceConfig(width, height); dev.reset(new ssm::Device(c)); ssm_ctx* x = dev->ctx();
                         dev->check(ssm_dev_alloc(x, np * 3, &d_bgr), "alloc"); dev->check(ssm_dev_alloc(x, np * 2, &d_dep), "alloc");
@@ -167,7 +179,7 @@ protected:
     const ParameterReader& parameterReader;
     DATASET dataset_type; int currentIndex = 0, start_index = 0, end_index = 0; uint64_t seed = 0; string dataset_dir;
     CAMERA_INTRINSIC_PARAMETERS camera;
-    bool rigid = false; int rigid_period = 20; cv::Mat base_bgr, base_sem;
+    bool pinned = true, rigid = false; int rigid_period = 20; cv::Mat base_bgr, base_sem;
     unique_ptr<ssm::Device> dev; void *d_bgr = nullptr, *d_dep = nullptr, *d_sem = nullptr, *d_pose = nullptr;
 };
 }  // namespace rgbd_tutor

@@ -390,6 +390,15 @@ int ssm_dev_alloc(ssm_ctx* ctx, size_t bytes, void** out);
 int ssm_dev_free(ssm_ctx* ctx, void* p);
 int ssm_memcpy_h2d(ssm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int ssm_memcpy_d2h(ssm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* the same upload, enqueued on the context stream without waiting: src_host must stay valid and unchanged until the next ssm_sync / synchronous call of the context
+ * (BatchTracker uploads a frame when it is queued, while the caller reads the next one) */
+int ssm_memcpy_h2d_async(ssm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+/* page-locked host memory for frame buffers (the reference's cv::Mat data comes from cv::imread / a camera driver: a cv::Mat can wrap user memory, cv::Mat(rows, cols,
+ * type, ptr)).  The host-pointer calls stage pageable inputs through a pinned ring (one extra pass over every image: ~0.06 ms of ssm_orb_extract's 0.25 for a 640 x 480
+ * frame); inputs that already live in memory from ssm_host_alloc are read by the DMA engine / the kernels where they are.  Any device of the process may use the
+ * memory.  ssm_host_free(NULL) is a no-op. */
+int ssm_host_alloc(size_t bytes, void** out);
+int ssm_host_free(void* p);
 /* synthetic 640x480 RGB-D + 12-class stream of BASELINE.json configs[1]; device pointers;
  * label_ids may be NULL */
 int ssm_synth_frames_dev(ssm_ctx* ctx, uint64_t seed, int first_frame, int n, int w, int h,

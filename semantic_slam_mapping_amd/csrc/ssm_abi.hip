@@ -471,8 +471,9 @@ static int ring_take(ssm_ctx* c, size_t hbytes, size_t dbytes, uint8_t** hp, uin
     c->h_ring_off += hbytes; c->d_ring_off += dbytes;
     return SSM_OK;
 }
+// in_place: the caller's buffers outlive the device work (the synchronous form) -- page-locked inputs are then used where they are
 static int orb_extract_enqueue(ssm_ctx* c, const uint8_t* img, int w, int h, int stride, int channels, const uint16_t* depth,
-                               ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out)
+                               ssm_keypoint* kps, uint8_t* desc, float* pos3d, int cap, int* n_out, bool in_place = false)
 {
     if (!img || !kps || !desc || !n_out) FAIL(c, SSM_E_INVAL, "null argument");
     if (w != c->g.W || h != c->g.H) FAIL(c, SSM_E_INVAL, "frame size differs from the context configuration");
@@ -489,9 +490,13 @@ static int orb_extract_enqueue(ssm_ctx* c, const uint8_t* img, int w, int h, int
     // the <= cap keypoints: it is staged into the pinned ring while gray .. quad-tree run (after their launches, before the describe launches) and the kernel reads it
     // there, through the ring's device mapping -- no 0.6 MB upload, no staging time in front of the first kernel.  (Measured and dropped: the blur on a side stream
     // beside FAST + the quad-tree -- two cross-stream events cost more than the 17 us they hide: 177 -> 223 us from first to last kernel.)
-    if ((size_t)stride == row) memcpy(h_in, img, ib);
-    else for (int y = 0; y < h; y++) memcpy(h_in + (size_t)y * row, img + (size_t)y * stride, row);
-    HIPCHK(c, hipMemcpyAsync(c->d_in_img, h_in, ib, hipMemcpyHostToDevice, c->stream));
+    const bool img_direct = in_place && (size_t)stride == row && host_is_pinned(img), depth_direct = in_place && depth && host_is_pinned(depth);
+    if (img_direct) HIPCHK(c, hipMemcpyAsync(c->d_in_img, img, ib, hipMemcpyHostToDevice, c->stream));       // page-locked input (ssm_host_alloc): no staging pass
+    else {
+        if ((size_t)stride == row) memcpy(h_in, img, ib);
+        else for (int y = 0; y < h; y++) memcpy(h_in + (size_t)y * row, img + (size_t)y * stride, row);
+        HIPCHK(c, hipMemcpyAsync(c->d_in_img, h_in, ib, hipMemcpyHostToDevice, c->stream));
+    }
     int32_t* dn = reinterpret_cast<int32_t*>(dp);
     ssm_keypoint* dk = reinterpret_cast<ssm_keypoint*>(dp + 64);
     uint8_t* dd = reinterpret_cast<uint8_t*>(dk + ocap);
@@ -505,9 +510,9 @@ static int orb_extract_enqueue(ssm_ctx* c, const uint8_t* img, int w, int h, int
         prof_begin(c, "blur");      HIPCHK(c, c->blur_mfma ? k_blur_mfma(1, g, c->d_pyr, c->d_blur, c->d_blur_tab, s) : k_blur(1, g, c->d_pyr, c->d_blur, s)); prof_end(c);
         const uint16_t* d_depth = nullptr;
         if (depth) {
-            memcpy(h_in + ib, depth, db);                          // (the device is busy with the launches above meanwhile)
+            if (!depth_direct) memcpy(h_in + ib, depth, db);       // (the device is busy with the launches above meanwhile)
             void* mapped = nullptr;
-            HIPCHK(c, hipHostGetDevicePointer(&mapped, h_in + ib, 0));
+            HIPCHK(c, hipHostGetDevicePointer(&mapped, depth_direct ? const_cast<uint16_t*>(depth) : reinterpret_cast<uint16_t*>(h_in + ib), 0));
             d_depth = reinterpret_cast<const uint16_t*>(mapped);
         }
         prof_begin(c, "describe");  HIPCHK(c, k_describe(1, g, c->d_pyr, c->d_blur, c->d_sel, c->d_nsel, c->d_pattern_f, d_depth, c->cfg.camera, c->d_kpaux, dk, dd, dps, dn, s)); prof_end(c);
@@ -539,7 +544,7 @@ extern "C" int ssm_orb_extract(ssm_ctx* c, const uint8_t* img, int w, int h, int
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
-    int r = orb_extract_enqueue(c, img, w, h, stride, channels, depth, kps, desc, pos3d, cap, n_out); if (r) return r;
+    int r = orb_extract_enqueue(c, img, w, h, stride, channels, depth, kps, desc, pos3d, cap, n_out, true); if (r) return r;
     return wait_pending(c);
 }
 extern "C" int ssm_wait(ssm_ctx* c)
@@ -963,6 +968,29 @@ extern "C" int ssm_memcpy_h2d(ssm_ctx* c, void* dst, const void* src, size_t byt
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SSM_OK;
+}
+extern "C" int ssm_memcpy_h2d_async(ssm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return SSM_E_INVAL;
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); g_create_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return SSM_E_NOMEM; }
+    *out = p; return SSM_OK;
+}
+extern "C" int ssm_host_free(void* p) { if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return SSM_E_HIP; } return SSM_OK; }
+// is [p, p + bytes) page-locked host memory the device can read (hipHostMalloc / hipHostRegister)?  (an unknown pointer makes hipPointerGetAttributes fail: that is "no")
+bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 extern "C" int ssm_memcpy_d2h(ssm_ctx* c, void* dst, const void* src, size_t bytes)
 {

@@ -169,6 +169,7 @@ SSM_HIDDEN void prof_begin(ssm_ctx* c, const char* name);
 SSM_HIDDEN void prof_end(ssm_ctx* c);
 SSM_HIDDEN int check_device_flags(ssm_ctx* c, bool with_map);
 SSM_HIDDEN int wait_pending(ssm_ctx* c);
+SSM_HIDDEN bool host_is_pinned(const void* p);             // page-locked host memory (ssm_host_alloc, hipHostRegister)?
 SSM_HIDDEN int ensure_side_streams(ssm_ctx* c);
 // ssm_map.hip
 SSM_HIDDEN int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2);

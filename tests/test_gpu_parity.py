@@ -393,6 +393,15 @@ def test_bench_default_line_carries_the_other_configs():
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == unit
     assert oc["configs[3]"]["cpu_baseline"]["quad_matches_equal_gpu"] is True
     assert oc["pose_loop"]["detail"]["tracked_frames"] == oc["pose_loop"]["detail"]["frames"]
+    # round 6: the PRODUCT in the same line -- host/exp_mapping (the C++ drop-in of experiment/exp_mapping.cpp) run as child processes before bench.py's first GPU call:
+    # the per-frame Tracker / Mapper loop (stream poses, solved poses), the bulk trackers (RGB-D with and without the chain, stereo), their maps and poses compared
+    em = oc["exp_mapping"]
+    assert "error" not in em and all("error" not in v for v in em["runs"].values()), em
+    for k in ("per_frame_fps", "per_frame_solved_fps", "batched_fps", "batched_solved_fps", "batched_stereo_pairs_per_s"):
+        assert em[k] is not None and em[k] > 0, (k, em.get(k))
+    assert em["map_fnv_equal"] is True and em["pose_fnv_equal"] is True
+    assert em["cpu_baseline"]["value"] > 0 and em["cpu_baseline"]["kind"] == "port"
+    assert set(("detect_ms", "match_ms", "pnp_ms")) <= set(em["per_call_ms"]) and all(int(v["lost"]) == 0 for v in em["runs"].values())
 
 
 def test_full_size_properties_of_configs1(oracle):
