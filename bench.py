@@ -830,7 +830,7 @@ def exp_mapping_legs(scale=1.0):
         # ---- stereo: a KITTI-layout directory written here (PNG, gray), then `exp_mapping --batched` with tracker_mode = stereo (BatchStereoTracker)
         import numpy as np
         from PIL import Image
-        NS = max(24, int(96 * scale))
+        NS = max(24, int(96 * scale)); SCH = 32 if NS >= 96 else 8
         L, R = stereo_sequence(NS + 1, 1241, 376, 100)
         seq = os.path.join(tmp, "kitti"); os.makedirs(os.path.join(seq, "image_2")); os.makedirs(os.path.join(seq, "image_3"))
         for i in range(NS + 1):
@@ -840,8 +840,8 @@ def exp_mapping_legs(scale=1.0):
         st_txt = st_txt.replace("map_output=/tmp/ssm_test_map.pcd", "").replace("image_width=640", "image_width=1241").replace("image_height=480", "image_height=376")
         for k, v in (("camera.cx", KITTI["cu"]), ("camera.cy", KITTI["cv"]), ("camera.fx", KITTI["f"]), ("camera.fy", KITTI["f"])):
             st_txt = "\n".join(("%s=%r" % (k, v)) if ln.startswith(k + "=") else ln for ln in st_txt.splitlines())
-        st_txt += ("\ndata_source=%s\ntracker_mode=stereo\ncamera.baseline=%r\ncamera.roix=%r\ncamera.roiy=%r\ncamera.roiz=%r\ninlier_threshold=2.0\ntracker_chunk=32\nssm_max_batch=32\n"
-                   "timing_skip_frames=32\nmapper_drain_ms=100\nkeyframe_min_translation=0.5\nreader_preload=1\n" % (seq, KITTI["baseline"], KITTI["roix"], KITTI["roiy"], KITTI["roiz"]))
+        st_txt += ("\ndata_source=%s\ntracker_mode=stereo\ncamera.baseline=%r\ncamera.roix=%r\ncamera.roiy=%r\ncamera.roiz=%r\ninlier_threshold=2.0\ntracker_chunk=%d\nssm_max_batch=%d\n"
+                   "timing_skip_frames=%d\nmapper_drain_ms=100\nkeyframe_min_translation=0.5\nreader_preload=1\n" % (seq, KITTI["baseline"], KITTI["roix"], KITTI["roiy"], KITTI["roiz"], SCH, SCH, SCH))
         legs["batched_stereo"] = run("d", st_txt, "--batched")
         out["runs"] = legs
         f = lambda leg, key: (round(float(legs[leg][key]), 1) if key in legs[leg] else None)
@@ -861,7 +861,7 @@ def exp_mapping_legs(scale=1.0):
                          "timed": "per_frame*: frames / wall time inside Tracker::updateFrame (where experiment/run_tracker.cpp:35-48 times it): uploads, kernels, downloads, host state machine, Mapper::viewer busy on its own "
                                   "thread and context; per_frame_loop_fps_reader_included adds FrameReader::next (host roll of the base frame) and PoseGraph::tryInsertKeyFrame.  batched*: frames / wall time of the whole loop "
                                   "over frames preloaded into page-locked host memory (reader_preload: BatchTracker / BatchStereoTracker push + flush -- upload, ORB + match tables [+ PnP chain] or quad matcher + SGBM + VO, "
-                                  "per-frame depth download for stereo -- then the key-frame gate), chunk %d (stream poses), 20 (solved), 32 (stereo); frame buffers from ssm_host_alloc (reader_pinned)" % CH}
+                                  "per-frame depth download for stereo -- then the key-frame gate), chunk %d (stream poses), 20 (solved), %d (stereo); frame buffers from ssm_host_alloc (reader_pinned)" % (CH, SCH)}
     except Exception as e:                      # a failing leg must not take the headline with it
         out["error"] = repr(e)
     finally:

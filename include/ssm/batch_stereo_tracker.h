@@ -40,19 +40,22 @@ public:
     int chunk() const { return N; }
     Tracker::trackerState getState() const { return (Tracker::trackerState)state; }
     // queue a frame (img_lc / img_rc = its rectified gray pair); when the chunk is full it is processed.  Returns the frames whose poses are now known.
-    vector<RGBDFrame::Ptr> push(const RGBDFrame::Ptr& f) { pending.push_back(f); return (int)pending.size() >= N ? flush() : vector<RGBDFrame::Ptr>(); }
+    // (the pair goes up when it is queued, without waiting: the frame is kept in `pending`, so its images stay valid)
+    vector<RGBDFrame::Ptr> push(const RGBDFrame::Ptr& f) {
+        const size_t np = (size_t)W * H; const size_t i = pending.size();
+        if (f->img_lc.cols != W || f->img_lc.rows != H || f->img_lc.type() != CV_8UC1 || !f->img_lc.isContinuous() ||
+            f->img_rc.cols != W || f->img_rc.rows != H || f->img_rc.type() != CV_8UC1 || !f->img_rc.isContinuous()) throw invalid_argument("BatchStereoTracker: frame geometry differs from the tracker's");
+        pending.push_back(f);
+        dev->check(ssm_memcpy_h2d_async(dev->ctx(), (uint8_t*)d_left + i * np, f->img_lc.data, np), "ssm_memcpy_h2d_async");
+        dev->check(ssm_memcpy_h2d_async(dev->ctx(), (uint8_t*)d_right + i * np, f->img_rc.data, np), "ssm_memcpy_h2d_async");
+        return (int)pending.size() >= N ? flush() : vector<RGBDFrame::Ptr>();
+    }
     // process whatever is queued: sets T_f_w and the depth image of every queued frame, fills infos (one entry per frame, in order)
     vector<RGBDFrame::Ptr> flush() {
         const int n = (int)pending.size();
         if (n == 0) return vector<RGBDFrame::Ptr>();
         const size_t np = (size_t)W * H; const int iters = voparam.ransac_iters;
-        for (int i = 0; i < n; i++) {
-            const RGBDFrame::Ptr& f = pending[i];
-            if (f->img_lc.cols != W || f->img_lc.rows != H || f->img_lc.type() != CV_8UC1 || !f->img_lc.isContinuous() ||
-                f->img_rc.cols != W || f->img_rc.rows != H || f->img_rc.type() != CV_8UC1 || !f->img_rc.isContinuous()) throw invalid_argument("BatchStereoTracker: frame geometry differs from the tracker's");
-            dev->check(ssm_memcpy_h2d(dev->ctx(), (uint8_t*)d_left + (size_t)i * np, f->img_lc.data, np), "ssm_memcpy_h2d");
-            dev->check(ssm_memcpy_h2d(dev->ctx(), (uint8_t*)d_right + (size_t)i * np, f->img_rc.data, np), "ssm_memcpy_h2d");
-        }
+        // (the images were uploaded by push())
         // the raw draws the VO object would make if every frame of the chunk ran; the object is put where the stream really went afterwards
         const VisualOdometry::RandState rs0 = viso.saveRand();
         vector<uint32_t> draws((size_t)n * iters * 3);
@@ -66,6 +69,13 @@ public:
         in.vo.reweighting = voparam.reweighting ? 1 : 0; in.vo.pad = 0; in.ransac_iters = iters; in.rand_stream = (const uint32_t*)d_rand;
         ssm_stereo_out_dev out;
         dev->check(ssm_stereo_seq_process(dev->ctx(), &in, &out), "ssm_stereo_seq_process");
+        // FrameReader's depth image of every frame (src/rgbdframe.cpp:81-116): into page-locked buffers, all downloads enqueued behind the kernels, one wait
+        for (int i = 0; i < n; i++) {
+            const RGBDFrame::Ptr& f = pending[i];
+            std::shared_ptr<void> blk = ssm::PinnedPool::instance().take(np * 2);
+            f->depth = cv::Mat(H, W, CV_16UC1, blk.get()); f->depth.hold(blk);
+            dev->check(ssm_memcpy_d2h_async(dev->ctx(), f->depth.data, out.depth + (size_t)i * np, np * 2), "ssm_memcpy_d2h_async");
+        }
         dev->check(ssm_sync(dev->ctx()), "ssm_sync");
         vector<int32_t> nquad(n), vres((size_t)n * 2); vector<double> tr((size_t)n * 6);
         dev->check(ssm_memcpy_d2h(dev->ctx(), nquad.data(), out.nquad, (size_t)n * 4), "ssm_memcpy_d2h");
@@ -76,8 +86,6 @@ public:
         long used = 0;                                      // draws of the frames walked so far, while the bulk results are in use
         for (int i = 0; i < n; i++) {
             const RGBDFrame::Ptr& f = pending[i];
-            if (f->depth.rows != H || f->depth.cols != W || f->depth.type() != CV_16UC1 || !f->depth.isContinuous()) f->depth.create(H, W, CV_16UC1);
-            dev->check(ssm_memcpy_d2h(dev->ctx(), f->depth.data, out.depth + (size_t)i * np, np * 2), "ssm_memcpy_d2h");      // FrameReader's depth image (src/rgbdframe.cpp:81-116)
             Info& info = infos[i];
             if (state == Tracker::NOT_READY) {              // initFirstFrame (track.cpp:30-36): the frame keeps the transform it arrived with
                 refBackT = f->getTransform(); speed = Eigen::Isometry3d::Identity(); state = Tracker::OK;

@@ -393,6 +393,8 @@ int ssm_memcpy_d2h(ssm_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 /* the same upload, enqueued on the context stream without waiting: src_host must stay valid and unchanged until the next ssm_sync / synchronous call of the context
  * (BatchTracker uploads a frame when it is queued, while the caller reads the next one) */
 int ssm_memcpy_h2d_async(ssm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+/* the download, enqueued without waiting: dst_host holds the data after the next ssm_sync (page-locked dst_host: a plain DMA; BatchStereoTracker fetches a chunk's depth images so) */
+int ssm_memcpy_d2h_async(ssm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 /* page-locked host memory for frame buffers (the reference's cv::Mat data comes from cv::imread / a camera driver: a cv::Mat can wrap user memory, cv::Mat(rows, cols,
  * type, ptr)).  The host-pointer calls stage pageable inputs through a pinned ring (one extra pass over every image: ~0.06 ms of ssm_orb_extract's 0.25 for a 640 x 480
  * frame); inputs that already live in memory from ssm_host_alloc are read by the DMA engine / the kernels where they are.  Any device of the process may use the

@@ -136,6 +136,7 @@ SYMBOLS = {
     "ssm_memcpy_h2d": (_I, [_P, _P, _P, _SZ]),
     "ssm_memcpy_d2h": (_I, [_P, _P, _P, _SZ]),
     "ssm_memcpy_h2d_async": (_I, [_P, _P, _P, _SZ]),
+    "ssm_memcpy_d2h_async": (_I, [_P, _P, _P, _SZ]),
     "ssm_host_alloc": (_I, [_SZ, C.POINTER(_P)]),
     "ssm_host_free": (_I, [_P]),
     "ssm_synth_frames_dev": (_I, [_P, _U64, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

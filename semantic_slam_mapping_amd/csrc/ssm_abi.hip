@@ -976,6 +976,13 @@ extern "C" int ssm_memcpy_h2d_async(ssm_ctx* c, void* dst, const void* src, size
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return SSM_OK;
 }
+extern "C" int ssm_memcpy_d2h_async(ssm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return SSM_OK;
+}
 extern "C" int ssm_host_alloc(size_t bytes, void** out)
 {
     if (!out || bytes == 0) return SSM_E_INVAL;

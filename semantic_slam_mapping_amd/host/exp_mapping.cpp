@@ -145,7 +145,7 @@ int main(int argc, char** argv)
         vector<RGBDFrame::Ptr> preloaded; size_t pre_i = 0; double preload_s = 0;
         const bool preload = parameterReader.getData<int>("reader_preload", 0) != 0;
         if (preload) { const tp a = now(); while (RGBDFrame::Ptr f = frameReader.next()) preloaded.push_back(f); preload_s = sec(a, now()); }
-        auto t0 = now(); tp t_timed0 = t0;
+        auto t0 = now(); tp t_timed0 = t0, t1 = t0;          // t1: the end of the loop (taken before a bulk tracker and its device context are torn down)
         auto read_next = [&]() {
             const tp a = now();
             RGBDFrame::Ptr f;
@@ -182,6 +182,7 @@ int main(int argc, char** argv)
             const tp a = now(); const bool count = nframes >= skip;
             if (bt) handle(bt->flush(), count);
             if (count) track_s += sec(a, now());
+            t1 = now();
             cout << "batched tracker: chunk " << (bt ? bt->chunk() : 0) << " lost " << lost << endl;
         } else if (batched_stereo) {
             // Tracker::estimateVO + FrameReader's SGBM depth in bulk (include/ssm/batch_stereo_tracker.h): quad matcher, depth and ego-motion of a chunk per launch
@@ -206,8 +207,9 @@ int main(int argc, char** argv)
             const tp a = now(); const bool count = nframes >= skip;
             if (bs) handle(bs->flush(), count);
             if (count) track_s += sec(a, now());
+            t1 = now();
             cout << "batched stereo tracker: chunk " << (bs ? bs->chunk() : 0) << " lost " << lost << endl;
-        } else
+        } else {
         while (RGBDFrame::Ptr frame = read_next()) {
             if (nframes == skip) { t_timed0 = now(); tracker->timing = Tracker::Timing(); }
             if (seq_len > 0 && nframes > 0 && nframes % seq_len == 0) tracker->reset();
@@ -223,7 +225,7 @@ int main(int argc, char** argv)
             nframes++;
             if (frame_period_ms > 0) this_thread::sleep_for(chrono::milliseconds(frame_period_ms));      // a camera's frame period (measurements of the viewer thread under a paced stream)
         }
-        const tp t1 = now();
+        t1 = now(); }
         const double s = sec(t0, t1), s_timed = sec(t_timed0, t1);
         mapper.SaveMap();
         poseGraph.shutdown();
