@@ -139,13 +139,20 @@ void ssm_cloud_free(ssm_ctx* ctx, ssm_cloud* cloud);
  * A cloud extent PCL's VoxelGrid refuses (dx dy dz > INT_MAX) leaves the unfiltered concatenation as the map, like mapper.h's `*out = *in`. */
 int  ssm_viewer_map_update(ssm_ctx* ctx, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out);
 int  ssm_viewer_map_fetch(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);                       /* the map after the last update (sorted by voxel index) */
-/* the persistent map of the context: table of exact sums keyed by voxel.  A full table DROPS points: the entry point that notices (ssm_map_insert,
- * ssm_sync after ssm_seq_process) returns SSM_E_CAPACITY once, and from then on ssm_map_size / ssm_map_export* / ssm_voxel_allgather keep returning
- * SSM_E_CAPACITY for this map -- it is incomplete -- until ssm_map_clear.  Skipped points (non-finite, or outside the 21-bit voxel index range) are
- * reported once as SSM_E_VOXEL_RANGE and leave the map usable (pcl::VoxelGrid skips such points too). */
+/* the persistent map of the context: table of exact sums keyed by voxel.  It grows like the reference's globalMap (src/mapper.cpp:121-158) and never drops a
+ * contribution below 2^voxel_max_capacity_log2 slots, whatever the stream does: ssm_seq_process sizes the table from the stream's own voxel rate; when a launch brings
+ * far more than that (the camera leaves a near wall at a fine leaf), what the table refuses waits in an overflow list, and blocks of the map kernel that start
+ * while that list is nearly full add nothing, log themselves and are run again after the table has grown -- which is why the DEVICE INPUTS of an
+ * ssm_seq_process call whose map stage ran must stay unchanged until the next ssm_sync / ssm_map_size / ssm_map_export* / ssm_voxel_allgather of the context.
+ * Only a map that needs more than the configured maximum loses contributions: the entry point that notices returns SSM_E_CAPACITY once, and from then on
+ * ssm_map_size / ssm_map_export* / ssm_voxel_allgather keep returning SSM_E_CAPACITY for this map -- it is incomplete -- until ssm_map_clear.  Skipped points
+ * (non-finite, or outside the 21-bit voxel index range) are reported once as SSM_E_VOXEL_RANGE and leave the map usable (pcl::VoxelGrid skips such points too). */
 int ssm_map_clear(ssm_ctx* ctx);
 int ssm_map_insert(ssm_ctx* ctx, const ssm_point* pts, int n);                 /* globalMap += cloud */
 int ssm_map_size(ssm_ctx* ctx, int* n_voxels);
+/* how the map got where it is: stats[0] = log2 of the table's slots now, [1] = times it was re-hashed into a larger table, [2] = blocks of the map kernel that were
+ * run again after skipping themselves, [3] = records its overflow list holds (a context that has run the map stage of ssm_seq_process keeps the large list) */
+int ssm_map_stats(ssm_ctx* ctx, int64_t stats[4]);
 int ssm_map_export(ssm_ctx* ctx, ssm_point* out, int cap, int* n_out);         /* centroids sorted by voxel index */
 int ssm_map_export_table(ssm_ctx* ctx, ssm_voxel* out, int cap, int* n_out);   /* key-sorted table, for merging */
 int ssm_map_merge_table(ssm_ctx* ctx, const ssm_voxel* tab, int n);            /* add another rank's table */

@@ -91,6 +91,7 @@ SYMBOLS = {
     "ssm_map_clear": (_I, [_P]),
     "ssm_map_insert": (_I, [_P, _P, _I]),
     "ssm_map_size": (_I, [_P, C.POINTER(_I)]),
+    "ssm_map_stats": (_I, [_P, C.POINTER(C.c_int64)]),
     "ssm_map_export": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_export_table": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_merge_table": (_I, [_P, _P, _I]),

@@ -510,6 +510,12 @@ class Context:
         pts = np.ascontiguousarray(pts, POINT_DTYPE)
         self._chk(self.lib.ssm_map_insert(self.h, _ptr(pts), len(pts)))
 
+    def map_stats(self):
+        """(log2 slots, times grown, blocks of the map kernel run again, overflow-list records): ssm_map_stats"""
+        st = (C.c_int64 * 4)()
+        self._chk(self.lib.ssm_map_stats(self.h, st))
+        return tuple(int(v) for v in st)
+
     def map_size(self):
         n = C.c_int(0)
         self._chk(self.lib.ssm_map_size(self.h, C.byref(n)))

@@ -295,7 +295,7 @@ __global__ void vox_clear_kernel(ssm_voxel* __restrict__ tab, uint32_t* __restri
         p[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
     }
 }
-__global__ void vox_reset_counters(int32_t* counters) { counters[0] = 0; counters[1] = 0; counters[2] = 0; }
+__global__ void vox_reset_counters(int32_t* counters) { counters[0] = 0; counters[1] = 0; counters[2] = 0; counters[6] = 0; counters[7] = 0; }
 hipError_t k_voxel_clear(ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s)
 {
     // cap_log2 < 0  =>  full clear of 2^-cap_log2 slots (first use)
@@ -371,48 +371,12 @@ hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_
     vox_insert_kernel<<<(int)blocks, 256, 0, s>>>(pts, n_dev, n_max, 1.0f / leaf, tab, cap_log2, counters);
     return hipGetLastError();
 }
-// ------------------------------------------------------------------ K10+K11+K12, streaming form (w % 16 == 0)
-// (1) class_bits_kernel: 1 bit per pixel = pedestrian|cyclist colour, 16 px per thread from three 16-B loads.
-// (2) vdilate_bits_kernel: OR of rows y-2..y+2 of those bits (the vertical half of the 5x5 box dilate).
-// (3) map_stream_kernel: one thread = 16 consecutive pixels of a row: depth/rgb/semantic arrive in eight 16-B loads
-//     issued up front, the horizontal half of the dilate is done on a 48-bit window in registers, every kept pixel is
-//     unprojected / transformed / quantised exactly like K11+K12, consecutive pixels with the same (voxel, label) are
-//     summed in registers (two runs per thread, further runs go straight to LDS), then ONE wave-wide segmented DPP scan
-//     per run slot merges neighbouring threads, the run tails update a block-local LDS hash (256 slots for the 3 x 4096
-//     pixels) and the block flushes it with one global atomic group per voxel.  No block barrier before the flush.
-//     The point list of generatePointCloud is never written: exact integer sums make the map independent of order, so
-//     the result is bit-identical to mask -> backproject -> insert (tests/test_gpu_parity.py).
-__global__ void __launch_bounds__(256)
-class_bits_kernel(const uint8_t* __restrict__ sem, int words_per_frame, uint16_t* __restrict__ raw)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= words_per_frame) return;
-    const size_t wi = (size_t)blockIdx.y * words_per_frame + i;
-    const uint4* p = reinterpret_cast<const uint4*>(sem + wi * 48);
-    const uint4 a = p[0], b = p[1], c = p[2];
-    const uint32_t d[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
-    uint32_t bits = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int o = 3 * k;                                   // byte offset of pixel k inside the 48 bytes
-        const uint32_t px = (o & 3) ? __builtin_amdgcn_alignbyte(d[(o >> 2) + 1], d[o >> 2], o & 3) : d[o >> 2];   // b | g<<8 | r<<16 | ..
-        const uint32_t bgr = px & 0xFFFFFFu;
-        bits |= (uint32_t)(bgr == (0u | (64u << 8) | (64u << 16)) || bgr == (192u | (128u << 8) | (0u << 16))) << k;   // (0,64,64) | (192,128,0) BGR
-    }
-    raw[wi] = (uint16_t)bits;
-}
-__global__ void __launch_bounds__(256)
-vdilate_bits_kernel(const uint16_t* __restrict__ raw, int wpr, int h, uint16_t* __restrict__ vb)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= wpr * h) return;
-    const int y = i / wpr, x = i - y * wpr;
-    const uint16_t* r = raw + (size_t)blockIdx.y * wpr * h;
-    uint32_t v = 0;
-#pragma unroll
-    for (int dy = -2; dy <= 2; dy++) { const int yy = y + dy; if (yy >= 0 && yy < h) v |= r[yy * wpr + x]; }
-    vb[(size_t)blockIdx.y * wpr * h + i] = (uint16_t)v;
-}
+// ------------------------------------------------------------------ K10+K11+K12, streaming form (w % 16 == 0): map_stream2_kernel below.
+// One thread = 16 consecutive pixels of a row; consecutive pixels with the same (voxel, label) are summed in registers, the run tails update a block-local LDS hash
+// (256 slots for the 3 x 4096 pixels of a block) and the block flushes it with one global atomic group per voxel.  The point list of generatePointCloud is never
+// written: exact integer sums make the map independent of order, so the result is bit-identical to mask -> backproject -> insert (tests/test_gpu_parity.py).
+// (Rounds 1-5 also carried the first form of this fusion -- class_bits_kernel + vdilate_bits_kernel + map_stream_kernel, every pixel through the full arithmetic,
+// two wave-wide segmented scans per chunk: 12 % slower, profiles/r03_*; removed in round 6, the compacting kernel covers every width the path accepts.)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_mov0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
 template <int CTRL, int ROW_MASK>
@@ -530,140 +494,8 @@ __device__ __forceinline__ double markstein_div(double n, double f, double r)
     q = fma(fma(-q, f, n), r, q);
     return fma(fma(-q, f, n), r, q);
 }
-template <bool FASTDIV>
-__global__ void __launch_bounds__(256, MS_MINB)
-map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
-                  const uint16_t* __restrict__ vbits, const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
-                  float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints)
-{
-    __shared__ LdsVox lt[MS_SLOTS];
-    __shared__ int s_npts;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wpr = w >> 4, words = wpr * h;
-    for (int i = tid; i < MS_SLOTS; i += 256) {
-        lt[i].key = SSM_VOX_EMPTY; lt[i].sx = 0; lt[i].sy = 0; lt[i].sz = 0; lt[i].r = lt[i].g = lt[i].b = lt[i].n = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) lt[i].hist[k] = 0;
-    }
-    if (tid == 0) s_npts = 0;
-    __syncthreads();
-    uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
-    int kept = 0; bool out_of_range = false;
-    // MS_CH chunks per block: neighbouring rows share most of their voxels, so the block table (and the global atomics of the
-    // flush, whose latency nothing overlaps) is paid once per 16 K pixels instead of once per 4 K
-#pragma unroll 1
-    for (int ch = 0; ch < MS_CH; ch++) {
-    const int wi = (blockIdx.x * MS_CH + ch) * 256 + tid;       // 16-pixel word of this frame
-    long long k0 = -2, k1 = -2; uint32_t l0 = 255, l1 = 255; RunAcc a0, a1;
-    a0.sx = a0.sy = a0.sz = 0; a0.r = a0.g = a0.b = a0.n = 0; a1 = a0;
-    // (wave-uniform condition: a lane past the frame's last word runs the body on that last word with nothing kept -- the palette table below is read with a
-    // wave shuffle from lanes 0 .. 15, which must stay active when the frame ends inside this wave)
-    if (wi - (tid & 63) < words) {
-        const bool inw = wi < words;
-        const int wic = inw ? wi : words - 1;
-        const size_t gw = (size_t)blockIdx.y * words + wic;
-        const int gy = wic / wpr, xw = wic - gy * wpr, gx0 = xw << 4;
-        const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
-        const uint4* pc = reinterpret_cast<const uint4*>(rgb + gw * 48);
-        const uint4* ps = reinterpret_cast<const uint4*>(sem + gw * 48);
-        const uint4 D0 = pd[0], D1 = pd[1], C0 = pc[0], C1 = pc[1], C2 = pc[2], S0 = ps[0], S1 = ps[1], S2 = ps[2];
-        const uint16_t* vb = vbits + (size_t)blockIdx.y * words + (size_t)gy * wpr;
-        const unsigned long long win = ((unsigned long long)(xw > 0 ? vb[xw - 1] : 0)) | ((unsigned long long)vb[xw] << 16) |
-                                       ((unsigned long long)(xw + 1 < wpr ? vb[xw + 1] : 0) << 32);
-        const uint32_t moving = (uint32_t)((win >> 14) | (win >> 15) | (win >> 16) | (win >> 17) | (win >> 18)) & 0xFFFFu;   // 5-wide OR
-        const uint32_t dd[8] = {D0.x, D0.y, D0.z, D0.w, D1.x, D1.y, D1.z, D1.w};
-        const uint32_t cc[13] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w, C2.x, C2.y, C2.z, C2.w, 0u};
-        const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
-        double T[12];
-        const bool hasT = pose != nullptr;
-        if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
-        const double yf = (double)gy - cam.cy;
-        // class id of every pixel, branch-free and outside the divergent part: a 16-slot perfect hash of the 12 palette
-        // colours ((bgr * K) >> 28), the table lives in lanes 0..15 of a register and is read with a wave shuffle; an entry
-        // is (label << 24 | bgr), so a colour outside the palette compares unequal and gets 255.  The same ids drive
-        // generatePointCloud's class gate (sky 0, pole 2, cyclist 11 are dropped, mapper.cpp:41-55).
-        const uint32_t tab_entry = label_hash_entry(lane & 15);
-        uint32_t labs[16]; uint32_t keepbits = 0;
-        const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-            const int o = 3 * k;
-            const uint32_t sbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(ss[(o >> 2) + 1], ss[o >> 2], o & 3) : ss[o >> 2]) & 0xFFFFFFu;
-            const uint32_t ent = (uint32_t)__shfl((int)tab_entry, (int)((sbgr * 0x7589a82bu) >> 28), 64);
-            labs[k] = (ent & 0xFFFFFFu) == sbgr ? ent >> 24 : 255u;
-            const bool gated = labs[k] < 12 && ((0x805u >> labs[k]) & 1u);
-            keepbits |= (uint32_t)(d != 0 && d <= dmax && !gated) << k;
-        }
-        keepbits &= ~moving;                                          // mapper.cpp:32
-        if (!inw) keepbits = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if ((keepbits >> k) & 1u) {
-                const int d = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-                const int o = 3 * k;
-                const uint32_t cbgr = ((o & 3) ? __builtin_amdgcn_alignbyte(cc[(o >> 2) + 1], cc[o >> 2], o & 3) : cc[o >> 2]) & 0xFFFFFFu;
-                float x, y, z;
-                if (FASTDIV) {
-                    z = (float)markstein_div((double)d, cam.scale, md.rscale);
-                    x = (float)markstein_div(((double)(gx0 + k) - cam.cx) * (double)z, cam.fx, md.rfx);
-                    y = (float)markstein_div(yf * (double)z, cam.fy, md.rfy);
-                } else {
-                    z = (float)((double)d / cam.scale);
-                    x = (float)(((double)(gx0 + k) - cam.cx) * (double)z / cam.fx);
-                    y = (float)(yf * (double)z / cam.fy);
-                }
-                float ox = x, oy = y, oz = z;
-                if (hasT) {
-                    const double X = x, Y = y, Z = z;
-                    ox = (float)(T[0] * X + T[3] * Y + T[6] * Z + T[9]);
-                    oy = (float)(T[1] * X + T[4] * Y + T[7] * Z + T[10]);
-                    oz = (float)(T[2] * X + T[5] * Y + T[8] * Z + T[11]);
-                }
-                const float fi = floorf(ox * inv_leaf), fj = floorf(oy * inv_leaf), fk = floorf(oz * inv_leaf);
-                const long long vi = (long long)(int)fi + (1 << 20), vj = (long long)(int)fj + (1 << 20), vk = (long long)(int)fk + (1 << 20);     // v_cvt_i32_f32 (saturating): an index the range check below rejects may be anything; float -> int64 costs ~8 instructions each
-                long long key = (vk << 42) | (vj << 21) | vi;
-                // range contract (oracle/mapper.c sso_voxel_key): such a point still counts in npoints (generatePointCloud emits it) but is not fused
-                if (!(fabsf(fi) < 1048576.0f && fabsf(fj) < 1048576.0f && fabsf(fk) < 1048576.0f)) { key = -1; out_of_range = true; }
-                const uint32_t lab = labs[k];
-                RunAcc p;
-                p.sx = f64_to_ll_rn((double)ox * 16777216.0); p.sy = f64_to_ll_rn((double)oy * 16777216.0); p.sz = f64_to_ll_rn((double)oz * 16777216.0);
-                p.b = cbgr & 255; p.g = (cbgr >> 8) & 255; p.r = cbgr >> 16; p.n = 1;
-                kept++;
-                if (k1 == -2 && (k0 == -2 || (k0 == key && l0 == lab))) {                 // still in the first run
-                    k0 = key; l0 = lab; a0.sx += p.sx; a0.sy += p.sy; a0.sz += p.sz; a0.r += p.r; a0.g += p.g; a0.b += p.b; a0.n += 1;
-                } else if (k1 == -2 || (k1 == key && l1 == lab)) {                       // second run
-                    k1 = key; l1 = lab; a1.sx += p.sx; a1.sy += p.sy; a1.sz += p.sz; a1.r += p.r; a1.g += p.g; a1.b += p.b; a1.n += 1;
-                } else {                                                                 // a third run inside 16 pixels: rare
-                    if (k1 >= 0) lds_vox_update(lt, k1, l1, a1, tab, cap_log2, counters, occ);
-                    k1 = key; l1 = lab; a1 = p;
-                }
-            }
-        }
-    }
-    // two wave-wide merges (first runs, second runs); waves of a block are independent until the final flush
-    if (__ballot(k0 != -2)) wave_flush(lt, k0, l0, a0, lane, tab, cap_log2, counters, occ);
-    if (__ballot(k1 != -2)) wave_flush(lt, k1, l1, a1, lane, tab, cap_log2, counters, occ);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o, 64);
-    if (lane == 0 && kept) atomicAdd(&s_npts, kept);
-    if (__ballot(out_of_range) && lane == 0) atomicOr(&counters[1], 2);
-    __syncthreads();
-    for (int i = tid; i < MS_SLOTS; i += 256) {
-        if (lt[i].key == SSM_VOX_EMPTY) continue;
-        ssm_voxel* v = vox_find_or_insert(tab, cap_log2, lt[i].key, counters, occ);
-        if (__builtin_expect(!v, 0)) { vox_overflow_packed(counters, lt[i].key, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n, lt[i].hist); continue; }
-        vox_add(v, lt[i].sx, lt[i].sy, lt[i].sz, lt[i].r, lt[i].g, lt[i].b, lt[i].n);
-#pragma unroll
-        for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
-    }
-    if (tid == 0 && s_npts) atomicAdd(&npoints[blockIdx.y], s_npts);
-}
 // ---- map_stream2_kernel: the same fusion with the kept pixels COMPACTED before the expensive part.
-// map_stream_kernel runs unprojection / pose transform / voxel key (about 170 of its 250 VALU instructions per pixel, most of them f64) for all 16
+// The first form (map_stream_kernel, removed) ran unprojection / pose transform / voxel key (about 170 of its 250 VALU instructions per pixel, most of them f64) for all 16
 // pixels of a lane as soon as any lane of the wave keeps that pixel; on the configs[1] stream 59 % of the pixels pass the gates, so 41 % of that work
 // is masked out.  Here a wave first decides (labels, depth range, class gates, moving mask: ~15 instructions per pixel), writes its lanes' depth and
 // kept pixels as 14-bit entries (source lane, pixel in the lane, label) to an LDS list in wave-scan order; then lane i takes the
@@ -673,15 +505,37 @@ map_stream_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict_
 // classifies the semantic rows of its three chunks plus two rows above and below (the vertical reach of the 5 x 5 dilate) into an LDS bit image -- the same
 // cache lines its gate pass reads right after -- and the gate pass ORs five rows x three words of it instead of loading three pre-dilated words.
 #define MS2_MINB 4
+// Lossless under any rate (round 6).  The table is sized from the stream's own rate (ssm_map.hip map_before_launch); when a launch brings far more voxels than
+// that (the camera leaves a near wall at a fine leaf), contributions the table refuses go to the context's overflow list, and a full list would DROP them.  So a
+// block that STARTS while the list holds more than `hw` records adds nothing at all: it logs (launch tag, frame, block) in the skip list and exits; the host
+// grows the map at its next look at the counters and launches exactly the logged blocks again (REDO: block ids from a list, no check).  A skipped block has
+// contributed nothing and its inputs are still where they were, so the redo is exact.  hw = list capacity - (blocks that can be resident: 256 CUs x MS2_MINB,
+// or the grid if smaller) x (records one block can append: one per pixel, MS_CH x 4096): after the last block that passed the check, only blocks resident at
+// that moment can still append, so the list never overflows and nothing is ever dropped.  Cost: one cached load per block.
+#define MS2_SKIP_CAP 65536
 #define MS2_CB_WORDS (MS_CH * 256 + 6 * 256)      // 16-pixel words of (rows of the block + 4 halo rows + partial first / last row) for widths up to 4096
-template <bool FASTDIV>
+template <bool FASTDIV, bool REDO>
 __global__ void __launch_bounds__(256, MS2_MINB)
 map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ sem,
                    const double* __restrict__ pose, int w, int h, ssm_camera cam, MapDiv md, double maxd,
-                   float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints, uint32_t mul_wpr)
+                   float inv_leaf, ssm_voxel* __restrict__ tab, int cap_log2, int32_t* __restrict__ counters, int32_t* __restrict__ npoints, uint32_t mul_wpr,
+                   int32_t* __restrict__ skip, int hw, int tag, int gx)
 {
     __shared__ LdsVox lt[MS_SLOTS];
-    __shared__ int s_npts;
+    __shared__ int s_npts, s_skip;
+    // REDO: `skip` holds the ids to run again, one per block of this launch: (tag << 24) | (frame * gx + block)
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (REDO) { const int id = skip[blockIdx.x] & 0xFFFFFF; by_ = id / gx; bx_ = id - by_ * gx; }
+    const int bx = bx_, by = by_;
+    if (!REDO && threadIdx.x == 0) {
+        int sk = 0;
+        if (__hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > hw) {
+            const int i = atomicAdd(&counters[6], 1);
+            if (i < MS2_SKIP_CAP) skip[i] = (tag << 24) | (by * gx + bx); else atomicOr(&counters[1], 1);      // (the host keeps grid <= MS2_SKIP_CAP / 4: cannot happen)
+            sk = 1;
+        }
+        s_skip = sk;
+    }
     __shared__ uint16_t vlist[4][1024];                                 // per wave: kept pixels in scan order: lane << 4 | pixel | label << 10
     __shared__ uint16_t cbits[MS2_CB_WORDS];                            // pedestrian | cyclist bit per pixel, rows ry0 .. of this frame, wpr words per row
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -690,7 +544,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     // moving-class bit of every pixel goes to the LDS bit image.  The rest of the bit image -- 2 rows above and below the block's rows and the parts of its
     // first / last row that belong to the neighbouring blocks -- is classified by all threads with the two compares the bit needs (rows outside the image: no
     // moving pixel).  (Before: every row of the block was read and classified here and read and hashed again in the gate pass.)
-    const int bw0 = blockIdx.x * MS_CH * 256;
+    const int bw0 = bx * MS_CH * 256;
     const int ry0 = (int)__umulhi((uint32_t)bw0, mul_wpr) - 2;
     const int own0 = bw0 - ry0 * wpr, own1 = min(bw0 + MS_CH * 256, words) - ry0 * wpr;      // the block's own words inside the bit image
     const uint32_t tab_entry = label_hash_entry(lane & 15);
@@ -698,13 +552,13 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
 #pragma unroll
     for (int ch = 0; ch < MS_CH; ch++) {
         labs[ch][0] = labs[ch][1] = 0u;
-        const int wi = (blockIdx.x * MS_CH + ch) * 256 + wv * 64 + lane;
+        const int wi = (bx * MS_CH + ch) * 256 + wv * 64 + lane;
         // EVERY lane of the wave runs the classification (a lane past the frame's last word re-reads that word and stores nothing): the palette table is
         // read with a wave shuffle from lanes 0 .. 15, which must not be masked off when the frame's words end inside this wave (found by
         // tests/test_gpu_fuzz.py at 176 x 88: 968 words, the last wave has 8 live lanes and lanes 8 .. 15 returned stale table entries)
         const bool inw = wi < words;
-        if ((blockIdx.x * MS_CH + ch) * 256 + wv * 64 < words) {      // wave-uniform
-            const uint4* ps = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + (inw ? wi : words - 1)) * 48);
+        if ((bx * MS_CH + ch) * 256 + wv * 64 < words) {      // wave-uniform
+            const uint4* ps = reinterpret_cast<const uint4*>(sem + ((size_t)by * words + (inw ? wi : words - 1)) * 48);
             const uint4 S0 = ps[0], S1 = ps[1], S2 = ps[2];
             const uint32_t ss[13] = {S0.x, S0.y, S0.z, S0.w, S1.x, S1.y, S1.z, S1.w, S2.x, S2.y, S2.z, S2.w, 0u};
             uint32_t bits = 0;
@@ -728,7 +582,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
             const int rr = (int)__umulhi((uint32_t)i, mul_wpr), gy = ry0 + rr;
             uint32_t bits = 0;
             if (gy >= 0 && gy < h) {
-                const uint4* p = reinterpret_cast<const uint4*>(sem + ((size_t)blockIdx.y * words + (size_t)((long long)ry0 * wpr + i)) * 48);
+                const uint4* p = reinterpret_cast<const uint4*>(sem + ((size_t)by * words + (size_t)((long long)ry0 * wpr + i)) * 48);
                 const uint4 a = p[0], b = p[1], c = p[2];
                 const uint32_t d[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, 0u};
 #pragma unroll
@@ -748,24 +602,25 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     }
     if (tid == 0) s_npts = 0;
     __syncthreads();
+    if (!REDO && s_skip) return;                                       // (block-uniform; nothing has been added anywhere yet)
     uint32_t* occ = reinterpret_cast<uint32_t*>(tab + (1u << cap_log2));
     int kept = 0; bool out_of_range = false;
     double T[12];
     const bool hasT = pose != nullptr;
-    if (hasT) { const double* P = pose + (size_t)blockIdx.y * 16;
+    if (hasT) { const double* P = pose + (size_t)by * 16;
 #pragma unroll
         for (int j = 0; j < 4; j++) { T[3*j] = P[4*j]; T[3*j+1] = P[4*j+1]; T[3*j+2] = P[4*j+2]; } }
     const int dmax = maxd >= 65535.0 ? 65535 : (int)maxd;          // integer d > maxd  <=>  d > floor(maxd)
 #pragma unroll 1
     for (int ch = 0; ch < MS_CH; ch++) {
-    const int wbase = (blockIdx.x * MS_CH + ch) * 256 + wv * 64;    // the wave's first 16-pixel word of this frame
+    const int wbase = (bx * MS_CH + ch) * 256 + wv * 64;    // the wave's first 16-pixel word of this frame
     const int wi = wbase + lane;
     uint32_t keepbits = 0;
     uint32_t lab4[2] = {labs[0][0], labs[0][1]};                     // (the chunk loop is not unrolled: the chunk's label registers by selects)
 #pragma unroll
     for (int c_ = 1; c_ < MS_CH; c_++) { lab4[0] = ch == c_ ? labs[c_][0] : lab4[0]; lab4[1] = ch == c_ ? labs[c_][1] : lab4[1]; }
     if (wi < words) {
-        const size_t gw = (size_t)blockIdx.y * words + wi;
+        const size_t gw = (size_t)by * words + wi;
         const int gy = (int)__umulhi((uint32_t)wi, mul_wpr), xw = wi - gy * wpr;
         const uint4* pd = reinterpret_cast<const uint4*>(depth + gw * 16);
         const uint4 D0 = pd[0], D1 = pd[1];
@@ -815,7 +670,7 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
     auto fetch = [&](int e, PixIn& q) {
         q.ent = vlist[wv][min(e, V - 1)];                               // (only called with V >= 1; entries past the end repeat the last one)
         const int sl = (q.ent >> 4) & 63, k = q.ent & 15;
-        const size_t gp = ((size_t)blockIdx.y * words + wbase + sl) * 16 + k;
+        const size_t gp = ((size_t)by * words + wbase + sl) * 16 + k;
         q.d = depth[gp];
         uint16_t c01; __builtin_memcpy(&c01, rgb + gp * 3, 2);
         q.c01 = c01; q.c2 = rgb[gp * 3 + 2];
@@ -899,49 +754,54 @@ map_stream2_kernel(const uint16_t* __restrict__ depth, const uint8_t* __restrict
 #pragma unroll
         for (int c = 0; c < 12; c++) { const uint32_t k = (lt[i].hist[c >> 1] >> (16 * (c & 1))) & 0xFFFF; if (k) atomicAdd(&v->hist[c], k); }
     }
-    if (tid == 0 && s_npts) atomicAdd(&npoints[blockIdx.y], s_npts);
+    if (tid == 0 && s_npts) atomicAdd(&npoints[by], s_npts);
 }
-hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
-                      ssm_camera cam, double max_distance, float leaf, uint16_t* bits_raw, uint16_t* bits_v,
-                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, bool compact)
+// MapDiv for a camera (see the struct): the reciprocal form when the divisors allow it; the check is cached per camera
+static bool map_div_for(const ssm_camera& cam, MapDiv& md)
 {
-    hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s);
-    if (e != hipSuccess) return e;
-    const int wpr = w >> 4, words = wpr * h;
-    const bool use2 = compact && (long long)words * wpr < (1ll << 32) && wpr <= 256;
-    if (!use2) {
-        class_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(sem, words, bits_raw);
-        vdilate_bits_kernel<<<dim3((words + 255) / 256, n), 256, 0, s>>>(bits_raw, wpr, h, bits_v);
-    }
-    // reciprocal form of the three divisions when the divisors allow it (see MapDiv); the check is cached per camera
     static std::mutex mu; static ssm_camera seen = {0, 0, 0, 0, 0}; static bool seen_ok = false;
-    MapDiv md; md.rscale = 1.0 / cam.scale; md.rfx = 1.0 / cam.fx; md.rfy = 1.0 / cam.fy;
-    bool fast;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (seen.scale != cam.scale || seen.fx != cam.fx || seen.fy != cam.fy) {
-            auto plain = [](double f) {                       // normal, positive, significand not all ones
-                uint64_t b; memcpy(&b, &f, 8);
-                const uint64_t man = b & 0xFFFFFFFFFFFFFull; const int ex = (int)((b >> 52) & 0x7FF);
-                return f > 0 && ex > 0 && ex < 0x7FF && man != 0xFFFFFFFFFFFFFull;
-            };
-            bool ok = plain(cam.scale) && plain(cam.fx) && plain(cam.fy);
-            for (int d = 0; d < 65536 && ok; d++) {           // every depth value through the same arithmetic on the host
-                double q = (double)d * md.rscale; q = std::fma(std::fma(-q, cam.scale, (double)d), md.rscale, q); q = std::fma(std::fma(-q, cam.scale, (double)d), md.rscale, q);
-                if (q != (double)d / cam.scale) ok = false;
-            }
-            seen = cam; seen_ok = ok;
+    md.rscale = 1.0 / cam.scale; md.rfx = 1.0 / cam.fx; md.rfy = 1.0 / cam.fy;
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen.scale != cam.scale || seen.fx != cam.fx || seen.fy != cam.fy) {
+        auto plain = [](double f) {                       // normal, positive, significand not all ones
+            uint64_t b; memcpy(&b, &f, 8);
+            const uint64_t man = b & 0xFFFFFFFFFFFFFull; const int ex = (int)((b >> 52) & 0x7FF);
+            return f > 0 && ex > 0 && ex < 0x7FF && man != 0xFFFFFFFFFFFFFull;
+        };
+        bool ok = plain(cam.scale) && plain(cam.fx) && plain(cam.fy);
+        for (int d = 0; d < 65536 && ok; d++) {           // every depth value through the same arithmetic on the host
+            double q = (double)d * md.rscale; q = std::fma(std::fma(-q, cam.scale, (double)d), md.rscale, q); q = std::fma(std::fma(-q, cam.scale, (double)d), md.rscale, q);
+            if (q != (double)d / cam.scale) ok = false;
         }
-        fast = seen_ok;
+        seen = cam; seen_ok = ok;
     }
-    const dim3 grid((words + 256 * MS_CH - 1) / (256 * MS_CH), n);
+    return seen_ok;
+}
+int k_map_fuse_blocks_per_frame(int w, int h) { const int words = (w >> 4) * h; return (words + 256 * MS_CH - 1) / (256 * MS_CH); }
+int k_map_fuse_block_records(void) { return MS_CH * 4096; }            // overflow records one block can append at most: one per pixel
+int k_map_fuse_resident_blocks(void) { return 256 * MS2_MINB; }
+int k_map_fuse_skip_cap(void) { return MS2_SKIP_CAP; }
+// n frames of w x h (w % 16 == 0, w <= 4096).  skip / hw / tag: see map_stream2_kernel (skip = the context's skip list, MS2_SKIP_CAP entries; counters[6] counts them).
+// nredo > 0: run exactly the blocks redo_ids[0 .. nredo) (device) of an earlier launch with these arguments again (its per-frame point counts go on counting).
+hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
+                      ssm_camera cam, double max_distance, float leaf,
+                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, int32_t* skip, int hw, int tag, const int32_t* redo_ids, int nredo)
+{
+    const int wpr = w >> 4, words = wpr * h;
+    if (!((long long)words * wpr < (1ll << 32) && wpr <= 256)) return hipErrorInvalidValue;      // frames wider than 4096 pixels: not supported by the fused map stage
+    if (nredo <= 0) { const hipError_t e = hipMemsetAsync(npoints, 0, sizeof(int32_t) * n, s); if (e != hipSuccess) return e; }
+    MapDiv md; const bool fast = map_div_for(cam, md);
+    const int gx = (words + 256 * MS_CH - 1) / (256 * MS_CH);
+    const dim3 grid(gx, n);
     const uint32_t mul_wpr = (uint32_t)(((1ull << 32) + wpr - 1) / wpr);           // floor(i / wpr) = umulhi(i, mul) for i < words (i * wpr < 2^32)
-    if (use2) {
-        if (fast) map_stream2_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
-        else map_stream2_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints, mul_wpr);
+    const double maxd = max_distance * cam.scale; const float il = 1.0f / leaf;
+    if (nredo > 0) {
+        int32_t* ids = const_cast<int32_t*>(redo_ids);
+        if (fast) map_stream2_kernel<true, true><<<nredo, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, maxd, il, tab, cap_log2, counters, npoints, mul_wpr, ids, 0, tag, gx);
+        else map_stream2_kernel<false, true><<<nredo, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, maxd, il, tab, cap_log2, counters, npoints, mul_wpr, ids, 0, tag, gx);
     } else {
-        if (fast) map_stream_kernel<true><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
-        else map_stream_kernel<false><<<grid, 256, 0, s>>>(depth, rgb, sem, bits_v, pose, w, h, cam, md, max_distance * cam.scale, 1.0f / leaf, tab, cap_log2, counters, npoints);
+        if (fast) map_stream2_kernel<true, false><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, maxd, il, tab, cap_log2, counters, npoints, mul_wpr, skip, hw, tag, gx);
+        else map_stream2_kernel<false, false><<<grid, 256, 0, s>>>(depth, rgb, sem, pose, w, h, cam, md, maxd, il, tab, cap_log2, counters, npoints, mul_wpr, skip, hw, tag, gx);
     }
     return hipGetLastError();
 }

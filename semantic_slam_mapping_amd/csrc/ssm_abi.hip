@@ -227,7 +227,7 @@ static int ctx_init(ssm_ctx* c)
     DALLOC(c, c->d_total, 2); DALLOC(c, c->d_points, (size_t)B * W * H);
     DALLOC(c, c->d_in_img, (size_t)W * H * 3); DALLOC(c, c->d_in_sem, (size_t)W * H * 3); DALLOC(c, c->d_in_depth, (size_t)W * H); DALLOC(c, c->d_in_pose, 16);
     DALLOC(c, c->map.ovf, VOX_OVF_RECORDS); c->map.ovf_cap = VOX_OVF_RECORDS;
-    { void* hp = nullptr; HIPCHK(c, hipHostMalloc(&hp, 32, hipHostMallocDefault)); c->h_map_snap = (int32_t*)hp; memset(hp, 0, 32); }
+    { void* hp = nullptr; HIPCHK(c, hipHostMalloc(&hp, 64, hipHostMallocDefault)); c->h_map_snap = (int32_t*)hp; memset(hp, 0, 64); }
     for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->map_snap_ev[k], hipEventDisableTiming));
     int r = table_alloc(c, c->map, cfg.voxel_capacity_log2); if (r) return r;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -250,7 +250,6 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     { const char* e = getenv("SSM_SGBM_STREAMS"); const int v = e ? atoi(e) : cfg->sgbm_streams; if (v > 0) c->stereo_sgbm_streams = v > 3 ? 3 : v; }
     c->sgbm_form_cfg = cfg->sgbm_form;
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
-    { const char* e = getenv("SSM_MAP_VARIANT"); c->map_compact = !(e && atoi(e) == 0); }      // 0: map_stream_kernel (every pixel through the full arithmetic)
     { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
     { const char* e = getenv("SSM_MATCH_VARIANT"); c->match_mfma = !(e && atoi(e) == 0); }      // 0: the VALU matcher in the sequence path (A/B runs)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
@@ -310,7 +309,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->ev_join3) hipEventDestroy(c->ev_join3);
-    if (c->d_mask3) hipFree(c->d_mask3);
+    if (c->map.skip) hipFree(c->map.skip); if (c->d_redo) hipFree(c->d_redo);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     delete c;
@@ -403,7 +402,6 @@ static int ensure_alt(ssm_ctx* c)
 {
     int r = ensure_alt_ws(c, c->alt); if (r) return r;
     if (c->nchains >= 3) { r = ensure_alt_ws(c, c->alt2); if (r) return r; }
-    if (!c->d_mask3) DALLOC(c, c->d_mask3, (size_t)c->B * c->g.W * c->g.H);
     return SSM_OK;
 }
 struct ChainSwap {                    // chains 1, 2 of ssm_seq_process: the helpers use c->stream and the c->d_* workspace; point both at that chain's set
@@ -885,7 +883,6 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
             if (!side_work) return SSM_OK;
             StreamSwap sw(c, side);
             hipStream_t s = map3 ? c->stream3 : c->stream;                // = stream2 inside this scope (unless serialised)
-            uint8_t* mask_ws = map3 ? c->d_mask3 : c->d_mask;
             struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } onmap(c, s);   // the stage events follow the kernels
             const uint8_t* sem_src = in->sem_bgr ? in->sem_bgr + (size_t)f0 * npix * 3 : nullptr;
             if (stages & SSM_STAGE_SEGNET) {          // Classifier in the loop (the variant commented out at src/rgbdframe.cpp:119-136)
@@ -903,10 +900,9 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                 const uint8_t* sem_q = sem_src + (size_t)q0 * npix * 3;
                 if ((W & 15) == 0) {         // streaming fused kernels (16 pixels per thread, 16-byte loads)
                     prof_begin(c, "map_fuse");
-                    HIPCHK(c, k_map_fuse(in->depth + (size_t)g0 * npix, in->bgr + (size_t)g0 * npix * 3, sem_q,
-                                         in->pose ? in->pose + (size_t)g0 * 16 : nullptr, nq, W, H, c->cfg.camera, c->cfg.mapper_max_distance,
-                                         (float)c->cfg.mapper_resolution, reinterpret_cast<uint16_t*>(mask_ws), reinterpret_cast<uint16_t*>(mask_ws) + (size_t)nq * (W >> 4) * H,
-                                         c->map.tab, c->map.cap_log2, c->map.counters, c->d_npoints + g0, s, c->map_compact));
+                    { MapLaunch L; L.depth = in->depth + (size_t)g0 * npix; L.rgb = in->bgr + (size_t)g0 * npix * 3; L.sem = sem_q; L.pose = in->pose ? in->pose + (size_t)g0 * 16 : nullptr;
+                      L.n = nq; L.w = W; L.h = H; L.npoints = c->d_npoints + g0; L.valid = true;
+                      r = map_fuse_launch(c, s, L); if (r) return r; }
                     prof_end(c);
                 } else {                     // odd widths: mask -> ordered back-projection -> insert
                     prof_begin(c, "mask");
@@ -919,7 +915,7 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
                     HIPCHK(c, k_voxel_insert(c->d_points, c->d_total, (int64_t)nq * (int64_t)npix, (float)c->cfg.mapper_resolution, c->map.tab, c->map.cap_log2, c->map.counters, s));
                     prof_end(c);
                 }
-                r = map_after_launch(c, s, nq); if (r) return r;
+                r = map_after_launch(c, s, nq, (stages & SSM_STAGE_SEGNET) != 0 && (W & 15) == 0); if (r) return r;
             }
             return SSM_OK;
         };

@@ -18,9 +18,12 @@
 struct VoxTable {           // tab[slots] | occ[slots] | counter block (32 bytes: count, flags, overflow records, overflow capacity, overflow list address)
     ssm_voxel* tab = nullptr; uint32_t* occ = nullptr; int32_t* counters = nullptr; int cap_log2 = 0;
     ssm_voxel* ovf = nullptr; int ovf_cap = 0;       // the overflow list of the context map (kernels_map.hip vox_overflow_slot); the temporary tables have none
+    int32_t* skip = nullptr;                         // the context map's skip list (kernels_map.hip map_stream2_kernel): blocks of the fused map stage that found the overflow list beyond its high-water mark
     size_t bytes() const { const size_t s = (size_t)1 << cap_log2; return s * sizeof(ssm_voxel) + s * 4 + 32; }
 };
-static const int VOX_OVF_RECORDS = 1 << 18;          // 29 MB per context
+static const int VOX_OVF_RECORDS = 1 << 18;          // 29 MB per context; a context that runs the fused map stage (ssm_seq_process) trades it for the large list of map_ensure_stream_list
+// one launch of the fused map stage, kept so that blocks it skipped can be run again (ssm_map.hip map_redo)
+struct MapLaunch { const uint16_t* depth; const uint8_t* rgb; const uint8_t* sem; const double* pose; int n, w, h; int32_t* npoints; bool valid; };
 struct StageRec { const char* name; hipEvent_t a, b; };
 // SegNet driving_webdemo: 26 conv layers; op list interleaves pools / unpools
 struct SegLayerDef { int cin, cout, h, w; };
@@ -79,7 +82,7 @@ struct ssm_ctx {
     bool side_ready = false;            // ensure_side_streams completed
     hipStream_t stream2 = nullptr;      // ssm_seq_process: the SegNet + map stage of a sub-batch runs here, beside the ORB + match chain
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr; uint8_t* d_mask3 = nullptr; int map_stream = 1;   // two-chain mode: the map stage on a stream of its own (SSM_MAP_STREAM=0: on the chain's stream)
+    hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr; int map_stream = 1;   // two-chain mode: the map stage on a stream of its own (SSM_MAP_STREAM=0: on the chain's stream)
     ssm_config cfg{};
     OrbGeom g{};
     std::string err;
@@ -118,8 +121,11 @@ struct ssm_ctx {
     int seq_cap = 0, prev_n = -1;
     ssm_keypoint* d_kps = nullptr; uint8_t* d_desc_all = nullptr; int32_t* d_nkp_all = nullptr; float* d_pos3d = nullptr;
     ssm_dmatch* d_matches = nullptr; int32_t* d_nmatch = nullptr; int32_t* d_match_pend = nullptr; int32_t* d_npoints = nullptr; uint8_t* d_hist_tmp = nullptr;
-    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true; bool map_compact = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
+    uint8_t* d_exp_q = nullptr; uint8_t* d_exp_t = nullptr; uint8_t* d_knn = nullptr; int capT = 0; bool match_mfma = true; bool map_first = true;   // the matcher's expanded descriptor rows (kernels_match.hip)
     // voxel tables
+    MapLaunch map_ring[8] = {}; unsigned map_ring_next = 0; int32_t* d_redo = nullptr; std::vector<int32_t> map_skipped;    // launches that may still have skipped blocks; ids to run again (host)
+    std::vector<hipStream_t> map_launch_streams; long map_redone = 0;      // streams fused launches were queued on; blocks run again so far
+    bool map_unexamined = false;                            // a fused map launch was queued since the counters were last read on a drained stream
     VoxTable map, tmp; bool map_full_reported = false;   // table-full already reported by check_device_flags (reset by ssm_map_clear)
     // the context map grows (map_settle); between the map launches of ssm_seq_process its counters come back through a two-slot ring of asynchronous copies
     int vox_max_log2 = 28; int32_t* h_map_snap = nullptr; hipEvent_t map_snap_ev[2] = {nullptr, nullptr}; uint64_t map_launches = 0; int map_grown = 0;
@@ -175,7 +181,8 @@ SSM_HIDDEN int ensure_side_streams(ssm_ctx* c);
 SSM_HIDDEN int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2);
 SSM_HIDDEN int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve, int32_t* counters_out = nullptr);
 SSM_HIDDEN int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq);
-SSM_HIDDEN int map_after_launch(ssm_ctx* c, hipStream_t s, int frames);
+SSM_HIDDEN int map_after_launch(ssm_ctx* c, hipStream_t s, int frames, bool inputs_volatile);
+SSM_HIDDEN int map_fuse_launch(ssm_ctx* c, hipStream_t s, const MapLaunch& L);      // one launch of the fused map stage on the context map, recorded for a redo
 // ssm_segnet_abi.hip
 SSM_HIDDEN int seg_init(ssm_ctx* c);
 SSM_HIDDEN int seg_forward_dev(ssm_ctx* c, const uint8_t* bgr, int n, uint8_t* labels_net, uint8_t* sem_bgr, int flags);

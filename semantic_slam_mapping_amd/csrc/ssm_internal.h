@@ -95,9 +95,16 @@ int backproject_chunks(int w, int h);
 hipError_t k_voxel_clear(ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
 hipError_t k_voxel_insert(const ssm_point* pts, const int64_t* n_dev, int64_t n_max, float leaf, ssm_voxel* tab,
                           int cap_log2, int32_t* counters, hipStream_t s);
+// the fused map stage (kernels_map.hip map_stream2_kernel): n frames of w x h (w % 16 == 0, w <= 4096).  skip: the context's skip list (k_map_fuse_skip_cap() ints,
+// counted in counters[6]); hw: a block that starts with more than hw records in the overflow list logs itself there and adds nothing; tag: the launch's slot in the
+// host's ring of launch descriptors.  nredo > 0: run the blocks redo_ids[0 .. nredo) (device; entries as logged) of the launch with these arguments again.
 hipError_t k_map_fuse(const uint16_t* depth, const uint8_t* rgb, const uint8_t* sem, const double* pose, int n, int w, int h,
-                      ssm_camera cam, double max_distance, float leaf, uint16_t* bits_raw, uint16_t* bits_v,
-                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, bool compact = true /* map_stream2_kernel; false: map_stream_kernel */);
+                      ssm_camera cam, double max_distance, float leaf,
+                      ssm_voxel* tab, int cap_log2, int32_t* counters, int32_t* npoints, hipStream_t s, int32_t* skip, int hw, int tag, const int32_t* redo_ids, int nredo);
+int k_map_fuse_blocks_per_frame(int w, int h);
+int k_map_fuse_block_records(void);        // overflow records one block can append at most
+int k_map_fuse_resident_blocks(void);      // blocks of the kernel the device can hold at a time
+int k_map_fuse_skip_cap(void);
 hipError_t k_voxel_merge(const ssm_voxel* src, int n, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
 hipError_t k_voxel_rehash(const ssm_voxel* src, int src_cap_log2, ssm_voxel* tab, int cap_log2, int32_t* counters, hipStream_t s);
 hipError_t k_voxel_compact(const ssm_voxel* tab, int cap_log2, ssm_voxel* out, int32_t* n_out, hipStream_t s);

@@ -1,6 +1,7 @@
 // ssm_map.hip -- the context's voxel map behind the C ABI: the growable table (map_settle), ssm_map_*, ssm_voxel_filter, the multi-GPU merge
 // (ssm_comm_*, ssm_voxel_allgather: RCCL) and the device-resident Mapper (ssm_backproject_dev, ssm_viewer_map_*).  Kernels: kernels_map.hip, voxel_sort.hip.
 #include "ssm_ctx.h"
+#include <algorithm>
 
 int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
 {
@@ -18,36 +19,121 @@ int table_alloc(ssm_ctx* c, VoxTable& t, int cap_log2)
     HIPCHK(c, hipStreamSynchronize(c->stream));                   // (the sources are on this stack)
     return SSM_OK;
 }
+// every stream of the context that may hold work on the context map (ssm_seq_process with SSM_MAP_STREAM=0 runs the map stage of alternate sub-batches on the
+// chains' own streams): waited for before the table is replaced or skipped blocks are run again (a launch on another stream could still be
+// inserting into the old table while it is re-hashed)
+static int map_drain_other_streams(ssm_ctx* c, hipStream_t s)
+{
+    for (hipStream_t st : c->map_launch_streams) if (st && st != s) HIPCHK(c, hipStreamSynchronize(st));      // (the streams fused launches were queued on: one, normally)
+    return SSM_OK;
+}
+// The fused map stage needs an overflow list that can take what every resident block may still append after the last block passed its high-water check
+// (kernels_map.hip map_stream2_kernel): 2^18 records of head room + resident blocks x records per block (1024 x 12288 records of 112 B: 1.4 GB of the device's 288).
+// The context trades its small list for it at the first fused launch; the map is at rest (list empty) when this runs.
+static int64_t map_stream_list_records()
+{
+    const char* e = getenv("SSM_MAP_TEST_SMALL_LIST"); const bool small = e && atoi(e) != 0;      // tests (read per launch): keep the 2^18-record list -- every block then skips itself and is run again, 21 at a time
+    return small ? (int64_t)VOX_OVF_RECORDS : (int64_t)VOX_OVF_RECORDS + (int64_t)k_map_fuse_resident_blocks() * k_map_fuse_block_records();
+}
+static int map_ensure_stream_list(ssm_ctx* c, hipStream_t s)
+{
+    VoxTable& t = c->map;
+    if (t.skip && t.ovf_cap >= map_stream_list_records()) return SSM_OK;
+    int r = map_settle(c, s, 0); if (r) return r;
+    if (!t.skip) { DALLOC(c, t.skip, (size_t)k_map_fuse_skip_cap()); DALLOC(c, c->d_redo, (size_t)k_map_fuse_skip_cap()); }
+    if (t.ovf_cap < map_stream_list_records()) {
+        ssm_voxel* big = nullptr;
+        DALLOC(c, big, (size_t)map_stream_list_records());
+        if (t.ovf) hipFree(t.ovf);
+        t.ovf = big; t.ovf_cap = (int)map_stream_list_records();
+        struct { int32_t cap, pad; ssm_voxel* buf; } tail = { t.ovf_cap, 0, t.ovf };
+        HIPCHK(c, hipMemcpyAsync(t.counters + 3, &tail.cap, 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(t.counters + 4, &tail.buf, 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return SSM_OK;
+}
+// One launch of the fused map stage on the context map.  Its arguments go into a ring of eight (the host looks at the counters at most a few launches late:
+// map_before_launch's snapshots, the start of the next call); the ring slot is the tag the launch's skipped blocks carry.
+int map_fuse_launch(ssm_ctx* c, hipStream_t s, const MapLaunch& L)
+{
+    VoxTable& t = c->map;
+    int r = map_ensure_stream_list(c, s); if (r) return r;
+    const int gx = k_map_fuse_blocks_per_frame(L.w, L.h);
+    if ((int64_t)gx * L.n > k_map_fuse_skip_cap() / 4) FAIL(c, SSM_E_INVAL, "map stage: more than " + std::to_string(k_map_fuse_skip_cap() / 4) + " blocks in one launch (frames per launch x frame size)");
+    const int64_t resident = std::min<int64_t>(k_map_fuse_resident_blocks(), (int64_t)gx * L.n);
+    const int64_t hw = (int64_t)t.ovf_cap - resident * k_map_fuse_block_records();
+    const int tag = (int)(c->map_ring_next++ & 7u);
+    c->map_ring[tag] = L; c->map_ring[tag].valid = true;
+    c->map_unexamined = true;
+    if (std::find(c->map_launch_streams.begin(), c->map_launch_streams.end(), s) == c->map_launch_streams.end()) c->map_launch_streams.push_back(s);
+    HIPCHK(c, k_map_fuse(L.depth, L.rgb, L.sem, L.pose, L.n, L.w, L.h, c->cfg.camera, c->cfg.mapper_max_distance, (float)c->cfg.mapper_resolution,
+                         t.tab, t.cap_log2, t.counters, L.npoints, s, t.skip, (int)hw, tag, nullptr, 0));
+    return SSM_OK;
+}
 // The context map has no capacity of its own (the reference's globalMap grows without limit, src/mapper.cpp:121-158): voxel_capacity_log2 is where it STARTS.
-// map_settle brings the map to rest on stream s (blocking): the overflow list is merged into the table and the table is re-hashed into a larger one whenever
-// 4 x (voxels + overflow records + reserve) exceeds its slots -- `reserve` = new voxels the caller is about to add at most, so that an insert / merge of a known
-// size can never overflow.  SSM_E_CAPACITY only beyond 2^vox_max_log2 slots (28: the key's range), SSM_E_NOMEM when the larger table cannot be allocated; in both
-// cases nothing is lost: table and list stay as they are.
+// map_settle brings the map to rest on stream s (blocking): blocks of the fused map stage that skipped themselves are run again (in batches the overflow list can
+// take whole), the overflow list is merged into the table, and the table is re-hashed into a larger one whenever 4 x (voxels + overflow records + reserve) exceeds
+// its slots -- `reserve` = new voxels the caller is about to add at most, so that an insert / merge of a known size can never overflow.  SSM_E_CAPACITY only when
+// something cannot be placed beyond 2^vox_max_log2 slots (28: the key's range), SSM_E_NOMEM when the larger table cannot be allocated; in both cases nothing is
+// lost: table and list stay as they are.
 int map_settle(ssm_ctx* c, hipStream_t s, int64_t reserve, int32_t* counters_out)       // counters_out: the table's counter block as it is when the map is at rest
 {
     VoxTable& t = c->map;
     int lo = 0;                                                   // overflow records [0, lo) are merged already
-    for (int round = 0; round < 64; round++) {
-        int32_t cnt[4];
-        HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 16, hipMemcpyDeviceToHost, s));
+    for (int round = 0; round < 4096; round++) {
+        int32_t cnt[8];
+        HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 32, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (c->map_unexamined || cnt[6] > 0) {
+            // fused launches may sit on the context's other streams: their skip entries (and their table traffic) are complete only when those have drained
+            { const int r = map_drain_other_streams(c, s); if (r) return r; }
+            HIPCHK(c, hipMemcpyAsync(cnt, t.counters, 32, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s));
+            c->map_unexamined = false;
+        }
+        if (cnt[6] > 0) {                                          // blocks that skipped themselves: take their ids over, the device list starts again
+            const int ns = cnt[6] < k_map_fuse_skip_cap() ? cnt[6] : k_map_fuse_skip_cap();
+            const size_t at = c->map_skipped.size(); c->map_skipped.resize(at + (size_t)ns);
+            const int32_t z = 0;
+            HIPCHK(c, hipMemcpyAsync(c->map_skipped.data() + at, t.skip, (size_t)ns * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(t.counters + 6, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s));
+            cnt[6] = 0;
+        }
         const int64_t n = cnt[0], hi = cnt[2] < t.ovf_cap ? cnt[2] : t.ovf_cap, m = hi - lo;
         const int64_t slots = (int64_t)1 << t.cap_log2;
         const bool grow = 4 * (n + m + reserve) > slots && t.cap_log2 < c->vox_max_log2;
-        if (!grow && 2 * (n + m + reserve) > slots) {
-            // at voxel_max_capacity_log2 and more than half full.  A caller that announced its insert (reserve) is refused before anything is added; records
-            // waiting in the overflow list have no table to go to: the map is incomplete from here on (flag bit 0, reported until ssm_map_clear)
+        if (!grow && 2 * (n + m + reserve) > slots && (m > 0 || reserve > 0)) {
+            // at voxel_max_capacity_log2 and more than half full with something still to place.  A caller that announced its insert (reserve) is refused before
+            // anything is added; records waiting in the overflow list have no table to go to: the map is incomplete from here on (flag bit 0, reported until
+            // ssm_map_clear).  (A complete map that is merely more than half full at the cap stays readable: nothing to place, nothing refused -- ADVICE r05.)
             if (m > 0) { const int32_t lost[2] = { cnt[1] | 1, 0 }; HIPCHK(c, hipMemcpyAsync(t.counters + 1, lost, 8, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
             FAIL(c, SSM_E_CAPACITY, "the voxel map needs more than 2^" + std::to_string(c->vox_max_log2) + " slots (voxel_max_capacity_log2)");
         }
         if (m <= 0 && !grow) {
             if (cnt[2] != 0) { const int32_t z = 0; HIPCHK(c, hipMemcpyAsync(t.counters + 2, &z, 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); cnt[2] = 0; }
+            lo = 0;
+            if (!c->map_skipped.empty()) {
+                // the map is at rest and its list is empty: run the next batch of skipped blocks again -- as many as the list can take whole, all of one launch
+                // (the ids of a launch carry its ring slot).  They add to the table what they can and the rest to the list; the loop then merges, grows, goes on.
+                const int tag = (c->map_skipped.back() >> 24) & 7;
+                const MapLaunch L = c->map_ring[tag];
+                if (!L.valid) FAIL(c, SSM_E_HIP, "voxel map: skipped blocks of a launch whose arguments are no longer known");
+                const size_t room = (size_t)(t.ovf_cap / k_map_fuse_block_records());
+                std::vector<int32_t> batch;
+                for (size_t i = c->map_skipped.size(); i-- > 0 && batch.size() < room; ) if (((c->map_skipped[i] >> 24) & 7) == tag) { batch.push_back(c->map_skipped[i]); c->map_skipped.erase(c->map_skipped.begin() + (long)i); }
+                HIPCHK(c, hipMemcpyAsync(c->d_redo, batch.data(), batch.size() * 4, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s));
+                HIPCHK(c, k_map_fuse(L.depth, L.rgb, L.sem, L.pose, L.n, L.w, L.h, c->cfg.camera, c->cfg.mapper_max_distance, (float)c->cfg.mapper_resolution,
+                                     t.tab, t.cap_log2, t.counters, L.npoints, s, t.skip, 0, tag, c->d_redo, (int)batch.size()));
+                c->map_redone += (long)batch.size();
+                continue;
+            }
             if (counters_out) memcpy(counters_out, cnt, 16);
             return SSM_OK;
         }
         if (grow) {
+            { const int r = map_drain_other_streams(c, s); if (r) return r; }      // nobody may still be inserting into the table that is replaced
             int L = t.cap_log2; while (L < c->vox_max_log2 && 4 * (n + m + reserve) > ((int64_t)1 << L)) L++;
-            VoxTable nt; nt.ovf = t.ovf; nt.ovf_cap = t.ovf_cap;
+            VoxTable nt; nt.ovf = t.ovf; nt.ovf_cap = t.ovf_cap; nt.skip = t.skip;
             { hipStream_t keep = c->stream; c->stream = s; const int r = table_alloc(c, nt, L); c->stream = keep; if (r) return r; }
             // the flags travel with the map; the new counter block goes on counting overflow records where the old one stopped (the records [lo, hi) are still to
             // merge, and the re-hash itself appends behind them should it need the list)
@@ -87,7 +173,7 @@ static int map_settle_exact(ssm_ctx* c, hipStream_t s, int64_t reserve)
     int32_t cnt[4];
     HIPCHK(c, hipMemcpyAsync(cnt, c->map.counters, 16, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s));
     map_learn_rate(c, cnt[0], c->map_frames);
-    c->map_launches = 0;
+    c->map_launches = 0; c->map_known_total = cnt[0]; c->map_known_frames = c->map_frames;      // (the count just read is the newest the host knows: the estimates start from it)
     return SSM_OK;
 }
 int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq)
@@ -109,18 +195,21 @@ int map_before_launch(ssm_ctx* c, hipStream_t s, int remaining, int* nq)
     }
     const int slot = (int)(c->map_launches & 1);
     HIPCHK(c, hipEventSynchronize(c->map_snap_ev[slot]));
-    const int32_t* cnt = c->h_map_snap + 4 * slot;
+    const int32_t* cnt = c->h_map_snap + 8 * slot;
     const int64_t total = (int64_t)cnt[0] + cnt[2], at = c->map_snap_frames[slot];
     map_learn_rate(c, total, at);
     c->map_known_total = total; c->map_known_frames = at;
     const double expect = (double)total + (double)(c->map_frames - at + remaining) * grant;
-    if (cnt[2] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2) || 2.0 * expect > (double)((int64_t)1 << t.cap_log2))
+    if (cnt[2] > 0 || cnt[6] > 0 || 4 * (int64_t)cnt[0] > ((int64_t)1 << t.cap_log2) || 2.0 * expect > (double)((int64_t)1 << t.cap_log2))      // (cnt[6]: blocks skipped themselves)
         return map_settle_exact(c, s, (int64_t)(remaining * grant));
     return SSM_OK;
 }
-int map_after_launch(ssm_ctx* c, hipStream_t s, int frames)
+int map_after_launch(ssm_ctx* c, hipStream_t s, int frames, bool inputs_volatile)
 {
     c->map_frames += frames;
+    // inputs_volatile: the launch read a buffer that the next work on this stream overwrites (the labels SegNet has just generated): blocks that skipped themselves
+    // must run again before that, so the map is brought to rest behind the launch (one wait per SegNet sub-batch, next to ~25 ms of SegNet)
+    if (inputs_volatile && c->map_vpf >= 0) { const int r = map_settle(c, s, 0); if (r) return r; }
     if (c->map_vpf < 0) {                                         // the context's first frames: wait for them once and take the rate
         int r = map_settle_exact(c, s, 0); if (r) return r;
         if (c->map_vpf < 0) c->map_vpf = 1.0;                     // (nothing was fused: every pixel gated; the next launches are granted little and watched)
@@ -129,7 +218,7 @@ int map_after_launch(ssm_ctx* c, hipStream_t s, int frames)
         return SSM_OK;
     }
     const int slot = (int)(c->map_launches & 1);
-    HIPCHK(c, hipMemcpyAsync(c->h_map_snap + 4 * slot, c->map.counters, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_map_snap + 8 * slot, c->map.counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(c->map_snap_ev[slot], s));
     c->map_snap_frames[slot] = c->map_frames;
     c->map_launches++;
@@ -190,6 +279,7 @@ extern "C" int ssm_map_clear(ssm_ctx* c)
     c->map_tail = nullptr;                                        // (the context stream has joined the map's side stream: from here the map's newest work is on it)
     HIPCHK(c, k_voxel_clear(c->map.tab, c->map.cap_log2, c->map.counters, c->stream));       // (the capacity it has grown to stays)
     c->map_full_reported = false; c->map_launches = 0; c->map_frames = 0; c->map_known_total = 0; c->map_known_frames = 0;      // (the rate map_vpf is the stream's: kept)
+    c->map_skipped.clear(); for (MapLaunch& L : c->map_ring) L.valid = false;            // (blocks that skipped themselves belong to the map that is cleared)
     return SSM_OK;
 }
 extern "C" int ssm_map_insert(ssm_ctx* c, const ssm_point* pts, int n)
@@ -216,6 +306,13 @@ extern "C" int ssm_map_size(ssm_ctx* c, int* n)
     if (!c || !n) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     return table_count(c, c->map, n);
+}
+extern "C" int ssm_map_stats(ssm_ctx* c, int64_t stats[4])
+{
+    if (!c || !stats) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu);
+    stats[0] = c->map.cap_log2; stats[1] = c->map_grown; stats[2] = c->map_redone; stats[3] = c->map.ovf_cap;
+    return SSM_OK;
 }
 extern "C" int ssm_map_export(ssm_ctx* c, ssm_point* out, int cap, int* n_out)
 {

@@ -351,6 +351,92 @@ def test_map_growth_follows_the_streams_voxel_rate_at_a_leaf_below_the_pixel_foo
         big.close()
 
 
+def _wall_then_stream(ctx, n_wall, n_all, W=640, H=480):
+    """device buffers of the configs[1] stream whose first n_wall frames see a wall at 0.4 m (every depth pixel 400 at scale 1000) and whose other frames are the stream's"""
+    bufs = [ctx.dev_alloc(n_all * W * H * 3), ctx.dev_alloc(n_all * W * H * 2), ctx.dev_alloc(n_all * W * H * 3), ctx.dev_alloc(n_all * 128)]
+    ctx.synth_frames_dev(SEED, 0, n_all, *bufs)
+    ctx.h2d(bufs[1], np.full((n_wall, H, W), 400, np.uint16))
+    return bufs
+
+
+def test_map_stays_lossless_when_the_voxel_rate_jumps(monkeypatch):
+    """VERDICT r05 item 5 / ADVICE r05: the table is sized from the stream's own voxel rate, and that rate can jump.  Leaf 4 mm; the first 20 frames see a wall at 0.4 m
+    (a pixel's footprint is 0.8 mm there: ~10^4 voxels per frame), the next 20 the normal stream (1 - 5 m: nearly every kept pixel a voxel of its own, ~2 x 10^5 per
+    frame).  From 2^10 slots (small launches, settled in front of each) and from 2^20 slots (whole sub-batches per launch, the table grown for the rate learnt on the
+    wall): blocks of the map kernel that start while the overflow list is beyond its high-water mark add nothing, log themselves and are run again after the table
+    has grown -- no SSM_E_CAPACITY, and the table equals the one of a context that starts with 2^25 slots, byte for byte.  The third context's list is cut down to the
+    minimum (test hook), so that the skip / redo path certainly runs; also with the map stage on the chains' own streams (SSM_MAP_STREAM=0)."""
+    import semantic_slam_mapping_amd as ssm
+    N, NW = 40, 20
+    big = ssm.Context(0, orb_features=500, max_batch=20, voxel_capacity_log2=25, mapper_resolution=0.004, camera=CAM)
+    bufs = _wall_then_stream(big, NW, N)
+    try:
+        big.seq_process(*bufs, N, stages=ssm.api.STAGE_MAP); big.sync()
+        ref = big.map_export_table()
+        per_frame_wall, per_frame_all = None, len(ref) / N
+        for log2, hook in ((10, None), (20, None), (20, "1"), (20, "map_stream0")):
+            if hook == "1":
+                monkeypatch.setenv("SSM_MAP_TEST_SMALL_LIST", "1")
+            if hook == "map_stream0":
+                monkeypatch.setenv("SSM_MAP_STREAM", "0")
+            c = ssm.Context(0, orb_features=500, max_batch=20, voxel_capacity_log2=log2, mapper_resolution=0.004, camera=CAM)
+            try:
+                stages = ssm.api.STAGE_MAP if hook != "map_stream0" else 0           # (all stages: the two-chain mode whose map stage alternates between streams)
+                c.seq_process(*bufs, NW, stages=stages); c.sync()
+                if per_frame_wall is None:
+                    per_frame_wall = c.map_size() / NW
+                    assert per_frame_all > 5 * per_frame_wall                       # the rate does jump
+                off = (640 * 480 * 3, 640 * 480 * 2, 640 * 480 * 3, 128)
+                c.seq_process(*[b + NW * o for b, o in zip(bufs, off)], N - NW, continue_sequence=True, stages=stages); c.sync()
+                assert c.map_export_table().tobytes() == ref.tobytes(), (log2, hook)
+                st = c.map_stats()
+                assert st[1] >= 1                                                    # it grew
+                if hook == "1":
+                    assert st[2] > 0, st                                             # and blocks were run again
+            finally:
+                c.close()
+                monkeypatch.delenv("SSM_MAP_TEST_SMALL_LIST", raising=False); monkeypatch.delenv("SSM_MAP_STREAM", raising=False)
+    finally:
+        for p in bufs:
+            big.dev_free(p)
+        big.close()
+
+
+def test_map_more_than_half_full_at_its_size_limit_stays_readable():
+    """voxel_max_capacity_log2 bounds the table; a COMPLETE map that is more than half full at that bound has lost nothing and must stay readable
+    (size, export, sync) -- only something that cannot be placed is refused"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=10, voxel_max_capacity_log2=10, camera=CAM)
+    try:
+        rng = np.random.default_rng(3)
+        pts = np.zeros(600, ssm.POINT_DTYPE)
+        pts["x"] = rng.uniform(-40, 40, len(pts)); pts["y"] = rng.uniform(-30, 30, len(pts)); pts["z"] = rng.uniform(0, 50, len(pts)); pts["w"] = 1.0
+        c.map_clear()
+        for a in range(0, 600, 100):          # 100 points at a time: each insert announces 100 new voxels, which 1024 slots take until the table is more than half full
+            try:
+                c.map_insert(pts[a:a + 100])
+            except ssm.SsmError as e:
+                assert e.code == -4
+                break
+        n = c.map_size()
+        assert 256 < n <= 600
+        c.sync()
+        assert len(c.map_export()) == n and len(c.map_export_table()) == n
+        # fill it beyond a half through the table merge of a map that fits (reserve = its size), then read again
+        d = ssm.Context(0, orb_features=500, max_batch=1, voxel_capacity_log2=12, camera=CAM)
+        try:
+            d.map_insert(pts); tab = d.map_export_table()
+        finally:
+            d.close()
+        assert len(tab) > 512
+        with pytest.raises(ssm.SsmError) as e:
+            c.map_merge_table(tab)                                                   # cannot be placed: refused before anything is added
+        assert e.value.code == -4
+        assert c.map_size() == n and len(c.map_export_table()) == n                  # ... and the map stays what it was, readable
+    finally:
+        c.close()
+
+
 # ---------------------------------------------------------------- bench.py contract (and its all-gather path on one GPU)
 def test_bench_line_and_allgather_path():
     import json, os, subprocess, sys
@@ -730,14 +816,13 @@ def test_sequence_with_sparse_and_empty_frames(oracle):
 
 
 def test_valu_variants_of_matcher_and_blur(oracle, frames, monkeypatch):
-    """The matcher, the blur and the map fusion have two implementations each: the default (matrix cores; compacting map kernel) and the earlier one
-    (SSM_MATCH_VARIANT=0 / SSM_BLUR_VARIANT=0 / SSM_MAP_VARIANT=0, read when a context is created).  The rest of this file runs the defaults; this runs
+    """The matcher and the blur have two implementations each: the default (matrix cores) and the earlier one
+    (SSM_MATCH_VARIANT=0 / SSM_BLUR_VARIANT=0, read when a context is created).  The rest of this file runs the defaults; this runs
     the earlier kernels through the same checks: host matcher API, ORB of one frame (the descriptors depend on the blur), and a short sequence (match
     tables, point counts and the fused map) against the oracle."""
     import semantic_slam_mapping_amd as ssm
     monkeypatch.setenv("SSM_MATCH_VARIANT", "0")
     monkeypatch.setenv("SSM_BLUR_VARIANT", "0")
-    monkeypatch.setenv("SSM_MAP_VARIANT", "0")          # map_stream_kernel instead of the compacting map_stream2_kernel
     c = ssm.Context(0, orb_features=1000, max_batch=4, voxel_capacity_log2=18, camera=CAM)
     try:
         rng = np.random.default_rng(77)
