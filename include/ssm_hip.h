@@ -353,8 +353,8 @@ typedef struct {              /* DEVICE pointers owned by the context, valid unt
     int max_corners;
 } ssm_stereo_out_dev;
 int ssm_stereo_seq_process(ssm_ctx* ctx, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out);
-/* frame pairs per launch of the stereo path: min(config max_batch, 128), or the environment variable SSM_STEREO_BATCH (0.45 GB of SGBM workspace per pair, two
-   workspaces; 128 per launch measured 1 % above 64 at 1241 x 376 x 80) */
+/* frame pairs per launch of the stereo path: min(config max_batch, 128), or the environment variable SSM_STEREO_BATCH (0.23 GB of SGBM workspace per pair in the default
+   formulation -- three cost-volume-sized buffers at 1241 x 376 x 80 --, two workspaces; 128 per launch measured 1 % above 64) */
 int ssm_stereo_batch(const ssm_ctx* ctx);
 
 /* ---- Classifier (include/segnet.h:22-46, src/segnet.cpp): SegNet driving_webdemo forward, fp16 MFMA, on the device.

@@ -1932,22 +1932,40 @@ bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out)
     }
     return false;
 }
-// workspace for nb frames per launch
-size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb)
+// workspace for nb frames per launch.  Cost-volume-sized buffers by formulation: form 2 (default) C + S04 + checkpoints = 3, form 1 C + four path volumes = 5, the
+// round-3 form C + five = 6 (round 6: sized by the CONFIGURED form -- it was always six, 0.45 GB per pair and 115 GB for the bench's two workspaces of 128 pairs;
+// a sub-batch that has to be repeated in form 1 runs in pieces that fit, see k_sgbm).  Never less than one frame in the largest form.
+static int sgbm_form_volumes(int form) { return form == 2 ? 3 : form == 1 ? 5 : 6; }
+static size_t sgbm_ws_bytes(int w, int h, const ssm_sgbm_params& p, int nb, int nvol)
 {
     const int maxD = p.minDisparity + p.numberOfDisparities, minX1 = maxD > 0 ? maxD : 0, maxX1 = w + (p.minDisparity < 0 ? p.minDisparity : 0);
     const size_t w1 = maxX1 > minX1 ? (size_t)(maxX1 - minX1) : 0, vol = w1 * h * p.numberOfDisparities * nb, np = (size_t)w * h * nb;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return al(32 * np) + 6 * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256 + al(256 + (size_t)nb * sgbm_mbox_bytes_per_frame((int)w1, p.numberOfDisparities));
+    return al(32 * np) + (size_t)nvol * al(vol * 2) + 2 * al(np * 2) + 3 * al(np * 4) + 256 + al(256 + (size_t)nb * sgbm_mbox_bytes_per_frame((int)w1, p.numberOfDisparities));
+}
+static int sgbm_resolve_form(int form_cfg) { return form_cfg == 0 ? sgbm_form() : form_cfg == 3 ? 0 : form_cfg == 1 ? 1 : 2; }
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb, int form_cfg)
+{
+    const size_t a = sgbm_ws_bytes(w, h, p, nb, sgbm_form_volumes(sgbm_resolve_form(form_cfg))), b = sgbm_ws_bytes(w, h, p, 1, 6);
+    return a > b ? a : b;
 }
 // left / right: device u8 images [nb][h][w]; disp_out: device int16 [nb][h][w] (x16 fixed point, (minD-1)*16 = invalid)
 // form: 0 = the process default (2 unless SSM_SGBM_FORM says otherwise), 1 / 2 / 3 = ssm_config.sgbm_form (3: the five-volume form, SSM_SGBM_FORM=0); concurrent: launches
 // of this function that may be in flight on other streams at the same time (the occupancy check of form 2)
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag,
+// ws_bytes: what `workspace` holds.  A formulation whose volumes for nb frames do not fit (form 1 as the repeat of a timed-out form-2 sub-batch in a workspace
+// sized for form 2) runs in pieces of frames that do, one after the other on the same stream.
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, size_t ws_bytes, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag,
                   int form_cfg, int concurrent)
 {
-    int form = form_cfg == 0 ? sgbm_form() : form_cfg == 3 ? 0 : form_cfg == 1 ? 1 : 2;
+    int form = sgbm_resolve_form(form_cfg);
     if (nb <= 0) return hipSuccess;
+    if (sgbm_ws_bytes(w, h, p, nb, sgbm_form_volumes(form)) > ws_bytes) {
+        if (nb == 1) return hipErrorOutOfMemory;
+        const int half = (nb + 1) / 2; const size_t np1_ = (size_t)w * h;
+        hipError_t e1 = k_sgbm(left, right, w, h, half, p, workspace, ws_bytes, disp_out, raw_only, s, fail_flag, form_cfg, concurrent);
+        if (e1 != hipSuccess) return e1;
+        return k_sgbm(left + (size_t)half * np1_, right + (size_t)half * np1_, w, h, nb - half, p, workspace, ws_bytes, disp_out + (size_t)half * np1_, raw_only, s, fail_flag, form_cfg, concurrent);
+    }
     const int minD = p.minDisparity, D = p.numberOfDisparities, maxD = minD + D;
     const int SW = p.SADWindowSize > 0 ? p.SADWindowSize : 5, SW2 = SW / 2;
     const int ftzero = (p.preFilterCap > 15 ? p.preFilterCap : 15) | 1;
@@ -1964,8 +1982,10 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
     uint3* planes = (uint3*)q; q += al(32 * np);                 // (12 bytes per pixel and image are used)
     const size_t vol = (size_t)w1 * h * D * nb;
     uint16_t* C = (uint16_t*)q; q += al(vol * 2);
-    uint16_t* Lv[5];
-    for (int i = 0; i < 5; i++) { Lv[i] = (uint16_t*)q; q += al(vol * 2); }
+    uint16_t* Lv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // (the layout sgbm_ws_bytes sizes: C + the form's volumes.  Form 2: S04 and the checkpoints in Lv[0], Lv[1]; form 1: the four path volumes 0, 1, 3, 4 -- the column
+    // direction lives inside sgbm_col_wta --; the round-3 form: all five)
+    for (int i = 0; i < 5; i++) { if (form == 2 ? i < 2 : form == 1 ? i != 2 : true) { Lv[i] = (uint16_t*)q; q += al(vol * 2); } }
     int16_t* d_raw = (int16_t*)q; q += al(np * 2);
     int16_t* d_tmp = (int16_t*)q; q += al(np * 2);
     unsigned* d2key = (unsigned*)q; q += al(np * 4);
@@ -2009,7 +2029,9 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
 #undef SG_AGG2
             default: return hipErrorInvalidValue;
         }
-        if (e == hipErrorCooperativeLaunchTooLarge) { form = 1; e = hipSuccess; }      // the sweep's strips cannot all be resident: the form without cross-block waits (nothing was launched)
+        if (e == hipErrorCooperativeLaunchTooLarge) {       // the sweep's strips cannot all be resident: the form without cross-block waits (nothing was launched; the cost volume is recomputed)
+            return k_sgbm(left, right, w, h, nb, p, workspace, ws_bytes, disp_out, raw_only, s, fail_flag, 1, concurrent);
+        }
     }
     if (form != 2) switch (D / 16) {
 #define SG_AGG1(KK) case KK: e = sgbm_aggregate<KK>(C, Lv, w, w1, h, nb, p, minX1, P1, P2, d_tmp, d2key, wta_out, form, s); break;

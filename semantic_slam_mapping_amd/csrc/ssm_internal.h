@@ -130,10 +130,10 @@ void k_sgbm_release_stream(hipStream_t s);
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                          int CinPad, int Cout, int relu, hipStream_t s);
 // nb frames per launch: left / right [nb][h][w], disp_out [nb][h][w]
-size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb);
+size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb, int form_cfg);      // sized for the configured formulation (0 = the default), never less than one frame in the largest
 bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out);      // false: SADWindowSize too wide for the streaming cost kernel
 // fail_flag: device int the sweep kernel ORs 1 into when a strip hand-off times out (never on a healthy device; the host turns it into SSM_E_HIP)
-hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag = nullptr,
+hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int nb, const ssm_sgbm_params& p, void* workspace, size_t ws_bytes, int16_t* disp_out, int raw_only, hipStream_t s, int* fail_flag = nullptr,
                   int form_cfg = 0, int concurrent = 1);
 hipError_t k_sgbm_depth(const int16_t* disp, int w, int h, int nb, double baseline, double cu, double cv, double f, double roix, double roiy, double roiz, double scale,
                         int* min_scratch /* nb ints */, uint16_t* depth, hipStream_t s);

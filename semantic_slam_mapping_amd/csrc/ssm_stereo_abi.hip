@@ -71,7 +71,7 @@ static int stereo_ensure_vo(ssm_ctx* c, int iters)
 static int stereo_ensure_sgbm(ssm_ctx* c, const ssm_sgbm_params& p, int nb, int which = 0)
 {
     StereoState* q = c->stereo;
-    const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb);
+    const size_t need = k_sgbm_workspace_bytes(q->w, q->h, p, nb, c->sgbm_form_cfg);
     void*& ws = q->sg_wsN[which]; size_t& have = q->sg_ws_bytesN[which];
     if (!q->dminN[which]) DALLOC(c, q->dminN[which], 128);
     if (need <= have) return SSM_OK;
@@ -157,7 +157,7 @@ static int stereo_seq_run(ssm_ctx* c, const ssm_stereo_frames_dev* in, ssm_stere
             hipStream_t sg = sgs[alt];
             struct StreamSet { ssm_ctx* c; hipStream_t keep; StreamSet(ssm_ctx* c_, hipStream_t s_) : c(c_), keep(c_->stream) { c->stream = s_; } ~StreamSet() { c->stream = keep; } } on(c, sg);   // stage events on SGBM's stream
             prof_begin(c, "sgbm");
-            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail + (f0 / B) % SG_FAIL_WORDS,
+            HIPCHK(c, k_sgbm(in->left + (size_t)f0 * np, in->right + (size_t)f0 * np, w, h, nb, in->sgbm, q->sg_wsN[alt], q->sg_ws_bytesN[alt], q->disp + (size_t)f0 * np, 0, sg, q->sg_fail + (f0 / B) % SG_FAIL_WORDS,
                              c->sgbm_form_cfg, nsg));
             HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in->baseline, in->cu, in->cv, in->f, in->roix, in->roiy, in->roiz, in->scale, q->dminN[alt], q->depth + (size_t)f0 * np, sg));
             prof_end(c);
@@ -315,7 +315,7 @@ static int sgbm_run(ssm_ctx* c, const uint8_t* left, const uint8_t* right, int w
     r = stereo_stage_images(c, imgs, 2, w, h, stride, &dev); if (r) return r;
     if (c->profiling) { c->recs.clear(); c->pool_used = 0; }      // ssm_get_stage_times then reports this call ("sgbm": all kernels of k_sgbm)
     prof_begin(c, "sgbm");
-    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->disp, stage, c->stream, q->sg_fail, form, 1));
+    HIPCHK(c, k_sgbm(dev, dev + (size_t)w * h, w, h, 1, *params, q->sg_wsN[0], q->sg_ws_bytesN[0], q->disp, stage, c->stream, q->sg_fail, form, 1));
     prof_end(c);
     q->sg_pending.valid = false;                                  // (the staged pair is this call's: the host-pointer entry points repeat a timed-out sweep themselves)
     *d_disp_out = q->disp; *d_depth_out = q->depth;
@@ -339,7 +339,7 @@ int sgbm_recover(ssm_ctx* c)
     for (int f0 = 0, bi = 0; f0 < in.n; f0 += B, bi++) {
         if (!sf[bi % SG_FAIL_WORDS]) continue;
         const int nb = in.n - f0 < B ? in.n - f0 : B;
-        HIPCHK(c, k_sgbm(in.left + (size_t)f0 * np, in.right + (size_t)f0 * np, w, h, nb, in.sgbm, q->sg_wsN[0], q->disp + (size_t)f0 * np, 0, c->stream, q->sg_fail + bi % SG_FAIL_WORDS, 1, 1));
+        HIPCHK(c, k_sgbm(in.left + (size_t)f0 * np, in.right + (size_t)f0 * np, w, h, nb, in.sgbm, q->sg_wsN[0], q->sg_ws_bytesN[0], q->disp + (size_t)f0 * np, 0, c->stream, q->sg_fail + bi % SG_FAIL_WORDS, 1, 1));
         HIPCHK(c, k_sgbm_depth(q->disp + (size_t)f0 * np, w, h, nb, in.baseline, in.cu, in.cv, in.f, in.roix, in.roiy, in.roiz, in.scale, q->dminN[0], q->depth + (size_t)f0 * np, c->stream));
         redone++;
     }

@@ -3,6 +3,8 @@ quad matcher of frame f against f - 1 (/root/reference/src/track.cpp:45-59, src/
 (src/stereo.cpp:11-30, src/rgbdframe.cpp:81-116), stereo VO on the quad matches with the host class's rand() stream
 (src/vo_stereo.cpp:47-152, src/vo.cpp:74-93).  Every output must equal, byte for byte, the CPU oracle run frame by frame the way the
 reference walks the sequence, and the per-pair entry points (which run the same kernels with one frame)."""
+import os
+import sys
 import numpy as np
 import pytest
 from conftest import SEED
@@ -184,3 +186,47 @@ def test_sweep_strip_handoffs_soak():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "sgbm_soak.py"), "4", "128"], capture_output=True, text=True, timeout=900)
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0 and r.stdout.count("4 rounds identical to the four-volume form") == 2
+
+
+def test_stereo_and_segnet_contexts_fit_side_by_side_at_bench_sizes():
+    """the SGBM workspace is sized by the configured formulation (three cost-volume-sized buffers for the default form 2, not six): at the bench's
+    128 pairs per launch of 1241 x 376 x 80 the two workspaces take <= 60 GB (they were 115 GB), so a stereo context and a SegNet-loaded RGB-D context of bench size
+    live on one device side by side"""
+    import torch
+    import semantic_slam_mapping_amd as ssm
+    from semantic_slam_mapping_amd import segnet_model
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import stereo_sequence, KITTI
+    from semantic_slam_mapping_amd.api import GlibcRand
+    Wd, Hd, F, ITERS = 1241, 376, 256, 200
+    free0 = torch.cuda.mem_get_info(0)[0]
+    st = ssm.Context(0, width=640, height=480, max_batch=128)
+    sg = None
+    try:
+        L, R = stereo_sequence(F, Wd, Hd, 100)
+        dl = st.dev_alloc(L.nbytes); dr = st.dev_alloc(R.nbytes); ds = st.dev_alloc(F * ITERS * 3 * 4)
+        st.h2d(dl, L); st.h2d(dr, R); st.h2d(ds, GlibcRand(0).draws(F * ITERS * 3))
+        vo = (KITTI["f"], KITTI["cu"], KITTI["cv"], KITTI["baseline"], 2.0, True)
+        out = st.stereo_seq_process(dl, dr, F, Wd, Hd, vo=vo, ransac_iters=ITERS, rand_stream_dev=ds, **KITTI); st.sync()
+        used_stereo = free0 - torch.cuda.mem_get_info(0)[0]
+        print("stereo context at 128 pairs per launch: %.1f GB" % (used_stereo / 1e9))
+        # two SGBM workspaces of 128 pairs: 2 x 128 x (3 x 69.8 MB of volumes + 18 MB) = 58.4 GB; + the quad matcher's pyramids, the sequence outputs and inputs of 256 frames
+        assert used_stereo < 70e9, used_stereo                      # (round 5: 115 GB for the workspaces alone)
+        sg = ssm.Context(0, orb_features=1000, max_batch=128, voxel_capacity_log2=22, camera=(318.6, 255.3, 517.3, 516.5, 1000.0))
+        for l, (wt, sc, sh) in enumerate(segnet_model.make_weights(1234)):
+            sg.segnet_set_layer(l, wt, sc, sh)
+        n = 128
+        bufs = [sg.dev_alloc(n * 640 * 480 * 3), sg.dev_alloc(n * 640 * 480 * 2), sg.dev_alloc(n * 640 * 480 * 3), sg.dev_alloc(n * 128)]
+        sg.synth_frames_dev(0x5EED0000, 0, n, *bufs)
+        sg.seq_process(bufs[0], bufs[1], None, bufs[3], n, stages=ssm.api.STAGE_MAP | ssm.api.STAGE_SEGNET); sg.sync()
+        assert sg.map_size() > 1000
+        res = st.stereo_seq_fetch(out, F, Wd, Hd, 1 | 4)
+        assert float(res["vo_result"][1:, 1].mean()) > 0.9
+        for p in bufs:
+            sg.dev_free(p)
+        for p in (dl, dr, ds):
+            st.dev_free(p)
+    finally:
+        if sg is not None:
+            sg.close()
+        st.close()
