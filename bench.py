@@ -329,7 +329,7 @@ def parse_args(argv=None):
     ap.add_argument("--segnet", action="store_true", help="configs[2]: labels from the on-GPU SegNet (fp16 MFMA) instead of precomputed masks")
     ap.add_argument("--serial-only", action="store_true", help="profiling aid: run ONLY serialised steps (every stage on one stream, no PCIe pass), so that a "
                     "rocprofv3 --stats run of this command has the same per-kernel average as roofline's launch duration; `value` is then the serialised rate")
-    ap.add_argument("--stereo-batch", type=int, default=int(os.environ.get("SSM_STEREO_BATCH", "128")), help="configs[3]: frame pairs per launch of the batched stereo path (0.23 GB of SGBM workspace each, two workspaces; "
+    ap.add_argument("--stereo-batch", type=int, default=128, help="configs[3]: frame pairs per launch of the batched stereo path (0.23 GB of SGBM workspace each, two workspaces; "
                     "round 5: 128 instead of 64 -- the sweep's strips of more frames in flight overlap better: 4.93 k -> 5.18 k pairs/s)")
     ap.add_argument("--solve-poses", action="store_true", help="also time the closed pose loop: ORB + match tables -> ssm_tracker_run (Tracker::updateFrame for every frame: "
                     "the serial PnP chain) -> the solved poses into the map stage; reported as `solve_poses` beside `value` (whose poses are the stream's)")

@@ -353,7 +353,7 @@ typedef struct {              /* DEVICE pointers owned by the context, valid unt
     int max_corners;
 } ssm_stereo_out_dev;
 int ssm_stereo_seq_process(ssm_ctx* ctx, const ssm_stereo_frames_dev* in, ssm_stereo_out_dev* out);
-/* frame pairs per launch of the stereo path: min(config max_batch, 128), or the environment variable SSM_STEREO_BATCH (0.23 GB of SGBM workspace per pair in the default
+/* frame pairs per launch of the stereo path: ssm_config.stereo_batch, else min(config max_batch, 128) (0.23 GB of SGBM workspace per pair in the default
    formulation -- three cost-volume-sized buffers at 1241 x 376 x 80 --, two workspaces; 128 per launch measured 1 % above 64) */
 int ssm_stereo_batch(const ssm_ctx* ctx);
 
@@ -395,6 +395,7 @@ int ssm_get_stage_times(ssm_ctx* ctx, const char** names, float* ms, int* launch
 /* ---- utilities (device memory without torch; synthetic stream generator for bench/tests) */
 int ssm_dev_alloc(ssm_ctx* ctx, size_t bytes, void** out);
 int ssm_dev_free(ssm_ctx* ctx, void* p);
+int ssm_dev_mem_info(ssm_ctx* ctx, size_t* free_bytes, size_t* total_bytes);      /* hipMemGetInfo on the context's device */
 int ssm_memcpy_h2d(ssm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int ssm_memcpy_d2h(ssm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 /* the same upload, enqueued on the context stream without waiting: src_host must stay valid and unchanged until the next ssm_sync / synchronous call of the context

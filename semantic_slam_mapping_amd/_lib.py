@@ -134,6 +134,7 @@ SYMBOLS = {
     "ssm_get_stage_times": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I)]),
     "ssm_dev_alloc": (_I, [_P, _SZ, C.POINTER(_P)]),
     "ssm_dev_free": (_I, [_P, _P]),
+    "ssm_dev_mem_info": (_I, [_P, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "ssm_memcpy_h2d": (_I, [_P, _P, _P, _SZ]),
     "ssm_memcpy_d2h": (_I, [_P, _P, _P, _SZ]),
     "ssm_memcpy_h2d_async": (_I, [_P, _P, _P, _SZ]),

@@ -573,6 +573,12 @@ class Context:
     def dev_free(self, p):
         self._chk(self.lib.ssm_dev_free(self.h, p))
 
+    def mem_info(self):
+        """(free, total) bytes of the context's device"""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.lib.ssm_dev_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         self._chk(self.lib.ssm_memcpy_h2d(self.h, dptr, _ptr(arr), arr.nbytes))

@@ -172,8 +172,8 @@ __device__ __forceinline__ void conv_epilogue(const floatx16 (&acc)[2][2], const
     }
 }
 
-// ------------------------------------------------------------------ conv3x3, LDS-DMA staged (the kernel the network runs on)
-// Same implicit GEMM and the same LDS images as above, but
+// ------------------------------------------------------------------ conv3x3, LDS-DMA staged: the scheme of the kernel the network runs on (conv3x3_dma2_kernel)
+// The implicit GEMM and LDS images described above, with
 //   * one 512-thread block (8 waves) per CU owns a 32 x 16 pixel tile x 64 output channels, so a staged weight slab is
 //     shared by twice the pixels (L2 -> LDS bytes per flop -35 %);
 //   * operands go global -> LDS by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write pass): the LDS image
@@ -201,179 +201,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // activation is never written.
 // EPI 2 (with NT = 1: one 32-channel output tile, half the weight staging and MFMAs): the class ArgMax of the last layer --
 // out is the uint8 label image [n][H][W]; the logits are never written.
-template <bool RELU, int EPI, int NT>
-__global__ void __launch_bounds__(512, 1)
-conv3x3_dma_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
-                   _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
-                   unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
-{
-    // two stage buffers, as two objects: the compiler then knows that the DMA into one never aliases the fragment reads of
-    // the other (with one array and a run-time index it drains vmcnt before every ds_read)
-    __shared__ __attribute__((aligned(16))) half8 lds0[DT_STAGE];
-    __shared__ __attribute__((aligned(16))) half8 lds1[DT_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    const int VH = (H + 2) & ~1, VR = n * VH;                                      // the launcher keeps VR < 65536
-    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;                   // floor(v / VH) = umulhi(v, magic) for v < 2^16
-    const int nchunks = Cin / CT_KC;
-    const unsigned plane_bytes = (unsigned)H * W * 64u;                            // one 32-channel chunk of one frame
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
-    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
-    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
-    constexpr int BROW = 32 * NT;                                                  // output channels per staged weight row
-    constexpr int BINS = 9 * 4 * BROW / 64;                                        // weight wave-instructions per stage: 36 or 18
-    constexpr int BK = (BINS + 7) / 8;                                             // per wave: 5 or 3
-    constexpr int NSTORE = EPI == 2 ? 2 : 8;                                       // store instructions per tile epilogue
-    // folded BN scale / shift of the block's 64 output channels (a persistent block keeps its cout tile), zero for padding
-    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
-    if (tid < 2 * CT_N) {
-        const int ch = (blockIdx.x % ncout_tiles) * CT_N + (tid & (CT_N - 1));
-        s_ss[tid >> 6][tid & (CT_N - 1)] = ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
-    }
-    // per-thread DMA slots: wave-instruction j = wv + 8k fills LDS chunks 64j..64j+63 of a stage.  Within a tile only the
-    // scalar offset moves from stage to stage; the per-lane input offsets are recomputed when the pipeline crosses into the
-    // block's next tile.
-    unsigned a_off[5], b_off[5]; int b_j[5];
-    int a_py[5], a_px[5]; unsigned a_c8[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int i = (wv + 8 * k) * 64 + lane;
-        const int c8 = i / DT_PLANE, p = i - c8 * DT_PLANE;
-        a_py[k] = i < DT_ACH ? p / DT_PW : -0x10000;                                // padding slots never become valid
-        a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
-        b_j[k] = min(wv + 8 * k, BINS - 1);                                        // surplus slots repeat the last instruction (same bytes, same place)
-        // the packed weights have 64-channel rows; with NT = 1 a wave-instruction takes the first 32 channels of two rows
-        b_off[k] = NT == 2 ? (unsigned)(b_j[k] * 64 + lane) * 16u : (unsigned)((2 * b_j[k] + (lane >> 5)) * 64 + (lane & 31)) * 16u;
-    }
-#define DT_TILE_OFFSETS(tile)                                                                           \
-    {   const int pt_ = (tile) / ncout_tiles;                                                           \
-        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
-        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
-            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
-            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;   /* exact for 0 <= v < 65536 */ \
-            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
-            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u;   /* out of range -> zeros */ \
-        } }
-#define DT_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 8 * (k)) * 64], 16, a_off[k], so, 0, 0);
-#define DT_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[DT_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
-    int tile = blockIdx.x;
-    DT_TILE_OFFSETS(tile)
-    {
-        const unsigned bso = (unsigned)(tile % ncout_tiles) * nchunks * (DT_BCH * 16u);
-#pragma unroll
-        for (int k = 0; k < 5; k++) { DT_DMA_A(k, lds0, 0u) if (k < BK) DT_DMA_B(k, lds0, bso) }
-        // NSTORE out-of-range (dropped) stores, so that "a tile's first DMA batch is followed by exactly NSTORE stores" also holds
-        // for the first tile: the wait at the top of every tile is then the same vmcnt(NSTORE) on every path
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-        const uint4v z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);
-    }
-    // nchunks is even (the launcher sends the 32-channel first layer elsewhere), so every tile starts in lds0 and the two
-    // stage bodies below use compile-time buffers
-    for (; tile < total_tiles; tile += gridDim.x) {
-        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
-        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;      // ty0 is a row of the stacked virtual image
-        floatx16 acc[2][NT];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < NT; b++)
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[a][b][k] = 0.f;
-        // one stage: 18 steps of 4 MFMAs on buffer `rd`, with the next stage's 10 DMA instructions (into `wr`) and the next
-        // step's fragment reads issued ahead of each step's MFMAs.  Past the block's last stage every DMA lane is out of
-        // range: a zero fill of the idle buffer, which keeps the stage body one basic block.
-#define DT_LOADF(rd, fbuf, st)                                                                          \
-        {   const int tap_ = (st) >> 1, c8_ = ((st) & 1) * 2 + hh, dy_ = tap_ / 3, dx_ = tap_ - dy_ * 3;      \
-            const half8* pa_ = rd + c8_ * DT_PLANE + (2 * wv + dy_) * DT_PW + r + dx_;                        \
-            const half8* pb_ = rd + DT_AINS * 64 + (tap_ * 4 + c8_) * BROW + r;                               \
-            fa[fbuf][0] = pa_[0]; fa[fbuf][1] = pa_[DT_PW]; fb[fbuf][0] = pb_[0]; if (NT == 2) fb[fbuf][1] = pb_[32]; }
-#define DT_STAGE_BODY(rd, wr)                                                                           \
-        {   half8 fa[2][2], fb[2][NT];                                                                  \
-            DT_LOADF(rd, 0, 0)                                                                          \
-            _Pragma("unroll") for (int st = 0; st < 18; st++) {                                         \
-                const int cur = st & 1;                                                                 \
-                if (st < 5) DT_DMA_A(st, wr, a_so)                                                      \
-                else if (st < 5 + BK) DT_DMA_B(st - 5, wr, b_so)                                        \
-                if (st + 1 < 18) DT_LOADF(rd, cur ^ 1, st + 1)                                          \
-                __builtin_amdgcn_sched_barrier(0);   /* reads of step st+1 stay ahead of the MFMAs of step st */ \
-                /* D[cout][pixel] += W[cout][k] X[k][pixel]: weights are the row operand */             \
-                _Pragma("unroll") for (int tm_ = 0; tm_ < 2; tm_++) _Pragma("unroll") for (int tn_ = 0; tn_ < NT; tn_++) \
-                    acc[tm_][tn_] = CT_MFMA(fb[cur][tn_], fa[cur][tm_], acc[tm_][tn_]); \
-                __builtin_amdgcn_sched_barrier(0);                                                      \
-            } }
-        for (int ck = 0; ck < nchunks; ck += 2) {
-            // this wave's share of the stage has landed (the DMA is older than the previous tile's epilogue stores, which may
-            // stay in flight: vmcnt retires in order); after the barrier everybody's has, and the previous stage is consumed
-            if (ck == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NSTORE);            // vmcnt(NSTORE): exactly that many stores per epilogue, all younger than the DMA
-            else __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
-            __builtin_amdgcn_s_barrier();
-            unsigned a_so = (unsigned)(ck + 1) * plane_bytes, b_so = ((unsigned)ct * nchunks + ck + 1) * (DT_BCH * 16u);
-            DT_STAGE_BODY(lds0, lds1)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __builtin_amdgcn_s_barrier();
-            // the stage after this one: the next 32 input channels of this tile, or the first 32 of the block's next tile
-            if (ck + 2 < nchunks) {
-                a_so = (unsigned)(ck + 2) * plane_bytes;
-                b_so = ((unsigned)ct * nchunks + ck + 2) * (DT_BCH * 16u);
-            } else {
-                const int nt = tile + gridDim.x;
-                DT_TILE_OFFSETS(nt)
-                a_so = 0u;
-                b_so = nt < total_tiles ? (unsigned)(nt % ncout_tiles) * nchunks * (DT_BCH * 16u) : 0x80000000u;
-            }
-            DT_STAGE_BODY(lds1, lds0)
-        }
-#undef DT_STAGE_BODY
-#undef DT_LOADF
-        // epilogue (conv_epilogue): this wave's two rows, 64 channels
-        const int cout_chunks = (Cout + 31) >> 5;
-        const int gx = tx0 + r;
-        const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
-        const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
-        const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
-        if constexpr (EPI == 2) {
-            // ArgMax over the classes (channels < Cout <= 12) of the fp16-rounded logits, first maximum wins (argmax_kernel's
-            // contract).  acc[tm][0][4g+q] is class 8g + 4hh + q: the lower half-wave owns classes 0-3 and 8-11, the upper 4-7.
-#pragma unroll
-            for (int tm = 0; tm < 2; tm++) {
-                _Float16 bv[2]; int bi[2];                                        // [g]: best of the lane's quad g
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const int c0 = 8 * g + 4 * hh;
-                    const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][c0]), sf = *reinterpret_cast<const float4*>(&s_ss[1][c0]);
-                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
-                    bv[g] = (_Float16)-65504.f; bi[g] = 255;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float val = __builtin_fmaf(acc[tm][0][4 * g + q], scv[q], sfv[q]);
-                        if (RELU) val = fmaxf(val, 0.f);
-                        const _Float16 hvq = (_Float16)val;
-                        if (c0 + q < Cout && (bi[g] == 255 || hvq > bv[g])) { bv[g] = hvq; bi[g] = c0 + q; }
-                    }
-                }
-                // the upper half's classes 4-7 travel to the lower half as (value bits << 8 | index)
-                unsigned short vb; memcpy(&vb, &bv[0], 2);
-                const unsigned mine = ((unsigned)vb << 8) | (unsigned)bi[0];
-                const unsigned theirs = __builtin_amdgcn_permlane32_swap(mine, mine, false, false)[1];     // lower lanes: the upper half's word
-                unsigned short tb = (unsigned short)(theirs >> 8); _Float16 tv; memcpy(&tv, &tb, 2);
-                const int ti = (int)(theirs & 255u);
-                _Float16 best = bv[0]; int lab = bi[0];                           // classes 0-3
-                if (ti != 255 && tv > best) { best = tv; lab = ti; }              // then 4-7
-                if (bi[1] != 255 && bv[1] > best) { best = bv[1]; lab = bi[1]; }  // then 8-11
-                const bool live = (tm ? live1 : live0) && hh == 0;
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lab, rsO, live ? (unsigned)((f * H + y0 + tm) * W + gx) : 0x80000000u, 0, 0);
-            }
-        } else
-            conv_epilogue<RELU, EPI>(acc, s_ss, rsO, rsC, f, y0, gx, live0, live1, ct * (CT_N / 32), cout_chunks, H, W, r, hh);
-    }
-#undef DT_DMA_A
-#undef DT_DMA_B
-#undef DT_TILE_OFFSETS
-}
-
+// (conv3x3_dma_kernel, the one-block-of-eight-waves form these notes were written for, was SSM_CONV_VARIANT=1 until round 6: 7 % slower than the two-block form below
+// on the network -- all eight waves reach the epilogue together and the MFMA pipe idles for its length --, profiles/r03_segnet_*.  The LDS images, the DMA scheme, the
+// stacked virtual image and the epilogue below are its.)
 // ------------------------------------------------------------------ conv3x3, LDS-DMA staged, TWO independent 4-wave blocks per CU
 // Same tile (32 x 16 pixels x 64 output channels), same LDS images, same DMA scheme and the same epilogue as
 // conv3x3_dma_kernel, but
@@ -607,7 +437,8 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
             const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
             const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
             if constexpr (EPI == 2) {
-                // class ArgMax, see conv3x3_dma_kernel
+                // ArgMax over the classes (channels < Cout <= 12) of the fp16-rounded logits, first maximum wins (argmax_kernel's contract).
+                // acc[..][0][4g+q] is class 8g + 4hh + q: the lower half-wave owns classes 0-3 and 8-11, the upper 4-7.
 #pragma unroll
                 for (int tm = 0; tm < 2; tm++) {
                     _Float16 bv[2]; int bi[2];
@@ -664,263 +495,10 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #undef D2_SLAB0
 }
 
-// ------------------------------------------------------------------ conv3x3 on v_mfma_f32_16x16x32_f16 (SSM_CONV_VARIANT=3; not the default)
-// On dense random operands the chip is power-limited and holds a markedly higher clock on the 16x16x32 MFMA shape than on
-// 32x32x16 at the same FLOPs per clock (the CT_ABL_MFMA16 build of scripts/ubench/conv_bench.hip: +18..21 % TFLOP/s), and this
-// kernel is 5 % faster than conv3x3_dma2_kernel there.  Inside the network (post-ReLU activations, half of them zero) the
-// chip is less power-limited, the shape buys nothing and the one-block-per-CU structure K = 32 forces costs 2 %: DESIGN.md 4.1.  K = 32 per MFMA = the four 8-channel planes of a 32-channel stage
-// (lane group g = lane / 16 supplies plane g), one MFMA step per tap.  Structure as conv3x3_dma_kernel: one persistent
-// 512-thread block per CU (a 32-channel stage is 76 KB, two buffers fill the LDS), 32 x 16 pixel tile x 16 MB output
-// channels, LDS-DMA staging with halo zeros from out-of-range offsets, one barrier per stage, pipeline across tiles.
-//   * a wave owns 2 rows: N blocks (row tm, half h) of 16 pixels, M blocks of 16 output channels: 4 MB MFMAs per tap;
-//   * taps are walked column (dx) major: the 4 halo rows x 2 halves a wave needs at one dx are read once for three taps;
-//   * plane pitch 624 chunks (a multiple of 16: the four lane groups of a ds_read_b128 then hit disjoint banks);
-//   * C/D: lane (g, p) holds channels 4g..4g+3 of pixel p of an M block; v_permlane16_swap between the M blocks of a pair
-//     gives every lane 8 consecutive channels, and one store instruction then writes 16 pixels x 64 contiguous bytes;
-//   * MB = 4: 64-channel tiles; MB = 2: 32-channel tiles where they balance the CUs better; MB = 1: the 12-class layer.
-#define K3_PP 624
-#define K3_AINS 40                            // input wave-instructions per stage (4 x 624 = 2496 of 2560 slots)
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-// store (EPI 0) or 2x2 max-pool + codes (EPI 1) of two rows x 8 consecutive channels per lane; byte = offset of those channels
-// inside the pixel's 64-byte chunk; even = the lane's pixel has an even x (its right neighbour is lane + 1, quad_perm)
-template <int EPI, typename RS>
-__device__ __forceinline__ void conv_emit(const uint4v (&vec)[2], const RS& rsO, const RS& rsC, int f, int y0, int gx, bool live0, bool live1,
-                                          int chunk, int cout_chunks, int H, int W, unsigned byte, bool even)
-{
-    if (EPI == 0) {
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            const bool live = tm ? live1 : live0;
-            const unsigned ob = live && chunk < cout_chunks ? (unsigned)((((f * cout_chunks + chunk) * H + y0 + tm) * W + gx) * 64) + byte : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(vec[tm], rsO, ob, 0, 0);
-        }
-    } else {
-        uint4v nb[2];
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-            nb[tm].x = __builtin_amdgcn_mov_dpp(vec[tm].x, 0xB1, 0xF, 0xF, true); nb[tm].y = __builtin_amdgcn_mov_dpp(vec[tm].y, 0xB1, 0xF, 0xF, true);
-            nb[tm].z = __builtin_amdgcn_mov_dpp(vec[tm].z, 0xB1, 0xF, 0xF, true); nb[tm].w = __builtin_amdgcn_mov_dpp(vec[tm].w, 0xB1, 0xF, 0xF, true);
-        }
-        const bool right = gx + 1 < W;
-        _Float16 best[8]; unsigned char bc[8];
-        _Float16 c01[8], c10[8], c11[8];
-        memcpy(best, &vec[0], 16); memcpy(c01, &nb[0], 16); memcpy(c10, &vec[1], 16); memcpy(c11, &nb[1], 16);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {                                             // pool2x2_kernel's contract: row-major scan, strict '>'
-            bc[k] = 0;
-            if (right && c01[k] > best[k]) { best[k] = c01[k]; bc[k] = 1; }
-            if (live1 && c10[k] > best[k]) { best[k] = c10[k]; bc[k] = 2; }
-            if (live1 && right && c11[k] > best[k]) { best[k] = c11[k]; bc[k] = 3; }
-        }
-        const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
-        const bool plive = live0 && even && chunk < cout_chunks;
-        const unsigned pidx = (unsigned)(((f * cout_chunks + chunk) * PH + (y0 >> 1)) * PW + (gx >> 1)) * 32u + (byte >> 1);   // elements
-        uint4v pv; memcpy(&pv, best, 16);
-        uint2v cv; memcpy(&cv, bc, 8);
-        __builtin_amdgcn_raw_buffer_store_b128(pv, rsO, plive ? pidx * 2u : 0x80000000u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(cv, rsC, plive ? pidx : 0x80000000u, 0, 0);
-    }
-}
-template <bool RELU, int EPI, int MB>
-__global__ void __launch_bounds__(512, 1)
-conv3x3_k32_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
-                   _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
-                   unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes)
-{
-    constexpr int BROW = 16 * MB;                                                  // output channels per tile = per staged weight row
-    constexpr int BINS = 9 * 4 * BROW / 64;                                        // weight wave-instructions per stage: 36, 18 or 9
-    constexpr int BK = (BINS + 7) / 8;                                             // per wave: 5, 3 or 2
-    constexpr int STAGE = K3_AINS * 64 + 36 * BROW;                                // chunks per LDS buffer (MB = 4: 77,824 B)
-    constexpr int NSTORE = EPI == 2 ? 4 : 2 * MB;                                  // store instructions per tile epilogue
-    constexpr int WAIT_TILE = 0x0F70 | NSTORE;                                     // s_waitcnt vmcnt(NSTORE)
-    constexpr int TPS = 4 / MB;                                                    // tiles per packed 64-channel weight slab
-    __shared__ __attribute__((aligned(16))) half8 lds0[STAGE];
-    __shared__ __attribute__((aligned(16))) half8 lds1[STAGE];
-    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p16 = lane & 15, g = lane >> 4;
-    const int VH = (H + 2) & ~1, VR = n * VH;
-    const unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
-    const int nchunks = Cin / CT_KC;
-    const unsigned plane_bytes = (unsigned)H * W * 64u;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
-    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
-    const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)code, 0, EPI == 1 ? out_bytes / 2 : 0, 0x00020000);
-    const int my_ct = blockIdx.x % ncout_tiles;
-    if (tid < 2 * CT_N) {
-        const int cl = tid & (CT_N - 1), ch = my_ct * BROW + cl;
-        s_ss[tid >> 6][cl] = cl < BROW && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
-    }
-    unsigned a_off[5], b_off[5]; int b_j[5];
-    int a_py[5], a_px[5]; unsigned a_c8[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int i = (wv + 8 * k) * 64 + lane;
-        const int c8 = i / K3_PP, p = i - c8 * K3_PP;
-        a_py[k] = (c8 < 4 && p < DT_PLANE) ? p / DT_PW : -0x10000;                  // padding slots never become valid
-        a_px[k] = p - (p / DT_PW) * DT_PW; a_c8[k] = c8 * 16u;
-        b_j[k] = min(wv + 8 * k, BINS - 1);
-        const int idx = b_j[k] * 64 + lane, row = idx / BROW, col = idx - row * BROW;   // LDS rows are (tap, c8) x BROW channels
-        b_off[k] = (unsigned)(row * 64 + col) * 16u;                              // packed weights: [tap][c8][cout 64][8]
-    }
-#define K3_SLAB0(ct_) ((unsigned)((ct_) / TPS) * nchunks * (DT_BCH * 16u) + (unsigned)((ct_) % TPS) * (BROW * 16u))
-#define K3_TILE_OFFSETS(tile)                                                                           \
-    {   const int pt_ = (tile) / ncout_tiles;                                                           \
-        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
-        _Pragma("unroll") for (int k = 0; k < 5; k++) {                                                 \
-            const int v = ty_ + a_py[k] - 1, gx = tx_ + a_px[k] - 1;                                    \
-            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
-            const bool ok = (tile) < total_tiles && v >= 0 && v < VR && gx >= 0 && gx < W && y < H;      \
-            a_off[k] = ok ? ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * W + gx) * 64u + a_c8[k] : 0x80000000u; \
-        } }
-#define K3_DMA_A(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 8 * (k)) * 64], 16, a_off[k], so, 0, 0);
-#define K3_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[K3_AINS * 64 + b_j[k] * 64], 16, b_off[k], so, 0, 0);
-    int tile = blockIdx.x;
-    K3_TILE_OFFSETS(tile)
-    {
-        const unsigned bso = K3_SLAB0(tile % ncout_tiles);
-#pragma unroll
-        for (int k = 0; k < 5; k++) { K3_DMA_A(k, lds0, 0u) if (k < BK) K3_DMA_B(k, lds0, bso) }
-        const uint4v z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 512 * k), 0, 0);   // see conv3x3_dma_kernel
-    }
-    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int x_idx = g * K3_PP + 2 * wv * DT_PW + p16;                           // this lane's pixel fragment base (plane g, the wave's first halo row)
-    const int w_idx = K3_AINS * 64 + g * BROW + p16;                              // this lane's weight fragment base (k group g)
-    for (; tile < total_tiles; tile += gridDim.x) {
-        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
-        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
-        floatx4 acc[2][2][MB];                                                    // [row][half][M block], first written with C = 0
-        // weight fragments of step st (tap = 3 dy + dx with dx = st / 3, dy = st % 3) and pixel fragments (halo row hr of the
-        // wave's four, half h) at column offset dx
-        // (one integer index per read: the pass that tags LDS accesses with the alias scopes of lds0 / lds1 follows pointer
-        // arithmetic only a few steps deep; an untagged ds_read makes the compiler wait for the DMA in flight)
-#define K3_LOADW(rd, fbuf, st)                                                                          \
-        {   _Pragma("unroll") for (int mb_ = 0; mb_ < MB; mb_++) fb[fbuf][mb_] = rd[w_idx + (3 * ((st) % 3) + (st) / 3) * 4 * BROW + 16 * mb_]; }
-#define K3_LOADX(rd, gbuf, dx_, q_) fa[gbuf][q_] = rd[x_idx + ((q_) >> 1) * DT_PW + 16 * ((q_) & 1) + (dx_)];   /* q = 2 hr + h */
-#define K3_STAGE_BODY(rd, wr, Z)                                                                        \
-        {   half8 fa[2][8], fb[2][MB];                                                                  \
-            _Pragma("unroll") for (int q = 0; q < 8; q++) K3_LOADX(rd, 0, 0, q)                         \
-            K3_LOADW(rd, 0, 0)                                                                          \
-            _Pragma("unroll") for (int st = 0; st < 9; st++) {                                          \
-                const int cur = st & 1, dxs = st / 3, dys = st - 3 * dxs, grp = dxs & 1;                \
-                if (st < 5) K3_DMA_A(st, wr, a_so)                                                      \
-                if (st >= 5 && st - 5 < BK) K3_DMA_B(st - 5, wr, b_so)                                  \
-                if (st == 0 && BK == 5) K3_DMA_B(4, wr, b_so)                                           \
-                if (st + 1 < 9) K3_LOADW(rd, cur ^ 1, st + 1)                                           \
-                if (dxs < 2) {   /* a third of the next column's 8 pixel fragments */                  \
-                    _Pragma("unroll") for (int q = 3 * dys; q < 3 * dys + 3 && q < 8; q++) K3_LOADX(rd, grp ^ 1, dxs + 1, q) \
-                }                                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                      \
-                /* D[cout][pixel] += W[cout][k] X[k][pixel] */                                          \
-                _Pragma("unroll") for (int tm_ = 0; tm_ < 2; tm_++) _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) _Pragma("unroll") for (int mb_ = 0; mb_ < MB; mb_++) \
-                    acc[tm_][h_][mb_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[cur][mb_], fa[grp][2 * (tm_ + dys) + h_], (Z) && st == 0 ? zero4 : acc[tm_][h_][mb_], 0, 0, 0); \
-                __builtin_amdgcn_sched_barrier(0);                                                      \
-            } }
-        // two stages (64 input channels) per step of the chunk loop, so that the buffers are compile-time; the tile's first pair
-        // is a separate instantiation (its wait differs, see conv3x3_dma2_kernel)
-#define K3_PAIR(ck, WAITC, FIRST)                                                                       \
-        {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
-            __builtin_amdgcn_s_barrier();                                                               \
-            unsigned a_so = (unsigned)((ck) + 1) * plane_bytes, b_so = K3_SLAB0(ct) + (unsigned)((ck) + 1) * (DT_BCH * 16u); \
-            K3_STAGE_BODY(lds0, lds1, FIRST)                                                            \
-            __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
-            __builtin_amdgcn_s_barrier();                                                               \
-            if ((ck) + 2 < nchunks) {                                                                   \
-                a_so = (unsigned)((ck) + 2) * plane_bytes;                                              \
-                b_so = K3_SLAB0(ct) + (unsigned)((ck) + 2) * (DT_BCH * 16u);                            \
-            } else {                                                                                    \
-                const int nt = tile + gridDim.x;                                                        \
-                K3_TILE_OFFSETS(nt)                                                                     \
-                a_so = 0u;                                                                              \
-                b_so = nt < total_tiles ? K3_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
-            }                                                                                           \
-            K3_STAGE_BODY(lds1, lds0, false) }
-        K3_PAIR(0, WAIT_TILE, true)
-        for (int ck = 2; ck < nchunks; ck += 2) K3_PAIR(ck, 0x0F70, false)
-#undef K3_PAIR
-#undef K3_STAGE_BODY
-#undef K3_LOADW
-#undef K3_LOADX
-        // epilogue: this wave's two rows
-        const int cout_chunks = (Cout + 31) >> 5;
-        const int v0 = ty0 + 2 * wv;                                              // even row of the stacked image; VH is even, so y0 is even too
-        const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
-        typedef float float2v __attribute__((ext_vector_type(2)));
-        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int gx = tx0 + 16 * h + p16;
-            const bool live0 = v0 < VR && y0 < H && gx < W, live1 = live0 && y0 + 1 < H;
-            if constexpr (EPI == 2) {
-                // class ArgMax (channels < Cout <= 12) of the fp16-rounded logits, first maximum wins: lane group g holds classes
-                // 4g..4g+3 of pixel p16; groups 1 and 2 send (value bits << 8 | index) to group 0
-#pragma unroll
-                for (int tm = 0; tm < 2; tm++) {
-                    const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][4 * g]), sf = *reinterpret_cast<const float4*>(&s_ss[1][4 * g]);
-                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
-                    _Float16 bv = (_Float16)-65504.f; int bi = 255;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float val = __builtin_fmaf(acc[tm][h][0][q], scv[q], sfv[q]);
-                        if (RELU) val = fmaxf(val, 0.f);
-                        const _Float16 hvq = (_Float16)val;
-                        if (4 * g + q < Cout && (bi == 255 || hvq > bv)) { bv = hvq; bi = 4 * g + q; }
-                    }
-                    unsigned short vb; memcpy(&vb, &bv, 2);
-                    const int mine = (int)(((unsigned)vb << 8) | (unsigned)bi);
-                    const int t1 = __shfl(mine, p16 + 16, 64), t2 = __shfl(mine, p16 + 32, 64);
-                    _Float16 best = bv; int lab = bi;                                   // classes 0-3 (group 0)
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const int t = k ? t2 : t1;
-                        unsigned short tb = (unsigned short)((unsigned)t >> 8); _Float16 tv; memcpy(&tv, &tb, 2);
-                        const int ti = t & 255;
-                        if (ti != 255 && (lab == 255 || tv > best)) { best = tv; lab = ti; }
-                    }
-                    const bool live = (tm ? live1 : live0) && g == 0;
-                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lab, rsO, live ? (unsigned)((f * H + y0 + tm) * W + gx) : 0x80000000u, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < MB / 2; j++) {                                // pairs of M blocks = 32-channel chunks
-                    uint4v vec[2];
-#pragma unroll
-                    for (int tm = 0; tm < 2; tm++) {
-                        unsigned pk[2][2];                                            // [M block of the pair][half2]
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const int cl = 16 * (2 * j + e) + 4 * g;
-                            const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
-                            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
-#pragma unroll
-                            for (int q = 0; q < 4; q += 2) {
-                                const float2v val = {__builtin_fmaf(acc[tm][h][2 * j + e][q], scv[q], sfv[q]), __builtin_fmaf(acc[tm][h][2 * j + e][q + 1], scv[q + 1], sfv[q + 1])};
-                                half2v h2 = __builtin_convertvector(val, half2v);
-                                if (RELU) h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
-                                memcpy(&pk[e][q >> 1], &h2, 4);
-                            }
-                        }
-                        // even lane groups keep block 2j (channels 4g..4g+3) and receive the odd group's block 2j (4g+4..4g+7);
-                        // odd groups receive the even group's block 2j+1 (4g-4..4g-1) and keep their own (4g..4g+3)
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                        vec[tm].x = s0[0]; vec[tm].y = s1[0]; vec[tm].z = s0[1]; vec[tm].w = s1[1];
-                    }
-                    const unsigned byte = (unsigned)((g & 1) * 32 + (g >> 1) * 16);   // even groups: block 2j, channels 4g..; odd: block 2j+1, channels 4(g-1)..
-                    conv_emit<EPI>(vec, rsO, rsC, f, y0, gx, live0, live1, ct * (MB / 2) + j, cout_chunks, H, W, byte, !(p16 & 1));
-                }
-            }
-        }
-    }
-#undef K3_DMA_A
-#undef K3_DMA_B
-#undef K3_TILE_OFFSETS
-#undef K3_SLAB0
-}
-
+// (Until round 6 a third form lived here, conv3x3_k32_kernel on v_mfma_f32_16x16x32_f16, SSM_CONV_VARIANT=3.  On dense random operands the chip is power-limited and
+// holds a markedly higher clock on that MFMA shape (+18..21 % TFLOP/s in scripts/ubench/conv_bench.hip's CT_ABL_MFMA16 build) and the kernel was 5 % faster there; inside
+// the network -- post-ReLU activations, half of them zero -- the chip is less power-limited, the shape buys nothing and the one-block-per-CU structure K = 32 forces cost
+// 2 %: DESIGN.md s.4.1, profiles/r04_segnet_*.)
 // ------------------------------------------------------------------ conv3x3 of an input with <= 8 channels (the network's first layer)
 // The input is one 8-channel (16-byte) vector per pixel, [n][H][W][8].  A 16-deep MFMA K step then covers TWO taps: the
 // lower half-wave (k 0..7) reads tap 2s and the upper (k 8..15) tap 2s+1 of the same LDS plane, i.e. the two halves just use
@@ -1209,12 +787,7 @@ static int conv_grid_limit()
     return cus;
 }
 // epi 0: conv; 1: conv + max-pool (out pooled, code); 2: conv + class ArgMax (out = uint8 labels [n][H][W]; Cout <= 12)
-static int conv_variant()
-{
-    static const int variant = [] { const char* e = getenv("SSM_CONV_VARIANT"); return e ? atoi(e) : 2; }();
-    return variant;
-}
-// ucode != nullptr: `in` is the max-pooled tensor of an H x W image and ucode its arg-max codes (un-pool on load, variant 2 only)
+// ucode != nullptr: `in` is the max-pooled tensor of an H x W image and ucode its arg-max codes (un-pool on load)
 static hipError_t conv_dma_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, uint8_t* code, int n, int H, int W,
                                   int CinPad, int Cout, int relu, int epi, hipStream_t s, const uint8_t* ucode = nullptr)
 {
@@ -1225,8 +798,7 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
     // 32-bit buffer offsets and a 16-bit virtual row index; callers batch below these
     if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
     const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, total = tx * ty * nct;
-    const int variant = conv_variant();
-    if (ucode && (variant != 2 || epi != 0 || !relu)) return hipErrorInvalidValue;
+    if (ucode && (epi != 0 || !relu)) return hipErrorInvalidValue;
 #ifdef SSM_CONV_ABLATE   /* scripts/ubench/conv_bench.hip only: zero-sized buffer descriptors drop the stores (1) / turn the DMA into zero fills (2) */
     static const int abl = [] { const char* e = getenv("SSM_CONV_ABL"); return e ? atoi(e) : 0; }();
     const unsigned long long in_bytes_k = (abl & 2) ? 0 : in_bytes, wt_bytes_k = (abl & 2) ? 0 : wt_bytes, out_bytes_k = (abl & 1) ? 0 : out_bytes;
@@ -1234,26 +806,7 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
 #define wt_bytes wt_bytes_k
 #define out_bytes out_bytes_k
 #endif
-    if (variant == 3) {
-        // conv3x3_k32_kernel: one persistent 8-wave block per CU; 64-channel tiles, or 32-channel ones when the last round of
-        // 64-wide tiles would leave more of the chip idle than the extra input staging of 32-wide tiles costs
-        const int cus = conv_grid_limit();
-        auto rounds = [&](int units, int tiles_n) { int gr = cus - cus % tiles_n; if (gr > units) gr = units; return (units + gr - 1) / gr; };
-        int mb = 4, nct_k = nct;
-        if (epi == 2) { mb = 1; nct_k = (Cout + 15) / 16; }
-        else if (Cout % 64 == 0 && rounds(2 * total, 2 * nct) * 0.56 < rounds(total, nct) * 1.0) { mb = 2; nct_k = 2 * nct; }
-        const int total_k = tx * ty * nct_k;
-        int grid = cus - cus % nct_k; if (grid > total_k) grid = total_k;
-#define K3_LAUNCH(R, E, M) conv3x3_k32_kernel<R, E, M><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
-        if (epi == 2) { if (relu) K3_LAUNCH(true, 2, 1); else K3_LAUNCH(false, 2, 1); }
-        else if (epi == 1 && mb == 2) { if (relu) K3_LAUNCH(true, 1, 2); else K3_LAUNCH(false, 1, 2); }
-        else if (epi == 1) { if (relu) K3_LAUNCH(true, 1, 4); else K3_LAUNCH(false, 1, 4); }
-        else if (mb == 2) { if (relu) K3_LAUNCH(true, 0, 2); else K3_LAUNCH(false, 0, 2); }
-        else { if (relu) K3_LAUNCH(true, 0, 4); else K3_LAUNCH(false, 0, 4); }
-#undef K3_LAUNCH
-        return hipGetLastError();
-    }
-    if (variant == 2) {
+    {
         // two persistent 4-wave blocks per CU (conv3x3_dma2_kernel); the grid is a multiple of the cout-tile count so a block keeps
         // its weight slab.  Tiles are 64 output channels wide, or 32 when that balances the CUs better: blocks b and b + grid/2
         // share a CU and its matrix cores, so a CU's time is the work of both; a 32-wide tile costs a bit more than half
@@ -1287,21 +840,13 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
         else { if (relu) D2_LAUNCH(true, 0, 2); else D2_LAUNCH(false, 0, 2); }
 #undef D2_LAUNCH
 #undef D2_LAUNCH_UP
-        return hipGetLastError();
-    }
-    // variant 1: one persistent 8-wave block per CU (the LDS holds one)
-    int grid = conv_grid_limit(); grid -= grid % nct; if (grid > total) grid = total;
-#define DT_LAUNCH(R, E, N) conv3x3_dma_kernel<R, E, N><<<grid, 512, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes)
-    if (epi == 2) { if (relu) DT_LAUNCH(true, 2, 1); else DT_LAUNCH(false, 2, 1); }
-    else if (epi == 1) { if (relu) DT_LAUNCH(true, 1, 2); else DT_LAUNCH(false, 1, 2); }
-    else { if (relu) DT_LAUNCH(true, 0, 2); else DT_LAUNCH(false, 0, 2); }
-#undef DT_LAUNCH
 #ifdef SSM_CONV_ABLATE
 #undef in_bytes
 #undef wt_bytes
 #undef out_bytes
 #endif
-    return hipGetLastError();
+        return hipGetLastError();
+    }
 }
 static hipError_t conv_first_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W, int Cout, int relu, hipStream_t s)
 {
@@ -1338,7 +883,7 @@ hipError_t k_segnet_conv_argmax(const void* in, const void* wt, const float* sca
 }
 // un-pool + conv + BN + ReLU in one pass: `pooled` is [n][CinPad/32][(H+1)/2][(W+1)/2][32] with its codes, out the H x W convolution
 // of the un-pooled image (which is never written).  Only the default kernel has this form: k_segnet_conv_unpool_available().
-int k_segnet_conv_unpool_available() { return conv_variant() == 2; }
+int k_segnet_conv_unpool_available() { return 1; }
 hipError_t k_segnet_conv_unpool(const void* pooled, const uint8_t* ucode, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
                                 int CinPad, int Cout, hipStream_t s)
 {

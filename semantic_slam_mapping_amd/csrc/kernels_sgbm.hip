@@ -657,87 +657,7 @@ __device__ __forceinline__ uint32_t pk_addsat15(uint32_t a, uint32_t b)
     constexpr uint32_t MM = 0x7FFF7FFFu;
     return pk_min16(pk_add16(pk_min16(a, MM), pk_min16(b, MM)), MM);
 }
-template <int K, int SEG>
-__global__ void __launch_bounds__(256)
-sgbm_rows(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int P1, int P2)
-{
-    constexpr int D = 16 * K, NP = (K + 1) / 2;
-    constexpr uint32_t LZERO_LAST = (K & 1) ? 0xFFFF0000u : 0u;
-    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15;
-    const bool live = g < h;                                  // dead groups run row 0 without stores (DPP wants the whole wave)
-    const int y = live ? g : 0;
-    const int nseg = (w1 + SEG - 1) / SEG;
-    const size_t rowi = (size_t)blockIdx.y * h + y;           // blockIdx.y = frame
-    const uint16_t* Crow = C_all + rowi * w1 * D + li * K;
-    uint16_t* Srow = S_all + rowi * w1 * D + li * K;
-    uint16_t* ck = ck_all + rowi * nseg * D + li * K;         // ck[s]: L0 in front of segment s (s >= 1)
-    const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
-    uint32_t Ca[SEG][NP], Cb[SEG][NP];
-    auto load_seg = [&](uint32_t (&Cq)[SEG][NP], int s) {
-#pragma unroll
-        for (int u = 0; u < SEG; u++) sg_load_pk<K>(Cq[u], Crow + (size_t)min(s * SEG + u, w1 - 1) * D);
-    };
-    // ---- pass 1: L0 left to right, checkpoints only
-    if (nseg > 1) {
-        uint32_t L[NP]; int mp = 0;
-#pragma unroll
-        for (int j = 0; j < NP; j++) L[j] = j == NP - 1 ? LZERO_LAST : 0u;
-        auto fwd_seg = [&](const uint32_t (&Cq)[SEG][NP], int s) {
-#pragma unroll
-            for (int u = 0; u < SEG; u++) sg_step_pk<K>(L, mp, Cq[u], P1P1, P2);
-            if (live) sg_store_pk<K>(ck + (size_t)(s + 1) * D, L);
-        };
-        load_seg(Ca, 0);
-        for (int s = 0; s < nseg - 1; s += 2) {
-            if (s + 1 < nseg - 1) load_seg(Cb, s + 1);
-            fwd_seg(Ca, s);
-            if (s + 1 >= nseg - 1) break;
-            if (s + 2 < nseg - 1) load_seg(Ca, s + 2);
-            fwd_seg(Cb, s + 1);
-        }
-    }
-    // ---- pass 2: segments right to left; L0 forward from the checkpoint, L4 backward, the sum out
-    uint32_t R[NP]; int mpr = 0;
-#pragma unroll
-    for (int j = 0; j < NP; j++) R[j] = j == NP - 1 ? LZERO_LAST : 0u;
-    uint32_t Fa[NP], Fb[NP];
-    auto load_ck = [&](uint32_t (&F)[NP], int s) {
-        if (s > 0) { sg_load_pk<K>(F, ck + (size_t)s * D); F[NP - 1] |= LZERO_LAST; }
-        else {
-#pragma unroll
-            for (int j = 0; j < NP; j++) F[j] = j == NP - 1 ? LZERO_LAST : 0u;
-        }
-    };
-    auto seg_run = [&](const uint32_t (&Cq)[SEG][NP], uint32_t (&F)[NP], int s) {
-        int mpf = sg_min_of<NP>(F);
-        uint32_t L0[SEG][NP];
-#pragma unroll
-        for (int u = 0; u < SEG; u++) {
-            if (s * SEG + u < w1) sg_step_pk<K>(F, mpf, Cq[u], P1P1, P2);          // (wave-uniform; false only in the last segment)
-#pragma unroll
-            for (int j = 0; j < NP; j++) L0[u][j] = F[j];
-        }
-#pragma unroll
-        for (int u = SEG - 1; u >= 0; u--) {
-            const int x = s * SEG + u;
-            if (x < w1) {
-                sg_step_pk<K>(R, mpr, Cq[u], P1P1, P2);
-                uint32_t S[NP];
-#pragma unroll
-                for (int j = 0; j < NP; j++) S[j] = pk_addsat15(L0[u][j], R[j]);
-                if (live) sg_store_pk<K>(Srow + (size_t)x * D, S);
-            }
-        }
-    };
-    load_seg(Ca, nseg - 1); load_ck(Fa, nseg - 1);
-    for (int s = nseg - 1; s >= 0; s -= 2) {
-        if (s - 1 >= 0) { load_seg(Cb, s - 1); load_ck(Fb, s - 1); }
-        seg_run(Ca, Fa, s);
-        if (s - 1 < 0) break;
-        if (s - 2 >= 0) { load_seg(Ca, s - 2); load_ck(Fa, s - 2); }
-        seg_run(Cb, Fb, s - 1);
-    }
-}
+// (the 16-lane form of this kernel, sgbm_rows<K, SEG>: D / 16 disparities per lane -- measured slower at every D (profiles/r04_stereo_*), removed in round 6)
 // sgbm_rows with EIGHT disparities per lane: a row is owned by D / 8 of a DPP row's 16 lanes (10 at D = 80), a lane's costs are ONE aligned 16-byte word.
 // sgbm_rows' five u16 per lane are an 8-byte + a 2-byte access at 2-byte alignment, for all 16 lanes: the kernel sat at 0.80 (busiest CU 0.94) of its
 // texture-address units' time (profiles/r04_stereo_ta_busy.md) with HBM at 4 TB/s; here a column is 10 lane-accesses instead of 32.  The idle lanes run along
@@ -1744,12 +1664,11 @@ static hipError_t sg_allow_lds(const void* fn, size_t bytes)
     return e;
 }
 // SSM_SGBM_FORM (read once per process): 2 = sgbm_rows + sgbm_sweep (default), 1 = four L volumes + sgbm_col_wta (round 3), 0 = five L volumes + sgbm_wta
-// (SSM_SGBM_FUSE_WTA=0, the older spelling of form 0, still works).  SSM_SGBM_STRIP: columns per sweep strip (tests: many seams on small images).
+// SSM_SGBM_STRIP: columns per sweep strip (tests: many seams on small images).
 static int sgbm_form()
 {
     static const int form = [] {
         const char* v = getenv("SSM_SGBM_FORM"); if (v) { const int f = atoi(v); return f < 0 ? 0 : f > 2 ? 2 : f; }
-        const char* u = getenv("SSM_SGBM_FUSE_WTA"); if (u && atoi(u) == 0) return 0;
         return 2;
     }();
     return form;
@@ -1778,7 +1697,6 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     const size_t np = (size_t)w * h, npb = np * nb;
     const int uniq = p.uniquenessRatio >= 0 ? p.uniquenessRatio : 10;
     static const int strip_env = [] { const char* v = getenv("SSM_SGBM_STRIP"); return v ? atoi(v) : 0; }();
-    static const int seg_env = [] { const char* v = getenv("SSM_SGBM_SEG"); return v ? atoi(v) : 0; }();
     // strips: at most 64 groups x SGS_CPG columns per block, and as few strips as that allows (the widest blocks: a row costs every block the same barrier and
     // hand-off whatever its width).  Measured at 64 pairs per launch: 10 strips of 118 columns 5.6 ms, 19 of 62 (two blocks per CU) the same, 12 of 98 7.4 ms --
     // 768 blocks are exactly three rounds on 256 CUs, but the strips of the frame that straddles a round boundary wait a whole round for their neighbours to
@@ -1789,11 +1707,10 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     int NS = (w1 + cap - 1) / cap;
     const int TX = ((w1 + NS - 1) / NS + SGS_CPG - 1) / SGS_CPG * SGS_CPG;
     NS = (w1 + TX - 1) / TX;
-    // eight lanes per pixel (sgbm_sweep8) unless its exchange buffers do not fit a CU's LDS (D = 128) or SSM_SGBM_SWEEP_LANES=16 asks for the 16-lane kernel
-    static const int lanes_env = [] { const char* v = getenv("SSM_SGBM_SWEEP_LANES"); return v ? atoi(v) : 8; }();
+    // eight lanes per pixel (sgbm_sweep8) unless its exchange buffers do not fit a CU's LDS (D = 128: the 16-lane kernel sgbm_sweep)
     const int threads8 = (TX * 8 + 63) / 64 * 64, ng8 = threads8 / 8;
     const size_t lds8 = (size_t)4 * ng8 * ((K + 1) * 8 + SGS8_XPAD) * 4 + (size_t)ng8 * D * 2;
-    const bool use8 = lanes_env != 16 && lds8 <= 150 * 1024;
+    const bool use8 = lds8 <= 150 * 1024;
     const int threads = use8 ? threads8 : (TX / SGS_CPG * 16 + 63) / 64 * 64, ng = threads / 16;
     const size_t lds = use8 ? lds8 : (size_t)4 * ng * NG * 16 * 4 + (size_t)ng * D * 2;
     auto sweep = use8 ? (costs_below_2_15 ? sgbm_sweep8<K, true> : sgbm_sweep8<K, false>) : (costs_below_2_15 ? sgbm_sweep<K, SGS_CPG, true> : sgbm_sweep<K, SGS_CPG, false>);
@@ -1821,58 +1738,20 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
         if (test_hook == 2 || (long)per_cu * sg_num_cus() < (long)NS * (concurrent > 0 ? concurrent : 1)) return hipErrorCooperativeLaunchTooLarge;
         per_cu_w = per_cu;
     }
-    static const int rows_lanes = [] { const char* v = getenv("SSM_SGBM_ROWS_LANES"); return v ? atoi(v) : 8; }();      // 16: sgbm_rows (D / 16 disparities per lane)
-    if (rows_lanes != 16) {
-        // checkpoints every 12 columns (SSM_SGBM_SEG = 8 | 16): 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage at 8 / 12 / 16, but 4.32 / 4.38 / 4.33 k pairs/s for
-        // the whole path -- 16 columns of costs in registers leave the kernels of the other streams less room beside it
-        if (seg_env == 8) sgbm_rows8<8><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
-        else if (seg_env == 16) sgbm_rows8<16><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
-        else sgbm_rows8<12><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
-    }
-    else if (seg_env == 6) sgbm_rows<K, 6><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
-    else sgbm_rows<K, SGR_SEG><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, P1, P2);
+    // checkpoints every 12 columns (measured at 8 / 12 / 16: 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage, but 4.32 / 4.38 / 4.33 k pairs/s for the whole
+    // path -- 16 columns of costs in registers leave the kernels of the other streams less room beside it)
+    sgbm_rows8<12><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
     sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
     e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
     if (e != hipSuccess) return e;
     const size_t mbytes = (size_t)nb * (NS - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
     e = hipMemsetAsync(flags, 0, 256 + mbytes, s);           // ticket counter, time-out word, every granule's tag
     if (e != hipSuccess) return e;
-    // SSM_SGBM_TAIL_SPLIT=1 (ablation; round 5, measured and NOT the default).  The idea: nb NS blocks on `slots` block slots run in rounds, 64 pairs x 10 strips on
-    // 256 slots are 2.5 rounds of work in 3 rounds of time, so sweep the frames of the under-filled last round with a SECOND launch of half-width strips (twice the
-    // blocks, half the waves each).  The measurement says the premise is wrong: 510 wide blocks (51 pairs, "two full rounds") take 3.90 ms where 640 blocks
-    // take 3.96 ms, and the 13 remaining pairs as 260 narrow blocks take 0.97 ms -- 76 us per pair in every launch against 62 us per pair for the plain 64-pair
-    // launch.  A launch's time is proportional to its pairs, not to its rounds: the strips of a frame advance in lock step and frames start as tickets are drawn, so
-    // blocks do not finish round by round and the "empty half of the last round" is filled by the frames still in flight; a launch with fewer pairs only has fewer of
-    // them overlapping.  (Stage 0.1862 vs 0.1723 ms per pair with the split on.)
-    int n1 = nb, NS2 = 0, TX2 = 0, threads2 = 0; size_t lds2 = 0;
-    {
-        static const int split_env = [] { const char* v = getenv("SSM_SGBM_TAIL_SPLIT"); return v ? atoi(v) : 0; }();
-        const long slots = (long)per_cu_w * sg_num_cus(), total = (long)nb * NS;
-        if (split_env != 0 && use8 && strip_env == 0 && slots > 0 && total > slots && cap >= 64) {
-            const long rest = total % slots;
-            if (rest > 0 && rest * 10 < slots * 8) {
-                const int cap2 = cap / 2;
-                NS2 = (w1 + cap2 - 1) / cap2; TX2 = ((w1 + NS2 - 1) / NS2 + SGS_CPG - 1) / SGS_CPG * SGS_CPG; NS2 = (w1 + TX2 - 1) / TX2;
-                threads2 = (TX2 * 8 + 63) / 64 * 64;
-                const int ngn = threads2 / 8;
-                lds2 = (size_t)4 * ngn * ((K + 1) * 8 + SGS8_XPAD) * 4 + (size_t)ngn * D * 2;
-                int pc2 = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, reinterpret_cast<const void*>(sweep), threads2, lds2) != hipSuccess) pc2 = 0;
-                if ((long)pc2 * sg_num_cus() >= (long)NS2 * (concurrent > 0 ? concurrent : 1)) n1 = (int)((total - rest) / NS);      // whole frames of the complete rounds
-            }
-        }
-    }
-    sweep<<<n1 * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
+    // (Round 5 measured a SECOND launch of half-width strips for the frames of an under-filled last round of blocks, SSM_SGBM_TAIL_SPLIT: 0.1862 vs 0.1723 ms per pair --
+    // a launch's time is proportional to its pairs, not to its rounds of blocks: strips of a frame advance in lock step and frames start as tickets are drawn, so the
+    // "empty half of the last round" is filled by the frames still in flight.  Removed in round 6)
+    sweep<<<nb * NS, threads, lds, s>>>(C, S04, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS, TX, disp_tmp, disp2key, flags,
                                        reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
-    if (n1 < nb) {
-        const int nb2 = nb - n1;
-        const size_t mbytes2 = (size_t)nb2 * (NS2 - 1) * 2 * SGS_SLOTS * NG * 16 * 8;
-        e = hipMemsetAsync(flags, 0, 256 + mbytes2, s);     // (behind the first launch on the stream: its tickets and mailboxes are done with)
-        if (e != hipSuccess) return e;
-        const size_t vofs = (size_t)n1 * w1 * h * D, pofs = (size_t)n1 * np;
-        sweep<<<nb2 * NS2, threads2, lds2, s>>>(C + vofs, S04 + vofs, w, w1, h, P1, P2, p.minDisparity, minX1, uniq, NS2, TX2, disp_tmp + pofs, disp2key + pofs, flags,
-                                               reinterpret_cast<sg_u64*>(reinterpret_cast<uint8_t*>(flags) + 256), fail_out);
-    }
     {   // SSM_SGBM_TEST_TIMEOUT=1 (tests): report a hand-off time-out whatever happened, so that the caller's repeat in form 1 runs
         static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
         if (test_hook == 1 && fail_out) { e = hipMemsetAsync(fail_out, 1, 4, s); if (e != hipSuccess) return e; }
@@ -2002,9 +1881,8 @@ hipError_t k_sgbm(const uint8_t* left, const uint8_t* right, int w, int h, int n
             (void)sg_allow_lds(reinterpret_cast<const void*>(kern), lds);       // the ring of a wide window needs more than the 64 KB default of dynamic LDS
             kern<<<dim3(nstrips, nb), SGC_THREADS, lds, s>>>(planes, w, h, minD, D, minX1, w1, SW2, P2, TX, tail, C);
         };
-        static const int cost_variant = [] { const char* v = getenv("SSM_SGBM_COST_VARIANT"); return v ? atoi(v) : 1; }();      // 0: the LDS ring for every configuration (ablation)
         const long cmax_c = (long)P2 + (long)SW * SW * (2 * ftzero + 63);
-        if (D == 80 && SW2 == 5 && TX == 32 && cost_variant != 0 && cmax_c < 65536 && w >= 8) {
+        if (D == 80 && SW2 == 5 && TX == 32 && cmax_c < 65536 && w >= 8) {
             // src/stereo.cpp:16-27: the ring in registers (13 KB of LDS per block) and the pre-filter records made inside the kernel's staging (no plane pass)
             constexpr int AWc = 32 + 10, RWc = AWc + 79;
             lds = 2 * ((((size_t)(AWc + 6) * 80) + 15) & ~(size_t)15) + 2 * (size_t)(AWc + RWc) * 16;

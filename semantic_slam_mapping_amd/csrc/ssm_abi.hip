@@ -244,13 +244,11 @@ extern "C" int ssm_create(int device, const ssm_config* cfg, ssm_ctx** out)
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return SSM_E_HIP; }
     ssm_ctx* c = new ssm_ctx();
     c->device = device; c->cfg = *cfg;
-    { const char* e = getenv("SSM_CHAINS"); c->nchains = e ? atoi(e) : 3; }
     // the stereo path's knobs come from the configuration (two contexts of a process may differ); the environment variables remain as overrides for ablation runs
-    { const char* e = getenv("SSM_STEREO_BATCH"); int b = e ? atoi(e) : cfg->stereo_batch > 0 ? cfg->stereo_batch : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 128 ? 128 : b; }
-    { const char* e = getenv("SSM_SGBM_STREAMS"); const int v = e ? atoi(e) : cfg->sgbm_streams; if (v > 0) c->stereo_sgbm_streams = v > 3 ? 3 : v; }
+    { int b = cfg->stereo_batch > 0 ? cfg->stereo_batch : (cfg->max_batch > 0 ? cfg->max_batch : 1); c->stereo_B = b < 1 ? 1 : b > 128 ? 128 : b; }
+    { const int v = cfg->sgbm_streams; if (v > 0) c->stereo_sgbm_streams = v > 3 ? 3 : v; }
     c->sgbm_form_cfg = cfg->sgbm_form;
     { const char* e = getenv("SSM_MAP_STREAM"); c->map_stream = e ? atoi(e) : 1; }
-    { const char* e = getenv("SSM_MAP_FIRST"); c->map_first = !(e && atoi(e) == 0); }
     { const char* e = getenv("SSM_MATCH_VARIANT"); c->match_mfma = !(e && atoi(e) == 0); }      // 0: the VALU matcher in the sequence path (A/B runs)
     c->B = cfg->max_batch > 0 ? cfg->max_batch : 1; c->R = cfg->tracker_ref_frames > 0 ? cfg->tracker_ref_frames : 1;
     int r = build_geometry(*cfg, c->g, c->err);
@@ -359,24 +357,9 @@ int ensure_side_streams(ssm_ctx* c)
 {
     if (c->side_ready) return SSM_OK;
     // each handle is created only if it is still missing: a call that failed half-way leaves side_ready false and the next call resumes
-    // SSM_MAP_CUS=N (ablation): the map stage's stream is confined to N compute units (hipExtStreamCreateWithCUMask; SSM_MAP_CUS_SPREAD=1: every
-    // (256 / N)-th unit instead of the first N), and with SSM_CHAIN_CUS=1 the ORB chains' side streams get the complement -- a static split of the machine in place of
-    // the hardware's block-by-block arbitration between kernels that each fill a CU on their own
-    auto cu_mask = [&](bool map_side, uint32_t (&m)[8]) -> bool {
-        const char* e = getenv("SSM_MAP_CUS"); const int n = e ? atoi(e) : 0;
-        if (n <= 0 || n >= 256) return false;
-        const char* sp = getenv("SSM_MAP_CUS_SPREAD"); const bool spread = sp && atoi(sp) != 0;
-        for (int k = 0; k < 8; k++) m[k] = 0;
-        for (int i = 0; i < n; i++) { const int bit = spread ? (int)((long)i * 256 / n) : i; m[bit >> 5] |= 1u << (bit & 31); }
-        if (!map_side) { const char* ce = getenv("SSM_CHAIN_CUS"); if (!(ce && atoi(ce) != 0)) return false; for (int k = 0; k < 8; k++) m[k] = ~m[k]; }
-        return true;
-    };
-    auto mk_stream = [&](hipStream_t* st, int role = 0) -> hipError_t {      // role 1: the map stream, 2: a chain's side stream
-        if (*st) return hipSuccess;
-        uint32_t m[8];
-        if (role && cu_mask(role == 1, m)) return hipExtStreamCreateWithCUMask(st, 8, m);
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    };
+    // (Round 5 measured a static split of the machine -- the map stage's stream confined to N compute units, the chains' streams to the rest, hipExtStreamCreateWithCUMask --
+    // against the hardware's block-by-block arbitration: -9 %, profiles/r05_cu_split.md.  The switches are gone.)
+    auto mk_stream = [&](hipStream_t* st, int = 0) -> hipError_t { return *st ? hipSuccess : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
     auto mk_event = [&](hipEvent_t* ev) -> hipError_t { return *ev ? hipSuccess : hipEventCreateWithFlags(ev, hipEventDisableTiming); };
     HIPCHK(c, mk_stream(&c->stream2, 2));
     HIPCHK(c, mk_stream(&c->stream3, 1)); HIPCHK(c, mk_event(&c->ev_join3));
@@ -963,6 +946,13 @@ extern "C" int ssm_memcpy_h2d(ssm_ctx* c, void* dst, const void* src, size_t byt
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SSM_OK;
+}
+extern "C" int ssm_dev_mem_info(ssm_ctx* c, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!c || !free_bytes || !total_bytes) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    HIPCHK(c, hipMemGetInfo(free_bytes, total_bytes));
     return SSM_OK;
 }
 extern "C" int ssm_memcpy_h2d_async(ssm_ctx* c, void* dst, const void* src, size_t bytes)

@@ -136,7 +136,7 @@ struct ssm_ctx {
     // SegNet
     struct SegNetState* seg = nullptr;
     // quad matcher
-    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // ssm_config.sgbm_streams (SSM_SGBM_STREAMS overrides: ablations)
+    struct StereoState* stereo = nullptr; int stereo_B = 16; int stereo_sgbm_streams = 2;      // ssm_config.sgbm_streams 
     int sgbm_form_cfg = 0; long sgbm_fallbacks = 0;                                              // ssm_config.sgbm_form; sub-batches repeated in form 1 after a sweep time-out
     // profiling
     bool profiling = false;

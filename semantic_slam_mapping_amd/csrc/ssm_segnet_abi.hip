@@ -24,8 +24,8 @@ int seg_init(ssm_ctx* c)
         g->coutp[l] = (k_seg_layers[l].cout + 63) & ~63;
         g->coutstore[l] = (k_seg_layers[l].cout + 31) & ~31;            // activations live in 32-channel chunks: [C/32][H][W][32]
     }
-    {   // frames per SegNet launch: 64 by default (more tiles per launch: better balance in the small layers; SSM_SEGNET_BATCH for experiments; the 64-channel layers bound it to 96 by their 2^31-byte buffers)
-        const char* e = getenv("SSM_SEGNET_BATCH"); int sb = e ? atoi(e) : 64; if (sb < 1) sb = 1; if (sb > 96) sb = 96;
+    {   // frames per SegNet launch: 64 by default (more tiles per launch: better balance in the small layers; the 64-channel layers bound it to 96 by their 2^31-byte buffers)
+        int sb = 64;
         g->batch = c->B < sb ? c->B : sb;
     }
     const size_t act = (size_t)g->batch * SEG_NW * SEG_NH * 64 * 2;

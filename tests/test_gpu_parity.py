@@ -576,15 +576,13 @@ def test_orb_other_scale_factors(oracle, frames, scale, levels):
         c.close()
 
 
-@pytest.mark.parametrize("map_stream,map_first", [("1", "1"), ("0", "1"), ("0", "0")])
-def test_two_chain_mode_equals_single_stream(monkeypatch, map_stream, map_first):
+@pytest.mark.parametrize("map_stream", ["1", "0"])
+def test_two_chain_mode_equals_single_stream(monkeypatch, map_stream):
     """ssm_seq_process runs alternate sub-batches as two chains on two streams (own workspace each, one event per chain for the
-    matcher's reference descriptors) and the map stage on a third stream (SSM_MAP_STREAM=0: on the chain's stream, chain 1 first or last:
-    SSM_MAP_FIRST); profiling mode 2 keeps every kernel on one stream with one workspace.  Same outputs, bit for bit, incl. ragged
+    matcher's reference descriptors) and the map stage on a third stream (SSM_MAP_STREAM=0: on the chain's stream, chain 1 first); profiling mode 2 keeps every kernel on one stream with one workspace.  Same outputs, bit for bit, incl. ragged
     last sub-batch and a continued sequence."""
     import semantic_slam_mapping_amd as ssm
     monkeypatch.setenv("SSM_MAP_STREAM", map_stream)
-    monkeypatch.setenv("SSM_MAP_FIRST", map_first)
     W, H, n = 640, 480, 23
     c = ssm.Context(0, orb_features=500, max_batch=4, voxel_capacity_log2=18, camera=CAM)
     bufs = [c.dev_alloc(n * W * H * 3), c.dev_alloc(n * W * H * 2), c.dev_alloc(n * W * H * 3), c.dev_alloc(n * 128)]

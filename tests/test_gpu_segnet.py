@@ -214,21 +214,6 @@ def test_seq_process_with_segnet_stage(ctx, oracle, seg):
             ctx.dev_free(p)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["1", "3"])
-def test_other_conv_kernels_pass_the_same_tests(variant):
-    """the two non-default convolution kernels (SSM_CONV_VARIANT=1: one 8-wave block per CU on 32x32x16 MFMAs; 3: the
-    16x16x32 kernel) against the same exactness tests; the variant is read once per process, hence the subprocess"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSM_CONV_VARIANT=variant)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_segnet.py"), "-x", "-q", "-m", "gpu",
-                        "-k", "conv_layer_exact or conv_pool_fused_exact or committed_fixture or fused_argmax or forward_tolerance"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "deselected" in r.stdout
-
-
 def test_label_colouring_on_a_width_that_is_no_multiple_of_four(oracle, seg):
     """label_color_kernel stores four pixels per thread as aligned dwords when every row starts on a multiple of four pixels; other widths take the one-pixel
     stores: a 322 x 242 frame against the same oracle resize + palette"""

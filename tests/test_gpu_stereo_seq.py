@@ -91,8 +91,7 @@ def test_sequence_equals_the_frame_by_frame_walk(oracle, batch, monkeypatch):
     draws from the rand() stream), sub-batches of 2 (carry between sub-batches) and one launch; a second call continues the sequence"""
     import semantic_slam_mapping_amd as ssm
     from semantic_slam_mapping_amd.api import GlibcRand
-    monkeypatch.setenv("SSM_STEREO_BATCH", str(batch))
-    c = ssm.Context(0, width=640, height=480, max_batch=2)
+    c = ssm.Context(0, width=640, height=480, max_batch=2, stereo_batch=batch)
     try:
         assert c.stereo_batch() == batch
         n, w, h, iters = 5, 480, 200, 60
@@ -192,15 +191,14 @@ def test_stereo_and_segnet_contexts_fit_side_by_side_at_bench_sizes():
     """the SGBM workspace is sized by the configured formulation (three cost-volume-sized buffers for the default form 2, not six): at the bench's
     128 pairs per launch of 1241 x 376 x 80 the two workspaces take <= 60 GB (they were 115 GB), so a stereo context and a SegNet-loaded RGB-D context of bench size
     live on one device side by side"""
-    import torch
     import semantic_slam_mapping_amd as ssm
     from semantic_slam_mapping_amd import segnet_model
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import stereo_sequence, KITTI
     from semantic_slam_mapping_amd.api import GlibcRand
     Wd, Hd, F, ITERS = 1241, 376, 256, 200
-    free0 = torch.cuda.mem_get_info(0)[0]
     st = ssm.Context(0, width=640, height=480, max_batch=128)
+    free0 = st.mem_info()[0]
     sg = None
     try:
         L, R = stereo_sequence(F, Wd, Hd, 100)
@@ -208,7 +206,7 @@ def test_stereo_and_segnet_contexts_fit_side_by_side_at_bench_sizes():
         st.h2d(dl, L); st.h2d(dr, R); st.h2d(ds, GlibcRand(0).draws(F * ITERS * 3))
         vo = (KITTI["f"], KITTI["cu"], KITTI["cv"], KITTI["baseline"], 2.0, True)
         out = st.stereo_seq_process(dl, dr, F, Wd, Hd, vo=vo, ransac_iters=ITERS, rand_stream_dev=ds, **KITTI); st.sync()
-        used_stereo = free0 - torch.cuda.mem_get_info(0)[0]
+        used_stereo = free0 - st.mem_info()[0]
         print("stereo context at 128 pairs per launch: %.1f GB" % (used_stereo / 1e9))
         # two SGBM workspaces of 128 pairs: 2 x 128 x (3 x 69.8 MB of volumes + 18 MB) = 58.4 GB; + the quad matcher's pyramids, the sequence outputs and inputs of 256 frames
         assert used_stereo < 70e9, used_stereo                      # (round 5: 115 GB for the workspaces alone)
