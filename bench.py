@@ -63,11 +63,34 @@ STAGE_KERNELS = {"gray": ["gray_kernel<true>"], "pyramid": ["resize4_kernel", "r
                  "segnet": ["segnet_prep_kernel", "conv3x3_", "unpool2x2_kernel", "label_color_kernel", "argmax_kernel"]}
 
 
+def traffic_profile(suffix, source):
+    """(path, None) of the newest committed profiles/rNN_<suffix> if it was collected for the CURRENT semantic_slam_mapping_amd/csrc/<source> (the file records the
+    sha256 of every kernel source it was made from: scripts/pmc_traffic.py), else (None, why) -- a kernel change without a re-collection must not keep the old ratio"""
+    import hashlib
+    path = latest_profile(suffix)
+    if not path:
+        return None, "no profiles/rNN_%s" % suffix
+    try:
+        rec = json.load(open(path)).get("sources_sha256", {}).get(source)
+        cur = hashlib.sha256(open(os.path.join(ROOT, "semantic_slam_mapping_amd", "csrc", source), "rb").read()).hexdigest()
+    except Exception as e:
+        return None, "%s: %r" % (os.path.relpath(path, ROOT), e)
+    if rec != cur:
+        return None, "%s is stale: collected for another %s (re-collect with scripts/collect_profiles.sh + scripts/make_profiles.sh)" % (os.path.relpath(path, ROOT), source)
+    return path, None
+
+
+TRAFFIC_SOURCE = {"traffic.json": "kernels_map.hip", "stereo_traffic.json": "kernels_sgbm.hip", "segnet_traffic.json": "kernels_segnet.hip"}
+
+
 def measured_traffic(stage, frames_per_launch, suffix="traffic.json"):
     """HBM bytes per launch of a stage from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json: FETCH_SIZE + WRITE_SIZE, separate passes;
     FETCH_SIZE x 2 on gfx950 for the kernels that read 16 B per lane, raw for the others: scripts/pmc_traffic.py), or None"""
     try:
-        k = json.load(open(latest_profile(suffix)))["kernels"]
+        path, why = traffic_profile(suffix, TRAFFIC_SOURCE[suffix])
+        if path is None:
+            return None
+        k = json.load(open(path))["kernels"]
         return round(sum(v.get("total_bytes_per_frame", v["total_bytes_per_frame_fetch_x2"]) for name, v in k.items() if any(n in name for n in STAGE_KERNELS[stage])) * frames_per_launch)      # (`in`: the fp16 kernels' names stay mangled in rocprofv3's output)
     except Exception:
         return None
@@ -200,7 +223,8 @@ def stereo_main(args):
                "quad_matches_equal_gpu": bool(int(res["nquad"][1]) == len(qm) and res["quad"][1, :len(qm)].tobytes() == qm.tobytes())}
     traffic = None
     try:        # HBM bytes of the SGBM kernels per launch from the committed PMC passes (profiles/rNN_stereo_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE)
-        kk = json.load(open(latest_profile("stereo_traffic.json")))["kernels"]
+        tpath, twhy = traffic_profile("stereo_traffic.json", "kernels_sgbm.hip")
+        kk = json.load(open(tpath))["kernels"]
         traffic = round(sum(v["total_bytes_per_frame"] for name, v in kk.items() if name.startswith("sgbm_")) * fpl)
     except Exception:
         pass
@@ -216,7 +240,7 @@ def stereo_main(args):
             "per_frame": {"quad_matches": round(float(nq.mean()), 1), "vo_success_rate": round(float(res["vo_result"][1:, 1].mean()), 3)},
             "roofline": {"bound": "hbm", "kernel": "sgbm (prefilter .. wta, median, speckle, depth: all kernels of the SGBM stage)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": None if traffic is None else os.path.relpath(latest_profile("stereo_traffic.json"), ROOT) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)",
+                         "traffic_source": traffic_profile("stereo_traffic.json", "kernels_sgbm.hip")[1] if traffic is None else os.path.relpath(latest_profile("stereo_traffic.json"), ROOT) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)",
                          "algorithmic_bytes_per_launch": round(alg),
                          "stages_ms_per_frame": {k: round(v[0] / (F * nser), 4) for k, v in stage_acc.items()},
                          "stages_ms_per_frame_overlapped": {k: round(v[0] / (F * args.steps), 4) for k, v in stage_ovl.items()}},
@@ -664,7 +688,9 @@ def rgbd_main(args):
             tf = segnet_model.flops() * frames_per_launch / (ms_per_launch * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv3x3_dma2_kernel + conv3x3_first_kernel (26 conv layers with fused pool / un-pool / ArgMax, prep, colouring: whole SegNet stage)", "achieved": round(tf, 1), "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": measured_traffic("segnet", frames_per_launch, "segnet_traffic.json")}
-            if roof["traffic"] is not None:
+            if roof["traffic"] is None:
+                roof["traffic_source"] = traffic_profile("segnet_traffic.json", "kernels_segnet.hip")[1]
+            else:
                 roof["traffic_source"] = os.path.relpath(latest_profile("segnet_traffic.json"), ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --segnet`, scripts/collect_profiles.sh pmc_segnet; per frame x frames per launch group, not measured in this run)"
         elif dom == "match":
             # K6 runs on the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4 on descriptors expanded to +-1 FP4 elements): 2 x 256 operations per
@@ -695,6 +721,8 @@ def rgbd_main(args):
                                          "note": "all kernels of a frame (ORB, match, map) at the timed rate `value`, two chains overlapped"}
         except Exception:
             pass
+        if roof.get("traffic") is None and "traffic_source" not in roof and dom in ("map_fuse", "voxel_insert"):
+            roof["traffic_source"] = traffic_profile("traffic.json", "kernels_map.hip")[1]      # why there is no figure (a stale or missing counter pass)
         if roof.get("traffic") is not None and "traffic_source" not in roof:     # `traffic` is NOT measured in this run: it is this kernel's figure from the committed counter passes of the same command
             roof["traffic_source"] = os.path.relpath(latest_profile("traffic.json"), ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/collect_profiles.sh pmc; per frame x frames per launch)"
         roof["stages_us_per_frame"] = {k: round(v[1], 3) for k, v in sorted(per_stage.items(), key=lambda kv: -kv[1][1])}

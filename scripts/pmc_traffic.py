@@ -47,7 +47,11 @@ def main():
                   "total_bytes_per_frame_fetch_x2": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / frames_total,
                   "total_bytes_per_frame_raw": (fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / frames_total}
         res[k]["total_bytes_per_frame"] = res[k]["total_bytes_per_frame_fetch_x2"]
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 reports half of the bytes read "
+    # the kernel sources these counters belong to: bench.py quotes a traffic file only while the source of the kernel it describes is byte for byte the same
+    import hashlib, os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantic_slam_mapping_amd", "csrc")
+    sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
+    json.dump({"sources_sha256": sha, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 reports half of the bytes read "
                        "(MI355X_MICROARCH.md s.HBM; calibrated for this repo's access patterns by scripts/ubench/fetch_calib.hip): total = fetch x 2 + write",
                "frames_in_profiled_run": frames_total,
                "kernels": res}, open(out, "w"), indent=1)
