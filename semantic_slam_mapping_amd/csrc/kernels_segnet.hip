@@ -495,6 +495,244 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
 #undef D2_SLAB0
 }
 
+// ------------------------------------------------------------------ conv3x3 by Winograd F(2, 3) along x (round 6)
+// y[2j], y[2j+1] of a row from d0 .. d3 = x[2j-1 .. 2j+2] of the three input rows dy:  V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3;
+// U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (per dy, packed on the host in fp32, stored fp16);  M_k = sum over (dy, cin) U_k V_k;
+// y[2j] = (M0 + M1) + M2, y[2j+1] = (M1 - M2) - M3.  Four MFMAs per output PAIR and dy instead of six: 1.5 x fewer than the direct form.
+// Same tile (32 x 16 pixels), the same stacked virtual image, LDS-DMA staging, two 4-wave blocks per CU, tile queue and BN / ReLU / 16-byte-store epilogue as
+// conv3x3_dma2_kernel with 32-cout tiles (NT = 1), but
+//   * an MFMA's 32 pixel columns are 16 pairs x 2 rows: lane r = (pair j = r & 15, row select rs = r >> 4) works on rows 4 wv + rp + 2 rs, rp = 0, 1, and
+//     acc[rp][k] are the four transform positions (8 accumulators, as the direct NT = 2 form has): a lane's 2 x 2 output block is (rows rp = 0, 1) x (its pair);
+//   * the halo image in LDS keeps the EVEN pixels of a row in front of the odd ones (the DMA's source offset is per lane, so this costs nothing): lane j reads
+//     d0 .. d3 at chunks j, 17 + j, j + 1, 18 + j of its row -- consecutive lanes, consecutive chunks -- and builds V0 .. V3 with 16 packed fp16 subtractions
+//     and additions in registers (nothing goes back to LDS); a lane needs the FOUR halo rows t = rp + dy = 0 .. 3 of its row select;
+//   * weights: 12 "taps" (dy, k) per stage instead of 9; the twelve fragments of a stage are read once and serve both rp.
+// Per wave and stage: 24 MFMAs, 28 ds_read_b128 (the direct NT = 1 form: 36 and 18).  Integer-valued data stays exact (the constants are 1, -1, 1/2).
+#define WG_TAPS 12
+#define WG_BCH_FULL (WG_TAPS * 4 * CT_N)      // chunks of transformed weights per (64-cout tile, 32-cin chunk): [tap][c8 4][cout 64][8]
+#define WG_BINS 12                            // weight wave-instructions per stage (12 taps x 2 c8 x 32 couts = 768 chunks)
+// the halo image of a stage: 2 planes (8 channels each) of 18 rows x 40 chunks: the 17 even pixels of a row, the 17 odd ones, 6 chunks of padding -- a row stride of
+// 40 chunks makes the chunks of lanes two rows apart (the row select of a lane, below) fall on the same bank groups as their own pair index: ds_read_b128 without
+// bank conflicts (the first version read rows ONE apart at a stride of 34: 38 % of its LDS cycles were conflicts)
+#define WG_PW 40
+#define WG_ODD 17
+#define WG_PLANE (DT_PH * WG_PW)              // 720
+#define WG_ACH (2 * WG_PLANE)                 // 1440 chunks of input per stage
+#define WG_AINS 23                            // input wave-instructions per stage (6 per wave; 1472 slots)
+#define WG_AK 6
+#define WG_STAGE (WG_AINS * 64 + WG_BINS * 64) // 2240 chunks = 35.8 KB per LDS buffer
+template <bool RELU>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wino_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
+                    _Float16* __restrict__ out, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
+                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue)
+{
+    __shared__ __attribute__((aligned(16))) half8 lds0[WG_STAGE];
+    __shared__ __attribute__((aligned(16))) half8 lds1[WG_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // an MFMA's 32 pixel columns: 16 pairs x 2 rows.  Lane r = (pair pj, row select rs): rows 4 wv + rp + 2 rs for the wave's two accumulator sets rp
+    const int r = lane & 31, hh = lane >> 5, pj = r & 15, rs = r >> 4;
+    // (the geometry the per-lane address arithmetic uses lives in VECTOR registers on purpose: the kernel runs out of scalar registers otherwise, and a spilled
+    // scalar next to the inline-assembly counter fetch below is what the first version of this kernel crashed on)
+    int VH = (H + 2) & ~1, VR = n * VH, Hv = H, Wv = W;
+    unsigned vh_magic = (0xFFFFFFFFu / (unsigned)VH) + 1u;
+    asm volatile("" : "+v"(VH), "+v"(VR), "+v"(Hv), "+v"(Wv), "+v"(vh_magic));
+    const int nchunks = Cin / CT_KC;
+    const unsigned plane_bytes = (unsigned)H * W * 64u;                            // one 32-channel chunk of one input frame
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+    constexpr int BK = 3;                                                          // weight wave-instructions per wave and stage
+    constexpr int NSTORE = 8;
+    constexpr int WAIT_TILE = 0x0F70 | (NSTORE & 15) | ((NSTORE >> 4) << 14);      // s_waitcnt vmcnt(NSTORE)
+    __shared__ __attribute__((aligned(16))) float s_ss[2][CT_N];
+    __shared__ int s_next;
+    const int my_ct = blockIdx.x % ncout_tiles, blocks_per_ct = gridDim.x / ncout_tiles;
+    if (tid < 2 * CT_N) {
+        const int cl = tid & (CT_N - 1), ch = my_ct * 32 + cl;
+        s_ss[tid >> 6][cl] = cl < 32 && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
+    }
+    unsigned a_off[WG_AK], b_off[BK];
+#pragma unroll
+    for (int k = 0; k < BK; k++) {
+        const int row = 2 * (wv + 4 * k) + (lane >> 5);                            // rows (tap, c) of the stage's weight image: wave-instruction wv + 4 k fills two of them
+        b_off[k] = (unsigned)((((row >> 1) * 4 + (row & 1)) * 64) + (lane & 31)) * 16u;
+    }
+    // the DMA slots of this thread: slot i = (wv + 4 k) 64 + lane -> (plane c8, halo row py, chunk q of the row); q < 17: even pixel 2 q, q < 34: odd pixel 2 (q - 17) + 1,
+    // else padding (an out-of-range offset: the DMA writes zeros).  One packed register per slot: py | px << 8 | c8 << 16, or -1
+    int a_slot[WG_AK];
+#pragma unroll
+    for (int k = 0; k < WG_AK; k++) {
+        const int i_ = (wv + 4 * k) * 64 + lane;
+        const int c8_ = i_ >= WG_PLANE ? 1 : 0, p_ = i_ - c8_ * WG_PLANE;
+        const int py_ = p_ / WG_PW, q_ = p_ - py_ * WG_PW;
+        const int px_ = q_ < WG_ODD ? 2 * q_ : 2 * (q_ - WG_ODD) + 1;
+        a_slot[k] = (i_ < WG_ACH && q_ < 2 * WG_ODD) ? (py_ | (px_ << 8) | (c8_ << 16)) : -1;
+    }
+#define WG_TILE_OFFSETS(tile)                                                                           \
+    {   const int pt_ = (tile) / ncout_tiles;                                                           \
+        const int tx_ = (pt_ % tiles_x) * DT_W, ty_ = (pt_ / tiles_x) * DT_H;                           \
+        _Pragma("unroll") for (int k = 0; k < WG_AK; k++) {                                             \
+            const int sl_ = a_slot[k];                                                                  \
+            const int v = ty_ + (sl_ & 255) - 1, gx = tx_ + ((sl_ >> 8) & 255) - 1;                     \
+            const int f = (int)__umulhi((unsigned)v, vh_magic), y = v - f * VH;                         \
+            const bool ok = (tile) < total_tiles && sl_ >= 0 && v >= 0 && v < VR && gx >= 0 && gx < Wv && y < Hv; \
+            a_off[k] = !ok ? 0x80000000u : ((unsigned)f * nchunks) * plane_bytes + ((unsigned)y * Wv + gx) * 64u + (unsigned)((sl_ >> 16) & 1) * 16u; \
+        } }
+#define WG_DMA_A(k, dst, so) { if (wv + 4 * (k) < WG_AINS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)&dst[(wv + 4 * (k)) * 64], 16, a_off[k], so, 0, 0); }
+#define WG_DMA_B(k, dst, so) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)&dst[WG_AINS * 64 + (wv + 4 * (k)) * 64], 16, b_off[k], so, 0, 0);
+    // byte offset of 32-cout tile ct's transformed weights for chunk 0: the first or second half of each 64-cout row of its 64-cout slab
+#define WG_SLAB0(ct_) ((unsigned)((ct_) >> 1) * nchunks * (WG_BCH_FULL * 16u) + (unsigned)((ct_) & 1) * 512u)
+    int tile = blockIdx.x;
+    if (blockIdx.x >= (gridDim.x >> 1)) {                                          // the two blocks of a CU half a tile out of phase (see conv3x3_dma2_kernel)
+        for (int i = 0; i < nchunks; i++) __builtin_amdgcn_s_sleep(12);            // 12 x 64 clk = one stage (24 MFMAs x 32 clk) per chunk
+    }
+    WG_TILE_OFFSETS(tile)
+    {
+        const unsigned bso = WG_SLAB0(tile % ncout_tiles);
+#pragma unroll
+        for (int k = 0; k < WG_AK; k++) { WG_DMA_A(k, lds0, 0u) if (k < BK) WG_DMA_B(k, lds0, bso) }
+        const uint4v z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NSTORE; k++) __builtin_amdgcn_raw_buffer_store_b128(z4, rsO, 0x80000000u + 16u * (tid + 256 * k), 0, 0);
+    }
+    int next_tile = total_tiles;
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // this lane's pixel chunks of halo row (4 wv + 2 rs + t), t = rp + dy = 0 .. 3: plane hh, even pixel j / odd pixel j / even j + 1 / odd j + 1
+    const int x_base = hh * WG_PLANE + (4 * wv + 2 * rs) * WG_PW + pj;
+    const int w_base = WG_AINS * 64 + hh * 32 + r;
+    for (; tile < total_tiles; tile = next_tile) {
+        const int ct = tile % ncout_tiles, pt = tile / ncout_tiles;
+        const int tx0 = (pt % tiles_x) * DT_W, ty0 = (pt / tiles_x) * DT_H;
+        floatx16 acc[2][4];                                                        // [rp][transform position]
+#define WG_LOADX(rd, buf, t_)                                                                           \
+        {   const half8* px_ = rd + x_base + (t_) * WG_PW;                                              \
+            xr[buf][0] = px_[0]; xr[buf][1] = px_[WG_ODD]; xr[buf][2] = px_[1]; xr[buf][3] = px_[WG_ODD + 1]; }
+#define WG_LOADW(rd, dst, dy_)                                                                          \
+        {   _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dst[k_] = (rd + w_base + ((dy_) * 4 + k_) * 64)[0]; }
+#define WG_XFORM(cur)                                                                                   \
+            half8 v_[4];                                                                                \
+            v_[0] = xr[cur][0] - xr[cur][2]; v_[1] = xr[cur][1] + xr[cur][2];                           \
+            v_[2] = xr[cur][2] - xr[cur][1]; v_[3] = xr[cur][1] - xr[cur][3];
+#define WG_MFMA4(rp_, w_, ZERO)                                                                         \
+            { _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) acc[rp_][k_] = CT_MFMA(w_[k_], v_[k_], (ZERO) ? zero16 : acc[rp_][k_]); }
+        // one stage: halo row t serves (rp, dy) = (0, t) for t <= 2 and (1, t - 1) for t >= 1.  Two sets of weight fragments are live at a time (wa: dy 0, then dy 2 once row
+        // 1's rp = 1 products have read dy 0; wb: dy 1); the pixel reads of row t + 1 are issued ahead of row t's MFMAs; the next stage's 9 DMA instructions (into `wr`)
+        // are spread over the rows.
+#define WG_STAGE_BODY(rd, wr, Z)                                                                        \
+        {   half8 wa[4], wb[4], xr[2][4];                                                               \
+            WG_LOADX(rd, 0, 0)                                                                          \
+            WG_LOADW(rd, wa, 0)                                                                         \
+            {   WG_DMA_A(0, wr, a_so) WG_DMA_A(1, wr, a_so) WG_DMA_A(2, wr, a_so)                       \
+                WG_DMA_A(3, wr, a_so) WG_DMA_A(4, wr, a_so) WG_DMA_A(5, wr, a_so)                       \
+                WG_DMA_B(0, wr, b_so) WG_DMA_B(1, wr, b_so) WG_DMA_B(2, wr, b_so)                       \
+                WG_LOADX(rd, 1, 1)                                                                      \
+                WG_LOADW(rd, wb, 1)                                                                     \
+                WG_XFORM(0)                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_MFMA4(0, wa, Z)                                                                      \
+                __builtin_amdgcn_sched_barrier(0); }                                                    \
+            {   WG_LOADX(rd, 0, 2)                                                                      \
+                WG_XFORM(1)                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_MFMA4(1, wa, Z)                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_LOADW(rd, wa, 2)                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_MFMA4(0, wb, false)                                                                  \
+                __builtin_amdgcn_sched_barrier(0); }                                                    \
+            {   WG_LOADX(rd, 1, 3)                                                                      \
+                WG_XFORM(0)                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_MFMA4(1, wb, false)                                                                  \
+                WG_MFMA4(0, wa, false)                                                                  \
+                __builtin_amdgcn_sched_barrier(0); }                                                    \
+            {   WG_XFORM(1)                                                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                WG_MFMA4(1, wa, false)                                                                  \
+                __builtin_amdgcn_sched_barrier(0); } }
+#define WG_CHUNK(ck, WAITC, FIRST)                                                                      \
+        {   __builtin_amdgcn_s_waitcnt(WAITC);                                                          \
+            __builtin_amdgcn_s_barrier();                                                               \
+            int fetched_;                                                                               \
+            if (FIRST && tid == 0) fetched_ = __hip_atomic_fetch_add(queue + 2 * my_ct, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            const unsigned slab = WG_SLAB0(ct) + (unsigned)(ck) * (WG_BCH_FULL * 16u);                  \
+            unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
+            WG_STAGE_BODY(lds0, lds1, FIRST)                                                            \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
+            if (FIRST && tid == 0) s_next = (blocks_per_ct + fetched_) * ncout_tiles + my_ct;           \
+            __builtin_amdgcn_s_barrier();                                                               \
+            if ((ck) + 1 < nchunks) {                                                                   \
+                a_so = (unsigned)((ck) + 1) * plane_bytes;                                              \
+                b_so = slab + WG_BCH_FULL * 16u;                                                        \
+            } else {                                                                                    \
+                const int nt = __builtin_amdgcn_readfirstlane(s_next);                                  \
+                next_tile = nt;                                                                         \
+                WG_TILE_OFFSETS(nt)                                                                     \
+                a_so = 0u;                                                                              \
+                b_so = nt < total_tiles ? WG_SLAB0(nt % ncout_tiles) : 0x80000000u;                     \
+            }                                                                                           \
+            WG_STAGE_BODY(lds1, lds0, false) }
+        WG_CHUNK(0, WAIT_TILE, true)
+        for (int ck = 1; ck < nchunks; ck++) WG_CHUNK(ck, 0x0F70, false)
+#undef WG_CHUNK
+#undef WG_STAGE_BODY
+#undef WG_LOADX
+#undef WG_LOADW
+#undef WG_XFORM
+#undef WG_MFMA4
+        // ---- epilogue: inverse transform (fp32), BN, ReLU, fp16; the lane holds the pixel pair (2 j, 2 j + 1) of row 4 wv + rp + 2 rs, channels 8 g + 4 hh + q
+        const int cout_chunks = (Cout + 31) >> 5;
+#pragma unroll
+        for (int rp = 0; rp < 2; rp++) {
+            const int v0 = ty0 + 4 * wv + rp + 2 * rs;
+            const int f = (int)__umulhi((unsigned)v0, vh_magic), y0 = v0 - f * VH;
+            const int gx = tx0 + 2 * pj;
+            const bool live = v0 < VR && y0 < Hv;
+#pragma unroll
+            for (int px = 0; px < 2; px++) {
+#pragma unroll
+                for (int gp = 0; gp < 2; gp++) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int g = 2 * gp + e, cl = 8 * g + 4 * hh;
+                        const float4 sc = *reinterpret_cast<const float4*>(&s_ss[0][cl]), sf = *reinterpret_cast<const float4*>(&s_ss[1][cl]);
+                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            float yv[2];
+#pragma unroll
+                            for (int u = 0; u < 2; u++) {
+                                const int i = 4 * g + q + u;
+                                yv[u] = px == 0 ? (acc[rp][0][i] + acc[rp][1][i]) + acc[rp][2][i] : (acc[rp][1][i] - acc[rp][2][i]) - acc[rp][3][i];
+                            }
+                            const float2v val = {__builtin_fmaf(yv[0], scv[q], sfv[q]), __builtin_fmaf(yv[1], scv[q + 1], sfv[q + 1])};
+                            half2v h2 = __builtin_convertvector(val, half2v);
+                            if (RELU) h2 = __builtin_elementwise_max(h2, (half2v){(_Float16)0, (_Float16)0});
+                            memcpy(&pk[e][q >> 1], &h2, 4);
+                        }
+                    }
+                    // lanes 0-31 keep quad 2gp (channels +0..3) and receive the upper half's quad 2gp (+4..7); lanes 32-63 receive the lower half's quad 2gp+1 (+8..11) and keep their own
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                    uint4v vec; vec.x = s0[0]; vec.y = s1[0]; vec.z = s0[1]; vec.w = s1[1];
+                    const bool lv = live && gx + px < Wv && ct < cout_chunks;
+                    const unsigned ob = lv ? (unsigned)((((f * cout_chunks + ct) * Hv + y0) * Wv + gx + px) * 64 + 16 * hh + 32 * gp) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(vec, rsO, ob, 0, 0);
+                }
+            }
+        }
+    }
+    if (tid == 0 && atomicAdd(&queue[2 * my_ct + 1], 1) == blocks_per_ct - 1) { queue[2 * my_ct] = 0; queue[2 * my_ct + 1] = 0; }
+#undef WG_DMA_A
+#undef WG_DMA_B
+#undef WG_TILE_OFFSETS
+#undef WG_SLAB0
+}
+
 // (Until round 6 a third form lived here, conv3x3_k32_kernel on v_mfma_f32_16x16x32_f16, SSM_CONV_VARIANT=3.  On dense random operands the chip is power-limited and
 // holds a markedly higher clock on that MFMA shape (+18..21 % TFLOP/s in scripts/ubench/conv_bench.hip's CT_ABL_MFMA16 build) and the kernel was 5 % faster there; inside
 // the network -- post-ReLU activations, half of them zero -- the chip is less power-limited, the shape buys nothing and the one-block-per-CU structure K = 32 forces cost
@@ -860,11 +1098,27 @@ static hipError_t conv_first_launch(const void* in, const void* wt, const float*
     return hipGetLastError();
 }
 // CinPad == 8: the <= 8-channel first layer ([n][H][W][8] input, its own weight packing); otherwise CinPad is a multiple of 64
+static hipError_t conv_wino_launch(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W, int CinPad, int Cout, int relu, hipStream_t s)
+{
+    const int nct64 = (Cout + CT_N - 1) / CT_N, VH = (H + 2) & ~1;
+    const unsigned long long in_bytes = (unsigned long long)n * H * W * CinPad * 2, wt_bytes = (unsigned long long)nct64 * CT_N * CinPad * WG_TAPS * 2, out_bytes = (unsigned long long)n * H * W * Cout * 2;
+    if (Cout % 32 || CinPad % (2 * CT_KC)) return hipErrorInvalidValue;
+    if (in_bytes >= 0x80000000ull || wt_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || (long long)n * VH >= 65536) return hipErrorInvalidValue;
+    const int tx = (W + DT_W - 1) / DT_W, ty = (n * VH + DT_H - 1) / DT_H, nct = Cout / 32, total = tx * ty * nct;
+    const int cus = conv_grid_limit();
+    int grid = 2 * cus; grid -= grid % nct; if (grid > total) grid = total;
+    int* queue = conv_tile_queue(s);
+    if (!queue || nct > 32) return hipErrorOutOfMemory;
+    if (relu) conv3x3_wino_kernel<true><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue);
+    else conv3x3_wino_kernel<false><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, n, H, W, CinPad, Cout, tx, nct, total, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue);
+    return hipGetLastError();
+}
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
-                         int CinPad, int Cout, int relu, hipStream_t s)
+                         int CinPad, int Cout, int relu, hipStream_t s, const void* wt_wino)
 {
     if (CinPad == 8) return conv_first_launch(in, wt, scale, shift, out, n, H, W, Cout, relu, s);
     if (CinPad % (2 * CT_KC)) return hipErrorInvalidValue;
+    if (wt_wino) return conv_wino_launch(in, wt_wino, scale, shift, out, n, H, W, CinPad, Cout, relu, s);
     return conv_dma_launch(in, wt, scale, shift, out, nullptr, n, H, W, CinPad, Cout, relu, 0, s);
 }
 // conv + BN + ReLU + max-pool 2x2 (CEIL) in one pass: out is [n][Cout/32][PH][PW][32], code the arg-max codes in the same index space

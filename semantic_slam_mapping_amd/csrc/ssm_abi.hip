@@ -291,7 +291,7 @@ extern "C" void ssm_destroy(ssm_ctx* c)
         void* sp[] = { g->actA, g->actB, g->labels, g->d_sem_gen, g->pre_xofs, g->pre_yofs, g->post_xofs, g->post_yofs, g->pre_xa, g->pre_ya, g->post_xa, g->post_ya,
                        g->code[0], g->code[1], g->code[2], g->code[3], g->code[4] };
         for (void* p : sp) if (p) hipFree(p);
-        for (int l = 0; l < SEG_LAYERS; l++) { if (g->w[l]) hipFree(g->w[l]); if (g->scale[l]) hipFree(g->scale[l]); if (g->shift[l]) hipFree(g->shift[l]); }
+        for (int l = 0; l < SEG_LAYERS; l++) { if (g->ww[l]) hipFree(g->ww[l]); if (g->w[l]) hipFree(g->w[l]); if (g->scale[l]) hipFree(g->scale[l]); if (g->shift[l]) hipFree(g->shift[l]); }
         delete g;
     }
     if (c->stereo) { stereo_free(c->stereo); delete c->stereo; }

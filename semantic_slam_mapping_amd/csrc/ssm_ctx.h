@@ -66,6 +66,7 @@ struct StereoState {        // workspace of the stereo path (quad matcher, SGBM 
 struct SegNetState {
     bool set[SEG_LAYERS] = {};
     void* w[SEG_LAYERS] = {}; float* scale[SEG_LAYERS] = {}; float* shift[SEG_LAYERS] = {};
+    void* ww[SEG_LAYERS] = {};           // the layer's weights in Winograd F(2, 3) form (kernels_segnet.hip conv3x3_wino_kernel), or null: the direct kernel only
     int cinp[SEG_LAYERS], coutp[SEG_LAYERS], coutstore[SEG_LAYERS];
     int batch = 0;
     void *actA = nullptr, *actB = nullptr, *last_logits = nullptr; uint8_t* code[5] = {}; uint8_t* labels = nullptr;

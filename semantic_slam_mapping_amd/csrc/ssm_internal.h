@@ -127,8 +127,9 @@ hipError_t k_segnet_prep(const uint8_t* bgr, int n, int sw, int sh, int dw, int 
 hipError_t k_segnet_begin(hipStream_t s);
 void k_segnet_release_stream(hipStream_t s);     // per-stream helper state of the SegNet / SGBM launchers, freed by ssm_destroy
 void k_sgbm_release_stream(hipStream_t s);
+// wt_wino != nullptr: the layer's weights transformed for the Winograd F(2, 3) kernel ([cout tile 64][cin chunk 32][tap = 4 dy + k][c8 4][cout 64][8] fp16): that kernel runs
 hipError_t k_segnet_conv(const void* in, const void* wt, const float* scale, const float* shift, void* out, int n, int H, int W,
-                         int CinPad, int Cout, int relu, hipStream_t s);
+                         int CinPad, int Cout, int relu, hipStream_t s, const void* wt_wino = nullptr);
 // nb frames per launch: left / right [nb][h][w], disp_out [nb][h][w]
 size_t k_sgbm_workspace_bytes(int w, int h, const ssm_sgbm_params& p, int nb, int form_cfg);      // sized for the configured formulation (0 = the default), never less than one frame in the largest
 bool sgbm_cost_geometry(int D, int SW, int* TX_out, size_t* lds_out);      // false: SADWindowSize too wide for the streaming cost kernel

@@ -46,6 +46,15 @@ int seg_init(ssm_ctx* c)
         (r = up(SEG_NW, c->g.W, &g->post_xofs, &g->post_xa)) || (r = up(SEG_NH, c->g.H, &g->post_yofs, &g->post_ya))) return r;
     return SSM_OK;
 }
+// the layer's Winograd weights when that kernel is to run it: SSM_CONV_WINOGRAD=1 (A/B runs and tests).  The default is the direct kernel on every layer: the
+// Winograd F(2, 3) kernel is bit-exact on integer data and 1.5 x lighter on the matrix cores, but it stages 2.8 x the bytes per MFMA (32-cout tiles: the sixteen
+// accumulators a 64-cout tile needs do not fit two waves per SIMD; 12 taps instead of 9) and ends up bound by the L2 -> LDS path: 203 vs 182 us per frame for the
+// stage (profiles/r06_segnet_winograd.md)
+static const void* seg_wino(const SegNetState* g, int l)
+{
+    static const bool on = [] { const char* e = getenv("SSM_CONV_WINOGRAD"); return e && atoi(e) != 0; }();
+    return on ? g->ww[l] : nullptr;
+}
 extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, const float* scale, const float* shift)
 {
     if (!c) return SSM_E_INVAL;
@@ -69,6 +78,25 @@ extern "C" int ssm_segnet_set_layer(ssm_ctx* c, int l, const float* weight, cons
             w[idx] = f32_to_f16(weight[((size_t)o * cin + i) * 9 + t]);
         }
     }
+    // the same weights for the Winograd F(2, 3) kernel (plain conv + BN + ReLU layers with whole 32-channel chunks on both sides): per dy the three taps of a row become
+    // U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2, in fp32, stored fp16 as [cout tile 64][cin chunk 32][tap = 4 dy + k][c8 4][cout 64][8]
+    std::vector<uint16_t> wwv;
+    if (cinp % 64 == 0 && cout % 32 == 0 && cinp != 8) {
+        wwv.assign((size_t)coutp * 12 * cinp, 0);
+        const int nck = cinp / 32;
+        for (int o = 0; o < cout; o++) for (int i = 0; i < cin; i++) for (int dy = 0; dy < 3; dy++) {
+            const float* gw = weight + ((size_t)o * cin + i) * 9 + dy * 3;
+            const float u[4] = { gw[0], (gw[0] + gw[1] + gw[2]) * 0.5f, (gw[0] - gw[1] + gw[2]) * 0.5f, gw[2] };
+            for (int k = 0; k < 4; k++) {
+                const size_t idx = ((((((size_t)(o / 64) * nck + i / 32) * 12 + (dy * 4 + k)) * 4 + (i % 32) / 8) * 64 + o % 64) * 8) + i % 8;
+                wwv[idx] = f32_to_f16(u[k]);
+            }
+        }
+    }
+    if (!wwv.empty()) {
+        if (!g->ww[l]) { uint16_t* p; r = dalloc(c, &p, wwv.size()); if (r) return r; g->ww[l] = p; }
+        HIPCHK(c, hipMemcpy(g->ww[l], wwv.data(), wwv.size() * 2, hipMemcpyHostToDevice));
+    }
     if (!g->w[l]) { uint16_t* p; r = dalloc(c, &p, w.size()); if (r) return r; g->w[l] = p; DALLOC(c, g->scale[l], coutp); DALLOC(c, g->shift[l], coutp); }
     std::vector<float> sc(coutp, 0.f), sh(coutp, 0.f);
     for (int o = 0; o < cout; o++) { sc[o] = scale[o]; sh[o] = shift[o]; }
@@ -88,7 +116,7 @@ static int seg_forward_core(ssm_ctx* c, int nb, void** logits_out)
     HIPCHK(c, k_segnet_begin(s));
     auto conv = [&](int l) -> int {
         const SegLayerDef& d = k_seg_layers[l];
-        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s));
+        HIPCHK(c, k_segnet_conv(cur, g->w[l], g->scale[l], g->shift[l], nxt, nb, d.h, d.w, g->cinp[l], d.cout, l != SEG_LAYERS - 1, s, seg_wino(g, l)));
         std::swap(cur, nxt); return SSM_OK;
     };
     auto unpool = [&](int i, int PH, int PW, int C, int H, int W) -> int { HIPCHK(c, k_segnet_unpool(cur, g->code[i], nb, PH, PW, C, nxt, H, W, s)); std::swap(cur, nxt); return SSM_OK; };
@@ -190,7 +218,7 @@ extern "C" int ssm_segnet_debug_op(ssm_ctx* c, int op, int arg, const uint16_t* 
         if (g->cinp[arg] == 8) { for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < k_seg_layers[arg].cin; ch++) hin[p * 8 + ch] = in[p * ci16 + ch]; }
         else for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < ci16; ch++) hin[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32] = in[p * ci16 + ch];
         HIPCHK(c, hipMemcpyAsync(g->actA, hin.data(), hin.size() * 2, hipMemcpyHostToDevice, s));
-        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, arg != SEG_LAYERS - 1, s));
+        HIPCHK(c, k_segnet_conv(g->actA, g->w[arg], g->scale[arg], g->shift[arg], g->actB, 1, H, W, g->cinp[arg], k_seg_layers[arg].cout, arg != SEG_LAYERS - 1, s, seg_wino(g, arg)));
         HIPCHK(c, hipMemcpyAsync(hout.data(), g->actB, hout.size() * 2, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         for (size_t p = 0; p < (size_t)H * W; p++) for (int ch = 0; ch < co16; ch++) out[p * co16 + ch] = hout[((size_t)(ch / 32) * H * W + p) * 32 + ch % 32];
