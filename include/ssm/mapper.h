@@ -33,6 +33,7 @@ public:
         invert_pose = para.getData<int>("mapper_invert_pose", 0) != 0;          // the commented alternative at mapper.cpp:89
         map_output = para.getData<string>("map_output", string(""));
         device_map = para.getData<int>("mapper_device_map", 1) != 0;
+        test_fail_update = para.getData<int>("mapper_test_fail_update", -1);        // tests: the device-resident update with this number fails (-> the host path from there on)
         viewerThread = make_shared<thread>(bind(&Mapper::viewer, this));
     }
     void shutdown() { shutdownFlag = true; if (viewerThread != nullptr && viewerThread->joinable()) viewerThread->join(); }
@@ -69,6 +70,7 @@ public:
                         poses.insert(poses.end(), T.data(), T.data() + 16);
                     }
                     int nmap = 0;
+                    if (test_fail_update >= 0 && cntGlobalUpdate == test_fail_update) d.check(ssm_viewer_map_release(d.ctx(), 1), "ssm_viewer_map_release");
                     d.check(ssm_viewer_map_update(d.ctx(), rebuild ? 1 : 0, cl.data(), poses.data(), (int)cl.size(), (float)resolution, &nmap), "ssm_viewer_map_update");
                     PointCloud::Ptr fetched(new PointCloud);
                     fetched->points.resize((size_t)nmap);
@@ -83,6 +85,7 @@ public:
                     cerr << "Mapper: the device-resident map update failed (" << e.what() << "); this and the following updates run on the host path" << endl;
                     for (auto& kv : devClouds) ssm_cloud_free(dev ? dev->ctx() : nullptr, kv.second);
                     devClouds.clear(); device_map = false; deviceMapFellBack = true;
+                    if (dev) ssm_viewer_map_release(dev->ctx(), 0);      // the slabs of the freed clouds and the update's buffers go back to the device: the host path's own device work (ssm_backproject, ssm_voxel_filter) needs the room
                 }
             }
             if (on_device) {
@@ -187,7 +190,7 @@ protected:
     int keyframe_size = 0; std::atomic<int> cntGlobalUpdate{0};       // read by other threads (updates()): atomic -- the reference's plain int is a data race
     double resolution = 0.8, max_distance = 8.0;
     std::atomic<bool> shutdownFlag{false};                           // set by shutdown() on another thread (ThreadSanitizer finding, profiles/r03_sanitizers.log)
-    bool fix_incremental = false, invert_pose = false, device_map = true;
+    bool fix_incremental = false, invert_pose = false, device_map = true; int test_fail_update = -1;
     std::unordered_map<const RGBDFrame*, ssm_cloud*> devClouds;       // key-frame -> its camera-frame cloud in device memory (held until the viewer ends)
     int area_thres = 1000; double overlay_portion_thres = 0.143;
     string map_output;

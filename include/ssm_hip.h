@@ -135,6 +135,10 @@ int  ssm_backproject_dev(ssm_ctx* ctx, const uint16_t* depth, const uint8_t* rgb
 int  ssm_cloud_size(const ssm_cloud* cloud);
 int  ssm_cloud_fetch(ssm_ctx* ctx, const ssm_cloud* cloud, const double* T, ssm_point* out, int cap, int* n_out);   /* transformed copy to the host (T = NULL: as stored) */
 void ssm_cloud_free(ssm_ctx* ctx, ssm_cloud* cloud);
+/* gives the device memory of the viewer's map path back: every slab whose clouds have all been freed, the concatenation buffer and the map buffer of
+ * ssm_viewer_map_update (the next update allocates again).  Mapper::viewer calls it when it falls back to its host path after a device error (out of memory on a long
+ * sequence), so that the host path's own device work has room.  test_fail_next: != 0 makes the NEXT ssm_viewer_map_update of the context fail with SSM_E_NOMEM (tests). */
+int  ssm_viewer_map_release(ssm_ctx* ctx, int test_fail_next);
 /* map <- VoxelGrid(leaf)( (rebuild ? nothing : the previous map's centroids) + sum over i of poses[i] * clouds[i] ); poses: n x 16 doubles, column-major, HOST.
  * A cloud extent PCL's VoxelGrid refuses (dx dy dz > INT_MAX) leaves the unfiltered concatenation as the map, like mapper.h's `*out = *in`. */
 int  ssm_viewer_map_update(ssm_ctx* ctx, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out);

@@ -87,6 +87,7 @@ SYMBOLS = {
     "ssm_cloud_fetch": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I)]),
     "ssm_cloud_free": (None, [_P, _P]),
     "ssm_viewer_map_update": (_I, [_P, _I, _P, _P, _I, _F, C.POINTER(_I)]),
+    "ssm_viewer_map_release": (_I, [_P, _I]),
     "ssm_viewer_map_fetch": (_I, [_P, _P, _I, C.POINTER(_I)]),
     "ssm_map_clear": (_I, [_P]),
     "ssm_map_insert": (_I, [_P, _P, _I]),

@@ -573,6 +573,20 @@ class Context:
     def dev_free(self, p):
         self._chk(self.lib.ssm_dev_free(self.h, p))
 
+    def host_alloc(self, shape, dtype):
+        """a numpy array in page-locked host memory (ssm_host_alloc): such inputs are read by the device where they are.  Free it with host_free(array)."""
+        shape = tuple(int(v) for v in np.atleast_1d(shape)); dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.ssm_host_alloc(max(nbytes, 1), C.byref(p)))
+        arr = np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dt).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {}); self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._chk(self.lib.ssm_host_free(C.c_void_p(p)))
+
     def mem_info(self):
         """(free, total) bytes of the context's device"""
         f, t = C.c_size_t(0), C.c_size_t(0)

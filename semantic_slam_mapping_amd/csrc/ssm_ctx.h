@@ -107,6 +107,7 @@ struct ssm_ctx {
     ssm_point* d_vmap = nullptr; int vmap_n = 0; size_t vmap_cap = 0;      // Mapper::viewer's filtered map, device-resident (ssm_viewer_map_update)
     ssm_point* d_vcat = nullptr; size_t vcat_cap = 0;                        // its concatenation buffer
     struct CloudSlab { ssm_point* d = nullptr; size_t cap = 0, used = 0; int live = 0; };
+    bool viewer_fail_next = false;                                           // tests: the next ssm_viewer_map_update fails (ssm_viewer_map_release)
     std::vector<CloudSlab> cloud_slabs;                                      // key-frame clouds (ssm_backproject_dev) are carved from slabs: no hipMalloc per cloud
     // staging for the host-pointer entry points (one frame) + generic scratch
     uint8_t *d_in_img = nullptr, *d_in_sem = nullptr; uint16_t* d_in_depth = nullptr; double* d_in_pose = nullptr;

@@ -587,11 +587,23 @@ static int grow_points(ssm_ctx* c, ssm_point*& p, size_t& cap, size_t need, size
     p = q; cap = ncap;
     return SSM_OK;
 }
+extern "C" int ssm_viewer_map_release(ssm_ctx* c, int test_fail_next)
+{
+    if (!c) return SSM_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
+    if (test_fail_next) { c->viewer_fail_next = true; return SSM_OK; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (ssm_ctx::CloudSlab& sl : c->cloud_slabs) if (sl.live == 0 && sl.d) { hipFree(sl.d); sl.d = nullptr; sl.cap = 0; sl.used = 0; }      // (an emptied slab is skipped by the allocator: cap 0)
+    if (c->d_vcat) { hipFree(c->d_vcat); c->d_vcat = nullptr; c->vcat_cap = 0; }
+    if (c->d_vmap) { hipFree(c->d_vmap); c->d_vmap = nullptr; c->vmap_cap = 0; c->vmap_n = 0; }
+    return SSM_OK;
+}
 extern "C" int ssm_viewer_map_update(ssm_ctx* c, int rebuild, ssm_cloud* const* clouds, const double* poses, int n, float leaf, int* n_map_out)
 {
     if (!c) return SSM_E_INVAL;
     std::lock_guard<std::mutex> lk(c->mu); hipSetDevice(c->device);
     if (n < 0 || (n && (!clouds || !poses)) || !(leaf > 0)) FAIL(c, SSM_E_INVAL, "bad arguments");
+    if (c->viewer_fail_next) { c->viewer_fail_next = false; FAIL(c, SSM_E_NOMEM, "ssm_viewer_map_update: failure requested by ssm_viewer_map_release(test_fail_next)"); }
     size_t total = rebuild ? 0 : (size_t)c->vmap_n;
     for (int i = 0; i < n; i++) { if (!clouds[i]) FAIL(c, SSM_E_INVAL, "null cloud"); if (clouds[i]->device != c->device) FAIL(c, SSM_E_INVAL, "cloud of another device"); total += (size_t)clouds[i]->n; }
     if (total > (size_t)0x7FFFFFFF) FAIL(c, SSM_E_CAPACITY, "more than 2^31 points in one map update");

@@ -65,6 +65,9 @@ int ssm_viewer_map_update(ssm_ctx*, int rebuild, ssm_cloud* const* clouds, const
     if (n_out) *n_out = (int)g_vmap.size();
     return SSM_OK;
 }
+int ssm_viewer_map_release(ssm_ctx*, int) { return SSM_OK; }
+int ssm_host_alloc(size_t bytes, void** out) { *out = malloc(bytes ? bytes : 1); return *out ? SSM_OK : SSM_E_NOMEM; }
+int ssm_host_free(void* p) { free(p); return SSM_OK; }
 int ssm_viewer_map_fetch(ssm_ctx*, ssm_point* out, int cap, int* n_out)
 { *n_out = (int)g_vmap.size(); if (*n_out > cap) return SSM_E_CAPACITY; if (*n_out) memcpy(out, g_vmap.data(), g_vmap.size() * sizeof(ssm_point)); return SSM_OK; }
 int ssm_voxel_filter(ssm_ctx*, const ssm_point* pts, int n, float, ssm_point* out, int cap, int* n_out)

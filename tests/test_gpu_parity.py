@@ -351,6 +351,34 @@ def test_map_growth_follows_the_streams_voxel_rate_at_a_leaf_below_the_pixel_foo
         big.close()
 
 
+def test_page_locked_inputs_are_used_in_place_and_give_the_same_features(oracle, frames):
+    """ssm_host_alloc (round 6): the synchronous ssm_orb_extract reads a page-locked image with the DMA engine where it is (no staging pass) and the depth image -- needed only
+    at the keypoints, by the last kernel -- through the buffer's device mapping.  Same keypoints, descriptors and 3-D positions as with pageable inputs and as the oracle;
+    also a strided page-locked image (staged: rows are repacked) and a buffer that is overwritten right after the call returns"""
+    import semantic_slam_mapping_amd as ssm
+    c = ssm.Context(0, orb_features=1000, max_batch=1, voxel_capacity_log2=14, camera=CAM)
+    try:
+        bgr, dep = frames[0][0], frames[0][1]
+        H, W = dep.shape
+        pb = c.host_alloc((H, W, 3), np.uint8); pd = c.host_alloc((H, W), np.uint16)
+        pb[:] = bgr; pd[:] = dep
+        k0, d0, p0 = c.detect_features(bgr, dep)
+        k1, d1, p1 = c.detect_features(pb, pd)
+        assert k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1) and np.array_equal(p0, p1)
+        check_orb(c, oracle, pb, pd)
+        pb[:] = 0; pd[:] = 0                                              # the call has returned: the buffers are the caller's again
+        k2, d2, p2 = c.detect_features(bgr, pd)                           # pageable image + page-locked (now zero) depth: features the same, positions the (0, 0, 0) sentinel
+        assert k2.tobytes() == k0.tobytes() and np.array_equal(d2, d0) and not p2.any()
+        wide = c.host_alloc((H, W + 16, 3), np.uint8); wide[:, :W] = bgr     # a strided view of page-locked memory (the python mirror packs it first: the pageable path)
+        k3, d3, _ = c.detect_features(wide[:, :W], dep)
+        assert k3.tobytes() == k0.tobytes() and np.array_equal(d3, d0)
+        f, t = c.mem_info(); assert 0 < f <= t
+        for a in (pb, pd, wide):
+            c.host_free(a)
+    finally:
+        c.close()
+
+
 def _wall_then_stream(ctx, n_wall, n_all, W=640, H=480):
     """device buffers of the configs[1] stream whose first n_wall frames see a wall at 0.4 m (every depth pixel 400 at scale 1000) and whose other frames are the stream's"""
     bufs = [ctx.dev_alloc(n_all * W * H * 3), ctx.dev_alloc(n_all * W * H * 2), ctx.dev_alloc(n_all * W * H * 3), ctx.dev_alloc(n_all * 128)]

@@ -180,7 +180,9 @@ def _run_exp_mapping(prm_text, tmp_path, name, *flags):
     print(r.stdout[-1500:], r.stderr[-1500:])
     assert r.returncode == 0
     last = [l for l in r.stdout.splitlines() if l.startswith("frames ")][-1].split()
-    return dict(zip(last[0::2], last[1::2]))
+    st = dict(zip(last[0::2], last[1::2]))
+    st["_stderr"] = r.stderr
+    return st
 
 
 @pytest.mark.gpu
@@ -292,6 +294,26 @@ def test_exp_mapping_tum_end_to_end_on_gpu(tmp_path):
         assert mine <= vox and len(mine) > 0.3 * len(vox)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_mapper_falls_back_to_the_host_path_with_the_same_map(tmp_path):
+    """ADVICE r05 (low): Mapper::viewer keeps its map on the device; when a device-resident update fails (out of memory on a long sequence) it frees its device clouds,
+    gives the slabs and the update's buffers back (ssm_viewer_map_release) and continues on the host path from the last published map -- the same bits.  The third
+    update is made to fail (mapper_test_fail_update); a paced stream (one frame per 25 ms: the viewer takes every key-frame as it arrives, so the update schedule is the
+    same in both runs) gives the PCD of a run that used the host path from the start (mapper_device_map = 0), byte for byte"""
+    subprocess.run(["make", "-C", HOST], check=True, stdout=subprocess.DEVNULL)
+    base = open(os.path.join(HOST, "parameters_test.txt")).read().replace("end_index=8", "end_index=24").replace("keyframe_min_translation=0.005", "keyframe_min_translation=0.02")
+    base += "\nsynthetic_rigid=1\nsequence_length=24\nframe_period_ms=25\nmapper_drain_ms=400\n"
+    def run(name, extra):
+        txt = base.replace("map_output=/tmp/ssm_test_map.pcd", f"map_output={tmp_path}/{name}.pcd") + extra
+        st = _run_exp_mapping(txt, tmp_path, name)
+        return st, open(tmp_path / f"{name}.pcd", "rb").read()
+    sa, a = run("host", "mapper_device_map=0\n")
+    sb, b = run("dev", "mapper_device_map=1\nmapper_test_fail_update=2\n")
+    assert "device-resident map update failed" in sb["_stderr"] and "device-resident map update failed" not in sa["_stderr"]
+    assert sa["keyframes"] == sb["keyframes"] and int(sa["map_updates"]) == int(sb["map_updates"]) >= 4
+    assert len(a) > 1000 and a == b
 
 
 def test_sanitizer_builds_of_oracle_and_host_layer(tmp_path):
