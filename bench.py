@@ -871,11 +871,17 @@ def exp_mapping_legs(scale=1.0):
         st_txt += ("\ndata_source=%s\ntracker_mode=stereo\ncamera.baseline=%r\ncamera.roix=%r\ncamera.roiy=%r\ncamera.roiz=%r\ninlier_threshold=2.0\ntracker_chunk=%d\nssm_max_batch=%d\n"
                    "timing_skip_frames=%d\nmapper_drain_ms=100\nkeyframe_min_translation=0.5\nreader_preload=1\n" % (seq, KITTI["baseline"], KITTI["roix"], KITTI["roiy"], KITTI["roiz"], SCH, SCH, SCH))
         legs["batched_stereo"] = run("d", st_txt, "--batched")
+        # the per-frame stereo loop -- what the CHECKED-IN reference runs (src/track.cpp:19 calls estimateVO): FrameReader::next computes the depth by SGBM (preloaded here, so
+        # that its time shows as preload_s, not in the loop), Tracker::updateFrame = ORB + QuadFeatureMatch + VisualOdometryStereo::Process per frame
+        legs["per_frame_stereo"] = run("e", st_txt.replace("timing_skip_frames=%d" % SCH, "timing_skip_frames=8"))
         out["runs"] = legs
         f = lambda leg, key: (round(float(legs[leg][key]), 1) if key in legs[leg] else None)
         f2 = lambda v: None if v is None else round(float(v), 4)
         out["per_frame_fps"] = f("per_frame", "tracker_fps"); out["per_frame_solved_fps"] = f("per_frame_solved", "tracker_fps")
         out["batched_fps"] = f("batched", "loop_fps"); out["batched_solved_fps"] = f("batched_solved", "loop_fps"); out["batched_stereo_pairs_per_s"] = f("batched_stereo", "loop_fps")
+        out["per_frame_stereo_pairs_per_s"] = f("per_frame_stereo", "tracker_fps")
+        if "preload_s" in legs["per_frame_stereo"]:           # FrameReader::next of the KITTI reader per frame: five PNG decodes + SGBM depth (ssm_stereo_depth)
+            out["per_frame_stereo_reader_ms"] = round(float(legs["per_frame_stereo"]["preload_s"]) * 1e3 / max(int(legs["per_frame_stereo"]["frames"]), 1), 2)
         out["per_frame_loop_fps_reader_included"] = {k: f(k, "loop_fps") for k in ("per_frame", "per_frame_solved")}
         out["per_call_ms"] = {k: f2(legs["per_frame_solved"].get(k)) for k in ("detect_ms", "match_ms", "pnp_ms", "tracker_ms", "reader_ms")}
         ok = all("error" not in v for v in legs.values())

@@ -511,7 +511,7 @@ def test_bench_default_line_carries_the_other_configs():
     # the per-frame Tracker / Mapper loop (stream poses, solved poses), the bulk trackers (RGB-D with and without the chain, stereo), their maps and poses compared
     em = oc["exp_mapping"]
     assert "error" not in em and all("error" not in v for v in em["runs"].values()), em
-    for k in ("per_frame_fps", "per_frame_solved_fps", "batched_fps", "batched_solved_fps", "batched_stereo_pairs_per_s"):
+    for k in ("per_frame_fps", "per_frame_solved_fps", "batched_fps", "batched_solved_fps", "batched_stereo_pairs_per_s", "per_frame_stereo_pairs_per_s"):
         assert em[k] is not None and em[k] > 0, (k, em.get(k))
     assert em["map_fnv_equal"] is True and em["pose_fnv_equal"] is True
     assert em["cpu_baseline"]["value"] > 0 and em["cpu_baseline"]["kind"] == "port"
