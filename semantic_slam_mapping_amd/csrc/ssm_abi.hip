@@ -794,6 +794,9 @@ extern "C" int ssm_seq_process(ssm_ctx* c, const ssm_frames_dev* in, ssm_seq_out
     if ((stages & SSM_STAGE_MAP) && (!in->depth || !in->bgr || (!in->sem_bgr && !(stages & SSM_STAGE_SEGNET)))) FAIL(c, SSM_E_INVAL, "bgr, depth and sem_bgr (or SSM_STAGE_SEGNET) are required for the map stage");
     const OrbGeom& g = c->g; const int R = c->R, n = in->n, W = g.W, H = g.H; hipStream_t s = c->stream;
     const size_t npix = (size_t)W * H;
+    // fused map launches of an earlier call that nobody has looked at since (no ssm_sync / map read in between): their skipped blocks -- if any -- are run again NOW,
+    // while the launch descriptors still point at that call's outputs (ensure_seq below may re-allocate the per-frame point counts)
+    if (c->map_unexamined) { const int r0 = map_settle(c, c->map_tail ? c->map_tail : c->stream, 0); if (r0) return r0; }
     int r = ensure_seq(c, n > 0 ? n : 1); if (r) return r;
     c->recs.clear(); c->pool_used = 0;
     // history rows
