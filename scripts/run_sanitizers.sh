@@ -7,7 +7,7 @@
 set -u
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r05_sanitizers.log}
+LOG=${1:-$ROOT/profiles/r06_sanitizers.log}
 HOST=$ROOT/semantic_slam_mapping_amd/host
 TMP=$(mktemp -d)
 export SSM_ROOT=$ROOT
