@@ -3,6 +3,13 @@
 # Usage: gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh stats|pmc|pmc_stereo|pmc_segnet'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
+# the sources a counter pass ran: written next to its output, quoted by scripts/pmc_traffic.py (bench.py reports a traffic profile only while these match)
+sha_of_sources() { python3 - "$1" <<'PY'
+import hashlib, json, os, sys
+c = "semantic_slam_mapping_amd/csrc"
+json.dump({f: hashlib.sha256(open(os.path.join(c, f), "rb").read()).hexdigest() for f in sorted(os.listdir(c)) if f.endswith(".hip")}, open(os.path.join(sys.argv[1], "sources_sha256.json"), "w"), indent=1)
+PY
+}
 if [ "$1" = "stats" ]; then
   ( time timeout 300 python3 bench.py > $O/line_default.json 2> $O/line_default.err ) 2> $O/line_default.time      # the command the driver times: configs[1] + other_configs
   timeout 300 python3 bench.py --leaf 0.02 --no-other-configs --steps 5 --warmup 2 > $O/line_leaf002.json 2> $O/line_leaf002.err      # SURVEY s.8(d)'s second leaf (the map grows from 2^20 slots)
@@ -28,6 +35,7 @@ elif [ "$1" = "pmc_segnet" ]; then
   A="--segnet --frames 128 --batch 128 --steps 1 --warmup 0 --no-cpu --serial-only"
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_seg -o runc -- python3 bench.py $A > $O/p_fetch_seg.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_seg -o runc -- python3 bench.py $A > $O/p_write_seg.log 2>&1
+  sha_of_sources $O/p_fetch_seg
   tail -1 $O/p_fetch_seg.log | cut -c1-200
 elif [ "$1" = "pmc_stereo" ]; then
   rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
@@ -35,6 +43,7 @@ elif [ "$1" = "pmc_stereo" ]; then
   timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq_st -o runc -- python3 bench.py $A > $O/p_sq_st.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_st -o runc -- python3 bench.py $A > $O/p_fetch_st.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_st -o runc -- python3 bench.py $A > $O/p_write_st.log 2>&1
+  sha_of_sources $O/p_fetch_st
   tail -2 $O/p_sq_st.log | cut -c1-300
 else
   export SSM_BENCH_H2D=0
@@ -42,5 +51,6 @@ else
   timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/p_sq -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_sq.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_write.log 2>&1
+  sha_of_sources $O/p_fetch
   tail -3 $O/p_sq.log | cut -c1-300
 fi

@@ -50,7 +50,11 @@ def main():
     # the kernel sources these counters belong to: bench.py quotes a traffic file only while the source of the kernel it describes is byte for byte the same
     import hashlib, os
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "semantic_slam_mapping_amd", "csrc")
-    sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
+    at_collection = os.path.join(fd, "sources_sha256.json")      # written on the GPU box by scripts/collect_profiles.sh next to the counters: the sources that actually ran
+    if os.path.exists(at_collection):
+        sha = json.load(open(at_collection))
+    else:
+        sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
     json.dump({"sources_sha256": sha, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 reports half of the bytes read "
                        "(MI355X_MICROARCH.md s.HBM; calibrated for this repo's access patterns by scripts/ubench/fetch_calib.hip): total = fetch x 2 + write",
                "frames_in_profiled_run": frames_total,

@@ -230,7 +230,7 @@ template <bool RELU, int EPI, int NT, bool UP = false>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict__ wt, const float* __restrict__ scale, const float* __restrict__ shift,
                     _Float16* __restrict__ out, uint8_t* __restrict__ code, int n, int H, int W, int Cin, int Cout, int tiles_x, int ncout_tiles, int total_tiles,
-                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue, const uint8_t* __restrict__ ucode)
+                    unsigned in_bytes, unsigned wt_bytes, unsigned out_bytes, int* __restrict__ queue, const uint8_t* __restrict__ ucode, int xcd_map)
 {
     __shared__ __attribute__((aligned(16))) half8 lds0[D2_STAGE];
     __shared__ __attribute__((aligned(16))) half8 lds1[D2_STAGE];
@@ -259,9 +259,21 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     // faster block idle at the end.  queue[2 ct + 1] counts the blocks that have drained the counter; the last one zeroes
     // both, so the buffer is ready for the next launch on the stream.
     __shared__ int s_next;
-    const int my_ct = blockIdx.x % ncout_tiles, blocks_per_ct = gridDim.x / ncout_tiles;
+    // Which tiles a block takes.  Blocks are dealt round-robin over the 8 XCDs (blockIdx.x % 8 labels the blocks that share an XCD and its L2: MI355X_MICROARCH.md).
+    // xcd_map (round 6): the blocks of one XCD group cover ALL cout tiles of the SAME pixel tiles (pixel tile p belongs to group p % 8), so an input tile is fetched
+    // into one L2 and served to its cout tiles from there; the weights (0.6 - 4.7 MB per layer) are what every XCD streams, from MALL.  The first mapping
+    // (my_ct = blockIdx.x % ncout_tiles: one cout tile per XCD group) kept a weight slab per L2 and made every XCD read the whole input: measured, the stage's reads
+    // were 133 MB of inputs once + 311 MB of re-reads per frame; with the XCD order the re-reads are 107 MB (profiles/r06_segnet_mfma_util.md).  The stage's time moved
+    // by 1 % only: the kernel is bound by the L2 -> LDS staging rate, not by HBM.
+    const int xg = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int my_ct = xcd_map ? xslot % ncout_tiles : blockIdx.x % ncout_tiles;
+    const int blocks_per_ct = xcd_map ? (gridDim.x >> 3) / ncout_tiles : gridDim.x / ncout_tiles;      // blocks that share this block's counter
+    int* const qp = queue + 2 * (xcd_map ? xg * ncout_tiles + my_ct : my_ct);                           // this block's counter pair
+    // tile index of this counter's i-th pixel tile: t_base + i t_stride (two scalars: the kernel is short of scalar registers)
+    const int t_base = xcd_map ? xg * ncout_tiles + my_ct : my_ct, t_stride = xcd_map ? 8 * ncout_tiles : ncout_tiles;
+#define D2_TILE_OF(i_) (t_base + (i_) * t_stride)
     if (tid < 2 * CT_N) {
-        const int cl = tid & (CT_N - 1), ch = (blockIdx.x % ncout_tiles) * CTW + cl;
+        const int cl = tid & (CT_N - 1), ch = my_ct * CTW + cl;
         s_ss[tid >> 6][cl] = cl < CTW && ch < Cout ? (tid < CT_N ? scale[ch] : shift[ch]) : 0.f;
     }
     unsigned a_off[5], b_off[5]; int b_j[5];
@@ -330,7 +342,7 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
     // byte offset of cout tile ct's weights for chunk 0: packed per 64-cout tile [chunk][tap][c8][cout 64][8]; a 32-cout tile is
     // the first or second half of each 64-cout row
 #define D2_SLAB0(ct_) (NT == 2 ? (unsigned)(ct_) * nchunks * (DT_BCH * 16u) : (unsigned)((ct_) >> 1) * nchunks * (DT_BCH * 16u) + (unsigned)((ct_) & 1) * 512u)
-    int tile = blockIdx.x;
+    int tile = xcd_map ? D2_TILE_OF(xslot / ncout_tiles) : (int)blockIdx.x;
     // phase shift between the two blocks of a CU (blocks i and i + gridDim/2 are dispatched to the same CU when the grid is
     // 2 x CUs): about half of a tile's MFMA time
     if (blockIdx.x >= (gridDim.x >> 1)) {
@@ -396,12 +408,12 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
                assembly, because the compiler would wait for a returning atomic at the end of the branch (draining the   \
                previous tile's stores) */                                                                  \
             int fetched_;                                                                               \
-            if (FIRST && tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched_) : "v"(0), "v"(1), "s"(queue + 2 * my_ct) : "memory"); \
+            if (FIRST && tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched_) : "v"(0), "v"(1), "s"(qp) : "memory"); \
             const unsigned slab = D2_SLAB0(ct) + (unsigned)(ck) * (DT_BCH * 16u);                       \
             unsigned a_so = (unsigned)(ck) * plane_bytes + 32u, b_so = slab + 2048u;   /* channels 16..31 of this chunk */ \
             D2_STAGE_BODY(lds0, lds1, FIRST)                                                                \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                         \
-            if (FIRST && tid == 0) s_next = (blocks_per_ct + fetched_) * ncout_tiles + my_ct;           \
+            if (FIRST && tid == 0) s_next = D2_TILE_OF(blocks_per_ct + fetched_);                       \
             D2_UNPOOL_MASK(lds1)                                                                        \
             D2_BARRIER();                                                               \
             if ((ck) + 1 < nchunks) {                                                                   \
@@ -478,7 +490,8 @@ conv3x3_dma2_kernel(const _Float16* __restrict__ in, const _Float16* __restrict_
         }
     }
     // exactly one fetch per block came back past the end: the last block of this cout tile to get there resets the counters
-    if (tid == 0 && atomicAdd(&queue[2 * my_ct + 1], 1) == blocks_per_ct - 1) { queue[2 * my_ct] = 0; queue[2 * my_ct + 1] = 0; }
+    if (tid == 0 && atomicAdd(&qp[1], 1) == blocks_per_ct - 1) { qp[0] = 0; qp[1] = 0; }
+#undef D2_TILE_OF
 #ifdef SSM_CONV_ABLATE
     if (tid == 0) {
         const unsigned long long life = __builtin_amdgcn_s_memtime() - t_start;
@@ -999,6 +1012,7 @@ void k_segnet_release_stream(hipStream_t s)                       // ssm_destroy
     auto it = g_tq_bufs.find({dev, s});
     if (it != g_tq_bufs.end()) { (void)hipFree(it->second); g_tq_bufs.erase(it); }
 }
+#define CONV_QUEUE_INTS 1024          // a counter pair per (XCD group, cout tile): 8 x 32 x 2 at most
 static int* conv_tile_queue(hipStream_t s)
 {
     std::mutex& mu = g_tq_mu; auto& bufs = g_tq_bufs;
@@ -1007,7 +1021,7 @@ static int* conv_tile_queue(hipStream_t s)
     auto it = bufs.find({dev, s});
     if (it != bufs.end()) return it->second;
     int* p = nullptr;
-    if (hipMalloc(&p, 64 * sizeof(int)) != hipSuccess || hipMemset(p, 0, 64 * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, CONV_QUEUE_INTS * sizeof(int)) != hipSuccess || hipMemset(p, 0, CONV_QUEUE_INTS * sizeof(int)) != hipSuccess) return nullptr;
     bufs[{dev, s}] = p;
     return p;
 }
@@ -1016,7 +1030,7 @@ static int* conv_tile_queue(hipStream_t s)
 hipError_t k_segnet_begin(hipStream_t s)
 {
     int* q = conv_tile_queue(s);
-    return q ? hipMemsetAsync(q, 0, 64 * sizeof(int), s) : hipErrorOutOfMemory;
+    return q ? hipMemsetAsync(q, 0, CONV_QUEUE_INTS * sizeof(int), s) : hipErrorOutOfMemory;
 }
 static int conv_grid_limit()
 {
@@ -1066,10 +1080,13 @@ static hipError_t conv_dma_launch(const void* in, const void* wt, const float* s
         else if (Cout % 64 == 0 && makespan(2 * total, 2 * nct, 0.56) < makespan(total, nct, 1.0)) { nt_w = 1; nct_k = 2 * nct; }
         const int total_k = tx * ty * nct_k;
         int grid = 2 * cus; grid -= grid % nct_k; if (grid > total_k) grid = total_k;
-#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode)
-#define D2_LAUNCH_UP(N) conv3x3_dma2_kernel<true, 0, N, true><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode)
+#define D2_LAUNCH(R, E, N) conv3x3_dma2_kernel<R, E, N><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode, xcd_map)
+#define D2_LAUNCH_UP(N) conv3x3_dma2_kernel<true, 0, N, true><<<grid, 256, 0, s>>>((const _Float16*)in, (const _Float16*)wt, scale, shift, (_Float16*)out, code, n, H, W, CinPad, Cout, tx, nct_k, total_k, (unsigned)in_bytes, (unsigned)wt_bytes, (unsigned)out_bytes, queue, ucode, xcd_map)
         int* queue = conv_tile_queue(s);
         if (!queue || nct_k > 32) return hipErrorOutOfMemory;
+        // the XCD-aware tile order needs whole groups of 8 x nct_k blocks (a full grid has them; a launch smaller than the grid keeps the plain order)
+        // (A/B on the stage, same box: 5.04-5.12k frames/s plain, 5.14-5.16k with the XCD order; measured bytes 607 -> 386 MB per frame)
+        const int xcd_map = grid % (8 * nct_k) == 0 ? 1 : 0;
         if (ucode) { if (nt_w == 1) D2_LAUNCH_UP(1); else D2_LAUNCH_UP(2); }
         else if (epi == 2) { if (relu) D2_LAUNCH(true, 2, 1); else D2_LAUNCH(false, 2, 1); }
         else if (epi == 1 && nt_w == 1) { if (relu) D2_LAUNCH(true, 1, 1); else D2_LAUNCH(false, 1, 1); }
