@@ -397,12 +397,16 @@ sgbm_cost_reg_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict
 // ------------------------------------------------------------------ one aggregation step on a 16-lane row (K disparities per lane)
 template <int CTRL>
 __device__ __forceinline__ int sg_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false); }
+// a lane permutation in which every lane has a source (rotations, quad_perm, mirrors): with bound_ctrl and no `old` the compiler folds the move into the
+// instruction that uses it (v_min_i32_dpp: ONE instruction per reduction stage; with `old = v` it was v_mov + v_mov_dpp + v_min -- round 6)
+template <int CTRL>
+__device__ __forceinline__ int sg_dpp_all(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 __device__ __forceinline__ int sg_rowmin(int v)
 {
-    v = min(v, sg_dpp<0x128>(v, v));      // row_ror:8
-    v = min(v, sg_dpp<0x124>(v, v));      // row_ror:4
-    v = min(v, sg_dpp<0x122>(v, v));      // row_ror:2
-    v = min(v, sg_dpp<0x121>(v, v));      // row_ror:1
+    v = min(v, sg_dpp_all<0x128>(v));     // row_ror:8
+    v = min(v, sg_dpp_all<0x124>(v));     // row_ror:4
+    v = min(v, sg_dpp_all<0x122>(v));     // row_ror:2
+    v = min(v, sg_dpp_all<0x121>(v));     // row_ror:1
     return v;
 }
 template <int K>
@@ -651,6 +655,12 @@ template <int NP> __device__ __forceinline__ int sg_min_of(const uint32_t (&L)[N
     for (int j = 1; j < NP; j++) m = pk_min16(m, L[j]);
     return sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
 }
+// min(32767, a + b) on packed pairs with a, b <= 32767: ONE instruction, v_pk_add_i16 with the clamp bit (both are non-negative as i16, the sum saturates at 32767)
+typedef short sg_i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_addsat_i15(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sg_i2v, a), __builtin_bit_cast(sg_i2v, b)));
+}
 // min(32767, a + b) on packed pairs, a and b any u16
 __device__ __forceinline__ uint32_t pk_addsat15(uint32_t a, uint32_t b)
 {
@@ -669,12 +679,15 @@ __device__ __forceinline__ void sg_step_pk8(uint32_t (&L)[4], int& minPrev, cons
     uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);                 // row_shl:1
     rgt = last ? MAXMAX : rgt;
     const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
-    uint32_t Ln[4], m = 0xFFFFFFFFu;
+    uint32_t Ln[4], LP[4], m = 0xFFFFFFFFu;
+    const uint32_t lftp = pk_add16(lft, P1P1), rgtp = pk_add16(rgt, P1P1);      // L + P1 once per pair: sg_step8
+#pragma unroll
+    for (int j = 0; j < 4; j++) LP[j] = pk_add16(L[j], P1P1);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t lm = __builtin_amdgcn_alignbyte(L[j], j > 0 ? L[j - 1] : lft, 2);
-        const uint32_t lp = __builtin_amdgcn_alignbyte(j < 3 ? L[j + 1] : rgt, L[j], 2);
-        const uint32_t t = pk_min16(pk_min16(L[j], pk_add16(lm, P1P1)), pk_min16(pk_add16(lp, P1P1), dd));
+        const uint32_t lm = __builtin_amdgcn_alignbyte(LP[j], j > 0 ? LP[j - 1] : lftp, 2);
+        const uint32_t lp = __builtin_amdgcn_alignbyte(j < 3 ? LP[j + 1] : rgtp, LP[j], 2);
+        const uint32_t t = pk_min16(pk_min16(L[j], lm), pk_min16(lp, dd));
         Ln[j] = pk_sub16(pk_add16(Cp[j], t), dd);
         m = pk_min16(m, Ln[j]);
     }
@@ -683,7 +696,7 @@ __device__ __forceinline__ void sg_step_pk8(uint32_t (&L)[4], int& minPrev, cons
 #pragma unroll
     for (int j = 0; j < 4; j++) L[j] = Ln[j];
 }
-template <int SEG>
+template <int SEG, bool FAST>
 __global__ void __launch_bounds__(256)
 sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int D, int P1, int P2)
 {
@@ -743,7 +756,10 @@ sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uin
             const int x = s * SEG + u;
             if (x < w1) {
                 sg_step_pk8(R, mpr, Cq[u], P1P1, P2, act, last);
-                if (live) Srow[(size_t)x * NL] = make_uint4(pk_addsat15(L0[u][0], R[0]), pk_addsat15(L0[u][1], R[1]), pk_addsat15(L0[u][2], R[2]), pk_addsat15(L0[u][3], R[3]));
+                if (live) {
+                    if (FAST) Srow[(size_t)x * NL] = make_uint4(pk_addsat_i15(L0[u][0], R[0]), pk_addsat_i15(L0[u][1], R[1]), pk_addsat_i15(L0[u][2], R[2]), pk_addsat_i15(L0[u][3], R[3]));      // every L < 2^15 (the launcher's bound on the costs)
+                    else Srow[(size_t)x * NL] = make_uint4(pk_addsat15(L0[u][0], R[0]), pk_addsat15(L0[u][1], R[1]), pk_addsat15(L0[u][2], R[2]), pk_addsat15(L0[u][3], R[3]));
+                }
             }
         }
     };
@@ -1001,26 +1017,31 @@ __device__ __forceinline__ void sg_step8(uint32_t (&L)[K], int& minPrev, const u
     lft = first ? MAXMAX : lft;                                                   // lane 0 of the GROUP (lane 8 of the DPP row would see the other group's lane 7)
     rgt = last ? MAXMAX : rgt;
     const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
-    uint32_t Ln[K], m = 0xFFFFFFFFu;
+    uint32_t Ln[K], LP[K], m = 0xFFFFFFFFu;
+    // L + P1 once per pair (round 6): the d - 1 / d + 1 neighbours are byte-aligned out of these sums (v_pk_add_u16 works on the halves separately, so adding before
+    // or after the alignment is the same bits); the group's edges add P1 to their MAX_COST / neighbour-lane word the same way
+    lft = pk_add16(lft, P1P1); rgt = pk_add16(rgt, P1P1);
+#pragma unroll
+    for (int j = 0; j < K; j++) LP[j] = pk_add16(L[j], P1P1);
 #pragma unroll
     for (int j = 0; j < K; j++) {
-        const uint32_t lm = __builtin_amdgcn_alignbyte(L[j], j > 0 ? L[j - 1] : lft, 2);             // (slot 2j-1, slot 2j)
-        const uint32_t lp = __builtin_amdgcn_alignbyte(j < K - 1 ? L[j + 1] : rgt, L[j], 2);         // (slot 2j+1, slot 2j+2)
-        const uint32_t t = pk_min16(pk_min16(L[j], pk_add16(lm, P1P1)), pk_min16(pk_add16(lp, P1P1), dd));
+        const uint32_t lm = __builtin_amdgcn_alignbyte(LP[j], j > 0 ? LP[j - 1] : lft, 2);           // (slot 2j-1, slot 2j) + P1
+        const uint32_t lp = __builtin_amdgcn_alignbyte(j < K - 1 ? LP[j + 1] : rgt, LP[j], 2);       // (slot 2j+1, slot 2j+2) + P1
+        const uint32_t t = pk_min16(pk_min16(L[j], lm), pk_min16(lp, dd));
         Ln[j] = pk_sub16(pk_add16(Cp[j], t), dd);
         m = pk_min16(m, Ln[j]);
     }
     int v = (int)min(m & 0xFFFFu, m >> 16);
-    v = min(v, sg_dpp<0xB1>(v, v));       // quad_perm [1,0,3,2]
-    v = min(v, sg_dpp<0x4E>(v, v));       // quad_perm [2,3,0,1]
-    v = min(v, sg_dpp<0x141>(v, v));      // row_half_mirror: lane i <-> 7 - i of its 8-lane half
+    v = min(v, sg_dpp_all<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = min(v, sg_dpp_all<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = min(v, sg_dpp_all<0x141>(v));     // row_half_mirror: lane i <-> 7 - i of its 8-lane half
     minPrev = v;
 #pragma unroll
     for (int j = 0; j < K; j++) L[j] = Ln[j];
 }
 __device__ __forceinline__ int sg_min8(int v)
 {
-    v = min(v, sg_dpp<0xB1>(v, v)); v = min(v, sg_dpp<0x4E>(v, v)); v = min(v, sg_dpp<0x141>(v, v));
+    v = min(v, sg_dpp_all<0xB1>(v)); v = min(v, sg_dpp_all<0x4E>(v)); v = min(v, sg_dpp_all<0x141>(v));
     return v;
 }
 template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], const uint16_t* p) { __builtin_memcpy(d, p, 4 * K); }      // 2 K u16, 4-byte aligned
@@ -1039,6 +1060,12 @@ template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], cons
 #ifndef SGS8_PACKED_UNIQ
 #define SGS8_PACKED_UNIQ 1
 #endif
+#ifdef SGS8_PROBE
+// a clock read no instruction is scheduled across (the first probes were moved behind the row's first wait by the scheduler and under-counted the row)
+__device__ __forceinline__ unsigned long long sgs8_clock() { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = clock64(); __builtin_amdgcn_sched_barrier(0); return t; }
+__device__ unsigned long long g_sgs8_probe[8]; __device__ unsigned long long g_sgs8_phase[3][12];   // [class: inner wave 5, mailbox-edge wave direct row, slow row][0 rows, 1.. cumulative cycles at the phase marks]
+//    // [0] rows of inner wave, [1] its cycles, [2] its barrier cycles, [3] rows of edge waves, [4] cycles, [5] barrier cycles, [6] slow-path rows, [7] poll cycles
+#endif
 template <int K, bool FAST>
 __global__ void __launch_bounds__(1024)
 sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_all, int w, int w1, int h, int P1, int P2, int minD, int minX1, int uniquenessRatio,
@@ -1047,7 +1074,16 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
     constexpr int D = 16 * K, NG = K + 1;                      // a lane: 2 K disparities = K pairs; a message: K pairs + the path minimum
     extern __shared__ __align__(16) uint8_t sw_smem[];
     __shared__ unsigned s_ticket; __shared__ int s_fail[2];
+    __shared__ __align__(32) uint32_t s_keep[(2 * K + 4) * 8];          // the uniqueness test's masks: row rel + 3, dword j = pair j (see the winner pass)
     const int ng = blockDim.x >> 3, g = threadIdx.x >> 3, li = threadIdx.x & 7;
+    for (int i = threadIdx.x; i < (2 * K + 4) * 8; i += blockDim.x) {
+        const int rel = (i >> 3) - 3, j = i & 7;
+        const uint32_t excl = rel >= 0 ? (7u << rel) : (7u >> -rel);  // slots rel .. rel + 2
+        s_keep[i] = ((excl >> (2 * j)) & 1u ? 0u : 0x8000u) | ((excl >> (2 * j + 1)) & 1u ? 0u : 0x80000000u);
+    }
+    uint32_t idxr[(2 * K + 3) / 4];                                     // the lane's disparity numbers li 2K + k as bytes (the winner pass builds its keys with v_perm_b32)
+#pragma unroll
+    for (int q = 0; q < (2 * K + 3) / 4; q++) idxr[q] = (uint32_t)(li * 2 * K + 4 * q) * 0x01010101u + 0x03020100u;
     uint32_t* xch = reinterpret_cast<uint32_t*>(sw_smem);     // [parity 2][direction 2][ng][NG][8]: dir 0 = L1 of the column (for its right neighbour), dir 1 = L3 (for its left neighbour)
     constexpr int XS = NG * 8 + SGS8_XPAD;                     // dwords per column slot
     uint16_t* srow = reinterpret_cast<uint16_t*>(xch + (size_t)4 * ng * XS) + (size_t)g * D;
@@ -1090,12 +1126,15 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             __builtin_amdgcn_s_sleep(4);
         }
     };
-    // the mailbox granules an outermost column will need in the NEXT row are fetched while this row's winner pass runs (a poll is a round trip to the memory
-    // side, ~1.2 k clocks, whether the data is there or not): pfl / pfr = the incoming L1 / L3 message of row y - 1, valid when every tag says y
-    sg_u64 pfl[NG], pfr[NG];
+    // the mailbox granules an outermost column will need in the NEXT row are fetched ahead (a poll is a round trip to the memory side, ~1.2 k clocks, whether the
+    // data is there or not): pf = the incoming message of row y - 1 -- L1 from the left strip for the lanes of column 0, L3 from the right strip for the lanes of the
+    // last column (a lane is never both) -- valid when every tag says y.  ONE array: with one per side the kernel spilled registers, and a spill's reload waits
+    // with vmcnt(0), i.e. for the NEXT row's cost loads as well: every row paid a trip to HBM (round 6, found with -DSGS8_PROBE)
+    sg_u64 pf[NG];
 #pragma unroll
-    for (int j = 0; j < NG; j++) pfl[j] = pfr[j] = 0;
+    for (int j = 0; j < NG; j++) pf[j] = 0;
     const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
+    const bool wave_mbox_l = (threadIdx.x >> 6) == 0 && strip > 0, wave_mbox_r = (int)(threadIdx.x >> 6) == ((TX - 1) >> 3) && strip < NS - 1;      // it holds edgeL / edgeR lanes
 #if SGS8_EDGE_PRIO
     // the waves that hold a strip's outermost columns do more per row (publish, poll / prefetch) and everybody waits for them at the row's barrier: they issue first
     if (wave_has_edge) __builtin_amdgcn_s_setprio(3);
@@ -1104,7 +1143,16 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
     uint32_t nl[NG], nr[NG];
 #pragma unroll
     for (int j = 0; j < NG; j++) nl[j] = nr[j] = 0u;              // "row -1": OpenCV's zeroed border
-    auto run_row = [&](const uint32_t (&V)[2][K], int y) {
+#ifdef SGS8_PROBE
+    unsigned long long pr_rows = 0, pr_cyc = 0, pr_bar = 0, pr_slow = 0, pr_poll = 0, pr_ph[3][12] = {};
+#endif
+    auto run_row = [&](uint32_t (&V)[2][K], int y) {
+#ifdef SGS8_PROBE
+        const unsigned long long pr_t0 = sgs8_clock(); unsigned long long pr_m[9] = {};
+#define PR_MARK(i_) pr_m[i_] = sgs8_clock() - pr_t0
+#else
+#define PR_MARK(i_)
+#endif
         // ---- the neighbouring columns' states of row y - 1 (LDS; the strip's outermost columns: the mailbox or the zeroed border, below)
 #if !SGS8_EARLY_BARRIER
         const int pp = (y + 1) & 1;
@@ -1117,90 +1165,95 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
         }
 #endif
         const bool outL = g == 0, outR = g >= TX - 1;
-        // ---- the outermost columns: the direction that comes from outside the strip.  The usual case: the neighbour strip is not behind, its message of row
-        // y - 1 sits in the prefetch registers, and the wave steps ONCE with the real predecessors like every other wave.
-        bool direct = false;
-        if (wave_has_edge) {
-            bool have = true;
-            if (edgeL && y > 0) {
-#pragma unroll
-                for (int j = 0; j < NG; j++) have &= (unsigned)(pfl[j] >> 32) == (unsigned)y;
-            }
-            if (edgeR && y > 0) {
-#pragma unroll
-                for (int j = 0; j < NG; j++) have &= (unsigned)(pfr[j] >> 32) == (unsigned)y;
-            }
-            direct = __builtin_amdgcn_ballot_w64(!have) == 0;
-            if (direct) {
-                if (outL) {
-#pragma unroll
-                    for (int j = 0; j < NG; j++) nl[j] = (edgeL && y > 0) ? (uint32_t)pfl[j] : 0u;
-                }
-                if (outR) {
-#pragma unroll
-                    for (int j = 0; j < NG; j++) nr[j] = (edgeR && y > 0) ? (uint32_t)pfr[j] : 0u;
-                }
-            }
-        }
-        // ---- otherwise: what a strip hands on never depends on what it receives in the same row (L1 flows right, L3 flows left), so the edge columns compute and
-        // publish their outgoing state BEFORE the incoming mailbox is polled (sgbm_sweep); they step a placeholder first and are redone behind the poll
-        // (the steps run for the whole wave -- DPP -- in place on L1 / L3)
-#pragma unroll
-        for (int j = 0; j < K; j++) { L1[j] = nl[j]; L3[j] = nr[j]; }
-        m1 = (int)nl[K]; m3 = (int)nr[K];
-        sg_step8<K>(L1, m1, V[0], P1P1, P2, first, last);
-        sg_step8<K>(L3, m3, V[0], P1P1, P2, first, last);
+        // the vertical direction needs no neighbour: it runs first, in front of the first use of the prefetched mailbox words (their loads were issued at the end of
+        // the previous row: SGS8_PF_POS)
         sg_step8<K>(L2, m2, V[0], P1P1, P2, first, last);
-        if (edgeR) {                                              // its L1 came from LDS: final
-            sg_u64* o = mslot(strip, 0, y & (SGS_SLOTS - 1));
+        // ---- L1 and L3.  A strip's outermost column takes the predecessor of ONE direction from outside the strip: the mailbox of the neighbour strip (its message of
+        // row y - 1 usually sits in the prefetch registers) or the image's zeroed border.  What a strip hands on never depends on what it receives in the same row
+        // (L1 flows right, L3 flows left), so a wave with a mailbox edge steps its OUTGOING direction first and publishes it at once -- the neighbour strip has
+        // almost a whole row to see it -- and only then looks at the incoming message (round 6; before, both directions were stepped, published behind the second
+        // one, and stepped again whenever the prefetch had missed).
+        bool direct = true;
+        if (wave_has_edge) {
+            if (outL && !(edgeL && y > 0)) {
 #pragma unroll
-            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L1[j], SG_RLX_AGENT);
-            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m1, SG_RLX_AGENT);
-        }
-        if (edgeL) {
-            sg_u64* o = mslot(strip - 1, 1, y & (SGS_SLOTS - 1));
-#pragma unroll
-            for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L3[j], SG_RLX_AGENT);
-            __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)m3, SG_RLX_AGENT);
-        }
-        if (wave_has_edge && !direct) {
-            bool okl = true, okr = true;
-            if (outL) {
-                if (edgeL && y > 0) okl = mbox_wait8(mslot(strip - 1, 0, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nl);
-                else {
-#pragma unroll
-                    for (int j = 0; j < NG; j++) nl[j] = 0u;
-                }
+                for (int j = 0; j < NG; j++) nl[j] = 0u;
             }
-            if (outR) {
-                if (edgeR && y > 0) okr = mbox_wait8(mslot(strip, 1, (y - 1) & (SGS_SLOTS - 1)), (unsigned)y, nr);
-                else {
+            if (outR && !(edgeR && y > 0)) {
 #pragma unroll
-                    for (int j = 0; j < NG; j++) nr[j] = 0u;
-                }
+                for (int j = 0; j < NG; j++) nr[j] = 0u;
             }
-            if (!(okl && okr)) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
-            // redo the two steps for the wave from the states of row y - 1 (nl / nr still hold them: LDS for the inner columns, the mailbox / the zeroed border for the
-            // outermost ones; the inner columns repeat their result)
+        }
+        const bool wL = wave_mbox_l && y > 0, wR = wave_mbox_r && y > 0;      // (wave-uniform) lanes of this wave take a predecessor from a mailbox
+        auto step_l1 = [&]() {
 #pragma unroll
-            for (int j = 0; j < K; j++) { L1[j] = nl[j]; L3[j] = nr[j]; }
-            m1 = (int)nl[K]; m3 = (int)nr[K];
+            for (int j = 0; j < K; j++) L1[j] = nl[j];
+            m1 = (int)nl[K];
             sg_step8<K>(L1, m1, V[0], P1P1, P2, first, last);
+        };
+        auto step_l3 = [&]() {
+#pragma unroll
+            for (int j = 0; j < K; j++) L3[j] = nr[j];
+            m3 = (int)nr[K];
             sg_step8<K>(L3, m3, V[0], P1P1, P2, first, last);
-        }
-        // the neighbours' messages of THIS row (for row y + 1), on their way during the winner pass below
+        };
+        auto publish = [&](bool mine, const uint32_t (&L)[K], int mn, sg_u64* o) {
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < K; j++) __hip_atomic_store(o + j * 8, ((sg_u64)(unsigned)(y + 1) << 32) | L[j], SG_RLX_AGENT);
+                __hip_atomic_store(o + K * 8, ((sg_u64)(unsigned)(y + 1) << 32) | (uint32_t)mn, SG_RLX_AGENT);
+            }
+        };
+        auto pub_l1 = [&]() { publish(edgeR, L1, m1, mslot(strip, 0, y & (SGS_SLOTS - 1))); };            // its L1 came from LDS: final
+        auto pub_l3 = [&]() { publish(edgeL, L3, m3, mslot(strip - 1, 1, y & (SGS_SLOTS - 1))); };
+        // the incoming message of row y - 1 for the lanes `mine`: the prefetched words when every tag says y, otherwise poll (bounded; a time-out stops the block)
+        auto take = [&](bool mine, uint32_t (&n)[NG], const sg_u64* slot) {
+            bool have = true;
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < NG; j++) have &= (unsigned)(pf[j] >> 32) == (unsigned)y;
+            }
+            if (__builtin_amdgcn_ballot_w64(mine && !have) == 0) {
+                if (mine) {
+#pragma unroll
+                    for (int j = 0; j < NG; j++) n[j] = (uint32_t)pf[j];
+                }
+            } else {
+                direct = false;
+#ifdef SGS8_PROBE
+                const unsigned long long pr_p0 = sgs8_clock();
+#endif
+                bool ok = true;
+                if (mine) ok = mbox_wait8(slot, (unsigned)y, n);
+#ifdef SGS8_PROBE
+                pr_poll += sgs8_clock() - pr_p0;
+#endif
+                if (!ok) { s_fail[y & 1] = 1; __hip_atomic_store(flags + 1, 1u, SG_RLX_AGENT); if (fail_out) atomicOr(fail_out, 1); }
+            }
+        };
+        auto take_l = [&]() { take(edgeL, nl, mslot(strip - 1, 0, (y - 1) & (SGS_SLOTS - 1))); };
+        auto take_r = [&]() { take(edgeR, nr, mslot(strip, 1, (y - 1) & (SGS_SLOTS - 1))); };
+        PR_MARK(0);
+        if (wL && wR) {                                           // a strip of one wave (tests): both directions with placeholders, publish, then the real ones
+            step_l1(); step_l3(); pub_l1(); pub_l3(); take_l(); take_r(); step_l1(); step_l3();
+        } else if (wR) { step_l1(); PR_MARK(6); pub_l1(); PR_MARK(7); take_r(); PR_MARK(8); step_l3(); pub_l3(); }
+        else if (wL) { step_l3(); PR_MARK(6); pub_l3(); PR_MARK(7); take_l(); PR_MARK(8); step_l1(); pub_l1(); }
+        else { step_l1(); step_l3(); pub_l1(); pub_l3(); }        // inner waves, the image's border, row 0
+        PR_MARK(1);
+#ifdef SGS8_PROBE
+        if (!direct) pr_slow++;
+#endif
+        // the neighbours' messages of THIS row (for row y + 1)
+        auto prefetch_mbox = [&]() {
         if (wave_has_edge && y + 1 < h) {
-            if (edgeL) {
-                const sg_u64* gq = mslot(strip - 1, 0, y & (SGS_SLOTS - 1));
+            if (edgeL || edgeR) {
+                const sg_u64* gq = edgeL ? mslot(strip - 1, 0, y & (SGS_SLOTS - 1)) : mslot(strip, 1, y & (SGS_SLOTS - 1));
 #pragma unroll
-                for (int j = 0; j < NG; j++) pfl[j] = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT);
-            }
-            if (edgeR) {
-                const sg_u64* gq = mslot(strip, 1, y & (SGS_SLOTS - 1));
-#pragma unroll
-                for (int j = 0; j < NG; j++) pfr[j] = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT);
+                for (int j = 0; j < NG; j++) pf[j] = __hip_atomic_load(gq + j * 8, SG_RLX_AGENT);
             }
         }
+        };
+        PR_MARK(2);
         if (!live) {                                              // a column outside the strip / image: its neighbours see the zeroed border
 #pragma unroll
             for (int j = 0; j < K; j++) L1[j] = L2[j] = L3[j] = 0u;
@@ -1229,19 +1282,23 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
         }
 #endif
+        PR_MARK(3);
         // ---- the winner pass of the group's pixel: S = min(32767, S04 + L1 + L2 + L3)
         {
             uint32_t sp2[K];
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                if (FAST) { constexpr uint32_t MM = 0x7FFF7FFFu; sp2[j] = pk_min16(pk_add16(pk_min16(pk_add16(L1[j], L2[j]), MM), pk_min16(pk_add16(L3[j], V[1][j]), MM)), MM); }
+                if (FAST) sp2[j] = pk_addsat_i15(pk_addsat_i15(L1[j], L2[j]), pk_addsat_i15(L3[j], V[1][j]));      // every L < 2^15, S04 <= 32767: three clamped adds (six instructions before)
                 else sp2[j] = pk_addsat15(pk_addsat15(pk_addsat15(L1[j], L2[j]), L3[j]), V[1][j]);
             }
-            int Sv[2 * K], best = INT_MAX;
+            // the key (S << 8 | disparity) of a value is ONE v_perm_b32: bytes 1 - 2 from the pair, byte 0 from the lane's table of disparity numbers (round 6; before:
+            // mask / shift + v_lshl_or per value)
+            int best = INT_MAX;
 #pragma unroll
-            for (int k = 0; k < 2 * K; k++) {
-                Sv[k] = (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
-                best = min(best, (Sv[k] << 8) | (li * 2 * K + k));
+            for (int j = 0; j < K; j++) {
+                const int klo = (int)__builtin_amdgcn_perm(sp2[j], idxr[(2 * j) >> 2], 0x0C050400u | (uint32_t)((2 * j) & 3));
+                const int khi = (int)__builtin_amdgcn_perm(sp2[j], idxr[(2 * j + 1) >> 2], 0x0C070600u | (uint32_t)((2 * j + 1) & 3));
+                best = min(best, min(klo, khi));
             }
 #pragma unroll
             for (int j = 0; j < K; j++) reinterpret_cast<uint32_t*>(srow)[li * K + j] = sp2[j];       // (every value <= 32767: the pairs are the u16 table as it stands)
@@ -1255,21 +1312,20 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
                 // subtraction inside 16 bits); the three disparities around the winner are masked out by a per-lane bit pattern: 2 + 2 instructions per pair instead of 5 per value
                 const uint32_t U2 = (uint32_t)min(uth + 1, 32768) * 0x00010001u;
                 const int rel = min(max(bestDisp - 1 - li * 2 * K, -3), 2 * K);     // this lane's slot of disparity bestDisp - 1 (clamped: outside -2 .. 2 K - 1 nothing of the triple is this lane's)
-                const uint32_t excl = rel >= 0 ? (7u << rel) : (7u >> -rel);        // slots rel .. rel + 2 (bits beyond 2 K - 1 are not looked at)
+                // the K masks of the lane (bit 15 / 31 of a pair unless the slot is one of rel .. rel + 2) come from a table in LDS, one 32-byte row per value of rel
+                // (round 6: two ds_read instead of five shift / mask instructions per pair)
+                const uint32_t* kp = s_keep + (rel + 3) * 8;
                 uint32_t acc = 0u;
 #pragma unroll
-                for (int j = 0; j < K; j++) {
-                    const uint32_t keep = ((excl >> (2 * j)) & 1u ? 0u : 0x8000u) | ((excl >> (2 * j + 1)) & 1u ? 0u : 0x80000000u);
-                    acc |= pk_sub16(sp2[j], U2) & keep;
-                }
+                for (int j = 0; j < K; j++) acc |= pk_sub16(sp2[j], U2) & kp[j];
                 bad = acc != 0u;
 #else
 #pragma unroll
-                for (int k = 0; k < 2 * K; k++) bad |= Sv[k] <= uth && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
+                for (int k = 0; k < 2 * K; k++) bad |= (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) <= uth && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
 #endif
             } else {
 #pragma unroll
-                for (int k = 0; k < 2 * K; k++) bad |= Sv[k] * udiv < minS * 100 && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
+                for (int k = 0; k < 2 * K; k++) bad |= (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) * udiv < minS * 100 && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
             }
             const unsigned long long bal = __ballot(bad);
             const bool rejected = ((bal >> (threadIdx.x & 56)) & 0xFFull) != 0;          // any lane of my 8-lane group
@@ -1285,19 +1341,44 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
                 disp1[(size_t)y * w + x + minX1] = (int16_t)(d + minD * SG_DISP_SCALE);
             }
         }
+        // The end of the row: the mailbox loads for row y + 1, then the costs of row y + 2 into the registers this row has finished with.  (Measured in round 6,
+        // stage time of the bench's serial pass: the mailbox loads behind the own publish / in the winner pass / here, the cost loads in the winner pass / here:
+        // 0.1607 - 0.1617 ms per pair for five of the six combinations, 0.1667 for mailbox loads right behind the publish with the cost loads here.)
+        prefetch_mbox();
+        load_row(V, y + 2);
 #if !SGS8_EARLY_BARRIER
+#ifdef SGS8_PROBE
+        const unsigned long long pr_b0 = sgs8_clock(); PR_MARK(4);
+#endif
         __syncthreads();
+#ifdef SGS8_PROBE
+        { const unsigned long long pr_t1 = sgs8_clock(); pr_bar += pr_t1 - pr_b0; pr_cyc += pr_t1 - pr_t0; pr_rows++; PR_MARK(5);
+          const int wvp = threadIdx.x >> 6; const bool mb_edge = (wvp == 0 && strip > 0) || (wvp == (int)((TX - 1) >> 3) && strip < NS - 1);
+          const int cls = wvp == 5 ? 0 : mb_edge ? (direct ? 1 : 2) : -1;
+          if (cls >= 0 && y > 0) { pr_ph[cls][0]++; for (int i = 0; i < 9; i++) pr_ph[cls][1 + i] += pr_m[i]; } }
+#endif
         if (s_fail[y & 1]) stop = true;                           // a hand-off timed out: every wave leaves at the same row
 #endif
     };
-    load_row(Va, 0);
+    load_row(Va, 0); load_row(Vb, 1);
+    // The first two rows are waited for HERE.  Otherwise the scheduler is free to issue Va's loads behind Vb's, the wait-count pass merges "Va is the youngest load" from this entry edge into the
+    // loop header, and every second row starts with vmcnt(0) -- which for an outermost wave means the mailbox loads it issued a moment ago.
+    // (The wait is made by USING the loaded words -- an empty asm with every register as an input: a bare s_waitcnt builtin is hoisted above the loads.)
+#pragma unroll
+    for (int j = 0; j < K; j++) asm volatile("" :: "v"(Va[0][j]), "v"(Va[1][j]), "v"(Vb[0][j]), "v"(Vb[1][j]));
     for (int y = 0; y < h && !stop; y += 2) {
-        load_row(Vb, y + 1);
         run_row(Va, y);
         if (y + 1 >= h || stop) break;
-        load_row(Va, y + 2);
         run_row(Vb, y + 1);
     }
+#ifdef SGS8_PROBE
+    if ((threadIdx.x & 63) == 0) {
+        for (int c = 0; c < 3; c++) for (int i = 0; i < 10; i++) if (pr_ph[c][i]) atomicAdd(&g_sgs8_phase[c][i], pr_ph[c][i]);
+        const int wv = threadIdx.x >> 6;
+        if (wv == 5) { atomicAdd(&g_sgs8_probe[0], pr_rows); atomicAdd(&g_sgs8_probe[1], pr_cyc); atomicAdd(&g_sgs8_probe[2], pr_bar); }
+        if (wave_has_edge && (edgeL || edgeR || true)) { atomicAdd(&g_sgs8_probe[3], pr_rows); atomicAdd(&g_sgs8_probe[4], pr_cyc); atomicAdd(&g_sgs8_probe[5], pr_bar); atomicAdd(&g_sgs8_probe[6], pr_slow); atomicAdd(&g_sgs8_probe[7], pr_poll); }
+    }
+#endif
 }
 // ------------------------------------------------------------------ winner-takes-all, one pixel per 16 lanes, all pixels in parallel
 // S(p, d) = min(32767, sum of the five L_r) (all terms >= 0: equal to OpenCV's two saturating steps).  disp2 (the right-image
@@ -1740,7 +1821,8 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     }
     // checkpoints every 12 columns (measured at 8 / 12 / 16: 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage, but 4.32 / 4.38 / 4.33 k pairs/s for the whole
     // path -- 16 columns of costs in registers leave the kernels of the other streams less room beside it)
-    sgbm_rows8<12><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
+    if (costs_below_2_15) sgbm_rows8<12, true><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
+    else sgbm_rows8<12, false><<<dim3((h * 16 + 255) / 256, nb), 256, 0, s>>>(C, S04, ck, w1, h, D, P1, P2);
     sgbm_fill<<<(unsigned)((npb + 255) / 256), 256, 0, s>>>(disp_tmp, (int)npb, (int16_t)((p.minDisparity - 1) * SG_DISP_SCALE));
     e = hipMemsetAsync(disp2key, 0xFF, npb * 4, s);
     if (e != hipSuccess) return e;
@@ -1756,6 +1838,20 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
         static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
         if (test_hook == 1 && fail_out) { e = hipMemsetAsync(fail_out, 1, 4, s); if (e != hipSuccess) return e; }
     }
+#ifdef SGS8_PROBE
+    if (use8) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long pr[8]; (void)hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_sgs8_probe), sizeof(pr));
+        fprintf(stderr, "[sgs8 probe] nb %d NS %d TX %d | inner wave: rows %llu, cycles/row %.0f, barrier wait/row %.0f | edge waves: rows %llu, cycles/row %.0f, barrier wait/row %.0f, slow-path rows %llu (%.3f), poll cycles per slow row %.0f\n",
+                nb, NS, TX, pr[0], (double)pr[1] / (pr[0] ? pr[0] : 1), (double)pr[2] / (pr[0] ? pr[0] : 1), pr[3], (double)pr[4] / (pr[3] ? pr[3] : 1), (double)pr[5] / (pr[3] ? pr[3] : 1), pr[6], (double)pr[6] / (pr[3] ? pr[3] : 1), (double)pr[7] / (pr[6] ? pr[6] : 1));
+        unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sgs8_probe), z, sizeof(z));
+        unsigned long long ph[3][12]; (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_sgs8_phase), sizeof(ph));
+        const char* cn[3] = {"inner wave 5", "mailbox-edge wave, direct row", "mailbox-edge wave, slow row"};
+        for (int c = 0; c < 3; c++) { const double n = ph[c][0] ? (double)ph[c][0] : 1.0;
+            fprintf(stderr, "[sgs8 phase] %-30s rows %9llu | L2 + neighbours + tag check %.0f | L1, L3, publish %.0f | slow path %.0f | exchange writes %.0f | winner pass %.0f | barrier %.0f || first step %.0f, publish %.0f, take %.0f (cumulative cycles)\n", cn[c], ph[c][0], ph[c][1] / n, ph[c][2] / n, ph[c][3] / n, ph[c][4] / n, ph[c][5] / n, ph[c][6] / n, ph[c][7] / n, ph[c][8] / n, ph[c][9] / n); }
+        unsigned long long zz[3][12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sgs8_phase), zz, sizeof(zz));
+    }
+#endif
     sgbm_lrcheck<<<dim3((w + 255) / 256, h, nb), 256, 0, s>>>(disp_tmp, disp2key, w, h, w1, p.minDisparity, minX1, p.disp12MaxDiff > 0 ? p.disp12MaxDiff : 1, disp1);
     return hipGetLastError();
 }
