@@ -79,11 +79,6 @@ sgbm_prefilter(const uint8_t* __restrict__ left, const uint8_t* __restrict__ rig
 // Two barriers per row.  Dynamic LDS: ring u16 [SW][TX][D] | pixrow u8 [TX + 2 SW2][D] | lrow uint4 [TX + 2 SW2] | rrow uint4 [TX + 2 SW2 + D - 1].
 // CD / CSW2 / CTX: compile-time D, SW2, TX of the instantiation for stereo.cpp's configuration (80 disparities, SAD 11); 0 = run-time values.
 #define SGC_THREADS 512
-#ifndef SGC_PIXEL_OCTETS
-#define SGC_PIXEL_OCTETS 1
-#endif
-typedef short sg_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ sg_s2 sg_as_s2(uint32_t v) { return __builtin_bit_cast(sg_s2, v); }
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) + __builtin_bit_cast(us2v, b))); }
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2v)(__builtin_bit_cast(us2v, a) - __builtin_bit_cast(us2v, b))); }
@@ -132,44 +127,30 @@ __device__ __forceinline__ void sgbm_cost_strip(const uint3* __restrict__ planes
         const uint8_t* pxd = pixrow + d;
         auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };       // strip column x (may be negative: apron)
         if (src && r + 1 < h) { lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre; if (r + 2 < h) pre = wide(src[(size_t)(r + 2) * w]); }      // row r + 1 for the next trip; row r + 2 on its way
-#if SGC_PIXEL_OCTETS
         {
             // pixel costs, one thread per (strip column i, eight consecutive disparities): the left pixel's word is read ONCE for the eight, the right pixels are
             // eight consecutive words, and the eight cost bytes leave as one 8-byte write (round 5: the (d, column chunk) layout read a left and a right word
             // and wrote one byte per cost -- 107 KB of LDS traffic per row and block against 60 KB now; the kernel's LDS pipe was busy 0.64 of the time)
-            const sg_s2 zero = {0, 0};
             const int NO = D >> 3;
             for (int it = tid; it < AW * NO; it += SGC_THREADS) {
                 const int o = it / AW, i = it - o * AW;
                 const uint4 L = lrow[i];
-                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z);
+                const us2v u = __builtin_bit_cast(us2v, L.x), u0 = __builtin_bit_cast(us2v, L.y), u1 = __builtin_bit_cast(us2v, L.z);
                 const uint4* rp = rrow + (i + (D - 1) - 8 * o);      // right pixel of disparity 8 o + dd: image column of i minus the disparity
                 uint32_t pk[2] = {0u, 0u};
 #pragma unroll
                 for (int dd = 0; dd < 8; dd++) {
                     const uint4 R = rp[-dd];
-                    const sg_s2 v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
-                    const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
-                    const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
-                    const sg_s2 m = __builtin_elementwise_min(c0, c1);
+                    const us2v v = __builtin_bit_cast(us2v, R.x), v0 = __builtin_bit_cast(us2v, R.y), v1 = __builtin_bit_cast(us2v, R.z);
+                    // (saturating differences: see sgbm_cost_strip_reg)
+                    const us2v c0 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(u, v1), __builtin_elementwise_sub_sat(v0, u));
+                    const us2v c1 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(v, u1), __builtin_elementwise_sub_sat(u0, v));
+                    const us2v m = __builtin_elementwise_min(c0, c1);
                     pk[dd >> 2] |= (uint32_t)(uint8_t)((int)m.x + ((int)m.y >> 2)) << (8 * (dd & 3));
                 }
                 *reinterpret_cast<uint2*>(pixrow + (size_t)i * D + 8 * o) = make_uint2(pk[0], pk[1]);
             }
         }
-#else
-        if (active) {
-            const sg_s2 zero = {0, 0};
-            for (int i = chunk; i < AW; i += nchunk) {
-                const uint4 L = lrow[i], R = rrow[i + (D - 1) - d];      // right pixel: image column of i minus the disparity
-                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z), v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
-                const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
-                const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
-                const sg_s2 m = __builtin_elementwise_min(c0, c1);
-                pixrow[i * D + d] = (uint8_t)((int)m.x + ((int)m.y >> 2));
-            }
-        }
-#endif
         __syncthreads();
         if (ncol > 0) {
             int sum = 0;
@@ -299,21 +280,22 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
             if (r + 2 < h) { advance(r + 3); pre = sg_prefilter_record(win, xi, w, ftzero); }      // the window now holds rows r + 1 .. r + 3: the record of row r + 2
         }
         {
-            const sg_s2 zero = {0, 0};
             constexpr int NO = D >> 3;
             for (int it = tid; it < AW * NO; it += SGC_THREADS) {
                 const int o = it / AW, i = it - o * AW;
                 const uint4 L = lrow[i];
-                const sg_s2 u = sg_as_s2(L.x), u0 = sg_as_s2(L.y), u1 = sg_as_s2(L.z);
+                const us2v u = __builtin_bit_cast(us2v, L.x), u0 = __builtin_bit_cast(us2v, L.y), u1 = __builtin_bit_cast(us2v, L.z);
                 const uint4* rp = rrow + (i + (D - 1) - 8 * o);
                 uint32_t pk[2] = {0u, 0u};
 #pragma unroll
                 for (int dd = 0; dd < 8; dd++) {
                     const uint4 R = rp[-dd];
-                    const sg_s2 v = sg_as_s2(R.x), v0 = sg_as_s2(R.y), v1 = sg_as_s2(R.z);
-                    const sg_s2 c0 = __builtin_elementwise_max(__builtin_elementwise_max(zero, u - v1), v0 - u);
-                    const sg_s2 c1 = __builtin_elementwise_max(__builtin_elementwise_max(zero, v - u1), u0 - v);
-                    const sg_s2 m = __builtin_elementwise_min(c0, c1);
+                    const us2v v = __builtin_bit_cast(us2v, R.x), v0 = __builtin_bit_cast(us2v, R.y), v1 = __builtin_bit_cast(us2v, R.z);
+                    // max(0, a - b) of values below 2^15 is the unsigned saturating difference (v_pk_sub_u16 clamp), and max(0, p, q) = max(max(0, p), max(0, q)):
+                    // seven packed instructions per cost instead of nine (round 6)
+                    const us2v c0 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(u, v1), __builtin_elementwise_sub_sat(v0, u));
+                    const us2v c1 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(v, u1), __builtin_elementwise_sub_sat(u0, v));
+                    const us2v m = __builtin_elementwise_min(c0, c1);
                     pk[dd >> 2] |= (uint32_t)(uint8_t)((int)m.x + ((int)m.y >> 2)) << (8 * (dd & 3));
                 }
                 *reinterpret_cast<uint2*>(pixrow + (size_t)i * D + 8 * o) = make_uint2(pk[0], pk[1]);
@@ -675,14 +657,14 @@ __device__ __forceinline__ uint32_t pk_addsat15(uint32_t a, uint32_t b)
 __device__ __forceinline__ void sg_step_pk8(uint32_t (&L)[4], int& minPrev, const uint32_t (&Cp)[4], uint32_t P1P1, int P2, bool act, bool last)
 {
     constexpr uint32_t MAXMAX = (uint32_t)SG_MAXC | ((uint32_t)SG_MAXC << 16);
-    const uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXMAX, (int)L[3]);           // row_shr:1 (lane 0 of the row: MAX_COST)
-    uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);                 // row_shl:1
-    rgt = last ? MAXMAX : rgt;
+    const uint32_t MAXP = pk_add16(MAXMAX, P1P1);                                   // L + P1 once per pair: sg_step8
     const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
     uint32_t Ln[4], LP[4], m = 0xFFFFFFFFu;
-    const uint32_t lftp = pk_add16(lft, P1P1), rgtp = pk_add16(rgt, P1P1);      // L + P1 once per pair: sg_step8
 #pragma unroll
     for (int j = 0; j < 4; j++) LP[j] = pk_add16(L[j], P1P1);
+    const uint32_t lftp = (uint32_t)sg_dpp<0x111>((int)MAXP, (int)LP[3]);           // row_shr:1 (lane 0 of the row: MAX_COST + P1)
+    uint32_t rgtp = (uint32_t)sg_dpp<0x101>((int)MAXP, (int)LP[0]);                 // row_shl:1
+    rgtp = last ? MAXP : rgtp;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t lm = __builtin_amdgcn_alignbyte(LP[j], j > 0 ? LP[j - 1] : lftp, 2);
@@ -1012,17 +994,17 @@ template <int K>
 __device__ __forceinline__ void sg_step8(uint32_t (&L)[K], int& minPrev, const uint32_t (&Cp)[K], uint32_t P1P1, int P2, bool first, bool last)
 {
     constexpr uint32_t MAXMAX = (uint32_t)SG_MAXC | ((uint32_t)SG_MAXC << 16);
-    uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXMAX, (int)L[K - 1]);          // row_shr:1: the left lane's last pair
-    uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXMAX, (int)L[0]);              // row_shl:1: the right lane's first pair
-    lft = first ? MAXMAX : lft;                                                   // lane 0 of the GROUP (lane 8 of the DPP row would see the other group's lane 7)
-    rgt = last ? MAXMAX : rgt;
+    // L + P1 once per pair (round 6): the d - 1 / d + 1 neighbours are byte-aligned out of these sums (v_pk_add_u16 works on the halves separately, so adding before
+    // or after the alignment is the same bits); the group's edges see MAX_COST + P1
+    const uint32_t MAXP = pk_add16(MAXMAX, P1P1);
     const uint32_t dd = (uint32_t)(minPrev + P2) * 0x00010001u;
     uint32_t Ln[K], LP[K], m = 0xFFFFFFFFu;
-    // L + P1 once per pair (round 6): the d - 1 / d + 1 neighbours are byte-aligned out of these sums (v_pk_add_u16 works on the halves separately, so adding before
-    // or after the alignment is the same bits); the group's edges add P1 to their MAX_COST / neighbour-lane word the same way
-    lft = pk_add16(lft, P1P1); rgt = pk_add16(rgt, P1P1);
 #pragma unroll
     for (int j = 0; j < K; j++) LP[j] = pk_add16(L[j], P1P1);
+    uint32_t lft = (uint32_t)sg_dpp<0x111>((int)MAXP, (int)LP[K - 1]);           // row_shr:1: the left lane's last pair
+    uint32_t rgt = (uint32_t)sg_dpp<0x101>((int)MAXP, (int)LP[0]);               // row_shl:1: the right lane's first pair
+    lft = first ? MAXP : lft;                                                     // lane 0 of the GROUP (lane 8 of the DPP row would see the other group's lane 7)
+    rgt = last ? MAXP : rgt;
 #pragma unroll
     for (int j = 0; j < K; j++) {
         const uint32_t lm = __builtin_amdgcn_alignbyte(LP[j], j > 0 ? LP[j - 1] : lft, 2);           // (slot 2j-1, slot 2j) + P1
@@ -1107,6 +1089,7 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
     const bool first = li == 0, last = li == 7;
     const uint32_t P1P1 = (uint32_t)P1 * 0x00010001u;
     const int udiv = 100 - uniquenessRatio;
+    const unsigned umagic = udiv > 1 ? (unsigned)(0x100000000ull / (unsigned)udiv) + 1u : 0u;
     uint32_t L1[K], L2[K], L3[K]; int m1 = 0, m2 = 0, m3 = 0;
 #pragma unroll
     for (int j = 0; j < K; j++) L1[j] = L2[j] = L3[j] = 0u;
@@ -1173,7 +1156,7 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
         // (L1 flows right, L3 flows left), so a wave with a mailbox edge steps its OUTGOING direction first and publishes it at once -- the neighbour strip has
         // almost a whole row to see it -- and only then looks at the incoming message (round 6; before, both directions were stepped, published behind the second
         // one, and stepped again whenever the prefetch had missed).
-        bool direct = true;
+        bool direct = true; (void)direct;                         // (read by the -DSGS8_PROBE build only)
         if (wave_has_edge) {
             if (outL && !(edgeL && y > 0)) {
 #pragma unroll
@@ -1306,7 +1289,10 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             const int minS = best >> 8, bestDisp = best & 255;
             bool bad = false;
             if (udiv > 0) {                                       // (uniform)
-                const int uth = minS > 0 ? sg_div_small(100 * minS - 1, udiv) : -1;
+                // (100 minS - 1) / udiv by a multiply-high: n < 2^22 and udiv <= 100, so floor(n m / 2^32) with m = floor(2^32 / udiv) + 1 is the exact quotient
+                // (n = q d + r: the product's excess over q is (r + n e / 2^32) / d with e <= d, and n e < 2^32); udiv = 1 has no 32-bit m
+                const int un = 100 * minS - 1;
+                const int uth = minS > 0 ? (udiv == 1 ? un : (int)__umulhi((unsigned)un, umagic)) : -1;
 #if SGS8_PACKED_UNIQ
                 // "S <= uth" for a pair at once: S - (uth + 1) borrows into bit 15 of its half exactly when S <= uth (S <= 32767; uth + 1 clamped to 32768 keeps the
                 // subtraction inside 16 bits); the three disparities around the winner are masked out by a per-lane bit pattern: 2 + 2 instructions per pair instead of 5 per value
@@ -1801,7 +1787,6 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
     // advances as soon as all NS strips of the lowest unfinished frame are resident -- which needs NS block slots for this launch even when `concurrent` sweeps
     // (the SGBM streams of the batched path) share the device.  Checked against the occupancy the runtime reports for this kernel, block size and LDS; when it
     // does not hold the caller takes form 1 (no cross-block waits).  SSM_SGBM_TEST_TIMEOUT=2 (tests) pretends it does not.
-    int per_cu_w = 0;                                        // resident blocks per CU of this (wide-strip) geometry
     {
         static std::mutex mu; static std::map<std::tuple<int, const void*, int, size_t>, int> occ;
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1817,7 +1802,6 @@ static hipError_t sgbm_aggregate2(const uint16_t* C, uint16_t* S04, uint16_t* ck
         }
         static const int test_hook = [] { const char* v = getenv("SSM_SGBM_TEST_TIMEOUT"); return v ? atoi(v) : 0; }();
         if (test_hook == 2 || (long)per_cu * sg_num_cus() < (long)NS * (concurrent > 0 ? concurrent : 1)) return hipErrorCooperativeLaunchTooLarge;
-        per_cu_w = per_cu;
     }
     // checkpoints every 12 columns (measured at 8 / 12 / 16: 0.1966 / 0.1933 / 0.1918 ms per pair for the SGBM stage, but 4.32 / 4.38 / 4.33 k pairs/s for the whole
     // path -- 16 columns of costs in registers leave the kernels of the other streams less room beside it)
