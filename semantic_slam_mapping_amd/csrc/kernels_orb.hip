@@ -376,10 +376,16 @@ blur_mfma_kernel(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, Or
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             pre[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-            if (sok[k]) pre[k] = *reinterpret_cast<const uint4*>(src + (size_t)reflect101(y0 - 3 + srow[k], h) * stride + (X0 - 16 + 16 * sq[k]));
+            // (a 32-bit offset from the block's uniform base: one register per staging slot instead of a 64-bit pointer.  With pointers the kernel spilled one, and a
+            // spill's reload waits with vmcnt(0), i.e. for the load issued in front of it: the three prefetches of a step went out one HBM round trip apart -- round 6)
+            if (sok[k]) pre[k] = *reinterpret_cast<const uint4*>(src + (uint32_t)(reflect101(y0 - 3 + srow[k], h) * stride + (X0 - 16 + 16 * sq[k])));
         }
     };
     fetch(0);
+    // The coefficient tables are waited for HERE, by using them (an empty asm with the registers as inputs).  Otherwise their loads are still pending on the loop's
+    // entry edge, the wait-count pass merges that into the loop header, and every step's first MFMAs wait with vmcnt(3) .. vmcnt(0) -- for the three prefetch
+    // loads the step has just issued: the prefetch never ran ahead (round 6; the same pattern as sgbm_sweep8's).
+    asm volatile("" :: "v"(B0), "v"(B1), "v"(Fs), "v"(Fn));
     for (int y0 = 0; y0 < h; y0 += BLUR_ROWS) {
         // stage p - 128 (the fetch was issued one step ago), then start the next step's loads
 #pragma unroll

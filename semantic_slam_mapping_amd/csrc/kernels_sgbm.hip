@@ -233,13 +233,12 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
     // staging: thread k < AW + RW owns one pixel column of the left / right image and makes its pre-filter record (value | min | max of the clipped x-Sobel and of the raw
     // intensity, sgbm_prefilter's arithmetic) for one row per trip from a rolling 3 x 5 window of raw pixels: one unaligned 8-byte load per row
     const uint8_t* src = nullptr; uint4 pre = make_uint4(0, 0, 0, 0);
-    int xi = 0, wofs = 0; uint2 win[3]; uint2 nxt = make_uint2(0u, 0u);
-    auto row_bytes = [&](int y) -> uint2 {             // the 8 bytes at column wstart of image row y (clamped), as two dwords
+    int xi = 0, wofs = 0; uint2 win[3]; unsigned long long nxt = 0ull;      // (one 64-bit value: as a uint2 the compiler copied the freshly loaded pair with its halves swapped at the branch's join -- and waited for the load there)
+    auto row_bytes = [&](int y) -> unsigned long long {             // the 8 bytes at column wstart of image row y (clamped)
         const uint8_t* q = src + (size_t)min(max(y, 0), h - 1) * w;
-        uint2 v; __builtin_memcpy(&v, q, 8); return v;
+        unsigned long long v; __builtin_memcpy(&v, q, 8); return v;
     };
-    auto unpack = [&](const uint2 v, uint2& o) {      // window position i = byte wofs + i of the 8 loaded (wofs -2 .. 5: positions outside the 8 bytes are columns outside the image)
-        const unsigned long long b = ((unsigned long long)v.y << 32) | v.x;
+    auto unpack = [&](const unsigned long long b, uint2& o) {      // window position i = byte wofs + i of the 8 loaded (wofs -2 .. 5: positions outside the 8 bytes are columns outside the image)
         const unsigned long long t = wofs >= 0 ? b >> (8 * wofs) : b << (8 * -wofs);
         o.x = (uint32_t)t; o.y = (uint32_t)(t >> 32);
     };
@@ -254,6 +253,7 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
     auto advance = [&](int ynew) {                      // the window moves one row down; row ynew (clamped) arrives from `nxt`, the load of the row behind it is issued
         win[0] = win[1]; win[1] = win[2];
         unpack(nxt, win[2]);
+        __builtin_amdgcn_sched_barrier(0);                // (the next load stays BEHIND the use of the previous one: hoisted above it, the use's vmcnt(0) waits for the new load)
         nxt = row_bytes(ynew + 1);
     };
     uint32_t ring[SW][NPAIR], Cacc[NPAIR], hs0[NPAIR];
@@ -275,10 +275,7 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
         const uint4* lrow = lrow2 + (size_t)(r & 1) * (AW + RW); const uint4* rrow = lrow + AW;
         const uint8_t* pxd = pixrow + d;
         auto px = [&](int x) -> int { const int i = x + SW2; return pxd[(EDGE ? min(max(i, lo), hi) : i) * D]; };
-        if (src && r + 1 < h) {
-            lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre;
-            if (r + 2 < h) { advance(r + 3); pre = sg_prefilter_record(win, xi, w, ftzero); }      // the window now holds rows r + 1 .. r + 3: the record of row r + 2
-        }
+        if (src && r + 1 < h) lrow2[(size_t)((r + 1) & 1) * (AW + RW) + tid] = pre;      // the record of row r + 1, made during the previous row
         {
             constexpr int NO = D >> 3;
             for (int it = tid; it < AW * NO; it += SGC_THREADS) {
@@ -302,6 +299,10 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
             }
         }
         __syncthreads();
+        // The staging threads move their window BEHIND the barrier (round 6): using the row loaded a row ago is a vmcnt(0) (the stores of a row are conditional,
+        // no count of younger operations is guaranteed), i.e. it also waits for the acknowledgement of this wave's cost stores of the previous row.  At the top of
+        // the row those had just been issued and the other waves sat at the barrier until the staging waves came; here the stores are half a row old.
+        if (src && r + 2 < h) { advance(r + 3); pre = sg_prefilter_record(win, xi, w, ftzero); }      // the window now holds rows r + 1 .. r + 3: the record of row r + 2
         if (ncol > 0) {
             int sum = 0;
 #pragma unroll
@@ -329,7 +330,7 @@ __device__ __forceinline__ void sgbm_cost_strip_reg(const uint8_t* __restrict__ 
     };
     if (src) {
         // window = rows -1 (= 0), 0, 1 -> the record of row 0; then rows 0, 1, 2 -> row 1's, kept in `pre`
-        uint2 t0 = row_bytes(0), t1 = row_bytes(1);
+        const unsigned long long t0 = row_bytes(0), t1 = row_bytes(1);
         unpack(t0, win[0]); unpack(t0, win[1]); unpack(t1, win[2]);
         nxt = row_bytes(2);
         lrow2[tid] = sg_prefilter_record(win, xi, w, ftzero);
