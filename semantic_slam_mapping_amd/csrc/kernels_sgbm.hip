@@ -681,6 +681,7 @@ __device__ __forceinline__ void sg_step_pk8(uint32_t (&L)[4], int& minPrev, cons
 }
 template <int SEG, bool FAST>
 __global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(2, 2)))      // (167 registers would allow three waves per SIMD: measured, the stereo path as a whole loses 3 % -- 5.47 k vs 5.68 k pairs/s -- with the kernel's own time unchanged: it is HBM-bound and the third wave only takes bandwidth from the kernels of the other streams earlier)
 sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uint16_t* __restrict__ ck_all, int w1, int h, int D, int P1, int P2)
 {
     const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, li = threadIdx.x & 15, NL = D >> 3;
@@ -707,23 +708,24 @@ sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uin
             for (int u = 0; u < SEG; u++) sg_step_pk8(L, mp, Cq[u], P1P1, P2, act, last);
             if (live) ck[(size_t)(s + 1) * NL] = make_uint4(L[0], L[1], L[2], L[3]);
         };
+        // The next segment's loads are UNCONDITIONAL (the index clamped, a row's last prefetch repeats a segment): behind a conditional prefetch the wait-count pass
+        // has no guaranteed number of younger loads and waits for the current segment with vmcnt(0), i.e. for the prefetch it has just issued -- the double
+        // buffer never overlapped a load with a step (round 6, found in the ISA: L x 12, s_waitcnt vmcnt(0)).
         load_seg(Ca, 0);
         for (int s = 0; s < nseg - 1; s += 2) {
-            if (s + 1 < nseg - 1) load_seg(Cb, s + 1);
+            load_seg(Cb, min(s + 1, nseg - 1));
             fwd_seg(Ca, s);
             if (s + 1 >= nseg - 1) break;
-            if (s + 2 < nseg - 1) load_seg(Ca, s + 2);
+            load_seg(Ca, min(s + 2, nseg - 1));
             fwd_seg(Cb, s + 1);
         }
     }
     // ---- pass 2: segments right to left; L0 forward from the checkpoint, L4 backward, the sum out
     uint32_t R[4] = {0u, 0u, 0u, 0u}; int mpr = 0;
     uint32_t Fa[4], Fb[4];
-    auto load_ck = [&](uint32_t (&F)[4], int s) {
-        if (s > 0) ld(F, ck + (size_t)s * NL);
-        else { F[0] = F[1] = F[2] = F[3] = 0u; }
-    };
+    auto load_ck = [&](uint32_t (&F)[4], int s) { ld(F, ck + (size_t)min(max(s, 1), nseg - 1) * NL); };      // (unconditional like the segments; segment 0 starts from zero: seg_run)
     auto seg_run = [&](const uint32_t (&Cq)[SEG][4], uint32_t (&F)[4], int s) {
+        if (s <= 0) { F[0] = F[1] = F[2] = F[3] = 0u; }                           // (wave-uniform)
         uint32_t m = pk_min16(pk_min16(F[0], F[1]), pk_min16(F[2], F[3]));
         m = act ? m : 0xFFFFFFFFu;
         int mpf = sg_rowmin((int)min(m & 0xFFFFu, m >> 16));
@@ -748,10 +750,10 @@ sgbm_rows8(const uint16_t* __restrict__ C_all, uint16_t* __restrict__ S_all, uin
     };
     load_seg(Ca, nseg - 1); load_ck(Fa, nseg - 1);
     for (int s = nseg - 1; s >= 0; s -= 2) {
-        if (s - 1 >= 0) { load_seg(Cb, s - 1); load_ck(Fb, s - 1); }
+        load_seg(Cb, max(s - 1, 0)); load_ck(Fb, s - 1);
         seg_run(Ca, Fa, s);
         if (s - 1 < 0) break;
-        if (s - 2 >= 0) { load_seg(Ca, s - 2); load_ck(Fa, s - 2); }
+        load_seg(Ca, max(s - 2, 0)); load_ck(Fa, s - 2);
         seg_run(Cb, Fb, s - 1);
     }
 }
