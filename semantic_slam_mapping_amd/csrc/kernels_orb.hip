@@ -1369,20 +1369,19 @@ orient_kernel(OrbGeom g, unsigned long long umax_pack, const uint8_t* __restrict
     }
     const int koff = left ? -16 : 0;
     const uint8_t* fr = pyr + (size_t)f * g.pyr_bytes;
-    uint4 px[OR_KPW]; bool ok[OR_KPW];
+    // The OR_KPW records first, then the OR_KPW pixel loads, each group UNCONDITIONAL (an empty or missing slot reads a harmless address): with the loads
+    // inside `if (rec.oidx >= 0)` the compiler issued record, wait, pixels, next record, vmcnt(0) (which waits for the pixels too) ... -- eight memory round trips
+    // one after the other per wave instead of two (round 6, found in the kernel's load / wait listing).
+    uint4 px[OR_KPW]; bool ok[OR_KPW]; KpRec rec[OR_KPW];
+#pragma unroll
+    for (int q = 0; q < OR_KPW; q++) rec[q] = recs[(size_t)f * g.sel_total + min(slot0 + q, g.sel_total - 1)];
 #pragma unroll
     for (int q = 0; q < OR_KPW; q++) {
-        ok[q] = false; px[q] = make_uint4(0, 0, 0, 0);
-        if (slot0 + q < g.sel_total) {
-            const KpRec rec = recs[(size_t)f * g.sel_total + slot0 + q];
-            ok[q] = rec.oidx >= 0;
-            if (ok[q]) {
-                // keypoints sit >= 19 px from every border: [x - 16, x + 16) x [y - 15, y + 15] lies inside the level
-                const uint8_t* p = fr + rec.off + v * (int)(rec.stride_level & 0xFFFFu) + koff;
-                uint4 t; __builtin_memcpy(&t, p, 16);                    // unaligned 16-byte load
-                px[q] = t;
-            }
-        }
+        ok[q] = slot0 + q < g.sel_total && rec[q].oidx >= 0;
+        // keypoints sit >= 19 px from every border: [x - 16, x + 16) x [y - 15, y + 15] lies inside the level
+        const uint8_t* p = ok[q] ? fr + rec[q].off + v * (int)(rec[q].stride_level & 0xFFFFu) + koff : fr;
+        uint4 t; __builtin_memcpy(&t, p, 16);                            // unaligned 16-byte load
+        px[q] = t;
     }
 #pragma unroll
     for (int q = 0; q < OR_KPW; q++) {
