@@ -1030,21 +1030,8 @@ __device__ __forceinline__ int sg_min8(int v)
     return v;
 }
 template <int K> __device__ __forceinline__ void sg_load8(uint32_t (&d)[K], const uint16_t* p) { __builtin_memcpy(d, p, 4 * K); }      // 2 K u16, 4-byte aligned
-// SGS8_EARLY_BARRIER=1 (ablation, measured round 5: 3979 vs 3986 us per 64 pairs -- no change): the row's barrier right behind the exchange writes, the next row's
-// neighbour reads issued behind it so that their LDS latency passes under the winner pass
-#ifndef SGS8_EARLY_BARRIER
-#define SGS8_EARLY_BARRIER 0
-#endif
 // exchange slots of a column: NG x 8 dwords, padded to SGS8_XSTRIDE so that the eight columns of a wave fall into different LDS banks (48 dwords: columns g and g + 4 collide)
-#ifndef SGS8_XPAD
 #define SGS8_XPAD 8
-#endif
-#ifndef SGS8_EDGE_PRIO
-#define SGS8_EDGE_PRIO 1
-#endif
-#ifndef SGS8_PACKED_UNIQ
-#define SGS8_PACKED_UNIQ 1
-#endif
 #ifdef SGS8_PROBE
 // a clock read no instruction is scheduled across (the first probes were moved behind the row's first wait by the scheduler and under-counted the row)
 __device__ __forceinline__ unsigned long long sgs8_clock() { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = clock64(); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -1121,11 +1108,9 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
     for (int j = 0; j < NG; j++) pf[j] = 0;
     const bool wave_has_edge = ((threadIdx.x & ~63) == 0) || ((int)(threadIdx.x | 63) >> 3) >= TX - 1;      // wave-uniform
     const bool wave_mbox_l = (threadIdx.x >> 6) == 0 && strip > 0, wave_mbox_r = (int)(threadIdx.x >> 6) == ((TX - 1) >> 3) && strip < NS - 1;      // it holds edgeL / edgeR lanes
-#if SGS8_EDGE_PRIO
     // the waves that hold a strip's outermost columns do more per row (publish, poll / prefetch) and everybody waits for them at the row's barrier: they issue first
     if (wave_has_edge) __builtin_amdgcn_s_setprio(3);
-#endif
-    // the neighbouring columns' states of the previous row: read from LDS right behind the row's barrier (SGS8_EARLY_BARRIER), i.e. one winner pass ahead of their use
+    // the neighbouring columns' states of the previous row (LDS)
     uint32_t nl[NG], nr[NG];
 #pragma unroll
     for (int j = 0; j < NG; j++) nl[j] = nr[j] = 0u;              // "row -1": OpenCV's zeroed border
@@ -1140,7 +1125,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #define PR_MARK(i_)
 #endif
         // ---- the neighbouring columns' states of row y - 1 (LDS; the strip's outermost columns: the mailbox or the zeroed border, below)
-#if !SGS8_EARLY_BARRIER
         const int pp = (y + 1) & 1;
         {   const uint32_t* p = xslot(pp, 0, g > 0 ? g - 1 : 0);
 #pragma unroll
@@ -1149,7 +1133,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #pragma unroll
             for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
         }
-#endif
         const bool outL = g == 0, outR = g >= TX - 1;
         // the vertical direction needs no neighbour: it runs first, in front of the first use of the prefetched mailbox words (their loads were issued at the end of
         // the previous row: SGS8_PF_POS)
@@ -1254,20 +1237,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
             for (int j = 0; j < K; j++) q[j * 8] = L3[j];
             q[K * 8] = (uint32_t)m3;
         }
-#if SGS8_EARLY_BARRIER
-        // The row's ONE barrier sits here, behind the exchange writes, and the next row's neighbour states are fetched right behind it: their LDS latency (all fifteen
-        // waves read at once) passes under the winner pass instead of at the head of the next row, where nothing else was ready to issue.  The winner pass itself
-        // needs no barrier: a group's S row in LDS is written and read by one wave.  (Parity double buffering as before: row y + 1's writes land in the other half.)
-        __syncthreads();
-        if (s_fail[y & 1]) { stop = true; return; }               // a hand-off timed out: every wave leaves at the same row
-        {   const uint32_t* p = xslot(y & 1, 0, g > 0 ? g - 1 : 0);
-#pragma unroll
-            for (int j = 0; j < NG; j++) nl[j] = p[j * 8];
-            const uint32_t* q = xslot(y & 1, 1, g < ng - 1 ? g + 1 : g);
-#pragma unroll
-            for (int j = 0; j < NG; j++) nr[j] = q[j * 8];
-        }
-#endif
         PR_MARK(3);
         // ---- the winner pass of the group's pixel: S = min(32767, S04 + L1 + L2 + L3)
         {
@@ -1296,7 +1265,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
                 // (n = q d + r: the product's excess over q is (r + n e / 2^32) / d with e <= d, and n e < 2^32); udiv = 1 has no 32-bit m
                 const int un = 100 * minS - 1;
                 const int uth = minS > 0 ? (udiv == 1 ? un : (int)__umulhi((unsigned)un, umagic)) : -1;
-#if SGS8_PACKED_UNIQ
                 // "S <= uth" for a pair at once: S - (uth + 1) borrows into bit 15 of its half exactly when S <= uth (S <= 32767; uth + 1 clamped to 32768 keeps the
                 // subtraction inside 16 bits); the three disparities around the winner are masked out by a per-lane bit pattern: 2 + 2 instructions per pair instead of 5 per value
                 const uint32_t U2 = (uint32_t)min(uth + 1, 32768) * 0x00010001u;
@@ -1308,10 +1276,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
 #pragma unroll
                 for (int j = 0; j < K; j++) acc |= pk_sub16(sp2[j], U2) & kp[j];
                 bad = acc != 0u;
-#else
-#pragma unroll
-                for (int k = 0; k < 2 * K; k++) bad |= (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) <= uth && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
-#endif
             } else {
 #pragma unroll
                 for (int k = 0; k < 2 * K; k++) bad |= (int)((sp2[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) * udiv < minS * 100 && (unsigned)(li * 2 * K + k - bestDisp + 1) > 2u;
@@ -1335,7 +1299,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
         // 0.1607 - 0.1617 ms per pair for five of the six combinations, 0.1667 for mailbox loads right behind the publish with the cost loads here.)
         prefetch_mbox();
         load_row(V, y + 2);
-#if !SGS8_EARLY_BARRIER
 #ifdef SGS8_PROBE
         const unsigned long long pr_b0 = sgs8_clock(); PR_MARK(4);
 #endif
@@ -1347,7 +1310,6 @@ sgbm_sweep8(const uint16_t* __restrict__ C_all, const uint16_t* __restrict__ S_a
           if (cls >= 0 && y > 0) { pr_ph[cls][0]++; for (int i = 0; i < 9; i++) pr_ph[cls][1 + i] += pr_m[i]; } }
 #endif
         if (s_fail[y & 1]) stop = true;                           // a hand-off timed out: every wave leaves at the same row
-#endif
     };
     load_row(Va, 0); load_row(Vb, 1);
     // The first two rows are waited for HERE.  Otherwise the scheduler is free to issue Va's loads behind Vb's, the wait-count pass merges "Va is the youngest load" from this entry edge into the
