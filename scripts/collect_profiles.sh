@@ -36,6 +36,7 @@ elif [ "$1" = "pmc_segnet" ]; then
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_seg -o runc -- python3 bench.py $A > $O/p_fetch_seg.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_seg -o runc -- python3 bench.py $A > $O/p_write_seg.log 2>&1
   sha_of_sources $O/p_fetch_seg
+  python3 scripts/pmc_traffic.py $O/p_fetch_seg $O/p_write_seg profiles/${ROUND:-r06}_segnet_traffic.json 64 128 > /dev/null      # (the box's copy: a `stats` pass in the same call quotes it)
   tail -1 $O/p_fetch_seg.log | cut -c1-200
 elif [ "$1" = "pmc_stereo" ]; then
   rm -rf $O/p_sq_st $O/p_fetch_st $O/p_write_st
@@ -44,6 +45,7 @@ elif [ "$1" = "pmc_stereo" ]; then
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch_st -o runc -- python3 bench.py $A > $O/p_fetch_st.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write_st -o runc -- python3 bench.py $A > $O/p_write_st.log 2>&1
   sha_of_sources $O/p_fetch_st
+  python3 scripts/pmc_traffic.py $O/p_fetch_st $O/p_write_st profiles/${ROUND:-r06}_stereo_traffic.json 32 64 > /dev/null
   tail -2 $O/p_sq_st.log | cut -c1-300
 else
   export SSM_BENCH_H2D=0
@@ -52,5 +54,6 @@ else
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/p_fetch -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_fetch.log 2>&1
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/p_write -o runc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-other-configs > $O/p_write.log 2>&1
   sha_of_sources $O/p_fetch
+  python3 scripts/pmc_traffic.py $O/p_fetch $O/p_write profiles/${ROUND:-r06}_traffic.json 250 > /dev/null
   tail -3 $O/p_sq.log | cut -c1-300
 fi
