@@ -829,7 +829,9 @@ hipError_t k_fast(int n, const OrbGeom& g, const uint8_t* pyr, cand_t* cand, int
     // counters in FRONT of the maxima (k_fast_ncand_pad ints, one allocation), so that this is one fill; any other layout takes the two fills
     hipError_t e;
     const ptrdiff_t gap = cellmax - ncand;
-    if (gap >= (ptrdiff_t)n * g.nlevels && gap <= (ptrdiff_t)1 << 24) e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * ((size_t)gap + (size_t)n * g.cells_total + 4), s);
+    // (a whole number of 16-byte words: the runtime splits any other size into two fill kernels, 4.7 us each in a per-frame call; the up to three extra ints are the
+    // head of the retry list, which fast_need_kernel writes afterwards)
+    if (gap >= (ptrdiff_t)n * g.nlevels && gap <= (ptrdiff_t)1 << 24) e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * (((size_t)gap + (size_t)n * g.cells_total + 4 + 3) & ~(size_t)3), s);
     else { e = hipMemsetAsync(ncand, 0, sizeof(int32_t) * n * g.nlevels, s); if (e == hipSuccess) e = hipMemsetAsync(cellmax, 0, sizeof(int32_t) * ((size_t)n * g.cells_total + 4), s); }
     if (e != hipSuccess) return e;
     // SSM_FAST_STAGE_CAP (tests): a smaller staging area forces the per-candidate global path that tiles with more than FT_STAGE maxima take
