@@ -88,3 +88,47 @@ def test_frame_block_partition():
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in blocks]
         assert max(sizes) - min(sizes) <= 1
+
+
+# kernels whose software prefetch a register spill silently turns into a synchronous load (a reload is followed by s_waitcnt vmcnt(0): DESIGN.md s.4.4) -- the hot
+# instantiations of the bench's configurations, by mangled-name prefix
+_NO_SPILL = {
+    "kernels_sgbm.hip": ["_Z11sgbm_sweep8ILi5ELb1E", "_Z10sgbm_rows8ILi12ELb1E", "_Z20sgbm_cost_reg_kernelILi80ELi5ELi32ELi6E"],
+    "kernels_orb.hip": ["_Z16blur_mfma_kernel", "_Z11fast_kernel", "_Z13orient_kernel", "_Z12brief_kernel", "_Z14resize4_kernel"],
+    "kernels_map.hip": ["_Z18map_stream2_kernelILb1ELb0E"],
+}
+
+
+def _resource_usage(src):
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "semantic_slam_mapping_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                        "-c", os.path.join(csrc, src), "-o", os.devnull], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, name = {}, None
+    for ln in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"remark:\s+(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|VGPRs): (\d+)", ln)
+        if m and name:
+            out[name][m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_hot_kernels_do_not_spill_registers():
+    """hipcc cross-compiles without a GPU; ~2 minutes for the three files (in parallel)"""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as ex:
+        usage = dict(zip(_NO_SPILL, ex.map(_resource_usage, _NO_SPILL)))
+    for src, prefixes in _NO_SPILL.items():
+        for p in prefixes:
+            hit = [k for k in usage[src] if k.startswith(p)]
+            assert hit, (src, p, sorted(usage[src])[:5])
+            for k in hit:
+                assert usage[src][k].get("VGPRs Spill", 0) == 0 and usage[src][k].get("ScratchSize [bytes/lane]", 0) == 0, (k, usage[src][k])
