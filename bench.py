@@ -70,13 +70,16 @@ def traffic_profile(suffix, source):
     path = latest_profile(suffix)
     if not path:
         return None, "no profiles/rNN_%s" % suffix
+    csrc = os.path.join(ROOT, "semantic_slam_mapping_amd", "csrc")
+    # a kernel file and the parts it includes (kernels_sgbm.hip: sgbm_*.inc)
+    files = [source] + sorted(f for f in os.listdir(csrc) if f.endswith(".inc") and f.startswith(source.replace("kernels_", "").replace(".hip", "") + "_"))
     try:
-        rec = json.load(open(path)).get("sources_sha256", {}).get(source)
-        cur = hashlib.sha256(open(os.path.join(ROOT, "semantic_slam_mapping_amd", "csrc", source), "rb").read()).hexdigest()
+        rec = json.load(open(path)).get("sources_sha256", {})
+        for f in files:
+            if rec.get(f) != hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest():
+                return None, "%s is stale: collected for another %s (re-collect with scripts/collect_profiles.sh + scripts/make_profiles.sh)" % (os.path.relpath(path, ROOT), f)
     except Exception as e:
         return None, "%s: %r" % (os.path.relpath(path, ROOT), e)
-    if rec != cur:
-        return None, "%s is stale: collected for another %s (re-collect with scripts/collect_profiles.sh + scripts/make_profiles.sh)" % (os.path.relpath(path, ROOT), source)
     return path, None
 
 

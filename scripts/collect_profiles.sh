@@ -7,7 +7,7 @@ O=gpurun_out
 sha_of_sources() { python3 - "$1" <<'PY'
 import hashlib, json, os, sys
 c = "semantic_slam_mapping_amd/csrc"
-json.dump({f: hashlib.sha256(open(os.path.join(c, f), "rb").read()).hexdigest() for f in sorted(os.listdir(c)) if f.endswith(".hip")}, open(os.path.join(sys.argv[1], "sources_sha256.json"), "w"), indent=1)
+json.dump({f: hashlib.sha256(open(os.path.join(c, f), "rb").read()).hexdigest() for f in sorted(os.listdir(c)) if f.endswith((".hip", ".inc"))}, open(os.path.join(sys.argv[1], "sources_sha256.json"), "w"), indent=1)
 PY
 }
 if [ "$1" = "stats" ]; then

@@ -54,7 +54,7 @@ def main():
     if os.path.exists(at_collection):
         sha = json.load(open(at_collection))
     else:
-        sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
+        sha = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".inc"))}
     json.dump({"sources_sha256": sha, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 reports half of the bytes read "
                        "(MI355X_MICROARCH.md s.HBM; calibrated for this repo's access patterns by scripts/ubench/fetch_calib.hip): total = fetch x 2 + write",
                "frames_in_profiled_run": frames_total,
